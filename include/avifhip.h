@@ -1,0 +1,144 @@
+/*
+ * avifhip.h -- C ABI of libavifhip.so: libavif's pixel-reformat path
+ * (avifImageYUVToRGB / avifImageRGBToYUV / alpha premultiply) executed by
+ * hand-written HIP kernels on AMD MI355X (gfx950).
+ *
+ * The boundary is libavif's own: the same avifImage / avifRGBImage structs, the
+ * same avifResult codes, the same argument meaning and error behaviour as the
+ * reference functions each entry point replaces (cited per function,
+ * file:line relative to the libavif source tree).  Plain C pointers and
+ * sizes only.  Buffers reachable from the structs may live in host memory
+ * (they are staged through HBM) or already in device memory (they are used in
+ * place); the library classifies each pointer itself.
+ *
+ * Arithmetic contract (see DESIGN.md "Parity"):
+ *   rgb->avoidLibYUV != 0  -> libavif's built-in fp32 path, byte-exact
+ *                             (src/reformat.c, src/alpha.c);
+ *   rgb->avoidLibYUV == 0  -> what a libyuv-enabled libavif computes: libyuv's
+ *                             fixed-point arithmetic for the combinations
+ *                             libavif dispatches to libyuv
+ *                             (src/reformat_libyuv.c), the fp32 path otherwise.
+ *                             avifhipSetArithmetic() can pin either family.
+ */
+#ifndef AVIFHIP_H
+#define AVIFHIP_H
+
+#include "avifhip/avif_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVIFHIP_API __attribute__((visibility("default")))
+
+/* ---- the four public conversion entry points (libavif seam A) ------------------------------- */
+
+/* Replaces avifImageYUVToRGB, include/avif/avif.h:1032, src/reformat.c:1649-1748.
+ * One fused kernel does colour conversion, chroma upsampling, alpha copy/fill/rescale,
+ * (un)premultiply and the half-float pass that the reference runs as up to four passes. */
+AVIFHIP_API avifResult avifhipImageYUVToRGB(const avifImage * image, avifRGBImage * rgb);
+
+/* Replaces avifImageRGBToYUV, include/avif/avif.h:1031, src/reformat.c:221-571.
+ * Planes that are NULL are allocated with malloc exactly like avifImageAllocatePlanes
+ * (src/avif.c:431-490) and marked image-owned. */
+AVIFHIP_API avifResult avifhipImageRGBToYUV(avifImage * image, const avifRGBImage * rgb);
+
+/* Replace avifRGBImagePremultiplyAlpha / avifRGBImageUnpremultiplyAlpha,
+ * include/avif/avif.h:1037-1038, src/alpha.c:151-336 / :338-535 (in place). */
+AVIFHIP_API avifResult avifhipRGBImagePremultiplyAlpha(avifRGBImage * rgb);
+AVIFHIP_API avifResult avifhipRGBImageUnpremultiplyAlpha(avifRGBImage * rgb);
+
+/* ---- device-resident / asynchronous variants ------------------------------------------------- */
+
+/* Same conversions with every buffer already in device memory, enqueued on `hipStream`
+ * (a hipStream_t passed as void*; NULL = the calling thread's library stream) WITHOUT
+ * synchronising.  No pointer classification, no staging, no allocation.
+ * avifhipImageRGBToYUVAsync requires all destination planes to be present. */
+AVIFHIP_API avifResult avifhipImageYUVToRGBAsync(const avifImage * image, avifRGBImage * rgb, void * hipStream);
+AVIFHIP_API avifResult avifhipImageRGBToYUVAsync(avifImage * image, const avifRGBImage * rgb, void * hipStream);
+AVIFHIP_API avifResult avifhipRGBImagePremultiplyAlphaAsync(avifRGBImage * rgb, void * hipStream);
+AVIFHIP_API avifResult avifhipRGBImageUnpremultiplyAlphaAsync(avifRGBImage * rgb, void * hipStream);
+
+/* Grid tiles / sequence frames.  Converts the sub-rectangle `rect` of a stitched
+ * canvas; chroma edge rules (src/reformat.c:768,784) are evaluated against the canvas, so the
+ * output equals the same rectangle of a whole-canvas avifImageYUVToRGB.  Plane pointers of
+ * `canvas` address canvas sample (0,0); only samples inside the rectangle plus a one-chroma-sample
+ * halo are read.  rect->x / rect->y must be even for subsampled formats (src/avif.c:335-337). */
+AVIFHIP_API avifResult avifhipImageYUVToRGBRectAsync(const avifImage * canvas,
+                                                     avifRGBImage * rgbCanvas,
+                                                     const avifCropRect * rect,
+                                                     void * hipStream);
+
+/* One launch for `count` independent device-resident conversions (tile farm: count tiles of a
+ * grid, or count frames of a sequence).  All images must share one kernel configuration
+ * (format, depth, range, matrix, RGB format...); rects may be NULL (whole images). */
+AVIFHIP_API avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
+                                                      const avifImage * const * images,
+                                                      avifRGBImage * const * rgbs,
+                                                      const avifCropRect * rects,
+                                                      void * hipStream);
+
+/* ---- integer helpers (src/reformat.c:1778-1840; used on decoded alpha planes, src/read.c:6724) */
+AVIFHIP_API int avifhipLimitedToFullY(uint32_t depth, int v);
+AVIFHIP_API int avifhipLimitedToFullUV(uint32_t depth, int v);
+AVIFHIP_API int avifhipFullToLimitedY(uint32_t depth, int v);
+AVIFHIP_API int avifhipFullToLimitedUV(uint32_t depth, int v);
+
+/* ---- library control ---------------------------------------------------------------------- */
+
+typedef enum avifhipArithmetic
+{
+    AVIFHIP_ARITHMETIC_AUTO = 0,   /* follow rgb->avoidLibYUV (default) */
+    AVIFHIP_ARITHMETIC_FLOAT = 1,  /* always libavif's built-in fp32 arithmetic */
+    AVIFHIP_ARITHMETIC_LIBYUV = 2  /* libyuv fixed-point wherever libavif would use libyuv, even if avoidLibYUV */
+} avifhipArithmetic;
+
+AVIFHIP_API void avifhipSetArithmetic(avifhipArithmetic mode);
+AVIFHIP_API avifhipArithmetic avifhipGetArithmetic(void);
+
+/* Diagnostics/tests: 0 routes every conversion through the universal one-lane-per-pixel kernels,
+ * 1 (default) lets the bandwidth-tuned tiled kernels take the configurations they cover. */
+AVIFHIP_API void avifhipSetTiledKernels(int enabled);
+
+/* Selects the HIP device used by the calling thread's context (default: current device). */
+AVIFHIP_API avifResult avifhipSetDevice(int device);
+/* Number of visible HIP devices; 0 when no GPU / no driver. */
+AVIFHIP_API int avifhipDeviceCount(void);
+/* Blocks until the calling thread's library stream (or `hipStream`) is idle. */
+AVIFHIP_API avifResult avifhipSynchronize(void * hipStream);
+/* Text of the last HIP/runtime failure on this thread ("" if none). */
+AVIFHIP_API const char * avifhipLastError(void);
+/* Which kernel family served the last conversion on this thread (diagnostics/tests):
+ * e.g. "yuv2rgb_tile<u8,420,bilinear,rgba8>" or "yuv2rgb_generic". */
+AVIFHIP_API const char * avifhipLastKernel(void);
+AVIFHIP_API const char * avifhipVersion(void);
+
+/* Plain device-memory helpers so C callers (and the ctypes tests) need no HIP headers. */
+AVIFHIP_API void * avifhipDeviceAlloc(size_t bytes);
+AVIFHIP_API void avifhipDeviceFree(void * devicePtr);
+AVIFHIP_API avifResult avifhipCopyToDevice(void * devicePtr, const void * hostPtr, size_t bytes);
+AVIFHIP_API avifResult avifhipCopyToHost(void * hostPtr, const void * devicePtr, size_t bytes);
+AVIFHIP_API avifResult avifhipDeviceMemset(void * devicePtr, int value, size_t bytes);
+
+/* Kernel timing with HIP events on the stream the kernels are launched on (bench.py):
+ * returns the average milliseconds per call of `iters` back-to-back
+ * avifhipImageYUVToRGBAsync launches after `warmup` untimed ones, or a negative value on error. */
+AVIFHIP_API double avifhipTimeYUVToRGB(const avifImage * image, avifRGBImage * rgb, int warmup, int iters, void * hipStream);
+AVIFHIP_API double avifhipTimeRGBToYUV(avifImage * image, const avifRGBImage * rgb, int warmup, int iters, void * hipStream);
+
+/* Synthetic planes for benchmarks/tests: xorshift32 stream
+ * (x^=x<<13; x^=x>>17; x^=x<<5), one draw per sample, value = lo + draw % (hi-lo+1), written
+ * as uint8 (bytesPerSample 1) or little-endian uint16 (2) rows. Returns the advanced state. */
+AVIFHIP_API uint32_t avifhipSynthFill(uint32_t state,
+                                      uint8_t * plane,
+                                      uint32_t rowBytes,
+                                      uint32_t width,
+                                      uint32_t height,
+                                      uint32_t bytesPerSample,
+                                      uint32_t lo,
+                                      uint32_t hi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVIFHIP_H */

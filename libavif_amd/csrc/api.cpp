@@ -1,0 +1,836 @@
+// api.cpp -- the C ABI of libavifhip.so (include/avifhip.h): argument checks and error codes of
+// libavif's entry points, pointer classification (host vs HBM), staging through device scratch for
+// host-resident images, kernel selection, and the per-thread stream/scratch context.
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <vector>
+
+#include "avifhip.h"
+#include "kernels.h"
+#include "plan.h"
+
+using namespace avifhip;
+
+namespace {
+
+std::atomic<int> gArithmetic { AVIFHIP_ARITHMETIC_AUTO };
+std::atomic<int> gTiledKernels { 1 };
+
+struct Scratch
+{
+    void * ptr = nullptr;
+    size_t capacity = 0;
+};
+
+// One context per calling thread: libavif's reformat functions are re-entrant and may be called
+// concurrently from up to 8 threads (src/reformat.c:1709-1735); nothing here is shared.
+struct Context
+{
+    int device = -1;
+    hipStream_t stream = nullptr;
+    Scratch planes[4]; // Y, U, V, A staging
+    Scratch pixels;    // interleaved RGB staging
+    Scratch table;     // batch descriptor table (device)
+    void * pinnedTable = nullptr;
+    size_t pinnedTableCapacity = 0;
+    hipEvent_t tableCopied = nullptr;
+    char lastError[512] = { 0 };
+    const char * lastKernel = "";
+
+    ~Context()
+    {
+        // Best effort: the runtime may already be shutting down at thread/process exit.
+        for (Scratch & s : planes)
+            if (s.ptr)
+                (void)hipFree(s.ptr);
+        if (pixels.ptr)
+            (void)hipFree(pixels.ptr);
+        if (table.ptr)
+            (void)hipFree(table.ptr);
+        if (pinnedTable)
+            (void)hipHostFree(pinnedTable);
+        if (tableCopied)
+            (void)hipEventDestroy(tableCopied);
+        if (stream)
+            (void)hipStreamDestroy(stream);
+    }
+};
+
+thread_local Context tls;
+
+void setError(const char * fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tls.lastError, sizeof(tls.lastError), fmt, ap);
+    va_end(ap);
+}
+
+// HIP failure -> avifResult.  The message is kept for avifhipLastError(); the sticky HIP error is cleared.
+avifResult hipFailed(hipError_t e, const char * what)
+{
+    setError("%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return (e == hipErrorOutOfMemory) ? AVIF_RESULT_OUT_OF_MEMORY : AVIF_RESULT_UNKNOWN_ERROR;
+}
+
+#define HIP_TRY(expr)                          \
+    do {                                       \
+        const hipError_t hipTryErr_ = (expr);  \
+        if (hipTryErr_ != hipSuccess)          \
+            return hipFailed(hipTryErr_, #expr); \
+    } while (0)
+
+avifResult ensureContext()
+{
+    if (tls.stream)
+        return AVIF_RESULT_OK;
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        setError("no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return AVIF_RESULT_UNKNOWN_ERROR;
+    }
+    if (tls.device >= 0)
+        HIP_TRY(hipSetDevice(tls.device));
+    else
+        HIP_TRY(hipGetDevice(&tls.device));
+    HIP_TRY(hipStreamCreateWithFlags(&tls.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&tls.tableCopied, hipEventDisableTiming));
+    return AVIF_RESULT_OK;
+}
+
+avifResult reserve(Scratch & s, size_t bytes)
+{
+    if (bytes <= s.capacity)
+        return AVIF_RESULT_OK;
+    if (s.ptr) {
+        HIP_TRY(hipStreamSynchronize(tls.stream));
+        HIP_TRY(hipFree(s.ptr));
+        s.ptr = nullptr;
+        s.capacity = 0;
+    }
+    const size_t rounded = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    HIP_TRY(hipMalloc(&s.ptr, rounded));
+    s.capacity = rounded;
+    return AVIF_RESULT_OK;
+}
+
+bool isDevicePointer(const void * p)
+{
+    if (!p)
+        return false;
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc memory on older runtimes
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+inline uint32_t alignUp(uint32_t v, uint32_t a)
+{
+    return (v + a - 1) / a * a;
+}
+
+int effectiveArithmetic()
+{
+    return gArithmetic.load(std::memory_order_relaxed);
+}
+
+// ---- kernel selection -----------------------------------------------------------------------
+
+avifResult enqueueYuvToRgb(const YuvToRgbPlan & plan, hipStream_t stream)
+{
+    hipError_t e;
+    if (gTiledKernels.load(std::memory_order_relaxed) && tileYuvToRgbSupported(plan)) {
+        e = launchYuvToRgbTile(plan, stream, &tls.lastKernel);
+    } else {
+        tls.lastKernel = "yuv2rgb_generic";
+        e = launchYuvToRgbGeneric(plan, stream);
+    }
+    if (e != hipSuccess)
+        return hipFailed(e, "YUV->RGB kernel launch");
+    return AVIF_RESULT_OK;
+}
+
+avifResult enqueueRgbToYuv(const RgbToYuvPlan & plan, hipStream_t stream)
+{
+    hipError_t e;
+    if (gTiledKernels.load(std::memory_order_relaxed) && tileRgbToYuvSupported(plan)) {
+        e = launchRgbToYuvTile(plan, stream, &tls.lastKernel);
+    } else {
+        tls.lastKernel = "rgb2yuv_generic";
+        e = launchRgbToYuvGeneric(plan, stream);
+    }
+    if (e != hipSuccess)
+        return hipFailed(e, "RGB->YUV kernel launch");
+    return AVIF_RESULT_OK;
+}
+
+avifResult enqueueAlphaMul(const AlphaMulPlan & plan, hipStream_t stream)
+{
+    tls.lastKernel = plan.unmultiply ? "unpremultiply_generic" : "premultiply_generic";
+    const hipError_t e = launchAlphaMulGeneric(plan, stream);
+    if (e != hipSuccess)
+        return hipFailed(e, "alpha multiply kernel launch");
+    return AVIF_RESULT_OK;
+}
+
+// ---- staging of host-resident buffers -----------------------------------------------------------
+
+struct PlaneGeometry
+{
+    uint32_t widthBytes[4];
+    uint32_t rows[4];
+};
+
+PlaneGeometry planeGeometry(const avifImage * image)
+{
+    PlaneGeometry g;
+    const uint32_t bps = (image->depth > 8) ? 2 : 1;
+    const int sx = (image->yuvFormat == AVIF_PIXEL_FORMAT_YUV444) ? 0 : 1;
+    const int sy = (image->yuvFormat == AVIF_PIXEL_FORMAT_YUV420 || image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400) ? 1 : 0;
+    const uint32_t cw = (uint32_t)(((uint64_t)image->width + sx) >> sx);
+    const uint32_t ch = (uint32_t)(((uint64_t)image->height + sy) >> sy);
+    g.widthBytes[0] = g.widthBytes[3] = image->width * bps;
+    g.rows[0] = g.rows[3] = image->height;
+    g.widthBytes[1] = g.widthBytes[2] = cw * bps;
+    g.rows[1] = g.rows[2] = ch;
+    return g;
+}
+
+// Replaces host plane pointers of `view` (a shallow copy of the caller's image) with device copies.
+// upload=false only reserves the device planes (RGB->YUV destinations).
+avifResult stagePlanes(avifImage * view, bool upload, bool mirrorRowBytes)
+{
+    const PlaneGeometry g = planeGeometry(view);
+    for (int p = 0; p < 4; ++p) {
+        uint8_t * host = (p < 3) ? view->yuvPlanes[p] : view->alphaPlane;
+        const uint32_t hostRowBytes = (p < 3) ? view->yuvRowBytes[p] : view->alphaRowBytes;
+        if (!host || !hostRowBytes || isDevicePointer(host))
+            continue;
+        const uint32_t pitch = mirrorRowBytes ? hostRowBytes : alignUp(g.widthBytes[p], 256);
+        const avifResult r = reserve(tls.planes[p], (size_t)pitch * g.rows[p]);
+        if (r != AVIF_RESULT_OK)
+            return r;
+        if (upload)
+            HIP_TRY(hipMemcpy2DAsync(tls.planes[p].ptr, pitch, host, hostRowBytes, g.widthBytes[p], g.rows[p], hipMemcpyHostToDevice, tls.stream));
+        if (p < 3) {
+            view->yuvPlanes[p] = (uint8_t *)tls.planes[p].ptr;
+            view->yuvRowBytes[p] = pitch;
+        } else {
+            view->alphaPlane = (uint8_t *)tls.planes[p].ptr;
+            view->alphaRowBytes = pitch;
+        }
+    }
+    return AVIF_RESULT_OK;
+}
+
+uint32_t rgbPixelBytes(const avifRGBImage * rgb)
+{
+    if (rgb->format == AVIF_RGB_FORMAT_RGB_565)
+        return 2;
+    return (uint32_t)rgbFormatChannelCount((int)rgb->format) * ((rgb->depth > 8) ? 2 : 1);
+}
+
+avifResult stagePixels(avifRGBImage * view, bool upload)
+{
+    const uint32_t widthBytes = view->width * rgbPixelBytes(view);
+    const uint32_t pitch = alignUp(widthBytes, 256);
+    const avifResult r = reserve(tls.pixels, (size_t)pitch * view->height);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    if (upload)
+        HIP_TRY(hipMemcpy2DAsync(tls.pixels.ptr, pitch, view->pixels, view->rowBytes, widthBytes, view->height, hipMemcpyHostToDevice, tls.stream));
+    view->pixels = (uint8_t *)tls.pixels.ptr;
+    view->rowBytes = pitch;
+    return AVIF_RESULT_OK;
+}
+
+hipStream_t pickStream(void * hipStream)
+{
+    return hipStream ? (hipStream_t)hipStream : tls.stream;
+}
+
+// malloc-backed avifImageAllocatePlanes, reference src/avif.c:431-490
+avifResult allocateHostPlanes(avifImage * image, bool withAlpha)
+{
+    if (image->width == 0 || image->height == 0 || image->depth == 0 || image->depth > 16)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const size_t bps = (image->depth > 8) ? 2 : 1;
+    const size_t fullRow = bps * image->width;
+    if (image->yuvFormat != AVIF_PIXEL_FORMAT_NONE) {
+        image->imageOwnsYUVPlanes = AVIF_TRUE;
+        if (!image->yuvPlanes[0]) {
+            image->yuvPlanes[0] = (uint8_t *)malloc(fullRow * image->height);
+            if (!image->yuvPlanes[0])
+                return AVIF_RESULT_OUT_OF_MEMORY;
+            image->yuvRowBytes[0] = (uint32_t)fullRow;
+        }
+        if (image->yuvFormat != AVIF_PIXEL_FORMAT_YUV400) {
+            const PlaneGeometry g = planeGeometry(image);
+            for (int p = 1; p <= 2; ++p) {
+                if (!image->yuvPlanes[p]) {
+                    image->yuvPlanes[p] = (uint8_t *)malloc((size_t)g.widthBytes[p] * g.rows[p]);
+                    if (!image->yuvPlanes[p])
+                        return AVIF_RESULT_OUT_OF_MEMORY;
+                    image->yuvRowBytes[p] = g.widthBytes[p];
+                }
+            }
+        }
+    }
+    if (withAlpha) {
+        image->imageOwnsAlphaPlane = AVIF_TRUE;
+        if (!image->alphaPlane) {
+            image->alphaPlane = (uint8_t *)malloc(fullRow * image->height);
+            if (!image->alphaPlane)
+                return AVIF_RESULT_OUT_OF_MEMORY;
+            image->alphaRowBytes = (uint32_t)fullRow;
+        }
+    }
+    return AVIF_RESULT_OK;
+}
+
+// Completes a RgbToYuvPlan once the destination planes exist: alpha plane source, src/reformat.c:545-569
+void finishRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, RgbToYuvPlan * plan)
+{
+    for (int p = 0; p < 3; ++p) {
+        plan->yuv.plane[p] = image->yuvPlanes[p];
+        plan->yuv.rowBytes[p] = image->yuvRowBytes[p];
+    }
+    plan->yuv.alpha = image->alphaPlane;
+    plan->yuv.alphaRowBytes = image->alphaRowBytes;
+    plan->rgb.pixels = rgb->pixels;
+    plan->rgb.rowBytes = rgb->rowBytes;
+    plan->alphaSource = ALPHA_KEEP;
+    if (image->alphaPlane && image->alphaRowBytes)
+        plan->alphaSource = (plan->rgb.hasAlpha && !rgb->ignoreAlpha) ? ALPHA_PLANE : ALPHA_FILL;
+}
+
+bool sharpYuvRequested(const avifImage * image, const avifRGBImage * rgb)
+{
+    return !rgbFormatIsGray((int)rgb->format) && rgb->chromaDownsampling == AVIF_CHROMA_DOWNSAMPLING_SHARP_YUV &&
+           image->yuvFormat == AVIF_PIXEL_FORMAT_YUV420;
+}
+
+} // namespace
+
+// =================================================================================================
+// YUV -> RGB
+// =================================================================================================
+
+extern "C" avifResult avifhipImageYUVToRGBRectAsync(const avifImage * canvas, avifRGBImage * rgbCanvas, const avifCropRect * rect, void * hipStream)
+{
+    if (!canvas || !rgbCanvas)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    YuvToRgbPlan plan;
+    const avifResult pr = makeYuvToRgbPlan(canvas, rgbCanvas, rect, effectiveArithmetic(), &plan);
+    if (pr != AVIF_RESULT_OK)
+        return pr;
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    return enqueueYuvToRgb(plan, pickStream(hipStream));
+}
+
+extern "C" avifResult avifhipImageYUVToRGBAsync(const avifImage * image, avifRGBImage * rgb, void * hipStream)
+{
+    return avifhipImageYUVToRGBRectAsync(image, rgb, nullptr, hipStream);
+}
+
+extern "C" avifResult avifhipImageYUVToRGB(const avifImage * image, avifRGBImage * rgb)
+{
+    if (!image || !rgb)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    // Validate exactly like the reference before touching the device (error-code matrix,
+    // tests/gtest/avif_fuzztest_yuvrgb.cc:36-46).
+    YuvToRgbPlan probe;
+    const avifResult pr = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), &probe);
+    if (pr != AVIF_RESULT_OK)
+        return pr;
+    if (!rgb->pixels) {
+        setError("avifhipImageYUVToRGB: rgb->pixels is NULL");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+
+    avifImage imageView;
+    memcpy(&imageView, image, sizeof(avifImage));
+    avifRGBImage rgbView = *rgb;
+    avifResult r = stagePlanes(&imageView, /*upload=*/true, /*mirrorRowBytes=*/false);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    const bool pixelsOnHost = !isDevicePointer(rgb->pixels);
+    if (pixelsOnHost) {
+        // destination bytes the kernel does not define (alpha kept as is) must survive the round trip
+        const bool keepsBytes = probe.rgb.hasAlpha && probe.alphaSource == ALPHA_KEEP;
+        r = stagePixels(&rgbView, /*upload=*/keepsBytes);
+        if (r != AVIF_RESULT_OK)
+            return r;
+    }
+    YuvToRgbPlan plan;
+    r = makeYuvToRgbPlan(&imageView, &rgbView, nullptr, effectiveArithmetic(), &plan);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    r = enqueueYuvToRgb(plan, tls.stream);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    if (pixelsOnHost) {
+        const uint32_t widthBytes = rgb->width * rgbPixelBytes(rgb);
+        HIP_TRY(hipMemcpy2DAsync(rgb->pixels, rgb->rowBytes, rgbView.pixels, rgbView.rowBytes, widthBytes, rgb->height, hipMemcpyDeviceToHost, tls.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(tls.stream));
+    return AVIF_RESULT_OK;
+}
+
+extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
+                                                     const avifImage * const * images,
+                                                     avifRGBImage * const * rgbs,
+                                                     const avifCropRect * rects,
+                                                     void * hipStream)
+{
+    if (count == 0)
+        return AVIF_RESULT_OK;
+    if (!images || !rgbs)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    const size_t bytes = (size_t)count * sizeof(YuvToRgbPlan);
+    if (bytes > tls.pinnedTableCapacity) {
+        if (tls.pinnedTable) {
+            HIP_TRY(hipEventSynchronize(tls.tableCopied));
+            HIP_TRY(hipHostFree(tls.pinnedTable));
+            tls.pinnedTable = nullptr;
+            tls.pinnedTableCapacity = 0;
+        }
+        HIP_TRY(hipHostMalloc(&tls.pinnedTable, bytes, hipHostMallocDefault));
+        tls.pinnedTableCapacity = bytes;
+    } else {
+        HIP_TRY(hipEventSynchronize(tls.tableCopied)); // previous upload must have consumed the table
+    }
+    YuvToRgbPlan * table = (YuvToRgbPlan *)tls.pinnedTable;
+    uint32_t maxW = 0, maxH = 0;
+    bool allTiled = gTiledKernels.load(std::memory_order_relaxed) != 0;
+    int variant = -2;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (!images[k] || !rgbs[k])
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        const avifResult pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, effectiveArithmetic(), &table[k]);
+        if (pr != AVIF_RESULT_OK)
+            return pr;
+        maxW = table[k].w > maxW ? table[k].w : maxW;
+        maxH = table[k].h > maxH ? table[k].h : maxH;
+        // one launch serves the whole batch only if every job maps to the same tiled kernel
+        const int v = tileYuvToRgbVariant(table[k]);
+        if (variant == -2)
+            variant = v;
+        if (v < 0 || v != variant)
+            allTiled = false;
+    }
+    const avifResult rr = reserve(tls.table, bytes);
+    if (rr != AVIF_RESULT_OK)
+        return rr;
+    hipStream_t stream = pickStream(hipStream);
+    HIP_TRY(hipMemcpyAsync(tls.table.ptr, table, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(tls.tableCopied, stream));
+    hipError_t e;
+    if (allTiled) {
+        e = launchYuvToRgbTileBatch((const YuvToRgbPlan *)tls.table.ptr, table[0], count, maxW, maxH, stream, &tls.lastKernel);
+    } else {
+        tls.lastKernel = "yuv2rgb_generic_batch";
+        e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)tls.table.ptr, count, maxW, maxH, stream);
+    }
+    if (e != hipSuccess)
+        return hipFailed(e, "YUV->RGB batch kernel launch");
+    return AVIF_RESULT_OK;
+}
+
+// =================================================================================================
+// RGB -> YUV
+// =================================================================================================
+
+extern "C" avifResult avifhipImageRGBToYUVAsync(avifImage * image, const avifRGBImage * rgb, void * hipStream)
+{
+    if (!image || !rgb)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    RgbToYuvPlan plan;
+    const avifResult pr = makeRgbToYuvPlan(image, rgb, effectiveArithmetic(), &plan);
+    if (pr != AVIF_RESULT_OK)
+        return pr;
+    if (sharpYuvRequested(image, rgb))
+        return AVIF_RESULT_NOT_IMPLEMENTED; // libsharpyuv is out of scope, like src/reformat_libsharpyuv.c:77-84
+    const bool needAlpha = plan.rgb.hasAlpha && !rgb->ignoreAlpha;
+    if (!image->yuvPlanes[0] || (image->yuvFormat != AVIF_PIXEL_FORMAT_YUV400 && (!image->yuvPlanes[1] || !image->yuvPlanes[2])) ||
+        (needAlpha && !image->alphaPlane)) {
+        setError("avifhipImageRGBToYUVAsync: destination planes must be allocated by the caller");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    finishRgbToYuvPlan(image, rgb, &plan);
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    return enqueueRgbToYuv(plan, pickStream(hipStream));
+}
+
+extern "C" avifResult avifhipImageRGBToYUV(avifImage * image, const avifRGBImage * rgb)
+{
+    if (!image || !rgb)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    RgbToYuvPlan plan;
+    avifResult r = makeRgbToYuvPlan(image, rgb, effectiveArithmetic(), &plan);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    const bool hasAlpha = plan.rgb.hasAlpha && !rgb->ignoreAlpha;
+    const bool pixelsOnHost = !isDevicePointer(rgb->pixels);
+    if (pixelsOnHost || !image->yuvPlanes[0]) {
+        r = allocateHostPlanes(image, hasAlpha); // src/reformat.c:236-240
+        if (r != AVIF_RESULT_OK)
+            return r;
+    }
+    if (sharpYuvRequested(image, rgb))
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    r = ensureContext();
+    if (r != AVIF_RESULT_OK)
+        return r;
+
+    avifImage imageView;
+    memcpy(&imageView, image, sizeof(avifImage));
+    avifRGBImage rgbView = *rgb;
+    const bool gray = rgbFormatIsGray((int)rgb->format);
+    // the gray path sets whole chroma rows (padding included) to the half value: keep the caller's pitch there
+    r = stagePlanes(&imageView, /*upload=*/false, /*mirrorRowBytes=*/gray);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    if (pixelsOnHost) {
+        r = stagePixels(&rgbView, /*upload=*/true);
+        if (r != AVIF_RESULT_OK)
+            return r;
+    }
+    r = makeRgbToYuvPlan(&imageView, &rgbView, effectiveArithmetic(), &plan);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    finishRgbToYuvPlan(&imageView, &rgbView, &plan);
+    r = enqueueRgbToYuv(plan, tls.stream);
+    if (r != AVIF_RESULT_OK)
+        return r;
+
+    const PlaneGeometry g = planeGeometry(image);
+    for (int p = 0; p < 4; ++p) {
+        uint8_t * host = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
+        const uint32_t hostRowBytes = (p < 3) ? image->yuvRowBytes[p] : image->alphaRowBytes;
+        const uint8_t * dev = (p < 3) ? imageView.yuvPlanes[p] : imageView.alphaPlane;
+        const uint32_t devRowBytes = (p < 3) ? imageView.yuvRowBytes[p] : imageView.alphaRowBytes;
+        if (!host || !hostRowBytes || host == dev)
+            continue; // absent, or already device-resident
+        if (gray && (p == 1 || p == 2)) {
+            HIP_TRY(hipMemcpyAsync(host, dev, (size_t)hostRowBytes * g.rows[p], hipMemcpyDeviceToHost, tls.stream));
+        } else if (p == 1 || p == 2) {
+            if (image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400)
+                continue; // colour source into 4:0:0: chroma untouched
+            HIP_TRY(hipMemcpy2DAsync(host, hostRowBytes, dev, devRowBytes, g.widthBytes[p], g.rows[p], hipMemcpyDeviceToHost, tls.stream));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(host, hostRowBytes, dev, devRowBytes, g.widthBytes[p], g.rows[p], hipMemcpyDeviceToHost, tls.stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(tls.stream));
+    return AVIF_RESULT_OK;
+}
+
+// =================================================================================================
+// premultiply / unpremultiply
+// =================================================================================================
+
+static avifResult alphaMulAsync(avifRGBImage * rgb, bool unmultiply, void * hipStream)
+{
+    if (!rgb)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    AlphaMulPlan plan;
+    const avifResult pr = makeAlphaMulPlan(rgb, unmultiply, effectiveArithmetic(), &plan);
+    if (pr != AVIF_RESULT_OK)
+        return pr;
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    return enqueueAlphaMul(plan, pickStream(hipStream));
+}
+
+static avifResult alphaMulSync(avifRGBImage * rgb, bool unmultiply)
+{
+    if (!rgb)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    AlphaMulPlan plan;
+    avifResult r = makeAlphaMulPlan(rgb, unmultiply, effectiveArithmetic(), &plan);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    r = ensureContext();
+    if (r != AVIF_RESULT_OK)
+        return r;
+    avifRGBImage view = *rgb;
+    const bool onHost = !isDevicePointer(rgb->pixels);
+    if (onHost) {
+        r = stagePixels(&view, /*upload=*/true);
+        if (r != AVIF_RESULT_OK)
+            return r;
+        r = makeAlphaMulPlan(&view, unmultiply, effectiveArithmetic(), &plan);
+        if (r != AVIF_RESULT_OK)
+            return r;
+    }
+    r = enqueueAlphaMul(plan, tls.stream);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    if (onHost) {
+        const uint32_t widthBytes = rgb->width * rgbPixelBytes(rgb);
+        HIP_TRY(hipMemcpy2DAsync(rgb->pixels, rgb->rowBytes, view.pixels, view.rowBytes, widthBytes, rgb->height, hipMemcpyDeviceToHost, tls.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(tls.stream));
+    return AVIF_RESULT_OK;
+}
+
+extern "C" avifResult avifhipRGBImagePremultiplyAlpha(avifRGBImage * rgb)
+{
+    return alphaMulSync(rgb, false);
+}
+extern "C" avifResult avifhipRGBImageUnpremultiplyAlpha(avifRGBImage * rgb)
+{
+    return alphaMulSync(rgb, true);
+}
+extern "C" avifResult avifhipRGBImagePremultiplyAlphaAsync(avifRGBImage * rgb, void * hipStream)
+{
+    return alphaMulAsync(rgb, false, hipStream);
+}
+extern "C" avifResult avifhipRGBImageUnpremultiplyAlphaAsync(avifRGBImage * rgb, void * hipStream)
+{
+    return alphaMulAsync(rgb, true, hipStream);
+}
+
+// =================================================================================================
+// integer range helpers, reference src/reformat.c:1750-1840
+// =================================================================================================
+
+namespace {
+struct RangeRow
+{
+    int lo, hiY, hiUV, full;
+};
+const RangeRow * rangeRow(uint32_t depth)
+{
+    static const RangeRow rows[3] = { { 16, 235, 240, 255 }, { 64, 940, 960, 1023 }, { 256, 3760, 3840, 4095 } };
+    switch (depth) {
+        case 8: return &rows[0];
+        case 10: return &rows[1];
+        case 12: return &rows[2];
+        default: return nullptr;
+    }
+}
+int clampHost(int v, int lo, int hi)
+{
+    return v < lo ? lo : (hi < v ? hi : v);
+}
+int limitedToFull(int v, int lo, int hi, int full)
+{
+    return clampHost((((v - lo) * full) + ((hi - lo) / 2)) / (hi - lo), 0, full);
+}
+int fullToLimited(int v, int lo, int hi, int full)
+{
+    return clampHost((((v * (hi - lo)) + (full / 2)) / full) + lo, lo, hi);
+}
+} // namespace
+
+extern "C" int avifhipLimitedToFullY(uint32_t depth, int v)
+{
+    const RangeRow * r = rangeRow(depth);
+    return r ? limitedToFull(v, r->lo, r->hiY, r->full) : v;
+}
+extern "C" int avifhipLimitedToFullUV(uint32_t depth, int v)
+{
+    const RangeRow * r = rangeRow(depth);
+    return r ? limitedToFull(v, r->lo, r->hiUV, r->full) : v;
+}
+extern "C" int avifhipFullToLimitedY(uint32_t depth, int v)
+{
+    const RangeRow * r = rangeRow(depth);
+    return r ? fullToLimited(v, r->lo, r->hiY, r->full) : v;
+}
+extern "C" int avifhipFullToLimitedUV(uint32_t depth, int v)
+{
+    const RangeRow * r = rangeRow(depth);
+    return r ? fullToLimited(v, r->lo, r->hiUV, r->full) : v;
+}
+
+// =================================================================================================
+// library control, device memory helpers, timing
+// =================================================================================================
+
+extern "C" void avifhipSetArithmetic(avifhipArithmetic mode)
+{
+    gArithmetic.store((int)mode, std::memory_order_relaxed);
+}
+extern "C" avifhipArithmetic avifhipGetArithmetic(void)
+{
+    return (avifhipArithmetic)gArithmetic.load(std::memory_order_relaxed);
+}
+extern "C" void avifhipSetTiledKernels(int enabled)
+{
+    gTiledKernels.store(enabled ? 1 : 0, std::memory_order_relaxed);
+}
+
+extern "C" int avifhipDeviceCount(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+extern "C" avifResult avifhipSetDevice(int device)
+{
+    if (tls.stream && tls.device != device) {
+        setError("avifhipSetDevice: this thread's context is already bound to device %d", tls.device);
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    HIP_TRY(hipSetDevice(device));
+    tls.device = device;
+    return AVIF_RESULT_OK;
+}
+
+extern "C" avifResult avifhipSynchronize(void * hipStream)
+{
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    HIP_TRY(hipStreamSynchronize(pickStream(hipStream)));
+    return AVIF_RESULT_OK;
+}
+
+extern "C" const char * avifhipLastError(void)
+{
+    return tls.lastError;
+}
+extern "C" const char * avifhipLastKernel(void)
+{
+    return tls.lastKernel;
+}
+extern "C" const char * avifhipVersion(void)
+{
+    return "avifhip 0.1.0 (gfx950; mirrors libavif 1.4.2 reformat path)";
+}
+
+extern "C" void * avifhipDeviceAlloc(size_t bytes)
+{
+    if (ensureContext() != AVIF_RESULT_OK)
+        return nullptr;
+    void * p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        hipFailed(e, "hipMalloc");
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void avifhipDeviceFree(void * devicePtr)
+{
+    if (devicePtr)
+        (void)hipFree(devicePtr);
+}
+extern "C" avifResult avifhipCopyToDevice(void * devicePtr, const void * hostPtr, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(devicePtr, hostPtr, bytes, hipMemcpyHostToDevice));
+    return AVIF_RESULT_OK;
+}
+extern "C" avifResult avifhipCopyToHost(void * hostPtr, const void * devicePtr, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(hostPtr, devicePtr, bytes, hipMemcpyDeviceToHost));
+    return AVIF_RESULT_OK;
+}
+extern "C" avifResult avifhipDeviceMemset(void * devicePtr, int value, size_t bytes)
+{
+    HIP_TRY(hipMemset(devicePtr, value, bytes));
+    return AVIF_RESULT_OK;
+}
+
+extern "C" double avifhipTimeYUVToRGB(const avifImage * image, avifRGBImage * rgb, int warmup, int iters, void * hipStream)
+{
+    if (iters <= 0 || ensureContext() != AVIF_RESULT_OK)
+        return -1.0;
+    hipStream_t stream = pickStream(hipStream);
+    for (int k = 0; k < warmup; ++k)
+        if (avifhipImageYUVToRGBAsync(image, rgb, stream) != AVIF_RESULT_OK)
+            return -1.0;
+    hipEvent_t t0, t1;
+    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess)
+        return -1.0;
+    (void)hipEventRecord(t0, stream);
+    for (int k = 0; k < iters; ++k)
+        if (avifhipImageYUVToRGBAsync(image, rgb, stream) != AVIF_RESULT_OK)
+            return -1.0;
+    (void)hipEventRecord(t1, stream);
+    float ms = -1.0f;
+    if (hipEventSynchronize(t1) != hipSuccess || hipEventElapsedTime(&ms, t0, t1) != hipSuccess)
+        ms = -1.0f;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return ms < 0 ? -1.0 : (double)ms / iters;
+}
+
+extern "C" double avifhipTimeRGBToYUV(avifImage * image, const avifRGBImage * rgb, int warmup, int iters, void * hipStream)
+{
+    if (iters <= 0 || ensureContext() != AVIF_RESULT_OK)
+        return -1.0;
+    hipStream_t stream = pickStream(hipStream);
+    for (int k = 0; k < warmup; ++k)
+        if (avifhipImageRGBToYUVAsync(image, rgb, stream) != AVIF_RESULT_OK)
+            return -1.0;
+    hipEvent_t t0, t1;
+    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess)
+        return -1.0;
+    (void)hipEventRecord(t0, stream);
+    for (int k = 0; k < iters; ++k)
+        if (avifhipImageRGBToYUVAsync(image, rgb, stream) != AVIF_RESULT_OK)
+            return -1.0;
+    (void)hipEventRecord(t1, stream);
+    float ms = -1.0f;
+    if (hipEventSynchronize(t1) != hipSuccess || hipEventElapsedTime(&ms, t0, t1) != hipSuccess)
+        ms = -1.0f;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return ms < 0 ? -1.0 : (double)ms / iters;
+}
+
+// Synthetic planes, BASELINE.md section 3 (xorshift32, one draw per sample, row-major)
+extern "C" uint32_t avifhipSynthFill(uint32_t state, uint8_t * plane, uint32_t rowBytes, uint32_t width, uint32_t height,
+                                     uint32_t bytesPerSample, uint32_t lo, uint32_t hi)
+{
+    uint32_t x = state ? state : 0x12345678u;
+    const uint32_t span = hi - lo + 1;
+    for (uint32_t j = 0; j < height; ++j) {
+        uint8_t * row = plane + (size_t)j * rowBytes;
+        for (uint32_t i = 0; i < width; ++i) {
+            x ^= x << 13;
+            x ^= x >> 17;
+            x ^= x << 5;
+            const uint32_t v = lo + (span ? x % span : x);
+            if (bytesPerSample == 1) {
+                row[i] = (uint8_t)v;
+            } else {
+                const uint16_t w = (uint16_t)v;
+                memcpy(row + 2 * (size_t)i, &w, 2);
+            }
+        }
+    }
+    return x;
+}

@@ -1,0 +1,290 @@
+// kernels_generic.hip -- the universal reformat kernels: every (format, depth, range, matrix,
+// upsampling, alpha mode) combination libavif's reformat.c/alpha.c accept, one lane per output
+// pixel (YUV->RGB, alpha passes) or per 2x2 block (RGB->YUV).  These are the correctness
+// backbone; the tiled kernels in kernels_tile.hip take over the bandwidth-critical
+// configurations and must agree with these bit for bit.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "pixel_generic.h"
+#include "pixel_math.h"
+
+namespace avifhip {
+
+__global__ __launch_bounds__(256) void yuvToRgbGenericKernel(YuvToRgbPlan p)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= p.w || j >= p.h)
+        return;
+    yuvToRgbPixel(p, p.x0 + i, p.y0 + j);
+}
+
+__global__ __launch_bounds__(256) void yuvToRgbGenericBatchKernel(const YuvToRgbPlan * __restrict__ table)
+{
+    const YuvToRgbPlan & p = table[blockIdx.z];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= p.w || j >= p.h)
+        return;
+    yuvToRgbPixel(p, p.x0 + i, p.y0 + j);
+}
+
+// --------------------------------------------------------------------------------------------
+// RGB -> YUV, one lane per 2x2 block (edge blocks 1x2 / 2x1 / 1x1), src/reformat.c:295-470, with
+// the alpha plane written in the same pass (src/reformat.c:545-569).
+struct Yuvf
+{
+    float y, u, v;
+};
+
+__device__ __forceinline__ unsigned loadChannel(const uint8_t * px, int off, int chanBytes)
+{
+    return (chanBytes == 1) ? (unsigned)px[off] : (unsigned)*reinterpret_cast<const uint16_t *>(px + off);
+}
+__device__ __forceinline__ void storeSample(uint8_t * plane, uint32_t rowBytes, uint32_t x, uint32_t y, int chanBytes, int v)
+{
+    uint8_t * q = plane + (size_t)y * rowBytes + (size_t)x * chanBytes;
+    if (chanBytes == 1)
+        *q = (uint8_t)v;
+    else
+        *reinterpret_cast<uint16_t *>(q) = (uint16_t)v;
+}
+
+__device__ __forceinline__ float applyAlphaSrc(float c, float a, int mul) // src/reformat.c:333-357
+{
+    if (a == 0)
+        return 0;
+    if (a < 1.0f) {
+        if (mul == MUL_MULTIPLY)
+            return c * a;
+        const float q = c / a;
+        return (q < 1.0f) ? q : 1.0f;
+    }
+    return c;
+}
+
+__device__ __forceinline__ Yuvf rgbToYuvPixel(const RgbToYuvPlan & p, uint32_t i, uint32_t j)
+{
+    const RgbSide & o = p.rgb;
+    const YuvSide & s = p.yuv;
+    const uint8_t * px = o.pixels + (size_t)j * o.rowBytes + (size_t)i * o.pixBytes;
+    float R = (float)loadChannel(px, o.offR, o.chanBytes) / o.maxf;
+    float G = (float)loadChannel(px, o.offG, o.chanBytes) / o.maxf;
+    float B = (float)loadChannel(px, o.offB, o.chanBytes) / o.maxf;
+    if (p.mul != MUL_NONE) {
+        const float a = (float)loadChannel(px, o.offA, o.chanBytes) / o.maxf;
+        R = applyAlphaSrc(R, a, p.mul);
+        G = applyAlphaSrc(G, a, p.mul);
+        B = applyAlphaSrc(B, a, p.mul);
+    }
+    Yuvf out;
+    if (s.mode == MODE_COEFF) { // :383-386
+        const float Y = (s.kr * R) + (s.kg * G) + (s.kb * B);
+        out.y = Y;
+        out.u = (B - Y) / (2 * (1 - s.kb));
+        out.v = (R - Y) / (2 * (1 - s.kr));
+    } else if (s.mode == MODE_IDENTITY) { // :361-365
+        out.y = G, out.u = B, out.v = R;
+    } else if (s.mode == MODE_YCGCO) { // :366-370
+        out.y = 0.5f * G + 0.25f * (R + B);
+        out.u = 0.5f * G - 0.25f * (R + B);
+        out.v = 0.5f * (R - B);
+    } else { // YCgCo-Re / Ro, :371-381
+        float t;
+        t = R * o.maxf;
+        const int Ri = (int)roundHalfUp((t < 0.0f) ? 0.0f : ((o.maxf < t) ? o.maxf : t));
+        t = G * o.maxf;
+        const int Gi = (int)roundHalfUp((t < 0.0f) ? 0.0f : ((o.maxf < t) ? o.maxf : t));
+        t = B * o.maxf;
+        const int Bi = (int)roundHalfUp((t < 0.0f) ? 0.0f : ((o.maxf < t) ? o.maxf : t));
+        const int Co = Ri - Bi;
+        const int tt = Bi + (Co >> 1);
+        const int Cg = Gi - tt;
+        out.y = (float)(tt + (Cg >> 1)) / s.rangeY;
+        out.u = (float)Cg / s.rangeUV;
+        out.v = (float)Co / s.rangeUV;
+    }
+    // luma (and 4:4:4 chroma) are stored right away, :389-406
+    storeSample(s.plane[0], s.rowBytes[0], i, j, s.chanBytes, quantizeY(out.y, s));
+    if (s.format == AVIF_PIXEL_FORMAT_YUV444) {
+        storeSample(s.plane[1], s.rowBytes[1], i, j, s.chanBytes, quantizeUV(out.u, s));
+        storeSample(s.plane[2], s.rowBytes[2], i, j, s.chanBytes, quantizeUV(out.v, s));
+    }
+    // alpha plane, src/alpha.c:9-149 via src/reformat.c:545-569
+    if (p.alphaSource == ALPHA_FILL) {
+        storeSample(s.alpha, s.alphaRowBytes, i, j, s.chanBytes, s.maxv);
+    } else if (p.alphaSource == ALPHA_PLANE) {
+        const unsigned sa = loadChannel(px, o.offA, o.chanBytes);
+        const unsigned a = (o.depth == s.depth) ? sa : rescaleAlpha(sa, o.maxf, (float)s.maxv, s.maxv);
+        storeSample(s.alpha, s.alphaRowBytes, i, j, s.chanBytes, (int)a);
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(256) void rgbToYuvGenericKernel(RgbToYuvPlan p)
+{
+    const uint32_t bx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t by = blockIdx.y * blockDim.y + threadIdx.y;
+    const uint32_t oi = bx * 2, oj = by * 2;
+    if (oi >= p.width || oj >= p.height)
+        return;
+    const YuvSide & s = p.yuv;
+    const uint32_t bw = (oi + 1 >= p.width) ? 1 : 2;
+    const uint32_t bh = (oj + 1 >= p.height) ? 1 : 2;
+
+    // conversion order bJ-outer / bI-inner as in :306-307; blk[bI][bJ]
+    Yuvf blk[2][2];
+    for (uint32_t bJ = 0; bJ < bh; ++bJ)
+        for (uint32_t bI = 0; bI < bw; ++bI)
+            blk[bI][bJ] = rgbToYuvPixel(p, oi + bI, oj + bJ);
+
+    if (s.format == AVIF_PIXEL_FORMAT_YUV420) { // :413-440
+        float sumU = 0.0f, sumV = 0.0f;
+        for (uint32_t bJ = 0; bJ < bh; ++bJ)
+            for (uint32_t bI = 0; bI < bw; ++bI) {
+                sumU += blk[bI][bJ].u;
+                sumV += blk[bI][bJ].v;
+            }
+        const float total = (float)(bw * bh);
+        storeSample(s.plane[1], s.rowBytes[1], bx, by, s.chanBytes, quantizeUV(sumU / total, s));
+        storeSample(s.plane[2], s.rowBytes[2], bx, by, s.chanBytes, quantizeUV(sumV / total, s));
+    } else if (s.format == AVIF_PIXEL_FORMAT_YUV422) { // :441-467
+        for (uint32_t bJ = 0; bJ < bh; ++bJ) {
+            float sumU = 0.0f, sumV = 0.0f;
+            for (uint32_t bI = 0; bI < bw; ++bI) {
+                sumU += blk[bI][bJ].u;
+                sumV += blk[bI][bJ].v;
+            }
+            const float total = (float)bw;
+            storeSample(s.plane[1], s.rowBytes[1], bx, oj + bJ, s.chanBytes, quantizeUV(sumU / total, s));
+            storeSample(s.plane[2], s.rowBytes[2], bx, oj + bJ, s.chanBytes, quantizeUV(sumV / total, s));
+        }
+    }
+}
+
+// gray source: Y from the gray channel, src/reformat.c:471-519 (chroma planes are filled separately)
+__global__ __launch_bounds__(256) void grayToYuvGenericKernel(RgbToYuvPlan p)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= p.width || j >= p.height)
+        return;
+    const RgbSide & o = p.rgb;
+    const YuvSide & s = p.yuv;
+    const uint8_t * px = o.pixels + (size_t)j * o.rowBytes + (size_t)i * o.pixBytes;
+    float g = (float)loadChannel(px, o.offGray, o.chanBytes) / o.maxf;
+    if (p.mul != MUL_NONE) {
+        const float a = (float)loadChannel(px, o.offA, o.chanBytes) / o.maxf;
+        g = applyAlphaSrc(g, a, p.mul);
+    }
+    storeSample(s.plane[0], s.rowBytes[0], i, j, s.chanBytes, quantizeY(g, s));
+    if (p.alphaSource == ALPHA_FILL) {
+        storeSample(s.alpha, s.alphaRowBytes, i, j, s.chanBytes, s.maxv);
+    } else if (p.alphaSource == ALPHA_PLANE) {
+        const unsigned sa = loadChannel(px, o.offA, o.chanBytes);
+        const unsigned a = (o.depth == s.depth) ? sa : rescaleAlpha(sa, o.maxf, (float)s.maxv, s.maxv);
+        storeSample(s.alpha, s.alphaRowBytes, i, j, s.chanBytes, (int)a);
+    }
+}
+
+// memset / avifMemset16 of the chroma planes to the half value, src/reformat.c:520-542
+__global__ __launch_bounds__(256) void fillSamplesKernel(uint8_t * plane, size_t sampleCount, int chanBytes, unsigned value)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= sampleCount)
+        return;
+    if (chanBytes == 1)
+        plane[k] = (uint8_t)value;
+    else
+        reinterpret_cast<uint16_t *>(plane)[k] = (uint16_t)value;
+}
+
+// --------------------------------------------------------------------------------------------
+// in-place premultiply / unpremultiply, src/alpha.c:151-535
+__global__ __launch_bounds__(256) void alphaMulGenericKernel(AlphaMulPlan p)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= p.width || j >= p.height)
+        return;
+    const RgbSide & o = p.rgb;
+    uint8_t * px = o.pixels + (size_t)j * o.rowBytes + (size_t)i * o.pixBytes;
+    const unsigned a = loadChannel(px, o.offA, o.chanBytes);
+    if (a >= (unsigned)o.maxv)
+        return; // opaque is a no-op
+    const int mode = p.unmultiply ? MUL_UNMULTIPLY : MUL_MULTIPLY;
+    const int nColour = o.isGray ? 1 : 3;
+    const int offs[3] = { o.isGray ? o.offGray : o.offR, o.offG, o.offB };
+    for (int k = 0; k < nColour; ++k) {
+        const unsigned c = loadChannel(px, offs[k], o.chanBytes);
+        const unsigned v = alphaMulInt(c, a, (unsigned)o.maxv, o.maxf, mode);
+        if (o.chanBytes == 1)
+            px[offs[k]] = (uint8_t)v;
+        else
+            *reinterpret_cast<uint16_t *>(px + offs[k]) = (uint16_t)v;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// launchers
+static inline dim3 gridFor(uint32_t w, uint32_t h, dim3 block, uint32_t z = 1)
+{
+    return dim3((w + block.x - 1) / block.x, (h + block.y - 1) / block.y, z);
+}
+
+hipError_t launchYuvToRgbGeneric(const YuvToRgbPlan & plan, hipStream_t stream)
+{
+    if (plan.w == 0 || plan.h == 0)
+        return hipSuccess;
+    const dim3 block(64, 4);
+    hipLaunchKernelGGL(yuvToRgbGenericKernel, gridFor(plan.w, plan.h, block), block, 0, stream, plan);
+    return hipGetLastError();
+}
+
+hipError_t launchYuvToRgbGenericBatch(const YuvToRgbPlan * deviceTable, uint32_t count, uint32_t maxW, uint32_t maxH, hipStream_t stream)
+{
+    if (count == 0 || maxW == 0 || maxH == 0)
+        return hipSuccess;
+    const dim3 block(64, 4);
+    hipLaunchKernelGGL(yuvToRgbGenericBatchKernel, gridFor(maxW, maxH, block, count), block, 0, stream, deviceTable);
+    return hipGetLastError();
+}
+
+hipError_t launchRgbToYuvGeneric(const RgbToYuvPlan & plan, hipStream_t stream)
+{
+    if (plan.width == 0 || plan.height == 0)
+        return hipSuccess;
+    const dim3 block(64, 4);
+    if (plan.rgb.isGray) {
+        hipLaunchKernelGGL(grayToYuvGenericKernel, gridFor(plan.width, plan.height, block), block, 0, stream, plan);
+        // chroma planes, if any, are set to half over shiftedH * rowBytes bytes (padding included)
+        const YuvSide & s = plan.yuv;
+        const uint32_t shiftedH = (uint32_t)(((uint64_t)plan.height + s.shiftY) >> s.shiftY);
+        const unsigned half = 1u << (s.depth - 1);
+        for (int pl = 1; pl <= 2; ++pl) {
+            if (!s.plane[pl])
+                continue;
+            const size_t samples = (size_t)shiftedH * s.rowBytes[pl] / (size_t)s.chanBytes;
+            if (samples == 0)
+                continue;
+            const unsigned blocks = (unsigned)((samples + 255) / 256);
+            hipLaunchKernelGGL(fillSamplesKernel, dim3(blocks), dim3(256), 0, stream, s.plane[pl], samples, s.chanBytes, half);
+        }
+    } else {
+        const uint32_t bw = (plan.width + 1) / 2, bh = (plan.height + 1) / 2;
+        hipLaunchKernelGGL(rgbToYuvGenericKernel, gridFor(bw, bh, block), block, 0, stream, plan);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launchAlphaMulGeneric(const AlphaMulPlan & plan, hipStream_t stream)
+{
+    if (plan.width == 0 || plan.height == 0)
+        return hipSuccess;
+    const dim3 block(64, 4);
+    hipLaunchKernelGGL(alphaMulGenericKernel, gridFor(plan.width, plan.height, block), block, 0, stream, plan);
+    return hipGetLastError();
+}
+
+} // namespace avifhip

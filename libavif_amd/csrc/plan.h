@@ -1,0 +1,109 @@
+// plan.h -- host-derived description of one reformat job, consumed by the HIP kernels.
+// POD only: it travels to the device by value (kernarg) or in a descriptor table (batch launches).
+#pragma once
+
+#include <stdint.h>
+
+#include "avifhip.h"
+
+namespace avifhip {
+
+enum ReformatMode : int { MODE_COEFF = 0, MODE_IDENTITY = 1, MODE_YCGCO = 2, MODE_YCGCO_RE = 3, MODE_YCGCO_RO = 4 };
+enum MulMode : int { MUL_NONE = 0, MUL_MULTIPLY = 1, MUL_UNMULTIPLY = 2 };
+enum AlphaSource : int {
+    ALPHA_KEEP = 0,  // destination alpha bytes (if any) are not written
+    ALPHA_FILL = 1,  // opaque                      (avifFillAlpha, src/alpha.c:9)
+    ALPHA_PLANE = 2  // from the alpha plane, copy or depth rescale (avifReformatAlpha, src/alpha.c:37)
+};
+enum Arith : int { ARITH_FLOAT = 0, ARITH_LIBYUV = 1 };
+
+// Interleaved-pixel side (avifRGBColorSpaceInfo, include/avif/internal.h:297-309)
+struct RgbSide
+{
+    uint8_t * pixels;
+    uint32_t rowBytes;
+    uint32_t depth;
+    int32_t format; // avifRGBFormat
+    int32_t chanBytes, pixBytes;
+    int32_t offR, offG, offB, offA, offGray;
+    int32_t hasAlpha, isGray, is565, isFloat;
+    int32_t maxv;
+    float maxf;
+    float f16Multiplier; // src/reformat.c:1411,1429-1430
+};
+
+// Planar side (avifYUVColorSpaceInfo, include/avif/internal.h:314-331)
+struct YuvSide
+{
+    uint8_t * plane[3];
+    uint8_t * alpha;
+    uint32_t rowBytes[3];
+    uint32_t alphaRowBytes;
+    uint32_t depth;
+    int32_t format; // avifPixelFormat
+    int32_t chanBytes;
+    int32_t shiftX, shiftY;
+    int32_t hasColor; // chroma planes present and format != 400
+    int32_t limited;
+    int32_t maxv;
+    int32_t mode; // ReformatMode
+    float kr, kg, kb;
+    float biasY, biasUV, rangeY, rangeUV;
+    // products the reference forms from kr/kb before touching pixel data (src/reformat.c:874-876)
+    float twoOneMinusKr; // 2*(1-kr)
+    float twoOneMinusKb; // 2*(1-kb)
+    float krOneMinusKr;  // kr*(1-kr)
+    float kbOneMinusKb;  // kb*(1-kb)
+};
+
+// libyuv YuvConstants as black-box verified in SURVEY.md Appendix D.1
+struct FixedPointMatrix
+{
+    int32_t yg, yb, ub, ug, vg, vr;
+};
+
+struct YuvToRgbPlan
+{
+    YuvSide yuv;
+    RgbSide rgb;
+    uint32_t canvasW, canvasH; // edge rules are evaluated against these (src/reformat.c:768,784)
+    uint32_t x0, y0, w, h;     // rectangle converted by this job
+    int32_t bilinear;          // 4-tap chroma filter requested (420/422 only)
+    int32_t alphaSource;       // AlphaSource
+    int32_t inLoopMul;         // MulMode applied in fp32 before quantisation (slow path, :894-947)
+    int32_t postMul;           // MulMode applied on the quantised integers (fast path + :1574-1585)
+    int32_t identityCopy;      // src/reformat.c:1278-1309
+    int32_t arith;             // Arith
+    FixedPointMatrix fx;       // valid when arith == ARITH_LIBYUV
+    int32_t fxShiftY, fxShiftUV, fxAlphaShift; // libyuv high-bit-depth reductions (Appendix D.3)
+};
+
+struct RgbToYuvPlan
+{
+    YuvSide yuv; // destination planes
+    RgbSide rgb; // source pixels (const in practice)
+    uint32_t width, height;
+    int32_t mul;         // MulMode applied in fp32 (src/reformat.c:325-358)
+    int32_t alphaSource; // ALPHA_KEEP (no alpha plane) / ALPHA_FILL / ALPHA_PLANE(= from rgb alpha channel)
+    int32_t arith;
+    int32_t fxFullRange;
+};
+
+struct AlphaMulPlan
+{
+    RgbSide rgb;
+    uint32_t width, height;
+    int32_t unmultiply;
+    int32_t arith;
+};
+
+// Host-side derivation (plan.cpp). Return an avifResult; AVIF_RESULT_OK means the plan is valid.
+avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, YuvToRgbPlan * out);
+avifResult makeRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, int arithMode, RgbToYuvPlan * out);
+avifResult makeAlphaMulPlan(const avifRGBImage * rgb, bool unmultiply, int arithMode, AlphaMulPlan * out);
+
+bool rgbFormatHasAlpha(int format);
+bool rgbFormatIsGray(int format);
+int rgbFormatChannelCount(int format);
+
+} // namespace avifhip

@@ -1,0 +1,99 @@
+"""ctypes binding of libavifhip.so (include/avifhip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, importing the
+binding raises; if no GPU is present the conversion entry points return an error code and
+``check`` raises with the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+from .abi import AVIF_RESULT_OK, avifCropRect, avifImage, avifRGBImage
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = CSRC / "libavifhip.so"
+
+# every symbol include/avifhip.h declares (tests assert the library exports each of them)
+EXPORTED_SYMBOLS = [
+    "avifhipImageYUVToRGB", "avifhipImageRGBToYUV", "avifhipRGBImagePremultiplyAlpha", "avifhipRGBImageUnpremultiplyAlpha",
+    "avifhipImageYUVToRGBAsync", "avifhipImageRGBToYUVAsync", "avifhipRGBImagePremultiplyAlphaAsync",
+    "avifhipRGBImageUnpremultiplyAlphaAsync", "avifhipImageYUVToRGBRectAsync", "avifhipImageYUVToRGBBatchAsync",
+    "avifhipLimitedToFullY", "avifhipLimitedToFullUV", "avifhipFullToLimitedY", "avifhipFullToLimitedUV",
+    "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
+    "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
+    "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
+    "avifhipSynthFill",
+]
+
+_lib = None
+
+
+class AvifHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Loads libavifhip.so (once). Raises if it has not been built: the HIP path is the only path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise AvifHipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"or `make -C {CSRC}`; there is no CPU fallback")
+    lib = C.CDLL(os.fspath(LIB_PATH))
+    P_IMG, P_RGB, P_RECT = C.POINTER(avifImage), C.POINTER(avifRGBImage), C.POINTER(avifCropRect)
+    vp, i32, u32 = C.c_void_p, C.c_int, C.c_uint32
+    sigs = {
+        "avifhipImageYUVToRGB": (i32, [P_IMG, P_RGB]),
+        "avifhipImageRGBToYUV": (i32, [P_IMG, P_RGB]),
+        "avifhipRGBImagePremultiplyAlpha": (i32, [P_RGB]),
+        "avifhipRGBImageUnpremultiplyAlpha": (i32, [P_RGB]),
+        "avifhipImageYUVToRGBAsync": (i32, [P_IMG, P_RGB, vp]),
+        "avifhipImageRGBToYUVAsync": (i32, [P_IMG, P_RGB, vp]),
+        "avifhipRGBImagePremultiplyAlphaAsync": (i32, [P_RGB, vp]),
+        "avifhipRGBImageUnpremultiplyAlphaAsync": (i32, [P_RGB, vp]),
+        "avifhipImageYUVToRGBRectAsync": (i32, [P_IMG, P_RGB, P_RECT, vp]),
+        "avifhipImageYUVToRGBBatchAsync": (i32, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), P_RECT, vp]),
+        "avifhipLimitedToFullY": (i32, [u32, i32]),
+        "avifhipLimitedToFullUV": (i32, [u32, i32]),
+        "avifhipFullToLimitedY": (i32, [u32, i32]),
+        "avifhipFullToLimitedUV": (i32, [u32, i32]),
+        "avifhipSetArithmetic": (None, [i32]),
+        "avifhipGetArithmetic": (i32, []),
+        "avifhipSetTiledKernels": (None, [i32]),
+        "avifhipSetDevice": (i32, [i32]),
+        "avifhipDeviceCount": (i32, []),
+        "avifhipSynchronize": (i32, [vp]),
+        "avifhipLastError": (C.c_char_p, []),
+        "avifhipLastKernel": (C.c_char_p, []),
+        "avifhipVersion": (C.c_char_p, []),
+        "avifhipDeviceAlloc": (vp, [C.c_size_t]),
+        "avifhipDeviceFree": (None, [vp]),
+        "avifhipCopyToDevice": (i32, [vp, vp, C.c_size_t]),
+        "avifhipCopyToHost": (i32, [vp, vp, C.c_size_t]),
+        "avifhipDeviceMemset": (i32, [vp, i32, C.c_size_t]),
+        "avifhipTimeYUVToRGB": (C.c_double, [P_IMG, P_RGB, i32, i32, vp]),
+        "avifhipTimeRGBToYUV": (C.c_double, [P_IMG, P_RGB, i32, i32, vp]),
+        "avifhipSynthFill": (u32, [u32, vp, u32, u32, u32, u32, u32, u32]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(result: int, what: str = "avifhip call") -> None:
+    if result != AVIF_RESULT_OK:
+        msg = load().avifhipLastError().decode() or "no detail"
+        raise AvifHipError(f"{what} failed with avifResult {result}: {msg}")
+
+
+def last_kernel() -> str:
+    return load().avifhipLastKernel().decode()
+
+
+def device_count() -> int:
+    return int(load().avifhipDeviceCount())

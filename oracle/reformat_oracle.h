@@ -1,0 +1,60 @@
+/*
+ * reformat_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of libavif's pixel-reformat path, used only as the checker
+ * by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The
+ * shipped library (libavif_amd/csrc) never includes, links or calls this.
+ *
+ * Two arithmetic families are restated:
+ *   oracle*            the reference's built-in floating-point path
+ *                      (/root/reference/src/reformat.c, src/alpha.c), pinned
+ *                      against the reference compiled from source
+ *                      (oracle/_ref/libavif_ref.so, see oracle/Makefile);
+ *   oracleLibyuv*      the fixed-point path libavif dispatches to in libyuv
+ *                      (third-party, pinned 5d03bf9 / LIBYUV_VERSION 1949, source
+ *                      absent from /root/reference; restated from SURVEY.md
+ *                      Appendix D and pinned against Pillow's bundled
+ *                      libavif 1.4.1 + libyuv 1922 binary).
+ */
+#ifndef AVIFHIP_REFORMAT_ORACLE_H
+#define AVIFHIP_REFORMAT_ORACLE_H
+
+#include "avifhip/avif_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference src/reformat.c:1649 (avifImageYUVToRGB), avoidLibYUV semantics (float path) */
+avifResult oracleImageYUVToRGB(const avifImage * image, avifRGBImage * rgb);
+/* reference src/reformat.c:221 (avifImageRGBToYUV); planes that are NULL are malloc'ed like src/avif.c:431 */
+avifResult oracleImageRGBToYUV(avifImage * image, const avifRGBImage * rgb);
+/* reference src/alpha.c:151 / :338 */
+avifResult oracleRGBImagePremultiplyAlpha(avifRGBImage * rgb);
+avifResult oracleRGBImageUnpremultiplyAlpha(avifRGBImage * rgb);
+/* reference src/reformat.c:1778-1840 */
+int oracleLimitedToFullY(uint32_t depth, int v);
+int oracleLimitedToFullUV(uint32_t depth, int v);
+int oracleFullToLimitedY(uint32_t depth, int v);
+int oracleFullToLimitedUV(uint32_t depth, int v);
+
+/*
+ * Same conversion as oracleImageYUVToRGB but only for the sub-rectangle `rect`
+ * of a stitched canvas, with the chroma-edge rules of src/reformat.c:768,784
+ * evaluated against the CANVAS: the result equals the
+ * corresponding rectangle of a whole-canvas conversion.  rgb describes the
+ * whole RGB canvas.  rect->x / rect->y must be even for subsampled formats.
+ */
+avifResult oracleImageYUVToRGBRect(const avifImage * canvas, avifRGBImage * rgbCanvas, const avifCropRect * rect);
+
+/* libyuv-compatible fixed-point path. Returns NOT_IMPLEMENTED
+ * for combinations libavif would not hand to libyuv (src/reformat_libyuv.c:932-1108). */
+avifResult oracleLibyuvImageYUVToRGB(const avifImage * image, avifRGBImage * rgb);
+avifResult oracleLibyuvImageRGBToYUV(avifImage * image, const avifRGBImage * rgb);
+avifResult oracleLibyuvRGBImagePremultiplyAlpha(avifRGBImage * rgb);
+avifResult oracleLibyuvRGBImageUnpremultiplyAlpha(avifRGBImage * rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
