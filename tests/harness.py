@@ -251,13 +251,15 @@ def run_r2y(backend: Backend, c: R2YCase):
     return res, img
 
 
-def planes_equal(a: abi.HostYUV, b: abi.HostYUV) -> Optional[str]:
-    """None if every plane byte (padding included) matches, else a description of the first difference."""
+def planes_equal(a: abi.HostYUV, b: abi.HostYUV, padding: bool = True) -> Optional[str]:
+    """None if every plane byte (row padding included unless padding=False) matches, else the first difference."""
     for p, (x, y) in enumerate(zip(a.planes + [a.alpha], b.planes + [b.alpha])):
         if (x is None) != (y is None):
             return f"plane {p}: presence differs"
         if x is None:
             continue
+        if not padding:
+            x, y = a.plane_samples(p), b.plane_samples(p)
         if not np.array_equal(x, y):
             d = np.argwhere(x != y)[0]
             return f"plane {p}: first difference at row {d[0]} byte {d[1]}: {x[tuple(d)]} != {y[tuple(d)]} ({(x != y).sum()} bytes differ)"
