@@ -84,6 +84,10 @@ AVIFHIP_API int avifhipLimitedToFullUV(uint32_t depth, int v);
 AVIFHIP_API int avifhipFullToLimitedY(uint32_t depth, int v);
 AVIFHIP_API int avifhipFullToLimitedUV(uint32_t depth, int v);
 
+/* kr, kg, kb of an image's CICP (matrixCoefficients / colorPrimaries): replaces avifCalcYUVCoefficients,
+ * include/avif/internal.h (src/colr.c:156-189). Host-only, needs no GPU. */
+AVIFHIP_API void avifhipCalcYUVCoefficients(const avifImage * image, float * outR, float * outG, float * outB);
+
 /* ---- library control ---------------------------------------------------------------------- */
 
 typedef enum avifhipArithmetic
@@ -99,6 +103,10 @@ AVIFHIP_API avifhipArithmetic avifhipGetArithmetic(void);
 /* Diagnostics/tests: 0 routes every conversion through the universal one-lane-per-pixel kernels,
  * 1 (default) lets the bandwidth-tuned tiled kernels take the configurations they cover. */
 AVIFHIP_API void avifhipSetTiledKernels(int enabled);
+
+/* Diagnostics/A-B measurements: bit mask of result-preserving performance knobs (plan.h TuningBits:
+ * bit0 reciprocal+FMA-residual division where verified exact, bit1 saturating byte pack). Default: all on. */
+AVIFHIP_API void avifhipSetTuning(uint32_t bits);
 
 /* Selects the HIP device used by the calling thread's context (default: current device). */
 AVIFHIP_API avifResult avifhipSetDevice(int device);

@@ -21,6 +21,7 @@ namespace {
 
 std::atomic<int> gArithmetic { AVIFHIP_ARITHMETIC_AUTO };
 std::atomic<int> gTiledKernels { 1 };
+std::atomic<uint32_t> gTuning { TUNE_DEFAULT };
 
 struct Scratch
 {
@@ -334,7 +335,7 @@ extern "C" avifResult avifhipImageYUVToRGBRectAsync(const avifImage * canvas, av
     if (!canvas || !rgbCanvas)
         return AVIF_RESULT_INVALID_ARGUMENT;
     YuvToRgbPlan plan;
-    const avifResult pr = makeYuvToRgbPlan(canvas, rgbCanvas, rect, effectiveArithmetic(), &plan);
+    const avifResult pr = makeYuvToRgbPlan(canvas, rgbCanvas, rect, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan);
     if (pr != AVIF_RESULT_OK)
         return pr;
     const avifResult cr = ensureContext();
@@ -355,7 +356,7 @@ extern "C" avifResult avifhipImageYUVToRGB(const avifImage * image, avifRGBImage
     // Validate exactly like the reference before touching the device (error-code matrix,
     // tests/gtest/avif_fuzztest_yuvrgb.cc:36-46).
     YuvToRgbPlan probe;
-    const avifResult pr = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), &probe);
+    const avifResult pr = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &probe);
     if (pr != AVIF_RESULT_OK)
         return pr;
     if (!rgb->pixels) {
@@ -381,7 +382,7 @@ extern "C" avifResult avifhipImageYUVToRGB(const avifImage * image, avifRGBImage
             return r;
     }
     YuvToRgbPlan plan;
-    r = makeYuvToRgbPlan(&imageView, &rgbView, nullptr, effectiveArithmetic(), &plan);
+    r = makeYuvToRgbPlan(&imageView, &rgbView, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan);
     if (r != AVIF_RESULT_OK)
         return r;
     r = enqueueYuvToRgb(plan, tls.stream);
@@ -428,7 +429,7 @@ extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
     for (uint32_t k = 0; k < count; ++k) {
         if (!images[k] || !rgbs[k])
             return AVIF_RESULT_INVALID_ARGUMENT;
-        const avifResult pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, effectiveArithmetic(), &table[k]);
+        const avifResult pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &table[k]);
         if (pr != AVIF_RESULT_OK)
             return pr;
         maxW = table[k].w > maxW ? table[k].w : maxW;
@@ -674,6 +675,11 @@ extern "C" int avifhipFullToLimitedUV(uint32_t depth, int v)
 // library control, device memory helpers, timing
 // =================================================================================================
 
+extern "C" void avifhipCalcYUVCoefficients(const avifImage * image, float * outR, float * outG, float * outB)
+{
+    calcYuvCoefficients(image, outR, outG, outB);
+}
+
 extern "C" void avifhipSetArithmetic(avifhipArithmetic mode)
 {
     gArithmetic.store((int)mode, std::memory_order_relaxed);
@@ -681,6 +687,10 @@ extern "C" void avifhipSetArithmetic(avifhipArithmetic mode)
 extern "C" avifhipArithmetic avifhipGetArithmetic(void)
 {
     return (avifhipArithmetic)gArithmetic.load(std::memory_order_relaxed);
+}
+extern "C" void avifhipSetTuning(uint32_t bits)
+{
+    gTuning.store(bits, std::memory_order_relaxed);
 }
 extern "C" void avifhipSetTiledKernels(int enabled)
 {

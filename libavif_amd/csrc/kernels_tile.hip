@@ -77,19 +77,36 @@ struct PixelOut
     unsigned r, g, b;
 };
 
-template <bool kHasMul>
+// Y,Cb,Cr -> unclamped R,G,B, src/reformat.c:874-876.  kFast: the plan's divisors are on the verified list
+// (reciprocal form, exactdiv.h).
+template <bool kFast>
+__device__ __forceinline__ void matrixRgb(const YuvSide & s, float Y, float Cb, float Cr, float & R, float & G, float & B)
+{
+    if (s.hasColor) {
+        R = Y + s.twoOneMinusKr * Cr;
+        B = Y + s.twoOneMinusKb * Cb;
+        const float num = 2 * ((s.krOneMinusKr * Cr) + (s.kbOneMinusKb * Cb));
+        G = Y - (kFast ? divByVerifiedConstant(num, s.kg, s.rcpKg) : (num / s.kg));
+    } else {
+        R = G = B = Y;
+    }
+}
+
+// (uint8_t)(0.5f + clamp01(c) * 255) packed into byte `slot` of `word`.  v_cvt_pk_u8_f32 rounds to nearest even
+// and saturates to [0, 255] (probed on gfx950, tests/tools/probe_cvt.hip); fed with floor(0.5f + c * 255) it is
+// exact, and because 0.5f + c * 255 is monotonic in c the saturation selects the same byte as clamping c first.
+__device__ __forceinline__ unsigned packByte(float c, float maxf, unsigned slot, unsigned word)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(0.5f + (c * maxf)), slot, word);
+}
+
+template <bool kHasMul, bool kFast>
 __device__ __forceinline__ PixelOut finishPixel(const YuvToRgbPlan & p, float Y, float Cb, float Cr, unsigned unormA, unsigned a)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
     float R, G, B;
-    if (s.hasColor) { // src/reformat.c:874-876
-        R = Y + s.twoOneMinusKr * Cr;
-        B = Y + s.twoOneMinusKb * Cb;
-        G = Y - ((2 * ((s.krOneMinusKr * Cr) + (s.kbOneMinusKb * Cb))) / s.kg);
-    } else {
-        R = G = B = Y;
-    }
+    matrixRgb<kFast>(s, Y, Cb, Cr, R, G, B);
     float Rc = clamp01(R), Gc = clamp01(G), Bc = clamp01(B);
     if (kHasMul && p.inLoopMul != MUL_NONE) {
         const float Ac = clamp01((float)minU(unormA, (unsigned)s.maxv) / ((float)s.maxv));
@@ -164,7 +181,7 @@ __device__ __forceinline__ void store4(uint8_t * dst, const PixelOut q[4], const
     }
 }
 
-template <typename YT, int SUB, bool BILINEAR, typename RT, int NCH, bool HASMUL>
+template <typename YT, int SUB, bool BILINEAR, typename RT, int NCH, bool HASMUL, bool FAST>
 __device__ __forceinline__ void tileBody(const YuvToRgbPlan & p, float (*sU)[kChromaPitch], float (*sV)[kChromaPitch])
 {
     const YuvSide & s = p.yuv;
@@ -224,8 +241,8 @@ __device__ __forceinline__ void tileBody(const YuvToRgbPlan & p, float (*sU)[kCh
             load4<YT>(s.plane[2] + (size_t)(Y0 + r) * s.rowBytes[2] + (size_t)X * sizeof(YT), vq);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                cb[r][k] = normUV(kWide ? minU(uq[k], yuvMax) : uq[k], s);
-                cr[r][k] = normUV(kWide ? minU(vq[k], yuvMax) : vq[k], s);
+                cb[r][k] = normUVT<FAST>(kWide ? minU(uq[k], yuvMax) : uq[k], s);
+                cr[r][k] = normUVT<FAST>(kWide ? minU(vq[k], yuvMax) : vq[k], s);
             }
         }
     } else if constexpr (!BILINEAR) {
@@ -247,7 +264,7 @@ __device__ __forceinline__ void tileBody(const YuvToRgbPlan & p, float (*sU)[kCh
             if (kWide) {
                 u0 = minU(u0, yuvMax), u1 = minU(u1, yuvMax), v0 = minU(v0, yuvMax), v1 = minU(v1, yuvMax);
             }
-            const float fu0 = normUV(u0, s), fu1 = normUV(u1, s), fv0 = normUV(v0, s), fv1 = normUV(v1, s);
+            const float fu0 = normUVT<FAST>(u0, s), fu1 = normUVT<FAST>(u1, s), fv0 = normUVT<FAST>(v0, s), fv1 = normUVT<FAST>(v1, s);
             cb[r][0] = cb[r][1] = fu0;
             cb[r][2] = cb[r][3] = fu1;
             cr[r][0] = cr[r][1] = fv0;
@@ -272,16 +289,16 @@ __device__ __forceinline__ void tileBody(const YuvToRgbPlan & p, float (*sU)[kCh
                 load4<YT>(s.plane[1] + (size_t)cy * s.rowBytes[1] + (size_t)(cx0 + 4 * grp) * sizeof(YT), uq);
                 load4<YT>(s.plane[2] + (size_t)cy * s.rowBytes[2] + (size_t)(cx0 + 4 * grp) * sizeof(YT), vq);
                 float2 f0, f1;
-                f0.x = normUV(kWide ? minU(uq[0], yuvMax) : uq[0], s);
-                f0.y = normUV(kWide ? minU(uq[1], yuvMax) : uq[1], s);
-                f1.x = normUV(kWide ? minU(uq[2], yuvMax) : uq[2], s);
-                f1.y = normUV(kWide ? minU(uq[3], yuvMax) : uq[3], s);
+                f0.x = normUVT<FAST>(kWide ? minU(uq[0], yuvMax) : uq[0], s);
+                f0.y = normUVT<FAST>(kWide ? minU(uq[1], yuvMax) : uq[1], s);
+                f1.x = normUVT<FAST>(kWide ? minU(uq[2], yuvMax) : uq[2], s);
+                f1.y = normUVT<FAST>(kWide ? minU(uq[3], yuvMax) : uq[3], s);
                 *reinterpret_cast<float2 *>(&sU[row][2 + 4 * grp]) = f0;
                 *reinterpret_cast<float2 *>(&sU[row][4 + 4 * grp]) = f1;
-                f0.x = normUV(kWide ? minU(vq[0], yuvMax) : vq[0], s);
-                f0.y = normUV(kWide ? minU(vq[1], yuvMax) : vq[1], s);
-                f1.x = normUV(kWide ? minU(vq[2], yuvMax) : vq[2], s);
-                f1.y = normUV(kWide ? minU(vq[3], yuvMax) : vq[3], s);
+                f0.x = normUVT<FAST>(kWide ? minU(vq[0], yuvMax) : vq[0], s);
+                f0.y = normUVT<FAST>(kWide ? minU(vq[1], yuvMax) : vq[1], s);
+                f1.x = normUVT<FAST>(kWide ? minU(vq[2], yuvMax) : vq[2], s);
+                f1.y = normUVT<FAST>(kWide ? minU(vq[3], yuvMax) : vq[3], s);
                 *reinterpret_cast<float2 *>(&sV[row][2 + 4 * grp]) = f0;
                 *reinterpret_cast<float2 *>(&sV[row][4 + 4 * grp]) = f1;
             }
@@ -299,7 +316,7 @@ __device__ __forceinline__ void tileBody(const YuvToRgbPlan & p, float (*sU)[kCh
             if (kWide)
                 v = minU(v, yuvMax);
             float (*dstPlane)[kChromaPitch] = plane ? sV : sU;
-            dstPlane[row][side ? (2 + 128) : 1] = normUV(v, s);
+            dstPlane[row][side ? (2 + 128) : 1] = normUVT<FAST>(v, s);
         }
         __syncthreads();
 
@@ -371,22 +388,39 @@ __device__ __forceinline__ void tileBody(const YuvToRgbPlan & p, float (*sU)[kCh
             a[k] = (unsigned)o.maxv;
             if (NCH == 4 && p.alphaSource == ALPHA_PLANE)
                 a[k] = (s.depth == o.depth) ? unormA : rescaleAlpha(unormA, (float)s.maxv, o.maxf, o.maxv);
-            q[k] = finishPixel<HASMUL>(p, normY(unormY, s), cb[r][k], cr[r][k], unormA, a[k]);
+            if constexpr (FAST && sizeof(RT) == 1 && NCH == 4 && !HASMUL) {
+                // 8-bit RGBA family: quantise, clamp and pack in one saturating byte conversion per channel
+                float R, G, B;
+                matrixRgb<true>(s, normYT<true>(unormY, s), cb[r][k], cr[r][k], R, G, B);
+                unsigned word = a[k] << (8 * o.offA);
+                word = packByte(R, o.maxf, (unsigned)o.offR, word);
+                word = packByte(G, o.maxf, (unsigned)o.offG, word);
+                word = packByte(B, o.maxf, (unsigned)o.offB, word);
+                q[k].r = word;
+            } else {
+                q[k] = finishPixel<HASMUL, FAST>(p, normYT<FAST>(unormY, s), cb[r][k], cr[r][k], unormA, a[k]);
+            }
         }
         uint8_t * dst = o.pixels + (size_t)(Y0 + r) * o.rowBytes + (size_t)X * (NCH * sizeof(RT));
-        store4<RT, NCH>(dst, q, a, swapRB, alphaFirst);
+        if constexpr (FAST && sizeof(RT) == 1 && NCH == 4 && !HASMUL) {
+            uint4 w;
+            w.x = q[0].r, w.y = q[1].r, w.z = q[2].r, w.w = q[3].r;
+            *reinterpret_cast<uint4 *>(dst) = w;
+        } else {
+            store4<RT, NCH>(dst, q, a, swapRB, alphaFirst);
+        }
     }
 }
 
-template <typename YT, int SUB, bool BILINEAR, typename RT, int NCH, bool HASMUL>
+template <typename YT, int SUB, bool BILINEAR, typename RT, int NCH, bool HASMUL, bool FAST>
 __global__ __launch_bounds__(256) void yuvToRgbTileKernel(YuvToRgbPlan p)
 {
     __shared__ __attribute__((aligned(16))) float sU[BILINEAR ? kChromaRowsMax : 1][kChromaPitch];
     __shared__ __attribute__((aligned(16))) float sV[BILINEAR ? kChromaRowsMax : 1][kChromaPitch];
-    tileBody<YT, SUB, BILINEAR, RT, NCH, HASMUL>(p, sU, sV);
+    tileBody<YT, SUB, BILINEAR, RT, NCH, HASMUL, FAST>(p, sU, sV);
 }
 
-template <typename YT, int SUB, bool BILINEAR, typename RT, int NCH, bool HASMUL>
+template <typename YT, int SUB, bool BILINEAR, typename RT, int NCH, bool HASMUL, bool FAST>
 __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const YuvToRgbPlan * __restrict__ table)
 {
     __shared__ __attribute__((aligned(16))) float sU[BILINEAR ? kChromaRowsMax : 1][kChromaPitch];
@@ -401,7 +435,7 @@ __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const YuvToRgbPla
             dst[k] = src[k];
     }
     __syncthreads();
-    tileBody<YT, SUB, BILINEAR, RT, NCH, HASMUL>(plan, sU, sV);
+    tileBody<YT, SUB, BILINEAR, RT, NCH, HASMUL, FAST>(plan, sU, sV);
 }
 
 struct TileKey
@@ -412,6 +446,7 @@ struct TileKey
     bool wideRgb;
     int nch;
     bool hasMul;
+    bool fast;
 };
 
 TileKey keyFor(const YuvToRgbPlan & p)
@@ -430,6 +465,7 @@ TileKey keyFor(const YuvToRgbPlan & p)
     k.wideRgb = p.rgb.chanBytes == 2;
     k.nch = p.rgb.hasAlpha ? 4 : 3;
     k.hasMul = (p.inLoopMul != MUL_NONE) || (p.postMul != MUL_NONE);
+    k.fast = (p.tuning & TUNE_EXACT_RECIPROCAL) && (p.tuning & TUNE_SATURATING_PACK) && p.yuv.exactNorm && p.yuv.exactKg;
     return k;
 }
 
@@ -438,15 +474,15 @@ bool aligned(const void * ptr, uint32_t rowBytes, uint32_t a)
     return ((uintptr_t)ptr % a) == 0 && (rowBytes % a) == 0;
 }
 
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool MUL>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool MUL, bool FAST>
 hipError_t launchOne(const YuvToRgbPlan * plan, const YuvToRgbPlan * table, uint32_t count, uint32_t w, uint32_t h, hipStream_t stream)
 {
     const dim3 block(kLanesX, kLanesY);
     const dim3 grid((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH, count);
     if (table)
-        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, MUL>), grid, block, 0, stream, table);
+        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, MUL, FAST>), grid, block, 0, stream, table);
     else
-        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, MUL>), grid, block, 0, stream, *plan);
+        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, MUL, FAST>), grid, block, 0, stream, *plan);
     return hipGetLastError();
 }
 
@@ -454,8 +490,10 @@ template <typename YT, int SUB, bool BIL>
 hipError_t launchRgbVariant(const TileKey & k, const YuvToRgbPlan * plan, const YuvToRgbPlan * table, uint32_t count, uint32_t w, uint32_t h, hipStream_t stream)
 {
 #define AVIFHIP_RGB_CASE(RT, NCH)                                                                      \
-    return k.hasMul ? launchOne<YT, SUB, BIL, RT, NCH, true>(plan, table, count, w, h, stream)         \
-                    : launchOne<YT, SUB, BIL, RT, NCH, false>(plan, table, count, w, h, stream)
+    return k.hasMul ? (k.fast ? launchOne<YT, SUB, BIL, RT, NCH, true, true>(plan, table, count, w, h, stream)    \
+                              : launchOne<YT, SUB, BIL, RT, NCH, true, false>(plan, table, count, w, h, stream))  \
+                    : (k.fast ? launchOne<YT, SUB, BIL, RT, NCH, false, true>(plan, table, count, w, h, stream)   \
+                              : launchOne<YT, SUB, BIL, RT, NCH, false, false>(plan, table, count, w, h, stream))
     if (!k.wideRgb) {
         if (k.nch == 4) {
             AVIFHIP_RGB_CASE(uint8_t, 4);
@@ -488,8 +526,8 @@ const char * kernelNameFor(const TileKey & k)
 {
     static thread_local char name[96];
     static const char * subs[] = { "444", "422", "420", "400" };
-    snprintf(name, sizeof(name), "yuv2rgb_tile<%s,%s,%s,%s%d%s>", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
-             k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.hasMul ? ",alphamul" : "");
+    snprintf(name, sizeof(name), "yuv2rgb_tile<%s,%s,%s,%s%d%s%s>", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
+             k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.hasMul ? ",alphamul" : "", k.fast ? "" : ",ieee-div");
     return name;
 }
 
@@ -530,7 +568,7 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
         return -1;
     const TileKey k = keyFor(plan);
     return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) |
-           ((k.hasMul ? 1 : 0) << 6);
+           ((k.hasMul ? 1 : 0) << 6) | ((k.fast ? 1 : 0) << 7);
 }
 
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)

@@ -4,6 +4,8 @@
 // Compiled with -ffp-contract=off: kr/kg/kb products must round like the reference's fp32 code.
 #include "plan.h"
 
+#include "exactdiv.h"
+
 #include <string.h>
 
 namespace avifhip {
@@ -105,7 +107,30 @@ static void coefficientsFromPrimaries(unsigned cp, float * kr, float * kb)
     *kb = (bY * (wX * (rY * gZ - gY * rZ) + wY * (gX * rZ - rX * gZ) + wZ * (rX * gY - gX * rY))) / den;
 }
 
-// reference src/reformat.c:119-159 (avifGetYUVColorSpaceInfo), src/colr.c:123-189, src/avif.c:39-72
+// reference src/colr.c:123-189 (matrixCoefficientsTables, avifCalcYUVCoefficients)
+void calcYuvCoefficients(const avifImage * image, float * krOut, float * kgOut, float * kbOut)
+{
+    float kr = 0.299f, kb = 0.114f; // unspecified => BT.601, src/colr.c:173-176
+    bool known = true;
+    switch (image->matrixCoefficients) {
+        case AVIF_MATRIX_COEFFICIENTS_BT709: kr = 0.2126f, kb = 0.0722f; break;
+        case AVIF_MATRIX_COEFFICIENTS_FCC: kr = 0.30f, kb = 0.11f; break;
+        case AVIF_MATRIX_COEFFICIENTS_BT470BG:
+        case AVIF_MATRIX_COEFFICIENTS_BT601: kr = 0.299f, kb = 0.114f; break;
+        case AVIF_MATRIX_COEFFICIENTS_SMPTE240: kr = 0.212f, kb = 0.087f; break;
+        case AVIF_MATRIX_COEFFICIENTS_BT2020_NCL: kr = 0.2627f, kb = 0.0593f; break;
+        case AVIF_MATRIX_COEFFICIENTS_CHROMA_DERIVED_NCL: coefficientsFromPrimaries(image->colorPrimaries, &kr, &kb); break;
+        default: known = false; break;
+    }
+    float kg = 1.0f - 0.299f - 0.114f;
+    if (known)
+        kg = 1.0f - kr - kb;
+    *krOut = kr;
+    *kgOut = kg;
+    *kbOut = kb;
+}
+
+// reference src/reformat.c:119-159 (avifGetYUVColorSpaceInfo), src/avif.c:39-72
 static bool fillYuvSide(const avifImage * image, YuvSide * s)
 {
     const uint32_t d = image->depth;
@@ -145,24 +170,7 @@ static bool fillYuvSide(const avifImage * image, YuvSide * s)
     s->limited = (image->yuvRange == AVIF_RANGE_LIMITED) ? 1 : 0;
     s->maxv = (1 << d) - 1;
 
-    float kr = 0.299f, kb = 0.114f; // unspecified => BT.601, src/colr.c:173-176
-    bool known = true;
-    switch (mc) {
-        case AVIF_MATRIX_COEFFICIENTS_BT709: kr = 0.2126f, kb = 0.0722f; break;
-        case AVIF_MATRIX_COEFFICIENTS_FCC: kr = 0.30f, kb = 0.11f; break;
-        case AVIF_MATRIX_COEFFICIENTS_BT470BG:
-        case AVIF_MATRIX_COEFFICIENTS_BT601: kr = 0.299f, kb = 0.114f; break;
-        case AVIF_MATRIX_COEFFICIENTS_SMPTE240: kr = 0.212f, kb = 0.087f; break;
-        case AVIF_MATRIX_COEFFICIENTS_BT2020_NCL: kr = 0.2627f, kb = 0.0593f; break;
-        case AVIF_MATRIX_COEFFICIENTS_CHROMA_DERIVED_NCL: coefficientsFromPrimaries(image->colorPrimaries, &kr, &kb); break;
-        default: known = false; break;
-    }
-    float kg = 1.0f - 0.299f - 0.114f;
-    if (known)
-        kg = 1.0f - kr - kb;
-    s->kr = kr;
-    s->kg = kg;
-    s->kb = kb;
+    calcYuvCoefficients(image, &s->kr, &s->kg, &s->kb);
     s->biasY = s->limited ? (float)(16 << (d - 8)) : 0.0f;
     s->biasUV = (float)(1 << (d - 1));
     s->rangeY = (float)(s->limited ? (219 << (d - 8)) : s->maxv);
@@ -197,10 +205,16 @@ static bool prepareState(const avifImage * image, const avifRGBImage * rgb, YuvS
     y->twoOneMinusKb = 2 * (1 - y->kb);
     y->krOneMinusKr = y->kr * (1 - y->kr);
     y->kbOneMinusKb = y->kb * (1 - y->kb);
+    // reciprocal forms, enabled only for divisors on the verified list (exactdiv.h)
+    y->rcpRangeY = 1.0f / y->rangeY;
+    y->rcpRangeUV = 1.0f / y->rangeUV;
+    y->exactNorm = (verifiedRangeDivisor(y->rangeY) && verifiedRangeDivisor(y->rangeUV)) ? 1 : 0;
+    y->rcpKg = (y->kg != 0.0f) ? 1.0f / y->kg : 0.0f;
+    y->exactKg = verifiedKgDivisor(y->kg) ? 1 : 0;
     return true;
 }
 
-avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, YuvToRgbPlan * out)
+avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, uint32_t tuning, YuvToRgbPlan * out)
 {
     (void)arithMode;
     if (!image->yuvPlanes[AVIF_CHAN_Y] || rgb->maxThreads < 0)
@@ -260,6 +274,7 @@ avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, c
     out->inLoopMul = fast ? MUL_NONE : mul;
     out->postMul = fast ? mul : MUL_NONE;
     out->arith = ARITH_FLOAT;
+    out->tuning = tuning;
     return AVIF_RESULT_OK;
 }
 

@@ -54,6 +54,12 @@ struct YuvSide
     float twoOneMinusKb; // 2*(1-kb)
     float krOneMinusKr;  // kr*(1-kr)
     float kbOneMinusKb;  // kb*(1-kb)
+    // Exact division by a plan constant without the IEEE divide sequence: q = x*rcp; q += fma(-q, d, x)*rcp
+    // (one FMA-residual correction).  Only enabled for divisors whose correction has been verified to be
+    // correctly rounded over the whole input domain (exactdiv.h); otherwise the kernels use '/'.
+    float rcpRangeY, rcpRangeUV, rcpKg;
+    int32_t exactNorm; // sample normalisation (cp - bias) / range may use the reciprocal form
+    int32_t exactKg;   // x / kg may use the reciprocal form
 };
 
 // libyuv YuvConstants as black-box verified in SURVEY.md Appendix D.1
@@ -76,6 +82,13 @@ struct YuvToRgbPlan
     int32_t arith;             // Arith
     FixedPointMatrix fx;       // valid when arith == ARITH_LIBYUV
     int32_t fxShiftY, fxShiftUV, fxAlphaShift; // libyuv high-bit-depth reductions (Appendix D.3)
+    uint32_t tuning;           // TuningBits: performance knobs that never change results
+};
+
+enum TuningBits : uint32_t {
+    TUNE_EXACT_RECIPROCAL = 1u << 0, // reciprocal + FMA-residual division where verified (else IEEE '/')
+    TUNE_SATURATING_PACK = 1u << 1,  // 8-bit outputs: v_cvt_pk_u8_f32 (truncating, saturating) instead of clamp+cvt+shift
+    TUNE_DEFAULT = TUNE_EXACT_RECIPROCAL | TUNE_SATURATING_PACK
 };
 
 struct RgbToYuvPlan
@@ -98,10 +111,12 @@ struct AlphaMulPlan
 };
 
 // Host-side derivation (plan.cpp). Return an avifResult; AVIF_RESULT_OK means the plan is valid.
-avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, YuvToRgbPlan * out);
+avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, uint32_t tuning, YuvToRgbPlan * out);
 avifResult makeRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, int arithMode, RgbToYuvPlan * out);
 avifResult makeAlphaMulPlan(const avifRGBImage * rgb, bool unmultiply, int arithMode, AlphaMulPlan * out);
 
+// kr/kg/kb for an image, reference src/colr.c:156-189 (avifCalcYUVCoefficients)
+void calcYuvCoefficients(const avifImage * image, float * kr, float * kg, float * kb);
 bool rgbFormatHasAlpha(int format);
 bool rgbFormatIsGray(int format);
 int rgbFormatChannelCount(int format);
