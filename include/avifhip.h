@@ -105,7 +105,7 @@ AVIFHIP_API avifhipArithmetic avifhipGetArithmetic(void);
 AVIFHIP_API void avifhipSetTiledKernels(int enabled);
 
 /* Diagnostics/A-B measurements: bit mask of result-preserving performance knobs (plan.h TuningBits:
- * bit0 reciprocal+FMA-residual division where verified exact, bit1 saturating byte pack). Default: all on. */
+ * bit0 XCD-banded tile order, bit1 non-temporal RGB stores). Default: bit0. */
 AVIFHIP_API void avifhipSetTuning(uint32_t bits);
 
 /* Selects the HIP device used by the calling thread's context (default: current device). */

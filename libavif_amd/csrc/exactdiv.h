@@ -1,13 +1,39 @@
-// exactdiv.h -- divisors for which the reciprocal form  q0 = x*r; q = fma(fma(-q0, d, x), r, q0), r = RN(1/d)
-// has been verified to equal IEEE-754 binary32 x / d over the kernels' whole input domain
-// (tests/tools/verify_exact_division.c, run by tests/test_exact_division.py: every mantissa and sign for the
-// kg divisors, every code point for the range divisors).  Anything not listed keeps the IEEE divide.
+// exactdiv.h -- division by plan constants without the IEEE divide sequence.
+//
+// For a constant d let  hi = RN(1/d)  and  lo = RN(1/d - hi)  (splitReciprocal).  Then
+//        q = fma(x, hi, x * lo)
+// differs from the exact quotient by a relative 2^-47 before its single final rounding, so it equals the
+// correctly rounded IEEE-754 binary32 quotient x / d unless x / d lies that close to a rounding boundary.
+// That is NOT guaranteed in general; it is established per divisor by exhaustive enumeration
+// (tests/tools/verify_exact_division.cpp, run by tests/test_exact_division.py):
+//   * verifiedKgDivisor       every mantissa and both signs of x (the identity is invariant under scaling x by
+//                             powers of two as long as x * lo stays normal, which holds for every operand the
+//                             kernels form);
+//   * verifiedIntegerDivisor  the same full-mantissa sweep, plus every integer x in [-65536, 65536]
+//                             (code points minus bias).
+// Divisors that are not listed keep the IEEE divide (the universal kernels).
 #pragma once
 
 #include <stdint.h>
 #include <string.h>
 
 namespace avifhip {
+
+struct RcpSplit
+{
+    float hi, lo;
+};
+
+// scale / d (scale a power of two) as RN(scale / d) and the rounded remainder
+inline RcpSplit splitReciprocal(float d, float scale)
+{
+    RcpSplit r = { 0.0f, 0.0f };
+    if (d != 0.0f) {
+        r.hi = scale * (1.0f / d);
+        r.lo = (float)((double)scale / (double)d - (double)r.hi);
+    }
+    return r;
+}
 
 inline uint32_t floatBits(float f)
 {
@@ -18,25 +44,26 @@ inline uint32_t floatBits(float f)
 
 // kg = 1 - kr - kb for every matrixCoefficients / colorPrimaries combination libavif accepts
 // (src/colr.c:123-135 table, :517-542 primaries-derived).
+static const uint32_t kVerifiedKgBits[] = {
+    0x3f161fb4u, 0x3f1645a1u, 0x3f170a3du, 0x3f2c18a0u, 0x3f2d9147u, 0x3f2d9169u, 0x3f2da76au, 0x3f3115c6u,
+    0x3f3374bcu, 0x3f3378a8u, 0x3f34e753u, 0x3f37154au, 0x3f371759u, 0x3f38ba77u, 0x3f800000u,
+};
 inline bool verifiedKgDivisor(float kg)
 {
-    static const uint32_t kVerified[] = {
-        0x3f161fb4u, 0x3f1645a1u, 0x3f170a3du, 0x3f2c18a0u, 0x3f2d9147u, 0x3f2d9169u, 0x3f2da76au, 0x3f3115c6u,
-        0x3f3374bcu, 0x3f3378a8u, 0x3f34e753u, 0x3f37154au, 0x3f371759u, 0x3f38ba77u, 0x3f800000u,
-    };
     const uint32_t b = floatBits(kg);
-    for (uint32_t v : kVerified)
+    for (uint32_t v : kVerifiedKgBits)
         if (v == b)
             return true;
     return false;
 }
 
-// rangeY / rangeUV: 219<<(d-8), 224<<(d-8) and (1<<d)-1 for d in {8, 10, 12, 16} (src/reformat.c:153-156)
-inline bool verifiedRangeDivisor(float range)
+// rangeY / rangeUV: 219<<(d-8), 224<<(d-8); channel maxima (1<<d)-1; d in {8, 10, 12, 16}
+// (src/reformat.c:153-156, :49, src/alpha.c:93,189)
+static const float kVerifiedIntegerDivisors[] = { 219.0f, 224.0f, 255.0f, 876.0f, 896.0f, 1023.0f, 3504.0f, 3584.0f, 4095.0f, 56064.0f, 57344.0f, 65535.0f };
+inline bool verifiedIntegerDivisor(float d)
 {
-    static const float kVerified[] = { 219.0f, 224.0f, 255.0f, 876.0f, 896.0f, 1023.0f, 3504.0f, 3584.0f, 4095.0f, 56064.0f, 57344.0f, 65535.0f };
-    for (float v : kVerified)
-        if (v == range)
+    for (float v : kVerifiedIntegerDivisors)
+        if (v == d)
             return true;
     return false;
 }

@@ -37,26 +37,10 @@ __device__ __forceinline__ float normUV(unsigned cp, const YuvSide & s)
     return (s.mode == MODE_IDENTITY) ? (((float)cp - s.biasY) / s.rangeY) : (((float)cp - s.biasUV) / s.rangeUV);
 }
 
-// x / d for a plan constant d whose reciprocal form is on the verified list (exactdiv.h): one multiply and
-// one FMA-residual correction reproduce the correctly rounded IEEE quotient bit for bit.
-__device__ __forceinline__ float divByVerifiedConstant(float x, float d, float rcp)
+// x / d for a plan constant d on the verified list (exactdiv.h): bit-identical to the IEEE quotient
+__device__ __forceinline__ float divExact(float x, RcpHL r)
 {
-    const float q0 = x * rcp;
-    const float e = __builtin_fmaf(-q0, d, x);
-    return __builtin_fmaf(e, rcp, q0);
-}
-// same values as normY / normUV (MODE_COEFF only), chosen per plan
-template <bool kExact>
-__device__ __forceinline__ float normYT(unsigned cp, const YuvSide & s)
-{
-    const float n = (float)cp - s.biasY;
-    return kExact ? divByVerifiedConstant(n, s.rangeY, s.rcpRangeY) : (n / s.rangeY);
-}
-template <bool kExact>
-__device__ __forceinline__ float normUVT(unsigned cp, const YuvSide & s)
-{
-    const float n = (float)cp - s.biasUV;
-    return kExact ? divByVerifiedConstant(n, s.rangeUV, s.rcpRangeUV) : (n / s.rangeUV);
+    return __builtin_fmaf(x, r.hi, x * r.lo);
 }
 
 __device__ __forceinline__ unsigned loadSample(const uint8_t * plane, uint32_t rowBytes, uint32_t x, uint32_t y, int chanBytes)

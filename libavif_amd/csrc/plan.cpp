@@ -28,6 +28,12 @@ int rgbFormatChannelCount(int f) // reference src/avif.c:681-690
     return rgbFormatHasAlpha(f) ? 4 : 3;
 }
 
+static RcpHL reciprocalOf(float d, float scale)
+{
+    const RcpSplit r = splitReciprocal(d, scale); // exactdiv.h: the form the verifier enumerates
+    return RcpHL { r.hi, r.lo };
+}
+
 // reference src/reformat.c:32-117 (avifGetRGBColorSpaceInfo)
 static bool fillRgbSide(const avifRGBImage * rgb, RgbSide * s)
 {
@@ -73,6 +79,7 @@ static bool fillRgbSide(const avifRGBImage * rgb, RgbSide * s)
     s->maxf = (float)s->maxv;
     const float scale = 1.0f / (float)((1 << d) - 1); // reference src/reformat.c:1429-1430
     s->f16Multiplier = 1.9259299444e-34f * scale;
+    s->rcpMax = reciprocalOf(s->maxf, 1.0f);
     return true;
 }
 
@@ -205,12 +212,15 @@ static bool prepareState(const avifImage * image, const avifRGBImage * rgb, YuvS
     y->twoOneMinusKb = 2 * (1 - y->kb);
     y->krOneMinusKr = y->kr * (1 - y->kr);
     y->kbOneMinusKb = y->kb * (1 - y->kb);
-    // reciprocal forms, enabled only for divisors on the verified list (exactdiv.h)
-    y->rcpRangeY = 1.0f / y->rangeY;
-    y->rcpRangeUV = 1.0f / y->rangeUV;
-    y->exactNorm = (verifiedRangeDivisor(y->rangeY) && verifiedRangeDivisor(y->rangeUV)) ? 1 : 0;
-    y->rcpKg = (y->kg != 0.0f) ? 1.0f / y->kg : 0.0f;
-    y->exactKg = verifiedKgDivisor(y->kg) ? 1 : 0;
+    // reciprocal forms, usable only when every divisor is on the verified list (exactdiv.h)
+    y->rcpRangeY = reciprocalOf(y->rangeY, 1.0f);
+    y->rcpRangeUV = reciprocalOf(y->rangeUV, 1.0f);
+    y->rcpKgTimes2 = reciprocalOf(y->kg, 2.0f);
+    y->rcpMax = reciprocalOf((float)y->maxv, 1.0f);
+    y->exactDiv = (verifiedIntegerDivisor(y->rangeY) && verifiedIntegerDivisor(y->rangeUV) && verifiedIntegerDivisor((float)y->maxv) &&
+                   verifiedIntegerDivisor(r->maxf) && (y->mode != MODE_COEFF || verifiedKgDivisor(y->kg)))
+                      ? 1
+                      : 0;
     return true;
 }
 

@@ -17,6 +17,13 @@ enum AlphaSource : int {
 };
 enum Arith : int { ARITH_FLOAT = 0, ARITH_LIBYUV = 1 };
 
+// 1/d of a plan constant d, split into RN(1/d) and the rounded remainder.  For the divisors on the verified list
+// (exactdiv.h)  fma(x, hi, x * lo)  equals the correctly rounded IEEE-754 binary32 quotient x / d bit for bit.
+struct RcpHL
+{
+    float hi, lo;
+};
+
 // Interleaved-pixel side (avifRGBColorSpaceInfo, include/avif/internal.h:297-309)
 struct RgbSide
 {
@@ -30,6 +37,7 @@ struct RgbSide
     int32_t maxv;
     float maxf;
     float f16Multiplier; // src/reformat.c:1411,1429-1430
+    RcpHL rcpMax;        // 1 / maxf (premultiply, src/alpha.c:189)
 };
 
 // Planar side (avifYUVColorSpaceInfo, include/avif/internal.h:314-331)
@@ -54,12 +62,13 @@ struct YuvSide
     float twoOneMinusKb; // 2*(1-kb)
     float krOneMinusKr;  // kr*(1-kr)
     float kbOneMinusKb;  // kb*(1-kb)
-    // Exact division by a plan constant without the IEEE divide sequence: q = x*rcp; q += fma(-q, d, x)*rcp
-    // (one FMA-residual correction).  Only enabled for divisors whose correction has been verified to be
-    // correctly rounded over the whole input domain (exactdiv.h); otherwise the kernels use '/'.
-    float rcpRangeY, rcpRangeUV, rcpKg;
-    int32_t exactNorm; // sample normalisation (cp - bias) / range may use the reciprocal form
-    int32_t exactKg;   // x / kg may use the reciprocal form
+    // Division by plan constants without the IEEE divide sequence (RcpHL above).  exactDiv is set only when every
+    // divisor of the plan is on the verified list (exactdiv.h); the tiled kernels require it, the universal kernels
+    // always use '/'.
+    RcpHL rcpRangeY, rcpRangeUV;
+    RcpHL rcpKgTimes2; // 2 / kg: (2 * x) / kg == x * (2 / kg) up to the same single rounding (power-of-two scaling)
+    RcpHL rcpMax;      // 1 / maxv (alpha normalisation and depth rescale, src/reformat.c:897, src/alpha.c:93)
+    int32_t exactDiv;
 };
 
 // libyuv YuvConstants as black-box verified in SURVEY.md Appendix D.1
@@ -86,9 +95,9 @@ struct YuvToRgbPlan
 };
 
 enum TuningBits : uint32_t {
-    TUNE_EXACT_RECIPROCAL = 1u << 0, // reciprocal + FMA-residual division where verified (else IEEE '/')
-    TUNE_SATURATING_PACK = 1u << 1,  // 8-bit outputs: v_cvt_pk_u8_f32 (truncating, saturating) instead of clamp+cvt+shift
-    TUNE_DEFAULT = TUNE_EXACT_RECIPROCAL | TUNE_SATURATING_PACK
+    TUNE_XCD_BANDS = 1u << 0,     // tiles of one XCD form a contiguous band of the image (chroma halo rows hit its L2)
+    TUNE_NONTEMPORAL = 1u << 1,   // streaming (nt) stores for the RGB output
+    TUNE_DEFAULT = TUNE_XCD_BANDS
 };
 
 struct RgbToYuvPlan

@@ -1,0 +1,30 @@
+"""The tiled kernels replace IEEE division by plan constants with fma(x, hi, x*lo) (libavif_amd/csrc/exactdiv.h).
+That is only legitimate for divisors for which the form has been enumerated exhaustively: this test runs the
+enumeration (tests/tools/verify_exact_division.cpp) over every divisor on the verified lists.  CPU only (needs an
+x86-64 host with FMA, which both the build container and the GPU box have)."""
+import os
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _has_fma() -> bool:
+    try:
+        return " fma " in Path("/proc/cpuinfo").read_text()
+    except OSError:
+        return False
+
+
+@pytest.mark.skipif(not _has_fma(), reason="host CPU lacks FMA")
+def test_every_listed_divisor_is_exact(tmp_path):
+    exe = tmp_path / "verify_exact_division"
+    subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", "-I", os.fspath(ROOT / "libavif_amd" / "csrc"),
+                    os.fspath(ROOT / "tests" / "tools" / "verify_exact_division.cpp"), "-o", os.fspath(exe)], check=True)
+    proc = subprocess.run([os.fspath(exe)], capture_output=True, text=True)
+    lines = proc.stdout.strip().splitlines()
+    assert proc.returncode == 0, proc.stdout[-2000:]
+    assert len(lines) == 15 + 12
+    assert all(line.endswith("mismatches=0") for line in lines), proc.stdout

@@ -43,7 +43,7 @@ def main():
     names = sys.argv[1:] or ["cfg2"]
     for name in names:
         dimg, drgb, bpp, px = setup(name)
-        variants = [("default", 3, 1), ("ieee-div", 0, 1), ("generic", 3, 0)]
+        variants = [("default", 1, 1), ("no-bands", 0, 1), ("nt-store", 3, 1), ("generic", 1, 0)]
         best = {}
         for rep in range(3):
             for label, tune, tiled in variants:
@@ -55,7 +55,7 @@ def main():
                 if rep == 2:
                     gbps = bpp * px / (best[label] * 1e-3) / 1e9
                     print(f"{name:6s} {label:9s} {best[label]*1000:8.1f} us  {px/1e6/(best[label]*1e-3):10.0f} MP/s  {gbps:7.0f} GB/s  {gbps/80:5.1f}% of 8 TB/s   [{k}]")
-        lib.avifhipSetTuning(3)
+        lib.avifhipSetTuning(1)
         lib.avifhipSetTiledKernels(1)
 
 
