@@ -409,7 +409,10 @@ extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
     const avifResult cr = ensureContext();
     if (cr != AVIF_RESULT_OK)
         return cr;
-    const size_t bytes = (size_t)count * sizeof(YuvToRgbPlan);
+    // pinned staging: [tile descriptors][plans: whole jobs, or the leftover right strips][leftover bottom rows]
+    const size_t tileBytes = (tileBatchTableBytes(count) + 255) & ~(size_t)255;
+    const size_t planBytes = (size_t)count * sizeof(YuvToRgbPlan);
+    const size_t bytes = tileBytes + 2 * planBytes;
     if (bytes > tls.pinnedTableCapacity) {
         if (tls.pinnedTable) {
             HIP_TRY(hipEventSynchronize(tls.tableCopied));
@@ -422,20 +425,22 @@ extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
     } else {
         HIP_TRY(hipEventSynchronize(tls.tableCopied)); // previous upload must have consumed the table
     }
-    YuvToRgbPlan * table = (YuvToRgbPlan *)tls.pinnedTable;
+    uint8_t * pinned = (uint8_t *)tls.pinnedTable;
+    YuvToRgbPlan * plansA = (YuvToRgbPlan *)(pinned + tileBytes);
+    YuvToRgbPlan * plansB = plansA + count;
     uint32_t maxW = 0, maxH = 0;
     bool allTiled = gTiledKernels.load(std::memory_order_relaxed) != 0;
     int variant = -2;
     for (uint32_t k = 0; k < count; ++k) {
         if (!images[k] || !rgbs[k])
             return AVIF_RESULT_INVALID_ARGUMENT;
-        const avifResult pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &table[k]);
+        const avifResult pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plansA[k]);
         if (pr != AVIF_RESULT_OK)
             return pr;
-        maxW = table[k].w > maxW ? table[k].w : maxW;
-        maxH = table[k].h > maxH ? table[k].h : maxH;
+        maxW = plansA[k].w > maxW ? plansA[k].w : maxW;
+        maxH = plansA[k].h > maxH ? plansA[k].h : maxH;
         // one launch serves the whole batch only if every job maps to the same tiled kernel
-        const int v = tileYuvToRgbVariant(table[k]);
+        const int v = tileYuvToRgbVariant(plansA[k]);
         if (variant == -2)
             variant = v;
         if (v < 0 || v != variant)
@@ -445,14 +450,36 @@ extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
     if (rr != AVIF_RESULT_OK)
         return rr;
     hipStream_t stream = pickStream(hipStream);
-    HIP_TRY(hipMemcpyAsync(tls.table.ptr, table, bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipEventRecord(tls.tableCopied, stream));
-    hipError_t e;
+    uint8_t * dev = (uint8_t *)tls.table.ptr;
+    hipError_t e = hipSuccess;
     if (allTiled) {
-        e = launchYuvToRgbTileBatch((const YuvToRgbPlan *)tls.table.ptr, table[0], count, maxW, maxH, stream, &tls.lastKernel);
+        const YuvToRgbPlan representative = plansA[0];
+        fillTileBatchTable(plansA, count, pinned);
+        // leftovers that do not fill a 4x2 pixel group: right strips (in place of the whole jobs) and bottom rows
+        uint32_t restW = 0, restH = 0, restMaxH = 0, restMaxW = 0;
+        for (uint32_t k = 0; k < count; ++k) {
+            const YuvToRgbPlan whole = plansA[k];
+            const uint32_t w4 = whole.w & ~3u, h2 = whole.h & ~1u;
+            plansB[k] = whole;
+            plansB[k].y0 = whole.y0 + h2, plansB[k].h = whole.h - h2, plansB[k].w = w4;
+            plansA[k].x0 = whole.x0 + w4, plansA[k].w = whole.w - w4;
+            restW = plansA[k].w > restW ? plansA[k].w : restW;
+            restMaxH = whole.h > restMaxH ? whole.h : restMaxH;
+            restH = plansB[k].h > restH ? plansB[k].h : restH;
+            restMaxW = w4 > restMaxW ? w4 : restMaxW;
+        }
+        HIP_TRY(hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(tls.tableCopied, stream));
+        e = launchYuvToRgbTileBatch(dev, representative, count, maxW, maxH, stream, &tls.lastKernel);
+        if (e == hipSuccess && restW)
+            e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)(dev + tileBytes), count, restW, restMaxH, stream);
+        if (e == hipSuccess && restH)
+            e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)(dev + tileBytes) + count, count, restMaxW, restH, stream);
     } else {
+        HIP_TRY(hipMemcpyAsync(dev + tileBytes, plansA, planBytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(tls.tableCopied, stream));
         tls.lastKernel = "yuv2rgb_generic_batch";
-        e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)tls.table.ptr, count, maxW, maxH, stream);
+        e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)(dev + tileBytes), count, maxW, maxH, stream);
     }
     if (e != hipSuccess)
         return hipFailed(e, "YUV->RGB batch kernel launch");

@@ -18,8 +18,13 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & plan);
 // id of the tiled-kernel instantiation serving `plan`, or -1 when only the generic kernel can
 int tileYuvToRgbVariant(const YuvToRgbPlan & plan);
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName);
-hipError_t launchYuvToRgbTileBatch(const YuvToRgbPlan * deviceTable, const YuvToRgbPlan & representative, uint32_t count,
-                                   uint32_t maxW, uint32_t maxH, hipStream_t stream, const char ** kernelName);
+// batch launches read a device table of distilled descriptors: tileBatchTableBytes(count) bytes, written on the host
+// by fillTileBatchTable.  They convert the whole-group part (w & ~3, h & ~1) of every job; the caller hands the
+// leftover columns/rows to launchYuvToRgbGenericBatch.
+size_t tileBatchTableBytes(uint32_t count);
+void fillTileBatchTable(const YuvToRgbPlan * plans, uint32_t count, void * hostTable);
+hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW,
+                                   uint32_t maxH, hipStream_t stream, const char ** kernelName);
 bool tileRgbToYuvSupported(const RgbToYuvPlan & plan);
 hipError_t launchRgbToYuvTile(const RgbToYuvPlan & plan, hipStream_t stream, const char ** kernelName);
 

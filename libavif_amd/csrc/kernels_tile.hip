@@ -1,8 +1,10 @@
 // kernels_tile.hip -- host-side dispatch of the bandwidth-tuned tiled kernels (tile_impl.h): which plans they
-// cover and which instantiation serves a plan (one workgroup per 256x8 tile).
+// cover, which instantiation serves a plan, how the image is cut into tiles, and the hand-over of the at most
+// 3 columns / 1 row that do not fill a 4x2 pixel group to the universal kernel.
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <string.h>
 
 #include "kernels.h"
 #include "tile_shared.h"
@@ -11,9 +13,17 @@ namespace avifhip {
 
 using namespace tile;
 
+namespace tile {
+#define AVIFHIP_DECLARE_TILE(name) hipError_t launchTile_##name(const TileKey &, const TileLaunch &);
+AVIFHIP_DECLARE_TILE(u8_444n) AVIFHIP_DECLARE_TILE(u8_400n) AVIFHIP_DECLARE_TILE(u8_422n) AVIFHIP_DECLARE_TILE(u8_422b)
+AVIFHIP_DECLARE_TILE(u8_420n) AVIFHIP_DECLARE_TILE(u8_420b) AVIFHIP_DECLARE_TILE(u16_444n) AVIFHIP_DECLARE_TILE(u16_400n)
+AVIFHIP_DECLARE_TILE(u16_422n) AVIFHIP_DECLARE_TILE(u16_422b) AVIFHIP_DECLARE_TILE(u16_420n) AVIFHIP_DECLARE_TILE(u16_420b)
+#undef AVIFHIP_DECLARE_TILE
+} // namespace tile
+
 namespace {
 
-constexpr uint32_t kTileW = 256, kTileH = 8;
+constexpr uint32_t kBandW = 256, kTargetBlocks = 2048;
 
 TileKey keyFor(const YuvToRgbPlan & p)
 {
@@ -31,6 +41,7 @@ TileKey keyFor(const YuvToRgbPlan & p)
     k.wideRgb = p.rgb.chanBytes == 2;
     k.nch = p.rgb.hasAlpha ? 4 : 3;
     k.hasMul = (p.inLoopMul != MUL_NONE) || (p.postMul != MUL_NONE);
+    k.alphaPlane = k.nch == 4 && p.alphaSource == ALPHA_PLANE;
     return k;
 }
 
@@ -43,14 +54,49 @@ const char * kernelNameFor(const TileKey & k)
 {
     static thread_local char name[112];
     static const char * subs[] = { "444", "422", "420", "400" };
-    snprintf(name, sizeof(name), "yuv2rgb_tile<%s,%s,%s,%s%d%s>", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
-             k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.hasMul ? ",alphamul" : "");
+    snprintf(name, sizeof(name), "yuv2rgb_tile<%s,%s,%s,%s%d%s%s>", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
+             k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "");
     return name;
 }
 
-uint32_t tilesOf(uint32_t w, uint32_t h)
+hipError_t launchFamily(const TileKey & k, const TileLaunch & L)
 {
-    return ((w + kTileW - 1) / kTileW) * ((h + kTileH - 1) / kTileH);
+    if (!k.wideYuv) {
+        switch (k.sub) {
+            case SUB_444: return launchTile_u8_444n(k, L);
+            case SUB_400: return launchTile_u8_400n(k, L);
+            case SUB_422: return k.bilinear ? launchTile_u8_422b(k, L) : launchTile_u8_422n(k, L);
+            default: return k.bilinear ? launchTile_u8_420b(k, L) : launchTile_u8_420n(k, L);
+        }
+    }
+    switch (k.sub) {
+        case SUB_444: return launchTile_u16_444n(k, L);
+        case SUB_400: return launchTile_u16_400n(k, L);
+        case SUB_422: return k.bilinear ? launchTile_u16_422b(k, L) : launchTile_u16_422n(k, L);
+        default: return k.bilinear ? launchTile_u16_420b(k, L) : launchTile_u16_420n(k, L);
+    }
+}
+
+// Work decomposition: a workgroup converts a tile of 256 x (8*NS) pixels, NS = strips per wave in {1, 2}.  Taller
+// tiles amortise the memory latency and the chroma halo rows; shorter ones keep small images spread over the chip.
+void decompose(uint32_t tuning, uint32_t w4, uint32_t h2, uint32_t jobs, bool batch, TileLaunch * L)
+{
+    const uint32_t bands = (w4 + kBandW - 1) / kBandW;
+    uint32_t ns = (tuning >> TUNE_STRIPS_SHIFT) & 0xffu;
+    if (ns == 0) {
+        // keep at least ~8 workgroups per CU in the launch
+        const uint64_t tiles8 = (uint64_t)bands * ((h2 + 7) / 8) * jobs;
+        ns = tiles8 >= 2 * kTargetBlocks ? 2 : 1;
+    }
+    ns = (ns >= 2 && !batch) ? 2 : 1; // the batch kernels exist for NS = 1 only: batches are made of small jobs
+    L->stripsPerWave = ns;
+    L->blocksPerJob = bands * ((h2 + 8 * ns - 1) / (8 * ns));
+}
+
+// largest byte offset the kernel forms from a plane base must fit 32 bits
+bool fits32(uint64_t rows, uint32_t pitch)
+{
+    return rows * (uint64_t)pitch < ((uint64_t)1 << 32);
 }
 
 } // namespace
@@ -77,11 +123,18 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
         return false;
     if (s.hasColor && (!aligned(s.plane[1], s.rowBytes[1], sampleVec) || !aligned(s.plane[2], s.rowBytes[2], sampleVec)))
         return false;
-    if (((o.hasAlpha && p.alphaSource == ALPHA_PLANE) || p.inLoopMul != MUL_NONE) && !aligned(s.alpha, s.alphaRowBytes, sampleVec))
+    const bool readsAlpha = (o.hasAlpha && p.alphaSource == ALPHA_PLANE) || p.inLoopMul != MUL_NONE || p.postMul != MUL_NONE;
+    if (readsAlpha && (!s.alpha || !s.alphaRowBytes || !aligned(s.alpha, s.alphaRowBytes, sampleVec)))
+        return false;
+    if (p.postMul != MUL_NONE && p.alphaSource != ALPHA_PLANE)
         return false;
     const int nch = o.hasAlpha ? 4 : 3;
     const uint32_t storeAlign = (nch == 4) ? 16u : (o.chanBytes == 1 ? 4u : 8u);
     if (!aligned(o.pixels, o.rowBytes, storeAlign))
+        return false;
+    // 32-bit lane offsets from the plane bases
+    if (!fits32(p.canvasH, s.rowBytes[0]) || !fits32(p.canvasH, o.rowBytes) || (s.hasColor && (!fits32(p.canvasH, s.rowBytes[1]) || !fits32(p.canvasH, s.rowBytes[2]))) ||
+        (readsAlpha && !fits32(p.canvasH, s.alphaRowBytes)))
         return false;
     return true;
 }
@@ -92,7 +145,7 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
         return -1;
     const TileKey k = keyFor(plan);
     return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) |
-           ((k.hasMul ? 1 : 0) << 6);
+           ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7);
 }
 
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)
@@ -100,28 +153,58 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     const TileKey k = keyFor(plan);
     if (kernelName)
         *kernelName = kernelNameFor(k);
+    const TileArgs A = distillArgs(plan);
     TileLaunch L;
-    L.plan = &plan;
+    L.args = &A;
     L.table = nullptr;
     L.count = 1;
-    L.blocksPerJob = tilesOf(plan.w, plan.h);
     L.stream = stream;
-    return k.wideYuv ? launchTileU16(k, L) : launchTileU8(k, L);
+    decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
+    hipError_t e = launchFamily(k, L);
+    if (e != hipSuccess)
+        return e;
+    // leftovers: columns [w4, w) of every row, then row h2 of the columns before w4 (both rectangles start on even
+    // coordinates, as the chroma rules of the universal kernel require)
+    if (A.w4 != plan.w) {
+        YuvToRgbPlan rest = plan;
+        rest.x0 = plan.x0 + A.w4, rest.w = plan.w - A.w4;
+        e = launchYuvToRgbGeneric(rest, stream);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (A.h2 != plan.h) {
+        YuvToRgbPlan rest = plan;
+        rest.y0 = plan.y0 + A.h2, rest.h = plan.h - A.h2, rest.w = A.w4;
+        e = launchYuvToRgbGeneric(rest, stream);
+    }
+    return e;
 }
 
-hipError_t launchYuvToRgbTileBatch(const YuvToRgbPlan * deviceTable, const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW,
+size_t tileBatchTableBytes(uint32_t count)
+{
+    return (size_t)count * sizeof(TileArgs);
+}
+
+void fillTileBatchTable(const YuvToRgbPlan * plans, uint32_t count, void * hostTable)
+{
+    TileArgs * t = static_cast<TileArgs *>(hostTable);
+    for (uint32_t k = 0; k < count; ++k)
+        t[k] = distillArgs(plans[k]);
+}
+
+hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW,
                                    uint32_t maxH, hipStream_t stream, const char ** kernelName)
 {
     const TileKey k = keyFor(representative);
     if (kernelName)
         *kernelName = kernelNameFor(k);
     TileLaunch L;
-    L.plan = nullptr;
-    L.table = deviceTable;
+    L.args = nullptr;
+    L.table = static_cast<const TileArgs *>(deviceTileTable);
     L.count = count;
-    L.blocksPerJob = tilesOf(maxW, maxH);
     L.stream = stream;
-    return k.wideYuv ? launchTileU16(k, L) : launchTileU8(k, L);
+    decompose(representative.tuning, maxW & ~3u, maxH & ~1u, count, true, &L);
+    return launchFamily(k, L);
 }
 
 bool tileRgbToYuvSupported(const RgbToYuvPlan &)

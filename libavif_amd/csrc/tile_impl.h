@@ -1,35 +1,35 @@
-// tile_impl.h -- bandwidth-tuned YUV->RGB kernels for gfx950 (MI355X), instantiated per sample type by
-// kernels_tile_u8.hip / kernels_tile_u16.hip.
+// tile_impl.h -- bandwidth-tuned YUV->RGB kernels for gfx950 (MI355X), instantiated by the kernels_tile_*.hip TUs.
 //
 // Scope: matrix-coefficient ("normal YUV") conversions into interleaved 3- or 4-channel RGB at 8-bit or 16-bit
 // containers, from 8-bit or 16-bit-container 4:4:4 / 4:2:2 / 4:2:0 / 4:0:0 planes, nearest or bilinear chroma
 // upsampling, alpha fill / copy / rescale and both flavours of alpha (un)premultiply -- every BASELINE
 // configuration and what avifdec asks for.  Everything else (gray outputs, RGB565, half float, identity / YCgCo
-// matrices, unaligned user buffers, divisors off the verified list) is served by kernels_generic.hip, whose
-// per-pixel routine is also the fallback for pixel groups cut by the image border here.
+// matrices, unaligned user buffers, divisors off the verified list, the <= 3 columns and <= 1 row that do not
+// fill a 4x2 pixel group) is served by kernels_generic.hip.
 //
-// Structure (wave = 64 lanes, workgroup = 4 waves, one workgroup per 256x8-pixel tile):
-//   * lane (tx,ty) owns 4 consecutive pixels of rows 2ty and 2ty+1 of the tile: one 4-sample vector load per plane
-//     and row (row-coalesced), one 16-byte store per row for RGBA8 (1 KiB contiguous per wave instruction);
-//   * bilinear chroma: the tile's chroma neighbourhood (4:2:0: 6 rows x 130 samples per plane) is normalised to
+// Structure (wave = 64 lanes, workgroup = 4 waves, one workgroup per tile of 256 x (8*NS) pixels):
+//   * wave w owns the NS vertically consecutive strips (256 x 2 pixels) w*NS .. w*NS+NS-1; lane tx owns 4 consecutive
+//     pixels of both rows of each strip: one 4-sample vector load per plane and row (row-coalesced), one 16-byte
+//     store per row for RGBA8 (1 KiB contiguous per wave instruction);
+//   * every load of the tile is issued before the first result is needed; stores of earlier strips drain while later
+//     strips are computed;
+//   * bilinear chroma: the tile's chroma neighbourhood (4:2:0: 4*NS+2 rows x 136 samples per plane) is normalised to
 //     fp32 once per sample and staged in LDS as interleaved (Cb,Cr) pairs; each lane reads its 4x3 neighbourhood
 //     with six 16-byte LDS loads and filters both planes at once with packed fp32 instructions, sharing the
 //     9/16, 3/16, 1/16 products between its pixels (the reference re-reads and re-normalises up to four chroma
 //     samples for every output pixel);
-//   * workgroups of one XCD (blockIdx % 8) take a contiguous band of tiles, so the chroma halo rows shared by
+//   * workgroups of one XCD (blockIdx % 8) take a contiguous run of tiles, so the chroma halo rows shared by
 //     vertically adjacent tiles are re-read from that XCD's L2 rather than from HBM;
-//   * arithmetic: the reference's operations in the reference's order (pixel_math.h), issued two at a time as
-//     v_pk_{add,mul,fma}_f32; divisions by plan constants use the exhaustively verified fma(x, hi, x*lo) form
-//     (exactdiv.h); 8-bit outputs are quantised, clamped and packed by v_cvt_pk_u8_f32 executed in
-//     round-toward-zero mode (it saturates to [0,255] and follows MODE.FP_ROUND: tests/tools/probe_cvt_mode.hip).
+//   * arithmetic: the reference's operations in the reference's order, no contraction; divisions by plan constants
+//     use the exhaustively verified fma(x, hi, x*lo) form (exactdiv.h); 8-bit outputs are quantised, clamped and
+//     packed by v_cvt_pk_u8_f32 executed in round-toward-zero mode (it saturates to [0,255] and follows
+//     MODE.FP_ROUND: tests/tools/probe_cvt_mode.hip);
+//   * the kernel arguments are a distilled TileArgs (tile_shared.h) that stays in scalar registers; addresses are
+//     uniform base + 32-bit lane offset.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
-#include <stdio.h>
-
-#include "kernels.h"
-#include "pixel_generic.h"
 #include "pixel_math.h"
 #include "tile_shared.h"
 
@@ -37,15 +37,26 @@ namespace avifhip {
 namespace tile {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTileW = 256;
-constexpr int kTileH = 8;
-constexpr int kLanesX = 64; // 4 pixels each
-constexpr int kLanesY = 4;  // 2 rows each
-// LDS chroma row: entry c+1 holds the (Cb,Cr) pair of chroma column cx0 + c, c in [-1, 128]; a lane's four
-// columns 2tx-1 .. 2tx+2 are entries 2tx .. 2tx+3: two 16-byte aligned loads
-constexpr int kChromaPitch = 132;
-constexpr int kChromaRowsMax = 8;
+constexpr int kBandW = 256; // pixels per strip row: 64 lanes x 4 pixels
+constexpr int kLanesX = 64;
+constexpr int kWavesPerBlock = 4;
+// LDS rows of normalised chroma: entry c+5 holds the (Cb,Cr) pair of chroma column cxb + c, c in [-4, 131]
+// (34 aligned 4-sample groups per row); a lane's four columns 2tx-1 .. 2tx+2 are entries 2tx+4 .. 2tx+7: two
+// 16-byte aligned loads.
+constexpr int kRowPitch = 140;
+constexpr int kStageGroups = 34;
+// chroma rows a workgroup stages for a tile of 4*NS strips (8*NS luma rows)
+template <int SUB, int NS>
+struct StageRows
+{
+    static constexpr int kRows = (SUB == SUB_420) ? (4 * NS + 2) : (8 * NS);
+    static constexpr int kTasks = kRows * kStageGroups;
+    static constexpr int kRounds = (kTasks + 255) / 256;
+};
 
 __device__ __forceinline__ f2 splat(float v)
 {
@@ -61,39 +72,6 @@ __device__ __forceinline__ f2 norm2(f2 cp, float bias, RcpHL r)
     const f2 n = cp - splat(bias);
     return fma2(n, splat(r.hi), n * splat(r.lo));
 }
-
-template <typename T>
-__device__ __forceinline__ void loadRaw4(const uint8_t * p, unsigned w[2])
-{
-    if constexpr (sizeof(T) == 1) {
-        w[0] = *reinterpret_cast<const uint32_t *>(p);
-        w[1] = 0;
-    } else {
-        const uint2 t = *reinterpret_cast<const uint2 *>(p);
-        w[0] = t.x;
-        w[1] = t.y;
-    }
-}
-template <typename T>
-__device__ __forceinline__ void decode4(const unsigned w[2], unsigned v[4])
-{
-    if constexpr (sizeof(T) == 1) {
-        v[0] = w[0] & 0xffu;
-        v[1] = (w[0] >> 8) & 0xffu;
-        v[2] = (w[0] >> 16) & 0xffu;
-        v[3] = w[0] >> 24;
-    } else {
-        v[0] = w[0] & 0xffffu;
-        v[1] = w[0] >> 16;
-        v[2] = w[1] & 0xffffu;
-        v[3] = w[1] >> 16;
-    }
-}
-template <typename T>
-__device__ __forceinline__ unsigned load1(const uint8_t * plane, uint32_t rowBytes, uint32_t x, uint32_t y)
-{
-    return (unsigned)*reinterpret_cast<const T *>(plane + (size_t)y * rowBytes + (size_t)x * sizeof(T));
-}
 __device__ __forceinline__ unsigned minU(unsigned a, unsigned b)
 {
     return a < b ? a : b;
@@ -102,12 +80,52 @@ __device__ __forceinline__ int clampI(int v, int lo, int hi)
 {
     return v < lo ? lo : (v > hi ? hi : v);
 }
-// four samples of one plane as floats, clamped to the depth's maximum for 16-bit containers (src/reformat.c:712,821)
+
+// Four consecutive samples as one vector load from a uniform base plus a 32-bit lane offset.
 template <typename T>
-__device__ __forceinline__ void samples4(const unsigned w[2], unsigned yuvMax, float f[4])
+struct Raw4
+{
+    unsigned w[sizeof(T) == 1 ? 1 : 2];
+};
+template <typename T>
+__device__ __forceinline__ Raw4<T> load4(const uint8_t * base, uint32_t off)
+{
+    Raw4<T> r;
+    if constexpr (sizeof(T) == 1) {
+        r.w[0] = *reinterpret_cast<const uint32_t *>(base + off);
+    } else {
+        const u2 t = *reinterpret_cast<const u2 *>(base + off);
+        r.w[0] = t.x;
+        r.w[1] = t.y;
+    }
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ unsigned load1(const uint8_t * base, uint32_t off)
+{
+    return (unsigned)*reinterpret_cast<const T *>(base + off);
+}
+template <typename T>
+__device__ __forceinline__ void decode4(const Raw4<T> & r, unsigned v[4])
+{
+    if constexpr (sizeof(T) == 1) {
+        v[0] = r.w[0] & 0xffu;
+        v[1] = (r.w[0] >> 8) & 0xffu;
+        v[2] = (r.w[0] >> 16) & 0xffu;
+        v[3] = r.w[0] >> 24;
+    } else {
+        v[0] = r.w[0] & 0xffffu;
+        v[1] = r.w[0] >> 16;
+        v[2] = r.w[1] & 0xffffu;
+        v[3] = r.w[1] >> 16;
+    }
+}
+// ... as floats, clamped to the depth's maximum for 16-bit containers (src/reformat.c:712,821)
+template <typename T>
+__device__ __forceinline__ void samples4(const Raw4<T> & r, unsigned yuvMax, float f[4])
 {
     unsigned v[4];
-    decode4<T>(w, v);
+    decode4<T>(r, v);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         f[k] = (float)((sizeof(T) == 2) ? minU(v[k], yuvMax) : v[k]);
@@ -119,56 +137,55 @@ struct PixelOut
 };
 
 // alpha at the RGB depth from a plane sample: copy or depth rescale (src/alpha.c:84-103, verified reciprocal form)
-__device__ __forceinline__ unsigned alphaFromPlane(const YuvToRgbPlan & p, unsigned sa)
+__device__ __forceinline__ unsigned alphaFromPlane(const TileArgs & A, unsigned sa)
 {
-    if (p.yuv.depth == p.rgb.depth)
+    if (!A.alphaRescale)
         return sa;
-    const float alphaF = divExact((float)sa, p.yuv.rcpMax);
-    const int dstAlpha = (int)(0.5f + (alphaF * p.rgb.maxf));
-    return (unsigned)clampInt(dstAlpha, 0, p.rgb.maxv);
+    const float alphaF = divExact((float)sa, A.rcpYuvMax);
+    const int dstAlpha = (int)(0.5f + (alphaF * A.rgbMaxF));
+    return (unsigned)clampInt(dstAlpha, 0, (int)A.rgbMax);
 }
 
 // (un)premultiply on stored integers with the verified reciprocal for "/ maxF" (src/alpha.c:180-192, :367-381)
-__device__ __forceinline__ unsigned alphaMulIntFast(const RgbSide & o, unsigned c, unsigned a, int mulMode)
+__device__ __forceinline__ unsigned alphaMulIntFast(const TileArgs & A, unsigned c, unsigned a, int mulMode)
 {
-    if (a >= (unsigned)o.maxv)
+    if (a >= A.rgbMax)
         return c;
     if (a == 0)
         return 0;
     if (mulMode == MUL_MULTIPLY)
-        return (unsigned)roundHalfUp(divExact((float)c * (float)a, o.rcpMax));
-    return unpremultiplyInt(c, a, o.maxf);
+        return (unsigned)roundHalfUp(divExact((float)c * (float)a, A.rcpRgbMax));
+    return unpremultiplyInt(c, a, A.rgbMaxF);
 }
 
 // General finish of one pixel from unclamped R,G,B: clamp, optional fp32 alpha multiply, quantise, optional integer
 // alpha multiply (src/reformat.c:886-961, :1574-1585).
-template <bool kHasMul>
-__device__ __forceinline__ PixelOut finishPixel(const YuvToRgbPlan & p, float R, float G, float B, unsigned unormA, unsigned a)
+template <bool HASMUL>
+__device__ __forceinline__ PixelOut finishPixel(const TileArgs & A, float R, float G, float B, unsigned unormA, unsigned a)
 {
-    const YuvSide & s = p.yuv;
-    const RgbSide & o = p.rgb;
     float Rc = clamp01(R), Gc = clamp01(G), Bc = clamp01(B);
-    if (kHasMul && p.inLoopMul != MUL_NONE) {
-        const float Ac = clamp01(divExact((float)minU(unormA, (unsigned)s.maxv), s.rcpMax));
-        Rc = applyAlphaF(Rc, Ac, p.inLoopMul);
-        Gc = applyAlphaF(Gc, Ac, p.inLoopMul);
-        Bc = applyAlphaF(Bc, Ac, p.inLoopMul);
+    if (HASMUL && A.inLoopMul != MUL_NONE) {
+        const float Ac = clamp01(divExact((float)minU(unormA, A.yuvMax), A.rcpYuvMax));
+        Rc = applyAlphaF(Rc, Ac, A.inLoopMul);
+        Gc = applyAlphaF(Gc, Ac, A.inLoopMul);
+        Bc = applyAlphaF(Bc, Ac, A.inLoopMul);
     }
     PixelOut q;
-    q.r = quantize(Rc, o.maxf);
-    q.g = quantize(Gc, o.maxf);
-    q.b = quantize(Bc, o.maxf);
-    if (kHasMul && p.postMul != MUL_NONE) {
-        q.r = alphaMulIntFast(o, q.r, a, p.postMul);
-        q.g = alphaMulIntFast(o, q.g, a, p.postMul);
-        q.b = alphaMulIntFast(o, q.b, a, p.postMul);
+    q.r = quantize(Rc, A.rgbMaxF);
+    q.g = quantize(Gc, A.rgbMaxF);
+    q.b = quantize(Bc, A.rgbMaxF);
+    if (HASMUL && A.postMul != MUL_NONE) {
+        q.r = alphaMulIntFast(A, q.r, a, A.postMul);
+        q.g = alphaMulIntFast(A, q.g, a, A.postMul);
+        q.b = alphaMulIntFast(A, q.b, a, A.postMul);
     }
     return q;
 }
 
 template <typename V>
-__device__ __forceinline__ void storeVec(V * dst, const V & v, bool nontemporal)
+__device__ __forceinline__ void storeVec(uint8_t * base, uint32_t off, const V & v, bool nontemporal)
 {
+    V * dst = reinterpret_cast<V *>(base + off);
     if (nontemporal)
         __builtin_nontemporal_store(v, dst);
     else
@@ -177,11 +194,8 @@ __device__ __forceinline__ void storeVec(V * dst, const V & v, bool nontemporal)
 
 // Store 4 consecutive pixels.  swapRB: B is the first colour channel; alphaFirst: A precedes colour.
 template <typename RT, int NCH>
-__device__ __forceinline__ void store4(uint8_t * dst, const PixelOut q[4], const unsigned a[4], bool swapRB, bool alphaFirst, bool nt)
+__device__ __forceinline__ void store4(uint8_t * base, uint32_t off, const PixelOut q[4], const unsigned a[4], bool swapRB, bool alphaFirst, bool nt)
 {
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    typedef unsigned u3 __attribute__((ext_vector_type(3)));
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
     unsigned x[4], z[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -193,10 +207,10 @@ __device__ __forceinline__ void store4(uint8_t * dst, const PixelOut q[4], const
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             w[k] = alphaFirst ? (a[k] | (x[k] << 8) | (q[k].g << 16) | (z[k] << 24)) : (x[k] | (q[k].g << 8) | (z[k] << 16) | (a[k] << 24));
-        storeVec(reinterpret_cast<u4 *>(dst), w, nt);
+        storeVec(base, off, w, nt);
     } else if constexpr (sizeof(RT) == 1 && NCH == 3) {
         // 12 bytes: x0 g0 z0 x1 | g1 z1 x2 g2 | z2 x3 g3 z3 (rows and pixel groups are 4-byte aligned)
-        unsigned * d = reinterpret_cast<unsigned *>(dst);
+        unsigned * d = reinterpret_cast<unsigned *>(base + off);
         d[0] = x[0] | (q[0].g << 8) | (z[0] << 16) | (x[1] << 24);
         d[1] = q[1].g | (z[1] << 8) | (x[2] << 16) | (q[2].g << 24);
         d[2] = z[2] | (x[3] << 8) | (q[3].g << 16) | (z[3] << 24);
@@ -214,51 +228,46 @@ __device__ __forceinline__ void store4(uint8_t * dst, const PixelOut q[4], const
                 w1[(k & 1) * 2 + 1] = hi;
             }
         }
-        storeVec(reinterpret_cast<u4 *>(dst), w0, nt);
-        storeVec(reinterpret_cast<u4 *>(dst) + 1, w1, nt);
+        storeVec(base, off, w0, nt);
+        storeVec(base, off + 16, w1, nt);
     } else { // 16-bit, 3 channels: 24 bytes = 3 x 8
-        u2 w0, w1, w2;
-        w0.x = x[0] | (q[0].g << 16);
-        w0.y = z[0] | (x[1] << 16);
-        w1.x = q[1].g | (z[1] << 16);
-        w1.y = x[2] | (q[2].g << 16);
-        w2.x = z[2] | (x[3] << 16);
-        w2.y = q[3].g | (z[3] << 16);
-        reinterpret_cast<u2 *>(dst)[0] = w0;
-        reinterpret_cast<u2 *>(dst)[1] = w1;
-        reinterpret_cast<u2 *>(dst)[2] = w2;
+        u2 * d = reinterpret_cast<u2 *>(base + off);
+        d[0] = (u2) { x[0] | (q[0].g << 16), z[0] | (x[1] << 16) };
+        d[1] = (u2) { q[1].g | (z[1] << 16), x[2] | (q[2].g << 16) };
+        d[2] = (u2) { z[2] | (x[3] << 16), q[3].g | (z[3] << 16) };
     }
-    (void)sizeof(u3);
 }
 
 // 8-bit RGBA family: (uint8_t)(0.5f + clamp01(c) * 255) for the three colour channels of four pixels, inserted into
-// words that already hold the alpha byte.  The inputs are t = 0.5f + c * 255 (unclamped c); v_cvt_pk_u8_f32 in
+// copies of words that hold the alpha byte.  The inputs are t = 0.5f + c * 255 (unclamped c); v_cvt_pk_u8_f32 in
 // round-toward-zero mode truncates like the C cast and saturates to [0, 255], and because t is monotonic in c the
 // saturation selects the same byte as clamping c first.  The rounding mode is changed only inside this block.
-__device__ __forceinline__ void packRgba8Row(unsigned w[4], const f2 br[4], const f2 g01, const f2 g23, unsigned slotR, unsigned slotG, unsigned slotB)
+__device__ __forceinline__ void packRgba8Row(unsigned w[4], const unsigned aw[4], const f2 br[4], const float g[4], unsigned slotR, unsigned slotG, unsigned slotB)
 {
+    // operands: %4/%5 = (B,R) of pixel 0 ... %10/%11 of pixel 3; %12..%15 = G; %16..%19 = alpha words; %20,%21,%22 = slots R,G,B
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-                 "v_cvt_pk_u8_f32 %0, %4, %18, %0\n\t"
-                 "v_cvt_pk_u8_f32 %1, %6, %18, %1\n\t"
-                 "v_cvt_pk_u8_f32 %2, %8, %18, %2\n\t"
-                 "v_cvt_pk_u8_f32 %3, %10, %18, %3\n\t"
-                 "v_cvt_pk_u8_f32 %0, %5, %16, %0\n\t"
-                 "v_cvt_pk_u8_f32 %1, %7, %16, %1\n\t"
-                 "v_cvt_pk_u8_f32 %2, %9, %16, %2\n\t"
-                 "v_cvt_pk_u8_f32 %3, %11, %16, %3\n\t"
-                 "v_cvt_pk_u8_f32 %0, %12, %17, %0\n\t"
-                 "v_cvt_pk_u8_f32 %1, %13, %17, %1\n\t"
-                 "v_cvt_pk_u8_f32 %2, %14, %17, %2\n\t"
-                 "v_cvt_pk_u8_f32 %3, %15, %17, %3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, %22, %16\n\t"
+                 "v_cvt_pk_u8_f32 %1, %6, %22, %17\n\t"
+                 "v_cvt_pk_u8_f32 %2, %8, %22, %18\n\t"
+                 "v_cvt_pk_u8_f32 %3, %10, %22, %19\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, %20, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %7, %20, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %9, %20, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %11, %20, %3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %12, %21, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %13, %21, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, %21, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %15, %21, %3\n\t"
                  "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-                 : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
-                 : "v"(br[0].x), "v"(br[0].y), "v"(br[1].x), "v"(br[1].y), "v"(br[2].x), "v"(br[2].y), "v"(br[3].x), "v"(br[3].y), "v"(g01.x),
-                   "v"(g01.y), "v"(g23.x), "v"(g23.y), "s"(slotR), "s"(slotG), "s"(slotB));
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                 : "v"(br[0].x), "v"(br[0].y), "v"(br[1].x), "v"(br[1].y), "v"(br[2].x), "v"(br[2].y), "v"(br[3].x), "v"(br[3].y), "v"(g[0]),
+                   "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(aw[0]), "v"(aw[1]), "v"(aw[2]), "v"(aw[3]), "s"(slotR), "s"(slotG), "s"(slotB));
 }
 
 // 8-bit RGB / BGR: 12 bytes x0 g0 z0 x1 | g1 z1 x2 g2 | z2 x3 g3 z3 from t = 0.5f + c * 255 (see packRgba8Row)
 __device__ __forceinline__ void packRgb8Row(unsigned w[3], const float x[4], const float g[4], const float z[4])
 {
+    // operand map: %3..%6 = x0..x3, %7..%10 = g0..g3, %11..%14 = z0..z3
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
                  "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\t"
                  "v_cvt_pk_u8_f32 %1, %8, 0, 0\n\t"
@@ -276,13 +285,11 @@ __device__ __forceinline__ void packRgb8Row(unsigned w[3], const float x[4], con
                  : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(z[0]), "v"(z[1]), "v"(z[2]),
                    "v"(z[3]));
-    // operand map: %3..%6 = x0..x3, %7..%10 = g0..g3, %11..%14 = z0..z3
-    // w0 = x0 g0 z0 x1 ; w1 = g1 z1 x2 g2 ; w2 = z2 x3 g3 z3
 }
 
-// tile index of this workgroup: workgroups are dispatched round-robin over the 8 XCDs, so giving XCD x the x-th
-// contiguous band of tiles keeps vertically adjacent tiles (which share chroma halo rows) on one L2
-__device__ __forceinline__ uint32_t tileOfBlock(uint32_t b, uint32_t n, bool bands)
+// Workgroups are dispatched round-robin over the 8 XCDs; giving XCD x the x-th contiguous run of tiles keeps
+// vertically adjacent tiles (which share chroma halo rows) on one L2.
+__device__ __forceinline__ uint32_t blockRemap(uint32_t b, uint32_t n, bool bands)
 {
     if (!bands || n < 64)
         return b;
@@ -291,356 +298,352 @@ __device__ __forceinline__ uint32_t tileOfBlock(uint32_t b, uint32_t n, bool ban
     return xcd * per + (xcd < rem ? xcd : rem) + slot;
 }
 
-template <typename YT, int SUB, bool BILINEAR, typename RT, int NCH, bool HASMUL>
-__device__ __forceinline__ void runTile(const YuvToRgbPlan & p, uint32_t nBlocks, f2 (*sC)[kChromaPitch])
+// Raw (undecoded) data of one strip (256 pixels x 2 rows) as loaded by one lane.
+template <typename YT, int SUB, bool BIL, bool NEEDA>
+struct StripRaw
 {
-    const YuvSide & s = p.yuv;
-    const RgbSide & o = p.rgb;
+    static constexpr bool kOwnChroma = SUB == SUB_444 || ((SUB == SUB_420 || SUB == SUB_422) && !BIL);
+    Raw4<YT> y[2];
+    Raw4<YT> a[NEEDA ? 2 : 1];
+    // 4:4:4: one vector per row | nearest 4:2:x: w[0] = the lane's two chroma samples of the row
+    Raw4<YT> u[kOwnChroma ? 2 : 1];
+    Raw4<YT> v[kOwnChroma ? 2 : 1];
+};
+
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+__device__ __forceinline__ void runBlock(const TileArgs & A, f2 (*rows)[kRowPitch])
+{
+    constexpr int kTileH = 8 * NS;
     constexpr bool kWide = sizeof(YT) == 2;
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const unsigned yuvMax = (unsigned)s.maxv;
-
-    const uint32_t tilesX = (p.w + kTileW - 1) / kTileW;
-    const uint32_t tilesY = (p.h + kTileH - 1) / kTileH;
+    constexpr bool kNeedA = APLANE || HASMUL;
+    constexpr uint32_t BPS = sizeof(YT);
+    constexpr uint32_t kPixBytes = NCH * sizeof(RT);
+    const int tx = threadIdx.x, wv = threadIdx.y;
+    const uint32_t tilesX = (A.w4 + kBandW - 1) / kBandW;
+    const uint32_t tilesY = (A.h2 + kTileH - 1) / kTileH;
     const uint32_t nTiles = tilesX * tilesY;
-    const uint32_t tileIndex = tileOfBlock(blockIdx.x, nBlocks, (p.tuning & TUNE_XCD_BANDS) != 0 && (gridDim.z == 1 || (nBlocks & 7) == 0));
-    if (tileIndex >= nTiles)
+    const uint32_t tile = blockRemap(blockIdx.x, gridDim.x, (A.tuning & TUNE_XCD_BANDS) != 0 && (gridDim.z == 1 || (gridDim.x & 7) == 0));
+    if (tile >= nTiles)
         return;
-    const uint32_t trow = tileIndex / tilesX;
-    const uint32_t tileX = (tileIndex - trow * tilesX) * kTileW;
+    const uint32_t trow = tile / tilesX;
+    const uint32_t bandX = (tile - trow * tilesX) * kBandW;
     const uint32_t tileY = trow * kTileH;
-    const bool edge = (tileX + kTileW > p.w) || (tileY + kTileH > p.h);
-    const bool groupFull = tileX + 4 * tx + 3 < p.w;
-    const uint32_t X = p.x0 + tileX + 4 * tx;
-    const uint32_t Y0 = p.y0 + tileY + 2 * ty;
-    const bool needAlpha = (NCH == 4 && p.alphaSource == ALPHA_PLANE) || (HASMUL && p.inLoopMul != MUL_NONE);
-    const bool nt = (p.tuning & TUNE_NONTEMPORAL) != 0;
+    const uint32_t X = bandX + 4 * tx;
+    const bool laneValid = X < A.w4;       // w4 is a multiple of 4: groups are whole or absent
+    const uint32_t Xc = laneValid ? X : 0; // absent lanes load (and discard) the row's first group
+    const bool nt = (A.tuning & TUNE_NONTEMPORAL) != 0;
+    const unsigned yuvMax = A.yuvMax;
 
-    // ---- bilinear: stage the tile's chroma neighbourhood in LDS (loads first, they are the longest chain) ----
-    if constexpr (BILINEAR) {
-        constexpr int kRows = (SUB == SUB_420) ? (kTileH / 2 + 2) : kTileH;
-        const uint32_t cw = (p.canvasW + 1) >> 1;
-        const uint32_t ch = (SUB == SUB_420) ? ((p.canvasH + 1) >> 1) : p.canvasH;
-        const uint32_t cx0 = (p.x0 + tileX) >> 1;
-        const uint32_t cy0 = (SUB == SUB_420) ? ((p.y0 + tileY) >> 1) : (p.y0 + tileY);
-        const int t = ty * kLanesX + tx;
-        // roles: lane t < 32*rows stages chroma group (row = t>>5, grp = t&31) of both planes; the LAST 2*rows lanes of
-        // the workgroup stage one halo column each (row = h>>1, side = h&1)
-        const int row = t >> 5, grp = t & 31;
-        if (row < kRows) {
-            // LDS row q holds canvas chroma row clamp(cy0 - 1 + q) for 4:2:0 or cy0 + q for 4:2:2; coordinates clamp
-            // to the canvas: exactly the reference's border rule (src/reformat.c:768,784)
-            const int cy = clampI((SUB == SUB_420) ? ((int)cy0 - 1 + row) : ((int)cy0 + row), 0, (int)ch - 1);
-            const uint32_t cx = cx0 + 4 * grp;
-            float fu[4], fv[4];
-            if (cx + 3 < cw) {
-                unsigned wu[2], wv[2];
-                loadRaw4<YT>(s.plane[1] + (size_t)cy * s.rowBytes[1] + (size_t)cx * sizeof(YT), wu);
-                loadRaw4<YT>(s.plane[2] + (size_t)cy * s.rowBytes[2] + (size_t)cx * sizeof(YT), wv);
-                samples4<YT>(wu, yuvMax, fu);
-                samples4<YT>(wv, yuvMax, fv);
-            } else {
-                // group cut by the right border of the canvas (edge tiles only)
+    // ---- bilinear: the tile's chroma neighbourhood, loads first (they head the longest dependency chain) ----
+    typedef StageRows<SUB, NS> SR;
+    const int cxb = A.cx0 + (int)(bandX >> 1); // chroma column of the band's first sample
+    // canvas chroma row held by LDS row 0
+    const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)(tileY >> 1) - 1 : A.cy0 + (int)tileY;
+    Raw4<YT> su[BIL ? SR::kRounds : 1], sv[BIL ? SR::kRounds : 1];
+    if constexpr (BIL) {
+        const int t = wv * kLanesX + tx;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int cxk = clampI((int)cx + k, 0, (int)cw - 1);
-                    const unsigned u = load1<YT>(s.plane[1], s.rowBytes[1], (uint32_t)cxk, (uint32_t)cy);
-                    const unsigned v = load1<YT>(s.plane[2], s.rowBytes[2], (uint32_t)cxk, (uint32_t)cy);
-                    fu[k] = (float)(kWide ? minU(u, yuvMax) : u);
-                    fv[k] = (float)(kWide ? minU(v, yuvMax) : v);
-                }
-            }
+        for (int j = 0; j < SR::kRounds; ++j) {
+            const int task = t + 256 * j;
+            if (task < SR::kTasks) {
+                // coordinates clamp to the canvas: exactly the reference's border rule (src/reformat.c:768,784) -- the
+                // neighbour of an edge sample is the sample itself
+                const int row = task / kStageGroups, grp = task - row * kStageGroups;
+                const int cy = clampI(rowBase + row, 0, A.ch - 1);
+                const int cxa = cxb - 4 + 4 * grp;
+                if (cxa >= 0 && cxa + 3 < A.cw) {
+                    su[j] = load4<YT>(A.u, (uint32_t)cy * A.uPitch + (uint32_t)cxa * BPS);
+                    sv[j] = load4<YT>(A.v, (uint32_t)cy * A.vPitch + (uint32_t)cxa * BPS);
+                } else {
+                    // group cut by the left or right border of the canvas
+                    su[j].w[0] = sv[j].w[0] = 0;
+                    if constexpr (kWide)
+                        su[j].w[1] = sv[j].w[1] = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                sC[row][1 + 4 * grp + k] = norm2((f2) { fu[k], fv[k] }, s.biasUV, s.rcpRangeUV);
-        }
-        const int h = kLanesX * kLanesY - 1 - t;
-        if (h < 2 * kRows) {
-            const int hrow = h >> 1, side = h & 1;
-            const int cy = clampI((SUB == SUB_420) ? ((int)cy0 - 1 + hrow) : ((int)cy0 + hrow), 0, (int)ch - 1);
-            const int cx = clampI(side ? (int)cx0 + 128 : (int)cx0 - 1, 0, (int)cw - 1);
-            const unsigned u = load1<YT>(s.plane[1], s.rowBytes[1], (uint32_t)cx, (uint32_t)cy);
-            const unsigned v = load1<YT>(s.plane[2], s.rowBytes[2], (uint32_t)cx, (uint32_t)cy);
-            sC[hrow][side ? 129 : 0] = norm2((f2) { (float)(kWide ? minU(u, yuvMax) : u), (float)(kWide ? minU(v, yuvMax) : v) }, s.biasUV, s.rcpRangeUV);
-        }
-    }
-
-    // ---- this lane's luma / alpha / co-sited chroma: issued before the barrier so they overlap the staging ----
-    unsigned rawY[2][2], rawA[2][2], rawU[2][2], rawV[2][2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const bool ok = groupFull && (tileY + 2 * ty + r < p.h);
-        rawY[r][0] = rawY[r][1] = rawA[r][0] = rawA[r][1] = 0;
-        rawU[r][0] = rawU[r][1] = rawV[r][0] = rawV[r][1] = 0;
-        if (ok) {
-            loadRaw4<YT>(s.plane[0] + (size_t)(Y0 + r) * s.rowBytes[0] + (size_t)X * sizeof(YT), rawY[r]);
-            if (needAlpha)
-                loadRaw4<YT>(s.alpha + (size_t)(Y0 + r) * s.alphaRowBytes + (size_t)X * sizeof(YT), rawA[r]);
-            if constexpr (SUB == SUB_444) {
-                loadRaw4<YT>(s.plane[1] + (size_t)(Y0 + r) * s.rowBytes[1] + (size_t)X * sizeof(YT), rawU[r]);
-                loadRaw4<YT>(s.plane[2] + (size_t)(Y0 + r) * s.rowBytes[2] + (size_t)X * sizeof(YT), rawV[r]);
-            } else if constexpr ((SUB == SUB_420 || SUB == SUB_422) && !BILINEAR) {
-                // nearest: chroma samples (X>>1, X>>1 + 1) of chroma row (j >> shiftY); one aligned pair load per plane
-                if (!(SUB == SUB_420 && r == 1)) {
-                    const uint32_t cy = (SUB == SUB_420) ? (Y0 >> 1) : (Y0 + r);
-                    const size_t off = (size_t)(X >> 1) * sizeof(YT);
-                    if constexpr (sizeof(YT) == 1) {
-                        rawU[r][0] = *reinterpret_cast<const uint16_t *>(s.plane[1] + (size_t)cy * s.rowBytes[1] + off);
-                        rawV[r][0] = *reinterpret_cast<const uint16_t *>(s.plane[2] + (size_t)cy * s.rowBytes[2] + off);
-                    } else {
-                        rawU[r][0] = *reinterpret_cast<const uint32_t *>(s.plane[1] + (size_t)cy * s.rowBytes[1] + off);
-                        rawV[r][0] = *reinterpret_cast<const uint32_t *>(s.plane[2] + (size_t)cy * s.rowBytes[2] + off);
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t cx = (uint32_t)clampI(cxa + k, 0, A.cw - 1);
+                        const unsigned u = load1<YT>(A.u, (uint32_t)cy * A.uPitch + cx * BPS);
+                        const unsigned v = load1<YT>(A.v, (uint32_t)cy * A.vPitch + cx * BPS);
+                        if constexpr (!kWide) {
+                            su[j].w[0] |= u << (8 * k);
+                            sv[j].w[0] |= v << (8 * k);
+                        } else {
+                            su[j].w[k >> 1] |= u << (16 * (k & 1));
+                            sv[j].w[k >> 1] |= v << (16 * (k & 1));
+                        }
                     }
                 }
             }
         }
     }
 
-    if constexpr (BILINEAR)
-        __syncthreads();
-
-    if (edge && !groupFull) {
-        // pixel group cut by the right border: per-pixel routine for the pixels that exist
-#pragma unroll 1
+    // ---- this wave's luma / alpha / co-sited chroma for all of its strips ----
+    StripRaw<YT, SUB, BIL, kNeedA> raw[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const uint32_t sy = tileY + 2 * (wv * NS + k);
+        const uint32_t syc = sy < A.h2 ? sy : 0; // absent strips load (and discard) the first one
+#pragma unroll
         for (int r = 0; r < 2; ++r) {
-            if (tileY + 2 * ty + r >= p.h)
-                continue;
-#pragma unroll 1
-            for (int k = 0; k < 4; ++k)
-                if (tileX + 4 * tx + k < p.w)
-                    yuvToRgbPixel(p, X + k, Y0 + r);
+            raw[k].y[r] = load4<YT>(A.y, (syc + r) * A.yPitch + Xc * BPS);
+            if constexpr (kNeedA)
+                raw[k].a[r] = load4<YT>(A.a, (syc + r) * A.aPitch + Xc * BPS);
+            if constexpr (SUB == SUB_444) {
+                raw[k].u[r] = load4<YT>(A.u, ((uint32_t)A.cy0 + syc + r) * A.uPitch + ((uint32_t)A.cx0 + Xc) * BPS);
+                raw[k].v[r] = load4<YT>(A.v, ((uint32_t)A.cy0 + syc + r) * A.vPitch + ((uint32_t)A.cx0 + Xc) * BPS);
+            } else if constexpr ((SUB == SUB_420 || SUB == SUB_422) && !BIL) {
+                // nearest: chroma samples (X>>1, X>>1 + 1) of chroma row (j >> shiftY); one aligned pair load per plane
+                if (!(SUB == SUB_420 && r == 1)) {
+                    const uint32_t cy = (uint32_t)A.cy0 + ((SUB == SUB_420) ? (syc >> 1) : (syc + r));
+                    const uint32_t cx = (uint32_t)A.cx0 + (Xc >> 1);
+                    if constexpr (!kWide) {
+                        raw[k].u[r].w[0] = *reinterpret_cast<const uint16_t *>(A.u + (cy * A.uPitch + cx));
+                        raw[k].v[r].w[0] = *reinterpret_cast<const uint16_t *>(A.v + (cy * A.vPitch + cx));
+                    } else {
+                        raw[k].u[r].w[0] = *reinterpret_cast<const uint32_t *>(A.u + (cy * A.uPitch + cx * 2));
+                        raw[k].v[r].w[0] = *reinterpret_cast<const uint32_t *>(A.v + (cy * A.vPitch + cx * 2));
+                    }
+                }
+            }
         }
-        return;
     }
 
-    // ---- (Cb,Cr) for the lane's 2 x 4 pixels ----
-    f2 uv[2][4];
-    if constexpr (SUB == SUB_400) {
+    if constexpr (BIL) {
+        const int t = wv * kLanesX + tx;
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                uv[r][k] = splat(0.5f);
-    } else if constexpr (SUB == SUB_444) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float fu[4], fv[4];
-            samples4<YT>(rawU[r], yuvMax, fu);
-            samples4<YT>(rawV[r], yuvMax, fv);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                uv[r][k] = norm2((f2) { fu[k], fv[k] }, s.biasUV, s.rcpRangeUV);
-        }
-    } else if constexpr (!BILINEAR) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (SUB == SUB_420 && r == 1) {
+        for (int j = 0; j < SR::kRounds; ++j) {
+            const int task = t + 256 * j;
+            if (task < SR::kTasks) {
+                const int row = task / kStageGroups, grp = task - row * kStageGroups;
+                float fu[4], fv[4];
+                samples4<YT>(su[j], yuvMax, fu);
+                samples4<YT>(sv[j], yuvMax, fv);
+                f2 * dst = &rows[row][4 * grp + 1];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    uv[1][k] = uv[0][k];
-                break;
-            }
-            constexpr unsigned kMask = kWide ? 0xffffu : 0xffu;
-            constexpr int kShift = kWide ? 16 : 8;
-            unsigned u0 = rawU[r][0] & kMask, u1 = (rawU[r][0] >> kShift) & kMask;
-            unsigned v0 = rawV[r][0] & kMask, v1 = (rawV[r][0] >> kShift) & kMask;
-            if (kWide) {
-                u0 = minU(u0, yuvMax), u1 = minU(u1, yuvMax), v0 = minU(v0, yuvMax), v1 = minU(v1, yuvMax);
-            }
-            const f2 c0 = norm2((f2) { (float)u0, (float)v0 }, s.biasUV, s.rcpRangeUV);
-            const f2 c1 = norm2((f2) { (float)u1, (float)v1 }, s.biasUV, s.rcpRangeUV);
-            uv[r][0] = uv[r][1] = c0;
-            uv[r][2] = uv[r][3] = c1;
-        }
-    } else {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        // 4-tap filter on normalised samples, src/reformat.c:834-837: ((closest*9/16 + horizontal*3/16) + vertical*3/16)
-        // + diagonal*1/16, evaluated for Cb and Cr at once; every product equals the reference's product for that tap
-        const f2 k9 = splat(9.0f / 16.0f), k3 = splat(3.0f / 16.0f), k1 = splat(1.0f / 16.0f);
-        auto loadRow = [&](int q, f2 m[4]) {
-            const f4 lo = *reinterpret_cast<const f4 *>(&sC[q][2 * tx]);
-            const f4 hi = *reinterpret_cast<const f4 *>(&sC[q][2 * tx + 2]);
-            m[0] = lo.xy, m[1] = lo.zw, m[2] = hi.xy, m[3] = hi.zw;
-        };
-        if constexpr (SUB == SUB_420) {
-            f2 m[4], v[2][4];
-            loadRow(ty + 1, m);
-            loadRow(ty, v[0]);     // even luma rows: vertical neighbour above
-            loadRow(ty + 2, v[1]); // odd luma rows: below
-            const f2 m9b = m[1] * k9, m9c = m[2] * k9;
-            const f2 m3a = m[0] * k3, m3b = m[1] * k3, m3c = m[2] * k3, m3d = m[3] * k3;
-            const f2 h0 = m9b + m3a, h1 = m9b + m3c, h2 = m9c + m3b, h3 = m9c + m3d;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const f2 v3b = v[r][1] * k3, v3c = v[r][2] * k3;
-                const f2 v1a = v[r][0] * k1, v1b = v[r][1] * k1, v1c = v[r][2] * k1, v1d = v[r][3] * k1;
-                uv[r][0] = (h0 + v3b) + v1a; // even pixel: horizontal neighbour on the left
-                uv[r][1] = (h1 + v3b) + v1c; // odd pixel: on the right
-                uv[r][2] = (h2 + v3c) + v1b;
-                uv[r][3] = (h3 + v3c) + v1d;
-            }
-        } else { // 4:2:2: the vertical neighbour is the sample itself (src/reformat.c:784-786)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                f2 m[4];
-                loadRow(2 * ty + r, m);
-                const f2 m9b = m[1] * k9, m9c = m[2] * k9;
-                const f2 m3a = m[0] * k3, m3b = m[1] * k3, m3c = m[2] * k3, m3d = m[3] * k3;
-                const f2 m1a = m[0] * k1, m1b = m[1] * k1, m1c = m[2] * k1, m1d = m[3] * k1;
-                uv[r][0] = ((m9b + m3a) + m3b) + m1a;
-                uv[r][1] = ((m9b + m3c) + m3b) + m1c;
-                uv[r][2] = ((m9c + m3b) + m3c) + m1b;
-                uv[r][3] = ((m9c + m3d) + m3c) + m1d;
+                    dst[k] = norm2((f2) { fu[k], fv[k] }, A.biasUV, A.rcpRangeUV);
             }
         }
+        __syncthreads();
     }
 
-    // ---- per-pixel arithmetic and stores ----
-    const bool swapRB = (o.offB < o.offR);
-    const bool alphaFirst = (NCH == 4) && (o.offA == 0);
-    const f2 cBR = { s.twoOneMinusKb, s.twoOneMinusKr }; // (Cb,Cr) -> (B - Y, R - Y), src/reformat.c:874-875
-    const f2 cUV = { s.kbOneMinusKb, s.krOneMinusKr };   // the two products of the green term, :876
+    const bool swapRB = A.slotB < A.slotR;
+    const bool alphaFirst = (NCH == 4) && (A.slotA == 0);
+    const f2 cBR = { A.cB, A.cR }; // (Cb,Cr) -> (B - Y, R - Y), src/reformat.c:874-875
+    const f2 cUV = { A.cU, A.cV }; // the two products of the green term, :876
+    const unsigned opaqueWord = A.rgbMax << (8 * A.slotA); // 8-bit RGBA: the alpha byte in place
+
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (edge && (tileY + 2 * ty + r >= p.h))
-            continue;
-        float fy[4];
-        samples4<YT>(rawY[r], yuvMax, fy);
-        const f2 y01 = norm2((f2) { fy[0], fy[1] }, s.biasY, s.rcpRangeY);
-        const f2 y23 = norm2((f2) { fy[2], fy[3] }, s.biasY, s.rcpRangeY);
-        const float yk[4] = { y01.x, y01.y, y23.x, y23.y };
-        f2 br[4]; // (B, R) per pixel
-        f2 g01, g23;
+    for (int k = 0; k < NS; ++k) {
+        const uint32_t sy = tileY + 2 * (wv * NS + k);
+        if (sy >= A.h2)
+            break;
+
+        // ---- (Cb,Cr) for the lane's 2 x 4 pixels ----
+        f2 uv[2][4];
         if constexpr (SUB == SUB_400) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                br[k] = splat(yk[k]);
-            g01 = y01, g23 = y23;
-        } else {
-            float sum[4];
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                br[k] = splat(yk[k]) + cBR * uv[r][k];
-                const f2 pr = cUV * uv[r][k];
-                sum[k] = pr.y + pr.x; // (kr(1-kr)*Cr) + (kb(1-kb)*Cb)
+                for (int i = 0; i < 4; ++i)
+                    uv[r][i] = splat(0.5f);
+        } else if constexpr (SUB == SUB_444) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                float fu[4], fv[4];
+                samples4<YT>(raw[k].u[r], yuvMax, fu);
+                samples4<YT>(raw[k].v[r], yuvMax, fv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    uv[r][i] = norm2((f2) { fu[i], fv[i] }, A.biasUV, A.rcpRangeUV);
             }
-            // G = Y - (2*sum)/kg with 2/kg in verified reciprocal form
-            const f2 s01 = { sum[0], sum[1] }, s23 = { sum[2], sum[3] };
-            g01 = y01 - fma2(s01, splat(s.rcpKgTimes2.hi), s01 * splat(s.rcpKgTimes2.lo));
-            g23 = y23 - fma2(s23, splat(s.rcpKgTimes2.hi), s23 * splat(s.rcpKgTimes2.lo));
-        }
-
-        unsigned av[4], a[4];
-        decode4<YT>(rawA[r], av);
+        } else if constexpr (!BIL) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            a[k] = (unsigned)o.maxv;
-            if (NCH == 4 && p.alphaSource == ALPHA_PLANE)
-                a[k] = alphaFromPlane(p, av[k]);
-        }
-        uint8_t * dst = o.pixels + (size_t)(Y0 + r) * o.rowBytes + (size_t)X * (NCH * sizeof(RT));
-
-        if constexpr (sizeof(RT) == 1 && !HASMUL) {
-            // 8-bit outputs: t = 0.5f + c * 255, then truncate + saturate + pack in one instruction per channel
-            const f2 half = splat(0.5f), mx = splat(o.maxf);
-            f2 tbr[4];
+            for (int r = 0; r < 2; ++r) {
+                if (SUB == SUB_420 && r == 1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                tbr[k] = half + (br[k] * mx);
-            const f2 tg01 = half + (g01 * mx), tg23 = half + (g23 * mx);
-            if constexpr (NCH == 4) {
-                typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                unsigned w[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    w[k] = a[k] << (8 * o.offA);
-                packRgba8Row(w, tbr, tg01, tg23, (unsigned)o.offR, (unsigned)o.offG, (unsigned)o.offB);
-                storeVec(reinterpret_cast<u4 *>(dst), (u4) { w[0], w[1], w[2], w[3] }, nt);
-            } else {
-                float x[4], g[4] = { tg01.x, tg01.y, tg23.x, tg23.y }, z[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    x[k] = swapRB ? tbr[k].x : tbr[k].y;
-                    z[k] = swapRB ? tbr[k].y : tbr[k].x;
+                    for (int i = 0; i < 4; ++i)
+                        uv[1][i] = uv[0][i];
+                    break;
                 }
-                unsigned w[3];
-                packRgb8Row(w, x, g, z);
-                unsigned * d = reinterpret_cast<unsigned *>(dst);
-                d[0] = w[0], d[1] = w[1], d[2] = w[2];
+                constexpr unsigned kMask = kWide ? 0xffffu : 0xffu;
+                constexpr int kShift = kWide ? 16 : 8;
+                unsigned u0 = raw[k].u[r].w[0] & kMask, u1 = (raw[k].u[r].w[0] >> kShift) & kMask;
+                unsigned v0 = raw[k].v[r].w[0] & kMask, v1 = (raw[k].v[r].w[0] >> kShift) & kMask;
+                if (kWide) {
+                    u0 = minU(u0, yuvMax), u1 = minU(u1, yuvMax), v0 = minU(v0, yuvMax), v1 = minU(v1, yuvMax);
+                }
+                const f2 c0 = norm2((f2) { (float)u0, (float)v0 }, A.biasUV, A.rcpRangeUV);
+                const f2 c1 = norm2((f2) { (float)u1, (float)v1 }, A.biasUV, A.rcpRangeUV);
+                uv[r][0] = uv[r][1] = c0;
+                uv[r][2] = uv[r][3] = c1;
             }
         } else {
-            const float gk[4] = { g01.x, g01.y, g23.x, g23.y };
-            PixelOut q[4];
+            // 4-tap filter on normalised samples, src/reformat.c:834-837: ((closest*9/16 + horizontal*3/16) + vertical*3/16)
+            // + diagonal*1/16, evaluated for Cb and Cr at once; every product equals the reference's product for that tap.
+            const f2 k9 = splat(9.0f / 16.0f), k3 = splat(3.0f / 16.0f), k1 = splat(1.0f / 16.0f);
+            auto loadRow = [&](int q, f2 m[4]) {
+                const f2 * src = &rows[q][2 * tx + 4];
+                const f4 lo = *reinterpret_cast<const f4 *>(src);
+                const f4 hi = *reinterpret_cast<const f4 *>(src + 2);
+                m[0] = lo.xy, m[1] = lo.zw, m[2] = hi.xy, m[3] = hi.zw;
+            };
+            if constexpr (SUB == SUB_420) {
+                const int qm = 1 + wv * NS + k; // LDS row of the strip's co-sited chroma row
+                f2 m[4], v[2][4];
+                loadRow(qm, m);
+                loadRow(qm - 1, v[0]); // even luma rows: vertical neighbour above
+                loadRow(qm + 1, v[1]); // odd luma rows: below
+                const f2 m9b = m[1] * k9, m9c = m[2] * k9;
+                const f2 m3a = m[0] * k3, m3b = m[1] * k3, m3c = m[2] * k3, m3d = m[3] * k3;
+                const f2 h0 = m9b + m3a, h1 = m9b + m3c, h2 = m9c + m3b, h3 = m9c + m3d;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                q[k] = finishPixel<HASMUL>(p, br[k].y, gk[k], br[k].x, needAlpha ? av[k] : 0u, a[k]);
-            store4<RT, NCH>(dst, q, a, swapRB, alphaFirst, nt);
+                for (int r = 0; r < 2; ++r) {
+                    const f2 v3b = v[r][1] * k3, v3c = v[r][2] * k3;
+                    const f2 v1a = v[r][0] * k1, v1b = v[r][1] * k1, v1c = v[r][2] * k1, v1d = v[r][3] * k1;
+                    uv[r][0] = (h0 + v3b) + v1a; // even pixel: horizontal neighbour on the left
+                    uv[r][1] = (h1 + v3b) + v1c; // odd pixel: on the right
+                    uv[r][2] = (h2 + v3c) + v1b;
+                    uv[r][3] = (h3 + v3c) + v1d;
+                }
+            } else { // 4:2:2: the vertical neighbour is the sample itself (src/reformat.c:784-786)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    f2 m[4];
+                    loadRow(2 * (wv * NS + k) + r, m);
+                    const f2 m9b = m[1] * k9, m9c = m[2] * k9;
+                    const f2 m3a = m[0] * k3, m3b = m[1] * k3, m3c = m[2] * k3, m3d = m[3] * k3;
+                    const f2 m1a = m[0] * k1, m1b = m[1] * k1, m1c = m[2] * k1, m1d = m[3] * k1;
+                    uv[r][0] = ((m9b + m3a) + m3b) + m1a;
+                    uv[r][1] = ((m9b + m3c) + m3b) + m1c;
+                    uv[r][2] = ((m9c + m3b) + m3c) + m1b;
+                    uv[r][3] = ((m9c + m3d) + m3c) + m1d;
+                }
+            }
+        }
+
+        // ---- per-pixel arithmetic and stores ----
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float fy[4];
+            samples4<YT>(raw[k].y[r], yuvMax, fy);
+            const f2 y01 = norm2((f2) { fy[0], fy[1] }, A.biasY, A.rcpRangeY);
+            const f2 y23 = norm2((f2) { fy[2], fy[3] }, A.biasY, A.rcpRangeY);
+            const float yk[4] = { y01.x, y01.y, y23.x, y23.y };
+            f2 br[4]; // (B, R) per pixel
+            float g[4];
+            if constexpr (SUB == SUB_400) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    br[i] = splat(yk[i]);
+                    g[i] = yk[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    br[i] = splat(yk[i]) + cBR * uv[r][i];
+                    const f2 pr = cUV * uv[r][i];
+                    const float sum = pr.y + pr.x; // (kr(1-kr)*Cr) + (kb(1-kb)*Cb)
+                    // G = Y - (2*sum)/kg with 2/kg in verified reciprocal form
+                    g[i] = yk[i] - __builtin_fmaf(sum, A.rcpKgTimes2.hi, sum * A.rcpKgTimes2.lo);
+                }
+            }
+
+            unsigned av[4] = { 0, 0, 0, 0 }, a[4];
+            if constexpr (kNeedA)
+                decode4<YT>(raw[k].a[r], av);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = APLANE ? alphaFromPlane(A, av[i]) : A.rgbMax;
+            const uint32_t off = (sy + r) * A.rgbPitch + X * kPixBytes;
+
+            if constexpr (sizeof(RT) == 1 && !HASMUL) {
+                // 8-bit outputs: t = 0.5f + c * 255, then truncate + saturate + pack in one instruction per channel
+                const f2 half = splat(0.5f), mx = splat(A.rgbMaxF);
+                f2 tbr[4];
+                float tg[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    tbr[i] = half + (br[i] * mx);
+                    tg[i] = 0.5f + (g[i] * A.rgbMaxF);
+                }
+                if constexpr (NCH == 4) {
+                    unsigned w[4], aw[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        aw[i] = APLANE ? (a[i] << (8 * A.slotA)) : opaqueWord;
+                    packRgba8Row(w, aw, tbr, tg, A.slotR, A.slotG, A.slotB);
+                    if (laneValid)
+                        storeVec(A.rgb, off, (u4) { w[0], w[1], w[2], w[3] }, nt);
+                } else {
+                    float x[4], z[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        x[i] = swapRB ? tbr[i].x : tbr[i].y;
+                        z[i] = swapRB ? tbr[i].y : tbr[i].x;
+                    }
+                    unsigned w[3];
+                    packRgb8Row(w, x, tg, z);
+                    if (laneValid) {
+                        unsigned * d = reinterpret_cast<unsigned *>(A.rgb + off);
+                        d[0] = w[0], d[1] = w[1], d[2] = w[2];
+                    }
+                }
+            } else {
+                PixelOut q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    q[i] = finishPixel<HASMUL>(A, br[i].y, g[i], br[i].x, av[i], a[i]);
+                if (laneValid)
+                    store4<RT, NCH>(A.rgb, off, q, a, swapRB, alphaFirst, nt);
+            }
         }
     }
 }
 
-template <typename YT, int SUB, bool BILINEAR, typename RT, int NCH, bool HASMUL>
-__global__ __launch_bounds__(256) void yuvToRgbTileKernel(YuvToRgbPlan p)
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+__global__ __launch_bounds__(256) void yuvToRgbTileKernel(TileArgs A)
 {
-    __shared__ __attribute__((aligned(16))) f2 sC[BILINEAR ? kChromaRowsMax : 1][kChromaPitch];
-    runTile<YT, SUB, BILINEAR, RT, NCH, HASMUL>(p, gridDim.x, sC);
+    __shared__ __attribute__((aligned(16))) f2 rows[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
+    runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, rows);
 }
 
-template <typename YT, int SUB, bool BILINEAR, typename RT, int NCH, bool HASMUL>
-__global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const YuvToRgbPlan * __restrict__ table)
+// one launch for a table of jobs (grid z = job); the descriptor is read with scalar loads
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+__global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * __restrict__ table)
 {
-    __shared__ __attribute__((aligned(16))) f2 sC[BILINEAR ? kChromaRowsMax : 1][kChromaPitch];
-    __shared__ YuvToRgbPlan plan;
-    {
-        // one cooperative copy of the job descriptor into LDS keeps it out of per-lane registers
-        const uint32_t * src = reinterpret_cast<const uint32_t *>(&table[blockIdx.z]);
-        uint32_t * dst = reinterpret_cast<uint32_t *>(&plan);
-        const int t = threadIdx.y * kLanesX + threadIdx.x;
-        for (int k = t; k < (int)(sizeof(YuvToRgbPlan) / 4); k += 256)
-            dst[k] = src[k];
-    }
-    __syncthreads();
-    runTile<YT, SUB, BILINEAR, RT, NCH, HASMUL>(plan, gridDim.x, sC);
+    __shared__ __attribute__((aligned(16))) f2 rows[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
+    runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], rows);
 }
 
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool MUL>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool MUL>
 hipError_t launchOne(const TileLaunch & L)
 {
-    const dim3 block(kLanesX, kLanesY);
+    const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(L.blocksPerJob, 1, L.count);
     if (L.table)
-        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, MUL>), grid, block, 0, L.stream, L.table);
+        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table);
+    else if (L.stripsPerWave >= 2)
+        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args);
     else
-        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, MUL>), grid, block, 0, L.stream, *L.plan);
+        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, *L.args);
     return hipGetLastError();
 }
 
-template <typename YT, int SUB, bool BIL>
-hipError_t launchRgbVariant(const TileKey & k, const TileLaunch & L)
+template <typename YT, int SUB, bool BIL, typename RT>
+hipError_t launchAlphaVariant(const TileKey & k, const TileLaunch & L)
 {
-#define AVIFHIP_RGB_CASE(RT, NCH) return k.hasMul ? launchOne<YT, SUB, BIL, RT, NCH, true>(L) : launchOne<YT, SUB, BIL, RT, NCH, false>(L)
-    if (!k.wideRgb) {
-        if (k.nch == 4) {
-            AVIFHIP_RGB_CASE(uint8_t, 4);
-        }
-        AVIFHIP_RGB_CASE(uint8_t, 3);
-    }
-    if (k.nch == 4) {
-        AVIFHIP_RGB_CASE(uint16_t, 4);
-    }
-    AVIFHIP_RGB_CASE(uint16_t, 3);
-#undef AVIFHIP_RGB_CASE
+    if (k.nch == 3)
+        return k.hasMul ? launchOne<YT, SUB, BIL, RT, 3, false, true>(L) : launchOne<YT, SUB, BIL, RT, 3, false, false>(L);
+    if (k.hasMul)
+        return launchOne<YT, SUB, BIL, RT, 4, true, true>(L);
+    return k.alphaPlane ? launchOne<YT, SUB, BIL, RT, 4, true, false>(L) : launchOne<YT, SUB, BIL, RT, 4, false, false>(L);
 }
 
-template <typename YT>
-hipError_t launchYuvVariant(const TileKey & k, const TileLaunch & L)
+template <typename YT, int SUB, bool BIL>
+hipError_t launchSubVariant(const TileKey & k, const TileLaunch & L)
 {
-    switch (k.sub) {
-        case SUB_444: return launchRgbVariant<YT, SUB_444, false>(k, L);
-        case SUB_400: return launchRgbVariant<YT, SUB_400, false>(k, L);
-        case SUB_422: return k.bilinear ? launchRgbVariant<YT, SUB_422, true>(k, L) : launchRgbVariant<YT, SUB_422, false>(k, L);
-        default: return k.bilinear ? launchRgbVariant<YT, SUB_420, true>(k, L) : launchRgbVariant<YT, SUB_420, false>(k, L);
-    }
+    return k.wideRgb ? launchAlphaVariant<YT, SUB, BIL, uint16_t>(k, L) : launchAlphaVariant<YT, SUB, BIL, uint8_t>(k, L);
 }
 
 } // namespace tile

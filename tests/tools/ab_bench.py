@@ -40,10 +40,12 @@ def setup(name):
 
 
 def main():
-    names = sys.argv[1:] or ["cfg2"]
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg2"]
     for name in names:
         dimg, drgb, bpp, px = setup(name)
-        variants = [("default", 1, 1), ("no-bands", 0, 1), ("nt-store", 3, 1), ("generic", 1, 0)]
+        variants = [("default", 1, 1), ("no-bands", 0, 1), ("nt-store", 3, 1), ("ns1", 1 | (1 << 8), 1), ("ns2", 1 | (2 << 8), 1), ("ns4", 1 | (4 << 8), 1)]
+        if "--generic" in sys.argv:
+            variants.append(("generic", 1, 0))
         best = {}
         for rep in range(3):
             for label, tune, tiled in variants:
