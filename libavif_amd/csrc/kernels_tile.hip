@@ -77,20 +77,28 @@ hipError_t launchFamily(const TileKey & k, const TileLaunch & L)
     }
 }
 
-// Work decomposition: a workgroup converts a tile of 256 x (8*NS) pixels, NS = strips per wave in {1, 2}.  Taller
-// tiles amortise the memory latency and the chroma halo rows; shorter ones keep small images spread over the chip.
+// Work decomposition: a workgroup walks down a run of `tilesPerRun` vertically consecutive tiles of 256 x (8*NS) pixels,
+// NS = strips per wave in {1, 2}.  Longer runs hide the memory latency behind the previous tile's arithmetic; taller
+// tiles amortise the chroma halo rows; short runs of small tiles keep small images spread over the whole chip.
 void decompose(uint32_t tuning, uint32_t w4, uint32_t h2, uint32_t jobs, bool batch, TileLaunch * L)
 {
     const uint32_t bands = (w4 + kBandW - 1) / kBandW;
-    uint32_t ns = (tuning >> TUNE_STRIPS_SHIFT) & 0xffu;
-    if (ns == 0) {
-        // keep at least ~8 workgroups per CU in the launch
-        const uint64_t tiles8 = (uint64_t)bands * ((h2 + 7) / 8) * jobs;
-        ns = tiles8 >= 2 * kTargetBlocks ? 2 : 1;
-    }
+    uint32_t ns = (tuning >> TUNE_STRIPS_SHIFT) & 0xfu;
+    const uint64_t tiles8 = (uint64_t)bands * ((h2 + 7) / 8) * jobs;
+    if (ns == 0)
+        ns = tiles8 >= 4 * kTargetBlocks ? 2 : 1;
     ns = (ns >= 2 && !batch) ? 2 : 1; // the batch kernels exist for NS = 1 only: batches are made of small jobs
+    const uint32_t tilesY = (h2 + 8 * ns - 1) / (8 * ns);
+    uint32_t run = (tuning >> TUNE_RUN_SHIFT) & 0xfu;
+    if (run == 0) {
+        // about kTargetBlocks workgroups (8 per CU) in the launch, at most 8 tiles each
+        const uint64_t tiles = (uint64_t)bands * tilesY * jobs;
+        run = (uint32_t)(tiles / kTargetBlocks);
+        run = run < 1 ? 1 : (run > 8 ? 8 : run);
+    }
     L->stripsPerWave = ns;
-    L->blocksPerJob = bands * ((h2 + 8 * ns - 1) / (8 * ns));
+    L->tilesPerRun = run;
+    L->blocksPerJob = bands * ((tilesY + run - 1) / run);
 }
 
 // largest byte offset the kernel forms from a plane base must fit 32 bits

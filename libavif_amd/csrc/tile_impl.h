@@ -182,14 +182,18 @@ __device__ __forceinline__ PixelOut finishPixel(const TileArgs & A, float R, flo
     return q;
 }
 
+// RGB output is written once and never read back by the kernel: non-temporal stores keep 130+ MB of it from
+// displacing the input planes in L2 / Infinity Cache (tests/tools/membw2.hip: 33 -> 26.5 us for cfg2's byte
+// movement when frames stream from HBM).
 template <typename V>
-__device__ __forceinline__ void storeVec(uint8_t * base, uint32_t off, const V & v, bool nontemporal)
+__device__ __forceinline__ void storeVec(uint8_t * base, uint32_t off, const V & v, bool)
 {
     V * dst = reinterpret_cast<V *>(base + off);
-    if (nontemporal)
-        __builtin_nontemporal_store(v, dst);
-    else
-        *dst = v;
+#ifdef AVIFHIP_PLAIN_STORES
+    *dst = v;
+#else
+    __builtin_nontemporal_store(v, dst);
+#endif
 }
 
 // Store 4 consecutive pixels.  swapRB: B is the first colour channel; alphaFirst: A precedes colour.
@@ -210,10 +214,9 @@ __device__ __forceinline__ void store4(uint8_t * base, uint32_t off, const Pixel
         storeVec(base, off, w, nt);
     } else if constexpr (sizeof(RT) == 1 && NCH == 3) {
         // 12 bytes: x0 g0 z0 x1 | g1 z1 x2 g2 | z2 x3 g3 z3 (rows and pixel groups are 4-byte aligned)
-        unsigned * d = reinterpret_cast<unsigned *>(base + off);
-        d[0] = x[0] | (q[0].g << 8) | (z[0] << 16) | (x[1] << 24);
-        d[1] = q[1].g | (z[1] << 8) | (x[2] << 16) | (q[2].g << 24);
-        d[2] = z[2] | (x[3] << 8) | (q[3].g << 16) | (z[3] << 24);
+        storeVec(base, off, x[0] | (q[0].g << 8) | (z[0] << 16) | (x[1] << 24), nt);
+        storeVec(base, off + 4, q[1].g | (z[1] << 8) | (x[2] << 16) | (q[2].g << 24), nt);
+        storeVec(base, off + 8, z[2] | (x[3] << 8) | (q[3].g << 16) | (z[3] << 24), nt);
     } else if constexpr (sizeof(RT) == 2 && NCH == 4) {
         u4 w0, w1;
 #pragma unroll
@@ -231,10 +234,9 @@ __device__ __forceinline__ void store4(uint8_t * base, uint32_t off, const Pixel
         storeVec(base, off, w0, nt);
         storeVec(base, off + 16, w1, nt);
     } else { // 16-bit, 3 channels: 24 bytes = 3 x 8
-        u2 * d = reinterpret_cast<u2 *>(base + off);
-        d[0] = (u2) { x[0] | (q[0].g << 16), z[0] | (x[1] << 16) };
-        d[1] = (u2) { q[1].g | (z[1] << 16), x[2] | (q[2].g << 16) };
-        d[2] = (u2) { z[2] | (x[3] << 16), q[3].g | (z[3] << 16) };
+        storeVec(base, off, (u2) { x[0] | (q[0].g << 16), z[0] | (x[1] << 16) }, nt);
+        storeVec(base, off + 8, (u2) { q[1].g | (z[1] << 16), x[2] | (q[2].g << 16) }, nt);
+        storeVec(base, off + 16, (u2) { z[2] | (x[3] << 16), q[3].g | (z[3] << 16) }, nt);
     }
 }
 
@@ -310,37 +312,36 @@ struct StripRaw
     Raw4<YT> v[kOwnChroma ? 2 : 1];
 };
 
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
-__device__ __forceinline__ void runBlock(const TileArgs & A, f2 (*rows)[kRowPitch])
+// Raw (undecoded) data of one tile as loaded by one lane: its share of the chroma neighbourhood to stage, and the
+// luma / alpha / co-sited chroma of its own strips.  Lives in registers while the previous tile is computed.
+template <typename YT, int SUB, bool BIL, bool NEEDA, int NS>
+struct TileRaw
 {
-    constexpr int kTileH = 8 * NS;
-    constexpr bool kWide = sizeof(YT) == 2;
-    constexpr bool kNeedA = APLANE || HASMUL;
-    constexpr uint32_t BPS = sizeof(YT);
-    constexpr uint32_t kPixBytes = NCH * sizeof(RT);
-    const int tx = threadIdx.x, wv = threadIdx.y;
-    const uint32_t tilesX = (A.w4 + kBandW - 1) / kBandW;
-    const uint32_t tilesY = (A.h2 + kTileH - 1) / kTileH;
-    const uint32_t nTiles = tilesX * tilesY;
-    const uint32_t tile = blockRemap(blockIdx.x, gridDim.x, (A.tuning & TUNE_XCD_BANDS) != 0 && (gridDim.z == 1 || (gridDim.x & 7) == 0));
-    if (tile >= nTiles)
-        return;
-    const uint32_t trow = tile / tilesX;
-    const uint32_t bandX = (tile - trow * tilesX) * kBandW;
-    const uint32_t tileY = trow * kTileH;
-    const uint32_t X = bandX + 4 * tx;
-    const bool laneValid = X < A.w4;       // w4 is a multiple of 4: groups are whole or absent
-    const uint32_t Xc = laneValid ? X : 0; // absent lanes load (and discard) the row's first group
-    const bool nt = (A.tuning & TUNE_NONTEMPORAL) != 0;
-    const unsigned yuvMax = A.yuvMax;
+    Raw4<YT> su[BIL ? StageRows<SUB, NS>::kRounds : 1], sv[BIL ? StageRows<SUB, NS>::kRounds : 1];
+    StripRaw<YT, SUB, BIL, NEEDA> raw[NS];
+};
 
-    // ---- bilinear: the tile's chroma neighbourhood, loads first (they head the longest dependency chain) ----
+// Per-lane constants of the band a workgroup walks down.
+struct BandCtx
+{
+    uint32_t X;     // first pixel column of this lane, relative to the rectangle
+    uint32_t Xc;    // ... clamped into the rectangle for loads
+    bool laneValid; // the lane's 4-pixel group exists (w4 is a multiple of 4: groups are whole or absent)
+    int cxb;        // canvas chroma column of the band's first sample
+};
+
+// issue every load of the tile whose first luma row (relative to the rectangle) is tileY
+template <typename YT, int SUB, bool BIL, bool NEEDA, int NS>
+__device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, uint32_t tileY, TileRaw<YT, SUB, BIL, NEEDA, NS> & T)
+{
+    constexpr bool kWide = sizeof(YT) == 2;
+    constexpr uint32_t BPS = sizeof(YT);
     typedef StageRows<SUB, NS> SR;
-    const int cxb = A.cx0 + (int)(bandX >> 1); // chroma column of the band's first sample
-    // canvas chroma row held by LDS row 0
-    const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)(tileY >> 1) - 1 : A.cy0 + (int)tileY;
-    Raw4<YT> su[BIL ? SR::kRounds : 1], sv[BIL ? SR::kRounds : 1];
+    const int tx = threadIdx.x, wv = threadIdx.y;
+    // ---- bilinear: this lane's share of the tile's chroma neighbourhood (first: it heads the longest chain) ----
     if constexpr (BIL) {
+        // canvas chroma row held by LDS row 0
+        const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)(tileY >> 1) - 1 : A.cy0 + (int)tileY;
         const int t = wv * kLanesX + tx;
 #pragma unroll
         for (int j = 0; j < SR::kRounds; ++j) {
@@ -350,83 +351,98 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, f2 (*rows)[kRowPitc
                 // neighbour of an edge sample is the sample itself
                 const int row = task / kStageGroups, grp = task - row * kStageGroups;
                 const int cy = clampI(rowBase + row, 0, A.ch - 1);
-                const int cxa = cxb - 4 + 4 * grp;
+                const int cxa = c.cxb - 4 + 4 * grp;
                 if (cxa >= 0 && cxa + 3 < A.cw) {
-                    su[j] = load4<YT>(A.u, (uint32_t)cy * A.uPitch + (uint32_t)cxa * BPS);
-                    sv[j] = load4<YT>(A.v, (uint32_t)cy * A.vPitch + (uint32_t)cxa * BPS);
+                    T.su[j] = load4<YT>(A.u, (uint32_t)cy * A.uPitch + (uint32_t)cxa * BPS);
+                    T.sv[j] = load4<YT>(A.v, (uint32_t)cy * A.vPitch + (uint32_t)cxa * BPS);
                 } else {
                     // group cut by the left or right border of the canvas
-                    su[j].w[0] = sv[j].w[0] = 0;
+                    T.su[j].w[0] = T.sv[j].w[0] = 0;
                     if constexpr (kWide)
-                        su[j].w[1] = sv[j].w[1] = 0;
+                        T.su[j].w[1] = T.sv[j].w[1] = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const uint32_t cx = (uint32_t)clampI(cxa + k, 0, A.cw - 1);
                         const unsigned u = load1<YT>(A.u, (uint32_t)cy * A.uPitch + cx * BPS);
                         const unsigned v = load1<YT>(A.v, (uint32_t)cy * A.vPitch + cx * BPS);
                         if constexpr (!kWide) {
-                            su[j].w[0] |= u << (8 * k);
-                            sv[j].w[0] |= v << (8 * k);
+                            T.su[j].w[0] |= u << (8 * k);
+                            T.sv[j].w[0] |= v << (8 * k);
                         } else {
-                            su[j].w[k >> 1] |= u << (16 * (k & 1));
-                            sv[j].w[k >> 1] |= v << (16 * (k & 1));
+                            T.su[j].w[k >> 1] |= u << (16 * (k & 1));
+                            T.sv[j].w[k >> 1] |= v << (16 * (k & 1));
                         }
                     }
                 }
             }
         }
     }
-
     // ---- this wave's luma / alpha / co-sited chroma for all of its strips ----
-    StripRaw<YT, SUB, BIL, kNeedA> raw[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const uint32_t sy = tileY + 2 * (wv * NS + k);
         const uint32_t syc = sy < A.h2 ? sy : 0; // absent strips load (and discard) the first one
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            raw[k].y[r] = load4<YT>(A.y, (syc + r) * A.yPitch + Xc * BPS);
-            if constexpr (kNeedA)
-                raw[k].a[r] = load4<YT>(A.a, (syc + r) * A.aPitch + Xc * BPS);
+            T.raw[k].y[r] = load4<YT>(A.y, (syc + r) * A.yPitch + c.Xc * BPS);
+            if constexpr (NEEDA)
+                T.raw[k].a[r] = load4<YT>(A.a, (syc + r) * A.aPitch + c.Xc * BPS);
             if constexpr (SUB == SUB_444) {
-                raw[k].u[r] = load4<YT>(A.u, ((uint32_t)A.cy0 + syc + r) * A.uPitch + ((uint32_t)A.cx0 + Xc) * BPS);
-                raw[k].v[r] = load4<YT>(A.v, ((uint32_t)A.cy0 + syc + r) * A.vPitch + ((uint32_t)A.cx0 + Xc) * BPS);
+                T.raw[k].u[r] = load4<YT>(A.u, ((uint32_t)A.cy0 + syc + r) * A.uPitch + ((uint32_t)A.cx0 + c.Xc) * BPS);
+                T.raw[k].v[r] = load4<YT>(A.v, ((uint32_t)A.cy0 + syc + r) * A.vPitch + ((uint32_t)A.cx0 + c.Xc) * BPS);
             } else if constexpr ((SUB == SUB_420 || SUB == SUB_422) && !BIL) {
                 // nearest: chroma samples (X>>1, X>>1 + 1) of chroma row (j >> shiftY); one aligned pair load per plane
                 if (!(SUB == SUB_420 && r == 1)) {
                     const uint32_t cy = (uint32_t)A.cy0 + ((SUB == SUB_420) ? (syc >> 1) : (syc + r));
-                    const uint32_t cx = (uint32_t)A.cx0 + (Xc >> 1);
+                    const uint32_t cx = (uint32_t)A.cx0 + (c.Xc >> 1);
                     if constexpr (!kWide) {
-                        raw[k].u[r].w[0] = *reinterpret_cast<const uint16_t *>(A.u + (cy * A.uPitch + cx));
-                        raw[k].v[r].w[0] = *reinterpret_cast<const uint16_t *>(A.v + (cy * A.vPitch + cx));
+                        T.raw[k].u[r].w[0] = *reinterpret_cast<const uint16_t *>(A.u + (cy * A.uPitch + cx));
+                        T.raw[k].v[r].w[0] = *reinterpret_cast<const uint16_t *>(A.v + (cy * A.vPitch + cx * 1));
                     } else {
-                        raw[k].u[r].w[0] = *reinterpret_cast<const uint32_t *>(A.u + (cy * A.uPitch + cx * 2));
-                        raw[k].v[r].w[0] = *reinterpret_cast<const uint32_t *>(A.v + (cy * A.vPitch + cx * 2));
+                        T.raw[k].u[r].w[0] = *reinterpret_cast<const uint32_t *>(A.u + (cy * A.uPitch + cx * 2));
+                        T.raw[k].v[r].w[0] = *reinterpret_cast<const uint32_t *>(A.v + (cy * A.vPitch + cx * 2));
                     }
                 }
             }
         }
     }
+}
 
-    if constexpr (BIL) {
-        const int t = wv * kLanesX + tx;
+// bilinear: normalise this lane's share of the chroma neighbourhood and put it into LDS
+template <typename YT, int SUB, bool NEEDA, int NS>
+__device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, SUB, true, NEEDA, NS> & T, f2 (*rows)[kRowPitch])
+{
+    typedef StageRows<SUB, NS> SR;
+    const int t = threadIdx.y * kLanesX + threadIdx.x;
 #pragma unroll
-        for (int j = 0; j < SR::kRounds; ++j) {
-            const int task = t + 256 * j;
-            if (task < SR::kTasks) {
-                const int row = task / kStageGroups, grp = task - row * kStageGroups;
-                float fu[4], fv[4];
-                samples4<YT>(su[j], yuvMax, fu);
-                samples4<YT>(sv[j], yuvMax, fv);
-                f2 * dst = &rows[row][4 * grp + 1];
+    for (int j = 0; j < SR::kRounds; ++j) {
+        const int task = t + 256 * j;
+        if (task < SR::kTasks) {
+            const int row = task / kStageGroups, grp = task - row * kStageGroups;
+            float fu[4], fv[4];
+            samples4<YT>(T.su[j], A.yuvMax, fu);
+            samples4<YT>(T.sv[j], A.yuvMax, fv);
+            f2 * dst = &rows[row][4 * grp + 1];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    dst[k] = norm2((f2) { fu[k], fv[k] }, A.biasUV, A.rcpRangeUV);
-            }
+            for (int k = 0; k < 4; ++k)
+                dst[k] = norm2((f2) { fu[k], fv[k] }, A.biasUV, A.rcpRangeUV);
         }
-        __syncthreads();
     }
+}
 
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+__device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & c, uint32_t tileY,
+                                            const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS> & T, f2 (*rows)[kRowPitch])
+{
+    constexpr bool kWide = sizeof(YT) == 2;
+    constexpr bool kNeedA = APLANE || HASMUL;
+    constexpr uint32_t kPixBytes = NCH * sizeof(RT);
+    const int tx = threadIdx.x, wv = threadIdx.y;
+    const bool nt = (A.tuning & TUNE_NONTEMPORAL) != 0;
+    const unsigned yuvMax = A.yuvMax;
+    const uint32_t X = c.X;
+    const bool laneValid = c.laneValid;
+    const StripRaw<YT, SUB, BIL, kNeedA> * raw = T.raw;
     const bool swapRB = A.slotB < A.slotR;
     const bool alphaFirst = (NCH == 4) && (A.slotA == 0);
     const f2 cBR = { A.cB, A.cR }; // (Cb,Cr) -> (B - Y, R - Y), src/reformat.c:874-875
@@ -585,8 +601,9 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, f2 (*rows)[kRowPitc
                     unsigned w[3];
                     packRgb8Row(w, x, tg, z);
                     if (laneValid) {
-                        unsigned * d = reinterpret_cast<unsigned *>(A.rgb + off);
-                        d[0] = w[0], d[1] = w[1], d[2] = w[2];
+                        storeVec(A.rgb, off, w[0], nt);
+                        storeVec(A.rgb, off + 4, w[1], nt);
+                        storeVec(A.rgb, off + 8, w[2], nt);
                     }
                 }
             } else {
@@ -601,19 +618,68 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, f2 (*rows)[kRowPitc
     }
 }
 
+
+// One workgroup walks down `tilesPerRun` vertically consecutive tiles (256 x 8*NS pixels each) of one band.  The loads
+// of tile i+1 are in flight while tile i is computed and stored, so a wave waits for memory once per run, not once
+// per tile; vertically consecutive tiles also re-read their shared chroma halo rows from the nearest cache.
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
-__global__ __launch_bounds__(256) void yuvToRgbTileKernel(TileArgs A)
+__device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRun, f2 (*rows)[kRowPitch])
+{
+    constexpr int kTileH = 8 * NS;
+    constexpr bool kNeedA = APLANE || HASMUL;
+    const uint32_t bands = (A.w4 + kBandW - 1) / kBandW;
+    const uint32_t tilesY = (A.h2 + kTileH - 1) / kTileH;
+    const uint32_t runsY = (tilesY + tilesPerRun - 1) / tilesPerRun;
+    const uint32_t nRuns = bands * runsY;
+    const uint32_t run = blockRemap(blockIdx.x, gridDim.x, (A.tuning & TUNE_XCD_BANDS) != 0 && (gridDim.z == 1 || (gridDim.x & 7) == 0));
+    if (run >= nRuns)
+        return;
+    const uint32_t rrow = run / bands;
+    const uint32_t bandX = (run - rrow * bands) * kBandW;
+    const uint32_t firstTile = rrow * tilesPerRun;
+    const uint32_t nTiles = (tilesY - firstTile < tilesPerRun) ? (tilesY - firstTile) : tilesPerRun;
+
+    BandCtx c;
+    c.X = bandX + 4 * threadIdx.x;
+    c.laneValid = c.X < A.w4;
+    c.Xc = c.laneValid ? c.X : 0; // absent lanes load (and discard) the row's first group
+    c.cxb = A.cx0 + (int)(bandX >> 1);
+
+    TileRaw<YT, SUB, BIL, kNeedA, NS> cur;
+    uint32_t tileY = firstTile * kTileH;
+    loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY, cur);
+    for (uint32_t i = 0; i < nTiles; ++i) {
+        if constexpr (BIL) {
+            stageTile<YT, SUB, kNeedA, NS>(A, cur, rows);
+            __syncthreads();
+        }
+        const bool more = i + 1 < nTiles;
+        TileRaw<YT, SUB, BIL, kNeedA, NS> nxt;
+        if (more)
+            loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY + kTileH, nxt);
+        computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, c, tileY, cur, rows);
+        if (!more)
+            break;
+        if constexpr (BIL)
+            __syncthreads(); // every wave is done reading the LDS rows before the next tile overwrites them
+        cur = nxt;
+        tileY += kTileH;
+    }
+}
+
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+__global__ __launch_bounds__(256) void yuvToRgbTileKernel(TileArgs A, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
-    runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, rows);
+    runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, tilesPerRun, rows);
 }
 
 // one launch for a table of jobs (grid z = job); the descriptor is read with scalar loads
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
-__global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * __restrict__ table)
+__global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
-    runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], rows);
+    runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows);
 }
 
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool MUL>
@@ -622,11 +688,11 @@ hipError_t launchOne(const TileLaunch & L)
     const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(L.blocksPerJob, 1, L.count);
     if (L.table)
-        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table);
+        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
     else if (L.stripsPerWave >= 2)
-        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args);
+        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
     else
-        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, *L.args);
+        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
     return hipGetLastError();
 }
 

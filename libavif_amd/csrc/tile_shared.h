@@ -90,8 +90,9 @@ struct TileLaunch
     const TileArgs * args;  // single job (kernarg) ...
     const TileArgs * table; // ... or device table of `count` jobs
     uint32_t count;
-    uint32_t blocksPerJob;  // workgroups covering the largest job: one per 256 x (8 * stripsPerWave) tile
-    uint32_t stripsPerWave; // 1, 2 or 4 vertically consecutive 256x2 strips per wave
+    uint32_t blocksPerJob;  // workgroups covering the largest job: one per run of tiles
+    uint32_t stripsPerWave; // NS: 1 or 2 vertically consecutive 256x2 strips per wave (tile = 256 x 8*NS pixels)
+    uint32_t tilesPerRun;   // vertically consecutive tiles one workgroup walks through (software-pipelined)
     hipStream_t stream;
 };
 

@@ -43,7 +43,8 @@ def main():
     names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg2"]
     for name in names:
         dimg, drgb, bpp, px = setup(name)
-        variants = [("default", 1, 1), ("no-bands", 0, 1), ("nt-store", 3, 1), ("ns1", 1 | (1 << 8), 1), ("ns2", 1 | (2 << 8), 1), ("ns4", 1 | (4 << 8), 1)]
+        variants = [("default", 1, 1), ("no-bands", 0, 1), ("ns1", 1 | (1 << 8), 1), ("ns2", 1 | (2 << 8), 1), ("ns2-run2", 1 | (2 << 8) | (2 << 12), 1),
+                    ("ns1-run4", 1 | (1 << 8) | (4 << 12), 1)]
         if "--generic" in sys.argv:
             variants.append(("generic", 1, 0))
         best = {}

@@ -57,10 +57,12 @@ int main(int argc, char ** argv)
         if (makeYuvToRgbPlan(&img, &rgb, nullptr, 1, tuning, &plans[k]) != AVIF_RESULT_OK) { printf("plan failed\n"); return 1; }
     }
     const dim3 block(kLanesX, kWavesPerBlock);
-    const dim3 grid(((W + 255) / 256) * ((H + 8 * KB_NS - 1) / (8 * KB_NS)));
+    const uint32_t run = argc > 3 ? (uint32_t)atoi(argv[3]) : 4;
+    const uint32_t tilesY = (H + 8 * KB_NS - 1) / (8 * KB_NS);
+    const dim3 grid(((W + 255) / 256) * ((tilesY + run - 1) / run));
     TileArgs args[NB];
     for (int k = 0; k < NB; ++k) args[k] = distillArgs(plans[k]);
-    auto launch = [&](int k) { hipLaunchKernelGGL((yuvToRgbTileKernel<uint8_t, SUB_420, KB_BIL, uint8_t, 4, false, false, KB_NS>), grid, block, 0, 0, args[k]); };
+    auto launch = [&](int k) { hipLaunchKernelGGL((yuvToRgbTileKernel<uint8_t, SUB_420, KB_BIL, uint8_t, 4, false, false, KB_NS>), grid, block, 0, 0, args[k], run); };
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float best[2] = { 1e9f, 1e9f };
     for (int mode = 0; mode < 2; ++mode)
