@@ -112,6 +112,10 @@ AVIFHIP_API void avifhipSetTuning(uint32_t bits);
 AVIFHIP_API avifResult avifhipSetDevice(int device);
 /* Number of visible HIP devices; 0 when no GPU / no driver. */
 AVIFHIP_API int avifhipDeviceCount(void);
+/* Extra HIP streams (returned as void*, usable as the `hipStream` argument of the Async entry points) so that
+ * independent frames / tiles can overlap each other's head and tail; NULL on failure. */
+AVIFHIP_API void * avifhipStreamCreate(void);
+AVIFHIP_API void avifhipStreamDestroy(void * hipStream);
 /* Blocks until the calling thread's library stream (or `hipStream`) is idle. */
 AVIFHIP_API avifResult avifhipSynchronize(void * hipStream);
 /* Text of the last HIP/runtime failure on this thread ("" if none). */
@@ -133,6 +137,9 @@ AVIFHIP_API avifResult avifhipDeviceMemset(void * devicePtr, int value, size_t b
  * avifhipImageYUVToRGBAsync launches after `warmup` untimed ones, or a negative value on error. */
 AVIFHIP_API double avifhipTimeYUVToRGB(const avifImage * image, avifRGBImage * rgb, int warmup, int iters, void * hipStream);
 AVIFHIP_API double avifhipTimeRGBToYUV(avifImage * image, const avifRGBImage * rgb, int warmup, int iters, void * hipStream);
+/* Same for launches that cycle over `count` distinct device-resident frames (launch k converts frame k % count), so
+ * that a working set larger than the Infinity Cache makes every launch stream from and to HBM. */
+AVIFHIP_API double avifhipTimeYUVToRGBCycle(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
 
 /* Synthetic planes for benchmarks/tests: xorshift32 stream
  * (x^=x<<13; x^=x>>17; x^=x<<5), one draw per sample, value = lo + draw % (hi-lo+1), written

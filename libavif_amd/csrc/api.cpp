@@ -745,6 +745,24 @@ extern "C" avifResult avifhipSetDevice(int device)
     return AVIF_RESULT_OK;
 }
 
+extern "C" void * avifhipStreamCreate(void)
+{
+    if (ensureContext() != AVIF_RESULT_OK)
+        return nullptr;
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        hipFailed(e, "hipStreamCreateWithFlags");
+        return nullptr;
+    }
+    return (void *)s;
+}
+extern "C" void avifhipStreamDestroy(void * hipStream)
+{
+    if (hipStream)
+        (void)hipStreamDestroy((hipStream_t)hipStream);
+}
+
 extern "C" avifResult avifhipSynchronize(void * hipStream)
 {
     const avifResult cr = ensureContext();
@@ -814,6 +832,30 @@ extern "C" double avifhipTimeYUVToRGB(const avifImage * image, avifRGBImage * rg
     (void)hipEventRecord(t0, stream);
     for (int k = 0; k < iters; ++k)
         if (avifhipImageYUVToRGBAsync(image, rgb, stream) != AVIF_RESULT_OK)
+            return -1.0;
+    (void)hipEventRecord(t1, stream);
+    float ms = -1.0f;
+    if (hipEventSynchronize(t1) != hipSuccess || hipEventElapsedTime(&ms, t0, t1) != hipSuccess)
+        ms = -1.0f;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return ms < 0 ? -1.0 : (double)ms / iters;
+}
+
+extern "C" double avifhipTimeYUVToRGBCycle(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream)
+{
+    if (iters <= 0 || count == 0 || !images || !rgbs || ensureContext() != AVIF_RESULT_OK)
+        return -1.0;
+    hipStream_t stream = pickStream(hipStream);
+    for (int k = 0; k < warmup; ++k)
+        if (avifhipImageYUVToRGBAsync(images[k % count], rgbs[k % count], stream) != AVIF_RESULT_OK)
+            return -1.0;
+    hipEvent_t t0, t1;
+    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess)
+        return -1.0;
+    (void)hipEventRecord(t0, stream);
+    for (int k = 0; k < iters; ++k)
+        if (avifhipImageYUVToRGBAsync(images[k % count], rgbs[k % count], stream) != AVIF_RESULT_OK)
             return -1.0;
     (void)hipEventRecord(t1, stream);
     float ms = -1.0f;

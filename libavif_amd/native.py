@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
-    "avifhipSynthFill",
+    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle",
 ]
 
 _lib = None
@@ -77,6 +77,10 @@ def load() -> C.CDLL:
         "avifhipTimeYUVToRGB": (C.c_double, [P_IMG, P_RGB, i32, i32, vp]),
         "avifhipTimeRGBToYUV": (C.c_double, [P_IMG, P_RGB, i32, i32, vp]),
         "avifhipSynthFill": (u32, [u32, vp, u32, u32, u32, u32, u32, u32]),
+        "avifhipStreamCreate": (vp, []),
+        "avifhipStreamDestroy": (None, [vp]),
+        "avifhipSetTuning": (None, [u32]),
+        "avifhipTimeYUVToRGBCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

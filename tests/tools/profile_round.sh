@@ -1,0 +1,24 @@
+#!/bin/bash
+# profile_round.sh <tag> -- run on the GPU box (via gpurun): collects for `python bench.py` (the bench command itself)
+#   1. rocprofv3 --kernel-trace --stats        -> per-kernel durations
+#   2. rocprofv3 --pmc FETCH_SIZE ...          -> HBM read traffic   (own pass, no trace domains besides kernel-trace)
+#   3. rocprofv3 --pmc WRITE_SIZE ...          -> HBM write traffic
+#   4. rocprofv3 --pmc SQ_* (two passes)       -> instruction mix / stall picture of the dominant kernel
+# and writes gpurun_out/<tag>/*.db plus gpurun_out/<tag>/bench.json.  tests/tools/profile_digest.py turns the
+# databases into the text/JSON summaries committed under profiles/.
+set -u
+TAG=${1:-r01}
+R=$PWD
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 2000 --warmup 200 --streams 1 --no-cpu-baseline"
+SHORT="python $R/bench.py --steps 300 --warmup 100 --streams 1 --no-cpu-baseline"   # counter passes: smaller databases
+$BENCH > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/stats.log"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- $SHORT > /dev/null 2> "$OUT/pmc_fetch.log"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o write -- $SHORT > /dev/null 2> "$OUT/pmc_write.log"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d "$OUT/pmc_sq1" -o sq1 -- $SHORT > /dev/null 2> "$OUT/pmc_sq1.log"
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA -d "$OUT/pmc_sq2" -o sq2 -- $SHORT > /dev/null 2> "$OUT/pmc_sq2.log"
+ls -R "$OUT" | head -40
+cat "$OUT/bench_plain.json"
