@@ -48,6 +48,16 @@ AVIFHIP_API avifResult avifhipImageRGBToYUV(avifImage * image, const avifRGBImag
 AVIFHIP_API avifResult avifhipRGBImagePremultiplyAlpha(avifRGBImage * rgb);
 AVIFHIP_API avifResult avifhipRGBImageUnpremultiplyAlpha(avifRGBImage * rgb);
 
+/* ---- libavif's accelerated-backend hooks (seam B, include/avif/internal.h:349-386) ---------------- */
+
+/* The job libavif's avifImageYUVToRGBImpl hands to avifImageYUVToRGBLibYUV (src/reformat.c:1453-1461,
+ * src/reformat_libyuv.c:932-1108): colour conversion WITHOUT alpha (un)multiply and without the half-float pass (the
+ * caller runs those afterwards through the hooks below); the alpha channel is written (from the alpha plane, or
+ * opaque) only when reformatAlpha is set. */
+AVIFHIP_API avifResult avifhipImageYUVToRGBColorOnly(const avifImage * image, avifRGBImage * rgb, avifBool reformatAlpha);
+/* Replaces avifRGBImageToF16 / avifRGBImageToF16LibYUV (src/reformat.c:1419-1443): in-place uint16 -> IEEE half. */
+AVIFHIP_API avifResult avifhipRGBImageToF16(avifRGBImage * rgb);
+
 /* ---- device-resident / asynchronous variants ------------------------------------------------- */
 
 /* Same conversions with every buffer already in device memory, enqueued on `hipStream`
@@ -123,6 +133,8 @@ AVIFHIP_API const char * avifhipLastError(void);
 /* Which kernel family served the last conversion on this thread (diagnostics/tests):
  * e.g. "yuv2rgb_tile<u8,420,bilinear,rgba8>" or "yuv2rgb_generic". */
 AVIFHIP_API const char * avifhipLastKernel(void);
+/* Number of conversions this thread has enqueued on a GPU so far (tests: proves the HIP path, not a fallback, ran). */
+AVIFHIP_API uint64_t avifhipLaunchCount(void);
 AVIFHIP_API const char * avifhipVersion(void);
 
 /* Plain device-memory helpers so C callers (and the ctypes tests) need no HIP headers. */

@@ -43,6 +43,7 @@ struct Context
     hipEvent_t tableCopied = nullptr;
     char lastError[512] = { 0 };
     const char * lastKernel = "";
+    uint64_t launches = 0; // kernels enqueued by this thread
 
     ~Context()
     {
@@ -161,6 +162,7 @@ avifResult enqueueYuvToRgb(const YuvToRgbPlan & plan, hipStream_t stream)
     }
     if (e != hipSuccess)
         return hipFailed(e, "YUV->RGB kernel launch");
+    ++tls.launches;
     return AVIF_RESULT_OK;
 }
 
@@ -175,6 +177,7 @@ avifResult enqueueRgbToYuv(const RgbToYuvPlan & plan, hipStream_t stream)
     }
     if (e != hipSuccess)
         return hipFailed(e, "RGB->YUV kernel launch");
+    ++tls.launches;
     return AVIF_RESULT_OK;
 }
 
@@ -184,6 +187,7 @@ avifResult enqueueAlphaMul(const AlphaMulPlan & plan, hipStream_t stream)
     const hipError_t e = launchAlphaMulGeneric(plan, stream);
     if (e != hipSuccess)
         return hipFailed(e, "alpha multiply kernel launch");
+    ++tls.launches;
     return AVIF_RESULT_OK;
 }
 
@@ -349,14 +353,14 @@ extern "C" avifResult avifhipImageYUVToRGBAsync(const avifImage * image, avifRGB
     return avifhipImageYUVToRGBRectAsync(image, rgb, nullptr, hipStream);
 }
 
-extern "C" avifResult avifhipImageYUVToRGB(const avifImage * image, avifRGBImage * rgb)
+static avifResult yuvToRgbSync(const avifImage * image, avifRGBImage * rgb, bool colorOnly, bool reformatAlpha)
 {
     if (!image || !rgb)
         return AVIF_RESULT_INVALID_ARGUMENT;
     // Validate exactly like the reference before touching the device (error-code matrix,
     // tests/gtest/avif_fuzztest_yuvrgb.cc:36-46).
     YuvToRgbPlan probe;
-    const avifResult pr = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &probe);
+    const avifResult pr = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &probe, colorOnly, reformatAlpha);
     if (pr != AVIF_RESULT_OK)
         return pr;
     if (!rgb->pixels) {
@@ -382,7 +386,7 @@ extern "C" avifResult avifhipImageYUVToRGB(const avifImage * image, avifRGBImage
             return r;
     }
     YuvToRgbPlan plan;
-    r = makeYuvToRgbPlan(&imageView, &rgbView, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan);
+    r = makeYuvToRgbPlan(&imageView, &rgbView, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan, colorOnly, reformatAlpha);
     if (r != AVIF_RESULT_OK)
         return r;
     r = enqueueYuvToRgb(plan, tls.stream);
@@ -394,6 +398,16 @@ extern "C" avifResult avifhipImageYUVToRGB(const avifImage * image, avifRGBImage
     }
     HIP_TRY(hipStreamSynchronize(tls.stream));
     return AVIF_RESULT_OK;
+}
+
+extern "C" avifResult avifhipImageYUVToRGB(const avifImage * image, avifRGBImage * rgb)
+{
+    return yuvToRgbSync(image, rgb, false, false);
+}
+
+extern "C" avifResult avifhipImageYUVToRGBColorOnly(const avifImage * image, avifRGBImage * rgb, avifBool reformatAlpha)
+{
+    return yuvToRgbSync(image, rgb, true, reformatAlpha != AVIF_FALSE);
 }
 
 extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
@@ -483,6 +497,7 @@ extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
     }
     if (e != hipSuccess)
         return hipFailed(e, "YUV->RGB batch kernel launch");
+    ++tls.launches;
     return AVIF_RESULT_OK;
 }
 
@@ -623,6 +638,36 @@ static avifResult alphaMulSync(avifRGBImage * rgb, bool unmultiply)
         const uint32_t widthBytes = rgb->width * rgbPixelBytes(rgb);
         HIP_TRY(hipMemcpy2DAsync(rgb->pixels, rgb->rowBytes, view.pixels, view.rowBytes, widthBytes, rgb->height, hipMemcpyDeviceToHost, tls.stream));
     }
+    HIP_TRY(hipStreamSynchronize(tls.stream));
+    return AVIF_RESULT_OK;
+}
+
+// in-place integer -> half float, src/reformat.c:1419-1443
+extern "C" avifResult avifhipRGBImageToF16(avifRGBImage * rgb)
+{
+    if (!rgb)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if (!rgb->isFloat || rgb->depth != 16 || !rgb->pixels || !rgb->rowBytes || rgb->format == AVIF_RGB_FORMAT_RGB_565)
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    avifResult r = ensureContext();
+    if (r != AVIF_RESULT_OK)
+        return r;
+    avifRGBImage view = *rgb;
+    const bool onHost = !isDevicePointer(rgb->pixels);
+    if (onHost) {
+        r = stagePixels(&view, /*upload=*/true);
+        if (r != AVIF_RESULT_OK)
+            return r;
+    }
+    const uint32_t channels = (uint32_t)rgbFormatChannelCount((int)rgb->format);
+    const float multiplier = 1.9259299444e-34f * (1.0f / 65535.0f); // src/reformat.c:1411,1429-1430
+    tls.lastKernel = "to_f16_generic";
+    const hipError_t e = launchToF16Generic(view.pixels, view.rowBytes, view.width * channels, view.height, multiplier, tls.stream);
+    if (e != hipSuccess)
+        return hipFailed(e, "half-float kernel launch");
+    ++tls.launches;
+    if (onHost)
+        HIP_TRY(hipMemcpy2DAsync(rgb->pixels, rgb->rowBytes, view.pixels, view.rowBytes, (size_t)rgb->width * channels * 2, rgb->height, hipMemcpyDeviceToHost, tls.stream));
     HIP_TRY(hipStreamSynchronize(tls.stream));
     return AVIF_RESULT_OK;
 }
@@ -779,6 +824,10 @@ extern "C" const char * avifhipLastError(void)
 extern "C" const char * avifhipLastKernel(void)
 {
     return tls.lastKernel;
+}
+extern "C" uint64_t avifhipLaunchCount(void)
+{
+    return tls.launches;
 }
 extern "C" const char * avifhipVersion(void)
 {

@@ -12,6 +12,8 @@ hipError_t launchYuvToRgbGeneric(const YuvToRgbPlan & plan, hipStream_t stream);
 hipError_t launchYuvToRgbGenericBatch(const YuvToRgbPlan * deviceTable, uint32_t count, uint32_t maxW, uint32_t maxH, hipStream_t stream);
 hipError_t launchRgbToYuvGeneric(const RgbToYuvPlan & plan, hipStream_t stream);
 hipError_t launchAlphaMulGeneric(const AlphaMulPlan & plan, hipStream_t stream);
+// in-place uint16 -> IEEE half over rows of `samplesPerRow` samples, src/reformat.c:1419-1443
+hipError_t launchToF16Generic(uint8_t * pixels, uint32_t rowBytes, uint32_t samplesPerRow, uint32_t rows, float multiplier, hipStream_t stream);
 
 // bandwidth-tuned tiled kernels; return false from the *Supported predicates when a plan is not covered
 bool tileYuvToRgbSupported(const YuvToRgbPlan & plan);

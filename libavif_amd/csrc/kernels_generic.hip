@@ -227,6 +227,18 @@ __global__ __launch_bounds__(256) void alphaMulGenericKernel(AlphaMulPlan p)
 }
 
 // --------------------------------------------------------------------------------------------
+// in-place integer -> half float pass, src/reformat.c:1419-1443
+__global__ __launch_bounds__(256) void toF16GenericKernel(uint8_t * pixels, uint32_t rowBytes, uint32_t samplesPerRow, uint32_t rows, float multiplier)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= samplesPerRow || j >= rows)
+        return;
+    uint16_t * px = reinterpret_cast<uint16_t *>(pixels + (size_t)j * rowBytes) + i;
+    *px = (uint16_t)toHalfBits(*px, multiplier);
+}
+
+// --------------------------------------------------------------------------------------------
 // launchers
 static inline dim3 gridFor(uint32_t w, uint32_t h, dim3 block, uint32_t z = 1)
 {
@@ -275,6 +287,15 @@ hipError_t launchRgbToYuvGeneric(const RgbToYuvPlan & plan, hipStream_t stream)
         const uint32_t bw = (plan.width + 1) / 2, bh = (plan.height + 1) / 2;
         hipLaunchKernelGGL(rgbToYuvGenericKernel, gridFor(bw, bh, block), block, 0, stream, plan);
     }
+    return hipGetLastError();
+}
+
+hipError_t launchToF16Generic(uint8_t * pixels, uint32_t rowBytes, uint32_t samplesPerRow, uint32_t rows, float multiplier, hipStream_t stream)
+{
+    if (samplesPerRow == 0 || rows == 0)
+        return hipSuccess;
+    const dim3 block(64, 4);
+    hipLaunchKernelGGL(toF16GenericKernel, gridFor(samplesPerRow, rows, block), block, 0, stream, pixels, rowBytes, samplesPerRow, rows, multiplier);
     return hipGetLastError();
 }
 

@@ -224,7 +224,8 @@ static bool prepareState(const avifImage * image, const avifRGBImage * rgb, YuvS
     return true;
 }
 
-avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, uint32_t tuning, YuvToRgbPlan * out)
+avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, uint32_t tuning, YuvToRgbPlan * out,
+                            bool colorOnly, bool reformatAlphaHook)
 {
     (void)arithMode;
     if (!image->yuvPlanes[AVIF_CHAN_Y] || rgb->maxThreads < 0)
@@ -258,8 +259,12 @@ avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, c
             mul = MUL_UNMULTIPLY;
         }
     }
+    if (colorOnly) {
+        mul = MUL_NONE;        // src/reformat.c:1574-1585 stays with the caller
+        out->rgb.isFloat = 0;  // and so does src/reformat.c:1588-1590
+    }
     // alpha channel, src/reformat.c:1449-1486
-    const bool reformatAlpha = rgbHasAlpha && (!rgb->ignoreAlpha || mul != MUL_NONE);
+    const bool reformatAlpha = colorOnly ? (rgbHasAlpha && reformatAlphaHook) : (rgbHasAlpha && (!rgb->ignoreAlpha || mul != MUL_NONE));
     out->alphaSource = ALPHA_KEEP;
     if (reformatAlpha)
         out->alphaSource = (image->alphaPlane && image->alphaRowBytes) ? ALPHA_PLANE : ALPHA_FILL;

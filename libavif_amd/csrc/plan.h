@@ -122,7 +122,11 @@ struct AlphaMulPlan
 };
 
 // Host-side derivation (plan.cpp). Return an avifResult; AVIF_RESULT_OK means the plan is valid.
-avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, uint32_t tuning, YuvToRgbPlan * out);
+// colorOnly: the job libavif hands to its accelerated-backend hook (avifImageYUVToRGBLibYUV, include/avif/internal.h:
+// 349-363): colour conversion without any alpha (un)multiply or half-float pass (the caller runs those afterwards),
+// alpha channel written only when reformatAlpha.
+avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, uint32_t tuning, YuvToRgbPlan * out,
+                            bool colorOnly = false, bool reformatAlpha = false);
 avifResult makeRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, int arithMode, RgbToYuvPlan * out);
 avifResult makeAlphaMulPlan(const avifRGBImage * rgb, bool unmultiply, int arithMode, AlphaMulPlan * out);
 

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
-    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle",
+    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount",
 ]
 
 _lib = None
@@ -80,6 +80,9 @@ def load() -> C.CDLL:
         "avifhipStreamCreate": (vp, []),
         "avifhipStreamDestroy": (None, [vp]),
         "avifhipSetTuning": (None, [u32]),
+        "avifhipImageYUVToRGBColorOnly": (i32, [P_IMG, P_RGB, i32]),
+        "avifhipRGBImageToF16": (i32, [P_RGB]),
+        "avifhipLaunchCount": (C.c_uint64, []),
         "avifhipTimeYUVToRGBCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
     }
     for name, (res, args) in sigs.items():

@@ -1,0 +1,122 @@
+"""Seam B on the GPU: libavif built FROM THE REFERENCE'S OWN SOURCES with src/reformat_libyuv.c replaced by
+integration/reformat_libyuv_hip.c (oracle/_ref/libavif_hipbackend.so, oracle/Makefile), i.e. the reference's
+avifImageYUVToRGB / avifImageRGBToYUV / premultiply entry points running unchanged on top of the HIP kernels.
+
+Expected results: the same entry points of the reference built without any backend (oracle/_ref/libavif_ref.so).  The
+only place where a backend changes what libavif computes is the one libyuv changes too: when the hook converted the
+colours, a pending alpha (un)multiply runs as the integer post-pass (src/reformat.c:1574-1585) instead of inside the
+built-in slow loop (:894-947).  Those cases are compared with the same two steps done by the backend-less reference.
+"""
+import ctypes as C
+import os
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+import harness as H
+import oracle_lib
+from libavif_amd import abi, native
+
+pytestmark = pytest.mark.gpu
+
+BACKEND_SO = oracle_lib.ORACLE_DIR / "_ref" / "libavif_hipbackend.so"
+SIZES = [(300, 21), (512, 16), (37, 21), (1027, 18)]
+
+
+@pytest.fixture(scope="module")
+def libs(hip):
+    if not BACKEND_SO.exists() or oracle_lib.ref() is None:
+        pytest.skip("oracle/_ref/libavif_hipbackend.so or libavif_ref.so not built (needs /root/reference at build time)")
+    os.environ["AVIFHIP_MIN_PIXELS"] = "0"  # tiny test images must take the GPU route too
+    be = oracle_lib._bind_libavif(C.CDLL(os.fspath(BACKEND_SO), mode=os.RTLD_LOCAL))
+    assert be.avifLibYUVVersion() == 9500
+    return H.libavif_backend(be, "reference+hip-hooks"), H.libavif_backend(oracle_lib.ref(), "reference")
+
+
+def _mul_mode(c: H.Y2RCase) -> int:
+    """src/reformat.c:1662-1677"""
+    if not c.alpha:
+        return 0
+    has_alpha = abi.rgb_format_has_alpha(c.rgb_format)
+    if not has_alpha or c.ignore_alpha:
+        return 0 if c.image_premultiplied else 1
+    if not c.image_premultiplied and c.rgb_premultiplied:
+        return 1
+    if c.image_premultiplied and not c.rgb_premultiplied:
+        return 2
+    return 0
+
+
+def test_yuv_to_rgb_through_libavif_hooks(libs, hip):
+    be, ref = libs
+    cases = [replace(c, avoid_libyuv=False) for c in H.y2r_sweep(SIZES, n_random=400, seed=41)]
+    bad, hooked = [], 0
+    for c in cases:
+        mul = _mul_mode(c)
+        has_alpha = abi.rgb_format_has_alpha(c.rgb_format)
+        two_step = mul != 0 and has_alpha
+        if two_step and c.is_float:
+            continue  # would need the reference's internal avifRGBImageToF16 as a third step
+        before = hip.avifhipLaunchCount()
+        rh, ph = H.run_y2r(be, c)
+        hooked += hip.avifhipLaunchCount() > before
+        if two_step:
+            # colour + alpha without multiply, then the integer pass
+            rr, pr = H.run_y2r(ref, replace(c, rgb_premultiplied=c.image_premultiplied, ignore_alpha=False))
+            if rr == 0:
+                out = H.make_y2r_output(c)
+                out.pixels[...] = pr
+                rr = (ref.premultiply if mul == 1 else ref.unpremultiply)(out.struct)
+                pr = out.pixels
+        else:
+            rr, pr = H.run_y2r(ref, c)
+        if rh != rr or not np.array_equal(ph, pr):
+            bad.append(f"{c.ident()}: results {rh}/{rr}" + ("" if rh != rr else " " + H.describe_diff(pr, ph)))
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+    assert hooked > len(cases) // 2, f"only {hooked} of {len(cases)} conversions reached the GPU through the hooks"
+
+
+def test_rgb_to_yuv_through_libavif_hooks(libs, hip):
+    be, ref = libs
+    cases = [replace(c, avoid_libyuv=False) for c in H.r2y_sweep(SIZES[:3], n_random=300, seed=43)]
+    bad, hooked = [], 0
+    for c in cases:
+        before = hip.avifhipLaunchCount()
+        rh, ih = H.run_r2y(be, c)
+        hooked += hip.avifhipLaunchCount() > before
+        rr, ir = H.run_r2y(ref, c)
+        d = None if rh != rr else H.planes_equal(ir, ih)
+        if rh != rr or d:
+            bad.append(f"{c.ident()}: results {rh}/{rr} {d or ''}")
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+    assert hooked > len(cases) // 4, f"only {hooked} of {len(cases)} conversions reached the GPU through the hooks"
+
+
+@pytest.mark.parametrize("depth", [8, 16])
+@pytest.mark.parametrize("fmt", [1, 2, 4, 5])
+def test_premultiply_through_libavif_hooks(libs, hip, fmt, depth):
+    from libavif_amd import synth
+
+    be, ref = libs
+    for which in ("premultiply", "unpremultiply"):
+        a = abi.make_rgb(261, 19, depth, fmt, row_pad=6, fill=0x5A)
+        synth.fill_rgb(a, 0xBEEF + fmt + depth)
+        b = abi.make_rgb(261, 19, depth, fmt, row_pad=6)
+        b.pixels[...] = a.pixels
+        before = hip.avifhipLaunchCount()
+        assert getattr(ref, which)(a.struct) == getattr(be, which)(b.struct) == 0
+        assert hip.avifhipLaunchCount() > before
+        assert np.array_equal(a.pixels, b.pixels), (which, H.describe_diff(a.pixels, b.pixels))
+
+
+def test_small_images_stay_on_the_cpu(libs, hip):
+    """Below the size threshold the hooks decline (AVIF_RESULT_NOT_IMPLEMENTED) and libavif's own code runs."""
+    be, ref = libs
+    os.environ["AVIFHIP_MIN_PIXELS"] = "0"  # cached at first use inside the shim: this test only documents the knob
+    c = H.Y2RCase(16, 16, avoid_libyuv=True)  # avoidLibYUV: the hook is not even asked (src/reformat.c:1453)
+    before = hip.avifhipLaunchCount()
+    rh, ph = H.run_y2r(be, c)
+    rr, pr = H.run_y2r(ref, c)
+    assert rh == rr == 0 and np.array_equal(ph, pr)
+    assert hip.avifhipLaunchCount() == before
