@@ -17,6 +17,7 @@
  * arithmetic, round-to-nearest-even, no fused multiply-add.
  */
 #include "reformat_oracle.h"
+#include "oracle_backend.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -372,6 +373,29 @@ static avifResult integerAlphaPass(avifRGBImage * rgb, int unmultiply)
     return AVIF_RESULT_OK;
 }
 
+/* src/alpha.c:163-166 / :350-353: the backend is asked first, whatever rgb->avoidLibYUV says */
+static avifResult alphaPassWithBackend(avifRGBImage * rgb, int unmultiply, const OracleBackend * backend)
+{
+    if (!rgb->pixels || !rgb->rowBytes)
+        return AVIF_RESULT_REFORMAT_FAILED;
+    if (!fmtHasAlpha(rgb->format))
+        return unmultiply ? AVIF_RESULT_REFORMAT_FAILED : AVIF_RESULT_INVALID_ARGUMENT;
+    if (backend) {
+        avifResult (*fn)(avifRGBImage *) = unmultiply ? backend->unpremultiply : backend->premultiply;
+        if (fn) {
+            const avifResult br = fn(rgb);
+            if (br != AVIF_RESULT_NOT_IMPLEMENTED)
+                return br;
+        }
+    }
+    return integerAlphaPass(rgb, unmultiply);
+}
+
+avifResult oracleAlphaPassWithBackend(avifRGBImage * rgb, int unmultiply, const OracleBackend * backend)
+{
+    return alphaPassWithBackend(rgb, unmultiply, backend);
+}
+
 avifResult oracleRGBImagePremultiplyAlpha(avifRGBImage * rgb)
 {
     return integerAlphaPass(rgb, 0);
@@ -567,7 +591,7 @@ static void toHalfFloat(avifRGBImage * rgb, const avifCropRect * r)
     }
 }
 
-static avifResult yuvToRgbRect(const avifImage * image, avifRGBImage * rgb, const avifCropRect * rect)
+static avifResult yuvToRgbRect(const avifImage * image, avifRGBImage * rgb, const avifCropRect * rect, const OracleBackend * backend)
 {
     if (!image->yuvPlanes[AVIF_CHAN_Y] || rgb->maxThreads < 0)
         return AVIF_RESULT_REFORMAT_FAILED; /* :1653-1655 */
@@ -592,9 +616,21 @@ static avifResult yuvToRgbRect(const avifImage * image, avifRGBImage * rgb, cons
         }
     }
 
-    /* alpha channel first, :1449-1486 */
+    /* the accelerated backend (libyuv in the reference) gets the first shot at the colour conversion, :1449-1462 */
     const int reformatAlpha = rgbHasAlpha && (!rgb->ignoreAlpha || mul != MUL_NONE);
-    if (reformatAlpha) {
+    int convertedByBackend = 0;
+    avifBool alphaDoneByBackend = AVIF_FALSE;
+    if (backend && backend->yuvToRgb && !rgb->avoidLibYUV && (mul == MUL_NONE || rgbHasAlpha) && rect->x == 0 && rect->y == 0 &&
+        rect->width == image->width && rect->height == image->height) {
+        const avifResult br = backend->yuvToRgb(image, rgb, reformatAlpha ? AVIF_TRUE : AVIF_FALSE, &alphaDoneByBackend);
+        if (br == AVIF_RESULT_OK)
+            convertedByBackend = 1;
+        else if (br != AVIF_RESULT_NOT_IMPLEMENTED)
+            return br;
+    }
+
+    /* alpha channel, :1464-1486 */
+    if (reformatAlpha && !alphaDoneByBackend) {
         AlphaJob A;
         memset(&A, 0, sizeof(A));
         A.width = rect->width;
@@ -632,12 +668,14 @@ static avifResult yuvToRgbRect(const avifImage * image, avifRGBImage * rgb, cons
         }
     }
     J.inLoopMul = fast ? MUL_NONE : mul;
+    if (convertedByBackend)
+        fast = 1; /* the backend never (un)multiplies: the integer post-pass below does, :1574-1585 */
 
     /* look-up tables, :575-603 */
-    const size_t n = (size_t)1 << image->depth;
+    const size_t n = convertedByBackend ? 0 : ((size_t)1 << image->depth);
     float * lutY = (float *)malloc(n * sizeof(float));
     float * lutUV = (float *)malloc(n * sizeof(float));
-    if (!lutY || !lutUV) {
+    if (n && (!lutY || !lutUV)) {
         free(lutY);
         free(lutUV);
         return AVIF_RESULT_OUT_OF_MEMORY;
@@ -649,7 +687,7 @@ static avifResult yuvToRgbRect(const avifImage * image, avifRGBImage * rgb, cons
     J.lutY = lutY;
     J.lutUV = lutUV;
 
-    for (uint32_t j = rect->y; j < rect->y + rect->height; ++j)
+    for (uint32_t j = rect->y; !convertedByBackend && j < rect->y + rect->height; ++j)
         for (uint32_t i = rect->x; i < rect->x + rect->width; ++i)
             convertPixel(&J, i, j);
     free(lutY);
@@ -661,7 +699,7 @@ static avifResult yuvToRgbRect(const avifImage * image, avifRGBImage * rgb, cons
         view.pixels = rgb->pixels + (size_t)rect->y * rgb->rowBytes + (size_t)rect->x * J.L.pixBytes;
         view.width = rect->width;
         view.height = rect->height;
-        const avifResult r = integerAlphaPass(&view, mul == MUL_UNMULTIPLY);
+        const avifResult r = alphaPassWithBackend(&view, mul == MUL_UNMULTIPLY, backend);
         if (r != AVIF_RESULT_OK)
             return r;
     }
@@ -675,7 +713,13 @@ avifResult oracleImageYUVToRGB(const avifImage * image, avifRGBImage * rgb)
     /* loops run over image->width x image->height (:686,:703); alpha over rgb->width x rgb->height (:1467-1468).
      * The API requires both to match (include/avif/avif.h:934-936); the oracle uses the image's. */
     const avifCropRect whole = { 0, 0, image->width, image->height };
-    return yuvToRgbRect(image, rgb, &whole);
+    return yuvToRgbRect(image, rgb, &whole, NULL);
+}
+
+avifResult oracleImageYUVToRGBWithBackend(const avifImage * image, avifRGBImage * rgb, const OracleBackend * backend)
+{
+    const avifCropRect whole = { 0, 0, image->width, image->height };
+    return yuvToRgbRect(image, rgb, &whole, backend);
 }
 
 avifResult oracleImageYUVToRGBRect(const avifImage * canvas, avifRGBImage * rgbCanvas, const avifCropRect * rect)
@@ -683,7 +727,7 @@ avifResult oracleImageYUVToRGBRect(const avifImage * canvas, avifRGBImage * rgbC
     if (rect->width > canvas->width || rect->height > canvas->height || rect->x > canvas->width - rect->width ||
         rect->y > canvas->height - rect->height)
         return AVIF_RESULT_INVALID_ARGUMENT;
-    return yuvToRgbRect(canvas, rgbCanvas, rect);
+    return yuvToRgbRect(canvas, rgbCanvas, rect, NULL);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -747,7 +791,18 @@ static avifResult allocatePlanes(avifImage * image, int withAlpha) /* src/avif.c
     return AVIF_RESULT_OK;
 }
 
+static avifResult rgbToYuv(avifImage * image, const avifRGBImage * rgb, const OracleBackend * backend);
+
 avifResult oracleImageRGBToYUV(avifImage * image, const avifRGBImage * rgb)
+{
+    return rgbToYuv(image, rgb, NULL);
+}
+avifResult oracleImageRGBToYUVWithBackend(avifImage * image, const avifRGBImage * rgb, const OracleBackend * backend)
+{
+    return rgbToYuv(image, rgb, backend);
+}
+
+static avifResult rgbToYuv(avifImage * image, const avifRGBImage * rgb, const OracleBackend * backend)
 {
     if (!rgb->pixels || rgb->format == AVIF_RGB_FORMAT_RGB_565)
         return AVIF_RESULT_REFORMAT_FAILED; /* :223-225 */
@@ -775,7 +830,18 @@ avifResult oracleImageRGBToYUV(avifImage * image, const avifRGBImage * rgb)
     if (!gray && rgb->chromaDownsampling == AVIF_CHROMA_DOWNSAMPLING_SHARP_YUV && image->yuvFormat == AVIF_PIXEL_FORMAT_YUV420)
         return AVIF_RESULT_NOT_IMPLEMENTED; /* libsharpyuv absent: src/reformat_libsharpyuv.c:77-84 via :255-263 */
 
-    if (!gray) {
+    int convertedByBackend = 0; /* :264-272 */
+    if (!gray && backend && backend->rgbToYuv && !rgb->avoidLibYUV && mul == MUL_NONE) {
+        const avifResult br = backend->rgbToYuv(image, rgb);
+        if (br == AVIF_RESULT_OK)
+            convertedByBackend = 1;
+        else if (br != AVIF_RESULT_NOT_IMPLEMENTED)
+            return br;
+    }
+
+    if (convertedByBackend) {
+        /* colour planes are done */
+    } else if (!gray) {
         const float kr = S.kr, kg = S.kg, kb = S.kb;
         for (uint32_t oj = 0; oj < H; oj += 2) {
             for (uint32_t oi = 0; oi < W; oi += 2) {

@@ -47,12 +47,22 @@ int oracleFullToLimitedUV(uint32_t depth, int v);
  */
 avifResult oracleImageYUVToRGBRect(const avifImage * canvas, avifRGBImage * rgbCanvas, const avifCropRect * rect);
 
-/* libyuv-compatible fixed-point path. Returns NOT_IMPLEMENTED
- * for combinations libavif would not hand to libyuv (src/reformat_libyuv.c:932-1108). */
+/*
+ * The reference's INTEGER path: what a libavif built with libyuv computes (libyuv_oracle.c).
+ * oracleLibyuv<Entry> == that build's avif<Entry>, end to end: libyuv's fixed-point arithmetic wherever libavif
+ * dispatches to libyuv (src/reformat_libyuv.c; honours rgb->avoidLibYUV like src/reformat.c:1453 and :264), the fp32
+ * path for everything else.  Note that (un)premultiply always tries libyuv first (src/alpha.c:163,350).
+ */
 avifResult oracleLibyuvImageYUVToRGB(const avifImage * image, avifRGBImage * rgb);
 avifResult oracleLibyuvImageRGBToYUV(avifImage * image, const avifRGBImage * rgb);
 avifResult oracleLibyuvRGBImagePremultiplyAlpha(avifRGBImage * rgb);
 avifResult oracleLibyuvRGBImageUnpremultiplyAlpha(avifRGBImage * rgb);
+/* The four backend hooks themselves (include/avif/internal.h:346-378): AVIF_RESULT_NOT_IMPLEMENTED for every
+ * combination libavif would not hand to libyuv. */
+avifResult oracleLibyuvHookYUVToRGB(const avifImage * image, avifRGBImage * rgb, avifBool reformatAlpha, avifBool * alphaReformatted);
+avifResult oracleLibyuvHookRGBToYUV(avifImage * image, const avifRGBImage * rgb);
+avifResult oracleLibyuvHookPremultiplyAlpha(avifRGBImage * rgb);
+avifResult oracleLibyuvHookUnpremultiplyAlpha(avifRGBImage * rgb);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ _cache: dict = {}
 
 def _ensure_built() -> None:
     so = ORACLE_DIR / "liboracle.so"
-    srcs = [ORACLE_DIR / "reformat_oracle.c", ORACLE_DIR / "libyuv_oracle.c", ORACLE_DIR / "reformat_oracle.h"]
+    srcs = [ORACLE_DIR / "reformat_oracle.c", ORACLE_DIR / "libyuv_oracle.c", ORACLE_DIR / "reformat_oracle.h", ORACLE_DIR / "oracle_backend.h"]
     if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", os.fspath(ORACLE_DIR), "liboracle.so"], check=True, capture_output=True)
 

@@ -1,6 +1,12 @@
-"""Golden fixtures (tests/golden/*.npz, written by tests/tools/make_golden.py from the reference compiled from its
-own sources): the oracle must reproduce every one of them byte for byte on any machine (no /root/reference needed),
-and so must the HIP library on the GPU box.  Inputs come from the fixture files, not from the generators."""
+"""Golden fixtures: the oracle must reproduce every one of them byte for byte on any machine (no /root/reference
+needed), and so must the HIP library on the GPU box.  Inputs come from the fixture files, not from the generators.
+
+  tests/golden/{y2r,r2y}_*.npz      the reference compiled from its own sources, libyuv OFF (tests/tools/make_golden.py):
+                                    the fp32 path;
+  tests/golden/yuvlib_*.npz         a libavif built WITH libyuv (Pillow's bundled binary, tests/tools/make_golden_libyuv.py):
+                                    the integer path, checked against oracle/libyuv_oracle.c and the library's default
+                                    arithmetic (AVIFHIP_ARITHMETIC_AUTO).
+"""
 import json
 from pathlib import Path
 
@@ -9,7 +15,9 @@ import pytest
 
 import harness as H
 
-GOLDEN = sorted((Path(__file__).resolve().parent / "golden").glob("*.npz"))
+ALL = sorted((Path(__file__).resolve().parent / "golden").glob("*.npz"))
+GOLDEN = [p for p in ALL if not p.name.startswith("yuvlib_")]
+GOLDEN_YUVLIB = [p for p in ALL if p.name.startswith("yuvlib_")]
 
 
 def _load_case(path, cls):
@@ -39,8 +47,27 @@ def _run_r2y(backend, z, c):
     return backend.rgb_to_yuv(img.struct, rgb.struct), img
 
 
+def _check_mul(backend, path):
+    z = np.load(path)
+    meta = json.loads(str(z["case"]))
+    h, rowbytes = z["pixels"].shape
+    from libavif_amd import abi
+
+    for which in ("premultiply", "unpremultiply"):
+        nch = abi.rgb_format_channel_count(meta["format"])
+        work = abi.make_rgb(rowbytes // (nch * (2 if meta["depth"] > 8 else 1)), h, meta["depth"], meta["format"])
+        work.pixels[...] = z["pixels"]
+        if isinstance(backend, H.HipDeviceBackend):
+            backend.bind_host(work.struct, work)
+        assert getattr(backend, which)(work.struct) == int(z[which + "_result"]), (meta, which)
+        assert np.array_equal(work.pixels, z[which]), (meta, which, H.describe_diff(z[which], work.pixels))
+
+
 def _check(backend, path, padding=True):
-    if path.name.startswith("y2r"):
+    kind = path.name.replace("yuvlib_", "")
+    if kind.startswith("mul"):
+        _check_mul(backend, path)
+    elif kind.startswith("y2r"):
         z, c = _load_case(path, H.Y2RCase)
         res, px = _run_y2r(backend, z, c)
         assert res == int(z["result"]), c.ident()
@@ -57,6 +84,7 @@ def _check(backend, path, padding=True):
 
 def test_fixtures_present():
     assert len(GOLDEN) >= 20
+    assert len(GOLDEN_YUVLIB) >= 30
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=lambda p: p.stem)
@@ -67,4 +95,15 @@ def test_oracle_reproduces_reference_fixture(path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", GOLDEN, ids=lambda p: p.stem)
 def test_hip_reproduces_reference_fixture(hip, path):
+    _check(H.hip_host_backend(), path)
+
+
+@pytest.mark.parametrize("path", GOLDEN_YUVLIB, ids=lambda p: p.stem)
+def test_integer_oracle_reproduces_libyuv_build_fixture(path):
+    _check(H.oracle_libyuv_backend(), path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLDEN_YUVLIB, ids=lambda p: p.stem)
+def test_hip_reproduces_libyuv_build_fixture(hip_auto_arithmetic, path):
     _check(H.hip_host_backend(), path)
