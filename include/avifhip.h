@@ -11,14 +11,15 @@
  * (they are staged through HBM) or already in device memory (they are used in
  * place); the library classifies each pointer itself.
  *
- * Arithmetic contract (see DESIGN.md "Parity"):
- *   rgb->avoidLibYUV != 0  -> libavif's built-in fp32 path, byte-exact
- *                             (src/reformat.c, src/alpha.c);
- *   rgb->avoidLibYUV == 0  -> what a libyuv-enabled libavif computes: libyuv's
- *                             fixed-point arithmetic for the combinations
- *                             libavif dispatches to libyuv
- *                             (src/reformat_libyuv.c), the fp32 path otherwise.
- *                             avifhipSetArithmetic() can pin either family.
+ * Arithmetic contract (see DESIGN.md "Parity"): results are byte-identical to one of the two libavif builds,
+ * selected by avifhipSetArithmetic() / the AVIFHIP_ARITHMETIC environment variable:
+ *   AUTO (default)  a libavif built WITH libyuv (the stock build): libyuv's fixed-point arithmetic for every
+ *                   combination libavif dispatches to libyuv (src/reformat_libyuv.c) -- honouring rgb->avoidLibYUV
+ *                   the way src/reformat.c:1453 and :264 do, and asking libyuv first for 8-bit RGBA/BGRA
+ *                   (un)premultiply whatever avoidLibYUV says, the way src/alpha.c:163,350 do -- and libavif's
+ *                   built-in fp32 arithmetic (src/reformat.c, src/alpha.c) for everything else;
+ *   FLOAT           a libavif built WITHOUT libyuv: the built-in fp32 arithmetic everywhere;
+ *   LIBYUV          as AUTO with rgb->avoidLibYUV ignored.
  */
 #ifndef AVIFHIP_H
 #define AVIFHIP_H
@@ -102,9 +103,9 @@ AVIFHIP_API void avifhipCalcYUVCoefficients(const avifImage * image, float * out
 
 typedef enum avifhipArithmetic
 {
-    AVIFHIP_ARITHMETIC_AUTO = 0,   /* follow rgb->avoidLibYUV (default) */
-    AVIFHIP_ARITHMETIC_FLOAT = 1,  /* always libavif's built-in fp32 arithmetic */
-    AVIFHIP_ARITHMETIC_LIBYUV = 2  /* libyuv fixed-point wherever libavif would use libyuv, even if avoidLibYUV */
+    AVIFHIP_ARITHMETIC_AUTO = 0,   /* what a libavif built with libyuv computes (default) */
+    AVIFHIP_ARITHMETIC_FLOAT = 1,  /* what a libavif built without libyuv computes: fp32 everywhere */
+    AVIFHIP_ARITHMETIC_LIBYUV = 2  /* AUTO, ignoring rgb->avoidLibYUV */
 } avifhipArithmetic;
 
 AVIFHIP_API void avifhipSetArithmetic(avifhipArithmetic mode);

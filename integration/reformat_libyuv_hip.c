@@ -14,9 +14,11 @@
  *                                worth a GPU round trip (small images), for a missing GPU, and for any HIP failure;
  *   anything else                is propagated to the caller: used only for the argument errors libavif itself
  *                                would report.
- * Arithmetic: libavifhip computes libavif's built-in fp32 arithmetic bit for bit, so results do not depend on
- * whether a hook ran or fell back (the libyuv hooks it replaces are 6-bit fixed point and differ from the built-in
- * path by up to 14 code values).
+ * Arithmetic: by default (AVIFHIP_ARITHMETIC=auto) every result is byte-identical to a stock libavif built with
+ * libyuv: the hooks compute libyuv's fixed-point arithmetic for the combinations src/reformat_libyuv.c hands to
+ * libyuv, libavif's built-in fp32 arithmetic for the combinations libyuv declines (instead of declining too), and
+ * decline the one case a hook cannot reproduce (a pending alpha multiply inside the built-in slow loop).  With
+ * AVIFHIP_ARITHMETIC=float every hook computes the built-in fp32 arithmetic, i.e. a libavif built without libyuv.
  */
 #include "avif/internal.h"
 

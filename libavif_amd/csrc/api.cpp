@@ -19,7 +19,7 @@ using namespace avifhip;
 
 namespace {
 
-std::atomic<int> gArithmetic { AVIFHIP_ARITHMETIC_AUTO };
+std::atomic<int> gArithmetic { -1 }; // -1: not decided yet (environment, then AUTO)
 std::atomic<int> gTiledKernels { 1 };
 std::atomic<uint32_t> gTuning { TUNE_DEFAULT };
 
@@ -144,9 +144,26 @@ inline uint32_t alignUp(uint32_t v, uint32_t a)
     return (v + a - 1) / a * a;
 }
 
+// Initial arithmetic family from the environment (AVIFHIP_ARITHMETIC=auto|float|libyuv), so that an unmodified
+// application over the seam-B build can choose; avifhipSetArithmetic() overrides.
+int arithmeticFromEnvironment()
+{
+    const char * e = getenv("AVIFHIP_ARITHMETIC");
+    if (e && !strcmp(e, "float"))
+        return AVIFHIP_ARITHMETIC_FLOAT;
+    if (e && !strcmp(e, "libyuv"))
+        return AVIFHIP_ARITHMETIC_LIBYUV;
+    return AVIFHIP_ARITHMETIC_AUTO;
+}
+
 int effectiveArithmetic()
 {
-    return gArithmetic.load(std::memory_order_relaxed);
+    int a = gArithmetic.load(std::memory_order_relaxed);
+    if (a < 0) {
+        a = arithmeticFromEnvironment();
+        gArithmetic.store(a, std::memory_order_relaxed);
+    }
+    return a;
 }
 
 // ---- kernel selection -----------------------------------------------------------------------
@@ -157,7 +174,7 @@ avifResult enqueueYuvToRgb(const YuvToRgbPlan & plan, hipStream_t stream)
     if (gTiledKernels.load(std::memory_order_relaxed) && tileYuvToRgbSupported(plan)) {
         e = launchYuvToRgbTile(plan, stream, &tls.lastKernel);
     } else {
-        tls.lastKernel = "yuv2rgb_generic";
+        tls.lastKernel = (plan.arith == ARITH_LIBYUV) ? "yuv2rgb_fixed_generic" : "yuv2rgb_generic";
         e = launchYuvToRgbGeneric(plan, stream);
     }
     if (e != hipSuccess)
@@ -172,7 +189,7 @@ avifResult enqueueRgbToYuv(const RgbToYuvPlan & plan, hipStream_t stream)
     if (gTiledKernels.load(std::memory_order_relaxed) && tileRgbToYuvSupported(plan)) {
         e = launchRgbToYuvTile(plan, stream, &tls.lastKernel);
     } else {
-        tls.lastKernel = "rgb2yuv_generic";
+        tls.lastKernel = (plan.arith == ARITH_LIBYUV) ? "rgb2yuv_fixed_generic" : "rgb2yuv_generic";
         e = launchRgbToYuvGeneric(plan, stream);
     }
     if (e != hipSuccess)
@@ -183,7 +200,8 @@ avifResult enqueueRgbToYuv(const RgbToYuvPlan & plan, hipStream_t stream)
 
 avifResult enqueueAlphaMul(const AlphaMulPlan & plan, hipStream_t stream)
 {
-    tls.lastKernel = plan.unmultiply ? "unpremultiply_generic" : "premultiply_generic";
+    tls.lastKernel = (plan.arith == ARITH_LIBYUV) ? (plan.unmultiply ? "unattenuate_fixed_generic" : "attenuate_fixed_generic")
+                                                  : (plan.unmultiply ? "unpremultiply_generic" : "premultiply_generic");
     const hipError_t e = launchAlphaMulGeneric(plan, stream);
     if (e != hipSuccess)
         return hipFailed(e, "alpha multiply kernel launch");
@@ -758,7 +776,7 @@ extern "C" void avifhipSetArithmetic(avifhipArithmetic mode)
 }
 extern "C" avifhipArithmetic avifhipGetArithmetic(void)
 {
-    return (avifhipArithmetic)gArithmetic.load(std::memory_order_relaxed);
+    return (avifhipArithmetic)effectiveArithmetic();
 }
 extern "C" void avifhipSetTuning(uint32_t bits)
 {

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "pixel_fixed.h"
 #include "pixel_generic.h"
 #include "pixel_math.h"
 
@@ -17,7 +18,10 @@ __global__ __launch_bounds__(256) void yuvToRgbGenericKernel(YuvToRgbPlan p)
     const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= p.w || j >= p.h)
         return;
-    yuvToRgbPixel(p, p.x0 + i, p.y0 + j);
+    if (p.arith == ARITH_LIBYUV)
+        yuvToRgbPixelFixed(p, p.x0 + i, p.y0 + j);
+    else
+        yuvToRgbPixel(p, p.x0 + i, p.y0 + j);
 }
 
 __global__ __launch_bounds__(256) void yuvToRgbGenericBatchKernel(const YuvToRgbPlan * __restrict__ table)
@@ -27,7 +31,10 @@ __global__ __launch_bounds__(256) void yuvToRgbGenericBatchKernel(const YuvToRgb
     const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= p.w || j >= p.h)
         return;
-    yuvToRgbPixel(p, p.x0 + i, p.y0 + j);
+    if (p.arith == ARITH_LIBYUV)
+        yuvToRgbPixelFixed(p, p.x0 + i, p.y0 + j);
+    else
+        yuvToRgbPixel(p, p.x0 + i, p.y0 + j);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -163,6 +170,56 @@ __global__ __launch_bounds__(256) void rgbToYuvGenericKernel(RgbToYuvPlan p)
     }
 }
 
+// RGB -> YUV in libyuv's fixed point (8-bit BT.601, appendix D.5), one lane per 2x2 block: luma per pixel; the RGB of
+// the block (4:2:0) or pair (4:2:2) is averaged per channel FIRST, with the last column / row replicated, and U, V come
+// from the average.  The alpha plane is libavif's own pass (src/reformat.c:545-569), fused in.
+__global__ __launch_bounds__(256) void rgbToYuvFixedKernel(RgbToYuvPlan p)
+{
+    const uint32_t bx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t by = blockIdx.y * blockDim.y + threadIdx.y;
+    const uint32_t oi = bx * 2, oj = by * 2;
+    if (oi >= p.width || oj >= p.height)
+        return;
+    const YuvSide & s = p.yuv;
+    const RgbSide & o = p.rgb;
+    const bool full = p.fxFullRange != 0;
+    const uint32_t x1 = (oi + 1 < p.width) ? oi + 1 : oi, y1 = (oj + 1 < p.height) ? oj + 1 : oj;
+    const Rgb8 c00 = fxLoadRgb(o, oi, oj), c10 = fxLoadRgb(o, x1, oj), c01 = fxLoadRgb(o, oi, y1), c11 = fxLoadRgb(o, x1, y1);
+    const Rgb8 blk[2][2] = { { c00, c01 }, { c10, c11 } }; // [bI][bJ]
+    const uint32_t bw = x1 - oi + 1, bh = y1 - oj + 1;
+    for (uint32_t bJ = 0; bJ < bh; ++bJ) {
+        for (uint32_t bI = 0; bI < bw; ++bI) {
+            const uint32_t i = oi + bI, j = oj + bJ;
+            s.plane[0][(size_t)j * s.rowBytes[0] + i] = (uint8_t)fxLuma(blk[bI][bJ], full);
+            if (s.format == AVIF_PIXEL_FORMAT_YUV444) {
+                s.plane[1][(size_t)j * s.rowBytes[1] + i] = (uint8_t)fxCb(blk[bI][bJ], full);
+                s.plane[2][(size_t)j * s.rowBytes[2] + i] = (uint8_t)fxCr(blk[bI][bJ], full);
+            }
+            if (p.alphaSource == ALPHA_FILL) {
+                s.alpha[(size_t)j * s.alphaRowBytes + i] = 255;
+            } else if (p.alphaSource == ALPHA_PLANE) {
+                s.alpha[(size_t)j * s.alphaRowBytes + i] = o.pixels[(size_t)j * o.rowBytes + (size_t)i * o.pixBytes + o.offA];
+            }
+        }
+    }
+    if (s.format == AVIF_PIXEL_FORMAT_YUV420) {
+        Rgb8 m;
+        m.r = (c00.r + c10.r + c01.r + c11.r + 2) >> 2;
+        m.g = (c00.g + c10.g + c01.g + c11.g + 2) >> 2;
+        m.b = (c00.b + c10.b + c01.b + c11.b + 2) >> 2;
+        s.plane[1][(size_t)by * s.rowBytes[1] + bx] = (uint8_t)fxCb(m, full);
+        s.plane[2][(size_t)by * s.rowBytes[2] + bx] = (uint8_t)fxCr(m, full);
+    } else if (s.format == AVIF_PIXEL_FORMAT_YUV422) {
+        for (uint32_t bJ = 0; bJ < bh; ++bJ) {
+            const Rgb8 a = blk[0][bJ], b = blk[1][bJ];
+            Rgb8 m;
+            m.r = (a.r + b.r + 1) >> 1, m.g = (a.g + b.g + 1) >> 1, m.b = (a.b + b.b + 1) >> 1;
+            s.plane[1][(size_t)(oj + bJ) * s.rowBytes[1] + bx] = (uint8_t)fxCb(m, full);
+            s.plane[2][(size_t)(oj + bJ) * s.rowBytes[2] + bx] = (uint8_t)fxCr(m, full);
+        }
+    }
+}
+
 // gray source: Y from the gray channel, src/reformat.c:471-519 (chroma planes are filled separately)
 __global__ __launch_bounds__(256) void grayToYuvGenericKernel(RgbToYuvPlan p)
 {
@@ -211,9 +268,15 @@ __global__ __launch_bounds__(256) void alphaMulGenericKernel(AlphaMulPlan p)
     const RgbSide & o = p.rgb;
     uint8_t * px = o.pixels + (size_t)j * o.rowBytes + (size_t)i * o.pixBytes;
     const unsigned a = loadChannel(px, o.offA, o.chanBytes);
+    const int mode = p.unmultiply ? MUL_UNMULTIPLY : MUL_MULTIPLY;
+    if (p.arith == ARITH_LIBYUV) { // ARGBAttenuate / ARGBUnattenuate: 8-bit RGBA / BGRA, every alpha value
+        px[o.offR] = (uint8_t)fxAlphaMul(px[o.offR], a, mode);
+        px[o.offG] = (uint8_t)fxAlphaMul(px[o.offG], a, mode);
+        px[o.offB] = (uint8_t)fxAlphaMul(px[o.offB], a, mode);
+        return;
+    }
     if (a >= (unsigned)o.maxv)
         return; // opaque is a no-op
-    const int mode = p.unmultiply ? MUL_UNMULTIPLY : MUL_MULTIPLY;
     const int nColour = o.isGray ? 1 : 3;
     const int offs[3] = { o.isGray ? o.offGray : o.offR, o.offG, o.offB };
     for (int k = 0; k < nColour; ++k) {
@@ -285,7 +348,10 @@ hipError_t launchRgbToYuvGeneric(const RgbToYuvPlan & plan, hipStream_t stream)
         }
     } else {
         const uint32_t bw = (plan.width + 1) / 2, bh = (plan.height + 1) / 2;
-        hipLaunchKernelGGL(rgbToYuvGenericKernel, gridFor(bw, bh, block), block, 0, stream, plan);
+        if (plan.arith == ARITH_LIBYUV)
+            hipLaunchKernelGGL(rgbToYuvFixedKernel, gridFor(bw, bh, block), block, 0, stream, plan);
+        else
+            hipLaunchKernelGGL(rgbToYuvGenericKernel, gridFor(bw, bh, block), block, 0, stream, plan);
     }
     return hipGetLastError();
 }

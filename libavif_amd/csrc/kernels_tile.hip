@@ -113,7 +113,7 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
-    if (p.arith != ARITH_FLOAT || p.identityCopy || s.mode != MODE_COEFF)
+    if (p.arith != ARITH_FLOAT || p.postMulFx || p.identityCopy || s.mode != MODE_COEFF)
         return false;
     if (!s.exactDiv)
         return false; // a divisor off the verified list (exactdiv.h): the universal kernel divides the IEEE way

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "pixel_fixed.h"
 #include "pixel_math.h"
 
 namespace avifhip {
@@ -103,9 +104,13 @@ __device__ inline void yuvToRgbPixel(const YuvToRgbPlan & p, uint32_t i, uint32_
     }
 
     if (p.postMul != MUL_NONE) { // src/reformat.c:1574-1585 on the stored integers
-        r = alphaMulInt(r, a, (unsigned)o.maxv, o.maxf, p.postMul);
-        g = alphaMulInt(g, a, (unsigned)o.maxv, o.maxf, p.postMul);
-        b = alphaMulInt(b, a, (unsigned)o.maxv, o.maxf, p.postMul);
+        if (p.postMulFx) { // a libyuv build attenuates 8-bit RGBA / BGRA with libyuv, src/alpha.c:163,350
+            r = fxAlphaMul(r, a, p.postMul), g = fxAlphaMul(g, a, p.postMul), b = fxAlphaMul(b, a, p.postMul);
+        } else {
+            r = alphaMulInt(r, a, (unsigned)o.maxv, o.maxf, p.postMul);
+            g = alphaMulInt(g, a, (unsigned)o.maxv, o.maxf, p.postMul);
+            b = alphaMulInt(b, a, (unsigned)o.maxv, o.maxf, p.postMul);
+        }
     }
 
     if (o.isFloat) { // depth 16 only

@@ -224,10 +224,148 @@ static bool prepareState(const avifImage * image, const avifRGBImage * rgb, YuvS
     return true;
 }
 
+
+// ---- the integer path: what libavif hands to libyuv (src/reformat_libyuv.c) ---------------------------------------
+
+namespace {
+
+// YuvConstants as libavif selects them (src/reformat_libyuv.c:775-904), numbers per SURVEY.md appendix D.1
+bool selectFixedPointMatrix(const avifImage * image, FixedPointMatrix * out)
+{
+    unsigned mc = image->matrixCoefficients;
+    if (image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400 && mc == AVIF_MATRIX_COEFFICIENTS_IDENTITY)
+        mc = AVIF_MATRIX_COEFFICIENTS_BT601; // :777-781
+    enum { NONE, BT709, BT601, BT2020 } family = NONE;
+    if (mc == AVIF_MATRIX_COEFFICIENTS_BT709) {
+        family = BT709;
+    } else if (mc == AVIF_MATRIX_COEFFICIENTS_BT470BG || mc == AVIF_MATRIX_COEFFICIENTS_BT601 || mc == AVIF_MATRIX_COEFFICIENTS_UNSPECIFIED) {
+        family = BT601;
+    } else if (mc == AVIF_MATRIX_COEFFICIENTS_BT2020_NCL) {
+        family = BT2020;
+    } else if (mc == AVIF_MATRIX_COEFFICIENTS_CHROMA_DERIVED_NCL) {
+        const unsigned cp = image->colorPrimaries;
+        family = (cp == 1 || cp == 2) ? BT709 : (cp == 5 || cp == 6) ? BT601 : (cp == 9) ? BT2020 : NONE;
+    }
+    const bool full = image->yuvRange == AVIF_RANGE_FULL;
+    static const FixedPointMatrix limited[3] = { { 18997, -1160, 128, 14, 34, 115 }, { 18997, -1160, 128, 25, 52, 102 }, { 19003, -1160, 128, 12, 42, 107 } };
+    static const FixedPointMatrix fullRange[3] = { { 16320, 32, 119, 12, 30, 101 }, { 16320, 32, 113, 22, 46, 90 }, { 16320, 32, 120, 11, 37, 94 } };
+    if (family == NONE)
+        return false;
+    *out = (full ? fullRange : limited)[(int)family - 1];
+    return true;
+}
+
+// libyuv entry points per RGB layout as bit sets over avifPixelFormat (the lookup tables of src/reformat_libyuv.c:551-712)
+constexpr uint8_t Y444 = 1u << AVIF_PIXEL_FORMAT_YUV444, Y422 = 1u << AVIF_PIXEL_FORMAT_YUV422, Y420 = 1u << AVIF_PIXEL_FORMAT_YUV420;
+struct FxEntries
+{
+    uint8_t filter8, alphaFilter8, matrix8, alphaMatrix8; // 8-bit planes: *MatrixFilter, *AlphaTo*MatrixFilter, *Matrix, *AlphaTo*Matrix
+    uint8_t filter10, matrix10;                           // 10-bit planes (each has its alpha twin)
+    uint8_t matrix12;                                     // 12-bit planes (no alpha twin)
+    uint8_t mono;                                         // I400ToARGBMatrix
+};
+constexpr FxEntries kRgb24 = { Y422 | Y420, 0, Y444 | Y420, 0, 0, 0, 0, 0 };
+constexpr FxEntries kArgbWord = { Y422 | Y420, Y422 | Y420, Y444 | Y422 | Y420, Y444 | Y422 | Y420, Y422 | Y420, Y444 | Y422 | Y420, Y420, 1 };
+constexpr FxEntries kRgbaWord = { 0, 0, Y422 | Y420, 0, 0, 0, 0, 0 };
+const FxEntries * fxEntriesFor(int format)
+{
+    switch (format) {
+        case AVIF_RGB_FORMAT_RGB:
+        case AVIF_RGB_FORMAT_BGR: return &kRgb24;      // libyuv "RGB24"/"RAW"
+        case AVIF_RGB_FORMAT_RGBA:
+        case AVIF_RGB_FORMAT_BGRA: return &kArgbWord;  // libyuv "ARGB"/"ABGR" (word order)
+        case AVIF_RGB_FORMAT_ARGB:
+        case AVIF_RGB_FORMAT_ABGR:
+        case AVIF_RGB_FORMAT_RGB_565: return &kRgbaWord; // libyuv "RGBA"/"BGRA" and RGB565: nearest-only entries
+        default: return nullptr;                        // gray layouts: no entry
+    }
+}
+
+struct FxRoute
+{
+    bool mono, filter, alpha;
+    int native; // 8, 10, 12
+};
+
+// getLibYUVConversionFunction, src/reformat_libyuv.c:714-772
+bool selectFixedPointRoute(int yuvFormat, int depth, const avifRGBImage * rgb, bool alphaPreferred, FxRoute * r)
+{
+    const FxEntries * e = fxEntriesFor((int)rgb->format);
+    if (!e)
+        return false;
+    const uint8_t bit = (uint8_t)(1u << yuvFormat);
+    const bool nearestOk = rgb->chromaUpsampling != AVIF_CHROMA_UPSAMPLING_BILINEAR && rgb->chromaUpsampling != AVIF_CHROMA_UPSAMPLING_BEST_QUALITY;
+    *r = FxRoute { false, false, false, 8 };
+    if (depth > 8) {
+        if (yuvFormat != AVIF_PIXEL_FORMAT_YUV444 && depth == 10 && (e->filter10 & bit)) {
+            *r = FxRoute { false, true, alphaPreferred, 10 };
+            return true;
+        }
+        if (yuvFormat == AVIF_PIXEL_FORMAT_YUV444 || nearestOk) {
+            if (depth == 10 && (e->matrix10 & bit)) {
+                *r = FxRoute { false, false, alphaPreferred, 10 };
+                return true;
+            }
+            if (depth == 12 && (e->matrix12 & bit)) {
+                *r = FxRoute { false, false, false, 12 };
+                return true;
+            }
+        }
+        // no high-bit-depth entry: an 8-bit one after a downshift, :743-745
+    }
+    if (yuvFormat == AVIF_PIXEL_FORMAT_YUV400) {
+        r->mono = true;
+        return e->mono != 0;
+    }
+    if (yuvFormat != AVIF_PIXEL_FORMAT_YUV444) {
+        if (alphaPreferred && (e->alphaFilter8 & bit)) {
+            r->filter = r->alpha = true;
+            return true;
+        }
+        if (e->filter8 & bit) {
+            r->filter = true;
+            return true;
+        }
+        if (!nearestOk)
+            return false;
+    }
+    if (alphaPreferred && (e->alphaMatrix8 & bit)) {
+        r->alpha = true;
+        return true;
+    }
+    return (e->matrix8 & bit) != 0;
+}
+
+// which (range, RGB layout, YUV layout) libyuv converts to YUV for libavif, src/reformat_libyuv.c:293-377
+bool fixedPointRgbToYuvCovered(const avifImage * image, const avifRGBImage * rgb)
+{
+    if (image->depth != 8 || rgb->depth != 8)
+        return false;
+    if (image->matrixCoefficients != AVIF_MATRIX_COEFFICIENTS_BT470BG && image->matrixCoefficients != AVIF_MATRIX_COEFFICIENTS_BT601)
+        return false;
+    const int f = (int)rgb->format, yf = (int)image->yuvFormat;
+    if (f < AVIF_RGB_FORMAT_RGB || f > AVIF_RGB_FORMAT_ABGR)
+        return false;
+    const bool full = image->yuvRange == AVIF_RANGE_FULL;
+    if (yf == AVIF_PIXEL_FORMAT_YUV400)
+        return full ? (f != AVIF_RGB_FORMAT_ARGB) : (f == AVIF_RGB_FORMAT_BGRA);
+    if (yf != AVIF_PIXEL_FORMAT_YUV444 && yf != AVIF_PIXEL_FORMAT_YUV422 && yf != AVIF_PIXEL_FORMAT_YUV420)
+        return false;
+    if (!full || f == AVIF_RGB_FORMAT_RGB)
+        return true;
+    return yf != AVIF_PIXEL_FORMAT_YUV444; // no full-range 4:4:4 entry for the other layouts, :352-358
+}
+
+bool attenuateCovered(const avifRGBImage * rgb) // src/reformat_libyuv.c:1120-1133
+{
+    return rgb->depth == 8 && (rgb->format == AVIF_RGB_FORMAT_RGBA || rgb->format == AVIF_RGB_FORMAT_BGRA);
+}
+
+} // namespace
+
 avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, uint32_t tuning, YuvToRgbPlan * out,
                             bool colorOnly, bool reformatAlphaHook)
 {
-    (void)arithMode;
     if (!image->yuvPlanes[AVIF_CHAN_Y] || rgb->maxThreads < 0)
         return AVIF_RESULT_REFORMAT_FAILED; // src/reformat.c:1653-1655
     memset(out, 0, sizeof(*out));
@@ -259,6 +397,7 @@ avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, c
             mul = MUL_UNMULTIPLY;
         }
     }
+    const int mulOfTheCall = mul; // what avifImageYUVToRGB derived before it reached the hook
     if (colorOnly) {
         mul = MUL_NONE;        // src/reformat.c:1574-1585 stays with the caller
         out->rgb.isFloat = 0;  // and so does src/reformat.c:1588-1590
@@ -290,12 +429,54 @@ avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, c
     out->postMul = fast ? mul : MUL_NONE;
     out->arith = ARITH_FLOAT;
     out->tuning = tuning;
+
+    // A libavif built with libyuv asks libyuv first, src/reformat.c:1453-1462 (the hook is that very call).
+    const bool askLibyuv = arithMode != AVIFHIP_ARITHMETIC_FLOAT && (arithMode == AVIFHIP_ARITHMETIC_LIBYUV || !rgb->avoidLibYUV || colorOnly) &&
+                           (mul == MUL_NONE || rgbHasAlpha);
+    FxRoute route;
+    const bool hasAlphaPlane = image->alphaPlane && image->alphaRowBytes;
+    if (askLibyuv && rgb->depth == 8 && (image->depth == 8 || image->depth == 10 || image->depth == 12) && // src/reformat_libyuv.c:939
+        selectFixedPointMatrix(image, &out->fx) &&
+        selectFixedPointRoute((int)image->yuvFormat, (int)image->depth, rgb, reformatAlpha && hasAlphaPlane, &route)) {
+        out->arith = ARITH_LIBYUV;
+        out->identityCopy = 0;
+        out->inLoopMul = MUL_NONE; // libyuv never (un)multiplies (attenuate = 0): always the post-pass, src/reformat.c:1574-1585
+        out->postMul = mul;
+        out->bilinear = (route.filter && !nearest) ? 1 : 0; // src/reformat_libyuv.c:965-968; plain *Matrix entries are nearest
+        out->fxNative = route.native;
+        out->fxDownshift = (image->depth > 8 && route.native == 8) ? (int)image->depth - 8 : 0; // :906-930
+        out->fxMono = route.mono ? 1 : 0;
+        if (!rgbHasAlpha) {
+            out->alphaSource = ALPHA_KEEP; // RGB / BGR / 565: there is no A byte
+        } else if (route.alpha) {
+            out->alphaSource = ALPHA_PLANE;
+            out->fxAlpha = FXA_SHIFT;
+            out->fxAlphaShift = (route.native == 10) ? 2 : out->fxDownshift;
+        } else if (hasAlphaPlane && reformatAlpha) {
+            out->alphaSource = ALPHA_PLANE; // libyuv's 255, then avifReformatAlpha over it, src/reformat.c:1464-1486
+            out->fxAlpha = FXA_FLOAT;
+        } else {
+            out->alphaSource = ALPHA_FILL; // libyuv's 255, even under rgb->ignoreAlpha
+            out->fxAlpha = FXA_OPAQUE;
+        }
+    }
+    if (colorOnly && arithMode != AVIFHIP_ARITHMETIC_FLOAT && out->arith != ARITH_LIBYUV && mulOfTheCall != MUL_NONE) {
+        // libyuv has no entry here, so a stock libavif converts with its own loops -- and if that is the slow loop, the
+        // pending (un)multiply happens INSIDE it in fp32 (src/reformat.c:894-947,1563-1566), which a hook cannot reproduce
+        // (after AVIF_RESULT_OK libavif runs the integer post-pass).  Decline: libavif's CPU code keeps the result identical.
+        bool fastOfTheCall = false;
+        if (!out->rgb.isGray && (!out->yuv.hasColor || image->yuvFormat == AVIF_PIXEL_FORMAT_YUV444 || nearest) && rgbHasAlpha)
+            fastOfTheCall = (out->yuv.mode == MODE_COEFF) || out->identityCopy;
+        if (!fastOfTheCall)
+            return AVIF_RESULT_NOT_IMPLEMENTED;
+    }
+    // avifRGBImagePremultiplyAlpha / Unpremultiply ask libyuv whatever avoidLibYUV says, src/alpha.c:163,350
+    out->postMulFx = (arithMode != AVIFHIP_ARITHMETIC_FLOAT && out->postMul != MUL_NONE && attenuateCovered(rgb)) ? 1 : 0;
     return AVIF_RESULT_OK;
 }
 
 avifResult makeRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, int arithMode, RgbToYuvPlan * out)
 {
-    (void)arithMode;
     if (!rgb->pixels || rgb->format == AVIF_RGB_FORMAT_RGB_565)
         return AVIF_RESULT_REFORMAT_FAILED; // src/reformat.c:223-225
     memset(out, 0, sizeof(*out));
@@ -314,12 +495,17 @@ avifResult makeRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, i
             out->mul = MUL_UNMULTIPLY;
     }
     out->arith = ARITH_FLOAT;
+    // src/reformat.c:264-272: libyuv is asked unless the source is gray, an alpha (un)multiply is pending or avoidLibYUV
+    if (arithMode != AVIFHIP_ARITHMETIC_FLOAT && (arithMode == AVIFHIP_ARITHMETIC_LIBYUV || !rgb->avoidLibYUV) && !out->rgb.isGray &&
+        out->mul == MUL_NONE && fixedPointRgbToYuvCovered(image, rgb)) {
+        out->arith = ARITH_LIBYUV;
+        out->fxFullRange = (image->yuvRange == AVIF_RANGE_FULL) ? 1 : 0;
+    }
     return AVIF_RESULT_OK;
 }
 
 avifResult makeAlphaMulPlan(const avifRGBImage * rgb, bool unmultiply, int arithMode, AlphaMulPlan * out)
 {
-    (void)arithMode;
     if (!rgb->pixels || !rgb->rowBytes)
         return AVIF_RESULT_REFORMAT_FAILED; // src/alpha.c:154-156, :341-343
     if (!rgbFormatHasAlpha((int)rgb->format))
@@ -330,7 +516,7 @@ avifResult makeAlphaMulPlan(const avifRGBImage * rgb, bool unmultiply, int arith
     out->width = rgb->width;
     out->height = rgb->height;
     out->unmultiply = unmultiply ? 1 : 0;
-    out->arith = ARITH_FLOAT;
+    out->arith = (arithMode != AVIFHIP_ARITHMETIC_FLOAT && attenuateCovered(rgb)) ? ARITH_LIBYUV : ARITH_FLOAT; // src/alpha.c:163,350
     return AVIF_RESULT_OK;
 }
 

@@ -16,6 +16,12 @@ enum AlphaSource : int {
     ALPHA_PLANE = 2  // from the alpha plane, copy or depth rescale (avifReformatAlpha, src/alpha.c:37)
 };
 enum Arith : int { ARITH_FLOAT = 0, ARITH_LIBYUV = 1 };
+// How the A channel of a fixed-point (libyuv-arithmetic) conversion is produced, src/reformat_libyuv.c:956-959,982-1100
+enum FxAlpha : int {
+    FXA_OPAQUE = 0, // libyuv's own 255 (also when rgb->ignoreAlpha: libyuv always writes the channel)
+    FXA_SHIFT = 1,  // an *Alpha* entry: plane sample >> fxAlphaShift, saturated to 255
+    FXA_FLOAT = 2   // libyuv wrote 255, then avifReformatAlpha (src/alpha.c:37-149) overwrote it: copy or fp32 rescale
+};
 
 // 1/d of a plan constant d, split into RN(1/d) and the rounded remainder.  For the divisors on the verified list
 // (exactdiv.h)  fma(x, hi, x * lo)  equals the correctly rounded IEEE-754 binary32 quotient x / d bit for bit.
@@ -88,9 +94,16 @@ struct YuvToRgbPlan
     int32_t inLoopMul;         // MulMode applied in fp32 before quantisation (slow path, :894-947)
     int32_t postMul;           // MulMode applied on the quantised integers (fast path + :1574-1585)
     int32_t identityCopy;      // src/reformat.c:1278-1309
-    int32_t arith;             // Arith
-    FixedPointMatrix fx;       // valid when arith == ARITH_LIBYUV
-    int32_t fxShiftY, fxShiftUV, fxAlphaShift; // libyuv high-bit-depth reductions (Appendix D.3)
+    int32_t arith;             // Arith: which arithmetic converts the colour channels
+    // ---- arith == ARITH_LIBYUV ----
+    FixedPointMatrix fx;
+    int32_t fxNative;          // 8, 10 (I010/I210/I410: y<<6|y>>4, chroma>>2 after upsampling) or 12 (I012: y<<4|y>>8, chroma>>4)
+    int32_t fxDownshift;       // Convert16To8Plane before an 8-bit entry: every sample >> fxDownshift, saturated to 255
+    int32_t fxMono;            // I400ToARGBMatrix: chroma = 128
+    int32_t fxAlpha;           // FxAlpha
+    int32_t fxAlphaShift;      // FXA_SHIFT: 0 (8-bit), 2 (native 10-bit) or the downshift
+    // ---- both arithmetics ----
+    int32_t postMulFx;         // the integer post-pass is libyuv's ARGBAttenuate / ARGBUnattenuate (appendix D.4)
     uint32_t tuning;           // TuningBits: performance knobs that never change results
 };
 
@@ -109,7 +122,7 @@ struct RgbToYuvPlan
     uint32_t width, height;
     int32_t mul;         // MulMode applied in fp32 (src/reformat.c:325-358)
     int32_t alphaSource; // ALPHA_KEEP (no alpha plane) / ALPHA_FILL / ALPHA_PLANE(= from rgb alpha channel)
-    int32_t arith;
+    int32_t arith;       // ARITH_LIBYUV: appendix D.5 (8-bit BT.601 only)
     int32_t fxFullRange;
 };
 
@@ -118,9 +131,15 @@ struct AlphaMulPlan
     RgbSide rgb;
     uint32_t width, height;
     int32_t unmultiply;
-    int32_t arith;
+    int32_t arith; // ARITH_LIBYUV: ARGBAttenuate / ARGBUnattenuate (8-bit RGBA / BGRA)
 };
 
+// arithMode (avifhipArithmetic): which libavif BUILD the result must equal.
+//   AUTO   a libavif built with libyuv (the default build): libyuv's fixed-point arithmetic wherever that build hands
+//          the work to libyuv -- honouring rgb->avoidLibYUV exactly like src/reformat.c:1453 and :264 do, and NOT
+//          honouring it for (un)premultiply exactly like src/alpha.c:163,350 -- the fp32 path everywhere else;
+//   FLOAT  a libavif built without libyuv: fp32 everywhere;
+//   LIBYUV as AUTO but rgb->avoidLibYUV is ignored.
 // Host-side derivation (plan.cpp). Return an avifResult; AVIF_RESULT_OK means the plan is valid.
 // colorOnly: the job libavif hands to its accelerated-backend hook (avifImageYUVToRGBLibYUV, include/avif/internal.h:
 // 349-363): colour conversion without any alpha (un)multiply or half-float pass (the caller runs those afterwards),

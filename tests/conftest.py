@@ -23,4 +23,15 @@ def hip():
     lib = native.load()
     if lib.avifhipDeviceCount() <= 0:
         pytest.skip("no HIP device visible")
+    # Tests using this fixture compare with the fp32 oracle (a libavif built without libyuv): pin that arithmetic.
+    # The integer path (the library's default, AVIFHIP_ARITHMETIC_AUTO) is tested through hip_auto_arithmetic.
+    lib.avifhipSetArithmetic(1)
     return lib
+
+
+@pytest.fixture()
+def hip_auto_arithmetic(hip):
+    """The library's default arithmetic: what a libavif built with libyuv computes (integer path where libyuv serves)."""
+    hip.avifhipSetArithmetic(0)
+    yield hip
+    hip.avifhipSetArithmetic(1)

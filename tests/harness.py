@@ -408,3 +408,51 @@ def r2y_sweep(sizes, n_random: int, seed: int = 11) -> list:
         seen.add(c)
         out.append(c)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# the sub-space libavif hands to libyuv (the reference's integer path)
+
+def libyuv_y2r_cases(sizes, n_random=1500, seed=23):
+    """Dense sample of the sub-space libavif hands to libyuv: 8-bit RGB outputs."""
+    rnd = random.Random(seed)
+    cases = []
+    for fmt, yf, yd, up in itertools.product(range(7), (1, 2, 3, 4), (8, 10, 12), (0, 1, 2, 3, 4)):
+        cases.append(Y2RCase(38, 11, rgb_format=fmt, yuv_format=yf, yuv_depth=yd, upsampling=up, matrix=rnd.choice((1, 5, 6, 2, 9)),
+                               yuv_range=rnd.choice((0, 1)), alpha=rnd.random() < 0.4, avoid_libyuv=False, seed=rnd.getrandbits(31) | 1))
+    for mc, cp, yr, yf in itertools.product((0, 1, 2, 4, 5, 6, 7, 8, 9, 12), (1, 2, 5, 6, 9, 12), (0, 1), (1, 3, 4)):
+        c = Y2RCase(21, 9, matrix=mc, color_primaries=cp, yuv_range=yr, yuv_format=yf, avoid_libyuv=False, rgb_format=rnd.choice((0, 1, 4)))
+        if valid_y2r(c):
+            cases.append(c)
+    for _ in range(n_random):
+        w, h = rnd.choice(sizes)
+        cases.append(Y2RCase(w, h, yuv_depth=rnd.choice((8, 8, 10, 12)), yuv_format=rnd.choice((1, 2, 3, 3, 4)), yuv_range=rnd.choice((0, 1)),
+                               matrix=rnd.choice((1, 5, 6, 2, 9, 12)), color_primaries=rnd.choice((1, 2, 5, 6, 9)), alpha=rnd.random() < 0.5,
+                               image_premultiplied=rnd.random() < 0.3, rgb_depth=8, rgb_format=rnd.choice(range(7)),
+                               upsampling=rnd.choice((0, 1, 2, 3, 4)), rgb_premultiplied=rnd.random() < 0.3, ignore_alpha=rnd.random() < 0.2,
+                               avoid_libyuv=False, row_pad=rnd.choice((0, 0, 6, 64)), seed=rnd.getrandbits(31) | 1,
+                               pattern=rnd.choice(("random", "random", "gradient"))))
+    seen, out = set(), []
+    for c in cases:
+        if c not in seen and valid_y2r(c):
+            seen.add(c)
+            out.append(c)
+    return out
+
+
+
+def libyuv_r2y_cases(sizes, n_random=1200, seed=29):
+    rnd = random.Random(seed)
+    cases = []
+    for fmt, yf, yr, mc in itertools.product((0, 1, 2, 3, 4, 5, 7, 8, 9), (1, 2, 3, 4), (0, 1), (5, 6, 2, 1)):
+        cases.append(R2YCase(23, 7, rgb_depth=8, yuv_depth=8, rgb_format=fmt, yuv_format=yf, yuv_range=yr, matrix=mc, avoid_libyuv=False,
+                               seed=rnd.getrandbits(31) | 1))
+    for _ in range(n_random):
+        w, h = rnd.choice(sizes)
+        cases.append(R2YCase(w, h, rgb_depth=8, yuv_depth=8, rgb_format=rnd.choice((0, 1, 2, 3, 4, 5)), matrix=rnd.choice((5, 6)),
+                               yuv_range=rnd.choice((0, 1)), yuv_format=rnd.choice((1, 2, 3, 3, 4)), avoid_libyuv=False,
+                               opaque=rnd.random() < 0.3, ignore_alpha=rnd.random() < 0.3, rgb_premultiplied=rnd.random() < 0.15,
+                               row_pad=rnd.choice((0, 6, 64)), seed=rnd.getrandbits(31) | 1))
+    return cases
+
+

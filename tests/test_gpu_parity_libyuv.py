@@ -1,0 +1,130 @@
+"""Parity tests proper (-m gpu) for the reference's INTEGER path: the HIP library in its default arithmetic
+(AVIFHIP_ARITHMETIC_AUTO = what a libavif built with libyuv computes) against the integer-path oracle
+(oracle/libyuv_oracle.c, pinned against the libyuv-enabled binary by tests/test_libyuv_oracle.py and the
+tests/golden/yuvlib_* fixtures).  Bit-exact on every byte of every output buffer, through the C ABI on host buffers
+and on device-resident buffers."""
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+import harness as H
+from libavif_amd import abi, farm, native
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [(37, 21), (1, 1), (2, 2), (1, 6), (6, 1), (3, 5), (127, 10), (64, 33)]
+TILED = [(512, 16), (300, 21), (256, 8), (777, 35), (1027, 18)]
+
+
+def _compare_y2r(be, oracle, cases):
+    bad, kernels = [], {}
+    for c in cases:
+        ro, po = H.run_y2r(oracle, c)
+        rh, ph = H.run_y2r(be, c)
+        k = native.last_kernel().split("<")[0]
+        kernels[k] = kernels.get(k, 0) + 1
+        if ro != rh or not np.array_equal(po, ph):
+            bad.append(f"{c.ident()} [{native.last_kernel()}]: results {ro}/{rh}" + ("" if ro != rh else " " + H.describe_diff(po, ph)))
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:25])
+    return kernels
+
+
+def test_yuv_to_rgb_libyuv_domain_host(hip_auto_arithmetic):
+    kernels = _compare_y2r(H.hip_host_backend(), H.oracle_libyuv_backend(), H.libyuv_y2r_cases(SMALL + TILED, n_random=900))
+    assert sum(v for k, v in kernels.items() if "fixed" in k) > 600, kernels
+
+
+def test_yuv_to_rgb_libyuv_domain_device(hip_auto_arithmetic):
+    kernels = _compare_y2r(H.HipDeviceBackend(), H.oracle_libyuv_backend(), H.libyuv_y2r_cases(SMALL + TILED, n_random=400, seed=77))
+    assert sum(v for k, v in kernels.items() if "fixed" in k) > 300, kernels
+
+
+def test_yuv_to_rgb_general_sweep_default_arithmetic(hip_auto_arithmetic):
+    """The whole configuration space with avoidLibYUV = 0 (the API default) and a slice with avoidLibYUV = 1."""
+    cases = [replace(c, avoid_libyuv=False) for c in H.y2r_sweep(SMALL + TILED[:2], n_random=700, seed=201)]
+    cases += H.y2r_sweep(SMALL[:3] + TILED[:1], n_random=200, seed=9)
+    _compare_y2r(H.hip_host_backend(), H.oracle_libyuv_backend(), cases)
+
+
+def test_yuv_to_rgb_generic_kernels_only(hip_auto_arithmetic):
+    hip_auto_arithmetic.avifhipSetTiledKernels(0)
+    try:
+        _compare_y2r(H.hip_host_backend(), H.oracle_libyuv_backend(), H.libyuv_y2r_cases(TILED[:3], n_random=300, seed=5))
+    finally:
+        hip_auto_arithmetic.avifhipSetTiledKernels(1)
+
+
+def test_forced_libyuv_arithmetic_ignores_avoid_flag(hip):
+    hip.avifhipSetArithmetic(2)
+    try:
+        for c in H.libyuv_y2r_cases([(300, 21)], n_random=60, seed=3)[:200]:
+            ro, po = H.run_y2r(H.oracle_libyuv_backend(), c)
+            rh, ph = H.run_y2r(H.hip_host_backend(), replace(c, avoid_libyuv=True))
+            assert ro == rh and np.array_equal(po, ph), c.ident()
+    finally:
+        hip.avifhipSetArithmetic(1)
+
+
+def _compare_r2y(be, oracle, cases, padding=True):
+    bad, fixed = [], 0
+    for c in cases:
+        ro, io = H.run_r2y(oracle, c)
+        rh, ih = H.run_r2y(be, c)
+        fixed += "fixed" in native.last_kernel()
+        d = None if ro != rh else H.planes_equal(io, ih, padding=padding)
+        if ro != rh or d:
+            bad.append(f"{c.ident()} [{native.last_kernel()}]: results {ro}/{rh} {d or ''}")
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:25])
+    return fixed
+
+
+def test_rgb_to_yuv_host(hip_auto_arithmetic):
+    cases = H.libyuv_r2y_cases(SMALL + TILED[:3], n_random=600) + [replace(c, avoid_libyuv=False) for c in H.r2y_sweep(SMALL, n_random=200, seed=61)]
+    assert _compare_r2y(H.hip_host_backend(), H.oracle_libyuv_backend(), cases) > 400
+
+
+def test_rgb_to_yuv_device(hip_auto_arithmetic):
+    cases = H.libyuv_r2y_cases(SMALL + TILED[:2], n_random=300, seed=31)
+    assert _compare_r2y(H.HipDeviceBackend(), H.oracle_libyuv_backend(), cases, padding=False) > 200
+
+
+@pytest.mark.parametrize("fmt", [abi.AVIF_RGB_FORMAT_RGBA, abi.AVIF_RGB_FORMAT_BGRA, abi.AVIF_RGB_FORMAT_ARGB])
+def test_exhaustive_alpha_pairs_8bit(hip_auto_arithmetic, fmt):
+    """All 65,536 (colour, alpha) pairs: ARGBAttenuate / ARGBUnattenuate for RGBA and BGRA, fp32 for ARGB."""
+    o = H.oracle_libyuv_backend()
+    a_first = fmt == abi.AVIF_RGB_FORMAT_ARGB
+    for be in (H.hip_host_backend(), H.HipDeviceBackend()):
+        for which in ("premultiply", "unpremultiply"):
+            a = abi.make_rgb(256, 256, 8, fmt)
+            ch = a.channels()
+            cols = [k for k in range(4) if k != (0 if a_first else 3)]
+            ch[:, :, cols[0]] = np.arange(256)[None, :]
+            ch[:, :, cols[1]] = 255 - np.arange(256)[None, :]
+            ch[:, :, cols[2]] = (np.arange(256)[None, :] * 7) % 256
+            ch[:, :, 0 if a_first else 3] = np.arange(256)[:, None]
+            b = abi.make_rgb(256, 256, 8, fmt)
+            b.pixels[...] = a.pixels
+            if isinstance(be, H.HipDeviceBackend):
+                be.bind_host(b.struct, b)
+            assert getattr(o, which)(a.struct) == getattr(be, which)(b.struct) == 0
+            assert np.array_equal(a.pixels, b.pixels), (be.name, which, H.describe_diff(a.pixels, b.pixels))
+            assert ("fixed" in native.last_kernel()) == (fmt != abi.AVIF_RGB_FORMAT_ARGB)
+
+
+def test_grid_farm_integer_path_equals_whole_canvas(hip_auto_arithmetic):
+    """Tiles of a stitched canvas converted independently (chroma edge rules against the canvas) reproduce the
+    whole-canvas conversion of the integer path, seams included."""
+    conv = farm.HipRectConverter()
+    for case, (tw, th) in [
+        (H.Y2RCase(1100, 150, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=8, upsampling=4, avoid_libyuv=False), (512, 64)),
+        (H.Y2RCase(777, 66, yuv_depth=8, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=8, upsampling=4, avoid_libyuv=False), (256, 32)),
+        (H.Y2RCase(640, 49, yuv_depth=8, yuv_format=2, yuv_range=1, matrix=6, rgb_depth=8, rgb_format=0, upsampling=4, avoid_libyuv=False), (320, 16)),
+    ]:
+        res, whole = H.run_y2r(H.oracle_libyuv_backend(), case)
+        assert res == 0
+        canvas = H.make_y2r_inputs(case)
+        rects = farm.grid_rects(case.w, case.h, tw, th)
+        out = H.make_y2r_output(case)
+        farm.convert_shard(canvas, out, rects, 0, 1, conv)
+        assert np.array_equal(out.pixels, whole), (case.ident(), H.describe_diff(whole, out.pixels))

@@ -51,58 +51,16 @@ def test_yuv_to_rgb_general_sweep(backends):
     assert integer > 100  # the sweep really reaches the fixed-point path
 
 
-def libyuv_domain_cases(n_random=1500, seed=23):
-    """Dense sample of the sub-space libavif hands to libyuv: 8-bit RGB outputs."""
-    rnd = random.Random(seed)
-    cases = []
-    for fmt, yf, yd, up in itertools.product(range(7), (1, 2, 3, 4), (8, 10, 12), (0, 1, 2, 3, 4)):
-        cases.append(H.Y2RCase(38, 11, rgb_format=fmt, yuv_format=yf, yuv_depth=yd, upsampling=up, matrix=rnd.choice((1, 5, 6, 2, 9)),
-                               yuv_range=rnd.choice((0, 1)), alpha=rnd.random() < 0.4, avoid_libyuv=False, seed=rnd.getrandbits(31) | 1))
-    for mc, cp, yr, yf in itertools.product((0, 1, 2, 4, 5, 6, 7, 8, 9, 12), (1, 2, 5, 6, 9, 12), (0, 1), (1, 3, 4)):
-        c = H.Y2RCase(21, 9, matrix=mc, color_primaries=cp, yuv_range=yr, yuv_format=yf, avoid_libyuv=False, rgb_format=rnd.choice((0, 1, 4)))
-        if H.valid_y2r(c):
-            cases.append(c)
-    for _ in range(n_random):
-        w, h = rnd.choice(SIZES)
-        cases.append(H.Y2RCase(w, h, yuv_depth=rnd.choice((8, 8, 10, 12)), yuv_format=rnd.choice((1, 2, 3, 3, 4)), yuv_range=rnd.choice((0, 1)),
-                               matrix=rnd.choice((1, 5, 6, 2, 9, 12)), color_primaries=rnd.choice((1, 2, 5, 6, 9)), alpha=rnd.random() < 0.5,
-                               image_premultiplied=rnd.random() < 0.3, rgb_depth=8, rgb_format=rnd.choice(range(7)),
-                               upsampling=rnd.choice((0, 1, 2, 3, 4)), rgb_premultiplied=rnd.random() < 0.3, ignore_alpha=rnd.random() < 0.2,
-                               avoid_libyuv=False, row_pad=rnd.choice((0, 0, 6, 64)), seed=rnd.getrandbits(31) | 1,
-                               pattern=rnd.choice(("random", "random", "gradient"))))
-    seen, out = set(), []
-    for c in cases:
-        if c not in seen and H.valid_y2r(c):
-            seen.add(c)
-            out.append(c)
-    return out
-
-
 def test_yuv_to_rgb_libyuv_domain(backends):
     o, p, f = backends
-    cases = libyuv_domain_cases()
+    cases = H.libyuv_y2r_cases(SIZES)
     integer = _compare_y2r(o, p, f, cases)
     assert integer > len(cases) // 2
 
 
-def libyuv_r2y_cases(n_random=1200, seed=29):
-    rnd = random.Random(seed)
-    cases = []
-    for fmt, yf, yr, mc in itertools.product((0, 1, 2, 3, 4, 5, 7, 8, 9), (1, 2, 3, 4), (0, 1), (5, 6, 2, 1)):
-        cases.append(H.R2YCase(23, 7, rgb_depth=8, yuv_depth=8, rgb_format=fmt, yuv_format=yf, yuv_range=yr, matrix=mc, avoid_libyuv=False,
-                               seed=rnd.getrandbits(31) | 1))
-    for _ in range(n_random):
-        w, h = rnd.choice(SIZES)
-        cases.append(H.R2YCase(w, h, rgb_depth=8, yuv_depth=8, rgb_format=rnd.choice((0, 1, 2, 3, 4, 5)), matrix=rnd.choice((5, 6)),
-                               yuv_range=rnd.choice((0, 1)), yuv_format=rnd.choice((1, 2, 3, 3, 4)), avoid_libyuv=False,
-                               opaque=rnd.random() < 0.3, ignore_alpha=rnd.random() < 0.3, rgb_premultiplied=rnd.random() < 0.15,
-                               row_pad=rnd.choice((0, 6, 64)), seed=rnd.getrandbits(31) | 1))
-    return cases
-
-
 def test_rgb_to_yuv(backends):
     o, p, f = backends
-    cases = [replace(c, avoid_libyuv=False) for c in H.r2y_sweep(SIZES, n_random=600, seed=103)] + libyuv_r2y_cases()
+    cases = [replace(c, avoid_libyuv=False) for c in H.r2y_sweep(SIZES, n_random=600, seed=103)] + H.libyuv_r2y_cases(SIZES)
     bad, integer = [], 0
     for c in cases:
         ro, io = H.run_r2y(o, c)
