@@ -11,6 +11,8 @@
 //                             kernels form);
 //   * verifiedIntegerDivisor  the same full-mantissa sweep, plus every integer x in [-65536, 65536]
 //                             (code points minus bias).
+//   * verifiedChromaDenominator  2*(1-kb) and 2*(1-kr) of the encode direction (src/reformat.c:384-385): the
+//                             full-mantissa sweep (the dividends B-Y, R-Y are arbitrary fp32 values in [-1, 1]).
 // Divisors that are not listed keep the IEEE divide (the universal kernels).
 #pragma once
 
@@ -64,6 +66,23 @@ inline bool verifiedIntegerDivisor(float d)
 {
     for (float v : kVerifiedIntegerDivisors)
         if (v == d)
+            return true;
+    return false;
+}
+
+// 2*(1-kb), 2*(1-kr) for every matrixCoefficients / colorPrimaries combination libavif accepts (same enumeration as kg),
+// EXCEPT 0x3fee5bb7 (1.86217391, a primaries-derived value): the enumeration finds 6 operands for which the reciprocal
+// form is off by one ulp, so plans with that divisor keep the IEEE divide.
+static const uint32_t kVerifiedChromaDenBits[] = {
+    0x3fb33333u, 0x3fb374bcu, 0x3fb376ecu, 0x3fbcbfadu, 0x3fbcbfb2u, 0x3fbf1507u, 0x3fc4abfeu, 0x3fc561ebu, 0x3fc72ab9u, 0x3fc9907cu,
+    0x3fc9930cu, 0x3fc9a1b3u, 0x3fc9ba5eu, 0x3fca5ec0u, 0x3fe2a8c8u, 0x3fe2d0e5u, 0x3fe3d70au, 0x3fe76ca2u, 0x3fe9ba5eu, 0x3fe9d6f5u,
+    0x3febb3dbu, 0x3fed844du, 0x3fed84ceu, 0x3fedbc9au, 0x3fee9263u, 0x3ff0d19au, 0x3ff0d1b7u, 0x40000000u,
+};
+inline bool verifiedChromaDenominator(float d)
+{
+    const uint32_t b = floatBits(d);
+    for (uint32_t v : kVerifiedChromaDenBits)
+        if (v == b)
             return true;
     return false;
 }

@@ -131,10 +131,10 @@ __device__ __forceinline__ Yuvf rgbToYuvPixel(const RgbToYuvPlan & p, uint32_t i
 
 __global__ __launch_bounds__(256) void rgbToYuvGenericKernel(RgbToYuvPlan p)
 {
-    const uint32_t bx = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t by = blockIdx.y * blockDim.y + threadIdx.y;
+    const uint32_t bx = (p.rx0 >> 1) + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t by = (p.ry0 >> 1) + blockIdx.y * blockDim.y + threadIdx.y;
     const uint32_t oi = bx * 2, oj = by * 2;
-    if (oi >= p.width || oj >= p.height)
+    if (oi >= p.rx0 + p.rw || oj >= p.ry0 + p.rh)
         return;
     const YuvSide & s = p.yuv;
     const uint32_t bw = (oi + 1 >= p.width) ? 1 : 2;
@@ -175,10 +175,10 @@ __global__ __launch_bounds__(256) void rgbToYuvGenericKernel(RgbToYuvPlan p)
 // from the average.  The alpha plane is libavif's own pass (src/reformat.c:545-569), fused in.
 __global__ __launch_bounds__(256) void rgbToYuvFixedKernel(RgbToYuvPlan p)
 {
-    const uint32_t bx = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t by = blockIdx.y * blockDim.y + threadIdx.y;
+    const uint32_t bx = (p.rx0 >> 1) + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t by = (p.ry0 >> 1) + blockIdx.y * blockDim.y + threadIdx.y;
     const uint32_t oi = bx * 2, oj = by * 2;
-    if (oi >= p.width || oj >= p.height)
+    if (oi >= p.rx0 + p.rw || oj >= p.ry0 + p.rh)
         return;
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
@@ -328,7 +328,7 @@ hipError_t launchYuvToRgbGenericBatch(const YuvToRgbPlan * deviceTable, uint32_t
 
 hipError_t launchRgbToYuvGeneric(const RgbToYuvPlan & plan, hipStream_t stream)
 {
-    if (plan.width == 0 || plan.height == 0)
+    if (plan.width == 0 || plan.height == 0 || plan.rw == 0 || plan.rh == 0)
         return hipSuccess;
     const dim3 block(64, 4);
     if (plan.rgb.isGray) {
@@ -347,7 +347,7 @@ hipError_t launchRgbToYuvGeneric(const RgbToYuvPlan & plan, hipStream_t stream)
             hipLaunchKernelGGL(fillSamplesKernel, dim3(blocks), dim3(256), 0, stream, s.plane[pl], samples, s.chanBytes, half);
         }
     } else {
-        const uint32_t bw = (plan.width + 1) / 2, bh = (plan.height + 1) / 2;
+        const uint32_t bw = (plan.rw + 1) / 2, bh = (plan.rh + 1) / 2;
         if (plan.arith == ARITH_LIBYUV)
             hipLaunchKernelGGL(rgbToYuvFixedKernel, gridFor(bw, bh, block), block, 0, stream, plan);
         else

@@ -1,0 +1,135 @@
+// kernels_r2y_tile.hip -- host-side dispatch of the bandwidth-tuned RGB -> YUV kernels (r2y_tile_impl.h): which plans
+// they cover, how the image is cut into strips, and the hand-over of the at most 3 columns / 1 row that do not fill a
+// 4x2 pixel group to the universal kernel.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include "kernels.h"
+#include "r2y_tile_shared.h"
+
+namespace avifhip {
+
+using namespace r2y;
+
+namespace {
+
+bool alignedTo(const void * ptr, uint32_t rowBytes, uint32_t a)
+{
+    return ((uintptr_t)ptr % a) == 0 && (rowBytes % a) == 0;
+}
+bool fits32(uint64_t rows, uint32_t pitch)
+{
+    return rows * (uint64_t)pitch < ((uint64_t)1 << 32);
+}
+
+R2YKey keyFor(const RgbToYuvPlan & p)
+{
+    R2YKey k;
+    k.wideRgb = p.rgb.chanBytes == 2;
+    k.wideYuv = p.yuv.chanBytes == 2;
+    k.nch = p.rgb.hasAlpha ? 4 : 3;
+    switch (p.yuv.format) {
+        case AVIF_PIXEL_FORMAT_YUV444: k.sub = SUB_444; break;
+        case AVIF_PIXEL_FORMAT_YUV422: k.sub = SUB_422; break;
+        case AVIF_PIXEL_FORMAT_YUV420: k.sub = SUB_420; break;
+        default: k.sub = SUB_400; break;
+    }
+    return k;
+}
+
+const char * kernelNameFor(const R2YKey & k)
+{
+    static thread_local char name[96];
+    static const char * subs[] = { "444", "422", "420", "400" };
+    snprintf(name, sizeof(name), "rgb2yuv_tile<%s%d,%s,%s>", k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.wideYuv ? "u16" : "u8", subs[k.sub]);
+    return name;
+}
+
+} // namespace
+
+bool tileRgbToYuvSupported(const RgbToYuvPlan & p)
+{
+    const YuvSide & s = p.yuv;
+    const RgbSide & o = p.rgb;
+    if (p.arith != ARITH_FLOAT || p.mul != MUL_NONE || o.isGray || o.is565 || s.mode != MODE_COEFF)
+        return false;
+    if (!s.exactDivEncode)
+        return false; // a divisor off the verified lists (exactdiv.h): the universal kernel divides the IEEE way
+    if (p.rx0 != 0 || p.ry0 != 0 || p.rw != p.width || p.rh != p.height)
+        return false;
+    if (p.width < 64 || p.height < 2)
+        return false;
+    const uint32_t bps = (uint32_t)s.chanBytes;
+    const int nch = o.hasAlpha ? 4 : 3;
+    const uint32_t loadAlign = (nch == 4) ? 16u : (o.chanBytes == 1 ? 4u : 8u);
+    if (!alignedTo(o.pixels, o.rowBytes, loadAlign))
+        return false;
+    if (!alignedTo(s.plane[0], s.rowBytes[0], 4 * bps))
+        return false;
+    if (s.format != AVIF_PIXEL_FORMAT_YUV400) {
+        const uint32_t chromaAlign = (s.format == AVIF_PIXEL_FORMAT_YUV444) ? 4 * bps : 2 * bps;
+        if (!s.plane[1] || !s.plane[2] || !alignedTo(s.plane[1], s.rowBytes[1], chromaAlign) || !alignedTo(s.plane[2], s.rowBytes[2], chromaAlign))
+            return false;
+    }
+    if (p.alphaSource != ALPHA_KEEP && (!s.alpha || !alignedTo(s.alpha, s.alphaRowBytes, 4 * bps)))
+        return false;
+    if (!fits32(p.height, o.rowBytes) || !fits32(p.height, s.rowBytes[0]) || !fits32(p.height, s.alphaRowBytes) || !fits32(p.height, s.rowBytes[1]) ||
+        !fits32(p.height, s.rowBytes[2]))
+        return false;
+    return true;
+}
+
+hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const char ** kernelName)
+{
+    const YuvSide & s = p.yuv;
+    const RgbSide & o = p.rgb;
+    const R2YKey k = keyFor(p);
+    if (kernelName)
+        *kernelName = kernelNameFor(k);
+    R2YArgs A;
+    memset(&A, 0, sizeof(A));
+    A.rgb = o.pixels;
+    A.y = s.plane[0], A.u = s.plane[1], A.v = s.plane[2], A.a = s.alpha;
+    A.rgbPitch = o.rowBytes, A.yPitch = s.rowBytes[0], A.uPitch = s.rowBytes[1], A.vPitch = s.rowBytes[2], A.aPitch = s.alphaRowBytes;
+    A.w4 = p.width & ~3u, A.h2 = p.height & ~1u;
+    A.kr = s.kr, A.kg = s.kg, A.kb = s.kb;
+    A.rcpRgbMax = o.rcpMax, A.rcpCbDen = s.rcpCbDen, A.rcpCrDen = s.rcpCrDen;
+    A.rangeY = s.rangeY, A.biasY = s.biasY, A.rangeUV = s.rangeUV, A.biasUV = s.biasUV;
+    A.yuvMax = (uint32_t)s.maxv, A.yuvMaxF = (float)s.maxv;
+    A.slotR = (uint32_t)(o.offR / o.chanBytes), A.slotB = (uint32_t)(o.offB / o.chanBytes), A.slotA = (uint32_t)(o.offA / o.chanBytes);
+    A.alphaMode = R2Y_ALPHA_NONE;
+    if (p.alphaSource == ALPHA_FILL)
+        A.alphaMode = R2Y_ALPHA_FILL;
+    else if (p.alphaSource == ALPHA_PLANE)
+        A.alphaMode = (o.depth == s.depth) ? R2Y_ALPHA_COPY : R2Y_ALPHA_RESCALE;
+
+    // decomposition: about 2048 workgroups (8 per CU); a wave walks down up to 8 strips
+    const uint32_t bands = (A.w4 + 255) / 256;
+    const uint32_t strips = A.h2 / 2;
+    const uint64_t waveStrips = (uint64_t)bands * strips;
+    uint32_t spw = (uint32_t)(waveStrips / (4 * 2048));
+    spw = spw < 1 ? 1 : (spw > 8 ? 8 : spw);
+    A.stripsPerWave = spw;
+    const uint32_t chunks = (strips + 4 * spw - 1) / (4 * spw);
+    hipError_t e = k.wideRgb ? launchR2YTileRgb16(k, A, bands * chunks, stream) : launchR2YTileRgb8(k, A, bands * chunks, stream);
+    if (e != hipSuccess)
+        return e;
+    // leftovers: columns [w4, width) of every row, then row h2 of the columns before w4 (even origins: whole 2x2 blocks)
+    if (A.w4 != p.width) {
+        RgbToYuvPlan rest = p;
+        rest.rx0 = A.w4, rest.rw = p.width - A.w4;
+        e = launchRgbToYuvGeneric(rest, stream);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (A.h2 != p.height) {
+        RgbToYuvPlan rest = p;
+        rest.ry0 = A.h2, rest.rh = p.height - A.h2, rest.rw = A.w4;
+        e = launchRgbToYuvGeneric(rest, stream);
+    }
+    return e;
+}
+
+} // namespace avifhip

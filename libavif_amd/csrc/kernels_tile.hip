@@ -215,13 +215,4 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
     return launchFamily(k, L);
 }
 
-bool tileRgbToYuvSupported(const RgbToYuvPlan &)
-{
-    return false;
-}
-hipError_t launchRgbToYuvTile(const RgbToYuvPlan &, hipStream_t, const char **)
-{
-    return hipErrorNotSupported;
-}
-
 } // namespace avifhip

@@ -217,6 +217,12 @@ static bool prepareState(const avifImage * image, const avifRGBImage * rgb, YuvS
     y->rcpRangeUV = reciprocalOf(y->rangeUV, 1.0f);
     y->rcpKgTimes2 = reciprocalOf(y->kg, 2.0f);
     y->rcpMax = reciprocalOf((float)y->maxv, 1.0f);
+    y->rcpCbDen = reciprocalOf(y->twoOneMinusKb, 1.0f);
+    y->rcpCrDen = reciprocalOf(y->twoOneMinusKr, 1.0f);
+    y->exactDivEncode = (y->mode == MODE_COEFF && verifiedChromaDenominator(y->twoOneMinusKb) && verifiedChromaDenominator(y->twoOneMinusKr) &&
+                         verifiedIntegerDivisor(r->maxf))
+                            ? 1
+                            : 0;
     y->exactDiv = (verifiedIntegerDivisor(y->rangeY) && verifiedIntegerDivisor(y->rangeUV) && verifiedIntegerDivisor((float)y->maxv) &&
                    verifiedIntegerDivisor(r->maxf) && (y->mode != MODE_COEFF || verifiedKgDivisor(y->kg)))
                       ? 1
@@ -486,6 +492,7 @@ avifResult makeRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, i
         return AVIF_RESULT_NOT_IMPLEMENTED; // :232-234
     out->width = image->width;
     out->height = image->height;
+    out->rx0 = 0, out->ry0 = 0, out->rw = image->width, out->rh = image->height;
     const bool hasAlpha = out->rgb.hasAlpha && !rgb->ignoreAlpha;
     out->mul = MUL_NONE; // :242-249
     if (hasAlpha) {

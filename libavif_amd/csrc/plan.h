@@ -75,6 +75,10 @@ struct YuvSide
     RcpHL rcpKgTimes2; // 2 / kg: (2 * x) / kg == x * (2 / kg) up to the same single rounding (power-of-two scaling)
     RcpHL rcpMax;      // 1 / maxv (alpha normalisation and depth rescale, src/reformat.c:897, src/alpha.c:93)
     int32_t exactDiv;
+    // encode direction (src/reformat.c:384-385): 1 / (2*(1-kb)), 1 / (2*(1-kr)); exactDivEncode when both denominators
+    // and the RGB channel maximum are on the verified lists
+    RcpHL rcpCbDen, rcpCrDen;
+    int32_t exactDivEncode;
 };
 
 // libyuv YuvConstants as black-box verified in SURVEY.md Appendix D.1
@@ -120,6 +124,7 @@ struct RgbToYuvPlan
     YuvSide yuv; // destination planes
     RgbSide rgb; // source pixels (const in practice)
     uint32_t width, height;
+    uint32_t rx0, ry0, rw, rh; // region converted by this job (even origin; edge blocks are decided against width/height)
     int32_t mul;         // MulMode applied in fp32 (src/reformat.c:325-358)
     int32_t alphaSource; // ALPHA_KEEP (no alpha plane) / ALPHA_FILL / ALPHA_PLANE(= from rgb alpha channel)
     int32_t arith;       // ARITH_LIBYUV: appendix D.5 (8-bit BT.601 only)

@@ -26,5 +26,5 @@ def test_every_listed_divisor_is_exact(tmp_path):
     proc = subprocess.run([os.fspath(exe)], capture_output=True, text=True)
     lines = proc.stdout.strip().splitlines()
     assert proc.returncode == 0, proc.stdout[-2000:]
-    assert len(lines) == 15 + 12
+    assert len(lines) == 15 + 12 + 28
     assert all(line.endswith("mismatches=0") for line in lines), proc.stdout

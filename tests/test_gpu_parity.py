@@ -65,14 +65,39 @@ def test_yuv_to_rgb_generic_kernels_on_tiled_sizes(hip):
 
 
 def _compare_r2y(be, oracle, cases, padding=True):
-    bad = []
+    bad, kernels = [], {}
     for c in cases:
         ro, io = H.run_r2y(oracle, c)
         rh, ih = H.run_r2y(be, c)
+        k = native.last_kernel().split("<")[0]
+        kernels[k] = kernels.get(k, 0) + 1
         d = None if ro != rh else H.planes_equal(io, ih, padding=padding)
         if ro != rh or d:
             bad.append(f"{c.ident()} [{native.last_kernel()}]: results {ro}/{rh} {d or ''}")
     assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:25])
+    return kernels
+
+
+def test_rgb_to_yuv_tiled_sweep_host(hip):
+    hip.avifhipSetTiledKernels(1)
+    kernels = _compare_r2y(H.hip_host_backend(), H.oracle_backend(), H.r2y_sweep(TILED, n_random=500, seed=71))
+    assert kernels.get("rgb2yuv_tile", 0) > 200, kernels
+    assert "rgb2yuv_generic" in kernels  # gray sources, identity / YCgCo matrices, pending alpha multiplies
+
+
+def test_rgb_to_yuv_tiled_sweep_device(hip):
+    hip.avifhipSetTiledKernels(1)
+    kernels = _compare_r2y(H.HipDeviceBackend(), H.oracle_backend(), H.r2y_sweep(TILED, n_random=300, seed=73), padding=False)
+    assert kernels.get("rgb2yuv_tile", 0) > 100, kernels
+
+
+def test_rgb_to_yuv_generic_kernels_on_tiled_sizes(hip):
+    hip.avifhipSetTiledKernels(0)
+    try:
+        kernels = _compare_r2y(H.hip_host_backend(), H.oracle_backend(), H.r2y_sweep(TILED[:3], n_random=150, seed=79))
+        assert set(kernels) == {"rgb2yuv_generic"}
+    finally:
+        hip.avifhipSetTiledKernels(1)
 
 
 def test_rgb_to_yuv_sweep_host(hip):

@@ -1,0 +1,80 @@
+"""Kernel timings of every BASELINE configuration on the GPU box (HIP events on the launch stream, device-resident
+buffers), in both arithmetic families.  Prints one JSON line per (configuration, arithmetic):
+    python tests/tools/cfg_bench.py [cfg2 cfg2n cfg3 cfg4 cfg4rgb cfg5 cfg5x64 ...]
+Algorithmic bytes per pixel are SURVEY.md 8d's figures."""
+import ctypes as C
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from libavif_amd import abi, device, native, synth  # noqa: E402
+
+lib = native.load()
+BIL, NEAR = abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, abi.AVIF_CHROMA_UPSAMPLING_NEAREST
+
+
+def y2r(w, h, depth, fmt, rng, mc, rgb_depth, up=BIL, alpha=False, premult=False, avoid=True, rgb_format=abi.AVIF_RGB_FORMAT_RGBA, seed=0x12345678):
+    img = abi.make_yuv(w, h, depth, fmt, rng, mc, with_alpha=alpha)
+    synth.fill_yuv(img, seed)
+    rgb = abi.make_rgb(w, h, rgb_depth, rgb_format, upsampling=up, alpha_premultiplied=premult, avoid_libyuv=avoid, allocate=False)
+    return device.DeviceYUV(img), device.DeviceRGB(rgb)
+
+
+def time_y2r(pair, iters=40):
+    return min(lib.avifhipTimeYUVToRGB(pair[0].struct, pair[1].struct, 4, iters, None) for _ in range(4))
+
+
+def run(name):
+    out = []
+    for arith, avoid in (("float", True), ("integer", False)):
+        lib.avifhipSetArithmetic(1 if arith == "float" else 0)
+        px, bpp, ms = 0, 0.0, None
+        if name in ("cfg2", "cfg2n"):
+            pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=BIL if name == "cfg2" else NEAR, avoid=avoid)
+            px, bpp, ms = 7680 * 4320, 5.5, time_y2r(pair)
+        elif name == "cfg3":
+            pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, avoid=avoid)
+            px, bpp, ms = 7680 * 4320, 16.0, time_y2r(pair, 20)
+        elif name in ("cfg4", "cfg4rgb", "cfg4_601"):
+            fmt = abi.AVIF_RGB_FORMAT_RGB if name == "cfg4rgb" else abi.AVIF_RGB_FORMAT_RGBA
+            mc = 6 if name == "cfg4_601" else 1
+            rgb = abi.make_rgb(3840, 2160, 8, fmt, avoid_libyuv=avoid)
+            synth.fill_rgb(rgb, 0x12345678, opaque=True)
+            img = abi.make_yuv(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, mc, with_alpha=(fmt == abi.AVIF_RGB_FORMAT_RGBA))
+            dimg, drgb = device.DeviceYUV(img), device.DeviceRGB(rgb, upload=True)
+            px, bpp = 3840 * 2160, (6.5 if fmt == abi.AVIF_RGB_FORMAT_RGBA else 4.5)
+            ms = min(lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 4, 40, None) for _ in range(4))
+        elif name in ("cfg5", "cfg5_8"):
+            pair = y2r(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 10 if name == "cfg5" else 8, avoid=avoid)
+            px, bpp, ms = 1920 * 1080, (11.0 if name == "cfg5" else 7.0), time_y2r(pair)
+        elif name in ("cfg5x64", "cfg5x64_8"):
+            rgb_depth = 10 if name == "cfg5x64" else 8
+            pairs = [y2r(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, rgb_depth, avoid=avoid, seed=0x12345678 + t) for t in range(64)]
+            imgs = (C.POINTER(abi.avifImage) * 64)(*[C.pointer(p[0].struct) for p in pairs])
+            rgbs = (C.POINTER(abi.avifRGBImage) * 64)(*[C.pointer(p[1].struct) for p in pairs])
+            for _ in range(3):
+                native.check(lib.avifhipImageYUVToRGBBatchAsync(64, imgs, rgbs, None, None))
+            native.check(lib.avifhipSynchronize(None))
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    native.check(lib.avifhipImageYUVToRGBBatchAsync(64, imgs, rgbs, None, None))
+                native.check(lib.avifhipSynchronize(None))
+                best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+            px, bpp, ms = 64 * 1920 * 1080, (11.0 if rgb_depth == 10 else 7.0), best
+        else:
+            raise SystemExit(f"unknown configuration {name}")
+        gbps = bpp * px / (ms * 1e-3) / 1e9
+        out.append({"config": name, "arithmetic": arith, "kernel": native.last_kernel(), "us": round(ms * 1e3, 2), "megapixels_per_s": round(px / 1e6 / (ms * 1e-3)),
+                    "algorithmic_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000, 4)})
+    lib.avifhipSetArithmetic(0)
+    return out
+
+
+if __name__ == "__main__":
+    for n in sys.argv[1:] or ["cfg2", "cfg2n", "cfg3", "cfg4", "cfg4rgb", "cfg4_601", "cfg5", "cfg5_8", "cfg5x64", "cfg5x64_8"]:
+        for line in run(n):
+            print(json.dumps(line), flush=True)

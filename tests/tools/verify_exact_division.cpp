@@ -7,6 +7,7 @@
  *                 reference's "2 *" into the constant).  The identity is invariant under scaling x by powers of two
  *                 while x * lo stays normal, so a binade covers every exponent the kernels produce.
  *   integer list  the same mantissa sweep with scale 1, plus every integer x in [-65536, 65536].
+ *   chroma denominators (2*(1-kb), 2*(1-kr), encode direction)  the mantissa sweep with scale 1.
  * Prints one line per divisor; exit status 1 if any mismatch.  Build: g++ -O2 -mfma -ffp-contract=off.
  */
 #include <math.h>
@@ -61,6 +62,14 @@ int main()
             ++n;
         }
         printf("int %.9g hi=%.9g lo=%.9g tested=%llu mismatches=%llu\n", d, r.hi, r.lo, n, bad);
+        failures += bad != 0;
+    }
+    for (uint32_t bits : kVerifiedChromaDenBits) {
+        const float d = asFloat(bits);
+        const RcpSplit r = splitReciprocal(d, 1.0f);
+        unsigned long long n = 0;
+        const unsigned long long bad = sweepMantissas(d, 1.0f, r, &n);
+        printf("den %.9g (0x%08x) hi=%.9g lo=%.9g tested=%llu mismatches=%llu\n", d, bits, r.hi, r.lo, n, bad);
         failures += bad != 0;
     }
     return failures ? 1 : 0;
