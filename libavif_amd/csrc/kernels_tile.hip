@@ -19,6 +19,11 @@ AVIFHIP_DECLARE_TILE(u8_444n) AVIFHIP_DECLARE_TILE(u8_400n) AVIFHIP_DECLARE_TILE
 AVIFHIP_DECLARE_TILE(u8_420n) AVIFHIP_DECLARE_TILE(u8_420b) AVIFHIP_DECLARE_TILE(u16_444n) AVIFHIP_DECLARE_TILE(u16_400n)
 AVIFHIP_DECLARE_TILE(u16_422n) AVIFHIP_DECLARE_TILE(u16_422b) AVIFHIP_DECLARE_TILE(u16_420n) AVIFHIP_DECLARE_TILE(u16_420b)
 #undef AVIFHIP_DECLARE_TILE
+#define AVIFHIP_DECLARE_TILE(name) hipError_t launchTileFx_##name(const TileKey &, const TileLaunch &);
+AVIFHIP_DECLARE_TILE(u8_444n) AVIFHIP_DECLARE_TILE(u8_400n) AVIFHIP_DECLARE_TILE(u8_422n) AVIFHIP_DECLARE_TILE(u8_422b)
+AVIFHIP_DECLARE_TILE(u8_420n) AVIFHIP_DECLARE_TILE(u8_420b) AVIFHIP_DECLARE_TILE(u16_444n) AVIFHIP_DECLARE_TILE(u16_400n)
+AVIFHIP_DECLARE_TILE(u16_422n) AVIFHIP_DECLARE_TILE(u16_422b) AVIFHIP_DECLARE_TILE(u16_420n) AVIFHIP_DECLARE_TILE(u16_420b)
+#undef AVIFHIP_DECLARE_TILE
 } // namespace tile
 
 namespace {
@@ -28,6 +33,7 @@ constexpr uint32_t kBandW = 256, kTargetBlocks = 2048;
 TileKey keyFor(const YuvToRgbPlan & p)
 {
     TileKey k;
+    k.fixedPoint = p.arith == ARITH_LIBYUV;
     k.wideYuv = p.yuv.chanBytes == 2;
     if (!p.yuv.hasColor)
         k.sub = SUB_400;
@@ -54,13 +60,29 @@ const char * kernelNameFor(const TileKey & k)
 {
     static thread_local char name[112];
     static const char * subs[] = { "444", "422", "420", "400" };
-    snprintf(name, sizeof(name), "yuv2rgb_tile<%s,%s,%s,%s%d%s%s>", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
+    snprintf(name, sizeof(name), "%s<%s,%s,%s,%s%d%s%s>", k.fixedPoint ? "yuv2rgb_fixed_tile" : "yuv2rgb_tile", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
              k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "");
     return name;
 }
 
 hipError_t launchFamily(const TileKey & k, const TileLaunch & L)
 {
+    if (k.fixedPoint) {
+        if (!k.wideYuv) {
+            switch (k.sub) {
+                case SUB_444: return launchTileFx_u8_444n(k, L);
+                case SUB_400: return launchTileFx_u8_400n(k, L);
+                case SUB_422: return k.bilinear ? launchTileFx_u8_422b(k, L) : launchTileFx_u8_422n(k, L);
+                default: return k.bilinear ? launchTileFx_u8_420b(k, L) : launchTileFx_u8_420n(k, L);
+            }
+        }
+        switch (k.sub) {
+            case SUB_444: return launchTileFx_u16_444n(k, L);
+            case SUB_400: return launchTileFx_u16_400n(k, L);
+            case SUB_422: return k.bilinear ? launchTileFx_u16_422b(k, L) : launchTileFx_u16_422n(k, L);
+            default: return k.bilinear ? launchTileFx_u16_420b(k, L) : launchTileFx_u16_420n(k, L);
+        }
+    }
     if (!k.wideYuv) {
         switch (k.sub) {
             case SUB_444: return launchTile_u8_444n(k, L);
@@ -113,10 +135,20 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
-    if (p.arith != ARITH_FLOAT || p.postMulFx || p.identityCopy || s.mode != MODE_COEFF)
-        return false;
-    if (!s.exactDiv)
-        return false; // a divisor off the verified list (exactdiv.h): the universal kernel divides the IEEE way
+    if (p.arith == ARITH_LIBYUV) {
+        // fixed-point kernels (tile_fx_impl.h): the only post-pass they carry is libyuv's own attenuate / unattenuate
+        if (p.postMul != MUL_NONE && !p.postMulFx)
+            return false;
+        if ((s.hasColor != 0) != (s.format != AVIF_PIXEL_FORMAT_YUV400))
+            return false;
+        if (p.fxAlpha == FXA_FLOAT && s.depth != o.depth && !s.exactDiv)
+            return false;
+    } else {
+        if (p.postMulFx || p.identityCopy || s.mode != MODE_COEFF)
+            return false;
+        if (!s.exactDiv)
+            return false; // a divisor off the verified list (exactdiv.h): the universal kernel divides the IEEE way
+    }
     if (o.isGray || o.is565 || o.isFloat)
         return false;
     if (o.hasAlpha && p.alphaSource == ALPHA_KEEP)
@@ -153,7 +185,7 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
         return -1;
     const TileKey k = keyFor(plan);
     return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) |
-           ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7);
+           ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7) | ((k.fixedPoint ? 1 : 0) << 8);
 }
 
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)

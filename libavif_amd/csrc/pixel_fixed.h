@@ -35,6 +35,12 @@ __device__ __forceinline__ int fxChromaBilinear(const uint8_t * plane, uint32_t 
     const bool edgeY = !vertical || (j == 0) || (j == canvasH - 1 && !(canvasH & 1));
     const uint32_t fi = (i & 1) ? ci + 1 : ci - 1; // used only when !edgeX
     const uint32_t fj = (j & 1) ? cj + 1 : cj - 1; // used only when !edgeY
+    // samples of 16-bit containers are held to 12 bits here, like the packed filter of the tiled kernels (tile_fx_impl.h):
+    // a no-op for samples inside their nominal depth
+    auto fxSample = [](const uint8_t * pl, uint32_t rb, uint32_t x, uint32_t y, int cb, int ds) {
+        const int v = avifhip::fxSample(pl, rb, x, y, cb, ds);
+        return (cb == 2 && ds == 0) ? min(v, 4095) : v;
+    };
     const int a0 = fxSample(plane, rowBytes, ci, cj, chanBytes, downshift);
     if (edgeX && edgeY)
         return a0;

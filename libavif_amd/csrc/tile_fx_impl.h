@@ -1,0 +1,330 @@
+// tile_fx_impl.h -- bandwidth-tuned YUV->RGB kernels for the reference's INTEGER path (libyuv's fixed-point arithmetic,
+// SURVEY.md appendix D.1-D.4, as dispatched by src/reformat_libyuv.c), instantiated by kernels_tile_fx_inst.hip.
+//
+// Same work decomposition, loads, software pipeline and stores as the fp32 tiled kernels (tile_impl.h); what differs is
+// the arithmetic, which is integer-only:
+//   * bilinear chroma: the tile's chroma neighbourhood is staged in LDS as RAW samples, one 32-bit word per chroma
+//     column holding (u | v << 16); libyuv's 9:3:3:1 filter with its +8 >> 4 rounding is evaluated on both planes at
+//     once with plain 32-bit shifts and adds (no field exceeds 16 * 1023 + 8, so no carry crosses the halves), sharing
+//     the 9x / 3x terms between a lane's 8 pixels.  Coordinates clamp to the canvas exactly like the fp32 staging:
+//     with a duplicated neighbour the 2-D formula (12a + 4b + 8) >> 4 IS libyuv's edge formula (3a + b + 2) >> 2, and
+//     (3a + a + 2) >> 2 == a, so the first column / row and the last column of an even width / last row of an even height
+//     need no special case (the last column of an ODD width never reaches these kernels: leftover columns go to the
+//     universal kernel);
+//   * matrix: one 24-bit multiply for luma, four multiply-adds for the chroma terms with the biases folded in, shifts,
+//     integer clamps, byte packing.
+// Scope: 8-bit RGB / BGR / RGBA / BGRA / ARGB / ABGR outputs from 8-bit planes, 10-bit planes through the I010 family or
+// any depth through the downshift route; alpha opaque / from the plane (shift or fp32 rescale); ARGBAttenuate /
+// ARGBUnattenuate post-pass.  RGB565 and the fp32 post-pass of ARGB/ABGR stay with the universal kernel.
+#pragma once
+
+#include "pixel_fixed.h"
+#include "tile_impl.h"
+
+namespace avifhip {
+namespace tile {
+
+// LDS row of staged chroma: entry c+5 holds (u | v << 16) of chroma column cxb + c, c in [-4, 131]
+constexpr int kFxRowPitch = 140;
+
+__device__ __forceinline__ unsigned fxReduce(unsigned v, unsigned downshift)
+{
+    return downshift ? minU(v >> downshift, 255u) : v;
+}
+// ... for the packed filter: samples of 16-bit containers are additionally held to 12 bits so that no field of the packed
+// sums can carry into its neighbour (fxChromaBilinear of the universal kernel applies the same bound; samples inside
+// their nominal depth never reach it)
+template <typename YT>
+__device__ __forceinline__ unsigned fxReduceForFilter(unsigned v, unsigned downshift)
+{
+    if constexpr (sizeof(YT) == 2)
+        return downshift ? minU(v >> downshift, 255u) : minU(v, 4095u);
+    else
+        return v;
+}
+
+template <typename YT, int SUB, bool NEEDA, int NS>
+__device__ __forceinline__ void stageTileFx(const TileArgs & A, const TileRaw<YT, SUB, true, NEEDA, NS> & T, unsigned (*rows)[kFxRowPitch])
+{
+    typedef StageRows<SUB, NS> SR;
+    const int t = threadIdx.y * kLanesX + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < SR::kRounds; ++j) {
+        const int task = t + 256 * j;
+        if (task < SR::kTasks) {
+            const int row = task / kStageGroups, grp = task - row * kStageGroups;
+            unsigned u[4], v[4];
+            decode4<YT>(T.su[j], u);
+            decode4<YT>(T.sv[j], v);
+            unsigned * dst = &rows[row][4 * grp + 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                dst[k] = fxReduceForFilter<YT>(u[k], A.fx.downshift) | (fxReduceForFilter<YT>(v[k], A.fx.downshift) << 16);
+        }
+    }
+}
+
+// 3x and 9x of a packed (u | v << 16) word
+__device__ __forceinline__ unsigned fx3(unsigned x)
+{
+    return (x << 1) + x;
+}
+__device__ __forceinline__ unsigned fx9(unsigned x)
+{
+    return (x << 3) + x;
+}
+
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
+__device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx & c, uint32_t tileY, const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS> & T,
+                                              unsigned (*rows)[kFxRowPitch])
+{
+    constexpr bool kWide = sizeof(YT) == 2;
+    constexpr bool kNeedA = APLANE || HASMUL;
+    const int tx = threadIdx.x, wv = threadIdx.y;
+    const bool nt = (A.tuning & TUNE_NONTEMPORAL) != 0;
+    const uint32_t X = c.X;
+    const bool laneValid = c.laneValid;
+    const StripRaw<YT, SUB, BIL, kNeedA> * raw = T.raw;
+    const TileArgs::Fx & F = A.fx;
+
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const uint32_t sy = tileY + 2 * (wv * NS + k);
+        if (sy >= A.h2)
+            break;
+
+        // ---- upsampled (u, v) of the lane's 2 x 4 pixels, at the planes' (reduced) depth, still packed u | v << 16 ----
+        unsigned uv[2][4];
+        if constexpr (SUB == SUB_400) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    uv[r][i] = (128u << F.cShr) | ((128u << F.cShr) << 16);
+        } else if constexpr (SUB == SUB_444) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                unsigned u[4], v[4];
+                decode4<YT>(raw[k].u[r], u);
+                decode4<YT>(raw[k].v[r], v);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    uv[r][i] = fxReduce(u[i], F.downshift) | (fxReduce(v[i], F.downshift) << 16);
+            }
+        } else if constexpr (!BIL) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (SUB == SUB_420 && r == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        uv[1][i] = uv[0][i];
+                    break;
+                }
+                constexpr unsigned kMask = kWide ? 0xffffu : 0xffu;
+                constexpr int kShift = kWide ? 16 : 8;
+                const unsigned u0 = raw[k].u[r].w[0] & kMask, u1 = (raw[k].u[r].w[0] >> kShift) & kMask;
+                const unsigned v0 = raw[k].v[r].w[0] & kMask, v1 = (raw[k].v[r].w[0] >> kShift) & kMask;
+                const unsigned c0 = fxReduce(u0, F.downshift) | (fxReduce(v0, F.downshift) << 16);
+                const unsigned c1 = fxReduce(u1, F.downshift) | (fxReduce(v1, F.downshift) << 16);
+                uv[r][0] = uv[r][1] = c0;
+                uv[r][2] = uv[r][3] = c1;
+            }
+        } else {
+            auto loadRow = [&](int q, unsigned m[4]) {
+                const u2 * src = reinterpret_cast<const u2 *>(&rows[q][2 * tx + 4]); // columns 2tx-1 .. 2tx+2, 8-byte aligned
+                const u2 lo = src[0], hi = src[1];
+                m[0] = lo.x, m[1] = lo.y, m[2] = hi.x, m[3] = hi.y;
+            };
+            if constexpr (SUB == SUB_420) {
+                // Scale2RowUp_Bilinear: (9 near + 3 horizontal + 3 vertical + 1 diagonal + 8) >> 4 per plane
+                const int qm = 1 + wv * NS + k;
+                unsigned m[4], f[2][4];
+                loadRow(qm, m);
+                loadRow(qm - 1, f[0]); // even luma rows lean to the chroma row above
+                loadRow(qm + 1, f[1]); // odd luma rows to the one below
+                const unsigned n9b = fx9(m[1]), n9c = fx9(m[2]);
+                const unsigned h0 = n9b + fx3(m[0]) + 0x00080008u, h1 = n9b + fx3(m[2]) + 0x00080008u;
+                const unsigned h2 = n9c + fx3(m[1]) + 0x00080008u, h3 = n9c + fx3(m[3]) + 0x00080008u;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const unsigned g3b = fx3(f[r][1]), g3c = fx3(f[r][2]);
+                    uv[r][0] = h0 + g3b + f[r][0]; // even pixel: horizontal neighbour on the left
+                    uv[r][1] = h1 + g3b + f[r][2]; // odd pixel: on the right
+                    uv[r][2] = h2 + g3c + f[r][1];
+                    uv[r][3] = h3 + g3c + f[r][3];
+                }
+            } else { // 4:2:2, ScaleRowUp2_Linear: (3 near + far + 2) >> 2
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    unsigned m[4];
+                    loadRow(2 * (wv * NS + k) + r, m);
+                    const unsigned n3b = fx3(m[1]) + 0x00020002u, n3c = fx3(m[2]) + 0x00020002u;
+                    uv[r][0] = n3b + m[0];
+                    uv[r][1] = n3b + m[2];
+                    uv[r][2] = n3c + m[1];
+                    uv[r][3] = n3c + m[3];
+                }
+            }
+        }
+
+        // ---- matrix, alpha, stores ----
+        // the filter's final ">> SH" is folded into the field extraction: uv holds the un-shifted sums
+        constexpr int SH = BIL ? (SUB == SUB_420 ? 4 : 2) : 0;
+        constexpr unsigned kField = BIL ? 0xfffu : 0xffffu; // filtered fields are 12 bits wide after the shift, plain samples 16
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            unsigned yv[4], av[4] = { 0, 0, 0, 0 };
+            decode4<YT>(raw[k].y[r], yv);
+            if constexpr (kNeedA)
+                decode4<YT>(raw[k].a[r], av);
+            unsigned X4[4], G4[4], Z4[4], a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // operands fit 24 bits (y32 < 2^16, yMul < 2^15, yMul8 < 2^23, chroma < 2^8, coefficients < 2^10): full-rate multiplies
+                unsigned y1;
+                int lo, hi;
+                if constexpr (!kWide) {
+                    y1 = __umul24(yv[i], F.yMul8) >> 16;
+                    lo = (int)((uv[r][i] >> SH) & 0xffu), hi = (int)((uv[r][i] >> (16 + SH)) & 0xffu);
+                } else {
+                    const unsigned y = fxReduce(yv[i], F.downshift);
+                    y1 = __umul24((y << F.yShl) | (y >> F.yShr), F.yMul) >> 16;
+                    lo = (int)minU(((uv[r][i] >> SH) & kField) >> F.cShr, 255u), hi = (int)minU(((uv[r][i] >> (16 + SH)) & kField) >> F.cShr, 255u);
+                }
+                const int yx = (int)(y1 << 2) + F.kX4, yz = (int)(y1 << 2) + F.kZ4, yg = (int)(y1 << 2) + F.kG4;
+                const int x = yx + __mul24(F.cX4, lo);
+                const int z = yz + __mul24(F.cZ4, hi);
+                const int g = (yg - __mul24(F.gLo4, lo)) - __mul24(F.gHi4, hi);
+                X4[i] = (unsigned)min(max(x, 0), 65535);
+                Z4[i] = (unsigned)min(max(z, 0), 65535);
+                G4[i] = (unsigned)min(max(g, 0), 65535);
+                if constexpr (APLANE) {
+                    if (F.alphaMode == FXA_SHIFT)
+                        a[i] = minU(av[i] >> F.alphaShift, 255u);
+                    else
+                        a[i] = alphaFromPlane(A, av[i]); // avifReformatAlpha over libyuv's 255: copy or fp32 rescale
+                } else {
+                    a[i] = 255u;
+                }
+            }
+            if constexpr (NCH == 4) {
+                u4 w;
+                if constexpr (HASMUL) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        unsigned x = X4[i] >> 8, g = G4[i] >> 8, z = Z4[i] >> 8;
+                        if (A.postMul != MUL_NONE) { // ARGBAttenuate / ARGBUnattenuate (tileYuvToRgbSupported admits no other post-pass)
+                            x = fxAlphaMul(x, a[i], A.postMul), g = fxAlphaMul(g, a[i], A.postMul), z = fxAlphaMul(z, a[i], A.postMul);
+                        }
+                        w[i] = __builtin_amdgcn_perm(x, g, F.selXGm) | __builtin_amdgcn_perm(z, a[i], F.selZAm);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        w[i] = __builtin_amdgcn_perm(X4[i], G4[i], F.selXG) | __builtin_amdgcn_perm(Z4[i], a[i], F.selZA);
+                }
+                if (laneValid)
+                    storeVec(A.rgb, (sy + r) * A.rgbPitch + X * 4, w, nt);
+            } else {
+                // 12 bytes: x0 g0 z0 x1 | g1 z1 x2 g2 | z2 x3 g3 z3, each byte = byte 1 of its 4x-scale value
+                constexpr unsigned kLoPair = 0x0c0c0105u, kHiPair = 0x01050c0cu;
+                const unsigned w0 = __builtin_amdgcn_perm(X4[0], G4[0], kLoPair) | __builtin_amdgcn_perm(Z4[0], X4[1], kHiPair);
+                const unsigned w1 = __builtin_amdgcn_perm(G4[1], Z4[1], kLoPair) | __builtin_amdgcn_perm(X4[2], G4[2], kHiPair);
+                const unsigned w2 = __builtin_amdgcn_perm(Z4[2], X4[3], kLoPair) | __builtin_amdgcn_perm(G4[3], Z4[3], kHiPair);
+                if (laneValid) {
+                    const uint32_t off = (sy + r) * A.rgbPitch + X * 3;
+                    storeVec(A.rgb, off, w0, nt);
+                    storeVec(A.rgb, off + 4, w1, nt);
+                    storeVec(A.rgb, off + 8, w2, nt);
+                }
+            }
+        }
+    }
+}
+
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
+__device__ __forceinline__ void runBlockFx(const TileArgs & A, uint32_t tilesPerRun, unsigned (*rows)[kFxRowPitch])
+{
+    constexpr int kTileH = 8 * NS;
+    constexpr bool kNeedA = APLANE || HASMUL;
+    const uint32_t bands = (A.w4 + kBandW - 1) / kBandW;
+    const uint32_t tilesY = (A.h2 + kTileH - 1) / kTileH;
+    const uint32_t runsY = (tilesY + tilesPerRun - 1) / tilesPerRun;
+    const uint32_t nRuns = bands * runsY;
+    const uint32_t run = blockRemap(blockIdx.x, gridDim.x, (A.tuning & TUNE_XCD_BANDS) != 0 && (gridDim.z == 1 || (gridDim.x & 7) == 0));
+    if (run >= nRuns)
+        return;
+    const uint32_t rrow = run / bands;
+    const uint32_t bandX = (run - rrow * bands) * kBandW;
+    const uint32_t firstTile = rrow * tilesPerRun;
+    const uint32_t nTiles = (tilesY - firstTile < tilesPerRun) ? (tilesY - firstTile) : tilesPerRun;
+
+    BandCtx c;
+    c.bandX = bandX;
+    c.X = bandX + 4 * threadIdx.x;
+    c.laneValid = c.X < A.w4;
+    c.Xc = c.laneValid ? c.X : 0;
+    c.cxb = A.cx0 + (int)(bandX >> 1);
+
+    TileRaw<YT, SUB, BIL, kNeedA, NS> cur;
+    uint32_t tileY = firstTile * kTileH;
+    loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY, cur);
+    for (uint32_t i = 0; i < nTiles; ++i) {
+        if constexpr (BIL) {
+            stageTileFx<YT, SUB, kNeedA, NS>(A, cur, rows);
+            __syncthreads();
+        }
+        const bool more = i + 1 < nTiles;
+        TileRaw<YT, SUB, BIL, kNeedA, NS> nxt;
+        if (more)
+            loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY + kTileH, nxt);
+        computeTileFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(A, c, tileY, cur, rows);
+        if (!more)
+            break;
+        if constexpr (BIL)
+            __syncthreads();
+        cur = nxt;
+        tileY += kTileH;
+    }
+}
+
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
+__global__ __launch_bounds__(256) void yuvToRgbTileFxKernel(TileArgs A, uint32_t tilesPerRun)
+{
+    __shared__ __attribute__((aligned(16))) unsigned rows[BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch];
+    runBlockFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(A, tilesPerRun, rows);
+}
+
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
+__global__ __launch_bounds__(256) void yuvToRgbTileFxBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
+{
+    __shared__ __attribute__((aligned(16))) unsigned rows[BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch];
+    runBlockFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows);
+}
+
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool MUL>
+hipError_t launchOneFx(const TileLaunch & L)
+{
+    const dim3 block(kLanesX, kWavesPerBlock);
+    const dim3 grid(L.blocksPerJob, 1, L.count);
+    if (L.table)
+        hipLaunchKernelGGL((yuvToRgbTileFxBatchKernel<YT, SUB, BIL, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
+    else if (L.stripsPerWave >= 2)
+        hipLaunchKernelGGL((yuvToRgbTileFxKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
+    else
+        hipLaunchKernelGGL((yuvToRgbTileFxKernel<YT, SUB, BIL, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
+    return hipGetLastError();
+}
+
+template <typename YT, int SUB, bool BIL>
+hipError_t launchFxVariant(const TileKey & k, const TileLaunch & L)
+{
+    if (k.nch == 3)
+        return launchOneFx<YT, SUB, BIL, 3, false, false>(L);
+    if (k.hasMul)
+        return launchOneFx<YT, SUB, BIL, 4, true, true>(L);
+    return k.alphaPlane ? launchOneFx<YT, SUB, BIL, 4, true, false>(L) : launchOneFx<YT, SUB, BIL, 4, false, false>(L);
+}
+
+} // namespace tile
+} // namespace avifhip

@@ -218,26 +218,52 @@ __device__ __forceinline__ void store4(uint8_t * base, uint32_t off, const Pixel
         storeVec(base, off + 4, q[1].g | (z[1] << 8) | (x[2] << 16) | (q[2].g << 24), nt);
         storeVec(base, off + 8, z[2] | (x[3] << 8) | (q[3].g << 16) | (z[3] << 24), nt);
     } else if constexpr (sizeof(RT) == 2 && NCH == 4) {
-        u4 w0, w1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned lo = alphaFirst ? (a[k] | (x[k] << 16)) : (x[k] | (q[k].g << 16));
-            const unsigned hi = alphaFirst ? (q[k].g | (z[k] << 16)) : (z[k] | (a[k] << 16));
-            if (k < 2) {
-                w0[(k & 1) * 2 + 0] = lo;
-                w0[(k & 1) * 2 + 1] = hi;
-            } else {
-                w1[(k & 1) * 2 + 0] = lo;
-                w1[(k & 1) * 2 + 1] = hi;
-            }
-        }
-        storeVec(base, off, w0, nt);
-        storeVec(base, off + 16, w1, nt);
+        // never reached: 16-bit RGBA rows go through store4WideRgba (contiguous store instructions)
+        static_assert(sizeof(RT) != 2 || NCH != 4, "use store4WideRgba");
     } else { // 16-bit, 3 channels: 24 bytes = 3 x 8
         storeVec(base, off, (u2) { x[0] | (q[0].g << 16), z[0] | (x[1] << 16) }, nt);
         storeVec(base, off + 8, (u2) { q[1].g | (z[1] << 16), x[2] | (q[2].g << 16) }, nt);
         storeVec(base, off + 16, (u2) { z[2] | (x[3] << 16), q[3].g | (z[3] << 16) }, nt);
     }
+}
+
+// 16-bit RGBA: a lane's 4 pixels are 32 bytes.  Two 16-byte stores at (32*lane, 32*lane + 16) make every store
+// instruction touch only half of each cache line (tests/tools/membw3.hip: cfg3's bytes take 111 us that way and 74 us
+// with contiguous instructions), so the wave first re-distributes its 2 KiB row segment: store instruction h covers bytes
+// [1024*h, 1024*h + 1024) and lane l writes the 16 bytes at 16*l of it, which belong to lane 32*h + (l >> 1), half (l & 1).
+// Must be called by every lane of the wave (the exchange reads all lanes); rowOff addresses the band's first pixel.
+__device__ __forceinline__ void store4WideRgba(uint8_t * base, uint32_t rowOff, const PixelOut q[4], const unsigned a[4], bool swapRB, bool alphaFirst,
+                                               uint32_t bandX, uint32_t w4)
+{
+    u4 w0, w1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned x = swapRB ? q[k].b : q[k].r, z = swapRB ? q[k].r : q[k].b;
+        const unsigned lo = alphaFirst ? (a[k] | (x << 16)) : (x | (q[k].g << 16));
+        const unsigned hi = alphaFirst ? (q[k].g | (z << 16)) : (z | (a[k] << 16));
+        if (k < 2) {
+            w0[(k & 1) * 2 + 0] = lo;
+            w0[(k & 1) * 2 + 1] = hi;
+        } else {
+            w1[(k & 1) * 2 + 0] = lo;
+            w1[(k & 1) * 2 + 1] = hi;
+        }
+    }
+    const int l = threadIdx.x;
+    const int src = l >> 1;
+    const bool upper = (l & 1) != 0;
+    u4 s0, s1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned a0 = __shfl(w0[c], src), b0 = __shfl(w1[c], src);
+        const unsigned a1 = __shfl(w0[c], 32 + src), b1 = __shfl(w1[c], 32 + src);
+        s0[c] = upper ? b0 : a0;
+        s1[c] = upper ? b1 : a1;
+    }
+    if (bandX + 4u * (uint32_t)src < w4)
+        __builtin_nontemporal_store(s0, reinterpret_cast<u4 *>(base + rowOff + 16u * (uint32_t)l));
+    if (bandX + 4u * (uint32_t)(32 + src) < w4)
+        __builtin_nontemporal_store(s1, reinterpret_cast<u4 *>(base + rowOff + 1024u + 16u * (uint32_t)l));
 }
 
 // 8-bit RGBA family: (uint8_t)(0.5f + clamp01(c) * 255) for the three colour channels of four pixels, inserted into
@@ -324,6 +350,7 @@ struct TileRaw
 // Per-lane constants of the band a workgroup walks down.
 struct BandCtx
 {
+    uint32_t bandX; // first pixel column of the band (wave row segment), relative to the rectangle
     uint32_t X;     // first pixel column of this lane, relative to the rectangle
     uint32_t Xc;    // ... clamped into the rectangle for loads
     bool laneValid; // the lane's 4-pixel group exists (w4 is a multiple of 4: groups are whole or absent)
@@ -611,8 +638,12 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     q[i] = finishPixel<HASMUL>(A, br[i].y, g[i], br[i].x, av[i], a[i]);
-                if (laneValid)
-                    store4<RT, NCH>(A.rgb, off, q, a, swapRB, alphaFirst, nt);
+                if constexpr (sizeof(RT) == 2 && NCH == 4) {
+                    store4WideRgba(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, a, swapRB, alphaFirst, c.bandX, A.w4);
+                } else {
+                    if (laneValid)
+                        store4<RT, NCH>(A.rgb, off, q, a, swapRB, alphaFirst, nt);
+                }
             }
         }
     }
@@ -640,6 +671,7 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRu
     const uint32_t nTiles = (tilesY - firstTile < tilesPerRun) ? (tilesY - firstTile) : tilesPerRun;
 
     BandCtx c;
+    c.bandX = bandX;
     c.X = bandX + 4 * threadIdx.x;
     c.laneValid = c.X < A.w4;
     c.Xc = c.laneValid ? c.X : 0; // absent lanes load (and discard) the row's first group

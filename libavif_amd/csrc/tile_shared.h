@@ -37,6 +37,25 @@ struct TileArgs
     int32_t alphaRescale;                // alpha plane depth differs from the rgb depth (src/alpha.c:84-103)
     int32_t inLoopMul, postMul;          // MulMode
     uint32_t tuning;
+    // ---- fixed-point (libyuv-arithmetic) kernels only: SURVEY.md appendix D.1-D.4 with the constants folded ----
+    // libyuv's "YVU trick" (src/reformat_libyuv.c:386-423) is applied to the plane pointers: `u` above addresses the plane
+    // feeding the FIRST colour byte of a pixel (X: R for RGB orders, B for BGR orders), `v` the one feeding the third (Z).
+    // All terms are kept at 4x scale so that, after a clamp to [0, 65535], the result byte is byte 1 of the register
+    // (clamp8(t >> 6) == clamp(4t, 0, 65535) >> 8) and v_perm_b32 packs it straight into place:
+    //   y1 = (((y << yShl) | (y >> yShr)) * yMul) >> 16               (8-bit planes: (y * yMul8) >> 16, yMul8 = 0x0101 * yMul)
+    //   X4 = (y1 << 2) + kX4 + cX4 * lo,  Z4 = (y1 << 2) + kZ4 + cZ4 * hi,  G4 = (y1 << 2) + kG4 - gLo4 * lo - gHi4 * hi
+    //   with lo, hi = clamp8(upsampled chroma >> cShr) of the two planes, every plane sample first reduced by >> downshift
+    struct Fx
+    {
+        uint32_t yShl, yShr, yMul, yMul8;
+        int32_t kX4, kZ4, kG4;
+        int32_t cX4, cZ4, gLo4, gHi4;
+        uint32_t cShr, downshift;
+        uint32_t selXG, selZA;   // v_perm_b32 selectors: byte 1 of (X4, G4) / byte 1 of Z4 and byte 0 of alpha into their slots
+        uint32_t selXGm, selZAm; // the same for values already reduced to byte 0 (after attenuate / unattenuate)
+        int32_t alphaMode;  // FxAlpha
+        uint32_t alphaShift;
+    } fx;
 };
 
 
@@ -71,11 +90,46 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     A.alphaRescale = (s.depth != o.depth) ? 1 : 0;
     A.inLoopMul = p.inLoopMul, A.postMul = p.postMul;
     A.tuning = p.tuning;
+    if (p.arith == ARITH_LIBYUV) {
+        const FixedPointMatrix & m = p.fx;
+        A.fx.yShl = (p.fxNative == 10) ? 6 : (p.fxNative == 12) ? 4 : 8;
+        A.fx.yShr = (p.fxNative == 10) ? 4 : (p.fxNative == 12) ? 8 : 0;
+        A.fx.yMul = (uint32_t)m.yg;
+        A.fx.yMul8 = 0x0101u * (uint32_t)m.yg;
+        const int kB = m.yb - 128 * m.ub, kR = m.yb - 128 * m.vr, kG = m.yb + 128 * (m.ug + m.vg);
+        const bool redFirst = A.slotR < A.slotB;
+        if (redFirst) { // X = R is fed by the V plane
+            const uint8_t * t = A.u;
+            A.u = A.v, A.v = t;
+            const uint32_t tp = A.uPitch;
+            A.uPitch = A.vPitch, A.vPitch = tp;
+            A.fx.kX4 = 4 * kR, A.fx.cX4 = 4 * m.vr, A.fx.kZ4 = 4 * kB, A.fx.cZ4 = 4 * m.ub, A.fx.gLo4 = 4 * m.vg, A.fx.gHi4 = 4 * m.ug;
+        } else {
+            A.fx.kX4 = 4 * kB, A.fx.cX4 = 4 * m.ub, A.fx.kZ4 = 4 * kR, A.fx.cZ4 = 4 * m.vr, A.fx.gLo4 = 4 * m.ug, A.fx.gHi4 = 4 * m.vg;
+        }
+        A.fx.kG4 = 4 * kG;
+        A.fx.cShr = (p.fxNative == 10) ? 2 : (p.fxNative == 12) ? 4 : 0;
+        A.fx.downshift = (uint32_t)p.fxDownshift;
+        // perm selectors: source bytes 4..7 = first operand, 0..3 = second operand, 12 = constant zero
+        const uint32_t slotX = redFirst ? A.slotR : A.slotB, slotZ = redFirst ? A.slotB : A.slotR;
+        auto place = [](uint32_t slotA_, uint32_t selA, uint32_t slotB_, uint32_t selB) {
+            uint32_t sel = 0x0c0c0c0cu;
+            sel = (sel & ~(0xffu << (8 * slotA_))) | (selA << (8 * slotA_));
+            sel = (sel & ~(0xffu << (8 * slotB_))) | (selB << (8 * slotB_));
+            return sel;
+        };
+        A.fx.selXG = place(slotX, 5, A.slotG, 1), A.fx.selXGm = place(slotX, 4, A.slotG, 0);
+        if (o.hasAlpha) {
+            A.fx.selZA = place(slotZ, 5, A.slotA, 0), A.fx.selZAm = place(slotZ, 4, A.slotA, 0);
+        }
+        A.fx.alphaMode = p.fxAlpha, A.fx.alphaShift = (uint32_t)p.fxAlphaShift;
+    }
     return A;
 }
 
 struct TileKey
 {
+    bool fixedPoint; // libyuv arithmetic (tile_fx_impl.h), 8-bit RGB outputs
     bool wideYuv;
     int sub;
     bool bilinear;
@@ -96,8 +150,6 @@ struct TileLaunch
     hipStream_t stream;
 };
 
-hipError_t launchTileU8(const TileKey & key, const TileLaunch & launch);
-hipError_t launchTileU16(const TileKey & key, const TileLaunch & launch);
 
 } // namespace tile
 } // namespace avifhip
