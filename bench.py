@@ -2,7 +2,10 @@
 """bench.py -- megapixels/s of libavif's YUV->RGB reformat hot path on MI355X.
 
 A "step" is one pass of the hot path over one synthetic 8K frame: 7680x4320 8-bit YUV 4:2:0, BT.709 limited
-range -> RGBA8 with bilinear chroma upsampling (BASELINE.json configs[1]), planes and pixels resident in HBM.
+range -> RGBA8 with bilinear chroma upsampling (BASELINE.json configs[1]), planes and pixels resident in HBM, converted
+with the API defaults (rgb.avoidLibYUV = 0): the reference's INTEGER path, i.e. byte-identical to what a libavif built
+with libyuv computes (I420ToARGBMatrixFilter, kFilterBilinear).  The fp32 path (avoidLibYUV = 1, byte-identical to a
+libavif built without libyuv) is timed next to it and reported inside "roofline" as "fp32_path".
 Steps cycle over several distinct frames so the working set (>700 MB) exceeds the 256 MB Infinity Cache: every
 byte of every step comes from and goes to HBM.  Frames are independent units of work (sequence frames / grid
 tiles), so consecutive steps are issued round-robin on a few HIP streams and overlap each other's head and tail.
@@ -46,6 +49,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=STREAMS)
+    ap.add_argument("--arithmetic", choices=("integer", "fp32"), default="integer",
+                    help="integer: API defaults, libyuv's fixed point (default); fp32: rgb.avoidLibYUV = 1, libavif's built-in path")
     return ap.parse_args()
 
 
@@ -77,7 +82,8 @@ def cpu_baseline(abi, synth, seconds: float):
     mp = WIDTH * HEIGHT / 1e6
     return {"value": round(mp * frames / t_total, 2), "unit": "megapixels/s", "cores": 1, "kind": kind,
             "sample": f"{frames} x 7680x4320 8-bit 4:2:0 BT.709 limited -> RGBA8 bilinear frames, libavif built-in float path "
-                      f"(avoidLibYUV=1, maxThreads=1: the reference runs 4:2:0 bilinear single-threaded), {t_total:.1f} s of CPU; "
+                      f"(the reference compiled from its own sources has no libyuv: avoidLibYUV=1 arithmetic; maxThreads=1: the reference "
+                      f"runs 4:2:0 bilinear single-threaded), {t_total:.1f} s of CPU; "
                       f"best frame {mp / best:.1f} MP/s",
             "best_value": round(mp / best, 2)}
 
@@ -105,7 +111,8 @@ def main():
     if lib.avifhipDeviceCount() <= 0:
         raise SystemExit("bench.py: no HIP device visible -- there is no CPU fallback for the product path")
     native.check(lib.avifhipSetDevice(local_rank if world > 1 else 0), "avifhipSetDevice")
-    lib.avifhipSetArithmetic(1)
+    lib.avifhipSetArithmetic(0)  # AVIFHIP_ARITHMETIC_AUTO: follow rgb.avoidLibYUV like a libavif built with libyuv
+    integer = args.arithmetic == "integer"
 
     # ---- synthetic frames, resident in HBM before the timed region ----
     frames = []
@@ -113,7 +120,7 @@ def main():
         img = abi.make_yuv(WIDTH, HEIGHT, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, abi.AVIF_MATRIX_COEFFICIENTS_BT709)
         synth.fill_yuv(img, 0x12345678 + rank * FRAMES_IN_FLIGHT + f)
         rgb = abi.make_rgb(WIDTH, HEIGHT, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR,
-                           avoid_libyuv=True, allocate=False)
+                           avoid_libyuv=not integer, allocate=False)
         dimg = device.DeviceYUV(img)
         drgb = device.DeviceRGB(rgb)
         frames.append((dimg, drgb))
@@ -161,6 +168,14 @@ def main():
     kernel_ms_stream = min(lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 4, 40, None) for _ in range(5))
     kernel_ms_same = min(lib.avifhipTimeYUVToRGB(frames[0][0].struct, frames[0][1].struct, 4, 40, None) for _ in range(5))
 
+    # the other arithmetic family on the same frames (same buffers, only rgb.avoidLibYUV flipped), kernel timing only
+    for _, drgb in frames:
+        drgb.struct.avoidLibYUV = 1 if integer else 0
+    other_ms_stream = min(lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 4, 40, None) for _ in range(5))
+    other_kernel = native.last_kernel()
+    for _, drgb in frames:
+        drgb.struct.avoidLibYUV = 0 if integer else 1
+
     mp_per_step = WIDTH * HEIGHT / 1e6
     value = mp_per_step * args.steps * world / elapsed
     alg_bytes = ALGORITHMIC_BYTES_PER_PIXEL * WIDTH * HEIGHT
@@ -182,7 +197,8 @@ def main():
         "config": {
             "workload": "7680x4320 8-bit YUV420 BT.709 limited -> RGBA8, bilinear chroma upsampling, HBM-resident, "
                         f"{FRAMES_IN_FLIGHT} distinct frames cycled per rank on {n_streams} HIP streams",
-            "arithmetic": "libavif built-in fp32 path, byte-exact",
+            "arithmetic": ("libavif API defaults (avoidLibYUV=0): libyuv fixed point, byte-identical to a libavif built with libyuv" if integer
+                           else "avoidLibYUV=1: libavif built-in fp32 path, byte-identical to a libavif built without libyuv"),
             "kernel": kernel_name,
             "frames_per_step": 1,
             "parallelism": f"frames sharded over {world} rank(s), no collective",
@@ -199,12 +215,21 @@ def main():
             "kernel_ms_same_frame": round(kernel_ms_same, 5),
             "frac_same_frame": round(alg_bytes / (kernel_ms_same * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "read_only_GBps": round(1.5 * WIDTH * HEIGHT / (kernel_ms_stream * 1e-3) / 1e9, 1),
+            ("fp32_path" if integer else "integer_path"): {
+                "kernel": other_kernel,
+                "kernel_ms_hbm_streaming": round(other_ms_stream, 5),
+                "achieved": round(alg_bytes / (other_ms_stream * 1e-3) / 1e9, 1),
+                "frac": round(alg_bytes / (other_ms_stream * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            },
         },
     }
     traffic_file = ROOT / "profiles" / "pmc_traffic.json"
     if traffic_file.exists():
         try:
-            out["roofline"]["traffic"] = json.loads(traffic_file.read_text()).get("traffic_bytes_per_launch")
+            tj = json.loads(traffic_file.read_text())
+            # the counters were collected for one kernel family: use them only for that family
+            if ("TileFxKernel" in tj.get("kernel", "")) == ("fixed" in kernel_name):
+                out["roofline"]["traffic"] = tj.get("traffic_bytes_per_launch")
         except Exception:
             pass
 

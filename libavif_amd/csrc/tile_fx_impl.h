@@ -243,7 +243,7 @@ __device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx 
 }
 
 template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
-__device__ __forceinline__ void runBlockFx(const TileArgs & A, uint32_t tilesPerRun, unsigned (*rows)[kFxRowPitch])
+__device__ __forceinline__ void runBlockFx(const TileArgs & A, uint32_t tilesPerRun, unsigned (*rows)[BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch])
 {
     constexpr int kTileH = 8 * NS;
     constexpr bool kNeedA = APLANE || HASMUL;
@@ -266,23 +266,26 @@ __device__ __forceinline__ void runBlockFx(const TileArgs & A, uint32_t tilesPer
     c.Xc = c.laneValid ? c.X : 0;
     c.cxb = A.cx0 + (int)(bandX >> 1);
 
+    // double-buffered LDS, one barrier per tile (see runBlock in tile_impl.h)
     TileRaw<YT, SUB, BIL, kNeedA, NS> cur;
     uint32_t tileY = firstTile * kTileH;
     loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY, cur);
+    if constexpr (BIL) {
+        stageTileFx<YT, SUB, kNeedA, NS>(A, cur, rows[0]);
+        __syncthreads();
+    }
     for (uint32_t i = 0; i < nTiles; ++i) {
-        if constexpr (BIL) {
-            stageTileFx<YT, SUB, kNeedA, NS>(A, cur, rows);
-            __syncthreads();
-        }
         const bool more = i + 1 < nTiles;
         TileRaw<YT, SUB, BIL, kNeedA, NS> nxt;
         if (more)
             loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY + kTileH, nxt);
-        computeTileFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(A, c, tileY, cur, rows);
+        computeTileFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(A, c, tileY, cur, rows[i & 1]);
         if (!more)
             break;
-        if constexpr (BIL)
+        if constexpr (BIL) {
+            stageTileFx<YT, SUB, kNeedA, NS>(A, nxt, rows[(i + 1) & 1]);
             __syncthreads();
+        }
         cur = nxt;
         tileY += kTileH;
     }
@@ -291,14 +294,14 @@ __device__ __forceinline__ void runBlockFx(const TileArgs & A, uint32_t tilesPer
 template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
 __global__ __launch_bounds__(256) void yuvToRgbTileFxKernel(TileArgs A, uint32_t tilesPerRun)
 {
-    __shared__ __attribute__((aligned(16))) unsigned rows[BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch];
+    __shared__ __attribute__((aligned(16))) unsigned rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch];
     runBlockFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(A, tilesPerRun, rows);
 }
 
 template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
 __global__ __launch_bounds__(256) void yuvToRgbTileFxBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
 {
-    __shared__ __attribute__((aligned(16))) unsigned rows[BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch];
+    __shared__ __attribute__((aligned(16))) unsigned rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch];
     runBlockFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows);
 }
 

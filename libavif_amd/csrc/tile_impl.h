@@ -654,7 +654,7 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 // of tile i+1 are in flight while tile i is computed and stored, so a wave waits for memory once per run, not once
 // per tile; vertically consecutive tiles also re-read their shared chroma halo rows from the nearest cache.
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
-__device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRun, f2 (*rows)[kRowPitch])
+__device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRun, f2 (*rows)[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch])
 {
     constexpr int kTileH = 8 * NS;
     constexpr bool kNeedA = APLANE || HASMUL;
@@ -677,23 +677,28 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRu
     c.Xc = c.laneValid ? c.X : 0; // absent lanes load (and discard) the row's first group
     c.cxb = A.cx0 + (int)(bandX >> 1);
 
+    // Two LDS buffers: while tile i is computed from one, the neighbourhood of tile i+1 (whose loads were issued before
+    // the computation started) is staged into the other -- one barrier per tile, and no wave waits for the slowest one
+    // between "done reading" and "may overwrite".
     TileRaw<YT, SUB, BIL, kNeedA, NS> cur;
     uint32_t tileY = firstTile * kTileH;
     loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY, cur);
+    if constexpr (BIL) {
+        stageTile<YT, SUB, kNeedA, NS>(A, cur, rows[0]);
+        __syncthreads();
+    }
     for (uint32_t i = 0; i < nTiles; ++i) {
-        if constexpr (BIL) {
-            stageTile<YT, SUB, kNeedA, NS>(A, cur, rows);
-            __syncthreads();
-        }
         const bool more = i + 1 < nTiles;
         TileRaw<YT, SUB, BIL, kNeedA, NS> nxt;
         if (more)
             loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY + kTileH, nxt);
-        computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, c, tileY, cur, rows);
+        computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, c, tileY, cur, rows[i & 1]);
         if (!more)
             break;
-        if constexpr (BIL)
-            __syncthreads(); // every wave is done reading the LDS rows before the next tile overwrites them
+        if constexpr (BIL) {
+            stageTile<YT, SUB, kNeedA, NS>(A, nxt, rows[(i + 1) & 1]);
+            __syncthreads();
+        }
         cur = nxt;
         tileY += kTileH;
     }
@@ -702,7 +707,7 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRu
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
 __global__ __launch_bounds__(256) void yuvToRgbTileKernel(TileArgs A, uint32_t tilesPerRun)
 {
-    __shared__ __attribute__((aligned(16))) f2 rows[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
+    __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
     runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, tilesPerRun, rows);
 }
 
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(256) void yuvToRgbTileKernel(TileArgs A, uint32_t t
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
 __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
 {
-    __shared__ __attribute__((aligned(16))) f2 rows[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
+    __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
     runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows);
 }
 
