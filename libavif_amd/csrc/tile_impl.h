@@ -149,13 +149,28 @@ __device__ __forceinline__ unsigned alphaFromPlane(const TileArgs & A, unsigned 
 // (un)premultiply on stored integers with the verified reciprocal for "/ maxF" (src/alpha.c:180-192, :367-381)
 __device__ __forceinline__ unsigned alphaMulIntFast(const TileArgs & A, unsigned c, unsigned a, int mulMode)
 {
+    if (mulMode == MUL_MULTIPLY) {
+        // floorf(c * a / maxF + 0.5f): the operand is never negative, so the truncating conversion is the floor; a == 0
+        // needs no special case (0 / maxF + 0.5f truncates to 0); a >= max leaves the channel untouched (:180-183)
+        const unsigned m = (unsigned)(divExact((float)c * (float)a, A.rcpRgbMax) + 0.5f);
+        return (a >= A.rgbMax) ? c : m;
+    }
     if (a >= A.rgbMax)
         return c;
     if (a == 0)
         return 0;
-    if (mulMode == MUL_MULTIPLY)
-        return (unsigned)roundHalfUp(divExact((float)c * (float)a, A.rcpRgbMax));
     return unpremultiplyInt(c, a, A.rgbMaxF);
+}
+
+// (T)(0.5f + clamp01(c) * max) without clamping first: t = 0.5f + c * max is monotonic in c, v_cvt_u32_f32 truncates toward
+// zero like the C cast and returns 0 for every negative operand, and the min restores the upper clamp (c >= 1 gives
+// t >= max + 0.5f, which truncates to max or more).  Identical to clamp-then-quantise for every finite c.
+__device__ __forceinline__ unsigned quantizeSat(float c, float maxf, unsigned maxv)
+{
+    const float t = 0.5f + (c * maxf);
+    unsigned q;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(t));
+    return minU(q, maxv);
 }
 
 // General finish of one pixel from unclamped R,G,B: clamp, optional fp32 alpha multiply, quantise, optional integer
@@ -163,17 +178,21 @@ __device__ __forceinline__ unsigned alphaMulIntFast(const TileArgs & A, unsigned
 template <bool HASMUL>
 __device__ __forceinline__ PixelOut finishPixel(const TileArgs & A, float R, float G, float B, unsigned unormA, unsigned a)
 {
-    float Rc = clamp01(R), Gc = clamp01(G), Bc = clamp01(B);
+    PixelOut q;
     if (HASMUL && A.inLoopMul != MUL_NONE) {
+        float Rc = clamp01(R), Gc = clamp01(G), Bc = clamp01(B);
         const float Ac = clamp01(divExact((float)minU(unormA, A.yuvMax), A.rcpYuvMax));
         Rc = applyAlphaF(Rc, Ac, A.inLoopMul);
         Gc = applyAlphaF(Gc, Ac, A.inLoopMul);
         Bc = applyAlphaF(Bc, Ac, A.inLoopMul);
+        q.r = quantize(Rc, A.rgbMaxF);
+        q.g = quantize(Gc, A.rgbMaxF);
+        q.b = quantize(Bc, A.rgbMaxF);
+        return q;
     }
-    PixelOut q;
-    q.r = quantize(Rc, A.rgbMaxF);
-    q.g = quantize(Gc, A.rgbMaxF);
-    q.b = quantize(Bc, A.rgbMaxF);
+    q.r = quantizeSat(R, A.rgbMaxF, A.rgbMax);
+    q.g = quantizeSat(G, A.rgbMaxF, A.rgbMax);
+    q.b = quantizeSat(B, A.rgbMaxF, A.rgbMax);
     if (HASMUL && A.postMul != MUL_NONE) {
         q.r = alphaMulIntFast(A, q.r, a, A.postMul);
         q.g = alphaMulIntFast(A, q.g, a, A.postMul);
