@@ -1,0 +1,113 @@
+/*
+ * avif_preload_hip.c -- seam A: an LD_PRELOAD-able interposer for applications that link a SHARED libavif and cannot be
+ * rebuilt.  It exports the four public reformat entry points of include/avif/avif.h:1031-1038
+ *     avifImageYUVToRGB, avifImageRGBToYUV, avifRGBImagePremultiplyAlpha, avifRGBImageUnpremultiplyAlpha
+ * with libavif's own signatures, serves them from libavifhip.so (the MI355X HIP kernels), and forwards to the real
+ * libavif (dlsym(RTLD_NEXT)) everything that is not worth a GPU round trip, that the GPU library declines, or that fails
+ * on the accelerator -- the application's call never fails because of the interposer.
+ *
+ *     LD_PRELOAD=/path/libavifhip_preload.so avifdec in.avif out.png
+ *
+ * Arithmetic follows the libavif being interposed: if it was built with libyuv (avifLibYUVVersion() != 0) results equal
+ * that build's (libavifhip's default, AVIFHIP_ARITHMETIC_AUTO); if it was built without, the fp32 arithmetic is pinned.
+ * AVIFHIP_ARITHMETIC in the environment overrides.  Only the four symbols above are interposed; calls libavif makes
+ * internally (e.g. avifImageYUVToRGB from its decoder helpers) are bound inside libavif and are not affected.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "avifhip.h"
+
+#define AVIF_EXPORT __attribute__((visibility("default")))
+
+typedef avifResult (*YuvToRgbFn)(const avifImage *, avifRGBImage *);
+typedef avifResult (*RgbToYuvFn)(avifImage *, const avifRGBImage *);
+typedef avifResult (*AlphaFn)(avifRGBImage *);
+typedef unsigned int (*VersionFn)(void);
+
+static struct
+{
+    int resolved;
+    YuvToRgbFn yuvToRgb;
+    RgbToYuvFn rgbToYuv;
+    AlphaFn premultiply, unpremultiply;
+    uint64_t minPixels;
+    int gpu;
+} g;
+
+static void resolve(void)
+{
+    if (g.resolved)
+        return;
+    g.yuvToRgb = (YuvToRgbFn)dlsym(RTLD_NEXT, "avifImageYUVToRGB");
+    g.rgbToYuv = (RgbToYuvFn)dlsym(RTLD_NEXT, "avifImageRGBToYUV");
+    g.premultiply = (AlphaFn)dlsym(RTLD_NEXT, "avifRGBImagePremultiplyAlpha");
+    g.unpremultiply = (AlphaFn)dlsym(RTLD_NEXT, "avifRGBImageUnpremultiplyAlpha");
+    const char * e = getenv("AVIFHIP_MIN_PIXELS");
+    const long v = e ? atol(e) : 512L * 512L;
+    g.minPixels = v < 0 ? 0 : (uint64_t)v;
+    g.gpu = avifhipDeviceCount() > 0;
+    if (!getenv("AVIFHIP_ARITHMETIC")) {
+        const VersionFn libyuvVersion = (VersionFn)dlsym(RTLD_NEXT, "avifLibYUVVersion");
+        if (libyuvVersion && libyuvVersion() == 0)
+            avifhipSetArithmetic(AVIFHIP_ARITHMETIC_FLOAT); /* the interposed libavif has no libyuv */
+    }
+    g.resolved = 1;
+}
+
+static int worthIt(uint32_t width, uint32_t height)
+{
+    return g.gpu && (uint64_t)width * height >= g.minPixels;
+}
+/* results after which the real libavif should take the call */
+static int declined(avifResult r)
+{
+    return r == AVIF_RESULT_NOT_IMPLEMENTED || r == AVIF_RESULT_UNKNOWN_ERROR || r == AVIF_RESULT_OUT_OF_MEMORY;
+}
+
+AVIF_EXPORT avifResult avifImageYUVToRGB(const avifImage * image, avifRGBImage * rgb)
+{
+    resolve();
+    if (image && rgb && worthIt(image->width, image->height)) {
+        const avifResult r = avifhipImageYUVToRGB(image, rgb);
+        if (!declined(r) || !g.yuvToRgb)
+            return r;
+    }
+    return g.yuvToRgb ? g.yuvToRgb(image, rgb) : AVIF_RESULT_NOT_IMPLEMENTED;
+}
+
+AVIF_EXPORT avifResult avifImageRGBToYUV(avifImage * image, const avifRGBImage * rgb)
+{
+    resolve();
+    /* libsharpyuv downsampling is libavif's own (src/reformat_libsharpyuv.c): leave those calls alone */
+    if (image && rgb && worthIt(image->width, image->height) && rgb->chromaDownsampling != AVIF_CHROMA_DOWNSAMPLING_SHARP_YUV) {
+        const avifResult r = avifhipImageRGBToYUV(image, rgb);
+        if (!declined(r) || !g.rgbToYuv)
+            return r;
+    }
+    return g.rgbToYuv ? g.rgbToYuv(image, rgb) : AVIF_RESULT_NOT_IMPLEMENTED;
+}
+
+AVIF_EXPORT avifResult avifRGBImagePremultiplyAlpha(avifRGBImage * rgb)
+{
+    resolve();
+    if (rgb && worthIt(rgb->width, rgb->height)) {
+        const avifResult r = avifhipRGBImagePremultiplyAlpha(rgb);
+        if (!declined(r) || !g.premultiply)
+            return r;
+    }
+    return g.premultiply ? g.premultiply(rgb) : AVIF_RESULT_NOT_IMPLEMENTED;
+}
+
+AVIF_EXPORT avifResult avifRGBImageUnpremultiplyAlpha(avifRGBImage * rgb)
+{
+    resolve();
+    if (rgb && worthIt(rgb->width, rgb->height)) {
+        const avifResult r = avifhipRGBImageUnpremultiplyAlpha(rgb);
+        if (!declined(r) || !g.unpremultiply)
+            return r;
+    }
+    return g.unpremultiply ? g.unpremultiply(rgb) : AVIF_RESULT_NOT_IMPLEMENTED;
+}
