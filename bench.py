@@ -165,13 +165,18 @@ def main():
     # (a) cycling over the distinct frames: every launch streams from/to HBM; (b) one frame repeated: its 50 MB of
     # input stay in the 256 MB Infinity Cache.  (a) is the roofline figure.
     n, imgs, rgbs = _cycle_args(frames)
-    kernel_ms_stream = min(lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 4, 40, None) for _ in range(5))
-    kernel_ms_same = min(lib.avifhipTimeYUVToRGB(frames[0][0].struct, frames[0][1].struct, 4, 40, None) for _ in range(5))
+    def median(xs):
+        xs = sorted(xs)
+        return xs[len(xs) // 2]
+
+    # median of 7 event-timed bursts of 40 launches (not the best one: the figure must agree with a profiler's average)
+    kernel_ms_stream = median([lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 4, 40, None) for _ in range(7)])
+    kernel_ms_same = median([lib.avifhipTimeYUVToRGB(frames[0][0].struct, frames[0][1].struct, 4, 40, None) for _ in range(7)])
 
     # the other arithmetic family on the same frames (same buffers, only rgb.avoidLibYUV flipped), kernel timing only
     for _, drgb in frames:
         drgb.struct.avoidLibYUV = 1 if integer else 0
-    other_ms_stream = min(lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 4, 40, None) for _ in range(5))
+    other_ms_stream = median([lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 4, 40, None) for _ in range(7)])
     other_kernel = native.last_kernel()
     for _, drgb in frames:
         drgb.struct.avoidLibYUV = 0 if integer else 1
