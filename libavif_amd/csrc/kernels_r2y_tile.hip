@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.h"
@@ -111,6 +112,8 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
     const uint64_t waveStrips = (uint64_t)bands * strips;
     uint32_t spw = (uint32_t)(waveStrips / (4 * 2048));
     spw = spw < 1 ? 1 : (spw > 8 ? 8 : spw);
+    if (const char * e = getenv("AVIFHIP_R2Y_SPW")) // diagnostics / A-B measurements only
+        spw = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : spw;
     A.stripsPerWave = spw;
     const uint32_t chunks = (strips + 4 * spw - 1) / (4 * spw);
     hipError_t e = k.wideRgb ? launchR2YTileRgb16(k, A, bands * chunks, stream) : launchR2YTileRgb8(k, A, bands * chunks, stream);

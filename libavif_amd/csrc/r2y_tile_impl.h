@@ -78,10 +78,15 @@ struct Yuvf
     float y, u, v;
 };
 
-// src/reformat.c:197-219
+// AVIF_CLAMP((int)floorf(v * range + bias + 0.5f), 0, max), src/reformat.c:197-219.  v_cvt_u32_f32 truncates toward zero
+// and returns 0 for every negative operand: for t >= 0 truncation is the floor, for t < 0 the floor is negative and the
+// reference's clamp returns 0 as well; the min restores the upper clamp.
 __device__ __forceinline__ int toUNorm(float v, float range, float bias, int maxv)
 {
-    return clampInt((int)floorf(((v * range) + bias) + 0.5f), 0, maxv);
+    const float t = ((v * range) + bias) + 0.5f;
+    unsigned q;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(t));
+    return (int)min(q, (unsigned)maxv);
 }
 
 template <typename YT>
@@ -126,6 +131,8 @@ __device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uin
     const int yuvMax = (int)A.yuvMax;
     const bool alphaFirst = (NCH == 4) && (A.slotA == 0);
     const bool swapRB = A.slotB < A.slotR;
+    const unsigned colourShift = alphaFirst ? 8u : 0u, alphaShift = alphaFirst ? 0u : 24u;
+    (void)colourShift, (void)alphaShift;
     Yuvf c[2][4];
     int yq[2][4], aq[2][4];
 #pragma unroll
@@ -133,12 +140,20 @@ __device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uin
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             // memory-order channels -> (first colour, G, last colour, alpha)
-            unsigned c0 = channelOf<RT, NCH>(S.row[r], i, 0), c1 = channelOf<RT, NCH>(S.row[r], i, 1), c2 = channelOf<RT, NCH>(S.row[r], i, 2);
-            unsigned ca = 0;
-            if constexpr (NCH == 4) {
-                const unsigned c3 = channelOf<RT, NCH>(S.row[r], i, 3);
-                ca = alphaFirst ? c0 : c3;
-                c0 = alphaFirst ? c1 : c0, c1 = alphaFirst ? c2 : c1, c2 = alphaFirst ? c3 : c2;
+            unsigned c0, c1, c2, ca = 0;
+            if constexpr (NCH == 4 && sizeof(RT) == 1) {
+                // one dword per pixel: alpha-first layouts shift the colour bytes down instead of selecting per channel
+                const unsigned w = S.row[r].w[i];
+                const unsigned cw = w >> colourShift;
+                c0 = cw & 0xffu, c1 = (cw >> 8) & 0xffu, c2 = (cw >> 16) & 0xffu;
+                ca = (w >> alphaShift) & 0xffu;
+            } else {
+                c0 = channelOf<RT, NCH>(S.row[r], i, 0), c1 = channelOf<RT, NCH>(S.row[r], i, 1), c2 = channelOf<RT, NCH>(S.row[r], i, 2);
+                if constexpr (NCH == 4) {
+                    const unsigned c3 = channelOf<RT, NCH>(S.row[r], i, 3);
+                    ca = alphaFirst ? c0 : c3;
+                    c0 = alphaFirst ? c1 : c0, c1 = alphaFirst ? c2 : c1, c2 = alphaFirst ? c3 : c2;
+                }
             }
             // "Unpack RGB into normalized float", src/reformat.c:312-323: channel / maxChannelF
             const float x = divExact((float)c0, A.rcpRgbMax), G = divExact((float)c1, A.rcpRgbMax), z = divExact((float)c2, A.rcpRgbMax);
