@@ -134,6 +134,14 @@ AVIFHIP_API const char * avifhipLastError(void);
 /* Which kernel family served the last conversion on this thread (diagnostics/tests):
  * e.g. "yuv2rgb_tile<u8,420,bilinear,rgba8>" or "yuv2rgb_generic". */
 AVIFHIP_API const char * avifhipLastKernel(void);
+/* Host-only (needs no GPU): how the library would serve avifhipImageYUVToRGB(image, rgb) under the current arithmetic
+ * setting, as text "arith=<fp32|libyuv> kernel=<tile|generic> native=<8|10|12> downshift=<n> bilinear=<0|1>
+ * alpha=<keep|fill|plane-shift|plane-float> inloopmul=<n> postmul=<n> postmulfx=<0|1>" -- the plan layer's restatement of
+ * src/reformat.c:1445-1593 and src/reformat_libyuv.c:544-1108, exposed for tests and diagnostics.  Returns the avifResult
+ * the conversion would start with (argument / format errors), writes at most `size` bytes including the terminator. */
+AVIFHIP_API avifResult avifhipExplainYUVToRGB(const avifImage * image, const avifRGBImage * rgb, char * text, size_t size);
+/* Same for avifhipImageRGBToYUV: "arith=<fp32|libyuv> kernel=<tile|generic> mul=<n>". */
+AVIFHIP_API avifResult avifhipExplainRGBToYUV(const avifImage * image, const avifRGBImage * rgb, char * text, size_t size);
 /* Number of conversions this thread has enqueued on a GPU so far (tests: proves the HIP path, not a fallback, ran). */
 AVIFHIP_API uint64_t avifhipLaunchCount(void);
 AVIFHIP_API const char * avifhipVersion(void);

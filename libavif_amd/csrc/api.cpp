@@ -835,6 +835,42 @@ extern "C" avifResult avifhipSynchronize(void * hipStream)
     return AVIF_RESULT_OK;
 }
 
+extern "C" avifResult avifhipExplainYUVToRGB(const avifImage * image, const avifRGBImage * rgb, char * text, size_t size)
+{
+    if (!image || !rgb || !text || !size)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    text[0] = 0;
+    YuvToRgbPlan p;
+    const avifResult r = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &p);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    const char * alpha = "keep";
+    if (p.alphaSource == ALPHA_FILL)
+        alpha = "fill";
+    else if (p.alphaSource == ALPHA_PLANE)
+        alpha = (p.arith == ARITH_LIBYUV && p.fxAlpha == FXA_SHIFT) ? "plane-shift" : "plane-float";
+    const bool tiled = gTiledKernels.load(std::memory_order_relaxed) && tileYuvToRgbSupported(p);
+    snprintf(text, size, "arith=%s kernel=%s native=%d downshift=%d bilinear=%d alpha=%s inloopmul=%d postmul=%d postmulfx=%d",
+             p.arith == ARITH_LIBYUV ? "libyuv" : "fp32", tiled ? "tile" : "generic", p.arith == ARITH_LIBYUV ? p.fxNative : 0,
+             p.arith == ARITH_LIBYUV ? p.fxDownshift : 0, p.bilinear, alpha, p.inLoopMul, p.postMul, p.postMulFx);
+    return AVIF_RESULT_OK;
+}
+
+extern "C" avifResult avifhipExplainRGBToYUV(const avifImage * image, const avifRGBImage * rgb, char * text, size_t size)
+{
+    if (!image || !rgb || !text || !size)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    text[0] = 0;
+    RgbToYuvPlan p;
+    const avifResult r = makeRgbToYuvPlan(image, rgb, effectiveArithmetic(), &p);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    finishRgbToYuvPlan(image, rgb, &p);
+    const bool tiled = gTiledKernels.load(std::memory_order_relaxed) && tileRgbToYuvSupported(p);
+    snprintf(text, size, "arith=%s kernel=%s mul=%d", p.arith == ARITH_LIBYUV ? "libyuv" : "fp32", tiled ? "tile" : "generic", p.mul);
+    return AVIF_RESULT_OK;
+}
+
 extern "C" const char * avifhipLastError(void)
 {
     return tls.lastError;

@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
     "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
+    "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV",
 ]
 
 _lib = None
@@ -84,6 +85,8 @@ def load() -> C.CDLL:
         "avifhipRGBImageToF16": (i32, [P_RGB]),
         "avifhipLaunchCount": (C.c_uint64, []),
         "avifhipTimeYUVToRGBCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
+        "avifhipExplainYUVToRGB": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
+        "avifhipExplainRGBToYUV": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -100,6 +103,19 @@ def check(result: int, what: str = "avifhip call") -> None:
 
 def last_kernel() -> str:
     return load().avifhipLastKernel().decode()
+
+
+def explain_y2r(image_struct, rgb_struct):
+    """(avifResult, {key: value}) of avifhipExplainYUVToRGB: host-only view of the plan layer's decisions."""
+    buf = C.create_string_buffer(256)
+    res = load().avifhipExplainYUVToRGB(image_struct, rgb_struct, buf, len(buf))
+    return res, dict(kv.split("=", 1) for kv in buf.value.decode().split())
+
+
+def explain_r2y(image_struct, rgb_struct):
+    buf = C.create_string_buffer(256)
+    res = load().avifhipExplainRGBToYUV(image_struct, rgb_struct, buf, len(buf))
+    return res, dict(kv.split("=", 1) for kv in buf.value.decode().split())
 
 
 def device_count() -> int:

@@ -41,6 +41,8 @@ def oracle() -> C.CDLL:
         for name in ("oracleRGBImagePremultiplyAlpha", "oracleRGBImageUnpremultiplyAlpha",
                      "oracleLibyuvRGBImagePremultiplyAlpha", "oracleLibyuvRGBImageUnpremultiplyAlpha"):
             getattr(lib, name).restype, getattr(lib, name).argtypes = C.c_int, [_P_RGB]
+        lib.oracleLibyuvHookYUVToRGB.restype, lib.oracleLibyuvHookYUVToRGB.argtypes = C.c_int, [_P_IMG, _P_RGB, C.c_int, C.POINTER(C.c_int)]
+        lib.oracleLibyuvHookRGBToYUV.restype, lib.oracleLibyuvHookRGBToYUV.argtypes = C.c_int, [_P_IMG, _P_RGB]
         lib.oracleImageYUVToRGBRect.restype, lib.oracleImageYUVToRGBRect.argtypes = C.c_int, [_P_IMG, _P_RGB, _P_RECT]
         for name in ("oracleLimitedToFullY", "oracleLimitedToFullUV", "oracleFullToLimitedY", "oracleFullToLimitedUV"):
             getattr(lib, name).restype, getattr(lib, name).argtypes = C.c_int, [C.c_uint32, C.c_int]
