@@ -89,6 +89,31 @@ AVIFHIP_API avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
                                                       const avifCropRect * rects,
                                                       void * hipStream);
 
+/* Decode-side tail of a grid image in one step: replaces, for a grid whose tiles were decoded into
+ * separate device-resident images,
+ *   avifDecoderDataCopyTileToImage x (rows * columns)   tile -> canvas copy, last column / row cropped (src/read.c:1823-1877)
+ *   avifImageLimitedToFullAlpha                         limited-range alpha tiles of old files (src/read.c:6724-6764,6822)
+ *   avifImageYUVToRGB(canvas, rgb)                      on the stitched canvas (src/reformat.c:1649)
+ * without materialising the YUV canvas: tiles are converted where they lie, with the chroma filter reaching across tile
+ * seams exactly as it would on the stitched canvas.  The result equals that three-step sequence byte for byte.
+ *   grid         rows, columns, outputWidth, outputHeight as in libavif's avifImageGrid (include/avif/internal.h)
+ *   colorTiles   rows * columns images, row-major, all with the first tile's geometry and format (src/read.c:1832-1842);
+ *                CICP, range and alphaPremultiplied are taken from colorTiles[0]
+ *   alphaTiles   NULL, or rows * columns images whose alphaPlane holds the decoded alpha tile (same tiling)
+ *   alphaIsLimitedRange   the alpha item is limited range (src/read.c:6822)
+ * Buffers are device-resident; enqueued on `hipStream` without synchronising. */
+typedef struct avifhipGrid
+{
+    uint32_t rows, columns;
+    uint32_t outputWidth, outputHeight;
+} avifhipGrid;
+AVIFHIP_API avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid,
+                                                const avifImage * const * colorTiles,
+                                                const avifImage * const * alphaTiles,
+                                                avifBool alphaIsLimitedRange,
+                                                avifRGBImage * rgbCanvas,
+                                                void * hipStream);
+
 /* ---- integer helpers (src/reformat.c:1778-1840; used on decoded alpha planes, src/read.c:6724) */
 AVIFHIP_API int avifhipLimitedToFullY(uint32_t depth, int v);
 AVIFHIP_API int avifhipLimitedToFullUV(uint32_t depth, int v);

@@ -63,6 +63,7 @@ typedef enum avifResult
     AVIF_RESULT_OK = 0,
     AVIF_RESULT_UNKNOWN_ERROR = 1,
     AVIF_RESULT_REFORMAT_FAILED = 5,
+    AVIF_RESULT_INVALID_IMAGE_GRID = 18,
     AVIF_RESULT_INVALID_ARGUMENT = 24,
     AVIF_RESULT_NOT_IMPLEMENTED = 25,
     AVIF_RESULT_OUT_OF_MEMORY = 26,

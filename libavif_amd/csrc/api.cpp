@@ -38,6 +38,7 @@ struct Context
     Scratch planes[4]; // Y, U, V, A staging
     Scratch pixels;    // interleaved RGB staging
     Scratch table;     // batch descriptor table (device)
+    Scratch gridTable; // tile table of a grid conversion (device)
     void * pinnedTable = nullptr;
     size_t pinnedTableCapacity = 0;
     hipEvent_t tableCopied = nullptr;
@@ -55,6 +56,8 @@ struct Context
             (void)hipFree(pixels.ptr);
         if (table.ptr)
             (void)hipFree(table.ptr);
+        if (gridTable.ptr)
+            (void)hipFree(gridTable.ptr);
         if (pinnedTable)
             (void)hipHostFree(pinnedTable);
         if (tableCopied)
@@ -428,11 +431,17 @@ extern "C" avifResult avifhipImageYUVToRGBColorOnly(const avifImage * image, avi
     return yuvToRgbSync(image, rgb, true, reformatAlpha != AVIF_FALSE);
 }
 
-extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
-                                                     const avifImage * const * images,
-                                                     avifRGBImage * const * rgbs,
-                                                     const avifCropRect * rects,
-                                                     void * hipStream)
+namespace {
+// Per-job overrides of a batch: the chroma window (cwinX0, cwinX1, cwinY0, cwinY1) and the limited-range alpha flag
+struct JobOverride
+{
+    int32_t window[4];
+    bool alphaLimited;
+};
+} // namespace
+
+static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects,
+                                 const JobOverride * overrides, void * hipStream)
 {
     if (count == 0)
         return AVIF_RESULT_OK;
@@ -469,6 +478,11 @@ extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
         const avifResult pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plansA[k]);
         if (pr != AVIF_RESULT_OK)
             return pr;
+        if (overrides) {
+            plansA[k].cwinX0 = overrides[k].window[0], plansA[k].cwinX1 = overrides[k].window[1];
+            plansA[k].cwinY0 = overrides[k].window[2], plansA[k].cwinY1 = overrides[k].window[3];
+            plansA[k].yuv.alphaLimited = overrides[k].alphaLimited ? 1 : 0;
+        }
         maxW = plansA[k].w > maxW ? plansA[k].w : maxW;
         maxH = plansA[k].h > maxH ? plansA[k].h : maxH;
         // one launch serves the whole batch only if every job maps to the same tiled kernel
@@ -515,6 +529,120 @@ extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
     }
     if (e != hipSuccess)
         return hipFailed(e, "YUV->RGB batch kernel launch");
+    ++tls.launches;
+    return AVIF_RESULT_OK;
+}
+
+extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
+                                                     const avifImage * const * images,
+                                                     avifRGBImage * const * rgbs,
+                                                     const avifCropRect * rects,
+                                                     void * hipStream)
+{
+    return batchAsyncImpl(count, images, rgbs, rects, nullptr, hipStream);
+}
+
+// Grid canvases: tiles converted where they lie (a batch of rectangle jobs over "virtual canvases" whose plane pointers are
+// shifted so that canvas coordinates address the tile's own memory, each confined to its own chroma samples), then the
+// pixels next to interior seams redone with samples fetched from both sides (kernels_generic.hip: GridReader).
+extern "C" avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
+                                               avifBool alphaIsLimitedRange, avifRGBImage * rgbCanvas, void * hipStream)
+{
+    if (!grid || !colorTiles || !rgbCanvas || !grid->rows || !grid->columns || !grid->outputWidth || !grid->outputHeight)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const uint32_t count = grid->rows * grid->columns;
+    const avifImage * first = colorTiles[0];
+    if (!first || !first->width || !first->height)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const uint32_t tw = first->width, th = first->height;
+    // the grid must cover the output and no tile may lie entirely outside it (ISO/IEC 23008-12 6.6.2.3.1, src/read.c:1538-1560)
+    if ((uint64_t)tw * grid->columns < grid->outputWidth || (uint64_t)th * grid->rows < grid->outputHeight ||
+        (uint64_t)tw * (grid->columns - 1) >= grid->outputWidth || (uint64_t)th * (grid->rows - 1) >= grid->outputHeight)
+        return AVIF_RESULT_INVALID_IMAGE_GRID;
+    const int sx = (first->yuvFormat == AVIF_PIXEL_FORMAT_YUV444) ? 0 : 1;
+    const int sy = (first->yuvFormat == AVIF_PIXEL_FORMAT_YUV420) ? 1 : 0;
+    const bool subsampled = first->yuvFormat == AVIF_PIXEL_FORMAT_YUV420 || first->yuvFormat == AVIF_PIXEL_FORMAT_YUV422;
+    if (count > 1 && subsampled && ((tw & 1) || (sy && (th & 1))))
+        return AVIF_RESULT_INVALID_IMAGE_GRID; // odd tile sizes cannot tile a subsampled canvas (src/read.c:1562-1580)
+    const uint32_t bps = (first->depth > 8) ? 2 : 1;
+
+    std::vector<avifImage> views(count);
+    std::vector<const avifImage *> viewPtrs(count);
+    std::vector<avifRGBImage *> rgbPtrs(count, rgbCanvas);
+    std::vector<avifCropRect> rects(count);
+    std::vector<JobOverride> overrides(count);
+    std::vector<GridTile> tiles(count);
+    for (uint32_t t = 0; t < count; ++t) {
+        const avifImage * tile = colorTiles[t];
+        if (!tile || !tile->yuvPlanes[0])
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        // "All tiles in a grid image should match the first tile", src/read.c:1832-1842
+        if (tile->width != tw || tile->height != th || tile->depth != first->depth || tile->yuvFormat != first->yuvFormat ||
+            tile->yuvRange != first->yuvRange || tile->colorPrimaries != first->colorPrimaries ||
+            tile->transferCharacteristics != first->transferCharacteristics || tile->matrixCoefficients != first->matrixCoefficients)
+            return AVIF_RESULT_INVALID_IMAGE_GRID;
+        const avifImage * atile = alphaTiles ? alphaTiles[t] : nullptr;
+        if (alphaTiles && (!atile || !atile->alphaPlane || atile->width != tw || atile->height != th || atile->depth != first->depth))
+            return AVIF_RESULT_INVALID_IMAGE_GRID;
+        const uint32_t col = t % grid->columns, row = t / grid->columns;
+        const uint32_t X0 = col * tw, Y0 = row * th;
+        avifCropRect & r = rects[t];
+        r.x = X0, r.y = Y0;
+        r.width = (X0 + tw > grid->outputWidth) ? grid->outputWidth - X0 : tw;   // src/read.c:1863-1868
+        r.height = (Y0 + th > grid->outputHeight) ? grid->outputHeight - Y0 : th;
+        avifImage & v = views[t];
+        memcpy(&v, first, sizeof(avifImage)); // CICP, range, alphaPremultiplied: the canvas takes the first tile's
+        v.width = grid->outputWidth, v.height = grid->outputHeight;
+        GridTile & gt = tiles[t];
+        memset(&gt, 0, sizeof(gt));
+        for (int p = 0; p < 3; ++p) {
+            const bool chroma = p > 0;
+            gt.plane[p] = tile->yuvPlanes[p], gt.rowBytes[p] = tile->yuvRowBytes[p];
+            v.yuvRowBytes[p] = tile->yuvRowBytes[p];
+            v.yuvPlanes[p] = nullptr;
+            if (tile->yuvPlanes[p]) {
+                const uint64_t ox = chroma ? (X0 >> sx) : X0, oy = chroma ? (Y0 >> sy) : Y0;
+                v.yuvPlanes[p] = tile->yuvPlanes[p] - (oy * tile->yuvRowBytes[p] + ox * bps); // canvas sample (0,0), virtually
+            }
+        }
+        v.alphaPlane = nullptr, v.alphaRowBytes = 0;
+        if (atile) {
+            gt.alpha = atile->alphaPlane, gt.alphaRowBytes = atile->alphaRowBytes;
+            v.alphaRowBytes = atile->alphaRowBytes;
+            v.alphaPlane = atile->alphaPlane - ((uint64_t)Y0 * atile->alphaRowBytes + (uint64_t)X0 * bps);
+            v.alphaPremultiplied = first->alphaPremultiplied;
+        }
+        viewPtrs[t] = &v;
+        JobOverride & o = overrides[t];
+        o.window[0] = (int32_t)(X0 >> sx), o.window[1] = (int32_t)((X0 >> sx) + ((r.width + sx) >> sx) - 1);
+        o.window[2] = (int32_t)(Y0 >> sy), o.window[3] = (int32_t)((Y0 >> sy) + ((r.height + sy) >> sy) - 1);
+        o.alphaLimited = atile && alphaIsLimitedRange;
+    }
+    avifResult r = batchAsyncImpl(count, viewPtrs.data(), rgbPtrs.data(), rects.data(), overrides.data(), hipStream);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    if (count == 1)
+        return AVIF_RESULT_OK;
+    // seams: only a filtering chroma upsampler looks across them
+    YuvToRgbPlan canvasPlan;
+    r = makeYuvToRgbPlan(viewPtrs[0], rgbCanvas, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &canvasPlan);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    canvasPlan.yuv.alphaLimited = (alphaTiles && alphaIsLimitedRange) ? 1 : 0;
+    const bool filters = canvasPlan.bilinear && canvasPlan.yuv.hasColor && subsampled;
+    if (!filters)
+        return AVIF_RESULT_OK;
+    const size_t tableBytes = tiles.size() * sizeof(GridTile);
+    r = reserve(tls.gridTable, tableBytes);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    hipStream_t stream = pickStream(hipStream);
+    HIP_TRY(hipMemcpyAsync(tls.gridTable.ptr, tiles.data(), tableBytes, hipMemcpyHostToDevice, stream)); // pageable source: staged before return
+    GridGeometry g;
+    g.columns = grid->columns, g.rows = grid->rows, g.tileW = tw, g.tileH = th, g.tileCW = tw >> sx, g.tileCH = th >> sy;
+    const hipError_t e = launchYuvToRgbGridSeams(canvasPlan, g, (const GridTile *)tls.gridTable.ptr, grid->columns > 1, sy && grid->rows > 1, stream);
+    if (e != hipSuccess)
+        return hipFailed(e, "grid seam kernel launch");
     ++tls.launches;
     return AVIF_RESULT_OK;
 }

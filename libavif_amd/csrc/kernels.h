@@ -11,6 +11,26 @@ namespace avifhip {
 hipError_t launchYuvToRgbGeneric(const YuvToRgbPlan & plan, hipStream_t stream);
 hipError_t launchYuvToRgbGenericBatch(const YuvToRgbPlan * deviceTable, uint32_t count, uint32_t maxW, uint32_t maxH, hipStream_t stream);
 hipError_t launchRgbToYuvGeneric(const RgbToYuvPlan & plan, hipStream_t stream);
+
+// A canvas stored as a grid of separate tile images (avifhipGridYUVToRGBAsync): where canvas sample (x, y) of each plane lives
+struct GridTile
+{
+    const uint8_t * plane[3];
+    const uint8_t * alpha;
+    uint32_t rowBytes[3];
+    uint32_t alphaRowBytes;
+};
+struct GridGeometry
+{
+    uint32_t columns, rows;
+    uint32_t tileW, tileH;   // luma / alpha samples per tile
+    uint32_t tileCW, tileCH; // chroma samples per tile
+};
+// Re-converts the pixels next to interior tile seams (the only ones whose chroma filter reaches into a neighbouring tile):
+// luma columns k*tileW-1, k*tileW when `vertical`, luma rows k*tileH-1, k*tileH when `horizontal`.  `canvasPlan` describes the
+// whole canvas (its plane pointers are not used); `deviceTiles` has columns*rows entries.
+hipError_t launchYuvToRgbGridSeams(const YuvToRgbPlan & canvasPlan, const GridGeometry & geometry, const GridTile * deviceTiles, bool vertical,
+                                   bool horizontal, hipStream_t stream);
 hipError_t launchAlphaMulGeneric(const AlphaMulPlan & plan, hipStream_t stream);
 // in-place uint16 -> IEEE half over rows of `samplesPerRow` samples, src/reformat.c:1419-1443
 hipError_t launchToF16Generic(uint8_t * pixels, uint32_t rowBytes, uint32_t samplesPerRow, uint32_t rows, float multiplier, hipStream_t stream);

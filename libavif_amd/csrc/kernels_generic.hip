@@ -38,6 +38,59 @@ __global__ __launch_bounds__(256) void yuvToRgbGenericBatchKernel(const YuvToRgb
 }
 
 // --------------------------------------------------------------------------------------------
+// Grid canvases: samples are fetched from the tile that holds them (src/read.c:1823-1877 would have copied them into one
+// canvas first).  Used only for the few pixels next to tile seams.
+struct GridReader
+{
+    const YuvSide & s;
+    const GridGeometry & g;
+    const GridTile * tiles;
+    __device__ __forceinline__ unsigned y(uint32_t x, uint32_t yy) const
+    {
+        const uint32_t tx = x / g.tileW, ty = yy / g.tileH;
+        const GridTile & t = tiles[ty * g.columns + tx];
+        return loadSample(t.plane[0], t.rowBytes[0], x - tx * g.tileW, yy - ty * g.tileH, s.chanBytes);
+    }
+    __device__ __forceinline__ unsigned c(int pl, uint32_t x, uint32_t yy) const
+    {
+        const uint32_t tx = x / g.tileCW, ty = yy / g.tileCH;
+        const GridTile & t = tiles[ty * g.columns + tx];
+        return loadSample(t.plane[pl], t.rowBytes[pl], x - tx * g.tileCW, yy - ty * g.tileCH, s.chanBytes);
+    }
+    __device__ __forceinline__ unsigned u(uint32_t x, uint32_t yy) const { return c(1, x, yy); }
+    __device__ __forceinline__ unsigned v(uint32_t x, uint32_t yy) const { return c(2, x, yy); }
+    __device__ __forceinline__ unsigned a(uint32_t x, uint32_t yy) const
+    {
+        const uint32_t tx = x / g.tileW, ty = yy / g.tileH;
+        const GridTile & t = tiles[ty * g.columns + tx];
+        const unsigned sa = loadSample(t.alpha, t.alphaRowBytes, x - tx * g.tileW, yy - ty * g.tileH, s.chanBytes);
+        return s.alphaLimited ? limitedToFullAlpha(sa, (int)s.depth) : sa;
+    }
+};
+
+// blockIdx.y = seam line (2 per interior seam: vertical seams first), x = position along the line
+__global__ __launch_bounds__(256) void yuvToRgbGridSeamKernel(YuvToRgbPlan p, GridGeometry g, const GridTile * __restrict__ tiles, uint32_t verticalLines)
+{
+    const uint32_t line = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i, j;
+    if (line < verticalLines) {
+        i = (line / 2 + 1) * g.tileW - 1 + (line & 1);
+        j = t;
+    } else {
+        const uint32_t l = line - verticalLines;
+        j = (l / 2 + 1) * g.tileH - 1 + (l & 1);
+        i = t;
+    }
+    if (i >= p.canvasW || j >= p.canvasH)
+        return;
+    const GridReader rd { p.yuv, g, tiles };
+    if (p.arith == ARITH_LIBYUV)
+        yuvToRgbPixelFixedT(p, rd, i, j);
+    else
+        yuvToRgbPixelT(p, rd, i, j);
+}
+
+// --------------------------------------------------------------------------------------------
 // RGB -> YUV, one lane per 2x2 block (edge blocks 1x2 / 2x1 / 1x1), src/reformat.c:295-470, with
 // the alpha plane written in the same pass (src/reformat.c:545-569).
 struct Yuvf
@@ -323,6 +376,17 @@ hipError_t launchYuvToRgbGenericBatch(const YuvToRgbPlan * deviceTable, uint32_t
         return hipSuccess;
     const dim3 block(64, 4);
     hipLaunchKernelGGL(yuvToRgbGenericBatchKernel, gridFor(maxW, maxH, block, count), block, 0, stream, deviceTable);
+    return hipGetLastError();
+}
+
+hipError_t launchYuvToRgbGridSeams(const YuvToRgbPlan & canvasPlan, const GridGeometry & g, const GridTile * deviceTiles, bool vertical, bool horizontal,
+                                   hipStream_t stream)
+{
+    const uint32_t vLines = vertical ? 2 * (g.columns - 1) : 0, hLines = horizontal ? 2 * (g.rows - 1) : 0;
+    if (vLines + hLines == 0)
+        return hipSuccess;
+    const uint32_t longest = canvasPlan.canvasW > canvasPlan.canvasH ? canvasPlan.canvasW : canvasPlan.canvasH;
+    hipLaunchKernelGGL(yuvToRgbGridSeamKernel, dim3((longest + 255) / 256, vLines + hLines), dim3(256), 0, stream, canvasPlan, g, deviceTiles, vLines);
     return hipGetLastError();
 }
 

@@ -151,6 +151,8 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
     }
     if (o.isGray || o.is565 || o.isFloat)
         return false;
+    if (s.alphaLimited)
+        return false; // limited-range alpha planes (pre-1.0 files, src/read.c:6818-6828): the universal kernel converts them
     if (o.hasAlpha && p.alphaSource == ALPHA_KEEP)
         return false; // destination alpha bytes must stay untouched: per-channel stores only
     if (p.w < 64 || p.h < 2)

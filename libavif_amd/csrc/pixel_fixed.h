@@ -16,43 +16,45 @@ __device__ __forceinline__ int fxClamp255(int v)
 
 // A plane sample as the selected libyuv entry sees it: Convert16To8Plane (src/reformat_libyuv.c:906-930) first when the
 // entry is an 8-bit one fed from deeper planes.
-__device__ __forceinline__ int fxSample(const uint8_t * plane, uint32_t rowBytes, uint32_t x, uint32_t y, int chanBytes, int downshift)
+__device__ __forceinline__ int fxReduceSample(unsigned v, int downshift)
 {
-    const int v = (int)loadSample(plane, rowBytes, x, y, chanBytes);
-    return downshift ? min(v >> downshift, 255) : v;
+    return downshift ? min((int)(v >> downshift), 255) : (int)v;
 }
 
 // Upsampled chroma at luma position (i, j) of a canvasW x canvasH image (appendix D.2: ScaleRowUp2_Linear /
 // Scale2RowUp_Bilinear as libyuv's I4xxToARGBMatrixFilter applies them).  Taps are 3:1 per axis towards the side the
 // luma sample leans to; the first and the LAST column are horizontally unfiltered (whatever the width's parity), the
-// first row and the last row of an even height are vertically unfiltered; each stage rounds to an integer.
-__device__ __forceinline__ int fxChromaBilinear(const uint8_t * plane, uint32_t rowBytes, int chanBytes, int downshift, bool vertical, uint32_t i,
-                                                uint32_t j, uint32_t canvasW, uint32_t canvasH)
+// first row and the last row of an even height are vertically unfiltered; each stage rounds to an integer.  `load(x, y)`
+// returns the plane's raw sample.  Samples of 16-bit containers are held to 12 bits here, like the packed filter of the
+// tiled kernels (tile_fx_impl.h): a no-op for samples inside their nominal depth.
+template <class Load>
+__device__ __forceinline__ int fxChromaBilinear(const Load & load, const YuvToRgbPlan & p, bool vertical, uint32_t i, uint32_t j)
 {
+    const int downshift = p.fxDownshift;
+    const bool wide = p.yuv.chanBytes == 2;
+    auto sample = [&](uint32_t x, uint32_t y) {
+        const int v = fxReduceSample(load(x, y), downshift);
+        return (wide && downshift == 0) ? min(v, 4095) : v;
+    };
     const uint32_t ci = i >> 1;
     const uint32_t cj = vertical ? (j >> 1) : j;
-    const bool edgeX = (i == 0) || (i == canvasW - 1);
-    const bool edgeY = !vertical || (j == 0) || (j == canvasH - 1 && !(canvasH & 1));
-    const uint32_t fi = (i & 1) ? ci + 1 : ci - 1; // used only when !edgeX
-    const uint32_t fj = (j & 1) ? cj + 1 : cj - 1; // used only when !edgeY
-    // samples of 16-bit containers are held to 12 bits here, like the packed filter of the tiled kernels (tile_fx_impl.h):
-    // a no-op for samples inside their nominal depth
-    auto fxSample = [](const uint8_t * pl, uint32_t rb, uint32_t x, uint32_t y, int cb, int ds) {
-        const int v = avifhip::fxSample(pl, rb, x, y, cb, ds);
-        return (cb == 2 && ds == 0) ? min(v, 4095) : v;
-    };
-    const int a0 = fxSample(plane, rowBytes, ci, cj, chanBytes, downshift);
+    const bool edgeX = (i == 0) || (i == p.canvasW - 1);
+    const bool edgeY = !vertical || (j == 0) || (j == p.canvasH - 1 && !(p.canvasH & 1));
+    // neighbours towards the side the luma sample leans to, held inside the job's chroma window
+    const uint32_t fi = (uint32_t)clampInt((i & 1) ? (int)ci + 1 : (int)ci - 1, p.cwinX0, p.cwinX1);
+    const uint32_t fj = (uint32_t)clampInt((j & 1) ? (int)cj + 1 : (int)cj - 1, p.cwinY0, p.cwinY1);
+    const int a0 = sample(ci, cj);
     if (edgeX && edgeY)
         return a0;
     if (edgeY) {
-        const int a1 = fxSample(plane, rowBytes, fi, cj, chanBytes, downshift);
+        const int a1 = sample(fi, cj);
         return (3 * a0 + a1 + 2) >> 2;
     }
-    const int b0 = fxSample(plane, rowBytes, ci, fj, chanBytes, downshift);
+    const int b0 = sample(ci, fj);
     if (edgeX)
         return (3 * a0 + b0 + 2) >> 2;
-    const int a1 = fxSample(plane, rowBytes, fi, cj, chanBytes, downshift);
-    const int b1 = fxSample(plane, rowBytes, fi, fj, chanBytes, downshift);
+    const int a1 = sample(fi, cj);
+    const int b1 = sample(fi, fj);
     return (9 * a0 + 3 * a1 + 3 * b0 + b1 + 8) >> 4;
 }
 
@@ -102,26 +104,27 @@ __device__ __forceinline__ unsigned fxAlphaMul(unsigned c, unsigned a, int mulMo
 
 // One output pixel of a fixed-point YUV -> 8-bit RGB conversion, with what libavif runs after the libyuv call fused in:
 // the alpha channel (src/reformat.c:1464-1486) and the (un)premultiply post-pass (:1574-1585).
-__device__ inline void yuvToRgbPixelFixed(const YuvToRgbPlan & p, uint32_t i, uint32_t j)
+template <class Reader>
+__device__ inline void yuvToRgbPixelFixedT(const YuvToRgbPlan & p, const Reader & rd, uint32_t i, uint32_t j)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
     uint8_t * dst = o.pixels + (size_t)j * o.rowBytes + (size_t)i * o.pixBytes;
 
-    const int y = fxSample(s.plane[0], s.rowBytes[0], i, j, s.chanBytes, p.fxDownshift);
+    const int y = fxReduceSample(rd.y(i, j), p.fxDownshift);
     int u = 128, v = 128;
     if (!p.fxMono) {
         if (s.format == AVIF_PIXEL_FORMAT_YUV444) {
-            u = fxSample(s.plane[1], s.rowBytes[1], i, j, s.chanBytes, p.fxDownshift);
-            v = fxSample(s.plane[2], s.rowBytes[2], i, j, s.chanBytes, p.fxDownshift);
+            u = fxReduceSample(rd.u(i, j), p.fxDownshift);
+            v = fxReduceSample(rd.v(i, j), p.fxDownshift);
         } else if (!p.bilinear) {
             const uint32_t cj = j >> s.shiftY;
-            u = fxSample(s.plane[1], s.rowBytes[1], i >> 1, cj, s.chanBytes, p.fxDownshift);
-            v = fxSample(s.plane[2], s.rowBytes[2], i >> 1, cj, s.chanBytes, p.fxDownshift);
+            u = fxReduceSample(rd.u(i >> 1, cj), p.fxDownshift);
+            v = fxReduceSample(rd.v(i >> 1, cj), p.fxDownshift);
         } else {
             const bool vertical = s.format == AVIF_PIXEL_FORMAT_YUV420;
-            u = fxChromaBilinear(s.plane[1], s.rowBytes[1], s.chanBytes, p.fxDownshift, vertical, i, j, p.canvasW, p.canvasH);
-            v = fxChromaBilinear(s.plane[2], s.rowBytes[2], s.chanBytes, p.fxDownshift, vertical, i, j, p.canvasW, p.canvasH);
+            u = fxChromaBilinear([&](uint32_t x, uint32_t yy) { return rd.u(x, yy); }, p, vertical, i, j);
+            v = fxChromaBilinear([&](uint32_t x, uint32_t yy) { return rd.v(x, yy); }, p, vertical, i, j);
         }
     } else if (p.fxNative != 8) {
         u = v = 128 << (p.fxNative - 8); // unreachable today (no mono entry above 8 bits); keeps fxMatrix's reduction neutral
@@ -131,7 +134,7 @@ __device__ inline void yuvToRgbPixelFixed(const YuvToRgbPlan & p, uint32_t i, ui
 
     unsigned a = 255;
     if (o.hasAlpha && p.alphaSource == ALPHA_PLANE) {
-        const unsigned sa = loadSample(s.alpha, s.alphaRowBytes, i, j, s.chanBytes);
+        const unsigned sa = rd.a(i, j);
         if (p.fxAlpha == FXA_SHIFT)
             a = min(sa >> p.fxAlphaShift, 255u);
         else
@@ -153,6 +156,11 @@ __device__ inline void yuvToRgbPixelFixed(const YuvToRgbPlan & p, uint32_t i, ui
     dst[o.offB] = (uint8_t)b;
     if (o.hasAlpha)
         dst[o.offA] = (uint8_t)a;
+}
+
+__device__ inline void yuvToRgbPixelFixed(const YuvToRgbPlan & p, uint32_t i, uint32_t j)
+{
+    yuvToRgbPixelFixedT(p, PlanReader { p.yuv }, i, j);
 }
 
 // ---- RGB -> YUV, 8-bit BT.601 (appendix D.5) ----------------------------------------------------------------

@@ -14,7 +14,8 @@ namespace avifhip {
 // alpha fill/copy/rescale (src/alpha.c:9-149), colour conversion with chroma upsampling and
 // in-loop alpha multiply (src/reformat.c:650-978) or the specialised loops (:980-1407) followed by
 // integer (un)premultiply (src/alpha.c:151-535), and the half-float pass (src/reformat.c:1419-1443).
-__device__ inline void yuvToRgbPixel(const YuvToRgbPlan & p, uint32_t i, uint32_t j)
+template <class Reader>
+__device__ inline void yuvToRgbPixelT(const YuvToRgbPlan & p, const Reader & rd, uint32_t i, uint32_t j)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
@@ -23,20 +24,20 @@ __device__ inline void yuvToRgbPixel(const YuvToRgbPlan & p, uint32_t i, uint32_
     unsigned r = 0, g = 0, b = 0, gray = 0;
 
     if (p.identityCopy) { // src/reformat.c:1278-1309
-        g = s.plane[0][(size_t)j * s.rowBytes[0] + i];
-        b = s.plane[1][(size_t)j * s.rowBytes[1] + i];
-        r = s.plane[2][(size_t)j * s.rowBytes[2] + i];
+        g = rd.y(i, j);
+        b = rd.u(i, j);
+        r = rd.v(i, j);
     } else {
-        const unsigned unormY = loadSampleClamped(s.plane[0], s.rowBytes[0], i, j, s.chanBytes, (unsigned)s.maxv);
+        const unsigned mxv = (unsigned)s.maxv; // "clamp incoming data to protect against bad LUT lookups", src/reformat.c:712,727,821
+        const unsigned unormY = min(rd.y(i, j), mxv);
         const float Y = normY(unormY, s);
         float Cb = 0.5f, Cr = 0.5f;
         if (s.hasColor) {
             const uint32_t uvI = i >> s.shiftX;
             const uint32_t uvJ = j >> s.shiftY;
-            const unsigned mx = (unsigned)s.maxv;
             if (s.format == AVIF_PIXEL_FORMAT_YUV444 || !p.bilinear) {
-                Cb = normUV(loadSampleClamped(s.plane[1], s.rowBytes[1], uvI, uvJ, s.chanBytes, mx), s);
-                Cr = normUV(loadSampleClamped(s.plane[2], s.rowBytes[2], uvI, uvJ, s.chanBytes, mx), s);
+                Cb = normUV(min(rd.u(uvI, uvJ), mxv), s);
+                Cr = normUV(min(rd.v(uvI, uvJ), mxv), s);
             } else {
                 // neighbour selection against the CANVAS borders, src/reformat.c:766-795
                 int dx, dy;
@@ -48,15 +49,16 @@ __device__ inline void yuvToRgbPixel(const YuvToRgbPlan & p, uint32_t i, uint32_
                     dy = 0;
                 else
                     dy = (j & 1) ? 1 : -1;
-                const uint32_t xn = (uint32_t)((int)uvI + dx), yn = (uint32_t)((int)uvJ + dy);
-                const float u00 = normUV(loadSampleClamped(s.plane[1], s.rowBytes[1], uvI, uvJ, s.chanBytes, mx), s);
-                const float u10 = normUV(loadSampleClamped(s.plane[1], s.rowBytes[1], xn, uvJ, s.chanBytes, mx), s);
-                const float u01 = normUV(loadSampleClamped(s.plane[1], s.rowBytes[1], uvI, yn, s.chanBytes, mx), s);
-                const float u11 = normUV(loadSampleClamped(s.plane[1], s.rowBytes[1], xn, yn, s.chanBytes, mx), s);
-                const float v00 = normUV(loadSampleClamped(s.plane[2], s.rowBytes[2], uvI, uvJ, s.chanBytes, mx), s);
-                const float v10 = normUV(loadSampleClamped(s.plane[2], s.rowBytes[2], xn, uvJ, s.chanBytes, mx), s);
-                const float v01 = normUV(loadSampleClamped(s.plane[2], s.rowBytes[2], uvI, yn, s.chanBytes, mx), s);
-                const float v11 = normUV(loadSampleClamped(s.plane[2], s.rowBytes[2], xn, yn, s.chanBytes, mx), s);
+                // ... and against the job's chroma window (the whole plane unless the canvas is a grid of separate tiles)
+                const uint32_t xn = (uint32_t)clampInt((int)uvI + dx, p.cwinX0, p.cwinX1), yn = (uint32_t)clampInt((int)uvJ + dy, p.cwinY0, p.cwinY1);
+                const float u00 = normUV(min(rd.u(uvI, uvJ), mxv), s);
+                const float u10 = normUV(min(rd.u(xn, uvJ), mxv), s);
+                const float u01 = normUV(min(rd.u(uvI, yn), mxv), s);
+                const float u11 = normUV(min(rd.u(xn, yn), mxv), s);
+                const float v00 = normUV(min(rd.v(uvI, uvJ), mxv), s);
+                const float v10 = normUV(min(rd.v(xn, uvJ), mxv), s);
+                const float v01 = normUV(min(rd.v(uvI, yn), mxv), s);
+                const float v11 = normUV(min(rd.v(xn, yn), mxv), s);
                 Cb = bilinear4(u00, u10, u01, u11);
                 Cr = bilinear4(v00, v10, v01, v11);
             }
@@ -72,7 +74,7 @@ __device__ inline void yuvToRgbPixel(const YuvToRgbPlan & p, uint32_t i, uint32_
             grayc = clamp01(Y);
         }
         if (p.inLoopMul != MUL_NONE) { // src/reformat.c:894-947
-            const unsigned unormA = loadSampleClamped(s.alpha, s.alphaRowBytes, i, j, s.chanBytes, (unsigned)s.maxv);
+            const unsigned unormA = min(rd.a(i, j), mxv);
             const float Ac = clamp01((float)unormA / ((float)s.maxv));
             Rc = applyAlphaF(Rc, Ac, p.inLoopMul);
             Gc = applyAlphaF(Gc, Ac, p.inLoopMul);
@@ -93,7 +95,7 @@ __device__ inline void yuvToRgbPixel(const YuvToRgbPlan & p, uint32_t i, uint32_
             a = (unsigned)o.maxv;
             writeAlpha = true;
         } else if (p.alphaSource == ALPHA_PLANE) {
-            const unsigned sa = loadSample(s.alpha, s.alphaRowBytes, i, j, s.chanBytes);
+            const unsigned sa = rd.a(i, j);
             a = (s.depth == o.depth) ? sa : rescaleAlpha(sa, (float)s.maxv, o.maxf, o.maxv);
             writeAlpha = true;
         } else if (o.isFloat) {
@@ -146,6 +148,11 @@ __device__ inline void yuvToRgbPixel(const YuvToRgbPlan & p, uint32_t i, uint32_
         if (writeAlpha)
             *reinterpret_cast<uint16_t *>(dst + o.offA) = (uint16_t)a;
     }
+}
+
+__device__ inline void yuvToRgbPixel(const YuvToRgbPlan & p, uint32_t i, uint32_t j)
+{
+    yuvToRgbPixelT(p, PlanReader { p.yuv }, i, j);
 }
 
 } // namespace avifhip

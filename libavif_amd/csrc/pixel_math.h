@@ -55,6 +55,29 @@ __device__ __forceinline__ unsigned loadSampleClamped(const uint8_t * plane, uin
     return (v < maxv) ? v : maxv;
 }
 
+// avifLimitedToFullY (src/reformat.c:1778-1791) on one alpha sample: ((v - lo) * full + (hi - lo) / 2) / (hi - lo), clamped
+__device__ __forceinline__ unsigned limitedToFullAlpha(unsigned v, int depth)
+{
+    const int lo = 16 << (depth - 8), range = 219 << (depth - 8), full = (1 << depth) - 1;
+    const int n = ((int)v - lo) * full + range / 2;
+    const int q = n / range; // C division truncates toward zero, like the reference
+    return (unsigned)clampInt(q, 0, full);
+}
+
+// Where a pixel routine gets its samples from.  PlanReader: the planes of the plan (one contiguous image).
+struct PlanReader
+{
+    const YuvSide & s;
+    __device__ __forceinline__ unsigned y(uint32_t x, uint32_t yy) const { return loadSample(s.plane[0], s.rowBytes[0], x, yy, s.chanBytes); }
+    __device__ __forceinline__ unsigned u(uint32_t x, uint32_t yy) const { return loadSample(s.plane[1], s.rowBytes[1], x, yy, s.chanBytes); }
+    __device__ __forceinline__ unsigned v(uint32_t x, uint32_t yy) const { return loadSample(s.plane[2], s.rowBytes[2], x, yy, s.chanBytes); }
+    __device__ __forceinline__ unsigned a(uint32_t x, uint32_t yy) const
+    {
+        const unsigned sa = loadSample(s.alpha, s.alphaRowBytes, x, yy, s.chanBytes);
+        return s.alphaLimited ? limitedToFullAlpha(sa, (int)s.depth) : sa;
+    }
+};
+
 // 4-tap chroma filter on normalised samples, src/reformat.c:834-837: four products, three adds, left to right.
 __device__ __forceinline__ float bilinear4(float closest, float horiz, float vert, float diag)
 {

@@ -390,6 +390,10 @@ avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, c
         out->x0 = 0, out->y0 = 0, out->w = image->width, out->h = image->height;
     }
 
+    out->cwinX0 = 0, out->cwinY0 = 0;
+    out->cwinX1 = (int32_t)(((uint64_t)image->width + out->yuv.shiftX) >> out->yuv.shiftX) - 1;
+    out->cwinY1 = (int32_t)(((uint64_t)image->height + ((image->yuvFormat == AVIF_PIXEL_FORMAT_YUV420) ? 1 : 0)) >> ((image->yuvFormat == AVIF_PIXEL_FORMAT_YUV420) ? 1 : 0)) - 1;
+
     // alpha multiply mode, src/reformat.c:1662-1677
     const bool rgbHasAlpha = out->rgb.hasAlpha != 0;
     int mul = MUL_NONE;

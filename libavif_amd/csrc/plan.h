@@ -58,6 +58,7 @@ struct YuvSide
     int32_t chanBytes;
     int32_t shiftX, shiftY;
     int32_t hasColor; // chroma planes present and format != 400
+    int32_t alphaLimited; // the alpha plane holds limited-range samples: avifLimitedToFullY first (src/read.c:6724-6764)
     int32_t limited;
     int32_t maxv;
     int32_t mode; // ReformatMode
@@ -93,6 +94,10 @@ struct YuvToRgbPlan
     RgbSide rgb;
     uint32_t canvasW, canvasH; // edge rules are evaluated against these (src/reformat.c:768,784)
     uint32_t x0, y0, w, h;     // rectangle converted by this job
+    // Chroma samples this job may read, in chroma-plane coordinates (inclusive): neighbours selected by the filter rules are
+    // clamped into the window.  The whole plane by default (a no-op: the rules never leave the plane); a tile's own samples
+    // when the "canvas" is a grid of separately stored tiles (avifhipGridYUVToRGBAsync), whose seams a second pass redoes.
+    int32_t cwinX0, cwinX1, cwinY0, cwinY1;
     int32_t bilinear;          // 4-tap chroma filter requested (420/422 only)
     int32_t alphaSource;       // AlphaSource
     int32_t inLoopMul;         // MulMode applied in fp32 before quantisation (slow path, :894-947)

@@ -393,12 +393,13 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
         for (int j = 0; j < SR::kRounds; ++j) {
             const int task = t + 256 * j;
             if (task < SR::kTasks) {
-                // coordinates clamp to the canvas: exactly the reference's border rule (src/reformat.c:768,784) -- the
-                // neighbour of an edge sample is the sample itself
+                // coordinates clamp to the job's chroma window (the whole plane of the canvas unless the canvas is a grid of
+                // separately stored tiles): exactly the reference's border rule (src/reformat.c:768,784) -- the neighbour
+                // of an edge sample is the sample itself
                 const int row = task / kStageGroups, grp = task - row * kStageGroups;
-                const int cy = clampI(rowBase + row, 0, A.ch - 1);
+                const int cy = clampI(rowBase + row, A.cyMin, A.cyMax);
                 const int cxa = c.cxb - 4 + 4 * grp;
-                if (cxa >= 0 && cxa + 3 < A.cw) {
+                if (cxa >= A.cxMin && cxa + 3 <= A.cxMax) {
                     T.su[j] = load4<YT>(A.u, (uint32_t)cy * A.uPitch + (uint32_t)cxa * BPS);
                     T.sv[j] = load4<YT>(A.v, (uint32_t)cy * A.vPitch + (uint32_t)cxa * BPS);
                 } else {
@@ -408,7 +409,7 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
                         T.su[j].w[1] = T.sv[j].w[1] = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const uint32_t cx = (uint32_t)clampI(cxa + k, 0, A.cw - 1);
+                        const uint32_t cx = (uint32_t)clampI(cxa + k, A.cxMin, A.cxMax);
                         const unsigned u = load1<YT>(A.u, (uint32_t)cy * A.uPitch + cx * BPS);
                         const unsigned v = load1<YT>(A.v, (uint32_t)cy * A.vPitch + cx * BPS);
                         if constexpr (!kWide) {

@@ -26,7 +26,7 @@ struct TileArgs
     uint32_t yPitch, aPitch, uPitch, vPitch, rgbPitch;
     uint32_t w4, h2;
     int32_t cx0, cy0;  // chroma coordinates of the rectangle origin
-    int32_t cw, ch;    // chroma plane size of the canvas
+    int32_t cxMin, cxMax, cyMin, cyMax; // chroma samples the job may read (inclusive): coordinates clamp into this window
     float biasY, biasUV;
     RcpHL rcpRangeY, rcpRangeUV, rcpKgTimes2, rcpYuvMax, rcpRgbMax;
     float cB, cR;      // 2(1-kb), 2(1-kr)
@@ -78,8 +78,7 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     const bool subY = s.hasColor && s.format == AVIF_PIXEL_FORMAT_YUV420;
     A.cx0 = (int32_t)(subX ? p.x0 >> 1 : p.x0);
     A.cy0 = (int32_t)(subY ? p.y0 >> 1 : p.y0);
-    A.cw = (int32_t)(subX ? (p.canvasW + 1) >> 1 : p.canvasW);
-    A.ch = (int32_t)(subY ? (p.canvasH + 1) >> 1 : p.canvasH);
+    A.cxMin = p.cwinX0, A.cxMax = p.cwinX1, A.cyMin = p.cwinY0, A.cyMax = p.cwinY1;
     A.biasY = s.biasY, A.biasUV = s.biasUV;
     A.rcpRangeY = s.rcpRangeY, A.rcpRangeUV = s.rcpRangeUV, A.rcpKgTimes2 = s.rcpKgTimes2, A.rcpYuvMax = s.rcpMax, A.rcpRgbMax = o.rcpMax;
     A.cB = s.twoOneMinusKb, A.cR = s.twoOneMinusKr, A.cU = s.kbOneMinusKb, A.cV = s.krOneMinusKr;

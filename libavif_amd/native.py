@@ -25,8 +25,12 @@ EXPORTED_SYMBOLS = [
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
     "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
-    "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV",
+    "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync",
 ]
+
+class avifhipGrid(C.Structure):
+    _fields_ = [("rows", C.c_uint32), ("columns", C.c_uint32), ("outputWidth", C.c_uint32), ("outputHeight", C.c_uint32)]
+
 
 _lib = None
 
@@ -87,6 +91,7 @@ def load() -> C.CDLL:
         "avifhipTimeYUVToRGBCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
         "avifhipExplainYUVToRGB": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
         "avifhipExplainRGBToYUV": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
+        "avifhipGridYUVToRGBAsync": (i32, [C.POINTER(avifhipGrid), C.POINTER(P_IMG), C.POINTER(P_IMG), i32, P_RGB, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

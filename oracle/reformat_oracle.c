@@ -986,6 +986,67 @@ static avifResult rgbToYuv(avifImage * image, const avifRGBImage * rgb, const Or
 }
 
 /* ------------------------------------------------------------------------- */
+/* grid images: tile -> canvas, alpha range, conversion  (src/read.c:1823-1877, :6724-6764, :6818-6828)   */
+
+static void copyPlaneRect(uint8_t * dst, size_t dstRowBytes, const uint8_t * src, size_t srcRowBytes, size_t bytesPerRow, uint32_t rows)
+{
+    for (uint32_t j = 0; j < rows; ++j) /* avifImageCopySamples, src/avif.c:187-225 */
+        memcpy(dst + (size_t)j * dstRowBytes, src + (size_t)j * srcRowBytes, bytesPerRow);
+}
+
+avifResult oracleGridYUVToRGB(const oracleGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
+                              avifBool alphaIsLimitedRange, avifRGBImage * rgb, int libyuvBuild)
+{
+    const avifImage * first = colorTiles[0];
+    const uint32_t tw = first->width, th = first->height;
+    const size_t bps = (first->depth > 8) ? 2 : 1;
+    const int sx = (first->yuvFormat == AVIF_PIXEL_FORMAT_YUV444) ? 0 : 1;
+    const int sy = (first->yuvFormat == AVIF_PIXEL_FORMAT_YUV420) ? 1 : 0;
+    avifImage canvas;
+    memcpy(&canvas, first, sizeof(canvas));
+    canvas.width = grid->outputWidth, canvas.height = grid->outputHeight;
+    canvas.yuvPlanes[0] = canvas.yuvPlanes[1] = canvas.yuvPlanes[2] = canvas.alphaPlane = NULL;
+    canvas.imageOwnsYUVPlanes = canvas.imageOwnsAlphaPlane = AVIF_FALSE;
+    avifResult r = allocatePlanes(&canvas, alphaTiles != NULL);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    for (uint32_t t = 0; t < grid->rows * grid->columns; ++t) {
+        const uint32_t X0 = (t % grid->columns) * tw, Y0 = (t / grid->columns) * th;
+        const uint32_t w = (X0 + tw > grid->outputWidth) ? grid->outputWidth - X0 : tw; /* :1863-1868 */
+        const uint32_t h = (Y0 + th > grid->outputHeight) ? grid->outputHeight - Y0 : th;
+        const avifImage * tile = colorTiles[t];
+        for (int p = 0; p < 3; ++p) {
+            if (!canvas.yuvPlanes[p] || !tile->yuvPlanes[p])
+                continue;
+            const int px = p ? sx : 0, py = p ? sy : 0;
+            copyPlaneRect(canvas.yuvPlanes[p] + (size_t)(Y0 >> py) * canvas.yuvRowBytes[p] + (size_t)(X0 >> px) * bps, canvas.yuvRowBytes[p],
+                          tile->yuvPlanes[p], tile->yuvRowBytes[p], (((size_t)w + px) >> px) * bps, (h + py) >> py);
+        }
+        if (alphaTiles) {
+            const avifImage * atile = alphaTiles[t];
+            for (uint32_t j = 0; j < h; ++j) {
+                const uint8_t * src = atile->alphaPlane + (size_t)j * atile->alphaRowBytes;
+                uint8_t * dst = canvas.alphaPlane + (size_t)(Y0 + j) * canvas.alphaRowBytes + (size_t)X0 * bps;
+                for (uint32_t i = 0; i < w; ++i) {
+                    int a = (bps == 2) ? (int)load16(src + 2 * (size_t)i) : src[i];
+                    if (alphaIsLimitedRange)
+                        a = oracleLimitedToFullY(first->depth, a); /* :6748,6758 */
+                    if (bps == 2)
+                        store16(dst + 2 * (size_t)i, (unsigned)a);
+                    else
+                        dst[i] = (uint8_t)a;
+                }
+            }
+        }
+    }
+    r = libyuvBuild ? oracleLibyuvImageYUVToRGB(&canvas, rgb) : oracleImageYUVToRGB(&canvas, rgb);
+    for (int p = 0; p < 3; ++p)
+        free(canvas.yuvPlanes[p]);
+    free(canvas.alphaPlane);
+    return r;
+}
+
+/* ------------------------------------------------------------------------- */
 /* limited <-> full integer helpers              (src/reformat.c:1750-1840)    */
 
 static int limitedToFull(int v, int lo, int hi, int full)

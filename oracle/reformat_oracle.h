@@ -48,6 +48,22 @@ int oracleFullToLimitedUV(uint32_t depth, int v);
 avifResult oracleImageYUVToRGBRect(const avifImage * canvas, avifRGBImage * rgbCanvas, const avifCropRect * rect);
 
 /*
+ * Decode-side tail of a grid image, the way the reference runs it: every tile copied into the
+ * canvas with the last column / row cropped (avifDecoderDataCopyTileToImage, src/read.c:1823-1877 = avifImageSetViewRect
+ * + avifImageCopySamples), limited-range alpha tiles converted to full range sample by sample first
+ * (avifImageLimitedToFullAlpha, src/read.c:6724-6764), then avifImageYUVToRGB on the canvas.  colorTiles / alphaTiles:
+ * rows*columns images, row-major (alphaTiles may be NULL); metadata is taken from colorTiles[0].  libyuvBuild selects the
+ * integer-path restatement (a libavif built with libyuv) for the conversion.
+ */
+typedef struct oracleGrid
+{
+    uint32_t rows, columns;
+    uint32_t outputWidth, outputHeight;
+} oracleGrid;
+avifResult oracleGridYUVToRGB(const oracleGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
+                              avifBool alphaIsLimitedRange, avifRGBImage * rgb, int libyuvBuild);
+
+/*
  * The reference's INTEGER path: what a libavif built with libyuv computes (libyuv_oracle.c).
  * oracleLibyuv<Entry> == that build's avif<Entry>, end to end: libyuv's fixed-point arithmetic wherever libavif
  * dispatches to libyuv (src/reformat_libyuv.c; honours rgb->avoidLibYUV like src/reformat.c:1453 and :264), the fp32

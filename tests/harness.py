@@ -456,3 +456,44 @@ def libyuv_r2y_cases(sizes, n_random=1200, seed=29):
     return cases
 
 
+
+
+# ---------------------------------------------------------------------------------------------------
+# grid images: separately stored tiles (the decode-side tail)
+
+
+@dataclass(frozen=True)
+class GridCase:
+    """A grid of `rows` x `columns` tiles of tile_w x tile_h covering out_w x out_h, converted like Y2RCase `conv`
+    (whose w, h are ignored)."""
+
+    rows: int
+    columns: int
+    tile_w: int
+    tile_h: int
+    out_w: int
+    out_h: int
+    conv: Y2RCase
+    alpha_limited: bool = False
+
+    def ident(self) -> str:
+        return f"grid{self.rows}x{self.columns}-tile{self.tile_w}x{self.tile_h}-out{self.out_w}x{self.out_h}{'-alim' if self.alpha_limited else ''}-" + self.conv.ident()
+
+
+def make_grid_tiles(g: GridCase):
+    """Independent random tiles (tile t seeded with conv.seed + t), alpha in each tile image's alpha plane."""
+    tiles = []
+    for t in range(g.rows * g.columns):
+        c = replace(g.conv, w=g.tile_w, h=g.tile_h, seed=(g.conv.seed + 7919 * t) & 0x7FFFFFFF | 1)
+        img = make_y2r_inputs(c)
+        if g.alpha_limited and img.alpha is not None:
+            d = c.yuv_depth
+            a = img.plane_samples(3)
+            lo, hi = 16 << (d - 8), 235 << (d - 8)
+            a[...] = (lo + a.astype(np.int64) % (hi - lo + 1) if t % 2 else a.astype(np.int64) % ((1 << d))).astype(a.dtype)  # some tiles out of range on purpose
+        tiles.append(img)
+    return tiles
+
+
+def grid_output(g: GridCase) -> abi.HostRGB:
+    return make_y2r_output(replace(g.conv, w=g.out_w, h=g.out_h))

@@ -43,6 +43,8 @@ def oracle() -> C.CDLL:
             getattr(lib, name).restype, getattr(lib, name).argtypes = C.c_int, [_P_RGB]
         lib.oracleLibyuvHookYUVToRGB.restype, lib.oracleLibyuvHookYUVToRGB.argtypes = C.c_int, [_P_IMG, _P_RGB, C.c_int, C.POINTER(C.c_int)]
         lib.oracleLibyuvHookRGBToYUV.restype, lib.oracleLibyuvHookRGBToYUV.argtypes = C.c_int, [_P_IMG, _P_RGB]
+        lib.oracleGridYUVToRGB.restype = C.c_int
+        lib.oracleGridYUVToRGB.argtypes = [C.c_void_p, C.POINTER(_P_IMG), C.POINTER(_P_IMG), C.c_int, _P_RGB, C.c_int]
         lib.oracleImageYUVToRGBRect.restype, lib.oracleImageYUVToRGBRect.argtypes = C.c_int, [_P_IMG, _P_RGB, _P_RECT]
         for name in ("oracleLimitedToFullY", "oracleLimitedToFullUV", "oracleFullToLimitedY", "oracleFullToLimitedUV"):
             getattr(lib, name).restype, getattr(lib, name).argtypes = C.c_int, [C.c_uint32, C.c_int]
@@ -58,6 +60,11 @@ def _bind_libavif(lib: C.CDLL) -> C.CDLL:
     for name in ("avifLimitedToFullY", "avifLimitedToFullUV", "avifFullToLimitedY", "avifFullToLimitedUV"):
         getattr(lib, name).restype, getattr(lib, name).argtypes = C.c_int, [C.c_uint32, C.c_int]
     lib.avifLibYUVVersion.restype = C.c_uint
+    # internal.h functions: exported by the from-source build (default visibility), not by a packaged shared libavif
+    if hasattr(lib, "avifImageSetViewRect"):
+        lib.avifImageSetViewRect.restype, lib.avifImageSetViewRect.argtypes = C.c_int, [_P_IMG, _P_IMG, _P_RECT]
+    if hasattr(lib, "avifImageCopySamples"):
+        lib.avifImageCopySamples.restype, lib.avifImageCopySamples.argtypes = None, [_P_IMG, _P_IMG, C.c_uint32]
     return lib
 
 

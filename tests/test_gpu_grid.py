@@ -1,0 +1,79 @@
+"""The decode-side tail of a grid image on the GPU (avifhipGridYUVToRGBAsync): tiles stored separately in HBM are
+converted where they lie -- no YUV canvas is materialised -- and the result must equal, byte for byte, what the
+reference does in three steps (tile -> canvas copies, limited-range alpha conversion, avifImageYUVToRGB on the canvas),
+seams included.  Expected values: oracleGridYUVToRGB, pinned against the reference's own functions by
+tests/test_grid_oracle.py."""
+import ctypes as C
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+import harness as H
+from libavif_amd import abi, device, native
+from test_grid_oracle import oracle_grid
+
+pytestmark = pytest.mark.gpu
+A = abi
+
+
+def cases(avoid_libyuv):
+    base = dict(avoid_libyuv=avoid_libyuv)
+    return [
+        # cfg5 in miniature: 10-bit 4:2:0 limited BT.709 -> RGBA(10) / RGBA8 bilinear, cropped last column and row
+        H.GridCase(3, 3, 512, 64, 1100, 150, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=10, upsampling=4, **base)),
+        H.GridCase(3, 3, 512, 64, 1100, 150, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=8, upsampling=4, **base)),
+        H.GridCase(2, 3, 256, 32, 701, 61, H.Y2RCase(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, **base)),
+        H.GridCase(2, 2, 320, 40, 639, 79, H.Y2RCase(0, 0, yuv_format=2, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_RGB, upsampling=4, **base)),
+        H.GridCase(2, 2, 320, 16, 640, 32, H.Y2RCase(0, 0, yuv_depth=12, yuv_format=1, yuv_range=0, matrix=9, rgb_depth=16, alpha=True, rgb_premultiplied=True, **base)),
+        H.GridCase(2, 4, 128, 24, 500, 41, H.Y2RCase(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=3, alpha=True, **base), alpha_limited=True),
+        H.GridCase(3, 2, 64, 64, 127, 190, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, upsampling=4, alpha=True, rgb_premultiplied=True, **base),
+                   alpha_limited=True),
+        H.GridCase(1, 1, 300, 22, 300, 22, H.Y2RCase(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, **base)),
+        H.GridCase(2, 2, 64, 16, 100, 30, H.Y2RCase(0, 0, yuv_format=3, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_RGB_565, upsampling=4, **base)),  # universal kernel
+    ]
+
+
+def run_grid(lib, g):
+    tiles = H.make_grid_tiles(g)
+    want = H.grid_output(g)
+    assert oracle_grid(g, tiles, want, libyuv_build=not g.conv.avoid_libyuv) == 0
+    dtiles = [device.DeviceYUV(t) for t in tiles]
+    out = H.grid_output(g)
+    drgb = device.DeviceRGB(out, upload=True)
+    n = g.rows * g.columns
+    P = C.POINTER(abi.avifImage)
+    colour = (P * n)(*[C.pointer(d.struct) for d in dtiles])
+    alpha = (P * n)(*[C.pointer(d.struct) for d in dtiles]) if g.conv.alpha else None
+    grid = native.avifhipGrid(g.rows, g.columns, g.out_w, g.out_h)
+    native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), colour, alpha, int(g.alpha_limited), drgb.struct, None), "avifhipGridYUVToRGBAsync")
+    native.check(lib.avifhipSynchronize(None), "sync")
+    drgb.download_into_host()
+    wb = g.out_w * abi.rgb_pixel_size(g.conv.rgb_format, g.conv.rgb_depth)
+    assert np.array_equal(out.pixels[:, :wb], want.pixels[:, :wb]), (g.ident(), native.last_kernel(), H.describe_diff(want.pixels[:, :wb], out.pixels[:, :wb]))
+
+
+@pytest.mark.parametrize("g", cases(True), ids=lambda g: g.ident())
+def test_grid_fp32_path(hip, g):
+    run_grid(hip, g)
+
+
+@pytest.mark.parametrize("g", cases(False), ids=lambda g: g.ident())
+def test_grid_default_arithmetic(hip_auto_arithmetic, g):
+    run_grid(hip_auto_arithmetic, g)
+
+
+def test_grid_argument_checks(hip):
+    g = cases(True)[0]
+    tiles = H.make_grid_tiles(g)
+    dtiles = [device.DeviceYUV(t) for t in tiles]
+    out = H.grid_output(g)
+    drgb = device.DeviceRGB(out)
+    n = g.rows * g.columns
+    P = C.POINTER(abi.avifImage)
+    colour = (P * n)(*[C.pointer(d.struct) for d in dtiles])
+    bad = native.avifhipGrid(g.rows, g.columns, g.out_w + 2 * g.tile_w, g.out_h)  # the tiles do not cover the output
+    assert hip.avifhipGridYUVToRGBAsync(C.byref(bad), colour, None, 0, drgb.struct, None) == 18  # AVIF_RESULT_INVALID_IMAGE_GRID
+    dtiles[3].struct.depth = 8  # a tile that does not match the first one, src/read.c:1832-1842
+    ok = native.avifhipGrid(g.rows, g.columns, g.out_w, g.out_h)
+    assert hip.avifhipGridYUVToRGBAsync(C.byref(ok), colour, None, 0, drgb.struct, None) == 18

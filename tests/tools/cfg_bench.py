@@ -65,6 +65,30 @@ def run(name):
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
             px, bpp, ms = 64 * 1920 * 1080, (11.0 if rgb_depth == 10 else 7.0), best
+        elif name in ("cfg5grid", "cfg5grid_8"):
+            # BASELINE configs[4]: 8 x 8 grid of decoded 1920x1080 10-bit 4:2:0 tiles -> one 15360x8640 RGBA canvas, tiles
+            # converted where they lie (avifhipGridYUVToRGBAsync: no YUV canvas, seams redone across tiles)
+            rgb_depth = 10 if name == "cfg5grid" else 8
+            tiles = []
+            for t in range(64):
+                img = abi.make_yuv(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+                synth.fill_yuv(img, 0x12345678 + t)
+                tiles.append(device.DeviceYUV(img))
+            rgb = abi.make_rgb(15360, 8640, rgb_depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=avoid, allocate=False)
+            drgb = device.DeviceRGB(rgb)
+            imgs = (C.POINTER(abi.avifImage) * 64)(*[C.pointer(t.struct) for t in tiles])
+            grid = native.avifhipGrid(8, 8, 15360, 8640)
+            for _ in range(3):
+                native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None))
+            native.check(lib.avifhipSynchronize(None))
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None))
+                native.check(lib.avifhipSynchronize(None))
+                best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+            px, bpp, ms = 64 * 1920 * 1080, (11.0 if rgb_depth == 10 else 7.0), best
         else:
             raise SystemExit(f"unknown configuration {name}")
         gbps = bpp * px / (ms * 1e-3) / 1e9
