@@ -28,6 +28,7 @@ bool fits32(uint64_t rows, uint32_t pitch)
 R2YKey keyFor(const RgbToYuvPlan & p)
 {
     R2YKey k;
+    k.fixedPoint = p.arith == ARITH_LIBYUV;
     k.wideRgb = p.rgb.chanBytes == 2;
     k.wideYuv = p.yuv.chanBytes == 2;
     k.nch = p.rgb.hasAlpha ? 4 : 3;
@@ -44,7 +45,8 @@ const char * kernelNameFor(const R2YKey & k)
 {
     static thread_local char name[96];
     static const char * subs[] = { "444", "422", "420", "400" };
-    snprintf(name, sizeof(name), "rgb2yuv_tile<%s%d,%s,%s>", k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.wideYuv ? "u16" : "u8", subs[k.sub]);
+    snprintf(name, sizeof(name), "%s<%s%d,%s,%s>", k.fixedPoint ? "rgb2yuv_fixed_tile" : "rgb2yuv_tile", k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8,
+             k.wideYuv ? "u16" : "u8", subs[k.sub]);
     return name;
 }
 
@@ -54,10 +56,16 @@ bool tileRgbToYuvSupported(const RgbToYuvPlan & p)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
-    if (p.arith != ARITH_FLOAT || p.mul != MUL_NONE || o.isGray || o.is565 || s.mode != MODE_COEFF)
+    if (p.mul != MUL_NONE || o.isGray || o.is565)
         return false;
-    if (!s.exactDivEncode)
-        return false; // a divisor off the verified lists (exactdiv.h): the universal kernel divides the IEEE way
+    if (p.arith == ARITH_FLOAT) {
+        if (s.mode != MODE_COEFF)
+            return false;
+        if (!s.exactDivEncode)
+            return false; // a divisor off the verified lists (exactdiv.h): the universal kernel divides the IEEE way
+    } else if (o.chanBytes != 1 || s.chanBytes != 1) {
+        return false; // libyuv converts 8-bit to 8-bit only (src/reformat_libyuv.c:277)
+    }
     if (p.rx0 != 0 || p.ry0 != 0 || p.rw != p.width || p.rh != p.height)
         return false;
     if (p.width < 64 || p.height < 2)
@@ -116,7 +124,18 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
         spw = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : spw;
     A.stripsPerWave = spw;
     const uint32_t chunks = (strips + 4 * spw - 1) / (4 * spw);
-    hipError_t e = k.wideRgb ? launchR2YTileRgb16(k, A, bands * chunks, stream) : launchR2YTileRgb8(k, A, bands * chunks, stream);
+    if (k.fixedPoint) { // appendix D.5, coefficients in memory order of the colour channels
+        const bool full = p.fxFullRange != 0;
+        const int yr = full ? 77 : 66, yg = full ? 150 : 129, yb = full ? 29 : 25;
+        const int ur = full ? -43 : -38, ug = full ? -85 : -74, ub = full ? 128 : 112;
+        const int vr = full ? 128 : 112, vg = full ? -107 : -94, vb = full ? -21 : -18;
+        const bool redFirst = A.slotR < A.slotB;
+        A.fx.y0 = redFirst ? yr : yb, A.fx.y1 = yg, A.fx.y2 = redFirst ? yb : yr, A.fx.yBias = full ? 128 : 0x1080;
+        A.fx.u0 = redFirst ? ur : ub, A.fx.u1 = ug, A.fx.u2 = redFirst ? ub : ur;
+        A.fx.v0 = redFirst ? vr : vb, A.fx.v1 = vg, A.fx.v2 = redFirst ? vb : vr;
+    }
+    hipError_t e = k.fixedPoint ? launchR2YTileFx(k, A, bands * chunks, stream)
+                                : (k.wideRgb ? launchR2YTileRgb16(k, A, bands * chunks, stream) : launchR2YTileRgb8(k, A, bands * chunks, stream));
     if (e != hipSuccess)
         return e;
     // leftovers: columns [w4, width) of every row, then row h2 of the columns before w4 (even origins: whole 2x2 blocks)

@@ -12,5 +12,11 @@ hipError_t R2Y_FN(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hip
 {
     return launchFamily<R2Y_RT>(key, args, blocks, stream);
 }
+#ifdef R2Y_WITH_FX
+hipError_t launchR2YTileFx(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream)
+{
+    return key.nch == 4 ? launchFxSub<4>(key.sub, args, blocks, stream) : launchFxSub<3>(key.sub, args, blocks, stream);
+}
+#endif
 } // namespace r2y
 } // namespace avifhip

@@ -220,6 +220,135 @@ __device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uin
     }
 }
 
+// ---- libyuv's fixed point (8-bit RGB -> 8-bit planes, BT.601, appendix D.5): same loads, stores and strip walk ----
+struct Rgb3
+{
+    int c0, c1, c2;
+};
+__device__ __forceinline__ int fxDot(const Rgb3 & p, int k0, int k1, int k2, int bias)
+{
+    // operands fit 24 bits: full-rate multiplies
+    return (__mul24(k0, p.c0) + __mul24(k1, p.c1) + __mul24(k2, p.c2) + bias) >> 8;
+}
+
+template <int NCH, int SUB>
+__device__ __forceinline__ void computeStripFx(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<uint8_t, NCH> & S)
+{
+    const bool alphaFirst = (NCH == 4) && (A.slotA == 0);
+    const unsigned colourShift = alphaFirst ? 8u : 0u, alphaShift = alphaFirst ? 0u : 24u;
+    (void)colourShift, (void)alphaShift;
+    const R2YArgs::Fx & F = A.fx;
+    Rgb3 px[2][4];
+    int yq[2][4], aq[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned ca = 255;
+            if constexpr (NCH == 4) {
+                const unsigned w = S.row[r].w[i];
+                const unsigned cw = w >> colourShift;
+                px[r][i].c0 = (int)(cw & 0xffu), px[r][i].c1 = (int)((cw >> 8) & 0xffu), px[r][i].c2 = (int)((cw >> 16) & 0xffu);
+                ca = (w >> alphaShift) & 0xffu;
+            } else {
+                px[r][i].c0 = (int)channelOf<uint8_t, 3>(S.row[r], i, 0), px[r][i].c1 = (int)channelOf<uint8_t, 3>(S.row[r], i, 1);
+                px[r][i].c2 = (int)channelOf<uint8_t, 3>(S.row[r], i, 2);
+            }
+            yq[r][i] = fxDot(px[r][i], F.y0, F.y1, F.y2, F.yBias);
+            aq[r][i] = (A.alphaMode == R2Y_ALPHA_COPY) ? (int)ca : 255; // libavif's own alpha pass, src/reformat.c:545-569
+        }
+    }
+    if (!laneValid)
+        return;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        store4Samples<uint8_t>(A.y, (sy + r) * A.yPitch + X, yq[r]);
+        if (A.alphaMode != R2Y_ALPHA_NONE)
+            store4Samples<uint8_t>(A.a, (sy + r) * A.aPitch + X, aq[r]);
+    }
+    if constexpr (SUB == SUB_444) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int uq[4], vq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uq[i] = fxDot(px[r][i], F.u0, F.u1, F.u2, 0x8000);
+                vq[i] = fxDot(px[r][i], F.v0, F.v1, F.v2, 0x8000);
+            }
+            store4Samples<uint8_t>(A.u, (sy + r) * A.uPitch + X, uq);
+            store4Samples<uint8_t>(A.v, (sy + r) * A.vPitch + X, vq);
+        }
+    } else if constexpr (SUB == SUB_420) {
+        int uq[2], vq[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { // the block's RGB is averaged first, per channel, then U and V come from the average
+            const Rgb3 &p00 = px[0][2 * b], &p10 = px[0][2 * b + 1], &p01 = px[1][2 * b], &p11 = px[1][2 * b + 1];
+            Rgb3 m;
+            m.c0 = (p00.c0 + p10.c0 + p01.c0 + p11.c0 + 2) >> 2;
+            m.c1 = (p00.c1 + p10.c1 + p01.c1 + p11.c1 + 2) >> 2;
+            m.c2 = (p00.c2 + p10.c2 + p01.c2 + p11.c2 + 2) >> 2;
+            uq[b] = fxDot(m, F.u0, F.u1, F.u2, 0x8000);
+            vq[b] = fxDot(m, F.v0, F.v1, F.v2, 0x8000);
+        }
+        store2Samples<uint8_t>(A.u, (sy >> 1) * A.uPitch + (X >> 1), uq[0], uq[1]);
+        store2Samples<uint8_t>(A.v, (sy >> 1) * A.vPitch + (X >> 1), vq[0], vq[1]);
+    } else if constexpr (SUB == SUB_422) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int uq[2], vq[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const Rgb3 &p0 = px[r][2 * b], &p1 = px[r][2 * b + 1];
+                Rgb3 m;
+                m.c0 = (p0.c0 + p1.c0 + 1) >> 1, m.c1 = (p0.c1 + p1.c1 + 1) >> 1, m.c2 = (p0.c2 + p1.c2 + 1) >> 1;
+                uq[b] = fxDot(m, F.u0, F.u1, F.u2, 0x8000);
+                vq[b] = fxDot(m, F.v0, F.v1, F.v2, 0x8000);
+            }
+            store2Samples<uint8_t>(A.u, (sy + r) * A.uPitch + (X >> 1), uq[0], uq[1]);
+            store2Samples<uint8_t>(A.v, (sy + r) * A.vPitch + (X >> 1), vq[0], vq[1]);
+        }
+    }
+}
+
+template <int NCH, int SUB>
+__global__ __launch_bounds__(256) void rgbToYuvTileFxKernel(R2YArgs A)
+{
+    const uint32_t bands = (A.w4 + 255) / 256;
+    const uint32_t band = blockIdx.x % bands, chunk = blockIdx.x / bands;
+    const uint32_t X = band * 256 + 4 * threadIdx.x;
+    const bool laneValid = X < A.w4;
+    const uint32_t Xc = laneValid ? X : 0;
+    StripRaw<uint8_t, NCH> cur;
+    uint32_t sy = (chunk * A.stripsPerWave * kWaves + threadIdx.y) * 2;
+    loadStrip<uint8_t, NCH>(A, sy, Xc, cur);
+    for (uint32_t s = 0; s < A.stripsPerWave; ++s) {
+        if (sy >= A.h2)
+            break;
+        StripRaw<uint8_t, NCH> nxt;
+        const bool more = s + 1 < A.stripsPerWave;
+        if (more)
+            loadStrip<uint8_t, NCH>(A, sy + 2 * kWaves, Xc, nxt);
+        computeStripFx<NCH, SUB>(A, sy, X, laneValid, cur);
+        if (!more)
+            break;
+        cur = nxt;
+        sy += 2 * kWaves;
+    }
+}
+
+template <int NCH>
+hipError_t launchFxSub(int sub, const R2YArgs & A, uint32_t blocks, hipStream_t stream)
+{
+    const dim3 block(kLanes, kWaves);
+    switch (sub) {
+        case SUB_444: hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB_444>), dim3(blocks), block, 0, stream, A); break;
+        case SUB_422: hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB_422>), dim3(blocks), block, 0, stream, A); break;
+        case SUB_420: hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB_420>), dim3(blocks), block, 0, stream, A); break;
+        default: hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB_400>), dim3(blocks), block, 0, stream, A); break;
+    }
+    return hipGetLastError();
+}
+
 template <typename RT, int NCH, typename YT, int SUB>
 __global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A)
 {

@@ -35,16 +35,28 @@ struct R2YArgs
     uint32_t slotR, slotB, slotA;
     int32_t alphaMode;
     uint32_t stripsPerWave;
+    // fixed-point kernels (libyuv's 8-bit BT.601 arithmetic), coefficients per MEMORY-order colour
+    // channel (c0 = first colour byte, c1 = G, c2 = third colour byte), so that no channel swap is needed:
+    //   Y = (y0*c0 + y1*c1 + y2*c2 + yBias) >> 8,  U = (u0*m0 + u1*m1 + u2*m2 + 0x8000) >> 8,  V likewise,
+    //   m = the per-channel average of the covered pixels, (a+b+c+d+2) >> 2 or (a+b+1) >> 1
+    struct Fx
+    {
+        int32_t y0, y1, y2, yBias;
+        int32_t u0, u1, u2;
+        int32_t v0, v1, v2;
+    } fx;
 };
 
 struct R2YKey
 {
+    bool fixedPoint; // libyuv arithmetic: 8-bit RGB -> 8-bit planes
     bool wideRgb, wideYuv;
     int nch, sub;
 };
 
 hipError_t launchR2YTileRgb8(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);
 hipError_t launchR2YTileRgb16(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);
+hipError_t launchR2YTileFx(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);
 
 } // namespace r2y
 } // namespace avifhip
