@@ -172,3 +172,39 @@ def test_default_arithmetic_equals_libyuv_build_premultiply(libs, hip_auto_arith
         b.pixels[...] = a.pixels
         assert getattr(o, which)(a.struct) == getattr(be, which)(b.struct) == 0
         assert np.array_equal(a.pixels, b.pixels), (which, H.describe_diff(a.pixels, b.pixels))
+
+
+# ---- threading: libavif calls the hooks from up to 8 threads on disjoint row bands --------------------------------
+
+
+@pytest.mark.parametrize("arith", ["float", "auto"])
+def test_hooks_from_libavif_worker_threads(libs, hip, arith):
+    """rgb->maxThreads = 8 makes avifImageYUVToRGB split the image into row bands converted by 8 pthreads
+    (src/reformat.c:1679-1745), each of which calls the backend hook concurrently: results must equal the single-threaded
+    ones (the reference's own invariant, tests/gtest/avifrgbtoyuvthreadingtest.cc) in both arithmetics."""
+    be, _ = libs
+    hip.avifhipSetArithmetic(1 if arith == "float" else 0)
+    try:
+        cases = [
+            H.Y2RCase(640, 360, yuv_format=1, matrix=1, yuv_range=0, avoid_libyuv=False),
+            H.Y2RCase(640, 360, yuv_format=3, matrix=1, yuv_range=0, upsampling=3, avoid_libyuv=False, alpha=True),
+            H.Y2RCase(1027, 201, yuv_depth=10, yuv_format=2, matrix=9, yuv_range=1, upsampling=4, rgb_depth=16, avoid_libyuv=False),
+            H.Y2RCase(800, 600, yuv_depth=10, yuv_format=1, matrix=9, yuv_range=1, rgb_depth=8, alpha=True, rgb_premultiplied=True, avoid_libyuv=False),
+        ]
+        for c in cases:
+            img = H.make_y2r_inputs(c)
+            outs = []
+            for threads in (1, 8, 8, 3):
+                rgb = H.make_y2r_output(c)
+                rgb.struct.maxThreads = threads
+                before = hip.avifhipLaunchCount()
+                assert be.yuv_to_rgb(img.struct, rgb.struct) == 0, c.ident()
+                outs.append(rgb.pixels.copy())
+            for o in outs[1:]:
+                assert np.array_equal(outs[0], o), (c.ident(), H.describe_diff(outs[0], o))
+            want_backend = H.oracle_backend() if arith == "float" else H.oracle_libyuv_backend()
+            if arith == "auto" or not (c.alpha and c.rgb_premultiplied):
+                ro, po = H.run_y2r(want_backend, c)
+                assert ro == 0 and np.array_equal(po, outs[0]), (c.ident(), H.describe_diff(po, outs[0]))
+    finally:
+        hip.avifhipSetArithmetic(1)
