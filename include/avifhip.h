@@ -114,6 +114,22 @@ AVIFHIP_API avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid,
                                                 avifRGBImage * rgbCanvas,
                                                 void * hipStream);
 
+/* The application-side pixel transforms libavif's tools apply to the converted RGB image, as ONE pass from `src` into
+ * `dst` (device-resident, enqueued on `hipStream`): replaces avifApplyTransforms (apps/shared/avifutil.c:787-825), i.e.
+ * clean-aperture crop (avifRGBImageSetViewRect, :667-682), then rotation by angle * 90 degrees anti-clockwise
+ * (avifRGBImageRotate, :687-743), then mirroring about the horizontal (axis 0) or vertical (axis 1) axis
+ * (avifRGBImageMirror, :745-785) -- the order MIAF 7.3.6.7 prescribes.  crop may be NULL (no 'clap'); pass rotate / mirror
+ * = AVIF_FALSE for an absent 'irot' / 'imir'.  dst must have the format and depth of src and the transformed size
+ * (crop size, swapped for angle 1 and 3).  The reference runs up to two full passes plus an allocation for this. */
+AVIFHIP_API avifResult avifhipRGBImageTransformAsync(avifRGBImage * dst,
+                                                     const avifRGBImage * src,
+                                                     const avifCropRect * crop,
+                                                     avifBool rotate,
+                                                     uint8_t angle,
+                                                     avifBool mirror,
+                                                     uint8_t axis,
+                                                     void * hipStream);
+
 /* ---- integer helpers (src/reformat.c:1778-1840; used on decoded alpha planes, src/read.c:6724) */
 AVIFHIP_API int avifhipLimitedToFullY(uint32_t depth, int v);
 AVIFHIP_API int avifhipLimitedToFullUV(uint32_t depth, int v);

@@ -836,6 +836,46 @@ extern "C" avifResult avifhipRGBImageUnpremultiplyAlphaAsync(avifRGBImage * rgb,
 }
 
 // =================================================================================================
+// application-side pixel transforms, reference apps/shared/avifutil.c:667-825
+// =================================================================================================
+
+extern "C" avifResult avifhipRGBImageTransformAsync(avifRGBImage * dst, const avifRGBImage * src, const avifCropRect * crop, avifBool rotate, uint8_t angle,
+                                                    avifBool mirror, uint8_t axis, void * hipStream)
+{
+    if (!dst || !src || !dst->pixels || !src->pixels)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if ((rotate && angle > 3) || (mirror && axis > 1))
+        return AVIF_RESULT_INVALID_ARGUMENT; // "Invalid angle." / "Invalid axis value.", apps/shared/avifutil.c:741,781
+    if (dst->format != src->format || dst->depth != src->depth)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    avifCropRect whole = { 0, 0, src->width, src->height };
+    const avifCropRect & r = crop ? *crop : whole;
+    if (r.width > src->width || r.height > src->height || r.x > src->width - r.width || r.y > src->height - r.height)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    TransformArgs A;
+    memset(&A, 0, sizeof(A));
+    const uint32_t px = rgbPixelBytes(src);
+    A.angle = (rotate && angle != 0) ? angle : 0; // :805
+    A.mirror = mirror ? (int32_t)axis : -1;
+    A.cw = r.width, A.ch = r.height;
+    A.dw = (A.angle & 1) ? r.height : r.width, A.dh = (A.angle & 1) ? r.width : r.height; // :692-693
+    if (dst->width != A.dw || dst->height != A.dh || (uint64_t)dst->rowBytes < (uint64_t)A.dw * px)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    A.src = src->pixels + (size_t)r.y * src->rowBytes + (size_t)r.x * px; // avifRGBImageSetViewRect, :677-680
+    A.dst = dst->pixels;
+    A.srcPitch = src->rowBytes, A.dstPitch = dst->rowBytes;
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    tls.lastKernel = (A.angle & 1) ? "rgb_transform_transpose" : "rgb_transform_rows";
+    const hipError_t e = launchRgbTransform(A, px, pickStream(hipStream));
+    if (e != hipSuccess)
+        return hipFailed(e, "pixel transform kernel launch");
+    ++tls.launches;
+    return AVIF_RESULT_OK;
+}
+
+// =================================================================================================
 // integer range helpers, reference src/reformat.c:1750-1840
 // =================================================================================================
 

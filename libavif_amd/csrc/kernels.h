@@ -50,4 +50,17 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
 bool tileRgbToYuvSupported(const RgbToYuvPlan & plan);
 hipError_t launchRgbToYuvTile(const RgbToYuvPlan & plan, hipStream_t stream, const char ** kernelName);
 
+// crop + rotate + mirror of an interleaved pixel buffer in one pass (kernels_transform.hip)
+struct TransformArgs
+{
+    const uint8_t * src; // first pixel of the cropped source rectangle
+    uint8_t * dst;
+    uint32_t srcPitch, dstPitch;
+    uint32_t cw, ch;  // cropped source size
+    uint32_t dw, dh;  // destination size
+    int32_t angle;    // 0..3, multiples of 90 degrees anti-clockwise
+    int32_t mirror;   // -1 none, 0 about the horizontal axis (top <-> bottom), 1 about the vertical axis (left <-> right)
+};
+hipError_t launchRgbTransform(const TransformArgs & args, uint32_t pixelBytes, hipStream_t stream);
+
 } // namespace avifhip

@@ -1,0 +1,119 @@
+// kernels_transform.hip -- clean-aperture crop, rotation and mirroring of an interleaved pixel buffer as one permutation
+// pass (apps/shared/avifutil.c:667-825: avifRGBImageSetViewRect + avifRGBImageRotate + avifRGBImageMirror, which the
+// reference runs as a view, a full copy and an in-place swap pass).  Pure byte movement: 2 x pixelBytes per pixel of HBM
+// traffic.  One workgroup moves a 32 x 32 tile of destination pixels; quarter-turn rotations go through an LDS tile so
+// that both the loads (along source rows) and the stores (along destination rows) are coalesced.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace avifhip {
+
+namespace {
+
+constexpr int naturalAlign(int px)
+{
+    return (px % 8 == 0) ? 8 : (px % 4 == 0) ? 4 : (px % 2 == 0) ? 2 : 1;
+}
+// one pixel, moved as a unit; ALIGNED = the buffers allow the pixel's natural alignment (else byte-granular moves)
+template <int PX, bool ALIGNED>
+struct alignas(ALIGNED ? naturalAlign(PX) : 1) Pixel
+{
+    uint8_t b[PX];
+};
+
+// destination pixel (x, y) -> pixel (i, j) of the cropped source
+__device__ __forceinline__ void sourceOf(const TransformArgs & A, uint32_t x, uint32_t y, uint32_t * i, uint32_t * j)
+{
+    // undo the mirror (applied last, :819-825), then the rotation (:711-740)
+    if (A.mirror == 1)
+        x = A.dw - 1 - x;
+    else if (A.mirror == 0)
+        y = A.dh - 1 - y;
+    switch (A.angle) {
+        case 1: *i = A.cw - 1 - y, *j = x; break;             // source (i, j) went to (j, cw - 1 - i)
+        case 2: *i = A.cw - 1 - x, *j = A.ch - 1 - y; break;  // ... to (cw - 1 - i, ch - 1 - j)
+        case 3: *i = y, *j = A.ch - 1 - x; break;             // ... to (ch - 1 - j, i)
+        default: *i = x, *j = y; break;
+    }
+}
+
+template <int PX, bool ALIGNED>
+__global__ __launch_bounds__(256) void transformRowsKernel(TransformArgs A)
+{
+    // angle 0 / 2: destination rows are source rows (possibly reversed): one lane per pixel is already coalesced
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= A.dw || y >= A.dh)
+        return;
+    uint32_t i, j;
+    sourceOf(A, x, y, &i, &j);
+    *reinterpret_cast<Pixel<PX, ALIGNED> *>(A.dst + (size_t)y * A.dstPitch + (size_t)x * PX) =
+        *reinterpret_cast<const Pixel<PX, ALIGNED> *>(A.src + (size_t)j * A.srcPitch + (size_t)i * PX);
+}
+
+template <int PX, bool ALIGNED>
+__global__ __launch_bounds__(256) void transformTransposeKernel(TransformArgs A)
+{
+    __shared__ Pixel<PX, ALIGNED> tile[32][33];
+    const uint32_t X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32;
+    const uint32_t X1 = min(X0 + 32, A.dw) - 1, Y1 = min(Y0 + 32, A.dh) - 1;
+    // the destination tile is the image of a 32 x 32 source tile: its origin is the smaller corner
+    uint32_t ia, ja, ib, jb;
+    sourceOf(A, X0, Y0, &ia, &ja);
+    sourceOf(A, X1, Y1, &ib, &jb);
+    const uint32_t i0 = min(ia, ib), j0 = min(ja, jb);
+    const uint32_t tx = threadIdx.x, ty = threadIdx.y; // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = i0 + tx, j = j0 + ty + 8 * k;
+        if (i < A.cw && j < A.ch)
+            tile[ty + 8 * k][tx] = *reinterpret_cast<const Pixel<PX, ALIGNED> *>(A.src + (size_t)j * A.srcPitch + (size_t)i * PX);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t x = X0 + tx, y = Y0 + ty + 8 * k;
+        if (x < A.dw && y < A.dh) {
+            uint32_t i, j;
+            sourceOf(A, x, y, &i, &j);
+            *reinterpret_cast<Pixel<PX, ALIGNED> *>(A.dst + (size_t)y * A.dstPitch + (size_t)x * PX) = tile[j - j0][i - i0];
+        }
+    }
+}
+
+template <int PX, bool ALIGNED>
+hipError_t launchFor(const TransformArgs & A, hipStream_t stream)
+{
+    if (A.angle == 1 || A.angle == 3)
+        hipLaunchKernelGGL((transformTransposeKernel<PX, ALIGNED>), dim3((A.dw + 31) / 32, (A.dh + 31) / 32), dim3(32, 8), 0, stream, A);
+    else
+        hipLaunchKernelGGL((transformRowsKernel<PX, ALIGNED>), dim3((A.dw + 63) / 64, (A.dh + 3) / 4), dim3(64, 4), 0, stream, A);
+    return hipGetLastError();
+}
+
+template <int PX>
+hipError_t launchPx(const TransformArgs & A, hipStream_t stream)
+{
+    constexpr uintptr_t a = (uintptr_t)naturalAlign(PX);
+    const bool aligned = ((uintptr_t)A.src % a) == 0 && ((uintptr_t)A.dst % a) == 0 && (A.srcPitch % a) == 0 && (A.dstPitch % a) == 0;
+    return aligned ? launchFor<PX, true>(A, stream) : launchFor<PX, false>(A, stream);
+}
+
+} // namespace
+
+hipError_t launchRgbTransform(const TransformArgs & A, uint32_t pixelBytes, hipStream_t stream)
+{
+    if (A.dw == 0 || A.dh == 0)
+        return hipSuccess;
+    switch (pixelBytes) { // gray 8/16, RGB565, RGB 8/16, RGBA 8/16
+        case 1: return launchPx<1>(A, stream);
+        case 2: return launchPx<2>(A, stream);
+        case 3: return launchPx<3>(A, stream);
+        case 4: return launchPx<4>(A, stream);
+        case 6: return launchPx<6>(A, stream);
+        case 8: return launchPx<8>(A, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace avifhip

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
     "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
-    "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync",
+    "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync",
 ]
 
 class avifhipGrid(C.Structure):
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
         "avifhipTimeYUVToRGBCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
         "avifhipExplainYUVToRGB": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
         "avifhipExplainRGBToYUV": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
+        "avifhipRGBImageTransformAsync": (i32, [P_RGB, P_RGB, P_RECT, i32, C.c_uint8, i32, C.c_uint8, vp]),
         "avifhipGridYUVToRGBAsync": (i32, [C.POINTER(avifhipGrid), C.POINTER(P_IMG), C.POINTER(P_IMG), i32, P_RGB, vp]),
     }
     for name, (res, args) in sigs.items():

@@ -1047,6 +1047,84 @@ avifResult oracleGridYUVToRGB(const oracleGrid * grid, const avifImage * const *
 }
 
 /* ------------------------------------------------------------------------- */
+/* crop / rotate / mirror of an RGB image            (apps/shared/avifutil.c:667-825)                              */
+
+static uint32_t rgbPixelSize(const avifRGBImage * rgb) /* avifRGBImagePixelSize, src/avif.c:692-698 */
+{
+    if (rgb->format == AVIF_RGB_FORMAT_RGB_565)
+        return 2;
+    return (uint32_t)fmtChannels(rgb->format) * ((rgb->depth > 8) ? 2 : 1);
+}
+
+avifResult oracleRGBImageTransform(avifRGBImage * dst, const avifRGBImage * src, const avifCropRect * crop, avifBool rotate, uint8_t angle,
+                                   avifBool mirror, uint8_t axis)
+{
+    const uint32_t px = rgbPixelSize(src);
+    /* the clean-aperture view, :667-682 */
+    const uint8_t * base = src->pixels;
+    uint32_t w = src->width, h = src->height;
+    if (crop) {
+        base += (size_t)crop->y * src->rowBytes + (size_t)crop->x * px;
+        w = crop->width, h = crop->height;
+    }
+    /* rotation into a new image, :687-743 (angle 0 or an absent box leave the view as it is, :805) */
+    const uint8_t a = rotate ? angle : 0;
+    if (a > 3)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const uint32_t nw = (a == 0 || a == 2) ? w : h, nh = (a == 0 || a == 2) ? h : w;
+    const size_t tmpBytes = (size_t)nw * nh * px;
+    uint8_t * tmp = (uint8_t *)malloc(tmpBytes > 0 ? tmpBytes : 1);
+    if (!tmp)
+        return AVIF_RESULT_OUT_OF_MEMORY;
+    const size_t tmpRow = (size_t)nw * px;
+    for (uint32_t j = 0; j < h; ++j) {
+        for (uint32_t i = 0; i < w; ++i) {
+            const uint8_t * s = base + (size_t)j * src->rowBytes + (size_t)i * px;
+            uint32_t x, y;
+            switch (a) {
+                case 1: x = j, y = w - 1 - i; break;          /* 90 degrees anti-clockwise, :711-718 */
+                case 2: x = w - 1 - i, y = h - 1 - j; break;  /* 180 degrees, :721-729 */
+                case 3: x = h - 1 - j, y = i; break;          /* 90 degrees clockwise, :732-739 */
+                default: x = i, y = j; break;
+            }
+            memcpy(tmp + (size_t)y * tmpRow + (size_t)x * px, s, px);
+        }
+    }
+    /* mirror in place, :745-785 */
+    if (mirror) {
+        if (axis == 0) {
+            for (uint32_t y = 0; y < nh / 2; ++y)
+                for (size_t k = 0; k < tmpRow; ++k) {
+                    const uint8_t t = tmp[(size_t)y * tmpRow + k];
+                    tmp[(size_t)y * tmpRow + k] = tmp[(size_t)(nh - 1 - y) * tmpRow + k];
+                    tmp[(size_t)(nh - 1 - y) * tmpRow + k] = t;
+                }
+        } else if (axis == 1) {
+            for (uint32_t y = 0; y < nh; ++y)
+                for (uint32_t x = 0; x < nw / 2; ++x)
+                    for (uint32_t k = 0; k < px; ++k) {
+                        uint8_t * p1 = tmp + (size_t)y * tmpRow + (size_t)x * px + k;
+                        uint8_t * p2 = tmp + (size_t)y * tmpRow + (size_t)(nw - 1 - x) * px + k;
+                        const uint8_t t = *p1;
+                        *p1 = *p2;
+                        *p2 = t;
+                    }
+        } else {
+            free(tmp);
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        }
+    }
+    if (dst->width != nw || dst->height != nh) {
+        free(tmp);
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    for (uint32_t y = 0; y < nh; ++y)
+        memcpy(dst->pixels + (size_t)y * dst->rowBytes, tmp + (size_t)y * tmpRow, tmpRow);
+    free(tmp);
+    return AVIF_RESULT_OK;
+}
+
+/* ------------------------------------------------------------------------- */
 /* limited <-> full integer helpers              (src/reformat.c:1750-1840)    */
 
 static int limitedToFull(int v, int lo, int hi, int full)

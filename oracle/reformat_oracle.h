@@ -64,6 +64,15 @@ avifResult oracleGridYUVToRGB(const oracleGrid * grid, const avifImage * const *
                               avifBool alphaIsLimitedRange, avifRGBImage * rgb, int libyuvBuild);
 
 /*
+ * The pixel transforms libavif's tools apply to the converted RGB image, apps/shared/avifutil.c:787-825
+ * (avifApplyTransforms): clean-aperture crop (:667-682), rotation by angle * 90 degrees anti-clockwise (:687-743), mirror
+ * about the horizontal (axis 0) / vertical (axis 1) axis (:745-785), in that order.  Writes the transformed image into
+ * dst (caller-allocated, transformed size).  crop may be NULL; rotate / mirror false = box absent.
+ */
+avifResult oracleRGBImageTransform(avifRGBImage * dst, const avifRGBImage * src, const avifCropRect * crop, avifBool rotate, uint8_t angle,
+                                   avifBool mirror, uint8_t axis);
+
+/*
  * The reference's INTEGER path: what a libavif built with libyuv computes (libyuv_oracle.c).
  * oracleLibyuv<Entry> == that build's avif<Entry>, end to end: libyuv's fixed-point arithmetic wherever libavif
  * dispatches to libyuv (src/reformat_libyuv.c; honours rgb->avoidLibYUV like src/reformat.c:1453 and :264), the fp32

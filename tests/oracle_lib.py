@@ -43,6 +43,8 @@ def oracle() -> C.CDLL:
             getattr(lib, name).restype, getattr(lib, name).argtypes = C.c_int, [_P_RGB]
         lib.oracleLibyuvHookYUVToRGB.restype, lib.oracleLibyuvHookYUVToRGB.argtypes = C.c_int, [_P_IMG, _P_RGB, C.c_int, C.POINTER(C.c_int)]
         lib.oracleLibyuvHookRGBToYUV.restype, lib.oracleLibyuvHookRGBToYUV.argtypes = C.c_int, [_P_IMG, _P_RGB]
+        lib.oracleRGBImageTransform.restype = C.c_int
+        lib.oracleRGBImageTransform.argtypes = [_P_RGB, _P_RGB, _P_RECT, C.c_int, C.c_uint8, C.c_int, C.c_uint8]
         lib.oracleGridYUVToRGB.restype = C.c_int
         lib.oracleGridYUVToRGB.argtypes = [C.c_void_p, C.POINTER(_P_IMG), C.POINTER(_P_IMG), C.c_int, _P_RGB, C.c_int]
         lib.oracleImageYUVToRGBRect.restype, lib.oracleImageYUVToRGBRect.argtypes = C.c_int, [_P_IMG, _P_RGB, _P_RECT]
@@ -73,6 +75,20 @@ def ref():
         path = ORACLE_DIR / "_ref" / "libavif_ref.so"
         _cache["ref"] = _bind_libavif(C.CDLL(os.fspath(path), mode=os.RTLD_LOCAL)) if path.exists() else None
     return _cache["ref"]
+
+
+def util_ref():
+    """apps/shared/avifutil.c of the reference, compiled from where it lies (oracle/Makefile target utilref), or None."""
+    if "util_ref" not in _cache:
+        path = ORACLE_DIR / "_ref" / "libavifutil_ref.so"
+        lib = None
+        if path.exists():
+            lib = C.CDLL(os.fspath(path), mode=os.RTLD_LOCAL)
+            lib.avifRGBImageSetViewRect.restype, lib.avifRGBImageSetViewRect.argtypes = None, [_P_RGB, _P_RGB, _P_RECT]
+            lib.avifRGBImageRotate.restype, lib.avifRGBImageRotate.argtypes = C.c_int, [_P_RGB, _P_RGB, C.POINTER(C.c_uint8)]
+            lib.avifRGBImageMirror.restype, lib.avifRGBImageMirror.argtypes = C.c_int, [_P_RGB, C.POINTER(C.c_uint8)]
+        _cache["util_ref"] = lib
+    return _cache["util_ref"]
 
 
 def pillow():

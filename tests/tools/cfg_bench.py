@@ -65,6 +65,29 @@ def run(name):
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
             px, bpp, ms = 64 * 1920 * 1080, (11.0 if rgb_depth == 10 else 7.0), best
+        elif name in ("xform90", "xform180"):
+            # avifApplyTransforms on the converted 8K RGBA8 image: clap crop + irot + imir in one pass (8 B/pixel)
+            if arith == "integer":
+                continue  # pure byte movement: no arithmetic family
+            angle = 1 if name == "xform90" else 2
+            src = abi.make_rgb(7680, 4320, 8, abi.AVIF_RGB_FORMAT_RGBA)
+            synth.fill_rgb(src, 0x1234)
+            crop = abi.avifCropRect(8, 4, 7664, 4312)
+            dw, dh = (4312, 7664) if angle == 1 else (7664, 4312)
+            dst = abi.make_rgb(dw, dh, 8, abi.AVIF_RGB_FORMAT_RGBA, allocate=False)
+            dsrc, ddst = device.DeviceRGB(src, upload=True), device.DeviceRGB(dst)
+            call = lambda: native.check(lib.avifhipRGBImageTransformAsync(ddst.struct, dsrc.struct, C.byref(crop), 1, angle, 1, 1, None))
+            for _ in range(3):
+                call()
+            native.check(lib.avifhipSynchronize(None))
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    call()
+                native.check(lib.avifhipSynchronize(None))
+                best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
+            px, bpp, ms = 7664 * 4312, 8.0, best
         elif name in ("cfg5grid", "cfg5grid_8"):
             # BASELINE configs[4]: 8 x 8 grid of decoded 1920x1080 10-bit 4:2:0 tiles -> one 15360x8640 RGBA canvas, tiles
             # converted where they lie (avifhipGridYUVToRGBAsync: no YUV canvas, seams redone across tiles)
