@@ -248,40 +248,41 @@ __device__ __forceinline__ void store4(uint8_t * base, uint32_t off, const Pixel
 
 // 16-bit RGBA: a lane's 4 pixels are 32 bytes.  Two 16-byte stores at (32*lane, 32*lane + 16) make every store
 // instruction touch only half of each cache line (tests/tools/membw3.hip: cfg3's bytes take 111 us that way and 74 us
-// with contiguous instructions), so the wave first re-distributes its 2 KiB row segment: store instruction h covers bytes
-// [1024*h, 1024*h + 1024) and lane l writes the 16 bytes at 16*l of it, which belong to lane 32*h + (l >> 1), half (l & 1).
-// Must be called by every lane of the wave (the exchange reads all lanes); rowOff addresses the band's first pixel.
-__device__ __forceinline__ void store4WideRgba(uint8_t * base, uint32_t rowOff, const PixelOut q[4], const unsigned a[4], bool swapRB, bool alphaFirst,
-                                               uint32_t bandX, uint32_t w4)
+// with contiguous instructions), so the wave first re-distributes its 2 KiB row segment through a wave-private LDS
+// buffer: written in lane order (32 bytes per lane), read back so that store instruction h covers bytes
+// [1024*h, 1024*h + 1024) with lane l writing the 16 bytes at 16*l.  Must be called by every lane of the wave.
+// q[k].r / q[k].b hold the first / third colour channel; rowOff addresses the band's first pixel.
+struct WideRowExchange
+{
+    u4 w[128]; // 2 KiB: one row segment of one wave
+};
+
+__device__ __forceinline__ void store4WideRgba(uint8_t * base, uint32_t rowOff, const PixelOut q[4], const unsigned a[4], bool alphaFirst, uint32_t bandX,
+                                               uint32_t w4, WideRowExchange & xchg)
 {
     u4 w0, w1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned x = swapRB ? q[k].b : q[k].r, z = swapRB ? q[k].r : q[k].b;
-        const unsigned lo = alphaFirst ? (a[k] | (x << 16)) : (x | (q[k].g << 16));
-        const unsigned hi = alphaFirst ? (q[k].g | (z << 16)) : (z | (a[k] << 16));
-        if (k < 2) {
-            w0[(k & 1) * 2 + 0] = lo;
-            w0[(k & 1) * 2 + 1] = hi;
-        } else {
-            w1[(k & 1) * 2 + 0] = lo;
-            w1[(k & 1) * 2 + 1] = hi;
-        }
+    if (alphaFirst) { // uniform: A X G Z
+        w0 = (u4) { a[0] | (q[0].r << 16), q[0].g | (q[0].b << 16), a[1] | (q[1].r << 16), q[1].g | (q[1].b << 16) };
+        w1 = (u4) { a[2] | (q[2].r << 16), q[2].g | (q[2].b << 16), a[3] | (q[3].r << 16), q[3].g | (q[3].b << 16) };
+    } else { // X G Z A
+        w0 = (u4) { q[0].r | (q[0].g << 16), q[0].b | (a[0] << 16), q[1].r | (q[1].g << 16), q[1].b | (a[1] << 16) };
+        w1 = (u4) { q[2].r | (q[2].g << 16), q[2].b | (a[2] << 16), q[3].r | (q[3].g << 16), q[3].b | (a[3] << 16) };
     }
     const int l = threadIdx.x;
-    const int src = l >> 1;
-    const bool upper = (l & 1) != 0;
-    u4 s0, s1;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const unsigned a0 = __shfl(w0[c], src), b0 = __shfl(w1[c], src);
-        const unsigned a1 = __shfl(w0[c], 32 + src), b1 = __shfl(w1[c], 32 + src);
-        s0[c] = upper ? b0 : a0;
-        s1[c] = upper ? b1 : a1;
-    }
-    if (bandX + 4u * (uint32_t)src < w4)
+    // the buffer is private to this wave, whose LDS accesses execute in program order; the fences only keep the compiler
+    // from moving the reads above the writes (other lanes' writes) or the next row's writes above these reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    xchg.w[2 * l] = w0;
+    xchg.w[2 * l + 1] = w1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u4 s0 = xchg.w[l], s1 = xchg.w[64 + l];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // slot l of instruction h holds the pixels of lane 32*h + (l >> 1)
+    if (bandX + 4u * (uint32_t)(l >> 1) < w4)
         __builtin_nontemporal_store(s0, reinterpret_cast<u4 *>(base + rowOff + 16u * (uint32_t)l));
-    if (bandX + 4u * (uint32_t)(32 + src) < w4)
+    if (bandX + 4u * (uint32_t)(32 + (l >> 1)) < w4)
         __builtin_nontemporal_store(s1, reinterpret_cast<u4 *>(base + rowOff + 1024u + 16u * (uint32_t)l));
 }
 
@@ -479,7 +480,7 @@ __device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, 
 
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
 __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & c, uint32_t tileY,
-                                            const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS> & T, f2 (*rows)[kRowPitch])
+                                            const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS> & T, f2 (*rows)[kRowPitch], WideRowExchange * xchg)
 {
     constexpr bool kWide = sizeof(YT) == 2;
     constexpr bool kNeedA = APLANE || HASMUL;
@@ -490,10 +491,11 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
     const uint32_t X = c.X;
     const bool laneValid = c.laneValid;
     const StripRaw<YT, SUB, BIL, kNeedA> * raw = T.raw;
-    const bool swapRB = A.slotB < A.slotR;
     const bool alphaFirst = (NCH == 4) && (A.slotA == 0);
-    const f2 cBR = { A.cB, A.cR }; // (Cb,Cr) -> (B - Y, R - Y), src/reformat.c:874-875
-    const f2 cUV = { A.cU, A.cV }; // the two products of the green term, :876
+    // (first colour X, third colour Z) of a pixel from the two chroma planes in TileArgs order (tile_shared.h): for BGR
+    // orders (Cb,Cr) -> (B - Y, R - Y), src/reformat.c:874-875; for RGB orders the planes and coefficients arrive swapped
+    const f2 cBR = { A.cB, A.cR };
+    const f2 cUV = { A.cU, A.cV }; // the two products of the green term, :876 (their sum is commutative)
     const unsigned opaqueWord = A.rgbMax << (8 * A.slotA); // 8-bit RGBA: the alpha byte in place
 
 #pragma unroll
@@ -635,15 +637,15 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         aw[i] = APLANE ? (a[i] << (8 * A.slotA)) : opaqueWord;
-                    packRgba8Row(w, aw, tbr, tg, A.slotR, A.slotG, A.slotB);
+                    packRgba8Row(w, aw, tbr, tg, A.slotZ, A.slotG, A.slotX);
                     if (laneValid)
                         storeVec(A.rgb, off, (u4) { w[0], w[1], w[2], w[3] }, nt);
                 } else {
                     float x[4], z[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        x[i] = swapRB ? tbr[i].x : tbr[i].y;
-                        z[i] = swapRB ? tbr[i].y : tbr[i].x;
+                        x[i] = tbr[i].x;
+                        z[i] = tbr[i].y;
                     }
                     unsigned w[3];
                     packRgb8Row(w, x, tg, z);
@@ -657,12 +659,12 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                 PixelOut q[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    q[i] = finishPixel<HASMUL>(A, br[i].y, g[i], br[i].x, av[i], a[i]);
+                    q[i] = finishPixel<HASMUL>(A, br[i].x, g[i], br[i].y, av[i], a[i]); // q.r = first colour, q.b = third
                 if constexpr (sizeof(RT) == 2 && NCH == 4) {
-                    store4WideRgba(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, a, swapRB, alphaFirst, c.bandX, A.w4);
+                    store4WideRgba(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, a, alphaFirst, c.bandX, A.w4, xchg[wv]);
                 } else {
                     if (laneValid)
-                        store4<RT, NCH>(A.rgb, off, q, a, swapRB, alphaFirst, nt);
+                        store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
                 }
             }
         }
@@ -674,7 +676,8 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 // of tile i+1 are in flight while tile i is computed and stored, so a wave waits for memory once per run, not once
 // per tile; vertically consecutive tiles also re-read their shared chroma halo rows from the nearest cache.
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
-__device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRun, f2 (*rows)[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch])
+__device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRun, f2 (*rows)[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch],
+                                         WideRowExchange * xchg)
 {
     constexpr int kTileH = 8 * NS;
     constexpr bool kNeedA = APLANE || HASMUL;
@@ -712,7 +715,7 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRu
         TileRaw<YT, SUB, BIL, kNeedA, NS> nxt;
         if (more)
             loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY + kTileH, nxt);
-        computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, c, tileY, cur, rows[i & 1]);
+        computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, c, tileY, cur, rows[i & 1], xchg);
         if (!more)
             break;
         if constexpr (BIL) {
@@ -728,7 +731,12 @@ template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, boo
 __global__ __launch_bounds__(256) void yuvToRgbTileKernel(TileArgs A, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
-    runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, tilesPerRun, rows);
+    if constexpr (sizeof(RT) == 2 && NCH == 4) {
+        __shared__ WideRowExchange xchg[kWavesPerBlock]; // one per wave, 16-bit RGBA only
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, tilesPerRun, rows, xchg);
+    } else {
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, tilesPerRun, rows, nullptr);
+    }
 }
 
 // one launch for a table of jobs (grid z = job); the descriptor is read with scalar loads
@@ -736,7 +744,12 @@ template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, boo
 __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
-    runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows);
+    if constexpr (sizeof(RT) == 2 && NCH == 4) {
+        __shared__ WideRowExchange xchg[kWavesPerBlock];
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows, xchg);
+    } else {
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows, nullptr);
+    }
 }
 
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool MUL>

@@ -34,6 +34,10 @@ struct TileArgs
     float rgbMaxF;
     uint32_t yuvMax, rgbMax;
     uint32_t slotR, slotG, slotB, slotA; // channel index inside a pixel
+    // libyuv's "YVU trick" (src/reformat_libyuv.c:386-423), applied by both kernel families: `u` above addresses the plane
+    // feeding the FIRST colour channel of a pixel (X: R for RGB orders, B for BGR orders), `v` the one feeding the third
+    // (Z), and cB / cU (cR / cV) are the coefficients of that first (third) channel -- so no kernel selects channels per pixel
+    uint32_t slotX, slotZ;
     int32_t alphaRescale;                // alpha plane depth differs from the rgb depth (src/alpha.c:84-103)
     int32_t inLoopMul, postMul;          // MulMode
     uint32_t tuning;
@@ -86,6 +90,17 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     A.yuvMax = (uint32_t)s.maxv, A.rgbMax = (uint32_t)o.maxv;
     A.slotR = (uint32_t)(o.offR / o.chanBytes), A.slotG = (uint32_t)(o.offG / o.chanBytes), A.slotB = (uint32_t)(o.offB / o.chanBytes);
     A.slotA = (uint32_t)(o.offA / o.chanBytes);
+    const bool redFirstColour = A.slotR < A.slotB;
+    A.slotX = redFirstColour ? A.slotR : A.slotB, A.slotZ = redFirstColour ? A.slotB : A.slotR;
+    if (redFirstColour && p.arith != ARITH_LIBYUV) { // the fixed-point block below does its own swap
+        const uint8_t * t = A.u;
+        A.u = A.v, A.v = t;
+        const uint32_t tp = A.uPitch;
+        A.uPitch = A.vPitch, A.vPitch = tp;
+        float tf = A.cB;
+        A.cB = A.cR, A.cR = tf;
+        tf = A.cU, A.cU = A.cV, A.cV = tf;
+    }
     A.alphaRescale = (s.depth != o.depth) ? 1 : 0;
     A.inLoopMul = p.inLoopMul, A.postMul = p.postMul;
     A.tuning = p.tuning;
