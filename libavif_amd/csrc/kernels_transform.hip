@@ -51,6 +51,40 @@ __global__ __launch_bounds__(256) void transformRowsKernel(TransformArgs A)
         *reinterpret_cast<const Pixel<PX, ALIGNED> *>(A.src + (size_t)j * A.srcPitch + (size_t)i * PX);
 }
 
+// angle 0 / 2 with 4-byte-aligned 4- or 8-byte pixels: 16 bytes per lane and access.  A destination group of N = 16 / PX
+// consecutive pixels is a run of N consecutive source pixels, read forwards or (mirrored / half turn) backwards.
+template <int PX>
+__global__ __launch_bounds__(256) void transformRowsWideKernel(TransformArgs A)
+{
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    constexpr uint32_t N = 16 / PX;
+    const uint32_t x = (blockIdx.x * 64 + threadIdx.x) * N, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= A.dw || y >= A.dh)
+        return;
+    uint8_t * dst = A.dst + (size_t)y * A.dstPitch + (size_t)x * PX;
+    if (x + N > A.dw) { // the row's last, partial group: pixel by pixel
+        for (uint32_t k = 0; x + k < A.dw; ++k) {
+            uint32_t i, j;
+            sourceOf(A, x + k, y, &i, &j);
+            *reinterpret_cast<Pixel<PX, true> *>(dst + k * PX) = *reinterpret_cast<const Pixel<PX, true> *>(A.src + (size_t)j * A.srcPitch + (size_t)i * PX);
+        }
+        return;
+    }
+    uint32_t i0, j0, i1, j1;
+    sourceOf(A, x, y, &i0, &j0);
+    sourceOf(A, x + N - 1, y, &i1, &j1); // same source row; i1 = i0 + N - 1 or i0 - (N - 1)
+    const bool reversed = i1 < i0;
+    const u4v v = *reinterpret_cast<const u4v *>(A.src + (size_t)j0 * A.srcPitch + (size_t)(reversed ? i1 : i0) * PX);
+    u4v o = v;
+    if (reversed) {
+        if constexpr (PX == 4)
+            o = (u4v) { v.w, v.z, v.y, v.x };
+        else
+            o = (u4v) { v.z, v.w, v.x, v.y };
+    }
+    __builtin_nontemporal_store(o, reinterpret_cast<u4v *>(dst));
+}
+
 template <int PX, bool ALIGNED>
 __global__ __launch_bounds__(256) void transformTransposeKernel(TransformArgs A)
 {
@@ -84,10 +118,19 @@ __global__ __launch_bounds__(256) void transformTransposeKernel(TransformArgs A)
 template <int PX, bool ALIGNED>
 hipError_t launchFor(const TransformArgs & A, hipStream_t stream)
 {
-    if (A.angle == 1 || A.angle == 3)
+    if (A.angle == 1 || A.angle == 3) {
         hipLaunchKernelGGL((transformTransposeKernel<PX, ALIGNED>), dim3((A.dw + 31) / 32, (A.dh + 31) / 32), dim3(32, 8), 0, stream, A);
-    else
+    } else if constexpr ((PX == 4 || PX == 8) && ALIGNED) {
+        // 16-byte stores need a 16-byte aligned destination; loads only the pixels' own 4-byte alignment
+        if (((uintptr_t)A.dst % 16) == 0 && (A.dstPitch % 16) == 0 && ((uintptr_t)A.src % 4) == 0 && (A.srcPitch % 4) == 0) {
+            constexpr uint32_t N = 16 / PX;
+            hipLaunchKernelGGL((transformRowsWideKernel<PX>), dim3(((A.dw + N - 1) / N + 63) / 64, (A.dh + 3) / 4), dim3(64, 4), 0, stream, A);
+        } else {
+            hipLaunchKernelGGL((transformRowsKernel<PX, ALIGNED>), dim3((A.dw + 63) / 64, (A.dh + 3) / 4), dim3(64, 4), 0, stream, A);
+        }
+    } else {
         hipLaunchKernelGGL((transformRowsKernel<PX, ALIGNED>), dim3((A.dw + 63) / 64, (A.dh + 3) / 4), dim3(64, 4), 0, stream, A);
+    }
     return hipGetLastError();
 }
 
