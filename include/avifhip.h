@@ -130,6 +130,15 @@ AVIFHIP_API avifResult avifhipRGBImageTransformAsync(avifRGBImage * dst,
                                                      uint8_t axis,
                                                      void * hipStream);
 
+/* Plane scaling.  Replaces avifImageScale, include/avif/avif.h:922, src/scale.c:23-201, which scales
+ * every plane with the vendored libyuv scaler under kFilterBox (third_party/libyuv/source/scale*.c): results are byte-identical
+ * (integer arithmetic).  avifhipImageScale works in place on a host-resident image exactly like the reference (new planes
+ * are malloc'ed with tight rows, old ones freed if the image owned them).  avifhipImageScaleAsync scales the planes of a
+ * device-resident `src` into the caller-allocated planes of `dst` (same depth and format; dst->width / height are the target
+ * size; every plane present in src must be present in dst), enqueued on `hipStream`. */
+AVIFHIP_API avifResult avifhipImageScale(avifImage * image, uint32_t dstWidth, uint32_t dstHeight);
+AVIFHIP_API avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * dst, void * hipStream);
+
 /* ---- integer helpers (src/reformat.c:1778-1840; used on decoded alpha planes, src/read.c:6724) */
 AVIFHIP_API int avifhipLimitedToFullY(uint32_t depth, int v);
 AVIFHIP_API int avifhipLimitedToFullUV(uint32_t depth, int v);

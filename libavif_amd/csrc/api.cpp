@@ -14,6 +14,7 @@
 #include "avifhip.h"
 #include "kernels.h"
 #include "plan.h"
+#include "scale_plan.h"
 
 using namespace avifhip;
 
@@ -39,9 +40,13 @@ struct Context
     Scratch pixels;    // interleaved RGB staging
     Scratch table;     // batch descriptor table (device)
     Scratch gridTable; // tile table of a grid conversion (device)
+    Scratch scaleTable; // schedules of a plane scale (device)
     void * pinnedTable = nullptr;
     size_t pinnedTableCapacity = 0;
     hipEvent_t tableCopied = nullptr;
+    void * pinnedUpload = nullptr; // staging for small host tables (grid tile tables, scale schedules)
+    size_t pinnedUploadCapacity = 0;
+    hipEvent_t uploadCopied = nullptr;
     char lastError[512] = { 0 };
     const char * lastKernel = "";
     uint64_t launches = 0; // kernels enqueued by this thread
@@ -58,10 +63,16 @@ struct Context
             (void)hipFree(table.ptr);
         if (gridTable.ptr)
             (void)hipFree(gridTable.ptr);
+        if (scaleTable.ptr)
+            (void)hipFree(scaleTable.ptr);
         if (pinnedTable)
             (void)hipHostFree(pinnedTable);
         if (tableCopied)
             (void)hipEventDestroy(tableCopied);
+        if (pinnedUpload)
+            (void)hipHostFree(pinnedUpload);
+        if (uploadCopied)
+            (void)hipEventDestroy(uploadCopied);
         if (stream)
             (void)hipStreamDestroy(stream);
     }
@@ -109,6 +120,28 @@ avifResult ensureContext()
         HIP_TRY(hipGetDevice(&tls.device));
     HIP_TRY(hipStreamCreateWithFlags(&tls.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&tls.tableCopied, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&tls.uploadCopied, hipEventDisableTiming));
+    return AVIF_RESULT_OK;
+}
+
+// Enqueues a copy of a small host table to device memory.  An asynchronous copy from pageable memory may still be reading
+// its source after the call returns, so the bytes go through a pinned per-thread staging buffer first; the buffer is reused
+// only after the previous upload has left it.
+avifResult uploadTableAsync(void * deviceDst, const void * hostSrc, size_t bytes, hipStream_t stream)
+{
+    if (tls.pinnedUpload)
+        HIP_TRY(hipEventSynchronize(tls.uploadCopied));
+    if (bytes > tls.pinnedUploadCapacity) {
+        if (tls.pinnedUpload)
+            HIP_TRY(hipHostFree(tls.pinnedUpload));
+        tls.pinnedUpload = nullptr, tls.pinnedUploadCapacity = 0;
+        const size_t rounded = (bytes + 65535) & ~(size_t)65535;
+        HIP_TRY(hipHostMalloc(&tls.pinnedUpload, rounded, hipHostMallocDefault));
+        tls.pinnedUploadCapacity = rounded;
+    }
+    memcpy(tls.pinnedUpload, hostSrc, bytes);
+    HIP_TRY(hipMemcpyAsync(deviceDst, tls.pinnedUpload, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(tls.uploadCopied, stream));
     return AVIF_RESULT_OK;
 }
 
@@ -637,7 +670,9 @@ extern "C" avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid, const a
     if (r != AVIF_RESULT_OK)
         return r;
     hipStream_t stream = pickStream(hipStream);
-    HIP_TRY(hipMemcpyAsync(tls.gridTable.ptr, tiles.data(), tableBytes, hipMemcpyHostToDevice, stream)); // pageable source: staged before return
+    r = uploadTableAsync(tls.gridTable.ptr, tiles.data(), tableBytes, stream);
+    if (r != AVIF_RESULT_OK)
+        return r;
     GridGeometry g;
     g.columns = grid->columns, g.rows = grid->rows, g.tileW = tw, g.tileH = th, g.tileCW = tw >> sx, g.tileCH = th >> sy;
     const hipError_t e = launchYuvToRgbGridSeams(canvasPlan, g, (const GridTile *)tls.gridTable.ptr, grid->columns > 1, sy && grid->rows > 1, stream);
@@ -833,6 +868,187 @@ extern "C" avifResult avifhipRGBImagePremultiplyAlphaAsync(avifRGBImage * rgb, v
 extern "C" avifResult avifhipRGBImageUnpremultiplyAlphaAsync(avifRGBImage * rgb, void * hipStream)
 {
     return alphaMulAsync(rgb, true, hipStream);
+}
+
+// =================================================================================================
+// plane scaling, reference src/scale.c:23-201
+// =================================================================================================
+
+namespace {
+
+struct PlaneDims
+{
+    int w[4], h[4];
+};
+PlaneDims planeDims(uint32_t width, uint32_t height, int yuvFormat)
+{
+    const int sx = (yuvFormat == AVIF_PIXEL_FORMAT_YUV444 || yuvFormat == AVIF_PIXEL_FORMAT_YUV400) ? 0 : 1;
+    const int sy = (yuvFormat == AVIF_PIXEL_FORMAT_YUV420) ? 1 : 0;
+    PlaneDims d;
+    d.w[0] = d.w[3] = (int)width, d.h[0] = d.h[3] = (int)height;
+    d.w[1] = d.w[2] = (int)((width + sx) >> sx), d.h[1] = d.h[2] = (int)((height + sy) >> sy);
+    return d;
+}
+
+} // namespace
+
+extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * dst, void * hipStream)
+{
+    if (!src || !dst || !dst->width || !dst->height)
+        return AVIF_RESULT_INVALID_ARGUMENT; // src/scale.c:35-38
+    if (src->depth != dst->depth || src->yuvFormat != dst->yuvFormat)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if ((src->yuvPlanes[0] || src->alphaPlane) && (src->width > 16384 || src->height > 16384))
+        return AVIF_RESULT_NOT_IMPLEMENTED; // "invalid width/height scale for libyuv", src/scale.c:66-80
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    hipStream_t stream = pickStream(hipStream);
+    const bool wide = src->depth > 8;
+    const PlaneDims sd = planeDims(src->width, src->height, (int)src->yuvFormat), dd = planeDims(dst->width, dst->height, (int)dst->yuvFormat);
+    // schedules of every plane in one table
+    std::vector<int32_t> tables;
+    size_t offset[4] = { 0, 0, 0, 0 };
+    ScaleSchedule sched[4];
+    bool present[4] = { false, false, false, false };
+    for (int p = 0; p < 4; ++p) {
+        const uint8_t * sp = (p < 3) ? src->yuvPlanes[p] : src->alphaPlane;
+        uint8_t * dp = (p < 3) ? dst->yuvPlanes[p] : dst->alphaPlane;
+        if (!sp || ((p == 1 || p == 2) && src->yuvFormat == AVIF_PIXEL_FORMAT_YUV400))
+            continue;
+        if (!dp) {
+            setError("avifhipImageScaleAsync: destination plane %d is missing", p);
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        }
+        present[p] = true;
+        sched[p] = makeScaleSchedule(sd.w[p], sd.h[p], dd.w[p], dd.h[p], wide);
+        offset[p] = tables.size();
+        for (const std::vector<int32_t> * v : { &sched[p].colA, &sched[p].colB, &sched[p].rowA, &sched[p].rowB, &sched[p].rowF })
+            tables.insert(tables.end(), v->begin(), v->end());
+    }
+    if (tables.empty())
+        return AVIF_RESULT_OK;
+    // per-thread device table: successive calls of one thread are ordered by the stream they share (like the grid table)
+    const avifResult rr = reserve(tls.scaleTable, tables.size() * sizeof(int32_t));
+    if (rr != AVIF_RESULT_OK)
+        return rr;
+    int32_t * dev = (int32_t *)tls.scaleTable.ptr;
+    const avifResult ur = uploadTableAsync(dev, tables.data(), tables.size() * sizeof(int32_t), stream);
+    if (ur != AVIF_RESULT_OK)
+        return ur;
+    for (int p = 0; p < 4; ++p) {
+        if (!present[p])
+            continue;
+        ScaleArgs A;
+        A.src = (p < 3) ? src->yuvPlanes[p] : src->alphaPlane;
+        A.dst = (p < 3) ? dst->yuvPlanes[p] : dst->alphaPlane;
+        A.srcPitch = (p < 3) ? src->yuvRowBytes[p] : src->alphaRowBytes;
+        A.dstPitch = (p < 3) ? dst->yuvRowBytes[p] : dst->alphaRowBytes;
+        A.srcW = sd.w[p], A.srcH = sd.h[p], A.dstW = dd.w[p], A.dstH = dd.h[p];
+        A.mode = sched[p].mode;
+        const int32_t * t = dev + offset[p];
+        A.colA = t, A.colB = t + dd.w[p], A.rowA = t + 2 * (size_t)dd.w[p], A.rowB = A.rowA + dd.h[p], A.rowF = A.rowB + dd.h[p];
+        const hipError_t e = launchScalePlane(A, wide, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "plane scaling kernel launch");
+    }
+    static const char * names[] = { "scale_point", "scale_down", "scale_up", "scale_box", "scale_up2" };
+    tls.lastKernel = names[sched[present[0] ? 0 : 3].mode];
+    ++tls.launches;
+    return AVIF_RESULT_OK;
+}
+
+// in place on a host-resident image, like the reference
+extern "C" avifResult avifhipImageScale(avifImage * image, uint32_t dstWidth, uint32_t dstHeight)
+{
+    if (!image)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if (image->width == dstWidth && image->height == dstHeight)
+        return AVIF_RESULT_OK; // "Nothing to do", src/scale.c:30-33
+    if (!dstWidth || !dstHeight)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if ((image->yuvPlanes[0] || image->alphaPlane) && (image->width > 16384 || image->height > 16384))
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    avifResult r = ensureContext();
+    if (r != AVIF_RESULT_OK)
+        return r;
+    const size_t bps = (image->depth > 8) ? 2 : 1;
+    const PlaneDims sd = planeDims(image->width, image->height, (int)image->yuvFormat), dd = planeDims(dstWidth, dstHeight, (int)image->yuvFormat);
+    avifImage srcView, dstView;
+    memcpy(&srcView, image, sizeof(avifImage));
+    memcpy(&dstView, image, sizeof(avifImage));
+    dstView.width = dstWidth, dstView.height = dstHeight;
+    // stage the source planes, reserve the destination planes (one device buffer: [sources][destinations])
+    size_t srcOff[4], dstOff[4], total = 0;
+    uint32_t srcPitch[4], dstPitch[4];
+    bool present[4];
+    for (int p = 0; p < 4; ++p) {
+        const uint8_t * sp = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
+        present[p] = sp && !((p == 1 || p == 2) && image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400);
+        srcOff[p] = dstOff[p] = 0, srcPitch[p] = dstPitch[p] = 0;
+        if (!present[p])
+            continue;
+        srcPitch[p] = alignUp((uint32_t)(sd.w[p] * bps), 256), dstPitch[p] = alignUp((uint32_t)(dd.w[p] * bps), 256);
+        srcOff[p] = total, total += (size_t)srcPitch[p] * sd.h[p];
+        dstOff[p] = total, total += (size_t)dstPitch[p] * dd.h[p];
+    }
+    if (total == 0) {
+        image->width = dstWidth, image->height = dstHeight;
+        return AVIF_RESULT_OK;
+    }
+    r = reserve(tls.pixels, total);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    uint8_t * base = (uint8_t *)tls.pixels.ptr;
+    for (int p = 0; p < 4; ++p) {
+        uint8_t ** sv = (p < 3) ? &srcView.yuvPlanes[p] : &srcView.alphaPlane;
+        uint8_t ** dv = (p < 3) ? &dstView.yuvPlanes[p] : &dstView.alphaPlane;
+        uint32_t * svp = (p < 3) ? &srcView.yuvRowBytes[p] : &srcView.alphaRowBytes;
+        uint32_t * dvp = (p < 3) ? &dstView.yuvRowBytes[p] : &dstView.alphaRowBytes;
+        if (!present[p]) {
+            *sv = *dv = nullptr;
+            continue;
+        }
+        const uint8_t * host = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
+        const uint32_t hostPitch = (p < 3) ? image->yuvRowBytes[p] : image->alphaRowBytes;
+        HIP_TRY(hipMemcpy2DAsync(base + srcOff[p], srcPitch[p], host, hostPitch, sd.w[p] * bps, sd.h[p], hipMemcpyHostToDevice, tls.stream));
+        *sv = base + srcOff[p], *svp = srcPitch[p];
+        *dv = base + dstOff[p], *dvp = dstPitch[p];
+    }
+    r = avifhipImageScaleAsync(&srcView, &dstView, tls.stream);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    // new planes: malloc'ed with tight rows like avifImageAllocatePlanes (src/avif.c:431-490)
+    uint8_t * fresh[4] = { nullptr, nullptr, nullptr, nullptr };
+    for (int p = 0; p < 4; ++p) {
+        if (!present[p])
+            continue;
+        fresh[p] = (uint8_t *)malloc((size_t)dd.w[p] * bps * dd.h[p]);
+        if (!fresh[p]) {
+            for (int q = 0; q < p; ++q)
+                free(fresh[q]);
+            (void)hipStreamSynchronize(tls.stream);
+            return AVIF_RESULT_OUT_OF_MEMORY;
+        }
+        HIP_TRY(hipMemcpy2DAsync(fresh[p], dd.w[p] * bps, base + dstOff[p], dstPitch[p], dd.w[p] * bps, dd.h[p], hipMemcpyDeviceToHost, tls.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(tls.stream));
+    for (int p = 0; p < 4; ++p) {
+        if (!present[p])
+            continue;
+        uint8_t ** plane = (p < 3) ? &image->yuvPlanes[p] : &image->alphaPlane;
+        uint32_t * pitch = (p < 3) ? &image->yuvRowBytes[p] : &image->alphaRowBytes;
+        const bool owned = (p < 3) ? image->imageOwnsYUVPlanes : image->imageOwnsAlphaPlane;
+        if (owned)
+            free(*plane); // src/scale.c:186-193 (avifFree is free, src/mem.c)
+        *plane = fresh[p], *pitch = (uint32_t)(dd.w[p] * bps);
+    }
+    if (image->yuvPlanes[0])
+        image->imageOwnsYUVPlanes = AVIF_TRUE;
+    if (image->alphaPlane)
+        image->imageOwnsAlphaPlane = AVIF_TRUE;
+    image->width = dstWidth, image->height = dstHeight;
+    return AVIF_RESULT_OK;
 }
 
 // =================================================================================================

@@ -63,4 +63,21 @@ struct TransformArgs
 };
 hipError_t launchRgbTransform(const TransformArgs & args, uint32_t pixelBytes, hipStream_t stream);
 
+// plane scaling (kernels_scale.hip): schedule tables live in device memory, modes as in scale_plan.h
+enum { SCALE_POINT_MODE = 0, SCALE_DOWN_MODE = 1, SCALE_UP_MODE = 2, SCALE_BOX_MODE = 3, SCALE_UP2_MODE = 4 };
+struct ScaleArgs
+{
+    const uint8_t * src;
+    uint8_t * dst;
+    uint32_t srcPitch, dstPitch;
+    int32_t srcW, srcH, dstW, dstH;
+    int32_t mode;
+    const int32_t * colA; // dstW entries each
+    const int32_t * colB;
+    const int32_t * rowA; // dstH entries each
+    const int32_t * rowB;
+    const int32_t * rowF;
+};
+hipError_t launchScalePlane(const ScaleArgs & args, bool wide, hipStream_t stream);
+
 } // namespace avifhip

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
     "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
-    "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync",
+    "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync",
 ]
 
 class avifhipGrid(C.Structure):
@@ -92,6 +92,8 @@ def load() -> C.CDLL:
         "avifhipExplainYUVToRGB": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
         "avifhipExplainRGBToYUV": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
         "avifhipRGBImageTransformAsync": (i32, [P_RGB, P_RGB, P_RECT, i32, C.c_uint8, i32, C.c_uint8, vp]),
+        "avifhipImageScale": (i32, [P_IMG, u32, u32]),
+        "avifhipImageScaleAsync": (i32, [P_IMG, P_IMG, vp]),
         "avifhipGridYUVToRGBAsync": (i32, [C.POINTER(avifhipGrid), C.POINTER(P_IMG), C.POINTER(P_IMG), i32, P_RGB, vp]),
     }
     for name, (res, args) in sigs.items():

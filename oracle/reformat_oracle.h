@@ -73,6 +73,12 @@ avifResult oracleRGBImageTransform(avifRGBImage * dst, const avifRGBImage * src,
                                    avifBool mirror, uint8_t axis);
 
 /*
+ * avifImageScale (src/scale.c:23-201; vendored libyuv scaler under kFilterBox, third_party/libyuv/source/scale*.c): every
+ * plane of `image` is replaced by its scaled version (scale_oracle.c).  The diagnostics argument of the reference is dropped.
+ */
+avifResult oracleImageScale(avifImage * image, uint32_t dstWidth, uint32_t dstHeight);
+
+/*
  * The reference's INTEGER path: what a libavif built with libyuv computes (libyuv_oracle.c).
  * oracleLibyuv<Entry> == that build's avif<Entry>, end to end: libyuv's fixed-point arithmetic wherever libavif
  * dispatches to libyuv (src/reformat_libyuv.c; honours rgb->avoidLibYUV like src/reformat.c:1453 and :264), the fp32

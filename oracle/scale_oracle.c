@@ -1,0 +1,445 @@
+/*
+ * scale_oracle.c -- TEST INFRASTRUCTURE (the checker), NOT PRODUCT CODE.
+ *
+ * Plane scaling of libavif: avifImageScale (/root/reference/src/scale.c:23-201), which scales every plane with the
+ * vendored libyuv scaler under kFilterBox (third_party/libyuv/source/scale.c:829-1007 ScalePlane / ScalePlane_16 /
+ * ScalePlane_12, scale_common.c, scale_any.c, row_common.c -- in tree, integer arithmetic).
+ *
+ * Restated as a per-sample model instead of the reference's row-buffer procedures: a plane scale is described by a
+ * MODE plus one schedule entry per destination row and per destination column (which source rows / columns feed it and
+ * with what fraction); every destination sample is then an independent function of at most 2 x 2 source samples (or a
+ * box of them).  The schedules reproduce the reference's 16.16 stepping including its clamps and its row-buffer
+ * bookkeeping (ScalePlaneBilinearUp), the sample functions reproduce its rounding (7-bit blend for 8-bit samples,
+ * 16-bit blend for 16-bit samples, 8-bit vertical fractions, 16-bit wrap-around of 8-bit box sums).
+ *
+ * Parity status: PINNED against avifImageScale of the reference compiled from source (oracle/_ref/libavif_ref.so):
+ * tests/test_scale.py, every (src size, dst size, depth, format) of its sweep byte-identical.
+ */
+#include "reformat_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+enum { F_NONE = 0, F_LINEAR, F_BILINEAR, F_BOX };
+enum { M_POINT = 0, M_DOWN, M_UP, M_BOX, M_UP2 };
+
+typedef struct PlaneSchedule
+{
+    int mode;
+    int wide;  /* 16-bit samples */
+    int dw, dh;
+    /* per destination column: POINT/DOWN/UP: source column + 16.16 fraction; UP2: near + far column; BOX: first column + width */
+    int * colA;
+    int * colB;
+    /* per destination row: DOWN/UP/UP2: first + second source row and the 8-bit fraction; BOX: first row + height */
+    int * rowA;
+    int * rowB;
+    int * rowF;
+} PlaneSchedule;
+
+static int min1(int v)
+{
+    return v < 1 ? 1 : v;
+}
+static int fixedDiv(int num, int div) /* scale_common.c:472-474 */
+{
+    return (int)(((int64_t)num << 16) / div);
+}
+static int fixedDiv1(int num, int div) /* :477-479 */
+{
+    return (int)((((int64_t)num << 16) - 0x00010001) / (div - 1));
+}
+static int centerStart(int d, int s) /* CENTERSTART, :482 */
+{
+    return (d < 0) ? -((-d >> 1) + s) : ((d >> 1) + s);
+}
+
+/* ScaleFilterReduce, scale_common.c:428-469 */
+static int filterReduce(int sw, int sh, int dw, int dh, int f)
+{
+    if (f == F_BOX && (dw * 2 >= sw || dh * 2 >= sh))
+        f = F_BILINEAR;
+    if (f == F_BILINEAR) {
+        if (sh == 1)
+            f = F_LINEAR;
+        if (dh == sh || dh * 3 == sh)
+            f = F_LINEAR;
+        if (sw == 1)
+            f = F_NONE;
+    }
+    if (f == F_LINEAR) {
+        if (sw == 1)
+            f = F_NONE;
+        if (dw == sw || dw * 3 == sw)
+            f = F_NONE;
+    }
+    return f;
+}
+
+/* ScaleSlope, scale_common.c:484-553 (positive widths only) */
+static void slope(int sw, int sh, int dw, int dh, int f, int * x, int * y, int * dx, int * dy)
+{
+    *x = *y = *dx = *dy = 0;
+    if (dw == 1 && sw >= 32768)
+        dw = sw;
+    if (dh == 1 && sh >= 32768)
+        dh = sh;
+    if (f == F_BOX) {
+        *dx = fixedDiv(sw, dw);
+        *dy = fixedDiv(sh, dh);
+    } else if (f == F_BILINEAR || f == F_LINEAR) {
+        if (dw <= sw) {
+            *dx = fixedDiv(sw, dw);
+            *x = centerStart(*dx, -32768);
+        } else if (sw > 1 && dw > 1) {
+            *dx = fixedDiv1(sw, dw);
+        }
+        if (f == F_BILINEAR) {
+            if (dh <= sh) {
+                *dy = fixedDiv(sh, dh);
+                *y = centerStart(*dy, -32768);
+            } else if (sh > 1 && dh > 1) {
+                *dy = fixedDiv1(sh, dh);
+            }
+        } else {
+            *dy = fixedDiv(sh, dh);
+            *y = *dy >> 1;
+        }
+    } else {
+        *dx = fixedDiv(sw, dw);
+        *dy = fixedDiv(sh, dh);
+        *x = centerStart(*dx, 0);
+        *y = centerStart(*dy, 0);
+    }
+}
+
+static int allocSchedule(PlaneSchedule * S, int dw, int dh)
+{
+    memset(S, 0, sizeof(*S));
+    S->dw = dw, S->dh = dh;
+    S->colA = (int *)calloc((size_t)dw, sizeof(int));
+    S->colB = (int *)calloc((size_t)dw, sizeof(int));
+    S->rowA = (int *)calloc((size_t)dh, sizeof(int));
+    S->rowB = (int *)calloc((size_t)dh, sizeof(int));
+    S->rowF = (int *)calloc((size_t)dh, sizeof(int));
+    return S->colA && S->colB && S->rowA && S->rowB && S->rowF;
+}
+static void freeSchedule(PlaneSchedule * S)
+{
+    free(S->colA), free(S->colB), free(S->rowA), free(S->rowB), free(S->rowF);
+}
+
+/* columns of the 2x upsamplers, scale_any.c:19-85: first and last destination column are unfiltered */
+static void up2Columns(PlaneSchedule * S, int sw)
+{
+    for (int i = 0; i < S->dw; ++i) {
+        const int near = i >> 1;
+        int far = (i & 1) ? near + 1 : near - 1;
+        if (i == 0 || i == S->dw - 1 || far < 0 || far > sw - 1)
+            far = near;
+        S->colA[i] = near, S->colB[i] = far;
+    }
+}
+static void filterColumns(PlaneSchedule * S, int x, int dx, int sw)
+{
+    for (int i = 0; i < S->dw; ++i, x += dx) {
+        S->colA[i] = x >> 16;
+        S->colB[i] = x & 0xffff;
+        if (S->colA[i] > sw - 1)
+            S->colA[i] = sw - 1; /* never reached by the reference's stepping; keeps the model inside the plane */
+    }
+}
+
+/* third_party/libyuv/source/scale.c:829-1007: which specialised scaler serves (sw x sh) -> (dw x dh) under kFilterBox */
+static int buildSchedule(PlaneSchedule * S, int sw, int sh, int dw, int dh, int wide)
+{
+    if (!allocSchedule(S, dw, dh))
+        return 0;
+    S->wide = wide;
+    const int f = filterReduce(sw, sh, dw, dh, F_BOX);
+    int x, y, dx, dy;
+    const int up2w = ((dw + 1) / 2 == sw), up2h = ((dh + 1) / 2 == sh);
+    const int copy = (dw == sw && dh == sh);
+    const int vertical = (dw == sw && f != F_BOX);
+    const int box = (f == F_BOX && dh * 2 < sh);
+    /* ScalePlane / ScalePlane_16 try copy, vertical and box before the 2x upsamplers (:851-884); ScalePlane_12, the entry for
+     * 16-bit samples, tries the 2x upsamplers first (:966-977) */
+    const int early = wide || !(copy || vertical || box);
+    const int up2linear = early && up2w && f == F_LINEAR;
+    const int up2bilinear = early && !up2linear && up2h && up2w && (f == F_BILINEAR || f == F_BOX);
+    if (up2linear) { /* ScalePlaneUp2_Linear / _12_Linear / _16_Linear, :464-495: linear columns, nearest rows */
+        S->mode = M_UP2;
+        up2Columns(S, sw);
+        if (dh == 1) {
+            S->rowA[0] = S->rowB[0] = (sh - 1) / 2;
+        } else {
+            dy = fixedDiv(sh - 1, dh - 1);
+            y = (1 << 15) - 1;
+            for (int j = 0; j < dh; ++j, y += dy)
+                S->rowA[j] = S->rowB[j] = y >> 16;
+        }
+        return 1;
+    }
+    if (up2bilinear) { /* ScalePlaneUp2_Bilinear and twins, :500-528 */
+        S->mode = M_UP2;
+        up2Columns(S, sw);
+        for (int j = 0; j < dh; ++j) {
+            const int near = j >> 1;
+            int far = (j & 1) ? near + 1 : near - 1;
+            if (j == 0 || (j == dh - 1 && !(dh & 1)) || far < 0 || far > sh - 1)
+                far = near;
+            S->rowA[j] = near, S->rowB[j] = far;
+        }
+        return 1;
+    }
+    if (copy) { /* CopyPlane */
+        S->mode = M_POINT;
+        for (int i = 0; i < dw; ++i)
+            S->colA[i] = i;
+        for (int j = 0; j < dh; ++j)
+            S->rowA[j] = j;
+        return 1;
+    }
+    if (vertical) { /* ScalePlaneVertical, scale_common.c:348-386 */
+        S->mode = M_DOWN;
+        y = 0, dy = 0;
+        if (dh <= sh) {
+            dy = fixedDiv(sh, dh);
+            y = centerStart(dy, -32768);
+        } else if (sh > 1 && dh > 1) {
+            dy = fixedDiv1(sh, dh);
+        }
+        const int maxY = (sh > 1) ? ((sh - 1) << 16) - 1 : 0;
+        for (int i = 0; i < dw; ++i)
+            S->colA[i] = i, S->colB[i] = 0;
+        for (int j = 0; j < dh; ++j) {
+            if (y > maxY)
+                y = maxY;
+            S->rowA[j] = y >> 16;
+            S->rowF[j] = f ? ((y >> 8) & 255) : 0;
+            S->rowB[j] = S->rowF[j] ? S->rowA[j] + 1 : S->rowA[j];
+            y += dy;
+        }
+        return 1;
+    }
+    if (box) { /* ScalePlaneBox / _16, scale.c:153-206, 208-256 */
+        S->mode = M_BOX;
+        slope(sw, sh, dw, dh, F_BOX, &x, &y, &dx, &dy);
+        const int maxY = sh << 16;
+        for (int j = 0; j < dh; ++j) {
+            const int iy = y >> 16;
+            y += dy;
+            if (y > maxY)
+                y = maxY;
+            S->rowA[j] = iy;
+            S->rowB[j] = min1((y >> 16) - iy);
+        }
+        if (dx & 0xffff) { /* ScaleAddCols2 */
+            for (int i = 0; i < dw; ++i) {
+                const int ix = x >> 16;
+                x += dx;
+                S->colA[i] = ix;
+                S->colB[i] = min1((x >> 16) - ix);
+            }
+        } else { /* ScaleAddCols1 (dx == 1.0 cannot reach the box scaler) */
+            const int bw = min1(dx >> 16);
+            int ix = x >> 16;
+            for (int i = 0; i < dw; ++i, ix += bw)
+                S->colA[i] = ix, S->colB[i] = bw;
+        }
+        return 1;
+    }
+    if (f && dh > sh) { /* ScalePlaneBilinearUp / _16, scale.c:384-459: two row buffers of horizontally filtered rows */
+        S->mode = M_UP;
+        slope(sw, sh, dw, dh, f, &x, &y, &dx, &dy);
+        filterColumns(S, x, dx, sw);
+        const int maxY = (sh - 1) << 16;
+        if (y > maxY)
+            y = maxY;
+        int yi = y >> 16;
+        int src = yi;       /* the source row the reference's `src` pointer addresses */
+        int buf[2], cur = 0; /* which source row each row buffer holds; `cur` = rowptr */
+        buf[0] = src;
+        if (sh > 1)
+            ++src;
+        buf[1] = src;
+        if (sh > 2)
+            ++src;
+        int lasty = yi;
+        for (int j = 0; j < dh; ++j) {
+            yi = y >> 16;
+            if (yi != lasty) {
+                if (y > maxY) {
+                    y = maxY;
+                    yi = y >> 16;
+                    src = yi;
+                }
+                if (yi != lasty) {
+                    buf[cur] = src;
+                    cur ^= 1;
+                    lasty = yi;
+                    if ((y + 65536) < maxY)
+                        ++src;
+                }
+            }
+            S->rowA[j] = buf[cur];
+            S->rowB[j] = buf[cur ^ 1];
+            S->rowF[j] = (f == F_LINEAR) ? 0 : ((y >> 8) & 255);
+            y += dy;
+        }
+        return 1;
+    }
+    if (f) { /* ScalePlaneBilinearDown / _16, scale.c:259-318: vertical blend first, then the columns */
+        S->mode = M_DOWN;
+        slope(sw, sh, dw, dh, f, &x, &y, &dx, &dy);
+        filterColumns(S, x, dx, sw);
+        const int maxY = (sh - 1) << 16;
+        if (y > maxY)
+            y = maxY;
+        for (int j = 0; j < dh; ++j) {
+            S->rowA[j] = y >> 16;
+            S->rowF[j] = (f == F_LINEAR) ? 0 : ((y >> 8) & 255);
+            S->rowB[j] = S->rowF[j] ? S->rowA[j] + 1 : S->rowA[j];
+            y += dy;
+            if (y > maxY)
+                y = maxY;
+        }
+        return 1;
+    }
+    /* ScalePlaneSimple / _16, scale.c:770-826: point sampling */
+    S->mode = M_POINT;
+    slope(sw, sh, dw, dh, F_NONE, &x, &y, &dx, &dy);
+    const int doubling = (sw * 2 == dw && x < 0x8000); /* ScaleColsUp2 */
+    for (int i = 0; i < dw; ++i, x += dx)
+        S->colA[i] = doubling ? (i >> 1) : (x >> 16);
+    for (int j = 0; j < dh; ++j, y += dy)
+        S->rowA[j] = y >> 16;
+    return 1;
+}
+
+static int sampleAt(const uint8_t * plane, size_t rowBytes, int wide, int x, int y)
+{
+    const uint8_t * p = plane + (size_t)y * rowBytes;
+    if (!wide)
+        return p[x];
+    uint16_t v;
+    memcpy(&v, p + 2 * (size_t)x, 2);
+    return v;
+}
+/* BLENDER of ScaleFilterCols, scale_common.c:192-195 (7-bit, 8-bit samples) and :254-258 (16-bit samples) */
+static int blendColumns(int a, int b, int f, int wide)
+{
+    if (!wide)
+        return (uint8_t)(a + ((((f >> 9) * (b - a)) + 0x40) >> 7));
+    return (uint16_t)(a + (int)((((int64_t)f * ((int64_t)b - a)) + 0x8000) >> 16));
+}
+/* InterpolateRow_C / _16_C, row_common.c:44-104 */
+static int blendRows(int a, int b, int yf)
+{
+    if (yf == 0)
+        return a;
+    if (yf == 128)
+        return (a + b + 1) >> 1;
+    return (a * (256 - yf) + b * yf + 128) >> 8;
+}
+
+static void scalePlane(const uint8_t * src, size_t srcRowBytes, int sw, uint8_t * dst, size_t dstRowBytes, const PlaneSchedule * S)
+{
+    const int wide = S->wide;
+    for (int j = 0; j < S->dh; ++j) {
+        for (int i = 0; i < S->dw; ++i) {
+            int out;
+            const int ca = S->colA[i], cb = S->colB[i], ra = S->rowA[j], rb = S->rowB[j], rf = S->rowF[j];
+            switch (S->mode) {
+                case M_POINT:
+                    out = sampleAt(src, srcRowBytes, wide, ca, ra);
+                    break;
+                case M_DOWN: { /* rows first (rounded to the sample type), then columns */
+                    const int c1 = (ca + 1 < sw) ? ca + 1 : ca;
+                    const int v0 = blendRows(sampleAt(src, srcRowBytes, wide, ca, ra), sampleAt(src, srcRowBytes, wide, ca, rb), rf);
+                    const int v1 = blendRows(sampleAt(src, srcRowBytes, wide, c1, ra), sampleAt(src, srcRowBytes, wide, c1, rb), rf);
+                    out = blendColumns(v0, v1, cb, wide);
+                    break;
+                }
+                case M_UP: { /* columns first (rounded), then rows */
+                    const int c1 = (ca + 1 < sw) ? ca + 1 : ca;
+                    const int h0 = blendColumns(sampleAt(src, srcRowBytes, wide, ca, ra), sampleAt(src, srcRowBytes, wide, c1, ra), cb, wide);
+                    const int h1 = blendColumns(sampleAt(src, srcRowBytes, wide, ca, rb), sampleAt(src, srcRowBytes, wide, c1, rb), cb, wide);
+                    out = blendRows(h0, h1, rf);
+                    break;
+                }
+                case M_BOX: {
+                    /* ScaleAddRow accumulates rows into uint16_t (8-bit samples: wraps) or uint32_t; SumPixels adds columns */
+                    uint32_t sum = 0;
+                    for (int c = 0; c < cb; ++c) {
+                        uint32_t colSum = 0;
+                        for (int r = 0; r < rb; ++r)
+                            colSum += (uint32_t)sampleAt(src, srcRowBytes, wide, ca + c, ra + r);
+                        sum += wide ? colSum : (colSum & 0xffffu);
+                    }
+                    const uint32_t scale = (uint32_t)(65536 / (min1(cb) * rb));
+                    out = wide ? (uint16_t)((sum * scale) >> 16) : (uint8_t)((sum * scale) >> 16);
+                    break;
+                }
+                default: { /* M_UP2: 9:3:3:1 with duplicated neighbours at the edges, scale_common.c:51-72, scale_any.c:45-85 */
+                    const int nn = sampleAt(src, srcRowBytes, wide, ca, ra), nf = sampleAt(src, srcRowBytes, wide, cb, ra);
+                    const int fn = sampleAt(src, srcRowBytes, wide, ca, rb), ff = sampleAt(src, srcRowBytes, wide, cb, rb);
+                    out = (9 * nn + 3 * nf + 3 * fn + ff + 8) >> 4;
+                    break;
+                }
+            }
+            if (wide) {
+                const uint16_t v = (uint16_t)out;
+                memcpy(dst + (size_t)j * dstRowBytes + 2 * (size_t)i, &v, 2);
+            } else {
+                dst[(size_t)j * dstRowBytes + i] = (uint8_t)out;
+            }
+        }
+    }
+}
+
+/* avifImageScale, src/scale.c:23-201: every plane that exists is replaced by its scaled version (malloc'ed, tight rows) */
+avifResult oracleImageScale(avifImage * image, uint32_t dstWidth, uint32_t dstHeight)
+{
+    if (image->width == dstWidth && image->height == dstHeight)
+        return AVIF_RESULT_OK;
+    if (!dstWidth || !dstHeight)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if ((image->yuvPlanes[0] || image->alphaPlane) && (image->width > 16384 || image->height > 16384))
+        return AVIF_RESULT_NOT_IMPLEMENTED; /* :69-80 */
+    const int wide = image->depth > 8;
+    const size_t bps = wide ? 2 : 1;
+    const int sx = (image->yuvFormat == AVIF_PIXEL_FORMAT_YUV444 || image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400) ? 0 : 1;
+    const int sy = (image->yuvFormat == AVIF_PIXEL_FORMAT_YUV420) ? 1 : 0;
+    const uint32_t srcW = image->width, srcH = image->height;
+    for (int p = 0; p < 4; ++p) {
+        uint8_t ** plane = (p < 3) ? &image->yuvPlanes[p] : &image->alphaPlane;
+        uint32_t * rowBytes = (p < 3) ? &image->yuvRowBytes[p] : &image->alphaRowBytes;
+        if (!*plane)
+            continue;
+        const int chroma = (p == 1 || p == 2);
+        if (chroma && image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400)
+            continue;
+        const int sw = chroma ? (int)((srcW + sx) >> sx) : (int)srcW, sh = chroma ? (int)((srcH + sy) >> sy) : (int)srcH;
+        const int dw = chroma ? (int)((dstWidth + sx) >> sx) : (int)dstWidth, dh = chroma ? (int)((dstHeight + sy) >> sy) : (int)dstHeight;
+        PlaneSchedule S;
+        uint8_t * out = (uint8_t *)malloc((size_t)dw * dh * bps);
+        if (!out || !buildSchedule(&S, sw, sh, dw, dh, wide)) {
+            free(out);
+            return AVIF_RESULT_OUT_OF_MEMORY;
+        }
+        scalePlane(*plane, *rowBytes, sw, out, (size_t)dw * bps, &S);
+        freeSchedule(&S);
+        const int owned = (p < 3) ? image->imageOwnsYUVPlanes : image->imageOwnsAlphaPlane;
+        if (owned)
+            free(*plane);
+        *plane = out;
+        *rowBytes = (uint32_t)((size_t)dw * bps);
+    }
+    image->width = dstWidth, image->height = dstHeight;
+    if (image->yuvPlanes[0])
+        image->imageOwnsYUVPlanes = AVIF_TRUE;
+    if (image->alphaPlane)
+        image->imageOwnsAlphaPlane = AVIF_TRUE;
+    return AVIF_RESULT_OK;
+}

@@ -25,7 +25,7 @@ _cache: dict = {}
 
 def _ensure_built() -> None:
     so = ORACLE_DIR / "liboracle.so"
-    srcs = [ORACLE_DIR / "reformat_oracle.c", ORACLE_DIR / "libyuv_oracle.c", ORACLE_DIR / "reformat_oracle.h", ORACLE_DIR / "oracle_backend.h"]
+    srcs = [ORACLE_DIR / "reformat_oracle.c", ORACLE_DIR / "libyuv_oracle.c", ORACLE_DIR / "scale_oracle.c", ORACLE_DIR / "reformat_oracle.h", ORACLE_DIR / "oracle_backend.h"]
     if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", os.fspath(ORACLE_DIR), "liboracle.so"], check=True, capture_output=True)
 
@@ -43,6 +43,7 @@ def oracle() -> C.CDLL:
             getattr(lib, name).restype, getattr(lib, name).argtypes = C.c_int, [_P_RGB]
         lib.oracleLibyuvHookYUVToRGB.restype, lib.oracleLibyuvHookYUVToRGB.argtypes = C.c_int, [_P_IMG, _P_RGB, C.c_int, C.POINTER(C.c_int)]
         lib.oracleLibyuvHookRGBToYUV.restype, lib.oracleLibyuvHookRGBToYUV.argtypes = C.c_int, [_P_IMG, _P_RGB]
+        lib.oracleImageScale.restype, lib.oracleImageScale.argtypes = C.c_int, [_P_IMG, C.c_uint32, C.c_uint32]
         lib.oracleRGBImageTransform.restype = C.c_int
         lib.oracleRGBImageTransform.argtypes = [_P_RGB, _P_RGB, _P_RECT, C.c_int, C.c_uint8, C.c_int, C.c_uint8]
         lib.oracleGridYUVToRGB.restype = C.c_int
@@ -65,6 +66,8 @@ def _bind_libavif(lib: C.CDLL) -> C.CDLL:
     # internal.h functions: exported by the from-source build (default visibility), not by a packaged shared libavif
     if hasattr(lib, "avifImageSetViewRect"):
         lib.avifImageSetViewRect.restype, lib.avifImageSetViewRect.argtypes = C.c_int, [_P_IMG, _P_IMG, _P_RECT]
+    if hasattr(lib, "avifImageScale"):
+        lib.avifImageScale.restype, lib.avifImageScale.argtypes = C.c_int, [_P_IMG, C.c_uint32, C.c_uint32, C.c_void_p]
     if hasattr(lib, "avifImageCopySamples"):
         lib.avifImageCopySamples.restype, lib.avifImageCopySamples.argtypes = None, [_P_IMG, _P_IMG, C.c_uint32]
     return lib

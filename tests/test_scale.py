@@ -1,0 +1,130 @@
+"""Plane scaling (avifImageScale, src/scale.c:23-201 over the vendored libyuv scaler).
+
+CPU: the oracle's per-sample restatement (oracle/scale_oracle.c) against avifImageScale of the reference compiled from its
+own sources -- every plane of every case byte-identical.  GPU (-m gpu): avifhipImageScale (host image, in place, like the
+reference) and avifhipImageScaleAsync (device-resident) against the oracle."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import harness as H
+import oracle_lib
+from libavif_amd import abi
+
+SIZES = [(64, 48), (33, 17), (1, 1), (5, 9), (100, 3), (2, 2), (17, 64), (128, 128), (7, 1), (1, 7), (255, 31)]
+RATIOS = [0.1, 0.25, 0.3, 1 / 3, 0.5, 0.6, 1, 1.5, 2, 3, 4.7]
+libc = C.CDLL(None)
+libc.free.argtypes = [C.c_void_p]
+
+
+def scale_cases(n, seed):
+    rnd = random.Random(seed)
+    out = [(H.Y2RCase(600, 700, yuv_depth=8, yuv_format=1, alpha=True, yuv_range=1), 9, 2),     # 350-row boxes: the 8-bit row sums wrap
+           (H.Y2RCase(600, 700, yuv_depth=10, yuv_format=3, yuv_range=1), 9, 2),
+           (H.Y2RCase(320, 200, yuv_depth=8, yuv_format=3, yuv_range=1), 640, 400),               # exact 2x (ScalePlaneUp2_Bilinear)
+           (H.Y2RCase(320, 200, yuv_depth=12, yuv_format=2, yuv_range=1, alpha=True), 639, 399),
+           (H.Y2RCase(1920, 1080, yuv_depth=8, yuv_format=3, yuv_range=1), 480, 270),            # a thumbnail
+           (H.Y2RCase(480, 270, yuv_depth=10, yuv_format=3, yuv_range=1), 1920, 1080)]
+    for _ in range(n):
+        sw, sh = rnd.choice(SIZES)
+        if rnd.random() < 0.5:
+            dw, dh = max(1, int(sw * rnd.choice(RATIOS))), max(1, int(sh * rnd.choice(RATIOS)))
+        else:
+            dw, dh = rnd.randint(1, 160), rnd.randint(1, 140)
+        if rnd.random() < 0.2:
+            dw, dh = max(1, 2 * sw - rnd.choice([0, 1])), max(1, 2 * sh - rnd.choice([0, 1]))
+        c = H.Y2RCase(sw, sh, yuv_depth=rnd.choice([8, 10, 12]), yuv_format=rnd.choice([1, 2, 3, 4]), alpha=rnd.random() < 0.4,
+                      seed=rnd.getrandbits(30) | 1, yuv_range=1)
+        out.append((c, dw, dh))
+    return out
+
+
+def planes_of(st):
+    """The (cropped) planes of an avifImage struct whose buffers may have been replaced by the callee."""
+    bps = 2 if st.depth > 8 else 1
+    cw, ch = abi.chroma_dims(st.width, st.height, st.yuvFormat)
+    out = []
+    for p in range(4):
+        ptr, rb = (st.yuvPlanes[p], st.yuvRowBytes[p]) if p < 3 else (st.alphaPlane, st.alphaRowBytes)
+        if not ptr:
+            out.append(None)
+            continue
+        w, h = (st.width, st.height) if p in (0, 3) else (cw, ch)
+        out.append(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h, rb))[:, : w * bps].copy())
+    return out
+
+
+def free_owned(st):
+    """avifImageScale leaves malloc'ed planes behind (src/avif.c:431-490)."""
+    if st.imageOwnsYUVPlanes:
+        for p in range(3):
+            if st.yuvPlanes[p]:
+                libc.free(C.cast(st.yuvPlanes[p], C.c_void_p))
+    if st.imageOwnsAlphaPlane and st.alphaPlane:
+        libc.free(C.cast(st.alphaPlane, C.c_void_p))
+
+
+def compare(a_planes, b_planes, what):
+    for p, (x, y) in enumerate(zip(a_planes, b_planes)):
+        assert (x is None) == (y is None), (what, p)
+        if x is not None:
+            assert x.shape == y.shape and np.array_equal(x, y), (what, p, int((x != y).sum()) if x.shape == y.shape else "shape")
+
+
+@pytest.mark.skipif(oracle_lib.ref() is None, reason="oracle/_ref/libavif_ref.so not built (needs /root/reference)")
+def test_oracle_equals_reference_avifImageScale():
+    ref, o = oracle_lib.ref(), oracle_lib.oracle()
+    diag = C.create_string_buffer(512)
+    for c, dw, dh in scale_cases(900, seed=1):
+        a, b = H.make_y2r_inputs(c), H.make_y2r_inputs(c)
+        ra, rb = ref.avifImageScale(a.struct, dw, dh, diag), o.oracleImageScale(b.struct, dw, dh)
+        assert ra == rb, (c.ident(), dw, dh)
+        if ra == 0:
+            assert (a.struct.width, a.struct.height) == (b.struct.width, b.struct.height) == (dw, dh)
+            compare(planes_of(a.struct), planes_of(b.struct), (c.ident(), dw, dh))
+        if (c.w, c.h) != (dw, dh):
+            free_owned(a.struct)
+            free_owned(b.struct)
+    img = H.make_y2r_inputs(H.Y2RCase(8, 8))
+    assert o.oracleImageScale(img.struct, 0, 4) == ref.avifImageScale(img.struct, 0, 4, diag) == abi.AVIF_RESULT_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_gpu_scale_in_place_equals_the_oracle(hip):
+    from libavif_amd import native
+
+    o = oracle_lib.oracle()
+    kernels = set()
+    for c, dw, dh in scale_cases(350, seed=2):
+        a, b = H.make_y2r_inputs(c), H.make_y2r_inputs(c)
+        ra, rb = o.oracleImageScale(a.struct, dw, dh), hip.avifhipImageScale(b.struct, dw, dh)
+        assert ra == rb == 0, (c.ident(), dw, dh, hip.avifhipLastError())
+        kernels.add(native.last_kernel())
+        assert (b.struct.width, b.struct.height) == (dw, dh)
+        compare(planes_of(a.struct), planes_of(b.struct), (c.ident(), dw, dh, native.last_kernel()))
+        if (c.w, c.h) != (dw, dh):
+            free_owned(a.struct)
+            free_owned(b.struct)
+    assert {"scale_down", "scale_up", "scale_box", "scale_up2", "scale_point"} <= kernels, kernels
+    img = H.make_y2r_inputs(H.Y2RCase(8, 8))
+    assert hip.avifhipImageScale(img.struct, 0, 4) == abi.AVIF_RESULT_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_gpu_scale_device_resident_equals_the_oracle(hip):
+    from libavif_amd import device, native
+
+    o = oracle_lib.oracle()
+    for c, dw, dh in scale_cases(60, seed=3)[:40]:
+        a, src = H.make_y2r_inputs(c), H.make_y2r_inputs(c)
+        assert o.oracleImageScale(a.struct, dw, dh) == 0
+        dst = H.make_y2r_inputs(H.Y2RCase(dw, dh, yuv_depth=c.yuv_depth, yuv_format=c.yuv_format, alpha=c.alpha, yuv_range=1))
+        dsrc, ddst = device.DeviceYUV(src), device.DeviceYUV(dst)
+        native.check(hip.avifhipImageScaleAsync(dsrc.struct, ddst.struct, None), "avifhipImageScaleAsync")
+        native.check(hip.avifhipSynchronize(None), "sync")
+        ddst.download_into_host()
+        compare(planes_of(a.struct), planes_of(dst.struct), (c.ident(), dw, dh))
+        if (c.w, c.h) != (dw, dh):
+            free_owned(a.struct)

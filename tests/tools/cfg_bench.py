@@ -65,6 +65,30 @@ def run(name):
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
             px, bpp, ms = 64 * 1920 * 1080, (11.0 if rgb_depth == 10 else 7.0), best
+        elif name in ("scale_box4", "scale_up2", "scale_down_1_5"):
+            # avifImageScale on 8-bit 4:2:0 planes: 8K -> 1080p (box), 4K -> 8K (2x upsampler), 8K -> 5120x2880 (bilinear down)
+            if arith == "integer":
+                continue  # one arithmetic: the vendored libyuv scaler's integers
+            (sw, sh), (dw, dh) = {"scale_box4": ((7680, 4320), (1920, 1080)), "scale_up2": ((3840, 2160), (7680, 4320)),
+                                  "scale_down_1_5": ((7680, 4320), (5120, 2880))}[name]
+            src = abi.make_yuv(sw, sh, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+            synth.fill_yuv(src, 0x77)
+            dst = abi.make_yuv(dw, dh, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+            dsrc, ddst = device.DeviceYUV(src), device.DeviceYUV(dst)
+            call = lambda: native.check(lib.avifhipImageScaleAsync(dsrc.struct, ddst.struct, None))
+            for _ in range(3):
+                call()
+            native.check(lib.avifhipSynchronize(None))
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    call()
+                native.check(lib.avifhipSynchronize(None))
+                best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+            # algorithmic bytes: every source sample read once + every destination sample written once, per luma pixel of the LARGER image
+            px = max(sw * sh, dw * dh)
+            bpp, ms = 1.5 * (sw * sh + dw * dh) / px, best
         elif name in ("xform90", "xform180"):
             # avifApplyTransforms on the converted 8K RGBA8 image: clap crop + irot + imir in one pass (8 B/pixel)
             if arith == "integer":
