@@ -139,6 +139,22 @@ AVIFHIP_API avifResult avifhipRGBImageTransformAsync(avifRGBImage * dst,
 AVIFHIP_API avifResult avifhipImageScale(avifImage * image, uint32_t dstWidth, uint32_t dstHeight);
 AVIFHIP_API avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * dst, void * hipStream);
 
+/* Sample Transform derived image items.  Replaces avifImageApplyOperations, include/avif/internal.h:
+ * 247-254, src/sampletransform.c:284-421: the postfix expression `tokens` is evaluated for every sample of the selected
+ * planes in saturating 32-bit arithmetic (sum, difference, product, quotient, and / or / xor, pow, min, max, negation,
+ * absolute value, not, bit-scan-reverse; src/sampletransform.c:199-277), the result clamped to the destination depth and
+ * stored; dstImage may be one of the inputs.  All images device-resident, same plane sizes (AVIF_RESULT_BMFF_PARSE_FAILED
+ * otherwise, like the reference); only AVIF_SAMPLE_TRANSFORM_BIT_DEPTH_32 is implemented (NOT_IMPLEMENTED otherwise, like the
+ * reference); an invalid expression answers AVIF_RESULT_INTERNAL_ERROR like the reference's release build; at most 64 tokens. */
+AVIFHIP_API avifResult avifhipImageApplyOperationsAsync(avifImage * dstImage,
+                                                        avifSampleTransformBitDepth bitDepth,
+                                                        uint32_t numTokens,
+                                                        const avifSampleTransformToken * tokens,
+                                                        uint8_t numInputImageItems,
+                                                        const avifImage * const * inputImageItems,
+                                                        avifPlanesFlags planes,
+                                                        void * hipStream);
+
 /* ---- integer helpers (src/reformat.c:1778-1840; used on decoded alpha planes, src/read.c:6724) */
 AVIFHIP_API int avifhipLimitedToFullY(uint32_t depth, int v);
 AVIFHIP_API int avifhipLimitedToFullUV(uint32_t depth, int v);

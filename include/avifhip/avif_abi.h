@@ -63,6 +63,7 @@ typedef enum avifResult
     AVIF_RESULT_OK = 0,
     AVIF_RESULT_UNKNOWN_ERROR = 1,
     AVIF_RESULT_REFORMAT_FAILED = 5,
+    AVIF_RESULT_BMFF_PARSE_FAILED = 9,
     AVIF_RESULT_INVALID_IMAGE_GRID = 18,
     AVIF_RESULT_INVALID_ARGUMENT = 24,
     AVIF_RESULT_NOT_IMPLEMENTED = 25,
@@ -228,5 +229,53 @@ AVIFHIP_STATIC_ASSERT(offsetof(avifImage, yuvRowBytes) == 48, "avifImage.yuvRowB
 AVIFHIP_STATIC_ASSERT(offsetof(avifImage, alphaPlane) == 64, "avifImage.alphaPlane");
 AVIFHIP_STATIC_ASSERT(offsetof(avifImage, alphaPremultiplied) == 80, "avifImage.alphaPremultiplied");
 AVIFHIP_STATIC_ASSERT(offsetof(avifImage, matrixCoefficients) == 108, "avifImage.matrixCoefficients");
+
+
+/* Sample Transform tokens ('sato' derived image items): libavif declares these in its INTERNAL header
+ * (include/avif/internal.h:179-228); mirrored here, layout-identical (sizeof(avifSampleTransformToken) == 12), unless that
+ * header is in use. */
+#ifndef AVIF_INTERNAL_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef enum avifSampleTransformBitDepth
+{
+    AVIF_SAMPLE_TRANSFORM_BIT_DEPTH_8 = 0,
+    AVIF_SAMPLE_TRANSFORM_BIT_DEPTH_16 = 1,
+    AVIF_SAMPLE_TRANSFORM_BIT_DEPTH_32 = 2,
+    AVIF_SAMPLE_TRANSFORM_BIT_DEPTH_64 = 3
+} avifSampleTransformBitDepth;
+typedef enum avifSampleTransformTokenType
+{
+    AVIF_SAMPLE_TRANSFORM_CONSTANT = 0,
+    AVIF_SAMPLE_TRANSFORM_INPUT_IMAGE_ITEM_INDEX = 1,
+    AVIF_SAMPLE_TRANSFORM_FIRST_UNARY_OPERATOR = 64,
+    AVIF_SAMPLE_TRANSFORM_NEGATION = 64,
+    AVIF_SAMPLE_TRANSFORM_ABSOLUTE = 65,
+    AVIF_SAMPLE_TRANSFORM_NOT = 66,
+    AVIF_SAMPLE_TRANSFORM_BSR = 67,
+    AVIF_SAMPLE_TRANSFORM_FIRST_BINARY_OPERATOR = 128,
+    AVIF_SAMPLE_TRANSFORM_SUM = 128,
+    AVIF_SAMPLE_TRANSFORM_DIFFERENCE = 129,
+    AVIF_SAMPLE_TRANSFORM_PRODUCT = 130,
+    AVIF_SAMPLE_TRANSFORM_QUOTIENT = 131,
+    AVIF_SAMPLE_TRANSFORM_AND = 132,
+    AVIF_SAMPLE_TRANSFORM_OR = 133,
+    AVIF_SAMPLE_TRANSFORM_XOR = 134,
+    AVIF_SAMPLE_TRANSFORM_POW = 135,
+    AVIF_SAMPLE_TRANSFORM_MIN = 136,
+    AVIF_SAMPLE_TRANSFORM_MAX = 137,
+    AVIF_SAMPLE_TRANSFORM_RESERVED = 138
+} avifSampleTransformTokenType;
+typedef struct avifSampleTransformToken
+{
+    avifSampleTransformTokenType type;
+    int32_t constant;            /* AVIF_SAMPLE_TRANSFORM_CONSTANT */
+    uint8_t inputImageItemIndex; /* AVIF_SAMPLE_TRANSFORM_INPUT_IMAGE_ITEM_INDEX, 1-based */
+} avifSampleTransformToken;
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVIF_INTERNAL_H */
 
 #endif /* AVIFHIP_AVIF_ABI_H */

@@ -41,6 +41,7 @@ struct Context
     Scratch table;     // batch descriptor table (device)
     Scratch gridTable; // tile table of a grid conversion (device)
     Scratch scaleTable; // schedules of a plane scale (device)
+    Scratch satoTable;  // input plane tables of a sample transform (device)
     void * pinnedTable = nullptr;
     size_t pinnedTableCapacity = 0;
     hipEvent_t tableCopied = nullptr;
@@ -65,6 +66,8 @@ struct Context
             (void)hipFree(gridTable.ptr);
         if (scaleTable.ptr)
             (void)hipFree(scaleTable.ptr);
+        if (satoTable.ptr)
+            (void)hipFree(satoTable.ptr);
         if (pinnedTable)
             (void)hipHostFree(pinnedTable);
         if (tableCopied)
@@ -870,10 +873,7 @@ extern "C" avifResult avifhipRGBImageUnpremultiplyAlphaAsync(avifRGBImage * rgb,
     return alphaMulAsync(rgb, true, hipStream);
 }
 
-// =================================================================================================
-// plane scaling, reference src/scale.c:23-201
-// =================================================================================================
-
+// plane sizes of an image (avifImagePlaneWidth / Height, reference src/avif.c:351-400)
 namespace {
 
 struct PlaneDims
@@ -891,6 +891,117 @@ PlaneDims planeDims(uint32_t width, uint32_t height, int yuvFormat)
 }
 
 } // namespace
+
+// =================================================================================================
+// Sample Transform derived image items, reference src/sampletransform.c
+// =================================================================================================
+
+extern "C" avifResult avifhipImageApplyOperationsAsync(avifImage * dstImage, avifSampleTransformBitDepth bitDepth, uint32_t numTokens,
+                                                       const avifSampleTransformToken * tokens, uint8_t numInputImageItems,
+                                                       const avifImage * const * inputImageItems, avifPlanesFlags planes, void * hipStream)
+{
+    if (!dstImage || !tokens || !inputImageItems)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    // avifSampleTransformExpressionIsValid, src/sampletransform.c:13-40 (AVIF_ASSERT_OR_RETURN: INTERNAL_ERROR in release builds)
+    if (numTokens == 0 || numTokens > (uint32_t)kSatoMaxTokens || numInputImageItems > kSatoMaxInputs)
+        return (numTokens == 0) ? AVIF_RESULT_INTERNAL_ERROR : AVIF_RESULT_NOT_IMPLEMENTED;
+    uint32_t depthOfStack = 0;
+    for (uint32_t t = 0; t < numTokens; ++t) {
+        const int type = (int)tokens[t].type;
+        if (type >= AVIF_SAMPLE_TRANSFORM_RESERVED)
+            return AVIF_RESULT_INTERNAL_ERROR;
+        if (type == AVIF_SAMPLE_TRANSFORM_INPUT_IMAGE_ITEM_INDEX && (tokens[t].inputImageItemIndex == 0 || tokens[t].inputImageItemIndex > numInputImageItems))
+            return AVIF_RESULT_INTERNAL_ERROR;
+        if (type < AVIF_SAMPLE_TRANSFORM_FIRST_UNARY_OPERATOR) {
+            ++depthOfStack;
+        } else if (type < AVIF_SAMPLE_TRANSFORM_FIRST_BINARY_OPERATOR) {
+            if (depthOfStack < 1)
+                return AVIF_RESULT_INTERNAL_ERROR;
+        } else {
+            if (depthOfStack < 2)
+                return AVIF_RESULT_INTERNAL_ERROR;
+            --depthOfStack;
+        }
+    }
+    if (depthOfStack != 1)
+        return AVIF_RESULT_INTERNAL_ERROR;
+    const bool skipColor = !(planes & AVIF_PLANES_YUV), skipAlpha = !(planes & AVIF_PLANES_A);
+    const PlaneDims dd = planeDims(dstImage->width, dstImage->height, (int)dstImage->yuvFormat);
+    auto planeW = [&](const avifImage * im, int c) { // avifImagePlaneWidth / Height, src/avif.c:351-400: 0 when the plane is absent
+        const PlaneDims d = planeDims(im->width, im->height, (int)im->yuvFormat);
+        const bool present = (c < 3) ? (im->yuvPlanes[c] && !((c == 1 || c == 2) && im->yuvFormat == AVIF_PIXEL_FORMAT_YUV400)) : im->alphaPlane != nullptr;
+        return present ? d.w[c] : 0;
+    };
+    auto planeH = [&](const avifImage * im, int c) {
+        const PlaneDims d = planeDims(im->width, im->height, (int)im->yuvFormat);
+        const bool present = (c < 3) ? (im->yuvPlanes[c] && !((c == 1 || c == 2) && im->yuvFormat == AVIF_PIXEL_FORMAT_YUV400)) : im->alphaPlane != nullptr;
+        return present ? d.h[c] : 0;
+    };
+    for (int c = 0; c < 4; ++c) { // :371-384
+        if ((skipColor && c < 3) || (skipAlpha && c == 3))
+            continue;
+        for (uint32_t i = 0; i < numInputImageItems; ++i) {
+            if (!inputImageItems[i])
+                return AVIF_RESULT_INVALID_ARGUMENT;
+            if (planeW(inputImageItems[i], c) != planeW(dstImage, c) || planeH(inputImageItems[i], c) != planeH(dstImage, c))
+                return AVIF_RESULT_BMFF_PARSE_FAILED;
+        }
+    }
+    if (bitDepth != AVIF_SAMPLE_TRANSFORM_BIT_DEPTH_32)
+        return AVIF_RESULT_NOT_IMPLEMENTED; // :386-395
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    hipStream_t stream = pickStream(hipStream);
+    // input plane tables of the (up to four) planes, one upload
+    SatoInputs tables[4];
+    memset(tables, 0, sizeof(tables));
+    bool run[4] = { false, false, false, false };
+    for (int c = 0; c < 4; ++c) {
+        if ((skipColor && c < 3) || (skipAlpha && c == 3) || planeW(dstImage, c) == 0 || planeH(dstImage, c) == 0)
+            continue;
+        run[c] = true;
+        for (uint32_t i = 0; i < numInputImageItems; ++i) {
+            const avifImage * im = inputImageItems[i];
+            tables[c].plane[i] = (c < 3) ? im->yuvPlanes[c] : im->alphaPlane;
+            tables[c].pitch[i] = (c < 3) ? im->yuvRowBytes[c] : im->alphaRowBytes;
+            tables[c].wide[i] = im->depth > 8;
+        }
+    }
+    avifResult r = reserve(tls.satoTable, sizeof(tables));
+    if (r != AVIF_RESULT_OK)
+        return r;
+    r = uploadTableAsync(tls.satoTable.ptr, tables, sizeof(tables), stream);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    SatoArgs A;
+    memset(&A, 0, sizeof(A));
+    A.numTokens = (int32_t)numTokens;
+    for (uint32_t t = 0; t < numTokens; ++t) {
+        A.tokens[t].type = (int32_t)tokens[t].type;
+        A.tokens[t].value = (tokens[t].type == AVIF_SAMPLE_TRANSFORM_INPUT_IMAGE_ITEM_INDEX) ? (int32_t)tokens[t].inputImageItemIndex - 1 : tokens[t].constant;
+    }
+    A.maxValue = (1 << dstImage->depth) - 1;
+    A.dstWide = dstImage->depth > 8;
+    for (int c = 0; c < 4; ++c) {
+        if (!run[c])
+            continue;
+        A.dst = (c < 3) ? dstImage->yuvPlanes[c] : dstImage->alphaPlane;
+        A.dstPitch = (c < 3) ? dstImage->yuvRowBytes[c] : dstImage->alphaRowBytes;
+        A.width = dd.w[c], A.height = dd.h[c];
+        const hipError_t e = launchSato(A, (const SatoInputs *)tls.satoTable.ptr + c, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "sample transform kernel launch");
+    }
+    tls.lastKernel = "sample_transform";
+    ++tls.launches;
+    return AVIF_RESULT_OK;
+}
+
+// =================================================================================================
+// plane scaling, reference src/scale.c:23-201
+// =================================================================================================
+
 
 extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * dst, void * hipStream)
 {

@@ -80,4 +80,28 @@ struct ScaleArgs
 };
 hipError_t launchScalePlane(const ScaleArgs & args, bool wide, hipStream_t stream);
 
+// Sample Transform expression evaluation (kernels_sato.hip), one lane per sample of one plane
+constexpr int kSatoMaxTokens = 64, kSatoMaxInputs = 32;
+struct SatoArgs
+{
+    uint8_t * dst;
+    uint32_t dstPitch;
+    int32_t dstWide;
+    int32_t width, height;
+    int32_t maxValue;
+    int32_t numTokens;
+    struct Token
+    {
+        int32_t type;  // avifSampleTransformTokenType
+        int32_t value; // constant, or 0-based input index
+    } tokens[kSatoMaxTokens];
+};
+struct SatoInputs // device table: the plane of every input image item
+{
+    const uint8_t * plane[kSatoMaxInputs];
+    uint32_t pitch[kSatoMaxInputs];
+    int32_t wide[kSatoMaxInputs];
+};
+hipError_t launchSato(const SatoArgs & args, const SatoInputs * deviceInputs, hipStream_t stream);
+
 } // namespace avifhip

@@ -25,8 +25,13 @@ EXPORTED_SYMBOLS = [
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
     "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
-    "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync",
+    "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
 ]
+
+class avifSampleTransformToken(C.Structure):
+    """include/avif/internal.h:222-228"""
+    _fields_ = [("type", C.c_int), ("constant", C.c_int32), ("inputImageItemIndex", C.c_uint8)]
+
 
 class avifhipGrid(C.Structure):
     _fields_ = [("rows", C.c_uint32), ("columns", C.c_uint32), ("outputWidth", C.c_uint32), ("outputHeight", C.c_uint32)]
@@ -92,6 +97,7 @@ def load() -> C.CDLL:
         "avifhipExplainYUVToRGB": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
         "avifhipExplainRGBToYUV": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
         "avifhipRGBImageTransformAsync": (i32, [P_RGB, P_RGB, P_RECT, i32, C.c_uint8, i32, C.c_uint8, vp]),
+        "avifhipImageApplyOperationsAsync": (i32, [P_IMG, i32, u32, C.POINTER(avifSampleTransformToken), C.c_uint8, C.POINTER(P_IMG), u32, vp]),
         "avifhipImageScale": (i32, [P_IMG, u32, u32]),
         "avifhipImageScaleAsync": (i32, [P_IMG, P_IMG, vp]),
         "avifhipGridYUVToRGBAsync": (i32, [C.POINTER(avifhipGrid), C.POINTER(P_IMG), C.POINTER(P_IMG), i32, P_RGB, vp]),

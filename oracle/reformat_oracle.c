@@ -1047,6 +1047,163 @@ avifResult oracleGridYUVToRGB(const oracleGrid * grid, const avifImage * const *
 }
 
 /* ------------------------------------------------------------------------- */
+/* Sample Transform expressions                       (src/sampletransform.c)                                        */
+
+static int32_t sat32(int64_t v) /* avifSampleTransformClamp32b, :194-197 */
+{
+    return v <= INT32_MIN ? INT32_MIN : (v >= INT32_MAX ? INT32_MAX : (int32_t)v);
+}
+static int32_t satoUnary(int32_t a, int op) /* :199-224 */
+{
+    if (op == AVIF_SAMPLE_TRANSFORM_NEGATION)
+        return sat32(-(int64_t)a);
+    if (op == AVIF_SAMPLE_TRANSFORM_ABSOLUTE)
+        return a >= 0 ? a : sat32(-(int64_t)a);
+    if (op == AVIF_SAMPLE_TRANSFORM_NOT)
+        return ~a;
+    int32_t log2v = 0; /* BSR */
+    if (a <= 0)
+        return 0;
+    for (a >>= 1; a != 0; a >>= 1)
+        ++log2v;
+    return log2v;
+}
+static int32_t satoBinary(int32_t l, int32_t r, int op) /* :226-277 */
+{
+    switch (op) {
+        case AVIF_SAMPLE_TRANSFORM_SUM:
+            return sat32((int64_t)l + r);
+        case AVIF_SAMPLE_TRANSFORM_DIFFERENCE:
+            return sat32((int64_t)l - r);
+        case AVIF_SAMPLE_TRANSFORM_PRODUCT:
+            return sat32((int64_t)l * r);
+        case AVIF_SAMPLE_TRANSFORM_QUOTIENT:
+            return r == 0 ? l : sat32((int64_t)l / r);
+        case AVIF_SAMPLE_TRANSFORM_AND:
+            return l & r;
+        case AVIF_SAMPLE_TRANSFORM_OR:
+            return l | r;
+        case AVIF_SAMPLE_TRANSFORM_XOR:
+            return l ^ r;
+        case AVIF_SAMPLE_TRANSFORM_POW: {
+            if (l == 0 || l == 1)
+                return l;
+            if (l == -1)
+                return (r % 2 == 0) ? 1 : -1;
+            if (r == 0)
+                return 1;
+            if (r == 1)
+                return l;
+            if (r < 0)
+                return 0;
+            int64_t acc = l;
+            for (int32_t i = 1; i < r; ++i) {
+                acc *= l;
+                if (acc < INT32_MIN || acc > INT32_MAX)
+                    return (l > 0 || r % 2 == 0) ? INT32_MAX : INT32_MIN;
+            }
+            return (int32_t)acc;
+        }
+        case AVIF_SAMPLE_TRANSFORM_MIN:
+            return l <= r ? l : r;
+        default:
+            return l <= r ? r : l;
+    }
+}
+
+static void planeGeometry(const avifImage * im, int c, uint32_t * w, uint32_t * h) /* avifImagePlaneWidth / Height, src/avif.c:351-400 */
+{
+    const int sx = (im->yuvFormat == AVIF_PIXEL_FORMAT_YUV444 || im->yuvFormat == AVIF_PIXEL_FORMAT_YUV400) ? 0 : 1;
+    const int sy = (im->yuvFormat == AVIF_PIXEL_FORMAT_YUV420) ? 1 : 0;
+    const int present = (c < 3) ? (im->yuvPlanes[c] != NULL && !((c == 1 || c == 2) && im->yuvFormat == AVIF_PIXEL_FORMAT_YUV400)) : (im->alphaPlane != NULL);
+    *w = *h = 0;
+    if (!present)
+        return;
+    *w = (c == 1 || c == 2) ? (im->width + sx) >> sx : im->width;
+    *h = (c == 1 || c == 2) ? (im->height + sy) >> sy : im->height;
+}
+
+avifResult oracleImageApplyOperations(avifImage * dstImage, avifSampleTransformBitDepth bitDepth, uint32_t numTokens,
+                                      const avifSampleTransformToken * tokens, uint8_t numInputImageItems, const avifImage * const * inputImageItems,
+                                      avifPlanesFlags planes)
+{
+    /* avifSampleTransformExpressionIsValid, :13-40 */
+    uint32_t depth = 0;
+    for (uint32_t t = 0; t < numTokens; ++t) {
+        const int type = (int)tokens[t].type;
+        if (type >= AVIF_SAMPLE_TRANSFORM_RESERVED)
+            return AVIF_RESULT_INTERNAL_ERROR;
+        if (type == AVIF_SAMPLE_TRANSFORM_INPUT_IMAGE_ITEM_INDEX && (tokens[t].inputImageItemIndex == 0 || tokens[t].inputImageItemIndex > numInputImageItems))
+            return AVIF_RESULT_INTERNAL_ERROR;
+        if (type < AVIF_SAMPLE_TRANSFORM_FIRST_UNARY_OPERATOR) {
+            ++depth;
+        } else if (type < AVIF_SAMPLE_TRANSFORM_FIRST_BINARY_OPERATOR) {
+            if (depth < 1)
+                return AVIF_RESULT_INTERNAL_ERROR;
+        } else {
+            if (depth < 2)
+                return AVIF_RESULT_INTERNAL_ERROR;
+            --depth;
+        }
+    }
+    if (depth != 1)
+        return AVIF_RESULT_INTERNAL_ERROR;
+    const int skipColor = !(planes & AVIF_PLANES_YUV), skipAlpha = !(planes & AVIF_PLANES_A);
+    for (int c = 0; c < 4; ++c) { /* :371-384 */
+        if ((skipColor && c < 3) || (skipAlpha && c == 3))
+            continue;
+        uint32_t w, h;
+        planeGeometry(dstImage, c, &w, &h);
+        for (uint32_t i = 0; i < numInputImageItems; ++i) {
+            uint32_t wi, hi;
+            planeGeometry(inputImageItems[i], c, &wi, &hi);
+            if (wi != w || hi != h)
+                return AVIF_RESULT_BMFF_PARSE_FAILED;
+        }
+    }
+    if (bitDepth != AVIF_SAMPLE_TRANSFORM_BIT_DEPTH_32)
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    int32_t * stack = (int32_t *)malloc((numTokens / 2 + 1) * sizeof(int32_t));
+    if (!stack)
+        return AVIF_RESULT_OUT_OF_MEMORY;
+    const int32_t maxValue = (1 << dstImage->depth) - 1;
+    for (int c = 0; c < 4; ++c) { /* :296-350 */
+        if ((skipColor && c < 3) || (skipAlpha && c == 3))
+            continue;
+        uint32_t w, h;
+        planeGeometry(dstImage, c, &w, &h);
+        for (uint32_t y = 0; y < h; ++y) {
+            for (uint32_t x = 0; x < w; ++x) {
+                uint32_t n = 0;
+                for (uint32_t t = 0; t < numTokens; ++t) {
+                    const int type = (int)tokens[t].type;
+                    if (type == AVIF_SAMPLE_TRANSFORM_CONSTANT) {
+                        stack[n++] = tokens[t].constant;
+                    } else if (type == AVIF_SAMPLE_TRANSFORM_INPUT_IMAGE_ITEM_INDEX) {
+                        const avifImage * im = inputImageItems[tokens[t].inputImageItemIndex - 1];
+                        const uint8_t * row = ((c < 3) ? im->yuvPlanes[c] : im->alphaPlane) + (size_t)((c < 3) ? im->yuvRowBytes[c] : im->alphaRowBytes) * y;
+                        stack[n++] = (im->depth > 8) ? (int32_t)load16(row + 2 * (size_t)x) : row[x];
+                    } else if (type < AVIF_SAMPLE_TRANSFORM_FIRST_BINARY_OPERATOR) {
+                        stack[n - 1] = satoUnary(stack[n - 1], type);
+                    } else {
+                        stack[n - 2] = satoBinary(stack[n - 2], stack[n - 1], type);
+                        --n;
+                    }
+                }
+                const int32_t v = clampi(stack[0], 0, maxValue);
+                uint8_t * row = ((c < 3) ? dstImage->yuvPlanes[c] : dstImage->alphaPlane) + (size_t)((c < 3) ? dstImage->yuvRowBytes[c] : dstImage->alphaRowBytes) * y;
+                if (dstImage->depth > 8)
+                    store16(row + 2 * (size_t)x, (unsigned)v);
+                else
+                    row[x] = (uint8_t)v;
+            }
+        }
+    }
+    free(stack);
+    return AVIF_RESULT_OK;
+}
+
+/* ------------------------------------------------------------------------- */
 /* crop / rotate / mirror of an RGB image            (apps/shared/avifutil.c:667-825)                              */
 
 static uint32_t rgbPixelSize(const avifRGBImage * rgb) /* avifRGBImagePixelSize, src/avif.c:692-698 */

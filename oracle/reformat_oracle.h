@@ -73,6 +73,14 @@ avifResult oracleRGBImageTransform(avifRGBImage * dst, const avifRGBImage * src,
                                    avifBool mirror, uint8_t axis);
 
 /*
+ * avifImageApplyOperations (include/avif/internal.h:247-254, src/sampletransform.c:284-421): the postfix expression `tokens`
+ * evaluated per sample of the selected planes in saturating 32-bit arithmetic, clamped to the destination depth.
+ */
+avifResult oracleImageApplyOperations(avifImage * dstImage, avifSampleTransformBitDepth bitDepth, uint32_t numTokens,
+                                      const avifSampleTransformToken * tokens, uint8_t numInputImageItems, const avifImage * const * inputImageItems,
+                                      avifPlanesFlags planes);
+
+/*
  * avifImageScale (src/scale.c:23-201; vendored libyuv scaler under kFilterBox, third_party/libyuv/source/scale*.c): every
  * plane of `image` is replaced by its scaled version (scale_oracle.c).  The diagnostics argument of the reference is dropped.
  */

@@ -43,6 +43,8 @@ def oracle() -> C.CDLL:
             getattr(lib, name).restype, getattr(lib, name).argtypes = C.c_int, [_P_RGB]
         lib.oracleLibyuvHookYUVToRGB.restype, lib.oracleLibyuvHookYUVToRGB.argtypes = C.c_int, [_P_IMG, _P_RGB, C.c_int, C.POINTER(C.c_int)]
         lib.oracleLibyuvHookRGBToYUV.restype, lib.oracleLibyuvHookRGBToYUV.argtypes = C.c_int, [_P_IMG, _P_RGB]
+        lib.oracleImageApplyOperations.restype = C.c_int
+        lib.oracleImageApplyOperations.argtypes = [_P_IMG, C.c_int, C.c_uint32, C.c_void_p, C.c_uint8, C.POINTER(_P_IMG), C.c_uint32]
         lib.oracleImageScale.restype, lib.oracleImageScale.argtypes = C.c_int, [_P_IMG, C.c_uint32, C.c_uint32]
         lib.oracleRGBImageTransform.restype = C.c_int
         lib.oracleRGBImageTransform.argtypes = [_P_RGB, _P_RGB, _P_RECT, C.c_int, C.c_uint8, C.c_int, C.c_uint8]
@@ -66,6 +68,9 @@ def _bind_libavif(lib: C.CDLL) -> C.CDLL:
     # internal.h functions: exported by the from-source build (default visibility), not by a packaged shared libavif
     if hasattr(lib, "avifImageSetViewRect"):
         lib.avifImageSetViewRect.restype, lib.avifImageSetViewRect.argtypes = C.c_int, [_P_IMG, _P_IMG, _P_RECT]
+    if hasattr(lib, "avifImageApplyOperations"):
+        lib.avifImageApplyOperations.restype = C.c_int
+        lib.avifImageApplyOperations.argtypes = [_P_IMG, C.c_int, C.c_uint32, C.c_void_p, C.c_uint8, C.POINTER(_P_IMG), C.c_uint32]
     if hasattr(lib, "avifImageScale"):
         lib.avifImageScale.restype, lib.avifImageScale.argtypes = C.c_int, [_P_IMG, C.c_uint32, C.c_uint32, C.c_void_p]
     if hasattr(lib, "avifImageCopySamples"):
