@@ -78,7 +78,27 @@ struct ScaleArgs
     const int32_t * rowB;
     const int32_t * rowF;
 };
-hipError_t launchScalePlane(const ScaleArgs & args, bool wide, hipStream_t stream);
+// Parameters of the row-staged kernel (wide loads of source-row segments into LDS, 4 destination samples per lane), chosen by
+// the host so that the block a wave stages -- the segments of every source row its `rowsPerWave` destination rows of 256
+// columns read -- fits kScaleStageBytes.  rowsPerWave == 0 (or a null pointer): the one-lane-per-sample gather kernel.
+constexpr int kScaleStageBytes = 16384;
+struct ScaleStaging
+{
+    int rowsPerWave = 0;
+    int rowsCap = 0;       // source rows a wave stages at most
+    uint32_t segPitch = 0; // bytes between staged rows (a multiple of 16, segment + alignment slack)
+};
+hipError_t launchScalePlane(const ScaleArgs & args, bool wide, hipStream_t stream); // gather kernel, one plane
+struct ScaleStagedLaunch
+{
+    ScaleArgs plane[4];
+    ScaleStaging staging[4];
+    int count;
+};
+// every plane in one launch.  `window`: the LDS-free window kernel (8-bit samples, point / bilinear / 2x modes, source width >= 8,
+// the source columns of every aligned group of 4 destination columns span <= 8 samples; only rowsPerWave of the staging is used;
+// column tables padded with copies of their last entry to a multiple of 4)
+hipError_t launchScalePlanesStaged(const ScaleStagedLaunch & launch, bool wide, bool window, hipStream_t stream);
 
 // Sample Transform expression evaluation (kernels_sato.hip), one lane per sample of one plane
 constexpr int kSatoMaxTokens = 64, kSatoMaxInputs = 32;

@@ -26,7 +26,16 @@ def scale_cases(n, seed):
            (H.Y2RCase(320, 200, yuv_depth=8, yuv_format=3, yuv_range=1), 640, 400),               # exact 2x (ScalePlaneUp2_Bilinear)
            (H.Y2RCase(320, 200, yuv_depth=12, yuv_format=2, yuv_range=1, alpha=True), 639, 399),
            (H.Y2RCase(1920, 1080, yuv_depth=8, yuv_format=3, yuv_range=1), 480, 270),            # a thumbnail
-           (H.Y2RCase(480, 270, yuv_depth=10, yuv_format=3, yuv_range=1), 1920, 1080)]
+           (H.Y2RCase(480, 270, yuv_depth=10, yuv_format=3, yuv_range=1), 1920, 1080),
+           # several 256-column segments per row, odd widths, padded (unaligned) rows: every kernel family's tails
+           (H.Y2RCase(1001, 77, yuv_depth=8, yuv_format=1, yuv_range=1, row_pad=6), 1333, 91),     # bilinear up
+           (H.Y2RCase(1001, 77, yuv_depth=8, yuv_format=3, yuv_range=1, alpha=True), 2002, 154),   # 2x
+           (H.Y2RCase(1501, 90, yuv_depth=8, yuv_format=2, yuv_range=1, row_pad=6), 1003, 61),     # bilinear down 1.5x
+           (H.Y2RCase(1501, 90, yuv_depth=8, yuv_format=1, yuv_range=1), 801, 47),                 # down 1.87x: windows too wide -> staged
+           (H.Y2RCase(2100, 130, yuv_depth=8, yuv_format=3, yuv_range=1, row_pad=6), 519, 31),     # box
+           (H.Y2RCase(1300, 64, yuv_depth=12, yuv_format=1, yuv_range=1, row_pad=6), 1733, 81),    # 16-bit samples: staged
+           (H.Y2RCase(1300, 64, yuv_depth=10, yuv_format=3, yuv_range=1), 433, 21),
+           (H.Y2RCase(5000, 40, yuv_depth=8, yuv_format=1, yuv_range=1), 280, 33)]                 # 17.9x: segments too long -> gather
     for _ in range(n):
         sw, sh = rnd.choice(SIZES)
         if rnd.random() < 0.5:
@@ -107,9 +116,31 @@ def test_gpu_scale_in_place_equals_the_oracle(hip):
         if (c.w, c.h) != (dw, dh):
             free_owned(a.struct)
             free_owned(b.struct)
-    assert {"scale_down", "scale_up", "scale_box", "scale_up2", "scale_point"} <= kernels, kernels
+    assert {"scale_down", "scale_up", "scale_box", "scale_up2", "scale_point"} <= {k.split("[")[0] for k in kernels}, kernels
+    assert {"gather", "staged", "window"} <= {k.split("[")[1].rstrip("]") for k in kernels}, kernels
     img = H.make_y2r_inputs(H.Y2RCase(8, 8))
     assert hip.avifhipImageScale(img.struct, 0, 4) == abi.AVIF_RESULT_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_gpu_scale_gather_kernel_only(hip):
+    """The one-lane-per-sample kernel (what serves geometries the staged and window kernels decline) on every case."""
+    from libavif_amd import native
+
+    o = oracle_lib.oracle()
+    hip.avifhipSetTiledKernels(0)
+    try:
+        for c, dw, dh in scale_cases(120, seed=4):
+            a, b = H.make_y2r_inputs(c), H.make_y2r_inputs(c)
+            ra, rb = o.oracleImageScale(a.struct, dw, dh), hip.avifhipImageScale(b.struct, dw, dh)
+            assert ra == rb == 0, (c.ident(), dw, dh, hip.avifhipLastError())
+            assert native.last_kernel().endswith("[gather]") or (c.w, c.h) == (dw, dh), native.last_kernel()
+            compare(planes_of(a.struct), planes_of(b.struct), (c.ident(), dw, dh, native.last_kernel()))
+            if (c.w, c.h) != (dw, dh):
+                free_owned(a.struct)
+                free_owned(b.struct)
+    finally:
+        hip.avifhipSetTiledKernels(1)
 
 
 @pytest.mark.gpu
@@ -117,14 +148,15 @@ def test_gpu_scale_device_resident_equals_the_oracle(hip):
     from libavif_amd import device, native
 
     o = oracle_lib.oracle()
-    for c, dw, dh in scale_cases(60, seed=3)[:40]:
+    for idx, (c, dw, dh) in enumerate(scale_cases(60, seed=3)[:48]):
+        tight = idx % 2 == 1  # rows at any byte alignment: the kernels' unaligned-row store paths
         a, src = H.make_y2r_inputs(c), H.make_y2r_inputs(c)
         assert o.oracleImageScale(a.struct, dw, dh) == 0
         dst = H.make_y2r_inputs(H.Y2RCase(dw, dh, yuv_depth=c.yuv_depth, yuv_format=c.yuv_format, alpha=c.alpha, yuv_range=1))
-        dsrc, ddst = device.DeviceYUV(src), device.DeviceYUV(dst)
+        dsrc, ddst = device.DeviceYUV(src, tight=tight), device.DeviceYUV(dst, tight=tight)
         native.check(hip.avifhipImageScaleAsync(dsrc.struct, ddst.struct, None), "avifhipImageScaleAsync")
         native.check(hip.avifhipSynchronize(None), "sync")
         ddst.download_into_host()
-        compare(planes_of(a.struct), planes_of(dst.struct), (c.ident(), dw, dh))
+        compare(planes_of(a.struct), planes_of(dst.struct), (c.ident(), dw, dh, tight, native.last_kernel()))
         if (c.w, c.h) != (dw, dh):
             free_owned(a.struct)
