@@ -68,7 +68,8 @@ typedef enum avifResult
     AVIF_RESULT_INVALID_ARGUMENT = 24,
     AVIF_RESULT_NOT_IMPLEMENTED = 25,
     AVIF_RESULT_OUT_OF_MEMORY = 26,
-    AVIF_RESULT_INTERNAL_ERROR = 29
+    AVIF_RESULT_INTERNAL_ERROR = 29,
+    AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE = 32
 } avifResult;
 
 typedef enum avifPixelFormat /* avif.h:280-289 */
@@ -230,6 +231,103 @@ AVIFHIP_STATIC_ASSERT(offsetof(avifImage, alphaPlane) == 64, "avifImage.alphaPla
 AVIFHIP_STATIC_ASSERT(offsetof(avifImage, alphaPremultiplied) == 80, "avifImage.alphaPremultiplied");
 AVIFHIP_STATIC_ASSERT(offsetof(avifImage, matrixCoefficients) == 108, "avifImage.matrixCoefficients");
 
+
+/* ---- gain maps (avifRGBImageApplyGainMap, reference src/gainmap.c): boundary types, avif.h:236-250, :419-453, :582-610, :630-711 ---- */
+#ifdef AVIFHIP_ABI_MIRROR
+#ifdef __cplusplus
+extern "C" {
+#endif
+enum /* avifColorPrimaries values, avif.h:336-355 */
+{
+    AVIF_COLOR_PRIMARIES_UNKNOWN = 0,
+    AVIF_COLOR_PRIMARIES_BT709 = 1,
+    AVIF_COLOR_PRIMARIES_UNSPECIFIED = 2,
+    AVIF_COLOR_PRIMARIES_BT470M = 4,
+    AVIF_COLOR_PRIMARIES_BT470BG = 5,
+    AVIF_COLOR_PRIMARIES_BT601 = 6,
+    AVIF_COLOR_PRIMARIES_SMPTE240 = 7,
+    AVIF_COLOR_PRIMARIES_GENERIC_FILM = 8,
+    AVIF_COLOR_PRIMARIES_BT2020 = 9,
+    AVIF_COLOR_PRIMARIES_XYZ = 10,
+    AVIF_COLOR_PRIMARIES_SMPTE431 = 11,
+    AVIF_COLOR_PRIMARIES_SMPTE432 = 12,
+    AVIF_COLOR_PRIMARIES_EBU3213 = 22
+};
+enum /* avifTransferCharacteristics values, avif.h:364-385 */
+{
+    AVIF_TRANSFER_CHARACTERISTICS_UNKNOWN = 0,
+    AVIF_TRANSFER_CHARACTERISTICS_BT709 = 1,
+    AVIF_TRANSFER_CHARACTERISTICS_UNSPECIFIED = 2,
+    AVIF_TRANSFER_CHARACTERISTICS_BT470M = 4,
+    AVIF_TRANSFER_CHARACTERISTICS_BT470BG = 5,
+    AVIF_TRANSFER_CHARACTERISTICS_BT601 = 6,
+    AVIF_TRANSFER_CHARACTERISTICS_SMPTE240 = 7,
+    AVIF_TRANSFER_CHARACTERISTICS_LINEAR = 8,
+    AVIF_TRANSFER_CHARACTERISTICS_LOG100 = 9,
+    AVIF_TRANSFER_CHARACTERISTICS_LOG100_SQRT10 = 10,
+    AVIF_TRANSFER_CHARACTERISTICS_IEC61966 = 11,
+    AVIF_TRANSFER_CHARACTERISTICS_BT1361 = 12,
+    AVIF_TRANSFER_CHARACTERISTICS_SRGB = 13,
+    AVIF_TRANSFER_CHARACTERISTICS_BT2020_10BIT = 14,
+    AVIF_TRANSFER_CHARACTERISTICS_BT2020_12BIT = 15,
+    AVIF_TRANSFER_CHARACTERISTICS_PQ = 16,
+    AVIF_TRANSFER_CHARACTERISTICS_SMPTE2084 = 16,
+    AVIF_TRANSFER_CHARACTERISTICS_SMPTE428 = 17,
+    AVIF_TRANSFER_CHARACTERISTICS_HLG = 18
+};
+typedef struct avifRWData
+{
+    uint8_t * data;
+    size_t size;
+} avifRWData;
+#define AVIF_DIAGNOSTICS_ERROR_BUFFER_SIZE 256
+typedef struct avifDiagnostics
+{
+    char error[AVIF_DIAGNOSTICS_ERROR_BUFFER_SIZE];
+} avifDiagnostics;
+typedef struct avifSignedFraction
+{
+    int32_t n;
+    uint32_t d;
+} avifSignedFraction;
+typedef struct avifUnsignedFraction
+{
+    uint32_t n;
+    uint32_t d;
+} avifUnsignedFraction;
+typedef struct avifContentLightLevelInformationBox
+{
+    uint16_t maxCLL;
+    uint16_t maxPALL;
+} avifContentLightLevelInformationBox;
+typedef struct avifGainMap
+{
+    struct avifImage * image; /* the gain map pixels (YUV planes; CICP fields ignored) */
+    avifSignedFraction gainMapMin[3];
+    avifSignedFraction gainMapMax[3];
+    avifUnsignedFraction gainMapGamma[3];
+    avifSignedFraction baseOffset[3];
+    avifSignedFraction alternateOffset[3];
+    avifUnsignedFraction baseHdrHeadroom;
+    avifUnsignedFraction alternateHdrHeadroom;
+    avifBool useBaseColorSpace;
+    avifRWData altICC;
+    avifColorPrimaries altColorPrimaries;
+    avifTransferCharacteristics altTransferCharacteristics;
+    avifMatrixCoefficients altMatrixCoefficients;
+    avifRange altYUVRange;
+    uint32_t altDepth;
+    uint32_t altPlaneCount;
+    avifContentLightLevelInformationBox altCLLI;
+} avifGainMap;
+#ifdef __cplusplus
+}
+#endif
+AVIFHIP_STATIC_ASSERT(sizeof(avifGainMap) == 192, "avifGainMap layout");
+AVIFHIP_STATIC_ASSERT(offsetof(avifGainMap, baseHdrHeadroom) == 128, "avifGainMap.baseHdrHeadroom");
+AVIFHIP_STATIC_ASSERT(offsetof(avifGainMap, useBaseColorSpace) == 144, "avifGainMap.useBaseColorSpace");
+AVIFHIP_STATIC_ASSERT(offsetof(avifGainMap, altColorPrimaries) == 168, "avifGainMap.altColorPrimaries");
+#endif /* AVIFHIP_ABI_MIRROR */
 
 /* Sample Transform tokens ('sato' derived image items): libavif declares these in its INTERNAL header
  * (include/avif/internal.h:179-228); mirrored here, layout-identical (sizeof(avifSampleTransformToken) == 12), unless that

@@ -124,6 +124,52 @@ assert C.sizeof(avifImage) == 224 and avifImage.matrixCoefficients.offset == 108
 assert C.sizeof(avifRGBImage) == 64 and avifRGBImage.pixels.offset == 48
 
 
+# --- gain maps (avif.h:419-453, :582-610, :630-711) -------------------------------
+AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE = 32
+
+
+class avifSignedFraction(C.Structure):
+    _fields_ = [("n", C.c_int32), ("d", C.c_uint32)]
+
+
+class avifUnsignedFraction(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("d", C.c_uint32)]
+
+
+class avifContentLightLevelInformationBox(C.Structure):
+    _fields_ = [("maxCLL", C.c_uint16), ("maxPALL", C.c_uint16)]
+
+
+class avifDiagnostics(C.Structure):
+    _fields_ = [("error", C.c_char * 256)]
+
+
+class avifGainMap(C.Structure):
+    _fields_ = [
+        ("image", C.POINTER(avifImage)),
+        ("gainMapMin", avifSignedFraction * 3),
+        ("gainMapMax", avifSignedFraction * 3),
+        ("gainMapGamma", avifUnsignedFraction * 3),
+        ("baseOffset", avifSignedFraction * 3),
+        ("alternateOffset", avifSignedFraction * 3),
+        ("baseHdrHeadroom", avifUnsignedFraction),
+        ("alternateHdrHeadroom", avifUnsignedFraction),
+        ("useBaseColorSpace", C.c_int),
+        ("altICC_data", C.c_void_p),
+        ("altICC_size", C.c_size_t),
+        ("altColorPrimaries", C.c_uint16),
+        ("altTransferCharacteristics", C.c_uint16),
+        ("altMatrixCoefficients", C.c_uint16),
+        ("altYUVRange", C.c_int),
+        ("altDepth", C.c_uint32),
+        ("altPlaneCount", C.c_uint32),
+        ("altCLLI", avifContentLightLevelInformationBox),
+    ]
+
+
+assert C.sizeof(avifGainMap) == 192 and avifGainMap.altColorPrimaries.offset == 168 and avifGainMap.useBaseColorSpace.offset == 144
+
+
 def rgb_format_has_alpha(fmt: int) -> bool:  # src/avif.c:675-679
     return fmt in (AVIF_RGB_FORMAT_RGBA, AVIF_RGB_FORMAT_ARGB, AVIF_RGB_FORMAT_BGRA, AVIF_RGB_FORMAT_ABGR,
                    AVIF_RGB_FORMAT_GRAYA, AVIF_RGB_FORMAT_AGRAY)

@@ -103,7 +103,18 @@ avifResult oracleLibyuvHookRGBToYUV(avifImage * image, const avifRGBImage * rgb)
 avifResult oracleLibyuvHookPremultiplyAlpha(avifRGBImage * rgb);
 avifResult oracleLibyuvHookUnpremultiplyAlpha(avifRGBImage * rgb);
 
+/* ---- gain-map application (gainmap_oracle.c): avifRGBImageApplyGainMap, reference src/gainmap.c:73-315 ---- */
+avifResult oracleRGBImageApplyGainMap(const avifRGBImage * baseImage, avifColorPrimaries baseColorPrimaries,
+                                      avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap, float hdrHeadroom,
+                                      avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
+                                      avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, int libyuvBuild);
+avifResult oracleGainMapValidateMetadata(const avifGainMap * gainMap);
+float oracleGainMapWeight(float hdrHeadroom, const avifGainMap * gainMap);
+float oracleTransferFunction(int transferCharacteristics, int direction, float v);
+int oracleColorPrimariesComputeRGBToRGBMatrix(int srcPrimaries, int dstPrimaries, double coeffs[3][3]);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif
