@@ -130,6 +130,47 @@ AVIFHIP_API avifResult avifhipRGBImageTransformAsync(avifRGBImage * dst,
                                                      uint8_t axis,
                                                      void * hipStream);
 
+/* Gain-map application (tone mapping), the decode-side consumer of the conversion path: drop-ins for
+ * avifRGBImageApplyGainMap / avifImageApplyGainMap (reference include/avif/avif.h:1727-1745, src/gainmap.c:73-355) with the
+ * same arguments, result codes and diagnostics.  Output bytes are IDENTICAL to the reference's on this machine: every libm
+ * transcendental of the reference is tabulated on the host with the host's libm (per sample code on the input side; as the
+ * fp32 steps of the quantised output transfer function on the output side), the GPU does the IEEE arithmetic in between.
+ * The only tolerance: clli->maxPALL, which the reference accumulates in fp32 pixel by pixel (order-dependent rounding) and
+ * this library in fp64 partial sums -- it may differ by rounding of the last nit.  The gain map's own YUV -> RGB conversion
+ * follows the library's arithmetic setting (default: what a libavif built with libyuv computes).
+ * avifhipRGBImageApplyGainMap: host images; toneMappedImage->pixels is (re)allocated with malloc like the reference does.
+ * ...Async: base pixels, gain-map planes and (pre-allocated) tone-mapped pixels are device-resident; the call enqueues on
+ * `hipStream` and WAITS for it, because the result code (NaN check) and the CLLI values depend on the pixels. */
+AVIFHIP_API avifResult avifhipRGBImageApplyGainMap(const avifRGBImage * baseImage,
+                                                   avifColorPrimaries baseColorPrimaries,
+                                                   avifTransferCharacteristics baseTransferCharacteristics,
+                                                   const avifGainMap * gainMap,
+                                                   float hdrHeadroom,
+                                                   avifColorPrimaries outputColorPrimaries,
+                                                   avifTransferCharacteristics outputTransferCharacteristics,
+                                                   avifRGBImage * toneMappedImage,
+                                                   avifContentLightLevelInformationBox * clli,
+                                                   avifDiagnostics * diag);
+AVIFHIP_API avifResult avifhipRGBImageApplyGainMapAsync(const avifRGBImage * baseImage,
+                                                        avifColorPrimaries baseColorPrimaries,
+                                                        avifTransferCharacteristics baseTransferCharacteristics,
+                                                        const avifGainMap * gainMap,
+                                                        float hdrHeadroom,
+                                                        avifColorPrimaries outputColorPrimaries,
+                                                        avifTransferCharacteristics outputTransferCharacteristics,
+                                                        avifRGBImage * toneMappedImage,
+                                                        avifContentLightLevelInformationBox * clli,
+                                                        avifDiagnostics * diag,
+                                                        void * hipStream);
+AVIFHIP_API avifResult avifhipImageApplyGainMap(const avifImage * baseImage,
+                                                const avifGainMap * gainMap,
+                                                float hdrHeadroom,
+                                                avifColorPrimaries outputColorPrimaries,
+                                                avifTransferCharacteristics outputTransferCharacteristics,
+                                                avifRGBImage * toneMappedImage,
+                                                avifContentLightLevelInformationBox * clli,
+                                                avifDiagnostics * diag);
+
 /* Plane scaling.  Replaces avifImageScale, include/avif/avif.h:922, src/scale.c:23-201, which scales
  * every plane with the vendored libyuv scaler under kFilterBox (third_party/libyuv/source/scale*.c): results are byte-identical
  * (integer arithmetic).  avifhipImageScale works in place on a host-resident image exactly like the reference (new planes

@@ -14,6 +14,7 @@
 #include "avifhip.h"
 #include "kernels.h"
 #include "plan.h"
+#include "gainmap_plan.h"
 #include "scale_plan.h"
 
 using namespace avifhip;
@@ -41,6 +42,20 @@ struct ScaleTableCache
     ScaleStaging window[4];  // window kernel
 };
 
+// what tls.gainMap[2] currently holds (the tables of avifhipRGBImageApplyGainMap): rebuilt only when a parameter changes
+struct GainMapTableCache
+{
+    bool valid = false;
+    struct Key
+    {
+        uint32_t baseTC, baseDepth, baseFloat, outTC, outDepth, outFloat, gainDepth, applyGain;
+        float gammaInv[3], minLog2[3], maxLog2[3], weight;
+        uint64_t stream;
+    } key;
+    size_t baseLutOffset = 0, gainLutOffset = 0, stepsOffset = 0; // in floats
+    uint32_t maxCode = 0, nanCode = 0;
+};
+
 // One context per calling thread: libavif's reformat functions are re-entrant and may be called
 // concurrently from up to 8 threads (src/reformat.c:1709-1735); nothing here is shared.
 struct Context
@@ -54,6 +69,8 @@ struct Context
     Scratch scaleTable; // schedules of a plane scale (device)
     ScaleTableCache scaleCache; // ... and which geometry they belong to
     Scratch satoTable;  // input plane tables of a sample transform (device)
+    Scratch gainMap[6]; // gain-map application: output pixels, gain map as RGB, tables, statistics, scaled gain-map planes, base pixels
+    GainMapTableCache gainMapCache; // what gainMap[2] holds
     void * pinnedTable = nullptr;
     size_t pinnedTableCapacity = 0;
     hipEvent_t tableCopied = nullptr;
@@ -80,6 +97,9 @@ struct Context
             (void)hipFree(scaleTable.ptr);
         if (satoTable.ptr)
             (void)hipFree(satoTable.ptr);
+        for (Scratch & g : gainMap)
+            if (g.ptr)
+                (void)hipFree(g.ptr);
         if (pinnedTable)
             (void)hipHostFree(pinnedTable);
         if (tableCopied)
@@ -1008,6 +1028,427 @@ extern "C" avifResult avifhipImageApplyOperationsAsync(avifImage * dstImage, avi
     tls.lastKernel = "sample_transform";
     ++tls.launches;
     return AVIF_RESULT_OK;
+}
+
+// =================================================================================================
+// gain-map application, reference src/gainmap.c:73-355
+// =================================================================================================
+
+namespace {
+
+void diagClear(avifDiagnostics * diag)
+{
+    if (diag)
+        diag->error[0] = '\0';
+}
+void diagPrintf(avifDiagnostics * diag, const char * fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    char text[AVIF_DIAGNOSTICS_ERROR_BUFFER_SIZE];
+    vsnprintf(text, sizeof(text), fmt, ap);
+    va_end(ap);
+    if (diag)
+        memcpy(diag->error, text, sizeof(text));
+    setError("%s", text);
+}
+
+inline float fractionToFloat(avifSignedFraction f) // src/gainmap.c:32-38
+{
+    return f.d == 0 ? 0.0f : (float)f.n / f.d;
+}
+inline float fractionToFloat(avifUnsignedFraction f) // :40-46
+{
+    return f.d == 0 ? 0.0f : (float)f.n / f.d;
+}
+
+avifResult gainMapValidateMetadata(const avifGainMap * gainMap, avifDiagnostics * diag) // :430-457
+{
+    for (int i = 0; i < 3; ++i) {
+        if (gainMap->gainMapMin[i].d == 0 || gainMap->gainMapMax[i].d == 0 || gainMap->gainMapGamma[i].d == 0 || gainMap->baseOffset[i].d == 0 ||
+            gainMap->alternateOffset[i].d == 0) {
+            diagPrintf(diag, "Per-channel denominator is 0 in gain map metadata");
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        }
+        if ((int64_t)gainMap->gainMapMax[i].n * gainMap->gainMapMin[i].d < (int64_t)gainMap->gainMapMin[i].n * gainMap->gainMapMax[i].d) {
+            diagPrintf(diag, "Per-channel max is less than per-channel min in gain map metadata");
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        }
+        if (gainMap->gainMapGamma[i].n == 0) {
+            diagPrintf(diag, "Per-channel gamma is 0 in gain map metadata");
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        }
+    }
+    if (gainMap->baseHdrHeadroom.d == 0 || gainMap->alternateHdrHeadroom.d == 0) {
+        diagPrintf(diag, "Headroom denominator is 0 in gain map metadata");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    if (gainMap->useBaseColorSpace != 0 && gainMap->useBaseColorSpace != 1) {
+        diagPrintf(diag, "useBaseColorSpace is %d in gain map metadata", gainMap->useBaseColorSpace);
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    return AVIF_RESULT_OK;
+}
+
+float gainMapWeight(float hdrHeadroom, const avifGainMap * gainMap) // avifGetGainMapWeight, :52-63
+{
+    const float base = fractionToFloat(gainMap->baseHdrHeadroom), alternate = fractionToFloat(gainMap->alternateHdrHeadroom);
+    if (base == alternate)
+        return 0.0f;
+    const float r = (hdrHeadroom - base) / (alternate - base);
+    const float w = (r < 0.0f) ? 0.0f : ((1.0f < r) ? 1.0f : r);
+    return (alternate < base) ? -w : w;
+}
+
+bool gainMapLayout(const avifRGBImage * rgb, GainMapPixelLayout * L) // avifGetRGBColorSpaceInfo, src/reformat.c:32-117
+{
+    if (rgb->depth != 8 && rgb->depth != 10 && rgb->depth != 12 && rgb->depth != 16)
+        return false;
+    if ((rgb->isFloat && rgb->depth != 16) || (rgb->format == AVIF_RGB_FORMAT_RGB_565 && rgb->depth != 8))
+        return false;
+    memset(L, 0, sizeof(*L));
+    const uint32_t cb = (rgb->depth > 8) ? 2 : 1;
+    L->channelBytes = cb;
+    uint32_t n = 0;
+    switch (rgb->format) {
+        case AVIF_RGB_FORMAT_RGB: L->offR = 0, L->offG = cb, L->offB = 2 * cb, n = 3; break;
+        case AVIF_RGB_FORMAT_RGBA: L->offR = 0, L->offG = cb, L->offB = 2 * cb, L->offA = 3 * cb, n = 4; break;
+        case AVIF_RGB_FORMAT_ARGB: L->offA = 0, L->offR = cb, L->offG = 2 * cb, L->offB = 3 * cb, n = 4; break;
+        case AVIF_RGB_FORMAT_BGR: L->offB = 0, L->offG = cb, L->offR = 2 * cb, n = 3; break;
+        case AVIF_RGB_FORMAT_BGRA: L->offB = 0, L->offG = cb, L->offR = 2 * cb, L->offA = 3 * cb, n = 4; break;
+        case AVIF_RGB_FORMAT_ABGR: L->offA = 0, L->offB = cb, L->offG = 2 * cb, L->offR = 3 * cb, n = 4; break;
+        case AVIF_RGB_FORMAT_RGB_565: L->is565 = 1, n = 2; break;
+        default: return false; // gray layouts have no R, G, B offsets for the tone-mapping loop to index
+    }
+    L->pixelBytes = L->is565 ? 2 : n * cb;
+    L->hasAlpha = (n == 4 && !L->is565) ? 1 : 0;
+    L->isFloat = rgb->isFloat ? 1 : 0;
+    L->depth = rgb->depth;
+    L->maxF = (float)((1u << rgb->depth) - 1);
+    return true;
+}
+
+// The tone-mapping of device-resident images.  `gainImage`: gainMap->image with device plane pointers.  The tone-mapped
+// image must already own device pixels of the base image's size.  Waits for the stream: the result code and the CLLI
+// values depend on the pixels.
+avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries basePrimaries, avifTransferCharacteristics baseTC, const avifGainMap * gainMap,
+                                const avifImage * gainImage, float weight, avifColorPrimaries outPrimaries, avifTransferCharacteristics outTC,
+                                avifRGBImage * out, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag, hipStream_t stream)
+{
+    const uint32_t width = base->width, height = base->height;
+    GainMapArgs A;
+    memset(&A, 0, sizeof(A));
+    if (!gainMapLayout(base, &A.baseL) || !gainMapLayout(out, &A.outL)) {
+        diagPrintf(diag, "Unsupported RGB color space");
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    }
+    A.base = base->pixels, A.basePitch = base->rowBytes, A.out = out->pixels, A.outPitch = out->rowBytes;
+    A.width = width, A.height = height;
+
+    const avifColorPrimaries mathPrimaries =
+        (gainMap->useBaseColorSpace || (gainMap->altColorPrimaries == AVIF_COLOR_PRIMARIES_UNSPECIFIED)) ? basePrimaries : gainMap->altColorPrimaries;
+    const bool applyGain = weight != 0.0f;
+    if (!applyGain) { // "Just convert from one rgb format to another", src/gainmap.c:142-170
+        const bool primariesDiffer = basePrimaries != outPrimaries;
+        if (primariesDiffer && !gainMapPrimariesMatrix(basePrimaries, outPrimaries, A.inM)) {
+            diagPrintf(diag, "Unsupported RGB color space conversion");
+            return AVIF_RESULT_NOT_IMPLEMENTED;
+        }
+        A.inConv = primariesDiffer ? 1 : 0;
+        A.convert = (outTC != baseTC || primariesDiffer) ? 1 : 0;
+    } else {
+        A.convert = 1;
+        A.inConv = (basePrimaries != mathPrimaries) ? 1 : 0, A.outConv = (mathPrimaries != outPrimaries) ? 1 : 0;
+        if ((A.inConv && !gainMapPrimariesMatrix(basePrimaries, mathPrimaries, A.inM)) ||
+            (A.outConv && !gainMapPrimariesMatrix(mathPrimaries, outPrimaries, A.outM))) {
+            diagPrintf(diag, "Unsupported RGB color space conversion");
+            return AVIF_RESULT_NOT_IMPLEMENTED;
+        }
+    }
+
+    // ---- the gain map as RGB at the base image's size, :185-212 ----
+    uint32_t gainDepth = 8;
+    if (applyGain) {
+        avifImage gm;
+        memcpy(&gm, gainImage, sizeof(avifImage));
+        if (gm.width != width || gm.height != height) {
+            avifImage scaled;
+            memcpy(&scaled, &gm, sizeof(avifImage));
+            scaled.width = width, scaled.height = height;
+            const PlaneDims dd = planeDims(width, height, (int)gm.yuvFormat);
+            const size_t bps = (gm.depth > 8) ? 2 : 1;
+            size_t offset[4] = { 0, 0, 0, 0 }, total = 0;
+            uint32_t pitch[4] = { 0, 0, 0, 0 };
+            for (int p = 0; p < 4; ++p) {
+                const uint8_t * sp = (p < 3) ? gm.yuvPlanes[p] : gm.alphaPlane;
+                if (!sp || ((p == 1 || p == 2) && gm.yuvFormat == AVIF_PIXEL_FORMAT_YUV400))
+                    continue;
+                pitch[p] = alignUp((uint32_t)(dd.w[p] * bps), 256);
+                offset[p] = total, total += (size_t)pitch[p] * dd.h[p];
+            }
+            const avifResult rr = reserve(tls.gainMap[4], total ? total : 1);
+            if (rr != AVIF_RESULT_OK)
+                return rr;
+            for (int p = 0; p < 4; ++p) {
+                uint8_t * dp = pitch[p] ? (uint8_t *)tls.gainMap[4].ptr + offset[p] : nullptr;
+                if (p < 3)
+                    scaled.yuvPlanes[p] = dp, scaled.yuvRowBytes[p] = pitch[p];
+                else
+                    scaled.alphaPlane = dp, scaled.alphaRowBytes = pitch[p];
+            }
+            const avifResult sr = avifhipImageScaleAsync(&gm, &scaled, stream);
+            if (sr != AVIF_RESULT_OK)
+                return sr;
+            memcpy(&gm, &scaled, sizeof(avifImage));
+        }
+        avifRGBImage rgbGain; // avifRGBImageSetDefaults, src/avif.c:700-717
+        memset(&rgbGain, 0, sizeof(rgbGain));
+        rgbGain.width = width, rgbGain.height = height, rgbGain.depth = gm.depth, rgbGain.format = AVIF_RGB_FORMAT_RGBA;
+        rgbGain.chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, rgbGain.chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
+        rgbGain.maxThreads = 1;
+        rgbGain.rowBytes = alignUp(width * 4 * ((gm.depth > 8) ? 2 : 1), 256);
+        const avifResult rr = reserve(tls.gainMap[1], (size_t)rgbGain.rowBytes * height);
+        if (rr != AVIF_RESULT_OK)
+            return rr;
+        rgbGain.pixels = (uint8_t *)tls.gainMap[1].ptr;
+        const avifResult cr = avifhipImageYUVToRGBAsync(&gm, &rgbGain, stream);
+        if (cr != AVIF_RESULT_OK)
+            return cr;
+        A.gain = rgbGain.pixels, A.gainPitch = rgbGain.rowBytes, A.gainDepth = gainDepth = gm.depth;
+        for (int c = 0; c < 3; ++c)
+            A.baseOffset[c] = fractionToFloat(gainMap->baseOffset[c]), A.altOffset[c] = fractionToFloat(gainMap->alternateOffset[c]);
+    }
+
+    // ---- tables (kept while the parameters stay the same: sequences of frames, tiles) ----
+    if (A.convert) {
+        GainMapTableCache & cache = tls.gainMapCache;
+        GainMapTableCache::Key key;
+        memset(&key, 0, sizeof(key));
+        key.baseTC = baseTC, key.baseDepth = base->depth, key.baseFloat = base->isFloat ? 1 : 0;
+        key.outTC = outTC, key.outDepth = A.outL.is565 ? 8 : out->depth, key.outFloat = out->isFloat ? 1 : 0;
+        key.gainDepth = gainDepth, key.applyGain = applyGain ? 1 : 0, key.stream = (uint64_t)(uintptr_t)stream;
+        if (applyGain) {
+            for (int c = 0; c < 3; ++c) {
+                key.gammaInv[c] = 1.0f / fractionToFloat(gainMap->gainMapGamma[c]);
+                key.minLog2[c] = fractionToFloat(gainMap->gainMapMin[c]), key.maxLog2[c] = fractionToFloat(gainMap->gainMapMax[c]);
+            }
+            key.weight = weight;
+        }
+        if (!cache.valid || memcmp(&cache.key, &key, sizeof(key)) != 0) {
+            cache.valid = false;
+            std::vector<float> tables = gainMapLinearLut(baseTC, base->depth, base->isFloat != 0);
+            cache.baseLutOffset = 0, cache.gainLutOffset = tables.size();
+            if (applyGain) {
+                for (int c = 0; c < 3; ++c) {
+                    const std::vector<float> g = gainMapGainLut(gainDepth, key.gammaInv[c], key.minLog2[c], key.maxLog2[c], weight);
+                    tables.insert(tables.end(), g.begin(), g.end());
+                }
+            }
+            cache.stepsOffset = tables.size();
+            const GainMapSteps & S = gainMapOutputSteps(outTC, key.outDepth, out->isFloat != 0);
+            tables.insert(tables.end(), S.steps.begin(), S.steps.end());
+            cache.maxCode = S.maxCode;
+            // what the reference computes for a NaN input (the weight-0 path can meet one in a half-float base image)
+            const float nanGamma = fminf(1.0f, fmaxf(0.0f, gainMapToGamma(outTC, NAN)));
+            cache.nanCode = out->isFloat ? ((uint32_t)0) : (uint32_t)(0.5f + nanGamma * (float)((1u << key.outDepth) - 1));
+            if (out->isFloat) {
+                const float f = nanGamma * 1.9259299444e-34f;
+                uint32_t u;
+                memcpy(&u, &f, 4);
+                cache.nanCode = (u >> 13) & 0xffffu;
+            }
+            const avifResult rr = reserve(tls.gainMap[2], tables.size() * sizeof(float));
+            if (rr != AVIF_RESULT_OK)
+                return rr;
+            const avifResult ur = uploadTableAsync(tls.gainMap[2].ptr, tables.data(), tables.size() * sizeof(float), stream);
+            if (ur != AVIF_RESULT_OK)
+                return ur;
+            cache.key = key;
+            cache.valid = true;
+        }
+        const float * t = (const float *)tls.gainMap[2].ptr;
+        A.baseLut = t + cache.baseLutOffset, A.gainLut = t + cache.gainLutOffset, A.steps = t + cache.stepsOffset;
+        A.maxCode = cache.maxCode, A.nanCode = cache.nanCode;
+    }
+
+    const avifResult sr = reserve(tls.gainMap[3], sizeof(GainMapStats));
+    if (sr != AVIF_RESULT_OK)
+        return sr;
+    A.stats = (GainMapStats *)tls.gainMap[3].ptr;
+    HIP_TRY(hipMemsetAsync(A.stats, 0, sizeof(GainMapStats), stream));
+    const hipError_t e = launchGainMapApply(A, stream);
+    if (e != hipSuccess)
+        return hipFailed(e, "gain map kernel launch");
+    tls.lastKernel = applyGain ? "gainmap_apply" : (A.convert ? "gainmap_convert" : "gainmap_requantise");
+    ++tls.launches;
+    GainMapStats stats;
+    HIP_TRY(hipMemcpyAsync(&stats, A.stats, sizeof(stats), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (applyGain && stats.nan) {
+        diagPrintf(diag, "Degenerate gain map parameters produce NaN");
+        return AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE;
+    }
+    if (applyGain && clli) { // src/gainmap.c:292-302 (the reference sums in fp32 pixel by pixel; here fp64 partial sums)
+        float rgbMaxLinear;
+        memcpy(&rgbMaxLinear, &stats.maxBits, 4);
+        const float kSdrWhiteNits = 203.0f;
+        auto toNits = [&](float v) -> uint16_t {
+            const float r = floorf(v * kSdrWhiteNits + 0.5f);
+            return (uint16_t)((r < 0.0f) ? 0.0f : ((65535.0f < r) ? 65535.0f : r));
+        };
+        clli->maxCLL = toNits(rgbMaxLinear);
+        clli->maxPALL = toNits((float)stats.sum / (float)((size_t)width * height));
+    }
+    return AVIF_RESULT_OK;
+}
+
+// argument checks shared by the entry points, src/gainmap.c:86-94
+avifResult gainMapCheckArguments(const avifRGBImage * base, const avifGainMap * gainMap, float hdrHeadroom, const avifRGBImage * out, avifDiagnostics * diag)
+{
+    diagClear(diag);
+    if (hdrHeadroom < 0.0f) {
+        diagPrintf(diag, "hdrHeadroom should be >= 0, got %f", hdrHeadroom);
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    if (base == NULL || gainMap == NULL || out == NULL) {
+        diagPrintf(diag, "NULL input image");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    return gainMapValidateMetadata(gainMap, diag);
+}
+
+bool gainMapIsPlainCopy(const avifRGBImage * base, avifColorPrimaries basePrimaries, avifTransferCharacteristics baseTC, float weight,
+                        avifColorPrimaries outPrimaries, avifTransferCharacteristics outTC, const avifRGBImage * out) // :120-128
+{
+    return weight == 0.0f && outTC == baseTC && outPrimaries == basePrimaries && base->format == out->format && base->depth == out->depth &&
+           base->isFloat == out->isFloat && base->rowBytes == out->rowBytes;
+}
+
+} // namespace
+
+extern "C" avifResult avifhipRGBImageApplyGainMapAsync(const avifRGBImage * baseImage, avifColorPrimaries baseColorPrimaries,
+                                                       avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap,
+                                                       float hdrHeadroom, avifColorPrimaries outputColorPrimaries,
+                                                       avifTransferCharacteristics outputTransferCharacteristics, avifRGBImage * toneMappedImage,
+                                                       avifContentLightLevelInformationBox * clli, avifDiagnostics * diag, void * hipStream)
+{
+    const avifResult ar = gainMapCheckArguments(baseImage, gainMap, hdrHeadroom, toneMappedImage, diag);
+    if (ar != AVIF_RESULT_OK)
+        return ar;
+    if (!baseImage->pixels || !toneMappedImage->pixels || !toneMappedImage->rowBytes || !gainMap->image) {
+        diagPrintf(diag, "avifhipRGBImageApplyGainMapAsync: device-resident base, gain map and tone-mapped pixels are required");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    hipStream_t stream = pickStream(hipStream);
+    toneMappedImage->width = baseImage->width, toneMappedImage->height = baseImage->height;
+    const float weight = gainMapWeight(hdrHeadroom, gainMap);
+    if (gainMapIsPlainCopy(baseImage, baseColorPrimaries, baseTransferCharacteristics, weight, outputColorPrimaries, outputTransferCharacteristics,
+                           toneMappedImage)) {
+        HIP_TRY(hipMemcpyAsync(toneMappedImage->pixels, baseImage->pixels, (size_t)baseImage->rowBytes * baseImage->height, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return AVIF_RESULT_OK;
+    }
+    return applyGainMapOnDevice(baseImage, baseColorPrimaries, baseTransferCharacteristics, gainMap, gainMap->image, weight, outputColorPrimaries,
+                                outputTransferCharacteristics, toneMappedImage, clli, diag, stream);
+}
+
+// host-resident images, like the reference: the tone-mapped image's pixels are (re)allocated with malloc (src/gainmap.c:112-114)
+extern "C" avifResult avifhipRGBImageApplyGainMap(const avifRGBImage * baseImage, avifColorPrimaries baseColorPrimaries,
+                                                  avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap, float hdrHeadroom,
+                                                  avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
+                                                  avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag)
+{
+    const avifResult ar = gainMapCheckArguments(baseImage, gainMap, hdrHeadroom, toneMappedImage, diag);
+    if (ar != AVIF_RESULT_OK)
+        return ar;
+    const uint32_t width = baseImage->width, height = baseImage->height;
+    toneMappedImage->width = width, toneMappedImage->height = height;
+    // avifRGBImageAllocatePixels, src/avif.c:719-737
+    free(toneMappedImage->pixels);
+    toneMappedImage->pixels = NULL, toneMappedImage->rowBytes = 0;
+    const uint32_t outPixelBytes = rgbPixelBytes(toneMappedImage);
+    if (!width || !height || width > UINT32_MAX / outPixelBytes)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const uint32_t outRowBytes = width * outPixelBytes;
+    toneMappedImage->pixels = (uint8_t *)malloc((size_t)outRowBytes * height);
+    if (!toneMappedImage->pixels)
+        return AVIF_RESULT_OUT_OF_MEMORY;
+    toneMappedImage->rowBytes = outRowBytes;
+
+    const float weight = gainMapWeight(hdrHeadroom, gainMap);
+    if (gainMapIsPlainCopy(baseImage, baseColorPrimaries, baseTransferCharacteristics, weight, outputColorPrimaries, outputTransferCharacteristics,
+                           toneMappedImage)) {
+        memcpy(toneMappedImage->pixels, baseImage->pixels, (size_t)baseImage->rowBytes * baseImage->height); // "Copy the base image", :124-127
+        return AVIF_RESULT_OK;
+    }
+    if (!baseImage->pixels || (weight != 0.0f && !gainMap->image))
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    // device copies: base pixels, gain map planes, tone-mapped pixels
+    avifRGBImage baseView, outView;
+    memcpy(&baseView, baseImage, sizeof(avifRGBImage));
+    memcpy(&outView, toneMappedImage, sizeof(avifRGBImage));
+    const uint32_t baseWidthBytes = width * rgbPixelBytes(baseImage);
+    baseView.rowBytes = alignUp(baseWidthBytes, 256);
+    avifResult r = reserve(tls.gainMap[5], (size_t)baseView.rowBytes * height);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    baseView.pixels = (uint8_t *)tls.gainMap[5].ptr;
+    HIP_TRY(hipMemcpy2DAsync(baseView.pixels, baseView.rowBytes, baseImage->pixels, baseImage->rowBytes, baseWidthBytes, height, hipMemcpyHostToDevice, tls.stream));
+    outView.rowBytes = alignUp(outRowBytes, 256);
+    r = reserve(tls.gainMap[0], (size_t)outView.rowBytes * height);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    outView.pixels = (uint8_t *)tls.gainMap[0].ptr;
+    avifImage gainView;
+    memset(&gainView, 0, sizeof(gainView));
+    if (weight != 0.0f) {
+        memcpy(&gainView, gainMap->image, sizeof(avifImage));
+        r = stagePlanes(&gainView, true, false);
+        if (r != AVIF_RESULT_OK)
+            return r;
+    }
+    r = applyGainMapOnDevice(&baseView, baseColorPrimaries, baseTransferCharacteristics, gainMap, &gainView, weight, outputColorPrimaries,
+                             outputTransferCharacteristics, &outView, clli, diag, tls.stream);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    HIP_TRY(hipMemcpy2DAsync(toneMappedImage->pixels, outRowBytes, outView.pixels, outView.rowBytes, outRowBytes, height, hipMemcpyDeviceToHost, tls.stream));
+    HIP_TRY(hipStreamSynchronize(tls.stream));
+    return AVIF_RESULT_OK;
+}
+
+// avifImageApplyGainMap, src/gainmap.c:317-355: the base image arrives as YUV
+extern "C" avifResult avifhipImageApplyGainMap(const avifImage * baseImage, const avifGainMap * gainMap, float hdrHeadroom,
+                                               avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
+                                               avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag)
+{
+    diagClear(diag);
+    if (!baseImage || !gainMap)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    // (ICC profiles, :328-331, live in the part of avifImage / avifGainMap this library does not read: the caller checks them)
+    avifRGBImage baseRgb; // avifRGBImageSetDefaults + avifRGBImageAllocatePixels, :333-335
+    memset(&baseRgb, 0, sizeof(baseRgb));
+    baseRgb.width = baseImage->width, baseRgb.height = baseImage->height, baseRgb.depth = baseImage->depth, baseRgb.format = AVIF_RGB_FORMAT_RGBA;
+    baseRgb.chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, baseRgb.chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
+    baseRgb.maxThreads = 1;
+    const uint32_t pixelBytes = rgbPixelBytes(&baseRgb);
+    if (!baseRgb.width || !baseRgb.height || baseRgb.width > UINT32_MAX / pixelBytes)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    baseRgb.rowBytes = baseRgb.width * pixelBytes;
+    baseRgb.pixels = (uint8_t *)malloc((size_t)baseRgb.rowBytes * baseRgb.height);
+    if (!baseRgb.pixels)
+        return AVIF_RESULT_OUT_OF_MEMORY;
+    avifResult r = avifhipImageYUVToRGB(baseImage, &baseRgb);
+    if (r == AVIF_RESULT_OK)
+        r = avifhipRGBImageApplyGainMap(&baseRgb, baseImage->colorPrimaries, baseImage->transferCharacteristics, gainMap, hdrHeadroom, outputColorPrimaries,
+                                        outputTransferCharacteristics, toneMappedImage, clli, diag);
+    free(baseRgb.pixels);
+    return r;
 }
 
 // =================================================================================================

@@ -124,4 +124,39 @@ struct SatoInputs // device table: the plane of every input image item
 };
 hipError_t launchSato(const SatoArgs & args, const SatoInputs * deviceInputs, hipStream_t stream);
 
+// Gain-map application (kernels_gainmap.hip; avifRGBImageApplyGainMap, reference src/gainmap.c:73-315): one lane per pixel.
+// All transcendentals arrive as host-built tables (gainmap_plan.h).
+struct GainMapPixelLayout // avifRGBColorSpaceInfo, src/reformat.c:32-117
+{
+    uint32_t channelBytes, pixelBytes, offR, offG, offB, offA;
+    int32_t hasAlpha, is565, isFloat;
+    uint32_t depth;
+    float maxF;
+};
+struct GainMapStats
+{
+    uint32_t maxBits; // bits of max(0, every tone-mapped linear value): rgbMaxLinear, src/gainmap.c:257-259
+    int32_t nan;      // a tone-mapped value was NaN, :277-281
+    double sum;       // sum over pixels of max(0, r, g, b): rgbSumLinear, :287
+};
+struct GainMapArgs
+{
+    const uint8_t * base;
+    uint8_t * out;
+    const uint8_t * gain; // the gain map as RGBA of gainDepth bits (avifRGBImageSetDefaults layout), or null: weight 0
+    uint32_t basePitch, outPitch, gainPitch, gainDepth;
+    GainMapPixelLayout baseL, outL;
+    uint32_t width, height;
+    const float * baseLut;  // linear light of every base sample code
+    const float * gainLut;  // 3 x (1 << gainDepth): exp2f(log2 gain * weight) per channel and gain-map sample code
+    const float * steps;    // output steps of the output transfer function: 2 pieces (x < 0, x >= 0) x (maxCode + 1) entries
+    uint32_t maxCode, nanCode;
+    int32_t convert;        // linearise, (convert primaries, apply the gain,) re-encode; 0: requantise the samples as they are
+    int32_t inConv, outConv;
+    double inM[9], outM[9]; // avifLinearRGBConvertColorSpace coefficients, row-major
+    float baseOffset[3], altOffset[3];
+    GainMapStats * stats;
+};
+hipError_t launchGainMapApply(const GainMapArgs & args, hipStream_t stream);
+
 } // namespace avifhip

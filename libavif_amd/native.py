@@ -10,7 +10,8 @@ import ctypes as C
 import os
 from pathlib import Path
 
-from .abi import AVIF_RESULT_OK, avifCropRect, avifImage, avifRGBImage
+from .abi import (AVIF_RESULT_OK, avifContentLightLevelInformationBox, avifCropRect, avifDiagnostics, avifGainMap, avifImage,
+                  avifRGBImage)
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libavifhip.so"
@@ -26,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
     "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
+    "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipImageApplyGainMap",
 ]
 
 class avifSampleTransformToken(C.Structure):
@@ -101,6 +103,12 @@ def load() -> C.CDLL:
         "avifhipImageScale": (i32, [P_IMG, u32, u32]),
         "avifhipImageScaleAsync": (i32, [P_IMG, P_IMG, vp]),
         "avifhipGridYUVToRGBAsync": (i32, [C.POINTER(avifhipGrid), C.POINTER(P_IMG), C.POINTER(P_IMG), i32, P_RGB, vp]),
+        "avifhipRGBImageApplyGainMap": (i32, [P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
+                                              C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics)]),
+        "avifhipRGBImageApplyGainMapAsync": (i32, [P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
+                                                   C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics), vp]),
+        "avifhipImageApplyGainMap": (i32, [P_IMG, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
+                                           C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

@@ -124,8 +124,9 @@ def cases(n_random: int, seed: int, sizes=((37, 21), (64, 33), (5, 3), (1, 1))) 
     out.append(GainMapCase(w0, h0, base_headroom=(3, 1), alt_headroom=(0, 1), headroom=1.0, gm_min=((-3, 1), (-2, 1), (-1, 1)), gm_max=((0, 1), (1, 2), (1, 1))))
     out.append(GainMapCase(w0, h0, gm_gamma=((1, 2), (2, 1), (22, 10)), base_offset=((0, 1), (1, 32), (-1, 128)), alt_offset=((1, 16), (0, 1), (1, 64))))
     out.append(GainMapCase(w0, h0, base_headroom=(1, 1), alt_headroom=(1, 1), out_tc=16))  # equal headrooms: weight 0
-    # degenerate metadata: exp2f overflows, the output matrix turns inf - inf into NaN -> AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE
-    out.append(GainMapCase(w0, h0, gm_max=((200, 1), (200, 1), (200, 1)), alt_headroom=(200, 1), headroom=200.0, out_primaries=9))
+    # degenerate metadata: exp2f overflows and 0 * inf is NaN -> AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE; overflow alone saturates
+    out.append(GainMapCase(w0, h0, gm_max=((2000, 1),) * 3, gm_min=((-2000, 1),) * 3, alt_headroom=(1, 1), headroom=1.0, out_primaries=9, base_offset=((0, 1),) * 3))
+    out.append(GainMapCase(w0, h0, gm_max=((200, 1),) * 3, alt_headroom=(200, 1), headroom=200.0, out_primaries=9))
     for _ in range(n_random):
         w, h = rnd.choice(sizes)
         bf = rnd.random() < 0.1

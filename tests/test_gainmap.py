@@ -62,3 +62,119 @@ def test_argument_errors():
     assert run(o.oracleRGBImageApplyGainMap, G.GainMapCase(8, 8, gm_gamma=((0, 1), (1, 1), (1, 1))), 0)[0] == abi.AVIF_RESULT_INVALID_ARGUMENT
     assert run(o.oracleRGBImageApplyGainMap, G.GainMapCase(8, 8, gm_min=((2, 1), (0, 1), (0, 1)), gm_max=((1, 1), (1, 1), (1, 1))), 0)[0] == abi.AVIF_RESULT_INVALID_ARGUMENT
     assert run(o.oracleRGBImageApplyGainMap, c, 0)[0] == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU: the product against the oracle
+
+
+def _compare_gpu(hip, cases, libyuv_build):
+    from libavif_amd import native
+
+    o = oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    bad, pall_off = [], 0
+    for c in cases:
+        ra, pa, ca = run(o.oracleRGBImageApplyGainMap, c, int(libyuv_build))
+        rb, pb, cb = run(hip.avifhipRGBImageApplyGainMap, c, C.byref(diag))
+        ok = ra == rb
+        if ok and ra == 0:
+            # every byte identical; maxCLL identical; maxPALL within one nit (fp32 running sum vs fp64 partial sums, include/avifhip.h)
+            ok = np.array_equal(pa, pb) and ca[0] == cb[0] and abs(ca[1] - cb[1]) <= 1
+            pall_off += int(ca[1] != cb[1])
+        if not ok:
+            bad.append(f"{c.ident()} [{native.last_kernel()}]: results {ra}/{rb} clli {ca}/{cb}" +
+                       ("" if ra or rb or pa is None or pb is None or np.array_equal(pa, pb) else
+                        f" {int((pa != pb).sum())} bytes differ, max |delta| {int(np.abs(pa.astype(int) - pb.astype(int)).max())}"))
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+    return pall_off
+
+
+@pytest.mark.gpu
+def test_gpu_equals_oracle_default_arithmetic(hip_auto_arithmetic):
+    """The library's default: the gain map's own YUV -> RGB conversion as a libavif built with libyuv computes it."""
+    off = _compare_gpu(hip_auto_arithmetic, G.cases(260, seed=2), libyuv_build=True)
+    assert off <= 6, off  # maxPALL off by one nit: rare
+
+
+@pytest.mark.gpu
+def test_gpu_equals_oracle_fp32_arithmetic(hip):
+    _compare_gpu(hip, G.cases(120, seed=3), libyuv_build=False)
+
+
+@pytest.mark.gpu
+def test_gpu_larger_images_and_16_bit_tables(hip_auto_arithmetic):
+    cases = [G.GainMapCase(1001, 333, base_depth=8, out_depth=8, gm_w=500, gm_h=167, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, out_tc=16, out_primaries=9),
+             G.GainMapCase(640, 360, base_depth=10, out_depth=10, base_tc=16, out_tc=13, base_primaries=9, out_primaries=1, headroom=1.0,
+                           base_headroom=(4, 1), alt_headroom=(0, 1), gm_min=((-4, 1),) * 3, gm_max=((0, 1),) * 3),
+             G.GainMapCase(515, 129, base_depth=16, out_depth=16, out_tc=18, gm_depth=10, gm_format=abi.AVIF_PIXEL_FORMAT_YUV444),
+             G.GainMapCase(515, 129, base_depth=8, out_depth=16, out_float=True, out_format=abi.AVIF_RGB_FORMAT_RGBA, out_tc=8),
+             G.GainMapCase(320, 200, base_depth=12, out_depth=12, headroom=0.0, out_tc=16, out_primaries=12)]
+    _compare_gpu(hip_auto_arithmetic, cases, libyuv_build=True)
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident(hip_auto_arithmetic):
+    """avifhipRGBImageApplyGainMapAsync: base pixels, gain-map planes and tone-mapped pixels in HBM."""
+    from libavif_amd import device, native
+
+    o = oracle_lib.oracle()
+    for c in G.cases(0, seed=4)[:60:3] + [G.GainMapCase(777, 211, gm_w=389, gm_h=106, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, out_tc=16, out_depth=10)]:
+        ra, pa, ca = run(o.oracleRGBImageApplyGainMap, c, 1)
+        base = G.make_base(c)
+        gm, keep = G.make_gain_map(c)
+        dbase = device.DeviceRGB(base, upload=True)
+        dgm_img = device.DeviceYUV(keep)
+        gm.image = C.pointer(dgm_img.struct)
+        out = abi.make_rgb(c.w, c.h, c.out_depth, c.out_format, is_float=c.out_float, avoid_libyuv=False)
+        dout = device.DeviceRGB(out, upload=True)
+        clli = abi.avifContentLightLevelInformationBox(0xFFFF, 0xFFFF)
+        diag = abi.avifDiagnostics()
+        rb = hip_auto_arithmetic.avifhipRGBImageApplyGainMapAsync(dbase.struct, c.base_primaries, c.base_tc, C.byref(gm), c.headroom, c.out_primaries,
+                                                                 c.out_tc, dout.struct, C.byref(clli), C.byref(diag), None)
+        assert ra == rb, (c.ident(), ra, rb, diag.error)
+        if ra == 0:
+            dout.download_into_host()
+            wb = c.w * abi.rgb_pixel_size(c.out_format, c.out_depth)
+            assert np.array_equal(out.pixels[:, :wb], pa[:, :wb]), (c.ident(), native.last_kernel())
+            assert clli.maxCLL == ca[0] and abs(clli.maxPALL - ca[1]) <= 1, (c.ident(), ca, (clli.maxCLL, clli.maxPALL))
+
+
+@pytest.mark.gpu
+def test_gpu_argument_errors(hip):
+    diag = abi.avifDiagnostics()
+    fn = hip.avifhipRGBImageApplyGainMap
+    assert run(fn, G.GainMapCase(8, 8, headroom=-1.0), C.byref(diag))[0] == abi.AVIF_RESULT_INVALID_ARGUMENT
+    assert b"hdrHeadroom" in diag.error
+    assert run(fn, G.GainMapCase(8, 8, gm_gamma=((0, 1), (1, 1), (1, 1))), C.byref(diag))[0] == abi.AVIF_RESULT_INVALID_ARGUMENT
+    assert run(fn, G.GainMapCase(8, 8, gm_min=((2, 1), (0, 1), (0, 1)), gm_max=((1, 1), (1, 1), (1, 1))), C.byref(diag))[0] == abi.AVIF_RESULT_INVALID_ARGUMENT
+    nan_case = G.GainMapCase(37, 21, gm_max=((2000, 1),) * 3, gm_min=((-2000, 1),) * 3, alt_headroom=(1, 1), headroom=1.0, out_primaries=9, base_offset=((0, 1),) * 3)
+    assert run(fn, nan_case, C.byref(diag))[0] == abi.AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE
+
+
+@pytest.mark.gpu
+def test_gpu_yuv_base_image(hip_auto_arithmetic):
+    """avifhipImageApplyGainMap (reference avifImageApplyGainMap, src/gainmap.c:317-355): the base image arrives as YUV."""
+    import harness as H
+
+    o = oracle_lib.oracle()
+    for c, yc in [(G.GainMapCase(320, 180, base_tc=13, base_primaries=1, out_tc=16, out_primaries=9, out_depth=10, gm_w=160, gm_h=90),
+                   H.Y2RCase(320, 180, yuv_depth=8, yuv_format=3, yuv_range=1, matrix=6, avoid_libyuv=False)),
+                  (G.GainMapCase(201, 77, base_depth=10, base_tc=14, base_primaries=9, out_tc=13, out_primaries=1, out_depth=8, headroom=1.0),
+                   H.Y2RCase(201, 77, yuv_depth=10, yuv_format=1, yuv_range=0, matrix=9, avoid_libyuv=False))]:
+        img = H.make_y2r_inputs(yc)
+        img.struct.colorPrimaries, img.struct.transferCharacteristics = c.base_primaries, c.base_tc
+        base = abi.make_rgb(c.w, c.h, yc.yuv_depth, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+        assert o.oracleLibyuvImageYUVToRGB(img.struct, base.struct) == 0
+        gm, keep = G.make_gain_map(c)
+        want, got = G.make_output(c), G.make_output(c)
+        clli_a, clli_b = abi.avifContentLightLevelInformationBox(), abi.avifContentLightLevelInformationBox()
+        diag = abi.avifDiagnostics()
+        assert o.oracleRGBImageApplyGainMap(base.struct, c.base_primaries, c.base_tc, C.byref(gm), c.headroom, c.out_primaries, c.out_tc, want.struct,
+                                            C.byref(clli_a), 1) == 0
+        assert hip_auto_arithmetic.avifhipImageApplyGainMap(img.struct, C.byref(gm), c.headroom, c.out_primaries, c.out_tc, got.struct, C.byref(clli_b),
+                                                            C.byref(diag)) == 0, diag.error
+        assert np.array_equal(G.output_bytes(want), G.output_bytes(got)), c.ident()
+        assert clli_a.maxCLL == clli_b.maxCLL and abs(clli_a.maxPALL - clli_b.maxPALL) <= 1
+        libc.free(C.cast(want.struct.pixels, C.c_void_p))
+        libc.free(C.cast(got.struct.pixels, C.c_void_p))
