@@ -53,7 +53,7 @@ struct GainMapTableCache
         uint64_t stream;
     } key;
     size_t baseLutOffset = 0, gainLutOffset = 0, stepsOffset = 0; // in floats
-    uint32_t maxCode = 0, nanCode = 0;
+    uint32_t maxCode = 0, nanCode = 0, stepEntries = 0;
 };
 
 // One context per calling thread: libavif's reformat functions are re-entrant and may be called
@@ -1247,7 +1247,7 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
             cache.stepsOffset = tables.size();
             const GainMapSteps & S = gainMapOutputSteps(outTC, key.outDepth, out->isFloat != 0);
             tables.insert(tables.end(), S.steps.begin(), S.steps.end());
-            cache.maxCode = S.maxCode;
+            cache.maxCode = S.maxCode, cache.stepEntries = S.pieceEntries;
             // what the reference computes for a NaN input (the weight-0 path can meet one in a half-float base image)
             const float nanGamma = fminf(1.0f, fmaxf(0.0f, gainMapToGamma(outTC, NAN)));
             cache.nanCode = out->isFloat ? ((uint32_t)0) : (uint32_t)(0.5f + nanGamma * (float)((1u << key.outDepth) - 1));
@@ -1268,13 +1268,22 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         }
         const float * t = (const float *)tls.gainMap[2].ptr;
         A.baseLut = t + cache.baseLutOffset, A.gainLut = t + cache.gainLutOffset, A.steps = t + cache.stepsOffset;
-        A.maxCode = cache.maxCode, A.nanCode = cache.nanCode;
+        A.maxCode = cache.maxCode, A.nanCode = cache.nanCode, A.stepEntries = cache.stepEntries;
+        // the kernel keeps the tables in LDS when all of them fit (up to 12-bit images; 16-bit and half-float tables stay in
+        // global memory)
+        const size_t stepsEntries = 2 * (size_t)cache.stepEntries, baseEntries = cache.gainLutOffset - cache.baseLutOffset,
+                     gainEntries = cache.stepsOffset - cache.gainLutOffset;
+        if ((stepsEntries + baseEntries + gainEntries) * sizeof(float) <= 64 * 1024)
+            A.ldsSteps = (uint32_t)stepsEntries, A.ldsBaseLut = (uint32_t)baseEntries, A.ldsGainLut = (uint32_t)gainEntries;
     }
 
-    const avifResult sr = reserve(tls.gainMap[3], sizeof(GainMapStats));
+    const size_t partials = kGainMapMaxGroups;
+    const avifResult sr = reserve(tls.gainMap[3], 64 + partials * (sizeof(double) + sizeof(float)));
     if (sr != AVIF_RESULT_OK)
         return sr;
     A.stats = (GainMapStats *)tls.gainMap[3].ptr;
+    A.blockSum = (double *)((uint8_t *)tls.gainMap[3].ptr + 64);
+    A.blockMax = (float *)(A.blockSum + partials);
     HIP_TRY(hipMemsetAsync(A.stats, 0, sizeof(GainMapStats), stream));
     const hipError_t e = launchGainMapApply(A, stream);
     if (e != hipSuccess)

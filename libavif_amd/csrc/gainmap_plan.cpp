@@ -357,12 +357,17 @@ const GainMapSteps & gainMapOutputSteps(int tc, uint32_t depth, bool isFloat)
     };
     // Two pieces, x < 0 and x >= 0, each monotone for every curve (BT.1361's negative branch ends ABOVE its value at +0,
     // src/colr.c:352-365, so one table over all of fp32 would not be a step function): piece p occupies
-    // steps[p * (maxCode + 1) ...], unreachable codes keep +inf.
-    const uint32_t n = S.maxCode + 1;
-    S.steps.assign((size_t)2 * n, INFINITY);
+    // steps[p * pieceEntries ...], unreachable codes keep +inf.
+    uint32_t n = 1;
+    while (n < S.maxCode + 1)
+        n <<= 1; // a power of two per piece (branch-free halving search); entries past maxCode are NaN: never <= x
+    S.pieceEntries = n;
+    S.steps.assign((size_t)2 * n, NAN);
     const uint32_t pieceLo[2] = { keyOfFloat(-INFINITY), keyOfFloat(0.0f) }, pieceHi[2] = { keyOfFloat(-0.0f) - 1, keyOfFloat(INFINITY) };
     for (int p = 0; p < 2; ++p) {
         float * T = S.steps.data() + (size_t)p * n;
+        for (uint32_t k = 1; k <= S.maxCode; ++k)
+            T[k] = INFINITY;
         T[0] = -INFINITY;
         uint32_t lowKey = pieceLo[p]; // steps are non-decreasing in k: each search starts where the previous one ended
         for (uint32_t k = 1; k <= S.maxCode; ++k) {

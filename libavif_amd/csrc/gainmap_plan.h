@@ -32,15 +32,15 @@ std::vector<float> gainMapLinearLut(int transferCharacteristics, uint32_t depth,
 // exp2f(lerp(minLog2, maxLog2, powf(v / max, gammaInv)) * weight) for every sample code of the gain map, src/gainmap.c:253-254
 std::vector<float> gainMapGainLut(uint32_t depth, float gammaInv, float minLog2, float maxLog2, float weight);
 
-// Output steps of a transfer function, in two pieces (x < 0: steps[0 .. maxCode]; x >= 0: steps[maxCode + 1 .. 2 maxCode + 1];
-// within each the quantised function is monotone): T[k], k = 1 .. maxCode, is the smallest fp32 x of the piece whose code
+// Output steps of a transfer function, in two pieces of pieceEntries (a power of two >= maxCode + 1) entries (x < 0 first, then
+// x >= 0; within each the quantised function is monotone; entries past maxCode are NaN): T[k], k = 1 .. maxCode, is the smallest fp32 x of the piece whose code
 // quantise(nanSafeClamp(linearToGamma(x))) is >= k; +inf when no x of the piece reaches k.  T[0] = -inf.  Integer outputs: code =
 // (uint)(0.5f + v * (2^depth - 1)), maxCode = 2^depth - 1; half-float outputs: code = bits(v * 2^-112) >> 13, maxCode =
 // 0x3c00 (1.0).  Cached; the returned pointer stays valid for the life of the process.
 struct GainMapSteps
 {
     std::vector<float> steps;
-    uint32_t maxCode = 0;
+    uint32_t maxCode = 0, pieceEntries = 0;
 };
 const GainMapSteps & gainMapOutputSteps(int transferCharacteristics, uint32_t depth, bool isFloat);
 

@@ -149,14 +149,18 @@ struct GainMapArgs
     uint32_t width, height;
     const float * baseLut;  // linear light of every base sample code
     const float * gainLut;  // 3 x (1 << gainDepth): exp2f(log2 gain * weight) per channel and gain-map sample code
-    const float * steps;    // output steps of the output transfer function: 2 pieces (x < 0, x >= 0) x (maxCode + 1) entries
-    uint32_t maxCode, nanCode;
+    const float * steps;    // output steps of the output transfer function: 2 pieces (x < 0, x >= 0) x stepEntries
+    uint32_t maxCode, nanCode, stepEntries; // stepEntries: entries per piece of `steps`, a power of two
+    uint32_t ldsSteps, ldsBaseLut, ldsGainLut; // entries of the tables when the kernel is to keep ALL of them in LDS, else all 0
     int32_t convert;        // linearise, (convert primaries, apply the gain,) re-encode; 0: requantise the samples as they are
     int32_t inConv, outConv;
     double inM[9], outM[9]; // avifLinearRGBConvertColorSpace coefficients, row-major
     float baseOffset[3], altOffset[3];
     GainMapStats * stats;
+    float * blockMax;   // one partial per workgroup (kGainMapMaxGroups entries each)
+    double * blockSum;
 };
+constexpr uint32_t kGainMapMaxGroups = 4096; // persistent workgroups of the apply kernel
 hipError_t launchGainMapApply(const GainMapArgs & args, hipStream_t stream);
 
 } // namespace avifhip

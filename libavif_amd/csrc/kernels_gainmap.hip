@@ -12,7 +12,6 @@ namespace avifhip {
 namespace {
 
 constexpr float kF16Multiplier = 1.9259299444e-34f; // src/reformat.c:1411
-constexpr uint32_t kStepsInLds = 8192; // both pieces of a 12-bit output
 
 __device__ __forceinline__ float f16ToFloat(uint32_t code) // avifF16ToFloat, src/reformat.c:1849-1854
 {
@@ -23,10 +22,22 @@ __device__ __forceinline__ uint32_t floatToF16(float v) // avifFloatToF16, :1842
     return (__float_as_uint(v * kF16Multiplier) >> 13) & 0xffffu;
 }
 
-// the three colour sample codes and alpha of pixel p (avifGetRGBAPixel, :1856-1897); alpha as the float the reference carries
-__device__ __forceinline__ void readPixel(const uint8_t * p, const GainMapPixelLayout & L, uint32_t code[3], float & alpha)
+// the three colour sample codes and alpha of pixel p (avifGetRGBAPixel, :1856-1897); alpha as the float the reference carries.
+// `vector`: 4-channel pixels at naturally aligned addresses are moved with one 4- or 8-byte access (the per-channel
+// accesses of the general path cost one vector-memory instruction each)
+__device__ __forceinline__ void readPixel(const uint8_t * p, const GainMapPixelLayout & L, bool vector, uint32_t code[3], float & alpha)
 {
-    if (L.channelBytes > 1) {
+    if (vector && L.pixelBytes == 4) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+        code[0] = (w >> (8 * L.offR)) & 0xff, code[1] = (w >> (8 * L.offG)) & 0xff, code[2] = (w >> (8 * L.offB)) & 0xff;
+        alpha = (float)((w >> (8 * L.offA)) & 0xff) / L.maxF;
+    } else if (vector && L.pixelBytes == 8) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(p);
+        auto pick = [&](uint32_t off) -> uint32_t { return (((off & 4) ? w.y : w.x) >> (8 * (off & 3))) & 0xffff; };
+        code[0] = pick(L.offR), code[1] = pick(L.offG), code[2] = pick(L.offB);
+        const uint32_t a = pick(L.offA);
+        alpha = L.isFloat ? f16ToFloat(a) : (float)a / L.maxF;
+    } else if (L.channelBytes > 1) {
         code[0] = *reinterpret_cast<const uint16_t *>(p + L.offR), code[1] = *reinterpret_cast<const uint16_t *>(p + L.offG);
         code[2] = *reinterpret_cast<const uint16_t *>(p + L.offB);
         const uint32_t a = L.hasAlpha ? *reinterpret_cast<const uint16_t *>(p + L.offA) : ((1u << L.depth) - 1);
@@ -52,9 +63,23 @@ __device__ __forceinline__ uint32_t quantise(float v, const GainMapPixelLayout &
     return (uint32_t)(int32_t)(0.5f + (v * L.maxF)) & mask;
 }
 
-__device__ __forceinline__ void writePixel(uint8_t * p, const GainMapPixelLayout & L, const uint32_t code[3], uint32_t alphaCode)
+__device__ __forceinline__ void writePixel(uint8_t * p, const GainMapPixelLayout & L, bool vector, const uint32_t code[3], uint32_t alphaCode)
 {
-    if (L.channelBytes > 1) {
+    if (vector && L.pixelBytes == 4) {
+        *reinterpret_cast<uint32_t *>(p) = ((code[0] & 0xff) << (8 * L.offR)) | ((code[1] & 0xff) << (8 * L.offG)) | ((code[2] & 0xff) << (8 * L.offB)) |
+                                           ((alphaCode & 0xff) << (8 * L.offA));
+    } else if (vector && L.pixelBytes == 8) {
+        uint2 w = { 0, 0 };
+        auto place = [&](uint32_t off, uint32_t v) {
+            const uint32_t s = (v & 0xffff) << (8 * (off & 3));
+            if (off & 4)
+                w.y |= s;
+            else
+                w.x |= s;
+        };
+        place(L.offR, code[0]), place(L.offG, code[1]), place(L.offB, code[2]), place(L.offA, alphaCode);
+        *reinterpret_cast<uint2 *>(p) = w;
+    } else if (L.channelBytes > 1) {
         *reinterpret_cast<uint16_t *>(p + L.offR) = (uint16_t)code[0], *reinterpret_cast<uint16_t *>(p + L.offG) = (uint16_t)code[1];
         *reinterpret_cast<uint16_t *>(p + L.offB) = (uint16_t)code[2];
         if (L.hasAlpha)
@@ -76,77 +101,109 @@ __device__ __forceinline__ void convertPrimaries(float v[3], const double M[9])
     v[0] = (float)r0, v[1] = (float)r1, v[2] = (float)r2;
 }
 
-// the output code of linear value x: the largest k with steps[k] <= x in the piece (x < 0, x >= 0) x belongs to
-__device__ __forceinline__ uint32_t codeOf(float x, const float * steps, uint32_t maxCode, uint32_t nanCode)
+// The output codes of three linear values: for each the largest k with steps[k] <= x in the piece (x < 0, x >= 0) x belongs
+// to.  Each piece has `entries` (a power of two) steps, steps[0] = -inf, NaN past the last code: a halving search without
+// branches, the three channels' (independent) chains of LDS reads advancing together.
+__device__ __forceinline__ void codesOf(const float x[3], const float * steps, uint32_t entries, uint32_t nanCode, uint32_t code[3])
 {
-    if (x != x)
-        return nanCode;
-    if (!(x < 0.0f))
-        steps += maxCode + 1;
-    uint32_t lo = 0, hi = maxCode;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (steps[mid] <= x)
-            lo = mid;
-        else
-            hi = mid - 1;
+    uint32_t pos[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        pos[c] = (x[c] < 0.0f) ? 0 : entries;
+    for (uint32_t s = entries >> 1; s; s >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            pos[c] += (steps[pos[c] + s] <= x[c]) ? s : 0;
     }
-    return lo;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        code[c] = (x[c] != x[c]) ? nanCode : (pos[c] & (entries - 1));
 }
 
-__global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A)
+// Persistent workgroups walking tiles of 64 x 4 pixels with a grid stride.  LDS_TABLES: the three tables (steps, base lookup,
+// gain lookup) are copied to LDS once per workgroup and addressed as LDS -- a pointer that may be either LDS or global memory
+// compiles to flat loads, which the searches cannot afford; the host picks this variant when everything fits (api.cpp).
+template <bool LDS_TABLES>
+__global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_t tilesX, uint32_t tiles)
 {
-    __shared__ float ldsSteps[kStepsInLds];
-    const bool stepsInLds = A.convert && (2 * (A.maxCode + 1) <= kStepsInLds);
-    if (stepsInLds) {
-        for (uint32_t k = threadIdx.y * 64 + threadIdx.x; k < 2 * (A.maxCode + 1); k += 256)
-            ldsSteps[k] = A.steps[k];
+    extern __shared__ float ldsTables[];
+    const float * steps = A.steps;
+    const float * baseLut = A.baseLut;
+    const float * gainLut = A.gainLut;
+    if constexpr (LDS_TABLES) {
+        const uint32_t t = threadIdx.y * 64 + threadIdx.x;
+        for (uint32_t k = t; k < A.ldsSteps; k += 256)
+            ldsTables[k] = A.steps[k];
+        for (uint32_t k = t; k < A.ldsBaseLut; k += 256)
+            ldsTables[A.ldsSteps + k] = A.baseLut[k];
+        for (uint32_t k = t; k < A.ldsGainLut; k += 256)
+            ldsTables[A.ldsSteps + A.ldsBaseLut + k] = A.gainLut[k];
         __syncthreads();
+        steps = ldsTables, baseLut = ldsTables + A.ldsSteps, gainLut = ldsTables + A.ldsSteps + A.ldsBaseLut;
     }
-    const float * steps = stepsInLds ? ldsSteps : A.steps;
+    const bool baseVector = A.baseL.hasAlpha && (((uintptr_t)A.base | A.basePitch) & (A.baseL.pixelBytes - 1)) == 0;
+    const bool outVector = A.outL.hasAlpha && (((uintptr_t)A.out | A.outPitch) & (A.outL.pixelBytes - 1)) == 0;
+    const uint32_t gainPixelBytes = 4 * ((A.gainDepth > 8) ? 2 : 1);
+    const bool gainVector = A.gain && (((uintptr_t)A.gain | A.gainPitch) & (gainPixelBytes - 1)) == 0;
 
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
-    const bool inside = i < A.width && j < A.height;
-    float pixelMax = 0.0f, toneMax = 0.0f;
+    float toneMax = 0.0f; // statistics of this lane over all its pixels
+    double sum = 0.0;
     bool sawNan = false;
-    if (inside) {
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t i = (tile % tilesX) * 64 + threadIdx.x, j = (tile / tilesX) * 4 + threadIdx.y;
+        if (i >= A.width || j >= A.height)
+            continue;
         uint32_t code[3];
         float alpha;
-        readPixel(A.base + (size_t)j * A.basePitch + (size_t)i * A.baseL.pixelBytes, A.baseL, code, alpha);
+        readPixel(A.base + (size_t)j * A.basePitch + (size_t)i * A.baseL.pixelBytes, A.baseL, baseVector, code, alpha);
         uint32_t outCode[3];
         if (!A.convert) { // :155-166 without a change of transfer function or primaries
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 outCode[c] = quantise(A.baseL.isFloat ? f16ToFloat(code[c]) : (float)code[c] / A.baseL.maxF, A.outL);
         } else {
-            float v[3] = { A.baseLut[code[0]], A.baseLut[code[1]], A.baseLut[code[2]] };
+            float v[3] = { baseLut[code[0]], baseLut[code[1]], baseLut[code[2]] };
             if (A.inConv)
                 convertPrimaries(v, A.inM);
             if (A.gain) { // :236-270
-                const uint8_t * g = A.gain + (size_t)j * A.gainPitch + (size_t)i * 4 * ((A.gainDepth > 8) ? 2 : 1);
+                const uint8_t * g = A.gain + (size_t)j * A.gainPitch + (size_t)i * gainPixelBytes;
                 const uint32_t n = 1u << A.gainDepth;
+                uint32_t gcode[3];
+                if (gainVector && A.gainDepth <= 8) {
+                    const uint32_t w = *reinterpret_cast<const uint32_t *>(g);
+                    gcode[0] = w & 0xff, gcode[1] = (w >> 8) & 0xff, gcode[2] = (w >> 16) & 0xff;
+                } else if (gainVector) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(g);
+                    gcode[0] = w.x & 0xffff, gcode[1] = w.x >> 16, gcode[2] = w.y & 0xffff;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        gcode[c] = (A.gainDepth > 8) ? reinterpret_cast<const uint16_t *>(g)[c] : g[c];
+                }
+                float pixelMax = 0.0f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const uint32_t gc = (A.gainDepth > 8) ? reinterpret_cast<const uint16_t *>(g)[c] : g[c];
-                    const float tone = (v[c] + A.baseOffset[c]) * A.gainLut[c * n + min(gc, n - 1)] - A.altOffset[c];
+                    const float tone = (v[c] + A.baseOffset[c]) * gainLut[c * n + min(gcode[c], n - 1)] - A.altOffset[c];
                     if (tone > toneMax)
                         toneMax = tone;
                     if (tone > pixelMax)
                         pixelMax = tone;
                     v[c] = tone;
                 }
+                sum += (double)pixelMax;
                 if (A.outConv)
                     convertPrimaries(v, A.outM);
-                sawNan = (v[0] != v[0]) || (v[1] != v[1]) || (v[2] != v[2]);
+                sawNan = sawNan || (v[0] != v[0]) || (v[1] != v[1]) || (v[2] != v[2]);
             }
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                outCode[c] = codeOf(v[c], steps, A.maxCode, A.nanCode);
+            codesOf(v, steps, A.stepEntries, A.nanCode, outCode);
         }
-        writePixel(A.out + (size_t)j * A.outPitch + (size_t)i * A.outL.pixelBytes, A.outL, outCode, A.outL.hasAlpha ? quantise(alpha, A.outL) : 0);
+        writePixel(A.out + (size_t)j * A.outPitch + (size_t)i * A.outL.pixelBytes, A.outL, outVector, outCode, A.outL.hasAlpha ? quantise(alpha, A.outL) : 0);
     }
-    if (A.gain) { // wave-level reduction, then one atomic per wave and statistic
-        double sum = (double)pixelMax;
+    if (A.gain) {
+        // statistics: wave reduction -> block reduction through LDS -> one partial per workgroup (no atomics: one atomic per
+        // wave on a single address cost 3 ms on a 4K image), summed by gainMapReduceKernel in a fixed order
+        __shared__ float waveMaxima[4];
+        __shared__ double waveSums[4];
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) {
             toneMax = fmaxf(toneMax, __shfl_xor(toneMax, m));
@@ -154,11 +211,40 @@ __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A)
         }
         const unsigned long long nanLanes = __ballot(sawNan);
         if (threadIdx.x == 0) {
-            atomicMax(&A.stats->maxBits, __float_as_uint(toneMax));
-            atomicAdd(&A.stats->sum, sum);
+            waveMaxima[threadIdx.y] = toneMax, waveSums[threadIdx.y] = sum;
             if (nanLanes)
                 atomicOr(&A.stats->nan, 1);
         }
+        __syncthreads();
+        if (threadIdx.x == 0 && threadIdx.y == 0) {
+            A.blockMax[blockIdx.x] = fmaxf(fmaxf(waveMaxima[0], waveMaxima[1]), fmaxf(waveMaxima[2], waveMaxima[3]));
+            A.blockSum[blockIdx.x] = ((waveSums[0] + waveSums[1]) + waveSums[2]) + waveSums[3];
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void gainMapReduceKernel(GainMapStats * stats, const float * blockMax, const double * blockSum, uint32_t blocks)
+{
+    __shared__ float maxima[1024];
+    __shared__ double sums[1024];
+    float m = 0.0f;
+    double s = 0.0;
+    for (uint32_t k = threadIdx.x; k < blocks; k += 1024) {
+        m = fmaxf(m, blockMax[k]);
+        s += blockSum[k];
+    }
+    maxima[threadIdx.x] = m, sums[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t half = 512; half > 0; half >>= 1) {
+        if (threadIdx.x < half) {
+            maxima[threadIdx.x] = fmaxf(maxima[threadIdx.x], maxima[threadIdx.x + half]);
+            sums[threadIdx.x] += sums[threadIdx.x + half];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats->maxBits = __float_as_uint(maxima[0]);
+        stats->sum = sums[0];
     }
 }
 
@@ -168,8 +254,15 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream)
 {
     if (!A.width || !A.height)
         return hipSuccess;
-    const dim3 grid((A.width + 63) / 64, (A.height + 3) / 4), block(64, 4);
-    hipLaunchKernelGGL(gainMapApplyKernel, grid, block, 0, stream, A);
+    const uint32_t tilesX = (A.width + 63) / 64, tiles = tilesX * ((A.height + 3) / 4);
+    const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
+    const size_t lds = (size_t)(A.ldsSteps + A.ldsBaseLut + A.ldsGainLut) * sizeof(float);
+    if (lds)
+        hipLaunchKernelGGL(gainMapApplyKernel<true>, dim3(groups), dim3(64, 4), lds, stream, A, tilesX, tiles);
+    else
+        hipLaunchKernelGGL(gainMapApplyKernel<false>, dim3(groups), dim3(64, 4), 0, stream, A, tilesX, tiles);
+    if (A.gain)
+        hipLaunchKernelGGL(gainMapReduceKernel, dim3(1), dim3(1024), 0, stream, A.stats, A.blockMax, A.blockSum, groups);
     return hipGetLastError();
 }
 

@@ -136,6 +136,58 @@ def run(name):
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
             px, bpp, ms = 64 * 1920 * 1080, (11.0 if rgb_depth == 10 else 7.0), best
+        elif name in ("gainmap4k", "gainmap4k_half", "gainmap4k_cpu"):
+            # avifRGBImageApplyGainMap: 3840x2160 RGBA8 sRGB BT.709 base -> RGBA10 PQ BT.2020 HDR rendition, 8-bit 4:4:4 gain map of the
+            # same size (or 4:2:0 at half size, rescaled on the device first).  Algorithmic bytes: base 4 + gain-map planes + output 8.
+            if arith == "integer":
+                continue
+            import ctypes
+            half = name == "gainmap4k_half"
+            w, h = 3840, 2160
+            base = abi.make_rgb(w, h, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+            synth.fill_rgb(base, 0x4242)
+            gimg = abi.make_yuv(w // 2 if half else w, h // 2 if half else h, 8, abi.AVIF_PIXEL_FORMAT_YUV420 if half else abi.AVIF_PIXEL_FORMAT_YUV444,
+                                abi.AVIF_RANGE_FULL, 6)
+            synth.fill_yuv(gimg, 0x99)
+            gm = abi.avifGainMap()
+            for i in range(3):
+                gm.gainMapMin[i].n, gm.gainMapMin[i].d = 0, 1
+                gm.gainMapMax[i].n, gm.gainMapMax[i].d = 3, 1
+                gm.gainMapGamma[i].n, gm.gainMapGamma[i].d = 1, 1
+                gm.baseOffset[i].n, gm.baseOffset[i].d = 1, 64
+                gm.alternateOffset[i].n, gm.alternateOffset[i].d = 1, 64
+            gm.baseHdrHeadroom.n, gm.baseHdrHeadroom.d, gm.alternateHdrHeadroom.n, gm.alternateHdrHeadroom.d = 0, 1, 3, 1
+            gm.useBaseColorSpace = 1
+            clli, diag = abi.avifContentLightLevelInformationBox(), abi.avifDiagnostics()
+            gain_bytes = (w * h * 3) if not half else (w * h * 3 // 8)
+            px, bpp = w * h, (4 * w * h + gain_bytes + 8 * w * h) / (w * h)
+            if name == "gainmap4k_cpu":
+                # the oracle (= the reference's arithmetic, one thread) on this host, for the ratio
+                sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+                import oracle_lib
+                o = oracle_lib.oracle()
+                gm.image = C.pointer(gimg.struct)
+                tone = abi.make_rgb(w, h, 10, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False, allocate=False)
+                t0 = time.perf_counter()
+                assert o.oracleRGBImageApplyGainMap(base.struct, 1, 13, C.byref(gm), 3.0, 9, 16, tone.struct, C.byref(clli), 1) == 0
+                ms = (time.perf_counter() - t0) * 1e3
+                ctypes.CDLL(None).free(ctypes.c_void_p(tone.struct.pixels))
+            else:
+                dbase, dgimg = device.DeviceRGB(base, upload=True), device.DeviceYUV(gimg)
+                gm.image = C.pointer(dgimg.struct)
+                tone = abi.make_rgb(w, h, 10, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False, allocate=False)
+                dout = device.DeviceRGB(tone)
+                call = lambda: native.check(lib.avifhipRGBImageApplyGainMapAsync(dbase.struct, 1, 13, C.byref(gm), 3.0, 9, 16, dout.struct, C.byref(clli),
+                                                                                 C.byref(diag), None))
+                for _ in range(3):
+                    call()
+                best = 1e9
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        call()  # waits for its stream: result code and CLLI depend on the pixels
+                    best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+                ms = best
         else:
             raise SystemExit(f"unknown configuration {name}")
         gbps = bpp * px / (ms * 1e-3) / 1e9
