@@ -85,6 +85,7 @@ def _bind_libavif(lib: C.CDLL) -> C.CDLL:
         lib.avifRGBImageApplyGainMap.restype = C.c_int
         lib.avifRGBImageApplyGainMap.argtypes = [_P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, _P_RGB,
                                                  C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics)]
+    if hasattr(lib, "avifColorPrimariesComputeRGBToRGBMatrix"):
         lib.avifColorPrimariesComputeRGBToRGBMatrix.restype = C.c_int
         lib.avifColorPrimariesComputeRGBToRGBMatrix.argtypes = [C.c_uint16, C.c_uint16, C.POINTER(C.c_double * 9)]
     if hasattr(lib, "avifImageCopySamples"):

@@ -55,6 +55,26 @@ def test_primaries_matrices_equal_reference():
                 assert list(ma) == list(mb), (a, b)
 
 
+@pytest.mark.skipif(oracle_lib.pillow() is None, reason="Pillow's bundled libavif (built with libyuv) not present")
+def test_oracle_libyuv_build_equals_libyuv_enabled_binary():
+    """The default-build flavour of the oracle (the gain map's own YUV -> RGB conversion and rescaling as a libavif built WITH
+    libyuv computes them) against the only libyuv-enabled libavif binary available offline (Pillow's, libavif 1.4.1)."""
+    pil, o = oracle_lib.pillow(), oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    bad = []
+    cases = G.cases(250, seed=5)
+    for c in cases:
+        if c.gm_depth > 8 and (c.gm_w or c.w, c.gm_h or c.h) != (c.w, c.h):
+            continue  # that binary rescales with libyuv 1922's own ScalePlane_12, not with the scaler vendored in the reference tree
+        ra, pa, ca = run(pil.avifRGBImageApplyGainMap, c, C.byref(diag))
+        rb, pb, cb = run(o.oracleRGBImageApplyGainMap, c, 1)
+        if rb == abi.AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE:
+            continue  # the NaN check (src/gainmap.c:277-281) is newer than libavif 1.4.1
+        if ra != rb or (ra == 0 and (not np.array_equal(pa, pb) or ca != cb)):
+            bad.append(f"{c.ident()}: results {ra}/{rb} clli {ca}/{cb}")
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+
+
 def test_argument_errors():
     o = oracle_lib.oracle()
     c = G.GainMapCase(8, 8)
