@@ -2,7 +2,7 @@
  * avif_preload_hip.c -- seam A: an LD_PRELOAD-able interposer for applications that link a SHARED libavif and cannot be
  * rebuilt.  It exports the four public reformat entry points of include/avif/avif.h:1031-1038
  *     avifImageYUVToRGB, avifImageRGBToYUV, avifRGBImagePremultiplyAlpha, avifRGBImageUnpremultiplyAlpha
- * with libavif's own signatures, serves them from libavifhip.so (the MI355X HIP kernels), and forwards to the real
+ * and the tone-mapping entry point avifRGBImageApplyGainMap (:1736-1745) with libavif's own signatures, serves them from libavifhip.so (the MI355X HIP kernels), and forwards to the real
  * libavif (dlsym(RTLD_NEXT)) everything that is not worth a GPU round trip, that the GPU library declines, or that fails
  * on the accelerator -- the application's call never fails because of the interposer.
  *
@@ -10,7 +10,7 @@
  *
  * Arithmetic follows the libavif being interposed: if it was built with libyuv (avifLibYUVVersion() != 0) results equal
  * that build's (libavifhip's default, AVIFHIP_ARITHMETIC_AUTO); if it was built without, the fp32 arithmetic is pinned.
- * AVIFHIP_ARITHMETIC in the environment overrides.  Only the four symbols above are interposed; calls libavif makes
+ * AVIFHIP_ARITHMETIC in the environment overrides.  Only the five symbols above are interposed; calls libavif makes
  * internally (e.g. avifImageYUVToRGB from its decoder helpers) are bound inside libavif and are not affected.
  */
 #define _GNU_SOURCE
@@ -26,6 +26,8 @@ typedef avifResult (*YuvToRgbFn)(const avifImage *, avifRGBImage *);
 typedef avifResult (*RgbToYuvFn)(avifImage *, const avifRGBImage *);
 typedef avifResult (*AlphaFn)(avifRGBImage *);
 typedef unsigned int (*VersionFn)(void);
+typedef avifResult (*GainMapFn)(const avifRGBImage *, avifColorPrimaries, avifTransferCharacteristics, const avifGainMap *, float, avifColorPrimaries,
+                                avifTransferCharacteristics, avifRGBImage *, avifContentLightLevelInformationBox *, avifDiagnostics *);
 
 static struct
 {
@@ -33,6 +35,7 @@ static struct
     YuvToRgbFn yuvToRgb;
     RgbToYuvFn rgbToYuv;
     AlphaFn premultiply, unpremultiply;
+    GainMapFn applyGainMap;
     uint64_t minPixels;
     int gpu;
 } g;
@@ -45,6 +48,7 @@ static void resolve(void)
     g.rgbToYuv = (RgbToYuvFn)dlsym(RTLD_NEXT, "avifImageRGBToYUV");
     g.premultiply = (AlphaFn)dlsym(RTLD_NEXT, "avifRGBImagePremultiplyAlpha");
     g.unpremultiply = (AlphaFn)dlsym(RTLD_NEXT, "avifRGBImageUnpremultiplyAlpha");
+    g.applyGainMap = (GainMapFn)dlsym(RTLD_NEXT, "avifRGBImageApplyGainMap");
     const char * e = getenv("AVIFHIP_MIN_PIXELS");
     const long v = e ? atol(e) : 512L * 512L;
     g.minPixels = v < 0 ? 0 : (uint64_t)v;
@@ -110,4 +114,29 @@ AVIF_EXPORT avifResult avifRGBImageUnpremultiplyAlpha(avifRGBImage * rgb)
             return r;
     }
     return g.unpremultiply ? g.unpremultiply(rgb) : AVIF_RESULT_NOT_IMPLEMENTED;
+}
+
+/* Tone mapping.  libavifhip (re)allocates toneMappedImage->pixels with malloc, libavif's avifRGBImageFreePixels releases
+ * them with free (avifFree, src/mem.c): the two are interchangeable, also when the call is handed on after a decline. */
+AVIF_EXPORT avifResult avifRGBImageApplyGainMap(const avifRGBImage * baseImage,
+                                                avifColorPrimaries baseColorPrimaries,
+                                                avifTransferCharacteristics baseTransferCharacteristics,
+                                                const avifGainMap * gainMap,
+                                                float hdrHeadroom,
+                                                avifColorPrimaries outputColorPrimaries,
+                                                avifTransferCharacteristics outputTransferCharacteristics,
+                                                avifRGBImage * toneMappedImage,
+                                                avifContentLightLevelInformationBox * clli,
+                                                avifDiagnostics * diag)
+{
+    resolve();
+    if (baseImage && gainMap && toneMappedImage && worthIt(baseImage->width, baseImage->height)) {
+        const avifResult r = avifhipRGBImageApplyGainMap(baseImage, baseColorPrimaries, baseTransferCharacteristics, gainMap, hdrHeadroom,
+                                                         outputColorPrimaries, outputTransferCharacteristics, toneMappedImage, clli, diag);
+        if (!declined(r) || !g.applyGainMap)
+            return r;
+    }
+    return g.applyGainMap ? g.applyGainMap(baseImage, baseColorPrimaries, baseTransferCharacteristics, gainMap, hdrHeadroom, outputColorPrimaries,
+                                           outputTransferCharacteristics, toneMappedImage, clli, diag)
+                          : AVIF_RESULT_NOT_IMPLEMENTED;
 }

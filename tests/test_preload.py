@@ -35,7 +35,7 @@ def test_interposer_exports_the_public_symbols():
     import ctypes
 
     lib = ctypes.CDLL(os.fspath(PRELOAD))
-    for sym in ("avifImageYUVToRGB", "avifImageRGBToYUV", "avifRGBImagePremultiplyAlpha", "avifRGBImageUnpremultiplyAlpha"):
+    for sym in ("avifImageYUVToRGB", "avifImageRGBToYUV", "avifRGBImagePremultiplyAlpha", "avifRGBImageUnpremultiplyAlpha", "avifRGBImageApplyGainMap"):
         assert hasattr(lib, sym), sym
 
 
@@ -55,5 +55,5 @@ def test_interposer_serves_the_calls_from_the_gpu(hip, tmp_path):
     _, want = _run(tmp_path, "plain.bin", preload=False)
     got_r, got = _run(tmp_path, "gpu.bin", preload=True, extra_env={"AVIFHIP_MIN_PIXELS": "0"})
     assert got_r[:3] == [0, 0, 0]
-    assert got_r[3] >= 3, "the three conversions must have run as HIP kernels"
+    assert got_r[3] >= 6, "the three conversions and the tone mapping (rescale, gain-map conversion, apply) must have run as HIP kernels"
     assert got == want

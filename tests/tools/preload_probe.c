@@ -14,6 +14,10 @@
 avifResult avifImageYUVToRGB(const avifImage * image, avifRGBImage * rgb);
 avifResult avifImageRGBToYUV(avifImage * image, const avifRGBImage * rgb);
 avifResult avifRGBImagePremultiplyAlpha(avifRGBImage * rgb);
+avifResult avifRGBImageApplyGainMap(const avifRGBImage * baseImage, avifColorPrimaries baseColorPrimaries, avifTransferCharacteristics baseTransferCharacteristics,
+                                    const avifGainMap * gainMap, float hdrHeadroom, avifColorPrimaries outputColorPrimaries,
+                                    avifTransferCharacteristics outputTransferCharacteristics, avifRGBImage * toneMappedImage,
+                                    avifContentLightLevelInformationBox * clli, avifDiagnostics * diag);
 
 static uint32_t rnd(uint32_t * s)
 {
@@ -60,12 +64,38 @@ int main(int argc, char ** argv)
         rgb.pixels[k] = (uint8_t)(rnd(&seed) & 0xff);
     const avifResult r3 = avifRGBImagePremultiplyAlpha(&rgb);
 
+    /* tone-map the premultiplied pixels with a half-size 4:2:0 gain map (a view on the first image's planes): sRGB -> 10-bit PQ BT.2020 */
+    avifImage gainImage = img;
+    gainImage.width = W / 2, gainImage.height = H / 2;
+    gainImage.yuvRange = AVIF_RANGE_FULL, gainImage.matrixCoefficients = AVIF_MATRIX_COEFFICIENTS_BT601;
+    avifGainMap gm;
+    memset(&gm, 0, sizeof(gm));
+    gm.image = &gainImage;
+    for (int c = 0; c < 3; ++c) {
+        gm.gainMapMin[c].n = 0, gm.gainMapMin[c].d = 1, gm.gainMapMax[c].n = 3, gm.gainMapMax[c].d = 1;
+        gm.gainMapGamma[c].n = 1, gm.gainMapGamma[c].d = 1;
+        gm.baseOffset[c].n = 1, gm.baseOffset[c].d = 64, gm.alternateOffset[c].n = 1, gm.alternateOffset[c].d = 64;
+    }
+    gm.baseHdrHeadroom.n = 0, gm.baseHdrHeadroom.d = 1, gm.alternateHdrHeadroom.n = 3, gm.alternateHdrHeadroom.d = 1;
+    gm.useBaseColorSpace = AVIF_TRUE;
+    avifRGBImage tone;
+    memset(&tone, 0, sizeof(tone));
+    tone.depth = 10, tone.format = AVIF_RGB_FORMAT_RGBA, tone.maxThreads = 1;
+    avifContentLightLevelInformationBox clli = { 0, 0 };
+    avifDiagnostics diag;
+    const avifResult r4 = avifRGBImageApplyGainMap(&rgb, 1, 13, &gm, 2.0f, 9, 16, &tone, &clli, &diag);
+
     FILE * f = fopen(argc > 1 ? argv[1] : "/dev/null", "wb");
     if (!f)
         return 2;
     fwrite(rgb.pixels, 1, (size_t)W * H * 4, f);
     fwrite(planes, 1, (size_t)W * H * 4, f);
+    if (r4 == AVIF_RESULT_OK)
+        fwrite(tone.pixels, 1, (size_t)tone.rowBytes * tone.height, f);
+    fwrite(&clli.maxCLL, 1, sizeof(clli.maxCLL), f);
     fclose(f);
+    if (r3 == AVIF_RESULT_OK && r4 != AVIF_RESULT_OK)
+        return 3;
     uint64_t (*launches)(void) = (uint64_t(*)(void))dlsym(RTLD_DEFAULT, "avifhipLaunchCount");
     printf("results %d %d %d launches %llu\n", (int)r1, (int)r2, (int)r3, launches ? (unsigned long long)launches() : 0ull);
     return 0;
