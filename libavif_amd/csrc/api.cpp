@@ -52,7 +52,7 @@ struct GainMapTableCache
         float gammaInv[3], minLog2[3], maxLog2[3], weight;
         uint64_t stream;
     } key;
-    size_t baseLutOffset = 0, gainLutOffset = 0, stepsOffset = 0; // in floats
+    size_t baseLutOffset = 0, gainLutOffset = 0, stepsOffset = 0, guideOffset = 0; // in floats
     uint32_t maxCode = 0, nanCode = 0, stepEntries = 0;
 };
 
@@ -1247,6 +1247,9 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
             cache.stepsOffset = tables.size();
             const GainMapSteps & S = gainMapOutputSteps(outTC, key.outDepth, out->isFloat != 0);
             tables.insert(tables.end(), S.steps.begin(), S.steps.end());
+            cache.guideOffset = tables.size();
+            tables.resize(tables.size() + (S.guide.size() + 1) / 2, 0.0f); // the 16-bit guide entries ride in float slots
+            memcpy(tables.data() + cache.guideOffset, S.guide.data(), S.guide.size() * sizeof(uint16_t));
             cache.maxCode = S.maxCode, cache.stepEntries = S.pieceEntries;
             // what the reference computes for a NaN input (the weight-0 path can meet one in a half-float base image)
             const float nanGamma = fminf(1.0f, fmaxf(0.0f, gainMapToGamma(outTC, NAN)));
@@ -1269,11 +1272,13 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         const float * t = (const float *)tls.gainMap[2].ptr;
         A.baseLut = t + cache.baseLutOffset, A.gainLut = t + cache.gainLutOffset, A.steps = t + cache.stepsOffset;
         A.maxCode = cache.maxCode, A.nanCode = cache.nanCode, A.stepEntries = cache.stepEntries;
+        A.guide = (const uint16_t *)(t + cache.guideOffset);
+        A.guideFirstBits = kGainMapGuideFirstBits, A.guideShift = kGainMapGuideShift, A.guideBuckets = kGainMapGuideBuckets;
         // the kernel keeps the tables in LDS when all of them fit (up to 12-bit images; 16-bit and half-float tables stay in
         // global memory)
         const size_t stepsEntries = 2 * (size_t)cache.stepEntries, baseEntries = cache.gainLutOffset - cache.baseLutOffset,
                      gainEntries = cache.stepsOffset - cache.gainLutOffset;
-        if ((stepsEntries + baseEntries + gainEntries) * sizeof(float) <= 64 * 1024)
+        if ((stepsEntries + baseEntries + gainEntries) * sizeof(float) + (kGainMapGuideBuckets + 2) * sizeof(uint16_t) <= 64 * 1024)
             A.ldsSteps = (uint32_t)stepsEntries, A.ldsBaseLut = (uint32_t)baseEntries, A.ldsGainLut = (uint32_t)gainEntries;
     }
 

@@ -385,6 +385,20 @@ const GainMapSteps & gainMapOutputSteps(int tc, uint32_t depth, bool isFloat)
             lowKey = lo;
         }
     }
+    // the guide over the x >= 0 piece
+    S.guide.resize(kGainMapGuideBuckets + 1);
+    {
+        const float * T = S.steps.data() + n;
+        uint32_t k = 0;
+        for (uint32_t b = 0; b <= kGainMapGuideBuckets; ++b) {
+            const uint32_t bits = kGainMapGuideFirstBits + (b << kGainMapGuideShift);
+            float x;
+            memcpy(&x, &bits, 4);
+            while (k < S.maxCode && T[k + 1] <= x)
+                ++k; // codes are non-decreasing along the buckets
+            S.guide[b] = (uint16_t)k;
+        }
+    }
     return cache.emplace(key, std::move(S)).first->second;
 }
 

@@ -41,7 +41,14 @@ struct GainMapSteps
 {
     std::vector<float> steps;
     uint32_t maxCode = 0, pieceEntries = 0;
+    // Where to start looking: for the x >= 0 piece, guide[b] is the code of the first fp32 value of bucket b, buckets being
+    // runs of 2^kGainMapGuideShift consecutive fp32 bit patterns from 2^kGainMapGuideMinExp up (64 per octave); the code of an x
+    // in bucket b lies in [guide[b], guide[b + 1]].  kGainMapGuideBuckets + 1 entries.
+    std::vector<uint16_t> guide;
 };
+constexpr int kGainMapGuideShift = 17, kGainMapGuideMinExp = -24, kGainMapGuideOctaves = 40;
+constexpr uint32_t kGainMapGuideBuckets = (uint32_t)kGainMapGuideOctaves << (23 - kGainMapGuideShift);
+constexpr uint32_t kGainMapGuideFirstBits = (uint32_t)(127 + kGainMapGuideMinExp) << 23;
 const GainMapSteps & gainMapOutputSteps(int transferCharacteristics, uint32_t depth, bool isFloat);
 
 } // namespace avifhip

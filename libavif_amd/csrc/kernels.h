@@ -150,8 +150,10 @@ struct GainMapArgs
     const float * baseLut;  // linear light of every base sample code
     const float * gainLut;  // 3 x (1 << gainDepth): exp2f(log2 gain * weight) per channel and gain-map sample code
     const float * steps;    // output steps of the output transfer function: 2 pieces (x < 0, x >= 0) x stepEntries
+    const uint16_t * guide; // GainMapSteps::guide (gainmap_plan.h): brackets of the search over the x >= 0 piece
+    uint32_t guideFirstBits, guideShift, guideBuckets;
     uint32_t maxCode, nanCode, stepEntries; // stepEntries: entries per piece of `steps`, a power of two
-    uint32_t ldsSteps, ldsBaseLut, ldsGainLut; // entries of the tables when the kernel is to keep ALL of them in LDS, else all 0
+    uint32_t ldsSteps, ldsBaseLut, ldsGainLut; // entries of the tables when the kernel is to keep ALL of them (and the guide) in LDS, else all 0
     int32_t convert;        // linearise, (convert primaries, apply the gain,) re-encode; 0: requantise the samples as they are
     int32_t inConv, outConv;
     double inM[9], outM[9]; // avifLinearRGBConvertColorSpace coefficients, row-major

@@ -102,22 +102,46 @@ __device__ __forceinline__ void convertPrimaries(float v[3], const double M[9])
 }
 
 // The output codes of three linear values: for each the largest k with steps[k] <= x in the piece (x < 0, x >= 0) x belongs
-// to.  Each piece has `entries` (a power of two) steps, steps[0] = -inf, NaN past the last code: a halving search without
-// branches, the three channels' (independent) chains of LDS reads advancing together.
-__device__ __forceinline__ void codesOf(const float x[3], const float * steps, uint32_t entries, uint32_t nanCode, uint32_t code[3])
+// to (each piece has `entries` steps, steps[0] = -inf).  The guide brackets the answer for x >= 0 (64 buckets per octave of
+// x: one or two codes wide for the log-like curves, a dozen at the top of a linear one), a bisection inside the bracket
+// finishes; the three channels' chains of table reads advance together.
+struct StepSearch
 {
-    uint32_t pos[3];
+    const float * steps;
+    const uint16_t * guide;
+    uint32_t entries, maxCode, nanCode, firstBits, shift, buckets;
+};
+__device__ __forceinline__ void codesOf(const float x[3], const StepSearch & S, uint32_t code[3])
+{
+    uint32_t lo[3], hi[3], base[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        pos[c] = (x[c] < 0.0f) ? 0 : entries;
-    for (uint32_t s = entries >> 1; s; s >>= 1) {
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t bits = __float_as_uint(x[c]);
+        if (x[c] < 0.0f || x[c] != x[c]) { // the x < 0 piece (BT.1361, IEC 61966-2-4 only reach above code 0 there): whole range
+            base[c] = 0, lo[c] = 0, hi[c] = S.maxCode;
+        } else {
+            base[c] = S.entries;
+            const uint32_t b = (bits - S.firstBits) >> S.shift;
+            if (bits < S.firstBits)
+                lo[c] = 0, hi[c] = S.guide[0];
+            else if (b >= S.buckets)
+                lo[c] = S.guide[S.buckets], hi[c] = S.maxCode;
+            else
+                lo[c] = S.guide[b], hi[c] = S.guide[b + 1];
+        }
+    }
+    while ((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2])) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            pos[c] += (steps[pos[c] + s] <= x[c]) ? s : 0;
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t mid = (lo[c] + hi[c] + 1) >> 1; // lo == hi: mid == lo, steps[lo] <= x holds, nothing changes
+            const bool up = S.steps[base[c] + mid] <= x[c];
+            lo[c] = (lo[c] < hi[c] && up) ? mid : lo[c];
+            hi[c] = (lo[c] < hi[c] && !up) ? mid - 1 : hi[c];
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        code[c] = (x[c] != x[c]) ? nanCode : (pos[c] & (entries - 1));
+        code[c] = (x[c] != x[c]) ? S.nanCode : lo[c];
 }
 
 // Persistent workgroups walking tiles of 64 x 4 pixels with a grid stride.  LDS_TABLES: the three tables (steps, base lookup,
@@ -130,6 +154,7 @@ __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_
     const float * steps = A.steps;
     const float * baseLut = A.baseLut;
     const float * gainLut = A.gainLut;
+    const uint16_t * guide = A.guide;
     if constexpr (LDS_TABLES) {
         const uint32_t t = threadIdx.y * 64 + threadIdx.x;
         for (uint32_t k = t; k < A.ldsSteps; k += 256)
@@ -138,9 +163,14 @@ __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_
             ldsTables[A.ldsSteps + k] = A.baseLut[k];
         for (uint32_t k = t; k < A.ldsGainLut; k += 256)
             ldsTables[A.ldsSteps + A.ldsBaseLut + k] = A.gainLut[k];
+        uint16_t * ldsGuide = reinterpret_cast<uint16_t *>(ldsTables + A.ldsSteps + A.ldsBaseLut + A.ldsGainLut);
+        for (uint32_t k = t; k <= A.guideBuckets; k += 256)
+            ldsGuide[k] = A.guide[k];
         __syncthreads();
         steps = ldsTables, baseLut = ldsTables + A.ldsSteps, gainLut = ldsTables + A.ldsSteps + A.ldsBaseLut;
+        guide = ldsGuide;
     }
+    const StepSearch search = { steps, guide, A.stepEntries, A.maxCode, A.nanCode, A.guideFirstBits, A.guideShift, A.guideBuckets };
     const bool baseVector = A.baseL.hasAlpha && (((uintptr_t)A.base | A.basePitch) & (A.baseL.pixelBytes - 1)) == 0;
     const bool outVector = A.outL.hasAlpha && (((uintptr_t)A.out | A.outPitch) & (A.outL.pixelBytes - 1)) == 0;
     const uint32_t gainPixelBytes = 4 * ((A.gainDepth > 8) ? 2 : 1);
@@ -195,7 +225,7 @@ __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_
                     convertPrimaries(v, A.outM);
                 sawNan = sawNan || (v[0] != v[0]) || (v[1] != v[1]) || (v[2] != v[2]);
             }
-            codesOf(v, steps, A.stepEntries, A.nanCode, outCode);
+            codesOf(v, search, outCode);
         }
         writePixel(A.out + (size_t)j * A.outPitch + (size_t)i * A.outL.pixelBytes, A.outL, outVector, outCode, A.outL.hasAlpha ? quantise(alpha, A.outL) : 0);
     }
@@ -256,7 +286,7 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream)
         return hipSuccess;
     const uint32_t tilesX = (A.width + 63) / 64, tiles = tilesX * ((A.height + 3) / 4);
     const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
-    const size_t lds = (size_t)(A.ldsSteps + A.ldsBaseLut + A.ldsGainLut) * sizeof(float);
+    const size_t lds = A.ldsSteps ? (size_t)(A.ldsSteps + A.ldsBaseLut + A.ldsGainLut) * sizeof(float) + ((size_t)A.guideBuckets + 2) * sizeof(uint16_t) : 0;
     if (lds)
         hipLaunchKernelGGL(gainMapApplyKernel<true>, dim3(groups), dim3(64, 4), lds, stream, A, tilesX, tiles);
     else
