@@ -1,0 +1,81 @@
+"""Golden fixtures of the paths next to the conversion (tests/golden/next_*.npz, written by tests/tools/make_golden_next.py
+from the reference compiled from its own sources): plane scaling and gain-map application.  The oracles must reproduce every
+one byte for byte on any machine -- no /root/reference, no oracle/_ref needed -- and so must the HIP library on the GPU box.
+Inputs come from the fixture files, not from the generators."""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import gainmap_cases as G
+import harness as H
+import oracle_lib
+import test_scale as TS
+from libavif_amd import abi
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+SCALE = sorted(GOLDEN.glob("next_scale_*.npz"))
+GAINMAP = sorted(GOLDEN.glob("next_gainmap_*.npz"))
+libc = C.CDLL(None)
+libc.free.argtypes = [C.c_void_p]
+
+
+def check_scale(path, scale_fn):
+    z = np.load(path)
+    c = H.Y2RCase(**json.loads(str(z["case"])))
+    dw, dh = (int(v) for v in z["dst"])
+    img = H.make_y2r_inputs(c)
+    for p, buf in enumerate(img.planes + [img.alpha]):
+        if buf is not None:
+            buf[...] = z[f"plane{p}"]
+    assert scale_fn(img.struct, dw, dh) == int(z["result"]), path.name
+    for p, buf in enumerate(TS.planes_of(img.struct)):
+        assert (buf is not None) == (f"out{p}" in z.files), (path.name, p)
+        if buf is not None:
+            assert np.array_equal(buf, z[f"out{p}"]), (path.name, p)
+    TS.free_owned(img.struct)
+
+
+def check_gainmap(path, apply_fn, extra):
+    z = np.load(path)
+    meta = json.loads(str(z["case"]))
+    c = G.GainMapCase(**{k: (tuple(tuple(x) if isinstance(x, list) else x for x in v) if isinstance(v, list) else v) for k, v in meta.items()})
+    base = G.make_base(c)
+    base.pixels[...] = z["base"]
+    gm, keep = G.make_gain_map(c)
+    for p, buf in enumerate(keep.planes):
+        if buf is not None:
+            buf[...] = z[f"gain{p}"]
+    out = G.make_output(c)
+    clli = abi.avifContentLightLevelInformationBox(0xFFFF, 0xFFFF)
+    res = apply_fn(base.struct, c.base_primaries, c.base_tc, C.byref(gm), c.headroom, c.out_primaries, c.out_tc, out.struct, C.byref(clli), extra)
+    assert res == int(z["result"]), path.name
+    if res == 0:
+        assert np.array_equal(G.output_bytes(out), z["output"]), path.name
+        assert clli.maxCLL == int(z["clli"][0]) and abs(clli.maxPALL - int(z["clli"][1])) <= 1, (path.name, clli.maxCLL, clli.maxPALL, z["clli"])
+    if out.struct.pixels:
+        libc.free(C.cast(out.struct.pixels, C.c_void_p))
+
+
+@pytest.mark.parametrize("path", SCALE, ids=lambda p: p.stem)
+def test_oracle_scale(path):
+    check_scale(path, oracle_lib.oracle().oracleImageScale)
+
+
+@pytest.mark.parametrize("path", GAINMAP, ids=lambda p: p.stem)
+def test_oracle_gainmap(path):
+    check_gainmap(path, oracle_lib.oracle().oracleRGBImageApplyGainMap, 0)  # the fixtures come from the libyuv-less build
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", SCALE, ids=lambda p: p.stem)
+def test_gpu_scale(hip, path):
+    check_scale(path, hip.avifhipImageScale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GAINMAP, ids=lambda p: p.stem)
+def test_gpu_gainmap(hip, path):
+    check_gainmap(path, hip.avifhipRGBImageApplyGainMap, C.byref(abi.avifDiagnostics()))  # `hip` pins the fp32 arithmetic

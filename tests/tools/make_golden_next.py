@@ -1,0 +1,81 @@
+"""make_golden_next.py -- writes tests/golden/next_*.npz: inputs and outputs of the REFERENCE (compiled from its own sources,
+oracle/_ref/libavif_ref.so) for the paths next to the conversion: plane scaling (avifImageScale) and gain-map
+application (avifRGBImageApplyGainMap).  Run in the build container (needs /root/reference at build time); the fixtures then
+pin the oracles -- and, on the GPU box, the product -- on machines where the reference binary is absent."""
+import ctypes as C
+import json
+import sys
+from dataclasses import asdict
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import gainmap_cases as G  # noqa: E402
+import harness as H  # noqa: E402
+import oracle_lib  # noqa: E402
+import test_gainmap as TG  # noqa: E402
+import test_scale as TS  # noqa: E402
+from libavif_amd import abi  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+ref = oracle_lib.ref()
+assert ref is not None, "build oracle/_ref first (make -C oracle ref)"
+
+SCALE = [(H.Y2RCase(64, 48, yuv_depth=8, yuv_format=3, yuv_range=1), 21, 16),             # box
+         (H.Y2RCase(33, 17, yuv_depth=8, yuv_format=1, yuv_range=1, alpha=True), 66, 34),    # 2x upsampler
+         (H.Y2RCase(100, 30, yuv_depth=8, yuv_format=2, yuv_range=1), 67, 20),             # bilinear down
+         (H.Y2RCase(40, 25, yuv_depth=10, yuv_format=3, yuv_range=1), 93, 61),             # bilinear up, 16-bit samples
+         (H.Y2RCase(90, 70, yuv_depth=12, yuv_format=1, yuv_range=1), 13, 9),              # box, 16-bit samples
+         (H.Y2RCase(17, 64, yuv_depth=8, yuv_format=4, yuv_range=1), 17, 200)]             # vertical only
+GAINMAP = [G.GainMapCase(37, 21), G.GainMapCase(37, 21, out_tc=16, out_primaries=9, out_depth=10),
+           G.GainMapCase(40, 30, gm_w=13, gm_h=7, gm_depth=12, base_tc=1, out_tc=18, out_depth=12, headroom=1.5),
+           G.GainMapCase(33, 17, base_depth=16, base_float=True, base_tc=8, out_float=True, out_depth=16, out_tc=8, base_primaries=9, out_primaries=12,
+                         use_base_color_space=False, alt_primaries=1),
+           G.GainMapCase(64, 48, gm_w=32, gm_h=24, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, gm_range=abi.AVIF_RANGE_LIMITED, gm_matrix=1,
+                         base_format=abi.AVIF_RGB_FORMAT_BGR, out_format=abi.AVIF_RGB_FORMAT_ARGB, out_tc=12),
+           G.GainMapCase(37, 21, headroom=0.0, out_tc=11, out_primaries=5, out_depth=16),
+           G.GainMapCase(37, 21, gm_max=((2000, 1),) * 3, gm_min=((-2000, 1),) * 3, alt_headroom=(1, 1), headroom=1.0, out_primaries=9,
+                         base_offset=((0, 1),) * 3)]
+
+
+def main():
+    diag = abi.avifDiagnostics()
+    for k, (c, dw, dh) in enumerate(SCALE):
+        img = H.make_y2r_inputs(c)
+        data = {"case": json.dumps(asdict(c)), "dst": np.array([dw, dh])}
+        for p, buf in enumerate(img.planes + [img.alpha]):
+            if buf is not None:
+                data[f"plane{p}"] = buf.copy()
+        res = ref.avifImageScale(img.struct, dw, dh, C.byref(diag))
+        data["result"] = np.array(res)
+        for p, buf in enumerate(TS.planes_of(img.struct)):
+            if buf is not None:
+                data[f"out{p}"] = buf
+        TS.free_owned(img.struct)
+        np.savez_compressed(OUT / f"next_scale_{k:02d}.npz", **data)
+    for k, c in enumerate(GAINMAP):
+        base = G.make_base(c)
+        gm, keep = G.make_gain_map(c)
+        data = {"case": json.dumps(asdict(c)), "base": base.pixels.copy()}
+        for p, buf in enumerate(keep.planes):
+            if buf is not None:
+                data[f"gain{p}"] = buf.copy()
+        out = G.make_output(c)
+        clli = abi.avifContentLightLevelInformationBox(0xFFFF, 0xFFFF)
+        res = ref.avifRGBImageApplyGainMap(base.struct, c.base_primaries, c.base_tc, C.byref(gm), c.headroom, c.out_primaries, c.out_tc, out.struct,
+                                           C.byref(clli), C.byref(diag))
+        data["result"], data["clli"] = np.array(res), np.array([clli.maxCLL, clli.maxPALL])
+        if res == 0:
+            data["output"] = G.output_bytes(out)
+        if out.struct.pixels:
+            TG.libc.free(C.cast(out.struct.pixels, C.c_void_p))
+        np.savez_compressed(OUT / f"next_gainmap_{k:02d}.npz", **data)
+    print("wrote", len(SCALE) + len(GAINMAP), "fixtures")
+
+
+if __name__ == "__main__":
+    main()
