@@ -197,7 +197,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "i32" if integer else "f32",  # the arithmetic type the path computes in: libyuv's fixed point / libavif's fp32
         "data": "synthetic",
         "config": {
             "workload": "7680x4320 8-bit YUV420 BT.709 limited -> RGBA8, bilinear chroma upsampling, HBM-resident, "

@@ -43,6 +43,17 @@ __device__ __forceinline__ unsigned fxReduceForFilter(unsigned v, unsigned downs
         return v;
 }
 
+// 8-bit planes through a filter: the staged words are pre-scaled by the filter's divisor-to-256 factor (4:2:0: sums of weight
+// 16, x16; 4:2:2: weight 4, x64), so that the filtered, rounded and shifted sample lands in byte 1 of its 16-bit field --
+// where the matrix multiplies read it with a byte select instead of a bit-field extract per plane and pixel.  No field
+// overflows: 255 * 256 + 128 < 65536.
+template <typename YT, int SUB, bool BIL>
+struct FxPrescale
+{
+    static constexpr bool kOn = BIL && sizeof(YT) == 1 && (SUB == SUB_420 || SUB == SUB_422);
+    static constexpr int kShift = !kOn ? 0 : (SUB == SUB_420 ? 4 : 6);
+};
+
 template <typename YT, int SUB, bool NEEDA, int NS>
 __device__ __forceinline__ void stageTileFx(const TileArgs & A, const TileRaw<YT, SUB, true, NEEDA, NS> & T, unsigned (*rows)[kFxRowPitch])
 {
@@ -59,20 +70,27 @@ __device__ __forceinline__ void stageTileFx(const TileArgs & A, const TileRaw<YT
             unsigned * dst = &rows[row][4 * grp + 1];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                dst[k] = fxReduceForFilter<YT>(u[k], A.fx.downshift) | (fxReduceForFilter<YT>(v[k], A.fx.downshift) << 16);
+                dst[k] = (fxReduceForFilter<YT>(u[k], A.fx.downshift) | (fxReduceForFilter<YT>(v[k], A.fx.downshift) << 16)) << FxPrescale<YT, SUB, true>::kShift;
         }
     }
 }
 
-// 3x and 9x of a packed (u | v << 16) word
+// 3x and 9x of a packed (u | v << 16) word.  Spelled as the shift-and-add instruction: from (x << 3) + x the compiler builds
+// x * 9 and, where an addend follows, v_mad_u64_u32 -- a quarter-rate 32 x 32 multiplier for what one full-rate
+// v_lshl_add_u32 does (six of them per 8 pixels of the 4:2:0 filter).
 __device__ __forceinline__ unsigned fx3(unsigned x)
 {
-    return (x << 1) + x;
+    unsigned r;
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 __device__ __forceinline__ unsigned fx9(unsigned x)
 {
-    return (x << 3) + x;
+    unsigned r;
+    asm("v_lshl_add_u32 %0, %1, 3, %1" : "=v"(r) : "v"(x));
+    return r;
 }
+
 
 template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
 __device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx & c, uint32_t tileY, const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS> & T,
@@ -142,9 +160,10 @@ __device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx 
                 loadRow(qm, m);
                 loadRow(qm - 1, f[0]); // even luma rows lean to the chroma row above
                 loadRow(qm + 1, f[1]); // odd luma rows to the one below
+                constexpr unsigned kRound = 0x00080008u << FxPrescale<YT, SUB, BIL>::kShift;
                 const unsigned n9b = fx9(m[1]), n9c = fx9(m[2]);
-                const unsigned h0 = n9b + fx3(m[0]) + 0x00080008u, h1 = n9b + fx3(m[2]) + 0x00080008u;
-                const unsigned h2 = n9c + fx3(m[1]) + 0x00080008u, h3 = n9c + fx3(m[3]) + 0x00080008u;
+                const unsigned h0 = n9b + fx3(m[0]) + kRound, h1 = n9b + fx3(m[2]) + kRound;
+                const unsigned h2 = n9c + fx3(m[1]) + kRound, h3 = n9c + fx3(m[3]) + kRound;
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const unsigned g3b = fx3(f[r][1]), g3c = fx3(f[r][2]);
@@ -158,7 +177,8 @@ __device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx 
                 for (int r = 0; r < 2; ++r) {
                     unsigned m[4];
                     loadRow(2 * (wv * NS + k) + r, m);
-                    const unsigned n3b = fx3(m[1]) + 0x00020002u, n3c = fx3(m[2]) + 0x00020002u;
+                    constexpr unsigned kRound = 0x00020002u << FxPrescale<YT, SUB, BIL>::kShift;
+                    const unsigned n3b = fx3(m[1]) + kRound, n3c = fx3(m[2]) + kRound;
                     uv[r][0] = n3b + m[0];
                     uv[r][1] = n3b + m[2];
                     uv[r][2] = n3c + m[1];
@@ -169,7 +189,7 @@ __device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx 
 
         // ---- matrix, alpha, stores ----
         // the filter's final ">> SH" is folded into the field extraction: uv holds the un-shifted sums
-        constexpr int SH = BIL ? (SUB == SUB_420 ? 4 : 2) : 0;
+        constexpr int SH = (BIL ? (SUB == SUB_420 ? 4 : 2) : 0) + FxPrescale<YT, SUB, BIL>::kShift; // 8 with the pre-scale: byte 1
         constexpr unsigned kField = BIL ? 0xfffu : 0xffffu; // filtered fields are 12 bits wide after the shift, plain samples 16
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
