@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void scalePlanesStagedKernel(ScaleStagedLaunch
 // with per-lane selectors computed once spreads them into packed 16-bit pairs, and the reference's integer arithmetic
 // runs two samples per instruction (v_pk_*_u16 / _i16: every intermediate of the 8-bit formulas fits 16 bits).  No LDS,
 // no staging prologue, ~6 VALU instructions per destination sample instead of ~25.
-// What bounds it (profiles/r02_scale_pmc.txt: TA_BUSY 70-80 % of the kernel): the CU's vector-memory path handles a
+// What bounds it (profiles/r01_scale_pmc.txt: TA_BUSY 70-80 % of the kernel): the CU's vector-memory path handles a
 // wave's load or store at 4 lanes per clock WHATEVER the lanes' access size, so the 4-byte-per-lane stores and the
 // 8+4-byte window loads run that path at a quarter of what 16-byte accesses reach.  (16 destination samples per lane
 // with 16-byte stores needs windows of up to 32 bytes, which v_perm_b32 cannot address; unaligned 8-byte LDS windows
