@@ -96,14 +96,28 @@ def main():
     n_gpus = args.gpus
     dist = None
     torch = None
-    if world > 1:
+    # (AVIFHIP_BENCH_FORCE_DIST=1: take the multi-rank code path -- torch + RCCL process group, barriers, max-over-ranks --
+    # with a single rank too, to exercise it on a one-GPU box)
+    if world > 1 or os.environ.get("AVIFHIP_BENCH_FORCE_DIST") == "1":
         # torch first: its bundled HIP runtime must be the one libavifhip.so binds to (same SONAME)
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on STDOUT when its communicator comes up; the contract is ONE JSON line there, so
+        # stdout points at stderr while the process group initialises and runs its first collective
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from libavif_amd import abi, device, native, synth
 
