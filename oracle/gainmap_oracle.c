@@ -661,3 +661,345 @@ avifResult oracleRGBImageApplyGainMap(const avifRGBImage * baseImage, avifColorP
     }
     return res;
 }
+
+/* ---- gain-map computation (the encode side), src/gainmap.c:357-428, :493-843 ---- */
+
+static const float kGainEpsilon = 1e-10f; /* :487 */
+
+static float roundfHalfUp(float v) { return floorf(v + 0.5f); } /* avifRoundf, src/utils.c:11-14 */
+
+/* avifDoubleToUnsignedFractionImpl, src/utils.c:238-281: best continued-fraction approximation */
+static int doubleToFraction(double v, uint32_t maxNumerator, uint32_t * numerator, uint32_t * denominator)
+{
+    if (isnan(v) || v < 0 || v > maxNumerator)
+        return 0;
+    const uint32_t maxD = (v <= 1) ? UINT32_MAX : (uint32_t)floor(maxNumerator / v);
+    *denominator = 1;
+    uint32_t previousD = 0;
+    double currentV = v - floor(v);
+    for (int iter = 0; iter < 39; ++iter) {
+        const double numeratorDouble = (double)(*denominator) * v;
+        *numerator = (uint32_t)round(numeratorDouble);
+        if (fabs(numeratorDouble - (*numerator)) == 0.0)
+            return 1;
+        currentV = 1.0 / currentV;
+        const double newD = previousD + floor(currentV) * (*denominator);
+        if (newD > (double)maxD)
+            return 1;
+        previousD = *denominator;
+        *denominator = (uint32_t)newD;
+        currentV -= floor(currentV);
+    }
+    *numerator = (uint32_t)round((double)(*denominator) * v);
+    return 1;
+}
+int oracleDoubleToSignedFraction(double v, avifSignedFraction * f) /* :283-294 */
+{
+    uint32_t n;
+    if (!doubleToFraction(fabs(v), INT32_MAX, &n, &f->d))
+        return 0;
+    f->n = (int32_t)n;
+    if (v < 0)
+        f->n *= -1;
+    return 1;
+}
+int oracleDoubleToUnsignedFraction(double v, avifUnsignedFraction * f) /* :296-299 */
+{
+    return doubleToFraction(v, UINT32_MAX, &f->n, &f->d);
+}
+
+/* avifColorPrimariesComputeYCoeffs, src/colr.c:517-542 */
+static void yCoefficients(int cp, float coeffs[3])
+{
+    float p[8];
+    primariesValues(cp, p);
+    const float rX = p[0], rY = p[1], gX = p[2], gY = p[3], bX = p[4], bY = p[5], wX = p[6], wY = p[7];
+    const float rZ = 1.0f - (rX + rY), gZ = 1.0f - (gX + gY), bZ = 1.0f - (bX + bY), wZ = 1.0f - (wX + wY);
+    const float kr = (rY * (wX * (gY * bZ - bY * gZ) + wY * (bX * gZ - gX * bZ) + wZ * (gX * bY - bX * gY))) /
+                     (wY * (rX * (gY * bZ - bY * gZ) + gX * (bY * rZ - rY * bZ) + bX * (rY * gZ - gY * rZ)));
+    const float kb = (bY * (wX * (rY * gZ - gY * rZ) + wY * (gX * rZ - rX * gZ) + wZ * (rX * gY - gX * rY))) /
+                     (wY * (rX * (gY * bZ - bY * gZ) + gX * (bY * rZ - rY * bZ) + bX * (rY * gZ - gY * rZ)));
+    coeffs[0] = kr, coeffs[2] = kb, coeffs[1] = 1.0f - coeffs[0] - coeffs[2];
+}
+
+/* avifChooseColorSpaceForGainMapMath, src/gainmap.c:496-533 */
+static avifResult chooseMathPrimaries(int basePrimaries, int altPrimaries, int * out)
+{
+    if (basePrimaries == altPrimaries) {
+        *out = basePrimaries;
+        return AVIF_RESULT_OK;
+    }
+    double baseToAlt[3][3], altToBase[3][3];
+    if (!oracleColorPrimariesComputeRGBToRGBMatrix(basePrimaries, altPrimaries, baseToAlt) ||
+        !oracleColorPrimariesComputeRGBToRGBMatrix(altPrimaries, basePrimaries, altToBase))
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    float baseMin = 0, altMin = 0;
+    for (int c = 0; c < 3; ++c) {
+        float rgba[4] = { 0, 0, 0, 0 };
+        rgba[c] = 1.0f;
+        convertColorSpace(rgba, altToBase);
+        for (int i = 0; i < 3; ++i)
+            baseMin = MINF(baseMin, rgba[i]);
+        rgba[0] = rgba[1] = rgba[2] = 0;
+        rgba[c] = 1.0f;
+        convertColorSpace(rgba, baseToAlt);
+        for (int i = 0; i < 3; ++i)
+            altMin = MINF(altMin, rgba[i]);
+    }
+    *out = (altMin <= baseMin) ? basePrimaries : altPrimaries;
+    return AVIF_RESULT_OK;
+}
+
+/* avifFindMinMaxWithoutOutliers, :375-428 */
+static int valueToBucket(float v, float lo, float hi, int n) /* :363-367 */
+{
+    v = CLAMPF(v, lo, hi);
+    const int idx = (int)roundfHalfUp((v - lo) / (hi - lo) * n);
+    return idx < n - 1 ? idx : n - 1;
+}
+static float bucketToValue(int idx, float lo, float hi, int n) { return idx * (hi - lo) / n + lo; } /* :369-372 */
+avifResult oracleFindMinMaxWithoutOutliers(const float * g, size_t numPixels, float * rangeMin, float * rangeMax)
+{
+    const float bucketSize = 0.01f, maxOutliersRatio = 0.001f;
+    const int maxOutliersOnEachSide = (int)roundfHalfUp(numPixels * maxOutliersRatio / 2.0f);
+    float lo = g[0], hi = g[0];
+    for (size_t i = 1; i < numPixels; ++i) {
+        lo = MINF(lo, g[i]);
+        hi = MAXF(hi, g[i]);
+    }
+    *rangeMin = lo, *rangeMax = hi;
+    if ((hi - lo) <= (bucketSize * 2) || maxOutliersOnEachSide == 0)
+        return AVIF_RESULT_OK;
+    const int maxNumBuckets = 10000;
+    const int byWidth = (int)ceilf((hi - lo) / bucketSize);
+    const int numBuckets = byWidth < maxNumBuckets ? byWidth : maxNumBuckets;
+    int * histogram = (int *)calloc((size_t)numBuckets, sizeof(int));
+    if (!histogram)
+        return AVIF_RESULT_OUT_OF_MEMORY;
+    for (size_t i = 0; i < numPixels; ++i)
+        ++histogram[valueToBucket(g[i], lo, hi, numBuckets)];
+    int leftOutliers = 0;
+    for (int i = 0; i < numBuckets; ++i) {
+        leftOutliers += histogram[i];
+        if (leftOutliers > maxOutliersOnEachSide)
+            break;
+        if (histogram[i] == 0)
+            *rangeMin = bucketToValue(i + 1, lo, hi, numBuckets);
+    }
+    int rightOutliers = 0;
+    for (int i = numBuckets - 1; i >= 0; --i) {
+        rightOutliers += histogram[i];
+        if (rightOutliers > maxOutliersOnEachSide)
+            break;
+        if (histogram[i] == 0)
+            *rangeMax = bucketToValue(i, lo, hi, numBuckets);
+    }
+    free(histogram);
+    return AVIF_RESULT_OK;
+}
+
+static void freePlanes(avifImage * image) /* avifImageFreePlanes(ALL), src/avif.c:492-517 */
+{
+    if (image->imageOwnsYUVPlanes)
+        for (int p = 0; p < 3; ++p)
+            free(image->yuvPlanes[p]);
+    for (int p = 0; p < 3; ++p)
+        image->yuvPlanes[p] = NULL, image->yuvRowBytes[p] = 0;
+    image->imageOwnsYUVPlanes = AVIF_FALSE;
+    if (image->imageOwnsAlphaPlane)
+        free(image->alphaPlane);
+    image->alphaPlane = NULL, image->alphaRowBytes = 0, image->imageOwnsAlphaPlane = AVIF_FALSE;
+}
+
+/*
+ * avifRGBImageComputeGainMap, src/gainmap.c:535-843.  gainMap->image carries the requested width / height / depth / format
+ * (and range / matrix) on entry and owns malloc'ed planes on success; `libyuvBuild` as in oracleRGBImageApplyGainMap (the
+ * gain map's RGB -> YUV conversion, :814).
+ */
+avifResult oracleRGBImageComputeGainMap(const avifRGBImage * baseRgb, avifColorPrimaries basePrimaries, avifTransferCharacteristics baseTC,
+                                        const avifRGBImage * altRgb, avifColorPrimaries altPrimaries, avifTransferCharacteristics altTC,
+                                        avifGainMap * gainMap, int libyuvBuild)
+{
+    if (baseRgb == NULL || altRgb == NULL || gainMap == NULL || gainMap->image == NULL)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if (baseRgb->width != altRgb->width || baseRgb->height != altRgb->height)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    avifImage * gmImage = gainMap->image;
+    if (gmImage->width == 0 || gmImage->height == 0 || gmImage->depth == 0 || (int)gmImage->yuvFormat <= 0 || (int)gmImage->yuvFormat >= 5)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const int colorSpacesDiffer = (basePrimaries != altPrimaries);
+    int mathPrimaries;
+    avifResult res = chooseMathPrimaries(basePrimaries, altPrimaries, &mathPrimaries);
+    if (res != AVIF_RESULT_OK)
+        return res;
+    const uint32_t width = baseRgb->width, height = baseRgb->height;
+    PixelLayout baseL, altL;
+    if (!pixelLayout(baseRgb, &baseL) || !pixelLayout(altRgb, &altL))
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+
+    const size_t numPixels = (size_t)width * height;
+    const int singleChannel = (gmImage->yuvFormat == AVIF_PIXEL_FORMAT_YUV400);
+    const int numChannels = singleChannel ? 1 : 3;
+    float * gainMapF[3] = { NULL, NULL, NULL };
+    avifRGBImage gainMapRGB;
+    memset(&gainMapRGB, 0, sizeof(gainMapRGB));
+    for (int c = 0; c < numChannels; ++c) {
+        gainMapF[c] = (float *)malloc(numPixels * sizeof(float));
+        if (!gainMapF[c]) {
+            res = AVIF_RESULT_OUT_OF_MEMORY;
+            goto cleanup;
+        }
+    }
+
+    for (int i = 0; i < 3; ++i) { /* avifGainMapSetEncodingDefaults, :18-30 */
+        gainMap->gainMapMin[i] = (avifSignedFraction) { 1, 1 }, gainMap->gainMapMax[i] = (avifSignedFraction) { 1, 1 };
+        gainMap->baseOffset[i] = (avifSignedFraction) { 1, 64 }, gainMap->alternateOffset[i] = (avifSignedFraction) { 1, 64 };
+        gainMap->gainMapGamma[i] = (avifUnsignedFraction) { 1, 1 };
+    }
+    gainMap->baseHdrHeadroom = (avifUnsignedFraction) { 0, 1 }, gainMap->alternateHdrHeadroom = (avifUnsignedFraction) { 1, 1 };
+    gainMap->useBaseColorSpace = (mathPrimaries == basePrimaries);
+
+    TransferFn baseToLinear, altToLinear, unused;
+    transferFunctions(baseTC, &baseToLinear, &unused);
+    transferFunctions(altTC, &altToLinear, &unused);
+    float yCoeffs[3];
+    yCoefficients(mathPrimaries, yCoeffs);
+    double coeffs[3][3];
+    if (colorSpacesDiffer) {
+        const int ok = gainMap->useBaseColorSpace ? oracleColorPrimariesComputeRGBToRGBMatrix(altPrimaries, basePrimaries, coeffs)
+                                                  : oracleColorPrimariesComputeRGBToRGBMatrix(basePrimaries, altPrimaries, coeffs);
+        if (!ok) {
+            res = AVIF_RESULT_NOT_IMPLEMENTED;
+            goto cleanup;
+        }
+    }
+    float baseOffset[3], altOffset[3];
+    for (int c = 0; c < 3; ++c)
+        baseOffset[c] = sFrac(gainMap->baseOffset[c]), altOffset[c] = sFrac(gainMap->alternateOffset[c]);
+
+    if (colorSpacesDiffer) { /* offsets that keep converted channels positive, :618-660 */
+        float rgba[4] = { 0 }, channelMin[3] = { 0 };
+        for (uint32_t j = 0; j < height; ++j) {
+            for (uint32_t i = 0; i < width; ++i) {
+                getPixel(gainMap->useBaseColorSpace ? altRgb : baseRgb, i, j, gainMap->useBaseColorSpace ? &altL : &baseL, rgba);
+                for (int c = 0; c < 3; ++c)
+                    rgba[c] = gainMap->useBaseColorSpace ? altToLinear(rgba[c]) : baseToLinear(rgba[c]);
+                convertColorSpace(rgba, coeffs);
+                for (int c = 0; c < 3; ++c)
+                    channelMin[c] = MINF(channelMin[c], rgba[c]);
+            }
+        }
+        for (int c = 0; c < 3; ++c) {
+            const float maxOffset = 0.1f;
+            if (channelMin[c] < -kGainEpsilon) {
+                if (gainMap->useBaseColorSpace)
+                    altOffset[c] = MINF(altOffset[c] - channelMin[c], maxOffset);
+                else
+                    baseOffset[c] = MINF(baseOffset[c] - channelMin[c], maxOffset);
+            }
+        }
+    }
+
+    float baseMax = 1.0f, altMax = 1.0f; /* raw log2 ratios, :663-715 */
+    for (uint32_t j = 0; j < height; ++j) {
+        for (uint32_t i = 0; i < width; ++i) {
+            float b[4], a[4];
+            getPixel(baseRgb, i, j, &baseL, b);
+            getPixel(altRgb, i, j, &altL, a);
+            for (int c = 0; c < 3; ++c)
+                b[c] = baseToLinear(b[c]), a[c] = altToLinear(a[c]);
+            if (colorSpacesDiffer)
+                convertColorSpace(gainMap->useBaseColorSpace ? a : b, coeffs);
+            for (int c = 0; c < numChannels; ++c) {
+                float base = b[c], alt = a[c];
+                if (singleChannel) {
+                    base = yCoeffs[0] * b[0] + yCoeffs[1] * b[1] + yCoeffs[2] * b[2];
+                    alt = yCoeffs[0] * a[0] + yCoeffs[1] * a[1] + yCoeffs[2] * a[2];
+                }
+                if (base > baseMax)
+                    baseMax = base;
+                if (alt > altMax)
+                    altMax = alt;
+                const float ratio = (alt + altOffset[c]) / (base + baseOffset[c]);
+                gainMapF[c][(size_t)j * width + i] = log2f(MAXF(ratio, kGainEpsilon));
+            }
+        }
+    }
+
+    const double baseHeadroom = log2f(MAXF(baseMax, kGainEpsilon)), altHeadroom = log2f(MAXF(altMax, kGainEpsilon));
+    if (!oracleDoubleToUnsignedFraction(baseHeadroom, &gainMap->baseHdrHeadroom) || !oracleDoubleToUnsignedFraction(altHeadroom, &gainMap->alternateHdrHeadroom)) {
+        res = AVIF_RESULT_INVALID_ARGUMENT;
+        goto cleanup;
+    }
+    if (altHeadroom < baseHeadroom)
+        for (int c = 0; c < numChannels; ++c)
+            for (size_t k = 0; k < numPixels; ++k)
+                gainMapF[c][k] *= -1.f;
+
+    float minLog2[3] = { 0, 0, 0 }, maxLog2[3] = { 0, 0, 0 };
+    for (int c = 0; c < numChannels; ++c) {
+        res = oracleFindMinMaxWithoutOutliers(gainMapF[c], numPixels, &minLog2[c], &maxLog2[c]);
+        if (res != AVIF_RESULT_OK)
+            goto cleanup;
+    }
+    for (int c = 0; c < 3; ++c) {
+        if (!oracleDoubleToSignedFraction(minLog2[singleChannel ? 0 : c], &gainMap->gainMapMin[c]) ||
+            !oracleDoubleToSignedFraction(maxLog2[singleChannel ? 0 : c], &gainMap->gainMapMax[c]) ||
+            !oracleDoubleToSignedFraction(altOffset[c], &gainMap->alternateOffset[c]) || !oracleDoubleToSignedFraction(baseOffset[c], &gainMap->baseOffset[c])) {
+            res = AVIF_RESULT_INVALID_ARGUMENT;
+            goto cleanup;
+        }
+    }
+
+    for (int c = 0; c < numChannels; ++c) { /* [min, max] -> [0, 1], :762-787 */
+        const float range = MAXF(maxLog2[c] - minLog2[c], 0.0f);
+        if (range == 0.0f) {
+            for (size_t k = 0; k < numPixels; ++k)
+                gainMapF[c][k] = 0.0f;
+        } else {
+            const float gamma = uFrac(gainMap->gainMapGamma[c]);
+            for (size_t k = 0; k < numPixels; ++k) {
+                float v = gainMapF[c][k];
+                v = CLAMPF(v, minLog2[c], maxLog2[c]);
+                v = powf((v - minLog2[c]) / range, gamma);
+                gainMapF[c][k] = nanSafeClamp(v);
+            }
+        }
+    }
+
+    const uint32_t requestedWidth = gmImage->width, requestedHeight = gmImage->height; /* to YUV, :789-823 */
+    gmImage->width = width, gmImage->height = height;
+    freePlanes(gmImage);
+    gainMapRGB.width = width, gainMapRGB.height = height, gainMapRGB.depth = gmImage->depth, gainMapRGB.format = AVIF_RGB_FORMAT_RGBA;
+    gainMapRGB.chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, gainMapRGB.chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
+    gainMapRGB.maxThreads = 1;
+    res = allocatePixels(&gainMapRGB);
+    if (res != AVIF_RESULT_OK)
+        goto cleanup;
+    PixelLayout gmL;
+    if (!pixelLayout(&gainMapRGB, &gmL)) {
+        res = AVIF_RESULT_NOT_IMPLEMENTED;
+        goto cleanup;
+    }
+    for (uint32_t j = 0; j < height; ++j) {
+        for (uint32_t i = 0; i < width; ++i) {
+            const size_t k = (size_t)j * width + i;
+            const float r = gainMapF[0][k], g = singleChannel ? r : gainMapF[1][k], b = singleChannel ? r : gainMapF[2][k];
+            const float px[4] = { r, g, b, 1.0f };
+            setPixel(&gainMapRGB, i, j, &gmL, px);
+        }
+    }
+    res = libyuvBuild ? oracleLibyuvImageRGBToYUV(gmImage, &gainMapRGB) : oracleImageRGBToYUV(gmImage, &gainMapRGB);
+    if (res != AVIF_RESULT_OK)
+        goto cleanup;
+    if (requestedWidth != gmImage->width || requestedHeight != gmImage->height)
+        res = oracleImageScale(gmImage, requestedWidth, requestedHeight);
+
+cleanup:
+    for (int c = 0; c < 3; ++c)
+        free(gainMapF[c]);
+    free(gainMapRGB.pixels);
+    if (res != AVIF_RESULT_OK)
+        freePlanes(gmImage);
+    return res;
+}

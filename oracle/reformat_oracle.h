@@ -108,6 +108,12 @@ avifResult oracleRGBImageApplyGainMap(const avifRGBImage * baseImage, avifColorP
                                       avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap, float hdrHeadroom,
                                       avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
                                       avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, int libyuvBuild);
+avifResult oracleRGBImageComputeGainMap(const avifRGBImage * baseRgb, avifColorPrimaries basePrimaries, avifTransferCharacteristics baseTC,
+                                        const avifRGBImage * altRgb, avifColorPrimaries altPrimaries, avifTransferCharacteristics altTC,
+                                        avifGainMap * gainMap, int libyuvBuild);
+avifResult oracleFindMinMaxWithoutOutliers(const float * gainMapF, size_t numPixels, float * rangeMin, float * rangeMax);
+int oracleDoubleToSignedFraction(double v, avifSignedFraction * fraction);
+int oracleDoubleToUnsignedFraction(double v, avifUnsignedFraction * fraction);
 avifResult oracleGainMapValidateMetadata(const avifGainMap * gainMap);
 float oracleGainMapWeight(float hdrHeadroom, const avifGainMap * gainMap);
 float oracleTransferFunction(int transferCharacteristics, int direction, float v);

@@ -145,3 +145,89 @@ def cases(n_random: int, seed: int, sizes=((37, 21), (64, 33), (5, 3), (1, 1))) 
                         alt_primaries=rnd.choice(PRIMARIES), headroom=rnd.choice((0.0, 0.5, 1.0, 2.0, 3.5, 6.0)), seed=rnd.getrandbits(30) | 1)
         out.append(c)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# gain-map computation (the encode side)
+
+
+@dataclass(frozen=True)
+class ComputeCase:
+    w: int
+    h: int
+    base_depth: int = 8
+    base_format: int = abi.AVIF_RGB_FORMAT_RGBA
+    base_primaries: int = 1
+    base_tc: int = 13
+    alt_depth: int = 10
+    alt_format: int = abi.AVIF_RGB_FORMAT_RGBA
+    alt_float: bool = False
+    alt_primaries: int = 1
+    alt_tc: int = 16
+    gm_w: int = 0
+    gm_h: int = 0
+    gm_depth: int = 8
+    gm_format: int = abi.AVIF_PIXEL_FORMAT_YUV444
+    gm_range: int = abi.AVIF_RANGE_FULL
+    gm_matrix: int = abi.AVIF_MATRIX_COEFFICIENTS_BT601
+    correlated: bool = True  # the alternate image is a brightened copy of the base (what a real HDR/SDR pair looks like) + noise
+    seed: int = 1
+
+    def ident(self) -> str:
+        return (f"{self.w}x{self.h}-b{self.base_depth}{abi.RGB_FORMAT_NAMES[self.base_format]}-cp{self.base_primaries}tc{self.base_tc}"
+                f"-a{self.alt_depth}{'f' if self.alt_float else ''}{abi.RGB_FORMAT_NAMES[self.alt_format]}-cp{self.alt_primaries}tc{self.alt_tc}"
+                f"-gm{self.gm_w or self.w}x{self.gm_h or self.h}d{self.gm_depth}f{self.gm_format}r{self.gm_range}m{self.gm_matrix}-{'c' if self.correlated else 'r'}{self.seed}")
+
+
+def make_compute_inputs(c: ComputeCase):
+    base = abi.make_rgb(c.w, c.h, c.base_depth, c.base_format, avoid_libyuv=False)
+    synth.fill_rgb(base, c.seed)
+    alt = abi.make_rgb(c.w, c.h, c.alt_depth, c.alt_format, is_float=c.alt_float, avoid_libyuv=False)
+    rng = np.random.default_rng(c.seed)
+    if c.correlated:
+        b = base.channels().astype(np.float64) / ((1 << c.base_depth) - 1)
+        nb, na = b.shape[2], alt.channels().shape[2]
+        src = np.zeros(alt.channels().shape, dtype=np.float64)
+        # map base channels by position (alpha, where present on both sides, included: its value does not matter)
+        for k in range(na):
+            src[:, :, k] = b[:, :, min(k, nb - 1)]
+        v = np.clip(src * rng.uniform(0.6, 1.0) + rng.normal(0, 0.02, src.shape), 0, 1)
+    else:
+        v = rng.random(alt.channels().shape)
+    if c.alt_float:
+        alt.channels()[...] = (v * 1.5).astype(np.float16).view(np.uint16)
+    else:
+        alt.channels()[...] = np.round(v * ((1 << c.alt_depth) - 1)).astype(alt.channels().dtype)
+    return base, alt
+
+
+def make_compute_gain_map(c: ComputeCase):
+    """avifGainMap whose image carries only the request (size, depth, format, range, matrix); the callee allocates the planes."""
+    img = abi.make_yuv(c.gm_w or c.w, c.gm_h or c.h, c.gm_depth, c.gm_format, c.gm_range, c.gm_matrix, allocate=False)
+    gm = abi.avifGainMap()
+    gm.image = C.pointer(img.struct)
+    return gm, img
+
+
+def compute_cases(n_random: int, seed: int, sizes=((37, 21), (64, 33), (5, 3), (120, 40))) -> list:
+    rnd = random.Random(seed)
+    w0, h0 = sizes[0]
+    out = [ComputeCase(w0, h0), ComputeCase(w0, h0, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400), ComputeCase(w0, h0, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, gm_depth=10),
+           ComputeCase(64, 48, gm_w=32, gm_h=24), ComputeCase(64, 48, gm_w=16, gm_h=12, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400, gm_depth=12),
+           ComputeCase(w0, h0, alt_primaries=9), ComputeCase(w0, h0, base_primaries=9, alt_primaries=1), ComputeCase(w0, h0, alt_primaries=12, gm_format=4),
+           ComputeCase(w0, h0, base_tc=16, base_depth=10, alt_tc=13, alt_depth=8),  # HDR base, SDR alternate: negative direction
+           ComputeCase(w0, h0, alt_float=True, alt_depth=16, alt_tc=8), ComputeCase(w0, h0, correlated=False),
+           ComputeCase(w0, h0, gm_range=abi.AVIF_RANGE_LIMITED, gm_matrix=1, gm_format=abi.AVIF_PIXEL_FORMAT_YUV422),
+           ComputeCase(120, 40, correlated=True, seed=9), ComputeCase(1, 1)]
+    for tc in TCS:
+        out.append(ComputeCase(w0, h0, base_tc=13, alt_tc=tc, seed=300 + tc))
+    for _ in range(n_random):
+        w, h = rnd.choice(sizes)
+        af = rnd.random() < 0.1
+        same = rnd.random() < 0.6
+        out.append(ComputeCase(w, h, base_depth=rnd.choice((8, 8, 10, 12, 16)), base_format=rnd.choice(RGB_FORMATS), base_primaries=rnd.choice(PRIMARIES),
+                               base_tc=rnd.choice(TCS), alt_depth=16 if af else rnd.choice((8, 10, 10, 12, 16)), alt_format=rnd.choice(RGB_FORMATS), alt_float=af,
+                               alt_primaries=rnd.choice(PRIMARIES), alt_tc=rnd.choice(TCS), gm_w=0 if same else rnd.randint(1, w), gm_h=0 if same else rnd.randint(1, h),
+                               gm_depth=rnd.choice((8, 8, 10, 12)), gm_format=rnd.choice((1, 2, 3, 4)), gm_range=rnd.choice((0, 1)), gm_matrix=rnd.choice((1, 6, 9)),
+                               correlated=rnd.random() < 0.8, seed=rnd.getrandbits(30) | 1))
+    return out

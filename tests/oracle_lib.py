@@ -58,6 +58,8 @@ def oracle() -> C.CDLL:
         lib.oracleRGBImageApplyGainMap.restype = C.c_int
         lib.oracleRGBImageApplyGainMap.argtypes = [_P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, _P_RGB,
                                                    C.POINTER(avifContentLightLevelInformationBox), C.c_int]
+        lib.oracleRGBImageComputeGainMap.restype = C.c_int
+        lib.oracleRGBImageComputeGainMap.argtypes = [_P_RGB, C.c_uint16, C.c_uint16, _P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_int]
         lib.oracleTransferFunction.restype, lib.oracleTransferFunction.argtypes = C.c_float, [C.c_int, C.c_int, C.c_float]
         lib.oracleColorPrimariesComputeRGBToRGBMatrix.restype = C.c_int
         lib.oracleColorPrimariesComputeRGBToRGBMatrix.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double * 9)]
@@ -85,6 +87,10 @@ def _bind_libavif(lib: C.CDLL) -> C.CDLL:
         lib.avifRGBImageApplyGainMap.restype = C.c_int
         lib.avifRGBImageApplyGainMap.argtypes = [_P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, _P_RGB,
                                                  C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics)]
+    if hasattr(lib, "avifRGBImageComputeGainMap"):
+        lib.avifRGBImageComputeGainMap.restype = C.c_int
+        lib.avifRGBImageComputeGainMap.argtypes = [_P_RGB, C.c_uint16, C.c_uint16, _P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap),
+                                                   C.POINTER(avifDiagnostics)]
     if hasattr(lib, "avifColorPrimariesComputeRGBToRGBMatrix"):
         lib.avifColorPrimariesComputeRGBToRGBMatrix.restype = C.c_int
         lib.avifColorPrimariesComputeRGBToRGBMatrix.argtypes = [C.c_uint16, C.c_uint16, C.POINTER(C.c_double * 9)]

@@ -75,6 +75,52 @@ def test_oracle_libyuv_build_equals_libyuv_enabled_binary():
     assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
 
 
+def gain_map_state(gm, img_struct):
+    """Everything avifRGBImageComputeGainMap writes: the metadata fractions and the gain map image."""
+    meta = []
+    for name in ("gainMapMin", "gainMapMax", "gainMapGamma", "baseOffset", "alternateOffset"):
+        meta += [(f.n, f.d) for f in getattr(gm, name)]
+    meta += [(gm.baseHdrHeadroom.n, gm.baseHdrHeadroom.d), (gm.alternateHdrHeadroom.n, gm.alternateHdrHeadroom.d), gm.useBaseColorSpace]
+    import test_scale as TS
+
+    planes = TS.planes_of(img_struct)
+    return meta, (img_struct.width, img_struct.height), planes
+
+
+def run_compute(fn, c, extra):
+    import test_scale as TS
+
+    base, alt = G.make_compute_inputs(c)
+    gm, img = G.make_compute_gain_map(c)
+    res = fn(base.struct, c.base_primaries, c.base_tc, alt.struct, c.alt_primaries, c.alt_tc, C.byref(gm), extra)
+    state = gain_map_state(gm, img.struct) if res == 0 else None
+    TS.free_owned(img.struct)
+    return res, state
+
+
+def states_equal(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    if a[0] != b[0] or a[1] != b[1]:
+        return False
+    return all((x is None) == (y is None) and (x is None or np.array_equal(x, y)) for x, y in zip(a[2], b[2]))
+
+
+@pytest.mark.skipif(oracle_lib.ref() is None, reason="oracle/_ref/libavif_ref.so not built (needs /root/reference)")
+def test_compute_oracle_equals_reference():
+    """avifRGBImageComputeGainMap (src/gainmap.c:535-843): metadata and gain-map planes identical."""
+    ref, o = oracle_lib.ref(), oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    bad = []
+    cases = G.compute_cases(250, seed=11)
+    for c in cases:
+        ra, sa = run_compute(ref.avifRGBImageComputeGainMap, c, C.byref(diag))
+        rb, sb = run_compute(o.oracleRGBImageComputeGainMap, c, 0)
+        if ra != rb or not states_equal(sa, sb):
+            bad.append(f"{c.ident()}: results {ra}/{rb}" + ("" if sa is None or sb is None else f" meta equal {sa[0] == sb[0]} size {sa[1]}/{sb[1]}"))
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+
+
 def test_argument_errors():
     o = oracle_lib.oracle()
     c = G.GainMapCase(8, 8)
