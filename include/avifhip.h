@@ -162,6 +162,19 @@ AVIFHIP_API avifResult avifhipRGBImageApplyGainMapAsync(const avifRGBImage * bas
                                                         avifContentLightLevelInformationBox * clli,
                                                         avifDiagnostics * diag,
                                                         void * hipStream);
+/* Gain-map computation (the encode side): drop-in for avifRGBImageComputeGainMap (reference include/avif/avif.h:1688-1722,
+ * src/gainmap.c:535-843): host images in; the metadata fractions of `gainMap` and the (malloc'ed) planes of gainMap->image -- whose
+ * width, height, depth, yuvFormat (range, matrix) carry the request, as in the reference -- out.  Byte-identical planes and
+ * metadata: the kernels carry the exact fp32 ratio of every sample; log2f / powf, the outlier histogram's bucket index and the
+ * final quantisation are monotone step functions of that ratio whose steps the host finds by bisection with its own libm. */
+AVIFHIP_API avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgbImage,
+                                                     avifColorPrimaries baseColorPrimaries,
+                                                     avifTransferCharacteristics baseTransferCharacteristics,
+                                                     const avifRGBImage * altRgbImage,
+                                                     avifColorPrimaries altColorPrimaries,
+                                                     avifTransferCharacteristics altTransferCharacteristics,
+                                                     avifGainMap * gainMap,
+                                                     avifDiagnostics * diag);
 AVIFHIP_API avifResult avifhipImageApplyGainMap(const avifImage * baseImage,
                                                 const avifGainMap * gainMap,
                                                 float hdrHeadroom,

@@ -69,7 +69,8 @@ struct Context
     Scratch scaleTable; // schedules of a plane scale (device)
     ScaleTableCache scaleCache; // ... and which geometry they belong to
     Scratch satoTable;  // input plane tables of a sample transform (device)
-    Scratch gainMap[6]; // gain-map application: output pixels, gain map as RGB, tables, statistics, scaled gain-map planes, base pixels
+    Scratch gainMap[11]; // gain maps: [0] output pixels, [1] gain map as RGB, [2] tables, [3] statistics / partials, [4] scaled planes, [5] base pixels;
+                         // computation: [6] tables, [7] ratios, [8] histograms, [9] alternate pixels, [10] gain-map planes
     GainMapTableCache gainMapCache; // what gainMap[2] holds
     void * pinnedTable = nullptr;
     size_t pinnedTableCapacity = 0;
@@ -1463,6 +1464,309 @@ extern "C" avifResult avifhipImageApplyGainMap(const avifImage * baseImage, cons
                                         outputTransferCharacteristics, toneMappedImage, clli, diag);
     free(baseRgb.pixels);
     return r;
+}
+
+// ---- gain-map computation (the encode side), reference src/gainmap.c:535-843 ----
+
+namespace {
+
+// device planes (Y, U, V, A) of a wxh image in one scratch buffer, 256-byte row pitch
+avifResult deviceGainMapPlanes(avifImage * view, uint32_t width, uint32_t height, Scratch & scratch)
+{
+    view->width = width, view->height = height;
+    const PlaneDims d = planeDims(width, height, (int)view->yuvFormat);
+    const size_t bps = (view->depth > 8) ? 2 : 1;
+    size_t offset[4], total = 0;
+    uint32_t pitch[4];
+    for (int p = 0; p < 4; ++p) {
+        const bool present = !((p == 1 || p == 2) && view->yuvFormat == AVIF_PIXEL_FORMAT_YUV400);
+        pitch[p] = present ? alignUp((uint32_t)(d.w[p] * bps), 256) : 0;
+        offset[p] = total, total += (size_t)pitch[p] * d.h[p];
+    }
+    const avifResult r = reserve(scratch, total);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    for (int p = 0; p < 4; ++p) {
+        uint8_t * ptr = pitch[p] ? (uint8_t *)scratch.ptr + offset[p] : nullptr;
+        if (p < 3)
+            view->yuvPlanes[p] = ptr, view->yuvRowBytes[p] = pitch[p];
+        else
+            view->alphaPlane = ptr, view->alphaRowBytes = pitch[p];
+    }
+    return AVIF_RESULT_OK;
+}
+
+void freeHostPlanes(avifImage * image) // avifImageFreePlanes(AVIF_PLANES_ALL), src/avif.c:492-517
+{
+    if (image->imageOwnsYUVPlanes)
+        for (int p = 0; p < 3; ++p)
+            free(image->yuvPlanes[p]);
+    for (int p = 0; p < 3; ++p)
+        image->yuvPlanes[p] = NULL, image->yuvRowBytes[p] = 0;
+    image->imageOwnsYUVPlanes = AVIF_FALSE;
+    if (image->imageOwnsAlphaPlane)
+        free(image->alphaPlane);
+    image->alphaPlane = NULL, image->alphaRowBytes = 0, image->imageOwnsAlphaPlane = AVIF_FALSE;
+}
+
+} // namespace
+
+// Host images in, gain-map metadata and (malloc'ed) gain-map planes out, like the reference.
+extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgbImage, avifColorPrimaries baseColorPrimaries,
+                                                    avifTransferCharacteristics baseTransferCharacteristics, const avifRGBImage * altRgbImage,
+                                                    avifColorPrimaries altColorPrimaries, avifTransferCharacteristics altTransferCharacteristics,
+                                                    avifGainMap * gainMap, avifDiagnostics * diag)
+{
+    diagClear(diag);
+    if (baseRgbImage == NULL || altRgbImage == NULL || gainMap == NULL || gainMap->image == NULL)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if (baseRgbImage->width != altRgbImage->width || baseRgbImage->height != altRgbImage->height) {
+        diagPrintf(diag, "Both images should have the same dimensions");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    avifImage * gmImage = gainMap->image;
+    if (gmImage->width == 0 || gmImage->height == 0 || gmImage->depth == 0 || (int)gmImage->yuvFormat <= (int)AVIF_PIXEL_FORMAT_NONE ||
+        (int)gmImage->yuvFormat > (int)AVIF_PIXEL_FORMAT_YUV400) {
+        diagPrintf(diag, "gainMap->image should be non null with desired width, height, depth and yuvFormat set");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    const bool colorSpacesDiffer = baseColorPrimaries != altColorPrimaries;
+    int mathPrimaries = 0;
+    if (!gainMapChooseMathPrimaries(baseColorPrimaries, altColorPrimaries, &mathPrimaries))
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    const uint32_t width = baseRgbImage->width, height = baseRgbImage->height;
+    GainMapComputeArgs A;
+    memset(&A, 0, sizeof(A));
+    if (!gainMapLayout(baseRgbImage, &A.baseL) || !gainMapLayout(altRgbImage, &A.altL)) {
+        diagPrintf(diag, "Unsupported RGB color space");
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    }
+    if (!width || !height || !baseRgbImage->pixels || !altRgbImage->pixels || gmImage->depth > 16)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const size_t numPixels = (size_t)width * height;
+    const bool singleChannel = gmImage->yuvFormat == AVIF_PIXEL_FORMAT_YUV400;
+    const int channels = singleChannel ? 1 : 3;
+    avifResult r = ensureContext();
+    if (r != AVIF_RESULT_OK)
+        return r;
+    hipStream_t stream = tls.stream;
+    tls.gainMapCache.valid = false; // (the apply path's tables are not touched, but keep the two paths independent of call order)
+
+    // avifGainMapSetEncodingDefaults, :18-30
+    for (int i = 0; i < 3; ++i) {
+        gainMap->gainMapMin[i].n = 1, gainMap->gainMapMin[i].d = 1, gainMap->gainMapMax[i].n = 1, gainMap->gainMapMax[i].d = 1;
+        gainMap->baseOffset[i].n = 1, gainMap->baseOffset[i].d = 64, gainMap->alternateOffset[i].n = 1, gainMap->alternateOffset[i].d = 64;
+        gainMap->gainMapGamma[i].n = 1, gainMap->gainMapGamma[i].d = 1;
+    }
+    gainMap->baseHdrHeadroom.n = 0, gainMap->baseHdrHeadroom.d = 1, gainMap->alternateHdrHeadroom.n = 1, gainMap->alternateHdrHeadroom.d = 1;
+    gainMap->useBaseColorSpace = (mathPrimaries == (int)baseColorPrimaries) ? AVIF_TRUE : AVIF_FALSE;
+
+    if (colorSpacesDiffer) {
+        const bool ok = gainMap->useBaseColorSpace ? gainMapPrimariesMatrix(altColorPrimaries, baseColorPrimaries, A.M)
+                                                   : gainMapPrimariesMatrix(baseColorPrimaries, altColorPrimaries, A.M);
+        if (!ok) {
+            diagPrintf(diag, "Unsupported RGB color space conversion");
+            return AVIF_RESULT_NOT_IMPLEMENTED;
+        }
+        A.convertAlt = gainMap->useBaseColorSpace ? 1 : 0, A.convertBase = gainMap->useBaseColorSpace ? 0 : 1;
+    }
+    A.singleChannel = singleChannel ? 1 : 0;
+    gainMapYCoefficients(mathPrimaries, A.yCoeffs);
+    float baseOffset[3], altOffset[3];
+    for (int c = 0; c < 3; ++c)
+        baseOffset[c] = fractionToFloat(gainMap->baseOffset[c]), altOffset[c] = fractionToFloat(gainMap->alternateOffset[c]);
+
+    // ---- device copies of the two images, lookup tables ----
+    A.width = width, A.height = height;
+    const uint32_t baseWidthBytes = width * rgbPixelBytes(baseRgbImage), altWidthBytes = width * rgbPixelBytes(altRgbImage);
+    A.basePitch = alignUp(baseWidthBytes, 256), A.altPitch = alignUp(altWidthBytes, 256);
+    if ((r = reserve(tls.gainMap[5], (size_t)A.basePitch * height)) != AVIF_RESULT_OK || (r = reserve(tls.gainMap[9], (size_t)A.altPitch * height)) != AVIF_RESULT_OK)
+        return r;
+    A.base = (const uint8_t *)tls.gainMap[5].ptr, A.alt = (const uint8_t *)tls.gainMap[9].ptr;
+    HIP_TRY(hipMemcpy2DAsync(tls.gainMap[5].ptr, A.basePitch, baseRgbImage->pixels, baseRgbImage->rowBytes, baseWidthBytes, height, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpy2DAsync(tls.gainMap[9].ptr, A.altPitch, altRgbImage->pixels, altRgbImage->rowBytes, altWidthBytes, height, hipMemcpyHostToDevice, stream));
+    std::vector<float> tables = gainMapLinearLut(baseTransferCharacteristics, baseRgbImage->depth, baseRgbImage->isFloat != 0);
+    const size_t altLutOffset = tables.size();
+    {
+        const std::vector<float> alt = gainMapLinearLut(altTransferCharacteristics, altRgbImage->depth, altRgbImage->isFloat != 0);
+        tables.insert(tables.end(), alt.begin(), alt.end());
+    }
+    // room for the step tables that follow (3 channels x at most 65536 entries)
+    const size_t stepsOffset = (tables.size() + 3) & ~(size_t)3, stepsCapacity = (size_t)3 * 65536;
+    if ((r = reserve(tls.gainMap[6], (stepsOffset + stepsCapacity) * sizeof(float))) != AVIF_RESULT_OK)
+        return r;
+    if ((r = uploadTableAsync(tls.gainMap[6].ptr, tables.data(), tables.size() * sizeof(float), stream)) != AVIF_RESULT_OK)
+        return r;
+    float * deviceTables = (float *)tls.gainMap[6].ptr;
+    A.baseLut = deviceTables, A.altLut = deviceTables + altLutOffset;
+    if ((r = reserve(tls.gainMap[7], (size_t)channels * numPixels * sizeof(float))) != AVIF_RESULT_OK ||
+        (r = reserve(tls.gainMap[3], (size_t)kGainMapMaxGroups * 8 * sizeof(float))) != AVIF_RESULT_OK)
+        return r;
+    A.ratios = (float *)tls.gainMap[7].ptr, A.partials = (float *)tls.gainMap[3].ptr;
+    const uint32_t tiles = ((width + 63) / 64) * ((height + 3) / 4);
+    const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
+    std::vector<float> partials((size_t)groups * 8);
+
+    // ---- pass 0: offsets that keep the converted side's channels positive, :618-660 ----
+    if (colorSpacesDiffer) {
+        hipError_t e = launchGainMapChannelMin(A, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "gain map channel-minimum kernel launch");
+        HIP_TRY(hipMemcpyAsync(partials.data(), A.partials, partials.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float channelMin[3] = { 0.0f, 0.0f, 0.0f };
+        for (uint32_t g = 0; g < groups; ++g)
+            for (int c = 0; c < 3; ++c)
+                channelMin[c] = (channelMin[c] < partials[(size_t)g * 8 + c]) ? channelMin[c] : partials[(size_t)g * 8 + c];
+        for (int c = 0; c < 3; ++c) {
+            const float maxOffset = 0.1f;
+            if (channelMin[c] < -1e-10f) {
+                if (gainMap->useBaseColorSpace) {
+                    const float o = altOffset[c] - channelMin[c];
+                    altOffset[c] = (o < maxOffset) ? o : maxOffset;
+                } else {
+                    const float o = baseOffset[c] - channelMin[c];
+                    baseOffset[c] = (o < maxOffset) ? o : maxOffset;
+                }
+            }
+        }
+    }
+    for (int c = 0; c < 3; ++c)
+        A.baseOffset[c] = baseOffset[c], A.altOffset[c] = altOffset[c];
+
+    // ---- pass 1: ratios, maxima, extreme ratios, :662-715 ----
+    {
+        hipError_t e = launchGainMapRatios(A, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "gain map ratio kernel launch");
+        HIP_TRY(hipMemcpyAsync(partials.data(), A.partials, partials.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    float baseMax = 1.0f, altMax = 1.0f, minRatio[3] = { INFINITY, INFINITY, INFINITY }, maxRatio[3] = { 0.0f, 0.0f, 0.0f };
+    for (uint32_t g = 0; g < groups; ++g) {
+        const float * p = &partials[(size_t)g * 8];
+        baseMax = fmaxf(baseMax, p[0]), altMax = fmaxf(altMax, p[1]);
+        for (int c = 0; c < channels; ++c)
+            minRatio[c] = fminf(minRatio[c], p[2 + c]), maxRatio[c] = fmaxf(maxRatio[c], p[5 + c]);
+    }
+    const float kEps = 1e-10f;
+    const double baseHeadroom = log2f(baseMax > kEps ? baseMax : kEps), alternateHeadroom = log2f(altMax > kEps ? altMax : kEps);
+    if (!gainMapDoubleToUnsignedFraction(baseHeadroom, &gainMap->baseHdrHeadroom.n, &gainMap->baseHdrHeadroom.d) ||
+        !gainMapDoubleToUnsignedFraction(alternateHeadroom, &gainMap->alternateHdrHeadroom.n, &gainMap->alternateHdrHeadroom.d))
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const float sign = (alternateHeadroom < baseHeadroom) ? -1.0f : 1.0f; // :728-739
+
+    // ---- pass 2: range without outliers, :741-749 ----
+    GainMapChannelRange ranges[3];
+    GainMapStepTable stepTables[3];
+    memset(stepTables, 0, sizeof(stepTables));
+    float minLog2[3] = { 0.0f, 0.0f, 0.0f }, maxLog2[3] = { 0.0f, 0.0f, 0.0f };
+    bool anyHistogram = false;
+    std::vector<float> hostSteps;
+    size_t histogramOffset[3] = { 0, 0, 0 }, histogramTotal = 0;
+    for (int c = 0; c < channels; ++c) {
+        ranges[c] = gainMapChannelRange(sign, minRatio[c], maxRatio[c], numPixels);
+        minLog2[c] = ranges[c].lo, maxLog2[c] = ranges[c].hi;
+        if (ranges[c].numBuckets > 0) {
+            uint32_t entries = 0;
+            const std::vector<float> steps = gainMapBucketSteps(ranges[c], &entries);
+            stepTables[c].steps = deviceTables + stepsOffset + hostSteps.size();
+            stepTables[c].entries = entries, stepTables[c].flipped = sign < 0 ? 1 : 0, stepTables[c].flip = (uint32_t)ranges[c].numBuckets - 1;
+            hostSteps.insert(hostSteps.end(), steps.begin(), steps.end());
+            histogramOffset[c] = histogramTotal, histogramTotal += (size_t)ranges[c].numBuckets;
+            anyHistogram = true;
+        }
+    }
+    if (anyHistogram) {
+        if ((r = reserve(tls.gainMap[8], histogramTotal * sizeof(uint32_t))) != AVIF_RESULT_OK)
+            return r;
+        if ((r = uploadTableAsync(deviceTables + stepsOffset, hostSteps.data(), hostSteps.size() * sizeof(float), stream)) != AVIF_RESULT_OK)
+            return r;
+        HIP_TRY(hipMemsetAsync(tls.gainMap[8].ptr, 0, histogramTotal * sizeof(uint32_t), stream));
+        uint32_t * histograms[3];
+        for (int c = 0; c < 3; ++c)
+            histograms[c] = (uint32_t *)tls.gainMap[8].ptr + histogramOffset[c];
+        const hipError_t e = launchGainMapHistogram(A.ratios, numPixels, channels, stepTables, histograms, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "gain map histogram kernel launch");
+        std::vector<uint32_t> hostHistograms(histogramTotal);
+        HIP_TRY(hipMemcpyAsync(hostHistograms.data(), tls.gainMap[8].ptr, histogramTotal * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < channels; ++c)
+            if (ranges[c].numBuckets > 0)
+                gainMapRangeWithoutOutliers(ranges[c], hostHistograms.data() + histogramOffset[c], &minLog2[c], &maxLog2[c]);
+    }
+    for (int c = 0; c < 3; ++c) { // metadata, :751-760
+        const int k = singleChannel ? 0 : c;
+        if (!gainMapDoubleToFraction(minLog2[k], &gainMap->gainMapMin[c].n, &gainMap->gainMapMin[c].d) ||
+            !gainMapDoubleToFraction(maxLog2[k], &gainMap->gainMapMax[c].n, &gainMap->gainMapMax[c].d) ||
+            !gainMapDoubleToFraction(altOffset[c], &gainMap->alternateOffset[c].n, &gainMap->alternateOffset[c].d) ||
+            !gainMapDoubleToFraction(baseOffset[c], &gainMap->baseOffset[c].n, &gainMap->baseOffset[c].d))
+            return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+
+    // ---- pass 3: [min, max] -> codes -> RGBA -> YUV (-> requested size), :762-829 ----
+    hostSteps.clear();
+    memset(stepTables, 0, sizeof(stepTables));
+    const uint32_t depth = gmImage->depth;
+    for (int c = 0; c < channels; ++c) {
+        const float range = (maxLog2[c] - minLog2[c] > 0.0f) ? maxLog2[c] - minLog2[c] : 0.0f;
+        if (range == 0.0f)
+            continue; // every value becomes 0, :766-773
+        const std::vector<float> steps = gainMapCodeSteps(ranges[c], minLog2[c], maxLog2[c], fractionToFloat(gainMap->gainMapGamma[c]), depth);
+        stepTables[c].steps = deviceTables + stepsOffset + hostSteps.size();
+        stepTables[c].entries = (uint32_t)steps.size(), stepTables[c].flipped = sign < 0 ? 1 : 0, stepTables[c].flip = (1u << depth) - 1;
+        hostSteps.insert(hostSteps.end(), steps.begin(), steps.end());
+    }
+    if (!hostSteps.empty() && (r = uploadTableAsync(deviceTables + stepsOffset, hostSteps.data(), hostSteps.size() * sizeof(float), stream)) != AVIF_RESULT_OK)
+        return r;
+    avifRGBImage rgbGain; // avifRGBImageSetDefaults, src/avif.c:700-717
+    memset(&rgbGain, 0, sizeof(rgbGain));
+    rgbGain.width = width, rgbGain.height = height, rgbGain.depth = depth, rgbGain.format = AVIF_RGB_FORMAT_RGBA;
+    rgbGain.chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, rgbGain.chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
+    rgbGain.maxThreads = 1;
+    rgbGain.rowBytes = alignUp(width * 4 * ((depth > 8) ? 2 : 1), 256);
+    if ((r = reserve(tls.gainMap[1], (size_t)rgbGain.rowBytes * height)) != AVIF_RESULT_OK)
+        return r;
+    rgbGain.pixels = (uint8_t *)tls.gainMap[1].ptr;
+    {
+        const hipError_t e = launchGainMapQuantise(A.ratios, width, height, channels, stepTables, rgbGain.pixels, rgbGain.rowBytes, depth, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "gain map quantisation kernel launch");
+    }
+    const uint32_t requestedWidth = gmImage->width, requestedHeight = gmImage->height;
+    freeHostPlanes(gmImage);
+    avifImage deviceGain;
+    memcpy(&deviceGain, gmImage, sizeof(avifImage));
+    if ((r = deviceGainMapPlanes(&deviceGain, width, height, tls.gainMap[10])) != AVIF_RESULT_OK)
+        return r;
+    if ((r = avifhipImageRGBToYUVAsync(&deviceGain, &rgbGain, stream)) != AVIF_RESULT_OK)
+        return r;
+    avifImage deviceFinal;
+    memcpy(&deviceFinal, &deviceGain, sizeof(avifImage));
+    if (requestedWidth != width || requestedHeight != height) {
+        if ((r = deviceGainMapPlanes(&deviceFinal, requestedWidth, requestedHeight, tls.gainMap[4])) != AVIF_RESULT_OK)
+            return r;
+        if ((r = avifhipImageScaleAsync(&deviceGain, &deviceFinal, stream)) != AVIF_RESULT_OK)
+            return r;
+    }
+    gmImage->width = deviceFinal.width, gmImage->height = deviceFinal.height;
+    if ((r = allocateHostPlanes(gmImage, true)) != AVIF_RESULT_OK) {
+        freeHostPlanes(gmImage);
+        return r;
+    }
+    const PlaneGeometry g = planeGeometry(gmImage);
+    for (int p = 0; p < 4; ++p) {
+        uint8_t * host = (p < 3) ? gmImage->yuvPlanes[p] : gmImage->alphaPlane;
+        const uint8_t * dev = (p < 3) ? deviceFinal.yuvPlanes[p] : deviceFinal.alphaPlane;
+        if (!host || !dev)
+            continue;
+        HIP_TRY(hipMemcpy2DAsync(host, (p < 3) ? gmImage->yuvRowBytes[p] : gmImage->alphaRowBytes, dev, (p < 3) ? deviceFinal.yuvRowBytes[p] : deviceFinal.alphaRowBytes,
+                                 g.widthBytes[p], g.rows[p], hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    tls.lastKernel = "gainmap_compute";
+    return AVIF_RESULT_OK;
 }
 
 // =================================================================================================

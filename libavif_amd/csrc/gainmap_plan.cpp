@@ -403,3 +403,206 @@ const GainMapSteps & gainMapOutputSteps(int tc, uint32_t depth, bool isFloat)
 }
 
 } // namespace avifhip
+
+// =====================================================================================================================
+// gain-map computation, host side
+// =====================================================================================================================
+namespace avifhip {
+
+namespace {
+
+void convertFloat3(float v[3], const double M[9]) // avifLinearRGBConvertColorSpace
+{
+    const double x = v[0], y = v[1], z = v[2];
+    const double r0 = M[0] * x + M[1] * y + M[2] * z, r1 = M[3] * x + M[4] * y + M[5] * z, r2 = M[6] * x + M[7] * y + M[8] * z;
+    v[0] = (float)r0, v[1] = (float)r1, v[2] = (float)r2;
+}
+
+bool doubleToFractionImpl(double v, uint32_t maxNumerator, uint32_t * numerator, uint32_t * denominator) // src/utils.c:238-281
+{
+    if (std::isnan(v) || v < 0 || v > maxNumerator)
+        return false;
+    const uint32_t maxD = (v <= 1) ? UINT32_MAX : (uint32_t)floor(maxNumerator / v);
+    *denominator = 1;
+    uint32_t previousD = 0;
+    double currentV = v - floor(v);
+    for (int iter = 0; iter < 39; ++iter) {
+        const double numeratorDouble = (double)(*denominator) * v;
+        *numerator = (uint32_t)round(numeratorDouble);
+        if (fabs(numeratorDouble - (*numerator)) == 0.0)
+            return true;
+        currentV = 1.0 / currentV;
+        const double newD = previousD + floor(currentV) * (*denominator);
+        if (newD > (double)maxD)
+            return true;
+        previousD = *denominator;
+        *denominator = (uint32_t)newD;
+        currentV -= floor(currentV);
+    }
+    *numerator = (uint32_t)round((double)(*denominator) * v);
+    return true;
+}
+
+inline float roundHalfUp(float v) // avifRoundf
+{
+    return floorf(v + 0.5f);
+}
+inline float valueOfRatio(float sign, float r)
+{
+    return sign * log2f(r); // (the reference multiplies by -1.f afterwards: the same fp32 value)
+}
+inline int bucketOfValue(float v, float lo, float hi, int n) // avifValueToBucketIdx, :363-367
+{
+    v = clampf(v, lo, hi);
+    const int idx = (int)roundHalfUp((v - lo) / (hi - lo) * n);
+    return idx < n - 1 ? idx : n - 1;
+}
+
+// T[i] = smallest r in [minRatio, maxRatio] (fp32 order) with m(r) >= i, for i = 1 .. count - 1; m non-decreasing
+template <typename Fn>
+std::vector<float> monotoneSteps(float minRatio, float maxRatio, uint32_t count, uint32_t entries, Fn m)
+{
+    std::vector<float> T(entries, NAN);
+    for (uint32_t i = 1; i < count; ++i)
+        T[i] = INFINITY;
+    T[0] = -INFINITY;
+    const uint32_t keyHi = keyOfFloat(maxRatio);
+    uint32_t lowKey = keyOfFloat(minRatio);
+    const uint32_t top = m(maxRatio);
+    for (uint32_t i = 1; i < count && i <= top; ++i) {
+        uint32_t lo = lowKey, hi = keyHi;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (m(floatOfKey(mid)) >= i)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        T[i] = floatOfKey(lo);
+        lowKey = lo;
+    }
+    return T;
+}
+
+} // namespace
+
+bool gainMapChooseMathPrimaries(int basePrimaries, int altPrimaries, int * mathPrimaries)
+{
+    if (basePrimaries == altPrimaries) {
+        *mathPrimaries = basePrimaries;
+        return true;
+    }
+    double baseToAlt[9], altToBase[9];
+    if (!gainMapPrimariesMatrix(basePrimaries, altPrimaries, baseToAlt) || !gainMapPrimariesMatrix(altPrimaries, basePrimaries, altToBase))
+        return false;
+    float baseMin = 0, altMin = 0;
+    for (int c = 0; c < 3; ++c) {
+        float v[3] = { 0, 0, 0 };
+        v[c] = 1.0f;
+        convertFloat3(v, altToBase);
+        for (int i = 0; i < 3; ++i)
+            baseMin = (baseMin < v[i]) ? baseMin : v[i];
+        v[0] = v[1] = v[2] = 0;
+        v[c] = 1.0f;
+        convertFloat3(v, baseToAlt);
+        for (int i = 0; i < 3; ++i)
+            altMin = (altMin < v[i]) ? altMin : v[i];
+    }
+    *mathPrimaries = (altMin <= baseMin) ? basePrimaries : altPrimaries;
+    return true;
+}
+
+void gainMapYCoefficients(int primaries, float coeffs[3])
+{
+    const float * p = primariesOf(primaries);
+    const float rX = p[0], rY = p[1], gX = p[2], gY = p[3], bX = p[4], bY = p[5], wX = p[6], wY = p[7];
+    const float rZ = 1.0f - (rX + rY), gZ = 1.0f - (gX + gY), bZ = 1.0f - (bX + bY), wZ = 1.0f - (wX + wY);
+    const float kr = (rY * (wX * (gY * bZ - bY * gZ) + wY * (bX * gZ - gX * bZ) + wZ * (gX * bY - bX * gY))) /
+                     (wY * (rX * (gY * bZ - bY * gZ) + gX * (bY * rZ - rY * bZ) + bX * (rY * gZ - gY * rZ)));
+    const float kb = (bY * (wX * (rY * gZ - gY * rZ) + wY * (gX * rZ - rX * gZ) + wZ * (rX * gY - gX * rY))) /
+                     (wY * (rX * (gY * bZ - bY * gZ) + gX * (bY * rZ - rY * bZ) + bX * (rY * gZ - gY * rZ)));
+    coeffs[0] = kr, coeffs[2] = kb, coeffs[1] = 1.0f - coeffs[0] - coeffs[2];
+}
+
+bool gainMapDoubleToFraction(double v, int32_t * n, uint32_t * d)
+{
+    uint32_t positive;
+    if (!doubleToFractionImpl(fabs(v), INT32_MAX, &positive, d))
+        return false;
+    *n = (int32_t)positive;
+    if (v < 0)
+        *n *= -1;
+    return true;
+}
+bool gainMapDoubleToUnsignedFraction(double v, uint32_t * n, uint32_t * d)
+{
+    return doubleToFractionImpl(v, UINT32_MAX, n, d);
+}
+
+GainMapChannelRange gainMapChannelRange(float sign, float minRatio, float maxRatio, size_t numPixels)
+{
+    GainMapChannelRange R;
+    R.sign = sign, R.minRatio = minRatio, R.maxRatio = maxRatio;
+    const float a = valueOfRatio(sign, minRatio), b = valueOfRatio(sign, maxRatio);
+    R.lo = (a < b) ? a : b, R.hi = (a < b) ? b : a;
+    const float bucketSize = 0.01f, maxOutliersRatio = 0.001f;
+    R.maxOutliersOnEachSide = (int)roundHalfUp(numPixels * maxOutliersRatio / 2.0f);
+    if ((R.hi - R.lo) <= (bucketSize * 2) || R.maxOutliersOnEachSide == 0)
+        return R;
+    const int byWidth = (int)ceilf((R.hi - R.lo) / bucketSize);
+    R.numBuckets = byWidth < 10000 ? byWidth : 10000;
+    return R;
+}
+
+std::vector<float> gainMapBucketSteps(const GainMapChannelRange & R, uint32_t * entries)
+{
+    uint32_t n = 1;
+    while (n < (uint32_t)R.numBuckets)
+        n <<= 1;
+    *entries = n;
+    const int nb = R.numBuckets;
+    return monotoneSteps(R.minRatio, R.maxRatio, (uint32_t)nb, n, [&](float r) -> uint32_t {
+        const int b = bucketOfValue(valueOfRatio(R.sign, r), R.lo, R.hi, nb);
+        return (uint32_t)(R.sign > 0 ? b : nb - 1 - b);
+    });
+}
+
+void gainMapRangeWithoutOutliers(const GainMapChannelRange & R, const uint32_t * histogram, float * rangeMin, float * rangeMax)
+{
+    *rangeMin = R.lo, *rangeMax = R.hi;
+    const int n = R.numBuckets;
+    auto bucketToValue = [&](int idx) -> float { return idx * (R.hi - R.lo) / n + R.lo; }; // avifBucketIdxToValue, :369-372
+    int leftOutliers = 0;
+    for (int i = 0; i < n; ++i) {
+        leftOutliers += (int)histogram[i];
+        if (leftOutliers > R.maxOutliersOnEachSide)
+            break;
+        if (histogram[i] == 0)
+            *rangeMin = bucketToValue(i + 1);
+    }
+    int rightOutliers = 0;
+    for (int i = n - 1; i >= 0; --i) {
+        rightOutliers += (int)histogram[i];
+        if (rightOutliers > R.maxOutliersOnEachSide)
+            break;
+        if (histogram[i] == 0)
+            *rangeMax = bucketToValue(i);
+    }
+}
+
+std::vector<float> gainMapCodeSteps(const GainMapChannelRange & R, float minLog2, float maxLog2, float gamma, uint32_t depth)
+{
+    const uint32_t n = 1u << depth, maxCode = n - 1;
+    const float maxF = (float)maxCode;
+    const float range = (maxLog2 - minLog2 > 0.0f) ? maxLog2 - minLog2 : 0.0f;
+    return monotoneSteps(R.minRatio, R.maxRatio, n, n, [&](float r) -> uint32_t {
+        float v = valueOfRatio(R.sign, r);
+        v = clampf(v, minLog2, maxLog2);
+        v = powf((v - minLog2) / range, gamma);
+        v = fminf(1.0f, fmaxf(0.0f, v));
+        const uint32_t code = (uint32_t)(0.5f + v * maxF);
+        return R.sign > 0 ? code : maxCode - code;
+    });
+}
+
+} // namespace avifhip

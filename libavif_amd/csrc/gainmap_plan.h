@@ -13,6 +13,7 @@
 // What is left for the GPU is IEEE fp32 / fp64 multiply-add arithmetic (exact, contraction off) and table lookups.
 #pragma once
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include <vector>
@@ -50,5 +51,43 @@ constexpr int kGainMapGuideShift = 17, kGainMapGuideMinExp = -24, kGainMapGuideO
 constexpr uint32_t kGainMapGuideBuckets = (uint32_t)kGainMapGuideOctaves << (23 - kGainMapGuideShift);
 constexpr uint32_t kGainMapGuideFirstBits = (uint32_t)(127 + kGainMapGuideMinExp) << 23;
 const GainMapSteps & gainMapOutputSteps(int transferCharacteristics, uint32_t depth, bool isFloat);
+
+} // namespace avifhip
+
+// ---- gain-map computation (avifRGBImageComputeGainMap, reference src/gainmap.c:535-843), host side ------------------------------
+// The same idea as for application: the GPU never evaluates log2f / powf.  The kernels carry the exact fp32 ratio r of every
+// sample ((alt + offset) / (base + offset), floored at 1e-10); the gain-map value sign * log2f(r), its histogram bucket and its
+// final quantised code are monotone step functions of r, whose steps the host finds by bisection with its own libm.
+namespace avifhip {
+
+// avifChooseColorSpaceForGainMapMath, src/gainmap.c:496-533; false: a primaries matrix is singular
+bool gainMapChooseMathPrimaries(int basePrimaries, int altPrimaries, int * mathPrimaries);
+// avifColorPrimariesComputeYCoeffs, src/colr.c:517-542
+void gainMapYCoefficients(int primaries, float coeffs[3]);
+// avifDoubleToSignedFraction / avifDoubleToUnsignedFraction, src/utils.c:238-299
+bool gainMapDoubleToFraction(double v, int32_t * n, uint32_t * d);
+bool gainMapDoubleToUnsignedFraction(double v, uint32_t * n, uint32_t * d);
+
+// One channel's gain-map values as a function of the ratio: value(r) = sign * log2f(r) (sign -1 when the alternate image has the
+// smaller headroom, src/gainmap.c:728-739).
+struct GainMapChannelRange
+{
+    float sign = 1.0f;
+    float minRatio = 0.0f, maxRatio = 0.0f; // extreme ratios over the image (from the GPU reduction)
+    float lo = 0.0f, hi = 0.0f;             // extreme gain-map values: value(minRatio), value(maxRatio) in value order
+    int numBuckets = 0;                     // 0: no histogram needed (avifFindMinMaxWithoutOutliers returns [lo, hi], :392-394)
+    int maxOutliersOnEachSide = 0;
+};
+// the first half of avifFindMinMaxWithoutOutliers (:375-399): extremes, outlier budget, bucket count
+GainMapChannelRange gainMapChannelRange(float sign, float minRatio, float maxRatio, size_t numPixels);
+// Steps of the MONOTONE bucket index m(r) over r in [minRatio, maxRatio]: m = bucket for sign > 0, numBuckets - 1 - bucket for sign
+// < 0.  entries (a power of two >= numBuckets) floats: T[0] = -inf, T[i] = smallest r with m(r) >= i (+inf if none), NaN padding.
+std::vector<float> gainMapBucketSteps(const GainMapChannelRange & range, uint32_t * entries);
+// the second half of avifFindMinMaxWithoutOutliers (:403-425) on a histogram indexed by BUCKET (not m)
+void gainMapRangeWithoutOutliers(const GainMapChannelRange & range, const uint32_t * histogram, float * rangeMin, float * rangeMax);
+// Steps of the monotone final code m(r): code for sign > 0, maxCode - code for sign < 0, where code = (uint)(0.5f + clamp01(powf((clamp(
+// value(r), minLog2, maxLog2) - minLog2) / range, gamma)) * maxCode) (src/gainmap.c:762-787, src/reformat.c:1920-1937); entries =
+// 2^depth.  rangeIsZero: every code is 0 (:766-773).
+std::vector<float> gainMapCodeSteps(const GainMapChannelRange & range, float minLog2, float maxLog2, float gamma, uint32_t depth);
 
 } // namespace avifhip

@@ -165,4 +165,41 @@ struct GainMapArgs
 constexpr uint32_t kGainMapMaxGroups = 4096; // persistent workgroups of the apply kernel
 hipError_t launchGainMapApply(const GainMapArgs & args, hipStream_t stream);
 
+// Gain-map computation (avifRGBImageComputeGainMap, reference src/gainmap.c:535-843): three passes over the pixels.
+struct GainMapComputeArgs
+{
+    const uint8_t * base;
+    const uint8_t * alt;
+    uint32_t basePitch, altPitch;
+    GainMapPixelLayout baseL, altL;
+    uint32_t width, height;
+    const float * baseLut; // linear light per sample code (gainmap_plan.h)
+    const float * altLut;
+    int32_t convertAlt, convertBase; // at most one: which side goes through M into the other's primaries (:676-684)
+    double M[9];
+    int32_t singleChannel;
+    float yCoeffs[3];
+    float baseOffset[3], altOffset[3];
+    float * ratios;   // channels x width*height: max((alt + offset) / (base + offset), 1e-10), :711-712
+    float * partials; // kGainMapMaxGroups x 8 floats, see the kernels
+};
+// pass 0 (only when the primaries differ): per-workgroup minima of the converted side's channels, min(0, .), :624-645.
+// partials[g * 8 + c], c < 3
+hipError_t launchGainMapChannelMin(const GainMapComputeArgs & args, hipStream_t stream);
+// pass 1: ratios + per-workgroup [baseMax, altMax (both >= 1, :663-664), minRatio[3], maxRatio[3]]
+hipError_t launchGainMapRatios(const GainMapComputeArgs & args, hipStream_t stream);
+struct GainMapStepTable
+{
+    const float * steps; // monotone steps over the ratio (gainmap_plan.h), `entries` (a power of two) floats
+    uint32_t entries;
+    uint32_t flip;       // index = flip - m when `flipped` (negative sign), else m
+    int32_t flipped;
+};
+// pass 2: histogram[c][bucket] += 1 for every sample; channels with tables[c].entries == 0 are skipped
+hipError_t launchGainMapHistogram(const float * ratios, size_t numPixels, int channels, const GainMapStepTable tables[3], uint32_t * const histograms[3],
+                                  hipStream_t stream);
+// pass 3: the gain map as RGBA of `depth` bits (avifRGBImageSetDefaults layout), alpha opaque; tables[c].entries == 0: code 0 (:766-773)
+hipError_t launchGainMapQuantise(const float * ratios, uint32_t width, uint32_t height, int channels, const GainMapStepTable tables[3], uint8_t * rgba,
+                                 uint32_t rgbaPitch, uint32_t depth, hipStream_t stream);
+
 } // namespace avifhip

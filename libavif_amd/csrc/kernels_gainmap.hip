@@ -278,6 +278,155 @@ __global__ __launch_bounds__(1024) void gainMapReduceKernel(GainMapStats * stats
     }
 }
 
+// ---- gain-map computation -----------------------------------------------------------------------------------------
+
+// linear light of the two images at one pixel, in the primaries the gain-map math runs in
+__device__ __forceinline__ void computeLinearPair(const GainMapComputeArgs & A, uint32_t i, uint32_t j, float b[3], float a[3])
+{
+    uint32_t code[3];
+    float alpha;
+    readPixel(A.base + (size_t)j * A.basePitch + (size_t)i * A.baseL.pixelBytes, A.baseL, false, code, alpha);
+    b[0] = A.baseLut[code[0]], b[1] = A.baseLut[code[1]], b[2] = A.baseLut[code[2]];
+    readPixel(A.alt + (size_t)j * A.altPitch + (size_t)i * A.altL.pixelBytes, A.altL, false, code, alpha);
+    a[0] = A.altLut[code[0]], a[1] = A.altLut[code[1]], a[2] = A.altLut[code[2]];
+    if (A.convertAlt)
+        convertPrimaries(a, A.M);
+    if (A.convertBase)
+        convertPrimaries(b, A.M);
+}
+
+template <int N>
+__device__ __forceinline__ void blockReduceStore(float v[N], const bool isMax[N], float * out)
+{
+    __shared__ float scratch[4][N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const float o = __shfl_xor(v[k], m);
+            v[k] = isMax[k] ? fmaxf(v[k], o) : fminf(v[k], o);
+        }
+    }
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            scratch[threadIdx.y][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            float r = scratch[0][k];
+            for (int w = 1; w < 4; ++w)
+                r = isMax[k] ? fmaxf(r, scratch[w][k]) : fminf(r, scratch[w][k]);
+            out[k] = r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gainMapChannelMinKernel(GainMapComputeArgs A, uint32_t tilesX, uint32_t tiles)
+{
+    float mn[3] = { 0.0f, 0.0f, 0.0f };
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t i = (tile % tilesX) * 64 + threadIdx.x, j = (tile / tilesX) * 4 + threadIdx.y;
+        if (i >= A.width || j >= A.height)
+            continue;
+        float b[3], a[3];
+        computeLinearPair(A, i, j, b, a);
+        const float * v = A.convertAlt ? a : b;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            mn[c] = (mn[c] < v[c]) ? mn[c] : v[c]; // AVIF_MIN: a NaN candidate replaces the minimum, like the reference's macro
+    }
+    const bool isMax[3] = { false, false, false };
+    blockReduceStore<3>(mn, isMax, A.partials + (size_t)blockIdx.x * 8);
+}
+
+__global__ __launch_bounds__(256) void gainMapRatioKernel(GainMapComputeArgs A, uint32_t tilesX, uint32_t tiles)
+{
+    const size_t numPixels = (size_t)A.width * A.height;
+    const int channels = A.singleChannel ? 1 : 3;
+    // [baseMax, altMax, minRatio x 3, maxRatio x 3]
+    float acc[8] = { 1.0f, 1.0f, __builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f, 0.0f, 0.0f };
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t i = (tile % tilesX) * 64 + threadIdx.x, j = (tile / tilesX) * 4 + threadIdx.y;
+        if (i >= A.width || j >= A.height)
+            continue;
+        float b[3], a[3];
+        computeLinearPair(A, i, j, b, a);
+        for (int c = 0; c < channels; ++c) {
+            float base = b[c], alt = a[c];
+            if (A.singleChannel) { // :699-703, products and sums in the reference's order
+                base = A.yCoeffs[0] * b[0] + A.yCoeffs[1] * b[1] + A.yCoeffs[2] * b[2];
+                alt = A.yCoeffs[0] * a[0] + A.yCoeffs[1] * a[1] + A.yCoeffs[2] * a[2];
+            }
+            if (base > acc[0])
+                acc[0] = base;
+            if (alt > acc[1])
+                acc[1] = alt;
+            const float ratio = (alt + A.altOffset[c]) / (base + A.baseOffset[c]);
+            const float r = (ratio > 1e-10f) ? ratio : 1e-10f; // AVIF_MAX(ratio, kEpsilon): NaN -> epsilon
+            A.ratios[(size_t)c * numPixels + (size_t)j * A.width + i] = r;
+            acc[2 + c] = fminf(acc[2 + c], r), acc[5 + c] = fmaxf(acc[5 + c], r);
+        }
+    }
+    const bool isMax[8] = { true, true, false, false, false, true, true, true };
+    blockReduceStore<8>(acc, isMax, A.partials + (size_t)blockIdx.x * 8);
+}
+
+// largest k with steps[k] <= x; `entries` a power of two, steps[0] = -inf, NaN padding
+__device__ __forceinline__ uint32_t stepIndex(const float * steps, uint32_t entries, float x)
+{
+    uint32_t pos = 0;
+    for (uint32_t s = entries >> 1; s; s >>= 1)
+        pos += (steps[pos + s] <= x) ? s : 0;
+    return pos;
+}
+
+struct GainMapStepTables
+{
+    GainMapStepTable t[3];
+};
+
+__global__ __launch_bounds__(256) void gainMapHistogramKernel(const float * ratios, size_t numPixels, int channels, GainMapStepTables T, uint32_t * h0,
+                                                              uint32_t * h1, uint32_t * h2)
+{
+    uint32_t * const hist[3] = { h0, h1, h2 };
+    for (int c = 0; c < channels; ++c) {
+        if (!T.t[c].entries)
+            continue;
+        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < numPixels; k += (size_t)gridDim.x * 256) {
+            const uint32_t m = stepIndex(T.t[c].steps, T.t[c].entries, ratios[(size_t)c * numPixels + k]);
+            atomicAdd(&hist[c][T.t[c].flipped ? T.t[c].flip - m : m], 1u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gainMapQuantiseKernel(const float * ratios, uint32_t width, uint32_t height, int channels, GainMapStepTables T,
+                                                             uint8_t * rgba, uint32_t rgbaPitch, uint32_t depth)
+{
+    const size_t numPixels = (size_t)width * height;
+    const uint32_t maxCode = (1u << depth) - 1;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < numPixels; k += (size_t)gridDim.x * 256) {
+        const uint32_t j = (uint32_t)(k / width), i = (uint32_t)(k - (size_t)j * width);
+        uint32_t code[3];
+        for (int c = 0; c < channels; ++c) {
+            if (!T.t[c].entries) {
+                code[c] = 0;
+                continue;
+            }
+            const uint32_t m = stepIndex(T.t[c].steps, T.t[c].entries, ratios[(size_t)c * numPixels + k]);
+            code[c] = T.t[c].flipped ? T.t[c].flip - m : m;
+        }
+        if (channels == 1)
+            code[1] = code[2] = code[0];
+        uint8_t * p = rgba + (size_t)j * rgbaPitch;
+        if (depth > 8)
+            reinterpret_cast<uint2 *>(p)[i] = { code[0] | (code[1] << 16), code[2] | (maxCode << 16) };
+        else
+            reinterpret_cast<uint32_t *>(p)[i] = code[0] | (code[1] << 8) | (code[2] << 16) | (maxCode << 24);
+    }
+}
+
 } // namespace
 
 hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream)
@@ -293,6 +442,46 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream)
         hipLaunchKernelGGL(gainMapApplyKernel<false>, dim3(groups), dim3(64, 4), 0, stream, A, tilesX, tiles);
     if (A.gain)
         hipLaunchKernelGGL(gainMapReduceKernel, dim3(1), dim3(1024), 0, stream, A.stats, A.blockMax, A.blockSum, groups);
+    return hipGetLastError();
+}
+
+hipError_t launchGainMapChannelMin(const GainMapComputeArgs & A, hipStream_t stream)
+{
+    const uint32_t tilesX = (A.width + 63) / 64, tiles = tilesX * ((A.height + 3) / 4);
+    const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
+    hipLaunchKernelGGL(gainMapChannelMinKernel, dim3(groups), dim3(64, 4), 0, stream, A, tilesX, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launchGainMapRatios(const GainMapComputeArgs & A, hipStream_t stream)
+{
+    const uint32_t tilesX = (A.width + 63) / 64, tiles = tilesX * ((A.height + 3) / 4);
+    const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
+    hipLaunchKernelGGL(gainMapRatioKernel, dim3(groups), dim3(64, 4), 0, stream, A, tilesX, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launchGainMapHistogram(const float * ratios, size_t numPixels, int channels, const GainMapStepTable tables[3], uint32_t * const histograms[3],
+                                  hipStream_t stream)
+{
+    GainMapStepTables T;
+    for (int c = 0; c < 3; ++c)
+        T.t[c] = tables[c];
+    const size_t want = (numPixels + 255) / 256;
+    const uint32_t groups = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
+    hipLaunchKernelGGL(gainMapHistogramKernel, dim3(groups), dim3(256), 0, stream, ratios, numPixels, channels, T, histograms[0], histograms[1], histograms[2]);
+    return hipGetLastError();
+}
+
+hipError_t launchGainMapQuantise(const float * ratios, uint32_t width, uint32_t height, int channels, const GainMapStepTable tables[3], uint8_t * rgba,
+                                 uint32_t rgbaPitch, uint32_t depth, hipStream_t stream)
+{
+    GainMapStepTables T;
+    for (int c = 0; c < 3; ++c)
+        T.t[c] = tables[c];
+    const size_t want = ((size_t)width * height + 255) / 256;
+    const uint32_t groups = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
+    hipLaunchKernelGGL(gainMapQuantiseKernel, dim3(groups), dim3(256), 0, stream, ratios, width, height, channels, T, rgba, rgbaPitch, depth);
     return hipGetLastError();
 }
 

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
     "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
-    "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipImageApplyGainMap",
+    "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap",
 ]
 
 class avifSampleTransformToken(C.Structure):
@@ -107,6 +107,7 @@ def load() -> C.CDLL:
                                               C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics)]),
         "avifhipRGBImageApplyGainMapAsync": (i32, [P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
                                                    C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics), vp]),
+        "avifhipRGBImageComputeGainMap": (i32, [P_RGB, C.c_uint16, C.c_uint16, P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.POINTER(avifDiagnostics)]),
         "avifhipImageApplyGainMap": (i32, [P_IMG, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
                                            C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics)]),
     }

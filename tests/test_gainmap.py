@@ -244,3 +244,34 @@ def test_gpu_yuv_base_image(hip_auto_arithmetic):
         assert clli_a.maxCLL == clli_b.maxCLL and abs(clli_a.maxPALL - clli_b.maxPALL) <= 1
         libc.free(C.cast(want.struct.pixels, C.c_void_p))
         libc.free(C.cast(got.struct.pixels, C.c_void_p))
+
+
+@pytest.mark.gpu
+def test_gpu_compute_equals_oracle_default_arithmetic(hip_auto_arithmetic):
+    """avifhipRGBImageComputeGainMap: metadata fractions and gain-map planes identical to the oracle's (the default-build flavour:
+    the gain map's RGB -> YUV conversion as a libavif built with libyuv computes it)."""
+    o = oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    bad = []
+    cases = G.compute_cases(120, seed=12) + [G.ComputeCase(1001, 333, gm_w=500, gm_h=167, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420),
+                                             G.ComputeCase(640, 360, alt_primaries=9, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400, gm_depth=10)]
+    for c in cases:
+        ra, sa = run_compute(o.oracleRGBImageComputeGainMap, c, 1)
+        rb, sb = run_compute(hip_auto_arithmetic.avifhipRGBImageComputeGainMap, c, C.byref(diag))
+        if ra != rb or not states_equal(sa, sb):
+            bad.append(f"{c.ident()}: results {ra}/{rb}" + ("" if sa is None or sb is None else f" meta equal {sa[0] == sb[0]} size {sa[1]}/{sb[1]}"))
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+
+
+@pytest.mark.gpu
+def test_gpu_compute_equals_oracle_fp32_arithmetic(hip):
+    o = oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    bad = []
+    cases = G.compute_cases(60, seed=13)
+    for c in cases:
+        ra, sa = run_compute(o.oracleRGBImageComputeGainMap, c, 0)
+        rb, sb = run_compute(hip.avifhipRGBImageComputeGainMap, c, C.byref(diag))
+        if ra != rb or not states_equal(sa, sb):
+            bad.append(f"{c.ident()}: results {ra}/{rb}" + ("" if sa is None or sb is None else f" meta equal {sa[0] == sb[0]} size {sa[1]}/{sb[1]}"))
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
