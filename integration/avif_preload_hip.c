@@ -2,7 +2,8 @@
  * avif_preload_hip.c -- seam A: an LD_PRELOAD-able interposer for applications that link a SHARED libavif and cannot be
  * rebuilt.  It exports the four public reformat entry points of include/avif/avif.h:1031-1038
  *     avifImageYUVToRGB, avifImageRGBToYUV, avifRGBImagePremultiplyAlpha, avifRGBImageUnpremultiplyAlpha
- * and the tone-mapping entry point avifRGBImageApplyGainMap (:1736-1745) with libavif's own signatures, serves them from libavifhip.so (the MI355X HIP kernels), and forwards to the real
+ * and the gain-map entry points avifRGBImageApplyGainMap (:1736-1745) and avifRGBImageComputeGainMap (:1752-1759) with
+ * libavif's own signatures, serves them from libavifhip.so (the MI355X HIP kernels), and forwards to the real
  * libavif (dlsym(RTLD_NEXT)) everything that is not worth a GPU round trip, that the GPU library declines, or that fails
  * on the accelerator -- the application's call never fails because of the interposer.
  *
@@ -10,7 +11,7 @@
  *
  * Arithmetic follows the libavif being interposed: if it was built with libyuv (avifLibYUVVersion() != 0) results equal
  * that build's (libavifhip's default, AVIFHIP_ARITHMETIC_AUTO); if it was built without, the fp32 arithmetic is pinned.
- * AVIFHIP_ARITHMETIC in the environment overrides.  Only the five symbols above are interposed; calls libavif makes
+ * AVIFHIP_ARITHMETIC in the environment overrides.  Only the six symbols above are interposed; calls libavif makes
  * internally (e.g. avifImageYUVToRGB from its decoder helpers) are bound inside libavif and are not affected.
  */
 #define _GNU_SOURCE
@@ -29,6 +30,9 @@ typedef unsigned int (*VersionFn)(void);
 typedef avifResult (*GainMapFn)(const avifRGBImage *, avifColorPrimaries, avifTransferCharacteristics, const avifGainMap *, float, avifColorPrimaries,
                                 avifTransferCharacteristics, avifRGBImage *, avifContentLightLevelInformationBox *, avifDiagnostics *);
 
+typedef avifResult (*ComputeGainMapFn)(const avifRGBImage *, avifColorPrimaries, avifTransferCharacteristics, const avifRGBImage *, avifColorPrimaries,
+                                       avifTransferCharacteristics, avifGainMap *, avifDiagnostics *);
+
 static struct
 {
     int resolved;
@@ -36,6 +40,7 @@ static struct
     RgbToYuvFn rgbToYuv;
     AlphaFn premultiply, unpremultiply;
     GainMapFn applyGainMap;
+    ComputeGainMapFn computeGainMap;
     uint64_t minPixels;
     int gpu;
 } g;
@@ -49,6 +54,7 @@ static void resolve(void)
     g.premultiply = (AlphaFn)dlsym(RTLD_NEXT, "avifRGBImagePremultiplyAlpha");
     g.unpremultiply = (AlphaFn)dlsym(RTLD_NEXT, "avifRGBImageUnpremultiplyAlpha");
     g.applyGainMap = (GainMapFn)dlsym(RTLD_NEXT, "avifRGBImageApplyGainMap");
+    g.computeGainMap = (ComputeGainMapFn)dlsym(RTLD_NEXT, "avifRGBImageComputeGainMap");
     const char * e = getenv("AVIFHIP_MIN_PIXELS");
     const long v = e ? atol(e) : 512L * 512L;
     g.minPixels = v < 0 ? 0 : (uint64_t)v;
@@ -139,4 +145,29 @@ AVIF_EXPORT avifResult avifRGBImageApplyGainMap(const avifRGBImage * baseImage,
     return g.applyGainMap ? g.applyGainMap(baseImage, baseColorPrimaries, baseTransferCharacteristics, gainMap, hdrHeadroom, outputColorPrimaries,
                                            outputTransferCharacteristics, toneMappedImage, clli, diag)
                           : AVIF_RESULT_NOT_IMPLEMENTED;
+}
+
+/* Gain-map computation.  libavifhip frees the planes gainMap->image owns and mallocs the new ones; libavif's
+ * avifImageFreePlanes / avifImageDestroy release them with free: interchangeable, like the pixels above. */
+AVIF_EXPORT avifResult avifRGBImageComputeGainMap(const avifRGBImage * baseRgbImage,
+                                                  avifColorPrimaries baseColorPrimaries,
+                                                  avifTransferCharacteristics baseTransferCharacteristics,
+                                                  const avifRGBImage * altRgbImage,
+                                                  avifColorPrimaries altColorPrimaries,
+                                                  avifTransferCharacteristics altTransferCharacteristics,
+                                                  avifGainMap * gainMap,
+                                                  avifDiagnostics * diag)
+{
+    resolve();
+    if (baseRgbImage && altRgbImage && gainMap && gainMap->image && worthIt(baseRgbImage->width, baseRgbImage->height)) {
+        const avifImage request = *gainMap->image; /* the requested size / format, should the call be handed on */
+        const avifResult r = avifhipRGBImageComputeGainMap(baseRgbImage, baseColorPrimaries, baseTransferCharacteristics, altRgbImage, altColorPrimaries,
+                                                           altTransferCharacteristics, gainMap, diag);
+        if (!declined(r) || !g.computeGainMap)
+            return r;
+        gainMap->image->width = request.width, gainMap->image->height = request.height;
+    }
+    return g.computeGainMap ? g.computeGainMap(baseRgbImage, baseColorPrimaries, baseTransferCharacteristics, altRgbImage, altColorPrimaries,
+                                               altTransferCharacteristics, gainMap, diag)
+                            : AVIF_RESULT_NOT_IMPLEMENTED;
 }

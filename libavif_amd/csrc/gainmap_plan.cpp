@@ -458,9 +458,11 @@ inline int bucketOfValue(float v, float lo, float hi, int n) // avifValueToBucke
     return idx < n - 1 ? idx : n - 1;
 }
 
-// T[i] = smallest r in [minRatio, maxRatio] (fp32 order) with m(r) >= i, for i = 1 .. count - 1; m non-decreasing
-template <typename Fn>
-std::vector<float> monotoneSteps(float minRatio, float maxRatio, uint32_t count, uint32_t entries, Fn m)
+// T[i] = smallest r in [minRatio, maxRatio] (fp32 order) with m(r) >= i, for i = 1 .. count - 1; m non-decreasing.  `guess(i)`
+// is an estimate of T[i] (any float): the search brackets the step by galloping away from it before bisecting, which costs ~10
+// evaluations of m instead of 32 when the estimate is good; correctness never depends on it.
+template <typename Fn, typename Guess>
+std::vector<float> monotoneSteps(float minRatio, float maxRatio, uint32_t count, uint32_t entries, Fn m, Guess guess)
 {
     std::vector<float> T(entries, NAN);
     for (uint32_t i = 1; i < count; ++i)
@@ -470,7 +472,37 @@ std::vector<float> monotoneSteps(float minRatio, float maxRatio, uint32_t count,
     uint32_t lowKey = keyOfFloat(minRatio);
     const uint32_t top = m(maxRatio);
     for (uint32_t i = 1; i < count && i <= top; ++i) {
+        // invariant: every key < lo has m < i; key hi has m >= i
         uint32_t lo = lowKey, hi = keyHi;
+        const float g = guess(i);
+        if (g == g && g > 0.0f) {
+            uint32_t k = keyOfFloat(g);
+            k = k < lo ? lo : (k > hi ? hi : k);
+            if (m(floatOfKey(k)) >= i) { // gallop down to a key with m < i
+                hi = k;
+                for (uint32_t step = 64; hi > lo; step <<= 2) {
+                    const uint32_t probe = (hi - lo > step) ? hi - step : lo;
+                    if (m(floatOfKey(probe)) >= i) {
+                        hi = probe;
+                        if (probe == lo)
+                            break;
+                    } else {
+                        lo = probe + 1;
+                        break;
+                    }
+                }
+            } else { // gallop up to a key with m >= i
+                lo = k + 1;
+                for (uint32_t step = 64; lo < hi; step <<= 2) {
+                    const uint32_t probe = (hi - lo > step) ? lo + step : hi;
+                    if (m(floatOfKey(probe)) >= i) {
+                        hi = probe;
+                        break;
+                    }
+                    lo = probe + 1;
+                }
+            }
+        }
         while (lo < hi) {
             const uint32_t mid = lo + (hi - lo) / 2;
             if (m(floatOfKey(mid)) >= i)
@@ -561,10 +593,16 @@ std::vector<float> gainMapBucketSteps(const GainMapChannelRange & R, uint32_t * 
         n <<= 1;
     *entries = n;
     const int nb = R.numBuckets;
-    return monotoneSteps(R.minRatio, R.maxRatio, (uint32_t)nb, n, [&](float r) -> uint32_t {
-        const int b = bucketOfValue(valueOfRatio(R.sign, r), R.lo, R.hi, nb);
-        return (uint32_t)(R.sign > 0 ? b : nb - 1 - b);
-    });
+    return monotoneSteps(
+        R.minRatio, R.maxRatio, (uint32_t)nb, n,
+        [&](float r) -> uint32_t {
+            const int b = bucketOfValue(valueOfRatio(R.sign, r), R.lo, R.hi, nb);
+            return (uint32_t)(R.sign > 0 ? b : nb - 1 - b);
+        },
+        [&](uint32_t i) -> float { // bucket b starts near value lo + (b - 0.5) / n * (hi - lo); m = b or nb - 1 - b
+            const float b = R.sign > 0 ? (float)i - 0.5f : (float)(nb - 1) - (float)i + 0.5f;
+            return exp2f(R.sign * (R.lo + b / (float)nb * (R.hi - R.lo)));
+        });
 }
 
 void gainMapRangeWithoutOutliers(const GainMapChannelRange & R, const uint32_t * histogram, float * rangeMin, float * rangeMax)
@@ -595,14 +633,20 @@ std::vector<float> gainMapCodeSteps(const GainMapChannelRange & R, float minLog2
     const uint32_t n = 1u << depth, maxCode = n - 1;
     const float maxF = (float)maxCode;
     const float range = (maxLog2 - minLog2 > 0.0f) ? maxLog2 - minLog2 : 0.0f;
-    return monotoneSteps(R.minRatio, R.maxRatio, n, n, [&](float r) -> uint32_t {
-        float v = valueOfRatio(R.sign, r);
-        v = clampf(v, minLog2, maxLog2);
-        v = powf((v - minLog2) / range, gamma);
-        v = fminf(1.0f, fmaxf(0.0f, v));
-        const uint32_t code = (uint32_t)(0.5f + v * maxF);
-        return R.sign > 0 ? code : maxCode - code;
-    });
+    return monotoneSteps(
+        R.minRatio, R.maxRatio, n, n,
+        [&](float r) -> uint32_t {
+            float v = valueOfRatio(R.sign, r);
+            v = clampf(v, minLog2, maxLog2);
+            v = powf((v - minLog2) / range, gamma);
+            v = fminf(1.0f, fmaxf(0.0f, v));
+            const uint32_t code = (uint32_t)(0.5f + v * maxF);
+            return R.sign > 0 ? code : maxCode - code;
+        },
+        [&](uint32_t i) -> float { // code c starts near ((c - 0.5) / maxCode)^(1 / gamma) of the way from minLog2 to maxLog2
+            const float c = R.sign > 0 ? (float)i - 0.5f : maxF - (float)i + 0.5f;
+            return exp2f(R.sign * (minLog2 + powf(c / maxF, 1.0f / gamma) * range));
+        });
 }
 
 } // namespace avifhip

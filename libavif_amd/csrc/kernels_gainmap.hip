@@ -387,17 +387,32 @@ struct GainMapStepTables
     GainMapStepTable t[3];
 };
 
+// Histograms are privatised: each (persistent) workgroup counts one channel at a time in LDS (<= 10000 buckets = 40 KB) and adds
+// its non-zero counts to the global histogram at the end -- one global atomic per sample took 5.9 ms on a 4K image (the
+// distribution is peaked: most samples fall into a few buckets).
+constexpr uint32_t kHistogramLdsBuckets = 10240;
+
 __global__ __launch_bounds__(256) void gainMapHistogramKernel(const float * ratios, size_t numPixels, int channels, GainMapStepTables T, uint32_t * h0,
                                                               uint32_t * h1, uint32_t * h2)
 {
+    __shared__ uint32_t local[kHistogramLdsBuckets];
     uint32_t * const hist[3] = { h0, h1, h2 };
     for (int c = 0; c < channels; ++c) {
         if (!T.t[c].entries)
             continue;
+        const uint32_t buckets = T.t[c].flip + 1;
+        for (uint32_t k = threadIdx.x; k < buckets; k += 256)
+            local[k] = 0;
+        __syncthreads();
         for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < numPixels; k += (size_t)gridDim.x * 256) {
             const uint32_t m = stepIndex(T.t[c].steps, T.t[c].entries, ratios[(size_t)c * numPixels + k]);
-            atomicAdd(&hist[c][T.t[c].flipped ? T.t[c].flip - m : m], 1u);
+            atomicAdd(&local[T.t[c].flipped ? T.t[c].flip - m : m], 1u);
         }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < buckets; k += 256)
+            if (local[k])
+                atomicAdd(&hist[c][k], local[k]);
+        __syncthreads();
     }
 }
 
@@ -468,7 +483,7 @@ hipError_t launchGainMapHistogram(const float * ratios, size_t numPixels, int ch
     for (int c = 0; c < 3; ++c)
         T.t[c] = tables[c];
     const size_t want = (numPixels + 255) / 256;
-    const uint32_t groups = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
+    const uint32_t groups = (uint32_t)(want < 1024 ? (want ? want : 1) : 1024); // few workgroups: each flushes a whole histogram
     hipLaunchKernelGGL(gainMapHistogramKernel, dim3(groups), dim3(256), 0, stream, ratios, numPixels, channels, T, histograms[0], histograms[1], histograms[2]);
     return hipGetLastError();
 }

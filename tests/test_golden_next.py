@@ -1,5 +1,5 @@
 """Golden fixtures of the paths next to the conversion (tests/golden/next_*.npz, written by tests/tools/make_golden_next.py
-from the reference compiled from its own sources): plane scaling and gain-map application.  The oracles must reproduce every
+from the reference compiled from its own sources): plane scaling, gain-map application and gain-map computation.  The oracles must reproduce every
 one byte for byte on any machine -- no /root/reference, no oracle/_ref needed -- and so must the HIP library on the GPU box.
 Inputs come from the fixture files, not from the generators."""
 import ctypes as C
@@ -18,6 +18,7 @@ from libavif_amd import abi
 GOLDEN = Path(__file__).resolve().parent / "golden"
 SCALE = sorted(GOLDEN.glob("next_scale_*.npz"))
 GAINMAP = sorted(GOLDEN.glob("next_gainmap_*.npz"))
+COMPUTE = sorted(GOLDEN.glob("next_gmcompute_*.npz"))
 libc = C.CDLL(None)
 libc.free.argtypes = [C.c_void_p]
 
@@ -57,6 +58,39 @@ def check_gainmap(path, apply_fn, extra):
         assert clli.maxCLL == int(z["clli"][0]) and abs(clli.maxPALL - int(z["clli"][1])) <= 1, (path.name, clli.maxCLL, clli.maxPALL, z["clli"])
     if out.struct.pixels:
         libc.free(C.cast(out.struct.pixels, C.c_void_p))
+
+
+def check_compute(path, compute_fn, extra):
+    import test_gainmap as TG
+
+    z = np.load(path)
+    c = G.ComputeCase(**json.loads(str(z["case"])))
+    base, alt = G.make_compute_inputs(c)
+    base.pixels[...] = z["base"]
+    alt.pixels[...] = z["alt"]
+    gm, img = G.make_compute_gain_map(c)
+    res = compute_fn(base.struct, c.base_primaries, c.base_tc, alt.struct, c.alt_primaries, c.alt_tc, C.byref(gm), extra)
+    assert res == int(z["result"]), path.name
+    if res == 0:
+        meta, size, planes = TG.gain_map_state(gm, img.struct)
+        assert [v for pair in meta[:-1] for v in pair] + [meta[-1]] == [int(v) for v in z["meta"]], path.name
+        assert list(size) == [int(v) for v in z["size"]], path.name
+        for p, buf in enumerate(planes):
+            assert (buf is not None) == (f"out{p}" in z.files), (path.name, p)
+            if buf is not None:
+                assert np.array_equal(buf, z[f"out{p}"]), (path.name, p)
+    TS.free_owned(img.struct)
+
+
+@pytest.mark.parametrize("path", COMPUTE, ids=lambda p: p.stem)
+def test_oracle_gainmap_compute(path):
+    check_compute(path, oracle_lib.oracle().oracleRGBImageComputeGainMap, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", COMPUTE, ids=lambda p: p.stem)
+def test_gpu_gainmap_compute(hip, path):
+    check_compute(path, hip.avifhipRGBImageComputeGainMap, C.byref(abi.avifDiagnostics()))
 
 
 @pytest.mark.parametrize("path", SCALE, ids=lambda p: p.stem)

@@ -35,7 +35,8 @@ def test_interposer_exports_the_public_symbols():
     import ctypes
 
     lib = ctypes.CDLL(os.fspath(PRELOAD))
-    for sym in ("avifImageYUVToRGB", "avifImageRGBToYUV", "avifRGBImagePremultiplyAlpha", "avifRGBImageUnpremultiplyAlpha", "avifRGBImageApplyGainMap"):
+    for sym in ("avifImageYUVToRGB", "avifImageRGBToYUV", "avifRGBImagePremultiplyAlpha", "avifRGBImageUnpremultiplyAlpha", "avifRGBImageApplyGainMap",
+                "avifRGBImageComputeGainMap"):
         assert hasattr(lib, sym), sym
 
 

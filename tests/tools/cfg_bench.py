@@ -188,6 +188,33 @@ def run(name):
                         call()  # waits for its stream: result code and CLLI depend on the pixels
                     best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
                 ms = best
+        elif name in ("gmcompute4k", "gmcompute4k_cpu"):
+            # avifRGBImageComputeGainMap: 3840x2160 RGBA8 sRGB base + RGBA10 PQ BT.2020 alternate -> 8-bit 4:4:4 gain map + metadata.
+            # The entry point takes HOST images (the encode side is host-driven): the time includes the PCIe transfers both ways.
+            if arith == "integer":
+                continue
+            sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+            import gainmap_cases as G
+            c = G.ComputeCase(3840, 2160, alt_primaries=9, seed=3)
+            base, alt = G.make_compute_inputs(c)
+            gm, img = G.make_compute_gain_map(c)
+            diag = abi.avifDiagnostics()
+            px, bpp = c.w * c.h, 4 + 8 + 3
+            if name == "gmcompute4k_cpu":
+                import oracle_lib
+                t0 = time.perf_counter()
+                assert oracle_lib.oracle().oracleRGBImageComputeGainMap(base.struct, 1, 13, alt.struct, 9, 16, C.byref(gm), 1) == 0
+                ms = (time.perf_counter() - t0) * 1e3
+            else:
+                call = lambda: native.check(lib.avifhipRGBImageComputeGainMap(base.struct, 1, 13, alt.struct, 9, 16, C.byref(gm), C.byref(diag)))
+                for _ in range(2):
+                    call()
+                best = 1e9
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    call()
+                    best = min(best, (time.perf_counter() - t0) * 1e3)
+                ms = best
         else:
             raise SystemExit(f"unknown configuration {name}")
         gbps = bpp * px / (ms * 1e-3) / 1e9

@@ -42,6 +42,12 @@ GAINMAP = [G.GainMapCase(37, 21), G.GainMapCase(37, 21, out_tc=16, out_primaries
                          base_offset=((0, 1),) * 3)]
 
 
+COMPUTE = [G.ComputeCase(37, 21), G.ComputeCase(64, 48, gm_w=32, gm_h=24, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, gm_depth=10),
+           G.ComputeCase(37, 21, alt_primaries=9, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400),
+           G.ComputeCase(37, 21, base_tc=16, base_depth=10, alt_tc=13, alt_depth=8, base_primaries=9, alt_primaries=1, gm_range=abi.AVIF_RANGE_LIMITED, gm_matrix=1),
+           G.ComputeCase(120, 40, alt_float=True, alt_depth=16, alt_tc=8, gm_depth=12, seed=5)]
+
+
 def main():
     diag = abi.avifDiagnostics()
     for k, (c, dw, dh) in enumerate(SCALE):
@@ -74,7 +80,21 @@ def main():
         if out.struct.pixels:
             TG.libc.free(C.cast(out.struct.pixels, C.c_void_p))
         np.savez_compressed(OUT / f"next_gainmap_{k:02d}.npz", **data)
-    print("wrote", len(SCALE) + len(GAINMAP), "fixtures")
+    for k, c in enumerate(COMPUTE):
+        base, alt = G.make_compute_inputs(c)
+        gm, img = G.make_compute_gain_map(c)
+        res = ref.avifRGBImageComputeGainMap(base.struct, c.base_primaries, c.base_tc, alt.struct, c.alt_primaries, c.alt_tc, C.byref(gm), C.byref(diag))
+        data = {"case": json.dumps(asdict(c)), "base": base.pixels.copy(), "alt": alt.pixels.copy(), "result": np.array(res)}
+        if res == 0:
+            meta, size, planes = TG.gain_map_state(gm, img.struct)
+            data["meta"] = np.array([v for pair in meta[:-1] for v in pair] + [meta[-1]], dtype=np.int64)
+            data["size"] = np.array(size)
+            for p, buf in enumerate(planes):
+                if buf is not None:
+                    data[f"out{p}"] = buf
+        TS.free_owned(img.struct)
+        np.savez_compressed(OUT / f"next_gmcompute_{k:02d}.npz", **data)
+    print("wrote", len(SCALE) + len(GAINMAP) + len(COMPUTE), "fixtures")
 
 
 if __name__ == "__main__":
