@@ -1,0 +1,746 @@
+// api_gainmap.cpp -- C ABI entry points for gain maps (include/avifhip.h): avifhipRGBImageApplyGainMap[Async],
+// avifhipImageApplyGainMap, avifhipRGBImageComputeGainMap.  Host logic mirrors reference src/gainmap.c; tables come from
+// gainmap_plan.cpp, kernels from kernels_gainmap.hip.
+#include "api_internal.h"
+
+using namespace avifhip;
+using namespace avifhip::api;
+
+// =================================================================================================
+// gain-map application, reference src/gainmap.c:73-355
+// =================================================================================================
+
+namespace {
+
+void diagClear(avifDiagnostics * diag)
+{
+    if (diag)
+        diag->error[0] = '\0';
+}
+void diagPrintf(avifDiagnostics * diag, const char * fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    char text[AVIF_DIAGNOSTICS_ERROR_BUFFER_SIZE];
+    vsnprintf(text, sizeof(text), fmt, ap);
+    va_end(ap);
+    if (diag)
+        memcpy(diag->error, text, sizeof(text));
+    setError("%s", text);
+}
+
+inline float fractionToFloat(avifSignedFraction f) // src/gainmap.c:32-38
+{
+    return f.d == 0 ? 0.0f : (float)f.n / f.d;
+}
+inline float fractionToFloat(avifUnsignedFraction f) // :40-46
+{
+    return f.d == 0 ? 0.0f : (float)f.n / f.d;
+}
+
+avifResult gainMapValidateMetadata(const avifGainMap * gainMap, avifDiagnostics * diag) // :430-457
+{
+    for (int i = 0; i < 3; ++i) {
+        if (gainMap->gainMapMin[i].d == 0 || gainMap->gainMapMax[i].d == 0 || gainMap->gainMapGamma[i].d == 0 || gainMap->baseOffset[i].d == 0 ||
+            gainMap->alternateOffset[i].d == 0) {
+            diagPrintf(diag, "Per-channel denominator is 0 in gain map metadata");
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        }
+        if ((int64_t)gainMap->gainMapMax[i].n * gainMap->gainMapMin[i].d < (int64_t)gainMap->gainMapMin[i].n * gainMap->gainMapMax[i].d) {
+            diagPrintf(diag, "Per-channel max is less than per-channel min in gain map metadata");
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        }
+        if (gainMap->gainMapGamma[i].n == 0) {
+            diagPrintf(diag, "Per-channel gamma is 0 in gain map metadata");
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        }
+    }
+    if (gainMap->baseHdrHeadroom.d == 0 || gainMap->alternateHdrHeadroom.d == 0) {
+        diagPrintf(diag, "Headroom denominator is 0 in gain map metadata");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    if (gainMap->useBaseColorSpace != 0 && gainMap->useBaseColorSpace != 1) {
+        diagPrintf(diag, "useBaseColorSpace is %d in gain map metadata", gainMap->useBaseColorSpace);
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    return AVIF_RESULT_OK;
+}
+
+float gainMapWeight(float hdrHeadroom, const avifGainMap * gainMap) // avifGetGainMapWeight, :52-63
+{
+    const float base = fractionToFloat(gainMap->baseHdrHeadroom), alternate = fractionToFloat(gainMap->alternateHdrHeadroom);
+    if (base == alternate)
+        return 0.0f;
+    const float r = (hdrHeadroom - base) / (alternate - base);
+    const float w = (r < 0.0f) ? 0.0f : ((1.0f < r) ? 1.0f : r);
+    return (alternate < base) ? -w : w;
+}
+
+bool gainMapLayout(const avifRGBImage * rgb, GainMapPixelLayout * L) // avifGetRGBColorSpaceInfo, src/reformat.c:32-117
+{
+    if (rgb->depth != 8 && rgb->depth != 10 && rgb->depth != 12 && rgb->depth != 16)
+        return false;
+    if ((rgb->isFloat && rgb->depth != 16) || (rgb->format == AVIF_RGB_FORMAT_RGB_565 && rgb->depth != 8))
+        return false;
+    memset(L, 0, sizeof(*L));
+    const uint32_t cb = (rgb->depth > 8) ? 2 : 1;
+    L->channelBytes = cb;
+    uint32_t n = 0;
+    switch (rgb->format) {
+        case AVIF_RGB_FORMAT_RGB: L->offR = 0, L->offG = cb, L->offB = 2 * cb, n = 3; break;
+        case AVIF_RGB_FORMAT_RGBA: L->offR = 0, L->offG = cb, L->offB = 2 * cb, L->offA = 3 * cb, n = 4; break;
+        case AVIF_RGB_FORMAT_ARGB: L->offA = 0, L->offR = cb, L->offG = 2 * cb, L->offB = 3 * cb, n = 4; break;
+        case AVIF_RGB_FORMAT_BGR: L->offB = 0, L->offG = cb, L->offR = 2 * cb, n = 3; break;
+        case AVIF_RGB_FORMAT_BGRA: L->offB = 0, L->offG = cb, L->offR = 2 * cb, L->offA = 3 * cb, n = 4; break;
+        case AVIF_RGB_FORMAT_ABGR: L->offA = 0, L->offB = cb, L->offG = 2 * cb, L->offR = 3 * cb, n = 4; break;
+        case AVIF_RGB_FORMAT_RGB_565: L->is565 = 1, n = 2; break;
+        default: return false; // gray layouts have no R, G, B offsets for the tone-mapping loop to index
+    }
+    L->pixelBytes = L->is565 ? 2 : n * cb;
+    L->hasAlpha = (n == 4 && !L->is565) ? 1 : 0;
+    L->isFloat = rgb->isFloat ? 1 : 0;
+    L->depth = rgb->depth;
+    L->maxF = (float)((1u << rgb->depth) - 1);
+    return true;
+}
+
+// The tone-mapping of device-resident images.  `gainImage`: gainMap->image with device plane pointers.  The tone-mapped
+// image must already own device pixels of the base image's size.  Waits for the stream: the result code and the CLLI
+// values depend on the pixels.
+avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries basePrimaries, avifTransferCharacteristics baseTC, const avifGainMap * gainMap,
+                                const avifImage * gainImage, float weight, avifColorPrimaries outPrimaries, avifTransferCharacteristics outTC,
+                                avifRGBImage * out, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag, hipStream_t stream)
+{
+    const uint32_t width = base->width, height = base->height;
+    GainMapArgs A;
+    memset(&A, 0, sizeof(A));
+    if (!gainMapLayout(base, &A.baseL) || !gainMapLayout(out, &A.outL)) {
+        diagPrintf(diag, "Unsupported RGB color space");
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    }
+    A.base = base->pixels, A.basePitch = base->rowBytes, A.out = out->pixels, A.outPitch = out->rowBytes;
+    A.width = width, A.height = height;
+
+    const avifColorPrimaries mathPrimaries =
+        (gainMap->useBaseColorSpace || (gainMap->altColorPrimaries == AVIF_COLOR_PRIMARIES_UNSPECIFIED)) ? basePrimaries : gainMap->altColorPrimaries;
+    const bool applyGain = weight != 0.0f;
+    if (!applyGain) { // "Just convert from one rgb format to another", src/gainmap.c:142-170
+        const bool primariesDiffer = basePrimaries != outPrimaries;
+        if (primariesDiffer && !gainMapPrimariesMatrix(basePrimaries, outPrimaries, A.inM)) {
+            diagPrintf(diag, "Unsupported RGB color space conversion");
+            return AVIF_RESULT_NOT_IMPLEMENTED;
+        }
+        A.inConv = primariesDiffer ? 1 : 0;
+        A.convert = (outTC != baseTC || primariesDiffer) ? 1 : 0;
+    } else {
+        A.convert = 1;
+        A.inConv = (basePrimaries != mathPrimaries) ? 1 : 0, A.outConv = (mathPrimaries != outPrimaries) ? 1 : 0;
+        if ((A.inConv && !gainMapPrimariesMatrix(basePrimaries, mathPrimaries, A.inM)) ||
+            (A.outConv && !gainMapPrimariesMatrix(mathPrimaries, outPrimaries, A.outM))) {
+            diagPrintf(diag, "Unsupported RGB color space conversion");
+            return AVIF_RESULT_NOT_IMPLEMENTED;
+        }
+    }
+
+    // ---- the gain map as RGB at the base image's size, :185-212 ----
+    uint32_t gainDepth = 8;
+    if (applyGain) {
+        avifImage gm;
+        memcpy(&gm, gainImage, sizeof(avifImage));
+        if (gm.width != width || gm.height != height) {
+            avifImage scaled;
+            memcpy(&scaled, &gm, sizeof(avifImage));
+            scaled.width = width, scaled.height = height;
+            const PlaneDims dd = planeDims(width, height, (int)gm.yuvFormat);
+            const size_t bps = (gm.depth > 8) ? 2 : 1;
+            size_t offset[4] = { 0, 0, 0, 0 }, total = 0;
+            uint32_t pitch[4] = { 0, 0, 0, 0 };
+            for (int p = 0; p < 4; ++p) {
+                const uint8_t * sp = (p < 3) ? gm.yuvPlanes[p] : gm.alphaPlane;
+                if (!sp || ((p == 1 || p == 2) && gm.yuvFormat == AVIF_PIXEL_FORMAT_YUV400))
+                    continue;
+                pitch[p] = alignUp((uint32_t)(dd.w[p] * bps), 256);
+                offset[p] = total, total += (size_t)pitch[p] * dd.h[p];
+            }
+            const avifResult rr = reserve(tls.gainMap[4], total ? total : 1);
+            if (rr != AVIF_RESULT_OK)
+                return rr;
+            for (int p = 0; p < 4; ++p) {
+                uint8_t * dp = pitch[p] ? (uint8_t *)tls.gainMap[4].ptr + offset[p] : nullptr;
+                if (p < 3)
+                    scaled.yuvPlanes[p] = dp, scaled.yuvRowBytes[p] = pitch[p];
+                else
+                    scaled.alphaPlane = dp, scaled.alphaRowBytes = pitch[p];
+            }
+            const avifResult sr = avifhipImageScaleAsync(&gm, &scaled, stream);
+            if (sr != AVIF_RESULT_OK)
+                return sr;
+            memcpy(&gm, &scaled, sizeof(avifImage));
+        }
+        avifRGBImage rgbGain; // avifRGBImageSetDefaults, src/avif.c:700-717
+        memset(&rgbGain, 0, sizeof(rgbGain));
+        rgbGain.width = width, rgbGain.height = height, rgbGain.depth = gm.depth, rgbGain.format = AVIF_RGB_FORMAT_RGBA;
+        rgbGain.chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, rgbGain.chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
+        rgbGain.maxThreads = 1;
+        rgbGain.rowBytes = alignUp(width * 4 * ((gm.depth > 8) ? 2 : 1), 256);
+        const avifResult rr = reserve(tls.gainMap[1], (size_t)rgbGain.rowBytes * height);
+        if (rr != AVIF_RESULT_OK)
+            return rr;
+        rgbGain.pixels = (uint8_t *)tls.gainMap[1].ptr;
+        const avifResult cr = avifhipImageYUVToRGBAsync(&gm, &rgbGain, stream);
+        if (cr != AVIF_RESULT_OK)
+            return cr;
+        A.gain = rgbGain.pixels, A.gainPitch = rgbGain.rowBytes, A.gainDepth = gainDepth = gm.depth;
+        for (int c = 0; c < 3; ++c)
+            A.baseOffset[c] = fractionToFloat(gainMap->baseOffset[c]), A.altOffset[c] = fractionToFloat(gainMap->alternateOffset[c]);
+    }
+
+    // ---- tables (kept while the parameters stay the same: sequences of frames, tiles) ----
+    if (A.convert) {
+        GainMapTableCache & cache = tls.gainMapCache;
+        GainMapTableCache::Key key;
+        memset(&key, 0, sizeof(key));
+        key.baseTC = baseTC, key.baseDepth = base->depth, key.baseFloat = base->isFloat ? 1 : 0;
+        key.outTC = outTC, key.outDepth = A.outL.is565 ? 8 : out->depth, key.outFloat = out->isFloat ? 1 : 0;
+        key.gainDepth = gainDepth, key.applyGain = applyGain ? 1 : 0, key.stream = (uint64_t)(uintptr_t)stream;
+        if (applyGain) {
+            for (int c = 0; c < 3; ++c) {
+                key.gammaInv[c] = 1.0f / fractionToFloat(gainMap->gainMapGamma[c]);
+                key.minLog2[c] = fractionToFloat(gainMap->gainMapMin[c]), key.maxLog2[c] = fractionToFloat(gainMap->gainMapMax[c]);
+            }
+            key.weight = weight;
+        }
+        if (!cache.valid || memcmp(&cache.key, &key, sizeof(key)) != 0) {
+            cache.valid = false;
+            std::vector<float> tables = gainMapLinearLut(baseTC, base->depth, base->isFloat != 0);
+            cache.baseLutOffset = 0, cache.gainLutOffset = tables.size();
+            if (applyGain) {
+                for (int c = 0; c < 3; ++c) {
+                    const std::vector<float> g = gainMapGainLut(gainDepth, key.gammaInv[c], key.minLog2[c], key.maxLog2[c], weight);
+                    tables.insert(tables.end(), g.begin(), g.end());
+                }
+            }
+            cache.stepsOffset = tables.size();
+            const GainMapSteps & S = gainMapOutputSteps(outTC, key.outDepth, out->isFloat != 0);
+            tables.insert(tables.end(), S.steps.begin(), S.steps.end());
+            cache.guideOffset = tables.size();
+            tables.resize(tables.size() + (S.guide.size() + 1) / 2, 0.0f); // the 16-bit guide entries ride in float slots
+            memcpy(tables.data() + cache.guideOffset, S.guide.data(), S.guide.size() * sizeof(uint16_t));
+            cache.maxCode = S.maxCode, cache.stepEntries = S.pieceEntries;
+            // what the reference computes for a NaN input (the weight-0 path can meet one in a half-float base image)
+            const float nanGamma = fminf(1.0f, fmaxf(0.0f, gainMapToGamma(outTC, NAN)));
+            cache.nanCode = out->isFloat ? ((uint32_t)0) : (uint32_t)(0.5f + nanGamma * (float)((1u << key.outDepth) - 1));
+            if (out->isFloat) {
+                const float f = nanGamma * 1.9259299444e-34f;
+                uint32_t u;
+                memcpy(&u, &f, 4);
+                cache.nanCode = (u >> 13) & 0xffffu;
+            }
+            const avifResult rr = reserve(tls.gainMap[2], tables.size() * sizeof(float));
+            if (rr != AVIF_RESULT_OK)
+                return rr;
+            const avifResult ur = uploadTableAsync(tls.gainMap[2].ptr, tables.data(), tables.size() * sizeof(float), stream);
+            if (ur != AVIF_RESULT_OK)
+                return ur;
+            cache.key = key;
+            cache.valid = true;
+        }
+        const float * t = (const float *)tls.gainMap[2].ptr;
+        A.baseLut = t + cache.baseLutOffset, A.gainLut = t + cache.gainLutOffset, A.steps = t + cache.stepsOffset;
+        A.maxCode = cache.maxCode, A.nanCode = cache.nanCode, A.stepEntries = cache.stepEntries;
+        A.guide = (const uint16_t *)(t + cache.guideOffset);
+        A.guideFirstBits = kGainMapGuideFirstBits, A.guideShift = kGainMapGuideShift, A.guideBuckets = kGainMapGuideBuckets;
+        // the kernel keeps the tables in LDS when all of them fit (up to 12-bit images; 16-bit and half-float tables stay in
+        // global memory)
+        const size_t stepsEntries = 2 * (size_t)cache.stepEntries, baseEntries = cache.gainLutOffset - cache.baseLutOffset,
+                     gainEntries = cache.stepsOffset - cache.gainLutOffset;
+        if ((stepsEntries + baseEntries + gainEntries) * sizeof(float) + (kGainMapGuideBuckets + 2) * sizeof(uint16_t) <= 64 * 1024)
+            A.ldsSteps = (uint32_t)stepsEntries, A.ldsBaseLut = (uint32_t)baseEntries, A.ldsGainLut = (uint32_t)gainEntries;
+    }
+
+    const size_t partials = kGainMapMaxGroups;
+    const avifResult sr = reserve(tls.gainMap[3], 64 + partials * (sizeof(double) + sizeof(float)));
+    if (sr != AVIF_RESULT_OK)
+        return sr;
+    A.stats = (GainMapStats *)tls.gainMap[3].ptr;
+    A.blockSum = (double *)((uint8_t *)tls.gainMap[3].ptr + 64);
+    A.blockMax = (float *)(A.blockSum + partials);
+    HIP_TRY(hipMemsetAsync(A.stats, 0, sizeof(GainMapStats), stream));
+    const hipError_t e = launchGainMapApply(A, stream);
+    if (e != hipSuccess)
+        return hipFailed(e, "gain map kernel launch");
+    tls.lastKernel = applyGain ? "gainmap_apply" : (A.convert ? "gainmap_convert" : "gainmap_requantise");
+    ++tls.launches;
+    GainMapStats stats;
+    HIP_TRY(hipMemcpyAsync(&stats, A.stats, sizeof(stats), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (applyGain && stats.nan) {
+        diagPrintf(diag, "Degenerate gain map parameters produce NaN");
+        return AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE;
+    }
+    if (applyGain && clli) { // src/gainmap.c:292-302 (the reference sums in fp32 pixel by pixel; here fp64 partial sums)
+        float rgbMaxLinear;
+        memcpy(&rgbMaxLinear, &stats.maxBits, 4);
+        const float kSdrWhiteNits = 203.0f;
+        auto toNits = [&](float v) -> uint16_t {
+            const float r = floorf(v * kSdrWhiteNits + 0.5f);
+            return (uint16_t)((r < 0.0f) ? 0.0f : ((65535.0f < r) ? 65535.0f : r));
+        };
+        clli->maxCLL = toNits(rgbMaxLinear);
+        clli->maxPALL = toNits((float)stats.sum / (float)((size_t)width * height));
+    }
+    return AVIF_RESULT_OK;
+}
+
+// argument checks shared by the entry points, src/gainmap.c:86-94
+avifResult gainMapCheckArguments(const avifRGBImage * base, const avifGainMap * gainMap, float hdrHeadroom, const avifRGBImage * out, avifDiagnostics * diag)
+{
+    diagClear(diag);
+    if (hdrHeadroom < 0.0f) {
+        diagPrintf(diag, "hdrHeadroom should be >= 0, got %f", hdrHeadroom);
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    if (base == NULL || gainMap == NULL || out == NULL) {
+        diagPrintf(diag, "NULL input image");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    return gainMapValidateMetadata(gainMap, diag);
+}
+
+bool gainMapIsPlainCopy(const avifRGBImage * base, avifColorPrimaries basePrimaries, avifTransferCharacteristics baseTC, float weight,
+                        avifColorPrimaries outPrimaries, avifTransferCharacteristics outTC, const avifRGBImage * out) // :120-128
+{
+    return weight == 0.0f && outTC == baseTC && outPrimaries == basePrimaries && base->format == out->format && base->depth == out->depth &&
+           base->isFloat == out->isFloat && base->rowBytes == out->rowBytes;
+}
+
+} // namespace
+
+extern "C" avifResult avifhipRGBImageApplyGainMapAsync(const avifRGBImage * baseImage, avifColorPrimaries baseColorPrimaries,
+                                                       avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap,
+                                                       float hdrHeadroom, avifColorPrimaries outputColorPrimaries,
+                                                       avifTransferCharacteristics outputTransferCharacteristics, avifRGBImage * toneMappedImage,
+                                                       avifContentLightLevelInformationBox * clli, avifDiagnostics * diag, void * hipStream)
+{
+    const avifResult ar = gainMapCheckArguments(baseImage, gainMap, hdrHeadroom, toneMappedImage, diag);
+    if (ar != AVIF_RESULT_OK)
+        return ar;
+    if (!baseImage->pixels || !toneMappedImage->pixels || !toneMappedImage->rowBytes || !gainMap->image) {
+        diagPrintf(diag, "avifhipRGBImageApplyGainMapAsync: device-resident base, gain map and tone-mapped pixels are required");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    hipStream_t stream = pickStream(hipStream);
+    toneMappedImage->width = baseImage->width, toneMappedImage->height = baseImage->height;
+    const float weight = gainMapWeight(hdrHeadroom, gainMap);
+    if (gainMapIsPlainCopy(baseImage, baseColorPrimaries, baseTransferCharacteristics, weight, outputColorPrimaries, outputTransferCharacteristics,
+                           toneMappedImage)) {
+        HIP_TRY(hipMemcpyAsync(toneMappedImage->pixels, baseImage->pixels, (size_t)baseImage->rowBytes * baseImage->height, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return AVIF_RESULT_OK;
+    }
+    return applyGainMapOnDevice(baseImage, baseColorPrimaries, baseTransferCharacteristics, gainMap, gainMap->image, weight, outputColorPrimaries,
+                                outputTransferCharacteristics, toneMappedImage, clli, diag, stream);
+}
+
+// host-resident images, like the reference: the tone-mapped image's pixels are (re)allocated with malloc (src/gainmap.c:112-114)
+extern "C" avifResult avifhipRGBImageApplyGainMap(const avifRGBImage * baseImage, avifColorPrimaries baseColorPrimaries,
+                                                  avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap, float hdrHeadroom,
+                                                  avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
+                                                  avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag)
+{
+    const avifResult ar = gainMapCheckArguments(baseImage, gainMap, hdrHeadroom, toneMappedImage, diag);
+    if (ar != AVIF_RESULT_OK)
+        return ar;
+    const uint32_t width = baseImage->width, height = baseImage->height;
+    toneMappedImage->width = width, toneMappedImage->height = height;
+    // avifRGBImageAllocatePixels, src/avif.c:719-737
+    free(toneMappedImage->pixels);
+    toneMappedImage->pixels = NULL, toneMappedImage->rowBytes = 0;
+    const uint32_t outPixelBytes = rgbPixelBytes(toneMappedImage);
+    if (!width || !height || width > UINT32_MAX / outPixelBytes)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const uint32_t outRowBytes = width * outPixelBytes;
+    toneMappedImage->pixels = (uint8_t *)malloc((size_t)outRowBytes * height);
+    if (!toneMappedImage->pixels)
+        return AVIF_RESULT_OUT_OF_MEMORY;
+    toneMappedImage->rowBytes = outRowBytes;
+
+    const float weight = gainMapWeight(hdrHeadroom, gainMap);
+    if (gainMapIsPlainCopy(baseImage, baseColorPrimaries, baseTransferCharacteristics, weight, outputColorPrimaries, outputTransferCharacteristics,
+                           toneMappedImage)) {
+        memcpy(toneMappedImage->pixels, baseImage->pixels, (size_t)baseImage->rowBytes * baseImage->height); // "Copy the base image", :124-127
+        return AVIF_RESULT_OK;
+    }
+    if (!baseImage->pixels || (weight != 0.0f && !gainMap->image))
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    // device copies: base pixels, gain map planes, tone-mapped pixels
+    avifRGBImage baseView, outView;
+    memcpy(&baseView, baseImage, sizeof(avifRGBImage));
+    memcpy(&outView, toneMappedImage, sizeof(avifRGBImage));
+    const uint32_t baseWidthBytes = width * rgbPixelBytes(baseImage);
+    baseView.rowBytes = alignUp(baseWidthBytes, 256);
+    avifResult r = reserve(tls.gainMap[5], (size_t)baseView.rowBytes * height);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    baseView.pixels = (uint8_t *)tls.gainMap[5].ptr;
+    HIP_TRY(hipMemcpy2DAsync(baseView.pixels, baseView.rowBytes, baseImage->pixels, baseImage->rowBytes, baseWidthBytes, height, hipMemcpyHostToDevice, tls.stream));
+    outView.rowBytes = alignUp(outRowBytes, 256);
+    r = reserve(tls.gainMap[0], (size_t)outView.rowBytes * height);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    outView.pixels = (uint8_t *)tls.gainMap[0].ptr;
+    avifImage gainView;
+    memset(&gainView, 0, sizeof(gainView));
+    if (weight != 0.0f) {
+        memcpy(&gainView, gainMap->image, sizeof(avifImage));
+        r = stagePlanes(&gainView, true, false);
+        if (r != AVIF_RESULT_OK)
+            return r;
+    }
+    r = applyGainMapOnDevice(&baseView, baseColorPrimaries, baseTransferCharacteristics, gainMap, &gainView, weight, outputColorPrimaries,
+                             outputTransferCharacteristics, &outView, clli, diag, tls.stream);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    HIP_TRY(hipMemcpy2DAsync(toneMappedImage->pixels, outRowBytes, outView.pixels, outView.rowBytes, outRowBytes, height, hipMemcpyDeviceToHost, tls.stream));
+    HIP_TRY(hipStreamSynchronize(tls.stream));
+    return AVIF_RESULT_OK;
+}
+
+// avifImageApplyGainMap, src/gainmap.c:317-355: the base image arrives as YUV
+extern "C" avifResult avifhipImageApplyGainMap(const avifImage * baseImage, const avifGainMap * gainMap, float hdrHeadroom,
+                                               avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
+                                               avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag)
+{
+    diagClear(diag);
+    if (!baseImage || !gainMap)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    // (ICC profiles, :328-331, live in the part of avifImage / avifGainMap this library does not read: the caller checks them)
+    avifRGBImage baseRgb; // avifRGBImageSetDefaults + avifRGBImageAllocatePixels, :333-335
+    memset(&baseRgb, 0, sizeof(baseRgb));
+    baseRgb.width = baseImage->width, baseRgb.height = baseImage->height, baseRgb.depth = baseImage->depth, baseRgb.format = AVIF_RGB_FORMAT_RGBA;
+    baseRgb.chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, baseRgb.chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
+    baseRgb.maxThreads = 1;
+    const uint32_t pixelBytes = rgbPixelBytes(&baseRgb);
+    if (!baseRgb.width || !baseRgb.height || baseRgb.width > UINT32_MAX / pixelBytes)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    baseRgb.rowBytes = baseRgb.width * pixelBytes;
+    baseRgb.pixels = (uint8_t *)malloc((size_t)baseRgb.rowBytes * baseRgb.height);
+    if (!baseRgb.pixels)
+        return AVIF_RESULT_OUT_OF_MEMORY;
+    avifResult r = avifhipImageYUVToRGB(baseImage, &baseRgb);
+    if (r == AVIF_RESULT_OK)
+        r = avifhipRGBImageApplyGainMap(&baseRgb, baseImage->colorPrimaries, baseImage->transferCharacteristics, gainMap, hdrHeadroom, outputColorPrimaries,
+                                        outputTransferCharacteristics, toneMappedImage, clli, diag);
+    free(baseRgb.pixels);
+    return r;
+}
+
+// ---- gain-map computation (the encode side), reference src/gainmap.c:535-843 ----
+
+namespace {
+
+// device planes (Y, U, V, A) of a wxh image in one scratch buffer, 256-byte row pitch
+avifResult deviceGainMapPlanes(avifImage * view, uint32_t width, uint32_t height, Scratch & scratch)
+{
+    view->width = width, view->height = height;
+    const PlaneDims d = planeDims(width, height, (int)view->yuvFormat);
+    const size_t bps = (view->depth > 8) ? 2 : 1;
+    size_t offset[4], total = 0;
+    uint32_t pitch[4];
+    for (int p = 0; p < 4; ++p) {
+        const bool present = !((p == 1 || p == 2) && view->yuvFormat == AVIF_PIXEL_FORMAT_YUV400);
+        pitch[p] = present ? alignUp((uint32_t)(d.w[p] * bps), 256) : 0;
+        offset[p] = total, total += (size_t)pitch[p] * d.h[p];
+    }
+    const avifResult r = reserve(scratch, total);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    for (int p = 0; p < 4; ++p) {
+        uint8_t * ptr = pitch[p] ? (uint8_t *)scratch.ptr + offset[p] : nullptr;
+        if (p < 3)
+            view->yuvPlanes[p] = ptr, view->yuvRowBytes[p] = pitch[p];
+        else
+            view->alphaPlane = ptr, view->alphaRowBytes = pitch[p];
+    }
+    return AVIF_RESULT_OK;
+}
+
+void freeHostPlanes(avifImage * image) // avifImageFreePlanes(AVIF_PLANES_ALL), src/avif.c:492-517
+{
+    if (image->imageOwnsYUVPlanes)
+        for (int p = 0; p < 3; ++p)
+            free(image->yuvPlanes[p]);
+    for (int p = 0; p < 3; ++p)
+        image->yuvPlanes[p] = NULL, image->yuvRowBytes[p] = 0;
+    image->imageOwnsYUVPlanes = AVIF_FALSE;
+    if (image->imageOwnsAlphaPlane)
+        free(image->alphaPlane);
+    image->alphaPlane = NULL, image->alphaRowBytes = 0, image->imageOwnsAlphaPlane = AVIF_FALSE;
+}
+
+} // namespace
+
+// Host images in, gain-map metadata and (malloc'ed) gain-map planes out, like the reference.
+extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgbImage, avifColorPrimaries baseColorPrimaries,
+                                                    avifTransferCharacteristics baseTransferCharacteristics, const avifRGBImage * altRgbImage,
+                                                    avifColorPrimaries altColorPrimaries, avifTransferCharacteristics altTransferCharacteristics,
+                                                    avifGainMap * gainMap, avifDiagnostics * diag)
+{
+    diagClear(diag);
+    if (baseRgbImage == NULL || altRgbImage == NULL || gainMap == NULL || gainMap->image == NULL)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if (baseRgbImage->width != altRgbImage->width || baseRgbImage->height != altRgbImage->height) {
+        diagPrintf(diag, "Both images should have the same dimensions");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    avifImage * gmImage = gainMap->image;
+    if (gmImage->width == 0 || gmImage->height == 0 || gmImage->depth == 0 || (int)gmImage->yuvFormat <= (int)AVIF_PIXEL_FORMAT_NONE ||
+        (int)gmImage->yuvFormat > (int)AVIF_PIXEL_FORMAT_YUV400) {
+        diagPrintf(diag, "gainMap->image should be non null with desired width, height, depth and yuvFormat set");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    const bool colorSpacesDiffer = baseColorPrimaries != altColorPrimaries;
+    int mathPrimaries = 0;
+    if (!gainMapChooseMathPrimaries(baseColorPrimaries, altColorPrimaries, &mathPrimaries))
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    const uint32_t width = baseRgbImage->width, height = baseRgbImage->height;
+    GainMapComputeArgs A;
+    memset(&A, 0, sizeof(A));
+    if (!gainMapLayout(baseRgbImage, &A.baseL) || !gainMapLayout(altRgbImage, &A.altL)) {
+        diagPrintf(diag, "Unsupported RGB color space");
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    }
+    if (!width || !height || !baseRgbImage->pixels || !altRgbImage->pixels || gmImage->depth > 16)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const size_t numPixels = (size_t)width * height;
+    const bool singleChannel = gmImage->yuvFormat == AVIF_PIXEL_FORMAT_YUV400;
+    const int channels = singleChannel ? 1 : 3;
+    avifResult r = ensureContext();
+    if (r != AVIF_RESULT_OK)
+        return r;
+    hipStream_t stream = tls.stream;
+    tls.gainMapCache.valid = false; // (the apply path's tables are not touched, but keep the two paths independent of call order)
+
+    // avifGainMapSetEncodingDefaults, :18-30
+    for (int i = 0; i < 3; ++i) {
+        gainMap->gainMapMin[i].n = 1, gainMap->gainMapMin[i].d = 1, gainMap->gainMapMax[i].n = 1, gainMap->gainMapMax[i].d = 1;
+        gainMap->baseOffset[i].n = 1, gainMap->baseOffset[i].d = 64, gainMap->alternateOffset[i].n = 1, gainMap->alternateOffset[i].d = 64;
+        gainMap->gainMapGamma[i].n = 1, gainMap->gainMapGamma[i].d = 1;
+    }
+    gainMap->baseHdrHeadroom.n = 0, gainMap->baseHdrHeadroom.d = 1, gainMap->alternateHdrHeadroom.n = 1, gainMap->alternateHdrHeadroom.d = 1;
+    gainMap->useBaseColorSpace = (mathPrimaries == (int)baseColorPrimaries) ? AVIF_TRUE : AVIF_FALSE;
+
+    if (colorSpacesDiffer) {
+        const bool ok = gainMap->useBaseColorSpace ? gainMapPrimariesMatrix(altColorPrimaries, baseColorPrimaries, A.M)
+                                                   : gainMapPrimariesMatrix(baseColorPrimaries, altColorPrimaries, A.M);
+        if (!ok) {
+            diagPrintf(diag, "Unsupported RGB color space conversion");
+            return AVIF_RESULT_NOT_IMPLEMENTED;
+        }
+        A.convertAlt = gainMap->useBaseColorSpace ? 1 : 0, A.convertBase = gainMap->useBaseColorSpace ? 0 : 1;
+    }
+    A.singleChannel = singleChannel ? 1 : 0;
+    gainMapYCoefficients(mathPrimaries, A.yCoeffs);
+    float baseOffset[3], altOffset[3];
+    for (int c = 0; c < 3; ++c)
+        baseOffset[c] = fractionToFloat(gainMap->baseOffset[c]), altOffset[c] = fractionToFloat(gainMap->alternateOffset[c]);
+
+    // ---- device copies of the two images, lookup tables ----
+    A.width = width, A.height = height;
+    const uint32_t baseWidthBytes = width * rgbPixelBytes(baseRgbImage), altWidthBytes = width * rgbPixelBytes(altRgbImage);
+    A.basePitch = alignUp(baseWidthBytes, 256), A.altPitch = alignUp(altWidthBytes, 256);
+    if ((r = reserve(tls.gainMap[5], (size_t)A.basePitch * height)) != AVIF_RESULT_OK || (r = reserve(tls.gainMap[9], (size_t)A.altPitch * height)) != AVIF_RESULT_OK)
+        return r;
+    A.base = (const uint8_t *)tls.gainMap[5].ptr, A.alt = (const uint8_t *)tls.gainMap[9].ptr;
+    HIP_TRY(hipMemcpy2DAsync(tls.gainMap[5].ptr, A.basePitch, baseRgbImage->pixels, baseRgbImage->rowBytes, baseWidthBytes, height, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpy2DAsync(tls.gainMap[9].ptr, A.altPitch, altRgbImage->pixels, altRgbImage->rowBytes, altWidthBytes, height, hipMemcpyHostToDevice, stream));
+    std::vector<float> tables = gainMapLinearLut(baseTransferCharacteristics, baseRgbImage->depth, baseRgbImage->isFloat != 0);
+    const size_t altLutOffset = tables.size();
+    {
+        const std::vector<float> alt = gainMapLinearLut(altTransferCharacteristics, altRgbImage->depth, altRgbImage->isFloat != 0);
+        tables.insert(tables.end(), alt.begin(), alt.end());
+    }
+    // room for the step tables that follow (3 channels x at most 65536 entries)
+    const size_t stepsOffset = (tables.size() + 3) & ~(size_t)3, stepsCapacity = (size_t)3 * 65536;
+    if ((r = reserve(tls.gainMap[6], (stepsOffset + stepsCapacity) * sizeof(float))) != AVIF_RESULT_OK)
+        return r;
+    if ((r = uploadTableAsync(tls.gainMap[6].ptr, tables.data(), tables.size() * sizeof(float), stream)) != AVIF_RESULT_OK)
+        return r;
+    float * deviceTables = (float *)tls.gainMap[6].ptr;
+    A.baseLut = deviceTables, A.altLut = deviceTables + altLutOffset;
+    if ((r = reserve(tls.gainMap[7], (size_t)channels * numPixels * sizeof(float))) != AVIF_RESULT_OK ||
+        (r = reserve(tls.gainMap[3], (size_t)kGainMapMaxGroups * 8 * sizeof(float))) != AVIF_RESULT_OK)
+        return r;
+    A.ratios = (float *)tls.gainMap[7].ptr, A.partials = (float *)tls.gainMap[3].ptr;
+    const uint32_t tiles = ((width + 63) / 64) * ((height + 3) / 4);
+    const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
+    std::vector<float> partials((size_t)groups * 8);
+
+    // ---- pass 0: offsets that keep the converted side's channels positive, :618-660 ----
+    if (colorSpacesDiffer) {
+        hipError_t e = launchGainMapChannelMin(A, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "gain map channel-minimum kernel launch");
+        HIP_TRY(hipMemcpyAsync(partials.data(), A.partials, partials.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float channelMin[3] = { 0.0f, 0.0f, 0.0f };
+        for (uint32_t g = 0; g < groups; ++g)
+            for (int c = 0; c < 3; ++c)
+                channelMin[c] = (channelMin[c] < partials[(size_t)g * 8 + c]) ? channelMin[c] : partials[(size_t)g * 8 + c];
+        for (int c = 0; c < 3; ++c) {
+            const float maxOffset = 0.1f;
+            if (channelMin[c] < -1e-10f) {
+                if (gainMap->useBaseColorSpace) {
+                    const float o = altOffset[c] - channelMin[c];
+                    altOffset[c] = (o < maxOffset) ? o : maxOffset;
+                } else {
+                    const float o = baseOffset[c] - channelMin[c];
+                    baseOffset[c] = (o < maxOffset) ? o : maxOffset;
+                }
+            }
+        }
+    }
+    for (int c = 0; c < 3; ++c)
+        A.baseOffset[c] = baseOffset[c], A.altOffset[c] = altOffset[c];
+
+    // ---- pass 1: ratios, maxima, extreme ratios, :662-715 ----
+    {
+        hipError_t e = launchGainMapRatios(A, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "gain map ratio kernel launch");
+        HIP_TRY(hipMemcpyAsync(partials.data(), A.partials, partials.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    float baseMax = 1.0f, altMax = 1.0f, minRatio[3] = { INFINITY, INFINITY, INFINITY }, maxRatio[3] = { 0.0f, 0.0f, 0.0f };
+    for (uint32_t g = 0; g < groups; ++g) {
+        const float * p = &partials[(size_t)g * 8];
+        baseMax = fmaxf(baseMax, p[0]), altMax = fmaxf(altMax, p[1]);
+        for (int c = 0; c < channels; ++c)
+            minRatio[c] = fminf(minRatio[c], p[2 + c]), maxRatio[c] = fmaxf(maxRatio[c], p[5 + c]);
+    }
+    const float kEps = 1e-10f;
+    const double baseHeadroom = log2f(baseMax > kEps ? baseMax : kEps), alternateHeadroom = log2f(altMax > kEps ? altMax : kEps);
+    if (!gainMapDoubleToUnsignedFraction(baseHeadroom, &gainMap->baseHdrHeadroom.n, &gainMap->baseHdrHeadroom.d) ||
+        !gainMapDoubleToUnsignedFraction(alternateHeadroom, &gainMap->alternateHdrHeadroom.n, &gainMap->alternateHdrHeadroom.d))
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const float sign = (alternateHeadroom < baseHeadroom) ? -1.0f : 1.0f; // :728-739
+
+    // ---- pass 2: range without outliers, :741-749 ----
+    GainMapChannelRange ranges[3];
+    GainMapStepTable stepTables[3];
+    memset(stepTables, 0, sizeof(stepTables));
+    float minLog2[3] = { 0.0f, 0.0f, 0.0f }, maxLog2[3] = { 0.0f, 0.0f, 0.0f };
+    bool anyHistogram = false;
+    std::vector<float> hostSteps;
+    size_t histogramOffset[3] = { 0, 0, 0 }, histogramTotal = 0;
+    for (int c = 0; c < channels; ++c) {
+        ranges[c] = gainMapChannelRange(sign, minRatio[c], maxRatio[c], numPixels);
+        minLog2[c] = ranges[c].lo, maxLog2[c] = ranges[c].hi;
+        if (ranges[c].numBuckets > 0) {
+            uint32_t entries = 0;
+            const std::vector<float> steps = gainMapBucketSteps(ranges[c], &entries);
+            stepTables[c].steps = deviceTables + stepsOffset + hostSteps.size();
+            stepTables[c].entries = entries, stepTables[c].flipped = sign < 0 ? 1 : 0, stepTables[c].flip = (uint32_t)ranges[c].numBuckets - 1;
+            hostSteps.insert(hostSteps.end(), steps.begin(), steps.end());
+            histogramOffset[c] = histogramTotal, histogramTotal += (size_t)ranges[c].numBuckets;
+            anyHistogram = true;
+        }
+    }
+    if (anyHistogram) {
+        if ((r = reserve(tls.gainMap[8], histogramTotal * sizeof(uint32_t))) != AVIF_RESULT_OK)
+            return r;
+        if ((r = uploadTableAsync(deviceTables + stepsOffset, hostSteps.data(), hostSteps.size() * sizeof(float), stream)) != AVIF_RESULT_OK)
+            return r;
+        HIP_TRY(hipMemsetAsync(tls.gainMap[8].ptr, 0, histogramTotal * sizeof(uint32_t), stream));
+        uint32_t * histograms[3];
+        for (int c = 0; c < 3; ++c)
+            histograms[c] = (uint32_t *)tls.gainMap[8].ptr + histogramOffset[c];
+        const hipError_t e = launchGainMapHistogram(A.ratios, numPixels, channels, stepTables, histograms, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "gain map histogram kernel launch");
+        std::vector<uint32_t> hostHistograms(histogramTotal);
+        HIP_TRY(hipMemcpyAsync(hostHistograms.data(), tls.gainMap[8].ptr, histogramTotal * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int c = 0; c < channels; ++c)
+            if (ranges[c].numBuckets > 0)
+                gainMapRangeWithoutOutliers(ranges[c], hostHistograms.data() + histogramOffset[c], &minLog2[c], &maxLog2[c]);
+    }
+    for (int c = 0; c < 3; ++c) { // metadata, :751-760
+        const int k = singleChannel ? 0 : c;
+        if (!gainMapDoubleToFraction(minLog2[k], &gainMap->gainMapMin[c].n, &gainMap->gainMapMin[c].d) ||
+            !gainMapDoubleToFraction(maxLog2[k], &gainMap->gainMapMax[c].n, &gainMap->gainMapMax[c].d) ||
+            !gainMapDoubleToFraction(altOffset[c], &gainMap->alternateOffset[c].n, &gainMap->alternateOffset[c].d) ||
+            !gainMapDoubleToFraction(baseOffset[c], &gainMap->baseOffset[c].n, &gainMap->baseOffset[c].d))
+            return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+
+    // ---- pass 3: [min, max] -> codes -> RGBA -> YUV (-> requested size), :762-829 ----
+    hostSteps.clear();
+    memset(stepTables, 0, sizeof(stepTables));
+    const uint32_t depth = gmImage->depth;
+    for (int c = 0; c < channels; ++c) {
+        const float range = (maxLog2[c] - minLog2[c] > 0.0f) ? maxLog2[c] - minLog2[c] : 0.0f;
+        if (range == 0.0f)
+            continue; // every value becomes 0, :766-773
+        const std::vector<float> steps = gainMapCodeSteps(ranges[c], minLog2[c], maxLog2[c], fractionToFloat(gainMap->gainMapGamma[c]), depth);
+        stepTables[c].steps = deviceTables + stepsOffset + hostSteps.size();
+        stepTables[c].entries = (uint32_t)steps.size(), stepTables[c].flipped = sign < 0 ? 1 : 0, stepTables[c].flip = (1u << depth) - 1;
+        hostSteps.insert(hostSteps.end(), steps.begin(), steps.end());
+    }
+    if (!hostSteps.empty() && (r = uploadTableAsync(deviceTables + stepsOffset, hostSteps.data(), hostSteps.size() * sizeof(float), stream)) != AVIF_RESULT_OK)
+        return r;
+    avifRGBImage rgbGain; // avifRGBImageSetDefaults, src/avif.c:700-717
+    memset(&rgbGain, 0, sizeof(rgbGain));
+    rgbGain.width = width, rgbGain.height = height, rgbGain.depth = depth, rgbGain.format = AVIF_RGB_FORMAT_RGBA;
+    rgbGain.chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, rgbGain.chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
+    rgbGain.maxThreads = 1;
+    rgbGain.rowBytes = alignUp(width * 4 * ((depth > 8) ? 2 : 1), 256);
+    if ((r = reserve(tls.gainMap[1], (size_t)rgbGain.rowBytes * height)) != AVIF_RESULT_OK)
+        return r;
+    rgbGain.pixels = (uint8_t *)tls.gainMap[1].ptr;
+    {
+        const hipError_t e = launchGainMapQuantise(A.ratios, width, height, channels, stepTables, rgbGain.pixels, rgbGain.rowBytes, depth, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "gain map quantisation kernel launch");
+    }
+    const uint32_t requestedWidth = gmImage->width, requestedHeight = gmImage->height;
+    freeHostPlanes(gmImage);
+    avifImage deviceGain;
+    memcpy(&deviceGain, gmImage, sizeof(avifImage));
+    if ((r = deviceGainMapPlanes(&deviceGain, width, height, tls.gainMap[10])) != AVIF_RESULT_OK)
+        return r;
+    if ((r = avifhipImageRGBToYUVAsync(&deviceGain, &rgbGain, stream)) != AVIF_RESULT_OK)
+        return r;
+    avifImage deviceFinal;
+    memcpy(&deviceFinal, &deviceGain, sizeof(avifImage));
+    if (requestedWidth != width || requestedHeight != height) {
+        if ((r = deviceGainMapPlanes(&deviceFinal, requestedWidth, requestedHeight, tls.gainMap[4])) != AVIF_RESULT_OK)
+            return r;
+        if ((r = avifhipImageScaleAsync(&deviceGain, &deviceFinal, stream)) != AVIF_RESULT_OK)
+            return r;
+    }
+    gmImage->width = deviceFinal.width, gmImage->height = deviceFinal.height;
+    if ((r = allocateHostPlanes(gmImage, true)) != AVIF_RESULT_OK) {
+        freeHostPlanes(gmImage);
+        return r;
+    }
+    const PlaneGeometry g = planeGeometry(gmImage);
+    for (int p = 0; p < 4; ++p) {
+        uint8_t * host = (p < 3) ? gmImage->yuvPlanes[p] : gmImage->alphaPlane;
+        const uint8_t * dev = (p < 3) ? deviceFinal.yuvPlanes[p] : deviceFinal.alphaPlane;
+        if (!host || !dev)
+            continue;
+        HIP_TRY(hipMemcpy2DAsync(host, (p < 3) ? gmImage->yuvRowBytes[p] : gmImage->alphaRowBytes, dev, (p < 3) ? deviceFinal.yuvRowBytes[p] : deviceFinal.alphaRowBytes,
+                                 g.widthBytes[p], g.rows[p], hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    tls.lastKernel = "gainmap_compute";
+    return AVIF_RESULT_OK;
+}
+

@@ -1,0 +1,168 @@
+// api_internal.h -- what the translation units behind the C ABI share (api.cpp: conversion path; api_gainmap.cpp: gain maps;
+// api_scale.cpp: plane scaling): the per-thread context (stream, device scratch, table caches), error plumbing, staging helpers.
+// Internal to libavifhip.so (hidden visibility).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <vector>
+
+#include "avifhip.h"
+#include "gainmap_plan.h"
+#include "kernels.h"
+#include "plan.h"
+#include "scale_plan.h"
+
+namespace avifhip {
+namespace api {
+
+struct Scratch
+{
+    void * ptr = nullptr;
+    size_t capacity = 0;
+};
+
+// what tls.scaleTable currently holds (avifhipImageScaleAsync)
+struct ScaleTableCache
+{
+    bool valid = false;
+    uint32_t key[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    size_t offset[4] = { 0, 0, 0, 0 };
+    int mode[4] = { 0, 0, 0, 0 };
+    ScaleStaging staging[4]; // row-staged kernel
+    ScaleStaging window[4];  // window kernel
+};
+
+// what tls.gainMap[2] currently holds (the tables of avifhipRGBImageApplyGainMap): rebuilt only when a parameter changes
+struct GainMapTableCache
+{
+    bool valid = false;
+    struct Key
+    {
+        uint32_t baseTC, baseDepth, baseFloat, outTC, outDepth, outFloat, gainDepth, applyGain;
+        float gammaInv[3], minLog2[3], maxLog2[3], weight;
+        uint64_t stream;
+    } key;
+    size_t baseLutOffset = 0, gainLutOffset = 0, stepsOffset = 0, guideOffset = 0; // in floats
+    uint32_t maxCode = 0, nanCode = 0, stepEntries = 0;
+};
+
+// One context per calling thread: libavif's reformat functions are re-entrant and may be called
+// concurrently from up to 8 threads (src/reformat.c:1709-1735); nothing here is shared.
+struct Context
+{
+    int device = -1;
+    hipStream_t stream = nullptr;
+    Scratch planes[4]; // Y, U, V, A staging
+    Scratch pixels;    // interleaved RGB staging
+    Scratch table;     // batch descriptor table (device)
+    Scratch gridTable; // tile table of a grid conversion (device)
+    Scratch scaleTable; // schedules of a plane scale (device)
+    ScaleTableCache scaleCache; // ... and which geometry they belong to
+    Scratch satoTable;  // input plane tables of a sample transform (device)
+    Scratch gainMap[11]; // gain maps: [0] output pixels, [1] gain map as RGB, [2] tables, [3] statistics / partials, [4] scaled planes, [5] base pixels;
+                         // computation: [6] tables, [7] ratios, [8] histograms, [9] alternate pixels, [10] gain-map planes
+    GainMapTableCache gainMapCache; // what gainMap[2] holds
+    void * pinnedTable = nullptr;
+    size_t pinnedTableCapacity = 0;
+    hipEvent_t tableCopied = nullptr;
+    void * pinnedUpload = nullptr; // staging for small host tables (grid tile tables, scale schedules)
+    size_t pinnedUploadCapacity = 0;
+    hipEvent_t uploadCopied = nullptr;
+    char lastError[512] = { 0 };
+    const char * lastKernel = "";
+    uint64_t launches = 0; // kernels enqueued by this thread
+
+    ~Context()
+    {
+        // Best effort: the runtime may already be shutting down at thread/process exit.
+        for (Scratch & s : planes)
+            if (s.ptr)
+                (void)hipFree(s.ptr);
+        if (pixels.ptr)
+            (void)hipFree(pixels.ptr);
+        if (table.ptr)
+            (void)hipFree(table.ptr);
+        if (gridTable.ptr)
+            (void)hipFree(gridTable.ptr);
+        if (scaleTable.ptr)
+            (void)hipFree(scaleTable.ptr);
+        if (satoTable.ptr)
+            (void)hipFree(satoTable.ptr);
+        for (Scratch & g : gainMap)
+            if (g.ptr)
+                (void)hipFree(g.ptr);
+        if (pinnedTable)
+            (void)hipHostFree(pinnedTable);
+        if (tableCopied)
+            (void)hipEventDestroy(tableCopied);
+        if (pinnedUpload)
+            (void)hipHostFree(pinnedUpload);
+        if (uploadCopied)
+            (void)hipEventDestroy(uploadCopied);
+        if (stream)
+            (void)hipStreamDestroy(stream);
+    }
+};
+
+extern thread_local Context tls;
+extern std::atomic<int> gTiledKernels;
+
+void setError(const char * fmt, ...);
+// HIP failure -> avifResult.  The message is kept for avifhipLastError(); the sticky HIP error is cleared.
+avifResult hipFailed(hipError_t e, const char * what);
+
+#define HIP_TRY(expr)                          \
+    do {                                       \
+        const hipError_t hipTryErr_ = (expr);  \
+        if (hipTryErr_ != hipSuccess)          \
+            return ::avifhip::api::hipFailed(hipTryErr_, #expr); \
+    } while (0)
+
+avifResult ensureContext();
+// Enqueues a copy of a small host table to device memory through a pinned per-thread staging buffer (see api.cpp)
+avifResult uploadTableAsync(void * deviceDst, const void * hostSrc, size_t bytes, hipStream_t stream);
+avifResult reserve(Scratch & s, size_t bytes);
+bool isDevicePointer(const void * p);
+inline uint32_t alignUp(uint32_t v, uint32_t a)
+{
+    return (v + a - 1) / a * a;
+}
+hipStream_t pickStream(void * hipStream);
+
+struct PlaneGeometry
+{
+    uint32_t widthBytes[4];
+    uint32_t rows[4];
+};
+PlaneGeometry planeGeometry(const avifImage * image);
+// Replaces host plane pointers of `view` (a shallow copy of the caller's image) with device copies (tls.planes)
+avifResult stagePlanes(avifImage * view, bool upload, bool mirrorRowBytes);
+uint32_t rgbPixelBytes(const avifRGBImage * rgb);
+avifResult stagePixels(avifRGBImage * view, bool upload);
+// malloc'ed planes like avifImageAllocatePlanes (src/avif.c:431-490): only the missing ones
+avifResult allocateHostPlanes(avifImage * image, bool withAlpha);
+
+// plane sizes of an image (avifImagePlaneWidth / Height, reference src/avif.c:351-400)
+struct PlaneDims
+{
+    int w[4], h[4];
+};
+inline PlaneDims planeDims(uint32_t width, uint32_t height, int yuvFormat)
+{
+    const int sx = (yuvFormat == AVIF_PIXEL_FORMAT_YUV444 || yuvFormat == AVIF_PIXEL_FORMAT_YUV400) ? 0 : 1;
+    const int sy = (yuvFormat == AVIF_PIXEL_FORMAT_YUV420) ? 1 : 0;
+    PlaneDims d;
+    d.w[0] = d.w[3] = (int)width, d.h[0] = d.h[3] = (int)height;
+    d.w[1] = d.w[2] = (int)((width + sx) >> sx), d.h[1] = d.h[2] = (int)((height + sy) >> sy);
+    return d;
+}
+
+} // namespace api
+} // namespace avifhip

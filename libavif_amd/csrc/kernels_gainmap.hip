@@ -146,7 +146,7 @@ __device__ __forceinline__ void codesOf(const float x[3], const StepSearch & S, 
 
 // Persistent workgroups walking tiles of 64 x 4 pixels with a grid stride.  LDS_TABLES: the three tables (steps, base lookup,
 // gain lookup) are copied to LDS once per workgroup and addressed as LDS -- a pointer that may be either LDS or global memory
-// compiles to flat loads, which the searches cannot afford; the host picks this variant when everything fits (api.cpp).
+// compiles to flat loads, which the searches cannot afford; the host picks this variant when everything fits (api_gainmap.cpp).
 template <bool LDS_TABLES>
 __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_t tilesX, uint32_t tiles)
 {

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void scalePlaneKernel(ScaleArgs A)
 // It first copies every source-row segment those samples need into a wave-private LDS block with 16-byte loads (all
 // issued before the first is waited for), then gathers from LDS (whose address path is not the bottleneck) and stores 4
 // samples per lane at once.  No workgroup barrier: a wave's LDS accesses execute in program order; the fences only
-// restrain the compiler.  The host (scaleStagedPlan, api.cpp) guarantees the block fits.  The chunks are 16-byte ALIGNED
+// restrain the compiler.  The host (scaleStagedPlan, api_scale.cpp) guarantees the block fits.  The chunks are 16-byte ALIGNED
 // pieces of the address space, so the first / last chunk of a segment may begin before / end after the bytes asked for
 // (even before the first or after the last byte of the plane): every chunk contains at least one byte of the segment, an
 // aligned 16-byte chunk never straddles a page, hence the load touches no page the plane does not own; the extra bytes
@@ -339,7 +339,7 @@ __device__ __forceinline__ void scalePlaneWindow(const ScaleArgs & A, int rowsPe
         return;
     const int jEnd = min(jBase + rowsPerWave, A.dstH);
 
-    // the lane's four destination columns (the column tables are padded with copies of their last entry, api.cpp)
+    // the lane's four destination columns (the column tables are padded with copies of their last entry, api_scale.cpp)
     const int4 ca4 = *reinterpret_cast<const int4 *>(A.colA + i0), cb4 = *reinterpret_cast<const int4 *>(A.colB + i0);
     const int ca[4] = { ca4.x, ca4.y, ca4.z, ca4.w }, cb[4] = { cb4.x, cb4.y, cb4.z, cb4.w };
     int c1[4];
