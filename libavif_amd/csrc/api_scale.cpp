@@ -67,6 +67,14 @@ ScaleStaging scaleStagedPlan(const ScaleSchedule & S, int srcW, bool wide, size_
         }
         if (cap <= maxRows) {
             st.rowsPerWave = rpw, st.rowsCap = cap;
+            if (S.mode == SCALE_BOX && !wide && cols == 256 && n > 0) { // uniform boxes of 4 / 8 columns: the dword path
+                const int w = S.colB[0];
+                bool uniform = (w == 4 || w == 8) && (n % 4 == 0); // (a box filter is only chosen beyond 2x, scale_plan.cpp)
+                for (size_t i = 0; i < n && uniform; ++i)
+                    uniform = S.colB[i] == w && S.colA[i] == S.colA[0] + (int)i * w;
+                // (the lane's 4 boxes must lie inside the row: guaranteed since the reference reads them; n % 4: no clamped tail lanes)
+                st.boxWidth = uniform ? w : 0;
+            }
             return st;
         }
     }

@@ -87,6 +87,7 @@ struct ScaleStaging
     int rowsPerWave = 0;
     int rowsCap = 0;       // source rows a wave stages at most
     uint32_t segPitch = 0; // bytes between staged rows (a multiple of 16, segment + alignment slack)
+    int boxWidth = 0;      // 8-bit boxes of one width w in {4, 8} with colA[i] = colA[0] + i * w: the kernel may sum dwords (v_sad_u8)
 };
 hipError_t launchScalePlane(const ScaleArgs & args, bool wide, hipStream_t stream); // gather kernel, one plane
 struct ScaleStagedLaunch

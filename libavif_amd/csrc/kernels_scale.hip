@@ -127,7 +127,7 @@ __device__ __forceinline__ int ldsSample(const uint8_t * stage, uint32_t off)
 }
 
 template <bool WIDE, int MODE>
-__device__ __forceinline__ void scalePlaneStaged(const ScaleArgs & A, int rowsPerWave, int rowsCap, uint32_t segPitch, u4v * stageAll)
+__device__ __forceinline__ void scalePlaneStaged(const ScaleArgs & A, int rowsPerWave, int rowsCap, uint32_t segPitch, int boxWidth, u4v * stageAll)
 {
     constexpr uint32_t kBps = WIDE ? 2 : 1;
     const int lane = threadIdx.x & 63;
@@ -201,12 +201,31 @@ __device__ __forceinline__ void scalePlaneStaged(const ScaleArgs & A, int rowsPe
         int out[4];
         if constexpr (MODE == SCALE_BOX_MODE) {
             uint32_t sum[4] = { 0, 0, 0, 0 };
-            for (int r = ra; r < ra + rb; ++r) {
-                const uint8_t * row = stage + rowBase(r);
+            // 8-bit boxes of one width 4 / 8 whose first byte is dword-aligned in the staged rows (uniform: segment start and
+            // row pitch multiples of 4): the lane's 4 boxes are `boxWidth` consecutive dwords of each row, summed a dword at a
+            // time by v_sad_u8 against zero -- 1-2 instructions per box and row instead of a read and an add per sample
+            const bool dwords = !WIDE && boxWidth && (((uint32_t)(uintptr_t)A.src | A.srcPitch | loByte) & 3u) == 0;
+            if (dwords) {
+                for (int r = ra; r < ra + rb; ++r) {
+                    const uint32_t * row = reinterpret_cast<const uint32_t *>(stage + rowBase(r) + oA[0]);
+                    if (boxWidth == 4) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    for (uint32_t o = oA[s]; o <= oB[s]; o += kBps)
-                        sum[s] += (uint32_t)ldsSample<WIDE>(row, o);
+                        for (int s = 0; s < 4; ++s)
+                            sum[s] = __builtin_amdgcn_sad_u8(row[s], 0u, sum[s]);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            sum[s] = __builtin_amdgcn_sad_u8(row[2 * s + 1], 0u, __builtin_amdgcn_sad_u8(row[2 * s], 0u, sum[s]));
+                    }
+                }
+            } else {
+                for (int r = ra; r < ra + rb; ++r) {
+                    const uint8_t * row = stage + rowBase(r);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        for (uint32_t o = oA[s]; o <= oB[s]; o += kBps)
+                            sum[s] += (uint32_t)ldsSample<WIDE>(row, o);
+                }
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -263,14 +282,14 @@ __global__ __launch_bounds__(256) void scalePlanesStagedKernel(ScaleStagedLaunch
     extern __shared__ u4v stageAll[]; // 4 waves x rowsCap staged rows x segPitch bytes
     const int p = blockIdx.z;
     const ScaleArgs & A = L.plane[p];
-    const int rpw = L.staging[p].rowsPerWave, cap = L.staging[p].rowsCap;
+    const int rpw = L.staging[p].rowsPerWave, cap = L.staging[p].rowsCap, bw = L.staging[p].boxWidth;
     const uint32_t pitch = L.staging[p].segPitch;
     switch (A.mode) { // uniform
-        case SCALE_POINT_MODE: scalePlaneStaged<WIDE, SCALE_POINT_MODE>(A, rpw, cap, pitch, stageAll); break;
-        case SCALE_DOWN_MODE: scalePlaneStaged<WIDE, SCALE_DOWN_MODE>(A, rpw, cap, pitch, stageAll); break;
-        case SCALE_UP_MODE: scalePlaneStaged<WIDE, SCALE_UP_MODE>(A, rpw, cap, pitch, stageAll); break;
-        case SCALE_BOX_MODE: scalePlaneStaged<WIDE, SCALE_BOX_MODE>(A, rpw, cap, pitch, stageAll); break;
-        default: scalePlaneStaged<WIDE, SCALE_UP2_MODE>(A, rpw, cap, pitch, stageAll); break;
+        case SCALE_POINT_MODE: scalePlaneStaged<WIDE, SCALE_POINT_MODE>(A, rpw, cap, pitch, 0, stageAll); break;
+        case SCALE_DOWN_MODE: scalePlaneStaged<WIDE, SCALE_DOWN_MODE>(A, rpw, cap, pitch, 0, stageAll); break;
+        case SCALE_UP_MODE: scalePlaneStaged<WIDE, SCALE_UP_MODE>(A, rpw, cap, pitch, 0, stageAll); break;
+        case SCALE_BOX_MODE: scalePlaneStaged<WIDE, SCALE_BOX_MODE>(A, rpw, cap, pitch, bw, stageAll); break;
+        default: scalePlaneStaged<WIDE, SCALE_UP2_MODE>(A, rpw, cap, pitch, 0, stageAll); break;
     }
 }
 

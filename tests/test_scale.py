@@ -35,7 +35,10 @@ def scale_cases(n, seed):
            (H.Y2RCase(2100, 130, yuv_depth=8, yuv_format=3, yuv_range=1, row_pad=6), 519, 31),     # box
            (H.Y2RCase(1300, 64, yuv_depth=12, yuv_format=1, yuv_range=1, row_pad=6), 1733, 81),    # 16-bit samples: staged
            (H.Y2RCase(1300, 64, yuv_depth=10, yuv_format=3, yuv_range=1), 433, 21),
-           (H.Y2RCase(5000, 40, yuv_depth=8, yuv_format=1, yuv_range=1), 280, 33)]                 # 17.9x: segments too long -> gather
+           (H.Y2RCase(5000, 40, yuv_depth=8, yuv_format=1, yuv_range=1), 280, 33),                # 17.9x: segments too long -> gather
+           (H.Y2RCase(2048, 96, yuv_depth=8, yuv_format=3, yuv_range=1), 512, 24),                # exact 4x boxes: the dword (v_sad_u8) path
+           (H.Y2RCase(2048, 128, yuv_depth=8, yuv_format=1, yuv_range=1, alpha=True), 256, 16),   # exact 8x
+           (H.Y2RCase(2052, 96, yuv_depth=8, yuv_format=1, yuv_range=1, row_pad=6), 513, 24)]     # 4x, but rows and tails off the dword grid                 # 17.9x: segments too long -> gather
     for _ in range(n):
         sw, sh = rnd.choice(SIZES)
         if rnd.random() < 0.5:
