@@ -322,7 +322,8 @@ template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int
 __global__ __launch_bounds__(256) void yuvToRgbTileFxBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) unsigned rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch];
-    runBlockFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows);
+    const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
+    runBlockFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(job, tilesPerRun, rows);
 }
 
 template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool MUL>

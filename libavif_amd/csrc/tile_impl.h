@@ -744,11 +744,14 @@ template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, boo
 __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
+    // a private copy of the job: read through the table pointer, every field would be re-loaded after each store (the compiler
+    // cannot rule out that the RGB stores alias the table) -- ~20 scalar loads per tile inside the pipelined loop
+    const TileArgs job = table[blockIdx.z];
     if constexpr (sizeof(RT) == 2 && NCH == 4) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows, xchg);
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, tilesPerRun, rows, xchg);
     } else {
-        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(table[blockIdx.z], tilesPerRun, rows, nullptr);
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, tilesPerRun, rows, nullptr);
     }
 }
 
