@@ -121,6 +121,23 @@ def test_compute_oracle_equals_reference():
     assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
 
 
+@pytest.mark.skipif(oracle_lib.pillow() is None, reason="Pillow's bundled libavif (built with libyuv) not present")
+def test_compute_oracle_libyuv_build_equals_libyuv_enabled_binary():
+    """avifRGBImageComputeGainMap of the libyuv-enabled binary (the gain map's RGB -> YUV conversion goes through libyuv there)
+    against the default-build flavour of the oracle.  Rescaled gain maps are left out: that binary scales with libyuv 1922's own
+    scaler, the reference tree (and the oracle) with the vendored one."""
+    pil, o = oracle_lib.pillow(), oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    bad = []
+    cases = [c for c in G.compute_cases(150, seed=21) if (c.gm_w or c.w, c.gm_h or c.h) == (c.w, c.h)]
+    for c in cases:
+        ra, sa = run_compute(pil.avifRGBImageComputeGainMap, c, C.byref(diag))
+        rb, sb = run_compute(o.oracleRGBImageComputeGainMap, c, 1)
+        if ra != rb or not states_equal(sa, sb):
+            bad.append(f"{c.ident()}: results {ra}/{rb}")
+    assert len(cases) > 80 and not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+
+
 def test_argument_errors():
     o = oracle_lib.oracle()
     c = G.GainMapCase(8, 8)
