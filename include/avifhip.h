@@ -175,6 +175,8 @@ AVIFHIP_API avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRg
                                                      avifTransferCharacteristics altTransferCharacteristics,
                                                      avifGainMap * gainMap,
                                                      avifDiagnostics * diag);
+/* avifImageComputeGainMap (reference src/gainmap.c:843-912): both renditions as YUV images */
+AVIFHIP_API avifResult avifhipImageComputeGainMap(const avifImage * baseImage, const avifImage * altImage, avifGainMap * gainMap, avifDiagnostics * diag);
 AVIFHIP_API avifResult avifhipImageApplyGainMap(const avifImage * baseImage,
                                                 const avifGainMap * gainMap,
                                                 float hdrHeadroom,

@@ -420,7 +420,10 @@ extern "C" avifResult avifhipImageApplyGainMap(const avifImage * baseImage, cons
     diagClear(diag);
     if (!baseImage || !gainMap)
         return AVIF_RESULT_INVALID_ARGUMENT;
-    // (ICC profiles, :328-331, live in the part of avifImage / avifGainMap this library does not read: the caller checks them)
+    if (baseImage->avifhipOpaqueIcc_[1] > 0 || gainMap->altICC.size > 0) { // icc.size, include/avifhip/avif_abi.h; :328-331
+        diagPrintf(diag, "Tone mapping for images with ICC profiles is not supported");
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    }
     avifRGBImage baseRgb; // avifRGBImageSetDefaults + avifRGBImageAllocatePixels, :333-335
     memset(&baseRgb, 0, sizeof(baseRgb));
     baseRgb.width = baseImage->width, baseRgb.height = baseImage->height, baseRgb.depth = baseImage->depth, baseRgb.format = AVIF_RGB_FORMAT_RGBA;
@@ -744,3 +747,52 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
     return AVIF_RESULT_OK;
 }
 
+
+// avifImageComputeGainMap, src/gainmap.c:843-912: both renditions arrive as YUV
+extern "C" avifResult avifhipImageComputeGainMap(const avifImage * baseImage, const avifImage * altImage, avifGainMap * gainMap, avifDiagnostics * diag)
+{
+    diagClear(diag);
+    if (baseImage == NULL || altImage == NULL || gainMap == NULL)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if (baseImage->avifhipOpaqueIcc_[1] > 0 || altImage->avifhipOpaqueIcc_[1] > 0) {
+        diagPrintf(diag, "Computing gain maps for images with ICC profiles is not supported");
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    }
+    if (baseImage->width != altImage->width || baseImage->height != altImage->height) {
+        diagPrintf(diag, "Image dimensions don't match, got %dx%d and %dx%d", baseImage->width, baseImage->height, altImage->width, altImage->height);
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    avifRGBImage rgb[2]; // avifRGBImageSetDefaults + avifRGBImageAllocatePixels for each rendition
+    const avifImage * src[2] = { baseImage, altImage };
+    memset(rgb, 0, sizeof(rgb));
+    avifResult r = AVIF_RESULT_OK;
+    for (int k = 0; k < 2 && r == AVIF_RESULT_OK; ++k) {
+        rgb[k].width = src[k]->width, rgb[k].height = src[k]->height, rgb[k].depth = src[k]->depth, rgb[k].format = AVIF_RGB_FORMAT_RGBA;
+        rgb[k].chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, rgb[k].chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
+        rgb[k].maxThreads = 1;
+        const uint32_t pixelBytes = rgbPixelBytes(&rgb[k]);
+        if (!rgb[k].width || !rgb[k].height || rgb[k].width > UINT32_MAX / pixelBytes) {
+            r = AVIF_RESULT_INVALID_ARGUMENT;
+            break;
+        }
+        rgb[k].rowBytes = rgb[k].width * pixelBytes;
+        rgb[k].pixels = (uint8_t *)malloc((size_t)rgb[k].rowBytes * rgb[k].height);
+        r = rgb[k].pixels ? avifhipImageYUVToRGB(src[k], &rgb[k]) : AVIF_RESULT_OUT_OF_MEMORY;
+    }
+    if (r == AVIF_RESULT_OK)
+        r = avifhipRGBImageComputeGainMap(&rgb[0], baseImage->colorPrimaries, baseImage->transferCharacteristics, &rgb[1], altImage->colorPrimaries,
+                                          altImage->transferCharacteristics, gainMap, diag);
+    if (r == AVIF_RESULT_OK) { // :900-906 (the alternate image has no ICC profile here: avifRWDataSet(.., NULL, 0) empties altICC)
+        free(gainMap->altICC.data);
+        gainMap->altICC.data = NULL, gainMap->altICC.size = 0;
+        gainMap->altColorPrimaries = altImage->colorPrimaries;
+        gainMap->altTransferCharacteristics = altImage->transferCharacteristics;
+        gainMap->altMatrixCoefficients = altImage->matrixCoefficients;
+        gainMap->altDepth = altImage->depth;
+        gainMap->altPlaneCount = (altImage->yuvFormat == AVIF_PIXEL_FORMAT_YUV400) ? 1 : 3;
+        memcpy(&gainMap->altCLLI, altImage->avifhipOpaqueTail_, sizeof(gainMap->altCLLI)); // avifImage.clli @110
+    }
+    free(rgb[0].pixels);
+    free(rgb[1].pixels);
+    return r;
+}

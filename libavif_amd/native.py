@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
     "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
-    "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap",
+    "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap",
 ]
 
 class avifSampleTransformToken(C.Structure):
@@ -108,6 +108,7 @@ def load() -> C.CDLL:
         "avifhipRGBImageApplyGainMapAsync": (i32, [P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
                                                    C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics), vp]),
         "avifhipRGBImageComputeGainMap": (i32, [P_RGB, C.c_uint16, C.c_uint16, P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.POINTER(avifDiagnostics)]),
+        "avifhipImageComputeGainMap": (i32, [P_IMG, P_IMG, C.POINTER(avifGainMap), C.POINTER(avifDiagnostics)]),
         "avifhipImageApplyGainMap": (i32, [P_IMG, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
                                            C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics)]),
     }

@@ -292,3 +292,31 @@ def test_gpu_compute_equals_oracle_fp32_arithmetic(hip):
         if ra != rb or not states_equal(sa, sb):
             bad.append(f"{c.ident()}: results {ra}/{rb}" + ("" if sa is None or sb is None else f" meta equal {sa[0] == sb[0]} size {sa[1]}/{sb[1]}"))
     assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+
+
+@pytest.mark.gpu
+def test_gpu_compute_from_yuv_images(hip_auto_arithmetic):
+    """avifhipImageComputeGainMap (reference avifImageComputeGainMap, src/gainmap.c:843-912): both renditions as YUV images; also fills
+    the alternate image's colorimetry into the gain map."""
+    import harness as H
+    import test_scale as TS
+
+    o = oracle_lib.oracle()
+    yb = H.Y2RCase(200, 120, yuv_depth=8, yuv_format=3, yuv_range=1, matrix=6, avoid_libyuv=False, seed=5)
+    ya = H.Y2RCase(200, 120, yuv_depth=10, yuv_format=1, yuv_range=0, matrix=9, avoid_libyuv=False, seed=6)
+    base_img, alt_img = H.make_y2r_inputs(yb), H.make_y2r_inputs(ya)
+    base_img.struct.colorPrimaries, base_img.struct.transferCharacteristics = 1, 13
+    alt_img.struct.colorPrimaries, alt_img.struct.transferCharacteristics, alt_img.struct.matrixCoefficients = 9, 16, 9
+    base = abi.make_rgb(200, 120, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+    alt = abi.make_rgb(200, 120, 10, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+    assert o.oracleLibyuvImageYUVToRGB(base_img.struct, base.struct) == 0 and o.oracleLibyuvImageYUVToRGB(alt_img.struct, alt.struct) == 0
+    c = G.ComputeCase(200, 120, gm_w=100, gm_h=60, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420)
+    gm_a, img_a = G.make_compute_gain_map(c)
+    gm_b, img_b = G.make_compute_gain_map(c)
+    assert o.oracleRGBImageComputeGainMap(base.struct, 1, 13, alt.struct, 9, 16, C.byref(gm_a), 1) == 0
+    diag = abi.avifDiagnostics()
+    assert hip_auto_arithmetic.avifhipImageComputeGainMap(base_img.struct, alt_img.struct, C.byref(gm_b), C.byref(diag)) == 0, diag.error
+    assert states_equal(gain_map_state(gm_a, img_a.struct), gain_map_state(gm_b, img_b.struct))
+    assert (gm_b.altColorPrimaries, gm_b.altTransferCharacteristics, gm_b.altMatrixCoefficients, gm_b.altDepth, gm_b.altPlaneCount) == (9, 16, 9, 10, 3)
+    TS.free_owned(img_a.struct)
+    TS.free_owned(img_b.struct)
