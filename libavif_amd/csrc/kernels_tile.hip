@@ -108,15 +108,17 @@ void decompose(uint32_t tuning, uint32_t w4, uint32_t h2, uint32_t jobs, bool ba
     uint32_t ns = (tuning >> TUNE_STRIPS_SHIFT) & 0xfu;
     const uint64_t tiles8 = (uint64_t)bands * ((h2 + 7) / 8) * jobs;
     if (ns == 0)
-        ns = tiles8 >= 4 * kTargetBlocks ? 2 : 1;
+        ns = 2 * tiles8 >= 3 * (uint64_t)kTargetBlocks ? 2 : 1; // from 4K frames up (tests/tools/geometry_sweep.py: 4K 11.1 -> 9.5 us)
     ns = (ns >= 2 && !batch) ? 2 : 1; // the batch kernels exist for NS = 1 only: batches are made of small jobs
     const uint32_t tilesY = (h2 + 8 * ns - 1) / (8 * ns);
     uint32_t run = (tuning >> TUNE_RUN_SHIFT) & 0xfu;
     if (run == 0) {
-        // about kTargetBlocks workgroups (8 per CU) in the launch, at most 8 tiles each
+        // about kTargetBlocks / 2 workgroups (4 per CU) in the launch, each walking 1..3 tiles: the sweep prefers fewer, longer-lived
+        // workgroups (the next tile's loads fly during the current tile's arithmetic) over one tile per workgroup; 8K frames keep
+        // their runs of 3
         const uint64_t tiles = (uint64_t)bands * tilesY * jobs;
-        run = (uint32_t)(tiles / kTargetBlocks);
-        run = run < 1 ? 1 : (run > 8 ? 8 : run);
+        run = (uint32_t)((2 * tiles + kTargetBlocks / 2) / kTargetBlocks);
+        run = run < 1 ? 1 : (run > 3 ? 3 : run);
     }
     L->stripsPerWave = ns;
     L->tilesPerRun = run;

@@ -31,9 +31,10 @@ def run(name):
     for arith, avoid in (("float", True), ("integer", False)):
         lib.avifhipSetArithmetic(1 if arith == "float" else 0)
         px, bpp, ms = 0, 0.0, None
-        if name in ("cfg2", "cfg2n"):
-            pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=BIL if name == "cfg2" else NEAR, avoid=avoid)
-            px, bpp, ms = 7680 * 4320, 5.5, time_y2r(pair)
+        if name in ("cfg2", "cfg2n", "cfg2_4k"):
+            w, h = (3840, 2160) if name == "cfg2_4k" else (7680, 4320)  # the north star asks for 4K planes beside the 8K headline
+            pair = y2r(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR if name == "cfg2n" else BIL, avoid=avoid)
+            px, bpp, ms = w * h, 5.5, time_y2r(pair)
         elif name == "cfg3":
             pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, avoid=avoid)
             px, bpp, ms = 7680 * 4320, 16.0, time_y2r(pair, 20)
