@@ -443,3 +443,17 @@ avifResult oracleImageScale(avifImage * image, uint32_t dstWidth, uint32_t dstHe
         image->imageOwnsAlphaPlane = AVIF_TRUE;
     return AVIF_RESULT_OK;
 }
+
+/* For tests of the product's HOST logic (libavif_amd/csrc/scale_plan.cpp, compared on the CPU): the schedule of one plane scale.
+ * Arrays of dstW / dstH entries; returns the mode (0 point, 1 down, 2 up, 3 box, 4 up2) or -1. */
+int oracleScaleSchedule(int srcW, int srcH, int dstW, int dstH, int wide, int * colA, int * colB, int * rowA, int * rowB, int * rowF)
+{
+    PlaneSchedule S;
+    if (!buildSchedule(&S, srcW, srcH, dstW, dstH, wide))
+        return -1;
+    memcpy(colA, S.colA, (size_t)dstW * sizeof(int)), memcpy(colB, S.colB, (size_t)dstW * sizeof(int));
+    memcpy(rowA, S.rowA, (size_t)dstH * sizeof(int)), memcpy(rowB, S.rowB, (size_t)dstH * sizeof(int)), memcpy(rowF, S.rowF, (size_t)dstH * sizeof(int));
+    const int mode = S.mode;
+    freeSchedule(&S);
+    return mode;
+}

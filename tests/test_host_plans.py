@@ -1,0 +1,140 @@
+"""The product's HOST logic on the CPU (no GPU needed): the pure-host planners behind the side-path kernels --
+libavif_amd/csrc/scale_plan.cpp (plane-scaling schedules) and gainmap_plan.cpp (transfer functions, primaries matrices, fractions,
+the fp32 steps of the quantised output transfer functions) -- compiled with g++ into a small test library and compared with the
+oracle (itself pinned against the reference).  What the kernels do with the tables is covered by the -m gpu tests."""
+import ctypes as C
+import os
+import random
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "libavif_amd" / "csrc"
+SO = ROOT / "tests" / "tools" / "libhostlogic.so"
+
+
+@pytest.fixture(scope="module")
+def host():
+    srcs = [ROOT / "tests" / "tools" / "hostlogic.cpp", CSRC / "scale_plan.cpp", CSRC / "gainmap_plan.cpp"]
+    deps = srcs + [CSRC / "scale_plan.h", CSRC / "gainmap_plan.h"]
+    if not SO.exists() or any(d.stat().st_mtime > SO.stat().st_mtime for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", f"-I{CSRC}", "-o", os.fspath(SO)] + [os.fspath(s) for s in srcs],
+                       check=True, capture_output=True)
+    lib = C.CDLL(os.fspath(SO))
+    ip = C.POINTER(C.c_int)
+    lib.hostScaleSchedule.restype, lib.hostScaleSchedule.argtypes = C.c_int, [C.c_int] * 5 + [ip] * 5
+    lib.hostTransferFunction.restype, lib.hostTransferFunction.argtypes = C.c_float, [C.c_int, C.c_int, C.c_float]
+    lib.hostPrimariesMatrix.restype, lib.hostPrimariesMatrix.argtypes = C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double * 9)]
+    lib.hostDoubleToSignedFraction.restype, lib.hostDoubleToSignedFraction.argtypes = C.c_int, [C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+    lib.hostDoubleToUnsignedFraction.restype, lib.hostDoubleToUnsignedFraction.argtypes = C.c_int, [C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.hostOutputSteps.restype = C.c_uint32
+    lib.hostOutputSteps.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.hostChooseMathPrimaries.restype, lib.hostChooseMathPrimaries.argtypes = C.c_int, [C.c_int, C.c_int]
+    return lib
+
+
+def test_scale_schedules_equal_the_oracles(host):
+    """Mode and every per-column / per-row schedule entry, over random plane geometries (both sample widths)."""
+    o = oracle_lib.oracle()
+    o.oracleScaleSchedule.restype, o.oracleScaleSchedule.argtypes = C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int)] * 5
+    rnd = random.Random(5)
+    checked = 0
+    for k in range(40000):
+        if k % 3 == 0:
+            sw, sh, dw, dh = rnd.randint(1, 300), rnd.randint(1, 300), rnd.randint(1, 300), rnd.randint(1, 300)
+        elif k % 3 == 1:
+            sw, sh = rnd.randint(1, 5000), rnd.randint(1, 40)
+            dw, dh = max(1, int(sw * rnd.choice((0.1, 0.25, 1 / 3, 0.5, 0.6, 1, 1.5, 2, 3)))), max(1, int(sh * rnd.choice((0.25, 0.5, 1, 2, 3))))
+        else:
+            sw, sh = rnd.randint(1, 64), rnd.randint(1, 64)
+            dw, dh = max(1, 2 * sw - rnd.choice((0, 1))), max(1, 2 * sh - rnd.choice((0, 1)))
+        wide = k & 1
+        a = [(C.c_int * n)() for n in (dw, dw, dh, dh, dh)]
+        b = [(C.c_int * n)() for n in (dw, dw, dh, dh, dh)]
+        ma = o.oracleScaleSchedule(sw, sh, dw, dh, wide, *a)
+        mb = host.hostScaleSchedule(sw, sh, dw, dh, wide, *b)
+        assert ma == mb, (sw, sh, dw, dh, wide, ma, mb)
+        for x, y, name in zip(a, b, ("colA", "colB", "rowA", "rowB", "rowF")):
+            if ma == 0 and name in ("colB", "rowB", "rowF"):
+                continue  # point sampling reads only the first column / row entry
+            if ma in (3, 4) and name == "rowF":
+                continue  # boxes and the 2x upsamplers carry no row fraction
+            assert list(x) == list(y), (sw, sh, dw, dh, wide, ma, name)
+        checked += 1
+    assert checked == 40000
+
+
+def test_transfer_functions_equal_the_oracles(host):
+    o = oracle_lib.oracle()
+    rng = np.random.default_rng(1)
+    values = np.concatenate([rng.uniform(-0.5, 1.5, 4000), rng.uniform(0, 60, 500), 10.0 ** rng.uniform(-9, 0, 2000), [0.0, -0.0, 1.0, 0.5, 1 / 12, 0.018053968510807,
+                             4.5 * 0.018053968510807, float("inf"), -float("inf")]]).astype(np.float32)
+    for tc in (1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 3, 99):
+        for direction in (0, 1):
+            for v in values:
+                a, b = o.oracleTransferFunction(tc, direction, float(v)), host.hostTransferFunction(tc, direction, float(v))
+                assert np.float32(a).tobytes() == np.float32(b).tobytes() or (a != a and b != b), (tc, direction, float(v), a, b)
+
+
+def test_primaries_and_fractions_equal_the_oracles(host):
+    o = oracle_lib.oracle()
+    o.oracleDoubleToSignedFraction.restype = C.c_int
+    o.oracleDoubleToUnsignedFraction.restype = C.c_int
+    from libavif_amd import abi
+
+    prim = (1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 22, 99)
+    for a in prim:
+        for b in prim:
+            ma, mb = (C.c_double * 9)(), (C.c_double * 9)()
+            ra, rb = o.oracleColorPrimariesComputeRGBToRGBMatrix(a, b, C.byref(ma)), host.hostPrimariesMatrix(a, b, C.byref(mb))
+            assert bool(ra) == bool(rb) and (not ra or list(ma) == list(mb)), (a, b)
+    rnd = random.Random(2)
+    for _ in range(20000):
+        v = rnd.choice((rnd.uniform(-8, 8), rnd.uniform(0, 1e-3), rnd.uniform(-1e6, 1e6), float(np.float32(rnd.uniform(-6, 6))), 0.0, 1.0, 1 / 64, 1e12, -3e9))
+        fs, fu = abi.avifSignedFraction(), abi.avifUnsignedFraction()
+        n, d, un, ud = C.c_int32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        o.oracleDoubleToSignedFraction.argtypes = [C.c_double, C.POINTER(abi.avifSignedFraction)]
+        o.oracleDoubleToUnsignedFraction.argtypes = [C.c_double, C.POINTER(abi.avifUnsignedFraction)]
+        ra, rb = o.oracleDoubleToSignedFraction(v, C.byref(fs)), host.hostDoubleToSignedFraction(v, C.byref(n), C.byref(d))
+        assert ra == rb and (not ra or (fs.n, fs.d) == (n.value, d.value)), v
+        ra, rb = o.oracleDoubleToUnsignedFraction(v, C.byref(fu)), host.hostDoubleToUnsignedFraction(v, C.byref(un), C.byref(ud))
+        assert ra == rb and (not ra or (fu.n, fu.d) == (un.value, ud.value)), v
+
+
+@pytest.mark.parametrize("tc", [1, 4, 8, 9, 11, 12, 13, 16, 18])
+@pytest.mark.parametrize("depth,is_float", [(8, 0), (10, 0), (16, 1)])
+def test_output_steps_reproduce_the_quantised_transfer_function(host, tc, depth, is_float):
+    """For random linear values x, the code found by searching the host-built steps equals quantise(clamp(linearToGamma(x))) computed
+    directly with the oracle's transfer function -- the property the gain-map kernel's exactness rests on."""
+    o = oracle_lib.oracle()
+    cap = 2 * 65536
+    steps = (C.c_float * cap)()
+    max_code = C.c_uint32()
+    entries = host.hostOutputSteps(tc, depth, is_float, steps, cap, C.byref(max_code))
+    T = np.frombuffer(steps, dtype=np.float32, count=2 * entries).copy()
+    rng = np.random.default_rng(tc * 100 + depth)
+    xs = np.concatenate([rng.uniform(-0.3, 1.3, 3000), 10.0 ** rng.uniform(-8, 2, 3000), -(10.0 ** rng.uniform(-8, 0, 500)), [0.0, -0.0, 1.0, 1e30, -1e30]]).astype(np.float32)
+    max_f = np.float32((1 << depth) - 1)
+    for x in xs:
+        g = np.float32(o.oracleTransferFunction(tc, 1, float(x)))
+        v = np.float32(min(np.float32(1.0), max(np.float32(0.0), g)))  # avifNanSafeClamp
+        if is_float:
+            want = int((np.float32(v * np.float32(1.9259299444e-34)).view(np.uint32) >> 13) & 0xFFFF)
+        else:
+            want = int(np.float32(np.float32(0.5) + v * max_f))
+        piece = T[:entries] if x < 0 else T[entries:]
+        with np.errstate(invalid="ignore"):
+            got = int(np.nonzero(piece[: max_code.value + 1] <= x)[0].max())
+        assert got == want, (tc, depth, is_float, float(x), got, want)
+
+
+def test_gain_map_math_primaries_choice(host):
+    """avifChooseColorSpaceForGainMapMath: the larger colour space; checked through the oracle's computation (metadata useBaseColorSpace)."""
+    assert host.hostChooseMathPrimaries(1, 1) == 1
+    assert host.hostChooseMathPrimaries(1, 9) == 9 and host.hostChooseMathPrimaries(9, 1) == 9  # BT.2020 contains BT.709
+    assert host.hostChooseMathPrimaries(12, 1) == 12
