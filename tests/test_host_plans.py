@@ -35,6 +35,10 @@ def host():
     lib.hostOutputSteps.restype = C.c_uint32
     lib.hostOutputSteps.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.hostChooseMathPrimaries.restype, lib.hostChooseMathPrimaries.argtypes = C.c_int, [C.c_int, C.c_int]
+    lib.hostCheckBucketSteps.restype = C.c_int
+    lib.hostCheckBucketSteps.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(C.c_int)]
+    lib.hostCheckCodeSteps.restype = C.c_int
+    lib.hostCheckCodeSteps.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int, C.c_uint32]
     return lib
 
 
@@ -138,3 +142,21 @@ def test_gain_map_math_primaries_choice(host):
     assert host.hostChooseMathPrimaries(1, 1) == 1
     assert host.hostChooseMathPrimaries(1, 9) == 9 and host.hostChooseMathPrimaries(9, 1) == 9  # BT.2020 contains BT.709
     assert host.hostChooseMathPrimaries(12, 1) == 12
+
+
+def test_gain_map_computation_step_tables(host):
+    """Gain-map computation rests on two host-built tables over the fp32 ratio: the outlier histogram's bucket steps and the final
+    code steps.  Searching them must give what the reference's formulas give directly, also right at and next to the steps."""
+    rnd = random.Random(9)
+    with_buckets = 0
+    for k in range(60):
+        sign = rnd.choice((1.0, -1.0))
+        min_r = 10.0 ** rnd.uniform(-3, 0.5)
+        max_r = min_r * 10.0 ** rnd.uniform(0.01, 3)
+        nb = C.c_int()
+        assert host.hostCheckBucketSteps(sign, min_r, max_r, rnd.choice((10, 5000, 2_000_000, 33_177_600)), 20000, k, C.byref(nb)) == 0, (sign, min_r, max_r)
+        with_buckets += nb.value > 0
+        lo, hi = sorted((sign * np.log2(min_r), sign * np.log2(max_r)))
+        cut = (hi - lo) * rnd.uniform(0, 0.2)
+        assert host.hostCheckCodeSteps(sign, min_r, max_r, lo + cut, hi - cut * rnd.uniform(0, 1), rnd.choice((1.0, 1.0, 0.5, 2.2)), rnd.choice((8, 10, 12)), 20000, k) == 0
+    assert with_buckets > 30

@@ -55,3 +55,85 @@ int hostChooseMathPrimaries(int basePrimaries, int altPrimaries)
 }
 
 } // extern "C"
+
+// ---- gain-map computation: the monotone-step tables against the formulas they tabulate (both evaluated here, on the host) ----
+#include <math.h>
+
+#include <random>
+
+namespace {
+
+uint32_t searchSteps(const std::vector<float> & T, uint32_t entries, float x) // what the kernels do: largest k with T[k] <= x
+{
+    uint32_t pos = 0;
+    for (uint32_t s = entries >> 1; s; s >>= 1)
+        pos += (T[pos + s] <= x) ? s : 0;
+    return pos;
+}
+float clampRef(float v, float lo, float hi)
+{
+    return (v < lo) ? lo : ((hi < v) ? hi : v);
+}
+// a ratio between minR and maxR, log-uniform, snapped to nearby step boundaries now and then
+float drawRatio(std::mt19937 & rng, float minR, float maxR, const std::vector<float> & T)
+{
+    std::uniform_real_distribution<float> u(0.0f, 1.0f);
+    if (u(rng) < 0.3f) {
+        const float t = T[1 + rng() % (T.size() - 1)];
+        if (t == t && t >= minR && t <= maxR)
+            return (u(rng) < 0.5f) ? t : nextafterf(t, (u(rng) < 0.5f) ? 0.0f : INFINITY);
+    }
+    return minR * powf(maxR / minR, u(rng));
+}
+
+} // namespace
+
+extern "C" {
+
+// mismatches between the bucket found through gainMapBucketSteps and avifValueToBucketIdx evaluated directly, over `samples` ratios
+int hostCheckBucketSteps(float sign, float minRatio, float maxRatio, uint64_t numPixels, int samples, uint32_t seed, int * numBuckets)
+{
+    const GainMapChannelRange R = gainMapChannelRange(sign, minRatio, maxRatio, (size_t)numPixels);
+    *numBuckets = R.numBuckets;
+    if (R.numBuckets == 0)
+        return 0;
+    uint32_t entries = 0;
+    const std::vector<float> T = gainMapBucketSteps(R, &entries);
+    std::mt19937 rng(seed);
+    int bad = 0;
+    for (int k = 0; k < samples; ++k) {
+        float r = drawRatio(rng, minRatio, maxRatio, T);
+        r = clampRef(r, minRatio, maxRatio);
+        const uint32_t m = searchSteps(T, entries, r);
+        const int got = sign > 0 ? (int)m : R.numBuckets - 1 - (int)m;
+        float v = clampRef(sign * log2f(r), R.lo, R.hi);
+        int want = (int)floorf((v - R.lo) / (R.hi - R.lo) * R.numBuckets + 0.5f);
+        want = want < R.numBuckets - 1 ? want : R.numBuckets - 1;
+        bad += got != want;
+    }
+    return bad;
+}
+
+// the same for the final codes (gainMapCodeSteps vs src/gainmap.c:776-782 + avifSetRGBAPixel)
+int hostCheckCodeSteps(float sign, float minRatio, float maxRatio, float minLog2, float maxLog2, float gamma, uint32_t depth, int samples, uint32_t seed)
+{
+    GainMapChannelRange R = gainMapChannelRange(sign, minRatio, maxRatio, 1000000);
+    const std::vector<float> T = gainMapCodeSteps(R, minLog2, maxLog2, gamma, depth);
+    const uint32_t entries = 1u << depth, maxCode = entries - 1;
+    const float range = maxLog2 - minLog2;
+    std::mt19937 rng(seed);
+    int bad = 0;
+    for (int k = 0; k < samples; ++k) {
+        float r = clampRef(drawRatio(rng, minRatio, maxRatio, T), minRatio, maxRatio);
+        const uint32_t m = searchSteps(T, entries, r);
+        const uint32_t got = sign > 0 ? m : maxCode - m;
+        float v = clampRef(sign * log2f(r), minLog2, maxLog2);
+        v = powf((v - minLog2) / range, gamma);
+        v = fminf(1.0f, fmaxf(0.0f, v));
+        const uint32_t want = (uint32_t)(0.5f + v * (float)maxCode);
+        bad += got != want;
+    }
+    return bad;
+}
+
+} // extern "C"
