@@ -285,9 +285,12 @@ __device__ __forceinline__ void computeLinearPair(const GainMapComputeArgs & A, 
 {
     uint32_t code[3];
     float alpha;
-    readPixel(A.base + (size_t)j * A.basePitch + (size_t)i * A.baseL.pixelBytes, A.baseL, false, code, alpha);
+    // 4-channel pixels at naturally aligned addresses: one 4- or 8-byte load per pixel (uniform conditions)
+    const bool baseVector = A.baseL.hasAlpha && (((uintptr_t)A.base | A.basePitch) & (A.baseL.pixelBytes - 1)) == 0;
+    const bool altVector = A.altL.hasAlpha && (((uintptr_t)A.alt | A.altPitch) & (A.altL.pixelBytes - 1)) == 0;
+    readPixel(A.base + (size_t)j * A.basePitch + (size_t)i * A.baseL.pixelBytes, A.baseL, baseVector, code, alpha);
     b[0] = A.baseLut[code[0]], b[1] = A.baseLut[code[1]], b[2] = A.baseLut[code[2]];
-    readPixel(A.alt + (size_t)j * A.altPitch + (size_t)i * A.altL.pixelBytes, A.altL, false, code, alpha);
+    readPixel(A.alt + (size_t)j * A.altPitch + (size_t)i * A.altL.pixelBytes, A.altL, altVector, code, alpha);
     a[0] = A.altLut[code[0]], a[1] = A.altLut[code[1]], a[2] = A.altLut[code[2]];
     if (A.convertAlt)
         convertPrimaries(a, A.M);
