@@ -171,17 +171,24 @@ class ComputeCase:
     gm_range: int = abi.AVIF_RANGE_FULL
     gm_matrix: int = abi.AVIF_MATRIX_COEFFICIENTS_BT601
     correlated: bool = True  # the alternate image is a brightened copy of the base (what a real HDR/SDR pair looks like) + noise
+    flat: int = -1           # >= 0: both images are this constant code (scaled to their depths): every ratio equal, range 0
     seed: int = 1
 
     def ident(self) -> str:
         return (f"{self.w}x{self.h}-b{self.base_depth}{abi.RGB_FORMAT_NAMES[self.base_format]}-cp{self.base_primaries}tc{self.base_tc}"
                 f"-a{self.alt_depth}{'f' if self.alt_float else ''}{abi.RGB_FORMAT_NAMES[self.alt_format]}-cp{self.alt_primaries}tc{self.alt_tc}"
-                f"-gm{self.gm_w or self.w}x{self.gm_h or self.h}d{self.gm_depth}f{self.gm_format}r{self.gm_range}m{self.gm_matrix}-{'c' if self.correlated else 'r'}{self.seed}")
+                f"-gm{self.gm_w or self.w}x{self.gm_h or self.h}d{self.gm_depth}f{self.gm_format}r{self.gm_range}m{self.gm_matrix}-{'c' if self.correlated else 'r'}{self.seed}"
+                f"{'' if self.flat < 0 else '-flat' + str(self.flat)}")
 
 
 def make_compute_inputs(c: ComputeCase):
     base = abi.make_rgb(c.w, c.h, c.base_depth, c.base_format, avoid_libyuv=False)
     synth.fill_rgb(base, c.seed)
+    if c.flat >= 0:
+        alt = abi.make_rgb(c.w, c.h, c.alt_depth, c.alt_format, is_float=c.alt_float, avoid_libyuv=False)
+        base.channels()[...] = (c.flat * ((1 << c.base_depth) - 1)) // 255
+        alt.channels()[...] = (c.flat * ((1 << c.alt_depth) - 1)) // 255
+        return base, alt
     alt = abi.make_rgb(c.w, c.h, c.alt_depth, c.alt_format, is_float=c.alt_float, avoid_libyuv=False)
     rng = np.random.default_rng(c.seed)
     if c.correlated:
@@ -218,7 +225,10 @@ def compute_cases(n_random: int, seed: int, sizes=((37, 21), (64, 33), (5, 3), (
            ComputeCase(w0, h0, base_tc=16, base_depth=10, alt_tc=13, alt_depth=8),  # HDR base, SDR alternate: negative direction
            ComputeCase(w0, h0, alt_float=True, alt_depth=16, alt_tc=8), ComputeCase(w0, h0, correlated=False),
            ComputeCase(w0, h0, gm_range=abi.AVIF_RANGE_LIMITED, gm_matrix=1, gm_format=abi.AVIF_PIXEL_FORMAT_YUV422),
-           ComputeCase(120, 40, correlated=True, seed=9), ComputeCase(1, 1)]
+           ComputeCase(120, 40, correlated=True, seed=9), ComputeCase(1, 1),
+           # constant images: one ratio everywhere, zero range (src/gainmap.c:766-773), no histogram
+           ComputeCase(37, 21, flat=0, alt_tc=13, alt_depth=8), ComputeCase(37, 21, flat=255), ComputeCase(64, 33, flat=100, alt_tc=13, alt_depth=8, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400),
+           ComputeCase(37, 21, flat=128, alt_primaries=9, gm_w=9, gm_h=5)]
     for tc in TCS:
         out.append(ComputeCase(w0, h0, base_tc=13, alt_tc=tc, seed=300 + tc))
     for _ in range(n_random):
