@@ -6,20 +6,27 @@ range -> RGBA8 with bilinear chroma upsampling (BASELINE.json configs[1]), plane
 with the API defaults (rgb.avoidLibYUV = 0): the reference's INTEGER path, i.e. byte-identical to what a libavif built
 with libyuv computes (I420ToARGBMatrixFilter, kFilterBilinear).  The fp32 path (avoidLibYUV = 1, byte-identical to a
 libavif built without libyuv) is timed next to it and reported inside "roofline" as "fp32_path".
-Steps cycle over several distinct frames so the working set (>700 MB) exceeds the 256 MB Infinity Cache: every
-byte of every step comes from and goes to HBM.  Frames are independent units of work (sequence frames / grid
-tiles), so consecutive steps are issued round-robin on a few HIP streams and overlap each other's head and tail.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R]
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU): every rank converts its own frames,
-there is no data-path collective ("scaling": "weak"); ranks only meet in the barrier around the timed region and
-the MAX over rank times.
+Timed region: W untimed warm-up steps, then EXACTLY K steps between a barrier + device synchronisation on both sides
+(MAX over ranks); that region is repeated R times (default 9) and the MEDIAN is reported as ms_per_step / value -- a single
+region of a few dozen 30-microsecond launches is noise.  Steps cycle over 4 distinct frames (730 MB) and are issued
+round-robin on 2 HIP streams: frames are independent units of work (sequence frames / grid tiles), so consecutive steps
+overlap each other's head and tail; that is why ms_per_step can be below one kernel's own duration ("value_basis").
+Before anything is timed the GPU is kept busy for --preheat-ms (default 300 ms): an idle MI355X sits at 95 MHz and
+needs ~40 ms of work to reach its running clocks (tests/tools/spread_probe.py: the first bursts run 55 -> 30 us per launch).
 
-The "roofline" object describes the dominant kernel alone: algorithmic bytes per launch (5.5 B/pixel: each input
-sample read once, each output byte written once) divided by the kernel's average duration, measured with HIP events
-on the launch stream over back-to-back launches that cycle over the same distinct frames (single stream, no
-overlap between launches).
+N > 1: one rank per GPU over RCCL (torch.distributed.run, launched by the driver -- or by this script itself when it is
+started plainly with --gpus N > 1); every rank converts its own frames, there is no data-path collective ("scaling":
+"weak"); ranks only meet in the barriers around the timed regions.
+
+"roofline" describes the dominant kernel alone: algorithmic bytes per launch (5.5 B/pixel: each input sample read once,
+each output byte written once) divided by the kernel's average duration, measured with HIP events on the launch stream over
+back-to-back single-stream launches that cycle over the same 4 frames.  With 4 frames the 200 MB of input planes can stay in
+the 256 MB Infinity Cache while the outputs stream to HBM; "deep_streaming" repeats the timing over 12 frames (2.2 GB), where
+nothing can.  "ceiling" is a kernel of the library that moves the same bytes with NO arithmetic (kernels_bench.hip), timed the
+same way: what the chip itself sustains for this byte movement.
 """
 from __future__ import annotations
 
@@ -27,6 +34,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,6 +45,7 @@ sys.path.insert(0, str(ROOT))
 
 WIDTH, HEIGHT = 7680, 4320
 FRAMES_IN_FLIGHT = 4  # distinct frame buffers cycled by the timed loop (4 x 182 MB > Infinity Cache)
+DEEP_FRAMES = 12      # ... by the "deep_streaming" kernel timing (2.2 GB: inputs cannot stay in the Infinity Cache either)
 STREAMS = 2           # independent frames overlap head/tail on this many HIP streams
 ALGORITHMIC_BYTES_PER_PIXEL = 5.5  # 1.5 B read (Y + U/4 + V/4) + 4 B written (RGBA8), SURVEY.md 8d
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -46,6 +56,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--preheat-ms", type=float, default=300.0, help="GPU work before anything is timed (clock ramp from idle)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=STREAMS)
@@ -113,12 +125,38 @@ def cpu_baseline(abi, synth, seconds: float):
             "best_value": round(mp / best, 2)}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one per GPU)
+    and hand back their exit code.  Fails loudly when the node has fewer than N GPUs."""
+    from libavif_amd import native
+
+    have = native.load().avifhipDeviceCount()
+    if have < n:
+        raise SystemExit(f"bench.py: --gpus {n} requested but only {have} HIP device(s) are visible -- refusing to report a {n}-GPU number")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.fspath(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     dist = None
     torch = None
     # (AVIFHIP_BENCH_FORCE_DIST=1: take the multi-rank code path -- torch + RCCL process group, barriers, max-over-ranks --
@@ -129,6 +167,8 @@ def main():
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, {torch.cuda.device_count()} device(s) visible)")
         torch.cuda.set_device(local_rank)
         # RCCL prints a version banner on STDOUT when its communicator comes up; the contract is ONE JSON line there, so
         # stdout points at stderr while the process group initialises and runs its first collective
@@ -155,9 +195,9 @@ def main():
 
     # ---- synthetic frames, resident in HBM before the timed region ----
     frames = []
-    for f in range(FRAMES_IN_FLIGHT):
+    for f in range(DEEP_FRAMES):
         img = abi.make_yuv(WIDTH, HEIGHT, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, abi.AVIF_MATRIX_COEFFICIENTS_BT709)
-        synth.fill_yuv(img, 0x12345678 + rank * FRAMES_IN_FLIGHT + f)
+        synth.fill_yuv(img, 0x12345678 + (rank * DEEP_FRAMES + f) % 4)  # 4 distinct contents are plenty: the buffers are what is cycled
         rgb = abi.make_rgb(WIDTH, HEIGHT, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR,
                            avoid_libyuv=not integer, allocate=False)
         dimg = device.DeviceYUV(img)
@@ -182,62 +222,83 @@ def main():
         for s in streams:
             native.check(lib.avifhipSynchronize(s), "avifhipSynchronize")
 
-    run(args.warmup)
-    device_sync()
-    if dist is not None:
-        torch.cuda.synchronize()
-        dist.barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    device_sync()
-    if dist is not None:
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # ---- preheat: clocks up before anything is timed ----
+    t_heat = time.perf_counter()
+    while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
+        run(200)
+        device_sync()
+
+    # ---- the contract's timed region, `repeats` times ----
+    region_s = []
+    for _ in range(max(1, args.repeats)):
+        run(args.warmup)
+        device_sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        device_sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            dist.barrier()
+        region_s.append(elapsed)
     kernel_name = native.last_kernel()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    elapsed = median(region_s)
 
-    # ---- dominant kernel: average launch duration from HIP events on the launch stream ----
-    # (a) cycling over the distinct frames: every launch streams from/to HBM; (b) one frame repeated: its 50 MB of
-    # input stay in the 256 MB Infinity Cache.  (a) is the roofline figure.
-    n, imgs, rgbs = _cycle_args(frames)
-    def median(xs):
-        xs = sorted(xs)
-        return xs[len(xs) // 2]
+    # ---- dominant kernel: average launch duration from HIP events on the launch stream, single stream, back to back ----
+    n4, imgs4, rgbs4 = _cycle_args(frames[:FRAMES_IN_FLIGHT])
+    nd, imgsd, rgbsd = _cycle_args(frames)
 
-    # median of 7 event-timed bursts of 40 launches (not the best one: the figure must agree with a profiler's average)
-    kernel_ms_stream = median([lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 4, 40, None) for _ in range(7)])
-    kernel_ms_same = median([lib.avifhipTimeYUVToRGB(frames[0][0].struct, frames[0][1].struct, 4, 40, None) for _ in range(7)])
+    def burst(fn, *a):
+        # median of 9 event-timed bursts of 40 launches (not the best one: the figure must agree with a profiler's average)
+        return median([fn(*a, 4, 40, None) for _ in range(9)])
+
+    kernel_ms_stream = burst(lib.avifhipTimeYUVToRGBCycle, n4, imgs4, rgbs4)
+    kernel_ms_deep = burst(lib.avifhipTimeYUVToRGBCycle, nd, imgsd, rgbsd)
+    kernel_ms_same = burst(lib.avifhipTimeYUVToRGB, frames[0][0].struct, frames[0][1].struct)
 
     # the other arithmetic family on the same frames (same buffers, only rgb.avoidLibYUV flipped), kernel timing only
     for _, drgb in frames:
         drgb.struct.avoidLibYUV = 1 if integer else 0
-    other_ms_stream = median([lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 4, 40, None) for _ in range(7)])
+    other_ms_stream = burst(lib.avifhipTimeYUVToRGBCycle, n4, imgs4, rgbs4)
     other_kernel = native.last_kernel()
     for _, drgb in frames:
         drgb.struct.avoidLibYUV = 0 if integer else 1
 
+    # the chip's ceiling for this byte movement: same bytes, same lane mapping, no arithmetic (overwrites the RGB buffers)
+    ceil_ms_stream = burst(lib.avifhipTimeStreamCeiling, n4, imgs4, rgbs4)
+    ceil_ms_deep = burst(lib.avifhipTimeStreamCeiling, nd, imgsd, rgbsd)
+
     mp_per_step = WIDTH * HEIGHT / 1e6
     value = mp_per_step * args.steps * world / elapsed
     alg_bytes = ALGORITHMIC_BYTES_PER_PIXEL * WIDTH * HEIGHT
-    achieved = alg_bytes / (kernel_ms_stream * 1e-3) / 1e9
 
+    def gbps(ms):
+        return alg_bytes / (ms * 1e-3) / 1e9
+
+    achieved = gbps(kernel_ms_stream)
     out = {
         "metric": "megapixels/sec YUV420->RGBA (8K)",
         "value": round(value, 1),
         "unit": "megapixels/s",
-        "n_gpus": n_gpus,
+        "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 5),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "i32" if integer else "f32",  # the arithmetic type the path computes in: libyuv's fixed point / libavif's fp32
+        "dtype": "i16" if integer else "f32",  # the arithmetic the path computes in: libyuv's fixed point in packed int16 lanes / libavif's fp32
         "data": "synthetic",
+        "value_basis": f"median of {len(region_s)} timed regions of {args.steps} steps each (min {1e3 * min(region_s) / args.steps:.5f}, max "
+                       f"{1e3 * max(region_s) / args.steps:.5f} ms/step); steps are issued round-robin on {n_streams} HIP streams, so "
+                       f"consecutive frames overlap head and tail and ms_per_step can be below roofline.kernel_ms (one kernel alone, single stream)",
         "config": {
             "workload": "7680x4320 8-bit YUV420 BT.709 limited -> RGBA8, bilinear chroma upsampling, HBM-resident, "
                         f"{FRAMES_IN_FLIGHT} distinct frames cycled per rank on {n_streams} HIP streams",
@@ -246,6 +307,8 @@ def main():
             "kernel": kernel_name,
             "frames_per_step": 1,
             "parallelism": f"frames sharded over {world} rank(s), no collective",
+            "preheat_ms": args.preheat_ms,
+            "repeats": len(region_s),
         },
         "roofline": {
             "bound": "hbm",
@@ -255,15 +318,31 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": None,
             "algorithmic_bytes_per_launch": int(alg_bytes),
-            "kernel_ms_hbm_streaming": round(kernel_ms_stream, 5),
+            "kernel_ms": round(kernel_ms_stream, 5),
+            "kernel_ms_hbm_streaming": round(kernel_ms_stream, 5),  # (name kept from round 1)
+            "frames_cycled": FRAMES_IN_FLIGHT,
             "kernel_ms_same_frame": round(kernel_ms_same, 5),
-            "frac_same_frame": round(alg_bytes / (kernel_ms_same * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "read_only_GBps": round(1.5 * WIDTH * HEIGHT / (kernel_ms_stream * 1e-3) / 1e9, 1),
+            "frac_same_frame": round(gbps(kernel_ms_same) / HBM_PEAK_GBPS, 4),
+            "ceiling": {
+                "what": "same bytes, same lane-to-byte mapping, no arithmetic (avifhipTimeStreamCeiling), same timing method",
+                "kernel_ms": round(ceil_ms_stream, 5),
+                "frac_of_peak": round(gbps(ceil_ms_stream) / HBM_PEAK_GBPS, 4),
+                "conversion_vs_ceiling": round(ceil_ms_stream / kernel_ms_stream, 4),
+            },
+            "deep_streaming": {
+                "what": f"{DEEP_FRAMES} frames cycled (2.2 GB): neither planes nor pixels can stay in the 256 MB Infinity Cache",
+                "kernel_ms": round(kernel_ms_deep, 5),
+                "achieved": round(gbps(kernel_ms_deep), 1),
+                "frac": round(gbps(kernel_ms_deep) / HBM_PEAK_GBPS, 4),
+                "ceiling_kernel_ms": round(ceil_ms_deep, 5),
+                "ceiling_frac_of_peak": round(gbps(ceil_ms_deep) / HBM_PEAK_GBPS, 4),
+                "conversion_vs_ceiling": round(ceil_ms_deep / kernel_ms_deep, 4),
+            },
             ("fp32_path" if integer else "integer_path"): {
                 "kernel": other_kernel,
-                "kernel_ms_hbm_streaming": round(other_ms_stream, 5),
-                "achieved": round(alg_bytes / (other_ms_stream * 1e-3) / 1e9, 1),
-                "frac": round(alg_bytes / (other_ms_stream * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "kernel_ms": round(other_ms_stream, 5),
+                "achieved": round(gbps(other_ms_stream), 1),
+                "frac": round(gbps(other_ms_stream) / HBM_PEAK_GBPS, 4),
             },
         },
     }
@@ -271,8 +350,8 @@ def main():
     if traffic_file.exists():
         try:
             tj = json.loads(traffic_file.read_text())
-            # the counters were collected for one kernel family: use them only for that family
-            if ("TileFxKernel" in tj.get("kernel", "")) == ("fixed" in kernel_name):
+            # the counters were collected for one kernel: use them only when that kernel is the one reported
+            if tj.get("kernel_family", "") == kernel_name:
                 out["roofline"]["traffic"] = tj.get("traffic_bytes_per_launch")
         except Exception:
             pass

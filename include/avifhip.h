@@ -283,6 +283,10 @@ AVIFHIP_API double avifhipTimeRGBToYUV(avifImage * image, const avifRGBImage * r
 /* Same for launches that cycle over `count` distinct device-resident frames (launch k converts frame k % count), so
  * that a working set larger than the Infinity Cache makes every launch stream from and to HBM. */
 AVIFHIP_API double avifhipTimeYUVToRGBCycle(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
+/* The chip's own ceiling for the byte movement of an 8-bit 4:2:0 -> 4-byte-pixel conversion: the same timing for a kernel that
+ * reads every plane sample once and writes every output byte once with NO arithmetic (kernels_bench.hip; the RGB buffers receive
+ * meaningless bytes).  Negative for other formats. */
+AVIFHIP_API double avifhipTimeStreamCeiling(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
 
 /* Synthetic planes for benchmarks/tests: xorshift32 stream
  * (x^=x<<13; x^=x>>17; x^=x<<5), one draw per sample, value = lo + draw % (hi-lo+1), written

@@ -13,9 +13,16 @@
  * that build's (libavifhip's default, AVIFHIP_ARITHMETIC_AUTO); if it was built without, the fp32 arithmetic is pinned.
  * AVIFHIP_ARITHMETIC in the environment overrides.  Only the six symbols above are interposed; calls libavif makes
  * internally (e.g. avifImageYUVToRGB from its decoder helpers) are bound inside libavif and are not affected.
+ *
+ * The application's avifImage / avifRGBImage / avifGainMap are read through the struct mirror of include/avifhip/avif_abi.h,
+ * which follows libavif AVIFHIP_MIRRORED_MAJOR.AVIFHIP_MIRRORED_MINOR.  The interposer therefore asks the interposed library
+ * for avifVersion() first: with another major.minor every call is passed straight through (AVIFHIP_PRELOAD_FORCE=1 serves the
+ * four reformat entry points anyway -- the fields they read have kept their places through 1.x -- but never the gain-map ones,
+ * whose structs changed between the experimental 1.0/1.1 builds and 1.2).
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -33,22 +40,41 @@ typedef avifResult (*GainMapFn)(const avifRGBImage *, avifColorPrimaries, avifTr
 typedef avifResult (*ComputeGainMapFn)(const avifRGBImage *, avifColorPrimaries, avifTransferCharacteristics, const avifRGBImage *, avifColorPrimaries,
                                        avifTransferCharacteristics, avifGainMap *, avifDiagnostics *);
 
+#define AVIFHIP_MIRRORED_MAJOR 1
+#define AVIFHIP_MIRRORED_MINOR 4
+
+typedef const char * (*VersionStringFn)(void);
+
+static pthread_once_t gOnce = PTHREAD_ONCE_INIT;
 static struct
 {
-    int resolved;
     YuvToRgbFn yuvToRgb;
     RgbToYuvFn rgbToYuv;
     AlphaFn premultiply, unpremultiply;
     GainMapFn applyGainMap;
     ComputeGainMapFn computeGainMap;
     uint64_t minPixels;
-    int gpu;
+    int gpu;      /* serve the reformat entry points from the GPU */
+    int gpuGainMap; /* ... and the gain-map ones */
 } g;
 
-static void resolve(void)
+/* 1 when the interposed libavif reports the mirrored major.minor, 0 when it reports another one or none */
+static int versionMatches(void)
 {
-    if (g.resolved)
-        return;
+    const VersionStringFn version = (VersionStringFn)dlsym(RTLD_NEXT, "avifVersion");
+    const char * v = version ? version() : NULL;
+    if (!v)
+        return 0;
+    char * end = NULL;
+    const long major = strtol(v, &end, 10);
+    if (!end || *end != '.')
+        return 0;
+    const long minor = strtol(end + 1, NULL, 10);
+    return major == AVIFHIP_MIRRORED_MAJOR && minor == AVIFHIP_MIRRORED_MINOR;
+}
+
+static void resolveOnce(void)
+{
     g.yuvToRgb = (YuvToRgbFn)dlsym(RTLD_NEXT, "avifImageYUVToRGB");
     g.rgbToYuv = (RgbToYuvFn)dlsym(RTLD_NEXT, "avifImageRGBToYUV");
     g.premultiply = (AlphaFn)dlsym(RTLD_NEXT, "avifRGBImagePremultiplyAlpha");
@@ -58,13 +84,22 @@ static void resolve(void)
     const char * e = getenv("AVIFHIP_MIN_PIXELS");
     const long v = e ? atol(e) : 512L * 512L;
     g.minPixels = v < 0 ? 0 : (uint64_t)v;
-    g.gpu = avifhipDeviceCount() > 0;
+    const int sameVersion = versionMatches();
+    const char * force = getenv("AVIFHIP_PRELOAD_FORCE");
+    const int haveGpu = avifhipDeviceCount() > 0;
+    g.gpuGainMap = haveGpu && sameVersion;
+    g.gpu = haveGpu && (sameVersion || (force && force[0] == '1'));
     if (!getenv("AVIFHIP_ARITHMETIC")) {
         const VersionFn libyuvVersion = (VersionFn)dlsym(RTLD_NEXT, "avifLibYUVVersion");
         if (libyuvVersion && libyuvVersion() == 0)
             avifhipSetArithmetic(AVIFHIP_ARITHMETIC_FLOAT); /* the interposed libavif has no libyuv */
     }
-    g.resolved = 1;
+}
+
+/* every field of g is published by pthread_once before any caller reads it */
+static void resolve(void)
+{
+    (void)pthread_once(&gOnce, resolveOnce);
 }
 
 static int worthIt(uint32_t width, uint32_t height)
@@ -136,7 +171,7 @@ AVIF_EXPORT avifResult avifRGBImageApplyGainMap(const avifRGBImage * baseImage,
                                                 avifDiagnostics * diag)
 {
     resolve();
-    if (baseImage && gainMap && toneMappedImage && worthIt(baseImage->width, baseImage->height)) {
+    if (g.gpuGainMap && baseImage && gainMap && toneMappedImage && worthIt(baseImage->width, baseImage->height)) {
         const avifResult r = avifhipRGBImageApplyGainMap(baseImage, baseColorPrimaries, baseTransferCharacteristics, gainMap, hdrHeadroom,
                                                          outputColorPrimaries, outputTransferCharacteristics, toneMappedImage, clli, diag);
         if (!declined(r) || !g.applyGainMap)
@@ -159,7 +194,7 @@ AVIF_EXPORT avifResult avifRGBImageComputeGainMap(const avifRGBImage * baseRgbIm
                                                   avifDiagnostics * diag)
 {
     resolve();
-    if (baseRgbImage && altRgbImage && gainMap && gainMap->image && worthIt(baseRgbImage->width, baseRgbImage->height)) {
+    if (g.gpuGainMap && baseRgbImage && altRgbImage && gainMap && gainMap->image && worthIt(baseRgbImage->width, baseRgbImage->height)) {
         const avifImage request = *gainMap->image; /* the requested size / format, should the call be handed on */
         const avifResult r = avifhipRGBImageComputeGainMap(baseRgbImage, baseColorPrimaries, baseTransferCharacteristics, altRgbImage, altColorPrimaries,
                                                            altTransferCharacteristics, gainMap, diag);

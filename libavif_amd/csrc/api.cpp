@@ -34,8 +34,15 @@ avifResult hipFailed(hipError_t e, const char * what)
 
 avifResult ensureContext()
 {
-    if (tls.stream)
+    if (tls.stream) {
+        // The context's stream and scratch belong to tls.device.  A host application that shares the thread (torch, anything
+        // driving several GPUs) may have made another device current since the last call: allocations would then land on that
+        // device while the kernels run on this one.  The thread is switched back (and stays there: avifhip.h, avifhipSetDevice).
+        int current = -1;
+        if (hipGetDevice(&current) != hipSuccess || current != tls.device)
+            HIP_TRY(hipSetDevice(tls.device));
         return AVIF_RESULT_OK;
+    }
     int count = 0;
     const hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -50,7 +57,29 @@ avifResult ensureContext()
     HIP_TRY(hipStreamCreateWithFlags(&tls.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&tls.tableCopied, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&tls.uploadCopied, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&tls.scratchUsed, hipEventDisableTiming));
     return AVIF_RESULT_OK;
+}
+
+ScratchScope::ScratchScope(hipStream_t s) : stream(s), result(AVIF_RESULT_OK)
+{
+    if (tls.scratchPending && tls.scratchStream != s) {
+        const hipError_t e = hipStreamWaitEvent(s, tls.scratchUsed, 0);
+        if (e != hipSuccess)
+            result = hipFailed(e, "hipStreamWaitEvent(scratch)");
+    }
+}
+
+ScratchScope::~ScratchScope()
+{
+    if (tls.scratchUsed && hipEventRecord(tls.scratchUsed, stream) == hipSuccess) {
+        tls.scratchStream = stream;
+        tls.scratchPending = true;
+    } else {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream); // could not mark the use: make sure nothing is pending instead
+        tls.scratchPending = false;
+    }
 }
 
 // Enqueues a copy of a small host table to device memory.  An asynchronous copy from pageable memory may still be reading
@@ -449,6 +478,9 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
     if (rr != AVIF_RESULT_OK)
         return rr;
     hipStream_t stream = pickStream(hipStream);
+    ScratchScope scratch(stream); // tls.table may still be read by a batch enqueued on another stream
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
     uint8_t * dev = (uint8_t *)tls.table.ptr;
     hipError_t e = hipSuccess;
     if (allTiled) {
@@ -590,6 +622,9 @@ extern "C" avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid, const a
     if (r != AVIF_RESULT_OK)
         return r;
     hipStream_t stream = pickStream(hipStream);
+    ScratchScope scratch(stream);
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
     r = uploadTableAsync(tls.gridTable.ptr, tiles.data(), tableBytes, stream);
     if (r != AVIF_RESULT_OK)
         return r;
@@ -809,6 +844,15 @@ extern "C" avifResult avifhipImageApplyOperationsAsync(avifImage * dstImage, avi
         const int type = (int)tokens[t].type;
         if (type >= AVIF_SAMPLE_TRANSFORM_RESERVED)
             return AVIF_RESULT_INTERNAL_ERROR;
+        // token types in the gaps of the enumeration (2..63, 68..127): the reference's validity check counts them as operands /
+        // unary operators, but its evaluator takes every type it does not know down the binary-operator path
+        // (src/sampletransform.c:313-336), whose assertions end the call with AVIF_RESULT_INTERNAL_ERROR at the latest; the kernel
+        // has no such path, so they are refused here
+        const bool known = type == AVIF_SAMPLE_TRANSFORM_CONSTANT || type == AVIF_SAMPLE_TRANSFORM_INPUT_IMAGE_ITEM_INDEX ||
+                           (type >= AVIF_SAMPLE_TRANSFORM_FIRST_UNARY_OPERATOR && type <= AVIF_SAMPLE_TRANSFORM_BSR) ||
+                           (type >= AVIF_SAMPLE_TRANSFORM_FIRST_BINARY_OPERATOR && type <= AVIF_SAMPLE_TRANSFORM_MAX);
+        if (!known)
+            return AVIF_RESULT_INTERNAL_ERROR;
         if (type == AVIF_SAMPLE_TRANSFORM_INPUT_IMAGE_ITEM_INDEX && (tokens[t].inputImageItemIndex == 0 || tokens[t].inputImageItemIndex > numInputImageItems))
             return AVIF_RESULT_INTERNAL_ERROR;
         if (type < AVIF_SAMPLE_TRANSFORM_FIRST_UNARY_OPERATOR) {
@@ -870,6 +914,9 @@ extern "C" avifResult avifhipImageApplyOperationsAsync(avifImage * dstImage, avi
     avifResult r = reserve(tls.satoTable, sizeof(tables));
     if (r != AVIF_RESULT_OK)
         return r;
+    ScratchScope scratch(stream);
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
     r = uploadTableAsync(tls.satoTable.ptr, tables, sizeof(tables), stream);
     if (r != AVIF_RESULT_OK)
         return r;

@@ -333,6 +333,9 @@ extern "C" avifResult avifhipRGBImageApplyGainMapAsync(const avifRGBImage * base
     if (cr != AVIF_RESULT_OK)
         return cr;
     hipStream_t stream = pickStream(hipStream);
+    ScratchScope scratch(stream); // tables and work buffers are per thread, not per stream
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
     toneMappedImage->width = baseImage->width, toneMappedImage->height = baseImage->height;
     const float weight = gainMapWeight(hdrHeadroom, gainMap);
     if (gainMapIsPlainCopy(baseImage, baseColorPrimaries, baseTransferCharacteristics, weight, outputColorPrimaries, outputTransferCharacteristics,

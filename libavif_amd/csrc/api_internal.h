@@ -75,6 +75,10 @@ struct Context
     void * pinnedUpload = nullptr; // staging for small host tables (grid tile tables, scale schedules)
     size_t pinnedUploadCapacity = 0;
     hipEvent_t uploadCopied = nullptr;
+    // last asynchronous user of the device scratch above (ScratchScope)
+    hipEvent_t scratchUsed = nullptr;
+    hipStream_t scratchStream = nullptr;
+    bool scratchPending = false;
     char lastError[512] = { 0 };
     const char * lastKernel = "";
     uint64_t launches = 0; // kernels enqueued by this thread
@@ -106,6 +110,8 @@ struct Context
             (void)hipHostFree(pinnedUpload);
         if (uploadCopied)
             (void)hipEventDestroy(uploadCopied);
+        if (scratchUsed)
+            (void)hipEventDestroy(scratchUsed);
         if (stream)
             (void)hipStreamDestroy(stream);
     }
@@ -126,6 +132,21 @@ avifResult hipFailed(hipError_t e, const char * what);
     } while (0)
 
 avifResult ensureContext();
+// The per-thread device scratch (descriptor tables, schedules, gain-map work buffers) is shared by every asynchronous entry point
+// that needs any, WHATEVER stream the caller passes: without ordering, a call on stream B could rewrite a table that a kernel
+// enqueued earlier on stream A is still reading.  An entry point that touches scratch opens a ScratchScope on its stream: the
+// constructor makes that stream wait for the scratch's previous user when that was a different stream, the destructor marks
+// everything enqueued on the stream so far as the new last user.  (Entry points that use no scratch -- single-image conversions --
+// pay nothing.)
+struct ScratchScope
+{
+    hipStream_t stream;
+    avifResult result;
+    explicit ScratchScope(hipStream_t s);
+    ~ScratchScope();
+    ScratchScope(const ScratchScope &) = delete;
+    ScratchScope & operator=(const ScratchScope &) = delete;
+};
 // Enqueues a copy of a small host table to device memory through a pinned per-thread staging buffer (see api.cpp)
 avifResult uploadTableAsync(void * deviceDst, const void * hostSrc, size_t bytes, hipStream_t stream);
 avifResult reserve(Scratch & s, size_t bytes);

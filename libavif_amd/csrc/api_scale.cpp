@@ -112,14 +112,19 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
         return AVIF_RESULT_INVALID_ARGUMENT;
     if ((src->yuvPlanes[0] || src->alphaPlane) && (src->width > 16384 || src->height > 16384))
         return AVIF_RESULT_NOT_IMPLEMENTED; // "invalid width/height scale for libyuv", src/scale.c:66-80
+    if (dst->width > 32768u || dst->height > 32768u || (uint64_t)dst->width * dst->height > (uint64_t)16384 * 16384)
+        return AVIF_RESULT_NOT_IMPLEMENTED; // avifDimensionsTooLarge with the default limits, src/scale.c:39-42
     const avifResult cr = ensureContext();
     if (cr != AVIF_RESULT_OK)
         return cr;
     hipStream_t stream = pickStream(hipStream);
+    ScratchScope scratch(stream); // the schedule table may still be read by a scale enqueued on another stream
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
     const bool wide = src->depth > 8;
     const PlaneDims sd = planeDims(src->width, src->height, (int)src->yuvFormat), dd = planeDims(dst->width, dst->height, (int)dst->yuvFormat);
     // The schedules of every plane live in one per-thread device table (successive calls of one thread are ordered by the
-    // stream they share, like the grid table).  Building and uploading them is O(width + height) host work plus one small
+    // stream they share, or through ScratchScope when the stream changes).  Building and uploading them is O(width + height) host work plus one small
     // copy -- as long as one kernel -- so the table of the last geometry is kept: a sequence of frames, or the tiles of a
     // grid, scaled to the same size pay for it once.
     bool present[4] = { false, false, false, false };
@@ -235,6 +240,10 @@ extern "C" avifResult avifhipImageScale(avifImage * image, uint32_t dstWidth, ui
         return AVIF_RESULT_INVALID_ARGUMENT;
     if ((image->yuvPlanes[0] || image->alphaPlane) && (image->width > 16384 || image->height > 16384))
         return AVIF_RESULT_NOT_IMPLEMENTED;
+    // avifDimensionsTooLarge(dstWidth, dstHeight, AVIF_DEFAULT_IMAGE_SIZE_LIMIT, AVIF_DEFAULT_IMAGE_DIMENSION_LIMIT), src/scale.c:39-42
+    // (16384 * 16384 pixels, 32768 per dimension: src/avif.c avifDimensionsTooLarge, include/avif/avif.h:88-95)
+    if (dstWidth > 32768u || dstHeight > 32768u || (uint64_t)dstWidth * dstHeight > (uint64_t)16384 * 16384)
+        return AVIF_RESULT_NOT_IMPLEMENTED;
     avifResult r = ensureContext();
     if (r != AVIF_RESULT_OK)
         return r;
@@ -296,9 +305,22 @@ extern "C" avifResult avifhipImageScale(avifImage * image, uint32_t dstWidth, ui
             (void)hipStreamSynchronize(tls.stream);
             return AVIF_RESULT_OUT_OF_MEMORY;
         }
-        HIP_TRY(hipMemcpy2DAsync(fresh[p], dd.w[p] * bps, base + dstOff[p], dstPitch[p], dd.w[p] * bps, dd.h[p], hipMemcpyDeviceToHost, tls.stream));
+        const hipError_t ce = hipMemcpy2DAsync(fresh[p], dd.w[p] * bps, base + dstOff[p], dstPitch[p], dd.w[p] * bps, dd.h[p], hipMemcpyDeviceToHost, tls.stream);
+        if (ce != hipSuccess) {
+            (void)hipStreamSynchronize(tls.stream);
+            for (int q = 0; q <= p; ++q)
+                free(fresh[q]);
+            return hipFailed(ce, "hipMemcpy2DAsync(scaled plane)");
+        }
     }
-    HIP_TRY(hipStreamSynchronize(tls.stream));
+    {
+        const hipError_t se = hipStreamSynchronize(tls.stream);
+        if (se != hipSuccess) {
+            for (int q = 0; q < 4; ++q)
+                free(fresh[q]);
+            return hipFailed(se, "hipStreamSynchronize(scaled planes)");
+        }
+    }
     for (int p = 0; p < 4; ++p) {
         if (!present[p])
             continue;

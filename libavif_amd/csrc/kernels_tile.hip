@@ -60,8 +60,10 @@ const char * kernelNameFor(const TileKey & k)
 {
     static thread_local char name[112];
     static const char * subs[] = { "444", "422", "420", "400" };
-    snprintf(name, sizeof(name), "%s<%s,%s,%s,%s%d%s%s>", k.fixedPoint ? "yuv2rgb_fixed_tile" : "yuv2rgb_tile", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
-             k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "");
+    // ",pk16": the packed 16-bit kernels (tile_pk_impl.h) serve 8-bit planes of the integer path unless a post-pass follows
+    const bool packed = k.fixedPoint && !k.wideYuv && !k.hasMul;
+    snprintf(name, sizeof(name), "%s<%s,%s,%s,%s%d%s%s%s>", k.fixedPoint ? "yuv2rgb_fixed_tile" : "yuv2rgb_tile", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
+             k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "", packed ? ",pk16" : "");
     return name;
 }
 
@@ -123,6 +125,15 @@ void decompose(uint32_t tuning, uint32_t w4, uint32_t h2, uint32_t jobs, bool ba
     L->stripsPerWave = ns;
     L->tilesPerRun = run;
     L->blocksPerJob = bands * ((tilesY + run - 1) / run);
+    // packed 16-bit integer kernels (tile_pk_impl.h) derive their own grid from these
+    L->maxW4 = w4, L->maxH2 = h2;
+    L->pkStrips = (tuning >> TUNE_STRIPS_SHIFT) & 0xfu;
+    const uint32_t wx = (tuning >> TUNE_WAVESX_SHIFT) & 3u;
+    // defaults from tests/tools/pk_sweep.py (profiles/r02_pk_sweep.txt): the four waves stacked (a 256 x 32 tile), one tile row per
+    // XCD chunk -- 28.8 us per 8K frame with 4 frames cycled, 36.0 with 12; raster order: 34.0 / 37.0
+    L->wavesXLog2 = wx ? wx - 1 : 0;
+    const uint32_t chunk = (tuning >> TUNE_CHUNK_SHIFT) & 0xfu;
+    L->chunkRows = (tuning & TUNE_XCD_BANDS) ? (chunk ? chunk : 1) : 0;
 }
 
 // largest byte offset the kernel forms from a plane base must fit 32 bits

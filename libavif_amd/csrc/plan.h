@@ -121,7 +121,10 @@ enum TuningBits : uint32_t {
     TUNE_NONTEMPORAL = 1u << 1,   // streaming (nt) stores for the RGB output
     TUNE_DEFAULT = TUNE_XCD_BANDS,
     TUNE_STRIPS_SHIFT = 8,        // bits 8..11: forced strips per wave (tile height / 8) of the tiled kernels, 0 = automatic
-    TUNE_RUN_SHIFT = 12           // bits 12..15: forced tiles per workgroup run, 0 = automatic
+    TUNE_RUN_SHIFT = 12,          // bits 12..15: forced tiles per workgroup run, 0 = automatic
+    // packed 16-bit integer kernels (tile_pk_impl.h): strips per wave from TUNE_STRIPS_SHIFT (2 or 4), and
+    TUNE_WAVESX_SHIFT = 16,       // bits 16..17: 1 + log2(waves of a workgroup side by side), 0 = automatic
+    TUNE_CHUNK_SHIFT = 20         // bits 20..23: tile rows per XCD chunk when TUNE_XCD_BANDS is set (0 = automatic), raster order otherwise
 };
 
 struct RgbToYuvPlan

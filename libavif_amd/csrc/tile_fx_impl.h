@@ -20,6 +20,7 @@
 
 #include "pixel_fixed.h"
 #include "tile_impl.h"
+#include "tile_pk_impl.h"
 
 namespace avifhip {
 namespace tile {
@@ -329,6 +330,9 @@ __global__ __launch_bounds__(256) void yuvToRgbTileFxBatchKernel(const TileArgs 
 template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool MUL>
 hipError_t launchOneFx(const TileLaunch & L)
 {
+    // 8-bit planes without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)
+    if constexpr (sizeof(YT) == 1 && !MUL)
+        return launchPk<SUB, BIL, NCH, APLANE>(L);
     const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(L.blocksPerJob, 1, L.count);
     if (L.table)

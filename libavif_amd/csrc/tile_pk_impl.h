@@ -1,0 +1,509 @@
+// tile_pk_impl.h -- the integer path's tiled YUV->RGB kernels for 8-bit planes and 8-bit RGB outputs, in wavefront-wide PACKED
+// 16-bit arithmetic (v_pk_mad_i16 / v_pk_ashrrev_i16 / v_sat_pk_u8_i16 / v_perm_b32), instantiated by kernels_tile_fx_inst.hip.
+// What it computes is libyuv's fixed point exactly (I420ToARGBMatrixFilter and its relatives as
+// src/reformat_libyuv.c:544-1108 dispatches them):
+//     y1 = ((y * 0x0101 * yg) >> 16) + yb;  b = clamp8((y1 + ub * (u - 128)) >> 6);  g = clamp8((y1 - (ug * (u - 128) + vg * (v - 128))) >> 6); ...
+// How it is arranged for gfx950:
+//   * work unit = one wave = 256 x (2 * NSW) pixels (NSW strips of two luma rows); a lane owns 4 consecutive pixels of every row:
+//     one dword load per plane and row, one 16-byte non-temporal store per row (1 KiB contiguous per wave instruction).  The four
+//     waves of a workgroup sit side by side (a 1024-pixel-wide tile) or stacked, and are independent of each other: NO workgroup
+//     barrier anywhere.  Every load of the wave's tile is issued before the first result is needed; occupancy (8 waves per
+//     SIMD) hides the rest;
+//   * workgroups take tiles in raster order (tests/tools/pattern_probe.hip: with frames streaming from HBM the chip moves cfg2's
+//     bytes 7-12% faster in raster order than in per-XCD bands), optionally in per-XCD chunks of a few tile rows;
+//   * bilinear chroma: the wave's chroma neighbourhood (NSW + 2 rows x 136 columns for 4:2:0) is staged in a wave-private LDS
+//     block as one word per column holding both planes, (u | v << 16) * 16 + 0x08080808.  The filter 9:3:3:1 runs on both planes
+//     at once with 32-bit shift-adds.  The constant carries libyuv's rounding (+8 per tap sum of 16) AND flips the top bit of
+//     the result byte: after the sum, byte 1 / byte 3 of a word hold (u' - 128) / (v' - 128) as signed bytes -- what the matrix
+//     wants.  Fields are allowed to wrap: the 32-bit sums are exact modulo 2^32, a carry out of the low field reaches only
+//     the fraction bits of the high field (its low byte is a multiple of 16, +1 never reaches byte 3);
+//   * matrix: pixels are processed as PAIRS, one 16-bit lane each.  v_perm_b32 with its sign-replicating selectors builds
+//     (u0 - 128 | u1 - 128) and (v0 - 128 | v1 - 128) from two filtered words; luma is one 24-bit multiply per pixel whose upper
+//     halves a v_perm_b32 pairs up; then X = mad(U, cX, Y) with saturation (y1 + 128 * 127 exceeds int16 for limited-range
+//     blue), Z = mad(V, cZ, Y), G = mad(V, -gHi, mad(U, -gLo, Y)); >> 6 per pair; v_sat_pk_u8_i16 clamps a pair to bytes;
+//     three v_perm_b32 interleave two pixels with their alpha.  9.5 VALU instructions per pixel for what took 18 as 32-bit
+//     scalar code (tile_fx_impl.h), all full rate;
+//   * libyuv's "YVU trick" (src/reformat_libyuv.c:386-423) is applied to the plane pointers (tile_shared.h): `u` feeds the
+//     first colour byte X.
+// Scope: 8-bit planes 4:4:4 / 4:2:2 / 4:2:0 / 4:0:0, nearest or bilinear, RGB / BGR / RGBA / BGRA / ARGB / ABGR, alpha opaque
+// or copied from the plane.  Deeper planes and the attenuate / unattenuate post-pass stay with tile_fx_impl.h.
+#pragma once
+
+#include "pixel_fixed.h"
+#include "tile_impl.h"
+
+namespace avifhip {
+namespace tile {
+
+constexpr int kPkPitch = 140;   // words per staged chroma row: entry c + 5 holds chroma column cxb + c, c in [-4, 131]
+constexpr int kPkGroups = 17;   // 8-column groups per staged row
+constexpr int kPkRowsPerRound = 3; // 3 x 17 = 51 of the wave's 64 lanes load 8 columns of both planes per round
+
+template <int SUB, int NSW>
+struct PkStage
+{
+    static constexpr int kRows = (SUB == SUB_420) ? NSW + 2 : 2 * NSW; // 4:2:2: one chroma row per luma row
+    static constexpr int kRounds = (kRows + kPkRowsPerRound - 1) / kPkRowsPerRound;
+    static constexpr unsigned kScale = (SUB == SUB_420) ? 16u : 64u;    // tap sums of 16 (9+3+3+1) / 4 (3+1), to 256
+    // per staged sample: rounding (weight sum / 2, scaled) + the top-bit flip (0x8000), divided by the weight sum
+    static constexpr unsigned kBias = (SUB == SUB_420) ? 0x08080808u : 0x20202020u;
+};
+
+// ---- packed 16-bit instructions (two pixels per instruction).  Operands named `k` are wave-uniform (kernel arguments or
+//      constants) and are read straight from scalar registers: one SGPR per VALU instruction is free ----
+__device__ __forceinline__ unsigned pkMad(unsigned a, unsigned k, unsigned c)
+{
+    unsigned d;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    return d;
+}
+// saturating: the exact a * k + c held to [-32768, 32767] per half (tests/tools/probe_pk.hip)
+__device__ __forceinline__ unsigned pkMadSat(unsigned a, unsigned k, unsigned c)
+{
+    unsigned d;
+    asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned pkAddK(unsigned a, unsigned k)
+{
+    unsigned d;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+    return d;
+}
+__device__ __forceinline__ unsigned pkSubK(unsigned a, unsigned k)
+{
+    unsigned d;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+    return d;
+}
+// arithmetic shift right of both halves by 6 (the inline constant's low half serves both)
+__device__ __forceinline__ unsigned pkAshr6(unsigned a)
+{
+    unsigned d;
+    asm("v_pk_ashrrev_i16 %0, 6, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(a));
+    return d;
+}
+// bits 0..15 = { clamp(lo, 0, 255), clamp(hi, 0, 255) }; bits 16..31 are not written (never read by the callers)
+__device__ __forceinline__ unsigned satPkU8(unsigned a)
+{
+    unsigned d;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(a));
+    return d;
+}
+// 3 * a on a packed word, as the shift-and-add instruction (from (a << 1) + a the compiler builds a quarter-rate 32-bit multiply)
+__device__ __forceinline__ unsigned pkTimes3(unsigned a)
+{
+    unsigned d;
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ unsigned add3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned d;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// Geometry of a launch (kernel argument, lives in SGPRs)
+struct PkGeom
+{
+    uint32_t wavesXLog2;  // waves of a workgroup side by side: 1 << wavesXLog2 in {1, 2, 4}
+    uint32_t tilesX, nTiles;
+    uint32_t magicTilesX; // ceil(2^32 / tilesX): tile / tilesX == mulhi(tile, magic) while tile * tilesX < 2^32; 0 when tilesX == 1
+    uint32_t chunk;       // tiles per XCD chunk (a few tile rows), 0 = plain raster order
+    uint32_t magicChunk;
+};
+
+__device__ __forceinline__ uint32_t pkTileOf(uint32_t b, const PkGeom & g)
+{
+    if (g.chunk == 0)
+        return b;
+    // workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it): XCD x takes the x-th chunk of every
+    // group of 8 chunks, so vertically adjacent tiles (which share chroma halo rows) mostly meet in one L2
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    const uint32_t sc = g.magicChunk ? __umulhi(slot, g.magicChunk) : slot, within = slot - sc * g.chunk;
+    return (sc * 8u + xcd) * g.chunk + within;
+}
+
+// ---- chroma neighbourhood: loads of one staging round (8 columns of both planes per lane) ----
+template <int SUB, int NSW>
+__device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int rowBase, int round, u2 & uD, u2 & vD)
+{
+    typedef PkStage<SUB, NSW> ST;
+    const int lane = threadIdx.x;
+    const int rr = (lane * 241) >> 12; // lane / 17
+    const int j = lane - rr * kPkGroups;
+    const int i = round * kPkRowsPerRound + rr;
+    uD = (u2) { 0, 0 };
+    vD = (u2) { 0, 0 };
+    if (rr < kPkRowsPerRound && i < ST::kRows) {
+        // coordinates clamp to the job's chroma window (the whole plane unless the canvas is a grid of separately stored tiles):
+        // the neighbour of an edge sample is the sample itself, which IS libyuv's edge rule ((3a + a + 2) >> 2 == a)
+        const int cy = clampI(rowBase + i, A.cyMin, A.cyMax);
+        const int cxa = cxb - 4 + 8 * j;
+        const uint32_t uRow = (uint32_t)cy * A.uPitch, vRow = (uint32_t)cy * A.vPitch;
+        if (cxa >= A.cxMin && cxa + 7 <= A.cxMax) {
+            uD = *reinterpret_cast<const u2 *>(A.u + (uRow + (uint32_t)cxa));
+            vD = *reinterpret_cast<const u2 *>(A.v + (vRow + (uint32_t)cxa));
+        } else {
+            // group cut by the left or right border of the window
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t cx = (uint32_t)clampI(cxa + k, A.cxMin, A.cxMax);
+                const unsigned u = A.u[uRow + cx], v = A.v[vRow + cx];
+                uD[k >> 2] |= u << (8 * (k & 3));
+                vD[k >> 2] |= v << (8 * (k & 3));
+            }
+        }
+    }
+}
+
+// ... and their conversion into staged words
+template <int SUB, int NSW>
+__device__ __forceinline__ void pkStageStore(int round, const u2 & uD, const u2 & vD, unsigned * ring)
+{
+    typedef PkStage<SUB, NSW> ST;
+    const int lane = threadIdx.x;
+    const int rr = (lane * 241) >> 12;
+    const int j = lane - rr * kPkGroups;
+    const int i = round * kPkRowsPerRound + rr;
+    if (rr < kPkRowsPerRound && i < ST::kRows) {
+        unsigned w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // (u_k | v_k << 16): bytes 0..3 of the selector address the second operand, 4..7 the first, 12 is zero
+            const unsigned p = __builtin_amdgcn_perm(vD[k >> 2], uD[k >> 2], 0x0c040c00u + (unsigned)(k & 3) * 0x00010001u);
+            w[k] = __umul24(p, ST::kScale) + ST::kBias;
+        }
+        unsigned * row = ring + i * kPkPitch + 8 * j; // entries 8j + 1 .. 8j + 8
+        row[1] = w[0];
+        *reinterpret_cast<u2 *>(row + 2) = (u2) { w[1], w[2] };
+        *reinterpret_cast<u2 *>(row + 4) = (u2) { w[3], w[4] };
+        *reinterpret_cast<u2 *>(row + 6) = (u2) { w[5], w[6] };
+        row[8] = w[7];
+    }
+}
+
+__device__ __forceinline__ void pkReadRow(const unsigned * ring, int q, unsigned m[4])
+{
+    const u2 * src = reinterpret_cast<const u2 *>(ring + q * kPkPitch + 2 * (int)threadIdx.x + 4); // columns 2tx-1 .. 2tx+2
+    const u2 lo = src[0], hi = src[1];
+    m[0] = lo.x, m[1] = lo.y, m[2] = hi.x, m[3] = hi.y;
+}
+
+// ---- one luma row of a lane: 4 pixels from their luma dword, (U, V) pairs and alpha dword ----
+// Up[p] / Vp[p]: (c0 - 128 | c1 - 128) as two int16 for pixel pair p.
+template <int SUB, int NCH, bool APLANE>
+__device__ __forceinline__ void pkRow(const TileArgs & A, unsigned yraw, unsigned araw, const unsigned Up[2], const unsigned Vp[2], uint32_t off, bool laneValid)
+{
+    const TileArgs::Fx & F = A.fx;
+    const unsigned k0 = __umul24(yraw & 0xffu, F.yMul8), k1 = __umul24((yraw >> 8) & 0xffu, F.yMul8);
+    const unsigned k2 = __umul24((yraw >> 16) & 0xffu, F.yMul8), k3 = __umul24(yraw >> 24, F.yMul8);
+    unsigned Y[2];
+    Y[0] = pkAddK(__builtin_amdgcn_perm(k1, k0, 0x07060302u), F.pkYb); // (y1 of pixel 0 | y1 of pixel 1)
+    Y[1] = pkAddK(__builtin_amdgcn_perm(k3, k2, 0x07060302u), F.pkYb);
+    unsigned px[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        unsigned X, G, Z;
+#ifdef AVIFHIP_ABLATE_MATRIX // measurement only (tests/tools/pkbench.hip): no matrix, no clamps
+        if constexpr (true) {
+            X = Up[p], G = Vp[p], Z = Y[p];
+        } else
+#endif
+        if constexpr (SUB == SUB_400) {
+            X = G = Z = satPkU8(pkAshr6(Y[p]));
+        } else {
+            X = pkMadSat(Up[p], F.pkCX, Y[p]);
+            Z = pkMadSat(Vp[p], F.pkCZ, Y[p]);
+            G = pkMad(Vp[p], F.pkGHi, pkMad(Up[p], F.pkGLo, Y[p]));
+            X = satPkU8(pkAshr6(X));
+            G = satPkU8(pkAshr6(G));
+            Z = satPkU8(pkAshr6(Z));
+        }
+        const unsigned XG = __builtin_amdgcn_perm(G, X, 0x05010400u); // x0 g0 x1 g1
+        unsigned ZA = Z;                                              // z0 z1 . .
+        if constexpr (APLANE)
+            ZA = __builtin_amdgcn_perm(araw, Z, p ? 0x07060100u : 0x05040100u); // z0 z1 a0 a1
+        px[2 * p] = __builtin_amdgcn_perm(ZA, XG, F.pkSel0);
+        px[2 * p + 1] = __builtin_amdgcn_perm(ZA, XG, F.pkSel1);
+    }
+    if (!laneValid)
+        return;
+    if constexpr (NCH == 4) {
+        storeVec(A.rgb, off, (u4) { px[0], px[1], px[2], px[3] }, true);
+    } else {
+        // pixels are (x g z .): 12 bytes x0 g0 z0 x1 | g1 z1 x2 g2 | z2 x3 g3 z3
+        typedef unsigned u3 __attribute__((ext_vector_type(3)));
+        const u3 w = { __builtin_amdgcn_perm(px[1], px[0], 0x04020100u), __builtin_amdgcn_perm(px[2], px[1], 0x05040201u),
+                       __builtin_amdgcn_perm(px[3], px[2], 0x06050402u) };
+        storeVec(A.rgb, off, w.x, true);
+        storeVec(A.rgb, off + 4, w.y, true);
+        storeVec(A.rgb, off + 8, w.z, true);
+    }
+}
+
+// (c0 - 128 | c1 - 128) from two filtered words (byte 1 = u - 128, byte 3 = v - 128 as signed bytes)
+__device__ __forceinline__ void pkPairsFromWords(const unsigned w[4], unsigned Up[2], unsigned Vp[2])
+{
+    // selectors 8..11 replicate the sign of byte 1 / 3 of the second / first operand
+    Up[0] = __builtin_amdgcn_perm(w[1], w[0], 0x0a050801u);
+    Vp[0] = __builtin_amdgcn_perm(w[1], w[0], 0x0b070903u);
+    Up[1] = __builtin_amdgcn_perm(w[3], w[2], 0x0a050801u);
+    Vp[1] = __builtin_amdgcn_perm(w[3], w[2], 0x0b070903u);
+}
+
+// Raw (undecoded) data of one wave tile (256 x 2*NSW pixels) as loaded by one lane; lives in registers while the previous tile
+// is computed.
+template <int SUB, bool BIL, bool APLANE, int NSW>
+struct PkRaw
+{
+    static constexpr bool kStaged = BIL && (SUB == SUB_420 || SUB == SUB_422);
+    static constexpr bool kOwnChroma = !kStaged && SUB != SUB_400;
+    u2 uD[kStaged ? PkStage<SUB, NSW>::kRounds : 1], vD[kStaged ? PkStage<SUB, NSW>::kRounds : 1]; // this lane's share of the neighbourhood
+    unsigned y[2 * NSW], a[APLANE ? 2 * NSW : 1];
+    unsigned u[kOwnChroma ? 2 * NSW : 1], v[kOwnChroma ? 2 * NSW : 1]; // 4:4:4: a dword per row | nearest: the lane's two samples
+};
+
+// where a wave works: band (256-pixel column) and first strip (pair of luma rows) of its tile
+struct PkSpot
+{
+    uint32_t band, strip0;
+};
+
+// ---- every load of a wave tile, longest dependency chain first ----
+template <int SUB, bool BIL, bool APLANE, int NSW>
+__device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkRaw<SUB, BIL, APLANE, NSW> & R)
+{
+    typedef PkRaw<SUB, BIL, APLANE, NSW> RawT;
+    typedef PkStage<SUB, NSW> ST;
+    const uint32_t bandX = w.band * (uint32_t)kBandW;
+    const uint32_t X = bandX + 4u * (uint32_t)threadIdx.x;
+    const uint32_t Xc = X < A.w4 ? X : 0u; // absent lanes load (and discard) the row's first group
+    const uint32_t strips = A.h2 >> 1;
+    if constexpr (RawT::kStaged) {
+        const int cxb = A.cx0 + (int)(bandX >> 1);
+        const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)w.strip0 - 1 : A.cy0 + 2 * (int)w.strip0;
+#pragma unroll
+        for (int t = 0; t < ST::kRounds; ++t)
+            pkStageLoad<SUB, NSW>(A, cxb, rowBase, t, R.uD[t], R.vD[t]);
+    }
+#pragma unroll
+    for (int s = 0; s < NSW; ++s) {
+        const uint32_t st = w.strip0 + (uint32_t)s;
+        const uint32_t sy = 2u * (st < strips ? st : strips - 1u); // absent strips load (and discard) the last one
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            R.y[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.y + ((sy + r) * A.yPitch + Xc));
+            if constexpr (APLANE)
+                R.a[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.a + ((sy + r) * A.aPitch + Xc));
+            if constexpr (SUB == SUB_444) {
+                R.u[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.u + (((uint32_t)A.cy0 + sy + r) * A.uPitch + ((uint32_t)A.cx0 + Xc)));
+                R.v[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.v + (((uint32_t)A.cy0 + sy + r) * A.vPitch + ((uint32_t)A.cx0 + Xc)));
+            } else if constexpr (RawT::kOwnChroma) {
+                // nearest: chroma samples (X >> 1, X >> 1 + 1) of the row's chroma row, one aligned pair per plane
+                if (!(SUB == SUB_420 && r == 1)) {
+                    const uint32_t cy = (uint32_t)A.cy0 + ((SUB == SUB_420) ? (sy >> 1) : (sy + r));
+                    const uint32_t cx = (uint32_t)A.cx0 + (Xc >> 1);
+                    R.u[2 * s + r] = *reinterpret_cast<const uint16_t *>(A.u + (cy * A.uPitch + cx));
+                    R.v[2 * s + r] = *reinterpret_cast<const uint16_t *>(A.v + (cy * A.vPitch + cx));
+                } else {
+                    R.u[2 * s + r] = R.v[2 * s + r] = 0;
+                }
+            }
+        }
+    }
+}
+
+// ---- the chroma neighbourhood into the wave's LDS block.  Wave-private: the LDS instructions of one wave execute in order;
+//      the fences keep the compiler from moving the reads above the writes ----
+template <int SUB, bool BIL, bool APLANE, int NSW>
+__device__ __forceinline__ void pkStage(const PkRaw<SUB, BIL, APLANE, NSW> & R, unsigned * ring)
+{
+    if constexpr (PkRaw<SUB, BIL, APLANE, NSW>::kStaged) {
+#pragma unroll
+        for (int t = 0; t < PkStage<SUB, NSW>::kRounds; ++t)
+            pkStageStore<SUB, NSW>(t, R.uD[t], R.vD[t], ring);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ---- filter, matrix, stores of a wave tile ----
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW>
+__device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW> & R, const unsigned * ring)
+{
+    constexpr bool kStaged = PkRaw<SUB, BIL, APLANE, NSW>::kStaged;
+    const uint32_t X = w.band * (uint32_t)kBandW + 4u * (uint32_t)threadIdx.x;
+    const bool laneValid = X < A.w4;
+    const uint32_t strips = A.h2 >> 1;
+    unsigned mA[4] = { 0, 0, 0, 0 }, mB[4] = { 0, 0, 0, 0 }, tA1 = 0, tA2 = 0, tB1 = 0, tB2 = 0;
+    if constexpr (kStaged && SUB == SUB_420) {
+        pkReadRow(ring, 0, mA);
+        pkReadRow(ring, 1, mB);
+        tA1 = pkTimes3(mA[1]), tA2 = pkTimes3(mA[2]);
+        tB1 = pkTimes3(mB[1]), tB2 = pkTimes3(mB[2]);
+    }
+#pragma unroll
+    for (int s = 0; s < NSW; ++s) {
+        const uint32_t st = w.strip0 + (uint32_t)s;
+        const bool stripValid = st < strips; // wave-uniform
+        const uint32_t sy = 2u * st;
+        unsigned Up[2][2], Vp[2][2]; // [luma row of the strip][pixel pair]
+        if constexpr (SUB == SUB_400) {
+            Up[0][0] = Up[0][1] = Up[1][0] = Up[1][1] = 0, Vp[0][0] = Vp[0][1] = Vp[1][0] = Vp[1][1] = 0;
+        } else if constexpr (kStaged && SUB == SUB_420) {
+            // Scale2RowUp_Bilinear: (9 near + 3 horizontal + 3 vertical + 1 diagonal + 8) >> 4; rows: A above, B co-sited, C below
+            unsigned mC[4];
+            pkReadRow(ring, s + 2, mC);
+            const unsigned tC1 = pkTimes3(mC[1]), tC2 = pkTimes3(mC[2]);
+#ifdef AVIFHIP_ABLATE_FILTER // measurement only: no filter arithmetic
+            pkPairsFromWords(mB, Up[0], Vp[0]);
+            pkPairsFromWords(mC, Up[1], Vp[1]);
+#else
+            const unsigned p1 = pkTimes3(tB1), p2 = pkTimes3(tB2); // 9 x
+            const unsigned a0 = pkTimes3(mB[0]) + p1, a1 = p1 + tB2, a2 = p2 + tB1, a3 = pkTimes3(mB[3]) + p2;
+            const unsigned we[4] = { add3(a0, tA1, mA[0]), add3(a1, tA1, mA[2]), add3(a2, tA2, mA[1]), add3(a3, tA2, mA[3]) }; // even row leans up
+            const unsigned wo[4] = { add3(a0, tC1, mC[0]), add3(a1, tC1, mC[2]), add3(a2, tC2, mC[1]), add3(a3, tC2, mC[3]) }; // odd row down
+            pkPairsFromWords(we, Up[0], Vp[0]);
+            pkPairsFromWords(wo, Up[1], Vp[1]);
+#endif
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                mA[k] = mB[k], mB[k] = mC[k];
+            tA1 = tB1, tA2 = tB2, tB1 = tC1, tB2 = tC2;
+        } else if constexpr (kStaged) { // 4:2:2, ScaleRowUp2_Linear: (3 near + far + 2) >> 2
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                unsigned m[4];
+                pkReadRow(ring, 2 * s + r, m);
+                const unsigned t1 = pkTimes3(m[1]), t2 = pkTimes3(m[2]);
+                const unsigned wd[4] = { t1 + m[0], t1 + m[2], t2 + m[1], t2 + m[3] };
+                pkPairsFromWords(wd, Up[r], Vp[r]);
+            }
+        } else if constexpr (SUB == SUB_444) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned u = R.u[2 * s + r], v = R.v[2 * s + r];
+                Up[r][0] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c010c00u), 0x00800080u);
+                Up[r][1] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c030c02u), 0x00800080u);
+                Vp[r][0] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c010c00u), 0x00800080u);
+                Vp[r][1] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c030c02u), 0x00800080u);
+            }
+        } else { // nearest 4:2:2 / 4:2:0: both pixels of a pair share their chroma sample
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (SUB == SUB_420 && r == 1) {
+                    Up[1][0] = Up[0][0], Up[1][1] = Up[0][1], Vp[1][0] = Vp[0][0], Vp[1][1] = Vp[0][1];
+                    break;
+                }
+                const unsigned u = R.u[2 * s + r], v = R.v[2 * s + r];
+                Up[r][0] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c000c00u), 0x00800080u);
+                Up[r][1] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c010c01u), 0x00800080u);
+                Vp[r][0] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c000c00u), 0x00800080u);
+                Vp[r][1] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c010c01u), 0x00800080u);
+            }
+        }
+        if (stripValid) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                pkRow<SUB, NCH, APLANE>(A, R.y[2 * s + r], APLANE ? R.a[2 * s + r] : 0u, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid);
+        }
+    }
+}
+
+// The waves of a workgroup are independent (no barrier anywhere): one wave, one tile of 256 x 2*NSW pixels, every load issued up
+// front.  One tile per wave and many short-lived workgroups is deliberate: a persistent variant (k x 256 workgroups walking over
+// their tiles with the next tile's loads in flight) measured 10-20% SLOWER on 8K frames, with frames streaming from HBM as well
+// as from the Infinity Cache (tests/tools/pk_sweep.py, profiles/r02_pk_sweep_persistent.txt) -- the dispatcher refilling 32 waves per CU in
+// tile order keeps the memory pipes fuller than a software pipeline one tile deep does.
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW>
+__device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g, unsigned * lds)
+{
+    typedef PkRaw<SUB, BIL, APLANE, NSW> RawT;
+    constexpr int kRingWords = RawT::kStaged ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
+    const uint32_t tile = pkTileOf(blockIdx.x, g);
+    if (tile >= g.nTiles)
+        return;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const uint32_t wx = wave & ((1u << g.wavesXLog2) - 1u), wy = wave >> g.wavesXLog2;
+    const uint32_t wavesY = 4u >> g.wavesXLog2;
+    const uint32_t trow = g.magicTilesX ? __umulhi(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
+    PkSpot w;
+    w.band = (tcol << g.wavesXLog2) + wx;
+    w.strip0 = (trow * wavesY + wy) * (uint32_t)NSW;
+    if (w.band * (uint32_t)kBandW >= A.w4 || 2u * w.strip0 >= A.h2)
+        return; // tiles at the right / bottom edge: a wave without work simply leaves
+    unsigned * ring = lds + wave * (uint32_t)kRingWords;
+    RawT raw;
+    pkLoad<SUB, BIL, APLANE, NSW>(A, w, raw);
+    pkStage<SUB, BIL, APLANE, NSW>(raw, ring);
+    pkCompute<SUB, BIL, NCH, APLANE, NSW>(A, w, raw, ring);
+}
+
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW>
+__global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g)
+{
+    constexpr int kRingWords = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
+    __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * kRingWords];
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW>(A, g, lds);
+}
+
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW>
+__global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
+{
+    constexpr int kRingWords = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
+    __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * kRingWords];
+    const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW>(job, g, lds);
+}
+
+// Launch geometry: strips per wave, waves side by side, tile order (TuningBits; tests/tools/geometry_sweep.py)
+inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t * nsw, PkGeom * g, uint32_t * blocks)
+{
+    const uint32_t bands = (w4 + (uint32_t)kBandW - 1) / (uint32_t)kBandW, strips = h2 / 2;
+    uint32_t ns = L.pkStrips; // 0 = automatic
+    if (ns != 2 && ns != 4)
+        ns = ((uint64_t)bands * ((strips + 3) / 4) * L.count >= 2048) ? 4 : 2; // small jobs: more, smaller waves
+    uint32_t wxl = L.wavesXLog2 <= 2 ? L.wavesXLog2 : 2;
+    while (wxl > 0 && (1u << wxl) > bands)
+        --wxl;
+    const uint32_t wavesX = 1u << wxl, wavesY = 4u / wavesX;
+    g->wavesXLog2 = wxl;
+    g->tilesX = (bands + wavesX - 1) / wavesX;
+    const uint32_t tilesY = (strips + ns * wavesY - 1) / (ns * wavesY);
+    g->nTiles = g->tilesX * tilesY;
+    auto magic = [](uint32_t d) { return d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0u; };
+    g->magicTilesX = magic(g->tilesX);
+    g->chunk = L.chunkRows * g->tilesX;
+    g->magicChunk = magic(g->chunk);
+    *nsw = ns;
+    // chunked order: padded to whole groups of 8 chunks (workgroups beyond the last tile leave at once)
+    *blocks = g->chunk ? ((g->nTiles + 8 * g->chunk - 1) / (8 * g->chunk)) * 8 * g->chunk : g->nTiles;
+}
+
+template <int SUB, bool BIL, int NCH, bool APLANE>
+hipError_t launchPk(const TileLaunch & L)
+{
+    uint32_t nsw, blocks;
+    PkGeom g;
+    pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
+    const dim3 block(kLanesX, kWavesPerBlock);
+    const dim3 grid(blocks, 1, L.count);
+    if (L.table) {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 4>), grid, block, 0, L.stream, L.table, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2>), grid, block, 0, L.stream, L.table, g);
+    } else {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4>), grid, block, 0, L.stream, *L.args, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2>), grid, block, 0, L.stream, *L.args, g);
+    }
+    return hipGetLastError();
+}
+
+} // namespace tile
+} // namespace avifhip

@@ -59,6 +59,12 @@ struct TileArgs
         uint32_t selXGm, selZAm; // the same for values already reduced to byte 0 (after attenuate / unattenuate)
         int32_t alphaMode;  // FxAlpha
         uint32_t alphaShift;
+        // packed 16-bit kernels (tile_pk_impl.h): both halves of a word hold the same int16 --
+        //   X = sat(pkCX * lo + y1), Z = sat(pkCZ * hi + y1), G = pkGHi * hi + (pkGLo * lo + y1), y1 = (y * yMul8 >> 16) + pkYb,
+        // lo / hi = upsampled chroma - 128 of the planes `u` / `v`; then >> 6 and a clamp to a byte
+        uint32_t pkYb, pkCX, pkCZ, pkGLo, pkGHi;
+        // v_perm_b32 selectors placing (x0 g0 x1 g1) [second operand] and (z0 z1 a0 a1) [first operand] into pixel 0 / pixel 1 of a pair
+        uint32_t pkSel0, pkSel1;
     } fx;
 };
 
@@ -137,6 +143,21 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
             A.fx.selZA = place(slotZ, 5, A.slotA, 0), A.fx.selZAm = place(slotZ, 4, A.slotA, 0);
         }
         A.fx.alphaMode = p.fxAlpha, A.fx.alphaShift = (uint32_t)p.fxAlphaShift;
+        auto splat16 = [](int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; };
+        A.fx.pkYb = splat16(m.yb);
+        A.fx.pkCX = splat16(A.fx.cX4 / 4), A.fx.pkCZ = splat16(A.fx.cZ4 / 4);
+        A.fx.pkGLo = splat16(-(A.fx.gLo4 / 4)), A.fx.pkGHi = splat16(-(A.fx.gHi4 / 4));
+        const bool planeAlpha = o.hasAlpha && p.alphaSource == ALPHA_PLANE;
+        // selector bytes: 0..3 = (x0 g0 x1 g1), 4..7 = (z0 z1 a0 a1), 12 = 0x00, 13 = 0xff
+        uint32_t sel0 = 0x0c0c0c0cu, sel1 = 0x0c0c0c0cu;
+        auto put = [](uint32_t sel, uint32_t slot, uint32_t v) { return (sel & ~(0xffu << (8 * slot))) | (v << (8 * slot)); };
+        sel0 = put(sel0, slotX, 0), sel1 = put(sel1, slotX, 2);
+        sel0 = put(sel0, A.slotG, 1), sel1 = put(sel1, A.slotG, 3);
+        sel0 = put(sel0, slotZ, 4), sel1 = put(sel1, slotZ, 5);
+        if (o.hasAlpha) {
+            sel0 = put(sel0, A.slotA, planeAlpha ? 6u : 0x0du), sel1 = put(sel1, A.slotA, planeAlpha ? 7u : 0x0du);
+        }
+        A.fx.pkSel0 = sel0, A.fx.pkSel1 = sel1;
     }
     return A;
 }
@@ -161,6 +182,11 @@ struct TileLaunch
     uint32_t blocksPerJob;  // workgroups covering the largest job: one per run of tiles
     uint32_t stripsPerWave; // NS: 1 or 2 vertically consecutive 256x2 strips per wave (tile = 256 x 8*NS pixels)
     uint32_t tilesPerRun;   // vertically consecutive tiles one workgroup walks through (software-pipelined)
+    // packed 16-bit kernels (tile_pk_impl.h): size of the largest job, and the tuning knobs (0 = automatic)
+    uint32_t maxW4, maxH2;
+    uint32_t pkStrips;      // strips (two luma rows) per wave: 2 or 4
+    uint32_t wavesXLog2;    // waves of a workgroup side by side (1 << n), the rest stacked
+    uint32_t chunkRows;     // tile rows per XCD chunk, 0 = plain raster order
     hipStream_t stream;
 };
 
