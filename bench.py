@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=STREAMS)
+    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
+                    help="cfg2 (default): 8K frames, one per step, frames sharded over the ranks (weak scaling); cfg5: ONE 15360x8640 canvas of 64 "
+                         "10-bit tiles per step, its tiles sharded over the ranks (strong scaling, BASELINE.json configs[4])")
     ap.add_argument("--arithmetic", choices=("integer", "fp32"), default="integer",
                     help="integer: API defaults, libyuv's fixed point (default); fp32: rgb.avoidLibYUV = 1, libavif's built-in path")
     return ap.parse_args()
@@ -192,6 +195,13 @@ def main():
     native.check(lib.avifhipSetDevice(local_rank if world > 1 else 0), "avifhipSetDevice")
     lib.avifhipSetArithmetic(0)  # AVIFHIP_ARITHMETIC_AUTO: follow rgb.avoidLibYUV like a libavif built with libyuv
     integer = args.arithmetic == "integer"
+    if args.workload == "cfg5":
+        out = run_cfg5(args, lib, rank, world, dist, torch)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     # ---- synthetic frames, resident in HBM before the timed region ----
     frames = []
@@ -229,25 +239,7 @@ def main():
         device_sync()
 
     # ---- the contract's timed region, `repeats` times ----
-    region_s = []
-    for _ in range(max(1, args.repeats)):
-        run(args.warmup)
-        device_sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-        t0 = time.perf_counter()
-        run(args.steps)
-        device_sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-            dist.barrier()
-        region_s.append(elapsed)
+    region_s = timed_regions(run, device_sync, args.steps, args.warmup, args.repeats, dist, torch)
     kernel_name = native.last_kernel()
     elapsed = median(region_s)
 
@@ -366,6 +358,131 @@ def main():
         lib.avifhipStreamDestroy(s)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def timed_regions(run_steps, sync, steps, warmup, repeats, dist, torch):
+    """The contract's timed region, `repeats` times: warm-up steps, barrier + sync, EXACTLY `steps` steps, sync, MAX over ranks."""
+    region_s = []
+    for _ in range(max(1, repeats)):
+        run_steps(warmup)
+        sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            dist.barrier()
+        region_s.append(elapsed)
+    return region_s
+
+
+def run_cfg5(args, lib, rank, world, dist, torch):
+    """BASELINE.json configs[4]: an 8 x 8 AVIF grid of 1920x1080 10-bit 4:2:0 tiles (one 15360x8640 canvas), YUV -> RGB with the API
+    defaults (RGBA at the image's depth: 10 bits in 16-bit containers, which libyuv declines -- the fp32 path), bilinear.  The tiles
+    are sharded over the ranks (contiguous blocks of the row-major tile list: whole tile rows; no collective): STRONG scaling of one canvas.  A step = one canvas.
+      value         : tiles and canvas resident in each rank's HBM, the rank's tiles converted by one batched launch
+      host_to_host  : the same canvas from and to HOST memory through avifhipImageYUVToRGBRects (each rank uploads only what
+                      its tiles need, downloads only its rectangles): the number an application sees, PCIe-bound"""
+    from libavif_amd import abi, device, farm, native, synth
+
+    W, H, TW, TH = 15360, 8640, 1920, 1080
+    rects = farm.grid_rects(W, H, TW, TH)
+    mine = farm.shard(len(rects), rank, world)
+    canvas = abi.make_yuv(W, H, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, abi.AVIF_MATRIX_COEFFICIENTS_BT709)
+    synth.fill_yuv(canvas, 0x12345678)  # the same decoded canvas on every rank
+    rgb_host = abi.make_rgb(W, H, 10, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, avoid_libyuv=False)
+    dimg = device.DeviceYUV(canvas)
+    drgb = device.DeviceRGB(rgb_host)
+    n = len(mine)
+    imgs = (C.POINTER(abi.avifImage) * max(n, 1))(*[C.pointer(dimg.struct)] * n)
+    rgbs = (C.POINTER(abi.avifRGBImage) * max(n, 1))(*[C.pointer(drgb.struct)] * n)
+    crops = (abi.avifCropRect * max(n, 1))(*[abi.avifCropRect(*rects[t]) for t in mine])
+    host_crops = (abi.avifCropRect * max(n, 1))(*[abi.avifCropRect(*rects[t]) for t in mine])
+
+    def run_device(steps):
+        for _ in range(steps):
+            if n:
+                native.check(lib.avifhipImageYUVToRGBBatchAsync(n, imgs, rgbs, crops, None), "avifhipImageYUVToRGBBatchAsync")
+
+    def sync():
+        native.check(lib.avifhipSynchronize(None), "avifhipSynchronize")
+
+    def run_host(steps):
+        for _ in range(steps):
+            if n:
+                native.check(lib.avifhipImageYUVToRGBRects(canvas.struct, rgb_host.struct, host_crops, n), "avifhipImageYUVToRGBRects")
+
+    t_heat = time.perf_counter()
+    while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
+        run_device(20)
+        sync()
+    steps = min(args.steps, 200)
+    warmup = min(args.warmup, 20)
+    region_s = timed_regions(run_device, sync, steps, warmup, args.repeats, dist, torch)
+    kernel_name = native.last_kernel()
+    elapsed = median(region_s)
+    host_steps = 3
+    host_s = timed_regions(run_host, lambda: None, host_steps, 1, max(3, args.repeats // 3), dist, torch)
+    host_elapsed = median(host_s)
+    up, down = C.c_uint64(0), C.c_uint64(0)
+    lib.avifhipLastTransferBytes(C.byref(up), C.byref(down))
+    mp = W * H / 1e6
+    alg_bytes_rank = 11.0 * sum(rects[t][2] * rects[t][3] for t in mine)  # 3 B in (10-bit 4:2:0) + 8 B out per pixel
+    ms_step = 1e3 * elapsed / steps
+    achieved = alg_bytes_rank / (ms_step * 1e-3) / 1e9 if n else 0.0
+    return {
+        "metric": "megapixels/sec YUV420->RGBA (8x8 grid of 1080p 10-bit tiles, one canvas sharded over the GPUs)",
+        "value": round(mp * steps / elapsed, 1),
+        "unit": "megapixels/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(ms_step, 5),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "value_basis": f"median of {len(region_s)} timed regions of {steps} canvases each (min {1e3 * min(region_s) / steps:.4f}, max {1e3 * max(region_s) / steps:.4f} "
+                       f"ms/canvas), MAX over ranks; canvas and pixels resident in every rank's HBM",
+        "config": {
+            "workload": "15360x8640 canvas = 8x8 grid of 1920x1080 10-bit YUV420 BT.709 limited tiles -> RGBA (10 bits in 16-bit containers, API defaults), bilinear, "
+                        f"contiguous blocks of tiles per rank ({n} on rank 0), one batched launch per rank and step",
+            "kernel": kernel_name,
+            "tiles_per_rank": [len(farm.shard(len(rects), r, world)) for r in range(world)],
+            "parallelism": f"tiles of one canvas sharded over {world} rank(s), no collective",
+            "preheat_ms": args.preheat_ms,
+            "repeats": len(region_s),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": int(alg_bytes_rank),
+            "kernel_ms": round(ms_step, 5),
+            "note": "rank 0's batched launch: its tiles' algorithmic bytes (11 B/pixel) over the step time (back-to-back launches, host clock)",
+        },
+        "host_to_host": {
+            "what": "the same canvas from HOST planes to HOST pixels through avifhipImageYUVToRGBRects, staging included; MAX over ranks",
+            "ms_per_canvas": round(1e3 * host_elapsed / host_steps, 3),
+            "megapixels_per_s": round(mp * host_steps / host_elapsed, 1),
+            "rank0_bytes_up": int(up.value),
+            "rank0_bytes_down": int(down.value),
+            "rank0_link_GBps": round((up.value + down.value) / (host_elapsed / host_steps) / 1e9, 1),
+        },
+        "cpu_baseline": None,
+    }
 
 
 def _cycle_args(frames):

@@ -59,6 +59,20 @@ AVIFHIP_API avifResult avifhipImageYUVToRGBColorOnly(const avifImage * image, av
 /* Replaces avifRGBImageToF16 / avifRGBImageToF16LibYUV (src/reformat.c:1419-1443): in-place uint16 -> IEEE half. */
 AVIFHIP_API avifResult avifhipRGBImageToF16(avifRGBImage * rgb);
 
+/* Rectangles of a HOST-resident canvas, converted into the same rectangles of a host-resident RGB canvas: what one rank of a
+ * tile farm does with its share of an AVIF grid (tiles stitched by src/read.c:1823-1877, then converted), or one band worker with
+ * its band.  Each rectangle equals the same rectangle of a whole-canvas avifImageYUVToRGB byte for byte (chroma edge rules are
+ * evaluated against the canvas, seams see their neighbours).  Only the plane samples the rectangles need cross the host link
+ * (their own plus the one-sample chroma halo of the bilinear filter), only the rectangles come back; uploads, kernels and
+ * downloads of successive rectangles overlap.  Rectangle origins must lie on the chroma grid (like avifImageSetViewRect,
+ * src/avif.c:335-337); pixels outside the rectangles are left untouched.  Synchronous. */
+AVIFHIP_API avifResult avifhipImageYUVToRGBRects(const avifImage * canvas, avifRGBImage * rgbCanvas, const avifCropRect * rects, uint32_t count);
+/* The bytes that call moves over the host link for these rectangles (needs no device): *bytesUp, *bytesDown. */
+AVIFHIP_API avifResult avifhipPlanRectTransfers(const avifImage * canvas, const avifRGBImage * rgbCanvas, const avifCropRect * rects, uint32_t count, uint64_t * bytesUp,
+                                                uint64_t * bytesDown);
+/* ... and what the calling thread's last avifhipImageYUVToRGBRects actually moved. */
+AVIFHIP_API void avifhipLastTransferBytes(uint64_t * bytesUp, uint64_t * bytesDown);
+
 /* ---- device-resident / asynchronous variants ------------------------------------------------- */
 
 /* Same conversions with every buffer already in device memory, enqueued on `hipStream`

@@ -230,7 +230,9 @@ AVIFHIP_STATIC_ASSERT(offsetof(avifImage, yuvRowBytes) == 48, "avifImage.yuvRowB
 AVIFHIP_STATIC_ASSERT(offsetof(avifImage, alphaPlane) == 64, "avifImage.alphaPlane");
 AVIFHIP_STATIC_ASSERT(offsetof(avifImage, alphaPremultiplied) == 80, "avifImage.alphaPremultiplied");
 AVIFHIP_STATIC_ASSERT(offsetof(avifImage, matrixCoefficients) == 108, "avifImage.matrixCoefficients");
+#ifdef AVIFHIP_ABI_MIRROR /* (members of the mirror only) */
 AVIFHIP_STATIC_ASSERT(offsetof(avifImage, avifhipOpaqueIcc_) == 88 && offsetof(avifImage, avifhipOpaqueTail_) == 110, "avifImage.icc / .clli");
+#endif
 
 
 /* ---- gain maps (avifRGBImageApplyGainMap, reference src/gainmap.c): boundary types, avif.h:236-250, :419-453, :582-610, :630-711 ---- */

@@ -11,6 +11,10 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "avifhip.h"
@@ -53,12 +57,56 @@ struct GainMapTableCache
     uint32_t maxCode = 0, nanCode = 0, stepEntries = 0;
 };
 
-// One context per calling thread: libavif's reformat functions are re-entrant and may be called
-// concurrently from up to 8 threads (src/reformat.c:1709-1735); nothing here is shared.
+// Copies between pageable host memory and the device run at full PCIe rate on this platform, but "asynchronous" ones block the
+// CALLING THREAD until they are done (tests/tools/pcie_probe.hip: hipMemcpyAsync from/to malloc'ed memory returns after the
+// whole transfer; two directions issued by one thread take the sum of their times, by two threads the maximum).  To use both
+// directions of the link at once, a host-resident call hands its downloads to this helper thread while its own thread keeps
+// uploading and launching.  One helper per context, started at the first banded call, parked on a condition variable between
+// calls.
+class CopyWorker
+{
+public:
+    struct Job
+    {
+        hipEvent_t after; // the copy may start once this event has completed
+        void * dst;
+        size_t dstPitch;
+        const void * src;
+        size_t srcPitch, widthBytes, rows;
+    };
+    CopyWorker(int device, hipStream_t stream);
+    ~CopyWorker();
+    void post(const Job & job);
+    hipError_t drain(); // blocks until every posted job is done; the first error since the last drain (hipSuccess if none)
+
+private:
+    void run();
+    int device_;
+    hipStream_t stream_;
+    std::mutex mutex_;
+    std::condition_variable wake_, idle_;
+    std::deque<Job> queue_;
+    int pending_ = 0;
+    bool stop_ = false;
+    hipError_t error_ = hipSuccess;
+    std::thread thread_;
+};
+
+// One context per calling thread at a time: libavif's reformat functions are re-entrant and may be called concurrently from up
+// to 8 threads (src/reformat.c:1709-1735); nothing here is shared between threads that run at the same time.  Contexts are
+// LEASED from a process-wide pool (currentContext()): libavif creates its worker threads anew for every call
+// (src/reformat.c:1625-1638), and a thread that ends hands its context -- streams, events, device scratch, pinned staging -- back
+// for the next one instead of destroying it.
 struct Context
 {
     int device = -1;
     hipStream_t stream = nullptr;
+    // host-resident calls split large images into row bands: uploads and downloads of different bands run on these two while
+    // `stream` computes (api.cpp: yuvToRgbSync)
+    hipStream_t upStream = nullptr, downStream = nullptr;
+    static constexpr int kMaxBands = 16;
+    hipEvent_t bandUp[kMaxBands] = {}, bandDone[kMaxBands] = {};
+    CopyWorker * downloader = nullptr; // issues the downloads of banded host-resident calls (created on first use)
     Scratch planes[4]; // Y, U, V, A staging
     Scratch pixels;    // interleaved RGB staging
     Scratch table;     // batch descriptor table (device)
@@ -82,6 +130,7 @@ struct Context
     char lastError[512] = { 0 };
     const char * lastKernel = "";
     uint64_t launches = 0; // kernels enqueued by this thread
+    uint64_t bytesUp = 0, bytesDown = 0; // host link traffic of the last avifhipImageYUVToRGBRects call
 
     ~Context()
     {
@@ -112,12 +161,25 @@ struct Context
             (void)hipEventDestroy(uploadCopied);
         if (scratchUsed)
             (void)hipEventDestroy(scratchUsed);
+        delete downloader;
+        for (int b = 0; b < kMaxBands; ++b) {
+            if (bandUp[b])
+                (void)hipEventDestroy(bandUp[b]);
+            if (bandDone[b])
+                (void)hipEventDestroy(bandDone[b]);
+        }
+        if (upStream)
+            (void)hipStreamDestroy(upStream);
+        if (downStream)
+            (void)hipStreamDestroy(downStream);
         if (stream)
             (void)hipStreamDestroy(stream);
     }
 };
 
-extern thread_local Context tls;
+// the calling thread's context (leased from the pool at the thread's first call, returned when the thread ends)
+Context & currentContext();
+#define tls (::avifhip::api::currentContext())
 extern std::atomic<int> gTiledKernels;
 
 void setError(const char * fmt, ...);

@@ -1,5 +1,5 @@
 """Tile farm: independent units of reformat work (tiles of an AVIF grid, frames of a sequence) spread over the GPUs of
-one node -- one process per GPU, unit t on rank t % world, NO data-path collective.
+one node -- one process per GPU, contiguous blocks of units per rank, NO data-path collective.
 
 Grid semantics (reference src/read.c:1823-1877 stitches decoded tiles into one canvas which the caller then converts
 as a whole): a tile job converts its rectangle of the stitched canvas with the chroma edge rules of
@@ -31,10 +31,15 @@ def grid_rects(canvas_w: int, canvas_h: int, tile_w: int, tile_h: int) -> List[R
 
 
 def shard(n_units: int, rank: int, world: int) -> List[int]:
-    """Units of this rank: round-robin, so that any prefix of the unit list is balanced."""
+    """Units of this rank: a contiguous, balanced block (sizes differ by at most one).  Contiguous because the tiles of a grid
+    are listed row by row: a rank's block is then whole tile rows (64 tiles on 8 ranks: one row each), which the library moves
+    between host and device as long full-width rows instead of many short ones ("contiguous blocks to keep host
+    staging sequential")."""
     if not 0 <= rank < world:
         raise ValueError("rank outside world")
-    return list(range(rank, n_units, world))
+    base, extra = divmod(n_units, world)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
 
 
 def validate_rects(rects: Iterable[Rect], yuv_format: int) -> None:
@@ -58,8 +63,10 @@ def convert_shard(canvas: abi.HostYUV, rgb_canvas: abi.HostRGB, rects: Sequence[
 
 
 class HipRectConverter:
-    """The product path: canvas planes resident in this rank's HBM, all of the rank's tiles in one batched launch
-    (avifhipImageYUVToRGBBatchAsync), results copied back into the host canvas rectangle by rectangle."""
+    """The product path: avifhipImageYUVToRGBRects -- the library uploads only what this rank's rectangles need (their plane
+    samples plus the one-sample chroma halo), converts them with the canvas's edge rules, and downloads only the rectangles
+    into the host canvas, uploads / kernels / downloads of successive rectangles overlapping.  `bytes_up` / `bytes_down` hold
+    what the last call moved over the host link."""
 
     def __init__(self):
         from . import device, native
@@ -70,18 +77,24 @@ class HipRectConverter:
             raise native.AvifHipError("HipRectConverter: no HIP device visible (there is no CPU fallback)")
 
     def __call__(self, canvas: abi.HostYUV, rgb_canvas: abi.HostRGB, rects: Sequence[Rect]) -> None:
-        dimg = self.device.DeviceYUV(canvas)
-        drgb = self.device.DeviceRGB(rgb_canvas, upload=True)
         n = len(rects)
-        imgs = (C.POINTER(abi.avifImage) * n)(*[C.pointer(dimg.struct)] * n)
-        rgbs = (C.POINTER(abi.avifRGBImage) * n)(*[C.pointer(drgb.struct)] * n)
         crops = (abi.avifCropRect * n)(*[abi.avifCropRect(x, y, w, h) for (x, y, w, h) in rects])
-        self.native.check(self.lib.avifhipImageYUVToRGBBatchAsync(n, imgs, rgbs, crops, None), "avifhipImageYUVToRGBBatchAsync")
-        self.native.check(self.lib.avifhipSynchronize(None), "avifhipSynchronize")
-        px = abi.rgb_pixel_size(rgb_canvas.struct.format, rgb_canvas.struct.depth)
-        raw = drgb.buffer.download(drgb.pitch * rgb_canvas.struct.height).reshape(rgb_canvas.struct.height, drgb.pitch)
-        for (x, y, w, h) in rects:
-            rgb_canvas.pixels[y:y + h, x * px:(x + w) * px] = raw[y:y + h, x * px:(x + w) * px]
+        self.native.check(self.lib.avifhipImageYUVToRGBRects(canvas.struct, rgb_canvas.struct, crops, n), "avifhipImageYUVToRGBRects")
+        up, down = C.c_uint64(0), C.c_uint64(0)
+        self.lib.avifhipLastTransferBytes(C.byref(up), C.byref(down))
+        self.bytes_up, self.bytes_down = int(up.value), int(down.value)
+
+
+def planned_transfers(canvas: abi.HostYUV, rgb_canvas: abi.HostRGB, rects: Sequence[Rect]) -> Tuple[int, int]:
+    """(bytes up, bytes down) avifhipImageYUVToRGBRects moves over the host link for these rectangles; needs no GPU."""
+    from . import native
+
+    lib = native.load()
+    n = len(rects)
+    crops = (abi.avifCropRect * n)(*[abi.avifCropRect(x, y, w, h) for (x, y, w, h) in rects])
+    up, down = C.c_uint64(0), C.c_uint64(0)
+    native.check(lib.avifhipPlanRectTransfers(canvas.struct, rgb_canvas.struct, crops, n, C.byref(up), C.byref(down)), "avifhipPlanRectTransfers")
+    return int(up.value), int(down.value)
 
 
 def timed_region(run: Callable[[], None], sync: Callable[[], None], dist=None) -> float:

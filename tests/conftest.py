@@ -15,6 +15,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_run(config) -> bool:
+    expr = config.getoption("-m") or ""
+    return "gpu" in expr and "not gpu" not in expr
+
+
+def pytest_sessionstart(session):
+    """`-m gpu` is the parity tier on the GPU box.  Its checkers are the prebuilt reference libraries under oracle/_ref (built here,
+    where /root/reference exists, shipped with the snapshot) and a GPU: if either is missing, dozens of tests would skip and the
+    run would still look green -- abort loudly instead."""
+    if not _gpu_run(session.config):
+        return
+    needed = ["oracle/liboracle.so", "oracle/_ref/libavif_ref.so", "oracle/_ref/libavif_hipbackend.so", "oracle/_ref/libavifutil_ref.so", "oracle/_ref/preload_probe",
+              "libavif_amd/csrc/libavifhip.so", "libavif_amd/csrc/libavifhip_preload.so"]
+    missing = [n for n in needed if not (ROOT / n).exists()]
+    if missing:
+        raise pytest.UsageError("GPU parity run without its checkers / native libraries: " + ", ".join(missing) +
+                                " -- run `python -c 'import __graft_entry__ as g; g.build()'` where /root/reference exists")
+    from libavif_amd import native
+
+    if native.load().avifhipDeviceCount() <= 0:
+        raise pytest.UsageError("`-m gpu` selected but no HIP device is visible: the HIP path is the only path, nothing would be tested")
+
+
 @pytest.fixture(scope="session")
 def hip():
     """The product library, with a GPU present (skips loudly otherwise; never falls back to CPU)."""

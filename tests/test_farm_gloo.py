@@ -58,6 +58,13 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         assert all(float(g.item()) == elapsed for g in gathered)
         np.save(os.path.join(out_dir, f"rgb_{rank}.npy"), rgb.pixels)
         np.save(os.path.join(out_dir, f"mine_{rank}.npy"), np.array(mine))
+        # what the PRODUCT converter (avifhipImageYUVToRGBRects) would move over this rank's host link for its tiles: planned on
+        # the host by the library itself (no GPU needed), summed over the ranks by a gloo all-reduce
+        up, down = farm.planned_transfers(canvas, rgb, [rects[t] for t in mine])
+        mine_t = torch.tensor([up, down], dtype=torch.int64)
+        total_t = mine_t.clone()
+        dist.all_reduce(total_t, op=dist.ReduceOp.SUM)
+        np.save(os.path.join(out_dir, f"bytes_{rank}.npy"), np.array([up, down, int(total_t[0]), int(total_t[1])]))
     finally:
         dist.destroy_process_group()
 
@@ -90,6 +97,16 @@ def test_two_ranks_farm_a_grid(tmp_path):
             else:
                 assert (tile == H.FILL_BYTE).all(), f"rank {r} wrote into tile {t} of another rank"
     assert np.array_equal(union[:, : case.w * px], whole[:, : case.w * px]), H.describe_diff(whole, union)
+    # host-link traffic of the product converter: every rank moves about 1/N of the canvas, not the whole of it
+    bytes_ = [np.load(tmp_path / f"bytes_{r}.npy").tolist() for r in range(world)]
+    canvas_in = case.w * case.h * 2 + 2 * ((case.w + 1) // 2) * ((case.h + 1) // 2) * 2  # 10-bit 4:2:0 planes
+    canvas_out = case.w * case.h * px
+    assert bytes_[0][2:] == bytes_[1][2:]  # the all-reduced totals
+    total_up, total_down = bytes_[0][2], bytes_[0][3]
+    assert total_down == canvas_out  # every pixel comes back exactly once
+    assert canvas_in <= total_up <= 1.35 * canvas_in  # every sample once, plus the one-sample chroma halo around 64 x 32 tiles
+    for up, down, _, _ in bytes_:
+        assert 0.35 * total_up <= up <= 0.65 * total_up and 0.35 * total_down <= down <= 0.65 * total_down, bytes_
 
 
 def test_shard_and_grid_helpers():

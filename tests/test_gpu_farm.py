@@ -42,6 +42,39 @@ def test_grid_farm_equals_whole_canvas(hip, world):
         assert np.array_equal(union.pixels[:, :wb], whole[:, :wb]), (case.ident(), native.last_kernel(), H.describe_diff(whole[:, :wb], union.pixels[:, :wb]))
 
 
+def test_farm_moves_only_its_share_over_the_host_link(hip):
+    """avifhipImageYUVToRGBRects uploads the rectangles' plane windows (+ chroma halo) and downloads the rectangles: per rank
+    ~1/N of the canvas, exactly what avifhipPlanRectTransfers announces."""
+    conv = farm.HipRectConverter()
+    case, (tw, th) = CASES[0]
+    canvas = H.make_y2r_inputs(case)
+    rects = farm.grid_rects(case.w, case.h, tw, th)
+    px = abi.rgb_pixel_size(case.rgb_format, case.rgb_depth)
+    world = 4
+    ups, downs = [], []
+    for rank in range(world):
+        out = H.make_y2r_output(case)
+        mine = farm.convert_shard(canvas, out, rects, rank, world, conv)
+        assert (conv.bytes_up, conv.bytes_down) == farm.planned_transfers(canvas, out, [rects[t] for t in mine])
+        ups.append(conv.bytes_up), downs.append(conv.bytes_down)
+    assert sum(downs) == case.w * case.h * px
+    canvas_in = case.w * case.h * 2 + 2 * ((case.w + 1) // 2) * ((case.h + 1) // 2) * 2
+    assert canvas_in <= sum(ups) <= 1.1 * canvas_in
+    assert max(ups) <= 0.45 * sum(ups)  # 9 tiles over 4 ranks: 3 + 2 + 2 + 2
+
+
+def test_rects_entry_point_error_codes(hip):
+    case, _ = CASES[0]
+    canvas = H.make_y2r_inputs(case)
+    out = H.make_y2r_output(case)
+    bad = (abi.avifCropRect * 1)(abi.avifCropRect(1, 0, 64, 32))  # x off the chroma grid
+    assert hip.avifhipImageYUVToRGBRects(canvas.struct, out.struct, bad, 1) != 0
+    outside = (abi.avifCropRect * 1)(abi.avifCropRect(case.w - 8, 0, 64, 32))
+    assert hip.avifhipImageYUVToRGBRects(canvas.struct, out.struct, outside, 1) != 0
+    assert (out.pixels == H.FILL_BYTE).all()
+    assert hip.avifhipImageYUVToRGBRects(canvas.struct, out.struct, None, 0) == 0
+
+
 def test_rect_entry_point_matches_oracle_rect(hip):
     o = oracle_lib.oracle()
     for case, _ in CASES:

@@ -31,7 +31,9 @@ SIZES = [(300, 21), (512, 16), (37, 21), (1027, 18)]
 @pytest.fixture(scope="module")
 def libs(hip):
     if not BACKEND_SO.exists() or oracle_lib.ref() is None:
-        pytest.skip("oracle/_ref/libavif_hipbackend.so or libavif_ref.so not built (needs /root/reference at build time)")
+        # these are GPU tests: the prebuilt reference libraries travel to the GPU box with the snapshot (oracle/_ref is not in
+        # .gpurunignore); a run without them must not report green
+        pytest.fail("oracle/_ref/libavif_hipbackend.so or libavif_ref.so is missing: build them where /root/reference exists (make -C oracle ref) and ship them")
     os.environ["AVIFHIP_MIN_PIXELS"] = "0"  # tiny test images must take the GPU route too
     be = oracle_lib._bind_libavif(C.CDLL(os.fspath(BACKEND_SO), mode=os.RTLD_LOCAL))
     assert be.avifLibYUVVersion() == 9500

@@ -50,9 +50,10 @@ def test_interposer_forwards_when_it_declines(tmp_path):
     assert got == want
 
 
-@needs_probe
 @pytest.mark.gpu
 def test_interposer_serves_the_calls_from_the_gpu(hip, tmp_path):
+    # a GPU test: the prebuilt probe travels with the snapshot; its absence must fail, not skip
+    assert PROBE.exists() and PRELOAD.exists(), "oracle/_ref/preload_probe or libavifhip_preload.so is missing: build them where /root/reference exists"
     _, want = _run(tmp_path, "plain.bin", preload=False)
     got_r, got = _run(tmp_path, "gpu.bin", preload=True, extra_env={"AVIFHIP_MIN_PIXELS": "0"})
     assert got_r[:3] == [0, 0, 0]

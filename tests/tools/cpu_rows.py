@@ -51,6 +51,31 @@ def main():
         t = best_of(lambda: pil.avifImageYUVToRGB(img.struct, rgb.struct), 5)
         rows.append({"config": "cfg2", "implementation": "libavif 1.4.1 + libyuv 1922 (Pillow's binary), default path", "maxThreads": 1, "ms": round(t * 1e3, 1),
                      "megapixels_per_s": round(mp / t, 1)})
+    # cfg1 / cfg3 / cfg4: one thread, maxThreads = 8 (cfg3's 4:4:4 path does use them; RGB->YUV has no threading), libyuv build
+    def y2r_rows(cfg, w, h, depth, fmt, rng, mc, rgb_depth, up, alpha=False, premult=False, reps=5):
+        im = abi.make_yuv(w, h, depth, fmt, rng, mc, with_alpha=alpha)
+        synth.fill_yuv(im, 0x12345678)
+        mpx = w * h / 1e6
+        for lib_, name_, avoid, thr in ((ref, "reference from source, built-in fp32 path", True, 1), (ref, "reference from source, built-in fp32 path", True, 8),
+                                        (pil, "libavif 1.4.1 + libyuv 1922 (Pillow's binary), default path", False, 1)):
+            if lib_ is None:
+                continue
+            out = abi.make_rgb(w, h, rgb_depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=up, avoid_libyuv=avoid, alpha_premultiplied=premult, max_threads=thr)
+            t = best_of(lambda: lib_.avifImageYUVToRGB(im.struct, out.struct), reps)
+            rows.append({"config": cfg, "implementation": name_, "maxThreads": thr, "ms": round(t * 1e3, 3), "megapixels_per_s": round(mpx / t, 1)})
+
+    y2r_rows("cfg1", 256, 256, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_FULL, 6, 8, abi.AVIF_CHROMA_UPSAMPLING_AUTOMATIC, reps=20)
+    y2r_rows("cfg3", 7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, abi.AVIF_CHROMA_UPSAMPLING_AUTOMATIC, alpha=True, premult=True, reps=3)
+    for lib_, name_, avoid in ((ref, "reference from source, built-in fp32 path", True), (pil, "libavif 1.4.1 + libyuv 1922 (Pillow's binary), default path (libyuv is BT.601-only: "
+                                                                                        "BT.709 runs the built-in path)", False)):
+        if lib_ is None:
+            continue
+        src = abi.make_rgb(3840, 2160, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=avoid)
+        synth.fill_rgb(src, 0xCAFEBABE, opaque=True)
+        dst = abi.make_yuv(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, with_alpha=True)
+        t = best_of(lambda: lib_.avifImageRGBToYUV(dst.struct, src.struct), 5)
+        rows.append({"config": "cfg4", "implementation": name_, "maxThreads": 1, "ms": round(t * 1e3, 2), "megapixels_per_s": round(3840 * 2160 / 1e6 / t, 1),
+                     "note": "avifImageRGBToYUV has no threading (src/reformat.c:221-571)"})
     # cfg5: 64 tiles over a pool of host threads
     lib, name = (ref, "reference from source, built-in fp32 path") if ref is not None else (pil, "Pillow's libavif")
     if lib is not None:
