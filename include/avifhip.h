@@ -251,6 +251,18 @@ AVIFHIP_API avifhipArithmetic avifhipGetArithmetic(void);
  * 1 (default) lets the bandwidth-tuned tiled kernels take the configurations they cover. */
 AVIFHIP_API void avifhipSetTiledKernels(int enabled);
 
+/* ---- row packing for the file writers next to the path (device-resident, asynchronous) -------- */
+
+/* The payload of a Y4M frame as y4mWrite emits it (apps/shared/y4m.c:603-618): planes Y, U, V (and A when `withAlpha`: 8-bit 4:4:4
+ * only, like the reference), every row cut to its width, 16-bit samples little-endian as stored.  `frame`: device memory of
+ * avifhipY4MFrameBytes(image, withAlpha) bytes.  The header line is the application's. */
+AVIFHIP_API size_t avifhipY4MFrameBytes(const avifImage * image, avifBool withAlpha);
+AVIFHIP_API avifResult avifhipImagePackY4MFrameAsync(const avifImage * image, avifBool withAlpha, uint8_t * frame, void * hipStream);
+/* The row data avifPNGWrite hands to libpng (apps/shared/avifpng.c:865-880) in the byte order of the PNG stream: pixel rows
+ * without padding (width * pixel bytes each), 16-bit samples swapped to big-endian -- png_set_swap done on the device, so the
+ * application calls png_write_image on these rows WITHOUT png_set_swap.  `rows`: device memory of height * width * pixel bytes. */
+AVIFHIP_API avifResult avifhipRGBImagePackPNGRowsAsync(const avifRGBImage * rgb, uint8_t * rows, void * hipStream);
+
 /* Diagnostics/A-B measurements: bit mask of result-preserving performance knobs (plan.h TuningBits:
  * bit0 XCD-banded tile order, bit1 non-temporal RGB stores). Default: bit0. */
 AVIFHIP_API void avifhipSetTuning(uint32_t bits);

@@ -1546,6 +1546,87 @@ extern "C" int avifhipDeviceCount(void)
     return count;
 }
 
+// =================================================================================================
+// row packing for the file writers: Y4M frame payload, PNG rows
+// =================================================================================================
+
+extern "C" size_t avifhipY4MFrameBytes(const avifImage * image, avifBool withAlpha)
+{
+    if (!image)
+        return 0;
+    const PlaneGeometry g = planeGeometry(image);
+    size_t total = 0;
+    for (int p = 0; p < 4; ++p) {
+        if ((p == 3 && !withAlpha) || ((p == 1 || p == 2) && image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400))
+            continue;
+        const uint8_t * plane = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
+        if (plane)
+            total += (size_t)g.widthBytes[p] * g.rows[p];
+    }
+    return total;
+}
+
+// y4mWrite's payload loop, apps/shared/y4m.c:603-618: planes Y..V (..A), each row cut to its width
+extern "C" avifResult avifhipImagePackY4MFrameAsync(const avifImage * image, avifBool withAlpha, uint8_t * frame, void * hipStream)
+{
+    if (!image || !frame || !image->yuvPlanes[0])
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if (image->depth != 8 && image->depth != 10 && image->depth != 12)
+        return AVIF_RESULT_NOT_IMPLEMENTED; // "y4mWrite unsupported depth", y4m.c:570-572
+    if (withAlpha && (!image->alphaPlane || !image->alphaRowBytes || image->depth != 8 || image->yuvFormat != AVIF_PIXEL_FORMAT_YUV444))
+        return AVIF_RESULT_NOT_IMPLEMENTED; // "writing alpha is currently only supported in 8bpc YUV444", y4m.c:487-489
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    hipStream_t stream = pickStream(hipStream);
+    const PlaneGeometry g = planeGeometry(image);
+    size_t offset = 0;
+    for (int p = 0; p < 4; ++p) {
+        if ((p == 3 && !withAlpha) || ((p == 1 || p == 2) && image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400))
+            continue;
+        const uint8_t * plane = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
+        if (!plane)
+            continue;
+        PackArgs A;
+        A.src = plane, A.dst = frame + offset;
+        A.srcPitch = (p < 3) ? image->yuvRowBytes[p] : image->alphaRowBytes;
+        A.dstPitch = A.widthBytes = g.widthBytes[p];
+        A.rows = g.rows[p];
+        A.swap16 = 0; // Y4M stores 16-bit samples little-endian, as libavif does
+        const hipError_t e = launchPackRows(A, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "row packing kernel launch");
+        offset += (size_t)A.widthBytes * A.rows;
+    }
+    tls.lastKernel = "pack_rows";
+    ++tls.launches;
+    return AVIF_RESULT_OK;
+}
+
+// what avifPNGWrite hands to libpng, apps/shared/avifpng.c:865-880: the pixel rows, and png_set_swap for depths above 8
+extern "C" avifResult avifhipRGBImagePackPNGRowsAsync(const avifRGBImage * rgb, uint8_t * rows, void * hipStream)
+{
+    if (!rgb || !rgb->pixels || !rows || !rgb->width || !rgb->height)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    if (rgb->format == AVIF_RGB_FORMAT_RGB_565 || rgb->isFloat)
+        return AVIF_RESULT_NOT_IMPLEMENTED; // the PNG writer asks for 8- or 16-bit integer RGB(A) / gray, avifpng.c:640-690
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    PackArgs A;
+    A.src = rgb->pixels, A.dst = rows;
+    A.srcPitch = rgb->rowBytes;
+    A.dstPitch = A.widthBytes = rgb->width * rgbPixelBytes(rgb);
+    A.rows = rgb->height;
+    A.swap16 = rgb->depth > 8;
+    const hipError_t e = launchPackRows(A, pickStream(hipStream));
+    if (e != hipSuccess)
+        return hipFailed(e, "row packing kernel launch");
+    tls.lastKernel = "pack_rows";
+    ++tls.launches;
+    return AVIF_RESULT_OK;
+}
+
 extern "C" avifResult avifhipSetDevice(int device)
 {
     if (tls.stream && tls.device != device) {
@@ -1674,7 +1755,11 @@ extern "C" avifResult avifhipCopyToHost(void * hostPtr, const void * devicePtr, 
 }
 extern "C" avifResult avifhipDeviceMemset(void * devicePtr, int value, size_t bytes)
 {
+    // hipMemset on device memory returns before the fill has run (it is enqueued on the null stream), and the library's own
+    // streams are non-blocking, i.e. NOT ordered behind the null stream: complete the fill here, as the name of a plain helper
+    // promises (tests/test_pack.py caught a kernel's output being overwritten by a late fill)
     HIP_TRY(hipMemset(devicePtr, value, bytes));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return AVIF_RESULT_OK;
 }
 

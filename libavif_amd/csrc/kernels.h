@@ -63,6 +63,18 @@ struct TransformArgs
 };
 hipError_t launchRgbTransform(const TransformArgs & args, uint32_t pixelBytes, hipStream_t stream);
 
+// row packing for the Y4M / PNG writers (kernels_pack.hip): rows of `widthBytes` bytes from a pitched source into a destination
+// whose pitch is widthBytes (a byte stream) or, for the 16-byte fast path, any multiple of 16
+struct PackArgs
+{
+    const uint8_t * src;
+    uint8_t * dst;
+    uint32_t srcPitch, dstPitch;
+    uint32_t widthBytes, rows;
+    int32_t swap16; // swap the bytes of every 16-bit sample (little-endian -> big-endian)
+};
+hipError_t launchPackRows(const PackArgs & args, hipStream_t stream);
+
 // plane scaling (kernels_scale.hip): schedule tables live in device memory, modes as in scale_plan.h
 enum { SCALE_POINT_MODE = 0, SCALE_DOWN_MODE = 1, SCALE_UP_MODE = 2, SCALE_BOX_MODE = 3, SCALE_UP2_MODE = 4 };
 struct ScaleArgs

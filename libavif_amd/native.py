@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
-    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
+    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
     "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap",
 ]
@@ -96,6 +96,9 @@ def load() -> C.CDLL:
         "avifhipRGBImageToF16": (i32, [P_RGB]),
         "avifhipLaunchCount": (C.c_uint64, []),
         "avifhipTimeYUVToRGBCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
+        "avifhipY4MFrameBytes": (C.c_size_t, [P_IMG, i32]),
+        "avifhipImagePackY4MFrameAsync": (i32, [P_IMG, i32, vp, vp]),
+        "avifhipRGBImagePackPNGRowsAsync": (i32, [P_RGB, vp, vp]),
         "avifhipImageYUVToRGBRects": (i32, [P_IMG, P_RGB, P_RECT, u32]),
         "avifhipPlanRectTransfers": (i32, [P_IMG, P_RGB, P_RECT, u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "avifhipLastTransferBytes": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

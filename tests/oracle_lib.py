@@ -26,7 +26,7 @@ _cache: dict = {}
 
 def _ensure_built() -> None:
     so = ORACLE_DIR / "liboracle.so"
-    srcs = [ORACLE_DIR / "reformat_oracle.c", ORACLE_DIR / "libyuv_oracle.c", ORACLE_DIR / "scale_oracle.c", ORACLE_DIR / "gainmap_oracle.c",
+    srcs = [ORACLE_DIR / "reformat_oracle.c", ORACLE_DIR / "libyuv_oracle.c", ORACLE_DIR / "scale_oracle.c", ORACLE_DIR / "gainmap_oracle.c", ORACLE_DIR / "pack_oracle.c",
             ORACLE_DIR / "reformat_oracle.h", ORACLE_DIR / "oracle_backend.h"]
     if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", os.fspath(ORACLE_DIR), "liboracle.so"], check=True, capture_output=True)
@@ -60,6 +60,8 @@ def oracle() -> C.CDLL:
                                                    C.POINTER(avifContentLightLevelInformationBox), C.c_int]
         lib.oracleRGBImageComputeGainMap.restype = C.c_int
         lib.oracleRGBImageComputeGainMap.argtypes = [_P_RGB, C.c_uint16, C.c_uint16, _P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_int]
+        lib.oraclePackY4MFrame.restype, lib.oraclePackY4MFrame.argtypes = C.c_size_t, [_P_IMG, C.c_int, C.c_void_p]
+        lib.oraclePackPNGRows.restype, lib.oraclePackPNGRows.argtypes = C.c_size_t, [_P_RGB, C.c_uint32, C.c_void_p]
         lib.oracleTransferFunction.restype, lib.oracleTransferFunction.argtypes = C.c_float, [C.c_int, C.c_int, C.c_float]
         lib.oracleColorPrimariesComputeRGBToRGBMatrix.restype = C.c_int
         lib.oracleColorPrimariesComputeRGBToRGBMatrix.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double * 9)]
@@ -116,6 +118,8 @@ def util_ref():
             lib.avifRGBImageSetViewRect.restype, lib.avifRGBImageSetViewRect.argtypes = None, [_P_RGB, _P_RGB, _P_RECT]
             lib.avifRGBImageRotate.restype, lib.avifRGBImageRotate.argtypes = C.c_int, [_P_RGB, _P_RGB, C.POINTER(C.c_uint8)]
             lib.avifRGBImageMirror.restype, lib.avifRGBImageMirror.argtypes = C.c_int, [_P_RGB, C.POINTER(C.c_uint8)]
+            if hasattr(lib, "y4mWrite"):  # apps/shared/y4m.c, in the same library since round 2
+                lib.y4mWrite.restype, lib.y4mWrite.argtypes = C.c_int, [C.c_char_p, _P_IMG]
         _cache["util_ref"] = lib
     return _cache["util_ref"]
 
