@@ -251,6 +251,22 @@ AVIFHIP_API avifhipArithmetic avifhipGetArithmetic(void);
  * 1 (default) lets the bandwidth-tuned tiled kernels take the configurations they cover. */
 AVIFHIP_API void avifhipSetTiledKernels(int enabled);
 
+/* ---- the decode-side tail in one step (device-resident, asynchronous) ------------------------ */
+
+/* YUV -> RGB with the application's transforms fused in: `rgb` receives what avifApplyTransforms (apps/shared/avifutil.c:787-825:
+ * clean-aperture crop, avifRGBImageRotate by `angle` quarter turns anti-clockwise, avifRGBImageMirror about `axis`) makes of the
+ * converted canvas -- byte for byte avifImageYUVToRGB followed by avifhipRGBImageTransformAsync, without the canvas-sized RGB
+ * image in between.  `rgb` has the TRANSFORMED size (crop size, swapped for quarter turns) and carries the conversion
+ * parameters (format, depth, chromaUpsampling, avoidLibYUV ...).  One launch where the tiled kernels store through the pixel
+ * map (the integer path's 8-bit kernels); two passes through per-thread scratch elsewhere. */
+AVIFHIP_API avifResult avifhipImageYUVToRGBTransformedAsync(const avifImage * image, avifRGBImage * rgb, const avifCropRect * crop, avifBool rotate, uint8_t angle,
+                                                            avifBool mirror, uint8_t axis, void * hipStream);
+/* The same for a grid of separately stored tiles (avifhipGridYUVToRGBAsync): tile -> canvas, limited -> full alpha, YUV -> RGB and
+ * the transforms, straight from the tiles into the final image. */
+AVIFHIP_API avifResult avifhipGridYUVToRGBTransformedAsync(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
+                                                           avifBool alphaIsLimitedRange, avifRGBImage * rgb, const avifCropRect * crop, avifBool rotate, uint8_t angle,
+                                                           avifBool mirror, uint8_t axis, void * hipStream);
+
 /* ---- row packing for the file writers next to the path (device-resident, asynchronous) -------- */
 
 /* The payload of a Y4M frame as y4mWrite emits it (apps/shared/y4m.c:603-618): planes Y, U, V (and A when `withAlpha`: 8-bit 4:4:4

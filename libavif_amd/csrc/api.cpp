@@ -847,7 +847,7 @@ struct JobOverride
 } // namespace
 
 static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects,
-                                 const JobOverride * overrides, void * hipStream)
+                                 const JobOverride * overrides, void * hipStream, const PixelMap * map = nullptr)
 {
     if (count == 0)
         return AVIF_RESULT_OK;
@@ -884,6 +884,8 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         const avifResult pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plansA[k]);
         if (pr != AVIF_RESULT_OK)
             return pr;
+        if (map)
+            plansA[k].rgb.map = *map; // fused crop / rotate / mirror: every job stores through the canvas's map
         if (overrides) {
             plansA[k].cwinX0 = overrides[k].window[0], plansA[k].cwinX1 = overrides[k].window[1];
             plansA[k].cwinY0 = overrides[k].window[2], plansA[k].cwinY1 = overrides[k].window[3];
@@ -954,8 +956,8 @@ extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
 // Grid canvases: tiles converted where they lie (a batch of rectangle jobs over "virtual canvases" whose plane pointers are
 // shifted so that canvas coordinates address the tile's own memory, each confined to its own chroma samples), then the
 // pixels next to interior seams redone with samples fetched from both sides (kernels_generic.hip: GridReader).
-extern "C" avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
-                                               avifBool alphaIsLimitedRange, avifRGBImage * rgbCanvas, void * hipStream)
+static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles, avifBool alphaIsLimitedRange,
+                                   avifRGBImage * rgbCanvas, void * hipStream, const PixelMap * map)
 {
     if (!grid || !colorTiles || !rgbCanvas || !grid->rows || !grid->columns || !grid->outputWidth || !grid->outputHeight)
         return AVIF_RESULT_INVALID_ARGUMENT;
@@ -1027,7 +1029,7 @@ extern "C" avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid, const a
         o.window[2] = (int32_t)(Y0 >> sy), o.window[3] = (int32_t)((Y0 >> sy) + ((r.height + sy) >> sy) - 1);
         o.alphaLimited = atile && alphaIsLimitedRange;
     }
-    avifResult r = batchAsyncImpl(count, viewPtrs.data(), rgbPtrs.data(), rects.data(), overrides.data(), hipStream);
+    avifResult r = batchAsyncImpl(count, viewPtrs.data(), rgbPtrs.data(), rects.data(), overrides.data(), hipStream, map);
     if (r != AVIF_RESULT_OK)
         return r;
     if (count == 1)
@@ -1038,6 +1040,8 @@ extern "C" avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid, const a
     if (r != AVIF_RESULT_OK)
         return r;
     canvasPlan.yuv.alphaLimited = (alphaTiles && alphaIsLimitedRange) ? 1 : 0;
+    if (map)
+        canvasPlan.rgb.map = *map;
     const bool filters = canvasPlan.bilinear && canvasPlan.yuv.hasColor && subsampled;
     if (!filters)
         return AVIF_RESULT_OK;
@@ -1059,6 +1063,132 @@ extern "C" avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid, const a
         return hipFailed(e, "grid seam kernel launch");
     ++tls.launches;
     return AVIF_RESULT_OK;
+}
+
+extern "C" avifResult avifhipGridYUVToRGBAsync(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
+                                               avifBool alphaIsLimitedRange, avifRGBImage * rgbCanvas, void * hipStream)
+{
+    return gridYuvToRgbImpl(grid, colorTiles, alphaTiles, alphaIsLimitedRange, rgbCanvas, hipStream, nullptr);
+}
+
+// ---- the decode-side tail in one step: tiles -> canvas (src/read.c:1823-1877), limited -> full alpha
+//      (:6724-6764), YUV -> RGB, and the application's avifApplyTransforms (apps/shared/avifutil.c:787-825) ----
+namespace {
+// validates crop / angle / axis like avifhipRGBImageTransformAsync and derives the destination size
+avifResult transformGeometry(uint32_t canvasW, uint32_t canvasH, const avifCropRect * crop, avifBool rotate, uint8_t angle, avifBool mirror, uint8_t axis, avifCropRect * r,
+                             int * quarterTurns, int * mirrorAxis, uint32_t * dw, uint32_t * dh)
+{
+    if ((rotate && angle > 3) || (mirror && axis > 1))
+        return AVIF_RESULT_INVALID_ARGUMENT; // "Invalid angle." / "Invalid axis value.", apps/shared/avifutil.c:741,781
+    const avifCropRect whole = { 0, 0, canvasW, canvasH };
+    *r = crop ? *crop : whole;
+    if (!r->width || !r->height || r->width > canvasW || r->height > canvasH || r->x > canvasW - r->width || r->y > canvasH - r->height)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    *quarterTurns = (rotate && angle != 0) ? angle : 0; // :805
+    *mirrorAxis = mirror ? (int)axis : -1;
+    *dw = (*quarterTurns & 1) ? r->height : r->width, *dh = (*quarterTurns & 1) ? r->width : r->height; // :692-693
+    return AVIF_RESULT_OK;
+}
+
+// conversion parameters of `out` on a canvas-sized buffer
+avifRGBImage canvasLike(const avifRGBImage * out, uint32_t w, uint32_t h, uint8_t * pixels, uint32_t rowBytes)
+{
+    avifRGBImage v = *out;
+    v.width = w, v.height = h, v.pixels = pixels, v.rowBytes = rowBytes;
+    return v;
+}
+} // namespace
+
+extern "C" avifResult avifhipGridYUVToRGBTransformedAsync(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
+                                                          avifBool alphaIsLimitedRange, avifRGBImage * rgb, const avifCropRect * crop, avifBool rotate, uint8_t angle,
+                                                          avifBool mirror, uint8_t axis, void * hipStream)
+{
+    if (!grid || !colorTiles || !colorTiles[0] || !rgb || !rgb->pixels)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    avifCropRect r;
+    int turns, mirrorAxis;
+    uint32_t dw, dh;
+    const avifResult gr = transformGeometry(grid->outputWidth, grid->outputHeight, crop, rotate, angle, mirror, axis, &r, &turns, &mirrorAxis, &dw, &dh);
+    if (gr != AVIF_RESULT_OK)
+        return gr;
+    const uint32_t px = rgbPixelBytes(rgb);
+    if (rgb->width != dw || rgb->height != dh || (uint64_t)rgb->rowBytes < (uint64_t)dw * px)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    // Fused when the conversion's tiled kernels can store through a map (today: the packed 16-bit integer kernels); otherwise
+    // two passes: conversion into a canvas-sized scratch buffer, then the permutation pass of avifhipRGBImageTransformAsync
+    const PixelMap map = makePixelMap(r.x, r.y, r.width, r.height, turns, mirrorAxis);
+    avifImage probeImage;
+    memcpy(&probeImage, colorTiles[0], sizeof(avifImage));
+    if (alphaTiles && alphaTiles[0])
+        probeImage.alphaPlane = alphaTiles[0]->alphaPlane, probeImage.alphaRowBytes = alphaTiles[0]->alphaRowBytes;
+    avifRGBImage probeRgb = canvasLike(rgb, probeImage.width, probeImage.height, rgb->pixels, rgb->rowBytes);
+    YuvToRgbPlan probe;
+    const avifResult pr = makeYuvToRgbPlan(&probeImage, &probeRgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &probe);
+    if (pr != AVIF_RESULT_OK)
+        return pr;
+    probe.rgb.map = map;
+    probe.yuv.alphaLimited = (alphaTiles && alphaIsLimitedRange) ? 1 : 0;
+    const bool fused = gTiledKernels.load(std::memory_order_relaxed) && tileYuvToRgbSupported(probe);
+    if (fused) {
+        avifRGBImage canvasRgb = canvasLike(rgb, grid->outputWidth, grid->outputHeight, rgb->pixels, rgb->rowBytes);
+        return gridYuvToRgbImpl(grid, colorTiles, alphaTiles, alphaIsLimitedRange, &canvasRgb, hipStream, &map);
+    }
+    hipStream_t stream = pickStream(hipStream);
+    ScratchScope scratch(stream);
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
+    const uint32_t pitch = alignUp(grid->outputWidth * px, 256);
+    const avifResult rr = reserve(tls.xformCanvas, (size_t)pitch * grid->outputHeight);
+    if (rr != AVIF_RESULT_OK)
+        return rr;
+    avifRGBImage canvasRgb = canvasLike(rgb, grid->outputWidth, grid->outputHeight, (uint8_t *)tls.xformCanvas.ptr, pitch);
+    const avifResult g1 = gridYuvToRgbImpl(grid, colorTiles, alphaTiles, alphaIsLimitedRange, &canvasRgb, stream, nullptr);
+    if (g1 != AVIF_RESULT_OK)
+        return g1;
+    return avifhipRGBImageTransformAsync(rgb, &canvasRgb, &r, rotate, angle, mirror, axis, stream);
+}
+
+extern "C" avifResult avifhipImageYUVToRGBTransformedAsync(const avifImage * image, avifRGBImage * rgb, const avifCropRect * crop, avifBool rotate, uint8_t angle,
+                                                           avifBool mirror, uint8_t axis, void * hipStream)
+{
+    if (!image || !rgb || !rgb->pixels)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    avifCropRect r;
+    int turns, mirrorAxis;
+    uint32_t dw, dh;
+    const avifResult gr = transformGeometry(image->width, image->height, crop, rotate, angle, mirror, axis, &r, &turns, &mirrorAxis, &dw, &dh);
+    if (gr != AVIF_RESULT_OK)
+        return gr;
+    const uint32_t px = rgbPixelBytes(rgb);
+    if (rgb->width != dw || rgb->height != dh || (uint64_t)rgb->rowBytes < (uint64_t)dw * px)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    avifRGBImage canvasRgb = canvasLike(rgb, image->width, image->height, rgb->pixels, rgb->rowBytes);
+    YuvToRgbPlan plan;
+    const avifResult pr = makeYuvToRgbPlan(image, &canvasRgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan);
+    if (pr != AVIF_RESULT_OK)
+        return pr;
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    hipStream_t stream = pickStream(hipStream);
+    plan.rgb.map = makePixelMap(r.x, r.y, r.width, r.height, turns, mirrorAxis);
+    if (gTiledKernels.load(std::memory_order_relaxed) && tileYuvToRgbSupported(plan))
+        return enqueueYuvToRgb(plan, stream); // one launch (plus the universal kernel on the <= 3 columns / 1 row of leftovers)
+    ScratchScope scratch(stream);
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
+    const uint32_t pitch = alignUp(image->width * px, 256);
+    const avifResult rr = reserve(tls.xformCanvas, (size_t)pitch * image->height);
+    if (rr != AVIF_RESULT_OK)
+        return rr;
+    canvasRgb.pixels = (uint8_t *)tls.xformCanvas.ptr, canvasRgb.rowBytes = pitch;
+    const avifResult c1 = avifhipImageYUVToRGBAsync(image, &canvasRgb, stream);
+    if (c1 != AVIF_RESULT_OK)
+        return c1;
+    return avifhipRGBImageTransformAsync(rgb, &canvasRgb, &r, rotate, angle, mirror, axis, stream);
 }
 
 // =================================================================================================

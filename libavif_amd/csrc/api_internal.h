@@ -114,6 +114,7 @@ struct Context
     Scratch scaleTable; // schedules of a plane scale (device)
     ScaleTableCache scaleCache; // ... and which geometry they belong to
     Scratch satoTable;  // input plane tables of a sample transform (device)
+    Scratch xformCanvas; // canvas-sized RGB of the two-pass route of avifhip*TransformedAsync (device)
     Scratch gainMap[11]; // gain maps: [0] output pixels, [1] gain map as RGB, [2] tables, [3] statistics / partials, [4] scaled planes, [5] base pixels;
                          // computation: [6] tables, [7] ratios, [8] histograms, [9] alternate pixels, [10] gain-map planes
     GainMapTableCache gainMapCache; // what gainMap[2] holds
@@ -148,6 +149,8 @@ struct Context
             (void)hipFree(scaleTable.ptr);
         if (satoTable.ptr)
             (void)hipFree(satoTable.ptr);
+        if (xformCanvas.ptr)
+            (void)hipFree(xformCanvas.ptr);
         for (Scratch & g : gainMap)
             if (g.ptr)
                 (void)hipFree(g.ptr);

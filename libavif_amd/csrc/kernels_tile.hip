@@ -48,6 +48,7 @@ TileKey keyFor(const YuvToRgbPlan & p)
     k.nch = p.rgb.hasAlpha ? 4 : 3;
     k.hasMul = (p.inLoopMul != MUL_NONE) || (p.postMul != MUL_NONE);
     k.alphaPlane = k.nch == 4 && p.alphaSource == ALPHA_PLANE;
+    k.mapped = p.rgb.map.on != 0;
     return k;
 }
 
@@ -62,8 +63,8 @@ const char * kernelNameFor(const TileKey & k)
     static const char * subs[] = { "444", "422", "420", "400" };
     // ",pk16": the packed 16-bit kernels (tile_pk_impl.h) serve 8-bit planes of the integer path unless a post-pass follows
     const bool packed = k.fixedPoint && !k.wideYuv && !k.hasMul;
-    snprintf(name, sizeof(name), "%s<%s,%s,%s,%s%d%s%s%s>", k.fixedPoint ? "yuv2rgb_fixed_tile" : "yuv2rgb_tile", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
-             k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "", packed ? ",pk16" : "");
+    snprintf(name, sizeof(name), "%s<%s,%s,%s,%s%d%s%s%s%s>", k.fixedPoint ? "yuv2rgb_fixed_tile" : "yuv2rgb_tile", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
+             k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "", packed ? ",pk16" : "", k.mapped ? ",mapped" : "");
     return name;
 }
 
@@ -164,8 +165,16 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
     }
     if (o.isGray || o.is565 || o.isFloat)
         return false;
-    if (s.alphaLimited)
-        return false; // limited-range alpha planes (pre-1.0 files, src/read.c:6818-6828): the universal kernel converts them
+    if (o.map.on) {
+        // fused crop / rotate / mirror: the packed 16-bit kernels store through the map; every other family leaves it to the
+        // universal kernel (the entry points convert into scratch and run the transform pass instead: api.cpp)
+        const bool packed = p.arith == ARITH_LIBYUV && s.chanBytes == 1 && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE;
+        if (!packed || (o.pixBytes != 4 && o.pixBytes != 3))
+            return false;
+        if (((uintptr_t)o.pixels % 4) != 0 || (o.rowBytes % 4) != 0)
+            return false;
+    }
+    // (limited-range alpha planes, pre-1.0 files, src/read.c:6818-6828: converted sample by sample inside the tiled kernels)
     if (o.hasAlpha && p.alphaSource == ALPHA_KEEP)
         return false; // destination alpha bytes must stay untouched: per-channel stores only
     if (p.w < 64 || p.h < 2)
@@ -184,11 +193,11 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
     if (p.postMul != MUL_NONE && p.alphaSource != ALPHA_PLANE)
         return false;
     const int nch = o.hasAlpha ? 4 : 3;
-    const uint32_t storeAlign = (nch == 4) ? 16u : (o.chanBytes == 1 ? 4u : 8u);
+    const uint32_t storeAlign = o.map.on ? 1u : ((nch == 4) ? 16u : (o.chanBytes == 1 ? 4u : 8u));
     if (!aligned(o.pixels, o.rowBytes, storeAlign))
         return false;
     // 32-bit lane offsets from the plane bases
-    if (!fits32(p.canvasH, s.rowBytes[0]) || !fits32(p.canvasH, o.rowBytes) || (s.hasColor && (!fits32(p.canvasH, s.rowBytes[1]) || !fits32(p.canvasH, s.rowBytes[2]))) ||
+    if (!fits32(p.canvasH, s.rowBytes[0]) || !fits32(o.map.on ? (o.map.transposed ? o.map.cw : o.map.ch) : p.canvasH, o.rowBytes) || (s.hasColor && (!fits32(p.canvasH, s.rowBytes[1]) || !fits32(p.canvasH, s.rowBytes[2]))) ||
         (readsAlpha && !fits32(p.canvasH, s.alphaRowBytes)))
         return false;
     return true;
@@ -200,7 +209,7 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
         return -1;
     const TileKey k = keyFor(plan);
     return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) |
-           ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7) | ((k.fixedPoint ? 1 : 0) << 8);
+           ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7) | ((k.fixedPoint ? 1 : 0) << 8) | ((k.mapped ? 1 : 0) << 9);
 }
 
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)
@@ -214,6 +223,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     L.table = nullptr;
     L.count = 1;
     L.stream = stream;
+    L.mapped = k.mapped;
     decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
     hipError_t e = launchFamily(k, L);
     if (e != hipSuccess)
@@ -258,6 +268,7 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
     L.table = static_cast<const TileArgs *>(deviceTileTable);
     L.count = count;
     L.stream = stream;
+    L.mapped = k.mapped;
     decompose(representative.tuning, maxW & ~3u, maxH & ~1u, count, true, &L);
     return launchFamily(k, L);
 }

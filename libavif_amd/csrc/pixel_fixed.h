@@ -109,7 +109,9 @@ __device__ inline void yuvToRgbPixelFixedT(const YuvToRgbPlan & p, const Reader 
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
-    uint8_t * dst = o.pixels + (size_t)j * o.rowBytes + (size_t)i * o.pixBytes;
+    uint8_t * dst = rgbPixelAddress(o, i, j);
+    if (!dst)
+        return; // outside the fused crop
 
     const int y = fxReduceSample(rd.y(i, j), p.fxDownshift);
     int u = 128, v = 128;

@@ -19,7 +19,9 @@ __device__ inline void yuvToRgbPixelT(const YuvToRgbPlan & p, const Reader & rd,
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
-    uint8_t * dst = o.pixels + (size_t)j * o.rowBytes + (size_t)i * o.pixBytes;
+    uint8_t * dst = rgbPixelAddress(o, i, j);
+    if (!dst)
+        return; // outside the fused crop
 
     unsigned r = 0, g = 0, b = 0, gray = 0;
 

@@ -191,4 +191,17 @@ __device__ __forceinline__ int quantizeUV(float v, const YuvSide & s)
     return clampInt(q, 0, s.maxv);
 }
 
+// address of canvas pixel (i, j) in the destination buffer, nullptr when the fused crop drops it (plan.h PixelMap)
+__device__ __forceinline__ uint8_t * rgbPixelAddress(const RgbSide & o, uint32_t i, uint32_t j)
+{
+    if (!o.map.on)
+        return o.pixels + (size_t)j * o.rowBytes + (size_t)i * o.pixBytes;
+    const uint32_t ii = i - o.map.cx, jj = j - o.map.cy;
+    if (ii >= o.map.cw || jj >= o.map.ch)
+        return nullptr;
+    const int32_t a = (int32_t)(o.map.transposed ? jj : ii), b = (int32_t)(o.map.transposed ? ii : jj);
+    const uint32_t x = (uint32_t)(o.map.sx * a + o.map.kx), y = (uint32_t)(o.map.sy * b + o.map.ky);
+    return o.pixels + (size_t)y * o.rowBytes + (size_t)x * o.pixBytes;
+}
+
 } // namespace avifhip

@@ -30,6 +30,38 @@ struct RcpHL
     float hi, lo;
 };
 
+// Where a converted canvas pixel goes when the decode-side transforms are fused into the conversion (SURVEY.md 8f rank 1:
+// avifApplyTransforms, apps/shared/avifutil.c:787-825 = clean-aperture crop as a view, avifRGBImageRotate :687-741,
+// avifRGBImageMirror :745-785, in that order).  Canvas pixel (i, j) with ii = i - cx < cw, jj = j - cy < ch lands at
+//     (x, y) = (sx * ii + kx, sy * jj + ky)            rows stay rows      (no rotation / half turn)
+//     (x, y) = (sx * jj + kx, sy * ii + ky)            rows become columns (quarter turns)
+// of the destination buffer (`pixels`, `rowBytes` of the RgbSide); pixels outside the crop are dropped.
+struct PixelMap
+{
+    int32_t on;
+    int32_t transposed;
+    int32_t sx, sy, kx, ky;
+    uint32_t cx, cy, cw, ch;
+};
+inline PixelMap makePixelMap(uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, int angle, int mirror /* -1 none, 0 top<->bottom, 1 left<->right */)
+{
+    PixelMap m;
+    m.on = 1, m.cx = cx, m.cy = cy, m.cw = cw, m.ch = ch;
+    m.transposed = angle & 1;
+    switch (angle & 3) { // anti-clockwise quarter turns: source (ii, jj) -> (jj, cw-1-ii) -> (cw-1-ii, ch-1-jj) -> (ch-1-jj, ii)
+        case 1: m.sx = 1, m.kx = 0, m.sy = -1, m.ky = (int32_t)cw - 1; break;
+        case 2: m.sx = -1, m.kx = (int32_t)cw - 1, m.sy = -1, m.ky = (int32_t)ch - 1; break;
+        case 3: m.sx = -1, m.kx = (int32_t)ch - 1, m.sy = 1, m.ky = 0; break;
+        default: m.sx = 1, m.kx = 0, m.sy = 1, m.ky = 0; break;
+    }
+    const int32_t dw = (int32_t)((angle & 1) ? ch : cw), dh = (int32_t)((angle & 1) ? cw : ch);
+    if (mirror == 1)
+        m.sx = -m.sx, m.kx = dw - 1 - m.kx;
+    else if (mirror == 0)
+        m.sy = -m.sy, m.ky = dh - 1 - m.ky;
+    return m;
+}
+
 // Interleaved-pixel side (avifRGBColorSpaceInfo, include/avif/internal.h:297-309)
 struct RgbSide
 {
@@ -44,6 +76,7 @@ struct RgbSide
     float maxf;
     float f16Multiplier; // src/reformat.c:1411,1429-1430
     RcpHL rcpMax;        // 1 / maxf (premultiply, src/alpha.c:189)
+    PixelMap map;        // fused crop / rotate / mirror (off unless the caller asks: avifhip*TransformedAsync)
 };
 
 // Planar side (avifYUVColorSpaceInfo, include/avif/internal.h:314-331)

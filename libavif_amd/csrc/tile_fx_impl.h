@@ -196,8 +196,14 @@ __device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx 
         for (int r = 0; r < 2; ++r) {
             unsigned yv[4], av[4] = { 0, 0, 0, 0 };
             decode4<YT>(raw[k].y[r], yv);
-            if constexpr (kNeedA)
+            if constexpr (kNeedA) {
                 decode4<YT>(raw[k].a[r], av);
+                if (A.alphaLim.on) { // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        av[i] = alphaToFullRange(A, av[i]);
+                }
+            }
             unsigned X4[4], G4[4], Z4[4], a[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

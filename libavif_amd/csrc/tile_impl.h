@@ -136,6 +136,14 @@ struct PixelOut
     unsigned r, g, b;
 };
 
+// a limited-range alpha sample as full range (TileArgs::AlphaLimited)
+__device__ __forceinline__ unsigned alphaToFullRange(const TileArgs & A, unsigned v)
+{
+    const int n = ((int)v - A.alphaLim.lo) * A.alphaLim.full + A.alphaLim.half;
+    const unsigned q = __umulhi((unsigned)max(n, 0), A.alphaLim.magic) >> A.alphaLim.shift; // a negative n truncates to <= 0 and clamps to 0
+    return minU(q, (unsigned)A.alphaLim.full);
+}
+
 // alpha at the RGB depth from a plane sample: copy or depth rescale (src/alpha.c:84-103, verified reciprocal form)
 __device__ __forceinline__ unsigned alphaFromPlane(const TileArgs & A, unsigned sa)
 {
@@ -615,8 +623,14 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
             }
 
             unsigned av[4] = { 0, 0, 0, 0 }, a[4];
-            if constexpr (kNeedA)
+            if constexpr (kNeedA) {
                 decode4<YT>(raw[k].a[r], av);
+                if (A.alphaLim.on) { // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        av[i] = alphaToFullRange(A, av[i]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 a[i] = APLANE ? alphaFromPlane(A, av[i]) : A.rgbMax;

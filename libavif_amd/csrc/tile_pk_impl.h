@@ -193,8 +193,10 @@ __device__ __forceinline__ void pkReadRow(const unsigned * ring, int q, unsigned
 
 // ---- one luma row of a lane: 4 pixels from their luma dword, (U, V) pairs and alpha dword ----
 // Up[p] / Vp[p]: (c0 - 128 | c1 - 128) as two int16 for pixel pair p.
-template <int SUB, int NCH, bool APLANE>
-__device__ __forceinline__ void pkRow(const TileArgs & A, unsigned yraw, unsigned araw, const unsigned Up[2], const unsigned Vp[2], uint32_t off, bool laneValid)
+// MAPPED: the four pixel words are handed back in `out` instead of being stored (the caller stores them through the PixelMap).
+template <int SUB, int NCH, bool APLANE, bool MAPPED>
+__device__ __forceinline__ void pkRow(const TileArgs & A, unsigned yraw, unsigned araw, const unsigned Up[2], const unsigned Vp[2], uint32_t off, bool laneValid,
+                                      unsigned out[4])
 {
     const TileArgs::Fx & F = A.fx;
     const unsigned k0 = __umul24(yraw & 0xffu, F.yMul8), k1 = __umul24((yraw >> 8) & 0xffu, F.yMul8);
@@ -202,6 +204,13 @@ __device__ __forceinline__ void pkRow(const TileArgs & A, unsigned yraw, unsigne
     unsigned Y[2];
     Y[0] = pkAddK(__builtin_amdgcn_perm(k1, k0, 0x07060302u), F.pkYb); // (y1 of pixel 0 | y1 of pixel 1)
     Y[1] = pkAddK(__builtin_amdgcn_perm(k3, k2, 0x07060302u), F.pkYb);
+    if constexpr (APLANE) {
+        if (A.alphaLim.on) { // limited-range alpha plane (wave-uniform): the four bytes to full range
+            const unsigned a0 = alphaToFullRange(A, araw & 0xffu), a1 = alphaToFullRange(A, (araw >> 8) & 0xffu);
+            const unsigned a2 = alphaToFullRange(A, (araw >> 16) & 0xffu), a3 = alphaToFullRange(A, araw >> 24);
+            araw = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+        }
+    }
     unsigned px[4];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -227,6 +236,10 @@ __device__ __forceinline__ void pkRow(const TileArgs & A, unsigned yraw, unsigne
             ZA = __builtin_amdgcn_perm(araw, Z, p ? 0x07060100u : 0x05040100u); // z0 z1 a0 a1
         px[2 * p] = __builtin_amdgcn_perm(ZA, XG, F.pkSel0);
         px[2 * p + 1] = __builtin_amdgcn_perm(ZA, XG, F.pkSel1);
+    }
+    if constexpr (MAPPED) {
+        out[0] = px[0], out[1] = px[1], out[2] = px[2], out[3] = px[3];
+        return;
     }
     if (!laneValid)
         return;
@@ -330,11 +343,84 @@ __device__ __forceinline__ void pkStage(const PkRaw<SUB, BIL, APLANE, NSW> & R, 
     }
 }
 
+// ---- stores through a PixelMap (fused crop / rotate / mirror).  A pixel word holds (x g z a) or (x g z .) ----
+typedef unsigned u4a4 __attribute__((ext_vector_type(4), aligned(4))); // 16-byte accesses at dword alignment (crops start anywhere)
+
+template <int NCH>
+__device__ __forceinline__ void pkStorePixel(uint8_t * dst, unsigned px)
+{
+    if constexpr (NCH == 4) {
+        *reinterpret_cast<unsigned *>(dst) = px;
+    } else {
+        dst[0] = (uint8_t)px, dst[1] = (uint8_t)(px >> 8), dst[2] = (uint8_t)(px >> 16);
+    }
+}
+
+// rows stay rows: the lane's four pixels of canvas row j, first at canvas column i
+template <int NCH>
+__device__ __forceinline__ void pkStoreMappedRow(const TileArgs & A, const unsigned px[4], uint32_t i, uint32_t j)
+{
+    const PixelMap & m = A.map;
+    const uint32_t ii = i - m.cx, jj = j - m.cy;
+    if (jj >= m.ch)
+        return;
+    uint8_t * row = A.rgb + (size_t)(uint32_t)(m.sy * (int32_t)jj + m.ky) * A.rgbPitch;
+    if (NCH == 4 && ii < m.cw && m.cw - ii >= 4u) { // all four inside the crop: one 16-byte store, forwards or mirrored
+        const bool fwd = m.sx > 0;
+        const uint32_t x = (uint32_t)(fwd ? (int32_t)ii + m.kx : m.kx - (int32_t)(ii + 3u));
+        const u4 v = fwd ? (u4) { px[0], px[1], px[2], px[3] } : (u4) { px[3], px[2], px[1], px[0] };
+        __builtin_nontemporal_store(v, reinterpret_cast<u4a4 *>(row + (size_t)x * 4u));
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t iik = ii + (uint32_t)k;
+        if (iik < m.cw)
+            pkStorePixel<NCH>(row + (size_t)(uint32_t)(m.sx * (int32_t)iik + m.kx) * NCH, px[k]);
+    }
+}
+
+// rows become columns (quarter turns): the lane's 4 columns x ROWS rows, first at canvas (i, j); `rowsValid` rows exist.  Each
+// source column is a run of ROWS consecutive destination pixels; plain stores: the pieces of one destination line come from
+// different waves and meet in L2 (tests/tools/transpose_probe.hip: 64 us for an 8K frame against 383 us non-temporal)
+template <int NCH, int ROWS>
+__device__ __forceinline__ void pkStoreMappedColumns(const TileArgs & A, const unsigned px[ROWS][4], uint32_t i, uint32_t j, uint32_t rowsValid)
+{
+    const PixelMap & m = A.map;
+    const uint32_t ii = i - m.cx, jj = j - m.cy;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t iic = ii + (uint32_t)c;
+        if (iic >= m.cw)
+            continue;
+        uint8_t * row = A.rgb + (size_t)(uint32_t)(m.sy * (int32_t)iic + m.ky) * A.rgbPitch;
+#pragma unroll
+        for (int q = 0; q < ROWS / 4; ++q) {
+            const uint32_t jq = jj + 4u * (uint32_t)q;
+            if (NCH == 4 && 4u * (uint32_t)q + 4u <= rowsValid && jq < m.ch && m.ch - jq >= 4u) {
+                const bool fwd = m.sx > 0;
+                const uint32_t x = (uint32_t)(fwd ? (int32_t)jq + m.kx : m.kx - (int32_t)(jq + 3u));
+                const u4 v = fwd ? (u4) { px[4 * q][c], px[4 * q + 1][c], px[4 * q + 2][c], px[4 * q + 3][c] }
+                                 : (u4) { px[4 * q + 3][c], px[4 * q + 2][c], px[4 * q + 1][c], px[4 * q][c] };
+                *reinterpret_cast<u4a4 *>(row + (size_t)x * 4u) = v;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t jr = jq + (uint32_t)r;
+                if (4u * (uint32_t)q + (uint32_t)r < rowsValid && jr < m.ch)
+                    pkStorePixel<NCH>(row + (size_t)(uint32_t)(m.sx * (int32_t)jr + m.kx) * NCH, px[4 * q + r][c]);
+            }
+        }
+    }
+}
+
 // ---- filter, matrix, stores of a wave tile ----
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED>
 __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW> & R, const unsigned * ring)
 {
     constexpr bool kStaged = PkRaw<SUB, BIL, APLANE, NSW>::kStaged;
+    unsigned held[MAPPED ? 2 * NSW : 1][4]; // quarter turns: every row of the tile, stored column-wise at the end
     const uint32_t X = w.band * (uint32_t)kBandW + 4u * (uint32_t)threadIdx.x;
     const bool laneValid = X < A.w4;
     const uint32_t strips = A.h2 >> 1;
@@ -407,8 +493,31 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
         }
         if (stripValid) {
 #pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                unsigned px[4];
+                pkRow<SUB, NCH, APLANE, MAPPED>(A, R.y[2 * s + r], APLANE ? R.a[2 * s + r] : 0u, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid, px);
+                if constexpr (MAPPED) {
+                    if (A.map.transposed) { // wave-uniform
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            held[2 * s + r][k] = px[k];
+                    } else if (laneValid) {
+                        pkStoreMappedRow<NCH>(A, px, (uint32_t)A.mapX0 + X, (uint32_t)A.mapY0 + sy + (uint32_t)r);
+                    }
+                }
+            }
+        } else if constexpr (MAPPED) {
+#pragma unroll
             for (int r = 0; r < 2; ++r)
-                pkRow<SUB, NCH, APLANE>(A, R.y[2 * s + r], APLANE ? R.a[2 * s + r] : 0u, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    held[2 * s + r][k] = 0;
+        }
+    }
+    if constexpr (MAPPED) {
+        if (A.map.transposed && laneValid) {
+            const uint32_t left = strips - w.strip0; // strips of the tile that exist (at least one)
+            pkStoreMappedColumns<NCH, 2 * NSW>(A, held, (uint32_t)A.mapX0 + X, (uint32_t)A.mapY0 + 2u * w.strip0, 2u * (left < (uint32_t)NSW ? left : (uint32_t)NSW));
         }
     }
 }
@@ -418,7 +527,7 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
 // their tiles with the next tile's loads in flight) measured 10-20% SLOWER on 8K frames, with frames streaming from HBM as well
 // as from the Infinity Cache (tests/tools/pk_sweep.py, profiles/r02_pk_sweep_persistent.txt) -- the dispatcher refilling 32 waves per CU in
 // tile order keeps the memory pipes fuller than a software pipeline one tile deep does.
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED>
 __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g, unsigned * lds)
 {
     typedef PkRaw<SUB, BIL, APLANE, NSW> RawT;
@@ -439,24 +548,24 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     RawT raw;
     pkLoad<SUB, BIL, APLANE, NSW>(A, w, raw);
     pkStage<SUB, BIL, APLANE, NSW>(raw, ring);
-    pkCompute<SUB, BIL, NCH, APLANE, NSW>(A, w, raw, ring);
+    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED>(A, w, raw, ring);
 }
 
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED>
 __global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g)
 {
     constexpr int kRingWords = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
     __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * kRingWords];
-    pkRunBlock<SUB, BIL, NCH, APLANE, NSW>(A, g, lds);
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED>(A, g, lds);
 }
 
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED>
 __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     constexpr int kRingWords = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
     __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * kRingWords];
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
-    pkRunBlock<SUB, BIL, NCH, APLANE, NSW>(job, g, lds);
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED>(job, g, lds);
 }
 
 // Launch geometry: strips per wave, waves side by side, tile order (TuningBits; tests/tools/geometry_sweep.py)
@@ -483,8 +592,8 @@ inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t 
     *blocks = g->chunk ? ((g->nTiles + 8 * g->chunk - 1) / (8 * g->chunk)) * 8 * g->chunk : g->nTiles;
 }
 
-template <int SUB, bool BIL, int NCH, bool APLANE>
-hipError_t launchPk(const TileLaunch & L)
+template <int SUB, bool BIL, int NCH, bool APLANE, bool MAPPED>
+hipError_t launchPkMapped(const TileLaunch & L)
 {
     uint32_t nsw, blocks;
     PkGeom g;
@@ -493,16 +602,22 @@ hipError_t launchPk(const TileLaunch & L)
     const dim3 grid(blocks, 1, L.count);
     if (L.table) {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 4>), grid, block, 0, L.stream, L.table, g);
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 4, MAPPED>), grid, block, 0, L.stream, L.table, g);
         else
-            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2>), grid, block, 0, L.stream, L.table, g);
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2, MAPPED>), grid, block, 0, L.stream, L.table, g);
     } else {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4>), grid, block, 0, L.stream, *L.args, g);
+            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4, MAPPED>), grid, block, 0, L.stream, *L.args, g);
         else
-            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2>), grid, block, 0, L.stream, *L.args, g);
+            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2, MAPPED>), grid, block, 0, L.stream, *L.args, g);
     }
     return hipGetLastError();
+}
+
+template <int SUB, bool BIL, int NCH, bool APLANE>
+hipError_t launchPk(const TileLaunch & L)
+{
+    return L.mapped ? launchPkMapped<SUB, BIL, NCH, APLANE, true>(L) : launchPkMapped<SUB, BIL, NCH, APLANE, false>(L);
 }
 
 } // namespace tile

@@ -41,6 +41,18 @@ struct TileArgs
     int32_t alphaRescale;                // alpha plane depth differs from the rgb depth (src/alpha.c:84-103)
     int32_t inLoopMul, postMul;          // MulMode
     uint32_t tuning;
+    // fused crop / rotate / mirror (plan.h PixelMap): `rgb` is then the destination buffer's first pixel, and canvas pixel
+    // (mapX0 + X, mapY0 + row) of the rectangle's pixel (X, row) goes where the map says.  Packed 16-bit kernels only.
+    PixelMap map;
+    int32_t mapX0, mapY0;
+    // limited-range alpha planes (pre-1.0 files: avifImageLimitedToFullAlpha, src/read.c:6724-6764, per sample avifLimitedToFullY,
+    // src/reformat.c:1778-1791): a' = clamp(((a - lo) * full + half) / range, 0, full), the division as multiply-high by
+    // `magic` then >> `shift` (exact for every sample of the depth: distillArgs)
+    struct AlphaLimited
+    {
+        int32_t on, lo, full, half;
+        uint32_t magic, shift;
+    } alphaLim;
     // ---- fixed-point (libyuv-arithmetic) kernels only: SURVEY.md appendix D.1-D.4 with the constants folded ----
     // libyuv's "YVU trick" (src/reformat_libyuv.c:386-423) is applied to the plane pointers: `u` above addresses the plane
     // feeding the FIRST colour byte of a pixel (X: R for RGB orders, B for BGR orders), `v` the one feeding the third (Z).
@@ -80,7 +92,18 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     A.a = s.alpha ? s.alpha + (size_t)p.y0 * s.alphaRowBytes + (size_t)p.x0 * s.chanBytes : nullptr;
     A.u = s.plane[1];
     A.v = s.plane[2];
-    A.rgb = o.pixels + (size_t)p.y0 * o.rowBytes + (size_t)p.x0 * o.pixBytes;
+    A.rgb = o.map.on ? o.pixels : o.pixels + (size_t)p.y0 * o.rowBytes + (size_t)p.x0 * o.pixBytes;
+    A.map = o.map;
+    if (s.alphaLimited) {
+        const int d = (int)s.depth;
+        const uint32_t range = 219u << (d - 8);
+        A.alphaLim.on = 1, A.alphaLim.lo = 16 << (d - 8), A.alphaLim.full = (1 << d) - 1, A.alphaLim.half = (int32_t)(range / 2);
+        // n / range == mulhi(n, magic) >> shift for 0 <= n <= (full - lo) * full + half: magic = floor(2^(32 + shift) / range) + 1 exceeds
+        // 2^(32 + shift) / range by less than 1, so the product's error stays below n / 2^32 ... n * range < 2^(32 + shift) suffices
+        A.alphaLim.shift = (uint32_t)(d - 1); // 219 << (d - 8) < 2^d: magic < 2^32
+        A.alphaLim.magic = (uint32_t)((((uint64_t)1 << (32 + A.alphaLim.shift)) / range) + 1);
+    }
+    A.mapX0 = (int32_t)p.x0, A.mapY0 = (int32_t)p.y0;
     A.yPitch = s.rowBytes[0], A.aPitch = s.alphaRowBytes, A.uPitch = s.rowBytes[1], A.vPitch = s.rowBytes[2], A.rgbPitch = o.rowBytes;
     A.w4 = p.w & ~3u;
     A.h2 = p.h & ~1u;
@@ -172,6 +195,7 @@ struct TileKey
     int nch;
     bool alphaPlane; // alpha channel comes from the alpha plane (otherwise opaque / absent)
     bool hasMul;
+    bool mapped;     // stores go through a PixelMap (fused crop / rotate / mirror)
 };
 
 struct TileLaunch
@@ -187,6 +211,7 @@ struct TileLaunch
     uint32_t pkStrips;      // strips (two luma rows) per wave: 2 or 4
     uint32_t wavesXLog2;    // waves of a workgroup side by side (1 << n), the rest stacked
     uint32_t chunkRows;     // tile rows per XCD chunk, 0 = plain raster order
+    bool mapped;            // stores go through the jobs' PixelMap
     hipStream_t stream;
 };
 

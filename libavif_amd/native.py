@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
-    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
+    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
     "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap",
 ]
@@ -96,6 +96,8 @@ def load() -> C.CDLL:
         "avifhipRGBImageToF16": (i32, [P_RGB]),
         "avifhipLaunchCount": (C.c_uint64, []),
         "avifhipTimeYUVToRGBCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
+        "avifhipImageYUVToRGBTransformedAsync": (i32, [P_IMG, P_RGB, P_RECT, i32, C.c_uint8, i32, C.c_uint8, vp]),
+        "avifhipGridYUVToRGBTransformedAsync": (i32, [C.POINTER(avifhipGrid), C.POINTER(P_IMG), C.POINTER(P_IMG), i32, P_RGB, P_RECT, i32, C.c_uint8, i32, C.c_uint8, vp]),
         "avifhipY4MFrameBytes": (C.c_size_t, [P_IMG, i32]),
         "avifhipImagePackY4MFrameAsync": (i32, [P_IMG, i32, vp, vp]),
         "avifhipRGBImagePackPNGRowsAsync": (i32, [P_RGB, vp, vp]),

@@ -1,0 +1,123 @@
+"""The decode-side tail in one step: avifhipGridYUVToRGBTransformedAsync / avifhipImageYUVToRGBTransformedAsync --
+tiles -> canvas (src/read.c:1823-1877), limited -> full alpha (:6724-6764), YUV -> RGB and the application's avifApplyTransforms
+(apps/shared/avifutil.c:787-825) -- must equal, byte for byte, the composition of the two oracles that are pinned separately
+against the reference: oracleGridYUVToRGB (tests/test_grid_oracle.py) then oracleRGBImageTransform (tests/test_transform.py).
+Covers the fused route (the integer path's packed 16-bit kernels store through the pixel map: rows for no rotation / half turns,
+columns for quarter turns; leftovers and seams through the universal kernels with the same map) and the two-pass route (every
+other kernel family), crops that start anywhere, limited-range alpha inside the tiled kernels."""
+import ctypes as C
+import itertools
+
+import numpy as np
+import pytest
+
+import harness as H
+from libavif_amd import abi, device, native
+from test_grid_oracle import oracle_grid
+from test_transform import call_oracle, out_dims
+
+pytestmark = pytest.mark.gpu
+A = abi
+
+
+def grid_cases(avoid_libyuv):
+    base = dict(avoid_libyuv=avoid_libyuv)
+    return [
+        # 8-bit 4:2:0 (the packed kernels when avoid_libyuv is off): seams, cropped last column / row, sizes off the 4 x 2 grid
+        H.GridCase(2, 3, 256, 32, 701, 61, H.Y2RCase(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, **base)),
+        H.GridCase(2, 3, 256, 32, 701, 61, H.Y2RCase(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, **base), alpha_limited=True),
+        H.GridCase(2, 2, 320, 40, 639, 79, H.Y2RCase(0, 0, yuv_format=2, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_RGB, upsampling=4, **base)),
+        H.GridCase(1, 1, 600, 70, 600, 70, H.Y2RCase(0, 0, yuv_format=1, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_BGRA, upsampling=3, alpha=True, **base)),
+        # other kernel families: two passes
+        H.GridCase(3, 3, 512, 64, 1100, 150, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=10, upsampling=4, **base)),
+        H.GridCase(2, 2, 64, 16, 100, 30, H.Y2RCase(0, 0, yuv_format=3, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_RGB_565, upsampling=4, **base)),
+    ]
+
+
+def transforms(w, h):
+    crops = [None, (w // 5 + 1, h // 7 + 1, w - w // 3, h - h // 2), (3, 1, w - 5, h - 2)]
+    for crop, angle, mirror in itertools.product(crops, (None, 1, 2, 3), (None, 0, 1)):
+        yield crop, angle, mirror
+
+
+def run_grid(lib, g):
+    tiles = H.make_grid_tiles(g)
+    canvas = H.grid_output(g)
+    assert oracle_grid(g, tiles, canvas, libyuv_build=not g.conv.avoid_libyuv) == 0
+    dtiles = [device.DeviceYUV(t) for t in tiles]
+    n = g.rows * g.columns
+    P = C.POINTER(abi.avifImage)
+    colour = (P * n)(*[C.pointer(d.struct) for d in dtiles])
+    alpha = (P * n)(*[C.pointer(d.struct) for d in dtiles]) if g.conv.alpha else None
+    grid = native.avifhipGrid(g.rows, g.columns, g.out_w, g.out_h)
+    fmt, depth = g.conv.rgb_format, (g.conv.rgb_depth or g.conv.yuv_depth)
+    px = abi.rgb_pixel_size(fmt, depth)
+    kernels = set()
+    for crop, angle, mirror in transforms(g.out_w, g.out_h):
+        dw, dh = out_dims(g.out_w, g.out_h, crop, angle)
+        want = abi.make_rgb(dw, dh, depth, fmt, fill=0x11)
+        assert call_oracle(canvas, want, crop, angle, mirror) == 0
+        got = abi.make_rgb(dw, dh, depth, fmt, upsampling=g.conv.upsampling, avoid_libyuv=g.conv.avoid_libyuv, alpha_premultiplied=g.conv.rgb_premultiplied, fill=0x22)
+        want.pixels[:, dw * px:] = 0x22
+        dgot = device.DeviceRGB(got, upload=True)
+        rect = abi.avifCropRect(*crop) if crop else None
+        native.check(lib.avifhipGridYUVToRGBTransformedAsync(C.byref(grid), colour, alpha, int(g.alpha_limited), dgot.struct, C.byref(rect) if rect else None,
+                                                            int(angle is not None), angle or 0, int(mirror is not None), mirror or 0, None), "grid + transform")
+        native.check(lib.avifhipSynchronize(None), "sync")
+        kernels.add(native.last_kernel())
+        dgot.download_into_host()
+        assert np.array_equal(got.pixels[:, : dw * px], want.pixels[:, : dw * px]), (g.ident(), crop, angle, mirror, native.last_kernel(),
+                                                                                      H.describe_diff(want.pixels[:, : dw * px], got.pixels[:, : dw * px]))
+    return kernels
+
+
+@pytest.mark.parametrize("g", grid_cases(False), ids=lambda g: g.ident())
+def test_grid_tail_default_arithmetic(hip_auto_arithmetic, g):
+    kernels = run_grid(hip_auto_arithmetic, g)
+    if g.conv.yuv_depth == 8 and g.conv.rgb_format != A.AVIF_RGB_FORMAT_RGB_565:
+        assert any("mapped" in k or "seam" in k or "generic" in k for k in kernels), kernels
+
+
+@pytest.mark.parametrize("g", grid_cases(True)[:3], ids=lambda g: g.ident())
+def test_grid_tail_fp32_path(hip, g):
+    run_grid(hip, g)
+
+
+def test_single_image_tail(hip_auto_arithmetic):
+    lib = hip_auto_arithmetic
+    cases = [H.Y2RCase(1030, 518, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, avoid_libyuv=False),
+             H.Y2RCase(771, 95, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, avoid_libyuv=False),
+             H.Y2RCase(640, 64, yuv_format=1, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_BGR, avoid_libyuv=False),
+             H.Y2RCase(300, 40, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, upsampling=4, avoid_libyuv=False)]
+    seen = set()
+    for c in cases:
+        res, canvas_px = H.run_y2r(H.oracle_libyuv_backend(), c)
+        assert res == 0
+        canvas = H.make_y2r_output(c)
+        canvas.pixels[...] = canvas_px
+        img = H.make_y2r_inputs(c)
+        dimg = device.DeviceYUV(img)
+        fmt, depth = c.rgb_format, (c.rgb_depth or c.yuv_depth)
+        px = abi.rgb_pixel_size(fmt, depth)
+        for crop, angle, mirror in transforms(c.w, c.h):
+            dw, dh = out_dims(c.w, c.h, crop, angle)
+            want = abi.make_rgb(dw, dh, depth, fmt, fill=0x11)
+            assert call_oracle(canvas, want, crop, angle, mirror) == 0
+            got = abi.make_rgb(dw, dh, depth, fmt, upsampling=c.upsampling, avoid_libyuv=False, fill=0x22)
+            dgot = device.DeviceRGB(got, upload=True, tight=(dw % 2 == 1))
+            rect = abi.avifCropRect(*crop) if crop else None
+            native.check(lib.avifhipImageYUVToRGBTransformedAsync(dimg.struct, dgot.struct, C.byref(rect) if rect else None, int(angle is not None), angle or 0,
+                                                                 int(mirror is not None), mirror or 0, None), "image + transform")
+            native.check(lib.avifhipSynchronize(None), "sync")
+            seen.add(native.last_kernel())
+            dgot.download_into_host()
+            assert np.array_equal(got.pixels[:, : dw * px], want.pixels[:, : dw * px]), (c.ident(), crop, angle, mirror, native.last_kernel(),
+                                                                                          H.describe_diff(want.pixels[:, : dw * px], got.pixels[:, : dw * px]))
+    assert any(k.endswith(",pk16,mapped>") for k in seen), seen  # the fused route ran
+    assert any(k.startswith("rgb_transform") for k in seen), seen  # ... and so did the two-pass route (10-bit case)
+    # argument errors: the destination must have the transformed size
+    c = cases[0]
+    dimg = device.DeviceYUV(H.make_y2r_inputs(c))
+    wrong = device.DeviceRGB(abi.make_rgb(c.w, c.h, 8, A.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False))
+    assert lib.avifhipImageYUVToRGBTransformedAsync(dimg.struct, wrong.struct, None, 1, 1, 0, 0, None) == abi.AVIF_RESULT_INVALID_ARGUMENT
+    assert lib.avifhipImageYUVToRGBTransformedAsync(dimg.struct, wrong.struct, None, 1, 5, 0, 0, None) == abi.AVIF_RESULT_INVALID_ARGUMENT

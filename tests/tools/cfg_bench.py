@@ -113,6 +113,41 @@ def run(name):
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
             px, bpp, ms = 7664 * 4312, 8.0, best
+        elif name in ("tail0", "tail180", "tail90", "tail90_two_pass", "tail180_two_pass"):
+            # the decode-side tail fused (avifhipImageYUVToRGBTransformedAsync): 8K 8-bit 4:2:0 -> RGBA8 bilinear with clap crop +
+            # irot + imir, against the same result in two passes (conversion, then avifhipRGBImageTransformAsync).  5.5 B/pixel of
+            # the cropped image is what HAS to move.
+            if arith == "float":
+                continue  # the fused route is the integer path's (the fp32 kernels take the two-pass route inside the same call)
+            angle = {"tail0": 0, "tail180": 2, "tail90": 1, "tail90_two_pass": 1, "tail180_two_pass": 2}[name]
+            img = abi.make_yuv(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+            synth.fill_yuv(img, 0x12345678)
+            dimg = device.DeviceYUV(img)
+            crop = abi.avifCropRect(8, 4, 7664, 4312)
+            dw, dh = (4312, 7664) if angle == 1 else (7664, 4312)
+            dst = abi.make_rgb(dw, dh, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False)
+            ddst = device.DeviceRGB(dst)
+            if name.endswith("two_pass"):
+                mid = abi.make_rgb(7680, 4320, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False)
+                dmid = device.DeviceRGB(mid)
+
+                def call():
+                    native.check(lib.avifhipImageYUVToRGBAsync(dimg.struct, dmid.struct, None))
+                    native.check(lib.avifhipRGBImageTransformAsync(ddst.struct, dmid.struct, C.byref(crop), 1, angle, 1, 1, None))
+            else:
+                def call():
+                    native.check(lib.avifhipImageYUVToRGBTransformedAsync(dimg.struct, ddst.struct, C.byref(crop), int(angle != 0), angle, int(angle != 0), 1, None))
+            for _ in range(3):
+                call()
+            native.check(lib.avifhipSynchronize(None))
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    call()
+                native.check(lib.avifhipSynchronize(None))
+                best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
+            px, bpp, ms = 7664 * 4312, 5.5, best
         elif name in ("cfg5grid", "cfg5grid_8"):
             # BASELINE configs[4]: 8 x 8 grid of decoded 1920x1080 10-bit 4:2:0 tiles -> one 15360x8640 RGBA canvas, tiles
             # converted where they lie (avifhipGridYUVToRGBAsync: no YUV canvas, seams redone across tiles)
