@@ -45,7 +45,7 @@ TileKey keyFor(const YuvToRgbPlan & p)
         k.sub = SUB_420;
     k.bilinear = p.bilinear && (k.sub == SUB_420 || k.sub == SUB_422);
     k.wideRgb = p.rgb.chanBytes == 2;
-    k.nch = p.rgb.hasAlpha ? 4 : 3;
+    k.nch = p.rgb.is565 ? 2 : (p.rgb.hasAlpha ? 4 : 3);
     k.hasMul = (p.inLoopMul != MUL_NONE) || (p.postMul != MUL_NONE);
     k.alphaPlane = k.nch == 4 && p.alphaSource == ALPHA_PLANE;
     k.mapped = p.rgb.map.on != 0;
@@ -64,7 +64,7 @@ const char * kernelNameFor(const TileKey & k)
     // ",pk16": the packed 16-bit kernels (tile_pk_impl.h) serve 8-bit planes of the integer path unless a post-pass follows
     const bool packed = k.fixedPoint && !k.wideYuv && !k.hasMul;
     snprintf(name, sizeof(name), "%s<%s,%s,%s,%s%d%s%s%s%s>", k.fixedPoint ? "yuv2rgb_fixed_tile" : "yuv2rgb_tile", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
-             k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "", packed ? ",pk16" : "", k.mapped ? ",mapped" : "");
+             k.nch == 4 ? "rgba" : (k.nch == 2 ? "rgb565_" : "rgb"), k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "", packed ? ",pk16" : "", k.mapped ? ",mapped" : "");
     return name;
 }
 
@@ -112,7 +112,8 @@ void decompose(uint32_t tuning, uint32_t w4, uint32_t h2, uint32_t jobs, bool ba
     const uint64_t tiles8 = (uint64_t)bands * ((h2 + 7) / 8) * jobs;
     if (ns == 0)
         ns = 2 * tiles8 >= 3 * (uint64_t)kTargetBlocks ? 2 : 1; // from 4K frames up (tests/tools/geometry_sweep.py: 4K 11.1 -> 9.5 us)
-    ns = (ns >= 2 && !batch) ? 2 : 1; // the batch kernels exist for NS = 1 only: batches are made of small jobs
+    const bool forced = ((tuning >> TUNE_STRIPS_SHIFT) & 0xfu) != 0;
+    ns = (ns >= 2 && (!batch || forced)) ? 2 : 1; // batches are made of small jobs: short tiles unless the sweep says otherwise
     const uint32_t tilesY = (h2 + 8 * ns - 1) / (8 * ns);
     uint32_t run = (tuning >> TUNE_RUN_SHIFT) & 0xfu;
     if (run == 0) {
@@ -135,6 +136,18 @@ void decompose(uint32_t tuning, uint32_t w4, uint32_t h2, uint32_t jobs, bool ba
     L->wavesXLog2 = wx ? wx - 1 : 0;
     const uint32_t chunk = (tuning >> TUNE_CHUNK_SHIFT) & 0xfu;
     L->chunkRows = (tuning & TUNE_XCD_BANDS) ? (chunk ? chunk : 1) : 0;
+    L->solo = (tuning & TUNE_COOPERATIVE) == 0; // (launchYuvToRgbTile / ...Batch narrow it down per kernel family)
+}
+
+// Where the wave-private kernels of the fp32 / 10-12-bit integer families beat round 1's cooperative runs (profiles/r02_solo_ab.txt:
+// cfg3 89.7 -> 85.3 us, fp32 cfg2 33.5 -> 32.0 us; but cfg5x64 284 -> 322 us, 4K fp32 cfg2 11.2 -> 11.8 us): whenever no chroma
+// neighbourhood is staged, and for 8-bit planes on frames from ~16 megapixels up.  Staged 16-bit planes keep the cooperative runs,
+// whose software pipeline (next tile's loads in flight during a long fp32 compute phase) is worth more than the missing barrier.
+bool soloPays(const TileKey & k, uint64_t pixels)
+{
+    if (!k.bilinear)
+        return true;
+    return !k.wideYuv && pixels >= ((uint64_t)16 << 20);
 }
 
 // largest byte offset the kernel forms from a plane base must fit 32 bits
@@ -163,8 +176,16 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
         if (!s.exactDiv)
             return false; // a divisor off the verified list (exactdiv.h): the universal kernel divides the IEEE way
     }
-    if (o.isGray || o.is565 || o.isFloat)
+    if (o.isGray || o.isFloat)
         return false;
+    if (o.is565) {
+        // RGB565 (Android's bitmap format, android_jni/.../libavif_jni.cc:206-223): libyuv's I420ToRGB565Matrix / I422ToRGB565Matrix --
+        // 8-bit 4:2:0 / 4:2:2 planes, nearest upsampling -- in the packed 16-bit kernels; everything else 565 stays universal
+        const bool packed = p.arith == ARITH_LIBYUV && s.chanBytes == 1 && !p.bilinear && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE &&
+                            (s.format == AVIF_PIXEL_FORMAT_YUV420 || s.format == AVIF_PIXEL_FORMAT_YUV422) && s.hasColor;
+        if (!packed || o.map.on)
+            return false;
+    }
     if (o.map.on) {
         // fused crop / rotate / mirror: the packed 16-bit kernels store through the map; every other family leaves it to the
         // universal kernel (the entry points convert into scratch and run the transform pass instead: api.cpp)
@@ -192,8 +213,8 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
         return false;
     if (p.postMul != MUL_NONE && p.alphaSource != ALPHA_PLANE)
         return false;
-    const int nch = o.hasAlpha ? 4 : 3;
-    const uint32_t storeAlign = o.map.on ? 1u : ((nch == 4) ? 16u : (o.chanBytes == 1 ? 4u : 8u));
+    const int nch = o.is565 ? 2 : (o.hasAlpha ? 4 : 3);
+    const uint32_t storeAlign = o.map.on ? 1u : ((nch == 4) ? 16u : (nch == 2 ? 8u : (o.chanBytes == 1 ? 4u : 8u)));
     if (!aligned(o.pixels, o.rowBytes, storeAlign))
         return false;
     // 32-bit lane offsets from the plane bases
@@ -208,7 +229,7 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
     if (!tileYuvToRgbSupported(plan))
         return -1;
     const TileKey k = keyFor(plan);
-    return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) |
+    return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) | ((k.nch == 2 ? 1 : 0) << 10) |
            ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7) | ((k.fixedPoint ? 1 : 0) << 8) | ((k.mapped ? 1 : 0) << 9);
 }
 
@@ -225,6 +246,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     L.stream = stream;
     L.mapped = k.mapped;
     decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
+    L.solo = L.solo && (soloPays(k, (uint64_t)A.w4 * A.h2) || (plan.tuning & TUNE_SOLO_ALWAYS));
     hipError_t e = launchFamily(k, L);
     if (e != hipSuccess)
         return e;
@@ -270,6 +292,7 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
     L.stream = stream;
     L.mapped = k.mapped;
     decompose(representative.tuning, maxW & ~3u, maxH & ~1u, count, true, &L);
+    L.solo = L.solo && (soloPays(k, (uint64_t)(maxW & ~3u) * (maxH & ~1u) * count) || (representative.tuning & TUNE_SOLO_ALWAYS));
     return launchFamily(k, L);
 }
 

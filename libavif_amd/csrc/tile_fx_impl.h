@@ -55,14 +55,14 @@ struct FxPrescale
     static constexpr int kShift = !kOn ? 0 : (SUB == SUB_420 ? 4 : 6);
 };
 
-template <typename YT, int SUB, bool NEEDA, int NS>
-__device__ __forceinline__ void stageTileFx(const TileArgs & A, const TileRaw<YT, SUB, true, NEEDA, NS> & T, unsigned (*rows)[kFxRowPitch])
+template <typename YT, int SUB, bool NEEDA, int NS, int WAVES = 4>
+__device__ __forceinline__ void stageTileFx(const TileArgs & A, const TileRaw<YT, SUB, true, NEEDA, NS, WAVES> & T, unsigned (*rows)[kFxRowPitch])
 {
-    typedef StageRows<SUB, NS> SR;
-    const int t = threadIdx.y * kLanesX + threadIdx.x;
+    typedef StageRows<SUB, NS, WAVES> SR;
+    const int t = ((WAVES == 1) ? 0 : (int)threadIdx.y * kLanesX) + (int)threadIdx.x;
 #pragma unroll
     for (int j = 0; j < SR::kRounds; ++j) {
-        const int task = t + 256 * j;
+        const int task = t + SR::kThreads * j;
         if (task < SR::kTasks) {
             const int row = task / kStageGroups, grp = task - row * kStageGroups;
             unsigned u[4], v[4];
@@ -93,13 +93,13 @@ __device__ __forceinline__ unsigned fx9(unsigned x)
 }
 
 
-template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
-__device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx & c, uint32_t tileY, const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS> & T,
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS, int WAVES = 4>
+__device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx & c, uint32_t tileY, const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS, WAVES> & T,
                                               unsigned (*rows)[kFxRowPitch])
 {
     constexpr bool kWide = sizeof(YT) == 2;
     constexpr bool kNeedA = APLANE || HASMUL;
-    const int tx = threadIdx.x, wv = threadIdx.y;
+    const int tx = threadIdx.x, wv = (WAVES == 1) ? 0 : (int)threadIdx.y;
     const bool nt = (A.tuning & TUNE_NONTEMPORAL) != 0;
     const uint32_t X = c.X;
     const bool laneValid = c.laneValid;
@@ -333,15 +333,91 @@ __global__ __launch_bounds__(256) void yuvToRgbTileFxBatchKernel(const TileArgs 
     runBlockFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(job, tilesPerRun, rows);
 }
 
+// ---- every wave for itself (see runSolo, tile_impl.h) ----
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
+__device__ __forceinline__ void runSoloFx(const TileArgs & A, const PkGeom & g, unsigned * lds)
+{
+    constexpr bool kNeedA = APLANE || HASMUL;
+    typedef StageRows<SUB, NS, 1> SR;
+    const uint32_t tile = pkTileOf(blockIdx.x, g);
+    if (tile >= g.nTiles)
+        return;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const uint32_t wx = wave & ((1u << g.wavesXLog2) - 1u), wy = wave >> g.wavesXLog2;
+    const uint32_t wavesY = 4u >> g.wavesXLog2;
+    const uint32_t trow = g.magicTilesX ? __umulhi(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
+    const uint32_t bandX = ((tcol << g.wavesXLog2) + wx) * (uint32_t)kBandW;
+    const uint32_t tileY = (trow * wavesY + wy) * (uint32_t)(2 * NS);
+    if (bandX >= A.w4 || tileY >= A.h2)
+        return;
+    BandCtx c;
+    c.bandX = bandX;
+    c.X = bandX + 4 * threadIdx.x;
+    c.laneValid = c.X < A.w4;
+    c.Xc = c.laneValid ? c.X : 0;
+    c.cxb = A.cx0 + (int)(bandX >> 1);
+    TileRaw<YT, SUB, BIL, kNeedA, NS, 1> raw;
+    loadTile<YT, SUB, BIL, kNeedA, NS, 1>(A, c, tileY, raw);
+    unsigned(*rows)[kFxRowPitch] = reinterpret_cast<unsigned(*)[kFxRowPitch]>(lds + (size_t)wave * (BIL ? SR::kRows : 1) * kFxRowPitch);
+    if constexpr (BIL) {
+        stageTileFx<YT, SUB, kNeedA, NS, 1>(A, raw, rows);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    computeTileFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS, 1>(A, c, tileY, raw, rows);
+}
+
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
+__global__ __launch_bounds__(256) void yuvToRgbTileFxSoloKernel(TileArgs A, PkGeom g)
+{
+    __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kFxRowPitch];
+    runSoloFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(A, g, lds);
+}
+
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int NS>
+__global__ __launch_bounds__(256) void yuvToRgbTileFxSoloBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
+{
+    __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kFxRowPitch];
+    const TileArgs job = table[blockIdx.z];
+    runSoloFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(job, g, lds);
+}
+
+template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool MUL>
+hipError_t launchSoloFx(const TileLaunch & L)
+{
+    uint32_t nsw, blocks;
+    PkGeom g;
+    pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
+    const dim3 block(kLanesX, kWavesPerBlock);
+    const dim3 grid(blocks, 1, L.count);
+    if (L.table) {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbTileFxSoloBatchKernel<YT, SUB, BIL, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, L.table, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbTileFxSoloBatchKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, g);
+    } else {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbTileFxSoloKernel<YT, SUB, BIL, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, *L.args, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbTileFxSoloKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, g);
+    }
+    return hipGetLastError();
+}
+
 template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool MUL>
 hipError_t launchOneFx(const TileLaunch & L)
 {
     // 8-bit planes without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)
     if constexpr (sizeof(YT) == 1 && !MUL)
         return launchPk<SUB, BIL, NCH, APLANE>(L);
+    if (L.solo)
+        return launchSoloFx<YT, SUB, BIL, NCH, APLANE, MUL>(L);
     const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(L.blocksPerJob, 1, L.count);
-    if (L.table)
+    if (L.table && L.stripsPerWave >= 2)
+        hipLaunchKernelGGL((yuvToRgbTileFxBatchKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
+    else if (L.table)
         hipLaunchKernelGGL((yuvToRgbTileFxBatchKernel<YT, SUB, BIL, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
     else if (L.stripsPerWave >= 2)
         hipLaunchKernelGGL((yuvToRgbTileFxKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
@@ -353,6 +429,10 @@ hipError_t launchOneFx(const TileLaunch & L)
 template <typename YT, int SUB, bool BIL>
 hipError_t launchFxVariant(const TileKey & k, const TileLaunch & L)
 {
+    if constexpr (sizeof(YT) == 1 && !BIL && (SUB == SUB_420 || SUB == SUB_422)) {
+        if (k.nch == 2) // RGB565: the packed 16-bit kernels only (tileYuvToRgbSupported admits nothing else)
+            return launchPk<SUB, BIL, 2, false>(L);
+    }
     if (k.nch == 3)
         return launchOneFx<YT, SUB, BIL, 3, false, false>(L);
     if (k.hasMul)

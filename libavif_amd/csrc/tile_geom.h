@@ -1,0 +1,59 @@
+// tile_geom.h -- launch geometry shared by the tiled kernels whose waves work for themselves (one wave, one tile of
+// 256 x 2*NSW pixels; tile_pk_impl.h and the wave-private kernels of tile_impl.h / tile_fx_impl.h): which tile a workgroup takes
+// and how a job is cut into tiles.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "tile_shared.h"
+
+namespace avifhip {
+namespace tile {
+
+// Geometry of a launch (kernel argument, lives in SGPRs)
+struct PkGeom
+{
+    uint32_t wavesXLog2;  // waves of a workgroup side by side: 1 << wavesXLog2 in {1, 2, 4}
+    uint32_t tilesX, nTiles;
+    uint32_t magicTilesX; // ceil(2^32 / tilesX): tile / tilesX == mulhi(tile, magic) while tile * tilesX < 2^32; 0 when tilesX == 1
+    uint32_t chunk;       // tiles per XCD chunk (a few tile rows), 0 = plain raster order
+    uint32_t magicChunk;
+};
+
+__device__ __forceinline__ uint32_t pkTileOf(uint32_t b, const PkGeom & g)
+{
+    if (g.chunk == 0)
+        return b;
+    // workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it): XCD x takes the x-th chunk of every
+    // group of 8 chunks, so vertically adjacent tiles (which share chroma halo rows) mostly meet in one L2
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    const uint32_t sc = g.magicChunk ? __umulhi(slot, g.magicChunk) : slot, within = slot - sc * g.chunk;
+    return (sc * 8u + xcd) * g.chunk + within;
+}
+
+// Launch geometry: strips per wave, waves side by side, tile order (TuningBits; tests/tools/geometry_sweep.py)
+inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t * nsw, PkGeom * g, uint32_t * blocks)
+{
+    const uint32_t bands = (w4 + 256u - 1) / 256u, strips = h2 / 2;
+    uint32_t ns = L.pkStrips; // 0 = automatic
+    if (ns != 2 && ns != 4)
+        ns = ((uint64_t)bands * ((strips + 3) / 4) * L.count >= 2048) ? 4 : 2; // small jobs: more, smaller waves
+    uint32_t wxl = L.wavesXLog2 <= 2 ? L.wavesXLog2 : 2;
+    while (wxl > 0 && (1u << wxl) > bands)
+        --wxl;
+    const uint32_t wavesX = 1u << wxl, wavesY = 4u / wavesX;
+    g->wavesXLog2 = wxl;
+    g->tilesX = (bands + wavesX - 1) / wavesX;
+    const uint32_t tilesY = (strips + ns * wavesY - 1) / (ns * wavesY);
+    g->nTiles = g->tilesX * tilesY;
+    auto magic = [](uint32_t d) { return d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0u; };
+    g->magicTilesX = magic(g->tilesX);
+    g->chunk = L.chunkRows * g->tilesX;
+    g->magicChunk = magic(g->chunk);
+    *nsw = ns;
+    // chunked order: padded to whole groups of 8 chunks (workgroups beyond the last tile leave at once)
+    *blocks = g->chunk ? ((g->nTiles + 8 * g->chunk - 1) / (8 * g->chunk)) * 8 * g->chunk : g->nTiles;
+}
+
+} // namespace tile
+} // namespace avifhip

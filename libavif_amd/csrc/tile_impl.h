@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pixel_math.h"
+#include "tile_geom.h"
 #include "tile_shared.h"
 
 namespace avifhip {
@@ -49,13 +50,15 @@ constexpr int kWavesPerBlock = 4;
 // 16-byte aligned loads.
 constexpr int kRowPitch = 140;
 constexpr int kStageGroups = 34;
-// chroma rows a workgroup stages for a tile of 4*NS strips (8*NS luma rows)
-template <int SUB, int NS>
+// chroma rows staged for a tile of WAVES * NS strips (2 * WAVES * NS luma rows) by WAVES waves: the four waves of a workgroup
+// together (WAVES = 4, one barrier per tile), or every wave for itself (WAVES = 1: wave-private LDS, no barrier)
+template <int SUB, int NS, int WAVES = 4>
 struct StageRows
 {
-    static constexpr int kRows = (SUB == SUB_420) ? (4 * NS + 2) : (8 * NS);
+    static constexpr int kRows = (SUB == SUB_420) ? (WAVES * NS + 2) : (2 * WAVES * NS);
     static constexpr int kTasks = kRows * kStageGroups;
-    static constexpr int kRounds = (kTasks + 255) / 256;
+    static constexpr int kThreads = 64 * WAVES;
+    static constexpr int kRounds = (kTasks + kThreads - 1) / kThreads;
 };
 
 __device__ __forceinline__ f2 splat(float v)
@@ -368,10 +371,10 @@ struct StripRaw
 
 // Raw (undecoded) data of one tile as loaded by one lane: its share of the chroma neighbourhood to stage, and the
 // luma / alpha / co-sited chroma of its own strips.  Lives in registers while the previous tile is computed.
-template <typename YT, int SUB, bool BIL, bool NEEDA, int NS>
+template <typename YT, int SUB, bool BIL, bool NEEDA, int NS, int WAVES = 4>
 struct TileRaw
 {
-    Raw4<YT> su[BIL ? StageRows<SUB, NS>::kRounds : 1], sv[BIL ? StageRows<SUB, NS>::kRounds : 1];
+    Raw4<YT> su[BIL ? StageRows<SUB, NS, WAVES>::kRounds : 1], sv[BIL ? StageRows<SUB, NS, WAVES>::kRounds : 1];
     StripRaw<YT, SUB, BIL, NEEDA> raw[NS];
 };
 
@@ -386,13 +389,13 @@ struct BandCtx
 };
 
 // issue every load of the tile whose first luma row (relative to the rectangle) is tileY
-template <typename YT, int SUB, bool BIL, bool NEEDA, int NS>
-__device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, uint32_t tileY, TileRaw<YT, SUB, BIL, NEEDA, NS> & T)
+template <typename YT, int SUB, bool BIL, bool NEEDA, int NS, int WAVES = 4>
+__device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, uint32_t tileY, TileRaw<YT, SUB, BIL, NEEDA, NS, WAVES> & T)
 {
     constexpr bool kWide = sizeof(YT) == 2;
     constexpr uint32_t BPS = sizeof(YT);
-    typedef StageRows<SUB, NS> SR;
-    const int tx = threadIdx.x, wv = threadIdx.y;
+    typedef StageRows<SUB, NS, WAVES> SR;
+    const int tx = threadIdx.x, wv = (WAVES == 1) ? 0 : (int)threadIdx.y;
     // ---- bilinear: this lane's share of the tile's chroma neighbourhood (first: it heads the longest chain) ----
     if constexpr (BIL) {
         // canvas chroma row held by LDS row 0
@@ -400,7 +403,7 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
         const int t = wv * kLanesX + tx;
 #pragma unroll
         for (int j = 0; j < SR::kRounds; ++j) {
-            const int task = t + 256 * j;
+            const int task = t + SR::kThreads * j;
             if (task < SR::kTasks) {
                 // coordinates clamp to the job's chroma window (the whole plane of the canvas unless the canvas is a grid of
                 // separately stored tiles): exactly the reference's border rule (src/reformat.c:768,784) -- the neighbour
@@ -465,14 +468,14 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
 }
 
 // bilinear: normalise this lane's share of the chroma neighbourhood and put it into LDS
-template <typename YT, int SUB, bool NEEDA, int NS>
-__device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, SUB, true, NEEDA, NS> & T, f2 (*rows)[kRowPitch])
+template <typename YT, int SUB, bool NEEDA, int NS, int WAVES = 4>
+__device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, SUB, true, NEEDA, NS, WAVES> & T, f2 (*rows)[kRowPitch])
 {
-    typedef StageRows<SUB, NS> SR;
-    const int t = threadIdx.y * kLanesX + threadIdx.x;
+    typedef StageRows<SUB, NS, WAVES> SR;
+    const int t = ((WAVES == 1) ? 0 : (int)threadIdx.y * kLanesX) + (int)threadIdx.x;
 #pragma unroll
     for (int j = 0; j < SR::kRounds; ++j) {
-        const int task = t + 256 * j;
+        const int task = t + SR::kThreads * j;
         if (task < SR::kTasks) {
             const int row = task / kStageGroups, grp = task - row * kStageGroups;
             float fu[4], fv[4];
@@ -486,14 +489,14 @@ __device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, 
     }
 }
 
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, int WAVES = 4>
 __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & c, uint32_t tileY,
-                                            const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS> & T, f2 (*rows)[kRowPitch], WideRowExchange * xchg)
+                                            const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS, WAVES> & T, f2 (*rows)[kRowPitch], WideRowExchange * xchg)
 {
     constexpr bool kWide = sizeof(YT) == 2;
     constexpr bool kNeedA = APLANE || HASMUL;
     constexpr uint32_t kPixBytes = NCH * sizeof(RT);
-    const int tx = threadIdx.x, wv = threadIdx.y;
+    const int tx = threadIdx.x, wv = (WAVES == 1) ? 0 : (int)threadIdx.y; // WAVES == 1: `xchg` is this wave's own exchange buffer
     const bool nt = (A.tuning & TUNE_NONTEMPORAL) != 0;
     const unsigned yuvMax = A.yuvMax;
     const uint32_t X = c.X;
@@ -769,12 +772,100 @@ __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * 
     }
 }
 
+// ---- every wave for itself (the structure of tile_pk_impl.h): one wave = one tile of 256 x 2*NS pixels, every load issued up
+//      front, the chroma neighbourhood in a wave-private LDS block, NO workgroup barrier; tiles in per-XCD chunks (tile_geom.h).
+//      Replaces the cooperative runs above wherever it measured faster (launchOne) ----
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+__device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2 * lds, WideRowExchange * xchg)
+{
+    constexpr bool kNeedA = APLANE || HASMUL;
+    typedef StageRows<SUB, NS, 1> SR;
+    const uint32_t tile = pkTileOf(blockIdx.x, g);
+    if (tile >= g.nTiles)
+        return;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const uint32_t wx = wave & ((1u << g.wavesXLog2) - 1u), wy = wave >> g.wavesXLog2;
+    const uint32_t wavesY = 4u >> g.wavesXLog2;
+    const uint32_t trow = g.magicTilesX ? __umulhi(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
+    const uint32_t bandX = ((tcol << g.wavesXLog2) + wx) * (uint32_t)kBandW;
+    const uint32_t tileY = (trow * wavesY + wy) * (uint32_t)(2 * NS);
+    if (bandX >= A.w4 || tileY >= A.h2)
+        return; // no barrier anywhere: a wave without work simply leaves
+    BandCtx c;
+    c.bandX = bandX;
+    c.X = bandX + 4 * threadIdx.x;
+    c.laneValid = c.X < A.w4;
+    c.Xc = c.laneValid ? c.X : 0;
+    c.cxb = A.cx0 + (int)(bandX >> 1);
+    TileRaw<YT, SUB, BIL, kNeedA, NS, 1> raw;
+    loadTile<YT, SUB, BIL, kNeedA, NS, 1>(A, c, tileY, raw);
+    f2(*rows)[kRowPitch] = reinterpret_cast<f2(*)[kRowPitch]>(lds + (size_t)wave * (BIL ? SR::kRows : 1) * kRowPitch);
+    if constexpr (BIL) {
+        stageTile<YT, SUB, kNeedA, NS, 1>(A, raw, rows);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, 1>(A, c, tileY, raw, rows, xchg ? xchg + wave : nullptr);
+}
+
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+__global__ __launch_bounds__(256) void yuvToRgbTileSoloKernel(TileArgs A, PkGeom g)
+{
+    __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
+    if constexpr (sizeof(RT) == 2 && NCH == 4) {
+        __shared__ WideRowExchange xchg[kWavesPerBlock];
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, g, lds, xchg);
+    } else {
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, g, lds, nullptr);
+    }
+}
+
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+__global__ __launch_bounds__(256) void yuvToRgbTileSoloBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
+{
+    __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
+    const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel
+    if constexpr (sizeof(RT) == 2 && NCH == 4) {
+        __shared__ WideRowExchange xchg[kWavesPerBlock];
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, g, lds, xchg);
+    } else {
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, g, lds, nullptr);
+    }
+}
+
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool MUL>
+hipError_t launchSolo(const TileLaunch & L)
+{
+    uint32_t nsw, blocks;
+    PkGeom g;
+    pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
+    const dim3 block(kLanesX, kWavesPerBlock);
+    const dim3 grid(blocks, 1, L.count);
+    if (L.table) {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, L.table, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, g);
+    } else {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, *L.args, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, g);
+    }
+    return hipGetLastError();
+}
+
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool MUL>
 hipError_t launchOne(const TileLaunch & L)
 {
+    if (L.solo)
+        return launchSolo<YT, SUB, BIL, RT, NCH, APLANE, MUL>(L);
     const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(L.blocksPerJob, 1, L.count);
-    if (L.table)
+    if (L.table && L.stripsPerWave >= 2)
+        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
+    else if (L.table)
         hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
     else if (L.stripsPerWave >= 2)
         hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);

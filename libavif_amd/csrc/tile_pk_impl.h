@@ -104,27 +104,6 @@ __device__ __forceinline__ unsigned add3(unsigned a, unsigned b, unsigned c)
     return d;
 }
 
-// Geometry of a launch (kernel argument, lives in SGPRs)
-struct PkGeom
-{
-    uint32_t wavesXLog2;  // waves of a workgroup side by side: 1 << wavesXLog2 in {1, 2, 4}
-    uint32_t tilesX, nTiles;
-    uint32_t magicTilesX; // ceil(2^32 / tilesX): tile / tilesX == mulhi(tile, magic) while tile * tilesX < 2^32; 0 when tilesX == 1
-    uint32_t chunk;       // tiles per XCD chunk (a few tile rows), 0 = plain raster order
-    uint32_t magicChunk;
-};
-
-__device__ __forceinline__ uint32_t pkTileOf(uint32_t b, const PkGeom & g)
-{
-    if (g.chunk == 0)
-        return b;
-    // workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it): XCD x takes the x-th chunk of every
-    // group of 8 chunks, so vertically adjacent tiles (which share chroma halo rows) mostly meet in one L2
-    const uint32_t xcd = b & 7u, slot = b >> 3;
-    const uint32_t sc = g.magicChunk ? __umulhi(slot, g.magicChunk) : slot, within = slot - sc * g.chunk;
-    return (sc * 8u + xcd) * g.chunk + within;
-}
-
 // ---- chroma neighbourhood: loads of one staging round (8 columns of both planes per lane) ----
 template <int SUB, int NSW>
 __device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int rowBase, int round, u2 & uD, u2 & vD)
@@ -211,7 +190,7 @@ __device__ __forceinline__ void pkRow(const TileArgs & A, unsigned yraw, unsigne
             araw = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
         }
     }
-    unsigned px[4];
+    unsigned px[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         unsigned X, G, Z;
@@ -230,6 +209,15 @@ __device__ __forceinline__ void pkRow(const TileArgs & A, unsigned yraw, unsigne
             G = satPkU8(pkAshr6(G));
             Z = satPkU8(pkAshr6(Z));
         }
+        if constexpr (NCH == 2) {
+            // RGB565 (I420ToRGB565Matrix / I422ToRGB565Matrix: b >> 3 | (g >> 2) << 5 | (r >> 3) << 11, src/reformat.c:619): both pixels of
+            // the pair at once, one per 16-bit half (masks first, so plain 32-bit shifts cannot leak across the halves)
+            const unsigned xh = __builtin_amdgcn_perm(0u, X, 0x0c010c00u) & 0x00f800f8u; // x0 . x1 .
+            const unsigned gh = __builtin_amdgcn_perm(0u, G, 0x0c010c00u) & 0x00fc00fcu;
+            const unsigned zh = __builtin_amdgcn_perm(0u, Z, 0x0c010c00u) & 0x00f800f8u;
+            px[p] = (zh << 8) | ((gh << 3) | (xh >> 3));
+            continue;
+        }
         const unsigned XG = __builtin_amdgcn_perm(G, X, 0x05010400u); // x0 g0 x1 g1
         unsigned ZA = Z;                                              // z0 z1 . .
         if constexpr (APLANE)
@@ -243,7 +231,9 @@ __device__ __forceinline__ void pkRow(const TileArgs & A, unsigned yraw, unsigne
     }
     if (!laneValid)
         return;
-    if constexpr (NCH == 4) {
+    if constexpr (NCH == 2) {
+        storeVec(A.rgb, off, (u2) { px[0], px[1] }, true); // four 16-bit pixels
+    } else if constexpr (NCH == 4) {
         storeVec(A.rgb, off, (u4) { px[0], px[1], px[2], px[3] }, true);
     } else {
         // pixels are (x g z .): 12 bytes x0 g0 z0 x1 | g1 z1 x2 g2 | z2 x3 g3 z3
@@ -566,30 +556,6 @@ __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __
     __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * kRingWords];
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
     pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED>(job, g, lds);
-}
-
-// Launch geometry: strips per wave, waves side by side, tile order (TuningBits; tests/tools/geometry_sweep.py)
-inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t * nsw, PkGeom * g, uint32_t * blocks)
-{
-    const uint32_t bands = (w4 + (uint32_t)kBandW - 1) / (uint32_t)kBandW, strips = h2 / 2;
-    uint32_t ns = L.pkStrips; // 0 = automatic
-    if (ns != 2 && ns != 4)
-        ns = ((uint64_t)bands * ((strips + 3) / 4) * L.count >= 2048) ? 4 : 2; // small jobs: more, smaller waves
-    uint32_t wxl = L.wavesXLog2 <= 2 ? L.wavesXLog2 : 2;
-    while (wxl > 0 && (1u << wxl) > bands)
-        --wxl;
-    const uint32_t wavesX = 1u << wxl, wavesY = 4u / wavesX;
-    g->wavesXLog2 = wxl;
-    g->tilesX = (bands + wavesX - 1) / wavesX;
-    const uint32_t tilesY = (strips + ns * wavesY - 1) / (ns * wavesY);
-    g->nTiles = g->tilesX * tilesY;
-    auto magic = [](uint32_t d) { return d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0u; };
-    g->magicTilesX = magic(g->tilesX);
-    g->chunk = L.chunkRows * g->tilesX;
-    g->magicChunk = magic(g->chunk);
-    *nsw = ns;
-    // chunked order: padded to whole groups of 8 chunks (workgroups beyond the last tile leave at once)
-    *blocks = g->chunk ? ((g->nTiles + 8 * g->chunk - 1) / (8 * g->chunk)) * 8 * g->chunk : g->nTiles;
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, bool MAPPED>

@@ -212,6 +212,7 @@ struct TileLaunch
     uint32_t wavesXLog2;    // waves of a workgroup side by side (1 << n), the rest stacked
     uint32_t chunkRows;     // tile rows per XCD chunk, 0 = plain raster order
     bool mapped;            // stores go through the jobs' PixelMap
+    bool solo;              // fp32 / 10-12-bit integer families: the wave-private kernels instead of the cooperative runs
     hipStream_t stream;
 };
 

@@ -128,3 +128,22 @@ def test_grid_farm_integer_path_equals_whole_canvas(hip_auto_arithmetic):
         out = H.make_y2r_output(case)
         farm.convert_shard(canvas, out, rects, 0, 1, conv)
         assert np.array_equal(out.pixels, whole), (case.ident(), H.describe_diff(whole, out.pixels))
+
+
+def test_rgb565_through_the_packed_kernels(hip_auto_arithmetic):
+    """RGB565 (Android's bitmap format): libyuv's I420ToRGB565Matrix / I422ToRGB565Matrix in the packed 16-bit tiled kernels, byte for
+    byte like the integer-path oracle; formats libyuv has no 565 entry for stay with the universal kernels."""
+    seen = set()
+    for fmt in (abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_PIXEL_FORMAT_YUV422, abi.AVIF_PIXEL_FORMAT_YUV444):
+        for (w, h) in ((1024, 64), (777, 35), (2052, 130)):
+            for rng in (abi.AVIF_RANGE_LIMITED, abi.AVIF_RANGE_FULL):
+                for mc in (1, 6, 9):
+                    c = H.Y2RCase(w, h, yuv_format=fmt, yuv_range=rng, matrix=mc, rgb_format=abi.AVIF_RGB_FORMAT_RGB_565, avoid_libyuv=False,
+                                  upsampling=abi.AVIF_CHROMA_UPSAMPLING_FASTEST)
+                    for be in (H.hip_host_backend(), H.HipDeviceBackend()):
+                        ro, po = H.run_y2r(H.oracle_libyuv_backend(), c)
+                        rh, ph = H.run_y2r(be, c)
+                        assert ro == rh and np.array_equal(po, ph), (c.ident(), native.last_kernel(), H.describe_diff(po, ph))
+                        seen.add((fmt, native.last_kernel()))
+    assert (abi.AVIF_PIXEL_FORMAT_YUV420, "yuv2rgb_fixed_tile<u8,420,nearest,rgb565_8,pk16>") in seen, seen
+    assert (abi.AVIF_PIXEL_FORMAT_YUV422, "yuv2rgb_fixed_tile<u8,422,nearest,rgb565_8,pk16>") in seen, seen

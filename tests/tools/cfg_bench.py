@@ -4,6 +4,7 @@ buffers), in both arithmetic families.  Prints one JSON line per (configuration,
 Algorithmic bytes per pixel are SURVEY.md 8d's figures."""
 import ctypes as C
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -12,6 +13,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from libavif_amd import abi, device, native, synth  # noqa: E402
 
 lib = native.load()
+if os.environ.get("AVIFHIP_TUNING"):  # A/B measurements: plan.h TuningBits (e.g. 5 = round 1's cooperative runs for the fp32 / 10-12-bit families)
+    lib.avifhipSetTuning(int(os.environ["AVIFHIP_TUNING"], 0))
 BIL, NEAR = abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, abi.AVIF_CHROMA_UPSAMPLING_NEAREST
 
 
@@ -31,7 +34,11 @@ def run(name):
     for arith, avoid in (("float", True), ("integer", False)):
         lib.avifhipSetArithmetic(1 if arith == "float" else 0)
         px, bpp, ms = 0, 0.0, None
-        if name in ("cfg2", "cfg2n", "cfg2_4k"):
+        if name == "cfg2_565":
+            # Android's bitmap format (android_jni/.../libavif_jni.cc:206-223): 8K 8-bit 4:2:0 -> RGB565, nearest (libyuv has no filtering 565 entry)
+            pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB_565)
+            px, bpp, ms = 7680 * 4320, 3.5, time_y2r(pair)
+        elif name in ("cfg2", "cfg2n", "cfg2_4k"):
             w, h = (3840, 2160) if name == "cfg2_4k" else (7680, 4320)  # the north star asks for 4K planes beside the 8K headline
             pair = y2r(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR if name == "cfg2n" else BIL, avoid=avoid)
             px, bpp, ms = w * h, 5.5, time_y2r(pair)
