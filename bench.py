@@ -184,6 +184,12 @@ def main():
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
+            # RCCL writes the banner through C stdio, which is block-buffered when stdout is not a terminal: without this flush the
+            # text would sit in the buffer and come out on the REAL stdout at exit, after the JSON line
+            try:
+                C.CDLL(None).fflush(None)
+            except Exception:
+                pass
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
