@@ -171,13 +171,23 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
         if (p.fxAlpha == FXA_FLOAT && s.depth != o.depth && !s.exactDiv)
             return false;
     } else {
-        if (p.postMulFx || p.identityCopy || s.mode != MODE_COEFF)
+        if (p.postMulFx)
             return false;
-        if (!s.exactDiv)
-            return false; // a divisor off the verified list (exactdiv.h): the universal kernel divides the IEEE way
+        if (p.identityCopy) {
+            // lossless RGB in 8-bit 4:4:4 planes: a byte shuffle inside the 4:4:4 kernel (no arithmetic, no divisors to verify)
+            if (p.inLoopMul != MUL_NONE || p.postMul != MUL_NONE || s.chanBytes != 1 || o.chanBytes != 1 || s.format != AVIF_PIXEL_FORMAT_YUV444)
+                return false;
+        } else {
+            if (s.mode != MODE_COEFF)
+                return false;
+            if (!s.exactDiv)
+                return false; // a divisor off the verified list (exactdiv.h): the universal kernel divides the IEEE way
+        }
     }
-    if (o.isGray || o.isFloat)
+    if (o.isGray)
         return false;
+    if (o.isFloat && (p.arith == ARITH_LIBYUV || o.chanBytes != 2))
+        return false; // half-float outputs (Android's RGBA_F16 bitmaps): 16-bit containers, the fp32 kernels convert at the store
     if (o.is565) {
         // RGB565 (Android's bitmap format, android_jni/.../libavif_jni.cc:206-223): libyuv's I420ToRGB565Matrix / I422ToRGB565Matrix --
         // 8-bit 4:2:0 / 4:2:2 planes, nearest upsampling -- in the packed 16-bit kernels; everything else 565 stays universal

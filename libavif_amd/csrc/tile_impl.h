@@ -639,6 +639,24 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                 a[i] = APLANE ? alphaFromPlane(A, av[i]) : A.rgbMax;
             const uint32_t off = (sy + r) * A.rgbPitch + X * kPixBytes;
 
+            if constexpr (SUB == SUB_444 && sizeof(YT) == 1 && sizeof(RT) == 1 && !HASMUL) {
+                // identity matrix, 8 bits in and out, full range (lossless RGB in 4:4:4 planes): G = Y, B = Cb, R = Cr, a byte shuffle
+                // (avifImageIdentity8ToRGB8ColorFullRange, src/reformat.c:1278-1309); `u` feeds the first colour channel (tile_shared.h)
+                if (A.identityCopy) { // wave-uniform
+                    unsigned yb[4], ub[4], vb[4];
+                    decode4<YT>(raw[k].y[r], yb);
+                    decode4<YT>(raw[k].u[r], ub);
+                    decode4<YT>(raw[k].v[r], vb);
+                    PixelOut q[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        q[i].r = ub[i], q[i].g = yb[i], q[i].b = vb[i];
+                    if (laneValid)
+                        store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
+                    continue;
+                }
+            }
+
             if constexpr (sizeof(RT) == 1 && !HASMUL) {
                 // 8-bit outputs: t = 0.5f + c * 255, then truncate + saturate + pack in one instruction per channel
                 const f2 half = splat(0.5f), mx = splat(A.rgbMaxF);
@@ -677,6 +695,15 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     q[i] = finishPixel<HASMUL>(A, br[i].x, g[i], br[i].y, av[i], a[i]); // q.r = first colour, q.b = third
+                if constexpr (sizeof(RT) == 2) {
+                    if (A.f16Mul != 0.0f) { // wave-uniform: avifRGBImageToF16 (src/reformat.c:1419-1443) on every channel, alpha included
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            q[i].r = toHalfBits(q[i].r, A.f16Mul), q[i].g = toHalfBits(q[i].g, A.f16Mul), q[i].b = toHalfBits(q[i].b, A.f16Mul);
+                            a[i] = toHalfBits(a[i], A.f16Mul);
+                        }
+                    }
+                }
                 if constexpr (sizeof(RT) == 2 && NCH == 4) {
                     store4WideRgba(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, a, alphaFirst, c.bandX, A.w4, xchg[wv]);
                 } else {

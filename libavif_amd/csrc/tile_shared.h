@@ -39,7 +39,9 @@ struct TileArgs
     // (Z), and cB / cU (cR / cV) are the coefficients of that first (third) channel -- so no kernel selects channels per pixel
     uint32_t slotX, slotZ;
     int32_t alphaRescale;                // alpha plane depth differs from the rgb depth (src/alpha.c:84-103)
+    float f16Mul;                        // half-float outputs (avifRGBImageToF16, src/reformat.c:1419-1443): the subnormal-trick multiplier, 0 = integer output
     int32_t inLoopMul, postMul;          // MulMode
+    int32_t identityCopy;                // 8-bit full-range identity matrix: bytes are copied (src/reformat.c:1278-1309)
     uint32_t tuning;
     // fused crop / rotate / mirror (plan.h PixelMap): `rgb` is then the destination buffer's first pixel, and canvas pixel
     // (mapX0 + X, mapY0 + row) of the rectangle's pixel (X, row) goes where the map says.  Packed 16-bit kernels only.
@@ -131,7 +133,9 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
         tf = A.cU, A.cU = A.cV, A.cV = tf;
     }
     A.alphaRescale = (s.depth != o.depth) ? 1 : 0;
+    A.f16Mul = o.isFloat ? o.f16Multiplier : 0.0f;
     A.inLoopMul = p.inLoopMul, A.postMul = p.postMul;
+    A.identityCopy = p.identityCopy;
     A.tuning = p.tuning;
     if (p.arith == ARITH_LIBYUV) {
         const FixedPointMatrix & m = p.fx;

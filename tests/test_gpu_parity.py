@@ -47,7 +47,27 @@ def test_yuv_to_rgb_small_sweep_device(hip):
 def test_yuv_to_rgb_tiled_sweep_host(hip):
     hip.avifhipSetTiledKernels(1)
     kernels = _compare_y2r(H.hip_host_backend(), H.oracle_backend(), H.y2r_sweep(TILED, n_random=500, seed=5), "yuv2rgb_tile")
-    assert "yuv2rgb_generic" in kernels  # gray / 565 / identity / float outputs still go through the universal kernel
+    assert "yuv2rgb_generic" in kernels  # gray outputs, YCgCo matrices, wider identity copies still go through the universal kernel
+
+
+def test_half_float_and_identity_copy_use_the_tiled_kernels(hip):
+    """Half-float RGB(A) outputs (avifRGBImageToF16 fused, src/reformat.c:1419-1443) and the 8-bit identity byte shuffle
+    (src/reformat.c:1278-1309) are served by the bandwidth-tuned kernels, byte-exact."""
+    hip.avifhipSetTiledKernels(1)
+    cases = []
+    for (w, h) in TILED:
+        for fmt, alpha, yf, up in ((1, True, 1, 3), (1, False, 3, 4), (0, False, 2, 3), (5, True, 3, 3), (2, True, 4, 3)):
+            cases.append(H.Y2RCase(w, h, rgb_format=fmt, rgb_depth=16, is_float=True, alpha=alpha, yuv_depth=10, yuv_format=yf, upsampling=up,
+                                   matrix=1, yuv_range=0, row_pad=6))
+        cases.append(H.Y2RCase(w, h, rgb_format=1, rgb_depth=16, is_float=True, alpha=True, yuv_depth=12, yuv_format=3, matrix=9, yuv_range=1,
+                               rgb_premultiplied=True))
+        for fmt, alpha in ((1, False), (1, True), (0, False), (4, True), (5, False), (3, False)):
+            cases.append(H.Y2RCase(w, h, rgb_format=fmt, rgb_depth=8, yuv_depth=8, yuv_format=1, matrix=0, yuv_range=1, alpha=alpha, row_pad=64))
+    for c in cases:
+        H.run_y2r(H.HipDeviceBackend(), c)
+        assert native.last_kernel().startswith("yuv2rgb_tile"), (c.ident(), native.last_kernel())
+    _compare_y2r(H.HipDeviceBackend(), H.oracle_backend(), cases)
+    _compare_y2r(H.hip_host_backend(), H.oracle_backend(), cases)
 
 
 def test_yuv_to_rgb_tiled_sweep_device(hip):

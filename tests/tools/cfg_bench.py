@@ -38,6 +38,22 @@ def run(name):
             # Android's bitmap format (android_jni/.../libavif_jni.cc:206-223): 8K 8-bit 4:2:0 -> RGB565, nearest (libyuv has no filtering 565 entry)
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB_565)
             px, bpp, ms = 7680 * 4320, 3.5, time_y2r(pair)
+        elif name in ("f16_420", "f16_444a"):
+            # half-float outputs (what an HDR compositor takes): 8K 10-bit -> RGBA F16; 4:2:0 bilinear without alpha (1.5*2 + 8 B/px), 4:4:4 with alpha (4*2 + 8)
+            if arith == "integer":
+                continue  # libyuv has no 16-bit outputs: one arithmetic
+            a444 = name == "f16_444a"
+            img = abi.make_yuv(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444 if a444 else abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 9, with_alpha=a444)
+            synth.fill_yuv(img, 0x4242)
+            rgb = abi.make_rgb(7680, 4320, 16, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=avoid, allocate=False)
+            rgb.struct.isFloat = 1
+            pair = (device.DeviceYUV(img), device.DeviceRGB(rgb))
+            px, bpp, ms = 7680 * 4320, (16.0 if a444 else 11.0), time_y2r(pair, 20)
+        elif name in ("ident8", "ident8rgb"):
+            # lossless RGB stored as 8-bit 4:4:4 GBR planes (identity matrix, full range): a byte shuffle, 3 + 4 (or 3 + 3) B/px
+            fmt = abi.AVIF_RGB_FORMAT_RGB if name == "ident8rgb" else abi.AVIF_RGB_FORMAT_RGBA
+            pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 0, 8, avoid=avoid, rgb_format=fmt)
+            px, bpp, ms = 7680 * 4320, (6.0 if name == "ident8rgb" else 7.0), time_y2r(pair)
         elif name in ("cfg2", "cfg2n", "cfg2_4k"):
             w, h = (3840, 2160) if name == "cfg2_4k" else (7680, 4320)  # the north star asks for 4K planes beside the 8K headline
             pair = y2r(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR if name == "cfg2n" else BIL, avoid=avoid)
