@@ -182,7 +182,10 @@ avifResult ensureContext()
         HIP_TRY(hipEventCreateWithFlags(&tls.bandUp[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&tls.bandDone[b], hipEventDisableTiming));
     }
-    HIP_TRY(hipEventCreateWithFlags(&tls.tableCopied, hipEventDisableTiming));
+    for (int k = 0; k < Context::kTableRing; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&tls.tableCopied[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&tls.tableConsumed[k], hipEventDisableTiming));
+    }
     HIP_TRY(hipEventCreateWithFlags(&tls.uploadCopied, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&tls.scratchUsed, hipEventDisableTiming));
     return AVIF_RESULT_OK;
@@ -860,19 +863,23 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
     const size_t tileBytes = (tileBatchTableBytes(count) + 255) & ~(size_t)255;
     const size_t planBytes = (size_t)count * sizeof(YuvToRgbPlan);
     const size_t bytes = tileBytes + 2 * planBytes;
+    constexpr int kRing = Context::kTableRing;
     if (bytes > tls.pinnedTableCapacity) {
         if (tls.pinnedTable) {
-            HIP_TRY(hipEventSynchronize(tls.tableCopied));
+            for (int k = 0; k < kRing; ++k)
+                HIP_TRY(hipEventSynchronize(tls.tableCopied[k]));
             HIP_TRY(hipHostFree(tls.pinnedTable));
             tls.pinnedTable = nullptr;
             tls.pinnedTableCapacity = 0;
+            HIP_TRY(hipDeviceSynchronize()); // the slots' device slices move as well: no batch may still be reading the old ones
         }
-        HIP_TRY(hipHostMalloc(&tls.pinnedTable, bytes, hipHostMallocDefault));
-        tls.pinnedTableCapacity = bytes;
-    } else {
-        HIP_TRY(hipEventSynchronize(tls.tableCopied)); // previous upload must have consumed the table
+        const size_t slotBytes = (bytes + 4095) & ~(size_t)4095;
+        HIP_TRY(hipHostMalloc(&tls.pinnedTable, slotBytes * kRing, hipHostMallocDefault));
+        tls.pinnedTableCapacity = slotBytes;
     }
-    uint8_t * pinned = (uint8_t *)tls.pinnedTable;
+    const uint32_t slot = tls.tableSlot++ % (uint32_t)kRing;
+    HIP_TRY(hipEventSynchronize(tls.tableCopied[slot])); // the upload of kRing batches ago has left this slot's pinned memory
+    uint8_t * pinned = (uint8_t *)tls.pinnedTable + (size_t)slot * tls.pinnedTableCapacity;
     YuvToRgbPlan * plansA = (YuvToRgbPlan *)(pinned + tileBytes);
     YuvToRgbPlan * plansB = plansA + count;
     uint32_t maxW = 0, maxH = 0;
@@ -900,14 +907,20 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         if (v < 0 || v != variant)
             allTiled = false;
     }
-    const avifResult rr = reserve(tls.table, bytes);
+    const avifResult rr = reserve(tls.table, tls.pinnedTableCapacity * kRing); // (growing it waits for the device: nothing reads the old one then)
     if (rr != AVIF_RESULT_OK)
         return rr;
     hipStream_t stream = pickStream(hipStream);
-    ScratchScope scratch(stream); // tls.table may still be read by a batch enqueued on another stream
-    if (scratch.result != AVIF_RESULT_OK)
-        return scratch.result;
-    uint8_t * dev = (uint8_t *)tls.table.ptr;
+    uint8_t * dev = (uint8_t *)tls.table.ptr + (size_t)slot * tls.pinnedTableCapacity;
+    // The table crosses the link on `upStream` while earlier batches compute on `stream`: the upload waits only for the kernels that read
+    // this slot's device slice kRing batches ago (on whichever stream they ran), the batch's kernels wait for the upload.
+    HIP_TRY(hipStreamWaitEvent(tls.upStream, tls.tableConsumed[slot], 0));
+    struct MarkConsumed
+    {
+        hipEvent_t ev;
+        hipStream_t s;
+        ~MarkConsumed() { (void)hipEventRecord(ev, s); }
+    } markConsumed = { tls.tableConsumed[slot], stream };
     hipError_t e = hipSuccess;
     if (allTiled) {
         const YuvToRgbPlan representative = plansA[0];
@@ -925,16 +938,18 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
             restH = plansB[k].h > restH ? plansB[k].h : restH;
             restMaxW = w4 > restMaxW ? w4 : restMaxW;
         }
-        HIP_TRY(hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipEventRecord(tls.tableCopied, stream));
+        HIP_TRY(hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, tls.upStream));
+        HIP_TRY(hipEventRecord(tls.tableCopied[slot], tls.upStream));
+        HIP_TRY(hipStreamWaitEvent(stream, tls.tableCopied[slot], 0));
         e = launchYuvToRgbTileBatch(dev, representative, count, maxW, maxH, stream, &tls.lastKernel);
         if (e == hipSuccess && restW)
             e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)(dev + tileBytes), count, restW, restMaxH, stream);
         if (e == hipSuccess && restH)
             e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)(dev + tileBytes) + count, count, restMaxW, restH, stream);
     } else {
-        HIP_TRY(hipMemcpyAsync(dev + tileBytes, plansA, planBytes, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipEventRecord(tls.tableCopied, stream));
+        HIP_TRY(hipMemcpyAsync(dev + tileBytes, plansA, planBytes, hipMemcpyHostToDevice, tls.upStream));
+        HIP_TRY(hipEventRecord(tls.tableCopied[slot], tls.upStream));
+        HIP_TRY(hipStreamWaitEvent(stream, tls.tableCopied[slot], 0));
         tls.lastKernel = "yuv2rgb_generic_batch";
         e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)(dev + tileBytes), count, maxW, maxH, stream);
     }

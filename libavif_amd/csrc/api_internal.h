@@ -118,9 +118,14 @@ struct Context
     Scratch gainMap[11]; // gain maps: [0] output pixels, [1] gain map as RGB, [2] tables, [3] statistics / partials, [4] scaled planes, [5] base pixels;
                          // computation: [6] tables, [7] ratios, [8] histograms, [9] alternate pixels, [10] gain-map planes
     GainMapTableCache gainMapCache; // what gainMap[2] holds
+    // batch descriptor tables travel through a ring of kTableRing slots (pinned host memory + the matching slice of `table`), uploaded on
+    // `upStream`: the host prepares batch n + 1 and its table crosses the link while batch n computes (api.cpp: batchAsyncImpl)
+    static constexpr int kTableRing = 4;
     void * pinnedTable = nullptr;
-    size_t pinnedTableCapacity = 0;
-    hipEvent_t tableCopied = nullptr;
+    size_t pinnedTableCapacity = 0; // bytes per slot
+    uint32_t tableSlot = 0;
+    hipEvent_t tableCopied[kTableRing] = {};   // the slot's upload has left the pinned memory (and the device slice holds it)
+    hipEvent_t tableConsumed[kTableRing] = {}; // the kernels reading the slot's device slice are done
     void * pinnedUpload = nullptr; // staging for small host tables (grid tile tables, scale schedules)
     size_t pinnedUploadCapacity = 0;
     hipEvent_t uploadCopied = nullptr;
@@ -156,8 +161,12 @@ struct Context
                 (void)hipFree(g.ptr);
         if (pinnedTable)
             (void)hipHostFree(pinnedTable);
-        if (tableCopied)
-            (void)hipEventDestroy(tableCopied);
+        for (int k = 0; k < kTableRing; ++k) {
+            if (tableCopied[k])
+                (void)hipEventDestroy(tableCopied[k]);
+            if (tableConsumed[k])
+                (void)hipEventDestroy(tableConsumed[k]);
+        }
         if (pinnedUpload)
             (void)hipHostFree(pinnedUpload);
         if (uploadCopied)

@@ -49,6 +49,7 @@ TileKey keyFor(const YuvToRgbPlan & p)
     k.hasMul = (p.inLoopMul != MUL_NONE) || (p.postMul != MUL_NONE);
     k.alphaPlane = k.nch == 4 && p.alphaSource == ALPHA_PLANE;
     k.mapped = p.rgb.map.on != 0;
+    k.wideDownshift = k.fixedPoint && k.wideYuv && p.fxDownshift != 0;
     return k;
 }
 
@@ -57,12 +58,12 @@ bool aligned(const void * ptr, uint32_t rowBytes, uint32_t a)
     return ((uintptr_t)ptr % a) == 0 && (rowBytes % a) == 0;
 }
 
-const char * kernelNameFor(const TileKey & k)
+const char * kernelNameFor(const TileKey & k, uint32_t tuning)
 {
     static thread_local char name[112];
     static const char * subs[] = { "444", "422", "420", "400" };
     // ",pk16": the packed 16-bit kernels (tile_pk_impl.h) serve 8-bit planes of the integer path unless a post-pass follows
-    const bool packed = k.fixedPoint && !k.wideYuv && !k.hasMul;
+    const bool packed = k.fixedPoint && !k.hasMul && (!k.wideYuv || (tuning & TUNE_COOPERATIVE) == 0);
     snprintf(name, sizeof(name), "%s<%s,%s,%s,%s%d%s%s%s%s>", k.fixedPoint ? "yuv2rgb_fixed_tile" : "yuv2rgb_tile", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
              k.nch == 4 ? "rgba" : (k.nch == 2 ? "rgb565_" : "rgb"), k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "", packed ? ",pk16" : "", k.mapped ? ",mapped" : "");
     return name;
@@ -240,14 +241,15 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
         return -1;
     const TileKey k = keyFor(plan);
     return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) | ((k.nch == 2 ? 1 : 0) << 10) |
-           ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7) | ((k.fixedPoint ? 1 : 0) << 8) | ((k.mapped ? 1 : 0) << 9);
+           ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7) | ((k.fixedPoint ? 1 : 0) << 8) | ((k.mapped ? 1 : 0) << 9) |
+           ((k.wideDownshift ? 1 : 0) << 11);
 }
 
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)
 {
     const TileKey k = keyFor(plan);
     if (kernelName)
-        *kernelName = kernelNameFor(k);
+        *kernelName = kernelNameFor(k, plan.tuning);
     const TileArgs A = distillArgs(plan);
     TileLaunch L;
     L.args = &A;
@@ -257,6 +259,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     L.mapped = k.mapped;
     decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)A.w4 * A.h2) || (plan.tuning & TUNE_SOLO_ALWAYS));
+    L.pkWide = (plan.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift;
     hipError_t e = launchFamily(k, L);
     if (e != hipSuccess)
         return e;
@@ -294,7 +297,7 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
 {
     const TileKey k = keyFor(representative);
     if (kernelName)
-        *kernelName = kernelNameFor(k);
+        *kernelName = kernelNameFor(k, representative.tuning);
     TileLaunch L;
     L.args = nullptr;
     L.table = static_cast<const TileArgs *>(deviceTileTable);
@@ -303,6 +306,14 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
     L.mapped = k.mapped;
     decompose(representative.tuning, maxW & ~3u, maxH & ~1u, count, true, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)(maxW & ~3u) * (maxH & ~1u) * count) || (representative.tuning & TUNE_SOLO_ALWAYS));
+    L.pkWide = (representative.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift;
+    // A batch whose bytes exceed the Infinity Cache (256 MB) streams from and to HBM whatever the tile order; the per-XCD chunks, which pay
+    // when planes are cache-resident, then only scatter the DRAM accesses: plain raster order (tests/tools/pkbench_wide.hip, 64 tiles of
+    // 1080p 10-bit -> RGBA8: 188 -> 175 us)
+    const double bytesPerPixel = (double)representative.yuv.chanBytes * (k.sub == SUB_444 ? 3.0 : k.sub == SUB_422 ? 2.0 : k.sub == SUB_420 ? 1.5 : 1.0) +
+                                 (double)representative.rgb.pixBytes + (k.alphaPlane || k.hasMul ? (double)representative.yuv.chanBytes : 0.0);
+    if ((double)maxW * maxH * count * bytesPerPixel > 192.0 * 1048576.0 && ((representative.tuning >> TUNE_CHUNK_SHIFT) & 0xfu) == 0)
+        L.chunkRows = 0;
     return launchFamily(k, L);
 }
 

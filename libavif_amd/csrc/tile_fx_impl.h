@@ -411,6 +411,11 @@ hipError_t launchOneFx(const TileLaunch & L)
     // 8-bit planes without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)
     if constexpr (sizeof(YT) == 1 && !MUL)
         return launchPk<SUB, BIL, NCH, APLANE>(L);
+    // 10- / 12-bit planes without a post-pass: the same kernels behind a front end for 16-bit containers
+    if constexpr (sizeof(YT) == 2 && !MUL) {
+        if (L.pkWide)
+            return launchPkWide<SUB, BIL, NCH, APLANE>(L);
+    }
     if (L.solo)
         return launchSoloFx<YT, SUB, BIL, NCH, APLANE, MUL>(L);
     const dim3 block(kLanesX, kWavesPerBlock);

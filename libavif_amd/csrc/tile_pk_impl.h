@@ -26,8 +26,17 @@
 //   * libyuv's "YVU trick" (src/reformat_libyuv.c:386-423) is applied to the plane pointers (tile_shared.h): `u` feeds the
 //     first colour byte X.
 // Scope: 8-bit planes 4:4:4 / 4:2:2 / 4:2:0 / 4:0:0, nearest or bilinear, RGB / BGR / RGBA / BGRA / ARGB / ABGR, alpha opaque
-// or copied from the plane.  Deeper planes and the attenuate / unattenuate post-pass stay with tile_fx_impl.h.
+// or copied from the plane.  10- and 12-bit planes (template parameter WIDE) enter the same arithmetic through one of libavif's two
+// routes (src/reformat_libyuv.c:714-772, :906-930):
+//   * WIDE_NATIVE: libyuv's I010 / I210 / I410 / I012 entries -- y32 = (y << 6) | (y >> 4), chroma filtered at the planes' depth and only
+//     then cut to a byte (clamp255(c >> 2)): staged words keep 16-bit fields (u | v << 16) + rounding, the filtered fields are paired up
+//     per plane and reduced with three packed instructions (shift, min, subtract 128);
+//   * WIDE_DOWNSHIFT: no high-bit-depth entry exists, libavif reduces every sample to 8 bits first (clamp255(s >> (depth - 8))) and calls
+//     the 8-bit entry: samples are narrowed right after the load, everything downstream is the 8-bit kernel.
+// The attenuate / unattenuate post-pass stays with tile_fx_impl.h.
 #pragma once
+
+#include <type_traits>
 
 #include "pixel_fixed.h"
 #include "tile_impl.h"
@@ -38,6 +47,17 @@ namespace tile {
 constexpr int kPkPitch = 140;   // words per staged chroma row: entry c + 5 holds chroma column cxb + c, c in [-4, 131]
 constexpr int kPkGroups = 17;   // 8-column groups per staged row
 constexpr int kPkRowsPerRound = 3; // 3 x 17 = 51 of the wave's 64 lanes load 8 columns of both planes per round
+
+enum PkWide { WIDE_NONE = 0, WIDE_NATIVE = 1, WIDE_DOWNSHIFT = 2 }; // 8-bit planes | 16-bit containers through libyuv's high-bit-depth entries | ... reduced to 8 bits first
+
+// what a lane holds of a row: 4 samples (a dword of bytes, or two dwords of 16-bit samples) / of a staged chroma row: 8 columns
+template <int WIDE>
+struct PkTypes
+{
+    typedef typename std::conditional<WIDE != WIDE_NONE, u2, unsigned>::type Row4;
+    typedef typename std::conditional<WIDE != WIDE_NONE, u4, u2>::type Col8;
+    static constexpr uint32_t kBytes = (WIDE != WIDE_NONE) ? 2 : 1;
+};
 
 template <int SUB, int NSW>
 struct PkStage
@@ -76,6 +96,36 @@ __device__ __forceinline__ unsigned pkSubK(unsigned a, unsigned k)
     asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
     return d;
 }
+// logical shifts of both halves by a wave-uniform amount (both halves of `k` hold it), unsigned minimum with a wave-uniform pair
+__device__ __forceinline__ unsigned pkLshrK(unsigned a, unsigned k)
+{
+    unsigned d;
+    asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(d) : "s"(k), "v"(a));
+    return d;
+}
+__device__ __forceinline__ unsigned pkLshlK(unsigned a, unsigned k)
+{
+    unsigned d;
+    asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "s"(k), "v"(a));
+    return d;
+}
+__device__ __forceinline__ unsigned pkMinK(unsigned a, unsigned k)
+{
+    unsigned d;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+    return d;
+}
+// clamp255(s >> shift) - 128 on a pair of 16-bit samples: what libyuv's 16-bit readers do to chroma before the matrix
+__device__ __forceinline__ unsigned pkChromaFromWide(unsigned pair, unsigned shiftSplat)
+{
+    return pkSubK(pkMinK(pkLshrK(pair, shiftSplat), 0x00ff00ffu), 0x00800080u);
+}
+// four 16-bit samples (two dwords) to four bytes clamp255(s >> shift)
+__device__ __forceinline__ unsigned pkNarrow(u2 r, unsigned shiftSplat)
+{
+    const unsigned lo = pkMinK(pkLshrK(r.x, shiftSplat), 0x00ff00ffu), hi = pkMinK(pkLshrK(r.y, shiftSplat), 0x00ff00ffu);
+    return __builtin_amdgcn_perm(hi, lo, 0x06040200u);
+}
 // arithmetic shift right of both halves by 6 (the inline constant's low half serves both)
 __device__ __forceinline__ unsigned pkAshr6(unsigned a)
 {
@@ -105,16 +155,18 @@ __device__ __forceinline__ unsigned add3(unsigned a, unsigned b, unsigned c)
 }
 
 // ---- chroma neighbourhood: loads of one staging round (8 columns of both planes per lane) ----
-template <int SUB, int NSW>
-__device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int rowBase, int round, u2 & uD, u2 & vD)
+template <int SUB, int NSW, int WIDE>
+__device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int rowBase, int round, typename PkTypes<WIDE>::Col8 & uD, typename PkTypes<WIDE>::Col8 & vD)
 {
     typedef PkStage<SUB, NSW> ST;
+    typedef typename PkTypes<WIDE>::Col8 Col8;
+    constexpr uint32_t B = PkTypes<WIDE>::kBytes;
     const int lane = threadIdx.x;
     const int rr = (lane * 241) >> 12; // lane / 17
     const int j = lane - rr * kPkGroups;
     const int i = round * kPkRowsPerRound + rr;
-    uD = (u2) { 0, 0 };
-    vD = (u2) { 0, 0 };
+    uD = Col8 {};
+    vD = Col8 {};
     if (rr < kPkRowsPerRound && i < ST::kRows) {
         // coordinates clamp to the job's chroma window (the whole plane unless the canvas is a grid of separately stored tiles):
         // the neighbour of an edge sample is the sample itself, which IS libyuv's edge rule ((3a + a + 2) >> 2 == a)
@@ -122,24 +174,33 @@ __device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int row
         const int cxa = cxb - 4 + 8 * j;
         const uint32_t uRow = (uint32_t)cy * A.uPitch, vRow = (uint32_t)cy * A.vPitch;
         if (cxa >= A.cxMin && cxa + 7 <= A.cxMax) {
-            uD = *reinterpret_cast<const u2 *>(A.u + (uRow + (uint32_t)cxa));
-            vD = *reinterpret_cast<const u2 *>(A.v + (vRow + (uint32_t)cxa));
+            uD = *reinterpret_cast<const Col8 *>(A.u + (uRow + (uint32_t)cxa * B));
+            vD = *reinterpret_cast<const Col8 *>(A.v + (vRow + (uint32_t)cxa * B));
         } else {
             // group cut by the left or right border of the window
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t cx = (uint32_t)clampI(cxa + k, A.cxMin, A.cxMax);
-                const unsigned u = A.u[uRow + cx], v = A.v[vRow + cx];
-                uD[k >> 2] |= u << (8 * (k & 3));
-                vD[k >> 2] |= v << (8 * (k & 3));
+                if constexpr (WIDE != WIDE_NONE) {
+                    const unsigned u = *reinterpret_cast<const uint16_t *>(A.u + (uRow + cx * 2u)), v = *reinterpret_cast<const uint16_t *>(A.v + (vRow + cx * 2u));
+                    uD[k >> 1] |= u << (16 * (k & 1));
+                    vD[k >> 1] |= v << (16 * (k & 1));
+                } else {
+                    const unsigned u = A.u[uRow + cx], v = A.v[vRow + cx];
+                    uD[k >> 2] |= u << (8 * (k & 3));
+                    vD[k >> 2] |= v << (8 * (k & 3));
+                }
             }
         }
     }
 }
 
 // ... and their conversion into staged words
-template <int SUB, int NSW>
-__device__ __forceinline__ void pkStageStore(int round, const u2 & uD, const u2 & vD, unsigned * ring)
+// WIDE_NATIVE: fields keep the planes' depth (held to 12 bits so that no tap sum leaves its field: 16 * 4095 + 8 < 65536 -- libyuv's own
+// 16-bit row functions are defined on that domain, ScaleRowUp2_Bilinear_12); WIDE_DOWNSHIFT: samples are cut to
+// bytes (`shiftSplat` = depth - 8 in both halves) and staged like 8-bit ones.
+template <int SUB, int NSW, int WIDE>
+__device__ __forceinline__ void pkStageStore(int round, const typename PkTypes<WIDE>::Col8 & uD, const typename PkTypes<WIDE>::Col8 & vD, unsigned shiftSplat, unsigned * ring)
 {
     typedef PkStage<SUB, NSW> ST;
     const int lane = threadIdx.x;
@@ -151,8 +212,16 @@ __device__ __forceinline__ void pkStageStore(int round, const u2 & uD, const u2 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             // (u_k | v_k << 16): bytes 0..3 of the selector address the second operand, 4..7 the first, 12 is zero
-            const unsigned p = __builtin_amdgcn_perm(vD[k >> 2], uD[k >> 2], 0x0c040c00u + (unsigned)(k & 3) * 0x00010001u);
-            w[k] = __umul24(p, ST::kScale) + ST::kBias;
+            if constexpr (WIDE == WIDE_NONE) {
+                const unsigned p = __builtin_amdgcn_perm(vD[k >> 2], uD[k >> 2], 0x0c040c00u + (unsigned)(k & 3) * 0x00010001u);
+                w[k] = __umul24(p, ST::kScale) + ST::kBias;
+            } else {
+                const unsigned p = __builtin_amdgcn_perm(vD[k >> 1], uD[k >> 1], (k & 1) ? 0x07060302u : 0x05040100u); // (u_k | v_k << 16), 16-bit fields
+                if constexpr (WIDE == WIDE_DOWNSHIFT)
+                    w[k] = __umul24(pkMinK(pkLshrK(p, shiftSplat), 0x00ff00ffu), ST::kScale) + ST::kBias;
+                else
+                    w[k] = pkMinK(p, 0x0fff0fffu); // (the rounding joins in the filter: a per-sample bias would be multiplied by the weight sum)
+            }
         }
         unsigned * row = ring + i * kPkPitch + 8 * j; // entries 8j + 1 .. 8j + 8
         row[1] = w[0];
@@ -173,23 +242,64 @@ __device__ __forceinline__ void pkReadRow(const unsigned * ring, int q, unsigned
 // ---- one luma row of a lane: 4 pixels from their luma dword, (U, V) pairs and alpha dword ----
 // Up[p] / Vp[p]: (c0 - 128 | c1 - 128) as two int16 for pixel pair p.
 // MAPPED: the four pixel words are handed back in `out` instead of being stored (the caller stores them through the PixelMap).
+// luma of a lane's 4 pixels as two pairs (y1 of pixel 0 | y1 of pixel 1), y1 = ((y32 * yg) >> 16) + yb
+template <int WIDE>
+__device__ __forceinline__ void pkLuma(const TileArgs & A, typename PkTypes<WIDE>::Row4 raw, unsigned Y[2])
+{
+    const TileArgs::Fx & F = A.fx;
+    if constexpr (WIDE == WIDE_NATIVE) {
+        // y32 = (y << 6) | (y >> 4) for 10-bit planes ((y << 4) | (y >> 8) for 12): the sample's bits replicated down to fill 16
+        const unsigned shl = F.yShl * 0x00010001u, shr = F.yShr * 0x00010001u;
+        const unsigned s0 = pkLshlK(raw.x, shl) | pkLshrK(raw.x, shr), s1 = pkLshlK(raw.y, shl) | pkLshrK(raw.y, shr);
+        const unsigned k0 = __umul24(s0 & 0xffffu, F.yMul), k1 = __umul24(s0 >> 16, F.yMul);
+        const unsigned k2 = __umul24(s1 & 0xffffu, F.yMul), k3 = __umul24(s1 >> 16, F.yMul);
+        Y[0] = pkAddK(__builtin_amdgcn_perm(k1, k0, 0x07060302u), F.pkYb);
+        Y[1] = pkAddK(__builtin_amdgcn_perm(k3, k2, 0x07060302u), F.pkYb);
+    } else {
+        unsigned yraw;
+        if constexpr (WIDE == WIDE_DOWNSHIFT)
+            yraw = pkNarrow(raw, F.downshift * 0x00010001u);
+        else
+            yraw = raw;
+        const unsigned k0 = __umul24(yraw & 0xffu, F.yMul8), k1 = __umul24((yraw >> 8) & 0xffu, F.yMul8);
+        const unsigned k2 = __umul24((yraw >> 16) & 0xffu, F.yMul8), k3 = __umul24(yraw >> 24, F.yMul8);
+        Y[0] = pkAddK(__builtin_amdgcn_perm(k1, k0, 0x07060302u), F.pkYb);
+        Y[1] = pkAddK(__builtin_amdgcn_perm(k3, k2, 0x07060302u), F.pkYb);
+    }
+}
+
+// alpha of a lane's 4 pixels as four bytes
+template <int WIDE>
+__device__ __forceinline__ unsigned pkAlpha(const TileArgs & A, typename PkTypes<WIDE>::Row4 raw)
+{
+    if constexpr (WIDE == WIDE_NONE) {
+        if (A.alphaLim.on) { // limited-range alpha plane (wave-uniform): the four bytes to full range
+            const unsigned a0 = alphaToFullRange(A, raw & 0xffu), a1 = alphaToFullRange(A, (raw >> 8) & 0xffu);
+            const unsigned a2 = alphaToFullRange(A, (raw >> 16) & 0xffu), a3 = alphaToFullRange(A, raw >> 24);
+            return a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+        }
+        return raw;
+    } else {
+        const TileArgs::Fx & F = A.fx;
+        if (!A.alphaLim.on && F.alphaMode == FXA_SHIFT) // libyuv's alpha twins: clamp255(a >> (depth - 8)), both wave-uniform
+            return pkNarrow(raw, F.alphaShift * 0x00010001u);
+        unsigned av[4] = { raw.x & 0xffffu, raw.x >> 16, raw.y & 0xffffu, raw.y >> 16 };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (A.alphaLim.on)
+                av[i] = alphaToFullRange(A, av[i]);
+            // libyuv's 255, then avifReformatAlpha over it (src/reformat.c:1464-1486): a shift or the fp32 rescale
+            av[i] = (F.alphaMode == FXA_SHIFT) ? minU(av[i] >> F.alphaShift, 255u) : alphaFromPlane(A, av[i]);
+        }
+        return av[0] | (av[1] << 8) | (av[2] << 16) | (av[3] << 24);
+    }
+}
+
 template <int SUB, int NCH, bool APLANE, bool MAPPED>
-__device__ __forceinline__ void pkRow(const TileArgs & A, unsigned yraw, unsigned araw, const unsigned Up[2], const unsigned Vp[2], uint32_t off, bool laneValid,
+__device__ __forceinline__ void pkRow(const TileArgs & A, const unsigned Y[2], unsigned araw, const unsigned Up[2], const unsigned Vp[2], uint32_t off, bool laneValid,
                                       unsigned out[4])
 {
     const TileArgs::Fx & F = A.fx;
-    const unsigned k0 = __umul24(yraw & 0xffu, F.yMul8), k1 = __umul24((yraw >> 8) & 0xffu, F.yMul8);
-    const unsigned k2 = __umul24((yraw >> 16) & 0xffu, F.yMul8), k3 = __umul24(yraw >> 24, F.yMul8);
-    unsigned Y[2];
-    Y[0] = pkAddK(__builtin_amdgcn_perm(k1, k0, 0x07060302u), F.pkYb); // (y1 of pixel 0 | y1 of pixel 1)
-    Y[1] = pkAddK(__builtin_amdgcn_perm(k3, k2, 0x07060302u), F.pkYb);
-    if constexpr (APLANE) {
-        if (A.alphaLim.on) { // limited-range alpha plane (wave-uniform): the four bytes to full range
-            const unsigned a0 = alphaToFullRange(A, araw & 0xffu), a1 = alphaToFullRange(A, (araw >> 8) & 0xffu);
-            const unsigned a2 = alphaToFullRange(A, (araw >> 16) & 0xffu), a3 = alphaToFullRange(A, araw >> 24);
-            araw = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
-        }
-    }
     unsigned px[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -256,16 +366,36 @@ __device__ __forceinline__ void pkPairsFromWords(const unsigned w[4], unsigned U
     Vp[1] = __builtin_amdgcn_perm(w[3], w[2], 0x0b070903u);
 }
 
+// ... from two filtered words with 16-bit fields (u | v << 16) at the planes' depth times the filter's weight sum
+__device__ __forceinline__ void pkPairsFromWideWords(const unsigned w[4], unsigned shiftSplat, unsigned Up[2], unsigned Vp[2])
+{
+    Up[0] = pkChromaFromWide(__builtin_amdgcn_perm(w[1], w[0], 0x05040100u), shiftSplat);
+    Vp[0] = pkChromaFromWide(__builtin_amdgcn_perm(w[1], w[0], 0x07060302u), shiftSplat);
+    Up[1] = pkChromaFromWide(__builtin_amdgcn_perm(w[3], w[2], 0x05040100u), shiftSplat);
+    Vp[1] = pkChromaFromWide(__builtin_amdgcn_perm(w[3], w[2], 0x07060302u), shiftSplat);
+}
+template <int WIDE>
+__device__ __forceinline__ void pkPairs(const unsigned w[4], unsigned shiftSplat, unsigned Up[2], unsigned Vp[2])
+{
+    if constexpr (WIDE == WIDE_NATIVE)
+        pkPairsFromWideWords(w, shiftSplat, Up, Vp);
+    else
+        pkPairsFromWords(w, Up, Vp);
+}
+
 // Raw (undecoded) data of one wave tile (256 x 2*NSW pixels) as loaded by one lane; lives in registers while the previous tile
 // is computed.
-template <int SUB, bool BIL, bool APLANE, int NSW>
+template <int SUB, bool BIL, bool APLANE, int NSW, int WIDE>
 struct PkRaw
 {
     static constexpr bool kStaged = BIL && (SUB == SUB_420 || SUB == SUB_422);
     static constexpr bool kOwnChroma = !kStaged && SUB != SUB_400;
-    u2 uD[kStaged ? PkStage<SUB, NSW>::kRounds : 1], vD[kStaged ? PkStage<SUB, NSW>::kRounds : 1]; // this lane's share of the neighbourhood
-    unsigned y[2 * NSW], a[APLANE ? 2 * NSW : 1];
-    unsigned u[kOwnChroma ? 2 * NSW : 1], v[kOwnChroma ? 2 * NSW : 1]; // 4:4:4: a dword per row | nearest: the lane's two samples
+    typedef typename PkTypes<WIDE>::Row4 Row4;
+    typedef typename PkTypes<WIDE>::Col8 Col8;
+    typedef typename std::conditional<SUB == SUB_444, Row4, unsigned>::type Own; // 4:4:4: four samples per row | nearest: the lane's two samples
+    Col8 uD[kStaged ? PkStage<SUB, NSW>::kRounds : 1], vD[kStaged ? PkStage<SUB, NSW>::kRounds : 1]; // this lane's share of the neighbourhood
+    Row4 y[2 * NSW], a[APLANE ? 2 * NSW : 1];
+    Own u[kOwnChroma ? 2 * NSW : 1], v[kOwnChroma ? 2 * NSW : 1];
 };
 
 // where a wave works: band (256-pixel column) and first strip (pair of luma rows) of its tile
@@ -275,21 +405,27 @@ struct PkSpot
 };
 
 // ---- every load of a wave tile, longest dependency chain first ----
-template <int SUB, bool BIL, bool APLANE, int NSW>
-__device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkRaw<SUB, BIL, APLANE, NSW> & R)
+template <int SUB, bool BIL, bool APLANE, int NSW, int WIDE>
+__device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R)
 {
-    typedef PkRaw<SUB, BIL, APLANE, NSW> RawT;
+    typedef PkRaw<SUB, BIL, APLANE, NSW, WIDE> RawT;
     typedef PkStage<SUB, NSW> ST;
+    typedef typename RawT::Row4 Row4;
+    constexpr uint32_t B = PkTypes<WIDE>::kBytes;
     const uint32_t bandX = w.band * (uint32_t)kBandW;
     const uint32_t X = bandX + 4u * (uint32_t)threadIdx.x;
     const uint32_t Xc = X < A.w4 ? X : 0u; // absent lanes load (and discard) the row's first group
     const uint32_t strips = A.h2 >> 1;
+#ifdef AVIFHIP_ABLATE_STAGE
+    if constexpr (false) {
+#else
     if constexpr (RawT::kStaged) {
+#endif
         const int cxb = A.cx0 + (int)(bandX >> 1);
         const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)w.strip0 - 1 : A.cy0 + 2 * (int)w.strip0;
 #pragma unroll
         for (int t = 0; t < ST::kRounds; ++t)
-            pkStageLoad<SUB, NSW>(A, cxb, rowBase, t, R.uD[t], R.vD[t]);
+            pkStageLoad<SUB, NSW, WIDE>(A, cxb, rowBase, t, R.uD[t], R.vD[t]);
     }
 #pragma unroll
     for (int s = 0; s < NSW; ++s) {
@@ -297,19 +433,24 @@ __device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkR
         const uint32_t sy = 2u * (st < strips ? st : strips - 1u); // absent strips load (and discard) the last one
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            R.y[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.y + ((sy + r) * A.yPitch + Xc));
+            R.y[2 * s + r] = *reinterpret_cast<const Row4 *>(A.y + ((sy + r) * A.yPitch + Xc * B));
             if constexpr (APLANE)
-                R.a[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.a + ((sy + r) * A.aPitch + Xc));
+                R.a[2 * s + r] = *reinterpret_cast<const Row4 *>(A.a + ((sy + r) * A.aPitch + Xc * B));
             if constexpr (SUB == SUB_444) {
-                R.u[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.u + (((uint32_t)A.cy0 + sy + r) * A.uPitch + ((uint32_t)A.cx0 + Xc)));
-                R.v[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.v + (((uint32_t)A.cy0 + sy + r) * A.vPitch + ((uint32_t)A.cx0 + Xc)));
+                R.u[2 * s + r] = *reinterpret_cast<const Row4 *>(A.u + (((uint32_t)A.cy0 + sy + r) * A.uPitch + ((uint32_t)A.cx0 + Xc) * B));
+                R.v[2 * s + r] = *reinterpret_cast<const Row4 *>(A.v + (((uint32_t)A.cy0 + sy + r) * A.vPitch + ((uint32_t)A.cx0 + Xc) * B));
             } else if constexpr (RawT::kOwnChroma) {
                 // nearest: chroma samples (X >> 1, X >> 1 + 1) of the row's chroma row, one aligned pair per plane
                 if (!(SUB == SUB_420 && r == 1)) {
                     const uint32_t cy = (uint32_t)A.cy0 + ((SUB == SUB_420) ? (sy >> 1) : (sy + r));
                     const uint32_t cx = (uint32_t)A.cx0 + (Xc >> 1);
-                    R.u[2 * s + r] = *reinterpret_cast<const uint16_t *>(A.u + (cy * A.uPitch + cx));
-                    R.v[2 * s + r] = *reinterpret_cast<const uint16_t *>(A.v + (cy * A.vPitch + cx));
+                    if constexpr (WIDE != WIDE_NONE) {
+                        R.u[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.u + (cy * A.uPitch + cx * 2u));
+                        R.v[2 * s + r] = *reinterpret_cast<const uint32_t *>(A.v + (cy * A.vPitch + cx * 2u));
+                    } else {
+                        R.u[2 * s + r] = *reinterpret_cast<const uint16_t *>(A.u + (cy * A.uPitch + cx));
+                        R.v[2 * s + r] = *reinterpret_cast<const uint16_t *>(A.v + (cy * A.vPitch + cx));
+                    }
                 } else {
                     R.u[2 * s + r] = R.v[2 * s + r] = 0;
                 }
@@ -320,13 +461,18 @@ __device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkR
 
 // ---- the chroma neighbourhood into the wave's LDS block.  Wave-private: the LDS instructions of one wave execute in order;
 //      the fences keep the compiler from moving the reads above the writes ----
-template <int SUB, bool BIL, bool APLANE, int NSW>
-__device__ __forceinline__ void pkStage(const PkRaw<SUB, BIL, APLANE, NSW> & R, unsigned * ring)
+template <int SUB, bool BIL, bool APLANE, int NSW, int WIDE>
+__device__ __forceinline__ void pkStage(const TileArgs & A, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, unsigned * ring)
 {
-    if constexpr (PkRaw<SUB, BIL, APLANE, NSW>::kStaged) {
+#ifdef AVIFHIP_ABLATE_STAGE // measurement only (tests/tools/pkbench_wide.hip): nothing is staged, the filter reads whatever the LDS holds
+    if constexpr (false) {
+#else
+    if constexpr (PkRaw<SUB, BIL, APLANE, NSW, WIDE>::kStaged) {
+#endif
+        const unsigned shiftSplat = A.fx.downshift * 0x00010001u;
 #pragma unroll
         for (int t = 0; t < PkStage<SUB, NSW>::kRounds; ++t)
-            pkStageStore<SUB, NSW>(t, R.uD[t], R.vD[t], ring);
+            pkStageStore<SUB, NSW, WIDE>(t, R.uD[t], R.vD[t], shiftSplat, ring);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -406,10 +552,13 @@ __device__ __forceinline__ void pkStoreMappedColumns(const TileArgs & A, const u
 }
 
 // ---- filter, matrix, stores of a wave tile ----
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED>
-__device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW> & R, const unsigned * ring)
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
+__device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, const unsigned * ring)
 {
-    constexpr bool kStaged = PkRaw<SUB, BIL, APLANE, NSW>::kStaged;
+    constexpr bool kStaged = PkRaw<SUB, BIL, APLANE, NSW, WIDE>::kStaged;
+    // 16-bit containers, wave-uniform shift pairs: filtered fields (weight sum 16 or 4) / plain samples down to a byte
+    const unsigned shFiltered = (((SUB == SUB_420) ? 4u : 2u) + A.fx.cShr) * 0x00010001u;
+    const unsigned shSample = (A.fx.downshift + A.fx.cShr) * 0x00010001u;
     unsigned held[MAPPED ? 2 * NSW : 1][4]; // quarter turns: every row of the tile, stored column-wise at the end
     const uint32_t X = w.band * (uint32_t)kBandW + 4u * (uint32_t)threadIdx.x;
     const bool laneValid = X < A.w4;
@@ -438,12 +587,14 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
             pkPairsFromWords(mB, Up[0], Vp[0]);
             pkPairsFromWords(mC, Up[1], Vp[1]);
 #else
-            const unsigned p1 = pkTimes3(tB1), p2 = pkTimes3(tB2); // 9 x
+            unsigned p1 = pkTimes3(tB1), p2 = pkTimes3(tB2); // 9 x
+            if constexpr (WIDE == WIDE_NATIVE)
+                p1 += 0x00080008u, p2 += 0x00080008u; // the filter's "+ 8" (8-bit fields carry it in their staging bias)
             const unsigned a0 = pkTimes3(mB[0]) + p1, a1 = p1 + tB2, a2 = p2 + tB1, a3 = pkTimes3(mB[3]) + p2;
             const unsigned we[4] = { add3(a0, tA1, mA[0]), add3(a1, tA1, mA[2]), add3(a2, tA2, mA[1]), add3(a3, tA2, mA[3]) }; // even row leans up
             const unsigned wo[4] = { add3(a0, tC1, mC[0]), add3(a1, tC1, mC[2]), add3(a2, tC2, mC[1]), add3(a3, tC2, mC[3]) }; // odd row down
-            pkPairsFromWords(we, Up[0], Vp[0]);
-            pkPairsFromWords(wo, Up[1], Vp[1]);
+            pkPairs<WIDE>(we, shFiltered, Up[0], Vp[0]);
+            pkPairs<WIDE>(wo, shFiltered, Up[1], Vp[1]);
 #endif
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -454,18 +605,25 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
             for (int r = 0; r < 2; ++r) {
                 unsigned m[4];
                 pkReadRow(ring, 2 * s + r, m);
-                const unsigned t1 = pkTimes3(m[1]), t2 = pkTimes3(m[2]);
+                unsigned t1 = pkTimes3(m[1]), t2 = pkTimes3(m[2]);
+                if constexpr (WIDE == WIDE_NATIVE)
+                    t1 += 0x00020002u, t2 += 0x00020002u;
                 const unsigned wd[4] = { t1 + m[0], t1 + m[2], t2 + m[1], t2 + m[3] };
-                pkPairsFromWords(wd, Up[r], Vp[r]);
+                pkPairs<WIDE>(wd, shFiltered, Up[r], Vp[r]);
             }
         } else if constexpr (SUB == SUB_444) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const unsigned u = R.u[2 * s + r], v = R.v[2 * s + r];
-                Up[r][0] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c010c00u), 0x00800080u);
-                Up[r][1] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c030c02u), 0x00800080u);
-                Vp[r][0] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c010c00u), 0x00800080u);
-                Vp[r][1] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c030c02u), 0x00800080u);
+                if constexpr (WIDE != WIDE_NONE) { // a dword is a pair already
+                    Up[r][0] = pkChromaFromWide(R.u[2 * s + r].x, shSample), Up[r][1] = pkChromaFromWide(R.u[2 * s + r].y, shSample);
+                    Vp[r][0] = pkChromaFromWide(R.v[2 * s + r].x, shSample), Vp[r][1] = pkChromaFromWide(R.v[2 * s + r].y, shSample);
+                } else {
+                    const unsigned u = R.u[2 * s + r], v = R.v[2 * s + r];
+                    Up[r][0] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c010c00u), 0x00800080u);
+                    Up[r][1] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c030c02u), 0x00800080u);
+                    Vp[r][0] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c010c00u), 0x00800080u);
+                    Vp[r][1] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c030c02u), 0x00800080u);
+                }
             }
         } else { // nearest 4:2:2 / 4:2:0: both pixels of a pair share their chroma sample
 #pragma unroll
@@ -474,18 +632,27 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
                     Up[1][0] = Up[0][0], Up[1][1] = Up[0][1], Vp[1][0] = Vp[0][0], Vp[1][1] = Vp[0][1];
                     break;
                 }
-                const unsigned u = R.u[2 * s + r], v = R.v[2 * s + r];
-                Up[r][0] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c000c00u), 0x00800080u);
-                Up[r][1] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c010c01u), 0x00800080u);
-                Vp[r][0] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c000c00u), 0x00800080u);
-                Vp[r][1] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c010c01u), 0x00800080u);
+                if constexpr (WIDE != WIDE_NONE) { // (c0 | c1) reduced once, then each half doubled
+                    const unsigned u = pkChromaFromWide(R.u[2 * s + r], shSample), v = pkChromaFromWide(R.v[2 * s + r], shSample);
+                    Up[r][0] = __builtin_amdgcn_perm(0u, u, 0x01000100u), Up[r][1] = __builtin_amdgcn_perm(0u, u, 0x03020302u);
+                    Vp[r][0] = __builtin_amdgcn_perm(0u, v, 0x01000100u), Vp[r][1] = __builtin_amdgcn_perm(0u, v, 0x03020302u);
+                } else {
+                    const unsigned u = R.u[2 * s + r], v = R.v[2 * s + r];
+                    Up[r][0] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c000c00u), 0x00800080u);
+                    Up[r][1] = pkSubK(__builtin_amdgcn_perm(0u, u, 0x0c010c01u), 0x00800080u);
+                    Vp[r][0] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c000c00u), 0x00800080u);
+                    Vp[r][1] = pkSubK(__builtin_amdgcn_perm(0u, v, 0x0c010c01u), 0x00800080u);
+                }
             }
         }
         if (stripValid) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                unsigned px[4];
-                pkRow<SUB, NCH, APLANE, MAPPED>(A, R.y[2 * s + r], APLANE ? R.a[2 * s + r] : 0u, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid, px);
+                unsigned px[4], Y[2], araw = 0;
+                pkLuma<WIDE>(A, R.y[2 * s + r], Y);
+                if constexpr (APLANE)
+                    araw = pkAlpha<WIDE>(A, R.a[2 * s + r]);
+                pkRow<SUB, NCH, APLANE, MAPPED>(A, Y, araw, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid, px);
                 if constexpr (MAPPED) {
                     if (A.map.transposed) { // wave-uniform
 #pragma unroll
@@ -517,10 +684,10 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
 // their tiles with the next tile's loads in flight) measured 10-20% SLOWER on 8K frames, with frames streaming from HBM as well
 // as from the Infinity Cache (tests/tools/pk_sweep.py, profiles/r02_pk_sweep_persistent.txt) -- the dispatcher refilling 32 waves per CU in
 // tile order keeps the memory pipes fuller than a software pipeline one tile deep does.
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
 __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g, unsigned * lds)
 {
-    typedef PkRaw<SUB, BIL, APLANE, NSW> RawT;
+    typedef PkRaw<SUB, BIL, APLANE, NSW, WIDE> RawT;
     constexpr int kRingWords = RawT::kStaged ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
     const uint32_t tile = pkTileOf(blockIdx.x, g);
     if (tile >= g.nTiles)
@@ -536,29 +703,29 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
         return; // tiles at the right / bottom edge: a wave without work simply leaves
     unsigned * ring = lds + wave * (uint32_t)kRingWords;
     RawT raw;
-    pkLoad<SUB, BIL, APLANE, NSW>(A, w, raw);
-    pkStage<SUB, BIL, APLANE, NSW>(raw, ring);
-    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED>(A, w, raw, ring);
+    pkLoad<SUB, BIL, APLANE, NSW, WIDE>(A, w, raw);
+    pkStage<SUB, BIL, APLANE, NSW, WIDE>(A, raw, ring);
+    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, w, raw, ring);
 }
 
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
 __global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g)
 {
     constexpr int kRingWords = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
     __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * kRingWords];
-    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED>(A, g, lds);
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, g, lds);
 }
 
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
 __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     constexpr int kRingWords = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
     __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * kRingWords];
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
-    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED>(job, g, lds);
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(job, g, lds);
 }
 
-template <int SUB, bool BIL, int NCH, bool APLANE, bool MAPPED>
+template <int SUB, bool BIL, int NCH, bool APLANE, bool MAPPED, int WIDE = WIDE_NONE>
 hipError_t launchPkMapped(const TileLaunch & L)
 {
     uint32_t nsw, blocks;
@@ -568,14 +735,14 @@ hipError_t launchPkMapped(const TileLaunch & L)
     const dim3 grid(blocks, 1, L.count);
     if (L.table) {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 4, MAPPED>), grid, block, 0, L.stream, L.table, g);
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, 0, L.stream, L.table, g);
         else
-            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2, MAPPED>), grid, block, 0, L.stream, L.table, g);
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, 0, L.stream, L.table, g);
     } else {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4, MAPPED>), grid, block, 0, L.stream, *L.args, g);
+            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, 0, L.stream, *L.args, g);
         else
-            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2, MAPPED>), grid, block, 0, L.stream, *L.args, g);
+            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, 0, L.stream, *L.args, g);
     }
     return hipGetLastError();
 }
@@ -584,6 +751,13 @@ template <int SUB, bool BIL, int NCH, bool APLANE>
 hipError_t launchPk(const TileLaunch & L)
 {
     return L.mapped ? launchPkMapped<SUB, BIL, NCH, APLANE, true>(L) : launchPkMapped<SUB, BIL, NCH, APLANE, false>(L);
+}
+
+// 16-bit containers: libyuv's high-bit-depth entries, or libavif's reduction to 8 bits followed by the 8-bit entry (plan.cpp: fxDownshift)
+template <int SUB, bool BIL, int NCH, bool APLANE>
+hipError_t launchPkWide(const TileLaunch & L)
+{
+    return L.wideDownshift ? launchPkMapped<SUB, BIL, NCH, APLANE, false, WIDE_DOWNSHIFT>(L) : launchPkMapped<SUB, BIL, NCH, APLANE, false, WIDE_NATIVE>(L);
 }
 
 } // namespace tile

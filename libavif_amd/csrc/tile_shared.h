@@ -200,6 +200,7 @@ struct TileKey
     bool alphaPlane; // alpha channel comes from the alpha plane (otherwise opaque / absent)
     bool hasMul;
     bool mapped;     // stores go through a PixelMap (fused crop / rotate / mirror)
+    bool wideDownshift; // integer path on 16-bit containers: samples are reduced to 8 bits first (no high-bit-depth libyuv entry)
 };
 
 struct TileLaunch
@@ -217,6 +218,8 @@ struct TileLaunch
     uint32_t chunkRows;     // tile rows per XCD chunk, 0 = plain raster order
     bool mapped;            // stores go through the jobs' PixelMap
     bool solo;              // fp32 / 10-12-bit integer families: the wave-private kernels instead of the cooperative runs
+    bool pkWide;            // 10-12-bit integer family without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)
+    bool wideDownshift;     // ... entered through the reduction to 8 bits (TileKey)
     hipStream_t stream;
 };
 

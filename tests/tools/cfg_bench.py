@@ -13,6 +13,24 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from libavif_amd import abi, device, native, synth  # noqa: E402
 
 lib = native.load()
+if os.environ.get("AVIFHIP_BENCH_SLAB"):
+    # A/B measurement: every device buffer carved out of ONE allocation (value = alignment in bytes) instead of one hipMalloc per plane --
+    # shows what many small allocations (1 MiB chroma planes of 1080p tiles) cost in address translation
+    _slab = {"base": None, "off": 0, "size": 6 << 30, "align": int(os.environ["AVIFHIP_BENCH_SLAB"], 0)}
+
+    def _slab_init(self, nbytes):
+        if _slab["base"] is None:
+            _slab["base"] = lib.avifhipDeviceAlloc(_slab["size"])
+            assert _slab["base"]
+        a = _slab["align"]
+        off = (_slab["off"] + a - 1) // a * a
+        self.nbytes = max(int(nbytes), 1)
+        assert off + self.nbytes <= _slab["size"]
+        self.ptr = _slab["base"] + off
+        _slab["off"] = off + self.nbytes
+
+    device.DeviceBuffer.__init__ = _slab_init
+    device.DeviceBuffer.free = lambda self: None
 if os.environ.get("AVIFHIP_TUNING"):  # A/B measurements: plan.h TuningBits (e.g. 5 = round 1's cooperative runs for the fp32 / 10-12-bit families)
     lib.avifhipSetTuning(int(os.environ["AVIFHIP_TUNING"], 0))
 BIL, NEAR = abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, abi.AVIF_CHROMA_UPSAMPLING_NEAREST
@@ -34,6 +52,7 @@ def run(name):
     for arith, avoid in (("float", True), ("integer", False)):
         lib.avifhipSetArithmetic(1 if arith == "float" else 0)
         px, bpp, ms = 0, 0.0, None
+        extra = {}
         if name == "cfg2_565":
             # Android's bitmap format (android_jni/.../libavif_jni.cc:206-223): 8K 8-bit 4:2:0 -> RGB565, nearest (libyuv has no filtering 565 entry)
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB_565)
@@ -81,13 +100,16 @@ def run(name):
             for _ in range(3):
                 native.check(lib.avifhipImageYUVToRGBBatchAsync(64, imgs, rgbs, None, None))
             native.check(lib.avifhipSynchronize(None))
-            best = 1e9
+            best, submit = 1e9, 1e9
             for _ in range(5):
                 t0 = time.perf_counter()
                 for _ in range(10):
                     native.check(lib.avifhipImageYUVToRGBBatchAsync(64, imgs, rgbs, None, None))
+                t1 = time.perf_counter()
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+                submit = min(submit, (t1 - t0) / 10 * 1e3)
+            extra["host_submit_us_per_batch"] = round(submit * 1e3, 1)  # the calling thread's own time per call (plans, table, launches)
             px, bpp, ms = 64 * 1920 * 1080, (11.0 if rgb_depth == 10 else 7.0), best
         elif name in ("scale_box4", "scale_up2", "scale_down_1_5"):
             # avifImageScale on 8-bit 4:2:0 planes: 8K -> 1080p (box), 4K -> 8K (2x upsampler), 8K -> 5120x2880 (bilinear down)
@@ -278,7 +300,7 @@ def run(name):
             raise SystemExit(f"unknown configuration {name}")
         gbps = bpp * px / (ms * 1e-3) / 1e9
         out.append({"config": name, "arithmetic": arith, "kernel": native.last_kernel(), "us": round(ms * 1e3, 2), "megapixels_per_s": round(px / 1e6 / (ms * 1e-3)),
-                    "algorithmic_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000, 4)})
+                    "algorithmic_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000, 4), **extra})
     lib.avifhipSetArithmetic(0)
     return out
 
