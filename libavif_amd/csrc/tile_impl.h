@@ -297,6 +297,64 @@ __device__ __forceinline__ void store4WideRgba(uint8_t * base, uint32_t rowOff, 
         __builtin_nontemporal_store(s1, reinterpret_cast<u4 *>(base + rowOff + 1024u + 16u * (uint32_t)l));
 }
 
+// 3-channel pixels: a lane's 4 pixels are NW = 3 (8-bit) or 6 (16-bit) dwords, and dword stores at a stride of 12 / 24 bytes make each of
+// the NW store instructions touch a third of every cache line of the row segment (8K identity copies: 49 us that way, against 34.5 us
+// for the 4-byte pixels' single 16-byte store per lane).  Same cure as for 16-bit RGBA: the wave re-distributes its segment (768 or 1536
+// bytes) through its private LDS buffer so that a store instruction writes 16 bytes per lane at consecutive addresses.  Must be called by
+// every lane of the wave; `validBytes` (a multiple of 4) is how much of the segment exists (bands cut by the right edge).
+typedef unsigned u4a4 __attribute__((ext_vector_type(4), aligned(4))); // rows of 3-channel pixels are only dword-aligned
+
+template <int NW>
+__device__ __forceinline__ void storeRowContiguous(uint8_t * base, uint32_t rowOff, const unsigned (&w)[NW], uint32_t validBytes, WideRowExchange & xchg)
+{
+    unsigned * words = reinterpret_cast<unsigned *>(xchg.w);
+    const uint32_t l = threadIdx.x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+        words[NW * l + k] = w[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr uint32_t kChunks = 16 * NW; // 16-byte pieces of the segment
+    constexpr int kInstr = (kChunks + 63) / 64;
+    u4 s[kInstr];
+#pragma unroll
+    for (int h = 0; h < kInstr; ++h)
+        s[h] = xchg.w[(64u * h + l) < kChunks ? 64u * h + l : 0u];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < kInstr; ++h) {
+        const uint32_t chunk = 64u * h + l, byte = 16u * chunk;
+        if (chunk >= kChunks || byte >= validBytes)
+            continue;
+        uint8_t * dst = base + rowOff + byte;
+        if (byte + 16u <= validBytes) {
+            __builtin_nontemporal_store(s[h], reinterpret_cast<u4a4 *>(dst));
+        } else { // the segment ends inside this piece
+#pragma unroll
+            for (uint32_t d = 0; d < 3; ++d)
+                if (byte + 4u * d < validBytes)
+                    __builtin_nontemporal_store(s[h][d], reinterpret_cast<unsigned *>(dst + 4u * d));
+        }
+    }
+}
+
+// ... of four finished pixels (q[k].r / q[k].b: first / third colour channel)
+template <typename RT>
+__device__ __forceinline__ void store4Rgb3(uint8_t * base, uint32_t rowOff, const PixelOut q[4], uint32_t validBytes, WideRowExchange & xchg)
+{
+    if constexpr (sizeof(RT) == 1) {
+        const unsigned w[3] = { q[0].r | (q[0].g << 8) | (q[0].b << 16) | (q[1].r << 24), q[1].g | (q[1].b << 8) | (q[2].r << 16) | (q[2].g << 24),
+                                q[2].b | (q[3].r << 8) | (q[3].g << 16) | (q[3].b << 24) };
+        storeRowContiguous<3>(base, rowOff, w, validBytes, xchg);
+    } else {
+        const unsigned w[6] = { q[0].r | (q[0].g << 16), q[0].b | (q[1].r << 16), q[1].g | (q[1].b << 16),
+                                q[2].r | (q[2].g << 16), q[2].b | (q[3].r << 16), q[3].g | (q[3].b << 16) };
+        storeRowContiguous<6>(base, rowOff, w, validBytes, xchg);
+    }
+}
+
 // 8-bit RGBA family: (uint8_t)(0.5f + clamp01(c) * 255) for the three colour channels of four pixels, inserted into
 // copies of words that hold the alpha byte.  The inputs are t = 0.5f + c * 255 (unclamped c); v_cvt_pk_u8_f32 in
 // round-toward-zero mode truncates like the C cast and saturates to [0, 255], and because t is monotonic in c the
@@ -508,6 +566,8 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
     const f2 cBR = { A.cB, A.cR };
     const f2 cUV = { A.cU, A.cV }; // the two products of the green term, :876 (their sum is commutative)
     const unsigned opaqueWord = A.rgbMax << (8 * A.slotA); // 8-bit RGBA: the alpha byte in place
+    // 3-channel pixels: bytes of the band's row segment that exist (storeRowContiguous)
+    const uint32_t segBytes = ((A.w4 - c.bandX < (uint32_t)kBandW) ? A.w4 - c.bandX : (uint32_t)kBandW) * kPixBytes;
 
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -651,8 +711,12 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         q[i].r = ub[i], q[i].g = yb[i], q[i].b = vb[i];
-                    if (laneValid)
-                        store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
+                    if constexpr (NCH == 3) {
+                        store4Rgb3<RT>(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, segBytes, xchg[wv]);
+                    } else {
+                        if (laneValid)
+                            store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
+                    }
                     continue;
                 }
             }
@@ -684,11 +748,7 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                     }
                     unsigned w[3];
                     packRgb8Row(w, x, tg, z);
-                    if (laneValid) {
-                        storeVec(A.rgb, off, w[0], nt);
-                        storeVec(A.rgb, off + 4, w[1], nt);
-                        storeVec(A.rgb, off + 8, w[2], nt);
-                    }
+                    storeRowContiguous<3>(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, w, segBytes, xchg[wv]);
                 }
             } else {
                 PixelOut q[4];
@@ -706,6 +766,8 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                 }
                 if constexpr (sizeof(RT) == 2 && NCH == 4) {
                     store4WideRgba(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, a, alphaFirst, c.bandX, A.w4, xchg[wv]);
+                } else if constexpr (NCH == 3) {
+                    store4Rgb3<RT>(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, segBytes, xchg[wv]);
                 } else {
                     if (laneValid)
                         store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
@@ -775,7 +837,7 @@ template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, boo
 __global__ __launch_bounds__(256) void yuvToRgbTileKernel(TileArgs A, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
-    if constexpr (sizeof(RT) == 2 && NCH == 4) {
+    if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock]; // one per wave, 16-bit RGBA only
         runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, tilesPerRun, rows, xchg);
     } else {
@@ -791,7 +853,7 @@ __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * 
     // a private copy of the job: read through the table pointer, every field would be re-loaded after each store (the compiler
     // cannot rule out that the RGB stores alias the table) -- ~20 scalar loads per tile inside the pipelined loop
     const TileArgs job = table[blockIdx.z];
-    if constexpr (sizeof(RT) == 2 && NCH == 4) {
+    if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
         runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, tilesPerRun, rows, xchg);
     } else {
@@ -840,7 +902,7 @@ template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, boo
 __global__ __launch_bounds__(256) void yuvToRgbTileSoloKernel(TileArgs A, PkGeom g)
 {
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
-    if constexpr (sizeof(RT) == 2 && NCH == 4) {
+    if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
         runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, g, lds, xchg);
     } else {
@@ -853,7 +915,7 @@ __global__ __launch_bounds__(256) void yuvToRgbTileSoloBatchKernel(const TileArg
 {
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel
-    if constexpr (sizeof(RT) == 2 && NCH == 4) {
+    if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
         runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, g, lds, xchg);
     } else {

@@ -295,9 +295,10 @@ __device__ __forceinline__ unsigned pkAlpha(const TileArgs & A, typename PkTypes
     }
 }
 
+// `xchg` / `segBytes`: 3-byte pixels only -- the wave's exchange buffer and the bytes of its row segment that exist (storeRowContiguous)
 template <int SUB, int NCH, bool APLANE, bool MAPPED>
 __device__ __forceinline__ void pkRow(const TileArgs & A, const unsigned Y[2], unsigned araw, const unsigned Up[2], const unsigned Vp[2], uint32_t off, bool laneValid,
-                                      unsigned out[4])
+                                      unsigned out[4], WideRowExchange * xchg, uint32_t segBytes)
 {
     const TileArgs::Fx & F = A.fx;
     unsigned px[4] = { 0, 0, 0, 0 };
@@ -339,20 +340,19 @@ __device__ __forceinline__ void pkRow(const TileArgs & A, const unsigned Y[2], u
         out[0] = px[0], out[1] = px[1], out[2] = px[2], out[3] = px[3];
         return;
     }
+    if constexpr (NCH == 3) {
+        // pixels are (x g z .): 12 bytes x0 g0 z0 x1 | g1 z1 x2 g2 | z2 x3 g3 z3, handed to 16-byte stores through the wave's LDS buffer
+        const unsigned w[3] = { __builtin_amdgcn_perm(px[1], px[0], 0x04020100u), __builtin_amdgcn_perm(px[2], px[1], 0x05040201u),
+                                __builtin_amdgcn_perm(px[3], px[2], 0x06050402u) };
+        storeRowContiguous<3>(A.rgb, off - 12u * (uint32_t)threadIdx.x, w, segBytes, *xchg);
+        return;
+    }
     if (!laneValid)
         return;
     if constexpr (NCH == 2) {
         storeVec(A.rgb, off, (u2) { px[0], px[1] }, true); // four 16-bit pixels
     } else if constexpr (NCH == 4) {
         storeVec(A.rgb, off, (u4) { px[0], px[1], px[2], px[3] }, true);
-    } else {
-        // pixels are (x g z .): 12 bytes x0 g0 z0 x1 | g1 z1 x2 g2 | z2 x3 g3 z3
-        typedef unsigned u3 __attribute__((ext_vector_type(3)));
-        const u3 w = { __builtin_amdgcn_perm(px[1], px[0], 0x04020100u), __builtin_amdgcn_perm(px[2], px[1], 0x05040201u),
-                       __builtin_amdgcn_perm(px[3], px[2], 0x06050402u) };
-        storeVec(A.rgb, off, w.x, true);
-        storeVec(A.rgb, off + 4, w.y, true);
-        storeVec(A.rgb, off + 8, w.z, true);
     }
 }
 
@@ -480,7 +480,7 @@ __device__ __forceinline__ void pkStage(const TileArgs & A, const PkRaw<SUB, BIL
 }
 
 // ---- stores through a PixelMap (fused crop / rotate / mirror).  A pixel word holds (x g z a) or (x g z .) ----
-typedef unsigned u4a4 __attribute__((ext_vector_type(4), aligned(4))); // 16-byte accesses at dword alignment (crops start anywhere)
+// (u4a4, tile_impl.h: 16-byte accesses at dword alignment -- crops start anywhere)
 
 template <int NCH>
 __device__ __forceinline__ void pkStorePixel(uint8_t * dst, unsigned px)
@@ -553,7 +553,7 @@ __device__ __forceinline__ void pkStoreMappedColumns(const TileArgs & A, const u
 
 // ---- filter, matrix, stores of a wave tile ----
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
-__device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, const unsigned * ring)
+__device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, const unsigned * ring, WideRowExchange * xchg)
 {
     constexpr bool kStaged = PkRaw<SUB, BIL, APLANE, NSW, WIDE>::kStaged;
     // 16-bit containers, wave-uniform shift pairs: filtered fields (weight sum 16 or 4) / plain samples down to a byte
@@ -563,6 +563,8 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
     const uint32_t X = w.band * (uint32_t)kBandW + 4u * (uint32_t)threadIdx.x;
     const bool laneValid = X < A.w4;
     const uint32_t strips = A.h2 >> 1;
+    const uint32_t bandX0 = w.band * (uint32_t)kBandW;
+    const uint32_t segBytes = ((A.w4 - bandX0 < (uint32_t)kBandW) ? A.w4 - bandX0 : (uint32_t)kBandW) * (uint32_t)NCH;
     unsigned mA[4] = { 0, 0, 0, 0 }, mB[4] = { 0, 0, 0, 0 }, tA1 = 0, tA2 = 0, tB1 = 0, tB2 = 0;
     if constexpr (kStaged && SUB == SUB_420) {
         pkReadRow(ring, 0, mA);
@@ -652,7 +654,7 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
                 pkLuma<WIDE>(A, R.y[2 * s + r], Y);
                 if constexpr (APLANE)
                     araw = pkAlpha<WIDE>(A, R.a[2 * s + r]);
-                pkRow<SUB, NCH, APLANE, MAPPED>(A, Y, araw, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid, px);
+                pkRow<SUB, NCH, APLANE, MAPPED>(A, Y, araw, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid, px, xchg, segBytes);
                 if constexpr (MAPPED) {
                     if (A.map.transposed) { // wave-uniform
 #pragma unroll
@@ -684,11 +686,20 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
 // their tiles with the next tile's loads in flight) measured 10-20% SLOWER on 8K frames, with frames streaming from HBM as well
 // as from the Infinity Cache (tests/tools/pk_sweep.py, profiles/r02_pk_sweep_persistent.txt) -- the dispatcher refilling 32 waves per CU in
 // tile order keeps the memory pipes fuller than a software pipeline one tile deep does.
+// LDS of a workgroup: the waves' chroma blocks (16-byte aligned in total), then their exchange buffers where rows of 3-byte pixels are stored
+template <int SUB, bool BIL, int NCH, int NSW, bool MAPPED>
+struct PkLds
+{
+    static constexpr int kRingWordsRaw = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
+    static constexpr int kRingWords = (NCH == 3 && !MAPPED) ? ((kRingWordsRaw + 3) & ~3) : kRingWordsRaw;
+    static constexpr int kWords = kWavesPerBlock * kRingWords + ((NCH == 3 && !MAPPED) ? kWavesPerBlock * (int)(sizeof(WideRowExchange) / 4) : 0);
+};
+
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
 __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g, unsigned * lds)
 {
     typedef PkRaw<SUB, BIL, APLANE, NSW, WIDE> RawT;
-    constexpr int kRingWords = RawT::kStaged ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
+    constexpr int kRingWords = PkLds<SUB, BIL, NCH, NSW, MAPPED>::kRingWords;
     const uint32_t tile = pkTileOf(blockIdx.x, g);
     if (tile >= g.nTiles)
         return;
@@ -702,25 +713,25 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     if (w.band * (uint32_t)kBandW >= A.w4 || 2u * w.strip0 >= A.h2)
         return; // tiles at the right / bottom edge: a wave without work simply leaves
     unsigned * ring = lds + wave * (uint32_t)kRingWords;
+    // 3-byte pixels, stored as rows: one exchange buffer per wave behind the chroma blocks
+    WideRowExchange * xchg = (NCH == 3 && !MAPPED) ? reinterpret_cast<WideRowExchange *>(lds + kWavesPerBlock * PkLds<SUB, BIL, NCH, NSW, MAPPED>::kRingWords) + wave : nullptr;
     RawT raw;
     pkLoad<SUB, BIL, APLANE, NSW, WIDE>(A, w, raw);
     pkStage<SUB, BIL, APLANE, NSW, WIDE>(A, raw, ring);
-    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, w, raw, ring);
+    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, w, raw, ring, xchg);
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
 __global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g)
 {
-    constexpr int kRingWords = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
-    __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * kRingWords];
+    __shared__ __attribute__((aligned(16))) unsigned lds[PkLds<SUB, BIL, NCH, NSW, MAPPED>::kWords];
     pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, g, lds);
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
 __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
-    constexpr int kRingWords = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
-    __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * kRingWords];
+    __shared__ __attribute__((aligned(16))) unsigned lds[PkLds<SUB, BIL, NCH, NSW, MAPPED>::kWords];
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
     pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(job, g, lds);
 }

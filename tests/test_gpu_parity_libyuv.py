@@ -40,6 +40,49 @@ def test_yuv_to_rgb_libyuv_domain_device(hip_auto_arithmetic):
     assert sum(v for k, v in kernels.items() if "fixed" in k) > 300, kernels
 
 
+def _wide_cases():
+    import itertools
+    cases = []
+    for (w, h), depth, yf, up, fmt in itertools.product(TILED, (10, 12), (1, 2, 3, 4), (3, 4), (0, 1, 2, 4)):
+        for alpha in ((False, True) if fmt != 0 else (False,)):
+            cases.append(H.Y2RCase(w, h, yuv_depth=depth, yuv_format=yf, upsampling=up, rgb_format=fmt, rgb_depth=8, alpha=alpha, avoid_libyuv=False,
+                                   matrix=(1, 6, 9)[(w + depth + yf) % 3], yuv_range=(w + yf + fmt) % 2, row_pad=64 if (h + fmt) % 2 else 0,
+                                   seed=(w * 31 + depth * 7 + yf * 5 + up * 3 + fmt) | 1))
+    return cases
+
+
+def test_wide_planes_run_in_the_packed_kernels(hip_auto_arithmetic):
+    """10- and 12-bit planes to 8-bit RGB through libyuv's high-bit-depth entries (I010 / I210 / I410 / I012 and their alpha twins) or through
+    libavif's reduction to 8 bits (src/reformat_libyuv.c:714-772, :906-930): every chroma layout, both upsamplings, 3- and 4-byte pixels, alpha
+    from the plane -- byte-exact, and served by the packed 16-bit kernels unless an (un)premultiply follows."""
+    cases = _wide_cases()
+    kernels = {}
+    bad = []
+    o = H.oracle_libyuv_backend()
+    for be in (H.HipDeviceBackend(), H.hip_host_backend()):
+        for c in cases:
+            ro, po = H.run_y2r(o, c)
+            rh, ph = H.run_y2r(be, c)
+            k = native.last_kernel()
+            kernels[k] = kernels.get(k, 0) + 1
+            if ro != rh or not np.array_equal(po, ph):
+                bad.append(f"{c.ident()} [{k}]: results {ro}/{rh}" + ("" if ro != rh else " " + H.describe_diff(po, ph)))
+    assert not bad, f"{len(bad)} of {2 * len(cases)} cases differ:\n" + "\n".join(bad[:25])
+    packed = sum(v for k, v in kernels.items() if "u16" in k and "pk16" in k)
+    assert packed > 0.6 * 2 * len(cases), kernels  # the rest: layouts libyuv has no entry for (fp32 kernels), small leftovers
+    assert not [k for k in kernels if k.startswith("yuv2rgb_fixed_tile<u16") and "alphamul" not in k and "pk16" not in k], kernels
+
+
+def test_wide_planes_cooperative_kernels_still_exact(hip_auto_arithmetic):
+    """The round-1 kernels of the 10/12-bit integer family stay selectable for A/B runs (plan.h TUNE_COOPERATIVE): same bytes."""
+    hip_auto_arithmetic.avifhipSetTuning(5)
+    try:
+        kernels = _compare_y2r(H.HipDeviceBackend(), H.oracle_libyuv_backend(), _wide_cases()[::7])
+        assert "yuv2rgb_fixed_tile" in kernels, kernels
+    finally:
+        hip_auto_arithmetic.avifhipSetTuning(1)
+
+
 def test_yuv_to_rgb_general_sweep_default_arithmetic(hip_auto_arithmetic):
     """The whole configuration space with avoidLibYUV = 0 (the API default) and a slice with avoidLibYUV = 1."""
     cases = [replace(c, avoid_libyuv=False) for c in H.y2r_sweep(SMALL + TILED[:2], n_random=700, seed=201)]

@@ -94,4 +94,5 @@ def main():
         print(json.dumps(traffic, indent=1))
 
 
-main()
+if __name__ == "__main__":
+    main()
