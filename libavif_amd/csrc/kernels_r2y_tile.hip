@@ -114,14 +114,14 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
     else if (p.alphaSource == ALPHA_PLANE)
         A.alphaMode = (o.depth == s.depth) ? R2Y_ALPHA_COPY : R2Y_ALPHA_RESCALE;
 
-    // decomposition: about 2048 workgroups (8 per CU); a wave walks down up to 8 strips
+    // decomposition: a wave takes 1, 2 or 4 vertically consecutive strips (tests/tools/cfg_bench.py with AVIFHIP_R2Y_SPW)
     const uint32_t bands = (A.w4 + 255) / 256;
     const uint32_t strips = A.h2 / 2;
     const uint64_t waveStrips = (uint64_t)bands * strips;
-    uint32_t spw = (uint32_t)(waveStrips / (4 * 2048));
-    spw = spw < 1 ? 1 : (spw > 8 ? 8 : spw);
+    uint32_t spw = waveStrips >= 4 * 8192 ? 2 : 1;
     if (const char * e = getenv("AVIFHIP_R2Y_SPW")) // diagnostics / A-B measurements only
         spw = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : spw;
+    spw = spw >= 4 ? 4 : (spw >= 2 ? 2 : 1);
     A.stripsPerWave = spw;
     const uint32_t chunks = (strips + 4 * spw - 1) / (4 * spw);
     if (k.fixedPoint) { // appendix D.5, coefficients in memory order of the colour channels

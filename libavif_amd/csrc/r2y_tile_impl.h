@@ -9,8 +9,8 @@
 //
 // Structure: wave = 64 lanes; a lane owns 4 consecutive pixels of 2 rows (two 2x2 chroma blocks): one 16-byte load per
 // row for RGBA8 (1 KiB contiguous per wave instruction), one 4-byte luma (and alpha) store per row, one 2-byte store per
-// chroma plane.  A wave walks down `stripsPerWave` strips (256 x 2 pixels) with the next strip's loads in flight while
-// the current one is computed.  No LDS: every input byte is used by exactly one lane.
+// chroma plane.  A wave takes `stripsPerWave` (1, 2 or 4) vertically consecutive strips (256 x 2 pixels), all loads issued up
+// front.  No LDS: every input byte is used by exactly one lane.
 //
 // Arithmetic: the reference's fp32 operations in the reference's order, no contraction; the three divisions by plan
 // constants (channel maximum, 2(1-kb), 2(1-kr)) use the exhaustively verified reciprocal form (exactdiv.h).
@@ -81,12 +81,15 @@ struct Yuvf
 // AVIF_CLAMP((int)floorf(v * range + bias + 0.5f), 0, max), src/reformat.c:197-219.  v_cvt_u32_f32 truncates toward zero
 // and returns 0 for every negative operand: for t >= 0 truncation is the floor, for t < 0 the floor is negative and the
 // reference's clamp returns 0 as well; the min restores the upper clamp.
-__device__ __forceinline__ int toUNorm(float v, float range, float bias, int maxv)
+__device__ __forceinline__ int truncClamp(float t, int maxv)
 {
-    const float t = ((v * range) + bias) + 0.5f;
     unsigned q;
     asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(t));
     return (int)min(q, (unsigned)maxv);
+}
+__device__ __forceinline__ int toUNorm(float v, float range, float bias, int maxv)
+{
+    return truncClamp(((v * range) + bias) + 0.5f, maxv);
 }
 
 template <typename YT>
@@ -124,52 +127,122 @@ __device__ __forceinline__ void loadStrip(const R2YArgs & A, uint32_t sy, uint32
     S.row[1] = loadRow<RT, NCH>(A.rgb, (syc + 1) * A.rgbPitch + Xc * kPix);
 }
 
-template <typename RT, int NCH, typename YT, int SUB>
-__device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S)
+// ---- fp32 arithmetic on pixel PAIRS: gfx950 multiplies and adds two fp32 lanes per instruction (v_pk_mul_f32 / v_pk_add_f32 /
+//      v_pk_fma_f32, each component rounded exactly like the scalar instruction), so horizontally adjacent pixels share every
+//      normalisation, matrix and quantisation instruction ----
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float v)
+{
+    return (f2) { v, v };
+}
+// x / d for a plan constant d on the verified list (exactdiv.h), both components: bit-identical to the IEEE quotients
+__device__ __forceinline__ f2 div2(f2 x, RcpHL r)
+{
+    return __builtin_elementwise_fma(x, splat2(r.hi), x * splat2(r.lo));
+}
+// t = v * range + bias + 0.5f, the operand of the reference's floorf (src/reformat.c:197-219), in the reference's order
+__device__ __forceinline__ f2 unormOperand(f2 v, float range, float bias)
+{
+    return ((v * splat2(range)) + splat2(bias)) + splat2(0.5f);
+}
+// AVIF_CLAMP((int)floorf(t), 0, 255) of four operands, packed little-endian.  v_cvt_pk_u8_f32 converts with the current rounding
+// mode and saturates to [0, 255]: under round-toward-zero that is the floor for t >= 0 and 0 for every negative t -- the same
+// byte as the reference's floor-then-clamp.  The rounding mode is changed only inside the block.
+__device__ __forceinline__ unsigned packU8x4(float a, float b, float c, float d)
+{
+    unsigned w;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %1, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %2, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %3, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 3, %0\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(w)
+                 : "v"(a), "v"(b), "v"(c), "v"(d));
+    return w;
+}
+
+// four samples of a row from two operand pairs
+template <typename YT>
+__device__ __forceinline__ void storeRow4(uint8_t * base, uint32_t off, f2 t01, f2 t23, int maxv)
+{
+    if constexpr (sizeof(YT) == 1) {
+        __builtin_nontemporal_store(packU8x4(t01.x, t01.y, t23.x, t23.y), reinterpret_cast<unsigned *>(base + off));
+    } else {
+        const int q[4] = { truncClamp(t01.x, maxv), truncClamp(t01.y, maxv), truncClamp(t23.x, maxv), truncClamp(t23.y, maxv) };
+        store4Samples<YT>(base, off, q);
+    }
+}
+
+template <typename RT, int NCH, typename YT, int SUB, bool SWAP>
+__device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S)
 {
     constexpr uint32_t BPS = sizeof(YT);
     const int yuvMax = (int)A.yuvMax;
     const bool alphaFirst = (NCH == 4) && (A.slotA == 0);
-    const bool swapRB = A.slotB < A.slotR;
-    const unsigned colourShift = alphaFirst ? 8u : 0u, alphaShift = alphaFirst ? 0u : 24u;
-    (void)colourShift, (void)alphaShift;
-    Yuvf c[2][4];
-    int yq[2][4], aq[2][4];
+    const unsigned colourShift = alphaFirst ? 8u : 0u;
+    (void)colourShift;
+    f2 tY[2][2], U[2][2], V[2][2]; // [row][pixel pair]: luma as the quantiser's operand, chroma normalised
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // memory-order channels -> (first colour, G, last colour, alpha)
-            unsigned c0, c1, c2, ca = 0;
-            if constexpr (NCH == 4 && sizeof(RT) == 1) {
-                // one dword per pixel: alpha-first layouts shift the colour bytes down instead of selecting per channel
-                const unsigned w = S.row[r].w[i];
-                const unsigned cw = w >> colourShift;
-                c0 = cw & 0xffu, c1 = (cw >> 8) & 0xffu, c2 = (cw >> 16) & 0xffu;
-                ca = (w >> alphaShift) & 0xffu;
-            } else {
-                c0 = channelOf<RT, NCH>(S.row[r], i, 0), c1 = channelOf<RT, NCH>(S.row[r], i, 1), c2 = channelOf<RT, NCH>(S.row[r], i, 2);
-                if constexpr (NCH == 4) {
-                    const unsigned c3 = channelOf<RT, NCH>(S.row[r], i, 3);
-                    ca = alphaFirst ? c0 : c3;
-                    c0 = alphaFirst ? c1 : c0, c1 = alphaFirst ? c2 : c1, c2 = alphaFirst ? c3 : c2;
+        for (int p = 0; p < 2; ++p) {
+            // memory-order colour channels (first colour, G, last colour) of the pair's two pixels
+            unsigned c0[2], c1[2], c2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * p + h;
+                if constexpr (NCH == 4 && sizeof(RT) == 1) {
+                    // one dword per pixel: alpha-first layouts shift the colour bytes down instead of selecting per channel
+                    const unsigned cw = S.row[r].w[i] >> colourShift;
+                    c0[h] = cw & 0xffu, c1[h] = (cw >> 8) & 0xffu, c2[h] = (cw >> 16) & 0xffu;
+                } else {
+                    c0[h] = channelOf<RT, NCH>(S.row[r], i, 0), c1[h] = channelOf<RT, NCH>(S.row[r], i, 1), c2[h] = channelOf<RT, NCH>(S.row[r], i, 2);
+                    if constexpr (NCH == 4) {
+                        const unsigned c3 = channelOf<RT, NCH>(S.row[r], i, 3);
+                        c0[h] = alphaFirst ? c1[h] : c0[h], c1[h] = alphaFirst ? c2[h] : c1[h], c2[h] = alphaFirst ? c3 : c2[h];
+                    }
                 }
             }
             // "Unpack RGB into normalized float", src/reformat.c:312-323: channel / maxChannelF
-            const float x = divExact((float)c0, A.rcpRgbMax), G = divExact((float)c1, A.rcpRgbMax), z = divExact((float)c2, A.rcpRgbMax);
-            const float R = swapRB ? z : x, B = swapRB ? x : z;
-            const float Y = ((A.kr * R) + (A.kg * G)) + (A.kb * B); // :383
-            c[r][i].y = Y;
-            c[r][i].u = divExact(B - Y, A.rcpCbDen); // (B - Y) / (2 * (1 - kb)), :384
-            c[r][i].v = divExact(R - Y, A.rcpCrDen); // (R - Y) / (2 * (1 - kr)), :385
-            yq[r][i] = toUNorm(Y, A.rangeY, A.biasY, yuvMax);
-            if (A.alphaMode == R2Y_ALPHA_COPY) {
-                aq[r][i] = (int)ca; // plain strided copy, src/alpha.c:44-79
-            } else if (A.alphaMode == R2Y_ALPHA_RESCALE) {
-                const float alphaF = divExact((float)ca, A.rcpRgbMax); // src/alpha.c:93-96
-                aq[r][i] = clampInt((int)(0.5f + (alphaF * A.yuvMaxF)), 0, yuvMax);
-            } else {
-                aq[r][i] = yuvMax; // avifFillAlpha
+            const f2 x = div2((f2) { (float)c0[0], (float)c0[1] }, A.rcpRgbMax);
+            const f2 G = div2((f2) { (float)c1[0], (float)c1[1] }, A.rcpRgbMax);
+            const f2 z = div2((f2) { (float)c2[0], (float)c2[1] }, A.rcpRgbMax);
+            const f2 R = SWAP ? z : x, B = SWAP ? x : z;
+            const f2 Y = ((splat2(A.kr) * R) + (splat2(A.kg) * G)) + (splat2(A.kb) * B); // :383
+            U[r][p] = div2(B - Y, A.rcpCbDen); // (B - Y) / (2 * (1 - kb)), :384
+            V[r][p] = div2(R - Y, A.rcpCrDen); // (R - Y) / (2 * (1 - kr)), :385
+            tY[r][p] = unormOperand(Y, A.rangeY, A.biasY);
+        }
+    }
+    // alpha plane: four samples per row
+    unsigned aw[2] = { 0, 0 };
+    int aq[2][4];
+    const bool alphaBytes = NCH == 4 && sizeof(RT) == 1 && sizeof(YT) == 1 && A.alphaMode == R2Y_ALPHA_COPY; // wave-uniform
+    if (A.alphaMode != R2Y_ALPHA_NONE) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if constexpr (NCH == 4 && sizeof(RT) == 1 && sizeof(YT) == 1) {
+                if (alphaBytes) { // plain strided copy, src/alpha.c:44-79: the four alpha bytes gathered by three byte permutes
+                    const unsigned sel = alphaFirst ? 0x0c0c0400u : 0x0c0c0703u;
+                    const unsigned a01 = __builtin_amdgcn_perm(S.row[r].w[1], S.row[r].w[0], sel), a23 = __builtin_amdgcn_perm(S.row[r].w[3], S.row[r].w[2], sel);
+                    aw[r] = __builtin_amdgcn_perm(a23, a01, 0x05040100u);
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned ca = 0;
+                if constexpr (NCH == 4)
+                    ca = channelOf<RT, NCH>(S.row[r], i, alphaFirst ? 0 : 3);
+                if (A.alphaMode == R2Y_ALPHA_COPY) {
+                    aq[r][i] = (int)ca;
+                } else if (A.alphaMode == R2Y_ALPHA_RESCALE) {
+                    const float alphaF = divExact((float)ca, A.rcpRgbMax); // src/alpha.c:93-96
+                    aq[r][i] = clampInt((int)(0.5f + (alphaF * A.yuvMaxF)), 0, yuvMax);
+                } else {
+                    aq[r][i] = yuvMax; // avifFillAlpha
+                }
             }
         }
     }
@@ -177,47 +250,54 @@ __device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uin
         return;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        store4Samples<YT>(A.y, (sy + r) * A.yPitch + X * BPS, yq[r]);
-        if (A.alphaMode != R2Y_ALPHA_NONE)
-            store4Samples<YT>(A.a, (sy + r) * A.aPitch + X * BPS, aq[r]);
+        storeRow4<YT>(A.y, (sy + r) * A.yPitch + X * BPS, tY[r][0], tY[r][1], yuvMax);
+        if (A.alphaMode != R2Y_ALPHA_NONE) {
+            if (alphaBytes)
+                __builtin_nontemporal_store(aw[r], reinterpret_cast<unsigned *>(A.a + ((sy + r) * A.aPitch + X)));
+            else
+                store4Samples<YT>(A.a, (sy + r) * A.aPitch + X * BPS, aq[r]);
+        }
     }
     if constexpr (SUB == SUB_444) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            int uq[4], vq[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uq[i] = toUNorm(c[r][i].u, A.rangeUV, A.biasUV, yuvMax);
-                vq[i] = toUNorm(c[r][i].v, A.rangeUV, A.biasUV, yuvMax);
-            }
-            store4Samples<YT>(A.u, (sy + r) * A.uPitch + X * BPS, uq);
-            store4Samples<YT>(A.v, (sy + r) * A.vPitch + X * BPS, vq);
+            storeRow4<YT>(A.u, (sy + r) * A.uPitch + X * BPS, unormOperand(U[r][0], A.rangeUV, A.biasUV), unormOperand(U[r][1], A.rangeUV, A.biasUV), yuvMax);
+            storeRow4<YT>(A.v, (sy + r) * A.vPitch + X * BPS, unormOperand(V[r][0], A.rangeUV, A.biasUV), unormOperand(V[r][1], A.rangeUV, A.biasUV), yuvMax);
         }
     } else if constexpr (SUB == SUB_420) {
-        // sum in the reference's order (bJ outer, bI inner, from 0.0f), then / 4 (exact), src/reformat.c:416-426
-        int uq[2], vq[2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const float su = ((c[0][2 * b].u + c[0][2 * b + 1].u) + c[1][2 * b].u) + c[1][2 * b + 1].u;
-            const float sv = ((c[0][2 * b].v + c[0][2 * b + 1].v) + c[1][2 * b].v) + c[1][2 * b + 1].v;
-            uq[b] = toUNorm(su * 0.25f, A.rangeUV, A.biasUV, yuvMax);
-            vq[b] = toUNorm(sv * 0.25f, A.rangeUV, A.biasUV, yuvMax);
+        // sum in the reference's order (bJ outer, bI inner, from 0.0f), then / 4 (exact), src/reformat.c:416-426; block b is pixel pair b
+        // of both rows.  (u of block 0, u of block 1) and (v, v) then share the quantiser's instructions.
+        const f2 su = { ((U[0][0].x + U[0][0].y) + U[1][0].x) + U[1][0].y, ((U[0][1].x + U[0][1].y) + U[1][1].x) + U[1][1].y };
+        const f2 sv = { ((V[0][0].x + V[0][0].y) + V[1][0].x) + V[1][0].y, ((V[0][1].x + V[0][1].y) + V[1][1].x) + V[1][1].y };
+        const f2 tu = unormOperand(su * splat2(0.25f), A.rangeUV, A.biasUV), tv = unormOperand(sv * splat2(0.25f), A.rangeUV, A.biasUV);
+        if constexpr (sizeof(YT) == 1) {
+            const unsigned uv = packU8x4(tu.x, tu.y, tv.x, tv.y);
+            __builtin_nontemporal_store((uint16_t)uv, reinterpret_cast<uint16_t *>(A.u + ((sy >> 1) * A.uPitch + (X >> 1))));
+            __builtin_nontemporal_store((uint16_t)(uv >> 16), reinterpret_cast<uint16_t *>(A.v + ((sy >> 1) * A.vPitch + (X >> 1))));
+        } else {
+            store2Samples<YT>(A.u, (sy >> 1) * A.uPitch + (X >> 1) * BPS, truncClamp(tu.x, yuvMax), truncClamp(tu.y, yuvMax));
+            store2Samples<YT>(A.v, (sy >> 1) * A.vPitch + (X >> 1) * BPS, truncClamp(tv.x, yuvMax), truncClamp(tv.y, yuvMax));
         }
-        store2Samples<YT>(A.u, (sy >> 1) * A.uPitch + (X >> 1) * BPS, uq[0], uq[1]);
-        store2Samples<YT>(A.v, (sy >> 1) * A.vPitch + (X >> 1) * BPS, vq[0], vq[1]);
     } else if constexpr (SUB == SUB_422) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) { // :444-453
-            int uq[2], vq[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                uq[b] = toUNorm((c[r][2 * b].u + c[r][2 * b + 1].u) * 0.5f, A.rangeUV, A.biasUV, yuvMax);
-                vq[b] = toUNorm((c[r][2 * b].v + c[r][2 * b + 1].v) * 0.5f, A.rangeUV, A.biasUV, yuvMax);
-            }
-            store2Samples<YT>(A.u, (sy + r) * A.uPitch + (X >> 1) * BPS, uq[0], uq[1]);
-            store2Samples<YT>(A.v, (sy + r) * A.vPitch + (X >> 1) * BPS, vq[0], vq[1]);
+            const f2 su = { U[r][0].x + U[r][0].y, U[r][1].x + U[r][1].y }, sv = { V[r][0].x + V[r][0].y, V[r][1].x + V[r][1].y };
+            const f2 tu = unormOperand(su * splat2(0.5f), A.rangeUV, A.biasUV), tv = unormOperand(sv * splat2(0.5f), A.rangeUV, A.biasUV);
+            store2Samples<YT>(A.u, (sy + r) * A.uPitch + (X >> 1) * BPS, truncClamp(tu.x, yuvMax), truncClamp(tu.y, yuvMax));
+            store2Samples<YT>(A.v, (sy + r) * A.vPitch + (X >> 1) * BPS, truncClamp(tv.x, yuvMax), truncClamp(tv.y, yuvMax));
         }
     }
+}
+
+template <typename RT, int NCH, typename YT, int SUB>
+__device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S)
+{
+    // which memory-order colour channel is red decides the operand ORDER of the luma sum (fp32 addition is not associative):
+    // one wave-uniform branch instead of selects per pixel
+    if (A.slotB < A.slotR)
+        computeStripT<RT, NCH, YT, SUB, true>(A, sy, X, laneValid, S);
+    else
+        computeStripT<RT, NCH, YT, SUB, false>(A, sy, X, laneValid, S);
 }
 
 // ---- libyuv's fixed point (8-bit RGB -> 8-bit planes, BT.601, appendix D.5): same loads, stores and strip walk ----
@@ -310,7 +390,7 @@ __device__ __forceinline__ void computeStripFx(const R2YArgs & A, uint32_t sy, u
     }
 }
 
-template <int NCH, int SUB>
+template <int NCH, int SUB, int NS>
 __global__ __launch_bounds__(256) void rgbToYuvTileFxKernel(R2YArgs A)
 {
     const uint32_t bands = (A.w4 + 255) / 256;
@@ -318,38 +398,49 @@ __global__ __launch_bounds__(256) void rgbToYuvTileFxKernel(R2YArgs A)
     const uint32_t X = band * 256 + 4 * threadIdx.x;
     const bool laneValid = X < A.w4;
     const uint32_t Xc = laneValid ? X : 0;
-    StripRaw<uint8_t, NCH> cur;
-    uint32_t sy = (chunk * A.stripsPerWave * kWaves + threadIdx.y) * 2;
-    loadStrip<uint8_t, NCH>(A, sy, Xc, cur);
-    for (uint32_t s = 0; s < A.stripsPerWave; ++s) {
-        if (sy >= A.h2)
+    const uint32_t first = (chunk * kWaves + threadIdx.y) * (2 * NS);
+    if (first >= A.h2)
+        return;
+    StripRaw<uint8_t, NCH> raw[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        loadStrip<uint8_t, NCH>(A, first + 2 * s, Xc, raw[s]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (first + 2 * s >= A.h2)
             break;
-        StripRaw<uint8_t, NCH> nxt;
-        const bool more = s + 1 < A.stripsPerWave;
-        if (more)
-            loadStrip<uint8_t, NCH>(A, sy + 2 * kWaves, Xc, nxt);
-        computeStripFx<NCH, SUB>(A, sy, X, laneValid, cur);
-        if (!more)
-            break;
-        cur = nxt;
-        sy += 2 * kWaves;
+        computeStripFx<NCH, SUB>(A, first + 2 * s, X, laneValid, raw[s]);
     }
+}
+
+template <int NCH, int SUB>
+void launchFxOne(const R2YArgs & A, uint32_t blocks, hipStream_t stream)
+{
+    const dim3 block(kLanes, kWaves);
+    if (A.stripsPerWave >= 4)
+        hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB, 4>), dim3(blocks), block, 0, stream, A);
+    else if (A.stripsPerWave >= 2)
+        hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB, 2>), dim3(blocks), block, 0, stream, A);
+    else
+        hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB, 1>), dim3(blocks), block, 0, stream, A);
 }
 
 template <int NCH>
 hipError_t launchFxSub(int sub, const R2YArgs & A, uint32_t blocks, hipStream_t stream)
 {
-    const dim3 block(kLanes, kWaves);
     switch (sub) {
-        case SUB_444: hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB_444>), dim3(blocks), block, 0, stream, A); break;
-        case SUB_422: hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB_422>), dim3(blocks), block, 0, stream, A); break;
-        case SUB_420: hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB_420>), dim3(blocks), block, 0, stream, A); break;
-        default: hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB_400>), dim3(blocks), block, 0, stream, A); break;
+        case SUB_444: launchFxOne<NCH, SUB_444>(A, blocks, stream); break;
+        case SUB_422: launchFxOne<NCH, SUB_422>(A, blocks, stream); break;
+        case SUB_420: launchFxOne<NCH, SUB_420>(A, blocks, stream); break;
+        default: launchFxOne<NCH, SUB_400>(A, blocks, stream); break;
     }
     return hipGetLastError();
 }
 
-template <typename RT, int NCH, typename YT, int SUB>
+// One wave, one tile of 256 x 2*NS pixels (NS vertically consecutive strips), every load issued before the first result is needed; the
+// four waves of a workgroup are stacked and independent.  (Round 1 walked a wave down its strips with the next strip's loads in
+// flight; like in the decode direction, many short-lived waves keep the memory pipes fuller: 4K RGBA8 -> 4:2:0 10.9 -> 9.9 us.)
+template <typename RT, int NCH, typename YT, int SUB, int NS>
 __global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A)
 {
     const uint32_t bands = (A.w4 + 255) / 256;
@@ -357,30 +448,30 @@ __global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A)
     const uint32_t X = band * 256 + 4 * threadIdx.x;
     const bool laneValid = X < A.w4;
     const uint32_t Xc = laneValid ? X : 0;
-    // the 4 waves of a workgroup take adjacent strips; a wave's next strip is 4 strips further down
-    const uint32_t first = (chunk * A.stripsPerWave * kWaves + threadIdx.y) * 2;
-    StripRaw<RT, NCH> cur;
-    uint32_t sy = first;
-    loadStrip<RT, NCH>(A, sy, Xc, cur);
-    for (uint32_t s = 0; s < A.stripsPerWave; ++s) {
-        if (sy >= A.h2)
+    const uint32_t first = (chunk * kWaves + threadIdx.y) * (2 * NS);
+    if (first >= A.h2)
+        return;
+    StripRaw<RT, NCH> raw[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        loadStrip<RT, NCH>(A, first + 2 * s, Xc, raw[s]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (first + 2 * s >= A.h2) // wave-uniform
             break;
-        StripRaw<RT, NCH> nxt;
-        const bool more = s + 1 < A.stripsPerWave;
-        if (more)
-            loadStrip<RT, NCH>(A, sy + 2 * kWaves, Xc, nxt);
-        computeStrip<RT, NCH, YT, SUB>(A, sy, X, laneValid, cur);
-        if (!more)
-            break;
-        cur = nxt;
-        sy += 2 * kWaves;
+        computeStrip<RT, NCH, YT, SUB>(A, first + 2 * s, X, laneValid, raw[s]);
     }
 }
 
 template <typename RT, int NCH, typename YT, int SUB>
 hipError_t launchOne(const R2YArgs & A, uint32_t blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
+    if (A.stripsPerWave >= 4)
+        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 4>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
+    else if (A.stripsPerWave >= 2)
+        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 2>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
+    else
+        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 1>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
     return hipGetLastError();
 }
 
