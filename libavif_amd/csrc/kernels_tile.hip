@@ -43,11 +43,14 @@ TileKey keyFor(const YuvToRgbPlan & p)
         k.sub = SUB_422;
     else
         k.sub = SUB_420;
+    k.gray = p.rgb.isGray != 0;
+    if (k.gray)
+        k.sub = SUB_400; // gray = clamp01(Y): chroma is never read (src/reformat.c:886-892)
     k.bilinear = p.bilinear && (k.sub == SUB_420 || k.sub == SUB_422);
     k.wideRgb = p.rgb.chanBytes == 2;
-    k.nch = p.rgb.is565 ? 2 : (p.rgb.hasAlpha ? 4 : 3);
+    k.nch = k.gray ? (p.rgb.hasAlpha ? 2 : 1) : (p.rgb.is565 ? 2 : (p.rgb.hasAlpha ? 4 : 3));
     k.hasMul = (p.inLoopMul != MUL_NONE) || (p.postMul != MUL_NONE);
-    k.alphaPlane = k.nch == 4 && p.alphaSource == ALPHA_PLANE;
+    k.alphaPlane = p.rgb.hasAlpha && !p.rgb.is565 && p.alphaSource == ALPHA_PLANE;
     k.mapped = p.rgb.map.on != 0;
     k.wideDownshift = k.fixedPoint && k.wideYuv && p.fxDownshift != 0;
     return k;
@@ -65,7 +68,7 @@ const char * kernelNameFor(const TileKey & k, uint32_t tuning)
     // ",pk16": the packed 16-bit kernels (tile_pk_impl.h) serve 8-bit planes of the integer path unless a post-pass follows
     const bool packed = k.fixedPoint && !k.hasMul && (!k.wideYuv || (tuning & TUNE_COOPERATIVE) == 0);
     snprintf(name, sizeof(name), "%s<%s,%s,%s,%s%d%s%s%s%s>", k.fixedPoint ? "yuv2rgb_fixed_tile" : "yuv2rgb_tile", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
-             k.nch == 4 ? "rgba" : (k.nch == 2 ? "rgb565_" : "rgb"), k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "", packed ? ",pk16" : "", k.mapped ? ",mapped" : "");
+             k.gray ? (k.nch == 2 ? "graya" : "gray") : (k.nch == 4 ? "rgba" : (k.nch == 2 ? "rgb565_" : "rgb")), k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "", packed ? ",pk16" : "", k.mapped ? ",mapped" : "");
     return name;
 }
 
@@ -185,8 +188,8 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
                 return false; // a divisor off the verified list (exactdiv.h): the universal kernel divides the IEEE way
         }
     }
-    if (o.isGray)
-        return false;
+    if (o.isGray && p.arith == ARITH_LIBYUV)
+        return false; // (libyuv has no gray entries: never the case)
     if (o.isFloat && (p.arith == ARITH_LIBYUV || o.chanBytes != 2))
         return false; // half-float outputs (Android's RGBA_F16 bitmaps): 16-bit containers, the fp32 kernels convert at the store
     if (o.is565) {
@@ -217,7 +220,7 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
         return false;
     if (!aligned(s.plane[0], s.rowBytes[0], sampleVec))
         return false;
-    if (s.hasColor && (!aligned(s.plane[1], s.rowBytes[1], sampleVec) || !aligned(s.plane[2], s.rowBytes[2], sampleVec)))
+    if (s.hasColor && !o.isGray && (!aligned(s.plane[1], s.rowBytes[1], sampleVec) || !aligned(s.plane[2], s.rowBytes[2], sampleVec)))
         return false;
     const bool readsAlpha = (o.hasAlpha && p.alphaSource == ALPHA_PLANE) || p.inLoopMul != MUL_NONE || p.postMul != MUL_NONE;
     if (readsAlpha && (!s.alpha || !s.alphaRowBytes || !aligned(s.alpha, s.alphaRowBytes, sampleVec)))
@@ -225,7 +228,7 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
     if (p.postMul != MUL_NONE && p.alphaSource != ALPHA_PLANE)
         return false;
     const int nch = o.is565 ? 2 : (o.hasAlpha ? 4 : 3);
-    const uint32_t storeAlign = o.map.on ? 1u : ((nch == 4) ? 16u : (nch == 2 ? 8u : (o.chanBytes == 1 ? 4u : 8u)));
+    const uint32_t storeAlign = o.map.on ? 1u : (o.isGray ? 4u * (uint32_t)o.pixBytes : ((nch == 4) ? 16u : (nch == 2 ? 8u : (o.chanBytes == 1 ? 4u : 8u))));
     if (!aligned(o.pixels, o.rowBytes, storeAlign))
         return false;
     // 32-bit lane offsets from the plane bases
@@ -242,7 +245,7 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
     const TileKey k = keyFor(plan);
     return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) | ((k.nch == 2 ? 1 : 0) << 10) |
            ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7) | ((k.fixedPoint ? 1 : 0) << 8) | ((k.mapped ? 1 : 0) << 9) |
-           ((k.wideDownshift ? 1 : 0) << 11);
+           ((k.wideDownshift ? 1 : 0) << 11) | ((k.gray ? 1 : 0) << 12);
 }
 
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)

@@ -257,6 +257,31 @@ __device__ __forceinline__ void store4(uint8_t * base, uint32_t off, const Pixel
     }
 }
 
+// Gray layouts (GRAY, GRAYA, AGRAY): 4, 8 or 16 bytes per lane, one store.  The value is the pixel's G channel: with no chroma every
+// colour channel equals clamp01(Y) and goes through the same alpha multiply and quantiser as the reference's `grayc`
+// (src/reformat.c:886-892, :894-947, :952-961).
+template <typename RT, int NCH>
+__device__ __forceinline__ void storeGray4(uint8_t * base, uint32_t off, const PixelOut q[4], const unsigned a[4], bool alphaFirst, bool nt)
+{
+    if constexpr (sizeof(RT) == 1 && NCH == 1) {
+        storeVec(base, off, q[0].g | (q[1].g << 8) | (q[2].g << 16) | (q[3].g << 24), nt);
+    } else if constexpr (sizeof(RT) == 1) {
+        unsigned p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            p[k] = alphaFirst ? (a[k] | (q[k].g << 8)) : (q[k].g | (a[k] << 8));
+        storeVec(base, off, (u2) { p[0] | (p[1] << 16), p[2] | (p[3] << 16) }, nt);
+    } else if constexpr (NCH == 1) {
+        storeVec(base, off, (u2) { q[0].g | (q[1].g << 16), q[2].g | (q[3].g << 16) }, nt);
+    } else {
+        u4 w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            w[k] = alphaFirst ? (a[k] | (q[k].g << 16)) : (q[k].g | (a[k] << 16));
+        storeVec(base, off, w, nt);
+    }
+}
+
 // 16-bit RGBA: a lane's 4 pixels are 32 bytes.  Two 16-byte stores at (32*lane, 32*lane + 16) make every store
 // instruction touch only half of each cache line (tests/tools/membw3.hip: cfg3's bytes take 111 us that way and 74 us
 // with contiguous instructions), so the wave first re-distributes its 2 KiB row segment through a wave-private LDS
@@ -560,7 +585,7 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
     const uint32_t X = c.X;
     const bool laneValid = c.laneValid;
     const StripRaw<YT, SUB, BIL, kNeedA> * raw = T.raw;
-    const bool alphaFirst = (NCH == 4) && (A.slotA == 0);
+    const bool alphaFirst = (NCH == 4 || NCH == 2) && (A.slotA == 0);
     // (first colour X, third colour Z) of a pixel from the two chroma planes in TileArgs order (tile_shared.h): for BGR
     // orders (Cb,Cr) -> (B - Y, R - Y), src/reformat.c:874-875; for RGB orders the planes and coefficients arrive swapped
     const f2 cBR = { A.cB, A.cR };
@@ -721,7 +746,7 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                 }
             }
 
-            if constexpr (sizeof(RT) == 1 && !HASMUL) {
+            if constexpr (sizeof(RT) == 1 && !HASMUL && NCH >= 3) {
                 // 8-bit outputs: t = 0.5f + c * 255, then truncate + saturate + pack in one instruction per channel
                 const f2 half = splat(0.5f), mx = splat(A.rgbMaxF);
                 f2 tbr[4];
@@ -768,6 +793,9 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                     store4WideRgba(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, a, alphaFirst, c.bandX, A.w4, xchg[wv]);
                 } else if constexpr (NCH == 3) {
                     store4Rgb3<RT>(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, segBytes, xchg[wv]);
+                } else if constexpr (NCH <= 2) {
+                    if (laneValid)
+                        storeGray4<RT, NCH>(A.rgb, off, q, a, alphaFirst, nt);
                 } else {
                     if (laneValid)
                         store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
@@ -966,6 +994,15 @@ hipError_t launchOne(const TileLaunch & L)
 template <typename YT, int SUB, bool BIL, typename RT>
 hipError_t launchAlphaVariant(const TileKey & k, const TileLaunch & L)
 {
+    if constexpr (SUB == SUB_400) { // gray layouts read luma (and alpha) only, whatever the image's chroma layout: wave-private kernels
+        if (k.nch == 1)
+            return k.hasMul ? launchSolo<YT, SUB, BIL, RT, 1, false, true>(L) : launchSolo<YT, SUB, BIL, RT, 1, false, false>(L);
+        if (k.nch == 2) {
+            if (k.hasMul)
+                return launchSolo<YT, SUB, BIL, RT, 2, true, true>(L);
+            return k.alphaPlane ? launchSolo<YT, SUB, BIL, RT, 2, true, false>(L) : launchSolo<YT, SUB, BIL, RT, 2, false, false>(L);
+        }
+    }
     if (k.nch == 3)
         return k.hasMul ? launchOne<YT, SUB, BIL, RT, 3, false, true>(L) : launchOne<YT, SUB, BIL, RT, 3, false, false>(L);
     if (k.hasMul)

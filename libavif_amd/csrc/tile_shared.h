@@ -201,6 +201,7 @@ struct TileKey
     bool hasMul;
     bool mapped;     // stores go through a PixelMap (fused crop / rotate / mirror)
     bool wideDownshift; // integer path on 16-bit containers: samples are reduced to 8 bits first (no high-bit-depth libyuv entry)
+    bool gray;          // GRAY / GRAYA / AGRAY outputs: nch = 1 or 2, luma only
 };
 
 struct TileLaunch

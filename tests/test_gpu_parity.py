@@ -47,7 +47,7 @@ def test_yuv_to_rgb_small_sweep_device(hip):
 def test_yuv_to_rgb_tiled_sweep_host(hip):
     hip.avifhipSetTiledKernels(1)
     kernels = _compare_y2r(H.hip_host_backend(), H.oracle_backend(), H.y2r_sweep(TILED, n_random=500, seed=5), "yuv2rgb_tile")
-    assert "yuv2rgb_generic" in kernels  # gray outputs, YCgCo matrices, wider identity copies still go through the universal kernel
+    assert "yuv2rgb_generic" in kernels  # YCgCo matrices, wider identity copies, untouched alpha bytes still go through the universal kernel
 
 
 def test_half_float_and_identity_copy_use_the_tiled_kernels(hip):
@@ -66,6 +66,24 @@ def test_half_float_and_identity_copy_use_the_tiled_kernels(hip):
     for c in cases:
         H.run_y2r(H.HipDeviceBackend(), c)
         assert native.last_kernel().startswith("yuv2rgb_tile"), (c.ident(), native.last_kernel())
+    _compare_y2r(H.HipDeviceBackend(), H.oracle_backend(), cases)
+    _compare_y2r(H.hip_host_backend(), H.oracle_backend(), cases)
+
+
+def test_gray_outputs_use_the_tiled_kernels(hip):
+    """GRAY / GRAYA / AGRAY outputs (clamp01(Y) through the alpha multiply and the quantiser, src/reformat.c:886-961) read luma and alpha
+    only and are served by the 4:0:0 instantiations of the bandwidth-tuned kernels, whatever the image's chroma layout."""
+    hip.avifhipSetTiledKernels(1)
+    cases = []
+    for (w, h) in TILED:
+        for fmt, yf, yd, rd, alpha, prem, fl in ((7, 1, 8, 8, False, False, False), (7, 3, 10, 16, True, False, False), (8, 3, 8, 8, True, False, False),
+                                                 (9, 2, 12, 12, True, True, False), (8, 4, 10, 8, False, False, False), (9, 1, 8, 16, True, False, False),
+                                                 (8, 3, 10, 16, True, False, True), (7, 3, 8, 16, False, False, True)):
+            cases.append(H.Y2RCase(w, h, rgb_format=fmt, rgb_depth=rd, yuv_depth=yd, yuv_format=yf, alpha=alpha, rgb_premultiplied=prem, is_float=fl,
+                                   matrix=(1, 6, 9)[(w + fmt) % 3], yuv_range=(w + yd) % 2, upsampling=(3, 4)[(h + fmt) % 2]))
+    for c in cases:
+        H.run_y2r(H.HipDeviceBackend(), c)
+        assert native.last_kernel().startswith("yuv2rgb_tile") and "gray" in native.last_kernel(), (c.ident(), native.last_kernel())
     _compare_y2r(H.HipDeviceBackend(), H.oracle_backend(), cases)
     _compare_y2r(H.hip_host_backend(), H.oracle_backend(), cases)
 

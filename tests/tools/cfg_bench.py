@@ -84,6 +84,16 @@ def run(name):
             fmt = abi.AVIF_RGB_FORMAT_RGB if name == "ident8rgb" else abi.AVIF_RGB_FORMAT_RGBA
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 0, 8, avoid=avoid, rgb_format=fmt)
             px, bpp, ms = 7680 * 4320, (6.0 if name == "ident8rgb" else 7.0), time_y2r(pair)
+        elif name in ("gray8", "graya16"):
+            # gray layouts: 8K 8-bit 4:2:0 -> GRAY8 (luma only: 1 + 1 B/px); 8K 10-bit 4:2:0 + alpha -> GRAYA16 (2 + 2 + 4 B/px)
+            if arith == "integer":
+                continue  # libyuv has no gray entries: one arithmetic
+            if name == "gray8":
+                pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_GRAY)
+                px, bpp, ms = 7680 * 4320, 2.0, time_y2r(pair)
+            else:
+                pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_GRAYA)
+                px, bpp, ms = 7680 * 4320, 8.0, time_y2r(pair)
         elif name == "cfg2_rgb":
             # 3-byte pixels (what avifdec hands to its JPEG / opaque PNG writers): 8K 8-bit 4:2:0 -> RGB8, bilinear, 1.5 + 3 B/px
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB)
