@@ -156,7 +156,8 @@ __device__ __forceinline__ unsigned add3(unsigned a, unsigned b, unsigned c)
 
 // ---- chroma neighbourhood: loads of one staging round (8 columns of both planes per lane) ----
 template <int SUB, int NSW, int WIDE>
-__device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int rowBase, int round, typename PkTypes<WIDE>::Col8 & uD, typename PkTypes<WIDE>::Col8 & vD)
+__device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int rowBase, int round, int slotMin, int slotMax, typename PkTypes<WIDE>::Col8 & uD,
+                                            typename PkTypes<WIDE>::Col8 & vD)
 {
     typedef PkStage<SUB, NSW> ST;
     typedef typename PkTypes<WIDE>::Col8 Col8;
@@ -167,7 +168,7 @@ __device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int row
     const int i = round * kPkRowsPerRound + rr;
     uD = Col8 {};
     vD = Col8 {};
-    if (rr < kPkRowsPerRound && i < ST::kRows) {
+    if (rr < kPkRowsPerRound && i < ST::kRows && i >= slotMin && i <= slotMax) {
         // coordinates clamp to the job's chroma window (the whole plane unless the canvas is a grid of separately stored tiles):
         // the neighbour of an edge sample is the sample itself, which IS libyuv's edge rule ((3a + a + 2) >> 2 == a)
         const int cy = clampI(rowBase + i, A.cyMin, A.cyMax);
@@ -200,14 +201,15 @@ __device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int row
 // 16-bit row functions are defined on that domain, ScaleRowUp2_Bilinear_12); WIDE_DOWNSHIFT: samples are cut to
 // bytes (`shiftSplat` = depth - 8 in both halves) and staged like 8-bit ones.
 template <int SUB, int NSW, int WIDE>
-__device__ __forceinline__ void pkStageStore(int round, const typename PkTypes<WIDE>::Col8 & uD, const typename PkTypes<WIDE>::Col8 & vD, unsigned shiftSplat, unsigned * ring)
+__device__ __forceinline__ void pkStageStore(int round, int slotMin, int slotMax, const typename PkTypes<WIDE>::Col8 & uD, const typename PkTypes<WIDE>::Col8 & vD,
+                                             unsigned shiftSplat, unsigned * ring)
 {
     typedef PkStage<SUB, NSW> ST;
     const int lane = threadIdx.x;
     const int rr = (lane * 241) >> 12;
     const int j = lane - rr * kPkGroups;
     const int i = round * kPkRowsPerRound + rr;
-    if (rr < kPkRowsPerRound && i < ST::kRows) {
+    if (rr < kPkRowsPerRound && i < ST::kRows && i >= slotMin && i <= slotMax) {
         unsigned w[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -402,6 +404,9 @@ struct PkRaw
 struct PkSpot
 {
     uint32_t band, strip0;
+    // staged chroma rows (slots 0 .. kRows-1 of the wave's neighbourhood) this wave loads and stages itself; the others are staged by
+    // the waves above and below it in the workgroup (pkRunBlock: shared halo rows)
+    int slotMin, slotMax;
 };
 
 // ---- every load of a wave tile, longest dependency chain first ----
@@ -425,7 +430,7 @@ __device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkR
         const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)w.strip0 - 1 : A.cy0 + 2 * (int)w.strip0;
 #pragma unroll
         for (int t = 0; t < ST::kRounds; ++t)
-            pkStageLoad<SUB, NSW, WIDE>(A, cxb, rowBase, t, R.uD[t], R.vD[t]);
+            pkStageLoad<SUB, NSW, WIDE>(A, cxb, rowBase, t, w.slotMin, w.slotMax, R.uD[t], R.vD[t]);
     }
 #pragma unroll
     for (int s = 0; s < NSW; ++s) {
@@ -462,7 +467,7 @@ __device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkR
 // ---- the chroma neighbourhood into the wave's LDS block.  Wave-private: the LDS instructions of one wave execute in order;
 //      the fences keep the compiler from moving the reads above the writes ----
 template <int SUB, bool BIL, bool APLANE, int NSW, int WIDE>
-__device__ __forceinline__ void pkStage(const TileArgs & A, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, unsigned * ring)
+__device__ __forceinline__ void pkStage(const TileArgs & A, const PkSpot & w, bool shared, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, unsigned * ring)
 {
 #ifdef AVIFHIP_ABLATE_STAGE // measurement only (tests/tools/pkbench_wide.hip): nothing is staged, the filter reads whatever the LDS holds
     if constexpr (false) {
@@ -472,10 +477,14 @@ __device__ __forceinline__ void pkStage(const TileArgs & A, const PkRaw<SUB, BIL
         const unsigned shiftSplat = A.fx.downshift * 0x00010001u;
 #pragma unroll
         for (int t = 0; t < PkStage<SUB, NSW>::kRounds; ++t)
-            pkStageStore<SUB, NSW, WIDE>(t, R.uD[t], R.vD[t], shiftSplat, ring);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            pkStageStore<SUB, NSW, WIDE>(t, w.slotMin, w.slotMax, R.uD[t], R.vD[t], shiftSplat, ring);
+        if (shared) { // workgroup-uniform: the stacked waves read each other's boundary rows -- the kernel's one workgroup barrier
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
 }
 
@@ -710,14 +719,24 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     PkSpot w;
     w.band = (tcol << g.wavesXLog2) + wx;
     w.strip0 = (trow * wavesY + wy) * (uint32_t)NSW;
-    if (w.band * (uint32_t)kBandW >= A.w4 || 2u * w.strip0 >= A.h2)
-        return; // tiles at the right / bottom edge: a wave without work simply leaves
-    unsigned * ring = lds + wave * (uint32_t)kRingWords;
+    // 4:2:0 with the four waves stacked: consecutive waves' chroma neighbourhoods overlap in two rows (the halo above and below each
+    // wave's NSW rows).  When frames stream from HBM those re-reads are not served by a cache any more (tests/tools/pkbench_wide.hip:
+    // the staged kernel costs exactly the halo's bytes more than nearest upsampling), so the workgroup stages ONE neighbourhood of
+    // 4 * NSW + 2 rows -- every wave its own NSW rows, the first and the last wave one halo row each -- and meets at one barrier.
+    const bool shared = RawT::kStaged && SUB == SUB_420 && g.wavesXLog2 == 0 && (A.tuning & TUNE_PRIVATE_HALO) == 0; // workgroup-uniform
+    const bool bandValid = w.band * (uint32_t)kBandW < A.w4, rowsValid = 2u * w.strip0 < A.h2;
+    if (!bandValid || (!rowsValid && !shared))
+        return; // tiles at the right / bottom edge: a wave without work simply leaves (sharing: its rows are still its neighbour's halo)
+    w.slotMin = (shared && wy > 0) ? 1 : 0;
+    w.slotMax = (shared && wy + 1 < wavesY) ? NSW : NSW + 1;
+    unsigned * ring = shared ? lds + wy * (uint32_t)(NSW * kPkPitch) : lds + wave * (uint32_t)kRingWords;
     // 3-byte pixels, stored as rows: one exchange buffer per wave behind the chroma blocks
     WideRowExchange * xchg = (NCH == 3 && !MAPPED) ? reinterpret_cast<WideRowExchange *>(lds + kWavesPerBlock * PkLds<SUB, BIL, NCH, NSW, MAPPED>::kRingWords) + wave : nullptr;
     RawT raw;
     pkLoad<SUB, BIL, APLANE, NSW, WIDE>(A, w, raw);
-    pkStage<SUB, BIL, APLANE, NSW, WIDE>(A, raw, ring);
+    pkStage<SUB, BIL, APLANE, NSW, WIDE>(A, w, shared, raw, ring);
+    if (!rowsValid)
+        return;
     pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, w, raw, ring, xchg);
 }
 

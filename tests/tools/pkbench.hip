@@ -15,6 +15,9 @@
 #ifndef PKB_BIL
 #define PKB_BIL true
 #endif
+#ifndef PKB_TUNING
+#define PKB_TUNING TUNE_DEFAULT
+#endif
 using namespace avifhip;
 using namespace avifhip::tile;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -56,7 +59,7 @@ int main(int argc, char ** argv)
         rgb.chromaUpsampling = PKB_BIL ? AVIF_CHROMA_UPSAMPLING_BILINEAR : AVIF_CHROMA_UPSAMPLING_NEAREST; rgb.avoidLibYUV = 0; rgb.maxThreads = 1;
         rgb.pixels = o[k]; rgb.rowBytes = W * 4;
         YuvToRgbPlan plan;
-        if (makeYuvToRgbPlan(&img, &rgb, nullptr, 0, TUNE_DEFAULT, &plan) != AVIF_RESULT_OK || plan.arith != ARITH_LIBYUV) { printf("plan failed\n"); return 1; }
+        if (makeYuvToRgbPlan(&img, &rgb, nullptr, 0, PKB_TUNING, &plan) != AVIF_RESULT_OK || plan.arith != ARITH_LIBYUV) { printf("plan failed\n"); return 1; }
         args[k] = distillArgs(plan);
     }
     TileLaunch L; memset(&L, 0, sizeof(L));
@@ -64,7 +67,7 @@ int main(int argc, char ** argv)
     uint32_t nsw, blocks; PkGeom g;
     pkGeometry(L, W, H, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock), grid(blocks);
-    auto launch = [&](int k) { hipLaunchKernelGGL((yuvToRgbPkKernel<SUB_420, PKB_BIL, 4, false, PKB_NSW, false>), grid, block, 0, 0, args[k], g); };
+    auto launch = [&](int k) { hipLaunchKernelGGL((yuvToRgbPkKernel<SUB_420, PKB_BIL, 4, false, PKB_NSW, false, WIDE_NONE>), grid, block, 0, 0, args[k], g); };
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3000; ++i) launch(i % 4); // clock ramp
     float res[2];

@@ -15,6 +15,9 @@
 #ifndef PKB_BIL
 #define PKB_BIL true
 #endif
+#ifndef PKB_TUNING
+#define PKB_TUNING TUNE_DEFAULT
+#endif
 using namespace avifhip;
 using namespace avifhip::tile;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -44,7 +47,7 @@ int main(int argc, char ** argv)
         rgb.chromaUpsampling = PKB_BIL ? AVIF_CHROMA_UPSAMPLING_BILINEAR : AVIF_CHROMA_UPSAMPLING_NEAREST; rgb.avoidLibYUV = 0; rgb.maxThreads = 1;
         rgb.pixels = o; rgb.rowBytes = W * 4;
         YuvToRgbPlan plan;
-        if (makeYuvToRgbPlan(&img, &rgb, nullptr, 0, TUNE_DEFAULT, &plan) != AVIF_RESULT_OK || plan.arith != ARITH_LIBYUV || plan.fxDownshift) { printf("plan failed\n"); return 1; }
+        if (makeYuvToRgbPlan(&img, &rgb, nullptr, 0, PKB_TUNING, &plan) != AVIF_RESULT_OK || plan.arith != ARITH_LIBYUV || plan.fxDownshift) { printf("plan failed\n"); return 1; }
         args[k] = distillArgs(plan);
     }
     TileArgs * table; CK(hipMalloc(&table, sizeof(TileArgs) * NJ)); CK(hipMemcpy(table, args.data(), sizeof(TileArgs) * NJ, hipMemcpyHostToDevice));
