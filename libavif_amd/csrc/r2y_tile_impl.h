@@ -127,6 +127,10 @@ __device__ __forceinline__ void loadStrip(const R2YArgs & A, uint32_t sy, uint32
     S.row[1] = loadRow<RT, NCH>(A.rgb, (syc + 1) * A.rgbPitch + Xc * kPix);
 }
 
+// (3-channel pixels are read with three dword loads per lane and row.  The decode direction's cure for 3-byte STORES -- 16-byte accesses
+//  at consecutive addresses, redistributed through a wave-private LDS buffer -- was measured for these LOADS and is slower: 8K RGB8 ->
+//  4:2:0 32.5 us against 29.7 us, 4K 9.5 against 8.8: partial-line reads are absorbed by the caches, partial-line writes are not.)
+
 // ---- fp32 arithmetic on pixel PAIRS: gfx950 multiplies and adds two fp32 lanes per instruction (v_pk_mul_f32 / v_pk_add_f32 /
 //      v_pk_fma_f32, each component rounded exactly like the scalar instruction), so horizontally adjacent pixels share every
 //      normalisation, matrix and quantisation instruction ----

@@ -105,10 +105,10 @@ def run(name):
         elif name == "cfg3":
             pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, avoid=avoid)
             px, bpp, ms = 7680 * 4320, 16.0, time_y2r(pair, 20)
-        elif name in ("cfg4", "cfg4rgb", "cfg4_601", "cfg4_8k"):
-            fmt = abi.AVIF_RGB_FORMAT_RGB if name == "cfg4rgb" else abi.AVIF_RGB_FORMAT_RGBA
+        elif name in ("cfg4", "cfg4rgb", "cfg4_601", "cfg4_8k", "cfg4rgb_8k"):
+            fmt = abi.AVIF_RGB_FORMAT_RGB if name.startswith("cfg4rgb") else abi.AVIF_RGB_FORMAT_RGBA
             mc = 6 if name == "cfg4_601" else 1
-            w, h = (7680, 4320) if name == "cfg4_8k" else (3840, 2160)  # the encode direction on the headline's frame size
+            w, h = (7680, 4320) if name.endswith("_8k") else (3840, 2160)  # the encode direction on the headline's frame size
             rgb = abi.make_rgb(w, h, 8, fmt, avoid_libyuv=avoid)
             synth.fill_rgb(rgb, 0x12345678, opaque=True)
             img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, mc, with_alpha=(fmt == abi.AVIF_RGB_FORMAT_RGBA))
