@@ -259,7 +259,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     L.table = nullptr;
     L.count = 1;
     L.stream = stream;
-    L.mapped = k.mapped;
+    L.mapped = k.mapped, L.transposed = k.mapped && plan.rgb.map.transposed;
     decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)A.w4 * A.h2) || (plan.tuning & TUNE_SOLO_ALWAYS));
     L.pkWide = (plan.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift;
@@ -306,7 +306,7 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
     L.table = static_cast<const TileArgs *>(deviceTileTable);
     L.count = count;
     L.stream = stream;
-    L.mapped = k.mapped;
+    L.mapped = k.mapped, L.transposed = k.mapped && representative.rgb.map.transposed;
     decompose(representative.tuning, maxW & ~3u, maxH & ~1u, count, true, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)(maxW & ~3u) * (maxH & ~1u) * count) || (representative.tuning & TUNE_SOLO_ALWAYS));
     L.pkWide = (representative.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift;

@@ -514,7 +514,10 @@ __device__ __forceinline__ void pkStoreMappedRow(const TileArgs & A, const unsig
         const bool fwd = m.sx > 0;
         const uint32_t x = (uint32_t)(fwd ? (int32_t)ii + m.kx : m.kx - (int32_t)(ii + 3u));
         const u4 v = fwd ? (u4) { px[0], px[1], px[2], px[3] } : (u4) { px[3], px[2], px[1], px[0] };
-        __builtin_nontemporal_store(v, reinterpret_cast<u4a4 *>(row + (size_t)x * 4u));
+        if (A.tuning & TUNE_NONTEMPORAL)
+            __builtin_nontemporal_store(v, reinterpret_cast<u4a4 *>(row + (size_t)x * 4u));
+        else
+            *reinterpret_cast<u4a4 *>(row + (size_t)x * 4u) = v;
         return;
     }
 #pragma unroll
@@ -560,9 +563,67 @@ __device__ __forceinline__ void pkStoreMappedColumns(const TileArgs & A, const u
     }
 }
 
+// Quarter turns, the four waves stacked: the workgroup's tile (256 columns x ROWS = 8 * NSW rows) is transposed through LDS, so that a
+// source COLUMN leaves as one run of ROWS consecutive destination pixels (128 bytes for 32 rows) and a store instruction writes 8 such
+// runs, 16 bytes per lane -- whole cache lines instead of the 32-byte pieces of pkStoreMappedColumns.  Layout: word (y, x) of the tile
+// at y * 256 + (x ^ 4 * ((y >> 2) & 7)): rows are written with aligned 16-byte LDS stores (the swizzle moves whole 4-word groups) and
+// read column-wise with two lanes per bank.  `tile` is shared by the workgroup; the caller's barrier separates it from the chroma
+// neighbourhoods it overlays.
+template <int NCH, int NSW>
+__device__ __forceinline__ void pkTransposeWrite(unsigned * tile, uint32_t wy, const unsigned (*held)[4])
+{
+    const uint32_t l = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 2 * NSW; ++r) {
+        const uint32_t y = wy * (uint32_t)(2 * NSW) + (uint32_t)r;
+        *reinterpret_cast<u4 *>(tile + y * 256u + 4u * (l ^ ((y >> 2) & 7u))) = (u4) { held[r][0], held[r][1], held[r][2], held[r][3] };
+    }
+}
+
+template <int NCH, int NSW>
+__device__ __forceinline__ void pkTransposeStore(const TileArgs & A, const unsigned * tile, uint32_t wv, uint32_t bandX0, uint32_t row0)
+{
+    constexpr uint32_t ROWS = 8 * NSW, RL = ROWS / 4, RUNS = 64 / RL; // lanes per run, runs per store instruction
+    const PixelMap & m = A.map;
+    const uint32_t l = threadIdx.x, t4 = l % RL;
+    const bool fwd = m.sx > 0;
+#pragma unroll
+    for (uint32_t q = 0; q < RL; ++q) {
+        const uint32_t xs = (wv * RL + q) * RUNS + l / RL; // source column of the tile
+        if (bandX0 + xs >= A.w4)
+            continue;
+        const uint32_t ii = (uint32_t)A.mapX0 + bandX0 + xs - m.cx;
+        if (ii >= m.cw)
+            continue;
+        uint8_t * dstRow = A.rgb + (size_t)(uint32_t)(m.sy * (int32_t)ii + m.ky) * A.rgbPitch;
+        // the lane's four pixels in ascending destination order: tile rows 4 * t4 .. + 3, backwards when the turn reverses them
+        unsigned px[4];
+        uint32_t jj[4];
+        bool ok[4], all = true;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t p = 4u * t4 + k, yr = fwd ? p : ROWS - 1u - p;
+            px[k] = tile[yr * 256u + (xs ^ (4u * ((yr >> 2) & 7u)))];
+            jj[k] = (uint32_t)A.mapY0 + row0 + yr - m.cy;
+            ok[k] = row0 + yr < A.h2 && jj[k] < m.ch;
+            all = all && ok[k];
+        }
+        if (NCH == 4 && all) {
+            const uint32_t x0 = (uint32_t)(m.sx * (int32_t)jj[0] + m.kx);
+            *reinterpret_cast<u4a4 *>(dstRow + (size_t)x0 * 4u) = (u4) { px[0], px[1], px[2], px[3] };
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (ok[k])
+                    pkStorePixel<NCH>(dstRow + (size_t)(uint32_t)(m.sx * (int32_t)jj[k] + m.kx) * NCH, px[k]);
+        }
+    }
+}
+
 // ---- filter, matrix, stores of a wave tile ----
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
-__device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, const unsigned * ring, WideRowExchange * xchg)
+__device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, const unsigned * ring, WideRowExchange * xchg,
+                                          unsigned * xposeTile, uint32_t wy)
 {
     constexpr bool kStaged = PkRaw<SUB, BIL, APLANE, NSW, WIDE>::kStaged;
     // 16-bit containers, wave-uniform shift pairs: filtered fields (weight sum 16 or 4) / plain samples down to a byte
@@ -683,7 +744,12 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
         }
     }
     if constexpr (MAPPED) {
-        if (A.map.transposed && laneValid) {
+        if (A.map.transposed && xposeTile) { // workgroup-uniform: every wave of the workgroup is here, with or without rows of its own
+            __syncthreads(); // the tile overlays the chroma neighbourhoods: every wave is done reading them
+            pkTransposeWrite<NCH, NSW>(xposeTile, wy, held);
+            __syncthreads();
+            pkTransposeStore<NCH, NSW>(A, xposeTile, wy, bandX0, 2u * (w.strip0 - wy * (uint32_t)NSW));
+        } else if (A.map.transposed && laneValid && w.strip0 < strips) {
             const uint32_t left = strips - w.strip0; // strips of the tile that exist (at least one)
             pkStoreMappedColumns<NCH, 2 * NSW>(A, held, (uint32_t)A.mapX0 + X, (uint32_t)A.mapY0 + 2u * w.strip0, 2u * (left < (uint32_t)NSW ? left : (uint32_t)NSW));
         }
@@ -701,7 +767,9 @@ struct PkLds
 {
     static constexpr int kRingWordsRaw = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
     static constexpr int kRingWords = (NCH == 3 && !MAPPED) ? ((kRingWordsRaw + 3) & ~3) : kRingWordsRaw;
-    static constexpr int kWords = kWavesPerBlock * kRingWords + ((NCH == 3 && !MAPPED) ? kWavesPerBlock * (int)(sizeof(WideRowExchange) / 4) : 0);
+    static constexpr int kXposeWords = MAPPED ? 8 * NSW * 256 : 0; // quarter turns: the workgroup's tile, overlaying the chroma blocks
+    static constexpr int kPlain = kWavesPerBlock * kRingWords + ((NCH == 3 && !MAPPED) ? kWavesPerBlock * (int)(sizeof(WideRowExchange) / 4) : 0);
+    static constexpr int kWords = kPlain > kXposeWords ? kPlain : kXposeWords;
 };
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
@@ -725,7 +793,9 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     // 4 * NSW + 2 rows -- every wave its own NSW rows, the first and the last wave one halo row each -- and meets at one barrier.
     const bool shared = RawT::kStaged && SUB == SUB_420 && g.wavesXLog2 == 0 && (A.tuning & TUNE_PRIVATE_HALO) == 0; // workgroup-uniform
     const bool bandValid = w.band * (uint32_t)kBandW < A.w4, rowsValid = 2u * w.strip0 < A.h2;
-    if (!bandValid || (!rowsValid && !shared))
+    // quarter turns through LDS (pkTransposeStore) need the four waves stacked, all of them to the end
+    const bool xpose = MAPPED && A.map.transposed && g.wavesXLog2 == 0 && (A.tuning & TUNE_PRIVATE_HALO) == 0; // workgroup-uniform
+    if (!bandValid || (!rowsValid && !shared && !xpose))
         return; // tiles at the right / bottom edge: a wave without work simply leaves (sharing: its rows are still its neighbour's halo)
     w.slotMin = (shared && wy > 0) ? 1 : 0;
     w.slotMax = (shared && wy + 1 < wavesY) ? NSW : NSW + 1;
@@ -735,22 +805,22 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     RawT raw;
     pkLoad<SUB, BIL, APLANE, NSW, WIDE>(A, w, raw);
     pkStage<SUB, BIL, APLANE, NSW, WIDE>(A, w, shared, raw, ring);
-    if (!rowsValid)
+    if (!rowsValid && !xpose)
         return;
-    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, w, raw, ring, xchg);
+    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, w, raw, ring, xchg, xpose ? lds : nullptr, wy);
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
 __global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g)
 {
-    __shared__ __attribute__((aligned(16))) unsigned lds[PkLds<SUB, BIL, NCH, NSW, MAPPED>::kWords];
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
     pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, g, lds);
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
 __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
-    __shared__ __attribute__((aligned(16))) unsigned lds[PkLds<SUB, BIL, NCH, NSW, MAPPED>::kWords];
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
     pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(job, g, lds);
 }
@@ -763,16 +833,20 @@ hipError_t launchPkMapped(const TileLaunch & L)
     pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(blocks, 1, L.count);
+    // LDS: the waves' chroma blocks (+ exchange buffers); quarter turns overlay them with the workgroup's transposition tile
+    const bool xpose = MAPPED && L.transposed;
+    const uint32_t lds4 = 4u * (uint32_t)(xpose ? PkLds<SUB, BIL, NCH, 4, MAPPED>::kWords : PkLds<SUB, BIL, NCH, 4, MAPPED>::kPlain);
+    const uint32_t lds2 = 4u * (uint32_t)(xpose ? PkLds<SUB, BIL, NCH, 2, MAPPED>::kWords : PkLds<SUB, BIL, NCH, 2, MAPPED>::kPlain);
     if (L.table) {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, 0, L.stream, L.table, g);
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, lds4, L.stream, L.table, g);
         else
-            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, 0, L.stream, L.table, g);
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, lds2, L.stream, L.table, g);
     } else {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, 0, L.stream, *L.args, g);
+            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, lds4, L.stream, *L.args, g);
         else
-            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, 0, L.stream, *L.args, g);
+            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, lds2, L.stream, *L.args, g);
     }
     return hipGetLastError();
 }
