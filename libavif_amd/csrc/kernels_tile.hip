@@ -203,7 +203,7 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
     if (o.map.on) {
         // fused crop / rotate / mirror: the packed 16-bit kernels store through the map; every other family leaves it to the
         // universal kernel (the entry points convert into scratch and run the transform pass instead: api.cpp)
-        const bool packed = p.arith == ARITH_LIBYUV && s.chanBytes == 1 && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE;
+        const bool packed = p.arith == ARITH_LIBYUV && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE && (s.chanBytes == 1 || (p.tuning & TUNE_COOPERATIVE) == 0);
         if (!packed || (o.pixBytes != 4 && o.pixBytes != 3))
             return false;
         if (((uintptr_t)o.pixels % 4) != 0 || (o.rowBytes % 4) != 0)

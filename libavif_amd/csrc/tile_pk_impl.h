@@ -861,6 +861,8 @@ hipError_t launchPk(const TileLaunch & L)
 template <int SUB, bool BIL, int NCH, bool APLANE>
 hipError_t launchPkWide(const TileLaunch & L)
 {
+    if (L.mapped)
+        return L.wideDownshift ? launchPkMapped<SUB, BIL, NCH, APLANE, true, WIDE_DOWNSHIFT>(L) : launchPkMapped<SUB, BIL, NCH, APLANE, true, WIDE_NATIVE>(L);
     return L.wideDownshift ? launchPkMapped<SUB, BIL, NCH, APLANE, false, WIDE_DOWNSHIFT>(L) : launchPkMapped<SUB, BIL, NCH, APLANE, false, WIDE_NATIVE>(L);
 }
 

@@ -28,6 +28,9 @@ def grid_cases(avoid_libyuv):
         H.GridCase(2, 3, 256, 32, 701, 61, H.Y2RCase(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, **base), alpha_limited=True),
         H.GridCase(2, 2, 320, 40, 639, 79, H.Y2RCase(0, 0, yuv_format=2, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_RGB, upsampling=4, **base)),
         H.GridCase(1, 1, 600, 70, 600, 70, H.Y2RCase(0, 0, yuv_format=1, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_BGRA, upsampling=3, alpha=True, **base)),
+        # 10- and 12-bit tiles into 8-bit pixels: the packed kernels' front ends for 16-bit containers (native I010 route / reduction to 8 bits), fused too
+        H.GridCase(2, 2, 320, 40, 600, 75, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=8, upsampling=4, **base)),
+        H.GridCase(2, 2, 256, 32, 500, 62, H.Y2RCase(0, 0, yuv_depth=12, yuv_format=3, yuv_range=1, matrix=1, rgb_depth=8, upsampling=4, alpha=True, **base), alpha_limited=True),
         # other kernel families: two passes
         H.GridCase(3, 3, 512, 64, 1100, 150, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=10, upsampling=4, **base)),
         H.GridCase(2, 2, 64, 16, 100, 30, H.Y2RCase(0, 0, yuv_format=3, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_RGB_565, upsampling=4, **base)),
@@ -88,6 +91,7 @@ def test_single_image_tail(hip_auto_arithmetic):
     cases = [H.Y2RCase(1030, 518, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, avoid_libyuv=False),
              H.Y2RCase(771, 95, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, avoid_libyuv=False),
              H.Y2RCase(640, 64, yuv_format=1, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_BGR, avoid_libyuv=False),
+             H.Y2RCase(771, 95, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=8, upsampling=4, alpha=True, avoid_libyuv=False),
              H.Y2RCase(300, 40, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, upsampling=4, avoid_libyuv=False)]
     seen = set()
     for c in cases:
@@ -114,7 +118,8 @@ def test_single_image_tail(hip_auto_arithmetic):
             assert np.array_equal(got.pixels[:, : dw * px], want.pixels[:, : dw * px]), (c.ident(), crop, angle, mirror, native.last_kernel(),
                                                                                           H.describe_diff(want.pixels[:, : dw * px], got.pixels[:, : dw * px]))
     assert any(k.endswith(",pk16,mapped>") for k in seen), seen  # the fused route ran
-    assert any(k.startswith("rgb_transform") for k in seen), seen  # ... and so did the two-pass route (10-bit case)
+    assert any(k.startswith("yuv2rgb_fixed_tile<u16") and k.endswith(",pk16,mapped>") for k in seen), seen  # ... for 10-bit planes as well
+    assert any(k.startswith("rgb_transform") for k in seen), seen  # ... and so did the two-pass route (16-bit pixels)
     # argument errors: the destination must have the transformed size
     c = cases[0]
     dimg = device.DeviceYUV(H.make_y2r_inputs(c))

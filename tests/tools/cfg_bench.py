@@ -185,14 +185,15 @@ def run(name):
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
             px, bpp, ms = 7664 * 4312, 8.0, best
-        elif name in ("tail0", "tail180", "tail90", "tail90_two_pass", "tail180_two_pass"):
+        elif name in ("tail0", "tail180", "tail90", "tail90_two_pass", "tail180_two_pass", "tail0_10", "tail90_10", "tail90_10_two_pass"):
             # the decode-side tail fused (avifhipImageYUVToRGBTransformedAsync): 8K 8-bit 4:2:0 -> RGBA8 bilinear with clap crop +
             # irot + imir, against the same result in two passes (conversion, then avifhipRGBImageTransformAsync).  5.5 B/pixel of
             # the cropped image is what HAS to move.
             if arith == "float":
                 continue  # the fused route is the integer path's (the fp32 kernels take the two-pass route inside the same call)
-            angle = {"tail0": 0, "tail180": 2, "tail90": 1, "tail90_two_pass": 1, "tail180_two_pass": 2}[name]
-            img = abi.make_yuv(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+            deep = "_10" in name  # 10-bit planes (HDR photographs): 3 + 4 B/pixel
+            angle = {"tail0": 0, "tail180": 2, "tail90": 1, "tail90_two_pass": 1, "tail180_two_pass": 2}[name.replace("_10", "")]
+            img = abi.make_yuv(7680, 4320, 10 if deep else 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
             synth.fill_yuv(img, 0x12345678)
             dimg = device.DeviceYUV(img)
             crop = abi.avifCropRect(8, 4, 7664, 4312)
@@ -219,7 +220,7 @@ def run(name):
                     call()
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
-            px, bpp, ms = 7664 * 4312, 5.5, best
+            px, bpp, ms = 7664 * 4312, (7.0 if deep else 5.5), best
         elif name in ("cfg5grid", "cfg5grid_8"):
             # BASELINE configs[4]: 8 x 8 grid of decoded 1920x1080 10-bit 4:2:0 tiles -> one 15360x8640 RGBA canvas, tiles
             # converted where they lie (avifhipGridYUVToRGBAsync: no YUV canvas, seams redone across tiles)
