@@ -186,7 +186,8 @@ avifResult ensureContext()
         HIP_TRY(hipEventCreateWithFlags(&tls.tableCopied[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&tls.tableConsumed[k], hipEventDisableTiming));
     }
-    HIP_TRY(hipEventCreateWithFlags(&tls.uploadCopied, hipEventDisableTiming));
+    for (int k = 0; k < Context::kTableRing; ++k)
+        HIP_TRY(hipEventCreateWithFlags(&tls.uploadCopied[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&tls.scratchUsed, hipEventDisableTiming));
     return AVIF_RESULT_OK;
 }
@@ -217,19 +218,24 @@ ScratchScope::~ScratchScope()
 // only after the previous upload has left it.
 avifResult uploadTableAsync(void * deviceDst, const void * hostSrc, size_t bytes, hipStream_t stream)
 {
-    if (tls.pinnedUpload)
-        HIP_TRY(hipEventSynchronize(tls.uploadCopied));
+    constexpr int kRing = Context::kTableRing;
     if (bytes > tls.pinnedUploadCapacity) {
-        if (tls.pinnedUpload)
+        if (tls.pinnedUpload) {
+            for (int k = 0; k < kRing; ++k)
+                HIP_TRY(hipEventSynchronize(tls.uploadCopied[k]));
             HIP_TRY(hipHostFree(tls.pinnedUpload));
+        }
         tls.pinnedUpload = nullptr, tls.pinnedUploadCapacity = 0;
-        const size_t rounded = (bytes + 65535) & ~(size_t)65535;
-        HIP_TRY(hipHostMalloc(&tls.pinnedUpload, rounded, hipHostMallocDefault));
+        const size_t rounded = (bytes + 16383) & ~(size_t)16383;
+        HIP_TRY(hipHostMalloc(&tls.pinnedUpload, rounded * kRing, hipHostMallocDefault));
         tls.pinnedUploadCapacity = rounded;
     }
-    memcpy(tls.pinnedUpload, hostSrc, bytes);
-    HIP_TRY(hipMemcpyAsync(deviceDst, tls.pinnedUpload, bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipEventRecord(tls.uploadCopied, stream));
+    const uint32_t slot = tls.uploadSlot++ % (uint32_t)kRing;
+    HIP_TRY(hipEventSynchronize(tls.uploadCopied[slot])); // the upload of kRing calls ago has left this slot
+    uint8_t * pinned = (uint8_t *)tls.pinnedUpload + (size_t)slot * tls.pinnedUploadCapacity;
+    memcpy(pinned, hostSrc, bytes);
+    HIP_TRY(hipMemcpyAsync(deviceDst, pinned, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(tls.uploadCopied[slot], stream));
     return AVIF_RESULT_OK;
 }
 
@@ -849,8 +855,11 @@ struct JobOverride
 };
 } // namespace
 
+// `extra` (optional): a host table of the caller that rides in the same upload (the grid's tile table for the seam kernel); its device
+// address comes back in *extraDevice, the ring slot in *slotOut -- the caller records tls.tableConsumed[slot] again after ITS kernels.
 static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects,
-                                 const JobOverride * overrides, void * hipStream, const PixelMap * map = nullptr)
+                                 const JobOverride * overrides, void * hipStream, const PixelMap * map = nullptr, const void * extra = nullptr, size_t extraBytes = 0,
+                                 const void ** extraDevice = nullptr, uint32_t * slotOut = nullptr)
 {
     if (count == 0)
         return AVIF_RESULT_OK;
@@ -862,7 +871,8 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
     // pinned staging: [tile descriptors][plans: whole jobs, or the leftover right strips][leftover bottom rows]
     const size_t tileBytes = (tileBatchTableBytes(count) + 255) & ~(size_t)255;
     const size_t planBytes = (size_t)count * sizeof(YuvToRgbPlan);
-    const size_t bytes = tileBytes + 2 * planBytes;
+    const size_t extraOffset = (tileBytes + 2 * planBytes + 255) & ~(size_t)255;
+    const size_t bytes = extra ? extraOffset + extraBytes : tileBytes + 2 * planBytes;
     constexpr int kRing = Context::kTableRing;
     if (bytes > tls.pinnedTableCapacity) {
         if (tls.pinnedTable) {
@@ -880,6 +890,10 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
     const uint32_t slot = tls.tableSlot++ % (uint32_t)kRing;
     HIP_TRY(hipEventSynchronize(tls.tableCopied[slot])); // the upload of kRing batches ago has left this slot's pinned memory
     uint8_t * pinned = (uint8_t *)tls.pinnedTable + (size_t)slot * tls.pinnedTableCapacity;
+    if (extra)
+        memcpy(pinned + extraOffset, extra, extraBytes);
+    if (slotOut)
+        *slotOut = slot;
     YuvToRgbPlan * plansA = (YuvToRgbPlan *)(pinned + tileBytes);
     YuvToRgbPlan * plansB = plansA + count;
     uint32_t maxW = 0, maxH = 0;
@@ -912,6 +926,8 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         return rr;
     hipStream_t stream = pickStream(hipStream);
     uint8_t * dev = (uint8_t *)tls.table.ptr + (size_t)slot * tls.pinnedTableCapacity;
+    if (extraDevice)
+        *extraDevice = dev + extraOffset;
     // The table crosses the link on `upStream` while earlier batches compute on `stream`: the upload waits only for the kernels that read
     // this slot's device slice kRing batches ago (on whichever stream they ran), the batch's kernels wait for the upload.
     HIP_TRY(hipStreamWaitEvent(tls.upStream, tls.tableConsumed[slot], 0));
@@ -947,7 +963,7 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         if (e == hipSuccess && restH)
             e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)(dev + tileBytes) + count, count, restMaxW, restH, stream);
     } else {
-        HIP_TRY(hipMemcpyAsync(dev + tileBytes, plansA, planBytes, hipMemcpyHostToDevice, tls.upStream));
+        HIP_TRY(hipMemcpyAsync(dev + tileBytes, plansA, extra ? bytes - tileBytes : planBytes, hipMemcpyHostToDevice, tls.upStream));
         HIP_TRY(hipEventRecord(tls.tableCopied[slot], tls.upStream));
         HIP_TRY(hipStreamWaitEvent(stream, tls.tableCopied[slot], 0));
         tls.lastKernel = "yuv2rgb_generic_batch";
@@ -1044,7 +1060,11 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
         o.window[2] = (int32_t)(Y0 >> sy), o.window[3] = (int32_t)((Y0 >> sy) + ((r.height + sy) >> sy) - 1);
         o.alphaLimited = atile && alphaIsLimitedRange;
     }
-    avifResult r = batchAsyncImpl(count, viewPtrs.data(), rgbPtrs.data(), rects.data(), overrides.data(), hipStream, map);
+    // the seam kernel's tile table rides in the batch's descriptor upload (its own copy on the compute stream cost 5 us plus two gaps)
+    const void * deviceTiles = nullptr;
+    uint32_t tableSlot = 0;
+    avifResult r = batchAsyncImpl(count, viewPtrs.data(), rgbPtrs.data(), rects.data(), overrides.data(), hipStream, map, tiles.data(), tiles.size() * sizeof(GridTile),
+                                  &deviceTiles, &tableSlot);
     if (r != AVIF_RESULT_OK)
         return r;
     if (count == 1)
@@ -1060,20 +1080,12 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
     const bool filters = canvasPlan.bilinear && canvasPlan.yuv.hasColor && subsampled;
     if (!filters)
         return AVIF_RESULT_OK;
-    const size_t tableBytes = tiles.size() * sizeof(GridTile);
-    r = reserve(tls.gridTable, tableBytes);
-    if (r != AVIF_RESULT_OK)
-        return r;
     hipStream_t stream = pickStream(hipStream);
-    ScratchScope scratch(stream);
-    if (scratch.result != AVIF_RESULT_OK)
-        return scratch.result;
-    r = uploadTableAsync(tls.gridTable.ptr, tiles.data(), tableBytes, stream);
-    if (r != AVIF_RESULT_OK)
-        return r;
     GridGeometry g;
+    memset(&g, 0, sizeof(g));
     g.columns = grid->columns, g.rows = grid->rows, g.tileW = tw, g.tileH = th, g.tileCW = tw >> sx, g.tileCH = th >> sy;
-    const hipError_t e = launchYuvToRgbGridSeams(canvasPlan, g, (const GridTile *)tls.gridTable.ptr, grid->columns > 1, sy && grid->rows > 1, stream);
+    const hipError_t e = launchYuvToRgbGridSeams(canvasPlan, g, (const GridTile *)deviceTiles, grid->columns > 1, sy && grid->rows > 1, stream);
+    (void)hipEventRecord(tls.tableConsumed[tableSlot], stream); // the slot is free again after the seam kernel, not after the batch
     if (e != hipSuccess)
         return hipFailed(e, "grid seam kernel launch");
     ++tls.launches;

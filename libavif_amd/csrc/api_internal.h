@@ -110,7 +110,6 @@ struct Context
     Scratch planes[4]; // Y, U, V, A staging
     Scratch pixels;    // interleaved RGB staging
     Scratch table;     // batch descriptor table (device)
-    Scratch gridTable; // tile table of a grid conversion (device)
     Scratch scaleTable; // schedules of a plane scale (device)
     ScaleTableCache scaleCache; // ... and which geometry they belong to
     Scratch satoTable;  // input plane tables of a sample transform (device)
@@ -126,9 +125,10 @@ struct Context
     uint32_t tableSlot = 0;
     hipEvent_t tableCopied[kTableRing] = {};   // the slot's upload has left the pinned memory (and the device slice holds it)
     hipEvent_t tableConsumed[kTableRing] = {}; // the kernels reading the slot's device slice are done
-    void * pinnedUpload = nullptr; // staging for small host tables (grid tile tables, scale schedules)
-    size_t pinnedUploadCapacity = 0;
-    hipEvent_t uploadCopied = nullptr;
+    void * pinnedUpload = nullptr; // staging for small host tables (grid tile tables, scale schedules): a ring of kTableRing slots, so that the
+    size_t pinnedUploadCapacity = 0; // calling thread does not wait for the previous call's upload (which sits behind that call's kernels); bytes per slot
+    uint32_t uploadSlot = 0;
+    hipEvent_t uploadCopied[kTableRing] = {};
     // last asynchronous user of the device scratch above (ScratchScope)
     hipEvent_t scratchUsed = nullptr;
     hipStream_t scratchStream = nullptr;
@@ -148,8 +148,6 @@ struct Context
             (void)hipFree(pixels.ptr);
         if (table.ptr)
             (void)hipFree(table.ptr);
-        if (gridTable.ptr)
-            (void)hipFree(gridTable.ptr);
         if (scaleTable.ptr)
             (void)hipFree(scaleTable.ptr);
         if (satoTable.ptr)
@@ -169,8 +167,9 @@ struct Context
         }
         if (pinnedUpload)
             (void)hipHostFree(pinnedUpload);
-        if (uploadCopied)
-            (void)hipEventDestroy(uploadCopied);
+        for (int k = 0; k < kTableRing; ++k)
+            if (uploadCopied[k])
+                (void)hipEventDestroy(uploadCopied[k]);
         if (scratchUsed)
             (void)hipEventDestroy(scratchUsed);
         delete downloader;

@@ -25,6 +25,8 @@ struct GridGeometry
     uint32_t columns, rows;
     uint32_t tileW, tileH;   // luma / alpha samples per tile
     uint32_t tileCW, tileCH; // chroma samples per tile
+    // ceil(2^32 / d) of the four sizes (filled by launchYuvToRgbGridSeams): x / d == mulhi(x, magic) for every canvas coordinate (x * d < 2^32)
+    uint32_t magicW, magicH, magicCW, magicCH;
 };
 // Re-converts the pixels next to interior tile seams (the only ones whose chroma filter reaches into a neighbouring tile):
 // luma columns k*tileW-1, k*tileW when `vertical`, luma rows k*tileH-1, k*tileH when `horizontal`.  `canvasPlan` describes the

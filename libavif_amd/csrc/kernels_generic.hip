@@ -44,16 +44,18 @@ struct GridReader
 {
     const YuvSide & s;
     const GridGeometry & g;
-    const GridTile * tiles;
+    const GridTile * tiles; // the workgroup's copy in LDS
+    // coordinate / tile size (canvas coordinates stay below 65536: exact)
+    static __device__ __forceinline__ uint32_t divBy(uint32_t x, uint32_t d, uint32_t magic) { return d > 1 ? __umulhi(x, magic) : x; }
     __device__ __forceinline__ unsigned y(uint32_t x, uint32_t yy) const
     {
-        const uint32_t tx = x / g.tileW, ty = yy / g.tileH;
+        const uint32_t tx = divBy(x, g.tileW, g.magicW), ty = divBy(yy, g.tileH, g.magicH);
         const GridTile & t = tiles[ty * g.columns + tx];
         return loadSample(t.plane[0], t.rowBytes[0], x - tx * g.tileW, yy - ty * g.tileH, s.chanBytes);
     }
     __device__ __forceinline__ unsigned c(int pl, uint32_t x, uint32_t yy) const
     {
-        const uint32_t tx = x / g.tileCW, ty = yy / g.tileCH;
+        const uint32_t tx = divBy(x, g.tileCW, g.magicCW), ty = divBy(yy, g.tileCH, g.magicCH);
         const GridTile & t = tiles[ty * g.columns + tx];
         return loadSample(t.plane[pl], t.rowBytes[pl], x - tx * g.tileCW, yy - ty * g.tileCH, s.chanBytes);
     }
@@ -61,7 +63,7 @@ struct GridReader
     __device__ __forceinline__ unsigned v(uint32_t x, uint32_t yy) const { return c(2, x, yy); }
     __device__ __forceinline__ unsigned a(uint32_t x, uint32_t yy) const
     {
-        const uint32_t tx = x / g.tileW, ty = yy / g.tileH;
+        const uint32_t tx = divBy(x, g.tileW, g.magicW), ty = divBy(yy, g.tileH, g.magicH);
         const GridTile & t = tiles[ty * g.columns + tx];
         const unsigned sa = loadSample(t.alpha, t.alphaRowBytes, x - tx * g.tileW, yy - ty * g.tileH, s.chanBytes);
         return s.alphaLimited ? limitedToFullAlpha(sa, (int)s.depth) : sa;
@@ -69,8 +71,21 @@ struct GridReader
 };
 
 // blockIdx.y = seam line (2 per interior seam: vertical seams first), x = position along the line
+template <bool LDS_TABLE>
 __global__ __launch_bounds__(256) void yuvToRgbGridSeamKernel(YuvToRgbPlan p, GridGeometry g, const GridTile * __restrict__ tiles, uint32_t verticalLines)
 {
+    // the tile table (plane pointers and pitches of up to kSeamTiles tiles) is read ~10 times per pixel: once into LDS
+    extern __shared__ __attribute__((aligned(16))) unsigned char seamLds[];
+    const GridTile * ldsTiles = tiles;
+    if constexpr (LDS_TABLE) {
+        ldsTiles = reinterpret_cast<const GridTile *>(seamLds);
+        const uint32_t words = g.columns * g.rows * (uint32_t)(sizeof(GridTile) / 4);
+        const uint32_t * src = reinterpret_cast<const uint32_t *>(tiles);
+        uint32_t * dst = reinterpret_cast<uint32_t *>(seamLds);
+        for (uint32_t k = threadIdx.x; k < words; k += blockDim.x)
+            dst[k] = src[k];
+        __syncthreads();
+    }
     const uint32_t line = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t i, j;
     if (line < verticalLines) {
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(256) void yuvToRgbGridSeamKernel(YuvToRgbPlan p, Gr
     }
     if (i >= p.canvasW || j >= p.canvasH)
         return;
-    const GridReader rd { p.yuv, g, tiles };
+    const GridReader rd { p.yuv, g, ldsTiles };
     if (p.arith == ARITH_LIBYUV)
         yuvToRgbPixelFixedT(p, rd, i, j);
     else
@@ -386,7 +401,14 @@ hipError_t launchYuvToRgbGridSeams(const YuvToRgbPlan & canvasPlan, const GridGe
     if (vLines + hLines == 0)
         return hipSuccess;
     const uint32_t longest = canvasPlan.canvasW > canvasPlan.canvasH ? canvasPlan.canvasW : canvasPlan.canvasH;
-    hipLaunchKernelGGL(yuvToRgbGridSeamKernel, dim3((longest + 255) / 256, vLines + hLines), dim3(256), 0, stream, canvasPlan, g, deviceTiles, vLines);
+    GridGeometry gm = g;
+    auto magic = [](uint32_t d) { return d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0u; };
+    gm.magicW = magic(g.tileW), gm.magicH = magic(g.tileH), gm.magicCW = magic(g.tileCW), gm.magicCH = magic(g.tileCH);
+    const size_t ldsBytes = (size_t)g.columns * g.rows * sizeof(GridTile);
+    if (ldsBytes <= 48 * 1024)
+        hipLaunchKernelGGL(yuvToRgbGridSeamKernel<true>, dim3((longest + 255) / 256, vLines + hLines), dim3(256), ldsBytes, stream, canvasPlan, gm, deviceTiles, vLines);
+    else // more than a thousand tiles: the table stays in global memory
+        hipLaunchKernelGGL(yuvToRgbGridSeamKernel<false>, dim3((longest + 255) / 256, vLines + hLines), dim3(256), 0, stream, canvasPlan, gm, deviceTiles, vLines);
     return hipGetLastError();
 }
 
