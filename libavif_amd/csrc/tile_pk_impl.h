@@ -1,4 +1,4 @@
-// tile_pk_impl.h -- the integer path's tiled YUV->RGB kernels for 8-bit planes and 8-bit RGB outputs, in wavefront-wide PACKED
+// tile_pk_impl.h -- the integer path's tiled YUV->RGB kernels for 8-bit (and, behind a front end, 10/12-bit) planes and 8-bit RGB outputs, in wavefront-wide PACKED
 // 16-bit arithmetic (v_pk_mad_i16 / v_pk_ashrrev_i16 / v_sat_pk_u8_i16 / v_perm_b32), instantiated by kernels_tile_fx_inst.hip.
 // What it computes is libyuv's fixed point exactly (I420ToARGBMatrixFilter and its relatives as
 // src/reformat_libyuv.c:544-1108 dispatches them):
@@ -6,13 +6,14 @@
 // How it is arranged for gfx950:
 //   * work unit = one wave = 256 x (2 * NSW) pixels (NSW strips of two luma rows); a lane owns 4 consecutive pixels of every row:
 //     one dword load per plane and row, one 16-byte non-temporal store per row (1 KiB contiguous per wave instruction).  The four
-//     waves of a workgroup sit side by side (a 1024-pixel-wide tile) or stacked, and are independent of each other: NO workgroup
-//     barrier anywhere.  Every load of the wave's tile is issued before the first result is needed; occupancy (8 waves per
-//     SIMD) hides the rest;
-//   * workgroups take tiles in raster order (tests/tools/pattern_probe.hip: with frames streaming from HBM the chip moves cfg2's
-//     bytes 7-12% faster in raster order than in per-XCD bands), optionally in per-XCD chunks of a few tile rows;
-//   * bilinear chroma: the wave's chroma neighbourhood (NSW + 2 rows x 136 columns for 4:2:0) is staged in a wave-private LDS
-//     block as one word per column holding both planes, (u | v << 16) * 16 + 0x08080808.  The filter 9:3:3:1 runs on both planes
+//     waves of a workgroup sit side by side (a 1024-pixel-wide tile) or stacked; they never wait for each other, except at ONE
+//     workgroup barrier where they share something: the chroma halo rows of stacked 4:2:0 bilinear tiles (pkRunBlock), the LDS
+//     transposition of fused quarter turns (pkTransposeStore).  Every load of the wave's tile is issued before the first result
+//     is needed; occupancy (8 waves per SIMD) hides the rest;
+//   * workgroups take tiles in per-XCD chunks of one tile row (planes resident in the Infinity Cache), or in raster order (batches
+//     that stream from HBM: tests/tools/pattern_probe.hip, pkbench_wide.hip);
+//   * bilinear chroma: the chroma neighbourhood (NSW + 2 rows x 136 columns per wave for 4:2:0) is staged in LDS
+//     as one word per column holding both planes, (u | v << 16) * 16 + 0x08080808.  The filter 9:3:3:1 runs on both planes
 //     at once with 32-bit shift-adds.  The constant carries libyuv's rounding (+8 per tap sum of 16) AND flips the top bit of
 //     the result byte: after the sum, byte 1 / byte 3 of a word hold (u' - 128) / (v' - 128) as signed bytes -- what the matrix
 //     wants.  Fields are allowed to wrap: the 32-bit sums are exact modulo 2^32, a carry out of the low field reaches only
@@ -756,7 +757,7 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
     }
 }
 
-// The waves of a workgroup are independent (no barrier anywhere): one wave, one tile of 256 x 2*NSW pixels, every load issued up
+// The waves of a workgroup work for themselves (one barrier at most, see below): one wave, one tile of 256 x 2*NSW pixels, every load issued up
 // front.  One tile per wave and many short-lived workgroups is deliberate: a persistent variant (k x 256 workgroups walking over
 // their tiles with the next tile's loads in flight) measured 10-20% SLOWER on 8K frames, with frames streaming from HBM as well
 // as from the Infinity Cache (tests/tools/pk_sweep.py, profiles/r02_pk_sweep_persistent.txt) -- the dispatcher refilling 32 waves per CU in
