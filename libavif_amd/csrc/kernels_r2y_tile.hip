@@ -59,10 +59,16 @@ bool tileRgbToYuvSupported(const RgbToYuvPlan & p)
     if (p.mul != MUL_NONE || o.isGray || o.is565)
         return false;
     if (p.arith == ARITH_FLOAT) {
-        if (s.mode != MODE_COEFF)
-            return false;
-        if (!s.exactDivEncode)
-            return false; // a divisor off the verified lists (exactdiv.h): the universal kernel divides the IEEE way
+        if (s.mode == MODE_IDENTITY) {
+            // lossless RGB as GBR planes (avifenc -l): no matrix, one division (channel / maximum); 4:4:4 or monochrome only
+            if (!s.exactDiv || (s.format != AVIF_PIXEL_FORMAT_YUV444 && s.format != AVIF_PIXEL_FORMAT_YUV400))
+                return false;
+        } else {
+            if (s.mode != MODE_COEFF)
+                return false;
+            if (!s.exactDivEncode)
+                return false; // a divisor off the verified lists (exactdiv.h): the universal kernel divides the IEEE way
+        }
     } else if (o.chanBytes != 1 || s.chanBytes != 1) {
         return false; // libyuv converts 8-bit to 8-bit only (src/reformat_libyuv.c:277)
     }
@@ -106,6 +112,9 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
     A.kr = s.kr, A.kg = s.kg, A.kb = s.kb;
     A.rcpRgbMax = o.rcpMax, A.rcpCbDen = s.rcpCbDen, A.rcpCrDen = s.rcpCrDen;
     A.rangeY = s.rangeY, A.biasY = s.biasY, A.rangeUV = s.rangeUV, A.biasUV = s.biasUV;
+    A.identity = (p.arith == ARITH_FLOAT && s.mode == MODE_IDENTITY) ? 1 : 0;
+    if (A.identity)
+        A.rangeUV = s.rangeY, A.biasUV = s.biasY; // src/reformat.c:205-211: identity quantises chroma like luma
     A.yuvMax = (uint32_t)s.maxv, A.yuvMaxF = (float)s.maxv;
     A.slotR = (uint32_t)(o.offR / o.chanBytes), A.slotB = (uint32_t)(o.offB / o.chanBytes), A.slotA = (uint32_t)(o.offA / o.chanBytes);
     A.alphaMode = R2Y_ALPHA_NONE;

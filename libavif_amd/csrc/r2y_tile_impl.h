@@ -213,10 +213,15 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
             const f2 G = div2((f2) { (float)c1[0], (float)c1[1] }, A.rcpRgbMax);
             const f2 z = div2((f2) { (float)c2[0], (float)c2[1] }, A.rcpRgbMax);
             const f2 R = SWAP ? z : x, B = SWAP ? x : z;
-            const f2 Y = ((splat2(A.kr) * R) + (splat2(A.kg) * G)) + (splat2(A.kb) * B); // :383
-            U[r][p] = div2(B - Y, A.rcpCbDen); // (B - Y) / (2 * (1 - kb)), :384
-            V[r][p] = div2(R - Y, A.rcpCrDen); // (R - Y) / (2 * (1 - kr)), :385
-            tY[r][p] = unormOperand(Y, A.rangeY, A.biasY);
+            if (A.identity) { // wave-uniform: GBR planes (lossless RGB), src/reformat.c:362-366 -- Y = G, U = B, V = R, all three on luma's scale
+                U[r][p] = B, V[r][p] = R;
+                tY[r][p] = unormOperand(G, A.rangeY, A.biasY);
+            } else {
+                const f2 Y = ((splat2(A.kr) * R) + (splat2(A.kg) * G)) + (splat2(A.kb) * B); // :383
+                U[r][p] = div2(B - Y, A.rcpCbDen); // (B - Y) / (2 * (1 - kb)), :384
+                V[r][p] = div2(R - Y, A.rcpCrDen); // (R - Y) / (2 * (1 - kr)), :385
+                tY[r][p] = unormOperand(Y, A.rangeY, A.biasY);
+            }
         }
     }
     // alpha plane: four samples per row

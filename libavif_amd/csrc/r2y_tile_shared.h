@@ -35,6 +35,7 @@ struct R2YArgs
     uint32_t slotR, slotB, slotA;
     int32_t alphaMode;
     uint32_t stripsPerWave;
+    uint32_t identity; // identity matrix: the planes are G, B, R, each quantised on luma's scale (rangeUV / biasUV hold luma's)
     // fixed-point kernels (libyuv's 8-bit BT.601 arithmetic), coefficients per MEMORY-order colour
     // channel (c0 = first colour byte, c1 = G, c2 = third colour byte), so that no channel swap is needed:
     //   Y = (y0*c0 + y1*c1 + y2*c2 + yBias) >> 8,  U = (u0*m0 + u1*m1 + u2*m2 + 0x8000) >> 8,  V likewise,

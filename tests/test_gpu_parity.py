@@ -123,6 +123,18 @@ def test_rgb_to_yuv_tiled_sweep_host(hip):
     assert "rgb2yuv_generic" in kernels  # gray sources, identity / YCgCo matrices, pending alpha multiplies
 
 
+def test_identity_encode_uses_the_tiled_kernels(hip):
+    """Lossless encodes (identity matrix: GBR planes, src/reformat.c:361-365) in the bandwidth-tuned encode kernels, full and limited range."""
+    hip.avifhipSetTiledKernels(1)
+    cases = []
+    for (w, h) in TILED:
+        for fmt, rd, yd, rng, yf in ((1, 8, 8, 1, 1), (0, 8, 8, 1, 1), (4, 8, 8, 0, 1), (1, 16, 10, 1, 1), (0, 16, 12, 1, 1), (1, 8, 8, 1, 4), (1, 10, 10, 1, 1)):
+            cases.append(H.R2YCase(w, h, rgb_depth=rd, rgb_format=fmt, yuv_depth=yd, yuv_format=yf, yuv_range=rng, matrix=0))
+    kernels = _compare_r2y(H.HipDeviceBackend(), H.oracle_backend(), cases, padding=False)
+    assert set(kernels) == {"rgb2yuv_tile"}, kernels
+    _compare_r2y(H.hip_host_backend(), H.oracle_backend(), cases)
+
+
 def test_rgb_to_yuv_tiled_sweep_device(hip):
     hip.avifhipSetTiledKernels(1)
     kernels = _compare_r2y(H.HipDeviceBackend(), H.oracle_backend(), H.r2y_sweep(TILED, n_random=300, seed=73), padding=False)

@@ -105,15 +105,18 @@ def run(name):
         elif name == "cfg3":
             pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, avoid=avoid)
             px, bpp, ms = 7680 * 4320, 16.0, time_y2r(pair, 20)
-        elif name in ("cfg4", "cfg4rgb", "cfg4_601", "cfg4_8k", "cfg4rgb_8k"):
+        elif name in ("cfg4", "cfg4rgb", "cfg4_601", "cfg4_8k", "cfg4rgb_8k", "ident8_enc"):
             fmt = abi.AVIF_RGB_FORMAT_RGB if name.startswith("cfg4rgb") else abi.AVIF_RGB_FORMAT_RGBA
             mc = 6 if name == "cfg4_601" else 1
-            w, h = (7680, 4320) if name.endswith("_8k") else (3840, 2160)  # the encode direction on the headline's frame size
+            w, h = (7680, 4320) if name.endswith("_8k") or name == "ident8_enc" else (3840, 2160)  # the encode direction on the headline's frame size
             rgb = abi.make_rgb(w, h, 8, fmt, avoid_libyuv=avoid)
             synth.fill_rgb(rgb, 0x12345678, opaque=True)
-            img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, mc, with_alpha=(fmt == abi.AVIF_RGB_FORMAT_RGBA))
+            if name == "ident8_enc":  # lossless encode (avifenc -l): 8K RGBA8 -> GBR planes 8-bit 4:4:4 full range + alpha, 4 + 3 + 1 B/px
+                img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 0, with_alpha=True)
+            else:
+                img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, mc, with_alpha=(fmt == abi.AVIF_RGB_FORMAT_RGBA))
             dimg, drgb = device.DeviceYUV(img), device.DeviceRGB(rgb, upload=True)
-            px, bpp = w * h, (6.5 if fmt == abi.AVIF_RGB_FORMAT_RGBA else 4.5)
+            px, bpp = w * h, (8.0 if name == "ident8_enc" else (6.5 if fmt == abi.AVIF_RGB_FORMAT_RGBA else 4.5))
             preheat(lambda n: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 0, n, None))
             ms = min(lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 4, 40, None) for _ in range(4))
         elif name in ("cfg5", "cfg5_8"):
