@@ -182,7 +182,8 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
             if (p.inLoopMul != MUL_NONE || p.postMul != MUL_NONE || s.chanBytes != 1 || o.chanBytes != 1 || s.format != AVIF_PIXEL_FORMAT_YUV444)
                 return false;
         } else {
-            if (s.mode != MODE_COEFF)
+            // matrix coefficients, or the identity matrix at any depth / range (GBR planes: 4:4:4; without chroma every matrix is the same)
+            if (s.mode != MODE_COEFF && !(s.mode == MODE_IDENTITY && (s.format == AVIF_PIXEL_FORMAT_YUV444 || !s.hasColor)))
                 return false;
             if (!s.exactDiv)
                 return false; // a divisor off the verified list (exactdiv.h): the universal kernel divides the IEEE way

@@ -699,6 +699,12 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                     br[i] = splat(yk[i]);
                     g[i] = yk[i];
                 }
+            } else if (SUB == SUB_444 && A.identityMatrix) { // wave-uniform: GBR planes, src/reformat.c:855-858 -- G = Y, B = Cb, R = Cr (normalised on luma's scale)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    br[i] = uv[r][i];
+                    g[i] = yk[i];
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {

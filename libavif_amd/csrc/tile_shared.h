@@ -42,6 +42,7 @@ struct TileArgs
     float f16Mul;                        // half-float outputs (avifRGBImageToF16, src/reformat.c:1419-1443): the subnormal-trick multiplier, 0 = integer output
     int32_t inLoopMul, postMul;          // MulMode
     int32_t identityCopy;                // 8-bit full-range identity matrix: bytes are copied (src/reformat.c:1278-1309)
+    int32_t identityMatrix;              // identity matrix otherwise: the planes are G, B, R on luma's scale (biasUV / rcpRangeUV hold luma's)
     uint32_t tuning;
     // fused crop / rotate / mirror (plan.h PixelMap): `rgb` is then the destination buffer's first pixel, and canvas pixel
     // (mapX0 + X, mapY0 + row) of the rectangle's pixel (X, row) goes where the map says.  Packed 16-bit kernels only.
@@ -136,6 +137,9 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     A.f16Mul = o.isFloat ? o.f16Multiplier : 0.0f;
     A.inLoopMul = p.inLoopMul, A.postMul = p.postMul;
     A.identityCopy = p.identityCopy;
+    A.identityMatrix = (p.arith != ARITH_LIBYUV && s.mode == MODE_IDENTITY && !p.identityCopy) ? 1 : 0;
+    if (A.identityMatrix)
+        A.biasUV = s.biasY, A.rcpRangeUV = s.rcpRangeY; // src/reformat.c:587-589: identity reads chroma through luma's table
     A.tuning = p.tuning;
     if (p.arith == ARITH_LIBYUV) {
         const FixedPointMatrix & m = p.fx;

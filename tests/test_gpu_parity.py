@@ -70,6 +70,21 @@ def test_half_float_and_identity_copy_use_the_tiled_kernels(hip):
     _compare_y2r(H.hip_host_backend(), H.oracle_backend(), cases)
 
 
+def test_identity_matrix_at_any_depth_uses_the_tiled_kernels(hip):
+    """GBR planes beyond the 8-bit full-range byte shuffle: limited range, 10 / 12 bits, other output depths (src/reformat.c:855-858)."""
+    hip.avifhipSetTiledKernels(1)
+    cases = []
+    for (w, h) in TILED:
+        for yd, rd, rng, fmt, alpha, yf in ((8, 8, 0, 1, False, 1), (10, 10, 1, 1, True, 1), (12, 16, 1, 0, False, 1), (10, 8, 1, 4, True, 1), (8, 16, 1, 5, False, 1),
+                                          (10, 16, 0, 1, False, 4)):
+            cases.append(H.Y2RCase(w, h, yuv_depth=yd, rgb_depth=rd, yuv_range=rng, rgb_format=fmt, alpha=alpha, yuv_format=yf, matrix=0, row_pad=64))
+    for c in cases:
+        H.run_y2r(H.HipDeviceBackend(), c)
+        assert native.last_kernel().startswith("yuv2rgb_tile"), (c.ident(), native.last_kernel())
+    _compare_y2r(H.HipDeviceBackend(), H.oracle_backend(), cases)
+    _compare_y2r(H.hip_host_backend(), H.oracle_backend(), cases)
+
+
 def test_gray_outputs_use_the_tiled_kernels(hip):
     """GRAY / GRAYA / AGRAY outputs (clamp01(Y) through the alpha multiply and the quantiser, src/reformat.c:886-961) read luma and alpha
     only and are served by the 4:0:0 instantiations of the bandwidth-tuned kernels, whatever the image's chroma layout."""
