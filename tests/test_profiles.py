@@ -54,7 +54,7 @@ def test_pmc_traffic_and_instruction_counts():
     assert t["kernel_family"] == "yuv2rgb_fixed_tile<u8,420,bilinear,rgba8,pk16>" and "yuvToRgbPkKernel" in t["kernel"]
     assert abs(t["traffic_bytes_per_launch"] - ALG) / ALG < 0.03  # measured HBM bytes per launch vs algorithmic bytes: no wasted re-reads
     pmc = (PROFILES / "r02_bench_pmc.txt").read_text()
-    block = pmc.split("yuvToRgbPkKernel<2, true, 4, false, 4>", 1)[1].split("\nvoid ", 1)[0]
+    block = re.split(r"yuvToRgbPkKernel<2, true, 4, false, 4, false, 0>[^\n]*\n", pmc, maxsplit=1)[1].split("\nvoid ", 1)[0]  # 4:2:0, bilinear, 4 channels, opaque, 4 strips, rows, 8-bit planes
     valu = float(re.search(r"SQ_INSTS_VALU\s+dispatches=\s*\d+\s+avg_per_dispatch=\s*([0-9.]+)", block).group(1))
     per_pixel = valu * 64 / (7680 * 4320)
     assert per_pixel <= 20.0, per_pixel  # 27.4 in round 1 (32-bit scalar matrix); packed 16-bit pairs now

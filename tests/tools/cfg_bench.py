@@ -224,19 +224,21 @@ def run(name):
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
             px, bpp, ms = 7664 * 4312, (7.0 if deep else 5.5), best
-        elif name in ("cfg5grid", "cfg5grid_8"):
+        elif name in ("cfg5grid", "cfg5grid_8", "photo_grid"):
             # BASELINE configs[4]: 8 x 8 grid of decoded 1920x1080 10-bit 4:2:0 tiles -> one 15360x8640 RGBA canvas, tiles
             # converted where they lie (avifhipGridYUVToRGBAsync: no YUV canvas, seams redone across tiles)
+            # photo_grid: what a phone camera writes -- 4032 x 3024 8-bit 4:2:0 as 8 x 6 tiles of 512 x 512 (the last row cropped) -> RGBA8
             rgb_depth = 10 if name == "cfg5grid" else 8
+            cols, rows, tw, th, ow, oh, depth = (8, 6, 512, 512, 4032, 3024, 8) if name == "photo_grid" else (8, 8, 1920, 1080, 15360, 8640, 10)
             tiles = []
-            for t in range(64):
-                img = abi.make_yuv(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+            for t in range(cols * rows):
+                img = abi.make_yuv(tw, th, depth, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED if depth == 10 else abi.AVIF_RANGE_FULL, 1 if depth == 10 else 6)
                 synth.fill_yuv(img, 0x12345678 + t)
                 tiles.append(device.DeviceYUV(img))
-            rgb = abi.make_rgb(15360, 8640, rgb_depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=avoid, allocate=False)
+            rgb = abi.make_rgb(ow, oh, rgb_depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=avoid, allocate=False)
             drgb = device.DeviceRGB(rgb)
-            imgs = (C.POINTER(abi.avifImage) * 64)(*[C.pointer(t.struct) for t in tiles])
-            grid = native.avifhipGrid(8, 8, 15360, 8640)
+            imgs = (C.POINTER(abi.avifImage) * (cols * rows))(*[C.pointer(t.struct) for t in tiles])
+            grid = native.avifhipGrid(rows, cols, ow, oh)
             for _ in range(3):
                 native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None))
             native.check(lib.avifhipSynchronize(None))
@@ -247,7 +249,7 @@ def run(name):
                     native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None))
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
-            px, bpp, ms = 64 * 1920 * 1080, (11.0 if rgb_depth == 10 else 7.0), best
+            px, bpp, ms = ow * oh, (11.0 if rgb_depth == 10 else (7.0 if depth == 10 else 5.5)), best
         elif name in ("gainmap4k", "gainmap4k_half", "gainmap4k_cpu"):
             # avifRGBImageApplyGainMap: 3840x2160 RGBA8 sRGB BT.709 base -> RGBA10 PQ BT.2020 HDR rendition, 8-bit 4:4:4 gain map of the
             # same size (or 4:2:0 at half size, rescaled on the device first).  Algorithmic bytes: base 4 + gain-map planes + output 8.
