@@ -67,7 +67,8 @@ int main(int argc, char ** argv)
     uint32_t nsw, blocks; PkGeom g;
     pkGeometry(L, W, H, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock), grid(blocks);
-    auto launch = [&](int k) { hipLaunchKernelGGL((yuvToRgbPkKernel<SUB_420, PKB_BIL, 4, false, PKB_NSW, false, WIDE_NONE>), grid, block, 4u * (uint32_t)PkLds<SUB_420, PKB_BIL, 4, PKB_NSW, false>::kPlain, 0, args[k], g); };
+    const uint32_t ldsBytes = 4u * (uint32_t)PkLds<SUB_420, PKB_BIL, 4, PKB_NSW, false>::kPlain;
+    auto launch = [&](int k) { hipLaunchKernelGGL((yuvToRgbPkKernel<SUB_420, PKB_BIL, 4, false, PKB_NSW, false, WIDE_NONE>), grid, block, ldsBytes, 0, args[k], g); };
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3000; ++i) launch(i % 4); // clock ramp
     float res[2];

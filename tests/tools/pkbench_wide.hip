@@ -56,7 +56,8 @@ int main(int argc, char ** argv)
     uint32_t nsw, blocks; PkGeom g;
     pkGeometry(L, W, H, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock), grid(blocks, 1, NJ);
-    auto launch = [&]() { hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB_420, PKB_BIL, 4, false, PKB_NSW, false, WIDE_NATIVE>), grid, block, 4u * (uint32_t)PkLds<SUB_420, PKB_BIL, 4, PKB_NSW, false>::kPlain, 0, table, g); };
+    const uint32_t ldsBytes = 4u * (uint32_t)PkLds<SUB_420, PKB_BIL, 4, PKB_NSW, false>::kPlain;
+    auto launch = [&]() { hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB_420, PKB_BIL, 4, false, PKB_NSW, false, WIDE_NATIVE>), grid, block, ldsBytes, 0, table, g); };
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 300; ++i) launch(); // clock ramp
     std::vector<float> t;
