@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.h"
@@ -249,6 +250,16 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
            ((k.wideDownshift ? 1 : 0) << 11) | ((k.gray ? 1 : 0) << 12);
 }
 
+namespace {
+// bytes of plane samples one pixel of a job reads
+double planeBytesPerPixel(const YuvToRgbPlan & p, const TileKey & k)
+{
+    return (double)p.yuv.chanBytes * ((k.sub == SUB_444 ? 3.0 : k.sub == SUB_422 ? 2.0 : k.sub == SUB_420 ? 1.5 : 1.0) + ((k.alphaPlane || k.hasMul) ? 1.0 : 0.0));
+}
+// Planes beyond this many bytes per launch cannot be resident in the 256 MB Infinity Cache next to anything else: streaming loads
+constexpr double kStreamPlaneBytes = 128.0 * 1048576.0;
+} // namespace
+
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)
 {
     const TileKey k = keyFor(plan);
@@ -260,7 +271,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     L.table = nullptr;
     L.count = 1;
     L.stream = stream;
-    L.mapped = k.mapped, L.transposed = k.mapped && plan.rgb.map.transposed;
+    L.mapped = k.mapped, L.transposed = k.mapped && plan.rgb.map.transposed, L.streamLoads = false;
     decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)A.w4 * A.h2) || (plan.tuning & TUNE_SOLO_ALWAYS));
     L.pkWide = (plan.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift;
@@ -308,6 +319,10 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
     L.count = count;
     L.stream = stream;
     L.mapped = k.mapped, L.transposed = k.mapped && representative.rgb.map.transposed;
+    // (upper bound from the largest job: batches are made of equally sized tiles)
+    L.streamLoads = (double)maxW * maxH * count * planeBytesPerPixel(representative, k) > kStreamPlaneBytes;
+    if (const char * e = getenv("AVIFHIP_STREAM_LOADS")) // diagnostics / A-B measurements only
+        L.streamLoads = atoi(e) != 0;
     decompose(representative.tuning, maxW & ~3u, maxH & ~1u, count, true, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)(maxW & ~3u) * (maxH & ~1u) * count) || (representative.tuning & TUNE_SOLO_ALWAYS));
     L.pkWide = (representative.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift;

@@ -39,25 +39,27 @@ struct RawRow
     unsigned w[kWords];
 };
 
+// plain loads: streaming (non-temporal) loads, round 1's choice, cost 12 % here (4K RGBA8 -> 4:2:0 10.3 -> 9.0 us, 8K 37.3 -> 33.3 us)
 template <typename RT, int NCH>
 __device__ __forceinline__ RawRow<RT, NCH> loadRow(const uint8_t * base, uint32_t off)
 {
     RawRow<RT, NCH> r;
     constexpr int kWords = RawRow<RT, NCH>::kWords;
-    if constexpr (kWords == 4) {
-        const u4 t = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(base + off));
-        r.w[0] = t.x, r.w[1] = t.y, r.w[2] = t.z, r.w[3] = t.w;
-    } else if constexpr (kWords == 8) {
-        const u4 t = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(base + off));
-        const u4 s = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(base + off + 16));
-        r.w[0] = t.x, r.w[1] = t.y, r.w[2] = t.z, r.w[3] = t.w, r.w[4] = s.x, r.w[5] = s.y, r.w[6] = s.z, r.w[7] = s.w;
-    } else if constexpr (kWords == 3) { // 12 bytes, 4-byte aligned
-        const unsigned * p = reinterpret_cast<const unsigned *>(base + off);
-        r.w[0] = __builtin_nontemporal_load(p), r.w[1] = __builtin_nontemporal_load(p + 1), r.w[2] = __builtin_nontemporal_load(p + 2);
-    } else { // 24 bytes, 8-byte aligned
-        const u2 * p = reinterpret_cast<const u2 *>(base + off);
-        const u2 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1), c = __builtin_nontemporal_load(p + 2);
-        r.w[0] = a.x, r.w[1] = a.y, r.w[2] = b.x, r.w[3] = b.y, r.w[4] = c.x, r.w[5] = c.y;
+    const unsigned * p = reinterpret_cast<const unsigned *>(base + off);
+    if constexpr (kWords == 4 || kWords == 8) {
+#pragma unroll
+        for (int h = 0; h < kWords / 4; ++h) {
+            const u4 t = reinterpret_cast<const u4 *>(p)[h];
+            r.w[4 * h] = t.x, r.w[4 * h + 1] = t.y, r.w[4 * h + 2] = t.z, r.w[4 * h + 3] = t.w;
+        }
+    } else if constexpr (kWords == 3) {
+        r.w[0] = p[0], r.w[1] = p[1], r.w[2] = p[2];
+    } else {
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const u2 t = reinterpret_cast<const u2 *>(p)[h];
+            r.w[2 * h] = t.x, r.w[2 * h + 1] = t.y;
+        }
     }
     return r;
 }

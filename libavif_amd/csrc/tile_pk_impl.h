@@ -411,7 +411,7 @@ struct PkSpot
 };
 
 // ---- every load of a wave tile ----
-template <int SUB, bool BIL, bool APLANE, int NSW, int WIDE>
+template <int SUB, bool BIL, bool APLANE, int NSW, int WIDE, bool STREAM>
 __device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R)
 {
     typedef PkRaw<SUB, BIL, APLANE, NSW, WIDE> RawT;
@@ -453,12 +453,27 @@ __device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkR
         const uint32_t sy = 2u * (st < strips ? st : strips - 1u); // absent strips load (and discard) the last one
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            R.y[2 * s + r] = *reinterpret_cast<const Row4 *>(A.y + ((sy + r) * A.yPitch + Xc * B));
-            if constexpr (APLANE)
-                R.a[2 * s + r] = *reinterpret_cast<const Row4 *>(A.a + ((sy + r) * A.aPitch + Xc * B));
+            // Planes too large to stay in the Infinity Cache (batches of tiles: TileLaunch::streamLoads) are read with streaming loads --
+            // 64 tiles of 1080p 10-bit: 173.8 -> 160.7 us; planes that ARE cache-resident must not be (an 8K frame cycled with three
+            // others: 28.3 -> 35.8 us): tests/tools/pkbench_wide.hip with -DPKB_STREAM=true.  A template parameter, not a
+            // run-time branch: the compiler merges the two branches' loads and the merged load loses its non-temporal mark.
+            if constexpr (STREAM) {
+                R.y[2 * s + r] = __builtin_nontemporal_load(reinterpret_cast<const Row4 *>(A.y + ((sy + r) * A.yPitch + Xc * B)));
+                if constexpr (APLANE)
+                    R.a[2 * s + r] = __builtin_nontemporal_load(reinterpret_cast<const Row4 *>(A.a + ((sy + r) * A.aPitch + Xc * B)));
+            } else {
+                R.y[2 * s + r] = *reinterpret_cast<const Row4 *>(A.y + ((sy + r) * A.yPitch + Xc * B));
+                if constexpr (APLANE)
+                    R.a[2 * s + r] = *reinterpret_cast<const Row4 *>(A.a + ((sy + r) * A.aPitch + Xc * B));
+            }
             if constexpr (SUB == SUB_444) {
-                R.u[2 * s + r] = *reinterpret_cast<const Row4 *>(A.u + (((uint32_t)A.cy0 + sy + r) * A.uPitch + ((uint32_t)A.cx0 + Xc) * B));
-                R.v[2 * s + r] = *reinterpret_cast<const Row4 *>(A.v + (((uint32_t)A.cy0 + sy + r) * A.vPitch + ((uint32_t)A.cx0 + Xc) * B));
+                const Row4 * up = reinterpret_cast<const Row4 *>(A.u + (((uint32_t)A.cy0 + sy + r) * A.uPitch + ((uint32_t)A.cx0 + Xc) * B));
+                const Row4 * vp = reinterpret_cast<const Row4 *>(A.v + (((uint32_t)A.cy0 + sy + r) * A.vPitch + ((uint32_t)A.cx0 + Xc) * B));
+                if constexpr (STREAM) {
+                    R.u[2 * s + r] = __builtin_nontemporal_load(up), R.v[2 * s + r] = __builtin_nontemporal_load(vp);
+                } else {
+                    R.u[2 * s + r] = *up, R.v[2 * s + r] = *vp;
+                }
             } else if constexpr (RawT::kOwnChroma) {
                 // nearest: chroma samples (X >> 1, X >> 1 + 1) of the row's chroma row, one aligned pair per plane
                 if (!(SUB == SUB_420 && r == 1)) {
@@ -789,7 +804,7 @@ struct PkLds
     static constexpr int kWords = kPlain > kXposeWords ? kPlain : kXposeWords;
 };
 
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM>
 __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g, unsigned * lds)
 {
     typedef PkRaw<SUB, BIL, APLANE, NSW, WIDE> RawT;
@@ -820,7 +835,7 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     // 3-byte pixels, stored as rows: one exchange buffer per wave behind the chroma blocks
     WideRowExchange * xchg = (NCH == 3 && !MAPPED) ? reinterpret_cast<WideRowExchange *>(lds + kWavesPerBlock * PkLds<SUB, BIL, NCH, NSW, MAPPED>::kRingWords) + wave : nullptr;
     RawT raw;
-    pkLoad<SUB, BIL, APLANE, NSW, WIDE>(A, w, raw);
+    pkLoad<SUB, BIL, APLANE, NSW, WIDE, STREAM>(A, w, raw);
     pkStage<SUB, BIL, APLANE, NSW, WIDE>(A, w, shared, raw, ring);
     if (!rowsValid && !xpose)
         return;
@@ -830,16 +845,17 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
 __global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g)
 {
+    constexpr bool STREAM = false; // single images: their planes are assumed cache-resident (just decoded / uploaded / produced)
     extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
-    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, g, lds);
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(A, g, lds);
 }
 
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM = false>
 __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
-    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(job, g, lds);
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(job, g, lds);
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, bool MAPPED, int WIDE = WIDE_NONE>
@@ -854,7 +870,12 @@ hipError_t launchPkMapped(const TileLaunch & L)
     const bool xpose = MAPPED && L.transposed;
     const uint32_t lds4 = 4u * (uint32_t)(xpose ? PkLds<SUB, BIL, NCH, 4, MAPPED>::kWords : PkLds<SUB, BIL, NCH, 4, MAPPED>::kPlain);
     const uint32_t lds2 = 4u * (uint32_t)(xpose ? PkLds<SUB, BIL, NCH, 2, MAPPED>::kWords : PkLds<SUB, BIL, NCH, 2, MAPPED>::kPlain);
-    if (L.table) {
+    if (L.table && L.streamLoads && !MAPPED) { // batches whose planes exceed the Infinity Cache
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 4, false, WIDE, true>), grid, block, lds4, L.stream, L.table, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2, false, WIDE, true>), grid, block, lds2, L.stream, L.table, g);
+    } else if (L.table) {
         if (nsw == 4)
             hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, lds4, L.stream, L.table, g);
         else

@@ -223,6 +223,7 @@ struct TileLaunch
     uint32_t chunkRows;     // tile rows per XCD chunk, 0 = plain raster order
     bool mapped;            // stores go through the jobs' PixelMap
     bool transposed;        // ... which turns rows into columns (quarter turns)
+    bool streamLoads;       // batches: the jobs' planes exceed what the Infinity Cache can hold -- luma / alpha rows as streaming loads
     bool solo;              // fp32 / 10-12-bit integer families: the wave-private kernels instead of the cooperative runs
     bool pkWide;            // 10-12-bit integer family without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)
     bool wideDownshift;     // ... entered through the reduction to 8 bits (TileKey)

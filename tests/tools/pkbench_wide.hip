@@ -15,6 +15,9 @@
 #ifndef PKB_BIL
 #define PKB_BIL true
 #endif
+#ifndef PKB_STREAM
+#define PKB_STREAM false // -DPKB_STREAM=true: luma rows as streaming (non-temporal) loads
+#endif
 #ifndef PKB_TUNING
 #define PKB_TUNING TUNE_DEFAULT
 #endif
@@ -57,7 +60,7 @@ int main(int argc, char ** argv)
     pkGeometry(L, W, H, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock), grid(blocks, 1, NJ);
     const uint32_t ldsBytes = 4u * (uint32_t)PkLds<SUB_420, PKB_BIL, 4, PKB_NSW, false>::kPlain;
-    auto launch = [&]() { hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB_420, PKB_BIL, 4, false, PKB_NSW, false, WIDE_NATIVE>), grid, block, ldsBytes, 0, table, g); };
+    auto launch = [&]() { hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB_420, PKB_BIL, 4, false, PKB_NSW, false, WIDE_NATIVE, PKB_STREAM>), grid, block, ldsBytes, 0, table, g); };
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 300; ++i) launch(); // clock ramp
     std::vector<float> t;
