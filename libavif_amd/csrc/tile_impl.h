@@ -103,6 +103,25 @@ __device__ __forceinline__ Raw4<T> load4(const uint8_t * base, uint32_t off)
     }
     return r;
 }
+// ... as a streaming (non-temporal) load: planes that cannot stay in the Infinity Cache (batches: TileLaunch::streamLoads; tile_pk_impl.h
+// pkLoad has the measurements and the reason for a template parameter)
+template <typename T, bool STREAM>
+__device__ __forceinline__ Raw4<T> load4s(const uint8_t * base, uint32_t off)
+{
+    if constexpr (!STREAM) {
+        return load4<T>(base, off);
+    } else {
+        Raw4<T> r;
+        if constexpr (sizeof(T) == 1) {
+            r.w[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(base + off));
+        } else {
+            const u2 t = __builtin_nontemporal_load(reinterpret_cast<const u2 *>(base + off));
+            r.w[0] = t.x;
+            r.w[1] = t.y;
+        }
+        return r;
+    }
+}
 template <typename T>
 __device__ __forceinline__ unsigned load1(const uint8_t * base, uint32_t off)
 {
@@ -472,7 +491,7 @@ struct BandCtx
 };
 
 // issue every load of the tile whose first luma row (relative to the rectangle) is tileY
-template <typename YT, int SUB, bool BIL, bool NEEDA, int NS, int WAVES = 4>
+template <typename YT, int SUB, bool BIL, bool NEEDA, int NS, int WAVES = 4, bool STREAM = false>
 __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, uint32_t tileY, TileRaw<YT, SUB, BIL, NEEDA, NS, WAVES> & T)
 {
     constexpr bool kWide = sizeof(YT) == 2;
@@ -526,12 +545,12 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
         const uint32_t syc = sy < A.h2 ? sy : 0; // absent strips load (and discard) the first one
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            T.raw[k].y[r] = load4<YT>(A.y, (syc + r) * A.yPitch + c.Xc * BPS);
+            T.raw[k].y[r] = load4s<YT, STREAM>(A.y, (syc + r) * A.yPitch + c.Xc * BPS);
             if constexpr (NEEDA)
-                T.raw[k].a[r] = load4<YT>(A.a, (syc + r) * A.aPitch + c.Xc * BPS);
+                T.raw[k].a[r] = load4s<YT, STREAM>(A.a, (syc + r) * A.aPitch + c.Xc * BPS);
             if constexpr (SUB == SUB_444) {
-                T.raw[k].u[r] = load4<YT>(A.u, ((uint32_t)A.cy0 + syc + r) * A.uPitch + ((uint32_t)A.cx0 + c.Xc) * BPS);
-                T.raw[k].v[r] = load4<YT>(A.v, ((uint32_t)A.cy0 + syc + r) * A.vPitch + ((uint32_t)A.cx0 + c.Xc) * BPS);
+                T.raw[k].u[r] = load4s<YT, STREAM>(A.u, ((uint32_t)A.cy0 + syc + r) * A.uPitch + ((uint32_t)A.cx0 + c.Xc) * BPS);
+                T.raw[k].v[r] = load4s<YT, STREAM>(A.v, ((uint32_t)A.cy0 + syc + r) * A.vPitch + ((uint32_t)A.cx0 + c.Xc) * BPS);
             } else if constexpr ((SUB == SUB_420 || SUB == SUB_422) && !BIL) {
                 // nearest: chroma samples (X>>1, X>>1 + 1) of chroma row (j >> shiftY); one aligned pair load per plane
                 if (!(SUB == SUB_420 && r == 1)) {
@@ -815,7 +834,7 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 // One workgroup walks down `tilesPerRun` vertically consecutive tiles (256 x 8*NS pixels each) of one band.  The loads
 // of tile i+1 are in flight while tile i is computed and stored, so a wave waits for memory once per run, not once
 // per tile; vertically consecutive tiles also re-read their shared chroma halo rows from the nearest cache.
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false>
 __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRun, f2 (*rows)[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch],
                                          WideRowExchange * xchg)
 {
@@ -845,7 +864,7 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRu
     // between "done reading" and "may overwrite".
     TileRaw<YT, SUB, BIL, kNeedA, NS> cur;
     uint32_t tileY = firstTile * kTileH;
-    loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY, cur);
+    loadTile<YT, SUB, BIL, kNeedA, NS, 4, STREAM>(A, c, tileY, cur);
     if constexpr (BIL) {
         stageTile<YT, SUB, kNeedA, NS>(A, cur, rows[0]);
         __syncthreads();
@@ -854,7 +873,7 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRu
         const bool more = i + 1 < nTiles;
         TileRaw<YT, SUB, BIL, kNeedA, NS> nxt;
         if (more)
-            loadTile<YT, SUB, BIL, kNeedA, NS>(A, c, tileY + kTileH, nxt);
+            loadTile<YT, SUB, BIL, kNeedA, NS, 4, STREAM>(A, c, tileY + kTileH, nxt);
         computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, c, tileY, cur, rows[i & 1], xchg);
         if (!more)
             break;
@@ -880,7 +899,7 @@ __global__ __launch_bounds__(256) void yuvToRgbTileKernel(TileArgs A, uint32_t t
 }
 
 // one launch for a table of jobs (grid z = job); the descriptor is read with scalar loads
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false>
 __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
@@ -889,16 +908,16 @@ __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * 
     const TileArgs job = table[blockIdx.z];
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, tilesPerRun, rows, xchg);
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, tilesPerRun, rows, xchg);
     } else {
-        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, tilesPerRun, rows, nullptr);
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, tilesPerRun, rows, nullptr);
     }
 }
 
 // ---- every wave for itself (the structure of tile_pk_impl.h): one wave = one tile of 256 x 2*NS pixels, every load issued up
 //      front, the chroma neighbourhood in a wave-private LDS block, NO workgroup barrier; tiles in per-XCD chunks (tile_geom.h).
 //      Replaces the cooperative runs above wherever it measured faster (launchOne) ----
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false>
 __device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2 * lds, WideRowExchange * xchg)
 {
     constexpr bool kNeedA = APLANE || HASMUL;
@@ -921,7 +940,7 @@ __device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2
     c.Xc = c.laneValid ? c.X : 0;
     c.cxb = A.cx0 + (int)(bandX >> 1);
     TileRaw<YT, SUB, BIL, kNeedA, NS, 1> raw;
-    loadTile<YT, SUB, BIL, kNeedA, NS, 1>(A, c, tileY, raw);
+    loadTile<YT, SUB, BIL, kNeedA, NS, 1, STREAM>(A, c, tileY, raw);
     f2(*rows)[kRowPitch] = reinterpret_cast<f2(*)[kRowPitch]>(lds + (size_t)wave * (BIL ? SR::kRows : 1) * kRowPitch);
     if constexpr (BIL) {
         stageTile<YT, SUB, kNeedA, NS, 1>(A, raw, rows);
@@ -944,16 +963,16 @@ __global__ __launch_bounds__(256) void yuvToRgbTileSoloKernel(TileArgs A, PkGeom
     }
 }
 
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false>
 __global__ __launch_bounds__(256) void yuvToRgbTileSoloBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, g, lds, xchg);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, g, lds, xchg);
     } else {
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(job, g, lds, nullptr);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, g, lds, nullptr);
     }
 }
 
@@ -965,7 +984,14 @@ hipError_t launchSolo(const TileLaunch & L)
     pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(blocks, 1, L.count);
-    if (L.table) {
+    if (L.table && L.streamLoads && sizeof(YT) == 2) { // batches of 16-bit planes beyond the Infinity Cache: streaming loads
+        if constexpr (sizeof(YT) == 2) {
+            if (nsw == 4)
+                hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, true>), grid, block, 0, L.stream, L.table, g);
+            else
+                hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, true>), grid, block, 0, L.stream, L.table, g);
+        }
+    } else if (L.table) {
         if (nsw == 4)
             hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, L.table, g);
         else
@@ -986,7 +1012,14 @@ hipError_t launchOne(const TileLaunch & L)
         return launchSolo<YT, SUB, BIL, RT, NCH, APLANE, MUL>(L);
     const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(L.blocksPerJob, 1, L.count);
-    if (L.table && L.stripsPerWave >= 2)
+    if (L.table && L.streamLoads && sizeof(YT) == 2) {
+        if constexpr (sizeof(YT) == 2) {
+            if (L.stripsPerWave >= 2)
+                hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, true>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
+            else
+                hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1, true>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
+        }
+    } else if (L.table && L.stripsPerWave >= 2)
         hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
     else if (L.table)
         hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
