@@ -24,6 +24,17 @@
 namespace avifhip {
 namespace r2y {
 
+// plane stores: streaming (non-temporal) unless -DAVIFHIP_R2Y_PLAIN_STORES (A/B measurements)
+template <typename V>
+__device__ __forceinline__ void storeOut(V v, V * dst)
+{
+#ifdef AVIFHIP_R2Y_PLAIN_STORES
+    *dst = v;
+#else
+    __builtin_nontemporal_store(v, dst);
+#endif
+}
+
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 typedef unsigned u3 __attribute__((ext_vector_type(3)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
@@ -98,20 +109,20 @@ template <typename YT>
 __device__ __forceinline__ void store4Samples(uint8_t * base, uint32_t off, const int q[4])
 {
     if constexpr (sizeof(YT) == 1) {
-        __builtin_nontemporal_store((unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24),
+        storeOut((unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24),
                                     reinterpret_cast<unsigned *>(base + off));
     } else {
         const u2 w = { (unsigned)q[0] | ((unsigned)q[1] << 16), (unsigned)q[2] | ((unsigned)q[3] << 16) };
-        __builtin_nontemporal_store(w, reinterpret_cast<u2 *>(base + off));
+        storeOut(w, reinterpret_cast<u2 *>(base + off));
     }
 }
 template <typename YT>
 __device__ __forceinline__ void store2Samples(uint8_t * base, uint32_t off, int q0, int q1)
 {
     if constexpr (sizeof(YT) == 1)
-        __builtin_nontemporal_store((uint16_t)((unsigned)q0 | ((unsigned)q1 << 8)), reinterpret_cast<uint16_t *>(base + off));
+        storeOut((uint16_t)((unsigned)q0 | ((unsigned)q1 << 8)), reinterpret_cast<uint16_t *>(base + off));
     else
-        __builtin_nontemporal_store((unsigned)q0 | ((unsigned)q1 << 16), reinterpret_cast<unsigned *>(base + off));
+        storeOut((unsigned)q0 | ((unsigned)q1 << 16), reinterpret_cast<unsigned *>(base + off));
 }
 
 template <typename RT, int NCH>
@@ -173,7 +184,7 @@ template <typename YT>
 __device__ __forceinline__ void storeRow4(uint8_t * base, uint32_t off, f2 t01, f2 t23, int maxv)
 {
     if constexpr (sizeof(YT) == 1) {
-        __builtin_nontemporal_store(packU8x4(t01.x, t01.y, t23.x, t23.y), reinterpret_cast<unsigned *>(base + off));
+        storeOut(packU8x4(t01.x, t01.y, t23.x, t23.y), reinterpret_cast<unsigned *>(base + off));
     } else {
         const int q[4] = { truncClamp(t01.x, maxv), truncClamp(t01.y, maxv), truncClamp(t23.x, maxv), truncClamp(t23.y, maxv) };
         store4Samples<YT>(base, off, q);
@@ -264,7 +275,7 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
         storeRow4<YT>(A.y, (sy + r) * A.yPitch + X * BPS, tY[r][0], tY[r][1], yuvMax);
         if (A.alphaMode != R2Y_ALPHA_NONE) {
             if (alphaBytes)
-                __builtin_nontemporal_store(aw[r], reinterpret_cast<unsigned *>(A.a + ((sy + r) * A.aPitch + X)));
+                storeOut(aw[r], reinterpret_cast<unsigned *>(A.a + ((sy + r) * A.aPitch + X)));
             else
                 store4Samples<YT>(A.a, (sy + r) * A.aPitch + X * BPS, aq[r]);
         }
@@ -283,8 +294,8 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
         const f2 tu = unormOperand(su * splat2(0.25f), A.rangeUV, A.biasUV), tv = unormOperand(sv * splat2(0.25f), A.rangeUV, A.biasUV);
         if constexpr (sizeof(YT) == 1) {
             const unsigned uv = packU8x4(tu.x, tu.y, tv.x, tv.y);
-            __builtin_nontemporal_store((uint16_t)uv, reinterpret_cast<uint16_t *>(A.u + ((sy >> 1) * A.uPitch + (X >> 1))));
-            __builtin_nontemporal_store((uint16_t)(uv >> 16), reinterpret_cast<uint16_t *>(A.v + ((sy >> 1) * A.vPitch + (X >> 1))));
+            storeOut((uint16_t)uv, reinterpret_cast<uint16_t *>(A.u + ((sy >> 1) * A.uPitch + (X >> 1))));
+            storeOut((uint16_t)(uv >> 16), reinterpret_cast<uint16_t *>(A.v + ((sy >> 1) * A.vPitch + (X >> 1))));
         } else {
             store2Samples<YT>(A.u, (sy >> 1) * A.uPitch + (X >> 1) * BPS, truncClamp(tu.x, yuvMax), truncClamp(tu.y, yuvMax));
             store2Samples<YT>(A.v, (sy >> 1) * A.vPitch + (X >> 1) * BPS, truncClamp(tv.x, yuvMax), truncClamp(tv.y, yuvMax));

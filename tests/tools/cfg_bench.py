@@ -12,6 +12,8 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from libavif_amd import abi, device, native, synth  # noqa: E402
 
+if os.environ.get("AVIFHIP_BENCH_LIB"):  # A/B measurements: a variant build of the library (e.g. different store policy)
+    native.LIB_PATH = Path(os.environ["AVIFHIP_BENCH_LIB"]).resolve()
 lib = native.load()
 if os.environ.get("AVIFHIP_BENCH_SLAB"):
     # A/B measurement: every device buffer carved out of ONE allocation (value = alignment in bytes) instead of one hipMalloc per plane --
