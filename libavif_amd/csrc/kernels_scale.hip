@@ -7,6 +7,13 @@
 
 #include "kernels.h"
 
+// destination samples are written once and not read again by the kernel: streaming stores (A/B: -DAVIFHIP_SCALE_PLAIN_STORES)
+#ifdef AVIFHIP_SCALE_PLAIN_STORES
+#define SCALE_STORE(ptr, value) (*(ptr) = (value))
+#else
+#define SCALE_STORE(ptr, value) __builtin_nontemporal_store((value), (ptr))
+#endif
+
 namespace avifhip {
 
 namespace {
@@ -258,9 +265,12 @@ __device__ __forceinline__ void scalePlaneStaged(const ScaleArgs & A, int rowsPe
         if (i0 + 3 < A.dstW && aligned) {
             if (WIDE) {
                 uint2 w = { (uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16) };
-                *reinterpret_cast<uint2 *>(d) = w;
+                {
+                    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                    SCALE_STORE(reinterpret_cast<u2v *>(d), ((u2v) { w.x, w.y }));
+                }
             } else {
-                *reinterpret_cast<uint32_t *>(d) = (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24);
+                SCALE_STORE(reinterpret_cast<uint32_t *>(d), (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24));
             }
         } else {
 #pragma unroll
@@ -421,7 +431,7 @@ __device__ __forceinline__ void scalePlaneWindow(const ScaleArgs & A, int rowsPe
             uint8_t * d = A.dst + (size_t)j * A.dstPitch + (size_t)i0;
             const bool aligned = (((uintptr_t)(A.dst + (size_t)j * A.dstPitch)) & 3u) == 0; // uniform
             if (i0 + 3 < A.dstW && aligned) {
-                *reinterpret_cast<uint32_t *>(d) = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
+                SCALE_STORE(reinterpret_cast<uint32_t *>(d), __builtin_amdgcn_perm(hi, lo, 0x06040200u));
             } else {
                 const uint32_t out[4] = { lo & 0xffu, (lo >> 16) & 0xffu, hi & 0xffu, (hi >> 16) & 0xffu };
 #pragma unroll
