@@ -117,6 +117,18 @@ def test_cfg5_grid_rgba10_fp32(hip):
     run_grid(hip, _cfg5(10, True))
 
 
+def test_large_batches_of_other_layouts(hip_auto_arithmetic):
+    """Batches whose planes exceed the Infinity Cache take the streaming-load instantiations of every kernel family: 4:4:4 + alpha tiles
+    (wave-private fp32 kernels), 12-bit 4:2:0 through the reduction to 8 bits and 10-bit 4:2:2 (packed kernels), nearest upsampling."""
+    for g in (H.GridCase(6, 6, 1920, 1080, 6 * 1920, 6 * 1080, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=1, yuv_range=1, matrix=9, rgb_depth=16, alpha=True,
+                                                                         rgb_premultiplied=True, avoid_libyuv=False)),
+              H.GridCase(7, 7, 1920, 1080, 7 * 1920, 7 * 1080, H.Y2RCase(0, 0, yuv_depth=12, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=8, upsampling=BILINEAR,
+                                                                         avoid_libyuv=False)),
+              H.GridCase(6, 6, 1920, 1080, 6 * 1920, 6 * 1080, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=2, yuv_range=0, matrix=9, rgb_depth=8, upsampling=3,
+                                                                         rgb_format=abi.AVIF_RGB_FORMAT_RGB, avoid_libyuv=False))):
+        run_grid(hip_auto_arithmetic, g)
+
+
 # ---------------------------------------------------------------------------------------------------
 # size-independent properties at the full sizes
 
