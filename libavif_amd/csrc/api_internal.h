@@ -41,6 +41,7 @@ struct ScaleTableCache
     int mode[4] = { 0, 0, 0, 0 };
     ScaleStaging staging[4]; // row-staged kernel
     ScaleStaging window[4];  // window kernel
+    bool doubling[4] = { false, false, false, false }; // 2x on both axes: the doubling kernel when the buffers' alignment allows
 };
 
 // what tls.gainMap[2] currently holds (the tables of avifhipRGBImageApplyGainMap): rebuilt only when a parameter changes

@@ -157,6 +157,7 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
             cache.mode[p] = sched.mode;
             cache.staging[p] = scaleStagedPlan(sched, sd.w[p], wide, 256);
             cache.window[p] = ScaleStaging();
+            cache.doubling[p] = sched.doubling && !wide;
             if (scaleWindowCovers(sched, sd.w[p], wide)) { // no staging: rows per wave only amortise the prologue
                 int rpw = 16;
                 while (rpw > 4 && ((size_t)dd.w[p] + 255) / 256 * (((size_t)dd.h[p] + 4 * rpw - 1) / (4 * rpw)) < 2048)
@@ -184,8 +185,9 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
     }
     const int32_t * dev = (const int32_t *)tls.scaleTable.ptr;
     const bool staged = gTiledKernels.load(std::memory_order_relaxed) != 0;
-    ScaleStagedLaunch L, W; // planes served by the row-staged kernel / by the window kernel
-    L.count = W.count = 0;
+    ScaleStagedLaunch L, W, D; // planes served by the row-staged kernel / by the window kernel / by the doubling kernel
+    L.count = W.count = D.count = 0;
+    bool firstDoubled = false;
     for (int p = 0; p < 4; ++p) {
         if (!present[p])
             continue;
@@ -199,6 +201,12 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
         const int32_t * t = dev + cache.offset[p];
         const size_t wPad = colTablePad((size_t)dd.w[p]), hPad = ((size_t)dd.h[p] + 3) & ~(size_t)3;
         A.colA = t, A.colB = t + wPad, A.rowA = t + 2 * wPad, A.rowB = A.rowA + hPad, A.rowF = A.rowB + hPad;
+        if (staged && cache.doubling[p] && scaleDoublingCovers(A)) {
+            D.plane[D.count] = A, D.staging[D.count] = ScaleStaging();
+            ++D.count;
+            firstDoubled = firstDoubled || p == (present[0] ? 0 : 3);
+            continue;
+        }
         if (staged && cache.window[p].rowsPerWave > 0) {
             W.plane[W.count] = A, W.staging[W.count] = cache.window[p];
             ++W.count;
@@ -213,7 +221,9 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
         if (e != hipSuccess)
             return hipFailed(e, "plane scaling kernel launch");
     }
-    hipError_t le = launchScalePlanesStaged(W, wide, true, stream);
+    hipError_t le = launchScalePlanesDoubling(D, stream);
+    if (le == hipSuccess)
+        le = launchScalePlanesStaged(W, wide, true, stream);
     if (le == hipSuccess)
         le = launchScalePlanesStaged(L, wide, false, stream);
     if (le != hipSuccess)
@@ -224,7 +234,7 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
                                         { "scale_point[window]", "scale_down[window]", "scale_up[window]", "scale_box[window]", "scale_up2[window]" } };
     const int first = present[0] ? 0 : 3;
     const int family = !staged ? 0 : cache.window[first].rowsPerWave > 0 ? 2 : cache.staging[first].rowsPerWave > 0 ? 1 : 0;
-    tls.lastKernel = names[family][cache.mode[first]];
+    tls.lastKernel = firstDoubled ? "scale_up2[doubling]" : names[family][cache.mode[first]];
     ++tls.launches;
     return AVIF_RESULT_OK;
 }

@@ -114,6 +114,9 @@ struct ScaleStagedLaunch
 // the source columns of every aligned group of 4 destination columns span <= 8 samples; only rowsPerWave of the staging is used;
 // column tables padded with copies of their last entry to a multiple of 4)
 hipError_t launchScalePlanesStaged(const ScaleStagedLaunch & launch, bool wide, bool window, hipStream_t stream);
+// 8-bit planes doubled on both axes (ScalePlaneUp2_Bilinear): needs no schedule tables; source rows dword-aligned, destination rows 16-byte aligned
+bool scaleDoublingCovers(const ScaleArgs & args);
+hipError_t launchScalePlanesDoubling(const ScaleStagedLaunch & launch, hipStream_t stream);
 
 // Sample Transform expression evaluation (kernels_sato.hip), one lane per sample of one plane
 constexpr int kSatoMaxTokens = 64, kSatoMaxInputs = 32;

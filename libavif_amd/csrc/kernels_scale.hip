@@ -443,6 +443,118 @@ __device__ __forceinline__ void scalePlaneWindow(const ScaleArgs & A, int rowsPe
     }
 }
 
+// ---- 2x on both axes (ScalePlaneUp2_Bilinear, scale.c:500-528; ScaleRowUp2_Bilinear_C: (9 near + 3 + 3 + 1 diagonal + 8) >> 4 with the
+//      neighbours of edge samples duplicated; the last destination column takes far = near, scale_plan.cpp upsample2Axis) ----
+// The window kernel spends a vector-memory instruction per 4 destination samples; here a lane owns 8 source columns = 16 destination
+// columns: one 8-byte load (+ two halo bytes) per SOURCE row, one 16-byte streaming store per DESTINATION row.  The filter is separable in
+// exact integers: H = 3 near + far + 2 per source row (<= 1022: 16-bit pairs, v_pk_mad_u16), out = (3 H_near + H_far) >> 4 -- the +2s sum up
+// to the +8.  A wave slides over kDoubleRows source rows with H of three rows in registers.
+constexpr int kDoubleRows = 4, kDoubleCols = 512;
+
+__device__ __forceinline__ unsigned pkMad3(unsigned a, unsigned c) // a * 3 + c on both 16-bit halves
+{
+    unsigned d;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(0x00030003u), "v"(c));
+    return d;
+}
+
+struct DoubledRow
+{
+    unsigned h[8]; // (H of destination column 2i | H of column 2i + 1) for the lane's source columns i = 0 .. 7
+};
+
+__device__ __forceinline__ DoubledRow doubleRowHorizontally(const ScaleArgs & A, int row, int c0, bool fullLane)
+{
+    const uint8_t * src = A.src + (size_t)row * A.srcPitch;
+    unsigned w0, w1;
+    if (fullLane) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(src + c0);
+        w0 = t.x, w1 = t.y;
+    } else { // the lane holding the row's last columns: missing ones repeat the last sample
+        w0 = w1 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned v = src[min(c0 + i, A.srcW - 1)];
+            if (i < 4)
+                w0 |= v << (8 * i);
+            else
+                w1 |= v << (8 * (i - 4));
+        }
+    }
+    const unsigned sl = src[max(c0 - 1, 0)], sr = src[min(c0 + 8, A.srcW - 1)];
+    DoubledRow R;
+    // v_perm_b32: selector bytes 0..3 address the second operand, 4..7 the first, 12 is zero
+    const unsigned f0 = __builtin_amdgcn_perm(w0, sl, 0x0c050c00u);  // (s[-1] | s[1] << 16)
+    const unsigned f7 = __builtin_amdgcn_perm(sr, w1, 0x0c040c02u);  // (s[6] | s[8] << 16)
+    unsigned f[8] = { f0, 0, 0, 0, 0, 0, 0, f7 };
+#pragma unroll
+    for (int i = 1; i < 7; ++i)
+        f[i] = __builtin_amdgcn_perm(w1, w0, 0x0c000c00u | (unsigned)(i - 1) | ((unsigned)(i + 1) << 16));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned s2 = __builtin_amdgcn_perm(w1, w0, 0x0c000c00u | (unsigned)i | ((unsigned)i << 16)); // (s[i] | s[i] << 16)
+        R.h[i] = pkMad3(s2, f[i]) + 0x00020002u;
+    }
+    // the last destination column of an odd width is an even one whose far neighbour is itself (upsample2Axis: lastIsEdge)
+    if (A.dstW & 1) {
+        const int iLast = A.srcW - 1 - c0;
+        if (iLast >= 0 && iLast < 8) {
+            const unsigned v = src[A.srcW - 1];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i == iLast)
+                    R.h[i] = (R.h[i] & 0xffff0000u) | (4u * v + 2u);
+        }
+    }
+    return R;
+}
+
+__global__ __launch_bounds__(256) void scalePlanesDoublingKernel(ScaleStagedLaunch L)
+{
+    const ScaleArgs & A = L.plane[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (int)blockIdx.x * kDoubleCols + 8 * lane;
+    const int j0 = ((int)blockIdx.y * 4 + wave) * kDoubleRows;
+    if (c0 >= A.srcW || j0 >= A.srcH)
+        return;
+    const bool fullLane = c0 + 8 <= A.srcW;
+    const int d0 = 2 * c0;
+    const bool fullStore = d0 + 16 <= A.dstW;
+    DoubledRow prev = doubleRowHorizontally(A, max(j0 - 1, 0), c0, fullLane);
+    DoubledRow cur = doubleRowHorizontally(A, j0, c0, fullLane);
+#pragma unroll
+    for (int r = 0; r < kDoubleRows; ++r) {
+        const int j = j0 + r;
+        if (j >= A.srcH) // wave-uniform
+            break;
+        const DoubledRow next = doubleRowHorizontally(A, min(j + 1, A.srcH - 1), c0, fullLane);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int dj = 2 * j + half;
+            if (dj >= A.dstH)
+                break;
+            const DoubledRow & far = half ? next : prev;
+            unsigned o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                o[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, pkMad3(cur.h[i], far.h[i])) >> splatPair(4));
+            typedef unsigned u4s __attribute__((ext_vector_type(4)));
+            const u4s px = { __builtin_amdgcn_perm(o[1], o[0], 0x06040200u), __builtin_amdgcn_perm(o[3], o[2], 0x06040200u),
+                             __builtin_amdgcn_perm(o[5], o[4], 0x06040200u), __builtin_amdgcn_perm(o[7], o[6], 0x06040200u) };
+            uint8_t * d = A.dst + (size_t)dj * A.dstPitch + (size_t)d0;
+            if (fullStore) {
+                __builtin_nontemporal_store(px, reinterpret_cast<u4s *>(d));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (d0 + k < A.dstW)
+                        d[k] = (uint8_t)(px[k >> 2] >> (8 * (k & 3)));
+            }
+        }
+        prev = cur, cur = next;
+    }
+}
+
 __global__ __launch_bounds__(256) void scalePlanesWindowKernel(ScaleStagedLaunch L)
 {
     const int p = blockIdx.z;
@@ -467,6 +579,25 @@ hipError_t launchScalePlane(const ScaleArgs & A, bool wide, hipStream_t stream)
         hipLaunchKernelGGL(scalePlaneKernel<true>, grid, block, 0, stream, A);
     else
         hipLaunchKernelGGL(scalePlaneKernel<false>, grid, block, 0, stream, A);
+    return hipGetLastError();
+}
+
+bool scaleDoublingCovers(const ScaleArgs & A)
+{
+    return A.mode == SCALE_UP2_MODE && A.srcW >= 8 && (((uintptr_t)A.src | A.srcPitch) & 3u) == 0 && (((uintptr_t)A.dst | A.dstPitch) & 15u) == 0;
+}
+
+hipError_t launchScalePlanesDoubling(const ScaleStagedLaunch & L, hipStream_t stream)
+{
+    if (L.count <= 0)
+        return hipSuccess;
+    unsigned gx = 1, gy = 1;
+    for (int p = 0; p < L.count; ++p) {
+        const ScaleArgs & A = L.plane[p];
+        const unsigned bx = (unsigned)(A.srcW + kDoubleCols - 1) / kDoubleCols, by = (unsigned)(A.srcH + 4 * kDoubleRows - 1) / (4 * kDoubleRows);
+        gx = bx > gx ? bx : gx, gy = by > gy ? by : gy;
+    }
+    hipLaunchKernelGGL(scalePlanesDoublingKernel, dim3(gx, gy, (unsigned)L.count), dim3(256), 0, stream, L);
     return hipGetLastError();
 }
 

@@ -132,6 +132,7 @@ ScaleSchedule makeScaleSchedule(int sw, int sh, int dw, int dh, bool wide)
     }
     if (up2Allowed && up2w && up2h && (f == BILINEAR || f == BOX)) { // ScalePlaneUp2_Bilinear and twins, :500-528
         S.mode = SCALE_UP2;
+        S.doubling = true;
         upsample2Axis(sw, dw, true, S.colA, S.colB);
         upsample2Axis(sh, dh, !(dh & 1), S.rowA, S.rowB);
         return S;

@@ -25,6 +25,7 @@ enum ScaleMode : int {
 struct ScaleSchedule
 {
     int mode = SCALE_POINT;
+    bool doubling = false; // UP2 on both axes (ScalePlaneUp2_Bilinear and twins): what the doubling kernel serves without the tables
     // per destination column.  POINT/DOWN/UP: source column, 16.16 fraction; UP2: near, far column; BOX: first column, width
     std::vector<int32_t> colA, colB;
     // per destination row.  DOWN/UP/UP2: first and second source row, 8-bit fraction; BOX: first row, height

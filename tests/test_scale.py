@@ -163,3 +163,30 @@ def test_gpu_scale_device_resident_equals_the_oracle(hip):
         compare(planes_of(a.struct), planes_of(dst.struct), (c.ident(), dw, dh, tight, native.last_kernel()))
         if (c.w, c.h) != (dw, dh):
             free_owned(a.struct)
+
+
+@pytest.mark.gpu
+def test_gpu_scale_doubling_kernel(hip):
+    """2x on both axes (ScalePlaneUp2_Bilinear) in the doubling kernel: even and odd destination sizes on either axis, widths off the 8-column
+    and 512-column grids, every 8-bit layout, alpha; device-resident with 256-byte row pitches (the kernel's alignment needs), and tight rows
+    (which it declines: the window kernel must serve those with the same bytes)."""
+    from libavif_amd import device, native
+
+    o = oracle_lib.oracle()
+    seen = set()
+    for (w, h), (ox, oy), yf, alpha, tight in [((520, 37), (0, 0), 3, False, False), ((520, 37), (1, 0), 3, True, False), ((521, 36), (0, 1), 1, False, False),
+                                               ((1031, 19), (1, 1), 2, False, False), ((64, 64), (0, 0), 4, True, False), ((9, 5), (1, 1), 1, False, False),
+                                               ((777, 130), (0, 0), 3, False, True), ((2048, 16), (1, 0), 3, False, False), ((8, 8), (0, 0), 1, True, False)]:
+        c = H.Y2RCase(w, h, yuv_depth=8, yuv_format=yf, alpha=alpha, yuv_range=1)
+        dw, dh = 2 * w - ox, 2 * h - oy
+        a, src = H.make_y2r_inputs(c), H.make_y2r_inputs(c)
+        assert o.oracleImageScale(a.struct, dw, dh) == 0
+        dst = H.make_y2r_inputs(H.Y2RCase(dw, dh, yuv_depth=8, yuv_format=yf, alpha=alpha, yuv_range=1))
+        dsrc, ddst = device.DeviceYUV(src, tight=tight), device.DeviceYUV(dst, tight=tight)
+        native.check(hip.avifhipImageScaleAsync(dsrc.struct, ddst.struct, None), "avifhipImageScaleAsync")
+        native.check(hip.avifhipSynchronize(None), "sync")
+        ddst.download_into_host()
+        seen.add((tight, native.last_kernel()))
+        compare(planes_of(a.struct), planes_of(dst.struct), (c.ident(), dw, dh, tight, native.last_kernel()))
+        free_owned(a.struct)
+    assert (False, "scale_up2[doubling]") in seen and not any(t and k == "scale_up2[doubling]" for t, k in seen), seen
