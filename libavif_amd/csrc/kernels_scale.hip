@@ -449,7 +449,10 @@ __device__ __forceinline__ void scalePlaneWindow(const ScaleArgs & A, int rowsPe
 // columns: one 8-byte load (+ two halo bytes) per SOURCE row, one 16-byte streaming store per DESTINATION row.  The filter is separable in
 // exact integers: H = 3 near + far + 2 per source row (<= 1022: 16-bit pairs, v_pk_mad_u16), out = (3 H_near + H_far) >> 4 -- the +2s sum up
 // to the +8.  A wave slides over kDoubleRows source rows with H of three rows in registers.
-constexpr int kDoubleRows = 4, kDoubleCols = 512;
+#ifndef AVIFHIP_DOUBLE_ROWS
+#define AVIFHIP_DOUBLE_ROWS 4
+#endif
+constexpr int kDoubleRows = AVIFHIP_DOUBLE_ROWS, kDoubleCols = 512;
 
 __device__ __forceinline__ unsigned pkMad3(unsigned a, unsigned c) // a * 3 + c on both 16-bit halves
 {
