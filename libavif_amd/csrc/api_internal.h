@@ -41,6 +41,7 @@ struct ScaleTableCache
     int mode[4] = { 0, 0, 0, 0 };
     ScaleStaging staging[4]; // row-staged kernel
     ScaleStaging window[4];  // window kernel
+    int exactBox[4] = { 0, 0, 0, 0 };                  // exact N x N boxes: the box kernel when the buffers' alignment allows
     bool doubling[4] = { false, false, false, false }; // 2x on both axes: the doubling kernel when the buffers' alignment allows
 };
 

@@ -158,6 +158,7 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
             cache.staging[p] = scaleStagedPlan(sched, sd.w[p], wide, 256);
             cache.window[p] = ScaleStaging();
             cache.doubling[p] = sched.doubling && !wide;
+            cache.exactBox[p] = wide ? 0 : sched.exactBox;
             if (scaleWindowCovers(sched, sd.w[p], wide)) { // no staging: rows per wave only amortise the prologue
                 int rpw = 16;
                 while (rpw > 4 && ((size_t)dd.w[p] + 255) / 256 * (((size_t)dd.h[p] + 4 * rpw - 1) / (4 * rpw)) < 2048)
@@ -185,9 +186,9 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
     }
     const int32_t * dev = (const int32_t *)tls.scaleTable.ptr;
     const bool staged = gTiledKernels.load(std::memory_order_relaxed) != 0;
-    ScaleStagedLaunch L, W, D; // planes served by the row-staged kernel / by the window kernel / by the doubling kernel
-    L.count = W.count = D.count = 0;
-    bool firstDoubled = false;
+    ScaleStagedLaunch L, W, D, B; // planes served by the row-staged kernel / the window kernel / the doubling kernel / the exact-box kernel
+    L.count = W.count = D.count = B.count = 0;
+    bool firstDoubled = false, firstBoxed = false;
     for (int p = 0; p < 4; ++p) {
         if (!present[p])
             continue;
@@ -207,6 +208,13 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
             firstDoubled = firstDoubled || p == (present[0] ? 0 : 3);
             continue;
         }
+        if (staged && cache.exactBox[p] && scaleExactBoxCovers(A)) {
+            B.plane[B.count] = A, B.staging[B.count] = ScaleStaging();
+            B.staging[B.count].boxWidth = cache.exactBox[p];
+            ++B.count;
+            firstBoxed = firstBoxed || p == (present[0] ? 0 : 3);
+            continue;
+        }
         if (staged && cache.window[p].rowsPerWave > 0) {
             W.plane[W.count] = A, W.staging[W.count] = cache.window[p];
             ++W.count;
@@ -223,6 +231,8 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
     }
     hipError_t le = launchScalePlanesDoubling(D, stream);
     if (le == hipSuccess)
+        le = launchScalePlanesExactBox(B, stream);
+    if (le == hipSuccess)
         le = launchScalePlanesStaged(W, wide, true, stream);
     if (le == hipSuccess)
         le = launchScalePlanesStaged(L, wide, false, stream);
@@ -234,7 +244,7 @@ extern "C" avifResult avifhipImageScaleAsync(const avifImage * src, avifImage * 
                                         { "scale_point[window]", "scale_down[window]", "scale_up[window]", "scale_box[window]", "scale_up2[window]" } };
     const int first = present[0] ? 0 : 3;
     const int family = !staged ? 0 : cache.window[first].rowsPerWave > 0 ? 2 : cache.staging[first].rowsPerWave > 0 ? 1 : 0;
-    tls.lastKernel = firstDoubled ? "scale_up2[doubling]" : names[family][cache.mode[first]];
+    tls.lastKernel = firstDoubled ? "scale_up2[doubling]" : firstBoxed ? "scale_box[exact]" : names[family][cache.mode[first]];
     ++tls.launches;
     return AVIF_RESULT_OK;
 }

@@ -115,6 +115,9 @@ struct ScaleStagedLaunch
 // column tables padded with copies of their last entry to a multiple of 4)
 hipError_t launchScalePlanesStaged(const ScaleStagedLaunch & launch, bool wide, bool window, hipStream_t stream);
 // 8-bit planes doubled on both axes (ScalePlaneUp2_Bilinear): needs no schedule tables; source rows dword-aligned, destination rows 16-byte aligned
+// 8-bit planes reduced by exact N x N boxes, N in {4, 8} (staging[].boxWidth = N): source rows 16-byte aligned, destination rows dword-aligned
+bool scaleExactBoxCovers(const ScaleArgs & args);
+hipError_t launchScalePlanesExactBox(const ScaleStagedLaunch & launch, hipStream_t stream);
 bool scaleDoublingCovers(const ScaleArgs & args);
 hipError_t launchScalePlanesDoubling(const ScaleStagedLaunch & launch, hipStream_t stream);
 

@@ -558,6 +558,77 @@ __global__ __launch_bounds__(256) void scalePlanesDoublingKernel(ScaleStagedLaun
     }
 }
 
+// ---- exact N x N boxes, N in {4, 8} (thumbnails at exactly 1/4 or 1/8: ScalePlaneBox with every box on the N-grid; ScaleAddRow sums rows
+//      in 16 bits -- no wrap below 258 rows -- and ScaleAddCols multiplies by 65536 / N^2, an exact shift) ----
+// A lane owns 4 destination samples: N / 4 16-byte loads per source row (1 or 2 KiB contiguous per wave instruction, streaming), N rows,
+// one v_sad_u8 per dword, one dword store.  No LDS, no tables.  The row-staged kernel copies the same bytes through LDS first.
+template <int N>
+__device__ __forceinline__ void scalePlaneExactBox(const ScaleArgs & A)
+{
+    typedef unsigned u4s __attribute__((ext_vector_type(4)));
+    constexpr int kLoads = N / 4;     // 16-byte loads per source row
+    constexpr int kRows = 8 / N;      // destination rows per wave: 8 source rows (32 / 64 registers of pixels) in flight
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = (int)blockIdx.x * 256 + 4 * lane;
+    const int j0 = ((int)blockIdx.y * 4 + wave) * kRows;
+    if (i0 >= A.dstW || j0 >= A.dstH)
+        return;
+    const bool whole = i0 + 4 <= A.dstW;
+    u4s raw[kRows][N][kLoads];
+    if (whole) {
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) {
+            const int j = min(j0 + q, A.dstH - 1); // rows past the end repeat the last one (loads only)
+#pragma unroll
+            for (int r = 0; r < N; ++r)
+#pragma unroll
+                for (int h = 0; h < kLoads; ++h)
+                    raw[q][r][h] = *reinterpret_cast<const u4s *>(A.src + (size_t)(j * N + r) * A.srcPitch + (size_t)i0 * N + 16 * h);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kRows; ++q) {
+        const int j = j0 + q;
+        if (j >= A.dstH) // wave-uniform
+            break;
+        uint32_t sum[4] = { 0, 0, 0, 0 };
+        if (whole) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (N == 4) {
+                        sum[s] = __builtin_amdgcn_sad_u8(raw[q][r][0][s], 0u, sum[s]);
+                    } else {
+                        const u4s & t = raw[q][r][s >> 1];
+                        sum[s] = __builtin_amdgcn_sad_u8(t[2 * (s & 1) + 1], 0u, __builtin_amdgcn_sad_u8(t[2 * (s & 1)], 0u, sum[s]));
+                    }
+                }
+            }
+            constexpr int kShift = (N == 4) ? 4 : 6; // (sum * (65536 / N^2)) >> 16
+            *reinterpret_cast<uint32_t *>(A.dst + (size_t)j * A.dstPitch + (size_t)i0) =
+                (sum[0] >> kShift) | ((sum[1] >> kShift) << 8) | ((sum[2] >> kShift) << 16) | ((sum[3] >> kShift) << 24);
+        } else { // the row's last, partial group of destination samples
+            for (int s = 0; i0 + s < A.dstW; ++s) {
+                uint32_t t = 0;
+                for (int r = 0; r < N; ++r)
+                    for (int c = 0; c < N; ++c)
+                        t += A.src[(size_t)(j * N + r) * A.srcPitch + (size_t)(i0 + s) * N + c];
+                A.dst[(size_t)j * A.dstPitch + (size_t)(i0 + s)] = (uint8_t)((t * (65536u / (N * N))) >> 16);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scalePlanesExactBoxKernel(ScaleStagedLaunch L)
+{
+    const ScaleArgs & A = L.plane[blockIdx.z];
+    if (L.staging[blockIdx.z].boxWidth == 4) // uniform
+        scalePlaneExactBox<4>(A);
+    else
+        scalePlaneExactBox<8>(A);
+}
+
 __global__ __launch_bounds__(256) void scalePlanesWindowKernel(ScaleStagedLaunch L)
 {
     const int p = blockIdx.z;
@@ -582,6 +653,26 @@ hipError_t launchScalePlane(const ScaleArgs & A, bool wide, hipStream_t stream)
         hipLaunchKernelGGL(scalePlaneKernel<true>, grid, block, 0, stream, A);
     else
         hipLaunchKernelGGL(scalePlaneKernel<false>, grid, block, 0, stream, A);
+    return hipGetLastError();
+}
+
+bool scaleExactBoxCovers(const ScaleArgs & A)
+{
+    return A.mode == SCALE_BOX_MODE && (((uintptr_t)A.src | A.srcPitch) & 15u) == 0 && (((uintptr_t)A.dst | A.dstPitch) & 3u) == 0;
+}
+
+hipError_t launchScalePlanesExactBox(const ScaleStagedLaunch & L, hipStream_t stream)
+{
+    if (L.count <= 0)
+        return hipSuccess;
+    unsigned gx = 1, gy = 1;
+    for (int p = 0; p < L.count; ++p) {
+        const ScaleArgs & A = L.plane[p];
+        const int rowsPerGroup = 4 * (8 / L.staging[p].boxWidth);
+        const unsigned bx = (unsigned)(A.dstW + 255) / 256, by = (unsigned)(A.dstH + rowsPerGroup - 1) / rowsPerGroup;
+        gx = bx > gx ? bx : gx, gy = by > gy ? by : gy;
+    }
+    hipLaunchKernelGGL(scalePlanesExactBoxKernel, dim3(gx, gy, (unsigned)L.count), dim3(256), 0, stream, L);
     return hipGetLastError();
 }
 

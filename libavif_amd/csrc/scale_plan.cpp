@@ -104,7 +104,24 @@ void filteredColumns(ScaleSchedule & S, int x, int dx, int sw)
 
 } // namespace
 
+static ScaleSchedule makeScaleScheduleImpl(int sw, int sh, int dw, int dh, bool wide);
+
 ScaleSchedule makeScaleSchedule(int sw, int sh, int dw, int dh, bool wide)
+{
+    ScaleSchedule S = makeScaleScheduleImpl(sw, sh, dw, dh, wide);
+    if (S.mode == SCALE_BOX && !wide && !S.colB.empty() && !S.rowB.empty()) {
+        const int n = S.colB[0];
+        bool exact = (n == 4 || n == 8) && sw == n * dw && sh == n * dh;
+        for (size_t i = 0; i < S.colA.size() && exact; ++i)
+            exact = S.colA[i] == n * (int)i && S.colB[i] == n;
+        for (size_t j = 0; j < S.rowA.size() && exact; ++j)
+            exact = S.rowA[j] == n * (int)j && S.rowB[j] == n;
+        S.exactBox = exact ? n : 0;
+    }
+    return S;
+}
+
+static ScaleSchedule makeScaleScheduleImpl(int sw, int sh, int dw, int dh, bool wide)
 {
     ScaleSchedule S;
     S.colA.assign(dw, 0), S.colB.assign(dw, 0);

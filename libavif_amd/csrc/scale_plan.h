@@ -25,6 +25,7 @@ enum ScaleMode : int {
 struct ScaleSchedule
 {
     int mode = SCALE_POINT;
+    int exactBox = 0;      // BOX with every box exactly N x N on the N-grid, N in {4, 8} (exact 4x / 8x thumbnails): what the box kernel serves
     bool doubling = false; // UP2 on both axes (ScalePlaneUp2_Bilinear and twins): what the doubling kernel serves without the tables
     // per destination column.  POINT/DOWN/UP: source column, 16.16 fraction; UP2: near, far column; BOX: first column, width
     std::vector<int32_t> colA, colB;

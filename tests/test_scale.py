@@ -190,3 +190,32 @@ def test_gpu_scale_doubling_kernel(hip):
         compare(planes_of(a.struct), planes_of(dst.struct), (c.ident(), dw, dh, tight, native.last_kernel()))
         free_owned(a.struct)
     assert (False, "scale_up2[doubling]") in seen and not any(t and k == "scale_up2[doubling]" for t, k in seen), seen
+
+
+@pytest.mark.gpu
+def test_gpu_scale_exact_box_kernel(hip):
+    """Thumbnails at exactly 1/4 and 1/8 (every box N x N on the N-grid) in the exact-box kernel: destination widths on and off the 4-sample
+    grid, every 8-bit layout, alpha; tight rows (unaligned: declined, the row-staged kernel serves them with the same bytes)."""
+    from libavif_amd import device, native
+
+    o = oracle_lib.oracle()
+    seen = set()
+    for (dw, dh), n, yf, alpha, tight in [((260, 33), 4, 1, False, False), ((512, 20), 4, 3, True, False), ((131, 17), 8, 1, False, False), ((258, 9), 4, 4, False, False),
+                                          ((64, 64), 8, 3, False, False), ((480, 270), 4, 3, False, False), ((130, 50), 4, 1, True, True), ((6, 6), 4, 1, False, False)]:
+        mult = n * (2 if yf == 3 else 1)  # subsampled planes must reduce by the same exact factor
+        w, h = dw * n, dh * n
+        if yf in (2, 3) and (dw % 2 or (yf == 3 and dh % 2)):
+            dw, dh = dw + dw % 2, dh + (dh % 2 if yf == 3 else 0)
+            w, h = dw * n, dh * n
+        c = H.Y2RCase(w, h, yuv_depth=8, yuv_format=yf, alpha=alpha, yuv_range=1)
+        a, src = H.make_y2r_inputs(c), H.make_y2r_inputs(c)
+        assert o.oracleImageScale(a.struct, dw, dh) == 0
+        dst = H.make_y2r_inputs(H.Y2RCase(dw, dh, yuv_depth=8, yuv_format=yf, alpha=alpha, yuv_range=1))
+        dsrc, ddst = device.DeviceYUV(src, tight=tight), device.DeviceYUV(dst, tight=tight)
+        native.check(hip.avifhipImageScaleAsync(dsrc.struct, ddst.struct, None), "avifhipImageScaleAsync")
+        native.check(hip.avifhipSynchronize(None), "sync")
+        ddst.download_into_host()
+        seen.add((tight, native.last_kernel()))
+        compare(planes_of(a.struct), planes_of(dst.struct), (c.ident(), dw, dh, n, tight, native.last_kernel()))
+        free_owned(a.struct)
+    assert (False, "scale_box[exact]") in seen, seen
