@@ -115,10 +115,85 @@ __global__ __launch_bounds__(256) void transformTransposeKernel(TransformArgs A)
     }
 }
 
+// Quarter turns of 4- or 8-byte pixels with 16 bytes per lane on BOTH sides (the 32 x 32 kernel above moves one pixel per lane and access:
+// 128-byte row pieces, a vector-memory instruction per 256 bytes).  A workgroup takes the source tile of 64 columns x 16 N rows
+// (N = 16 / PX pixels per 16 bytes) behind a destination tile of 16 N columns x 64 rows: 1024 16-byte loads along source rows into an LDS
+// tile whose 16-byte chunks are XOR-swizzled by the row group, then every lane gathers the N pixels of one destination chunk column-wise
+// (two lanes per bank) and stores them: a wave instruction writes 4 destination rows of 256 contiguous bytes.
+template <int PX>
+__global__ __launch_bounds__(256) void transformTransposeWideKernel(TransformArgs A)
+{
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr uint32_t N = 16 / PX, W = PX / 4;          // pixels per chunk, dwords per pixel
+    constexpr uint32_t TW = 16 * N, TH = 64;             // destination tile
+    constexpr uint32_t SR = TW, CH = 64 / N;             // source tile: SR rows of CH chunks (64 pixels)
+    __shared__ __attribute__((aligned(16))) u4v tile[SR * CH]; // 16 KiB
+    const uint32_t X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
+    const uint32_t X1 = min(X0 + TW, A.dw) - 1, Y1 = min(Y0 + TH, A.dh) - 1;
+    uint32_t ia, ja, ib, jb;
+    sourceOf(A, X0, Y0, &ia, &ja);
+    sourceOf(A, X1, Y1, &ib, &jb);
+    const uint32_t i0 = min(ia, ib), j0 = min(ja, jb);
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t idx = t + 256 * k, jj = idx / CH, c = idx % CH;
+        const uint32_t i = i0 + N * c, j = j0 + jj;
+        u4v v = { 0, 0, 0, 0 };
+        if (j < A.ch && i < A.cw) {
+            const uint8_t * p = A.src + (size_t)j * A.srcPitch + (size_t)i * PX;
+            if (i + N <= A.cw) {
+                v = *reinterpret_cast<const u4u *>(p);
+            } else { // the row's last, partial chunk
+                for (uint32_t q = 0; i + q < A.cw; ++q)
+                    for (uint32_t w = 0; w < W; ++w)
+                        v[q * W + w] = reinterpret_cast<const uint32_t *>(p)[q * W + w];
+            }
+        }
+        tile[jj * CH + (c ^ ((jj / N) & (CH - 1)))] = v;
+    }
+    __syncthreads();
+    const uint32_t * words = reinterpret_cast<const uint32_t *>(tile);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t idx = t + 256 * k, yy = idx / 16, gx = idx % 16;
+        const uint32_t x = X0 + N * gx, y = Y0 + yy;
+        if (x >= A.dw || y >= A.dh)
+            continue;
+        u4v o = { 0, 0, 0, 0 };
+#pragma unroll
+        for (uint32_t q = 0; q < N; ++q) {
+            uint32_t i, j;
+            sourceOf(A, min(x + q, A.dw - 1), y, &i, &j);
+            const uint32_t jj = j - j0, ii = i - i0;
+            const uint32_t chunk = jj * CH + ((ii / N) ^ ((jj / N) & (CH - 1)));
+#pragma unroll
+            for (uint32_t w = 0; w < W; ++w)
+                o[q * W + w] = words[chunk * 4 + (ii % N) * W + w];
+        }
+        uint8_t * d = A.dst + (size_t)y * A.dstPitch + (size_t)x * PX;
+        if (x + N <= A.dw) {
+            __builtin_nontemporal_store(o, reinterpret_cast<u4v *>(d));
+        } else {
+            for (uint32_t q = 0; x + q < A.dw; ++q)
+                for (uint32_t w = 0; w < W; ++w)
+                    reinterpret_cast<uint32_t *>(d)[q * W + w] = o[q * W + w];
+        }
+    }
+}
+
 template <int PX, bool ALIGNED>
 hipError_t launchFor(const TransformArgs & A, hipStream_t stream)
 {
     if (A.angle == 1 || A.angle == 3) {
+        if constexpr ((PX == 4 || PX == 8) && ALIGNED) {
+            if (((uintptr_t)A.dst % 16) == 0 && (A.dstPitch % 16) == 0 && ((uintptr_t)A.src % 4) == 0 && (A.srcPitch % 4) == 0) {
+                constexpr uint32_t TW = 16 * (16 / PX);
+                hipLaunchKernelGGL((transformTransposeWideKernel<PX>), dim3((A.dw + TW - 1) / TW, (A.dh + 63) / 64), dim3(256), 0, stream, A);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((transformTransposeKernel<PX, ALIGNED>), dim3((A.dw + 31) / 32, (A.dh + 31) / 32), dim3(32, 8), 0, stream, A);
     } else if constexpr ((PX == 4 || PX == 8) && ALIGNED) {
         // 16-byte stores need a 16-byte aligned destination; loads only the pixels' own 4-byte alignment
