@@ -528,6 +528,7 @@ avifResult makeAlphaMulPlan(const avifRGBImage * rgb, bool unmultiply, int arith
     out->height = rgb->height;
     out->unmultiply = unmultiply ? 1 : 0;
     out->arith = (arithMode != AVIFHIP_ARITHMETIC_FLOAT && attenuateCovered(rgb)) ? ARITH_LIBYUV : ARITH_FLOAT; // src/alpha.c:163,350
+    out->exactDiv = verifiedIntegerDivisor(out->rgb.maxf) ? 1 : 0;
     return AVIF_RESULT_OK;
 }
 

@@ -182,6 +182,7 @@ struct AlphaMulPlan
     uint32_t width, height;
     int32_t unmultiply;
     int32_t arith; // ARITH_LIBYUV: ARGBAttenuate / ARGBUnattenuate (8-bit RGBA / BGRA)
+    int32_t exactDiv; // the channel maximum is on the verified list (exactdiv.h): "/ maxF" may use the reciprocal form
 };
 
 // arithMode (avifhipArithmetic): which libavif BUILD the result must equal.

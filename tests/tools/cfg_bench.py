@@ -96,6 +96,24 @@ def run(name):
             else:
                 pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_GRAYA)
                 px, bpp, ms = 7680 * 4320, 8.0, time_y2r(pair)
+        elif name in ("premul8", "premul16", "unpremul8"):
+            # avifRGBImagePremultiplyAlpha / UnpremultiplyAlpha in place on a device-resident 8K RGBA image: every pixel read and written once
+            depth = 16 if name == "premul16" else 8
+            rgb = abi.make_rgb(7680, 4320, depth, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=avoid)
+            synth.fill_rgb(rgb, 0x5151)
+            drgb = device.DeviceRGB(rgb, upload=True)
+            fn = lib.avifhipRGBImageUnpremultiplyAlphaAsync if name == "unpremul8" else lib.avifhipRGBImagePremultiplyAlphaAsync
+            for _ in range(300):
+                native.check(fn(drgb.struct, None))
+            native.check(lib.avifhipSynchronize(None))
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    native.check(fn(drgb.struct, None))
+                native.check(lib.avifhipSynchronize(None))
+                best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
+            px, bpp, ms = 7680 * 4320, (8.0 if depth == 8 else 16.0), best
         elif name == "cfg2_rgb":
             # 3-byte pixels (what avifdec hands to its JPEG / opaque PNG writers): 8K 8-bit 4:2:0 -> RGB8, bilinear, 1.5 + 3 B/px
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB)
