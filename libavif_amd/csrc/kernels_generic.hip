@@ -507,11 +507,35 @@ hipError_t launchRgbToYuvGeneric(const RgbToYuvPlan & plan, hipStream_t stream)
     return hipGetLastError();
 }
 
+// ... 8 samples (16 bytes) per lane when the rows allow
+__global__ __launch_bounds__(256) void toF16WideKernel(uint8_t * pixels, uint32_t rowBytes, uint32_t samplesPerRow, uint32_t rows, float multiplier)
+{
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) * 8, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= samplesPerRow || j >= rows)
+        return;
+    uint8_t * p = pixels + (size_t)j * rowBytes + (size_t)i * 2;
+    if (i + 8 > samplesPerRow) {
+        for (uint32_t k = 0; i + k < samplesPerRow; ++k)
+            reinterpret_cast<uint16_t *>(p)[k] = (uint16_t)toHalfBits(reinterpret_cast<uint16_t *>(p)[k], multiplier);
+        return;
+    }
+    u4v v = *reinterpret_cast<const u4v *>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        v[k] = toHalfBits(v[k] & 0xffffu, multiplier) | (toHalfBits(v[k] >> 16, multiplier) << 16);
+    *reinterpret_cast<u4v *>(p) = v;
+}
+
 hipError_t launchToF16Generic(uint8_t * pixels, uint32_t rowBytes, uint32_t samplesPerRow, uint32_t rows, float multiplier, hipStream_t stream)
 {
     if (samplesPerRow == 0 || rows == 0)
         return hipSuccess;
     const dim3 block(64, 4);
+    if (((uintptr_t)pixels % 16) == 0 && (rowBytes % 16) == 0) {
+        hipLaunchKernelGGL(toF16WideKernel, gridFor((samplesPerRow + 7) / 8, rows, block), block, 0, stream, pixels, rowBytes, samplesPerRow, rows, multiplier);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(toF16GenericKernel, gridFor(samplesPerRow, rows, block), block, 0, stream, pixels, rowBytes, samplesPerRow, rows, multiplier);
     return hipGetLastError();
 }
