@@ -37,7 +37,8 @@ inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t 
     const uint32_t bands = (w4 + 256u - 1) / 256u, strips = h2 / 2;
     uint32_t ns = L.pkStrips; // 0 = automatic
     if (ns != 2 && ns != 4)
-        ns = ((uint64_t)bands * ((strips + 3) / 4) * L.count >= 2048) ? 4 : 2; // small jobs: more, smaller waves
+        ns = ((uint64_t)bands * ((strips + 15) / 16) * L.count >= 2048) ? 4 : 2; // 4 strips per wave only if that still makes 2048 workgroups
+                                                                                 // (8 per CU): a 4K frame runs 12 % faster with 2 (9.4 -> 8.2 us)
     uint32_t wxl = L.wavesXLog2 <= 2 ? L.wavesXLog2 : 2;
     while (wxl > 0 && (1u << wxl) > bands)
         --wxl;
