@@ -1375,6 +1375,56 @@ static avifResult alphaMulAsync(avifRGBImage * rgb, bool unmultiply, void * hipS
     return enqueueAlphaMul(plan, pickStream(hipStream));
 }
 
+// In-place passes over host-resident pixels (premultiply / unpremultiply, half float): rows go up, through the kernel and back in bands,
+// so that both directions of the link and the kernel overlap (the same three streams and helper thread as yuvToRgbSync).
+// `launch(view, y0, rows, stream)` enqueues the pass on rows [y0, y0 + rows) of the device copy.
+template <class Launch>
+static avifResult inPlaceBanded(avifRGBImage * rgb, uint32_t pixelRowBytes, Launch launch)
+{
+    avifRGBImage view = *rgb;
+    avifResult r = stagePixels(&view, /*upload=*/false);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    const uint32_t bandRows = bandRowsFor(rgb->width, rgb->height);
+    const bool banded = bandRows < rgb->height;
+    if (banded && !tls.downloader)
+        tls.downloader = new CopyWorker(tls.device, tls.downStream);
+    DrainOnExit drainOnExit = { banded ? tls.downloader : nullptr };
+    int band = 0;
+    for (uint32_t y0 = 0; y0 < rgb->height; y0 += bandRows, ++band) {
+        const uint32_t rows = (y0 + bandRows < rgb->height) ? bandRows : rgb->height - y0;
+        const int e = band % Context::kMaxBands;
+        HIP_TRY(hipMemcpy2DAsync(view.pixels + (size_t)y0 * view.rowBytes, view.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes, rows,
+                                 hipMemcpyHostToDevice, tls.upStream));
+        HIP_TRY(hipEventRecord(tls.bandUp[e], tls.upStream));
+        HIP_TRY(hipStreamWaitEvent(tls.stream, tls.bandUp[e], 0));
+        r = launch(view, y0, rows, tls.stream);
+        if (r != AVIF_RESULT_OK) {
+            (void)hipStreamSynchronize(tls.upStream);
+            (void)hipStreamSynchronize(tls.stream);
+            return r;
+        }
+        HIP_TRY(hipEventRecord(tls.bandDone[e], tls.stream));
+        const CopyWorker::Job job = { tls.bandDone[e], rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, view.pixels + (size_t)y0 * view.rowBytes, view.rowBytes,
+                                      pixelRowBytes, rows };
+        if (banded) {
+            tls.downloader->post(job);
+        } else {
+            HIP_TRY(hipStreamWaitEvent(tls.downStream, job.after, 0));
+            HIP_TRY(hipMemcpy2DAsync(job.dst, job.dstPitch, job.src, job.srcPitch, job.widthBytes, job.rows, hipMemcpyDeviceToHost, tls.downStream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(tls.stream));
+    if (banded) {
+        const hipError_t de = tls.downloader->drain();
+        if (de != hipSuccess)
+            return hipFailed(de, "download of processed rows");
+    } else {
+        HIP_TRY(hipStreamSynchronize(tls.downStream));
+    }
+    return AVIF_RESULT_OK;
+}
+
 static avifResult alphaMulSync(avifRGBImage * rgb, bool unmultiply)
 {
     if (!rgb)
@@ -1386,25 +1436,21 @@ static avifResult alphaMulSync(avifRGBImage * rgb, bool unmultiply)
     r = ensureContext();
     if (r != AVIF_RESULT_OK)
         return r;
-    avifRGBImage view = *rgb;
-    const bool onHost = !isDevicePointer(rgb->pixels);
-    if (onHost) {
-        r = stagePixels(&view, /*upload=*/true);
+    if (isDevicePointer(rgb->pixels)) {
+        r = enqueueAlphaMul(plan, tls.stream);
         if (r != AVIF_RESULT_OK)
             return r;
-        r = makeAlphaMulPlan(&view, unmultiply, effectiveArithmetic(), &plan);
-        if (r != AVIF_RESULT_OK)
-            return r;
+        HIP_TRY(hipStreamSynchronize(tls.stream));
+        return AVIF_RESULT_OK;
     }
-    r = enqueueAlphaMul(plan, tls.stream);
-    if (r != AVIF_RESULT_OK)
-        return r;
-    if (onHost) {
-        const uint32_t widthBytes = rgb->width * rgbPixelBytes(rgb);
-        HIP_TRY(hipMemcpy2DAsync(rgb->pixels, rgb->rowBytes, view.pixels, view.rowBytes, widthBytes, rgb->height, hipMemcpyDeviceToHost, tls.stream));
-    }
-    HIP_TRY(hipStreamSynchronize(tls.stream));
-    return AVIF_RESULT_OK;
+    return inPlaceBanded(rgb, rgb->width * rgbPixelBytes(rgb), [&](const avifRGBImage & view, uint32_t y0, uint32_t rows, hipStream_t stream) -> avifResult {
+        avifRGBImage bandView = view;
+        bandView.pixels = view.pixels + (size_t)y0 * view.rowBytes;
+        bandView.height = rows;
+        AlphaMulPlan bandPlan;
+        const avifResult pr = makeAlphaMulPlan(&bandView, unmultiply, effectiveArithmetic(), &bandPlan);
+        return pr != AVIF_RESULT_OK ? pr : enqueueAlphaMul(bandPlan, stream);
+    });
 }
 
 // in-place integer -> half float, src/reformat.c:1419-1443
@@ -1417,24 +1463,24 @@ extern "C" avifResult avifhipRGBImageToF16(avifRGBImage * rgb)
     avifResult r = ensureContext();
     if (r != AVIF_RESULT_OK)
         return r;
-    avifRGBImage view = *rgb;
-    const bool onHost = !isDevicePointer(rgb->pixels);
-    if (onHost) {
-        r = stagePixels(&view, /*upload=*/true);
-        if (r != AVIF_RESULT_OK)
-            return r;
-    }
     const uint32_t channels = (uint32_t)rgbFormatChannelCount((int)rgb->format);
     const float multiplier = 1.9259299444e-34f * (1.0f / 65535.0f); // src/reformat.c:1411,1429-1430
     tls.lastKernel = "to_f16_generic";
-    const hipError_t e = launchToF16Generic(view.pixels, view.rowBytes, view.width * channels, view.height, multiplier, tls.stream);
-    if (e != hipSuccess)
-        return hipFailed(e, "half-float kernel launch");
-    ++tls.launches;
-    if (onHost)
-        HIP_TRY(hipMemcpy2DAsync(rgb->pixels, rgb->rowBytes, view.pixels, view.rowBytes, (size_t)rgb->width * channels * 2, rgb->height, hipMemcpyDeviceToHost, tls.stream));
-    HIP_TRY(hipStreamSynchronize(tls.stream));
-    return AVIF_RESULT_OK;
+    if (isDevicePointer(rgb->pixels)) {
+        const hipError_t e = launchToF16Generic(rgb->pixels, rgb->rowBytes, rgb->width * channels, rgb->height, multiplier, tls.stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "half-float kernel launch");
+        ++tls.launches;
+        HIP_TRY(hipStreamSynchronize(tls.stream));
+        return AVIF_RESULT_OK;
+    }
+    return inPlaceBanded(rgb, rgb->width * channels * 2, [&](const avifRGBImage & view, uint32_t y0, uint32_t rows, hipStream_t stream) -> avifResult {
+        const hipError_t e = launchToF16Generic(view.pixels + (size_t)y0 * view.rowBytes, view.rowBytes, view.width * channels, rows, multiplier, stream);
+        if (e != hipSuccess)
+            return hipFailed(e, "half-float kernel launch");
+        ++tls.launches;
+        return AVIF_RESULT_OK;
+    });
 }
 
 extern "C" avifResult avifhipRGBImagePremultiplyAlpha(avifRGBImage * rgb)

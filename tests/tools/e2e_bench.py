@@ -70,6 +70,18 @@ def r2y(name, w, h, reps=8):
     row(name, "avifhipImageRGBToYUV (host buffers)", w, h, best, mean, nbytes_yuv(img) + rgb.pixels.nbytes)
 
 
+def premultiply(name, depth, reps=6):
+    """avifRGBImagePremultiplyAlpha in place on a host-resident 8K RGBA image (what the seam-B hook and avifenc --premultiply see)."""
+    rgb = abi.make_rgb(7680, 4320, depth, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+    synth.fill_rgb(rgb, 0x7171)
+
+    def go():
+        native.check(lib.avifhipRGBImagePremultiplyAlpha(rgb.struct))
+
+    best, mean = timeit(go, reps)
+    row(name, "avifhipRGBImagePremultiplyAlpha (host buffer, in place)", 7680, 4320, best, mean, 2 * rgb.pixels.nbytes)
+
+
 def cfg5():
     W, H, TW, TH = 15360, 8640, 1920, 1080
     # (a) 64 separate tile images, one call each
@@ -131,6 +143,10 @@ def seam_b():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["premultiply"]:
+        premultiply("premultiply 8K RGBA8", 8)
+        premultiply("premultiply 8K RGBA16", 16)
+        sys.exit(0)
     y2r("cfg1", 256, 256, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_FULL, 6, 8, up=abi.AVIF_CHROMA_UPSAMPLING_AUTOMATIC, reps=50)
     y2r("cfg2", 7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8)
     y2r("cfg2 at 4K", 3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8)
