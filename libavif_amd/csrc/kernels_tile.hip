@@ -54,6 +54,7 @@ TileKey keyFor(const YuvToRgbPlan & p)
     k.alphaPlane = p.rgb.hasAlpha && !p.rgb.is565 && p.alphaSource == ALPHA_PLANE;
     k.mapped = p.rgb.map.on != 0;
     k.wideDownshift = k.fixedPoint && k.wideYuv && p.fxDownshift != 0;
+    k.attenuate = k.fixedPoint && p.postMul == MUL_MULTIPLY && p.postMulFx && k.nch == 4 && k.alphaPlane && (p.tuning & TUNE_COOPERATIVE) == 0;
     return k;
 }
 
@@ -67,7 +68,7 @@ const char * kernelNameFor(const TileKey & k, uint32_t tuning)
     static thread_local char name[112];
     static const char * subs[] = { "444", "422", "420", "400" };
     // ",pk16": the packed 16-bit kernels (tile_pk_impl.h) serve 8-bit planes of the integer path unless a post-pass follows
-    const bool packed = k.fixedPoint && !k.hasMul && (!k.wideYuv || (tuning & TUNE_COOPERATIVE) == 0);
+    const bool packed = k.fixedPoint && (!k.hasMul || (k.attenuate && !k.mapped)) && (!k.wideYuv || (tuning & TUNE_COOPERATIVE) == 0);
     snprintf(name, sizeof(name), "%s<%s,%s,%s,%s%d%s%s%s%s>", k.fixedPoint ? "yuv2rgb_fixed_tile" : "yuv2rgb_tile", k.wideYuv ? "u16" : "u8", subs[k.sub], k.bilinear ? "bilinear" : "nearest",
              k.gray ? (k.nch == 2 ? "graya" : "gray") : (k.nch == 4 ? "rgba" : (k.nch == 2 ? "rgb565_" : "rgb")), k.wideRgb ? 16 : 8, k.alphaPlane ? ",alpha" : "", k.hasMul ? ",alphamul" : "", packed ? ",pk16" : "", k.mapped ? ",mapped" : "");
     return name;
@@ -247,7 +248,7 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
     const TileKey k = keyFor(plan);
     return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) | ((k.nch == 2 ? 1 : 0) << 10) |
            ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7) | ((k.fixedPoint ? 1 : 0) << 8) | ((k.mapped ? 1 : 0) << 9) |
-           ((k.wideDownshift ? 1 : 0) << 11) | ((k.gray ? 1 : 0) << 12);
+           ((k.wideDownshift ? 1 : 0) << 11) | ((k.gray ? 1 : 0) << 12) | ((k.attenuate ? 1 : 0) << 13);
 }
 
 namespace {
@@ -274,7 +275,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     L.mapped = k.mapped, L.transposed = k.mapped && plan.rgb.map.transposed, L.streamLoads = false;
     decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)A.w4 * A.h2) || (plan.tuning & TUNE_SOLO_ALWAYS));
-    L.pkWide = (plan.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift;
+    L.pkWide = (plan.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift, L.attenuate = k.attenuate;
     hipError_t e = launchFamily(k, L);
     if (e != hipSuccess)
         return e;
@@ -325,7 +326,7 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
         L.streamLoads = atoi(e) != 0;
     decompose(representative.tuning, maxW & ~3u, maxH & ~1u, count, true, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)(maxW & ~3u) * (maxH & ~1u) * count) || (representative.tuning & TUNE_SOLO_ALWAYS));
-    L.pkWide = (representative.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift;
+    L.pkWide = (representative.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift, L.attenuate = k.attenuate;
     // A batch whose bytes exceed the Infinity Cache (256 MB) streams from and to HBM whatever the tile order; the per-XCD chunks, which pay
     // when planes are cache-resident, then only scatter the DRAM accesses: plain raster order (tests/tools/pkbench_wide.hip, 64 tiles of
     // 1080p 10-bit -> RGBA8: 188 -> 175 us)

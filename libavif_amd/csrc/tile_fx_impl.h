@@ -411,6 +411,15 @@ hipError_t launchOneFx(const TileLaunch & L)
     // 8-bit planes without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)
     if constexpr (sizeof(YT) == 1 && !MUL)
         return launchPk<SUB, BIL, NCH, APLANE>(L);
+    // premultiplied outputs (ARGBAttenuate after the conversion): the packed kernels with the pass fused in; unattenuate stays here
+    if constexpr (MUL) {
+        if (L.attenuate && !L.mapped) {
+            if constexpr (sizeof(YT) == 1)
+                return launchPkAttenuate<SUB, BIL, WIDE_NONE>(L);
+            else if (L.pkWide)
+                return L.wideDownshift ? launchPkAttenuate<SUB, BIL, WIDE_DOWNSHIFT>(L) : launchPkAttenuate<SUB, BIL, WIDE_NATIVE>(L);
+        }
+    }
     // 10- / 12-bit planes without a post-pass: the same kernels behind a front end for 16-bit containers
     if constexpr (sizeof(YT) == 2 && !MUL) {
         if (L.pkWide)

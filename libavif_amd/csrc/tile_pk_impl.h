@@ -299,7 +299,9 @@ __device__ __forceinline__ unsigned pkAlpha(const TileArgs & A, typename PkTypes
 }
 
 // `xchg` / `segBytes`: 3-byte pixels only -- the wave's exchange buffer and the bytes of its row segment that exist (storeRowContiguous)
-template <int SUB, int NCH, bool APLANE, bool MAPPED>
+// ATT: libyuv's ARGBAttenuate on the three colour bytes, (c * a + 255) >> 8 (appendix D.4; what libavif runs after the conversion when the
+// pixels are to be premultiplied, src/reformat.c:1574-1585 -> src/alpha.c:163) -- on pixel pairs, before the bytes are packed.
+template <int SUB, int NCH, bool APLANE, bool MAPPED, bool ATT = false>
 __device__ __forceinline__ void pkRow(const TileArgs & A, const unsigned Y[2], unsigned araw, const unsigned Up[2], const unsigned Vp[2], uint32_t off, bool laneValid,
                                       unsigned out[4], WideRowExchange * xchg, uint32_t segBytes)
 {
@@ -322,6 +324,17 @@ __device__ __forceinline__ void pkRow(const TileArgs & A, const unsigned Y[2], u
             X = satPkU8(pkAshr6(X));
             G = satPkU8(pkAshr6(G));
             Z = satPkU8(pkAshr6(Z));
+        }
+        if constexpr (ATT) {
+            // colour bytes (c0 c1 . .) and alpha bytes spread to 16-bit pairs, (c * a + 255) >> 8 per half (65280 at most), bytes gathered again
+            const unsigned Ap = __builtin_amdgcn_perm(0u, araw, p ? 0x0c030c02u : 0x0c010c00u);
+            auto att = [&](unsigned c) {
+                unsigned d;
+                const unsigned c2 = __builtin_amdgcn_perm(0u, c, 0x0c010c00u);
+                asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(c2), "v"(Ap), "s"(0x00ff00ffu));
+                return __builtin_amdgcn_perm(0u, d, 0x0c0c0301u); // byte 1 of each half
+            };
+            X = att(X), G = att(G), Z = att(Z);
         }
         if constexpr (NCH == 2) {
             // RGB565 (I420ToRGB565Matrix / I422ToRGB565Matrix: b >> 3 | (g >> 2) << 5 | (r >> 3) << 11, src/reformat.c:619): both pixels of
@@ -653,7 +666,7 @@ __device__ __forceinline__ void pkTransposeStore(const TileArgs & A, const unsig
 }
 
 // ---- filter, matrix, stores of a wave tile ----
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool ATT = false>
 __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, const unsigned * ring, WideRowExchange * xchg,
                                           unsigned * xposeTile, uint32_t wy)
 {
@@ -756,7 +769,7 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
                 pkLuma<WIDE>(A, R.y[2 * s + r], Y);
                 if constexpr (APLANE)
                     araw = pkAlpha<WIDE>(A, R.a[2 * s + r]);
-                pkRow<SUB, NCH, APLANE, MAPPED>(A, Y, araw, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid, px, xchg, segBytes);
+                pkRow<SUB, NCH, APLANE, MAPPED, ATT>(A, Y, araw, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid, px, xchg, segBytes);
                 if constexpr (MAPPED) {
                     if (A.map.transposed) { // wave-uniform
 #pragma unroll
@@ -804,7 +817,7 @@ struct PkLds
     static constexpr int kWords = kPlain > kXposeWords ? kPlain : kXposeWords;
 };
 
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM, bool ATT = false>
 __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g, unsigned * lds)
 {
     typedef PkRaw<SUB, BIL, APLANE, NSW, WIDE> RawT;
@@ -839,7 +852,7 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     pkStage<SUB, BIL, APLANE, NSW, WIDE>(A, w, shared, raw, ring);
     if (!rowsValid && !xpose)
         return;
-    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE>(A, w, raw, ring, xchg, xpose ? lds : nullptr, wy);
+    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, ATT>(A, w, raw, ring, xchg, xpose ? lds : nullptr, wy);
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
@@ -856,6 +869,44 @@ __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __
     extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
     pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(job, g, lds);
+}
+
+// ... with the attenuate pass of premultiplied outputs fused in (alpha from the plane, 4-byte pixels, rows)
+template <int SUB, bool BIL, int NSW, int WIDE>
+__global__ __launch_bounds__(256) void yuvToRgbPkAttenuateKernel(TileArgs A, PkGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, true>(A, g, lds);
+}
+template <int SUB, bool BIL, int NSW, int WIDE>
+__global__ __launch_bounds__(256) void yuvToRgbPkAttenuateBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    const TileArgs job = table[blockIdx.z];
+    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, true>(job, g, lds);
+}
+
+template <int SUB, bool BIL, int WIDE>
+hipError_t launchPkAttenuate(const TileLaunch & L)
+{
+    uint32_t nsw, blocks;
+    PkGeom g;
+    pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
+    const dim3 block(kLanesX, kWavesPerBlock);
+    const dim3 grid(blocks, 1, L.count);
+    const uint32_t lds4 = 4u * (uint32_t)PkLds<SUB, BIL, 4, 4, false>::kPlain, lds2 = 4u * (uint32_t)PkLds<SUB, BIL, 4, 2, false>::kPlain;
+    if (L.table) {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbPkAttenuateBatchKernel<SUB, BIL, 4, WIDE>), grid, block, lds4, L.stream, L.table, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbPkAttenuateBatchKernel<SUB, BIL, 2, WIDE>), grid, block, lds2, L.stream, L.table, g);
+    } else {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbPkAttenuateKernel<SUB, BIL, 4, WIDE>), grid, block, lds4, L.stream, *L.args, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbPkAttenuateKernel<SUB, BIL, 2, WIDE>), grid, block, lds2, L.stream, *L.args, g);
+    }
+    return hipGetLastError();
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, bool MAPPED, int WIDE = WIDE_NONE>

@@ -205,6 +205,7 @@ struct TileKey
     bool hasMul;
     bool mapped;     // stores go through a PixelMap (fused crop / rotate / mirror)
     bool wideDownshift; // integer path on 16-bit containers: samples are reduced to 8 bits first (no high-bit-depth libyuv entry)
+    bool attenuate;     // integer path with libyuv's ARGBAttenuate after the conversion (premultiplied outputs): fused into the packed kernels
     bool gray;          // GRAY / GRAYA / AGRAY outputs: nch = 1 or 2, luma only
 };
 
@@ -223,6 +224,7 @@ struct TileLaunch
     uint32_t chunkRows;     // tile rows per XCD chunk, 0 = plain raster order
     bool mapped;            // stores go through the jobs' PixelMap
     bool transposed;        // ... which turns rows into columns (quarter turns)
+    bool attenuate;         // TileKey::attenuate
     bool streamLoads;       // batches: the jobs' planes exceed what the Infinity Cache can hold -- luma / alpha rows as streaming loads
     bool solo;              // fp32 / 10-12-bit integer families: the wave-private kernels instead of the cooperative runs
     bool pkWide;            // 10-12-bit integer family without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)

@@ -73,6 +73,31 @@ def test_wide_planes_run_in_the_packed_kernels(hip_auto_arithmetic):
     assert not [k for k in kernels if k.startswith("yuv2rgb_fixed_tile<u16") and "alphamul" not in k and "pk16" not in k], kernels
 
 
+def test_premultiplied_outputs_fuse_the_attenuate_pass(hip_auto_arithmetic):
+    """Images with an alpha plane into premultiplied RGBA / BGRA (Android's bitmaps): libyuv's conversion followed by ARGBAttenuate
+    (src/reformat.c:1574-1585 -> src/alpha.c:163), in one pass of the packed kernels -- 8-, 10- and 12-bit planes, every chroma layout."""
+    import itertools
+    cases = []
+    for (w, h), depth, yf, up, fmt in itertools.product(TILED, (8, 10, 12), (1, 2, 3, 4), (3, 4), (1, 4)):
+        cases.append(H.Y2RCase(w, h, yuv_depth=depth, yuv_format=yf, upsampling=up, rgb_format=fmt, rgb_depth=8, alpha=True, rgb_premultiplied=True, avoid_libyuv=False,
+                               matrix=(1, 6, 9)[(w + depth + yf) % 3], yuv_range=(w + yf + fmt) % 2, row_pad=64 if (h + fmt) % 2 else 0,
+                               seed=(w * 17 + depth * 11 + yf * 5 + up * 3 + fmt) | 1))
+    kernels = {}
+    bad = []
+    o = H.oracle_libyuv_backend()
+    for be in (H.HipDeviceBackend(), H.hip_host_backend()):
+        for c in cases:
+            ro, po = H.run_y2r(o, c)
+            rh, ph = H.run_y2r(be, c)
+            k = native.last_kernel()
+            kernels[k] = kernels.get(k, 0) + 1
+            if ro != rh or not np.array_equal(po, ph):
+                bad.append(f"{c.ident()} [{k}]: results {ro}/{rh}" + ("" if ro != rh else " " + H.describe_diff(po, ph)))
+    assert not bad, f"{len(bad)} of {2 * len(cases)} cases differ:\n" + "\n".join(bad[:25])
+    fused = sum(v for k, v in kernels.items() if "alphamul,pk16" in k)
+    assert fused > 0.6 * 2 * len(cases), kernels
+
+
 def test_wide_planes_cooperative_kernels_still_exact(hip_auto_arithmetic):
     """The round-1 kernels of the 10/12-bit integer family stay selectable for A/B runs (plan.h TUNE_COOPERATIVE): same bytes."""
     hip_auto_arithmetic.avifhipSetTuning(5)

@@ -114,6 +114,11 @@ def run(name):
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
             px, bpp, ms = 7680 * 4320, (8.0 if depth == 8 else 16.0), best
+        elif name in ("cfg2_alpha", "cfg2_premul"):
+            # images with an alpha plane: 8K 8-bit 4:2:0 + A -> RGBA8 bilinear, straight or premultiplied (what Android's bitmaps take:
+            # android_jni/.../libavif_jni.cc); 1.5 + 1 + 4 B/px
+            pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, alpha=True, premult=(name == "cfg2_premul"), avoid=avoid)
+            px, bpp, ms = 7680 * 4320, 6.5, time_y2r(pair)
         elif name == "cfg2_rgb":
             # 3-byte pixels (what avifdec hands to its JPEG / opaque PNG writers): 8K 8-bit 4:2:0 -> RGB8, bilinear, 1.5 + 3 B/px
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB)
