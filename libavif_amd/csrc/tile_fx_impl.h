@@ -15,7 +15,10 @@
 //     integer clamps, byte packing.
 // Scope: 8-bit RGB / BGR / RGBA / BGRA / ARGB / ABGR outputs from 8-bit planes, 10-bit planes through the I010 family or
 // any depth through the downshift route; alpha opaque / from the plane (shift or fp32 rescale); ARGBAttenuate /
-// ARGBUnattenuate post-pass.  RGB565 and the fp32 post-pass of ARGB/ABGR stay with the universal kernel.
+// ARGBUnattenuate post-pass.
+// Since round 2 these kernels are the fall-back of the packed 16-bit ones (tile_pk_impl.h, dispatched from launchOneFx below):
+// what they still serve by default is ARGBUnattenuate, and the attenuate pass behind a pixel map; with TUNE_COOPERATIVE they take
+// the 10/12-bit planes back for A/B runs.
 #pragma once
 
 #include "pixel_fixed.h"

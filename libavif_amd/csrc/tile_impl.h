@@ -3,11 +3,14 @@
 // Scope: matrix-coefficient ("normal YUV") conversions into interleaved 3- or 4-channel RGB at 8-bit or 16-bit
 // containers, from 8-bit or 16-bit-container 4:4:4 / 4:2:2 / 4:2:0 / 4:0:0 planes, nearest or bilinear chroma
 // upsampling, alpha fill / copy / rescale and both flavours of alpha (un)premultiply -- every BASELINE
-// configuration and what avifdec asks for.  Everything else (gray outputs, RGB565, half float, identity / YCgCo
-// matrices, unaligned user buffers, divisors off the verified list, the <= 3 columns and <= 1 row that do not
-// fill a 4x2 pixel group) is served by kernels_generic.hip.
+// configuration and what avifdec asks for -- plus half-float outputs, gray layouts (1 or 2 channels from the 4:0:0
+// instantiations) and the identity matrix (round 2).  Everything else (the YCgCo family, destinations whose alpha
+// bytes must stay untouched, unaligned user buffers, divisors off the verified list, the <= 3 columns and <= 1 row
+// that do not fill a 4x2 pixel group) is served by kernels_generic.hip; RGB565 by the packed kernels (tile_pk_impl.h).
 //
-// Structure (wave = 64 lanes, workgroup = 4 waves, one workgroup per tile of 256 x (8*NS) pixels):
+// Two structures share the arithmetic (computeTile).  Cooperative runs, round 1 (wave = 64 lanes, workgroup = 4 waves, one
+// workgroup per tile of 256 x (8*NS) pixels, described below), kept for staged 16-bit planes and small frames; wave-private tiles
+// (runSolo, the packed kernels' geometry: tile_geom.h) wherever an A/B run favoured them (kernels_tile.hip soloPays):
 //   * wave w owns the NS vertically consecutive strips (256 x 2 pixels) w*NS .. w*NS+NS-1; lane tx owns 4 consecutive
 //     pixels of both rows of each strip: one 4-sample vector load per plane and row (row-coalesced), one 16-byte
 //     store per row for RGBA8 (1 KiB contiguous per wave instruction);
