@@ -28,6 +28,7 @@ def host():
     lib = C.CDLL(os.fspath(SO))
     ip = C.POINTER(C.c_int)
     lib.hostScaleSchedule.restype, lib.hostScaleSchedule.argtypes = C.c_int, [C.c_int] * 5 + [ip] * 5
+    lib.hostScaleSpecialisation.restype, lib.hostScaleSpecialisation.argtypes = C.c_int, [C.c_int] * 5
     lib.hostTransferFunction.restype, lib.hostTransferFunction.argtypes = C.c_float, [C.c_int, C.c_int, C.c_float]
     lib.hostPrimariesMatrix.restype, lib.hostPrimariesMatrix.argtypes = C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double * 9)]
     lib.hostDoubleToSignedFraction.restype, lib.hostDoubleToSignedFraction.argtypes = C.c_int, [C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
@@ -160,3 +161,48 @@ def test_gain_map_computation_step_tables(host):
         cut = (hi - lo) * rnd.uniform(0, 0.2)
         assert host.hostCheckCodeSteps(sign, min_r, max_r, lo + cut, hi - cut * rnd.uniform(0, 1), rnd.choice((1.0, 1.0, 0.5, 2.2)), rnd.choice((8, 10, 12)), 20000, k) == 0
     assert with_buckets > 30
+
+
+def test_scale_specialisations_follow_from_the_schedules(host):
+    """The doubling kernel and the exact-box kernel ignore the schedule tables: they may only be chosen when the tables say exactly what the
+    kernels compute -- near = k >> 1 with the far neighbour one step away, clamped, the LAST column's far neighbour itself (upsample2Axis);
+    boxes of N x N on the N-grid -- and for 8-bit samples only (the 16-bit dispatch order differs)."""
+    rnd = random.Random(11)
+    seen = {"doubling": 0, 4: 0, 8: 0, "none": 0}
+    for k in range(6000):
+        kind = k % 4
+        if kind == 0:
+            sw, sh = rnd.randint(1, 700), rnd.randint(1, 90)
+            dw, dh = max(1, 2 * sw - rnd.choice((0, 1))), max(1, 2 * sh - rnd.choice((0, 1)))
+        elif kind == 1:
+            n = rnd.choice((4, 8))
+            dw, dh = rnd.randint(1, 300), rnd.randint(1, 60)
+            sw, sh = n * dw, n * dh
+        elif kind == 2:
+            n = rnd.choice((3, 4, 5, 8))
+            dw, dh = rnd.randint(1, 200), rnd.randint(1, 40)
+            sw, sh = n * dw + rnd.choice((0, 0, 1, 3)), n * dh + rnd.choice((0, 0, 2))
+        else:
+            sw, sh, dw, dh = rnd.randint(1, 400), rnd.randint(1, 60), rnd.randint(1, 400), rnd.randint(1, 60)
+        for wide in (0, 1):
+            a = [(C.c_int * n_)() for n_ in (dw, dw, dh, dh, dh)]
+            mode = host.hostScaleSchedule(sw, sh, dw, dh, wide, *a)
+            spec = host.hostScaleSpecialisation(sw, sh, dw, dh, wide)
+            doubling, box = spec & 1, spec >> 8
+            colA, colB, rowA, rowB = (list(x) for x in a[:4])
+            if doubling:
+                assert mode == 4 and not box
+                assert colA == [i >> 1 for i in range(dw)] and rowA == [j >> 1 for j in range(dh)]
+                assert colB == [(i >> 1) if i == dw - 1 else min(max((i >> 1) + (1 if i & 1 else -1), 0), sw - 1) for i in range(dw)], (sw, dw)
+                assert rowB == [min(max((j >> 1) + (1 if j & 1 else -1), 0), sh - 1) for j in range(dh)], (sh, dh)
+                seen["doubling"] += 1
+            elif box:
+                assert mode == 3 and not wide and box in (4, 8) and sw == box * dw and sh == box * dh
+                assert colA == [box * i for i in range(dw)] and colB == [box] * dw and rowA == [box * j for j in range(dh)] and rowB == [box] * dh
+                seen[box] += 1
+            else:
+                seen["none"] += 1
+                if not wide and mode == 3 and dw and sw in (4 * dw, 8 * dw) and sh * dw == sw * dh:
+                    # an exact 4x / 8x reduction that reached the box filter must have been recognised
+                    assert colB != [sw // dw] * dw or rowB != [sh // dh] * dh or colA != [sw // dw * i for i in range(dw)], (sw, sh, dw, dh)
+    assert seen["doubling"] > 500 and seen[4] > 100 and seen[8] > 100 and seen["none"] > 2000, seen

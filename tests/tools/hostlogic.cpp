@@ -19,6 +19,13 @@ int hostScaleSchedule(int srcW, int srcH, int dstW, int dstH, int wide, int * co
     return S.mode;
 }
 
+// which specialised kernel the schedule qualifies for: bit 0 = doubling kernel (2x on both axes), bits 8.. = exact-box size N (0, 4, 8)
+int hostScaleSpecialisation(int srcW, int srcH, int dstW, int dstH, int wide)
+{
+    const ScaleSchedule S = makeScaleSchedule(srcW, srcH, dstW, dstH, wide != 0);
+    return (S.doubling ? 1 : 0) | (S.exactBox << 8);
+}
+
 float hostTransferFunction(int tc, int direction, float v)
 {
     return direction ? gainMapToGamma(tc, v) : gainMapToLinear(tc, v);
