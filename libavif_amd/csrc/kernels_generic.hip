@@ -5,6 +5,7 @@
 // configurations and must agree with these bit for bit.
 #include <hip/hip_runtime.h>
 
+#include "exactdiv.h"
 #include "kernels.h"
 #include "pixel_fixed.h"
 #include "pixel_generic.h"
@@ -357,9 +358,9 @@ __global__ __launch_bounds__(256) void alphaMulGenericKernel(AlphaMulPlan p)
     }
 }
 
-// ... for 4-channel pixels in 16-byte aligned rows: a lane owns 16 bytes (4 pixels of 8-bit channels, 2 of 16-bit ones), one load and
-// one store per lane instead of four byte loads and three byte stores per pixel.  Same per-channel arithmetic; the alpha channel's
-// bits pass through untouched.
+// ... for 4-channel pixels in 16-byte aligned rows: lanes work on groups of 16 bytes (4 pixels of 8-bit channels, 2 of 16-bit ones), one
+// load and one store per group instead of four byte loads and three byte stores per pixel.  Same results per channel; the alpha
+// channel's bits pass through untouched.
 // premultiply with "/ maxF" in the verified reciprocal form: floorf(c * a / maxF + 0.5f); the operand is never negative, so the truncating
 // conversion is the floor; a == 0 needs no special case; a >= max leaves the channel untouched (src/alpha.c:180-192)
 __device__ __forceinline__ unsigned premultiplyExact(unsigned c, unsigned a, unsigned maxv, RcpHL rcpMax)
@@ -368,58 +369,122 @@ __device__ __forceinline__ unsigned premultiplyExact(unsigned c, unsigned a, uns
     return (a >= maxv) ? c : m;
 }
 
-template <typename CT>
-__global__ __launch_bounds__(256) void alphaMulWideKernel(AlphaMulPlan p)
+// which arithmetic an instantiation of the 16-byte kernel carries (one each: the five of them in one body made 12,000 instructions)
+enum { AMUL_FX_MULTIPLY = 0, AMUL_FX_UNMULTIPLY, AMUL_EXACT_MULTIPLY, AMUL_IEEE_MULTIPLY, AMUL_IEEE_UNMULTIPLY, AMUL_INT_UNMULTIPLY };
+
+// what a pixel's alpha contributes to its three colour channels
+struct AlphaOperand
 {
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    constexpr uint32_t N = (sizeof(CT) == 1) ? 4 : 2; // pixels per lane
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
-    const uint32_t i = g * N;
-    if (i >= p.width || j >= p.height)
-        return;
-    const RgbSide & o = p.rgb;
-    uint8_t * px = o.pixels + (size_t)j * o.rowBytes + (size_t)i * o.pixBytes;
-    const int mode = p.unmultiply ? MUL_UNMULTIPLY : MUL_MULTIPLY;
-    const uint32_t slotA = (uint32_t)o.offA / sizeof(CT); // 0 or 3
-    if (i + N > p.width) { // the row's last, partial group
-        for (uint32_t q = 0; i + q < p.width; ++q) {
-            CT * c = reinterpret_cast<CT *>(px) + 4 * q;
-            const unsigned a = c[slotA];
-            for (uint32_t k = 0; k < 4; ++k)
-                if (k != slotA)
-                    c[k] = (CT)((p.arith == ARITH_LIBYUV) ? fxAlphaMul(c[k], a, mode) : alphaMulInt(c[k], a, (unsigned)o.maxv, o.maxf, mode));
-        }
-        return;
+    unsigned a;
+    float rcp2a; // AMUL_INT_UNMULTIPLY: an estimate of 1 / (2a) (exactdiv.h: unpremultiplyByEstimate)
+    unsigned ia; // AMUL_FX_UNMULTIPLY: ARGBUnattenuate's 8.8 reciprocal of a (pixel_fixed.h: fxUnattenuate)
+};
+template <int VARIANT>
+__device__ __forceinline__ AlphaOperand alphaOperand(unsigned a)
+{
+    AlphaOperand A = { a, 0.0f, 0u };
+    if constexpr (VARIANT == AMUL_INT_UNMULTIPLY)
+        A.rcp2a = __builtin_amdgcn_rcpf((float)(2u * (a ? a : 1u)));
+    if constexpr (VARIANT == AMUL_FX_UNMULTIPLY) {
+        const unsigned d = (a & 0xffu) ? (a & 0xffu) : 1u;
+        const unsigned q = quotient65536ByEstimate(d, __builtin_amdgcn_rcpf((float)d));
+        A.ia = (a == 0u) ? 0u : (a == 1u) ? 0xffffu : (a == 255u) ? 0x100u : q;
     }
-    u4v v = *reinterpret_cast<const u4v *>(px);
+    return A;
+}
+
+template <int VARIANT>
+__device__ __forceinline__ unsigned alphaMulChannel(const RgbSide & o, unsigned c, const AlphaOperand & A, unsigned maxv, float maxf)
+{
+    if constexpr (VARIANT == AMUL_FX_MULTIPLY) {
+        return fxAlphaMul(c, A.a, MUL_MULTIPLY);
+    } else if constexpr (VARIANT == AMUL_FX_UNMULTIPLY) {
+        const unsigned t = (((c & 0xffu) * 0x101u) * (A.ia & 0xffffu)) >> 16; // fxUnattenuate with the pixel's reciprocal formed once
+        return (t >= 0x8000u) ? 0u : min(t, 255u);
+    } else if constexpr (VARIANT == AMUL_EXACT_MULTIPLY) {
+        return premultiplyExact(c, A.a, maxv, o.rcpMax);
+    } else if constexpr (VARIANT == AMUL_INT_UNMULTIPLY) {
+        const unsigned q = unpremultiplyByEstimate(c, A.a ? A.a : 1u, maxv, A.rcp2a);
+        return (A.a >= maxv) ? c : (A.a == 0u) ? 0u : q; // src/alpha.c:367-373
+    } else {
+        return alphaMulInt(c, A.a, maxv, maxf, VARIANT == AMUL_IEEE_MULTIPLY ? MUL_MULTIPLY : MUL_UNMULTIPLY);
+    }
+}
+
+// the N pixels of one 16-byte group; alpha is channel 0 (alphaFirst) or channel 3, channels 1 and 2 are colours either way
+template <typename CT, int VARIANT>
+__device__ __forceinline__ void alphaMulGroup(const AlphaMulPlan & p, unsigned (&v)[4], bool alphaFirst)
+{
+    const RgbSide & o = p.rgb;
+    constexpr uint32_t N = (sizeof(CT) == 1) ? 4 : 2; // pixels per group
 #pragma unroll
     for (uint32_t q = 0; q < N; ++q) {
         if constexpr (sizeof(CT) == 1) {
             const unsigned w = v[q];
-            const unsigned a = (w >> (8 * slotA)) & 0xffu;
-            unsigned r = w & (0xffu << (8 * slotA));
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                const unsigned c = (w >> (8 * k)) & 0xffu;
-                const unsigned m = (p.arith == ARITH_LIBYUV)                 ? fxAlphaMul(c, a, mode)
-                                   : (mode == MUL_MULTIPLY && p.exactDiv) ? premultiplyExact(c, a, 255u, o.rcpMax)
-                                                                          : alphaMulInt(c, a, 255u, 255.0f, mode);
-                r |= (k == slotA) ? 0u : (m << (8 * k));
-            }
-            v[q] = r;
+            const unsigned b0 = w & 0xffu, b3 = w >> 24;
+            const AlphaOperand A = alphaOperand<VARIANT>(alphaFirst ? b0 : b3);
+            const unsigned m1 = alphaMulChannel<VARIANT>(o, (w >> 8) & 0xffu, A, 255u, 255.0f);
+            const unsigned m2 = alphaMulChannel<VARIANT>(o, (w >> 16) & 0xffu, A, 255u, 255.0f);
+            const unsigned mx = alphaMulChannel<VARIANT>(o, alphaFirst ? b3 : b0, A, 255u, 255.0f); // the colour at the other end
+            v[q] = (alphaFirst ? (b0 | (mx << 24)) : (mx | (b3 << 24))) | (m1 << 8) | (m2 << 16);
         } else {
             const unsigned lo = v[2 * q], hi = v[2 * q + 1];
-            unsigned c[4] = { lo & 0xffffu, lo >> 16, hi & 0xffffu, hi >> 16 };
-            const unsigned a = c[slotA];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k)
-                c[k] = (k == slotA) ? c[k]
-                                    : (mode == MUL_MULTIPLY && p.exactDiv) ? premultiplyExact(c[k], a, (unsigned)o.maxv, o.rcpMax)
-                                                                           : alphaMulInt(c[k], a, (unsigned)o.maxv, o.maxf, mode);
-            v[2 * q] = c[0] | (c[1] << 16), v[2 * q + 1] = c[2] | (c[3] << 16);
+            const unsigned c0 = lo & 0xffffu, c3 = hi >> 16;
+            const AlphaOperand A = alphaOperand<VARIANT>(alphaFirst ? c0 : c3);
+            const unsigned m1 = alphaMulChannel<VARIANT>(o, lo >> 16, A, (unsigned)o.maxv, o.maxf);
+            const unsigned m2 = alphaMulChannel<VARIANT>(o, hi & 0xffffu, A, (unsigned)o.maxv, o.maxf);
+            const unsigned mx = alphaMulChannel<VARIANT>(o, alphaFirst ? c3 : c0, A, (unsigned)o.maxv, o.maxf);
+            v[2 * q] = (alphaFirst ? c0 : mx) | (m1 << 16), v[2 * q + 1] = m2 | ((alphaFirst ? mx : c3) << 16);
         }
     }
-    *reinterpret_cast<u4v *>(px) = v;
+}
+
+// A lane owns kAlphaMulGroups groups of one row, 64 groups apart (every load and store instruction of the wave covers 1 KiB of the row),
+// and requests all of them before the arithmetic starts: the divide sequences of the un-premultiply direction are long enough that
+// one 16-byte request per lane left the memory system idle most of the time.
+constexpr uint32_t kAlphaMulGroups = 4;
+
+template <typename CT, int VARIANT>
+__global__ __launch_bounds__(256) void alphaMulWideKernel(AlphaMulPlan p)
+{
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    constexpr uint32_t N = (sizeof(CT) == 1) ? 4 : 2; // pixels per group
+    constexpr uint32_t G = kAlphaMulGroups;
+    const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (j >= p.height)
+        return;
+    const RgbSide & o = p.rgb;
+    uint8_t * row = o.pixels + (size_t)j * o.rowBytes;
+    const uint32_t g0 = blockIdx.x * (64u * G) + threadIdx.x;
+    const uint32_t slotA = (uint32_t)o.offA / sizeof(CT); // 0 or 3
+    u4v in[G];
+#pragma unroll
+    for (uint32_t k = 0; k < G; ++k) {
+        const uint32_t i = (g0 + 64u * k) * N;
+        in[k] = u4v { 0u, 0u, 0u, 0u };
+        if (i + N <= p.width)
+            in[k] = *reinterpret_cast<const u4v *>(row + (size_t)(g0 + 64u * k) * 16u);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < G; ++k) {
+        const uint32_t i = (g0 + 64u * k) * N;
+        uint8_t * px = row + (size_t)(g0 + 64u * k) * 16u;
+        if (i + N <= p.width) {
+            unsigned v[4] = { in[k].x, in[k].y, in[k].z, in[k].w };
+            alphaMulGroup<CT, VARIANT>(p, v, slotA == 0);
+            *reinterpret_cast<u4v *>(px) = u4v { v[0], v[1], v[2], v[3] };
+        } else if (i < p.width) { // the row's last, partial group: the plain forms of the same results
+            constexpr int kEdge = (VARIANT == AMUL_EXACT_MULTIPLY) ? (int)AMUL_IEEE_MULTIPLY : (VARIANT == AMUL_INT_UNMULTIPLY) ? (int)AMUL_IEEE_UNMULTIPLY : VARIANT;
+            for (uint32_t q = 0; i + q < p.width; ++q) {
+                CT * c = reinterpret_cast<CT *>(px) + 4 * q;
+                const unsigned a = c[slotA];
+                for (uint32_t ch = 0; ch < 4; ++ch)
+                    if (ch != slotA)
+                        c[ch] = (VARIANT == AMUL_FX_UNMULTIPLY) ? (CT)fxAlphaMul(c[ch], a, MUL_UNMULTIPLY)
+                                                                : (CT)alphaMulChannel<kEdge>(o, c[ch], alphaOperand<kEdge>(a), (unsigned)o.maxv, o.maxf);
+            }
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -548,10 +613,30 @@ hipError_t launchAlphaMulGeneric(const AlphaMulPlan & plan, hipStream_t stream)
     const RgbSide & o = plan.rgb;
     const bool fourChannels = !o.isGray && !o.is565 && o.hasAlpha && o.pixBytes == 4 * o.chanBytes;
     if (fourChannels && ((uintptr_t)o.pixels % 16) == 0 && (o.rowBytes % 16) == 0) {
-        if (o.chanBytes == 1)
-            hipLaunchKernelGGL(alphaMulWideKernel<uint8_t>, gridFor((plan.width + 3) / 4, plan.height, block), block, 0, stream, plan);
-        else
-            hipLaunchKernelGGL(alphaMulWideKernel<uint16_t>, gridFor((plan.width + 1) / 2, plan.height, block), block, 0, stream, plan);
+        const uint32_t groups = (o.chanBytes == 1) ? (plan.width + 3) / 4 : (plan.width + 1) / 2;
+        const dim3 grid = gridFor((groups + kAlphaMulGroups - 1) / kAlphaMulGroups, plan.height, block);
+        const int variant = (plan.arith == ARITH_LIBYUV) ? (plan.unmultiply ? AMUL_FX_UNMULTIPLY : AMUL_FX_MULTIPLY)
+                            : plan.unmultiply            ? (unpremultiplyIntegerCovers(o.maxv) ? AMUL_INT_UNMULTIPLY : AMUL_IEEE_UNMULTIPLY)
+                            : plan.exactDiv              ? AMUL_EXACT_MULTIPLY
+                                                         : AMUL_IEEE_MULTIPLY;
+        if (o.chanBytes == 1) {
+            switch (variant) {
+                case AMUL_FX_MULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_FX_MULTIPLY>), grid, block, 0, stream, plan); break;
+                case AMUL_FX_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_FX_UNMULTIPLY>), grid, block, 0, stream, plan); break;
+                case AMUL_EXACT_MULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_EXACT_MULTIPLY>), grid, block, 0, stream, plan); break;
+                case AMUL_IEEE_MULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_IEEE_MULTIPLY>), grid, block, 0, stream, plan); break;
+                case AMUL_INT_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_INT_UNMULTIPLY>), grid, block, 0, stream, plan); break;
+                default: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_IEEE_UNMULTIPLY>), grid, block, 0, stream, plan); break;
+            }
+        } else {
+            switch (variant) { // (the fixed-point arithmetic is 8-bit only: plan.cpp)
+                case AMUL_EXACT_MULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint16_t, AMUL_EXACT_MULTIPLY>), grid, block, 0, stream, plan); break;
+                case AMUL_IEEE_MULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint16_t, AMUL_IEEE_MULTIPLY>), grid, block, 0, stream, plan); break;
+                case AMUL_IEEE_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint16_t, AMUL_IEEE_UNMULTIPLY>), grid, block, 0, stream, plan); break;
+                case AMUL_INT_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint16_t, AMUL_INT_UNMULTIPLY>), grid, block, 0, stream, plan); break;
+                default: hipLaunchKernelGGL(alphaMulGenericKernel, gridFor(plan.width, plan.height, block), block, 0, stream, plan); break;
+            }
+        }
         return hipGetLastError();
     }
     hipLaunchKernelGGL(alphaMulGenericKernel, gridFor(plan.width, plan.height, block), block, 0, stream, plan);

@@ -28,3 +28,15 @@ def test_every_listed_divisor_is_exact(tmp_path):
     assert proc.returncode == 0, proc.stdout[-2000:]
     assert len(lines) == 15 + 12 + 28
     assert all(line.endswith("mismatches=0") for line in lines), proc.stdout
+
+
+def test_integer_unpremultiply_equals_the_float_expression(tmp_path):
+    """exactdiv.h: unpremultiplyByEstimate / quotient65536ByEstimate, every operand pair, reciprocal estimates off by up to 2 ulp."""
+    exe = tmp_path / "verify_unpremultiply_integer"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", os.fspath(ROOT / "libavif_amd" / "csrc"),
+                    os.fspath(ROOT / "tests" / "tools" / "verify_unpremultiply_integer.cpp"), "-o", os.fspath(exe)], check=True)
+    proc = subprocess.run([os.fspath(exe)], capture_output=True, text=True)
+    lines = proc.stdout.strip().splitlines()
+    assert proc.returncode == 0, proc.stdout[-2000:]
+    assert len(lines) == 3 * 5 + 5
+    assert all(line.endswith("mismatches=0") for line in lines), proc.stdout

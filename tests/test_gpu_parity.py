@@ -214,6 +214,28 @@ def test_exhaustive_alpha_pairs_8bit(hip):
         assert np.array_equal(a.pixels, b.pixels), which
 
 
+@pytest.mark.parametrize("depth,fmt", [(10, abi.AVIF_RGB_FORMAT_RGBA), (10, abi.AVIF_RGB_FORMAT_ARGB), (12, abi.AVIF_RGB_FORMAT_BGRA)])
+def test_exhaustive_alpha_pairs_10_and_12_bit(hip, depth, fmt):
+    """Every (colour, alpha) pair of a 10- / 12-bit channel, both directions: the un-premultiply direction runs on integers
+    (libavif_amd/csrc/exactdiv.h: unpremultiplyByEstimate), which has to equal the reference's float expression everywhere."""
+    o, be = H.oracle_backend(), H.HipDeviceBackend()
+    n = 1 << depth
+    a_first = fmt == abi.AVIF_RGB_FORMAT_ARGB
+    for which in ("premultiply", "unpremultiply"):
+        a = abi.make_rgb(n, n, depth, fmt)
+        ch = a.channels()
+        cols = [k for k in range(4) if k != (0 if a_first else 3)]
+        ch[:, :, cols[0]] = np.arange(n)[None, :]
+        ch[:, :, cols[1]] = (n - 1) - np.arange(n)[None, :]
+        ch[:, :, cols[2]] = (np.arange(n)[None, :] * 7) % n
+        ch[:, :, 0 if a_first else 3] = np.arange(n)[:, None]
+        b = abi.make_rgb(n, n, depth, fmt)
+        b.pixels[...] = a.pixels
+        be.bind_host(b.struct, b)
+        assert getattr(o, which)(a.struct) == getattr(be, which)(b.struct) == 0
+        assert np.array_equal(a.pixels, b.pixels), (which, H.describe_diff(a.pixels, b.pixels))
+
+
 def test_error_codes(hip):
     """Same error-code matrix as the reference (tests/gtest/avif_fuzztest_yuvrgb.cc:36-46, src/alpha.c:154-161,341-348)."""
     o, be = H.oracle_backend(), H.hip_host_backend()
