@@ -346,11 +346,9 @@ __device__ __forceinline__ void runSoloFx(const TileArgs & A, const PkGeom & g, 
     if (tile >= g.nTiles)
         return;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
-    const uint32_t wx = wave & ((1u << g.wavesXLog2) - 1u), wy = wave >> g.wavesXLog2;
-    const uint32_t wavesY = 4u >> g.wavesXLog2;
-    const uint32_t trow = g.magicTilesX ? __umulhi(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
-    const uint32_t bandX = ((tcol << g.wavesXLog2) + wx) * (uint32_t)kBandW;
-    const uint32_t tileY = (trow * wavesY + wy) * (uint32_t)(2 * NS);
+    const PkPlace place = pkPlaceOf(tile, wave, g, (uint32_t)NS);
+    const uint32_t bandX = place.band * (uint32_t)kBandW;
+    const uint32_t tileY = place.strip0 * 2u;
     if (bandX >= A.w4 || tileY >= A.h2)
         return;
     BandCtx c;

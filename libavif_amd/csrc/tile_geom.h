@@ -20,15 +20,47 @@ struct PkGeom
     uint32_t magicChunk;
 };
 
-__device__ __forceinline__ uint32_t pkTileOf(uint32_t b, const PkGeom & g)
+// (The index arithmetic below is constexpr -- callable from host and device code alike -- so that tests/tools/geometry_check.cpp can walk
+// every workgroup and wave of a launch on the CPU and count how often each strip of each band is visited: tests/test_host_plans.py.)
+__attribute__((always_inline)) constexpr uint32_t mulHi32(uint32_t a, uint32_t b)
+{
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+}
+
+__attribute__((always_inline)) constexpr uint32_t pkTileOf(uint32_t b, const PkGeom & g)
 {
     if (g.chunk == 0)
         return b;
     // workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it): XCD x takes the x-th chunk of every
     // group of 8 chunks, so vertically adjacent tiles (which share chroma halo rows) mostly meet in one L2
     const uint32_t xcd = b & 7u, slot = b >> 3;
-    const uint32_t sc = g.magicChunk ? __umulhi(slot, g.magicChunk) : slot, within = slot - sc * g.chunk;
+    const uint32_t sc = g.magicChunk ? mulHi32(slot, g.magicChunk) : slot, within = slot - sc * g.chunk;
     return (sc * 8u + xcd) * g.chunk + within;
+}
+
+// Where wave `wave` (0..3) of the workgroup that took `tile` works: its band of 256 pixels and its first strip of 2 rows (it owns
+// `ns` consecutive strips)
+struct PkPlace
+{
+    uint32_t band, strip0;
+};
+__attribute__((always_inline)) constexpr PkPlace pkPlaceOf(uint32_t tile, uint32_t wave, const PkGeom & g, uint32_t ns)
+{
+    const uint32_t wx = wave & ((1u << g.wavesXLog2) - 1u), wy = wave >> g.wavesXLog2;
+    const uint32_t wavesY = 4u >> g.wavesXLog2;
+    const uint32_t trow = g.magicTilesX ? mulHi32(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
+    return PkPlace { (tcol << g.wavesXLog2) + wx, (trow * wavesY + wy) * ns };
+}
+
+// The cooperative kernels' order (tile_impl.h runBlock, tile_fx_impl.h): workgroups are dispatched round-robin over the 8 XCDs;
+// giving XCD x the x-th contiguous run of tiles keeps vertically adjacent tiles (which share chroma halo rows) on one L2.
+__attribute__((always_inline)) constexpr uint32_t blockRemap(uint32_t b, uint32_t n, bool bands)
+{
+    if (!bands || n < 64)
+        return b;
+    const uint32_t per = n >> 3, rem = n & 7;
+    const uint32_t xcd = b & 7, slot = b >> 3;
+    return xcd * per + (xcd < rem ? xcd : rem) + slot;
 }
 
 // Launch geometry: strips per wave, waves side by side, tile order (TuningBits; tests/tools/geometry_sweep.py)

@@ -451,17 +451,6 @@ __device__ __forceinline__ void packRgb8Row(unsigned w[3], const float x[4], con
                    "v"(z[3]));
 }
 
-// Workgroups are dispatched round-robin over the 8 XCDs; giving XCD x the x-th contiguous run of tiles keeps
-// vertically adjacent tiles (which share chroma halo rows) on one L2.
-__device__ __forceinline__ uint32_t blockRemap(uint32_t b, uint32_t n, bool bands)
-{
-    if (!bands || n < 64)
-        return b;
-    const uint32_t per = n >> 3, rem = n & 7;
-    const uint32_t xcd = b & 7, slot = b >> 3;
-    return xcd * per + (xcd < rem ? xcd : rem) + slot;
-}
-
 // Raw (undecoded) data of one strip (256 pixels x 2 rows) as loaded by one lane.
 template <typename YT, int SUB, bool BIL, bool NEEDA>
 struct StripRaw
@@ -929,11 +918,9 @@ __device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2
     if (tile >= g.nTiles)
         return;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
-    const uint32_t wx = wave & ((1u << g.wavesXLog2) - 1u), wy = wave >> g.wavesXLog2;
-    const uint32_t wavesY = 4u >> g.wavesXLog2;
-    const uint32_t trow = g.magicTilesX ? __umulhi(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
-    const uint32_t bandX = ((tcol << g.wavesXLog2) + wx) * (uint32_t)kBandW;
-    const uint32_t tileY = (trow * wavesY + wy) * (uint32_t)(2 * NS);
+    const PkPlace place = pkPlaceOf(tile, wave, g, (uint32_t)NS);
+    const uint32_t bandX = place.band * (uint32_t)kBandW;
+    const uint32_t tileY = place.strip0 * 2u;
     if (bandX >= A.w4 || tileY >= A.h2)
         return; // no barrier anywhere: a wave without work simply leaves
     BandCtx c;

@@ -826,12 +826,11 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     if (tile >= g.nTiles)
         return;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
-    const uint32_t wx = wave & ((1u << g.wavesXLog2) - 1u), wy = wave >> g.wavesXLog2;
-    const uint32_t wavesY = 4u >> g.wavesXLog2;
-    const uint32_t trow = g.magicTilesX ? __umulhi(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
+    const PkPlace place = pkPlaceOf(tile, wave, g, (uint32_t)NSW);
+    const uint32_t wy = wave >> g.wavesXLog2, wavesY = 4u >> g.wavesXLog2; // the wave's row among the workgroup's stacked waves
     PkSpot w;
-    w.band = (tcol << g.wavesXLog2) + wx;
-    w.strip0 = (trow * wavesY + wy) * (uint32_t)NSW;
+    w.band = place.band;
+    w.strip0 = place.strip0;
     // 4:2:0 with the four waves stacked: consecutive waves' chroma neighbourhoods overlap in two rows (the halo above and below each
     // wave's NSW rows).  When frames stream from HBM those re-reads are not served by a cache any more (tests/tools/pkbench_wide.hip:
     // the staged kernel costs exactly the halo's bytes more than nearest upsampling), so the workgroup stages ONE neighbourhood of

@@ -206,3 +206,36 @@ def test_scale_specialisations_follow_from_the_schedules(host):
                     # an exact 4x / 8x reduction that reached the box filter must have been recognised
                     assert colB != [sw // dw] * dw or rowB != [sh // dh] * dh or colA != [sw // dw * i for i in range(dw)], (sw, sh, dw, dh)
     assert seen["doubling"] > 500 and seen[4] > 100 and seen[8] > 100 and seen["none"] > 2000, seen
+
+
+@pytest.fixture(scope="module")
+def geometry():
+    """tests/tools/geometry_check.cpp over libavif_amd/csrc/tile_geom.h, host code only (hipcc --cuda-host-only: no GPU involved)."""
+    src, so = ROOT / "tests" / "tools" / "geometry_check.cpp", ROOT / "tests" / "tools" / "libgeometrycheck.so"
+    deps = [src, CSRC / "tile_geom.h", CSRC / "tile_shared.h", CSRC / "plan.h"]
+    if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared", f"-I{CSRC}", f"-I{ROOT / 'include'}",
+                        "-o", os.fspath(so), os.fspath(src)], check=True, capture_output=True)
+    lib = C.CDLL(os.fspath(so))
+    lib.geomCheckPk.restype, lib.geomCheckPk.argtypes = C.c_int, [C.c_uint32] * 6
+    lib.geomSweepPk.restype, lib.geomSweepPk.argtypes = C.c_uint64, [C.c_uint32, C.POINTER(C.c_uint32 * 7), C.POINTER(C.c_uint64)]
+    lib.geomSweepRemap.restype, lib.geomSweepRemap.argtypes = C.c_uint64, [C.c_uint32]
+    return lib
+
+
+def test_every_wave_tile_of_a_launch_is_visited_exactly_once(geometry):
+    """The wave-private kernels' launch geometry (pkGeometry) and index arithmetic (pkTileOf / pkPlaceOf: XCD chunks, multiply-high
+    divisions), walked on the CPU: every band x strip run of a job has exactly one owner, for every tuning the launchers can form."""
+    first, cases = (C.c_uint32 * 7)(), C.c_uint64()
+    bad = geometry.geomSweepPk(400, C.byref(first), C.byref(cases))
+    assert bad == 0 and cases.value > 1_000_000, (bad, list(first))
+    for w, h in [(1920, 1080), (3840, 2160), (7680, 4320), (15360, 8640), (16384, 16384), (16380, 16382), (4, 2), (260, 16384), (16384, 2)]:
+        for count in (1, 64):
+            for strips in (0, 2, 4):
+                for wxl in (0, 1, 2):
+                    for chunk_rows in (0, 1, 2, 5, 15):
+                        assert geometry.geomCheckPk(w & ~3, h & ~1, count, strips, wxl, chunk_rows) == 0, (w, h, count, strips, wxl, chunk_rows)
+
+
+def test_the_cooperative_kernels_block_order_is_a_permutation(geometry):
+    assert geometry.geomSweepRemap(20000) == 0

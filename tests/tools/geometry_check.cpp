@@ -1,0 +1,119 @@
+// geometry_check.cpp -- test tool (not shipped).  Walks the launch geometry of the wave-private tiled kernels on the CPU with the
+// PRODUCT's own index arithmetic (libavif_amd/csrc/tile_geom.h: pkGeometry on the host side, pkTileOf / pkPlaceOf / blockRemap as the
+// kernels evaluate them -- constexpr, so the same functions compile for the host) and counts how often every wave-tile of a job is
+// visited: exactly once each, nothing outside, for every combination of image size and tuning the launchers can form.
+// Built by tests/test_host_plans.py with `hipcc -x hip --cuda-host-only` (host code only; no GPU needed).
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "tile_geom.h"
+
+using namespace avifhip;
+using namespace avifhip::tile;
+
+namespace {
+
+// 0 = every wave-tile of a w4 x h2 job visited exactly once; otherwise a code saying what went wrong
+int checkPk(uint32_t w4, uint32_t h2, uint32_t count, uint32_t pkStrips, uint32_t wavesXLog2, uint32_t chunkRows, std::vector<uint8_t> & seenTile,
+            std::vector<uint8_t> & seenPlace)
+{
+    TileLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.count = count, L.pkStrips = pkStrips, L.wavesXLog2 = wavesXLog2, L.chunkRows = chunkRows;
+    uint32_t nsw = 0, blocks = 0;
+    PkGeom g;
+    pkGeometry(L, w4, h2, &nsw, &g, &blocks);
+    if (nsw != 2 && nsw != 4)
+        return 1;
+    if (blocks < g.nTiles || blocks > 0x7fffffffu)
+        return 2;
+    const uint32_t bands = (w4 + 255u) / 256u, strips = h2 / 2, stripRuns = (strips + nsw - 1) / nsw;
+    seenTile.assign(g.nTiles, 0);
+    seenPlace.assign((size_t)bands * stripRuns, 0);
+    for (uint32_t b = 0; b < blocks; ++b) {
+        const uint32_t tile = pkTileOf(b, g);
+        if (tile >= g.nTiles)
+            continue; // padding of the chunked order: the workgroup leaves at once
+        if (seenTile[tile]++)
+            return 3; // two workgroups took the same tile
+        for (uint32_t wave = 0; wave < 4; ++wave) {
+            const PkPlace p = pkPlaceOf(tile, wave, g, nsw);
+            if (p.band * 256u >= w4 || 2u * p.strip0 >= h2)
+                continue; // the kernels' "no work for this wave" exit
+            if (p.strip0 % nsw)
+                return 4;
+            const size_t at = (size_t)(p.strip0 / nsw) * bands + p.band;
+            if (p.band >= bands || at >= seenPlace.size())
+                return 5;
+            if (seenPlace[at]++)
+                return 6; // two waves own the same strips
+        }
+    }
+    for (uint8_t s : seenTile)
+        if (s != 1)
+            return 7;
+    for (uint8_t s : seenPlace)
+        if (s != 1)
+            return 8; // strips nobody converts
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int geomCheckPk(uint32_t w4, uint32_t h2, uint32_t count, uint32_t pkStrips, uint32_t wavesXLog2, uint32_t chunkRows)
+{
+    std::vector<uint8_t> a, b;
+    return checkPk(w4, h2, count, pkStrips, wavesXLog2, chunkRows, a, b);
+}
+
+// every tuning (strips 0/2/4, waves side by side 1/2/4, chunk rows 0..15) x job counts {1, 3, 64} over the widths around every listed band count
+// and every even height up to maxH2; returns the number of failing combinations and describes the first one in `first`
+// (w4, h2, count, pkStrips, wavesXLog2, chunkRows, code)
+uint64_t geomSweepPk(uint32_t maxH2, uint32_t * first, uint64_t * casesOut)
+{
+    static const uint32_t bandCounts[] = { 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64 };
+    static const uint32_t chunkRows[] = { 0, 1, 2, 3, 8, 15 };
+    static const uint32_t counts[] = { 1, 3, 64 };
+    std::vector<uint8_t> a, b;
+    uint64_t bad = 0, cases = 0;
+    for (uint32_t n : bandCounts)
+        for (uint32_t w4 : { 256u * n - 252u, 256u * n - 4u, 256u * n })
+            for (uint32_t h2 = 2; h2 <= maxH2; h2 += 2)
+                for (uint32_t count : counts)
+                    for (uint32_t strips : { 0u, 2u, 4u })
+                        for (uint32_t wxl = 0; wxl <= 2; ++wxl)
+                            for (uint32_t cr : chunkRows) {
+                                const int code = checkPk(w4, h2, count, strips, wxl, cr, a, b);
+                                ++cases;
+                                if (code && !bad++) {
+                                    const uint32_t f[7] = { w4, h2, count, strips, wxl, cr, (uint32_t)code };
+                                    memcpy(first, f, sizeof(f));
+                                }
+                            }
+    *casesOut = cases;
+    return bad;
+}
+
+// blockRemap (the cooperative kernels' order) is a permutation of [0, n) for every grid size up to maxN, with and without the XCD bands
+uint64_t geomSweepRemap(uint32_t maxN)
+{
+    std::vector<uint8_t> seen;
+    uint64_t bad = 0;
+    for (uint32_t n = 1; n <= maxN; ++n)
+        for (int bands = 0; bands < 2; ++bands) {
+            seen.assign(n, 0);
+            bool ok = true;
+            for (uint32_t b = 0; b < n && ok; ++b) {
+                const uint32_t r = blockRemap(b, n, bands != 0);
+                ok = r < n && !seen[r]++;
+            }
+            bad += !ok;
+        }
+    return bad;
+}
+
+} // extern "C"
