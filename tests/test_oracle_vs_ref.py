@@ -82,6 +82,27 @@ def test_exhaustive_alpha_pairs_8bit(backends):
         assert np.array_equal(a.pixels, b.pixels), which
 
 
+@pytest.mark.parametrize("depth,fmt", [(10, abi.AVIF_RGB_FORMAT_RGBA), (10, abi.AVIF_RGB_FORMAT_ARGB), (12, abi.AVIF_RGB_FORMAT_BGRA)])
+def test_exhaustive_alpha_pairs_10_and_12_bit(backends, depth, fmt):
+    """Every (colour, alpha) pair of a 10- / 12-bit channel, both directions: what tests/test_gpu_parity.py holds the product's
+    integer un-premultiply against is itself the reference's result."""
+    o, r = backends
+    n = 1 << depth
+    a_first = fmt == abi.AVIF_RGB_FORMAT_ARGB
+    for which in ("premultiply", "unpremultiply"):
+        a = abi.make_rgb(n, n, depth, fmt)
+        ch = a.channels()
+        cols = [k for k in range(4) if k != (0 if a_first else 3)]
+        ch[:, :, cols[0]] = np.arange(n)[None, :]
+        ch[:, :, cols[1]] = (n - 1) - np.arange(n)[None, :]
+        ch[:, :, cols[2]] = (np.arange(n)[None, :] * 7) % n
+        ch[:, :, 0 if a_first else 3] = np.arange(n)[:, None]
+        b = abi.make_rgb(n, n, depth, fmt)
+        b.pixels[...] = a.pixels
+        assert getattr(o, which)(a.struct) == getattr(r, which)(b.struct) == 0
+        assert np.array_equal(a.pixels, b.pixels), which
+
+
 def test_limited_full_helpers():
     o, r = oracle_lib.oracle(), oracle_lib.ref()
     for depth in (8, 10, 12, 9):
