@@ -3,6 +3,7 @@ buffers), in both arithmetic families.  Prints one JSON line per (configuration,
     python tests/tools/cfg_bench.py [cfg2 cfg2n cfg3 cfg4 cfg4rgb cfg5 cfg5x64 ...]
 Algorithmic bytes per pixel are SURVEY.md 8d's figures."""
 import ctypes as C
+import numpy as np
 import json
 import os
 import sys
@@ -96,13 +97,16 @@ def run(name):
             else:
                 pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_GRAYA)
                 px, bpp, ms = 7680 * 4320, 8.0, time_y2r(pair)
-        elif name in ("premul8", "premul16", "unpremul8"):
+        elif name in ("premul8", "premul16", "unpremul8", "premul10", "unpremul10", "unpremul16"):
             # avifRGBImagePremultiplyAlpha / UnpremultiplyAlpha in place on a device-resident 8K RGBA image: every pixel read and written once
-            depth = 16 if name == "premul16" else 8
+            # (10-bit: the integer un-premultiply in 16-bit containers; 16-bit: the IEEE division stays)
+            depth = int(name[-2:]) if name[-2:] in ("10", "16") else 8
             rgb = abi.make_rgb(7680, 4320, depth, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=avoid)
             synth.fill_rgb(rgb, 0x5151)
+            if depth == 10:
+                rgb.pixels.view(np.uint16)[...] &= 1023
             drgb = device.DeviceRGB(rgb, upload=True)
-            fn = lib.avifhipRGBImageUnpremultiplyAlphaAsync if name == "unpremul8" else lib.avifhipRGBImagePremultiplyAlphaAsync
+            fn = lib.avifhipRGBImageUnpremultiplyAlphaAsync if name.startswith("unpremul") else lib.avifhipRGBImagePremultiplyAlphaAsync
             for _ in range(300):
                 native.check(fn(drgb.struct, None))
             native.check(lib.avifhipSynchronize(None))
