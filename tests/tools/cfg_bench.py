@@ -3,12 +3,13 @@ buffers), in both arithmetic families.  Prints one JSON line per (configuration,
     python tests/tools/cfg_bench.py [cfg2 cfg2n cfg3 cfg4 cfg4rgb cfg5 cfg5x64 ...]
 Algorithmic bytes per pixel are SURVEY.md 8d's figures."""
 import ctypes as C
-import numpy as np
 import json
 import os
 import sys
 import time
 from pathlib import Path
+
+import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from libavif_amd import abi, device, native, synth  # noqa: E402
