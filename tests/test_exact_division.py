@@ -38,5 +38,5 @@ def test_integer_unpremultiply_equals_the_float_expression(tmp_path):
     proc = subprocess.run([os.fspath(exe)], capture_output=True, text=True)
     lines = proc.stdout.strip().splitlines()
     assert proc.returncode == 0, proc.stdout[-2000:]
-    assert len(lines) == 3 * 5 + 5
+    assert len(lines) == 2 * 3 * 5 + 5
     assert all(line.endswith("mismatches=0") for line in lines), proc.stdout

@@ -3,7 +3,7 @@
  *      min(floorf((float)c * maxF / (float)a + 0.5f), maxF)
  * for every 16-bit code c and every 0 < a < max, max in {255, 1023, 4095}, with the reciprocal estimate 1 / (2a) taken
  * correctly rounded and perturbed by -2 .. +2 ulp (the kernels' v_rcp_f32 is good to 1 ulp).  Likewise quotient65536ByEstimate
- * (floor(65536 / a), 0 < a < 256) against the integer division.
+ * (floor(65536 / a), 0 < a < 256) against the integer division, and unpremultiplyByLowEstimate (estimate biased low, one-sided correction).
  * Prints one line per (max, perturbation); exit status 1 on any mismatch.  Build: g++ -O2 -ffp-contract=off (no -ffast-math).
  */
 #include <math.h>
@@ -32,20 +32,24 @@ int main()
         const float maxF = (float)maxv;
         const unsigned cEnd = (maxv == 255u) ? 256u : 65536u; // 8-bit channels cannot hold more; 16-bit containers can hold any code
         for (int ulps = -2; ulps <= 2; ++ulps) {
-            unsigned long long bad = 0, tested = 0;
+            unsigned long long bad = 0, badLow = 0, tested = 0;
             for (unsigned a = 1; a < maxv; ++a) {
                 const float r = nudge(1.0f / (float)(2u * a), ulps);
+                const volatile float rLowV = r * kUnpremultiplyBias;
+                const float rLow = rLowV;
                 for (unsigned c = 0; c < cEnd; ++c) {
                     const volatile float t = (float)c * maxF; // (volatile: one rounding per operation, as written)
                     const volatile float q = t / (float)a;
                     const float rounded = floorf(q + 0.5f);
                     const unsigned want = (unsigned)(rounded < maxF ? rounded : maxF);
                     bad += (unpremultiplyByEstimate(c, a, maxv, r) != want);
+                    badLow += (unpremultiplyByLowEstimate(c, a, maxv, rLow) != want);
                     ++tested;
                 }
             }
             printf("max=%u ulps=%+d tested=%llu mismatches=%llu\n", maxv, ulps, tested, bad);
-            failures += bad != 0;
+            printf("max=%u ulps=%+d low-estimate form tested=%llu mismatches=%llu\n", maxv, ulps, tested, badLow);
+            failures += bad != 0 || badLow != 0;
         }
     }
     for (int ulps = -2; ulps <= 2; ++ulps) { // ARGBUnattenuate's reciprocals
