@@ -107,16 +107,21 @@ constexpr unsigned unpremultiplyByEstimate(unsigned c, unsigned a, unsigned maxv
 }
 // The same quotient from an estimate that is deliberately LOW: rLow = estimate * kUnpremultiplyBias, so that whatever the estimate's (few ulp of)
 // error the truncated product can only be the quotient or one short of it, and the correction is one compare and one add
-// (not wired into a kernel yet: three instructions per channel fewer than the two-sided form; enumerated by the same tool).
+// (three instructions per channel fewer than the two-sided form; enumerated by the same tool, a == max included).
 constexpr float kUnpremultiplyBias = 0.99999952316284179688f; // 1 - 2^-21
-constexpr unsigned unpremultiplyByLowEstimate(unsigned c, unsigned a, unsigned maxv, float rLow)
+// (general operands: d = 2a and mul = 2 * max for 0 < a <= max -- a == max returns c, the reference's "opaque pixels are left alone" -- and
+// d = 1, mul = 0 for a == 0, which returns 0 like the reference: the callers form them once per pixel)
+constexpr unsigned unpremultiplyByLowEstimateOperands(unsigned c, unsigned a, unsigned d, unsigned mul, unsigned maxv, float rLow)
 {
-    const unsigned d = 2u * a;
-    const unsigned n = (c & 0xffffu) * ((2u * maxv) & 0x3fffu) + a;
+    const unsigned n = (c & 0xffffu) * (mul & 0x3fffu) + a;
     const unsigned q0 = (unsigned)((float)n * rLow);
     const unsigned rem = n - (q0 & 0xffffffu) * (d & 0xffffffu);
     const unsigned q = q0 + (rem >= d ? 1u : 0u);
     return q < maxv ? q : maxv;
+}
+constexpr unsigned unpremultiplyByLowEstimate(unsigned c, unsigned a, unsigned maxv, float rLow)
+{
+    return unpremultiplyByLowEstimateOperands(c, a, 2u * a, 2u * maxv, maxv, rLow);
 }
 
 // floor(65536 / a) for 0 < a < 256 (ARGBUnattenuate's table of reciprocals) from an estimate r of 1 / a good to a

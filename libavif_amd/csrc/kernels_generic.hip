@@ -376,20 +376,25 @@ enum { AMUL_FX_MULTIPLY = 0, AMUL_FX_UNMULTIPLY, AMUL_EXACT_MULTIPLY, AMUL_IEEE_
 struct AlphaOperand
 {
     unsigned a;
-    float rcp2a; // AMUL_INT_UNMULTIPLY: an estimate of 1 / (2a) (exactdiv.h: unpremultiplyByEstimate)
-    unsigned ia; // AMUL_FX_UNMULTIPLY: ARGBUnattenuate's 8.8 reciprocal of a (pixel_fixed.h: fxUnattenuate)
+    // AMUL_INT_UNMULTIPLY (exactdiv.h: unpremultiplyByLowEstimateOperands): divisor 2a, the numerator's factor 2 * max, and an estimate of
+    // 1 / (2a) biased low; a == 0 divides 0 by 1 (the reference's result, 0); a >= max is held to max, which returns the channel itself
+    unsigned d, mul;
+    float rLow;
+    unsigned ia; // AMUL_FX_UNMULTIPLY: ARGBUnattenuate's 8.8 reciprocal of a (pixel_fixed.h: fxUnattenuateReciprocal)
 };
 template <int VARIANT>
-__device__ __forceinline__ AlphaOperand alphaOperand(unsigned a)
+__device__ __forceinline__ AlphaOperand alphaOperand(unsigned a, unsigned maxv)
 {
-    AlphaOperand A = { a, 0.0f, 0u };
-    if constexpr (VARIANT == AMUL_INT_UNMULTIPLY)
-        A.rcp2a = __builtin_amdgcn_rcpf((float)(2u * (a ? a : 1u)));
-    if constexpr (VARIANT == AMUL_FX_UNMULTIPLY) {
-        const unsigned d = (a & 0xffu) ? (a & 0xffu) : 1u;
-        const unsigned q = quotient65536ByEstimate(d, __builtin_amdgcn_rcpf((float)d));
-        A.ia = (a == 0u) ? 0u : (a == 1u) ? 0xffffu : (a == 255u) ? 0x100u : q;
+    AlphaOperand A = { a, 0u, 0u, 0.0f, 0u };
+    if constexpr (VARIANT == AMUL_INT_UNMULTIPLY) {
+        const unsigned am = min(a, maxv);
+        A.a = am;
+        A.d = am ? 2u * am : 1u;
+        A.mul = am ? 2u * maxv : 0u;
+        A.rLow = __builtin_amdgcn_rcpf((float)A.d) * kUnpremultiplyBias;
     }
+    if constexpr (VARIANT == AMUL_FX_UNMULTIPLY)
+        A.ia = fxUnattenuateReciprocal(a);
     return A;
 }
 
@@ -399,13 +404,12 @@ __device__ __forceinline__ unsigned alphaMulChannel(const RgbSide & o, unsigned 
     if constexpr (VARIANT == AMUL_FX_MULTIPLY) {
         return fxAlphaMul(c, A.a, MUL_MULTIPLY);
     } else if constexpr (VARIANT == AMUL_FX_UNMULTIPLY) {
-        const unsigned t = (((c & 0xffu) * 0x101u) * (A.ia & 0xffffu)) >> 16; // fxUnattenuate with the pixel's reciprocal formed once
-        return (t >= 0x8000u) ? 0u : min(t, 255u);
+        return fxUnattenuateBy(c, A.ia); // the pixel's reciprocal formed once
     } else if constexpr (VARIANT == AMUL_EXACT_MULTIPLY) {
         return premultiplyExact(c, A.a, maxv, o.rcpMax);
     } else if constexpr (VARIANT == AMUL_INT_UNMULTIPLY) {
-        const unsigned q = unpremultiplyByEstimate(c, A.a ? A.a : 1u, maxv, A.rcp2a);
-        return (A.a >= maxv) ? c : (A.a == 0u) ? 0u : q; // src/alpha.c:367-373
+        // (opaque pixels, which the reference leaves alone whatever their colour bits, are restored per pixel by the caller: src/alpha.c:367-373)
+        return unpremultiplyByLowEstimateOperands(c, A.a, A.d, A.mul, maxv, A.rLow);
     } else {
         return alphaMulInt(c, A.a, maxv, maxf, VARIANT == AMUL_IEEE_MULTIPLY ? MUL_MULTIPLY : MUL_UNMULTIPLY);
     }
@@ -422,19 +426,26 @@ __device__ __forceinline__ void alphaMulGroup(const AlphaMulPlan & p, unsigned (
         if constexpr (sizeof(CT) == 1) {
             const unsigned w = v[q];
             const unsigned b0 = w & 0xffu, b3 = w >> 24;
-            const AlphaOperand A = alphaOperand<VARIANT>(alphaFirst ? b0 : b3);
+            const unsigned a = alphaFirst ? b0 : b3;
+            const AlphaOperand A = alphaOperand<VARIANT>(a, 255u);
             const unsigned m1 = alphaMulChannel<VARIANT>(o, (w >> 8) & 0xffu, A, 255u, 255.0f);
             const unsigned m2 = alphaMulChannel<VARIANT>(o, (w >> 16) & 0xffu, A, 255u, 255.0f);
             const unsigned mx = alphaMulChannel<VARIANT>(o, alphaFirst ? b3 : b0, A, 255u, 255.0f); // the colour at the other end
             v[q] = (alphaFirst ? (b0 | (mx << 24)) : (mx | (b3 << 24))) | (m1 << 8) | (m2 << 16);
+            // (8-bit channels cannot exceed the maximum: an opaque pixel comes out as itself)
         } else {
             const unsigned lo = v[2 * q], hi = v[2 * q + 1];
             const unsigned c0 = lo & 0xffffu, c3 = hi >> 16;
-            const AlphaOperand A = alphaOperand<VARIANT>(alphaFirst ? c0 : c3);
+            const unsigned a = alphaFirst ? c0 : c3;
+            const AlphaOperand A = alphaOperand<VARIANT>(a, (unsigned)o.maxv);
             const unsigned m1 = alphaMulChannel<VARIANT>(o, lo >> 16, A, (unsigned)o.maxv, o.maxf);
             const unsigned m2 = alphaMulChannel<VARIANT>(o, hi & 0xffffu, A, (unsigned)o.maxv, o.maxf);
             const unsigned mx = alphaMulChannel<VARIANT>(o, alphaFirst ? c3 : c0, A, (unsigned)o.maxv, o.maxf);
             v[2 * q] = (alphaFirst ? c0 : mx) | (m1 << 16), v[2 * q + 1] = m2 | ((alphaFirst ? mx : c3) << 16);
+            if constexpr (VARIANT == AMUL_INT_UNMULTIPLY) {
+                if (a >= (unsigned)o.maxv) // opaque: left alone, stray bits above the depth included
+                    v[2 * q] = lo, v[2 * q + 1] = hi;
+            }
         }
     }
 }
@@ -481,7 +492,7 @@ __global__ __launch_bounds__(256) void alphaMulWideKernel(AlphaMulPlan p)
                 for (uint32_t ch = 0; ch < 4; ++ch)
                     if (ch != slotA)
                         c[ch] = (VARIANT == AMUL_FX_UNMULTIPLY) ? (CT)fxAlphaMul(c[ch], a, MUL_UNMULTIPLY)
-                                                                : (CT)alphaMulChannel<kEdge>(o, c[ch], alphaOperand<kEdge>(a), (unsigned)o.maxv, o.maxf);
+                                                                : (CT)alphaMulChannel<kEdge>(o, c[ch], alphaOperand<kEdge>(a, (unsigned)o.maxv), (unsigned)o.maxv, o.maxf);
             }
         }
     }

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "exactdiv.h"
 #include "pixel_math.h"
 
 namespace avifhip {
@@ -91,11 +92,22 @@ __device__ __forceinline__ unsigned fxAttenuate(unsigned c, unsigned a)
 {
     return (c * a + 255u) >> 8;
 }
+// ARGBUnattenuate's 8.8 reciprocal of a pixel's alpha, formed once per pixel: floor(65536 / a) from v_rcp_f32 and one exact correction step
+// instead of the 32-bit integer division sequence (exactdiv.h: quotient65536ByEstimate, enumerated for every a)
+__device__ __forceinline__ unsigned fxUnattenuateReciprocal(unsigned a)
+{
+    const unsigned d = (a & 0xffu) ? (a & 0xffu) : 1u;
+    const unsigned q = quotient65536ByEstimate(d, __builtin_amdgcn_rcpf((float)d));
+    return (a == 0u) ? 0u : (a == 1u) ? 0xffffu : (a == 255u) ? 0x100u : q;
+}
+__device__ __forceinline__ unsigned fxUnattenuateBy(unsigned c, unsigned ia)
+{
+    const unsigned t = (((c & 0xffu) * 0x101u) * (ia & 0xffffu)) >> 16;
+    return (t >= 0x8000u) ? 0u : min(t, 255u);
+}
 __device__ __forceinline__ unsigned fxUnattenuate(unsigned c, unsigned a)
 {
-    const unsigned ia = (a == 0) ? 0u : (a == 1) ? 0xffffu : (a == 255) ? 0x100u : (0x10000u / a);
-    const unsigned t = ((c * 0x101u) * ia) >> 16;
-    return (t >= 0x8000u) ? 0u : min(t, 255u);
+    return fxUnattenuateBy(c, fxUnattenuateReciprocal(a));
 }
 __device__ __forceinline__ unsigned fxAlphaMul(unsigned c, unsigned a, int mulMode)
 {

@@ -243,8 +243,11 @@ __device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         unsigned x = X4[i] >> 8, g = G4[i] >> 8, z = Z4[i] >> 8;
-                        if (A.postMul != MUL_NONE) { // ARGBAttenuate / ARGBUnattenuate (tileYuvToRgbSupported admits no other post-pass)
-                            x = fxAlphaMul(x, a[i], A.postMul), g = fxAlphaMul(g, a[i], A.postMul), z = fxAlphaMul(z, a[i], A.postMul);
+                        if (A.postMul == MUL_MULTIPLY) { // ARGBAttenuate / ARGBUnattenuate (tileYuvToRgbSupported admits no other post-pass)
+                            x = fxAttenuate(x, a[i]), g = fxAttenuate(g, a[i]), z = fxAttenuate(z, a[i]);
+                        } else if (A.postMul == MUL_UNMULTIPLY) {
+                            const unsigned ia = fxUnattenuateReciprocal(a[i]); // once per pixel, no integer division
+                            x = fxUnattenuateBy(x, ia), g = fxUnattenuateBy(g, ia), z = fxUnattenuateBy(z, ia);
                         }
                         w[i] = __builtin_amdgcn_perm(x, g, F.selXGm) | __builtin_amdgcn_perm(z, a[i], F.selZAm);
                     }

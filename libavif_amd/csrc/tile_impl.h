@@ -33,6 +33,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "exactdiv.h"
 #include "pixel_math.h"
 #include "tile_geom.h"
 #include "tile_shared.h"
@@ -170,68 +171,158 @@ __device__ __forceinline__ unsigned alphaToFullRange(const TileArgs & A, unsigne
 }
 
 // alpha at the RGB depth from a plane sample: copy or depth rescale (src/alpha.c:84-103, verified reciprocal form)
-__device__ __forceinline__ unsigned alphaFromPlane(const TileArgs & A, unsigned sa)
+__device__ __forceinline__ unsigned alphaRescaled(const TileArgs & A, unsigned sa)
 {
-    if (!A.alphaRescale)
-        return sa;
     const float alphaF = divExact((float)sa, A.rcpYuvMax);
     const int dstAlpha = (int)(0.5f + (alphaF * A.rgbMaxF));
     return (unsigned)clampInt(dstAlpha, 0, (int)A.rgbMax);
 }
-
-// (un)premultiply on stored integers with the verified reciprocal for "/ maxF" (src/alpha.c:180-192, :367-381)
-__device__ __forceinline__ unsigned alphaMulIntFast(const TileArgs & A, unsigned c, unsigned a, int mulMode)
+__device__ __forceinline__ unsigned alphaFromPlane(const TileArgs & A, unsigned sa)
 {
-    if (mulMode == MUL_MULTIPLY) {
-        // floorf(c * a / maxF + 0.5f): the operand is never negative, so the truncating conversion is the floor; a == 0
-        // needs no special case (0 / maxF + 0.5f truncates to 0); a >= max leaves the channel untouched (:180-183)
-        const unsigned m = (unsigned)(divExact((float)c * (float)a, A.rcpRgbMax) + 0.5f);
-        return (a >= A.rgbMax) ? c : m;
+    return A.alphaRescale ? alphaRescaled(A, sa) : sa;
+}
+
+// ---- quantisation and alpha (un)premultiply: the reference's values by cheaper instruction sequences, each one enumerated
+//      (tests/tools/verify_fp32_shortcuts.cpp, run by tests/test_exact_division.py) ----
+
+// (T)(0.5f + clamp01(c) * max) without clamping first, the multiply and the add in ONE instruction.  Two facts:
+//   * fmaf(c, max, 0.5f) truncates to the same integer as 0.5f + (c * max) for EVERY binary32 c and max in {255, 1023, 4095, 65535}
+//     (the sum's ulp is never finer than the product's where an integer boundary could be crossed; enumerated over all 2^32 operands);
+//   * t is monotonic in c, v_cvt_u32_f32 truncates toward zero like the C cast and returns 0 for every negative operand, and the min
+//     restores the upper clamp (c >= 1 gives t >= max + 0.5f): identical to clamp-then-quantise for every finite c.
+__device__ __forceinline__ float quantizeArg(float c, float maxf)
+{
+    return __builtin_fmaf(c, maxf, 0.5f);
+}
+__device__ __forceinline__ unsigned truncU32(float t)
+{
+    unsigned q;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(t));
+    return q;
+}
+__device__ __forceinline__ unsigned quantizeSat(float c, float maxf, unsigned maxv)
+{
+    return minU(truncU32(quantizeArg(c, maxf)), maxv);
+}
+
+// AVIF_CLAMP(x, 0.0f, 1.0f) (include/avif/internal.h:18) as the VOP3 clamp modifier of the instruction that produces x: the clamp
+// costs nothing.  (A -0.0f may come out as +0.0f; every consumer below maps both to the same integer.)
+__device__ __forceinline__ float sat01(float x)
+{
+    float r;
+    asm("v_max_f32_e64 %0, %1, %1 clamp" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float addSat01(float a, float b)
+{
+    float r;
+    asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float subSat01(float a, float b)
+{
+    float r;
+    asm("v_sub_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fmaSat01(float a, float b, float c)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// In-loop alpha of the reference's slow path (src/reformat.c:894-947) for the three clamped colours of one pixel and the pixel's
+// normalised alpha Ac in [0, 1]; returns the quantiser's arguments t = c' * max + 0.5f (one rounding, see quantizeArg).
+//   multiply:   Ac == 0 -> 0, Ac < 1 -> c * Ac, else c.  c * 0 is 0 and c * 1 is c: the product alone is all three cases.
+//   unmultiply: Ac == 0 -> 0, Ac < 1 -> min(c / Ac, 1), else c.  The three IEEE divisions share their divisor, so its reciprocal is formed
+//               once: v_rcp_f32 (1 ulp) and one Newton step give the correctly rounded r = RN(1 / Ac) for every Ac = a / max the alpha plane
+//               can produce, and then q = fma(fma(-q0, Ac, c), r, q0), q0 = c * r, IS the correctly rounded quotient (Markstein's
+//               correction) -- enumerated for every alpha code of the 8-, 10- and 12-bit planes against every c in {0} U [2^-40, 1]
+//               (smaller positive c cannot arise: c is a sum of terms that are multiples of 2^-34), estimates off by up to 2 ulp.
+//               The final fma carries the clamp (min(q, 1)); c / 1 comes out as c.  16-bit alpha planes keep the IEEE division.
+struct InLoopAlpha
+{
+    float Ac, r;
+    bool zero;
+};
+template <bool UNMUL, bool WIDE>
+__device__ __forceinline__ InLoopAlpha inLoopAlpha(const TileArgs & A, unsigned unormA)
+{
+    InLoopAlpha L;
+    const float af = (float)(WIDE ? minU(unormA, A.yuvMax) : unormA); // (8-bit samples cannot exceed the maximum)
+    L.Ac = fmaSat01(af, A.rcpYuvMax.hi, af * A.rcpYuvMax.lo); // clamp01(unormA / yuvMax), src/reformat.c:896
+    L.r = 0.0f, L.zero = false;
+    if constexpr (UNMUL) {
+        L.zero = L.Ac == 0.0f;
+        const float d = L.zero ? 1.0f : L.Ac;
+        const float r0 = __builtin_amdgcn_rcpf(d);
+        L.r = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+        L.Ac = d;
     }
+    return L;
+}
+template <bool UNMUL>
+__device__ __forceinline__ float inLoopChannel(const TileArgs & A, float c, const InLoopAlpha & L)
+{
+    if constexpr (!UNMUL) {
+        return quantizeArg(c * L.Ac, A.rgbMaxF);
+    } else {
+        const float q0 = c * L.r;
+        const float q = fmaSat01(__builtin_fmaf(-q0, L.Ac, c), L.r, q0);
+        return quantizeArg(L.zero ? 0.0f : q, A.rgbMaxF);
+    }
+}
+// ... with the IEEE division (alpha planes deeper than 12 bits)
+__device__ __forceinline__ float inLoopChannelIeee(const TileArgs & A, float c, float Ac)
+{
+    return quantizeArg(applyAlphaF(c, Ac, MUL_UNMULTIPLY), A.rgbMaxF);
+}
+
+// The integer post-pass of the reference's fast paths (src/alpha.c:180-192, :367-381) on one pixel's quantised colours.
+//   multiply:   floorf(c * a / maxF + 0.5f) with "/ maxF" in the verified reciprocal form; a == 0 needs no special case (0 / maxF + 0.5f
+//               truncates to 0); a >= max leaves the pixel untouched (:180-183).
+//   unmultiply: exactdiv.h's unpremultiplyByLowEstimate for channel maxima up to 4095 -- the pixel's 1 / (2a) from v_rcp_f32, biased low, one
+//               compare-and-add per channel; a == max needs no special case (the quotient is c), a > max (stray bits above the depth in a 16-bit
+//               container) is held to max, which returns c like the reference's `a >= max` test, and a == 0 divides 0 by 1.
+//               Depth 16 keeps the IEEE division (c * 65535.0f rounds).
+struct PostAlpha
+{
+    unsigned a, d, mul;
+    float af, rLow;
+};
+template <bool UNMUL>
+__device__ __forceinline__ PostAlpha postAlpha(const TileArgs & A, unsigned a)
+{
+    PostAlpha P;
+    P.a = a, P.af = (float)a, P.d = 0, P.mul = 0, P.rLow = 0.0f;
+    if constexpr (UNMUL) {
+        const unsigned am = minU(a, A.rgbMax);
+        P.a = am;
+        P.d = am ? 2u * am : 1u;
+        P.mul = am ? 2u * A.rgbMax : 0u;
+        P.rLow = __builtin_amdgcn_rcpf((float)P.d) * kUnpremultiplyBias;
+    }
+    return P;
+}
+template <bool UNMUL>
+__device__ __forceinline__ unsigned postChannel(const TileArgs & A, unsigned c, const PostAlpha & P)
+{
+    if constexpr (!UNMUL) {
+        const unsigned m = truncU32(divExact((float)c * P.af, A.rcpRgbMax) + 0.5f);
+        return (P.a >= A.rgbMax) ? c : m;
+    } else {
+        return unpremultiplyByLowEstimateOperands(c, P.a, P.d, P.mul, A.rgbMax, P.rLow);
+    }
+}
+// ... depth 16: the reference's own expression
+__device__ __forceinline__ unsigned postChannelIeee(const TileArgs & A, unsigned c, unsigned a)
+{
     if (a >= A.rgbMax)
         return c;
     if (a == 0)
         return 0;
     return unpremultiplyInt(c, a, A.rgbMaxF);
-}
-
-// (T)(0.5f + clamp01(c) * max) without clamping first: t = 0.5f + c * max is monotonic in c, v_cvt_u32_f32 truncates toward
-// zero like the C cast and returns 0 for every negative operand, and the min restores the upper clamp (c >= 1 gives
-// t >= max + 0.5f, which truncates to max or more).  Identical to clamp-then-quantise for every finite c.
-__device__ __forceinline__ unsigned quantizeSat(float c, float maxf, unsigned maxv)
-{
-    const float t = 0.5f + (c * maxf);
-    unsigned q;
-    asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(t));
-    return minU(q, maxv);
-}
-
-// General finish of one pixel from unclamped R,G,B: clamp, optional fp32 alpha multiply, quantise, optional integer
-// alpha multiply (src/reformat.c:886-961, :1574-1585).
-template <bool HASMUL>
-__device__ __forceinline__ PixelOut finishPixel(const TileArgs & A, float R, float G, float B, unsigned unormA, unsigned a)
-{
-    PixelOut q;
-    if (HASMUL && A.inLoopMul != MUL_NONE) {
-        float Rc = clamp01(R), Gc = clamp01(G), Bc = clamp01(B);
-        const float Ac = clamp01(divExact((float)minU(unormA, A.yuvMax), A.rcpYuvMax));
-        Rc = applyAlphaF(Rc, Ac, A.inLoopMul);
-        Gc = applyAlphaF(Gc, Ac, A.inLoopMul);
-        Bc = applyAlphaF(Bc, Ac, A.inLoopMul);
-        q.r = quantize(Rc, A.rgbMaxF);
-        q.g = quantize(Gc, A.rgbMaxF);
-        q.b = quantize(Bc, A.rgbMaxF);
-        return q;
-    }
-    q.r = quantizeSat(R, A.rgbMaxF, A.rgbMax);
-    q.g = quantizeSat(G, A.rgbMaxF, A.rgbMax);
-    q.b = quantizeSat(B, A.rgbMaxF, A.rgbMax);
-    if (HASMUL && A.postMul != MUL_NONE) {
-        q.r = alphaMulIntFast(A, q.r, a, A.postMul);
-        q.g = alphaMulIntFast(A, q.g, a, A.postMul);
-        q.b = alphaMulIntFast(A, q.b, a, A.postMul);
-    }
-    return q;
 }
 
 // RGB output is written once and never read back by the kernel: non-temporal stores keep 130+ MB of it from
@@ -602,6 +693,11 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
     const f2 cBR = { A.cB, A.cR };
     const f2 cUV = { A.cU, A.cV }; // the two products of the green term, :876 (their sum is commutative)
     const unsigned opaqueWord = A.rgbMax << (8 * A.slotA); // 8-bit RGBA: the alpha byte in place
+#ifdef AVIFHIP_PROBE_MULMODE // instruction-count probes only (tests/tools/isa_count.py): one alpha mode compiled in
+    const int inLoopMode = (AVIFHIP_PROBE_MULMODE) <= 2 ? (AVIFHIP_PROBE_MULMODE) : MUL_NONE, postMode = (AVIFHIP_PROBE_MULMODE) > 2 ? (AVIFHIP_PROBE_MULMODE) - 2 : MUL_NONE;
+#else
+    const int inLoopMode = A.inLoopMul, postMode = A.postMul;
+#endif
     // 3-channel pixels: bytes of the band's row segment that exist (storeRowContiguous)
     const uint32_t segBytes = ((A.w4 - c.bandX < (uint32_t)kBandW) ? A.w4 - c.bandX : (uint32_t)kBandW) * kPixBytes;
 
@@ -702,7 +798,159 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
             const f2 y01 = norm2((f2) { fy[0], fy[1] }, A.biasY, A.rcpRangeY);
             const f2 y23 = norm2((f2) { fy[2], fy[3] }, A.biasY, A.rcpRangeY);
             const float yk[4] = { y01.x, y01.y, y23.x, y23.y };
-            f2 br[4]; // (B, R) per pixel
+
+            unsigned av[4] = { 0, 0, 0, 0 }, a[4];
+            if constexpr (kNeedA) {
+                decode4<YT>(raw[k].a[r], av);
+                if (A.alphaLim.on) { // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        av[i] = alphaToFullRange(A, av[i]);
+                }
+            }
+            if (APLANE && A.alphaRescale) { // wave-uniform, and a branch around all four pixels (per pixel the compiler computes the rescale and selects)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = alphaRescaled(A, av[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = APLANE ? av[i] : A.rgbMax;
+            }
+            const uint32_t off = (sy + r) * A.rgbPitch + X * kPixBytes;
+            const uint32_t bandOff = (sy + r) * A.rgbPitch + c.bandX * kPixBytes;
+
+            // finished integers (q[i].r / q[i].b: first / third colour channel) to their pixels
+            auto emitQ = [&](PixelOut (&q)[4]) {
+                if constexpr (sizeof(RT) == 2) {
+                    if (A.f16Mul != 0.0f) { // wave-uniform: avifRGBImageToF16 (src/reformat.c:1419-1443) on every channel, alpha included
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            q[i].r = toHalfBits(q[i].r, A.f16Mul), q[i].g = toHalfBits(q[i].g, A.f16Mul), q[i].b = toHalfBits(q[i].b, A.f16Mul);
+                            a[i] = toHalfBits(a[i], A.f16Mul);
+                        }
+                    }
+                }
+                if constexpr (sizeof(RT) == 2 && NCH == 4) {
+                    store4WideRgba(A.rgb, bandOff, q, a, alphaFirst, c.bandX, A.w4, xchg[wv]);
+                } else if constexpr (NCH == 3) {
+                    store4Rgb3<RT>(A.rgb, bandOff, q, segBytes, xchg[wv]);
+                } else if constexpr (NCH <= 2) {
+                    if (laneValid)
+                        storeGray4<RT, NCH>(A.rgb, off, q, a, alphaFirst, nt);
+                } else {
+                    if (laneValid)
+                        store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
+                }
+            };
+            // the quantiser's arguments t = c * max + 0.5f (quantizeArg) of the row's (first, third) colours and of green to their pixels:
+            // 8-bit colour outputs truncate, saturate and pack in one instruction per channel (packRgba8Row), the others through v_cvt_u32_f32
+            auto emitT = [&](const f2 (&tbr)[4], const float (&tg)[4]) {
+                if constexpr (sizeof(RT) == 1 && NCH >= 3) {
+                    if constexpr (NCH == 4) {
+                        unsigned w[4], aw[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            aw[i] = APLANE ? (a[i] << (8 * A.slotA)) : opaqueWord;
+                        packRgba8Row(w, aw, tbr, tg, A.slotZ, A.slotG, A.slotX);
+                        if (laneValid)
+                            storeVec(A.rgb, off, (u4) { w[0], w[1], w[2], w[3] }, nt);
+                    } else {
+                        float x[4], z[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            x[i] = tbr[i].x;
+                            z[i] = tbr[i].y;
+                        }
+                        unsigned w[3];
+                        packRgb8Row(w, x, tg, z);
+                        storeRowContiguous<3>(A.rgb, bandOff, w, segBytes, xchg[wv]);
+                    }
+                } else {
+                    PixelOut q[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        q[i].r = minU(truncU32(tbr[i].x), A.rgbMax);
+                        q[i].g = minU(truncU32(tg[i]), A.rgbMax);
+                        q[i].b = minU(truncU32(tbr[i].y), A.rgbMax);
+                    }
+                    emitQ(q);
+                }
+            };
+
+            if constexpr (SUB == SUB_444 && sizeof(YT) == 1 && sizeof(RT) == 1 && !HASMUL) {
+                // identity matrix, 8 bits in and out, full range (lossless RGB in 4:4:4 planes): G = Y, B = Cb, R = Cr, a byte shuffle
+                // (avifImageIdentity8ToRGB8ColorFullRange, src/reformat.c:1278-1309); `u` feeds the first colour channel (tile_shared.h)
+                if (A.identityCopy) { // wave-uniform
+                    unsigned yb[4], ub[4], vb[4];
+                    decode4<YT>(raw[k].y[r], yb);
+                    decode4<YT>(raw[k].u[r], ub);
+                    decode4<YT>(raw[k].v[r], vb);
+                    PixelOut q[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        q[i].r = ub[i], q[i].g = yb[i], q[i].b = vb[i];
+                    if constexpr (NCH == 3) {
+                        store4Rgb3<RT>(A.rgb, bandOff, q, segBytes, xchg[wv]);
+                    } else {
+                        if (laneValid)
+                            store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
+                    }
+                    continue;
+                }
+            }
+
+            if constexpr (HASMUL) {
+                if (inLoopMode != MUL_NONE) { // wave-uniform: the slow path's alpha arithmetic in fp32 before quantisation (src/reformat.c:894-947)
+                    // clamped colours: the matrix in scalar form so that each channel's last instruction carries the clamp
+                    float X[4], G[4], Z[4];
+                    if constexpr (SUB == SUB_400) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            X[i] = G[i] = Z[i] = sat01(yk[i]);
+                    } else if (SUB == SUB_444 && A.identityMatrix) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            X[i] = sat01(uv[r][i].x), G[i] = sat01(yk[i]), Z[i] = sat01(uv[r][i].y);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            X[i] = addSat01(yk[i], A.cB * uv[r][i].x);
+                            Z[i] = addSat01(yk[i], A.cR * uv[r][i].y);
+                            const float sum = (A.cV * uv[r][i].y) + (A.cU * uv[r][i].x);
+                            G[i] = subSat01(yk[i], __builtin_fmaf(sum, A.rcpKgTimes2.hi, sum * A.rcpKgTimes2.lo));
+                        }
+                    }
+                    f2 tbr[4];
+                    float tg[4];
+                    if (inLoopMode == MUL_MULTIPLY) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const InLoopAlpha L = inLoopAlpha<false, kWide>(A, av[i]);
+                            tbr[i] = (f2) { inLoopChannel<false>(A, X[i], L), inLoopChannel<false>(A, Z[i], L) };
+                            tg[i] = inLoopChannel<false>(A, G[i], L);
+                        }
+                    } else if (!kWide || A.yuvMax <= 4095u) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const InLoopAlpha L = inLoopAlpha<true, kWide>(A, av[i]);
+                            tbr[i] = (f2) { inLoopChannel<true>(A, X[i], L), inLoopChannel<true>(A, Z[i], L) };
+                            tg[i] = inLoopChannel<true>(A, G[i], L);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float Ac = inLoopAlpha<false, kWide>(A, av[i]).Ac;
+                            tbr[i] = (f2) { inLoopChannelIeee(A, X[i], Ac), inLoopChannelIeee(A, Z[i], Ac) };
+                            tg[i] = inLoopChannelIeee(A, G[i], Ac);
+                        }
+                    }
+                    emitT(tbr, tg);
+                    continue;
+                }
+            }
+
+            f2 br[4]; // unclamped (first, third) colour per pixel
             float g[4];
             if constexpr (SUB == SUB_400) {
 #pragma unroll
@@ -727,96 +975,43 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                 }
             }
 
-            unsigned av[4] = { 0, 0, 0, 0 }, a[4];
-            if constexpr (kNeedA) {
-                decode4<YT>(raw[k].a[r], av);
-                if (A.alphaLim.on) { // wave-uniform
+            if constexpr (HASMUL) {
+                // fast paths: quantise, then the integer post-pass (src/reformat.c:1574-1585)
+                PixelOut q[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        av[i] = alphaToFullRange(A, av[i]);
+                for (int i = 0; i < 4; ++i) {
+                    q[i].r = quantizeSat(br[i].x, A.rgbMaxF, A.rgbMax);
+                    q[i].g = quantizeSat(g[i], A.rgbMaxF, A.rgbMax);
+                    q[i].b = quantizeSat(br[i].y, A.rgbMaxF, A.rgbMax);
                 }
-            }
+                if (postMode == MUL_MULTIPLY) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = APLANE ? alphaFromPlane(A, av[i]) : A.rgbMax;
-            const uint32_t off = (sy + r) * A.rgbPitch + X * kPixBytes;
-
-            if constexpr (SUB == SUB_444 && sizeof(YT) == 1 && sizeof(RT) == 1 && !HASMUL) {
-                // identity matrix, 8 bits in and out, full range (lossless RGB in 4:4:4 planes): G = Y, B = Cb, R = Cr, a byte shuffle
-                // (avifImageIdentity8ToRGB8ColorFullRange, src/reformat.c:1278-1309); `u` feeds the first colour channel (tile_shared.h)
-                if (A.identityCopy) { // wave-uniform
-                    unsigned yb[4], ub[4], vb[4];
-                    decode4<YT>(raw[k].y[r], yb);
-                    decode4<YT>(raw[k].u[r], ub);
-                    decode4<YT>(raw[k].v[r], vb);
-                    PixelOut q[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        q[i].r = ub[i], q[i].g = yb[i], q[i].b = vb[i];
-                    if constexpr (NCH == 3) {
-                        store4Rgb3<RT>(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, segBytes, xchg[wv]);
-                    } else {
-                        if (laneValid)
-                            store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
+                    for (int i = 0; i < 4; ++i) {
+                        const PostAlpha P = postAlpha<false>(A, a[i]);
+                        q[i].r = postChannel<false>(A, q[i].r, P), q[i].g = postChannel<false>(A, q[i].g, P), q[i].b = postChannel<false>(A, q[i].b, P);
                     }
-                    continue;
+                } else if (postMode == MUL_UNMULTIPLY && A.rgbMax <= 4095u) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const PostAlpha P = postAlpha<true>(A, a[i]);
+                        q[i].r = postChannel<true>(A, q[i].r, P), q[i].g = postChannel<true>(A, q[i].g, P), q[i].b = postChannel<true>(A, q[i].b, P);
+                    }
+                } else if (postMode == MUL_UNMULTIPLY) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        q[i].r = postChannelIeee(A, q[i].r, a[i]), q[i].g = postChannelIeee(A, q[i].g, a[i]), q[i].b = postChannelIeee(A, q[i].b, a[i]);
                 }
-            }
-
-            if constexpr (sizeof(RT) == 1 && !HASMUL && NCH >= 3) {
-                // 8-bit outputs: t = 0.5f + c * 255, then truncate + saturate + pack in one instruction per channel
+                emitQ(q);
+            } else {
                 const f2 half = splat(0.5f), mx = splat(A.rgbMaxF);
                 f2 tbr[4];
                 float tg[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    tbr[i] = half + (br[i] * mx);
-                    tg[i] = 0.5f + (g[i] * A.rgbMaxF);
+                    tbr[i] = fma2(br[i], mx, half);
+                    tg[i] = quantizeArg(g[i], A.rgbMaxF);
                 }
-                if constexpr (NCH == 4) {
-                    unsigned w[4], aw[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        aw[i] = APLANE ? (a[i] << (8 * A.slotA)) : opaqueWord;
-                    packRgba8Row(w, aw, tbr, tg, A.slotZ, A.slotG, A.slotX);
-                    if (laneValid)
-                        storeVec(A.rgb, off, (u4) { w[0], w[1], w[2], w[3] }, nt);
-                } else {
-                    float x[4], z[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        x[i] = tbr[i].x;
-                        z[i] = tbr[i].y;
-                    }
-                    unsigned w[3];
-                    packRgb8Row(w, x, tg, z);
-                    storeRowContiguous<3>(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, w, segBytes, xchg[wv]);
-                }
-            } else {
-                PixelOut q[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    q[i] = finishPixel<HASMUL>(A, br[i].x, g[i], br[i].y, av[i], a[i]); // q.r = first colour, q.b = third
-                if constexpr (sizeof(RT) == 2) {
-                    if (A.f16Mul != 0.0f) { // wave-uniform: avifRGBImageToF16 (src/reformat.c:1419-1443) on every channel, alpha included
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            q[i].r = toHalfBits(q[i].r, A.f16Mul), q[i].g = toHalfBits(q[i].g, A.f16Mul), q[i].b = toHalfBits(q[i].b, A.f16Mul);
-                            a[i] = toHalfBits(a[i], A.f16Mul);
-                        }
-                    }
-                }
-                if constexpr (sizeof(RT) == 2 && NCH == 4) {
-                    store4WideRgba(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, a, alphaFirst, c.bandX, A.w4, xchg[wv]);
-                } else if constexpr (NCH == 3) {
-                    store4Rgb3<RT>(A.rgb, (sy + r) * A.rgbPitch + c.bandX * kPixBytes, q, segBytes, xchg[wv]);
-                } else if constexpr (NCH <= 2) {
-                    if (laneValid)
-                        storeGray4<RT, NCH>(A.rgb, off, q, a, alphaFirst, nt);
-                } else {
-                    if (laneValid)
-                        store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
-                }
+                emitT(tbr, tg);
             }
         }
     }

@@ -40,3 +40,17 @@ def test_integer_unpremultiply_equals_the_float_expression(tmp_path):
     assert proc.returncode == 0, proc.stdout[-2000:]
     assert len(lines) == 2 * 3 * 5 + 5
     assert all(line.endswith("mismatches=0") for line in lines), proc.stdout
+
+
+@pytest.mark.skipif(not _has_fma(), reason="host CPU lacks FMA")
+def test_fp32_shortcuts_of_the_tiles_are_exact(tmp_path):
+    """tile_impl.h: quantisation by one fma (every binary32 operand, four channel maxima) and the un-premultiply's shared-reciprocal
+    division (every alpha code of 8/10/12-bit planes, one binade of colours -- the sequence is scale-invariant)."""
+    exe = tmp_path / "verify_fp32_shortcuts"
+    subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", os.fspath(ROOT / "tests" / "tools" / "verify_fp32_shortcuts.cpp"), "-o", os.fspath(exe),
+                    "-lpthread"], check=True)
+    proc = subprocess.run([os.fspath(exe)], capture_output=True, text=True)
+    lines = proc.stdout.strip().splitlines()
+    assert proc.returncode == 0, proc.stdout[-2000:]
+    assert len(lines) == 4 + 2 * 3
+    assert all(line.endswith("mismatches=0") for line in lines), proc.stdout

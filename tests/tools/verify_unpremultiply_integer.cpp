@@ -47,6 +47,17 @@ int main()
                     ++tested;
                 }
             }
+            // the operands the kernels form for the two ends of the alpha range: a == 0 (the reference answers 0) divides 0 by 1, a == max (the
+            // reference leaves the channel alone) takes the general form and must return c for every c <= max (the kernels restore larger ones)
+            {
+                const volatile float rOneV = nudge(1.0f, ulps) * kUnpremultiplyBias, rMaxV = nudge(1.0f / (float)(2u * maxv), ulps) * kUnpremultiplyBias;
+                const float rOne = rOneV, rMax = rMaxV;
+                for (unsigned c = 0; c < cEnd; ++c) {
+                    badLow += (unpremultiplyByLowEstimateOperands(c, 0u, 1u, 0u, maxv, rOne) != 0u);
+                    if (c <= maxv)
+                        badLow += (unpremultiplyByLowEstimateOperands(c, maxv, 2u * maxv, 2u * maxv, maxv, rMax) != c);
+                }
+            }
             printf("max=%u ulps=%+d tested=%llu mismatches=%llu\n", maxv, ulps, tested, bad);
             printf("max=%u ulps=%+d low-estimate form tested=%llu mismatches=%llu\n", maxv, ulps, tested, badLow);
             failures += bad != 0 || badLow != 0;
