@@ -21,6 +21,15 @@ N > 1: one rank per GPU over RCCL (torch.distributed.run, launched by the driver
 started plainly with --gpus N > 1); every rank converts its own frames, there is no data-path collective ("scaling":
 "weak"); ranks only meet in the barriers around the timed regions.
 
+The line also carries, as first-class fields measured in the same run: "roofline.cold" (the same kernel with 12 frames cycled, 2.2 GB:
+nothing stays in the Infinity Cache), "fp32" (the built-in fp32 arithmetic, rgb.avoidLibYUV = 1, on the same frames) and "planes_4k"
+(3840x2160 planes, both arithmetics): the north star asks for 4K and 8K planes and the reference compiled from its own sources computes
+the fp32 arithmetic.
+
+  python bench.py --dry-run --gpus N   exercises the rank / aggregation code (process group, barriers, MAX over ranks, the single JSON
+  line, cfg5's tile blocks) WITHOUT a GPU over gloo with a converter that only sleeps; the line says "data": "dry-run" and its numbers
+  mean nothing (tests/test_bench_ranks.py).
+
 "roofline" describes the dominant kernel alone: algorithmic bytes per launch (5.5 B/pixel: each input sample read once,
 each output byte written once) divided by the kernel's average duration, measured with HIP events on the launch stream over
 back-to-back single-stream launches that cycle over the same 4 frames.  With 4 frames the 200 MB of input planes can stay in
@@ -66,6 +75,8 @@ def parse_args():
                          "10-bit tiles per step, its tiles sharded over the ranks (strong scaling, BASELINE.json configs[4])")
     ap.add_argument("--arithmetic", choices=("integer", "fp32"), default="integer",
                     help="integer: API defaults, libyuv's fixed point (default); fp32: rgb.avoidLibYUV = 1, libavif's built-in path")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: gloo process group and a converter that sleeps -- exercises the multi-rank plumbing only (numbers are meaningless)")
     return ap.parse_args()
 
 
@@ -131,11 +142,12 @@ def cpu_baseline(abi, synth, seconds: float):
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one per GPU)
     and hand back their exit code.  Fails loudly when the node has fewer than N GPUs."""
-    from libavif_amd import native
+    if "--dry-run" not in sys.argv:
+        from libavif_amd import native
 
-    have = native.load().avifhipDeviceCount()
-    if have < n:
-        raise SystemExit(f"bench.py: --gpus {n} requested but only {have} HIP device(s) are visible -- refusing to report a {n}-GPU number")
+        have = native.load().avifhipDeviceCount()
+        if have < n:
+            raise SystemExit(f"bench.py: --gpus {n} requested but only {have} HIP device(s) are visible -- refusing to report a {n}-GPU number")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -144,6 +156,65 @@ def spawn_ranks(n: int) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
+
+
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: communication libraries print banners through C stdio, which is block-buffered
+    when stdout is not a terminal -- without the flush on the way out the text would sit in the buffer and come out on the REAL stdout at
+    exit, after the JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
+class DryRunLib:
+    """--dry-run: stands in for libavifhip.so so that the rank / aggregation code runs where there is no GPU.  Converts nothing: every
+    conversion call sleeps for about a kernel's duration, every timing helper returns a constant."""
+
+    def __init__(self, world):
+        self._world = world
+
+    def avifhipDeviceCount(self):
+        return self._world
+
+    def avifhipLastError(self):
+        return b"dry run"
+
+    def avifhipLastTransferBytes(self, up, down):
+        up._obj.value, down._obj.value = 0, 0
+
+    def __getattr__(self, name):
+        if name.startswith("avifhipTime"):
+            return lambda *a: 0.03
+        if name in ("avifhipImageYUVToRGBAsync", "avifhipImageYUVToRGBBatchAsync", "avifhipImageYUVToRGBRects"):
+            def convert(*a):
+                time.sleep(30e-6)
+                return 0
+            return convert
+        if name == "avifhipStreamCreate":
+            return lambda *a: 1
+        if name.startswith("avifhip"):
+            return lambda *a: 0
+        raise AttributeError(name)
+
+
+class _HostOnly:
+    """--dry-run: what device.DeviceYUV / DeviceRGB hand to the timed loop, without device memory."""
+
+    def __init__(self, host):
+        self.struct = host.struct
 
 
 def median(xs):
@@ -164,7 +235,16 @@ def main():
     torch = None
     # (AVIFHIP_BENCH_FORCE_DIST=1: take the multi-rank code path -- torch + RCCL process group, barriers, max-over-ranks --
     # with a single rank too, to exercise it on a one-GPU box)
-    if world > 1 or os.environ.get("AVIFHIP_BENCH_FORCE_DIST") == "1":
+    if args.dry_run:
+        if world > 1:
+            import torch  # noqa: F811
+            import torch.distributed as dist  # noqa: F811
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            with _stdout_to_stderr():  # (gloo announces its connections on stdout, like RCCL its version)
+                dist.init_process_group(backend="gloo")
+                dist.barrier()
+    elif world > 1 or os.environ.get("AVIFHIP_BENCH_FORCE_DIST") == "1":
         # torch first: its bundled HIP runtime must be the one libavifhip.so binds to (same SONAME)
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
@@ -175,27 +255,20 @@ def main():
         torch.cuda.set_device(local_rank)
         # RCCL prints a version banner on STDOUT when its communicator comes up; the contract is ONE JSON line there, so
         # stdout points at stderr while the process group initialises and runs its first collective
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with _stdout_to_stderr():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            # RCCL writes the banner through C stdio, which is block-buffered when stdout is not a terminal: without this flush the
-            # text would sit in the buffer and come out on the REAL stdout at exit, after the JSON line
-            try:
-                C.CDLL(None).fflush(None)
-            except Exception:
-                pass
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
 
     from libavif_amd import abi, device, native, synth
 
-    lib = native.load()
+    global WIDTH, HEIGHT
+    if args.dry_run:
+        lib = DryRunLib(world)
+        native.last_kernel = lambda: "dry-run"
+        WIDTH, HEIGHT = 256, 128  # nothing is converted: token frames
+    else:
+        lib = native.load()
     if lib.avifhipDeviceCount() <= 0:
         raise SystemExit("bench.py: no HIP device visible -- there is no CPU fallback for the product path")
     native.check(lib.avifhipSetDevice(local_rank if world > 1 else 0), "avifhipSetDevice")
@@ -210,16 +283,19 @@ def main():
         return
 
     # ---- synthetic frames, resident in HBM before the timed region ----
-    frames = []
-    for f in range(DEEP_FRAMES):
-        img = abi.make_yuv(WIDTH, HEIGHT, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, abi.AVIF_MATRIX_COEFFICIENTS_BT709)
-        synth.fill_yuv(img, 0x12345678 + (rank * DEEP_FRAMES + f) % 4)  # 4 distinct contents are plenty: the buffers are what is cycled
-        rgb = abi.make_rgb(WIDTH, HEIGHT, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR,
-                           avoid_libyuv=not integer, allocate=False)
-        dimg = device.DeviceYUV(img)
-        drgb = device.DeviceRGB(rgb)
-        frames.append((dimg, drgb))
-        del img
+    def make_frames(w, h, count):
+        out = []
+        for f in range(count):
+            img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, abi.AVIF_MATRIX_COEFFICIENTS_BT709)
+            synth.fill_yuv(img, 0x12345678 + (rank * DEEP_FRAMES + f) % 4)  # 4 distinct contents are plenty: the buffers are what is cycled
+            rgb = abi.make_rgb(w, h, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR,
+                               avoid_libyuv=not integer, allocate=False)
+            out.append((_HostOnly(img), _HostOnly(rgb)) if args.dry_run else (device.DeviceYUV(img), device.DeviceRGB(rgb)))
+            del img
+        return out
+
+    frames = make_frames(WIDTH, HEIGHT, DEEP_FRAMES)
+    frames_4k = make_frames(WIDTH // 2, HEIGHT // 2, FRAMES_IN_FLIGHT)  # the north star's second plane size (3840x2160)
     n_streams = max(1, min(args.streams, FRAMES_IN_FLIGHT))
     streams = [lib.avifhipStreamCreate() for _ in range(n_streams)]
     if any(not s for s in streams):
@@ -240,7 +316,7 @@ def main():
 
     # ---- preheat: clocks up before anything is timed ----
     t_heat = time.perf_counter()
-    while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
+    while (time.perf_counter() - t_heat) * 1e3 < (0.0 if args.dry_run else args.preheat_ms):
         run(200)
         device_sync()
 
@@ -249,25 +325,31 @@ def main():
     kernel_name = native.last_kernel()
     elapsed = median(region_s)
 
-    # ---- dominant kernel: average launch duration from HIP events on the launch stream, single stream, back to back ----
+    # ---- kernels alone: average launch duration from HIP events on the launch stream, single stream, back to back ----
     n4, imgs4, rgbs4 = _cycle_args(frames[:FRAMES_IN_FLIGHT])
     nd, imgsd, rgbsd = _cycle_args(frames)
+    nk, imgsk, rgbsk = _cycle_args(frames_4k)
 
     def burst(fn, *a):
         # median of 9 event-timed bursts of 40 launches (not the best one: the figure must agree with a profiler's average)
         return median([fn(*a, 4, 40, None) for _ in range(9)])
 
-    kernel_ms_stream = burst(lib.avifhipTimeYUVToRGBCycle, n4, imgs4, rgbs4)
-    kernel_ms_deep = burst(lib.avifhipTimeYUVToRGBCycle, nd, imgsd, rgbsd)
-    kernel_ms_same = burst(lib.avifhipTimeYUVToRGB, frames[0][0].struct, frames[0][1].struct)
+    def set_arithmetic(use_integer: bool) -> None:
+        for _, drgb in frames + frames_4k:
+            drgb.struct.avoidLibYUV = 0 if use_integer else 1
 
-    # the other arithmetic family on the same frames (same buffers, only rgb.avoidLibYUV flipped), kernel timing only
-    for _, drgb in frames:
-        drgb.struct.avoidLibYUV = 1 if integer else 0
-    other_ms_stream = burst(lib.avifhipTimeYUVToRGBCycle, n4, imgs4, rgbs4)
-    other_kernel = native.last_kernel()
-    for _, drgb in frames:
-        drgb.struct.avoidLibYUV = 0 if integer else 1
+    timings = {}
+    for fam, use_integer in (("integer", True), ("fp32", False)):
+        set_arithmetic(use_integer)
+        t = {"warm": burst(lib.avifhipTimeYUVToRGBCycle, n4, imgs4, rgbs4)}
+        t["kernel"] = native.last_kernel()
+        t["cold"] = burst(lib.avifhipTimeYUVToRGBCycle, nd, imgsd, rgbsd)
+        t["same"] = burst(lib.avifhipTimeYUVToRGB, frames[0][0].struct, frames[0][1].struct)
+        t["4k"] = burst(lib.avifhipTimeYUVToRGBCycle, nk, imgsk, rgbsk)
+        timings[fam] = t
+    set_arithmetic(integer)
+    main_fam, other_fam = ("integer", "fp32") if integer else ("fp32", "integer")
+    kernel_ms_stream, kernel_ms_deep, kernel_ms_same = timings[main_fam]["warm"], timings[main_fam]["cold"], timings[main_fam]["same"]
 
     # the chip's ceiling for this byte movement: same bytes, same lane mapping, no arithmetic (overwrites the RGB buffers)
     ceil_ms_stream = burst(lib.avifhipTimeStreamCeiling, n4, imgs4, rgbs4)
@@ -277,10 +359,16 @@ def main():
     value = mp_per_step * args.steps * world / elapsed
     alg_bytes = ALGORITHMIC_BYTES_PER_PIXEL * WIDTH * HEIGHT
 
-    def gbps(ms):
-        return alg_bytes / (ms * 1e-3) / 1e9
+    def gbps(ms, pixels=WIDTH * HEIGHT):
+        return ALGORITHMIC_BYTES_PER_PIXEL * pixels / (ms * 1e-3) / 1e9
+
+    def block(ms, pixels=WIDTH * HEIGHT, **extra):
+        """{kernel_ms, achieved GB/s, fraction of the HBM peak, megapixels/s of the kernel alone}"""
+        return {"kernel_ms": round(ms, 5), "achieved": round(gbps(ms, pixels), 1), "frac": round(gbps(ms, pixels) / HBM_PEAK_GBPS, 4),
+                "value": round(pixels / 1e6 / (ms * 1e-3), 1), **extra}
 
     achieved = gbps(kernel_ms_stream)
+    px4k = (WIDTH // 2) * (HEIGHT // 2)
     out = {
         "metric": "megapixels/sec YUV420->RGBA (8K)",
         "value": round(value, 1),
@@ -293,10 +381,11 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "i16" if integer else "f32",  # the arithmetic the path computes in: libyuv's fixed point in packed int16 lanes / libavif's fp32
-        "data": "synthetic",
+        "data": "dry-run (no GPU, nothing converted: numbers are meaningless)" if args.dry_run else "synthetic",
         "value_basis": f"median of {len(region_s)} timed regions of {args.steps} steps each (min {1e3 * min(region_s) / args.steps:.5f}, max "
                        f"{1e3 * max(region_s) / args.steps:.5f} ms/step); steps are issued round-robin on {n_streams} HIP streams, so "
-                       f"consecutive frames overlap head and tail and ms_per_step can be below roofline.kernel_ms (one kernel alone, single stream)",
+                       f"consecutive frames overlap head and tail and ms_per_step can be below roofline.kernel_ms (one kernel alone, single stream); "
+                       f"the input planes of the {FRAMES_IN_FLIGHT} cycled frames can stay in the Infinity Cache -- roofline.cold is the figure without that help",
         "config": {
             "workload": "7680x4320 8-bit YUV420 BT.709 limited -> RGBA8, bilinear chroma upsampling, HBM-resident, "
                         f"{FRAMES_IN_FLIGHT} distinct frames cycled per rank on {n_streams} HIP streams",
@@ -315,9 +404,10 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": None,
+            "traffic_source": None,
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "kernel_ms": round(kernel_ms_stream, 5),
-            "kernel_ms_hbm_streaming": round(kernel_ms_stream, 5),  # (name kept from round 1)
+            "kernel_ms_inputs_cache_resident": round(kernel_ms_stream, 5),  # = kernel_ms: 4 frames cycled, their 200 MB of planes fit the 256 MB Infinity Cache
             "frames_cycled": FRAMES_IN_FLIGHT,
             "kernel_ms_same_frame": round(kernel_ms_same, 5),
             "frac_same_frame": round(gbps(kernel_ms_same) / HBM_PEAK_GBPS, 4),
@@ -327,35 +417,37 @@ def main():
                 "frac_of_peak": round(gbps(ceil_ms_stream) / HBM_PEAK_GBPS, 4),
                 "conversion_vs_ceiling": round(ceil_ms_stream / kernel_ms_stream, 4),
             },
-            "deep_streaming": {
-                "what": f"{DEEP_FRAMES} frames cycled (2.2 GB): neither planes nor pixels can stay in the 256 MB Infinity Cache",
-                "kernel_ms": round(kernel_ms_deep, 5),
-                "achieved": round(gbps(kernel_ms_deep), 1),
-                "frac": round(gbps(kernel_ms_deep) / HBM_PEAK_GBPS, 4),
-                "ceiling_kernel_ms": round(ceil_ms_deep, 5),
-                "ceiling_frac_of_peak": round(gbps(ceil_ms_deep) / HBM_PEAK_GBPS, 4),
-                "conversion_vs_ceiling": round(ceil_ms_deep / kernel_ms_deep, 4),
-            },
-            ("fp32_path" if integer else "integer_path"): {
-                "kernel": other_kernel,
-                "kernel_ms": round(other_ms_stream, 5),
-                "achieved": round(gbps(other_ms_stream), 1),
-                "frac": round(gbps(other_ms_stream) / HBM_PEAK_GBPS, 4),
-            },
+            "cold": block(kernel_ms_deep, what=f"{DEEP_FRAMES} frames cycled (2.2 GB): neither planes nor pixels can stay in the 256 MB Infinity Cache",
+                          frames_cycled=DEEP_FRAMES, ceiling_kernel_ms=round(ceil_ms_deep, 5),
+                          ceiling_frac_of_peak=round(gbps(ceil_ms_deep) / HBM_PEAK_GBPS, 4), conversion_vs_ceiling=round(ceil_ms_deep / kernel_ms_deep, 4)),
+        },
+        # the other arithmetic and the other plane size, measured in this run with the same method as roofline.kernel_ms
+        "fp32": block(timings["fp32"]["warm"], kernel=timings["fp32"]["kernel"], cold=block(timings["fp32"]["cold"]),
+                      what="rgb.avoidLibYUV = 1: libavif's built-in fp32 arithmetic (what the reference compiled from its own sources computes), same 8K frames"),
+        "integer": block(timings["integer"]["warm"], kernel=timings["integer"]["kernel"], cold=block(timings["integer"]["cold"]),
+                         what="API defaults: libyuv's fixed point (what a stock libavif computes), same 8K frames"),
+        "planes_4k": {
+            "what": f"3840x2160 planes, same configuration, {FRAMES_IN_FLIGHT} frames cycled, kernel alone ({int(ALGORITHMIC_BYTES_PER_PIXEL * px4k)} B per launch)",
+            "integer": block(timings["integer"]["4k"], px4k),
+            "fp32": block(timings["fp32"]["4k"], px4k),
         },
     }
+    # (names of round 2's line, kept for the profile tooling)
+    out["roofline"]["deep_streaming"] = out["roofline"]["cold"]
+    out["roofline"]["fp32_path" if integer else "integer_path"] = {k: out[other_fam][k] for k in ("kernel", "kernel_ms", "achieved", "frac")}
     traffic_file = ROOT / "profiles" / "pmc_traffic.json"
-    if traffic_file.exists():
+    if traffic_file.exists() and not args.dry_run:
         try:
             tj = json.loads(traffic_file.read_text())
-            # the counters were collected for one kernel: use them only when that kernel is the one reported
+            # the counters were collected for one kernel in a separate rocprofv3 --pmc run: use them only when that kernel is the one reported
             if tj.get("kernel_family", "") == kernel_name:
                 out["roofline"]["traffic"] = tj.get("traffic_bytes_per_launch")
+                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; not measured in this run)"
         except Exception:
             pass
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(abi, synth, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
@@ -368,21 +460,23 @@ def main():
 
 def timed_regions(run_steps, sync, steps, warmup, repeats, dist, torch):
     """The contract's timed region, `repeats` times: warm-up steps, barrier + sync, EXACTLY `steps` steps, sync, MAX over ranks."""
+    on_gpu = dist is not None and dist.get_backend() != "gloo"  # (--dry-run meets over gloo, without a device)
     region_s = []
     for _ in range(max(1, repeats)):
         run_steps(warmup)
         sync()
         if dist is not None:
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
             dist.barrier()
         t0 = time.perf_counter()
         run_steps(steps)
         sync()
-        if dist is not None:
+        if on_gpu:
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
             dist.barrier()
@@ -402,11 +496,14 @@ def run_cfg5(args, lib, rank, world, dist, torch):
     W, H, TW, TH = 15360, 8640, 1920, 1080
     rects = farm.grid_rects(W, H, TW, TH)
     mine = farm.shard(len(rects), rank, world)
-    canvas = abi.make_yuv(W, H, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, abi.AVIF_MATRIX_COEFFICIENTS_BT709)
-    synth.fill_yuv(canvas, 0x12345678)  # the same decoded canvas on every rank
-    rgb_host = abi.make_rgb(W, H, 10, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, avoid_libyuv=False)
-    dimg = device.DeviceYUV(canvas)
-    drgb = device.DeviceRGB(rgb_host)
+    dry = args.dry_run
+    # (--dry-run: nothing is converted -- a token canvas, the tile list and the sharding are the real ones)
+    canvas = abi.make_yuv(W, H, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, abi.AVIF_MATRIX_COEFFICIENTS_BT709, allocate=not dry)
+    if not dry:
+        synth.fill_yuv(canvas, 0x12345678)  # the same decoded canvas on every rank
+    rgb_host = abi.make_rgb(W, H, 10, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, avoid_libyuv=False, allocate=not dry)
+    dimg = _HostOnly(canvas) if dry else device.DeviceYUV(canvas)
+    drgb = _HostOnly(rgb_host) if dry else device.DeviceRGB(rgb_host)
     n = len(mine)
     imgs = (C.POINTER(abi.avifImage) * max(n, 1))(*[C.pointer(dimg.struct)] * n)
     rgbs = (C.POINTER(abi.avifRGBImage) * max(n, 1))(*[C.pointer(drgb.struct)] * n)
@@ -427,7 +524,7 @@ def run_cfg5(args, lib, rank, world, dist, torch):
                 native.check(lib.avifhipImageYUVToRGBRects(canvas.struct, rgb_host.struct, host_crops, n), "avifhipImageYUVToRGBRects")
 
     t_heat = time.perf_counter()
-    while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:
+    while (time.perf_counter() - t_heat) * 1e3 < (0.0 if dry else args.preheat_ms):
         run_device(20)
         sync()
     steps = min(args.steps, 200)
@@ -456,7 +553,7 @@ def run_cfg5(args, lib, rank, world, dist, torch):
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "dry-run (no GPU, nothing converted: numbers are meaningless)" if dry else "synthetic",
         "value_basis": f"median of {len(region_s)} timed regions of {steps} canvases each (min {1e3 * min(region_s) / steps:.4f}, max {1e3 * max(region_s) / steps:.4f} "
                        f"ms/canvas), MAX over ranks; canvas and pixels resident in every rank's HBM",
         "config": {

@@ -87,54 +87,14 @@ inline bool verifiedChromaDenominator(float d)
     return false;
 }
 
-// Un-premultiply on integers (src/alpha.c:367-381: min(floorf((float)c * maxF / (float)a + 0.5f), maxF), 0 < a < max) without the three IEEE
-// divides per pixel.  For channel maxima up to 4095, c * maxF is exact in binary32 and the rounded quotient cannot cross a half-integer (a
-// quotient with denominator a < max is at least 1 / (2a) away from one, the rounding moves it by less), so the result is the integer
-//      q = floor((2 * c * max + a) / (2 * a)),  clamped to max.
-// q is formed from ANY estimate r of 1 / (2a) that is good to a few ulp (the kernels use v_rcp_f32) and one correction step with the exact
-// remainder; quotients far beyond max, where the estimate's error exceeds the step, clamp whatever the step does.  Established -- for r
-// perturbed by up to +-2 ulp -- by exhaustive enumeration of every (c, a) with c any 16-bit code and 0 < a < max, max in {255, 1023, 4095}
-// (tests/tools/verify_unpremultiply_integer.cpp, run by tests/test_exact_division.py).  Depth 16 keeps the IEEE divide (c * 65535.0f rounds).
-// constexpr: callable from host and device code alike.
-constexpr unsigned unpremultiplyByEstimate(unsigned c, unsigned a, unsigned maxv, float r)
-{
-    const unsigned d = 2u * a;                                         // a < 4095: 13 bits
-    const unsigned n = (c & 0xffffu) * ((2u * maxv) & 0x3fffu) + a;    // < 2^30
-    const unsigned q0 = (unsigned)((float)n * r);                      // < 2^29; within 1 of the quotient wherever the quotient is near max or below
-    const int rem = (int)(n - (q0 & 0xffffffu) * (d & 0xffffffu));     // 24-bit multiply: exact for q0 < 2^24, beyond that the result clamps anyway
-    const unsigned q = rem < 0 ? q0 - 1u : ((unsigned)rem >= d ? q0 + 1u : q0);
-    return q < maxv ? q : maxv;
-}
-// The same quotient from an estimate that is deliberately LOW: rLow = estimate * kUnpremultiplyBias, so that whatever the estimate's (few ulp of)
-// error the truncated product can only be the quotient or one short of it, and the correction is one compare and one add
-// (three instructions per channel fewer than the two-sided form; enumerated by the same tool, a == max included).
-constexpr float kUnpremultiplyBias = 0.99999952316284179688f; // 1 - 2^-21
-// (general operands: d = 2a and mul = 2 * max for 0 < a <= max -- a == max returns c, the reference's "opaque pixels are left alone" -- and
-// d = 1, mul = 0 for a == 0, which returns 0 like the reference: the callers form them once per pixel)
-constexpr unsigned unpremultiplyByLowEstimateOperands(unsigned c, unsigned a, unsigned d, unsigned mul, unsigned maxv, float rLow)
-{
-    const unsigned n = (c & 0xffffu) * (mul & 0x3fffu) + a;
-    const unsigned q0 = (unsigned)((float)n * rLow);
-    const unsigned rem = n - (q0 & 0xffffffu) * (d & 0xffffffu);
-    const unsigned q = q0 + (rem >= d ? 1u : 0u);
-    return q < maxv ? q : maxv;
-}
-constexpr unsigned unpremultiplyByLowEstimate(unsigned c, unsigned a, unsigned maxv, float rLow)
-{
-    return unpremultiplyByLowEstimateOperands(c, a, 2u * a, 2u * maxv, maxv, rLow);
-}
-
 // floor(65536 / a) for 0 < a < 256 (ARGBUnattenuate's table of reciprocals) from an estimate r of 1 / a good to a
-// few ulp and one correction step with the exact remainder -- instead of the 32-bit integer division sequence.  Same enumeration.
+// few ulp and one correction step with the exact remainder -- instead of the 32-bit integer division sequence.  Enumerated for every a with
+// the estimate off by up to 2 ulp (tests/tools/verify_unpremultiply_integer.cpp).
 constexpr unsigned quotient65536ByEstimate(unsigned a, float r)
 {
     const unsigned q0 = (unsigned)(65536.0f * r);
     const int rem = (int)(65536u - (q0 & 0xffffffu) * (a & 0xffu));
     return rem < 0 ? q0 - 1u : ((unsigned)rem >= a ? q0 + 1u : q0);
-}
-inline bool unpremultiplyIntegerCovers(int maxv)
-{
-    return maxv == 255 || maxv == 1023 || maxv == 4095;
 }
 
 } // namespace avifhip

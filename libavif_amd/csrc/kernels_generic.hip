@@ -370,29 +370,21 @@ __device__ __forceinline__ unsigned premultiplyExact(unsigned c, unsigned a, uns
 }
 
 // which arithmetic an instantiation of the 16-byte kernel carries (one each: the five of them in one body made 12,000 instructions)
-enum { AMUL_FX_MULTIPLY = 0, AMUL_FX_UNMULTIPLY, AMUL_EXACT_MULTIPLY, AMUL_IEEE_MULTIPLY, AMUL_IEEE_UNMULTIPLY, AMUL_INT_UNMULTIPLY };
+enum { AMUL_FX_MULTIPLY = 0, AMUL_FX_UNMULTIPLY, AMUL_EXACT_MULTIPLY, AMUL_IEEE_MULTIPLY, AMUL_IEEE_UNMULTIPLY, AMUL_RCP_UNMULTIPLY };
 
 // what a pixel's alpha contributes to its three colour channels
 struct AlphaOperand
 {
     unsigned a;
-    // AMUL_INT_UNMULTIPLY (exactdiv.h: unpremultiplyByLowEstimateOperands): divisor 2a, the numerator's factor 2 * max, and an estimate of
-    // 1 / (2a) biased low; a == 0 divides 0 by 1 (the reference's result, 0); a >= max is held to max, which returns the channel itself
-    unsigned d, mul;
-    float rLow;
-    unsigned ia; // AMUL_FX_UNMULTIPLY: ARGBUnattenuate's 8.8 reciprocal of a (pixel_fixed.h: fxUnattenuateReciprocal)
+    UnpremulRcp rcp; // AMUL_RCP_UNMULTIPLY: the pixel's exact reciprocal (pixel_math.h)
+    unsigned ia;     // AMUL_FX_UNMULTIPLY: ARGBUnattenuate's 8.8 reciprocal of a (pixel_fixed.h: fxUnattenuateReciprocal)
 };
 template <int VARIANT>
-__device__ __forceinline__ AlphaOperand alphaOperand(unsigned a, unsigned maxv)
+__device__ __forceinline__ AlphaOperand alphaOperand(unsigned a)
 {
-    AlphaOperand A = { a, 0u, 0u, 0.0f, 0u };
-    if constexpr (VARIANT == AMUL_INT_UNMULTIPLY) {
-        const unsigned am = min(a, maxv);
-        A.a = am;
-        A.d = am ? 2u * am : 1u;
-        A.mul = am ? 2u * maxv : 0u;
-        A.rLow = __builtin_amdgcn_rcpf((float)A.d) * kUnpremultiplyBias;
-    }
+    AlphaOperand A = { a, { 0.0f, 0.0f }, 0u };
+    if constexpr (VARIANT == AMUL_RCP_UNMULTIPLY)
+        A.rcp = unpremulRcp((float)(a ? a : 1u));
     if constexpr (VARIANT == AMUL_FX_UNMULTIPLY)
         A.ia = fxUnattenuateReciprocal(a);
     return A;
@@ -407,12 +399,56 @@ __device__ __forceinline__ unsigned alphaMulChannel(const RgbSide & o, unsigned 
         return fxUnattenuateBy(c, A.ia); // the pixel's reciprocal formed once
     } else if constexpr (VARIANT == AMUL_EXACT_MULTIPLY) {
         return premultiplyExact(c, A.a, maxv, o.rcpMax);
-    } else if constexpr (VARIANT == AMUL_INT_UNMULTIPLY) {
-        // (opaque pixels, which the reference leaves alone whatever their colour bits, are restored per pixel by the caller: src/alpha.c:367-373)
-        return unpremultiplyByLowEstimateOperands(c, A.a, A.d, A.mul, maxv, A.rLow);
+    } else if constexpr (VARIANT == AMUL_RCP_UNMULTIPLY) {
+        // (transparent and opaque pixels, which the reference answers with 0 / leaves alone, are settled per pixel by the caller: src/alpha.c:367-373)
+        return min((unsigned)unpremulRcpArg((float)c, A.rcp, maxf), maxv);
     } else {
         return alphaMulInt(c, A.a, maxv, maxf, VARIANT == AMUL_IEEE_MULTIPLY ? MUL_MULTIPLY : MUL_UNMULTIPLY);
     }
+}
+
+// AMUL_RCP_UNMULTIPLY on the four 8-bit pixels of a group: bytes in and out without integer detours -- v_cvt_f32_ubyteN reads a channel
+// straight from the pixel word, v_cvt_pk_u8_f32 under round-toward-zero (the floor of the non-negative argument, saturated at 255: the
+// reference's min) writes it back in place; the alpha byte rides along in the word.
+__device__ __forceinline__ void unpremultiplyGroup8(unsigned (&v)[4], bool alphaFirst)
+{
+    float t[4][3];
+    unsigned keep[4], zero[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned w = v[q];
+        const unsigned a = alphaFirst ? (w & 0xffu) : (w >> 24);
+        const UnpremulRcp R = unpremulRcp(a ? (float)a : 1.0f);
+        // the three colour bytes: 1 and 2 always, and the one at the other end from alpha
+        t[q][0] = unpremulRcpArg((float)((w >> 8) & 0xffu), R, 255.0f);
+        t[q][1] = unpremulRcpArg((float)((w >> 16) & 0xffu), R, 255.0f);
+        t[q][2] = unpremulRcpArg(alphaFirst ? (float)(w >> 24) : (float)(w & 0xffu), R, 255.0f);
+        keep[q] = (a == 255u) ? 1u : 0u; // opaque: left alone
+        zero[q] = (a == 0u) ? 1u : 0u;   // transparent: colours 0
+    }
+    unsigned o[4] = { v[0], v[1], v[2], v[3] };
+    const unsigned slotEnd = alphaFirst ? 3u : 0u;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %7, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %10, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %13, 1, %3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %11, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %14, 2, %3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, %16, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, %16, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %12, %16, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %15, %16, %3\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])
+                 : "v"(t[0][0]), "v"(t[0][1]), "v"(t[0][2]), "v"(t[1][0]), "v"(t[1][1]), "v"(t[1][2]), "v"(t[2][0]), "v"(t[2][1]), "v"(t[2][2]),
+                   "v"(t[3][0]), "v"(t[3][1]), "v"(t[3][2]), "s"(slotEnd));
+    const unsigned alphaMask = alphaFirst ? 0x000000ffu : 0xff000000u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        v[q] = keep[q] ? v[q] : (zero[q] ? (v[q] & alphaMask) : o[q]);
 }
 
 // the N pixels of one 16-byte group; alpha is channel 0 (alphaFirst) or channel 3, channels 1 and 2 are colours either way
@@ -421,30 +457,34 @@ __device__ __forceinline__ void alphaMulGroup(const AlphaMulPlan & p, unsigned (
 {
     const RgbSide & o = p.rgb;
     constexpr uint32_t N = (sizeof(CT) == 1) ? 4 : 2; // pixels per group
+    if constexpr (sizeof(CT) == 1 && VARIANT == AMUL_RCP_UNMULTIPLY) {
+        unpremultiplyGroup8(v, alphaFirst);
+        return;
+    }
 #pragma unroll
     for (uint32_t q = 0; q < N; ++q) {
         if constexpr (sizeof(CT) == 1) {
             const unsigned w = v[q];
             const unsigned b0 = w & 0xffu, b3 = w >> 24;
-            const unsigned a = alphaFirst ? b0 : b3;
-            const AlphaOperand A = alphaOperand<VARIANT>(a, 255u);
+            const AlphaOperand A = alphaOperand<VARIANT>(alphaFirst ? b0 : b3);
             const unsigned m1 = alphaMulChannel<VARIANT>(o, (w >> 8) & 0xffu, A, 255u, 255.0f);
             const unsigned m2 = alphaMulChannel<VARIANT>(o, (w >> 16) & 0xffu, A, 255u, 255.0f);
             const unsigned mx = alphaMulChannel<VARIANT>(o, alphaFirst ? b3 : b0, A, 255u, 255.0f); // the colour at the other end
             v[q] = (alphaFirst ? (b0 | (mx << 24)) : (mx | (b3 << 24))) | (m1 << 8) | (m2 << 16);
-            // (8-bit channels cannot exceed the maximum: an opaque pixel comes out as itself)
         } else {
             const unsigned lo = v[2 * q], hi = v[2 * q + 1];
             const unsigned c0 = lo & 0xffffu, c3 = hi >> 16;
             const unsigned a = alphaFirst ? c0 : c3;
-            const AlphaOperand A = alphaOperand<VARIANT>(a, (unsigned)o.maxv);
+            const AlphaOperand A = alphaOperand<VARIANT>(a);
             const unsigned m1 = alphaMulChannel<VARIANT>(o, lo >> 16, A, (unsigned)o.maxv, o.maxf);
             const unsigned m2 = alphaMulChannel<VARIANT>(o, hi & 0xffffu, A, (unsigned)o.maxv, o.maxf);
             const unsigned mx = alphaMulChannel<VARIANT>(o, alphaFirst ? c3 : c0, A, (unsigned)o.maxv, o.maxf);
             v[2 * q] = (alphaFirst ? c0 : mx) | (m1 << 16), v[2 * q + 1] = m2 | ((alphaFirst ? mx : c3) << 16);
-            if constexpr (VARIANT == AMUL_INT_UNMULTIPLY) {
+            if constexpr (VARIANT == AMUL_RCP_UNMULTIPLY) {
                 if (a >= (unsigned)o.maxv) // opaque: left alone, stray bits above the depth included
                     v[2 * q] = lo, v[2 * q + 1] = hi;
+                else if (a == 0u) // transparent: colours 0
+                    v[2 * q] = alphaFirst ? c0 : 0u, v[2 * q + 1] = alphaFirst ? 0u : (c3 << 16);
             }
         }
     }
@@ -485,14 +525,14 @@ __global__ __launch_bounds__(256) void alphaMulWideKernel(AlphaMulPlan p)
             alphaMulGroup<CT, VARIANT>(p, v, slotA == 0);
             *reinterpret_cast<u4v *>(px) = u4v { v[0], v[1], v[2], v[3] };
         } else if (i < p.width) { // the row's last, partial group: the plain forms of the same results
-            constexpr int kEdge = (VARIANT == AMUL_EXACT_MULTIPLY) ? (int)AMUL_IEEE_MULTIPLY : (VARIANT == AMUL_INT_UNMULTIPLY) ? (int)AMUL_IEEE_UNMULTIPLY : VARIANT;
+            constexpr int kEdge = (VARIANT == AMUL_EXACT_MULTIPLY) ? (int)AMUL_IEEE_MULTIPLY : (VARIANT == AMUL_RCP_UNMULTIPLY) ? (int)AMUL_IEEE_UNMULTIPLY : VARIANT;
             for (uint32_t q = 0; i + q < p.width; ++q) {
                 CT * c = reinterpret_cast<CT *>(px) + 4 * q;
                 const unsigned a = c[slotA];
                 for (uint32_t ch = 0; ch < 4; ++ch)
                     if (ch != slotA)
                         c[ch] = (VARIANT == AMUL_FX_UNMULTIPLY) ? (CT)fxAlphaMul(c[ch], a, MUL_UNMULTIPLY)
-                                                                : (CT)alphaMulChannel<kEdge>(o, c[ch], alphaOperand<kEdge>(a, (unsigned)o.maxv), (unsigned)o.maxv, o.maxf);
+                                                                : (CT)alphaMulChannel<kEdge>(o, c[ch], alphaOperand<kEdge>(a), (unsigned)o.maxv, o.maxf);
             }
         }
     }
@@ -627,7 +667,7 @@ hipError_t launchAlphaMulGeneric(const AlphaMulPlan & plan, hipStream_t stream)
         const uint32_t groups = (o.chanBytes == 1) ? (plan.width + 3) / 4 : (plan.width + 1) / 2;
         const dim3 grid = gridFor((groups + kAlphaMulGroups - 1) / kAlphaMulGroups, plan.height, block);
         const int variant = (plan.arith == ARITH_LIBYUV) ? (plan.unmultiply ? AMUL_FX_UNMULTIPLY : AMUL_FX_MULTIPLY)
-                            : plan.unmultiply            ? (unpremultiplyIntegerCovers(o.maxv) ? AMUL_INT_UNMULTIPLY : AMUL_IEEE_UNMULTIPLY)
+                            : plan.unmultiply            ? (plan.exactDiv ? AMUL_RCP_UNMULTIPLY : AMUL_IEEE_UNMULTIPLY)
                             : plan.exactDiv              ? AMUL_EXACT_MULTIPLY
                                                          : AMUL_IEEE_MULTIPLY;
         if (o.chanBytes == 1) {
@@ -636,7 +676,7 @@ hipError_t launchAlphaMulGeneric(const AlphaMulPlan & plan, hipStream_t stream)
                 case AMUL_FX_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_FX_UNMULTIPLY>), grid, block, 0, stream, plan); break;
                 case AMUL_EXACT_MULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_EXACT_MULTIPLY>), grid, block, 0, stream, plan); break;
                 case AMUL_IEEE_MULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_IEEE_MULTIPLY>), grid, block, 0, stream, plan); break;
-                case AMUL_INT_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_INT_UNMULTIPLY>), grid, block, 0, stream, plan); break;
+                case AMUL_RCP_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_RCP_UNMULTIPLY>), grid, block, 0, stream, plan); break;
                 default: hipLaunchKernelGGL((alphaMulWideKernel<uint8_t, AMUL_IEEE_UNMULTIPLY>), grid, block, 0, stream, plan); break;
             }
         } else {
@@ -644,7 +684,7 @@ hipError_t launchAlphaMulGeneric(const AlphaMulPlan & plan, hipStream_t stream)
                 case AMUL_EXACT_MULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint16_t, AMUL_EXACT_MULTIPLY>), grid, block, 0, stream, plan); break;
                 case AMUL_IEEE_MULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint16_t, AMUL_IEEE_MULTIPLY>), grid, block, 0, stream, plan); break;
                 case AMUL_IEEE_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint16_t, AMUL_IEEE_UNMULTIPLY>), grid, block, 0, stream, plan); break;
-                case AMUL_INT_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint16_t, AMUL_INT_UNMULTIPLY>), grid, block, 0, stream, plan); break;
+                case AMUL_RCP_UNMULTIPLY: hipLaunchKernelGGL((alphaMulWideKernel<uint16_t, AMUL_RCP_UNMULTIPLY>), grid, block, 0, stream, plan); break;
                 default: hipLaunchKernelGGL(alphaMulGenericKernel, gridFor(plan.width, plan.height, block), block, 0, stream, plan); break;
             }
         }

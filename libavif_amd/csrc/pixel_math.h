@@ -159,6 +159,31 @@ __device__ __forceinline__ unsigned alphaMulInt(unsigned c, unsigned a, unsigned
     return (mulMode == MUL_MULTIPLY) ? premultiplyInt(c, a, maxf) : unpremultiplyInt(c, a, maxf);
 }
 
+// Un-premultiply on stored integers WITHOUT the IEEE division sequence (tiled kernels and the 16-byte in-place pass).  The reference's
+// min(floorf((float)c * maxF / (float)a + 0.5f), maxF) (src/alpha.c:367-381) divides the three colours of a pixel by the same alpha, so the
+// reciprocal is formed once: v_rcp_f32 (1 ulp) and one Newton step give r = RN(1 / a) for every alpha code, and then
+//      q = fma(fma(-q0, a, x), r, q0),  q0 = x * r,  x = RN(c * maxF)
+// IS the correctly rounded x / a (Markstein's correction step) -- enumerated for every 16-bit code c and every 0 < a < max, max in
+// {255, 1023, 4095, 65535}, reciprocal estimates off by up to 2 ulp (tests/tools/verify_fp32_shortcuts.cpp).  Five full-rate fp32
+// instructions per channel: on gfx950 fp32 add / mul / fma issue in ~2.8 cycles per wave, conversions and integer operations in ~4.3
+// (profiles/r03_valu_rate.txt), which is why this beats the integer form with its remainder test.
+struct UnpremulRcp
+{
+    float af, r;
+};
+__device__ __forceinline__ UnpremulRcp unpremulRcp(float af) // af: the alpha code as a float, not 0
+{
+    const float r0 = __builtin_amdgcn_rcpf(af);
+    return { af, __builtin_fmaf(__builtin_fmaf(-af, r0, 1.0f), r0, r0) };
+}
+// ... the argument of the final truncation: x / a + 0.5f (the caller truncates and holds the result to max)
+__device__ __forceinline__ float unpremulRcpArg(float cf, const UnpremulRcp & R, float maxf)
+{
+    const float x = cf * maxf;
+    const float q0 = x * R.r;
+    return __builtin_fmaf(__builtin_fmaf(-q0, R.af, x), R.r, q0) + 0.5f;
+}
+
 // alpha depth rescale, src/alpha.c:93-96
 __device__ __forceinline__ unsigned rescaleAlpha(unsigned srcAlpha, float srcMaxF, float dstMaxF, int dstMax)
 {

@@ -282,27 +282,21 @@ __device__ __forceinline__ float inLoopChannelIeee(const TileArgs & A, float c, 
 // The integer post-pass of the reference's fast paths (src/alpha.c:180-192, :367-381) on one pixel's quantised colours.
 //   multiply:   floorf(c * a / maxF + 0.5f) with "/ maxF" in the verified reciprocal form; a == 0 needs no special case (0 / maxF + 0.5f
 //               truncates to 0); a >= max leaves the pixel untouched (:180-183).
-//   unmultiply: exactdiv.h's unpremultiplyByLowEstimate for channel maxima up to 4095 -- the pixel's 1 / (2a) from v_rcp_f32, biased low, one
-//               compare-and-add per channel; a == max needs no special case (the quotient is c), a > max (stray bits above the depth in a 16-bit
-//               container) is held to max, which returns c like the reference's `a >= max` test, and a == 0 divides 0 by 1.
-//               Depth 16 keeps the IEEE division (c * 65535.0f rounds).
+//   unmultiply: min(floorf(c * maxF / a + 0.5f), maxF) with the pixel's exact reciprocal formed once (pixel_math.h unpremulRcp: every
+//               depth); a == 0 answers 0, a >= max leaves the channel alone (:367-373).
 struct PostAlpha
 {
-    unsigned a, d, mul;
-    float af, rLow;
+    unsigned a;
+    float af;
+    UnpremulRcp rcp;
 };
 template <bool UNMUL>
 __device__ __forceinline__ PostAlpha postAlpha(const TileArgs & A, unsigned a)
 {
     PostAlpha P;
-    P.a = a, P.af = (float)a, P.d = 0, P.mul = 0, P.rLow = 0.0f;
-    if constexpr (UNMUL) {
-        const unsigned am = minU(a, A.rgbMax);
-        P.a = am;
-        P.d = am ? 2u * am : 1u;
-        P.mul = am ? 2u * A.rgbMax : 0u;
-        P.rLow = __builtin_amdgcn_rcpf((float)P.d) * kUnpremultiplyBias;
-    }
+    P.a = a, P.af = (float)a, P.rcp = { 0.0f, 0.0f };
+    if constexpr (UNMUL)
+        P.rcp = unpremulRcp(a ? P.af : 1.0f);
     return P;
 }
 template <bool UNMUL>
@@ -312,17 +306,9 @@ __device__ __forceinline__ unsigned postChannel(const TileArgs & A, unsigned c, 
         const unsigned m = truncU32(divExact((float)c * P.af, A.rcpRgbMax) + 0.5f);
         return (P.a >= A.rgbMax) ? c : m;
     } else {
-        return unpremultiplyByLowEstimateOperands(c, P.a, P.d, P.mul, A.rgbMax, P.rLow);
+        const unsigned q = minU(truncU32(unpremulRcpArg((float)c, P.rcp, A.rgbMaxF)), A.rgbMax);
+        return (P.a >= A.rgbMax) ? c : (P.a == 0u ? 0u : q);
     }
-}
-// ... depth 16: the reference's own expression
-__device__ __forceinline__ unsigned postChannelIeee(const TileArgs & A, unsigned c, unsigned a)
-{
-    if (a >= A.rgbMax)
-        return c;
-    if (a == 0)
-        return 0;
-    return unpremultiplyInt(c, a, A.rgbMaxF);
 }
 
 // RGB output is written once and never read back by the kernel: non-temporal stores keep 130+ MB of it from
@@ -990,16 +976,12 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                         const PostAlpha P = postAlpha<false>(A, a[i]);
                         q[i].r = postChannel<false>(A, q[i].r, P), q[i].g = postChannel<false>(A, q[i].g, P), q[i].b = postChannel<false>(A, q[i].b, P);
                     }
-                } else if (postMode == MUL_UNMULTIPLY && A.rgbMax <= 4095u) {
+                } else if (postMode == MUL_UNMULTIPLY) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const PostAlpha P = postAlpha<true>(A, a[i]);
                         q[i].r = postChannel<true>(A, q[i].r, P), q[i].g = postChannel<true>(A, q[i].g, P), q[i].b = postChannel<true>(A, q[i].b, P);
                     }
-                } else if (postMode == MUL_UNMULTIPLY) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        q[i].r = postChannelIeee(A, q[i].r, a[i]), q[i].g = postChannelIeee(A, q[i].g, a[i]), q[i].b = postChannelIeee(A, q[i].b, a[i]);
                 }
                 emitQ(q);
             } else {

@@ -30,27 +30,16 @@ def test_every_listed_divisor_is_exact(tmp_path):
     assert all(line.endswith("mismatches=0") for line in lines), proc.stdout
 
 
-def test_integer_unpremultiply_equals_the_float_expression(tmp_path):
-    """exactdiv.h: unpremultiplyByEstimate / quotient65536ByEstimate, every operand pair, reciprocal estimates off by up to 2 ulp."""
-    exe = tmp_path / "verify_unpremultiply_integer"
-    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", os.fspath(ROOT / "libavif_amd" / "csrc"),
-                    os.fspath(ROOT / "tests" / "tools" / "verify_unpremultiply_integer.cpp"), "-o", os.fspath(exe)], check=True)
-    proc = subprocess.run([os.fspath(exe)], capture_output=True, text=True)
-    lines = proc.stdout.strip().splitlines()
-    assert proc.returncode == 0, proc.stdout[-2000:]
-    assert len(lines) == 2 * 3 * 5 + 5
-    assert all(line.endswith("mismatches=0") for line in lines), proc.stdout
-
-
 @pytest.mark.skipif(not _has_fma(), reason="host CPU lacks FMA")
 def test_fp32_shortcuts_of_the_tiles_are_exact(tmp_path):
-    """tile_impl.h: quantisation by one fma (every binary32 operand, four channel maxima) and the un-premultiply's shared-reciprocal
-    division (every alpha code of 8/10/12-bit planes, one binade of colours -- the sequence is scale-invariant)."""
+    """tile_impl.h / pixel_math.h / exactdiv.h: quantisation by one fma (every binary32 operand, four channel maxima); the un-premultiply's
+    shared-reciprocal division in fp32 (every alpha code of 8/10/12-bit planes, one binade of colours -- the sequence is scale-invariant)
+    and on integers (every code pair of every depth); ARGBUnattenuate's reciprocal from an estimate."""
     exe = tmp_path / "verify_fp32_shortcuts"
-    subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", os.fspath(ROOT / "tests" / "tools" / "verify_fp32_shortcuts.cpp"), "-o", os.fspath(exe),
-                    "-lpthread"], check=True)
+    subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", "-I", os.fspath(ROOT / "libavif_amd" / "csrc"),
+                    os.fspath(ROOT / "tests" / "tools" / "verify_fp32_shortcuts.cpp"), "-o", os.fspath(exe), "-lpthread"], check=True)
     proc = subprocess.run([os.fspath(exe)], capture_output=True, text=True)
     lines = proc.stdout.strip().splitlines()
     assert proc.returncode == 0, proc.stdout[-2000:]
-    assert len(lines) == 4 + 2 * 3
+    assert len(lines) == 4 + 2 * 3 + 2 * 4 + 5
     assert all(line.endswith("mismatches=0") for line in lines), proc.stdout

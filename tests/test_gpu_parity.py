@@ -217,7 +217,7 @@ def test_exhaustive_alpha_pairs_8bit(hip):
 @pytest.mark.parametrize("depth,fmt", [(10, abi.AVIF_RGB_FORMAT_RGBA), (10, abi.AVIF_RGB_FORMAT_ARGB), (12, abi.AVIF_RGB_FORMAT_BGRA)])
 def test_exhaustive_alpha_pairs_10_and_12_bit(hip, depth, fmt):
     """Every (colour, alpha) pair of a 10- / 12-bit channel, both directions: the un-premultiply direction runs on integers
-    (libavif_amd/csrc/exactdiv.h: unpremultiplyByEstimate), which has to equal the reference's float expression everywhere."""
+    (pixel_math.h: unpremulRcp, the shared exact reciprocal), which has to equal the reference's float expression everywhere."""
     o, be = H.oracle_backend(), H.HipDeviceBackend()
     n = 1 << depth
     a_first = fmt == abi.AVIF_RGB_FORMAT_ARGB

@@ -1,5 +1,6 @@
-/* verify_fp32_shortcuts.cpp -- test tool (not shipped).  Enumerates the two instruction-saving identities the fp32 tiles
- * (libavif_amd/csrc/tile_impl.h) rely on, with the host's IEEE arithmetic (hardware FMA: build with -mfma -ffp-contract=off):
+/* verify_fp32_shortcuts.cpp -- test tool (not shipped).  Enumerates the instruction-saving identities the fp32 tiles
+ * (libavif_amd/csrc/tile_impl.h) and the alpha passes (kernels_generic.hip, pixel_math.h, pixel_fixed.h) rely on, with the host's IEEE
+ * arithmetic (hardware FMA: build with -mfma -ffp-contract=off -I libavif_amd/csrc):
  *
  * 1. quantizeArg: the reference quantises a channel as (T)(0.5f + (c * max)) -- a multiply, an add, a truncation
  *    (src/reformat.c:952-961).  The kernels compute fmaf(c, max, 0.5f): ONE rounding.  Checked: both truncate (and saturate to
@@ -14,6 +15,13 @@
  *    in c -- scaling c by a power of two scales q0, the remainder and q by the same power as long as nothing leaves the normal range --
  *    so one binade of c stands for all of them down to 2^-100, far below anything the matrix can produce (its terms are multiples of 2^-70).
  *
+ * 3. unpremulRcp / unpremulRcpArg: the integer post-pass min(floorf((float)c * maxF / (float)a + 0.5f), maxF) (src/alpha.c:367-381) with the
+ *    same shared-reciprocal division, x = RN(c * maxF) over the integer a.  Checked for every 16-bit code c (8-bit codes for max 255) and
+ *    every 0 < a < max, max in {255, 1023, 4095, 65535} -- 4.6e9 pairs -- reciprocal estimates off by up to 2 ulp.
+ *
+ * 4. quotient65536ByEstimate (exactdiv.h): floor(65536 / a), ARGBUnattenuate's 8.8 reciprocal, from an estimate of 1 / a off by up to
+ *    2 ulp, against the integer division, every 0 < a < 256.
+ *
  * Prints one line per case ending in "mismatches=0"; exit status 1 otherwise.
  */
 #include <atomic>
@@ -23,6 +31,8 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+
+#include "exactdiv.h"
 
 static inline float fromBits(uint32_t u)
 {
@@ -120,6 +130,46 @@ int main(int argc, char ** argv)
         printf("shared reciprocal max=%u reciprocal mismatches=%llu\n", maxv, (unsigned long long)badRcp.load());
         printf("shared reciprocal max=%u quotients tested=%llu mismatches=%llu\n", maxv, (unsigned long long)tested.load(), (unsigned long long)bad.load());
         failures += bad != 0 || badRcp != 0;
+    }
+    const unsigned pixelMaxima[4] = { 255u, 1023u, 4095u, 65535u };
+    for (unsigned maxv : pixelMaxima) {
+        const float maxF = (float)maxv;
+        const unsigned cEnd = (maxv == 255u) ? 256u : 65536u; // 8-bit channels cannot hold more; 16-bit containers can hold any code
+        std::atomic<uint64_t> bad { 0 }, badRcp { 0 }, tested { 0 };
+        parallel(nt, [&](unsigned t) {
+            uint64_t b = 0, br = 0, n = 0;
+            for (unsigned a = 1 + t; a < maxv; a += nt) {
+                const float af = (float)a;
+                const float r = (float)(1.0 / (double)a); // a < 2^16: the double quotient rounds to the correctly rounded binary32 reciprocal
+                for (int ulps = -2; ulps <= 2; ++ulps) {
+                    const float r0 = fromBits((uint32_t)((int32_t)toBits(r) + ulps));
+                    br += fmaf(fmaf(-af, r0, 1.0f), r0, r0) != r;
+                }
+                for (unsigned c = 0; c < cEnd; ++c, ++n) {
+                    const volatile float xv = (float)c * maxF; // (volatile: one rounding per operation, as the reference is written)
+                    const float x = xv;
+                    const float q0 = x * r;
+                    const float mine = floorf(fmaf(fmaf(-q0, af, x), r, q0) + 0.5f);
+                    const volatile float quotient = x / af;
+                    const float want = floorf(quotient + 0.5f);
+                    b += (mine < maxF ? mine : maxF) != (want < maxF ? want : maxF);
+                }
+            }
+            bad += b, badRcp += br, tested += n;
+        });
+        printf("integer unpremultiply max=%u reciprocal mismatches=%llu\n", maxv, (unsigned long long)badRcp.load());
+        printf("integer unpremultiply max=%u tested=%llu mismatches=%llu\n", maxv, (unsigned long long)tested.load(), (unsigned long long)bad.load());
+        failures += bad != 0 || badRcp != 0;
+    }
+
+    for (int ulps = -2; ulps <= 2; ++ulps) { // ARGBUnattenuate's reciprocals
+        unsigned long long bad = 0, tested = 0;
+        for (unsigned a = 1; a < 256; ++a, ++tested) {
+            const float r = fromBits((uint32_t)((int32_t)toBits(1.0f / (float)a) + ulps));
+            bad += avifhip::quotient65536ByEstimate(a, r) != 65536u / a;
+        }
+        printf("quotient65536 ulps=%+d tested=%llu mismatches=%llu\n", ulps, tested, bad);
+        failures += bad != 0;
     }
     return failures ? 1 : 0;
 }
