@@ -331,7 +331,12 @@ def main():
     nk, imgsk, rgbsk = _cycle_args(frames_4k)
 
     def burst(fn, *a):
-        # median of 9 event-timed bursts of 40 launches (not the best one: the figure must agree with a profiler's average)
+        # 40 ms of the SAME kernel first: after a change of kernel the first ~10 ms of launches run up to 25 % slower (tests/tools/
+        # sustain_probe.py, profiles/r03_sustain_probe.txt: the fp32 kernel 39.9, 34.8, 38.3 ... us per launch before it settles at 32-33),
+        # then the median of 9 event-timed bursts of 40 launches (not the best one: the figure must agree with a profiler's average)
+        spent = 0.0
+        while spent < 40.0:
+            spent += max(fn(*a, 0, 100, None), 1e-3) * 100
         return median([fn(*a, 4, 40, None) for _ in range(9)])
 
     def set_arithmetic(use_integer: bool) -> None:

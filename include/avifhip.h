@@ -271,7 +271,8 @@ AVIFHIP_API avifResult avifhipGridYUVToRGBTransformedAsync(const avifhipGrid * g
 
 /* The payload of a Y4M frame as y4mWrite emits it (apps/shared/y4m.c:603-618): planes Y, U, V (and A when `withAlpha`: 8-bit 4:4:4
  * only, like the reference), every row cut to its width, 16-bit samples little-endian as stored.  `frame`: device memory of
- * avifhipY4MFrameBytes(image, withAlpha) bytes.  The header line is the application's. */
+ * avifhipY4MFrameBytes(image, withAlpha) bytes -- 0 for every combination the packer refuses (depths other than 8 / 10 / 12, alpha
+ * outside 8-bit 4:4:4): the two entry points agree on what a frame is.  The header line is the application's. */
 AVIFHIP_API size_t avifhipY4MFrameBytes(const avifImage * image, avifBool withAlpha);
 AVIFHIP_API avifResult avifhipImagePackY4MFrameAsync(const avifImage * image, avifBool withAlpha, uint8_t * frame, void * hipStream);
 /* The row data avifPNGWrite hands to libpng (apps/shared/avifpng.c:865-880) in the byte order of the PNG stream: pixel rows

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 
+#include <unistd.h>
+
 using namespace avifhip;
 using namespace avifhip::api;
 
@@ -153,9 +155,59 @@ avifResult hipFailed(hipError_t e, const char * what)
 }
 
 
+namespace {
+// destroys whatever a failed first-time ensureContext() managed to create, so that the next call starts from scratch
+void discardPartialContext()
+{
+    auto dropStream = [](hipStream_t & s) {
+        if (s)
+            (void)hipStreamDestroy(s);
+        s = nullptr;
+    };
+    auto dropEvent = [](hipEvent_t & e) {
+        if (e)
+            (void)hipEventDestroy(e);
+        e = nullptr;
+    };
+    dropStream(tls.stream), dropStream(tls.upStream), dropStream(tls.downStream);
+    for (int b = 0; b < Context::kMaxBands; ++b)
+        dropEvent(tls.bandUp[b]), dropEvent(tls.bandDone[b]);
+    for (int k = 0; k < Context::kTableRing; ++k)
+        dropEvent(tls.tableCopied[k]), dropEvent(tls.tableConsumed[k]), dropEvent(tls.uploadCopied[k]);
+    dropEvent(tls.scratchUsed);
+    (void)hipGetLastError();
+    tls.ready = false;
+}
+
+avifResult buildContext()
+{
+    HIP_TRY(hipStreamCreateWithFlags(&tls.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&tls.upStream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&tls.downStream, hipStreamNonBlocking));
+    for (int b = 0; b < Context::kMaxBands; ++b) {
+        HIP_TRY(hipEventCreateWithFlags(&tls.bandUp[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&tls.bandDone[b], hipEventDisableTiming));
+    }
+    for (int k = 0; k < Context::kTableRing; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&tls.tableCopied[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&tls.tableConsumed[k], hipEventDisableTiming));
+    }
+    for (int k = 0; k < Context::kTableRing; ++k)
+        HIP_TRY(hipEventCreateWithFlags(&tls.uploadCopied[k], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&tls.scratchUsed, hipEventDisableTiming));
+    return AVIF_RESULT_OK;
+}
+} // namespace
+
 avifResult ensureContext()
 {
-    if (tls.stream) {
+    if (tls.ready && tls.ownerPid != (int)getpid()) {
+        // a fork()ed child (Python multiprocessing's default start method) inherits the parent's context: its streams belong to a runtime
+        // the child does not have, and its download helper thread does not exist here -- waiting for it would block forever.  Nothing of it
+        // can be released from this side; the child starts over with a context of its own.
+        lease.context = new Context;
+    }
+    if (tls.ready) {
         // The context's stream and scratch belong to tls.device.  A host application that shares the thread (torch, anything
         // driving several GPUs) may have made another device current since the last call: allocations would then land on that
         // device while the kernels run on this one.  The thread is switched back (and stays there: avifhip.h, avifhipSetDevice).
@@ -175,20 +227,18 @@ avifResult ensureContext()
         HIP_TRY(hipSetDevice(tls.device));
     else
         HIP_TRY(hipGetDevice(&tls.device));
-    HIP_TRY(hipStreamCreateWithFlags(&tls.stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&tls.upStream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&tls.downStream, hipStreamNonBlocking));
-    for (int b = 0; b < Context::kMaxBands; ++b) {
-        HIP_TRY(hipEventCreateWithFlags(&tls.bandUp[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&tls.bandDone[b], hipEventDisableTiming));
+    // all or nothing: contexts are pooled and recycled to other threads for the life of the process, so a context whose creation failed
+    // half way (an event that could not be created) must not look initialised -- what exists is destroyed and the next call retries
+    const avifResult built = buildContext();
+    if (built != AVIF_RESULT_OK) {
+        char keep[sizeof(tls.lastError)];
+        memcpy(keep, tls.lastError, sizeof(keep));
+        discardPartialContext();
+        memcpy(tls.lastError, keep, sizeof(keep));
+        return built;
     }
-    for (int k = 0; k < Context::kTableRing; ++k) {
-        HIP_TRY(hipEventCreateWithFlags(&tls.tableCopied[k], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&tls.tableConsumed[k], hipEventDisableTiming));
-    }
-    for (int k = 0; k < Context::kTableRing; ++k)
-        HIP_TRY(hipEventCreateWithFlags(&tls.uploadCopied[k], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&tls.scratchUsed, hipEventDisableTiming));
+    tls.ownerPid = (int)getpid();
+    tls.ready = true;
     return AVIF_RESULT_OK;
 }
 
@@ -996,6 +1046,12 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
     const avifImage * first = colorTiles[0];
     if (!first || !first->width || !first->height)
         return AVIF_RESULT_INVALID_ARGUMENT;
+    if (grid->outputWidth >= 65536u || grid->outputHeight >= 65536u) {
+        // the seam kernel divides canvas coordinates by the tile size with a 32-bit multiply-high (kernels_generic.hip GridReader::divBy),
+        // exact only below 65536; libavif's own default limits (16384^2 pixels, 32768 per side) are far inside
+        setError("grid canvases of 65536 pixels or more per side are not supported (%u x %u)", grid->outputWidth, grid->outputHeight);
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    }
     const uint32_t tw = first->width, th = first->height;
     // the grid must cover the output and no tile may lie entirely outside it (ISO/IEC 23008-12 6.6.2.3.1, src/read.c:1538-1560)
     if ((uint64_t)tw * grid->columns < grid->outputWidth || (uint64_t)th * grid->rows < grid->outputHeight ||
@@ -1757,6 +1813,12 @@ extern "C" size_t avifhipY4MFrameBytes(const avifImage * image, avifBool withAlp
 {
     if (!image)
         return 0;
+    // the frame avifhipImagePackY4MFrameAsync would write: no frame (0) for what it refuses -- depths y4mWrite does not support, alpha
+    // outside 8-bit 4:4:4 (apps/shared/y4m.c:487-489, :570-572)
+    if (image->depth != 8 && image->depth != 10 && image->depth != 12)
+        return 0;
+    if (withAlpha && (!image->alphaPlane || !image->alphaRowBytes || image->depth != 8 || image->yuvFormat != AVIF_PIXEL_FORMAT_YUV444))
+        return 0;
     const PlaneGeometry g = planeGeometry(image);
     size_t total = 0;
     for (int p = 0; p < 4; ++p) {
@@ -1832,7 +1894,7 @@ extern "C" avifResult avifhipRGBImagePackPNGRowsAsync(const avifRGBImage * rgb, 
 
 extern "C" avifResult avifhipSetDevice(int device)
 {
-    if (tls.stream && tls.device != device) {
+    if (tls.ready && tls.device != device) {
         // the thread's context lives on another device: hand it back and lease one of `device`
         HIP_TRY(hipStreamSynchronize(tls.stream));
         {

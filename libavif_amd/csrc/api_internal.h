@@ -102,6 +102,8 @@ private:
 struct Context
 {
     int device = -1;
+    bool ready = false; // streams and events all exist (ensureContext commits only a completely built context)
+    int ownerPid = 0;   // the process that built it: a fork()ed child must not use the parent's streams or wait for its helper thread
     hipStream_t stream = nullptr;
     // host-resident calls split large images into row bands: uploads and downloads of different bands run on these two while
     // `stream` computes (api.cpp: yuvToRgbSync)

@@ -32,6 +32,7 @@ R2YKey keyFor(const RgbToYuvPlan & p)
     k.wideRgb = p.rgb.chanBytes == 2;
     k.wideYuv = p.yuv.chanBytes == 2;
     k.nch = p.rgb.hasAlpha ? 4 : 3;
+    k.hasMul = p.mul != MUL_NONE;
     switch (p.yuv.format) {
         case AVIF_PIXEL_FORMAT_YUV444: k.sub = SUB_444; break;
         case AVIF_PIXEL_FORMAT_YUV422: k.sub = SUB_422; break;
@@ -45,8 +46,8 @@ const char * kernelNameFor(const R2YKey & k)
 {
     static thread_local char name[96];
     static const char * subs[] = { "444", "422", "420", "400" };
-    snprintf(name, sizeof(name), "%s<%s%d,%s,%s>", k.fixedPoint ? "rgb2yuv_fixed_tile" : "rgb2yuv_tile", k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8,
-             k.wideYuv ? "u16" : "u8", subs[k.sub]);
+    snprintf(name, sizeof(name), "%s<%s%d,%s,%s%s>", k.fixedPoint ? "rgb2yuv_fixed_tile" : "rgb2yuv_tile", k.nch == 4 ? "rgba" : "rgb", k.wideRgb ? 16 : 8,
+             k.wideYuv ? "u16" : "u8", subs[k.sub], k.hasMul ? ",alphamul" : "");
     return name;
 }
 
@@ -56,12 +57,19 @@ bool tileRgbToYuvSupported(const RgbToYuvPlan & p)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
-    if (p.mul != MUL_NONE || o.isGray || o.is565)
+    if (o.isGray || o.is565)
         return false;
+    if (p.mul != MUL_NONE && (p.arith != ARITH_FLOAT || !o.hasAlpha))
+        return false; // pending alpha (un)multiply: 4-channel sources of the fp32 arithmetic (libyuv is never asked: src/reformat.c:255)
     if (p.arith == ARITH_FLOAT) {
         if (s.mode == MODE_IDENTITY) {
             // lossless RGB as GBR planes (avifenc -l): no matrix, one division (channel / maximum); 4:4:4 or monochrome only
             if (!s.exactDiv || (s.format != AVIF_PIXEL_FORMAT_YUV444 && s.format != AVIF_PIXEL_FORMAT_YUV400))
+                return false;
+        } else if (s.mode == MODE_YCGCO || s.mode == MODE_YCGCO_RE || s.mode == MODE_YCGCO_RO) {
+            // three adds on the normalised channels / integer lifting on the codes and "/ range": the channel maximum and the ranges must be
+            // on the verified list
+            if (!s.exactDiv)
                 return false;
         } else {
             if (s.mode != MODE_COEFF)
@@ -113,6 +121,9 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
     A.rcpRgbMax = o.rcpMax, A.rcpCbDen = s.rcpCbDen, A.rcpCrDen = s.rcpCrDen;
     A.rangeY = s.rangeY, A.biasY = s.biasY, A.rangeUV = s.rangeUV, A.biasUV = s.biasUV;
     A.identity = (p.arith == ARITH_FLOAT && s.mode == MODE_IDENTITY) ? 1 : 0;
+    A.matrixMode = (p.arith == ARITH_FLOAT) ? s.mode : MODE_COEFF;
+    A.rcpRangeY = s.rcpRangeY, A.rcpRangeUV = s.rcpRangeUV, A.rgbMaxF = o.maxf;
+    A.mulMode = p.mul;
     if (A.identity)
         A.rangeUV = s.rangeY, A.biasUV = s.biasY; // src/reformat.c:205-211: identity quantises chroma like luma
     A.yuvMax = (uint32_t)s.maxv, A.yuvMaxF = (float)s.maxv;

@@ -184,8 +184,10 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
             if (p.inLoopMul != MUL_NONE || p.postMul != MUL_NONE || s.chanBytes != 1 || o.chanBytes != 1 || s.format != AVIF_PIXEL_FORMAT_YUV444)
                 return false;
         } else {
-            // matrix coefficients, or the identity matrix at any depth / range (GBR planes: 4:4:4; without chroma every matrix is the same)
-            if (s.mode != MODE_COEFF && !(s.mode == MODE_IDENTITY && (s.format == AVIF_PIXEL_FORMAT_YUV444 || !s.hasColor)))
+            // matrix coefficients, the identity matrix at any depth / range (GBR planes: 4:4:4; without chroma every matrix is the same), or the
+            // YCgCo family (three adds / integer lifting per pixel)
+            const bool ycgco = s.mode == MODE_YCGCO || s.mode == MODE_YCGCO_RE || s.mode == MODE_YCGCO_RO;
+            if (s.mode != MODE_COEFF && !ycgco && !(s.mode == MODE_IDENTITY && (s.format == AVIF_PIXEL_FORMAT_YUV444 || !s.hasColor)))
                 return false;
             if (!s.exactDiv)
                 return false; // a divisor off the verified list (exactdiv.h): the universal kernel divides the IEEE way
@@ -204,10 +206,12 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
             return false;
     }
     if (o.map.on) {
-        // fused crop / rotate / mirror: the packed 16-bit kernels store through the map; every other family leaves it to the
-        // universal kernel (the entry points convert into scratch and run the transform pass instead: api.cpp)
+        // fused crop / rotate / mirror: the packed 16-bit kernels (3- and 4-byte pixels) and the wave-private fp32 kernels (4-channel pixels of
+        // 4 or 8 bytes: tile_map_impl.h) store through the map; every other family leaves it to the universal kernel (the entry points
+        // convert into scratch and run the transform pass instead: api.cpp)
         const bool packed = p.arith == ARITH_LIBYUV && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE && (s.chanBytes == 1 || (p.tuning & TUNE_COOPERATIVE) == 0);
-        if (!packed || (o.pixBytes != 4 && o.pixBytes != 3))
+        const bool fp32Mapped = p.arith != ARITH_LIBYUV && !o.isGray && !o.is565 && o.hasAlpha && (o.pixBytes == 4 || o.pixBytes == 8);
+        if (!(packed && (o.pixBytes == 4 || o.pixBytes == 3)) && !fp32Mapped)
             return false;
         if (((uintptr_t)o.pixels % 4) != 0 || (o.rowBytes % 4) != 0)
             return false;

@@ -2,10 +2,10 @@
 // src/reformat.c:275-470 + the alpha plane pass :545-569), instantiated by kernels_r2y_tile_*.hip.
 //
 // Scope: interleaved 3- or 4-channel RGB at 8-bit or 16-bit containers into 8-bit or 16-bit-container 4:4:4 / 4:2:2 /
-// 4:2:0 / 4:0:0 planes with the matrix-coefficient ("normal YUV") transform, no alpha (un)multiply, with the alpha
-// plane (copy / depth rescale / opaque fill) written in the same pass.  Gray sources, identity / YCgCo matrices, pending
-// alpha multiplies, unaligned buffers, divisors off the verified list and the <= 3 columns / <= 1 row that do not fill
-// a 4x2 pixel group go to kernels_generic.hip.
+// 4:2:0 / 4:0:0 planes with the matrix-coefficient ("normal YUV") transform, the identity matrix, YCgCo and YCgCo-Re / -Ro, a pending alpha
+// multiply / un-multiply on the normalised channels (src/reformat.c:325-358), with the alpha plane (copy / depth rescale / opaque fill)
+// written in the same pass; gray sources in their own kernel at the end of this file.  Unaligned buffers, divisors off the verified
+// list and the <= 3 columns / <= 1 row that do not fill a 4x2 pixel group go to kernels_generic.hip.
 //
 // Structure: wave = 64 lanes; a lane owns 4 consecutive pixels of 2 rows (two 2x2 chroma blocks): one 16-byte load per
 // row for RGBA8 (1 KiB contiguous per wave instruction), one 4-byte luma (and alpha) store per row, one 2-byte store per
@@ -191,6 +191,45 @@ __device__ __forceinline__ void storeRow4(uint8_t * base, uint32_t off, f2 t01, 
     }
 }
 
+// Pending alpha (un)multiply on the normalised channels of a pixel pair (src/reformat.c:325-358); a = alpha / max.
+//   multiply:   a == 0 -> 0, a < 1 -> c * a, else c: the product with min(a, 1) is all three cases.
+//   unmultiply: a == 0 -> 0, a < 1 -> min(c / a, 1), else c.  The three divisions share their divisor: r = RN(1 / a) from v_rcp_f32 and one
+//               Newton step, then q = fma(fma(-q0, a, c), r, q0), q0 = c * r, is the correctly rounded quotient -- enumerated for every pair
+//               of channel codes (c, a) of every depth (tests/tools/verify_fp32_shortcuts.cpp).
+__device__ __forceinline__ float unmulChannel(float c, float d, float r, bool below1, bool zero)
+{
+    const float q0 = c * r;
+    const float q = __builtin_fmaf(__builtin_fmaf(-q0, d, c), r, q0);
+    const float m = below1 ? fminf(q, 1.0f) : c;
+    return zero ? 0.0f : m;
+}
+__device__ __forceinline__ void alphaOnPair(bool multiply, f2 a, f2 & x, f2 & g, f2 & z)
+{
+    if (multiply) {
+        const f2 am = { fminf(a.x, 1.0f), fminf(a.y, 1.0f) };
+        x = x * am, g = g * am, z = z * am;
+        return;
+    }
+    float xs[2] = { x.x, x.y }, gs[2] = { g.x, g.y }, zs[2] = { z.x, z.y };
+    const float as[2] = { a.x, a.y };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool zero = as[h] == 0.0f, below1 = as[h] < 1.0f;
+        const float d = (zero || !below1) ? 1.0f : as[h];
+        const float r0 = __builtin_amdgcn_rcpf(d);
+        const float r = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+        xs[h] = unmulChannel(xs[h], d, r, below1, zero), gs[h] = unmulChannel(gs[h], d, r, below1, zero), zs[h] = unmulChannel(zs[h], d, r, below1, zero);
+    }
+    x = (f2) { xs[0], xs[1] }, g = (f2) { gs[0], gs[1] }, z = (f2) { zs[0], zs[1] };
+}
+// (int)avifRoundf(AVIF_CLAMP(c * maxF, 0, maxF)): a normalised channel back to its code for the YCgCo-R lifting, src/reformat.c:375-377
+__device__ __forceinline__ int liftCode(float c, float maxf)
+{
+    const float v = c * maxf;
+    const float cl = (v < 0.0f) ? 0.0f : ((maxf < v) ? maxf : v);
+    return (int)floorf(cl + 0.5f);
+}
+
 template <typename RT, int NCH, typename YT, int SUB, bool SWAP>
 __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S)
 {
@@ -225,12 +264,40 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
             const f2 x = div2((f2) { (float)c0[0], (float)c0[1] }, A.rcpRgbMax);
             const f2 G = div2((f2) { (float)c1[0], (float)c1[1] }, A.rcpRgbMax);
             const f2 z = div2((f2) { (float)c2[0], (float)c2[1] }, A.rcpRgbMax);
-            const f2 R = SWAP ? z : x, B = SWAP ? x : z;
-            if (A.identity) { // wave-uniform: GBR planes (lossless RGB), src/reformat.c:362-366 -- Y = G, U = B, V = R, all three on luma's scale
+            f2 xs = x, Gs = G, zs = z;
+            if constexpr (NCH == 4) {
+                if (A.mulMode != MUL_NONE) { // wave-uniform: pending alpha (un)multiply on the normalised channels, src/reformat.c:325-358
+                    unsigned ca[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        ca[h] = channelOf<RT, NCH>(S.row[r], 2 * p + h, alphaFirst ? 0 : 3);
+                    const f2 a = div2((f2) { (float)ca[0], (float)ca[1] }, A.rcpRgbMax);
+                    alphaOnPair(A.mulMode == MUL_MULTIPLY, a, xs, Gs, zs);
+                }
+            }
+            const f2 R = SWAP ? zs : xs, B = SWAP ? xs : zs;
+            const f2 G2 = Gs;
+            if (A.matrixMode == MODE_YCGCO) { // wave-uniform, src/reformat.c:368-372: 0.5 G +- 0.25 (R + B), 0.5 (R - B)
+                const f2 hg = splat2(0.5f) * G2, q = splat2(0.25f) * (R + B);
+                U[r][p] = hg - q, V[r][p] = splat2(0.5f) * (R - B);
+                tY[r][p] = unormOperand(hg + q, A.rangeY, A.biasY);
+            } else if (A.matrixMode == MODE_YCGCO_RE || A.matrixMode == MODE_YCGCO_RO) { // integer lifting on the channel codes, :373-383
+                float yv[2], uv2[2], vv[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int Ri = liftCode(h ? R.y : R.x, A.rgbMaxF), Gi = liftCode(h ? G2.y : G2.x, A.rgbMaxF), Bi = liftCode(h ? B.y : B.x, A.rgbMaxF);
+                    const int Co = Ri - Bi, t = Bi + (Co >> 1), Cg = Gi - t;
+                    yv[h] = divExact((float)(t + (Cg >> 1)), A.rcpRangeY);
+                    uv2[h] = divExact((float)Cg, A.rcpRangeUV);
+                    vv[h] = divExact((float)Co, A.rcpRangeUV);
+                }
+                U[r][p] = (f2) { uv2[0], uv2[1] }, V[r][p] = (f2) { vv[0], vv[1] };
+                tY[r][p] = unormOperand((f2) { yv[0], yv[1] }, A.rangeY, A.biasY);
+            } else if (A.identity) { // wave-uniform: GBR planes (lossless RGB), src/reformat.c:362-366 -- Y = G, U = B, V = R, all three on luma's scale
                 U[r][p] = B, V[r][p] = R;
-                tY[r][p] = unormOperand(G, A.rangeY, A.biasY);
+                tY[r][p] = unormOperand(G2, A.rangeY, A.biasY);
             } else {
-                const f2 Y = ((splat2(A.kr) * R) + (splat2(A.kg) * G)) + (splat2(A.kb) * B); // :383
+                const f2 Y = ((splat2(A.kr) * R) + (splat2(A.kg) * G2)) + (splat2(A.kb) * B); // :383
                 U[r][p] = div2(B - Y, A.rcpCbDen); // (B - Y) / (2 * (1 - kb)), :384
                 V[r][p] = div2(R - Y, A.rcpCrDen); // (R - Y) / (2 * (1 - kr)), :385
                 tY[r][p] = unormOperand(Y, A.rangeY, A.biasY);

@@ -36,6 +36,13 @@ struct R2YArgs
     int32_t alphaMode;
     uint32_t stripsPerWave;
     uint32_t identity; // identity matrix: the planes are G, B, R, each quantised on luma's scale (rangeUV / biasUV hold luma's)
+    // the other matrices without coefficients (src/reformat.c:368-381): MODE_YCGCO (three adds on the normalised channels) and
+    // MODE_YCGCO_RE / _RO (integer lifting on the channel codes, then "/ range" in the verified reciprocal form); MODE_COEFF otherwise
+    int32_t matrixMode;
+    RcpHL rcpRangeY, rcpRangeUV;
+    float rgbMaxF;
+    // pending alpha (un)multiply, applied to the normalised channels before the matrix (src/reformat.c:325-358); 4-channel sources only
+    int32_t mulMode;
     // fixed-point kernels (libyuv's 8-bit BT.601 arithmetic), coefficients per MEMORY-order colour
     // channel (c0 = first colour byte, c1 = G, c2 = third colour byte), so that no channel swap is needed:
     //   Y = (y0*c0 + y1*c1 + y2*c2 + yBias) >> 8,  U = (u0*m0 + u1*m1 + u2*m2 + 0x8000) >> 8,  V likewise,
@@ -53,6 +60,7 @@ struct R2YKey
     bool fixedPoint; // libyuv arithmetic: 8-bit RGB -> 8-bit planes
     bool wideRgb, wideYuv;
     int nch, sub;
+    bool hasMul; // pending alpha (un)multiply (kernel name only: a wave-uniform branch inside the kernels)
 };
 
 hipError_t launchR2YTileRgb8(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);

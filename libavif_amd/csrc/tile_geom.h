@@ -18,6 +18,9 @@ struct PkGeom
     uint32_t magicTilesX; // ceil(2^32 / tilesX): tile / tilesX == mulhi(tile, magic) while tile * tilesX < 2^32; 0 when tilesX == 1
     uint32_t chunk;       // tiles per XCD chunk (a few tile rows), 0 = plain raster order
     uint32_t magicChunk;
+    // quarter turns (launches that store through a transposing PixelMap): tiles are numbered DOWN the columns of the tile grid and a chunk is
+    // one tile column, so the workgroups an XCD runs one after the other write neighbouring pieces of the same destination rows
+    uint32_t columnMajor, tilesY, magicTilesY;
 };
 
 // (The index arithmetic below is constexpr -- callable from host and device code alike -- so that tests/tools/geometry_check.cpp can walk
@@ -48,7 +51,12 @@ __attribute__((always_inline)) constexpr PkPlace pkPlaceOf(uint32_t tile, uint32
 {
     const uint32_t wx = wave & ((1u << g.wavesXLog2) - 1u), wy = wave >> g.wavesXLog2;
     const uint32_t wavesY = 4u >> g.wavesXLog2;
-    const uint32_t trow = g.magicTilesX ? mulHi32(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
+    uint32_t trow = 0, tcol = 0;
+    if (g.columnMajor) {
+        tcol = g.magicTilesY ? mulHi32(tile, g.magicTilesY) : tile, trow = tile - tcol * g.tilesY;
+    } else {
+        trow = g.magicTilesX ? mulHi32(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
+    }
     return PkPlace { (tcol << g.wavesXLog2) + wx, (trow * wavesY + wy) * ns };
 }
 
@@ -81,7 +89,10 @@ inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t 
     g->nTiles = g->tilesX * tilesY;
     auto magic = [](uint32_t d) { return d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0u; };
     g->magicTilesX = magic(g->tilesX);
-    g->chunk = L.chunkRows * g->tilesX;
+    g->columnMajor = L.transposed ? 1u : 0u;
+    g->tilesY = tilesY, g->magicTilesY = magic(tilesY);
+    // magic divisions are exact while tile * divisor < 2^32: tiles number far fewer than 2^16 (32768-pixel sides: 128 x 4096)
+    g->chunk = L.transposed ? (L.chunkRows ? tilesY : 0u) : L.chunkRows * g->tilesX;
     g->magicChunk = magic(g->chunk);
     *nsw = ns;
     // chunked order: padded to whole groups of 8 chunks (workgroups beyond the last tile leave at once)

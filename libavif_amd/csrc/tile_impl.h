@@ -36,6 +36,7 @@
 #include "exactdiv.h"
 #include "pixel_math.h"
 #include "tile_geom.h"
+#include "tile_map_impl.h"
 #include "tile_shared.h"
 
 namespace avifhip {
@@ -528,6 +529,24 @@ __device__ __forceinline__ void packRgb8Row(unsigned w[3], const float x[4], con
                    "v"(z[3]));
 }
 
+// YCgCo family, one pixel: (first colour, green, third colour) unclamped from normalised luma, the two normalised chroma samples in plane
+// order (`u` plane, `v` plane of TileArgs) and the luma code (src/reformat.c:853-871).
+__device__ __forceinline__ void ycgcoPixel(const TileArgs & A, float Y, f2 uvp, unsigned unormY, float & X, float & G, float & Z)
+{
+    const float cg = A.cgFirst ? uvp.x : uvp.y, co = A.cgFirst ? uvp.y : uvp.x;
+    float R, B;
+    if (A.ycgco == 1) {
+        const float t = Y - cg;
+        G = Y + cg, B = t - co, R = t + co;
+    } else { // YCgCo-Re / -Ro: lifting on integers, then "/ maxF" in the verified reciprocal form
+        const int Cg = (int)floorf((cg * A.yuvMaxF) + 0.5f), Co = (int)floorf((co * A.yuvMaxF) + 0.5f);
+        const int t = (int)unormY - (Cg >> 1);
+        const int gi = clampI(t + Cg, 0, (int)A.rgbMax), bi = clampI(t - (Co >> 1), 0, (int)A.rgbMax), ri = clampI(bi + Co, 0, (int)A.rgbMax);
+        G = divExact((float)gi, A.rcpRgbMax), B = divExact((float)bi, A.rcpRgbMax), R = divExact((float)ri, A.rcpRgbMax);
+    }
+    X = A.cgFirst ? B : R, Z = A.cgFirst ? R : B; // cgFirst <=> blue is the first colour channel
+}
+
 // Raw (undecoded) data of one strip (256 pixels x 2 rows) as loaded by one lane.
 template <typename YT, int SUB, bool BIL, bool NEEDA>
 struct StripRaw
@@ -660,10 +679,18 @@ __device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, 
     }
 }
 
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, int WAVES = 4>
+// MAP (4-channel pixels, wave-private tiles only): stores go through the job's PixelMap (tile_map_impl.h) -- MAP_ROWS: rows stay rows, stored
+// straight away; MAP_TURNED: quarter turns, into `held` (2 * NS rows of the lane's four pixels, 4 * PW words each), which the caller
+// transposes through LDS.  Separate instantiations: the rows of a whole tile held in registers cost the row-wise kernels their occupancy.
+enum MapMode : int { MAP_NONE = 0, MAP_ROWS = 1, MAP_TURNED = 2 };
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, int WAVES = 4, int MAP = MAP_NONE>
 __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & c, uint32_t tileY,
-                                            const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS, WAVES> & T, f2 (*rows)[kRowPitch], WideRowExchange * xchg)
+                                            const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS, WAVES> & T, f2 (*rows)[kRowPitch], WideRowExchange * xchg,
+                                            unsigned * held = nullptr)
 {
+    constexpr bool MAPPED = MAP != MAP_NONE;
+    static_assert(!MAPPED || (NCH == 4 && WAVES == 1), "mapped stores: 4-channel pixels, wave-private tiles");
+    constexpr int PW = (sizeof(RT) == 1) ? 1 : 2; // dwords per 4-channel pixel
     constexpr bool kWide = sizeof(YT) == 2;
     constexpr bool kNeedA = APLANE || HASMUL;
     constexpr uint32_t kPixBytes = NCH * sizeof(RT);
@@ -806,6 +833,23 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
             const uint32_t off = (sy + r) * A.rgbPitch + X * kPixBytes;
             const uint32_t bandOff = (sy + r) * A.rgbPitch + c.bandX * kPixBytes;
 
+            // finished pixel words through the job's PixelMap: canvas pixel (mapX0 + X .. + 3, mapY0 + row)
+            auto emitMapped = [&](const unsigned (&px)[4][PW]) {
+                if constexpr (MAP == MAP_TURNED) { // quarter turns leave through the caller's LDS transposition
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int wd = 0; wd < PW; ++wd)
+                            held[((2 * k + r) * 4 + i) * PW + wd] = px[i][wd];
+                } else if constexpr (MAP == MAP_ROWS) {
+                    if constexpr (PW == 1) {
+                        if (laneValid)
+                            mapStoreRow<1>(A, px, (uint32_t)A.mapX0 + X, (uint32_t)A.mapY0 + sy + (uint32_t)r, nt);
+                    } else {
+                        mapStoreRowWide(A, px, (uint32_t)A.mapX0 + c.bandX, c.bandX, (uint32_t)A.mapY0 + sy + (uint32_t)r, reinterpret_cast<mu4 *>(xchg[wv].w));
+                    }
+                }
+            };
             // finished integers (q[i].r / q[i].b: first / third colour channel) to their pixels
             auto emitQ = [&](PixelOut (&q)[4]) {
                 if constexpr (sizeof(RT) == 2) {
@@ -817,7 +861,19 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                         }
                     }
                 }
-                if constexpr (sizeof(RT) == 2 && NCH == 4) {
+                if constexpr (MAPPED) {
+                    unsigned px[4][PW];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (PW == 1) {
+                            px[i][0] = alphaFirst ? (a[i] | (q[i].r << 8) | (q[i].g << 16) | (q[i].b << 24)) : (q[i].r | (q[i].g << 8) | (q[i].b << 16) | (a[i] << 24));
+                        } else {
+                            px[i][0] = alphaFirst ? (a[i] | (q[i].r << 16)) : (q[i].r | (q[i].g << 16));
+                            px[i][1] = alphaFirst ? (q[i].g | (q[i].b << 16)) : (q[i].b | (a[i] << 16));
+                        }
+                    }
+                    emitMapped(px);
+                } else if constexpr (sizeof(RT) == 2 && NCH == 4) {
                     store4WideRgba(A.rgb, bandOff, q, a, alphaFirst, c.bandX, A.w4, xchg[wv]);
                 } else if constexpr (NCH == 3) {
                     store4Rgb3<RT>(A.rgb, bandOff, q, segBytes, xchg[wv]);
@@ -839,8 +895,12 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                         for (int i = 0; i < 4; ++i)
                             aw[i] = APLANE ? (a[i] << (8 * A.slotA)) : opaqueWord;
                         packRgba8Row(w, aw, tbr, tg, A.slotZ, A.slotG, A.slotX);
-                        if (laneValid)
+                        if constexpr (MAPPED) {
+                            const unsigned px[4][PW] = { { w[0] }, { w[1] }, { w[2] }, { w[3] } };
+                            emitMapped(px);
+                        } else if (laneValid) {
                             storeVec(A.rgb, off, (u4) { w[0], w[1], w[2], w[3] }, nt);
+                        }
                     } else {
                         float x[4], z[4];
 #pragma unroll
@@ -878,6 +938,12 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                         q[i].r = ub[i], q[i].g = yb[i], q[i].b = vb[i];
                     if constexpr (NCH == 3) {
                         store4Rgb3<RT>(A.rgb, bandOff, q, segBytes, xchg[wv]);
+                    } else if constexpr (MAPPED) {
+                        unsigned px[4][PW];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            px[i][0] = alphaFirst ? (a[i] | (q[i].r << 8) | (q[i].g << 16) | (q[i].b << 24)) : (q[i].r | (q[i].g << 8) | (q[i].b << 16) | (a[i] << 24));
+                        emitMapped(px);
                     } else {
                         if (laneValid)
                             store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
@@ -898,6 +964,15 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             X[i] = sat01(uv[r][i].x), G[i] = sat01(yk[i]), Z[i] = sat01(uv[r][i].y);
+                    } else if (A.ycgco) {
+                        unsigned yc[4];
+                        decode4<YT>(raw[k].y[r], yc);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float x, g, z;
+                            ycgcoPixel(A, yk[i], uv[r][i], kWide ? minU(yc[i], yuvMax) : yc[i], x, g, z);
+                            X[i] = sat01(x), G[i] = sat01(g), Z[i] = sat01(z);
+                        }
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -949,6 +1024,15 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                 for (int i = 0; i < 4; ++i) {
                     br[i] = uv[r][i];
                     g[i] = yk[i];
+                }
+            } else if (A.ycgco) { // wave-uniform: YCgCo / YCgCo-Re / -Ro
+                unsigned yc[4];
+                decode4<YT>(raw[k].y[r], yc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x, z;
+                    ycgcoPixel(A, yk[i], uv[r][i], kWide ? minU(yc[i], yuvMax) : yc[i], x, g[i], z);
+                    br[i] = (f2) { x, z };
                 }
             } else {
 #pragma unroll
@@ -1143,6 +1227,136 @@ __global__ __launch_bounds__(256) void yuvToRgbTileSoloBatchKernel(const TileArg
     }
 }
 
+// ---- ... storing through the job's PixelMap (fused crop / rotate / mirror; 4-channel pixels).  LDS is sized at launch (SoloMapLds): the
+//      waves' chroma blocks, then their exchange buffers (8-byte pixels); for quarter turns the workgroup's transposition tile (32 KiB)
+//      overlays both behind a barrier.  Quarter turns need the four waves stacked and ALL of them to the end, with or without rows of
+//      their own: every wave stores a quarter of the tile's columns ----
+template <typename YT, int SUB, bool BIL, typename RT, int NS>
+struct SoloMapLds
+{
+    static constexpr uint32_t kStageBytes = (uint32_t)(kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch * sizeof(f2));
+    static constexpr uint32_t kXchgBytes = (sizeof(RT) == 2) ? (uint32_t)(kWavesPerBlock * sizeof(WideRowExchange)) : 0u;
+    static constexpr uint32_t kPlain = kStageBytes + kXchgBytes;
+    static constexpr uint32_t kTileBytes = 4u * MapTile<(sizeof(RT) == 1) ? 1 : 2>::kWords;
+    static constexpr bool kTurns = 8 * NS == (int)MapTile<(sizeof(RT) == 1) ? 1 : 2>::kRows; // the tile's rows = the four waves' rows
+    static constexpr uint32_t kTurned = kPlain > kTileBytes ? kPlain : kTileBytes;
+};
+
+template <typename YT, int SUB, bool BIL, typename RT, bool APLANE, bool HASMUL, int NS, bool TURNED>
+__device__ __forceinline__ void runSoloMapped(const TileArgs & A, const PkGeom & g, uint8_t * ldsBytes)
+{
+    constexpr bool kNeedA = APLANE || HASMUL;
+    constexpr int PW = (sizeof(RT) == 1) ? 1 : 2;
+    typedef StageRows<SUB, NS, 1> SR;
+    typedef SoloMapLds<YT, SUB, BIL, RT, NS> LDS;
+    static_assert(!TURNED || LDS::kTurns, "quarter turns: the workgroup's rows must be the transposition tile's");
+    const uint32_t tile = pkTileOf(blockIdx.x, g);
+    if (tile >= g.nTiles)
+        return;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const PkPlace place = pkPlaceOf(tile, wave, g, (uint32_t)NS);
+    const uint32_t bandX = place.band * (uint32_t)kBandW;
+    const uint32_t tileY = place.strip0 * 2u;
+    if (bandX >= A.w4)
+        return; // (stacked waves share their band: the whole workgroup leaves)
+    const bool rowsValid = tileY < A.h2;
+    if (!rowsValid && !TURNED)
+        return;
+    BandCtx c;
+    c.bandX = bandX;
+    c.X = bandX + 4 * threadIdx.x;
+    c.laneValid = c.X < A.w4;
+    c.Xc = c.laneValid ? c.X : 0;
+    c.cxb = A.cx0 + (int)(bandX >> 1);
+    unsigned held[TURNED ? 2 * NS * 4 * PW : 1];
+    if constexpr (TURNED) {
+#pragma unroll
+        for (int i = 0; i < 2 * NS * 4 * PW; ++i)
+            held[i] = 0;
+    }
+    if (rowsValid) {
+        TileRaw<YT, SUB, BIL, kNeedA, NS, 1> raw;
+        loadTile<YT, SUB, BIL, kNeedA, NS, 1, false>(A, c, tileY, raw);
+        f2(*rows)[kRowPitch] = reinterpret_cast<f2(*)[kRowPitch]>(reinterpret_cast<f2 *>(ldsBytes) + (size_t)wave * (BIL ? SR::kRows : 1) * kRowPitch);
+        if constexpr (BIL) {
+            stageTile<YT, SUB, kNeedA, NS, 1>(A, raw, rows);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        WideRowExchange * xchg = (sizeof(RT) == 2) ? reinterpret_cast<WideRowExchange *>(ldsBytes + LDS::kStageBytes) + wave : nullptr;
+        computeTile<YT, SUB, BIL, RT, 4, APLANE, HASMUL, NS, 1, TURNED ? MAP_TURNED : MAP_ROWS>(A, c, tileY, raw, rows, xchg, held);
+    }
+    if constexpr (TURNED) {
+        unsigned * tileWords = reinterpret_cast<unsigned *>(ldsBytes);
+        __syncthreads(); // the tile overlays the chroma blocks and exchange buffers: every wave is done with them
+#pragma unroll
+        for (int rr = 0; rr < 2 * NS; ++rr) {
+            unsigned px[4][PW];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int wd = 0; wd < PW; ++wd)
+                    px[i][wd] = held[(rr * 4 + i) * PW + wd];
+            mapTransposeWrite<PW>(tileWords, wave * (uint32_t)(2 * NS) + (uint32_t)rr, px);
+        }
+        __syncthreads();
+        mapTransposeStore<PW>(A, tileWords, wave, bandX, tileY - wave * (uint32_t)(2 * NS));
+    }
+}
+
+template <typename YT, int SUB, bool BIL, typename RT, bool APLANE, bool HASMUL, int NS, bool TURNED>
+__global__ __launch_bounds__(256) void yuvToRgbTileSoloMappedKernel(TileArgs A, PkGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsMapped[]; // SoloMapLds<...>::kPlain bytes, kTurned for quarter turns
+    runSoloMapped<YT, SUB, BIL, RT, APLANE, HASMUL, NS, TURNED>(A, g, ldsMapped);
+}
+
+template <typename YT, int SUB, bool BIL, typename RT, bool APLANE, bool HASMUL, int NS, bool TURNED>
+__global__ __launch_bounds__(256) void yuvToRgbTileSoloMappedBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsMapped[];
+    const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel
+    runSoloMapped<YT, SUB, BIL, RT, APLANE, HASMUL, NS, TURNED>(job, g, ldsMapped);
+}
+
+template <typename YT, int SUB, bool BIL, typename RT, bool APLANE, bool MUL>
+hipError_t launchSoloMapped(const TileLaunch & L)
+{
+    // quarter turns: the workgroup's rows must be the transposition tile's (tile_map_impl.h MapTile: 32 rows of 4-byte pixels, 16 of
+    // 8-byte pixels), the four waves stacked, tiles numbered down the columns (tile_geom.h); rows: the automatic choice
+    constexpr int kTurnNS = (sizeof(RT) == 1) ? 4 : 2;
+    TileLaunch M = L;
+    if (L.transposed)
+        M.pkStrips = kTurnNS, M.wavesXLog2 = 0;
+    uint32_t nsw, blocks;
+    PkGeom g;
+    pkGeometry(M, M.maxW4, M.maxH2, &nsw, &g, &blocks);
+    const dim3 block(kLanesX, kWavesPerBlock);
+    const dim3 grid(blocks, 1, L.count);
+    if (L.transposed) {
+        const uint32_t lds = SoloMapLds<YT, SUB, BIL, RT, kTurnNS>::kTurned;
+        if (L.table)
+            hipLaunchKernelGGL((yuvToRgbTileSoloMappedBatchKernel<YT, SUB, BIL, RT, APLANE, MUL, kTurnNS, true>), grid, block, lds, L.stream, L.table, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbTileSoloMappedKernel<YT, SUB, BIL, RT, APLANE, MUL, kTurnNS, true>), grid, block, lds, L.stream, *L.args, g);
+        return hipGetLastError();
+    }
+    const uint32_t lds4 = SoloMapLds<YT, SUB, BIL, RT, 4>::kPlain, lds2 = SoloMapLds<YT, SUB, BIL, RT, 2>::kPlain;
+    if (L.table) {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbTileSoloMappedBatchKernel<YT, SUB, BIL, RT, APLANE, MUL, 4, false>), grid, block, lds4, L.stream, L.table, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbTileSoloMappedBatchKernel<YT, SUB, BIL, RT, APLANE, MUL, 2, false>), grid, block, lds2, L.stream, L.table, g);
+    } else {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbTileSoloMappedKernel<YT, SUB, BIL, RT, APLANE, MUL, 4, false>), grid, block, lds4, L.stream, *L.args, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbTileSoloMappedKernel<YT, SUB, BIL, RT, APLANE, MUL, 2, false>), grid, block, lds2, L.stream, *L.args, g);
+    }
+    return hipGetLastError();
+}
+
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool MUL>
 hipError_t launchSolo(const TileLaunch & L)
 {
@@ -1211,6 +1425,11 @@ hipError_t launchAlphaVariant(const TileKey & k, const TileLaunch & L)
     }
     if (k.nch == 3)
         return k.hasMul ? launchOne<YT, SUB, BIL, RT, 3, false, true>(L) : launchOne<YT, SUB, BIL, RT, 3, false, false>(L);
+    if (L.mapped) { // fused crop / rotate / mirror (4-channel pixels only: tileYuvToRgbSupported)
+        if (k.hasMul)
+            return launchSoloMapped<YT, SUB, BIL, RT, true, true>(L);
+        return k.alphaPlane ? launchSoloMapped<YT, SUB, BIL, RT, true, false>(L) : launchSoloMapped<YT, SUB, BIL, RT, false, false>(L);
+    }
     if (k.hasMul)
         return launchOne<YT, SUB, BIL, RT, 4, true, true>(L);
     return k.alphaPlane ? launchOne<YT, SUB, BIL, RT, 4, true, false>(L) : launchOne<YT, SUB, BIL, RT, 4, false, false>(L);

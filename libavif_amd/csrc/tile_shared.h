@@ -43,6 +43,10 @@ struct TileArgs
     int32_t inLoopMul, postMul;          // MulMode
     int32_t identityCopy;                // 8-bit full-range identity matrix: bytes are copied (src/reformat.c:1278-1309)
     int32_t identityMatrix;              // identity matrix otherwise: the planes are G, B, R on luma's scale (biasUV / rcpRangeUV hold luma's)
+    // YCgCo (1: three adds on the normalised samples, src/reformat.c:853-858) and YCgCo-Re / -Ro (2: integer lifting from the luma code and
+    // the chroma scaled back to codes, :859-871); `cgFirst`: the plane `u` above is Cg (B is the first colour channel), else `v` is
+    int32_t ycgco, cgFirst;
+    float yuvMaxF;
     uint32_t tuning;
     // fused crop / rotate / mirror (plan.h PixelMap): `rgb` is then the destination buffer's first pixel, and canvas pixel
     // (mapX0 + X, mapY0 + row) of the rectangle's pixel (X, row) goes where the map says.  Packed 16-bit kernels only.
@@ -140,6 +144,9 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     A.identityMatrix = (p.arith != ARITH_LIBYUV && s.mode == MODE_IDENTITY && !p.identityCopy) ? 1 : 0;
     if (A.identityMatrix)
         A.biasUV = s.biasY, A.rcpRangeUV = s.rcpRangeY; // src/reformat.c:587-589: identity reads chroma through luma's table
+    A.ycgco = (p.arith == ARITH_LIBYUV) ? 0 : (s.mode == MODE_YCGCO ? 1 : ((s.mode == MODE_YCGCO_RE || s.mode == MODE_YCGCO_RO) ? 2 : 0));
+    A.cgFirst = redFirstColour ? 0 : 1; // (the fp32 block above swapped the planes for red-first orders)
+    A.yuvMaxF = (float)s.maxv;
     A.tuning = p.tuning;
     if (p.arith == ARITH_LIBYUV) {
         const FixedPointMatrix & m = p.fx;

@@ -81,21 +81,18 @@ def test_grid_tail_default_arithmetic(hip_auto_arithmetic, g):
         assert any("mapped" in k or "seam" in k or "generic" in k for k in kernels), kernels
 
 
-@pytest.mark.parametrize("g", grid_cases(True)[:3], ids=lambda g: g.ident())
+@pytest.mark.parametrize("g", [grid_cases(True)[k] for k in (0, 1, 2, 6)], ids=lambda g: g.ident())
 def test_grid_tail_fp32_path(hip, g):
-    run_grid(hip, g)
+    kernels = run_grid(hip, g)
+    if abi.rgb_format_has_alpha(g.conv.rgb_format):  # 4-channel pixels of 4 or 8 bytes: the fp32 tiles store through the map themselves
+        assert any(k.startswith("yuv2rgb_tile<") and k.endswith(",mapped>") for k in kernels), kernels
+        assert not any(k.startswith("rgb_transform") for k in kernels), kernels
 
 
-def test_single_image_tail(hip_auto_arithmetic):
-    lib = hip_auto_arithmetic
-    cases = [H.Y2RCase(1030, 518, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, avoid_libyuv=False),
-             H.Y2RCase(771, 95, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, avoid_libyuv=False),
-             H.Y2RCase(640, 64, yuv_format=1, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_BGR, avoid_libyuv=False),
-             H.Y2RCase(771, 95, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=8, upsampling=4, alpha=True, avoid_libyuv=False),
-             H.Y2RCase(300, 40, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, upsampling=4, avoid_libyuv=False)]
+def run_single(lib, oracle, cases, avoid_libyuv):
     seen = set()
     for c in cases:
-        res, canvas_px = H.run_y2r(H.oracle_libyuv_backend(), c)
+        res, canvas_px = H.run_y2r(oracle, c)
         assert res == 0
         canvas = H.make_y2r_output(c)
         canvas.pixels[...] = canvas_px
@@ -107,7 +104,7 @@ def test_single_image_tail(hip_auto_arithmetic):
             dw, dh = out_dims(c.w, c.h, crop, angle)
             want = abi.make_rgb(dw, dh, depth, fmt, fill=0x11)
             assert call_oracle(canvas, want, crop, angle, mirror) == 0
-            got = abi.make_rgb(dw, dh, depth, fmt, upsampling=c.upsampling, avoid_libyuv=False, fill=0x22)
+            got = abi.make_rgb(dw, dh, depth, fmt, upsampling=c.upsampling, avoid_libyuv=avoid_libyuv, alpha_premultiplied=c.rgb_premultiplied, fill=0x22)
             dgot = device.DeviceRGB(got, upload=True, tight=(dw % 2 == 1))
             rect = abi.avifCropRect(*crop) if crop else None
             native.check(lib.avifhipImageYUVToRGBTransformedAsync(dimg.struct, dgot.struct, C.byref(rect) if rect else None, int(angle is not None), angle or 0,
@@ -117,12 +114,44 @@ def test_single_image_tail(hip_auto_arithmetic):
             dgot.download_into_host()
             assert np.array_equal(got.pixels[:, : dw * px], want.pixels[:, : dw * px]), (c.ident(), crop, angle, mirror, native.last_kernel(),
                                                                                           H.describe_diff(want.pixels[:, : dw * px], got.pixels[:, : dw * px]))
+    return seen
+
+
+def test_single_image_tail(hip_auto_arithmetic):
+    lib = hip_auto_arithmetic
+    cases = [H.Y2RCase(1030, 518, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, avoid_libyuv=False),
+             H.Y2RCase(771, 95, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, avoid_libyuv=False),
+             H.Y2RCase(640, 64, yuv_format=1, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_BGR, avoid_libyuv=False),
+             H.Y2RCase(771, 95, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=8, upsampling=4, alpha=True, avoid_libyuv=False),
+             # cfg5's shape: 10-bit planes into RGBA at the image's depth (the API default, src/avif.c:704) -- libyuv declines, the fp32 tiles store 8-byte pixels through the map
+             H.Y2RCase(300, 40, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=10, upsampling=4, avoid_libyuv=False),
+             H.Y2RCase(300, 40, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, upsampling=4, avoid_libyuv=False),
+             # 3-channel 16-bit pixels: no mapped stores, two passes
+             H.Y2RCase(300, 40, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, rgb_format=A.AVIF_RGB_FORMAT_RGB, upsampling=4, avoid_libyuv=False)]
+    seen = run_single(lib, H.oracle_libyuv_backend(), cases, False)
     assert any(k.endswith(",pk16,mapped>") for k in seen), seen  # the fused route ran
     assert any(k.startswith("yuv2rgb_fixed_tile<u16") and k.endswith(",pk16,mapped>") for k in seen), seen  # ... for 10-bit planes as well
-    assert any(k.startswith("rgb_transform") for k in seen), seen  # ... and so did the two-pass route (16-bit pixels)
+    assert any(k.startswith("yuv2rgb_tile<u16,420,bilinear,rgba16") and k.endswith(",mapped>") for k in seen), seen  # ... and for 8-byte pixels from the fp32 tiles
+    assert any(k.startswith("rgb_transform") for k in seen), seen  # ... and so did the two-pass route (3-channel 16-bit pixels)
     # argument errors: the destination must have the transformed size
     c = cases[0]
     dimg = device.DeviceYUV(H.make_y2r_inputs(c))
     wrong = device.DeviceRGB(abi.make_rgb(c.w, c.h, 8, A.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False))
     assert lib.avifhipImageYUVToRGBTransformedAsync(dimg.struct, wrong.struct, None, 1, 1, 0, 0, None) == abi.AVIF_RESULT_INVALID_ARGUMENT
     assert lib.avifhipImageYUVToRGBTransformedAsync(dimg.struct, wrong.struct, None, 1, 5, 0, 0, None) == abi.AVIF_RESULT_INVALID_ARGUMENT
+
+
+def test_single_image_tail_fp32(hip):
+    """The fp32 arithmetic (rgb.avoidLibYUV = 1): every 4-channel family stores through the map -- 8-bit and 16-bit pixels, nearest and bilinear
+    chroma, alpha from the plane, premultiplied outputs (in-loop and post-pass alpha), the identity matrix; images taller than one tile."""
+    cases = [H.Y2RCase(1030, 518, yuv_format=3, yuv_range=0, matrix=1, upsampling=4),
+             H.Y2RCase(771, 95, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, rgb_format=A.AVIF_RGB_FORMAT_BGRA),
+             H.Y2RCase(771, 95, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, rgb_premultiplied=True),
+             H.Y2RCase(516, 70, yuv_format=1, yuv_range=1, matrix=0, rgb_format=A.AVIF_RGB_FORMAT_ARGB),
+             H.Y2RCase(640, 66, yuv_depth=10, yuv_format=1, yuv_range=1, matrix=9, alpha=True, rgb_depth=16, rgb_premultiplied=True),
+             H.Y2RCase(900, 130, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=10, upsampling=4),
+             H.Y2RCase(644, 50, yuv_depth=12, yuv_format=2, yuv_range=0, matrix=9, rgb_depth=12, upsampling=3, alpha=True, rgb_format=A.AVIF_RGB_FORMAT_ABGR),
+             H.Y2RCase(300, 40, yuv_depth=10, yuv_format=4, yuv_range=1, matrix=1, rgb_depth=16)]
+    seen = run_single(hip, H.oracle_backend(), cases, True)
+    assert all(k.startswith("yuv2rgb_tile<") and k.endswith(",mapped>") or "generic" in k for k in seen), seen
+    assert any(k.startswith("yuv2rgb_tile<u8") for k in seen) and any(k.startswith("yuv2rgb_tile<u16") for k in seen), seen

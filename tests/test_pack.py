@@ -106,6 +106,8 @@ def test_gpu_y4m_frame(hip):
     dimg = device.DeviceYUV(img)
     buf = device.DeviceBuffer(1 << 16)
     assert hip.avifhipImagePackY4MFrameAsync(dimg.struct, 1, buf.ptr, None) == abi.AVIF_RESULT_NOT_IMPLEMENTED
+    assert hip.avifhipY4MFrameBytes(dimg.struct, 1) == 0  # ... and the size query agrees: no such frame
+    assert hip.avifhipY4MFrameBytes(dimg.struct, 0) == 64 * 16 * 2 * 3
     assert hip.avifhipImagePackY4MFrameAsync(None, 0, buf.ptr, None) == abi.AVIF_RESULT_INVALID_ARGUMENT
 
 

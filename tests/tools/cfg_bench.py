@@ -135,18 +135,26 @@ def run(name):
         elif name == "cfg3":
             pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, avoid=avoid)
             px, bpp, ms = 7680 * 4320, 16.0, time_y2r(pair, 20)
-        elif name in ("cfg4", "cfg4rgb", "cfg4_601", "cfg4_8k", "cfg4rgb_8k", "ident8_enc"):
+        elif name in ("cfg4", "cfg4rgb", "cfg4_601", "cfg4_8k", "cfg4rgb_8k", "ident8_enc", "cfg4_premul_8k", "cfg4_unpremul_8k", "cfg4_ycgco_8k"):
             fmt = abi.AVIF_RGB_FORMAT_RGB if name.startswith("cfg4rgb") else abi.AVIF_RGB_FORMAT_RGBA
             mc = 6 if name == "cfg4_601" else 1
             w, h = (7680, 4320) if name.endswith("_8k") or name == "ident8_enc" else (3840, 2160)  # the encode direction on the headline's frame size
-            rgb = abi.make_rgb(w, h, 8, fmt, avoid_libyuv=avoid)
-            synth.fill_rgb(rgb, 0x12345678, opaque=True)
+            # pending alpha multiply (straight RGBA into a premultiplied image: what avifenc --premultiply asks for) / un-multiply on the encode side
+            mul = {"cfg4_premul_8k": 1, "cfg4_unpremul_8k": 2}.get(name, 0)
+            if mul and arith == "integer":
+                continue  # (libyuv is never asked when alpha is pending: one arithmetic)
+            rgb = abi.make_rgb(w, h, 8, fmt, avoid_libyuv=avoid, alpha_premultiplied=(mul == 2))
+            synth.fill_rgb(rgb, 0x12345678, opaque=(mul == 0))
             if name == "ident8_enc":  # lossless encode (avifenc -l): 8K RGBA8 -> GBR planes 8-bit 4:4:4 full range + alpha, 4 + 3 + 1 B/px
                 img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 0, with_alpha=True)
+            elif name == "cfg4_ycgco_8k":  # YCgCo 8-bit 4:4:4 full range + alpha, 4 + 3 + 1 B/px
+                if arith == "integer":
+                    continue
+                img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 8, with_alpha=True)
             else:
-                img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, mc, with_alpha=(fmt == abi.AVIF_RGB_FORMAT_RGBA))
+                img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, mc, with_alpha=(fmt == abi.AVIF_RGB_FORMAT_RGBA), alpha_premultiplied=(mul == 1))
             dimg, drgb = device.DeviceYUV(img), device.DeviceRGB(rgb, upload=True)
-            px, bpp = w * h, (8.0 if name == "ident8_enc" else (6.5 if fmt == abi.AVIF_RGB_FORMAT_RGBA else 4.5))
+            px, bpp = w * h, (8.0 if name in ("ident8_enc", "cfg4_ycgco_8k") else (6.5 if fmt == abi.AVIF_RGB_FORMAT_RGBA else 4.5))
             preheat(lambda n: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 0, n, None))
             ms = min(lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 4, 40, None) for _ in range(4))
         elif name in ("cfg5", "cfg5_8"):
@@ -218,23 +226,29 @@ def run(name):
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
             px, bpp, ms = 7664 * 4312, 8.0, best
-        elif name in ("tail0", "tail180", "tail90", "tail90_two_pass", "tail180_two_pass", "tail0_10", "tail90_10", "tail90_10_two_pass"):
+        elif name in ("tail0", "tail180", "tail90", "tail90_two_pass", "tail180_two_pass", "tail0_10", "tail90_10", "tail90_10_two_pass",
+                      "tail0_rgba10", "tail180_rgba10", "tail90_rgba10", "tail90_rgba10_two_pass", "tail90_nocrop", "tail90_rgba10_nocrop"):
             # the decode-side tail fused (avifhipImageYUVToRGBTransformedAsync): 8K 8-bit 4:2:0 -> RGBA8 bilinear with clap crop +
             # irot + imir, against the same result in two passes (conversion, then avifhipRGBImageTransformAsync).  5.5 B/pixel of
-            # the cropped image is what HAS to move.
-            if arith == "float":
-                continue  # the fused route is the integer path's (the fp32 kernels take the two-pass route inside the same call)
-            deep = "_10" in name  # 10-bit planes (HDR photographs): 3 + 4 B/pixel
-            angle = {"tail0": 0, "tail180": 2, "tail90": 1, "tail90_two_pass": 1, "tail180_two_pass": 2}[name.replace("_10", "")]
+            # the cropped image is what HAS to move.  "_10": 10-bit planes -> RGBA8 (3 + 4 B/pixel); "_rgba10": 10-bit planes -> RGBA at the
+            # image's depth, the API default (cfg5's pixels: 3 + 8 B/pixel, fp32 arithmetic in either library setting -- libyuv has no 16-bit outputs)
+            wide = "_rgba10" in name
+            if arith == "float" and "_10" in name:
+                continue  # (covered by the integer row: the packed kernels; the fp32 twin of 10 -> 8 bits is not a default anybody gets)
+            if arith == "integer" and wide:
+                continue  # one arithmetic
+            deep = "_10" in name or wide
+            nocrop = name.endswith("_nocrop")  # the whole frame turned (no clap): destination runs start on cache-line boundaries
+            angle = {"tail0": 0, "tail180": 2, "tail90": 1, "tail90_two_pass": 1, "tail180_two_pass": 2}[name.replace("_nocrop", "").replace("_rgba10", "").replace("_10", "")]
             img = abi.make_yuv(7680, 4320, 10 if deep else 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
             synth.fill_yuv(img, 0x12345678)
             dimg = device.DeviceYUV(img)
-            crop = abi.avifCropRect(8, 4, 7664, 4312)
-            dw, dh = (4312, 7664) if angle == 1 else (7664, 4312)
-            dst = abi.make_rgb(dw, dh, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False)
+            crop = abi.avifCropRect(0, 0, 7680, 4320) if nocrop else abi.avifCropRect(8, 4, 7664, 4312)
+            dw, dh = (crop.height, crop.width) if angle == 1 else (crop.width, crop.height)
+            dst = abi.make_rgb(dw, dh, 10 if wide else 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=avoid, allocate=False)
             ddst = device.DeviceRGB(dst)
             if name.endswith("two_pass"):
-                mid = abi.make_rgb(7680, 4320, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False)
+                mid = abi.make_rgb(7680, 4320, 10 if wide else 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=avoid, allocate=False)
                 dmid = device.DeviceRGB(mid)
 
                 def call():
@@ -253,7 +267,7 @@ def run(name):
                     call()
                 native.check(lib.avifhipSynchronize(None))
                 best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
-            px, bpp, ms = 7664 * 4312, (7.0 if deep else 5.5), best
+            px, bpp, ms = crop.width * crop.height, (11.0 if wide else 7.0 if deep else 5.5), best
         elif name in ("cfg5grid", "cfg5grid_8", "photo_grid"):
             # BASELINE configs[4]: 8 x 8 grid of decoded 1920x1080 10-bit 4:2:0 tiles -> one 15360x8640 RGBA canvas, tiles
             # converted where they lie (avifhipGridYUVToRGBAsync: no YUV canvas, seams redone across tiles)

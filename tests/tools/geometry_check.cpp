@@ -17,11 +17,12 @@ namespace {
 
 // 0 = every wave-tile of a w4 x h2 job visited exactly once; otherwise a code saying what went wrong
 int checkPk(uint32_t w4, uint32_t h2, uint32_t count, uint32_t pkStrips, uint32_t wavesXLog2, uint32_t chunkRows, std::vector<uint8_t> & seenTile,
-            std::vector<uint8_t> & seenPlace)
+            std::vector<uint8_t> & seenPlace, bool transposed = false)
 {
     TileLaunch L;
     memset(&L, 0, sizeof(L));
     L.count = count, L.pkStrips = pkStrips, L.wavesXLog2 = wavesXLog2, L.chunkRows = chunkRows;
+    L.transposed = transposed; // quarter turns: tiles numbered down the columns, one tile column per XCD chunk
     uint32_t nsw = 0, blocks = 0;
     PkGeom g;
     pkGeometry(L, w4, h2, &nsw, &g, &blocks);
@@ -67,7 +68,8 @@ extern "C" {
 int geomCheckPk(uint32_t w4, uint32_t h2, uint32_t count, uint32_t pkStrips, uint32_t wavesXLog2, uint32_t chunkRows)
 {
     std::vector<uint8_t> a, b;
-    return checkPk(w4, h2, count, pkStrips, wavesXLog2, chunkRows, a, b);
+    const int rowMajor = checkPk(w4, h2, count, pkStrips, wavesXLog2, chunkRows, a, b);
+    return rowMajor ? rowMajor : checkPk(w4, h2, count, pkStrips, wavesXLog2, chunkRows, a, b, true);
 }
 
 // every tuning (strips 0/2/4, waves side by side 1/2/4, chunk rows 0..15) x job counts {1, 3, 64} over the widths around every listed band count
@@ -87,7 +89,11 @@ uint64_t geomSweepPk(uint32_t maxH2, uint32_t * first, uint64_t * casesOut)
                     for (uint32_t strips : { 0u, 2u, 4u })
                         for (uint32_t wxl = 0; wxl <= 2; ++wxl)
                             for (uint32_t cr : chunkRows) {
-                                const int code = checkPk(w4, h2, count, strips, wxl, cr, a, b);
+                                int code = checkPk(w4, h2, count, strips, wxl, cr, a, b);
+                                if (!code && wxl == 0 && cr <= 1) { // the quarter-turn order (waves stacked, one tile column per chunk or raster)
+                                    code = checkPk(w4, h2, count, strips, wxl, cr, a, b, true);
+                                    ++cases;
+                                }
                                 ++cases;
                                 if (code && !bad++) {
                                     const uint32_t f[7] = { w4, h2, count, strips, wxl, cr, (uint32_t)code };
