@@ -56,6 +56,17 @@ AVIFHIP_API avifResult avifhipRGBImageUnpremultiplyAlpha(avifRGBImage * rgb);
  * caller runs those afterwards through the hooks below); the alpha channel is written (from the alpha plane, or
  * opaque) only when reformatAlpha is set. */
 AVIFHIP_API avifResult avifhipImageYUVToRGBColorOnly(const avifImage * image, avifRGBImage * rgb, avifBool reformatAlpha);
+/* The same job with libavif's NEXT steps folded in: after AVIF_RESULT_OK from its colour hook, avifImageYUVToRGBImpl calls
+ * avifRGBImagePremultiplyAlpha / avifRGBImageUnpremultiplyAlpha on the same pixels when an alpha (un)multiply is pending and
+ * avifRGBImageToF16 when rgb->isFloat (src/reformat.c:1574-1590) -- each another hook call that would move a host-resident image across
+ * the bus both ways.  When those steps can be computed in the same pass (the integer post-pass after the conversion: what a
+ * libyuv-backed libavif computes too), the pixels handed back are FINAL and *folded says which follow-up calls the caller must answer
+ * with AVIF_RESULT_OK without touching the pixels (AVIFHIP_FOLDED_*); otherwise *folded is 0 and the result is
+ * avifhipImageYUVToRGBColorOnly's.  integration/reformat_libyuv_hip.c keeps the one-shot bookkeeping. */
+#define AVIFHIP_FOLDED_PREMULTIPLY 1u
+#define AVIFHIP_FOLDED_UNPREMULTIPLY 2u
+#define AVIFHIP_FOLDED_TO_F16 4u
+AVIFHIP_API avifResult avifhipImageYUVToRGBHook(const avifImage * image, avifRGBImage * rgb, avifBool reformatAlpha, uint32_t * folded);
 /* Replaces avifRGBImageToF16 / avifRGBImageToF16LibYUV (src/reformat.c:1419-1443): in-place uint16 -> IEEE half. */
 AVIFHIP_API avifResult avifhipRGBImageToF16(avifRGBImage * rgb);
 

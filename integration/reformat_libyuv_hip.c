@@ -25,6 +25,7 @@
 #include "avifhip.h" /* sees AVIF_AVIF_H: uses libavif's own struct definitions */
 
 #include <stdlib.h>
+#include <string.h>
 
 /* Below this many pixels a conversion costs less on the CPU than the PCIe round trip (env override for tests). */
 static uint32_t avifHipMinPixels(void)
@@ -50,8 +51,59 @@ static avifResult avifHipOrFallback(avifResult r)
     return (r == AVIF_RESULT_UNKNOWN_ERROR || r == AVIF_RESULT_OUT_OF_MEMORY) ? AVIF_RESULT_NOT_IMPLEMENTED : r;
 }
 
+/* One-shot note from the colour hook to the hooks libavif calls right after it on the same thread for the same pixels
+ * (src/reformat.c:1574-1590: avifRGBImagePremultiplyAlpha / UnpremultiplyAlpha, then avifRGBImageToF16): avifhipImageYUVToRGBHook has
+ * already produced the FINAL pixels, so those calls are answered without moving the image across the bus again.  A step is skipped only
+ * if it is the very next hook call of this thread, for the same buffer and geometry, and a sample of the pixels still reads as the colour
+ * hook left it; every other hook call drops the note.  (Between the two calls there is only libavif's own code: no application code runs
+ * inside avifImageYUVToRGB, and a later, separate avifRGBImagePremultiplyAlpha of the application finds no note.) */
+typedef struct avifHipFoldNote
+{
+    const uint8_t * pixels;
+    uint32_t width, height, rowBytes, depth;
+    avifRGBFormat format;
+    uint32_t steps; /* AVIFHIP_FOLDED_* still to be answered */
+    uint64_t sample;
+} avifHipFoldNote;
+static _Thread_local avifHipFoldNote avifHipNote;
+
+/* 64 probes of 8 bytes spread over the buffer (first and last row included): a cheap guard against a caller that changes the pixels
+ * between two hook calls it makes itself */
+static uint64_t avifHipSamplePixels(const avifRGBImage * rgb)
+{
+    const uint32_t pixelBytes = avifRGBImagePixelSize(rgb);
+    const uint64_t rowPayload = (uint64_t)rgb->width * pixelBytes;
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    if (!rgb->pixels || rowPayload < 8 || !rgb->height)
+        return h;
+    for (uint32_t k = 0; k < 64; ++k) {
+        const uint32_t row = (uint32_t)(((uint64_t)k * (rgb->height - 1)) / 63);
+        const uint64_t col = ((uint64_t)k * 0x9e3779b1u) % (rowPayload - 7);
+        uint64_t v;
+        memcpy(&v, rgb->pixels + (size_t)row * rgb->rowBytes + col, 8);
+        h = (h ^ v) * 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    return h;
+}
+
+/* AVIF_TRUE: `step` was folded into the colour hook's result for exactly these pixels -- consume it */
+static avifBool avifHipTakeFoldedStep(const avifRGBImage * rgb, uint32_t step)
+{
+    avifHipFoldNote * n = &avifHipNote;
+    const avifBool match = (n->steps & step) && n->pixels == rgb->pixels && n->width == rgb->width && n->height == rgb->height &&
+                           n->rowBytes == rgb->rowBytes && n->depth == rgb->depth && n->format == rgb->format && n->sample == avifHipSamplePixels(rgb);
+    if (!match) {
+        n->steps = 0;
+        return AVIF_FALSE;
+    }
+    n->steps &= ~step; /* (a remaining step sees the same pixels: nothing was written) */
+    return AVIF_TRUE;
+}
+
 avifResult avifImageRGBToYUVLibYUV(avifImage * image, const avifRGBImage * rgb)
 {
+    avifHipNote.steps = 0;
     /* called only without alpha (un)multiply and for non-gray sources (src/reformat.c:255,265); planes are allocated */
     if (!avifHipWorthIt(image->width, image->height))
         return AVIF_RESULT_NOT_IMPLEMENTED;
@@ -60,17 +112,27 @@ avifResult avifImageRGBToYUVLibYUV(avifImage * image, const avifRGBImage * rgb)
 
 avifResult avifImageYUVToRGBLibYUV(const avifImage * image, avifRGBImage * rgb, avifBool reformatAlpha, avifBool * alphaReformattedWithLibYUV)
 {
+    avifHipNote.steps = 0;
     *alphaReformattedWithLibYUV = AVIF_FALSE; /* must be valid for OK and NOT_IMPLEMENTED (internal.h:361-363) */
     if (!avifHipWorthIt(image->width, image->height))
         return AVIF_RESULT_NOT_IMPLEMENTED;
-    const avifResult r = avifHipOrFallback(avifhipImageYUVToRGBColorOnly(image, rgb, reformatAlpha));
+    uint32_t folded = 0;
+    const avifResult r = avifHipOrFallback(avifhipImageYUVToRGBHook(image, rgb, reformatAlpha, &folded));
     if (r == AVIF_RESULT_OK && reformatAlpha)
         *alphaReformattedWithLibYUV = AVIF_TRUE; /* copied / rescaled from the alpha plane, or opaque fill */
+    if (r == AVIF_RESULT_OK && folded) {
+        avifHipNote.pixels = rgb->pixels, avifHipNote.width = rgb->width, avifHipNote.height = rgb->height, avifHipNote.rowBytes = rgb->rowBytes;
+        avifHipNote.depth = rgb->depth, avifHipNote.format = rgb->format;
+        avifHipNote.sample = avifHipSamplePixels(rgb);
+        avifHipNote.steps = folded;
+    }
     return r;
 }
 
 avifResult avifRGBImagePremultiplyAlphaLibYUV(avifRGBImage * rgb)
 {
+    if (avifHipTakeFoldedStep(rgb, AVIFHIP_FOLDED_PREMULTIPLY))
+        return AVIF_RESULT_OK;
     if (!avifHipWorthIt(rgb->width, rgb->height))
         return AVIF_RESULT_NOT_IMPLEMENTED;
     return avifHipOrFallback(avifhipRGBImagePremultiplyAlpha(rgb));
@@ -78,6 +140,8 @@ avifResult avifRGBImagePremultiplyAlphaLibYUV(avifRGBImage * rgb)
 
 avifResult avifRGBImageUnpremultiplyAlphaLibYUV(avifRGBImage * rgb)
 {
+    if (avifHipTakeFoldedStep(rgb, AVIFHIP_FOLDED_UNPREMULTIPLY))
+        return AVIF_RESULT_OK;
     if (!avifHipWorthIt(rgb->width, rgb->height))
         return AVIF_RESULT_NOT_IMPLEMENTED;
     return avifHipOrFallback(avifhipRGBImageUnpremultiplyAlpha(rgb));
@@ -85,6 +149,8 @@ avifResult avifRGBImageUnpremultiplyAlphaLibYUV(avifRGBImage * rgb)
 
 avifResult avifRGBImageToF16LibYUV(avifRGBImage * rgb)
 {
+    if (avifHipTakeFoldedStep(rgb, AVIFHIP_FOLDED_TO_F16))
+        return AVIF_RESULT_OK;
     if (!avifHipWorthIt(rgb->width, rgb->height))
         return AVIF_RESULT_NOT_IMPLEMENTED;
     return avifHipOrFallback(avifhipRGBImageToF16(rgb));

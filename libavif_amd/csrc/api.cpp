@@ -896,6 +896,38 @@ extern "C" avifResult avifhipImageYUVToRGBColorOnly(const avifImage * image, avi
     return yuvToRgbSync(image, rgb, true, reformatAlpha != AVIF_FALSE);
 }
 
+// The colour hook with what libavif does NEXT folded in.  After AVIF_RESULT_OK from avifImageYUVToRGBLibYUV, avifImageYUVToRGBImpl runs
+// avifRGBImagePremultiplyAlpha / UnpremultiplyAlpha on the same pixels when an alpha (un)multiply is pending and avifRGBImageToF16 when
+// rgb->isFloat (src/reformat.c:1574-1590) -- each of them another hook call that stages a host-resident image across the bus both ways
+// (8K RGBA16: 265 MB each way per call).  The whole-call plan computes exactly that sequence in one pass (the integer post-pass after the
+// conversion is what a libyuv-backed libavif runs too), so the hook can hand back the FINAL pixels and tell its caller which follow-up
+// calls to answer with AVIF_RESULT_OK without touching the pixels again.
+extern "C" avifResult avifhipImageYUVToRGBHook(const avifImage * image, avifRGBImage * rgb, avifBool reformatAlpha, uint32_t * folded)
+{
+    if (folded)
+        *folded = 0;
+    if (!image || !rgb)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    YuvToRgbPlan hook, whole;
+    const avifResult hr = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &hook, true, reformatAlpha != AVIF_FALSE);
+    if (hr != AVIF_RESULT_OK)
+        return hr; // (declines exactly what avifhipImageYUVToRGBColorOnly declines)
+    const bool pending = hook.mulOfTheCall != MUL_NONE || rgb->isFloat;
+    if (!folded || !pending)
+        return yuvToRgbSync(image, rgb, true, reformatAlpha != AVIF_FALSE);
+    // the whole call must be the hook's job plus post-passes: same arithmetic family, same alpha channel, the multiply as a post-pass
+    const avifResult wr = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &whole, false, false);
+    const bool sameJob = wr == AVIF_RESULT_OK && whole.arith == hook.arith && whole.alphaSource == hook.alphaSource && whole.inLoopMul == MUL_NONE &&
+                         whole.postMul == hook.mulOfTheCall && whole.bilinear == hook.bilinear && whole.identityCopy == hook.identityCopy;
+    if (!sameJob)
+        return yuvToRgbSync(image, rgb, true, reformatAlpha != AVIF_FALSE);
+    const avifResult r = yuvToRgbSync(image, rgb, false, false);
+    if (r == AVIF_RESULT_OK)
+        *folded = (hook.mulOfTheCall == MUL_MULTIPLY ? AVIFHIP_FOLDED_PREMULTIPLY : hook.mulOfTheCall == MUL_UNMULTIPLY ? AVIFHIP_FOLDED_UNPREMULTIPLY : 0u) |
+                  (rgb->isFloat ? AVIFHIP_FOLDED_TO_F16 : 0u);
+    return r;
+}
+
 namespace {
 // Per-job overrides of a batch: the chroma window (cwinX0, cwinX1, cwinY0, cwinY1) and the limited-range alpha flag
 struct JobOverride
@@ -949,12 +981,20 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
     uint32_t maxW = 0, maxH = 0;
     bool allTiled = gTiledKernels.load(std::memory_order_relaxed) != 0;
     int variant = -2;
+    const int arithmetic = effectiveArithmetic();
+    const uint32_t tuning = gTuning.load(std::memory_order_relaxed);
+    YuvToRgbPlan firstPlan;
     for (uint32_t k = 0; k < count; ++k) {
         if (!images[k] || !rgbs[k])
             return AVIF_RESULT_INVALID_ARGUMENT;
-        const avifResult pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plansA[k]);
+        // tiles of a grid / frames of a sequence share everything a plan is derived from: derive once, re-bind the buffers
+        avifResult pr = AVIF_RESULT_OK;
+        if (k == 0 || !rebindYuvToRgbPlan(firstPlan, images[0], rgbs[0], images[k], rgbs[k], rects ? &rects[k] : nullptr, &plansA[k], &pr))
+            pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, arithmetic, tuning, &plansA[k]);
         if (pr != AVIF_RESULT_OK)
             return pr;
+        if (k == 0)
+            firstPlan = plansA[0]; // (before the per-job overrides below)
         if (map)
             plansA[k].rgb.map = *map; // fused crop / rotate / mirror: every job stores through the canvas's map
         if (overrides) {

@@ -49,6 +49,7 @@ size_t tileBatchTableBytes(uint32_t count);
 void fillTileBatchTable(const YuvToRgbPlan * plans, uint32_t count, void * hostTable);
 hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW,
                                    uint32_t maxH, hipStream_t stream, const char ** kernelName);
+hipError_t launchGrayChromaFill(const RgbToYuvPlan & plan, hipStream_t stream);
 bool tileRgbToYuvSupported(const RgbToYuvPlan & plan);
 hipError_t launchRgbToYuvTile(const RgbToYuvPlan & plan, hipStream_t stream, const char ** kernelName);
 

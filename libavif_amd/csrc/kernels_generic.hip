@@ -292,9 +292,10 @@ __global__ __launch_bounds__(256) void rgbToYuvFixedKernel(RgbToYuvPlan p)
 // gray source: Y from the gray channel, src/reformat.c:471-519 (chroma planes are filled separately)
 __global__ __launch_bounds__(256) void grayToYuvGenericKernel(RgbToYuvPlan p)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (the region rx0 .. rx0 + rw of every row: the whole image, or the columns the tiled kernel leaves over)
+    const uint32_t i = p.rx0 + blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
-    if (i >= p.width || j >= p.height)
+    if (i >= p.rx0 + p.rw || i >= p.width || j >= p.height)
         return;
     const RgbSide & o = p.rgb;
     const YuvSide & s = p.yuv;
@@ -593,26 +594,34 @@ hipError_t launchYuvToRgbGridSeams(const YuvToRgbPlan & canvasPlan, const GridGe
     return hipGetLastError();
 }
 
+// gray sources: the chroma planes, if any, are set to the half value over shiftedH * rowBytes bytes (padding included), src/reformat.c:520-542
+hipError_t launchGrayChromaFill(const RgbToYuvPlan & plan, hipStream_t stream)
+{
+    const YuvSide & s = plan.yuv;
+    const uint32_t shiftedH = (uint32_t)(((uint64_t)plan.height + s.shiftY) >> s.shiftY);
+    const unsigned half = 1u << (s.depth - 1);
+    for (int pl = 1; pl <= 2; ++pl) {
+        if (!s.plane[pl])
+            continue;
+        const size_t samples = (size_t)shiftedH * s.rowBytes[pl] / (size_t)s.chanBytes;
+        if (samples == 0)
+            continue;
+        const unsigned blocks = (unsigned)((samples + 255) / 256);
+        hipLaunchKernelGGL(fillSamplesKernel, dim3(blocks), dim3(256), 0, stream, s.plane[pl], samples, s.chanBytes, half);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launchRgbToYuvGeneric(const RgbToYuvPlan & plan, hipStream_t stream)
 {
     if (plan.width == 0 || plan.height == 0 || plan.rw == 0 || plan.rh == 0)
         return hipSuccess;
     const dim3 block(64, 4);
     if (plan.rgb.isGray) {
-        hipLaunchKernelGGL(grayToYuvGenericKernel, gridFor(plan.width, plan.height, block), block, 0, stream, plan);
-        // chroma planes, if any, are set to half over shiftedH * rowBytes bytes (padding included)
-        const YuvSide & s = plan.yuv;
-        const uint32_t shiftedH = (uint32_t)(((uint64_t)plan.height + s.shiftY) >> s.shiftY);
-        const unsigned half = 1u << (s.depth - 1);
-        for (int pl = 1; pl <= 2; ++pl) {
-            if (!s.plane[pl])
-                continue;
-            const size_t samples = (size_t)shiftedH * s.rowBytes[pl] / (size_t)s.chanBytes;
-            if (samples == 0)
-                continue;
-            const unsigned blocks = (unsigned)((samples + 255) / 256);
-            hipLaunchKernelGGL(fillSamplesKernel, dim3(blocks), dim3(256), 0, stream, s.plane[pl], samples, s.chanBytes, half);
-        }
+        hipLaunchKernelGGL(grayToYuvGenericKernel, gridFor(plan.rw, plan.height, block), block, 0, stream, plan);
+        if (plan.rx0 != 0)
+            return hipGetLastError(); // leftover columns of the tiled gray kernel: the chroma planes are the caller's
+        return launchGrayChromaFill(plan, stream);
     } else {
         const uint32_t bw = (plan.rw + 1) / 2, bh = (plan.rh + 1) / 2;
         if (plan.arith == ARITH_LIBYUV)

@@ -57,8 +57,22 @@ bool tileRgbToYuvSupported(const RgbToYuvPlan & p)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
-    if (o.isGray || o.is565)
+    if (o.is565)
         return false;
+    if (o.isGray) {
+        // gray sources (GRAY / GRAYA / AGRAY -> luma): 16-byte loads, 4-sample stores; the reference's own loop in either arithmetic
+        // (libyuv is never asked for gray sources, src/reformat.c:255)
+        if (!s.exactDiv || p.rx0 != 0 || p.ry0 != 0 || p.rw != p.width || p.rh != p.height || p.width < 64)
+            return false;
+        if (p.mul != MUL_NONE && !o.hasAlpha)
+            return false;
+        const uint32_t ybps = (uint32_t)s.chanBytes;
+        if (!alignedTo(o.pixels, o.rowBytes, 16) || !alignedTo(s.plane[0], s.rowBytes[0], 4 * ybps))
+            return false;
+        if (p.alphaSource != ALPHA_KEEP && (!s.alpha || !alignedTo(s.alpha, s.alphaRowBytes, 4 * ybps)))
+            return false;
+        return true;
+    }
     if (p.mul != MUL_NONE && (p.arith != ARITH_FLOAT || !o.hasAlpha))
         return false; // pending alpha (un)multiply: 4-channel sources of the fp32 arithmetic (libyuv is never asked: src/reformat.c:255)
     if (p.arith == ARITH_FLOAT) {
@@ -104,10 +118,52 @@ bool tileRgbToYuvSupported(const RgbToYuvPlan & p)
     return true;
 }
 
+namespace {
+hipError_t launchGrayToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const char ** kernelName)
+{
+    const YuvSide & s = p.yuv;
+    const RgbSide & o = p.rgb;
+    const int gch = o.hasAlpha ? 2 : 1;
+    if (kernelName) {
+        static thread_local char name[64];
+        snprintf(name, sizeof(name), "gray2yuv_tile<%s%d,%s%s>", gch == 2 ? "graya" : "gray", o.chanBytes == 2 ? 16 : 8, s.chanBytes == 2 ? "u16" : "u8", p.mul != MUL_NONE ? ",alphamul" : "");
+        *kernelName = name;
+    }
+    GrayArgs A;
+    memset(&A, 0, sizeof(A));
+    const uint32_t ppl = 16u / ((uint32_t)gch * (uint32_t)o.chanBytes);
+    A.gray = o.pixels, A.y = s.plane[0], A.a = (p.alphaSource != ALPHA_KEEP) ? s.alpha : nullptr;
+    A.grayPitch = o.rowBytes, A.yPitch = s.rowBytes[0], A.aPitch = s.alphaRowBytes;
+    A.wP = p.width - p.width % ppl, A.height = p.height;
+    A.rcpRgbMax = o.rcpMax;
+    A.rangeY = s.rangeY, A.biasY = s.biasY, A.yuvMax = (uint32_t)s.maxv, A.yuvMaxF = (float)s.maxv;
+    A.alphaFirst = (gch == 2 && o.offA == 0) ? 1u : 0u;
+    A.alphaMode = R2Y_ALPHA_NONE;
+    if (p.alphaSource == ALPHA_FILL)
+        A.alphaMode = R2Y_ALPHA_FILL;
+    else if (p.alphaSource == ALPHA_PLANE)
+        A.alphaMode = (o.depth == s.depth) ? R2Y_ALPHA_COPY : R2Y_ALPHA_RESCALE;
+    A.mulMode = p.mul;
+    hipError_t e = (o.chanBytes == 2) ? launchR2YGray16(gch, s.chanBytes == 2, A, stream) : launchR2YGray8(gch, s.chanBytes == 2, A, stream);
+    if (e != hipSuccess)
+        return e;
+    if (A.wP != p.width) { // the columns that do not fill a lane's 16 bytes
+        RgbToYuvPlan rest = p;
+        rest.rx0 = A.wP, rest.rw = p.width - A.wP;
+        e = launchRgbToYuvGeneric(rest, stream);
+        if (e != hipSuccess)
+            return e;
+    }
+    return launchGrayChromaFill(p, stream);
+}
+} // namespace
+
 hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const char ** kernelName)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
+    if (o.isGray)
+        return launchGrayToYuvTile(p, stream, kernelName);
     const R2YKey k = keyFor(p);
     if (kernelName)
         *kernelName = kernelNameFor(k);

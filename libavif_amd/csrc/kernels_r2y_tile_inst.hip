@@ -12,6 +12,12 @@ hipError_t R2Y_FN(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hip
 {
     return launchFamily<R2Y_RT>(key, args, blocks, stream);
 }
+#ifdef R2Y_GRAY_FN
+hipError_t R2Y_GRAY_FN(int grayChannels, bool wideYuv, const GrayArgs & args, hipStream_t stream)
+{
+    return launchGray<R2Y_RT>(grayChannels, wideYuv, args, stream);
+}
+#endif
 #ifdef R2Y_WITH_FX
 hipError_t launchR2YTileFx(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream)
 {

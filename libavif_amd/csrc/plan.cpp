@@ -408,6 +408,7 @@ avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, c
         }
     }
     const int mulOfTheCall = mul; // what avifImageYUVToRGB derived before it reached the hook
+    out->mulOfTheCall = mul;
     if (colorOnly) {
         mul = MUL_NONE;        // src/reformat.c:1574-1585 stays with the caller
         out->rgb.isFloat = 0;  // and so does src/reformat.c:1588-1590
@@ -483,6 +484,45 @@ avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, c
     // avifRGBImagePremultiplyAlpha / Unpremultiply ask libyuv whatever avoidLibYUV says, src/alpha.c:163,350
     out->postMulFx = (arithMode != AVIFHIP_ARITHMETIC_FLOAT && out->postMul != MUL_NONE && attenuateCovered(rgb)) ? 1 : 0;
     return AVIF_RESULT_OK;
+}
+
+bool rebindYuvToRgbPlan(const YuvToRgbPlan & proto, const avifImage * pi, const avifRGBImage * pr, const avifImage * image, const avifRGBImage * rgb,
+                        const avifCropRect * rect, YuvToRgbPlan * out, avifResult * result)
+{
+    // everything makeYuvToRgbPlan reads, except buffer addresses, pitches and the rectangle
+    if (image->width != pi->width || image->height != pi->height || image->depth != pi->depth || image->yuvFormat != pi->yuvFormat ||
+        image->yuvRange != pi->yuvRange || image->colorPrimaries != pi->colorPrimaries || image->transferCharacteristics != pi->transferCharacteristics ||
+        image->matrixCoefficients != pi->matrixCoefficients || image->alphaPremultiplied != pi->alphaPremultiplied)
+        return false;
+    for (int p = 0; p < 3; ++p)
+        if ((image->yuvPlanes[p] != nullptr) != (pi->yuvPlanes[p] != nullptr) || (image->yuvRowBytes[p] != 0) != (pi->yuvRowBytes[p] != 0))
+            return false;
+    if ((image->alphaPlane != nullptr) != (pi->alphaPlane != nullptr) || (image->alphaRowBytes != 0) != (pi->alphaRowBytes != 0))
+        return false;
+    if (rgb != pr &&
+        (rgb->width != pr->width || rgb->height != pr->height || rgb->depth != pr->depth || rgb->format != pr->format || rgb->chromaUpsampling != pr->chromaUpsampling ||
+         rgb->chromaDownsampling != pr->chromaDownsampling || rgb->avoidLibYUV != pr->avoidLibYUV || rgb->ignoreAlpha != pr->ignoreAlpha ||
+         rgb->alphaPremultiplied != pr->alphaPremultiplied || rgb->isFloat != pr->isFloat || rgb->maxThreads != pr->maxThreads || (rgb->pixels != nullptr) != (pr->pixels != nullptr)))
+        return false;
+    *out = proto;
+    for (int p = 0; p < 3; ++p) {
+        out->yuv.plane[p] = image->yuvPlanes[p];
+        out->yuv.rowBytes[p] = image->yuvRowBytes[p];
+    }
+    out->yuv.alpha = image->alphaPlane;
+    out->yuv.alphaRowBytes = image->alphaRowBytes;
+    out->rgb.pixels = rgb->pixels;
+    out->rgb.rowBytes = rgb->rowBytes;
+    *result = AVIF_RESULT_OK;
+    if (rect) {
+        if (rect->width > image->width || rect->height > image->height || rect->x > image->width - rect->width || rect->y > image->height - rect->height ||
+            (image->yuvFormat != AVIF_PIXEL_FORMAT_YUV400 && ((rect->x & out->yuv.shiftX) || (rect->y & out->yuv.shiftY))))
+            *result = AVIF_RESULT_INVALID_ARGUMENT;
+        out->x0 = rect->x, out->y0 = rect->y, out->w = rect->width, out->h = rect->height;
+    } else {
+        out->x0 = 0, out->y0 = 0, out->w = image->width, out->h = image->height;
+    }
+    return true;
 }
 
 avifResult makeRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, int arithMode, RgbToYuvPlan * out)

@@ -146,6 +146,7 @@ struct YuvToRgbPlan
     int32_t fxAlphaShift;      // FXA_SHIFT: 0 (8-bit), 2 (native 10-bit) or the downshift
     // ---- both arithmetics ----
     int32_t postMulFx;         // the integer post-pass is libyuv's ARGBAttenuate / ARGBUnattenuate (appendix D.4)
+    int32_t mulOfTheCall;      // the MulMode avifImageYUVToRGB derives for these arguments (src/reformat.c:1662-1677), whatever this job applies of it
     uint32_t tuning;           // TuningBits: performance knobs that never change results
 };
 
@@ -197,6 +198,12 @@ struct AlphaMulPlan
 // alpha channel written only when reformatAlpha.
 avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, uint32_t tuning, YuvToRgbPlan * out,
                             bool colorOnly = false, bool reformatAlpha = false);
+// The plan of (image, rgb, rect) from the plan `proto` already made for (protoImage, protoRgb) with the same arithmetic and tuning, when the
+// two jobs differ in nothing a plan is derived from except where their buffers are and which rectangle they convert -- the tiles of a grid,
+// the frames of a sequence.  Returns false when they do differ (the caller then makes the plan from scratch); a 48-tile photograph costs
+// one derivation (colour coefficients, reciprocals, libyuv's dispatch) instead of 48.
+bool rebindYuvToRgbPlan(const YuvToRgbPlan & proto, const avifImage * protoImage, const avifRGBImage * protoRgb, const avifImage * image, const avifRGBImage * rgb,
+                        const avifCropRect * rect, YuvToRgbPlan * out, avifResult * result);
 avifResult makeRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, int arithMode, RgbToYuvPlan * out);
 avifResult makeAlphaMulPlan(const avifRGBImage * rgb, bool unmultiply, int arithMode, AlphaMulPlan * out);
 

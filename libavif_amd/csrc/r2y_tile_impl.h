@@ -196,12 +196,27 @@ __device__ __forceinline__ void storeRow4(uint8_t * base, uint32_t off, f2 t01, 
 //   unmultiply: a == 0 -> 0, a < 1 -> min(c / a, 1), else c.  The three divisions share their divisor: r = RN(1 / a) from v_rcp_f32 and one
 //               Newton step, then q = fma(fma(-q0, a, c), r, q0), q0 = c * r, is the correctly rounded quotient -- enumerated for every pair
 //               of channel codes (c, a) of every depth (tests/tools/verify_fp32_shortcuts.cpp).
-__device__ __forceinline__ float unmulChannel(float c, float d, float r, bool below1, bool zero)
+// (per pixel: the divisor d -- 1 where the reference leaves the channel alone or answers 0 --, its exact reciprocal r -- 0 where the answer
+//  is 0, so that the quotient comes out as 0 without a select per channel -- and the upper clamp: 1 below full alpha, none otherwise)
+struct UnmulOperand
 {
-    const float q0 = c * r;
-    const float q = __builtin_fmaf(__builtin_fmaf(-q0, d, c), r, q0);
-    const float m = below1 ? fminf(q, 1.0f) : c;
-    return zero ? 0.0f : m;
+    float d, r, lim;
+};
+__device__ __forceinline__ UnmulOperand unmulOperand(float a)
+{
+    const bool zero = a == 0.0f, below1 = a < 1.0f;
+    UnmulOperand U;
+    U.d = (zero || !below1) ? 1.0f : a;
+    const float r0 = __builtin_amdgcn_rcpf(U.d);
+    const float r = __builtin_fmaf(__builtin_fmaf(-U.d, r0, 1.0f), r0, r0);
+    U.r = zero ? 0.0f : r;
+    U.lim = below1 ? 1.0f : __builtin_inff();
+    return U;
+}
+__device__ __forceinline__ float unmulChannel(float c, const UnmulOperand & U)
+{
+    const float q0 = c * U.r;
+    return fminf(__builtin_fmaf(__builtin_fmaf(-q0, U.d, c), U.r, q0), U.lim);
 }
 __device__ __forceinline__ void alphaOnPair(bool multiply, f2 a, f2 & x, f2 & g, f2 & z)
 {
@@ -210,17 +225,10 @@ __device__ __forceinline__ void alphaOnPair(bool multiply, f2 a, f2 & x, f2 & g,
         x = x * am, g = g * am, z = z * am;
         return;
     }
-    float xs[2] = { x.x, x.y }, gs[2] = { g.x, g.y }, zs[2] = { z.x, z.y };
-    const float as[2] = { a.x, a.y };
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const bool zero = as[h] == 0.0f, below1 = as[h] < 1.0f;
-        const float d = (zero || !below1) ? 1.0f : as[h];
-        const float r0 = __builtin_amdgcn_rcpf(d);
-        const float r = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
-        xs[h] = unmulChannel(xs[h], d, r, below1, zero), gs[h] = unmulChannel(gs[h], d, r, below1, zero), zs[h] = unmulChannel(zs[h], d, r, below1, zero);
-    }
-    x = (f2) { xs[0], xs[1] }, g = (f2) { gs[0], gs[1] }, z = (f2) { zs[0], zs[1] };
+    const UnmulOperand U0 = unmulOperand(a.x), U1 = unmulOperand(a.y);
+    x = (f2) { unmulChannel(x.x, U0), unmulChannel(x.y, U1) };
+    g = (f2) { unmulChannel(g.x, U0), unmulChannel(g.y, U1) };
+    z = (f2) { unmulChannel(z.x, U0), unmulChannel(z.y, U1) };
 }
 // (int)avifRoundf(AVIF_CLAMP(c * maxF, 0, maxF)): a normalised channel back to its code for the YCgCo-R lifting, src/reformat.c:375-377
 __device__ __forceinline__ int liftCode(float c, float maxf)
@@ -581,6 +589,120 @@ hipError_t launchFamily(const R2YKey & k, const R2YArgs & A, uint32_t blocks, hi
     if (k.nch == 4)
         return k.wideYuv ? launchSub<RT, 4, uint16_t>(k.sub, A, blocks, stream) : launchSub<RT, 4, uint8_t>(k.sub, A, blocks, stream);
     return k.wideYuv ? launchSub<RT, 3, uint16_t>(k.sub, A, blocks, stream) : launchSub<RT, 3, uint8_t>(k.sub, A, blocks, stream);
+}
+
+// ---- gray sources (GRAY / GRAYA / AGRAY -> the luma plane, src/reformat.c:471-519; the chroma planes, if any, are set to the half value by
+//      the caller and the alpha plane is written here: copy / depth rescale / opaque fill).  A lane owns the PPL pixels of one 16-byte load,
+//      a wave 64 of them of ROWS consecutive rows (all loads issued first); luma and alpha leave as 16-byte stores where PPL samples fill
+//      them.  Arithmetic: g = code / max in the verified reciprocal form, the pending alpha (un)multiply of alphaOnPair, the quantiser
+//      of the colour kernels ----
+template <typename RT, int GCH, typename YT, bool AFIRST>
+__global__ __launch_bounds__(256) void grayToYuvTileKernel(GrayArgs A)
+{
+    constexpr int PPL = 16 / (GCH * (int)sizeof(RT)); // pixels per lane: 16 (GRAY8), 8 (GRAYA8, GRAY16), 4 (GRAYA16)
+    constexpr int ROWS = 2;
+    const uint32_t X = (blockIdx.x * kLanes + threadIdx.x) * PPL;
+    const uint32_t row0 = (blockIdx.y * kWaves + threadIdx.y) * ROWS;
+    if (X >= A.wP || row0 >= A.height)
+        return;
+    u4 raw[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t j = (row0 + r < A.height) ? row0 + r : row0;
+        raw[r] = *reinterpret_cast<const u4 *>(A.gray + (size_t)j * A.grayPitch + (size_t)X * (GCH * sizeof(RT)));
+    }
+    // (every branch below is wave-uniform and spans all of a row's pixels: a first version that tested the alpha mode per pixel spent its
+    //  time in 800 scalar branches per wave -- 37 us for an 8K GRAY8 frame)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        if (row0 + r >= A.height)
+            break;
+        const unsigned w[4] = { raw[r].x, raw[r].y, raw[r].z, raw[r].w };
+        // channel k (0 .. GCH-1, memory order) of pixel i
+        auto chan = [&](int i, int k) -> unsigned {
+            const int idx = i * GCH + k;
+            if constexpr (sizeof(RT) == 1)
+                return (w[idx >> 2] >> (8 * (idx & 3))) & 0xffu;
+            else
+                return (w[idx >> 1] >> (16 * (idx & 1))) & 0xffffu;
+        };
+        float g[PPL];
+        unsigned ca[PPL];
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            g[i] = divExact((float)chan(i, (GCH == 2 && AFIRST) ? 1 : 0), A.rcpRgbMax);
+            ca[i] = (GCH == 2) ? chan(i, AFIRST ? 0 : 1) : 0u;
+        }
+        if constexpr (GCH == 2) {
+            if (A.mulMode == MUL_MULTIPLY) {
+#pragma unroll
+                for (int i = 0; i < PPL; ++i)
+                    g[i] = g[i] * fminf(divExact((float)ca[i], A.rcpRgbMax), 1.0f);
+            } else if (A.mulMode == MUL_UNMULTIPLY) {
+#pragma unroll
+                for (int i = 0; i < PPL; ++i)
+                    g[i] = unmulChannel(g[i], unmulOperand(divExact((float)ca[i], A.rcpRgbMax)));
+            }
+        }
+        uint8_t * yRow = A.y + (size_t)(row0 + r) * A.yPitch + (size_t)X * sizeof(YT);
+#pragma unroll
+        for (int q = 0; q < PPL / 4; ++q) {
+            float t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                t[i] = ((g[4 * q + i] * A.rangeY) + A.biasY) + 0.5f;
+            if constexpr (sizeof(YT) == 1) {
+                storeOut(packU8x4(t[0], t[1], t[2], t[3]), reinterpret_cast<unsigned *>(yRow + 4 * q));
+            } else {
+                const int yq[4] = { truncClamp(t[0], (int)A.yuvMax), truncClamp(t[1], (int)A.yuvMax), truncClamp(t[2], (int)A.yuvMax), truncClamp(t[3], (int)A.yuvMax) };
+                store4Samples<YT>(yRow, 8 * q, yq);
+            }
+        }
+        if (A.alphaMode != R2Y_ALPHA_NONE) {
+            uint8_t * aRow = A.a + (size_t)(row0 + r) * A.aPitch + (size_t)X * sizeof(YT);
+            int aq[PPL];
+            if (A.alphaMode == R2Y_ALPHA_COPY) {
+#pragma unroll
+                for (int i = 0; i < PPL; ++i)
+                    aq[i] = (int)ca[i];
+            } else if (A.alphaMode == R2Y_ALPHA_RESCALE) {
+#pragma unroll
+                for (int i = 0; i < PPL; ++i)
+                    aq[i] = clampInt((int)(0.5f + (divExact((float)ca[i], A.rcpRgbMax) * A.yuvMaxF)), 0, (int)A.yuvMax);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPL; ++i)
+                    aq[i] = (int)A.yuvMax;
+            }
+#pragma unroll
+            for (int q = 0; q < PPL / 4; ++q)
+                store4Samples<YT>(aRow, (uint32_t)(4 * q * sizeof(YT)), &aq[4 * q]);
+        }
+    }
+}
+
+template <typename RT>
+hipError_t launchGray(int gch, bool wideYuv, const GrayArgs & A, hipStream_t stream)
+{
+    const uint32_t ppl = 16u / ((uint32_t)gch * (uint32_t)sizeof(RT));
+    const dim3 block(kLanes, kWaves), grid((A.wP / ppl + kLanes - 1) / kLanes, (A.height + 2 * kWaves - 1) / (2 * kWaves));
+    if (gch == 1) {
+        if (wideYuv)
+            hipLaunchKernelGGL((grayToYuvTileKernel<RT, 1, uint16_t, false>), grid, block, 0, stream, A);
+        else
+            hipLaunchKernelGGL((grayToYuvTileKernel<RT, 1, uint8_t, false>), grid, block, 0, stream, A);
+    } else if (A.alphaFirst) {
+        if (wideYuv)
+            hipLaunchKernelGGL((grayToYuvTileKernel<RT, 2, uint16_t, true>), grid, block, 0, stream, A);
+        else
+            hipLaunchKernelGGL((grayToYuvTileKernel<RT, 2, uint8_t, true>), grid, block, 0, stream, A);
+    } else {
+        if (wideYuv)
+            hipLaunchKernelGGL((grayToYuvTileKernel<RT, 2, uint16_t, false>), grid, block, 0, stream, A);
+        else
+            hipLaunchKernelGGL((grayToYuvTileKernel<RT, 2, uint8_t, false>), grid, block, 0, stream, A);
+    }
+    return hipGetLastError();
 }
 
 } // namespace r2y

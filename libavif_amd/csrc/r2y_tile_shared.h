@@ -63,6 +63,24 @@ struct R2YKey
     bool hasMul; // pending alpha (un)multiply (kernel name only: a wave-uniform branch inside the kernels)
 };
 
+// gray sources (r2y_tile_impl.h grayToYuvTileKernel)
+struct GrayArgs
+{
+    const uint8_t * gray; // source pixels
+    uint8_t * y;
+    uint8_t * a;
+    uint32_t grayPitch, yPitch, aPitch;
+    uint32_t wP, height; // columns converted here (a multiple of the pixels per lane) and rows
+    RcpHL rcpRgbMax;
+    float rangeY, biasY, yuvMaxF;
+    uint32_t yuvMax;
+    uint32_t alphaFirst; // AGRAY
+    int32_t alphaMode;   // R2Y_ALPHA_*
+    int32_t mulMode;
+};
+hipError_t launchR2YGray8(int grayChannels, bool wideYuv, const GrayArgs & args, hipStream_t stream);
+hipError_t launchR2YGray16(int grayChannels, bool wideYuv, const GrayArgs & args, hipStream_t stream);
+
 hipError_t launchR2YTileRgb8(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);
 hipError_t launchR2YTileRgb16(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);
 hipError_t launchR2YTileFx(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
-    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
+    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
     "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap",
 ]
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
         "avifhipStreamDestroy": (None, [vp]),
         "avifhipSetTuning": (None, [u32]),
         "avifhipImageYUVToRGBColorOnly": (i32, [P_IMG, P_RGB, i32]),
+        "avifhipImageYUVToRGBHook": (i32, [P_IMG, P_RGB, i32, C.POINTER(C.c_uint32)]),
         "avifhipRGBImageToF16": (i32, [P_RGB]),
         "avifhipLaunchCount": (C.c_uint64, []),
         "avifhipTimeYUVToRGBCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),

@@ -210,3 +210,68 @@ def test_hooks_from_libavif_worker_threads(libs, hip, arith):
                 assert ro == 0 and np.array_equal(po, outs[0]), (c.ident(), H.describe_diff(po, outs[0]))
     finally:
         hip.avifhipSetArithmetic(1)
+
+
+# ---- the colour hook folds libavif's next steps (src/reformat.c:1574-1590) into its own pass ---------------------
+
+
+def _fold_case():
+    # cfg3's shape in small: 10-bit 4:4:4 + alpha -> premultiplied RGBA16 (libyuv declines 16-bit pixels: fp32 colour, integer post-pass)
+    return H.Y2RCase(640, 66, yuv_depth=10, yuv_format=1, yuv_range=1, matrix=9, alpha=True, rgb_depth=16, rgb_premultiplied=True, avoid_libyuv=False)
+
+
+def test_pending_premultiply_costs_no_second_pass(libs, hip_auto_arithmetic):
+    """avifImageYUVToRGB with a pending premultiply used to be two hook calls, each moving the image across the bus both ways; the colour hook now
+    returns the final pixels and answers libavif's follow-up call itself -- and only that one."""
+    be, _ = libs
+    lib, o = hip_auto_arithmetic, H.oracle_libyuv_backend()
+    for c in (_fold_case(), replace(_fold_case(), is_float=True), replace(_fold_case(), rgb_depth=8, yuv_depth=8, image_premultiplied=True, rgb_premultiplied=False, yuv_format=1)):
+        want_r, want = H.run_y2r(o, c)
+        before = lib.avifhipLaunchCount()
+        got_r, got = H.run_y2r(be, c)
+        launches = lib.avifhipLaunchCount() - before
+        assert got_r == want_r == 0 and np.array_equal(got, want), (c.ident(), H.describe_diff(want, got))
+        # one conversion kernel (plus at most the two leftover launches of the tiled route): no separate (un)premultiply / half-float pass
+        assert 1 <= launches <= 3, (c.ident(), launches)
+    # ... and a later, separate premultiply of the application on the same buffer is a real one (no stale note)
+    c = _fold_case()
+    out = H.make_y2r_output(c)
+    img = H.make_y2r_inputs(c)
+    assert be.yuv_to_rgb(img.struct, out.struct) == 0
+    out.pixels.view(np.uint16)[:, 3::4] //= 2  # the application edits alpha ...
+    twin = H.make_y2r_output(c)
+    twin.pixels[...] = out.pixels
+    before = lib.avifhipLaunchCount()
+    assert be.premultiply(out.struct) == 0 and o.premultiply(twin.struct) == 0  # ... and premultiplies again
+    assert lib.avifhipLaunchCount() > before
+    assert np.array_equal(out.pixels, twin.pixels), H.describe_diff(twin.pixels, out.pixels)
+
+
+def test_changed_pixels_between_hook_calls_fall_back_to_the_staged_path(libs, hip_auto_arithmetic):
+    """The hooks called directly (internal symbols), pixels changed in between: the follow-up hook must do real work on the changed pixels."""
+    lib = hip_auto_arithmetic
+    raw = C.CDLL(os.fspath(BACKEND_SO), mode=os.RTLD_LOCAL)
+    y2r = raw.avifImageYUVToRGBLibYUV
+    y2r.restype, y2r.argtypes = C.c_int, [C.POINTER(abi.avifImage), C.POINTER(abi.avifRGBImage), C.c_int, C.POINTER(C.c_int)]
+    pre = raw.avifRGBImagePremultiplyAlphaLibYUV
+    pre.restype, pre.argtypes = C.c_int, [C.POINTER(abi.avifRGBImage)]
+    c = _fold_case()
+    img = H.make_y2r_inputs(c)
+    o = H.oracle_libyuv_backend()
+    for mutate in (False, True):
+        out = H.make_y2r_output(c)
+        flag = C.c_int(0)
+        assert y2r(img.struct, out.struct, 1, C.byref(flag)) == 0 and flag.value == 1
+        folded = out.pixels.copy()  # final pixels: already premultiplied
+        if mutate:
+            out.pixels[...] ^= 0x01
+        before = lib.avifhipLaunchCount()
+        assert pre(out.struct) == 0
+        if not mutate:
+            assert lib.avifhipLaunchCount() == before and np.array_equal(out.pixels, folded)  # answered from the note
+        else:
+            assert lib.avifhipLaunchCount() > before  # a real premultiply of what is there now
+            twin = H.make_y2r_output(c)
+            twin.pixels[...] = folded ^ 0x01
+            assert o.premultiply(twin.struct) == 0
+            assert np.array_equal(out.pixels, twin.pixels), H.describe_diff(twin.pixels, out.pixels)
