@@ -66,10 +66,11 @@ bool tileRgbToYuvSupported(const RgbToYuvPlan & p)
             return false;
         if (p.mul != MUL_NONE && !o.hasAlpha)
             return false;
-        const uint32_t ybps = (uint32_t)s.chanBytes;
-        if (!alignedTo(o.pixels, o.rowBytes, 16) || !alignedTo(s.plane[0], s.rowBytes[0], 4 * ybps))
+        const uint32_t ybps = (uint32_t)s.chanBytes, ppl = 16u / ((o.hasAlpha ? 2u : 1u) * (uint32_t)o.chanBytes);
+        const uint32_t planeVec = ppl * ybps < 16u ? ppl * ybps : 16u; // a lane's samples of a plane row leave as one store (16 bytes at most)
+        if (!alignedTo(o.pixels, o.rowBytes, 16) || !alignedTo(s.plane[0], s.rowBytes[0], planeVec))
             return false;
-        if (p.alphaSource != ALPHA_KEEP && (!s.alpha || !alignedTo(s.alpha, s.alphaRowBytes, 4 * ybps)))
+        if (p.alphaSource != ALPHA_KEEP && (!s.alpha || !alignedTo(s.alpha, s.alphaRowBytes, planeVec)))
             return false;
         return true;
     }

@@ -644,7 +644,21 @@ __global__ __launch_bounds__(256) void grayToYuvTileKernel(GrayArgs A)
                     g[i] = unmulChannel(g[i], unmulOperand(divExact((float)ca[i], A.rcpRgbMax)));
             }
         }
-        uint8_t * yRow = A.y + (size_t)(row0 + r) * A.yPitch + (size_t)X * sizeof(YT);
+        // the lane's PPL samples of a plane row as dwords, stored 16 bytes at a time where that many exist (4-byte stores at a lane stride of
+        // 16 made every store instruction touch a quarter of each cache line: 31 us for an 8K GRAY8 frame)
+        constexpr int kWords = PPL * (int)sizeof(YT) / 4; // 4 (GRAY8 -> 8-bit), 8 (GRAY8 -> 16-bit), 2, 4, 1 or 2
+        auto storePlaneRow = [&](uint8_t * dst, const unsigned (&wd)[kWords]) {
+            if constexpr (kWords >= 4) {
+#pragma unroll
+                for (int h = 0; h < kWords / 4; ++h)
+                    storeOut((u4) { wd[4 * h], wd[4 * h + 1], wd[4 * h + 2], wd[4 * h + 3] }, reinterpret_cast<u4 *>(dst + 16 * h));
+            } else if constexpr (kWords == 2) {
+                storeOut((u2) { wd[0], wd[1] }, reinterpret_cast<u2 *>(dst));
+            } else {
+                storeOut(wd[0], reinterpret_cast<unsigned *>(dst));
+            }
+        };
+        unsigned yw[kWords];
 #pragma unroll
         for (int q = 0; q < PPL / 4; ++q) {
             float t[4];
@@ -652,31 +666,39 @@ __global__ __launch_bounds__(256) void grayToYuvTileKernel(GrayArgs A)
             for (int i = 0; i < 4; ++i)
                 t[i] = ((g[4 * q + i] * A.rangeY) + A.biasY) + 0.5f;
             if constexpr (sizeof(YT) == 1) {
-                storeOut(packU8x4(t[0], t[1], t[2], t[3]), reinterpret_cast<unsigned *>(yRow + 4 * q));
+                yw[q] = packU8x4(t[0], t[1], t[2], t[3]);
             } else {
-                const int yq[4] = { truncClamp(t[0], (int)A.yuvMax), truncClamp(t[1], (int)A.yuvMax), truncClamp(t[2], (int)A.yuvMax), truncClamp(t[3], (int)A.yuvMax) };
-                store4Samples<YT>(yRow, 8 * q, yq);
+                yw[2 * q] = (unsigned)truncClamp(t[0], (int)A.yuvMax) | ((unsigned)truncClamp(t[1], (int)A.yuvMax) << 16);
+                yw[2 * q + 1] = (unsigned)truncClamp(t[2], (int)A.yuvMax) | ((unsigned)truncClamp(t[3], (int)A.yuvMax) << 16);
             }
         }
+        storePlaneRow(A.y + (size_t)(row0 + r) * A.yPitch + (size_t)X * sizeof(YT), yw);
         if (A.alphaMode != R2Y_ALPHA_NONE) {
-            uint8_t * aRow = A.a + (size_t)(row0 + r) * A.aPitch + (size_t)X * sizeof(YT);
-            int aq[PPL];
+            unsigned aq[PPL];
             if (A.alphaMode == R2Y_ALPHA_COPY) {
 #pragma unroll
                 for (int i = 0; i < PPL; ++i)
-                    aq[i] = (int)ca[i];
+                    aq[i] = ca[i];
             } else if (A.alphaMode == R2Y_ALPHA_RESCALE) {
 #pragma unroll
                 for (int i = 0; i < PPL; ++i)
-                    aq[i] = clampInt((int)(0.5f + (divExact((float)ca[i], A.rcpRgbMax) * A.yuvMaxF)), 0, (int)A.yuvMax);
+                    aq[i] = (unsigned)clampInt((int)(0.5f + (divExact((float)ca[i], A.rcpRgbMax) * A.yuvMaxF)), 0, (int)A.yuvMax);
             } else {
 #pragma unroll
                 for (int i = 0; i < PPL; ++i)
-                    aq[i] = (int)A.yuvMax;
+                    aq[i] = A.yuvMax;
             }
+            unsigned aw[kWords];
 #pragma unroll
-            for (int q = 0; q < PPL / 4; ++q)
-                store4Samples<YT>(aRow, (uint32_t)(4 * q * sizeof(YT)), &aq[4 * q]);
+            for (int q = 0; q < PPL / 4; ++q) {
+                if constexpr (sizeof(YT) == 1) {
+                    aw[q] = aq[4 * q] | (aq[4 * q + 1] << 8) | (aq[4 * q + 2] << 16) | (aq[4 * q + 3] << 24);
+                } else {
+                    aw[2 * q] = aq[4 * q] | (aq[4 * q + 1] << 16);
+                    aw[2 * q + 1] = aq[4 * q + 2] | (aq[4 * q + 3] << 16);
+                }
+            }
+            storePlaneRow(A.a + (size_t)(row0 + r) * A.aPitch + (size_t)X * sizeof(YT), aw);
         }
     }
 }

@@ -154,54 +154,70 @@ __device__ __forceinline__ void mapTransposeWrite(unsigned * tile, uint32_t y, c
 
 // the workgroup's tile out, column by column: wave `wv` (0..3) takes 64 of the 256 columns.  `bandX0`: the tile's first column within the
 // rectangle, `row0`: its first row within the rectangle; rows / columns beyond the rectangle (w4 x h2) hold nothing.
-template <int PW>
+// PB: bytes per pixel -- 4 or 8 (one 16-byte store per lane and run piece), or 3 (the packed kernels' RGB8: pixels arrive as words, leave as
+// three bytes each).  Everything that does not depend on the iteration is formed once per lane: which tile rows the lane gathers, where
+// they land along the destination row, whether they exist; an iteration only advances the source column -- the first version recomputed
+// all of it per iteration and spent more instructions on storing a quarter turn than on converting the pixels (61 against 36 per pixel for
+// 10-bit -> RGBA10, profiles/r03_tail_pmc.txt).
+template <int PW, int PB = 4 * PW, uint32_t ROWS = MapTile<PW>::kRows>
 __device__ __forceinline__ void mapTransposeStore(const TileArgs & A, const unsigned * tile, uint32_t wv, uint32_t bandX0, uint32_t row0)
 {
-    constexpr uint32_t ROWS = MapTile<PW>::kRows, PPL = 4u / (uint32_t)PW; // pixels per lane and store: 16 bytes
+    constexpr uint32_t PPL = 4u / (uint32_t)PW; // pixels per lane and store: 16 bytes
     constexpr uint32_t RL = ROWS / PPL, RUNS = 64u / RL;                   // lanes per run, runs per store instruction: 8 and 8
     const PixelMap & m = A.map;
     const uint32_t l = threadIdx.x, t = l % RL;
     const bool fwd = m.sx > 0;
+    // ---- per lane, once: its PPL tile rows in ascending destination order (backwards when the turn reverses them) ----
+    uint32_t rowWord[PPL], swz[PPL], xDst[PPL];
+    bool ok[PPL], all = true;
 #pragma unroll
-    for (uint32_t q = 0; q < 64u / RUNS; ++q) {
-        const uint32_t xs = wv * 64u + q * RUNS + l / RL; // source column of the tile
-        if (bandX0 + xs >= A.w4)
+    for (uint32_t k = 0; k < PPL; ++k) {
+        const uint32_t p = PPL * t + k, yr = fwd ? p : ROWS - 1u - p;
+        const uint32_t jj = (uint32_t)A.mapY0 + row0 + yr - m.cy;
+        rowWord[k] = yr * 256u, swz[k] = mapSwizzle<PW>(yr);
+        xDst[k] = (uint32_t)(m.sx * (int32_t)jj + m.kx);
+        ok[k] = row0 + yr < A.h2 && jj < m.ch;
+        all = all && ok[k];
+    }
+    // ---- the lane's first source column; an iteration moves RUNS columns on: one destination row pitch times +-RUNS further ----
+    uint32_t xs = wv * 64u + l / RL;
+    const uint32_t iiBase = (uint32_t)A.mapX0 + bandX0 - m.cx; // (wraps when the tile starts left of the crop: ii is compared unsigned)
+    // (signed: a lane whose first column lies left of the crop starts at a negative row and steps into the image)
+    uint8_t * dstRow = A.rgb + (ptrdiff_t)(m.sy * (int32_t)(iiBase + xs) + m.ky) * (ptrdiff_t)A.rgbPitch;
+    const ptrdiff_t rowStep = (ptrdiff_t)m.sy * (ptrdiff_t)RUNS * (ptrdiff_t)A.rgbPitch;
+#pragma unroll
+    for (uint32_t q = 0; q < 64u / RUNS; ++q, xs += RUNS, dstRow += rowStep) {
+        if (bandX0 + xs >= A.w4 || iiBase + xs >= m.cw)
             continue;
-        const uint32_t ii = (uint32_t)A.mapX0 + bandX0 + xs - m.cx;
-        if (ii >= m.cw)
-            continue;
-        uint8_t * dstRow = A.rgb + (size_t)(uint32_t)(m.sy * (int32_t)ii + m.ky) * A.rgbPitch;
-        // the lane's pixels in ascending destination order: tile rows PPL * t .. + PPL - 1, backwards when the turn reverses them
         unsigned px[PPL][PW];
-        uint32_t jj[PPL];
-        bool ok[PPL], all = true;
 #pragma unroll
         for (uint32_t k = 0; k < PPL; ++k) {
-            const uint32_t p = PPL * t + k, yr = fwd ? p : ROWS - 1u - p;
-            const uint32_t e = yr * 256u + (xs ^ mapSwizzle<PW>(yr));
+            const uint32_t e = rowWord[k] + (xs ^ swz[k]);
             if constexpr (PW == 1) {
                 px[k][0] = tile[e];
             } else {
                 const mu2 v = *reinterpret_cast<const mu2 *>(tile + 2u * e);
                 px[k][0] = v.x, px[k][1] = v.y;
             }
-            jj[k] = (uint32_t)A.mapY0 + row0 + yr - m.cy;
-            ok[k] = row0 + yr < A.h2 && jj[k] < m.ch;
-            all = all && ok[k];
         }
-        if (all) {
-            const uint32_t x0 = (uint32_t)(m.sx * (int32_t)jj[0] + m.kx);
+        if (PB != 3 && all) {
             mu4 v;
             if constexpr (PW == 1)
                 v = (mu4) { px[0][0], px[1][0], px[2][0], px[3][0] };
             else
                 v = (mu4) { px[0][0], px[0][1], px[1][0], px[1][1] };
-            *reinterpret_cast<mu4a4 *>(dstRow + (size_t)x0 * (4u * PW)) = v;
+            *reinterpret_cast<mu4a4 *>(dstRow + (size_t)xDst[0] * PB) = v;
         } else {
 #pragma unroll
-            for (uint32_t k = 0; k < PPL; ++k)
-                if (ok[k])
-                    mapStorePixel<PW>(dstRow + (size_t)(uint32_t)(m.sx * (int32_t)jj[k] + m.kx) * (4u * PW), px[k]);
+            for (uint32_t k = 0; k < PPL; ++k) {
+                if (!ok[k])
+                    continue;
+                uint8_t * dst = dstRow + (size_t)xDst[k] * PB;
+                if constexpr (PB == 3)
+                    dst[0] = (uint8_t)px[k][0], dst[1] = (uint8_t)(px[k][0] >> 8), dst[2] = (uint8_t)(px[k][0] >> 16);
+                else
+                    mapStorePixel<PW>(dst, px[k]);
+            }
         }
     }
 }

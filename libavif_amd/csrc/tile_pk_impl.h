@@ -625,44 +625,11 @@ __device__ __forceinline__ void pkTransposeWrite(unsigned * tile, uint32_t wy, c
     }
 }
 
+// (the way out is tile_map_impl.h's mapTransposeStore: the same layout, everything invariant hoisted out of its loop)
 template <int NCH, int NSW>
 __device__ __forceinline__ void pkTransposeStore(const TileArgs & A, const unsigned * tile, uint32_t wv, uint32_t bandX0, uint32_t row0)
 {
-    constexpr uint32_t ROWS = 8 * NSW, RL = ROWS / 4, RUNS = 64 / RL; // lanes per run, runs per store instruction
-    const PixelMap & m = A.map;
-    const uint32_t l = threadIdx.x, t4 = l % RL;
-    const bool fwd = m.sx > 0;
-#pragma unroll
-    for (uint32_t q = 0; q < RL; ++q) {
-        const uint32_t xs = (wv * RL + q) * RUNS + l / RL; // source column of the tile
-        if (bandX0 + xs >= A.w4)
-            continue;
-        const uint32_t ii = (uint32_t)A.mapX0 + bandX0 + xs - m.cx;
-        if (ii >= m.cw)
-            continue;
-        uint8_t * dstRow = A.rgb + (size_t)(uint32_t)(m.sy * (int32_t)ii + m.ky) * A.rgbPitch;
-        // the lane's four pixels in ascending destination order: tile rows 4 * t4 .. + 3, backwards when the turn reverses them
-        unsigned px[4];
-        uint32_t jj[4];
-        bool ok[4], all = true;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t p = 4u * t4 + k, yr = fwd ? p : ROWS - 1u - p;
-            px[k] = tile[yr * 256u + (xs ^ (4u * ((yr >> 2) & 7u)))];
-            jj[k] = (uint32_t)A.mapY0 + row0 + yr - m.cy;
-            ok[k] = row0 + yr < A.h2 && jj[k] < m.ch;
-            all = all && ok[k];
-        }
-        if (NCH == 4 && all) {
-            const uint32_t x0 = (uint32_t)(m.sx * (int32_t)jj[0] + m.kx);
-            *reinterpret_cast<u4a4 *>(dstRow + (size_t)x0 * 4u) = (u4) { px[0], px[1], px[2], px[3] };
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k)
-                if (ok[k])
-                    pkStorePixel<NCH>(dstRow + (size_t)(uint32_t)(m.sx * (int32_t)jj[k] + m.kx) * NCH, px[k]);
-        }
-    }
+    mapTransposeStore<1, NCH, 8u * (uint32_t)NSW>(A, tile, wv, bandX0, row0); // (32 rows, or 16 for small jobs)
 }
 
 // ---- filter, matrix, stores of a wave tile ----

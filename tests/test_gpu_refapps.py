@@ -157,7 +157,7 @@ def test_avifyuv_drift_bounded(apps):
     outs = []
     for exe in ("avifyuv_ref", "avifyuv_hip"):
         env = dict(os.environ, AVIFHIP_ARITHMETIC="float", AVIFHIP_MIN_PIXELS="0")
-        proc = subprocess.run(["timeout", "-s", "INT", "60", "stdbuf", "-oL", os.fspath(apps / exe), "-m", "drift"], capture_output=True, text=True, env=env)
+        proc = subprocess.run(["timeout", "-s", "INT", "30", "stdbuf", "-oL", os.fspath(apps / exe), "-m", "drift"], capture_output=True, text=True, env=env)
         lines = proc.stdout.splitlines()
         outs.append(lines[:-1] if lines else lines)  # the last line may be cut
     n = min(len(outs[0]), len(outs[1]))
