@@ -320,6 +320,10 @@ AVIFHIP_API avifResult avifhipExplainYUVToRGB(const avifImage * image, const avi
 AVIFHIP_API avifResult avifhipExplainRGBToYUV(const avifImage * image, const avifRGBImage * rgb, char * text, size_t size);
 /* Number of conversions this thread has enqueued on a GPU so far (tests: proves the HIP path, not a fallback, ran). */
 AVIFHIP_API uint64_t avifhipLaunchCount(void);
+/* Number of batch / grid descriptor tables this thread has sent to the device.  A batch or grid call whose buffers, geometry and settings
+ * equal the previous one's (a decoder converting into the same tile buffers frame after frame) launches on the table the device still
+ * holds and does not count (tests). */
+AVIFHIP_API uint64_t avifhipTableUploadCount(void);
 AVIFHIP_API const char * avifhipVersion(void);
 
 /* Plain device-memory helpers so C callers (and the ctypes tests) need no HIP headers. */

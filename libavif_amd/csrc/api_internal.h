@@ -1,5 +1,5 @@
-// api_internal.h -- what the translation units behind the C ABI share (api.cpp: conversion path; api_gainmap.cpp: gain maps;
-// api_scale.cpp: plane scaling): the per-thread context (stream, device scratch, table caches), error plumbing, staging helpers.
+// api_internal.h -- what the translation units behind the C ABI share (api.cpp: context and control; api_decode / _batch / _encode / _apps.cpp:
+// the conversion path; api_gainmap.cpp: gain maps; api_scale.cpp: plane scaling): the per-thread context (stream, device scratch, table caches), error plumbing, staging helpers.
 // Internal to libavifhip.so (hidden visibility).
 #pragma once
 
@@ -106,7 +106,7 @@ struct Context
     int ownerPid = 0;   // the process that built it: a fork()ed child must not use the parent's streams or wait for its helper thread
     hipStream_t stream = nullptr;
     // host-resident calls split large images into row bands: uploads and downloads of different bands run on these two while
-    // `stream` computes (api.cpp: yuvToRgbSync)
+    // `stream` computes (api_decode.cpp: yuvToRgbSync)
     hipStream_t upStream = nullptr, downStream = nullptr;
     static constexpr int kMaxBands = 16;
     hipEvent_t bandUp[kMaxBands] = {}, bandDone[kMaxBands] = {};
@@ -122,13 +122,20 @@ struct Context
                          // computation: [6] tables, [7] ratios, [8] histograms, [9] alternate pixels, [10] gain-map planes
     GainMapTableCache gainMapCache; // what gainMap[2] holds
     // batch descriptor tables travel through a ring of kTableRing slots (pinned host memory + the matching slice of `table`), uploaded on
-    // `upStream`: the host prepares batch n + 1 and its table crosses the link while batch n computes (api.cpp: batchAsyncImpl)
+    // `upStream`: the host prepares batch n + 1 and its table crosses the link while batch n computes (api_batch.cpp: batchAsyncImpl)
     static constexpr int kTableRing = 4;
     void * pinnedTable = nullptr;
     size_t pinnedTableCapacity = 0; // bytes per slot
     uint32_t tableSlot = 0;
     hipEvent_t tableCopied[kTableRing] = {};   // the slot's upload has left the pinned memory (and the device slice holds it)
     hipEvent_t tableConsumed[kTableRing] = {}; // the kernels reading the slot's device slice are done
+    bool tableSlotIdle[kTableRing] = { true, true, true, true }; // no upload out of the slot's pinned memory since the thread last waited for tableCopied
+    // the most recent upload, if small: a batch whose table is byte-identical launches on the copy the device still holds (batchAsyncImpl)
+    static constexpr size_t kResidentTableMax = 256 * 1024;
+    int residentSlot = -1;
+    size_t residentBytes = 0;
+    hipStream_t residentStream = nullptr;
+    bool residentAllTiled = false;
     void * pinnedUpload = nullptr; // staging for small host tables (grid tile tables, scale schedules): a ring of kTableRing slots, so that the
     size_t pinnedUploadCapacity = 0; // calling thread does not wait for the previous call's upload (which sits behind that call's kernels); bytes per slot
     uint32_t uploadSlot = 0;
@@ -140,6 +147,7 @@ struct Context
     char lastError[512] = { 0 };
     const char * lastKernel = "";
     uint64_t launches = 0; // kernels enqueued by this thread
+    uint64_t tableUploads = 0; // batch tables sent to the device by this thread
     uint64_t bytesUp = 0, bytesDown = 0; // host link traffic of the last avifhipImageYUVToRGBRects call
 
     ~Context()
@@ -224,7 +232,7 @@ struct ScratchScope
     ScratchScope(const ScratchScope &) = delete;
     ScratchScope & operator=(const ScratchScope &) = delete;
 };
-// Enqueues a copy of a small host table to device memory through a pinned per-thread staging buffer (see api.cpp)
+// Enqueues a copy of a small host table to device memory through a pinned per-thread staging buffer (api.cpp: uploadTableAsync)
 avifResult uploadTableAsync(void * deviceDst, const void * hostSrc, size_t bytes, hipStream_t stream);
 avifResult reserve(Scratch & s, size_t bytes);
 bool isDevicePointer(const void * p);
@@ -261,6 +269,30 @@ inline PlaneDims planeDims(uint32_t width, uint32_t height, int yuvFormat)
     d.w[1] = d.w[2] = (int)((width + sx) >> sx), d.h[1] = d.h[2] = (int)((height + sy) >> sy);
     return d;
 }
+
+// library-wide settings (avifhipSetArithmetic / SetTiledKernels / SetTuning)
+extern std::atomic<int> gArithmetic;
+extern std::atomic<int> gTiledKernels;
+extern std::atomic<uint32_t> gTuning;
+int effectiveArithmetic();
+// launches of the planned conversions on `stream` (tiled kernels where the plan allows, the universal kernel otherwise)
+avifResult enqueueYuvToRgb(const YuvToRgbPlan & plan, hipStream_t stream);
+avifResult enqueueRgbToYuv(const RgbToYuvPlan & plan, hipStream_t stream);
+avifResult enqueueAlphaMul(const AlphaMulPlan & plan, hipStream_t stream);
+void finishRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, RgbToYuvPlan * plan);
+bool sharpYuvRequested(const avifImage * image, const avifRGBImage * rgb);
+// row bands of a host-resident call (api_decode.cpp: yuvToRgbSync): rows per band -- multiples of 32 rows, at least ~2 megapixels each
+uint32_t bandRowsFor(uint32_t width, uint32_t height);
+// leaves no download running into the caller's memory when a banded call returns early
+struct DrainOnExit
+{
+    CopyWorker * worker;
+    ~DrainOnExit()
+    {
+        if (worker)
+            (void)worker->drain();
+    }
+};
 
 } // namespace api
 } // namespace avifhip

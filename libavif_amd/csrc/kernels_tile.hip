@@ -208,7 +208,7 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
     if (o.map.on) {
         // fused crop / rotate / mirror: the packed 16-bit kernels (3- and 4-byte pixels) and the wave-private fp32 kernels (4-channel pixels of
         // 4 or 8 bytes: tile_map_impl.h) store through the map; every other family leaves it to the universal kernel (the entry points
-        // convert into scratch and run the transform pass instead: api.cpp)
+        // convert into scratch and run the transform pass instead: api_batch.cpp)
         const bool packed = p.arith == ARITH_LIBYUV && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE && (s.chanBytes == 1 || (p.tuning & TUNE_COOPERATIVE) == 0);
         const bool fp32Mapped = p.arith != ARITH_LIBYUV && !o.isGray && !o.is565 && o.hasAlpha && (o.pixBytes == 4 || o.pixBytes == 8);
         if (!(packed && (o.pixBytes == 4 || o.pixBytes == 3)) && !fp32Mapped)

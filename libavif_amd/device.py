@@ -90,6 +90,19 @@ class DeviceYUV:
                 self.struct.alphaPlane = buf.ptr
                 self.struct.alphaRowBytes = pitch
 
+    def upload(self) -> None:
+        """Copies the host twin's planes into the device buffers again (new samples in the same buffers)."""
+        hs = self.host.struct
+        bps = 2 if hs.depth > 8 else 1
+        for p in range(4):
+            src = self.host.alpha if p == 3 else self.host.planes[p]
+            if src is None or self.buffers[p] is None:
+                continue
+            w, h = self.geo[p]
+            staged = np.zeros((h, self.pitch[p]), dtype=np.uint8)
+            staged[:, : w * bps] = src[:h, : w * bps]
+            self.buffers[p].upload(staged)
+
     def download_into_host(self) -> None:
         """Copies the device planes back into the host twin (RGB->YUV results)."""
         hs = self.host.struct
@@ -118,6 +131,12 @@ class DeviceRGB:
             self.buffer.upload(staged)
         self.struct.pixels = self.buffer.ptr
         self.struct.rowBytes = self.pitch
+
+    def upload(self) -> None:
+        hs = self.host.struct
+        staged = np.zeros((hs.height, self.pitch), dtype=np.uint8)
+        staged[:, : self.width_bytes] = self.host.pixels[:, : self.width_bytes]
+        self.buffer.upload(staged)
 
     def download_into_host(self) -> None:
         hs = self.host.struct

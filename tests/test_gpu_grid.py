@@ -77,3 +77,60 @@ def test_grid_argument_checks(hip):
     dtiles[3].struct.depth = 8  # a tile that does not match the first one, src/read.c:1832-1842
     ok = native.avifhipGrid(g.rows, g.columns, g.out_w, g.out_h)
     assert hip.avifhipGridYUVToRGBAsync(C.byref(ok), colour, None, 0, drgb.struct, None) == 18
+
+
+def test_repeated_grid_call_reuses_the_table_on_the_device(hip):
+    """A decoder converts into the same tile buffers frame after frame: the second call's descriptor table equals the first one's and is
+    not sent again; new PIXELS in the same buffers are picked up (nothing derived from pixels is kept), other buffers send a new table."""
+    g = cases(True)[2]
+    tiles = H.make_grid_tiles(g)
+    dtiles = [device.DeviceYUV(t) for t in tiles]
+    n = g.rows * g.columns
+    P = C.POINTER(abi.avifImage)
+    colour = (P * n)(*[C.pointer(d.struct) for d in dtiles])
+    grid = native.avifhipGrid(g.rows, g.columns, g.out_w, g.out_h)
+    wb = g.out_w * abi.rgb_pixel_size(g.conv.rgb_format, g.conv.rgb_depth)
+
+    def convert(into):
+        native.check(hip.avifhipGridYUVToRGBAsync(C.byref(grid), colour, colour, int(g.alpha_limited), into.struct, None), "avifhipGridYUVToRGBAsync")
+        native.check(hip.avifhipSynchronize(None), "sync")
+        into.download_into_host()
+
+    def expect(ts):
+        want = H.grid_output(g)
+        assert oracle_grid(g, ts, want, libyuv_build=False) == 0
+        return want.pixels[:, :wb]
+
+    out = H.grid_output(g)
+    drgb = device.DeviceRGB(out, upload=True)
+    before = hip.avifhipTableUploadCount()
+    convert(drgb)
+    assert hip.avifhipTableUploadCount() == before + 1
+    assert np.array_equal(out.pixels[:, :wb], expect(tiles))
+    out.pixels[:] = 0
+    drgb.upload()
+    convert(drgb)
+    assert hip.avifhipTableUploadCount() == before + 1  # same buffers, same geometry: the table is already there
+    assert np.array_equal(out.pixels[:, :wb], expect(tiles))
+    # the next frame in the same buffers
+    rng = np.random.default_rng(99)
+    for t, d in zip(tiles, dtiles):
+        for plane in t.planes:
+            if plane is not None:
+                plane[:] = rng.integers(0, 256, plane.shape, dtype=plane.dtype)
+        if t.alpha is not None:
+            t.alpha[:] = rng.integers(0, 256, t.alpha.shape, dtype=t.alpha.dtype)
+        d.upload()
+    convert(drgb)
+    assert hip.avifhipTableUploadCount() == before + 1
+    assert np.array_equal(out.pixels[:, :wb], expect(tiles))
+    # another destination: another table
+    out2 = H.grid_output(g)
+    drgb2 = device.DeviceRGB(out2, upload=True)
+    convert(drgb2)
+    assert hip.avifhipTableUploadCount() == before + 2
+    assert np.array_equal(out2.pixels[:, :wb], expect(tiles))
+    # ... and back: the first table is no longer the resident one
+    convert(drgb)
+    assert hip.avifhipTableUploadCount() == before + 3
+    assert np.array_equal(out.pixels[:, :wb], expect(tiles))

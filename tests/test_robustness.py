@@ -58,7 +58,7 @@ def test_interposer_passes_through_other_libavif_versions(tmp_path, version, exp
 @pytest.mark.gpu
 def test_tables_shared_across_streams_are_ordered(hip_auto_arithmetic):
     """Batch launches from ONE thread on TWO streams, alternating, with different descriptor tables each time: the second upload must not
-    overwrite the table a kernel of the other stream is still reading (api.cpp per-thread tables)."""
+    overwrite the table a kernel of the other stream is still reading (api_batch.cpp per-thread tables)."""
     from libavif_amd import device, farm
 
     lib = hip_auto_arithmetic
