@@ -199,10 +199,12 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
         return false; // half-float outputs (Android's RGBA_F16 bitmaps): 16-bit containers, the fp32 kernels convert at the store
     if (o.is565) {
         // RGB565 (Android's bitmap format, android_jni/.../libavif_jni.cc:206-223): libyuv's I420ToRGB565Matrix / I422ToRGB565Matrix --
-        // 8-bit 4:2:0 / 4:2:2 planes, nearest upsampling -- in the packed 16-bit kernels; everything else 565 stays universal
+        // 8-bit 4:2:0 / 4:2:2 planes, nearest upsampling -- in the packed 16-bit kernels
         const bool packed = p.arith == ARITH_LIBYUV && s.chanBytes == 1 && !p.bilinear && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE &&
                             (s.format == AVIF_PIXEL_FORMAT_YUV420 || s.format == AVIF_PIXEL_FORMAT_YUV422) && s.hasColor;
-        if (!packed || o.map.on)
+        // ... and from the fp32 arithmetic (10- / 12-bit sources, filtered chroma, avoidLibYUV) in the fp32 tiles, alpha arithmetic aside
+        const bool fp32 = p.arith != ARITH_LIBYUV && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE;
+        if (!(packed || fp32) || o.map.on)
             return false;
     }
     if (o.map.on) {

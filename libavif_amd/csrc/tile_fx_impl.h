@@ -67,7 +67,8 @@ __device__ __forceinline__ void stageTileFx(const TileArgs & A, const TileRaw<YT
     for (int j = 0; j < SR::kRounds; ++j) {
         const int task = t + SR::kThreads * j;
         if (task < SR::kTasks) {
-            const int row = task / kStageGroups, grp = task - row * kStageGroups;
+            int row, grp;
+            SR::place(task, row, grp);
             unsigned u[4], v[4];
             decode4<YT>(T.su[j], u);
             decode4<YT>(T.sv[j], v);
@@ -76,6 +77,10 @@ __device__ __forceinline__ void stageTileFx(const TileArgs & A, const TileRaw<YT
             for (int k = 0; k < 4; ++k)
                 dst[k] = (fxReduceForFilter<YT>(u[k], A.fx.downshift) | (fxReduceForFilter<YT>(v[k], A.fx.downshift) << 16)) << FxPrescale<YT, SUB, true>::kShift;
         }
+    }
+    if constexpr (SR::kSplitHalo) { // (tile_impl.h StageRows: the side samples, one lane each)
+        if (t < 2 * SR::kRows)
+            rows[t >> 1][(t & 1) ? 4 * 33 + 1 : 4] = (fxReduceForFilter<YT>(T.hu, A.fx.downshift) | (fxReduceForFilter<YT>(T.hv, A.fx.downshift) << 16)) << FxPrescale<YT, SUB, true>::kShift;
     }
 }
 

@@ -57,13 +57,27 @@ constexpr int kRowPitch = 140;
 constexpr int kStageGroups = 34;
 // chroma rows staged for a tile of WAVES * NS strips (2 * WAVES * NS luma rows) by WAVES waves: the four waves of a workgroup
 // together (WAVES = 4, one barrier per tile), or every wave for itself (WAVES = 1: wave-private LDS, no barrier)
+// A task = four consecutive samples of one row (a 4-byte / 8-byte load per plane).  The row needs 1 + 128 + 1 samples: WAVES = 4 takes them as
+// 34 aligned groups (the band's 32 and one either side, of which one sample is used); a single wave would spend a whole extra round of its
+// 64 lanes on those 2 x kRows side groups (6 rows x 34 = 204 tasks: a fourth round for 12 of them), so WAVES = 1 stages the band's 32 groups
+// in rounds (kSplitHalo: 6 x 32 = 192 tasks, three rounds exactly) and the two side SAMPLES of every row by one lane each, once.
 template <int SUB, int NS, int WAVES = 4>
 struct StageRows
 {
     static constexpr int kRows = (SUB == SUB_420) ? (WAVES * NS + 2) : (2 * WAVES * NS);
-    static constexpr int kTasks = kRows * kStageGroups;
+    static constexpr bool kSplitHalo = WAVES == 1;
+    static constexpr int kGroups = kSplitHalo ? 32 : kStageGroups; // groups per row that go through the rounds
+    static constexpr int kFirstGroup = kSplitHalo ? 1 : 0;         // ... the first of them, counted from the group left of the band
+    static constexpr int kTasks = kRows * kGroups;
     static constexpr int kThreads = 64 * WAVES;
     static constexpr int kRounds = (kTasks + kThreads - 1) / kThreads;
+    static_assert(!kSplitHalo || 2 * kRows <= 64, "one lane per side sample");
+    // row and group (0 = the group left of the band) of a task
+    static __device__ __forceinline__ void place(int task, int & row, int & grp)
+    {
+        row = task / kGroups;
+        grp = task - row * kGroups + kFirstGroup;
+    }
 };
 
 __device__ __forceinline__ f2 splat(float v)
@@ -529,6 +543,15 @@ __device__ __forceinline__ void packRgb8Row(unsigned w[3], const float x[4], con
                    "v"(z[3]));
 }
 
+// a + b of two halves of one register pair, as ONE scalar v_add_f32: written in C the two sums of neighbouring pixels are paired into a
+// v_pk_add_f32 behind three v_mov_b32 that bring the halves side by side (12 cycles per pixel pair against 5, profiles/r03_valu_rate.txt)
+__device__ __forceinline__ float addScalar(float a, float b)
+{
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // YCgCo family, one pixel: (first colour, green, third colour) unclamped from normalised luma, the two normalised chroma samples in plane
 // order (`u` plane, `v` plane of TileArgs) and the luma code (src/reformat.c:853-871).
 __device__ __forceinline__ void ycgcoPixel(const TileArgs & A, float Y, f2 uvp, unsigned unormY, float & X, float & G, float & Z)
@@ -565,6 +588,7 @@ template <typename YT, int SUB, bool BIL, bool NEEDA, int NS, int WAVES = 4>
 struct TileRaw
 {
     Raw4<YT> su[BIL ? StageRows<SUB, NS, WAVES>::kRounds : 1], sv[BIL ? StageRows<SUB, NS, WAVES>::kRounds : 1];
+    unsigned hu, hv; // StageRows::kSplitHalo: the side sample this lane brings (lane 2 * row + side, side 0 = left of the band)
     StripRaw<YT, SUB, BIL, NEEDA> raw[NS];
 };
 
@@ -598,7 +622,8 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
                 // coordinates clamp to the job's chroma window (the whole plane of the canvas unless the canvas is a grid of
                 // separately stored tiles): exactly the reference's border rule (src/reformat.c:768,784) -- the neighbour
                 // of an edge sample is the sample itself
-                const int row = task / kStageGroups, grp = task - row * kStageGroups;
+                int row, grp;
+                SR::place(task, row, grp);
                 const int cy = clampI(rowBase + row, A.cyMin, A.cyMax);
                 const int cxa = c.cxb - 4 + 4 * grp;
                 if (cxa >= A.cxMin && cxa + 3 <= A.cxMax) {
@@ -624,6 +649,16 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
                     }
                 }
             }
+        }
+    }
+    if constexpr (BIL && SR::kSplitHalo) {
+        T.hu = T.hv = 0;
+        if (tx < 2 * SR::kRows) {
+            const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)(tileY >> 1) - 1 : A.cy0 + (int)tileY;
+            const int cy = clampI(rowBase + (tx >> 1), A.cyMin, A.cyMax);
+            const uint32_t cx = (uint32_t)clampI((tx & 1) ? c.cxb + 128 : c.cxb - 1, A.cxMin, A.cxMax);
+            T.hu = load1<YT>(A.u, (uint32_t)cy * A.uPitch + cx * BPS);
+            T.hv = load1<YT>(A.v, (uint32_t)cy * A.vPitch + cx * BPS);
         }
     }
     // ---- this wave's luma / alpha / co-sited chroma for all of its strips ----
@@ -667,7 +702,8 @@ __device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, 
     for (int j = 0; j < SR::kRounds; ++j) {
         const int task = t + SR::kThreads * j;
         if (task < SR::kTasks) {
-            const int row = task / kStageGroups, grp = task - row * kStageGroups;
+            int row, grp;
+            SR::place(task, row, grp);
             float fu[4], fv[4];
             samples4<YT>(T.su[j], A.yuvMax, fu);
             samples4<YT>(T.sv[j], A.yuvMax, fv);
@@ -675,6 +711,12 @@ __device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, 
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 dst[k] = norm2((f2) { fu[k], fv[k] }, A.biasUV, A.rcpRangeUV);
+        }
+    }
+    if constexpr (SR::kSplitHalo) { // the sample left of the band (column 4 of the row: the last of group 0) and right of it (133: the first of group 33)
+        if (t < 2 * SR::kRows) {
+            const unsigned u = (sizeof(YT) == 2) ? minU(T.hu, A.yuvMax) : T.hu, v = (sizeof(YT) == 2) ? minU(T.hv, A.yuvMax) : T.hv;
+            rows[t >> 1][(t & 1) ? 4 * 33 + 1 : 4] = norm2((f2) { (float)u, (float)v }, A.biasUV, A.rcpRangeUV);
         }
     }
 }
@@ -693,7 +735,9 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
     constexpr int PW = (sizeof(RT) == 1) ? 1 : 2; // dwords per 4-channel pixel
     constexpr bool kWide = sizeof(YT) == 2;
     constexpr bool kNeedA = APLANE || HASMUL;
-    constexpr uint32_t kPixBytes = NCH * sizeof(RT);
+    constexpr bool IS565 = NCH == 5; // RGB565: one 16-bit word per pixel (template code 5; 8-bit RT)
+    static_assert(!IS565 || (sizeof(RT) == 1 && !HASMUL && !APLANE && !MAPPED), "RGB565: 8-bit channels, no alpha");
+    constexpr uint32_t kPixBytes = IS565 ? 2u : NCH * sizeof(RT);
     const int tx = threadIdx.x, wv = (WAVES == 1) ? 0 : (int)threadIdx.y; // WAVES == 1: `xchg` is this wave's own exchange buffer
     const bool nt = (A.tuning & TUNE_NONTEMPORAL) != 0;
     const unsigned yuvMax = A.yuvMax;
@@ -714,6 +758,10 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
     // 3-channel pixels: bytes of the band's row segment that exist (storeRowContiguous)
     const uint32_t segBytes = ((A.w4 - c.bandX < (uint32_t)kBandW) ? A.w4 - c.bandX : (uint32_t)kBandW) * kPixBytes;
 
+    struct // 4:2:0 bilinear: what the strip's co-sited and lower chroma rows hand to the next strip (see there)
+    {
+        f2 m3b, m3c, m1[4], b[4], b3b, b3c, b1[4];
+    } carry;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const uint32_t sy = tileY + 2 * (wv * NS + k);
@@ -770,23 +818,52 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                 m[0] = lo.xy, m[1] = lo.zw, m[2] = hi.xy, m[3] = hi.zw;
             };
             if constexpr (SUB == SUB_420) {
+                // A chroma row serves three strips in turn: as the row below (its products by 3/16 of the two middle columns and by 1/16 of all
+                // four), as the co-sited row (adds 9/16 of the middle columns, 3/16 of the outer ones) and as the row above (nothing new).  The
+                // loop over the wave's strips is unrolled, so a row's samples and products stay in registers from one strip to the next: one
+                // row read from LDS and ten products per strip instead of three rows and eighteen.  Same products, same sums as before.
                 const int qm = 1 + wv * NS + k; // LDS row of the strip's co-sited chroma row
-                f2 m[4], v[2][4];
-                loadRow(qm, m);
-                loadRow(qm - 1, v[0]); // even luma rows: vertical neighbour above
-                loadRow(qm + 1, v[1]); // odd luma rows: below
-                const f2 m9b = m[1] * k9, m9c = m[2] * k9;
-                const f2 m3a = m[0] * k3, m3b = m[1] * k3, m3c = m[2] * k3, m3d = m[3] * k3;
-                const f2 h0 = m9b + m3a, h1 = m9b + m3c, h2 = m9c + m3b, h3 = m9c + m3d;
+                f2 m[4], m3b, m3c, m1[4], a3b, a3c, a1[4];
+                if (k == 0) {
+                    f2 a[4];
+                    loadRow(qm, m);
+                    loadRow(qm - 1, a); // even luma rows: vertical neighbour above
+                    m3b = m[1] * k3, m3c = m[2] * k3;
+                    a3b = a[1] * k3, a3c = a[2] * k3;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const f2 v3b = v[r][1] * k3, v3c = v[r][2] * k3;
-                    const f2 v1a = v[r][0] * k1, v1b = v[r][1] * k1, v1c = v[r][2] * k1, v1d = v[r][3] * k1;
-                    uv[r][0] = (h0 + v3b) + v1a; // even pixel: horizontal neighbour on the left
-                    uv[r][1] = (h1 + v3b) + v1c; // odd pixel: on the right
-                    uv[r][2] = (h2 + v3c) + v1b;
-                    uv[r][3] = (h3 + v3c) + v1d;
+                    for (int i = 0; i < 4; ++i)
+                        a1[i] = a[i] * k1; // (m1: the next strip's row above -- filled below)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        m1[i] = m[i] * k1;
+                } else {
+                    a3b = carry.m3b, a3c = carry.m3c;
+                    m3b = carry.b3b, m3c = carry.b3c;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        a1[i] = carry.m1[i], m[i] = carry.b[i], m1[i] = carry.b1[i];
                 }
+                f2 b[4], b1[4];
+                loadRow(qm + 1, b); // odd luma rows: below
+                const f2 b3b = b[1] * k3, b3c = b[2] * k3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    b1[i] = b[i] * k1;
+                const f2 m9b = m[1] * k9, m9c = m[2] * k9;
+                const f2 m3a = m[0] * k3, m3d = m[3] * k3;
+                const f2 h0 = m9b + m3a, h1 = m9b + m3c, h2 = m9c + m3b, h3 = m9c + m3d;
+                uv[0][0] = (h0 + a3b) + a1[0]; // even pixel: horizontal neighbour on the left
+                uv[0][1] = (h1 + a3b) + a1[2]; // odd pixel: on the right
+                uv[0][2] = (h2 + a3c) + a1[1];
+                uv[0][3] = (h3 + a3c) + a1[3];
+                uv[1][0] = (h0 + b3b) + b1[0];
+                uv[1][1] = (h1 + b3b) + b1[2];
+                uv[1][2] = (h2 + b3c) + b1[1];
+                uv[1][3] = (h3 + b3c) + b1[3];
+                carry.m3b = m3b, carry.m3c = m3c, carry.b3b = b3b, carry.b3c = b3c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    carry.m1[i] = m1[i], carry.b[i] = b[i], carry.b1[i] = b1[i];
             } else { // 4:2:2: the vertical neighbour is the sample itself (src/reformat.c:784-786)
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
@@ -880,10 +957,23 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                 } else if constexpr (NCH <= 2) {
                     if (laneValid)
                         storeGray4<RT, NCH>(A.rgb, off, q, a, alphaFirst, nt);
+                } else if constexpr (IS565) {
+                    // (RGB565 leaves through emitT / emit565)
                 } else {
                     if (laneValid)
                         store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
                 }
+            };
+            // RGB565 (Android's bitmap format; here from the fp32 arithmetic: 10- / 12-bit sources, filtered chroma, avoidLibYUV): the format has no
+            // channel offsets, so the 'first' colour is blue and the 'third' red (tile_shared.h distillArgs); four pixels = 8 bytes per lane.
+            // b >> 3 | (g >> 2) << 5 | (r >> 3) << 11 of the 8-bit channels, src/reformat.c:619-626
+            auto emit565 = [&](const unsigned (&b8)[4], const unsigned (&g8)[4], const unsigned (&r8)[4]) {
+                unsigned h[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    h[i] = pack565(r8[i], g8[i], b8[i]);
+                if (laneValid)
+                    storeVec(A.rgb, off, (u2) { h[0] | (h[1] << 16), h[2] | (h[3] << 16) }, nt);
             };
             // the quantiser's arguments t = c * max + 0.5f (quantizeArg) of the row's (first, third) colours and of green to their pixels:
             // 8-bit colour outputs truncate, saturate and pack in one instruction per channel (packRgba8Row), the others through v_cvt_u32_f32
@@ -901,6 +991,12 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                         } else if (laneValid) {
                             storeVec(A.rgb, off, (u4) { w[0], w[1], w[2], w[3] }, nt);
                         }
+                    } else if constexpr (IS565) {
+                        unsigned b8[4], g8[4], r8[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            b8[i] = minU(truncU32(tbr[i].x), 255u), g8[i] = minU(truncU32(tg[i]), 255u), r8[i] = minU(truncU32(tbr[i].y), 255u);
+                        emit565(b8, g8, r8);
                     } else {
                         float x[4], z[4];
 #pragma unroll
@@ -938,6 +1034,8 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                         q[i].r = ub[i], q[i].g = yb[i], q[i].b = vb[i];
                     if constexpr (NCH == 3) {
                         store4Rgb3<RT>(A.rgb, bandOff, q, segBytes, xchg[wv]);
+                    } else if constexpr (IS565) {
+                        emit565(ub, yb, vb);
                     } else if constexpr (MAPPED) {
                         unsigned px[4][PW];
 #pragma unroll
@@ -1039,7 +1137,9 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                 for (int i = 0; i < 4; ++i) {
                     br[i] = splat(yk[i]) + cBR * uv[r][i];
                     const f2 pr = cUV * uv[r][i];
-                    const float sum = pr.y + pr.x; // (kr(1-kr)*Cr) + (kb(1-kb)*Cb)
+                    // (kr(1-kr)*Cr) + (kb(1-kb)*Cb).  (The kernels with pending alpha arithmetic and unfiltered chroma keep the C form: they are bound
+                    // by memory, and cfg3's lost 19 % to the very same instructions laid out differently around this block -- 76 KB of code.)
+                    const float sum = (BIL || !HASMUL) ? addScalar(pr.y, pr.x) : pr.y + pr.x;
                     // G = Y - (2*sum)/kg with 2/kg in verified reciprocal form
                     g[i] = yk[i] - __builtin_fmaf(sum, A.rcpKgTimes2.hi, sum * A.rcpKgTimes2.lo);
                 }
@@ -1414,6 +1514,12 @@ hipError_t launchOne(const TileLaunch & L)
 template <typename YT, int SUB, bool BIL, typename RT>
 hipError_t launchAlphaVariant(const TileKey & k, const TileLaunch & L)
 {
+    if (!k.gray && k.nch == 2) { // RGB565 (tileYuvToRgbSupported: 8-bit channels, no pending alpha arithmetic, no map)
+        if constexpr (sizeof(RT) == 1)
+            return launchOne<YT, SUB, BIL, RT, 5, false, false>(L);
+        else
+            return hipErrorInvalidValue;
+    }
     if constexpr (SUB == SUB_400) { // gray layouts read luma (and alpha) only, whatever the image's chroma layout: wave-private kernels
         if (k.nch == 1)
             return k.hasMul ? launchSolo<YT, SUB, BIL, RT, 1, false, true>(L) : launchSolo<YT, SUB, BIL, RT, 1, false, false>(L);
