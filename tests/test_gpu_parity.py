@@ -103,6 +103,25 @@ def test_gray_outputs_use_the_tiled_kernels(hip):
     _compare_y2r(H.hip_host_backend(), H.oracle_backend(), cases)
 
 
+def test_rgb565_from_the_fp32_arithmetic_uses_the_tiled_kernels(hip):
+    """RGB565 where libyuv has no entry (10- / 12-bit planes -- an HDR image into an Android RGB_565 bitmap --, filtered chroma, 4:4:4, gray,
+    avoidLibYUV): the fp32 tiles quantise to 8 bits and pack b >> 3 | (g >> 2) << 5 | (r >> 3) << 11 (src/reformat.c:619-626), the identity
+    copy and the YCgCo family included; a pending alpha (un)multiply stays with the universal kernel."""
+    hip.avifhipSetTiledKernels(1)
+    cases = []
+    for (w, h) in TILED:
+        for yf, yd, mc, rng, up in ((3, 8, 1, 0, 4), (3, 10, 9, 0, 4), (2, 12, 6, 1, 4), (3, 10, 1, 0, 3), (1, 8, 0, 1, 4), (1, 10, 0, 1, 4), (1, 8, 8, 1, 4),
+                                    (4, 12, 1, 1, 4), (2, 8, 5, 0, 3), (1, 12, 9, 0, 4)):
+            cases.append(H.Y2RCase(w, h, rgb_format=abi.AVIF_RGB_FORMAT_RGB_565, rgb_depth=8, yuv_depth=yd, yuv_format=yf, matrix=mc, yuv_range=rng, upsampling=up))
+    for c in cases:
+        H.run_y2r(H.HipDeviceBackend(), c)
+        assert native.last_kernel().startswith("yuv2rgb_tile") and "rgb565" in native.last_kernel(), (c.ident(), native.last_kernel())
+    _compare_y2r(H.HipDeviceBackend(), H.oracle_backend(), cases)
+    _compare_y2r(H.hip_host_backend(), H.oracle_backend(), cases)
+    pending = H.Y2RCase(512, 16, rgb_format=abi.AVIF_RGB_FORMAT_RGB_565, rgb_depth=8, yuv_depth=10, yuv_format=3, alpha=True, image_premultiplied=True)
+    _compare_y2r(H.HipDeviceBackend(), H.oracle_backend(), [pending])
+
+
 def test_yuv_to_rgb_tiled_sweep_device(hip):
     hip.avifhipSetTiledKernels(1)
     _compare_y2r(H.HipDeviceBackend(), H.oracle_backend(), H.y2r_sweep(TILED, n_random=300, seed=17), "yuv2rgb_tile")
