@@ -1,7 +1,8 @@
 """The committed measurement evidence is self-consistent: the bench line printed under rocprofv3 and the rocprofv3 kernel statistics of
 the same command agree on the dominant kernel's duration, the roofline fields follow from each other, the HBM traffic the PMC passes
 measured matches the algorithmic bytes the roofline is computed from, and the instruction counters back the "packed 16-bit"
-claim (profiles/r02_bench_*)."""
+claim (profiles/r03_bench_*); and every configuration row of profiles/r03_cfgs_bench.jsonl agrees with the
+profiler's own average over the very launches it was timed on (profiles/r03_cfgs_kernel_stats.txt: one rocprofv3 run per configuration)."""
 import json
 import re
 from pathlib import Path
@@ -15,13 +16,13 @@ def _line(name):
 
 
 def _dominant():
-    stats = (PROFILES / "r02_bench_kernel_stats.txt").read_text().splitlines()
+    stats = (PROFILES / "r03_bench_kernel_stats.txt").read_text().splitlines()
     assert "bench.py" in stats[0]
     return stats[2]
 
 
 def test_bench_line_and_rocprof_stats_agree():
-    line = _line("r02_bench_line_under_rocprof.json")
+    line = _line("r03_bench_line_under_rocprof.json")
     dominant = _dominant()
     assert "yuvToRgbPkKernel<2, true, 4, false" in dominant  # the packed 16-bit 4:2:0 bilinear RGBA8 kernel the bench line names
     assert line["config"]["kernel"] == "yuv2rgb_fixed_tile<u8,420,bilinear,rgba8,pk16>"
@@ -32,7 +33,7 @@ def test_bench_line_and_rocprof_stats_agree():
 
 
 def test_roofline_fields_follow_from_each_other():
-    for name in ("r02_bench_line.json", "r02_bench_line_under_rocprof.json", "r02_bench_line_default_run.json", "r02_bench_line_driver_flags.json"):
+    for name in ("r03_bench_line.json", "r03_bench_line_under_rocprof.json", "r03_bench_line_default_run.json", "r03_bench_line_driver_flags.json"):
         d = _line(name)
         r = d["roofline"]
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -42,8 +43,19 @@ def test_roofline_fields_follow_from_each_other():
         assert r["frac"] >= 0.70
         # the byte-movement-only kernel is the ceiling: the conversion cannot beat it by more than noise, and stays within 15% of it
         assert 0.85 <= r["ceiling"]["conversion_vs_ceiling"] <= 1.03
-        deep = r["deep_streaming"]
-        assert deep["kernel_ms"] > r["kernel_ms"] and abs(deep["frac"] - ALG / (deep["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3
+        cold = r["cold"]  # first-class: frames cycled through more memory than the Infinity Cache holds
+        assert r["deep_streaming"] == cold  # (round 2's name, kept for readers of older lines)
+        assert cold["kernel_ms"] > r["kernel_ms"] and abs(cold["frac"] - ALG / (cold["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3
+        assert cold["frames_cycled"] * ALG > 4 * 256e6 and cold["frac"] >= 0.60
+        assert r["kernel_ms_inputs_cache_resident"] == r["kernel_ms"] and "kernel_ms_hbm_streaming" not in r
+        assert r["traffic"] is None or ("pmc_traffic.json" in r["traffic_source"] and abs(r["traffic"] - ALG) / ALG < 0.03)
+        for key in ("fp32", "integer"):
+            side = d[key]
+            assert abs(side["frac"] - ALG / (side["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3 and side["cold"]["kernel_ms"] > side["kernel_ms"]
+        assert d["integer"]["kernel_ms"] == r["kernel_ms"] and r["fp32_path"]["frac"] == d["fp32"]["frac"]
+        assert d["fp32"]["frac"] >= 0.70  # the built-in fp32 arithmetic at 8K, sustained (bursts after 40 ms of the same kernel)
+        p4 = d["planes_4k"]
+        assert abs(p4["integer"]["frac"] - ALG / 4 / (p4["integer"]["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3 and p4["integer"]["frac"] >= 0.55 and p4["fp32"]["frac"] >= 0.45
         assert abs(d["value"] - 7680 * 4320 / 1e6 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
         assert d["metric"].startswith("megapixels/sec") and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
         assert d["dtype"] == "i16" and d["n_gpus"] == 1 and d["config"]["repeats"] >= 1
@@ -53,7 +65,7 @@ def test_pmc_traffic_and_instruction_counts():
     t = json.loads((PROFILES / "pmc_traffic.json").read_text())
     assert t["kernel_family"] == "yuv2rgb_fixed_tile<u8,420,bilinear,rgba8,pk16>" and "yuvToRgbPkKernel" in t["kernel"]
     assert abs(t["traffic_bytes_per_launch"] - ALG) / ALG < 0.03  # measured HBM bytes per launch vs algorithmic bytes: no wasted re-reads
-    pmc = (PROFILES / "r02_bench_pmc.txt").read_text()
+    pmc = (PROFILES / "r03_bench_pmc.txt").read_text()
     block = re.split(r"yuvToRgbPkKernel<2, true, 4, false, 4, false, 0>[^\n]*\n", pmc, maxsplit=1)[1].split("\nvoid ", 1)[0]  # 4:2:0, bilinear, 4 channels, opaque, 4 strips, rows, 8-bit planes
     valu = float(re.search(r"SQ_INSTS_VALU\s+dispatches=\s*\d+\s+avg_per_dispatch=\s*([0-9.]+)", block).group(1))
     per_pixel = valu * 64 / (7680 * 4320)
@@ -61,13 +73,13 @@ def test_pmc_traffic_and_instruction_counts():
 
 
 def test_default_run_carries_the_cpu_baseline():
-    for name in ("r02_bench_line_default_run.json", "r02_bench_line_driver_flags.json"):
+    for name in ("r03_bench_line_default_run.json", "r03_bench_line_driver_flags.json"):
         cb = _line(name)["cpu_baseline"]
         assert cb["kind"] == "reference" and cb["cores"] == 1 and cb["unit"] == "megapixels/s" and 50 < cb["value"] < 500
 
 
 def test_end_to_end_rows_present():
-    rows = [json.loads(l) for l in (PROFILES / "r02_e2e.jsonl").read_text().splitlines() if l.strip()]
+    rows = [json.loads(l) for l in (PROFILES / "r03_e2e.jsonl").read_text().splitlines() if l.strip()]
     by = {(r["config"], r["call"]): r for r in rows}
     cfg2 = by[("cfg2", "avifhipImageYUVToRGB (host buffers)")]
     assert cfg2["host_link_GBps"] >= 0.6 * 56.9  # both directions of the link busy: above 60% of the one-way PCIe rate measured on the box
@@ -76,4 +88,73 @@ def test_end_to_end_rows_present():
     assert any(k[0].startswith("cfg5") for k in by)
     one = [r for r in rows if r.get("maxThreads") == 1 and r["config"] == "cfg3"][0]
     eight = [r for r in rows if r.get("maxThreads") == 8 and r["config"] == "cfg3"][0]
-    assert eight["best_ms"] <= one["best_ms"] * 1.05  # libavif's worker threads over the hooks: no slower than one thread
+    # through libavif's hooks the pixels cross the link once in each direction (the colour hook folds libavif's follow-up premultiply / F16
+    # calls into its pass): the C ABI's own time with one thread; libavif's eight worker threads split the image into eight hook calls
+    direct = by[("cfg3", "avifhipImageYUVToRGB (host buffers)")]
+    assert one["best_ms"] <= direct["best_ms"] * 1.03 and eight["best_ms"] <= 7.2  # (12.2 ms in round 2)
+
+
+def _cfg_blocks():
+    """{config: [(kernel, calls, avg_us)]} of profiles/r03_cfgs_kernel_stats.txt"""
+    text = (PROFILES / "r03_cfgs_kernel_stats.txt").read_text()
+    out = {}
+    for block in text.split("\n== ")[1:]:
+        lines = block.splitlines()
+        rows = []
+        for l in lines[1:]:
+            m = re.match(r"^\s{3}(\S.*?)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", l)
+            if m and not l.strip().startswith("kernel "):
+                rows.append((m.group(1), int(m.group(2)), float(m.group(3))))
+        out[lines[0].strip()] = rows
+    return out
+
+
+def test_every_configuration_row_agrees_with_the_profiler():
+    """One box, one call, one run per configuration: the event-timed row (median of bursts after 60 ms of the same kernel) and rocprofv3's
+    average over all launches of that run are within 5 % for every single-kernel configuration; rows clocked on the host around API calls
+    (several kernels per call) are never faster than the kernels the profiler saw per call."""
+    rows = [json.loads(l) for l in (PROFILES / "r03_cfgs_bench.jsonl").read_text().splitlines() if l.startswith("{")]
+    blocks = _cfg_blocks()
+    assert len(rows) >= 70 and len(blocks) >= 45
+    worst = 0.0
+    for r in rows:
+        kernels = blocks[r["config"]]
+        assert kernels, r["config"]
+        if r["clock"] == "events":
+            avg = min((a for _, _, a in kernels), key=lambda a: abs(a - r["us"]))
+            rel = abs(avg - r["us"]) / avg
+            if avg < 12.0 and 0.0 <= r["us"] - avg < 1.5:
+                continue  # launches this short: the events also see the ~1 us between two kernels, the profiler does not
+            worst = max(worst, rel)
+            assert rel < 0.05, (r["config"], r["arithmetic"], r["us"], kernels)
+        else:
+            # wall clock per API call: never below the call's own kernel; one kernel per call -> the same 5 %
+            closest = min((a for _, _, a in kernels), key=lambda a: abs(a - r["us"]))
+            assert any(a <= 1.05 * r["us"] for _, _, a in kernels), (r["config"], r["us"], kernels)
+            one_kernel = r["config"].startswith(("tail", "xform", "premul", "unpremul", "cfg5x64")) and "two_pass" not in r["config"]
+            if one_kernel:
+                assert abs(closest - r["us"]) / closest < 0.05, (r["config"], r["arithmetic"], r["us"], kernels)
+    assert worst < 0.05
+    by = {(r["config"], r["arithmetic"]): r for r in rows}
+    # the round's targets, on the profiler's averages (VERDICT r02, items 1, 4, 5, 7)
+    def avg_of(cfg, needle):
+        return [avg for k, _, avg in blocks[cfg] if needle in k][0]
+    assert avg_of("cfg2", "yuvToRgbTileSoloKernel<unsigned char, 2, true, unsigned char, 4") <= 32.6
+    assert by[("cfg2", "float")]["frac_of_8TBps"] >= 0.70
+    assert by[("cfg2_premul", "float")]["us"] <= 43.0 and by[("unpremul8", "float")]["us"] <= 47.0
+    assert by[("tail90", "integer")]["frac_of_8TBps"] >= 0.58
+    assert by[("cfg2_565", "float")]["frac_of_8TBps"] >= 0.60 and "rgb565" in by[("cfg2_565", "float")]["kernel"]
+    assert by[("cfg4_premul_8k", "float")]["frac_of_8TBps"] >= 0.60 and by[("cfg4_ycgco_8k", "float")]["frac_of_8TBps"] >= 0.60
+    assert by[("gray_enc_8k", "float")]["frac_of_8TBps"] >= 0.60 and by[("graya_enc_8k", "float")]["frac_of_8TBps"] >= 0.60
+    assert by[("photo_grid", "integer")]["us"] <= 30.0
+
+
+def test_fp32_instruction_counts():
+    """the fp32 tiles' vector instructions per pixel (rocprofv3 --pmc SQ_INSTS_VALU, own pass)."""
+    text = (PROFILES / "r03_cfgs_pmc.txt").read_text()
+    def valu_per_pixel(cfg, needle):
+        block = text.split(f"\n== {cfg}\n", 1)[1].split("\n== ", 1)[0]
+        kernel = [b for b in block.split("\n   void ") if needle in b][0]
+        return float(re.search(r"SQ_INSTS_VALU\s+dispatches=\s*\d+\s+avg_per_dispatch=\s*([0-9.]+)", kernel).group(1)) * 64 / (7680 * 4320)
+    assert valu_per_pixel("cfg2", "yuvToRgbTileSoloKernel<unsigned char, 2, true, unsigned char, 4, false, false") <= 24.0  # 30.6 in round 2, 25.2 before this round's last pass (the target of 22 stands)
+    assert valu_per_pixel("cfg2_premul", "yuvToRgbTileSoloKernel<unsigned char, 2, true, unsigned char, 4, true, true") <= 40.0  # 47.9 in round 2

@@ -50,6 +50,9 @@ def y2r(w, h, depth, fmt, rng, mc, rgb_depth, up=BIL, alpha=False, premult=False
 PREHEAT_MS = float(os.environ.get("AVIFHIP_BENCH_PREHEAT_MS", "60"))  # an idle chip sits at ~95 MHz and needs tens of milliseconds of work to ramp (bench.py does the same)
 
 
+CLOCK = "events"  # how the row being measured is timed: "events" (HIP events around kernel launches inside the library) or "host" (wall clock around API calls)
+
+
 def preheat(fn):
     """Calls fn(iters) -> ms per launch until PREHEAT_MS of GPU work have run."""
     spent = 0.0
@@ -58,18 +61,42 @@ def preheat(fn):
 
 
 def settled(fn):
-    """Median of 7 event-timed bursts (not the best one: the rows must agree with a profiler's average over the same launches; a kernel that
+    """Median of 9 event-timed bursts (not the best one: the rows must agree with a profiler's average over the same launches; a kernel that
     is hard on the vector ALUs runs its first ~10 ms after a change of kernel up to 25 % slower: profiles/r03_sustain_probe.txt)."""
-    xs = sorted(fn() for _ in range(7))
-    return xs[3]
+    global CLOCK
+    CLOCK = "events"
+    xs = sorted(fn() for _ in range(9))
+    return xs[4]
 
 
-def time_y2r(pair, iters=40):
+def host_clock(call, burst=100):
+    """Milliseconds per call of an asynchronous entry point that launches more than one kernel (or whose kernel is not behind avifhipTime*):
+    wall clock around bursts of calls, each closed by a synchronisation -- PREHEAT_MS of the same calls first, then the median of 7 bursts,
+    so that the bursts, not the first slow milliseconds after a change of kernel, carry a profiler's average over the run."""
+    global CLOCK
+    CLOCK = "host"
+    end = time.perf_counter() + PREHEAT_MS * 1e-3
+    while time.perf_counter() < end:
+        for _ in range(20):
+            call()
+        native.check(lib.avifhipSynchronize(None))
+    xs = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        for _ in range(burst):
+            call()
+        native.check(lib.avifhipSynchronize(None))
+        xs.append((time.perf_counter() - t0) / burst * 1e3)
+    return sorted(xs)[3]
+
+
+def time_y2r(pair, iters=100):
     preheat(lambda n: lib.avifhipTimeYUVToRGB(pair[0].struct, pair[1].struct, 0, n, None))
     return settled(lambda: lib.avifhipTimeYUVToRGB(pair[0].struct, pair[1].struct, 4, iters, None))
 
 
 def run(name):
+    global CLOCK
     out = []
     for arith, avoid in (("float", True), ("integer", False)):
         lib.avifhipSetArithmetic(1 if arith == "float" else 0)
@@ -115,16 +142,7 @@ def run(name):
                 rgb.pixels.view(np.uint16)[...] &= 1023
             drgb = device.DeviceRGB(rgb, upload=True)
             fn = lib.avifhipRGBImageUnpremultiplyAlphaAsync if name.startswith("unpremul") else lib.avifhipRGBImagePremultiplyAlphaAsync
-            for _ in range(300):
-                native.check(fn(drgb.struct, None))
-            native.check(lib.avifhipSynchronize(None))
-            best = 1e9
-            for _ in range(5):
-                t0 = time.perf_counter()
-                for _ in range(20):
-                    native.check(fn(drgb.struct, None))
-                native.check(lib.avifhipSynchronize(None))
-                best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
+            best = host_clock(lambda: native.check(fn(drgb.struct, None)))
             px, bpp, ms = 7680 * 4320, (8.0 if depth == 8 else 16.0), best
         elif name in ("cfg2_alpha", "cfg2_premul"):
             # images with an alpha plane: 8K 8-bit 4:2:0 + A -> RGBA8 bilinear, straight or premultiplied (what Android's bitmaps take:
@@ -163,7 +181,7 @@ def run(name):
             dimg, drgb = device.DeviceYUV(img), device.DeviceRGB(rgb, upload=True)
             px, bpp = w * h, (8.0 if name in ("ident8_enc", "cfg4_ycgco_8k") else (6.5 if fmt == abi.AVIF_RGB_FORMAT_RGBA else 4.5))
             preheat(lambda n: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 0, n, None))
-            ms = settled(lambda: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 4, 40, None))
+            ms = settled(lambda: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 4, 100, None))
         elif name in ("gray_enc_8k", "graya_enc_8k"):
             # gray sources of the encode direction (a grayscale PNG through avifenc): 8K GRAY8 -> 4:0:0 luma (1 + 1 B/px); GRAYA8 -> luma + alpha (2 + 2 B/px)
             if arith == "integer":
@@ -174,7 +192,7 @@ def run(name):
             img = abi.make_yuv(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV400, abi.AVIF_RANGE_FULL, 1, with_alpha=with_a)
             dimg, drgb = device.DeviceYUV(img), device.DeviceRGB(rgb, upload=True)
             preheat(lambda n: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 0, n, None))
-            px, bpp, ms = 7680 * 4320, (4.0 if with_a else 2.0), settled(lambda: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 4, 40, None))
+            px, bpp, ms = 7680 * 4320, (4.0 if with_a else 2.0), settled(lambda: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 4, 100, None))
         elif name in ("cfg5", "cfg5_8"):
             pair = y2r(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 10 if name == "cfg5" else 8, avoid=avoid)
             px, bpp, ms = 1920 * 1080, (11.0 if name == "cfg5" else 7.0), time_y2r(pair)
@@ -186,6 +204,7 @@ def run(name):
             for _ in range(int(PREHEAT_MS / 0.2) + 3):
                 native.check(lib.avifhipImageYUVToRGBBatchAsync(64, imgs, rgbs, None, None))
             native.check(lib.avifhipSynchronize(None))
+            CLOCK = "host"
             best, submit = 1e9, 1e9
             for _ in range(5):
                 t0 = time.perf_counter()
@@ -208,16 +227,7 @@ def run(name):
             dst = abi.make_yuv(dw, dh, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
             dsrc, ddst = device.DeviceYUV(src), device.DeviceYUV(dst)
             call = lambda: native.check(lib.avifhipImageScaleAsync(dsrc.struct, ddst.struct, None))
-            for _ in range(3):
-                call()
-            native.check(lib.avifhipSynchronize(None))
-            best = 1e9
-            for _ in range(5):
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    call()
-                native.check(lib.avifhipSynchronize(None))
-                best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+            best = host_clock(call)
             # algorithmic bytes: every source sample read once + every destination sample written once, per luma pixel of the LARGER image
             px = max(sw * sh, dw * dh)
             bpp, ms = 1.5 * (sw * sh + dw * dh) / px, best
@@ -233,16 +243,7 @@ def run(name):
             dst = abi.make_rgb(dw, dh, 8, abi.AVIF_RGB_FORMAT_RGBA, allocate=False)
             dsrc, ddst = device.DeviceRGB(src, upload=True), device.DeviceRGB(dst)
             call = lambda: native.check(lib.avifhipRGBImageTransformAsync(ddst.struct, dsrc.struct, C.byref(crop), 1, angle, 1, 1, None))
-            for _ in range(3):
-                call()
-            native.check(lib.avifhipSynchronize(None))
-            best = 1e9
-            for _ in range(5):
-                t0 = time.perf_counter()
-                for _ in range(20):
-                    call()
-                native.check(lib.avifhipSynchronize(None))
-                best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
+            best = host_clock(call)
             px, bpp, ms = 7664 * 4312, 8.0, best
         elif name in ("tail0", "tail180", "tail90", "tail90_two_pass", "tail180_two_pass", "tail0_10", "tail90_10", "tail90_10_two_pass",
                       "tail0_rgba10", "tail180_rgba10", "tail90_rgba10", "tail90_rgba10_two_pass", "tail90_nocrop", "tail90_rgba10_nocrop"):
@@ -275,16 +276,7 @@ def run(name):
             else:
                 def call():
                     native.check(lib.avifhipImageYUVToRGBTransformedAsync(dimg.struct, ddst.struct, C.byref(crop), int(angle != 0), angle, int(angle != 0), 1, None))
-            for _ in range(3):
-                call()
-            native.check(lib.avifhipSynchronize(None))
-            best = 1e9
-            for _ in range(5):
-                t0 = time.perf_counter()
-                for _ in range(20):
-                    call()
-                native.check(lib.avifhipSynchronize(None))
-                best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
+            best = host_clock(call)
             px, bpp, ms = crop.width * crop.height, (11.0 if wide else 7.0 if deep else 5.5), best
         elif name in ("cfg5grid", "cfg5grid_8", "photo_grid"):
             # BASELINE configs[4]: 8 x 8 grid of decoded 1920x1080 10-bit 4:2:0 tiles -> one 15360x8640 RGBA canvas, tiles
@@ -301,20 +293,12 @@ def run(name):
             drgb = device.DeviceRGB(rgb)
             imgs = (C.POINTER(abi.avifImage) * (cols * rows))(*[C.pointer(t.struct) for t in tiles])
             grid = native.avifhipGrid(rows, cols, ow, oh)
-            for _ in range(3):
-                native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None))
-            native.check(lib.avifhipSynchronize(None))
-            best = 1e9
-            for _ in range(5):
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None))
-                native.check(lib.avifhipSynchronize(None))
-                best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+            best = host_clock(lambda: native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None)))
             px, bpp, ms = ow * oh, (11.0 if rgb_depth == 10 else (7.0 if depth == 10 else 5.5)), best
         elif name in ("gainmap4k", "gainmap4k_half", "gainmap4k_cpu"):
             # avifRGBImageApplyGainMap: 3840x2160 RGBA8 sRGB BT.709 base -> RGBA10 PQ BT.2020 HDR rendition, 8-bit 4:4:4 gain map of the
             # same size (or 4:2:0 at half size, rescaled on the device first).  Algorithmic bytes: base 4 + gain-map planes + output 8.
+            CLOCK = "host"
             if arith == "integer":
                 continue
             import ctypes
@@ -394,7 +378,7 @@ def run(name):
         else:
             raise SystemExit(f"unknown configuration {name}")
         gbps = bpp * px / (ms * 1e-3) / 1e9
-        out.append({"config": name, "arithmetic": arith, "kernel": native.last_kernel(), "us": round(ms * 1e3, 2), "megapixels_per_s": round(px / 1e6 / (ms * 1e-3)),
+        out.append({"config": name, "arithmetic": arith, "kernel": native.last_kernel(), "clock": CLOCK, "us": round(ms * 1e3, 2), "megapixels_per_s": round(px / 1e6 / (ms * 1e-3)),
                     "algorithmic_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000, 4), **extra})
     lib.avifhipSetArithmetic(0)
     return out
