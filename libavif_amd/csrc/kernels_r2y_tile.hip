@@ -199,6 +199,9 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
     if (const char * e = getenv("AVIFHIP_R2Y_SPW")) // diagnostics / A-B measurements only
         spw = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : spw;
     spw = spw >= 4 ? 4 : (spw >= 2 ? 2 : 1);
+    const bool plain = A.mulMode == MUL_NONE && A.matrixMode != MODE_YCGCO && A.matrixMode != MODE_YCGCO_RE && A.matrixMode != MODE_YCGCO_RO;
+    if (!plain && !k.fixedPoint && spw < 2)
+        spw = 2; // the kernels of the rare modes exist with two strips per wave or more (r2y_tile_impl.h launchOnePlainOrNot)
     A.stripsPerWave = spw;
     const uint32_t chunks = (strips + 4 * spw - 1) / (4 * spw);
     if (k.fixedPoint) { // appendix D.5, coefficients in memory order of the colour channels

@@ -238,7 +238,10 @@ __device__ __forceinline__ int liftCode(float c, float maxf)
     return (int)floorf(cl + 0.5f);
 }
 
-template <typename RT, int NCH, typename YT, int SUB, bool SWAP>
+// PLAIN: matrix coefficients or the identity matrix and no pending alpha arithmetic -- what nearly every encode is.  It is a kernel of its
+// own (launchOne picks): with the YCgCo family and the alpha (un)multiply compiled into the same loop as wave-uniform branches, the
+// one-strip kernel that serves 4K frames took 120 vector registers (half the occupancy) and cfg4 went from 9.0 to 14.9 us.
+template <typename RT, int NCH, typename YT, int SUB, bool SWAP, bool PLAIN>
 __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S)
 {
     constexpr uint32_t BPS = sizeof(YT);
@@ -273,7 +276,7 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
             const f2 G = div2((f2) { (float)c1[0], (float)c1[1] }, A.rcpRgbMax);
             const f2 z = div2((f2) { (float)c2[0], (float)c2[1] }, A.rcpRgbMax);
             f2 xs = x, Gs = G, zs = z;
-            if constexpr (NCH == 4) {
+            if constexpr (NCH == 4 && !PLAIN) {
                 if (A.mulMode != MUL_NONE) { // wave-uniform: pending alpha (un)multiply on the normalised channels, src/reformat.c:325-358
                     unsigned ca[2];
 #pragma unroll
@@ -285,11 +288,11 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
             }
             const f2 R = SWAP ? zs : xs, B = SWAP ? xs : zs;
             const f2 G2 = Gs;
-            if (A.matrixMode == MODE_YCGCO) { // wave-uniform, src/reformat.c:368-372: 0.5 G +- 0.25 (R + B), 0.5 (R - B)
+            if (!PLAIN && A.matrixMode == MODE_YCGCO) { // wave-uniform, src/reformat.c:368-372: 0.5 G +- 0.25 (R + B), 0.5 (R - B)
                 const f2 hg = splat2(0.5f) * G2, q = splat2(0.25f) * (R + B);
                 U[r][p] = hg - q, V[r][p] = splat2(0.5f) * (R - B);
                 tY[r][p] = unormOperand(hg + q, A.rangeY, A.biasY);
-            } else if (A.matrixMode == MODE_YCGCO_RE || A.matrixMode == MODE_YCGCO_RO) { // integer lifting on the channel codes, :373-383
+            } else if (!PLAIN && (A.matrixMode == MODE_YCGCO_RE || A.matrixMode == MODE_YCGCO_RO)) { // integer lifting on the channel codes, :373-383
                 float yv[2], uv2[2], vv[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -386,15 +389,15 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
     }
 }
 
-template <typename RT, int NCH, typename YT, int SUB>
+template <typename RT, int NCH, typename YT, int SUB, bool PLAIN>
 __device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S)
 {
     // which memory-order colour channel is red decides the operand ORDER of the luma sum (fp32 addition is not associative):
     // one wave-uniform branch instead of selects per pixel
     if (A.slotB < A.slotR)
-        computeStripT<RT, NCH, YT, SUB, true>(A, sy, X, laneValid, S);
+        computeStripT<RT, NCH, YT, SUB, true, PLAIN>(A, sy, X, laneValid, S);
     else
-        computeStripT<RT, NCH, YT, SUB, false>(A, sy, X, laneValid, S);
+        computeStripT<RT, NCH, YT, SUB, false, PLAIN>(A, sy, X, laneValid, S);
 }
 
 // ---- libyuv's fixed point (8-bit RGB -> 8-bit planes, BT.601, appendix D.5): same loads, stores and strip walk ----
@@ -537,7 +540,7 @@ hipError_t launchFxSub(int sub, const R2YArgs & A, uint32_t blocks, hipStream_t 
 // One wave, one tile of 256 x 2*NS pixels (NS vertically consecutive strips), every load issued before the first result is needed; the
 // four waves of a workgroup are stacked and independent.  (Round 1 walked a wave down its strips with the next strip's loads in
 // flight; like in the decode direction, many short-lived waves keep the memory pipes fuller: 4K RGBA8 -> 4:2:0 10.9 -> 9.9 us.)
-template <typename RT, int NCH, typename YT, int SUB, int NS>
+template <typename RT, int NCH, typename YT, int SUB, int NS, bool PLAIN>
 __global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A)
 {
     const uint32_t bands = (A.w4 + 255) / 256;
@@ -556,20 +559,29 @@ __global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A)
     for (int s = 0; s < NS; ++s) {
         if (first + 2 * s >= A.h2) // wave-uniform
             break;
-        computeStrip<RT, NCH, YT, SUB>(A, first + 2 * s, X, laneValid, raw[s]);
+        computeStrip<RT, NCH, YT, SUB, PLAIN>(A, first + 2 * s, X, laneValid, raw[s]);
     }
+}
+
+template <typename RT, int NCH, typename YT, int SUB, bool PLAIN>
+hipError_t launchOnePlainOrNot(const R2YArgs & A, uint32_t blocks, hipStream_t stream)
+{
+    if (A.stripsPerWave >= 4)
+        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 4, PLAIN>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
+    else if (A.stripsPerWave >= 2)
+        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 2, PLAIN>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
+    else if constexpr (PLAIN)
+        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 1, PLAIN>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
+    else
+        return hipErrorInvalidValue; // (the rare modes run two strips per wave or more: kernels_r2y_tile.hip)
+    return hipGetLastError();
 }
 
 template <typename RT, int NCH, typename YT, int SUB>
 hipError_t launchOne(const R2YArgs & A, uint32_t blocks, hipStream_t stream)
 {
-    if (A.stripsPerWave >= 4)
-        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 4>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
-    else if (A.stripsPerWave >= 2)
-        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 2>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
-    else
-        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 1>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
-    return hipGetLastError();
+    const bool plain = A.mulMode == MUL_NONE && A.matrixMode != MODE_YCGCO && A.matrixMode != MODE_YCGCO_RE && A.matrixMode != MODE_YCGCO_RO;
+    return plain ? launchOnePlainOrNot<RT, NCH, YT, SUB, true>(A, blocks, stream) : launchOnePlainOrNot<RT, NCH, YT, SUB, false>(A, blocks, stream);
 }
 
 template <typename RT, int NCH, typename YT>

@@ -147,6 +147,8 @@ def test_every_configuration_row_agrees_with_the_profiler():
     assert by[("cfg4_premul_8k", "float")]["frac_of_8TBps"] >= 0.60 and by[("cfg4_ycgco_8k", "float")]["frac_of_8TBps"] >= 0.60
     assert by[("gray_enc_8k", "float")]["frac_of_8TBps"] >= 0.60 and by[("graya_enc_8k", "float")]["frac_of_8TBps"] >= 0.60
     assert by[("photo_grid", "integer")]["us"] <= 30.0
+    # the encode direction at 4K (a round-3 build had lost it: 14.9 us with the rare modes compiled into the same kernel)
+    assert by[("cfg4", "float")]["us"] <= 9.6 and by[("cfg4rgb", "float")]["us"] <= 7.8
 
 
 def test_fp32_instruction_counts():
