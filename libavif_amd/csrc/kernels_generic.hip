@@ -71,9 +71,84 @@ struct GridReader
     }
 };
 
+// The two pixels either side of a seam look at the same four chroma positions (the co-sited sample of each and the other's: the neighbour
+// every filter picks leans across the seam), so one lane converts the pair and fetches the quad once: a sample behind the tile table costs
+// ~20 instructions and two dependent memory round trips, the selects that serve it from registers five.
+template <class Base>
+struct SeamPairReader
+{
+    const Base & base;
+    uint32_t c0, c1, r0, r1; // chroma columns / rows of the quad
+    unsigned qu[2][2], qv[2][2]; // [row][column]
+    __device__ __forceinline__ unsigned y(uint32_t x, uint32_t yy) const { return base.y(x, yy); }
+    __device__ __forceinline__ unsigned a(uint32_t x, uint32_t yy) const { return base.a(x, yy); }
+    __device__ __forceinline__ unsigned pick(const unsigned (&q)[2][2], uint32_t x, uint32_t yy) const
+    {
+        const unsigned top = (x == c1) ? q[0][1] : q[0][0], bottom = (x == c1) ? q[1][1] : q[1][0];
+        return (yy == r1) ? bottom : top;
+    }
+    __device__ __forceinline__ bool holds(uint32_t x, uint32_t yy) const { return (x == c0 || x == c1) && (yy == r0 || yy == r1); }
+    __device__ __forceinline__ unsigned u(uint32_t x, uint32_t yy) const { return holds(x, yy) ? pick(qu, x, yy) : base.u(x, yy); }
+    __device__ __forceinline__ unsigned v(uint32_t x, uint32_t yy) const { return holds(x, yy) ? pick(qv, x, yy) : base.v(x, yy); }
+};
+
+// one workgroup = 256 positions along one seam (vertical seams first); a lane = the two pixels either side of the seam at its position
+template <bool LDS_TABLE>
+__global__ __launch_bounds__(256) void yuvToRgbGridSeamKernel(YuvToRgbPlan p, GridGeometry g, const GridTile * __restrict__ tiles, uint32_t verticalSeams,
+                                                              uint32_t blocksPerVertical, uint32_t blocksPerHorizontal)
+{
+    // the tile table (plane pointers and pitches of up to kSeamTiles tiles) is read ~10 times per pixel: once into LDS
+    extern __shared__ __attribute__((aligned(16))) unsigned char seamLds[];
+    const GridTile * ldsTiles = tiles;
+    if constexpr (LDS_TABLE) {
+        ldsTiles = reinterpret_cast<const GridTile *>(seamLds);
+        const uint32_t words = g.columns * g.rows * (uint32_t)(sizeof(GridTile) / 4);
+        const uint32_t * src = reinterpret_cast<const uint32_t *>(tiles);
+        uint32_t * dst = reinterpret_cast<uint32_t *>(seamLds);
+        for (uint32_t k = threadIdx.x; k < words; k += blockDim.x)
+            dst[k] = src[k];
+        __syncthreads();
+    }
+    const uint32_t verticalBlocks = verticalSeams * blocksPerVertical;
+    const bool vertical = blockIdx.x < verticalBlocks;
+    uint32_t i0, j0, i1, j1;
+    if (vertical) {
+        const uint32_t seam = blockIdx.x / blocksPerVertical, t = (blockIdx.x - seam * blocksPerVertical) * blockDim.x + threadIdx.x;
+        i0 = (seam + 1) * g.tileW - 1, i1 = i0 + 1, j0 = j1 = t;
+    } else {
+        const uint32_t b = blockIdx.x - verticalBlocks;
+        const uint32_t seam = b / blocksPerHorizontal, t = (b - seam * blocksPerHorizontal) * blockDim.x + threadIdx.x;
+        j0 = (seam + 1) * g.tileH - 1, j1 = j0 + 1, i0 = i1 = t;
+    }
+    if (i0 >= p.canvasW || j0 >= p.canvasH)
+        return;
+    const bool second = i1 < p.canvasW && j1 < p.canvasH; // (always, for seams inside the canvas)
+    const GridReader rd { p.yuv, g, ldsTiles };
+    // the quad: columns / rows of the first pixel's co-sited sample and of the one across the seam, held inside the canvas's planes
+    const YuvSide & s = p.yuv;
+    SeamPairReader<GridReader> pr { rd, 0, 0, 0, 0, {}, {} };
+    const uint32_t ci = i0 >> s.shiftX, cj = j0 >> s.shiftY;
+    auto lean = [](uint32_t full, uint32_t c, int lo, int hi) { return (uint32_t)clampInt((full & 1) ? (int)c + 1 : (int)c - 1, lo, hi); };
+    pr.c0 = ci, pr.c1 = s.shiftX ? lean(i0, ci, p.cwinX0, p.cwinX1) : ci;
+    pr.r0 = cj, pr.r1 = s.shiftY ? lean(j0, cj, p.cwinY0, p.cwinY1) : cj;
+    pr.qu[0][0] = rd.u(pr.c0, pr.r0), pr.qu[0][1] = rd.u(pr.c1, pr.r0), pr.qu[1][0] = rd.u(pr.c0, pr.r1), pr.qu[1][1] = rd.u(pr.c1, pr.r1);
+    pr.qv[0][0] = rd.v(pr.c0, pr.r0), pr.qv[0][1] = rd.v(pr.c1, pr.r0), pr.qv[1][0] = rd.v(pr.c0, pr.r1), pr.qv[1][1] = rd.v(pr.c1, pr.r1);
+    if (p.arith == ARITH_LIBYUV) {
+        yuvToRgbPixelFixedT(p, pr, i0, j0);
+        if (second)
+            yuvToRgbPixelFixedT(p, pr, i1, j1);
+    } else {
+        yuvToRgbPixelT(p, pr, i0, j0);
+        if (second)
+            yuvToRgbPixelT(p, pr, i1, j1);
+    }
+}
+
+// ... and one lane per pixel (small grids: the kernel is a chain of memory round trips there, and a lane with one pixel has the shorter one --
+// 7.0 us against 9.5 for the 82 thousand seam pixels of a 12-megapixel photograph; 17.2 against 14.3 for the 336 thousand of cfg5's canvas).
 // blockIdx.y = seam line (2 per interior seam: vertical seams first), x = position along the line
 template <bool LDS_TABLE>
-__global__ __launch_bounds__(256) void yuvToRgbGridSeamKernel(YuvToRgbPlan p, GridGeometry g, const GridTile * __restrict__ tiles, uint32_t verticalLines)
+__global__ __launch_bounds__(256) void yuvToRgbGridSeamPixelKernel(YuvToRgbPlan p, GridGeometry g, const GridTile * __restrict__ tiles, uint32_t verticalLines)
 {
     // the tile table (plane pointers and pitches of up to kSeamTiles tiles) is read ~10 times per pixel: once into LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char seamLds[];
@@ -579,18 +654,28 @@ hipError_t launchYuvToRgbGenericBatch(const YuvToRgbPlan * deviceTable, uint32_t
 hipError_t launchYuvToRgbGridSeams(const YuvToRgbPlan & canvasPlan, const GridGeometry & g, const GridTile * deviceTiles, bool vertical, bool horizontal,
                                    hipStream_t stream)
 {
-    const uint32_t vLines = vertical ? 2 * (g.columns - 1) : 0, hLines = horizontal ? 2 * (g.rows - 1) : 0;
-    if (vLines + hLines == 0)
+    const uint32_t vSeams = vertical ? g.columns - 1 : 0, hSeams = horizontal ? g.rows - 1 : 0;
+    if (vSeams + hSeams == 0)
         return hipSuccess;
-    const uint32_t longest = canvasPlan.canvasW > canvasPlan.canvasH ? canvasPlan.canvasW : canvasPlan.canvasH;
+    const uint32_t bv = (canvasPlan.canvasH + 255) / 256, bh = (canvasPlan.canvasW + 255) / 256;
+    const uint32_t blocks = vSeams * bv + hSeams * bh;
     GridGeometry gm = g;
     auto magic = [](uint32_t d) { return d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0u; };
     gm.magicW = magic(g.tileW), gm.magicH = magic(g.tileH), gm.magicCW = magic(g.tileCW), gm.magicCH = magic(g.tileCH);
     const size_t ldsBytes = (size_t)g.columns * g.rows * sizeof(GridTile);
+    const uint64_t seamPixels = 2ull * ((uint64_t)vSeams * canvasPlan.canvasH + (uint64_t)hSeams * canvasPlan.canvasW);
+    bool pairs = seamPixels >= 200000;
+    if (const char * e = getenv("AVIFHIP_SEAM_PAIRS")) // tests (small grids through the pair kernel) and A/B measurements
+        pairs = atoi(e) != 0;
+    if (!pairs && ldsBytes <= 48 * 1024) { // few seam pixels: one lane each (see yuvToRgbGridSeamPixelKernel)
+        const uint32_t longest = canvasPlan.canvasW > canvasPlan.canvasH ? canvasPlan.canvasW : canvasPlan.canvasH;
+        hipLaunchKernelGGL(yuvToRgbGridSeamPixelKernel<true>, dim3((longest + 255) / 256, 2 * (vSeams + hSeams)), dim3(256), ldsBytes, stream, canvasPlan, gm, deviceTiles, 2 * vSeams);
+        return hipGetLastError();
+    }
     if (ldsBytes <= 48 * 1024)
-        hipLaunchKernelGGL(yuvToRgbGridSeamKernel<true>, dim3((longest + 255) / 256, vLines + hLines), dim3(256), ldsBytes, stream, canvasPlan, gm, deviceTiles, vLines);
+        hipLaunchKernelGGL(yuvToRgbGridSeamKernel<true>, dim3(blocks), dim3(256), ldsBytes, stream, canvasPlan, gm, deviceTiles, vSeams, bv, bh);
     else // more than a thousand tiles: the table stays in global memory
-        hipLaunchKernelGGL(yuvToRgbGridSeamKernel<false>, dim3((longest + 255) / 256, vLines + hLines), dim3(256), 0, stream, canvasPlan, gm, deviceTiles, vLines);
+        hipLaunchKernelGGL(yuvToRgbGridSeamKernel<false>, dim3(blocks), dim3(256), 0, stream, canvasPlan, gm, deviceTiles, vSeams, bv, bh);
     return hipGetLastError();
 }
 

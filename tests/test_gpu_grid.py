@@ -63,6 +63,20 @@ def test_grid_default_arithmetic(hip_auto_arithmetic, g):
     run_grid(hip_auto_arithmetic, g)
 
 
+@pytest.mark.parametrize("pairs", ["0", "1"])
+def test_both_seam_kernels(hip, pairs, monkeypatch):
+    """Seams are redone by one lane per pixel (small grids) or one lane per pair of pixels either side of a seam sharing the chroma quad
+    (large ones); AVIFHIP_SEAM_PAIRS forces either, so that the small test grids go through both, in both arithmetics."""
+    monkeypatch.setenv("AVIFHIP_SEAM_PAIRS", pairs)
+    try:
+        for avoid in (True, False):
+            hip.avifhipSetArithmetic(1 if avoid else 0)
+            for g in cases(avoid)[:7]:
+                run_grid(hip, g)
+    finally:
+        hip.avifhipSetArithmetic(1)
+
+
 def test_grid_argument_checks(hip):
     g = cases(True)[0]
     tiles = H.make_grid_tiles(g)
