@@ -147,13 +147,15 @@ void decompose(uint32_t tuning, uint32_t w4, uint32_t h2, uint32_t jobs, bool ba
 
 // Where the wave-private kernels of the fp32 / 10-12-bit integer families beat round 1's cooperative runs (profiles/r02_solo_ab.txt:
 // cfg3 89.7 -> 85.3 us, fp32 cfg2 33.5 -> 32.0 us; but cfg5x64 284 -> 322 us, 4K fp32 cfg2 11.2 -> 11.8 us): whenever no chroma
-// neighbourhood is staged, and for 8-bit planes on frames from ~16 megapixels up.  Staged 16-bit planes keep the cooperative runs,
+// neighbourhood is staged, and for 8-bit planes on frames from ~6 megapixels up (round 2: 16).  Staged 16-bit planes keep the cooperative runs,
 // whose software pipeline (next tile's loads in flight during a long fp32 compute phase) is worth more than the missing barrier.
 bool soloPays(const TileKey & k, uint64_t pixels)
 {
     if (!k.bilinear)
         return true;
-    return !k.wideYuv && pixels >= ((uint64_t)16 << 20);
+    // (round 3, after the wave-private kernels' staging lost a round and their filter its re-reads: 4K fp32 cfg2 9.6 us cooperative, 8.4-9.0
+    //  wave-private, profiles/r03_cfgs_bench.jsonl; a 1080p 10-bit tile still 6.0 against 6.4)
+    return !k.wideYuv && pixels >= ((uint64_t)6 << 20);
 }
 
 // largest byte offset the kernel forms from a plane base must fit 32 bits
