@@ -19,7 +19,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rnd = random.Random(seed)
 lib = native.load()
-sizes = [(1920, 1080), (1281, 723), (2048, 64), (4100, 38), (516, 1030), (259, 517), (1024, 1024), (3841, 19), (640, 481)]
+sizes = [(1920, 1080), (1281, 723), (2048, 64), (4100, 38), (516, 1030), (259, 517), (1024, 1024), (3841, 19), (640, 481),
+         (3840, 2160), (3850, 1702)]  # the last two: above 6 megapixels, where 8-bit bilinear frames take the wave-private fp32 kernels
 bad = 0
 kernels = {}
 for arithmetic in (0, 1):
