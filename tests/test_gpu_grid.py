@@ -30,6 +30,13 @@ def cases(avoid_libyuv):
         H.GridCase(3, 2, 64, 64, 127, 190, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, upsampling=4, alpha=True, rgb_premultiplied=True, **base),
                    alpha_limited=True),
         H.GridCase(1, 1, 300, 22, 300, 22, H.Y2RCase(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, **base)),
+        # no leftover columns / rows anywhere (every job entirely in the tiled kernels; seams across 2 to 4 tiles per side)
+        H.GridCase(2, 3, 256, 32, 704, 60, H.Y2RCase(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, **base)),
+        H.GridCase(3, 3, 256, 32, 768, 96, H.Y2RCase(0, 0, yuv_depth=12, yuv_format=3, yuv_range=1, matrix=9, rgb_depth=8, upsampling=4, **base)),
+        H.GridCase(2, 2, 320, 40, 640, 80, H.Y2RCase(0, 0, yuv_format=2, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_RGB, upsampling=4, **base)),
+        H.GridCase(3, 2, 64, 64, 128, 192, H.Y2RCase(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, upsampling=4, alpha=True, rgb_premultiplied=True, **base),
+                   alpha_limited=True),
+        H.GridCase(4, 5, 64, 16, 316, 62, H.Y2RCase(0, 0, yuv_format=3, yuv_range=0, matrix=5, rgb_format=A.AVIF_RGB_FORMAT_BGRA, upsampling=4, **base)),
         H.GridCase(2, 2, 64, 16, 100, 30, H.Y2RCase(0, 0, yuv_format=3, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_RGB_565, upsampling=4, **base)),  # universal kernel
     ]
 
@@ -71,7 +78,7 @@ def test_both_seam_kernels(hip, pairs, monkeypatch):
     try:
         for avoid in (True, False):
             hip.avifhipSetArithmetic(1 if avoid else 0)
-            for g in cases(avoid)[:7]:
+            for g in cases(avoid):
                 run_grid(hip, g)
     finally:
         hip.avifhipSetArithmetic(1)
