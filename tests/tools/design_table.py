@@ -1,0 +1,89 @@
+"""Prints DESIGN.md section 4.5's table from the round's committed evidence (profiles/<tag>_cfgs_bench.jsonl + <tag>_cfgs_kernel_stats.txt).
+    python tests/tools/design_table.py [tag]"""
+import json
+import re
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[2]
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+DESC = {
+    "cfg2": "cfg2: 8K 8-bit 4:2:0 BT.709 limited → RGBA8 bilinear (4 frames cycled)",
+    "cfg2_4k": "cfg2 at 4K (3840 × 2160; the north star's second plane size)",
+    "cfg2n": "cfg2 with nearest upsampling",
+    "cfg2_rgb": "cfg2 → RGB8 (3-byte pixels)",
+    "cfg2_565": "cfg2 → RGB565, nearest (Android bitmaps)",
+    "cfg2_alpha": "cfg2 + alpha plane → RGBA8",
+    "cfg2_premul": "cfg2 + alpha plane → RGBA8 premultiplied",
+    "cfg3": "cfg3: 8K 10-bit 4:4:4 + A → RGBA16 premultiplied",
+    "cfg4": "cfg4: 4K RGBA8 → 8-bit 4:2:0 BT.709 + A plane",
+    "cfg4rgb": "cfg4 from RGB8",
+    "cfg4_601": "cfg4 with BT.601 (avifenc's default matrix)",
+    "cfg4_8k": "cfg4 at 8K",
+    "cfg4_premul_8k": "… with a pending alpha multiply (`avifenc --premultiply`)",
+    "cfg4_unpremul_8k": "… with a pending alpha un-multiply",
+    "cfg4_ycgco_8k": "8K RGBA8 → YCgCo 4:4:4 + A",
+    "ident8_enc": "lossless encode: 8K RGBA8 → identity 8-bit 4:4:4 + A",
+    "gray_enc_8k": "8K GRAY8 → luma plane",
+    "graya_enc_8k": "8K GRAYA8 → luma + alpha planes",
+    "cfg5": "cfg5 tile: 1080p 10-bit 4:2:0 → RGBA(10) bilinear, single launch (launch-bound)",
+    "cfg5_8": "cfg5 tile → RGBA8",
+    "cfg5x64": "cfg5 canvas: 64 tiles in one batch launch → RGBA(10)",
+    "cfg5x64_8": "cfg5 canvas → RGBA8",
+    "f16_420": "8K 10-bit 4:2:0 → RGBA F16",
+    "f16_444a": "8K 10-bit 4:4:4 + A → RGBA F16",
+    "ident8": "8K identity 8-bit 4:4:4 → RGBA8 (byte shuffle)",
+    "ident8rgb": "… → RGB8",
+    "gray8": "8K 8-bit 4:2:0 → GRAY8",
+    "graya16": "8K 10-bit + alpha → GRAYA16",
+    "premul8": "`avifRGBImagePremultiplyAlpha` in place, 8K RGBA8",
+    "unpremul8": "`avifRGBImageUnpremultiplyAlpha` in place, 8K RGBA8",
+    "unpremul16": "… 8K RGBA16",
+    "tail0": "decode-side tail (§4.6): 8K cfg2 + crop (8,4,7664,4312), fused",
+    "tail180": "… + half turn + mirror, fused",
+    "tail90": "… + quarter turn + mirror, fused",
+    "tail90_two_pass": "… + quarter turn, two passes (conversion, then `avifhipRGBImageTransformAsync`)",
+    "tail0_10": "tail from 10-bit planes → RGBA8: crop only",
+    "tail90_10": "… + quarter turn",
+    "tail0_rgba10": "tail, 10-bit planes → RGBA(10) (the API default depth): crop only",
+    "tail180_rgba10": "… + half turn + mirror",
+    "tail90_rgba10": "… + quarter turn + mirror",
+    "tail90_rgba10_two_pass": "… in two passes",
+    "cfg5grid": "cfg5 through the grid entry point (tiles where the decoder left them + seam kernel) → RGBA(10)",
+    "cfg5grid_8": "… → RGBA8",
+    "photo_grid": "a phone photograph: 4032 × 3024 8-bit 4:2:0 as 8 × 6 tiles of 512 × 512 → RGBA8, grid entry point, same buffers call after call",
+    "xform90": "`avifhipRGBImageTransformAsync` alone: 8K RGBA8 crop + quarter turn",
+    "xform180": "… crop + half turn",
+    "scale_box4": "plane scaling 8K → 4K (§4.8)",
+    "scale_up2": "… 4K → 8K",
+    "scale_down_1_5": "… 8K → 5120 × 2880",
+}
+
+
+def blocks():
+    out = {}
+    for block in (ROOT / "profiles" / f"{TAG}_cfgs_kernel_stats.txt").read_text().split("\n== ")[1:]:
+        lines = block.splitlines()
+        rows = []
+        for l in lines[1:]:
+            m = re.match(r"^\s{3}(\S.*?)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", l)
+            if m and not l.strip().startswith("kernel "):
+                rows.append((m.group(1), int(m.group(2)), float(m.group(3))))
+        out[lines[0].strip()] = rows
+    return out
+
+
+rows = [json.loads(l) for l in (ROOT / "profiles" / f"{TAG}_cfgs_bench.jsonl").read_text().splitlines() if l.startswith("{")]
+B = blocks()
+print("| config | arithmetic | kernel | µs: HIP events or wall clock per call (rocprofv3 average of the same run) | fraction of 8 TB/s |")
+print("|---|---|---|---|---|")
+for r in rows:
+    ks = B[r["config"]]
+    closest = min((a for _, _, a in ks), key=lambda a: abs(a - r["us"]))
+    if r["clock"] == "events" or len(ks) == 1 or abs(closest - r["us"]) / closest < 0.06:
+        prof = f"{closest:.1f}"
+    else:
+        most = max(c for _, c, _ in ks)
+        prof = " + ".join(f"{a:.1f}" for _, c, a in ks if 2 * c >= most)
+    clock = "" if r["clock"] == "events" else " per call"
+    print(f"| {DESC.get(r['config'], r['config'])} | {r['arithmetic'].replace('float', 'fp32')} | `{r['kernel']}` | {r['us']:.1f}{clock} ({prof}) | {r['frac_of_8TBps']:.2f} |")
