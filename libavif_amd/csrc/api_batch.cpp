@@ -367,35 +367,6 @@ avifRGBImage canvasLike(const avifRGBImage * out, uint32_t w, uint32_t h, uint8_
 }
 } // namespace
 
-// The crop, grown to the left / upwards to an origin the tile kernels take (x a multiple of 8, y even: kernels_tile.hip
-// tileYuvToRgbSupported): only what the crop keeps is converted; the few extra columns / rows are dropped by the map.
-// A quarter turn stores 128-byte runs along destination rows, one per tile row band (tile_map_impl.h mapTransposeStore), and where those
-// start within a 128-byte line is set by the first row converted.  Measured at 8K -> RGBA16 (cfg_bench tail90_rgba10, one box): runs that
-// are whole lines 377 k megapixels/s, split 32 + 96 bytes 341 k, 48 + 80 339 k, 64 + 64 306 k.  So the rectangle starts up to one run's
-// pixels above the crop, on the row that makes the runs whole lines, or failing that keeps them furthest from an even split.
-static avifCropRect coverOfCrop(const avifCropRect & r, const PixelMap & map, const avifRGBImage * rgb, uint32_t pixelBytes)
-{
-    const uint32_t x0 = r.x & ~7u;
-    uint32_t y0 = r.y & ~1u;
-    if (map.transposed && (pixelBytes == 4 || pixelBytes == 8)) {
-        const int64_t runPx = 128 / pixelBytes;
-        int bestScore = -1;
-        uint32_t bestY = y0;
-        for (uint32_t y = y0;; y -= 2) {
-            const int64_t d = (int64_t)y - (int64_t)r.y; // first converted row, in crop rows (<= 0)
-            const int64_t startPx = map.sx > 0 ? (int64_t)map.kx + d : (int64_t)map.kx - d - (runPx - 1);
-            const uint32_t off = (uint32_t)(((int64_t)(uintptr_t)rgb->pixels + startPx * (int64_t)pixelBytes) & 127);
-            const int score = off == 0 ? 1000 : abs((int)off - 64);
-            if (score > bestScore)
-                bestScore = score, bestY = y;
-            if (off == 0 || y < 2 || (int64_t)(y0 - y) + 2 >= runPx)
-                break;
-        }
-        y0 = bestY;
-    }
-    return avifCropRect { x0, y0, r.x + r.width - x0, r.y + r.height - y0 };
-}
-
 extern "C" avifResult avifhipGridYUVToRGBTransformedAsync(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
                                                           avifBool alphaIsLimitedRange, avifRGBImage * rgb, const avifCropRect * crop, avifBool rotate, uint8_t angle,
                                                           avifBool mirror, uint8_t axis, void * hipStream)
@@ -431,7 +402,7 @@ extern "C" avifResult avifhipGridYUVToRGBTransformedAsync(const avifhipGrid * gr
     const bool fused = gTiledKernels.load(std::memory_order_relaxed) && tileYuvToRgbSupported(probe);
     if (fused) {
         avifRGBImage canvasRgb = canvasLike(rgb, grid->outputWidth, grid->outputHeight, rgb->pixels, rgb->rowBytes);
-        const avifCropRect cover = coverOfCrop(r, map, rgb, px);
+        const avifCropRect cover = coverOfCrop(r, map, (uintptr_t)rgb->pixels, px);
         return gridYuvToRgbImpl(grid, colorTiles, alphaTiles, alphaIsLimitedRange, &canvasRgb, hipStream, &map, &cover);
     }
     hipStream_t stream = pickStream(hipStream);
@@ -466,7 +437,7 @@ extern "C" avifResult avifhipImageYUVToRGBTransformedAsync(const avifImage * ima
     avifRGBImage canvasRgb = canvasLike(rgb, image->width, image->height, rgb->pixels, rgb->rowBytes);
     YuvToRgbPlan plan;
     const PixelMap map = makePixelMap(r.x, r.y, r.width, r.height, turns, mirrorAxis);
-    const avifCropRect cover = coverOfCrop(r, map, rgb, px);
+    const avifCropRect cover = coverOfCrop(r, map, (uintptr_t)rgb->pixels, px);
     const avifResult pr = makeYuvToRgbPlan(image, &canvasRgb, &cover, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan);
     if (pr != AVIF_RESULT_OK)
         return pr;

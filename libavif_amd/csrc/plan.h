@@ -62,6 +62,35 @@ inline PixelMap makePixelMap(uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch,
     return m;
 }
 
+// The crop, grown to the left / upwards to an origin the tile kernels take (x a multiple of 8, y even: kernels_tile.hip
+// tileYuvToRgbSupported): only what the crop keeps is converted; the few extra columns / rows are dropped by the map.
+// A quarter turn stores 128-byte runs along destination rows, one per tile row band (tile_map_impl.h mapTransposeStore), and where those
+// start within a 128-byte line is set by the first row converted.  Measured at 8K -> RGBA16 (cfg_bench tail90_rgba10, one box): runs that
+// are whole lines 377 k megapixels/s, split 32 + 96 bytes 341 k, 48 + 80 339 k, 64 + 64 306 k.  So the rectangle starts up to one run's
+// pixels above the crop, on the row that makes the runs whole lines, or failing that keeps them furthest from an even split.
+inline avifCropRect coverOfCrop(const avifCropRect & r, const PixelMap & map, uintptr_t pixelsAddress, uint32_t pixelBytes)
+{
+    const uint32_t x0 = r.x & ~7u;
+    uint32_t y0 = r.y & ~1u;
+    if (map.transposed && (pixelBytes == 4 || pixelBytes == 8)) {
+        const int64_t runPx = 128 / pixelBytes;
+        int bestScore = -1;
+        uint32_t bestY = y0;
+        for (uint32_t y = y0;; y -= 2) {
+            const int64_t d = (int64_t)y - (int64_t)r.y; // first converted row, in crop rows (<= 0)
+            const int64_t startPx = map.sx > 0 ? (int64_t)map.kx + d : (int64_t)map.kx - d - (runPx - 1);
+            const uint32_t off = (uint32_t)(((int64_t)pixelsAddress + startPx * (int64_t)pixelBytes) & 127);
+            const int score = off == 0 ? 1000 : ((int)off > 64 ? (int)off - 64 : 64 - (int)off);
+            if (score > bestScore)
+                bestScore = score, bestY = y;
+            if (off == 0 || y < 2 || (int64_t)(y0 - y) + 2 >= runPx)
+                break;
+        }
+        y0 = bestY;
+    }
+    return avifCropRect { x0, y0, r.x + r.width - x0, r.y + r.height - y0 };
+}
+
 // Interleaved-pixel side (avifRGBColorSpaceInfo, include/avif/internal.h:297-309)
 struct RgbSide
 {

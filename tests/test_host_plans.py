@@ -21,13 +21,15 @@ SO = ROOT / "tests" / "tools" / "libhostlogic.so"
 @pytest.fixture(scope="module")
 def host():
     srcs = [ROOT / "tests" / "tools" / "hostlogic.cpp", CSRC / "scale_plan.cpp", CSRC / "gainmap_plan.cpp"]
-    deps = srcs + [CSRC / "scale_plan.h", CSRC / "gainmap_plan.h"]
+    deps = srcs + [CSRC / "scale_plan.h", CSRC / "gainmap_plan.h", CSRC / "plan.h"]
     if not SO.exists() or any(d.stat().st_mtime > SO.stat().st_mtime for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", f"-I{CSRC}", "-o", os.fspath(SO)] + [os.fspath(s) for s in srcs],
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", f"-I{CSRC}", f"-I{ROOT / 'include'}", "-o", os.fspath(SO)] + [os.fspath(s) for s in srcs],
                        check=True, capture_output=True)
     lib = C.CDLL(os.fspath(SO))
     ip = C.POINTER(C.c_int)
     lib.hostScaleSchedule.restype, lib.hostScaleSchedule.argtypes = C.c_int, [C.c_int] * 5 + [ip] * 5
+    lib.hostCoverOfCrop.restype = None
+    lib.hostCoverOfCrop.argtypes = [C.c_uint32] * 4 + [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32 * 4)]
     lib.hostScaleSpecialisation.restype, lib.hostScaleSpecialisation.argtypes = C.c_int, [C.c_int] * 5
     lib.hostTransferFunction.restype, lib.hostTransferFunction.argtypes = C.c_float, [C.c_int, C.c_int, C.c_float]
     lib.hostPrimariesMatrix.restype, lib.hostPrimariesMatrix.argtypes = C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double * 9)]
@@ -239,3 +241,45 @@ def test_every_wave_tile_of_a_launch_is_visited_exactly_once(geometry):
 
 def test_the_cooperative_kernels_block_order_is_a_permutation(geometry):
     assert geometry.geomSweepRemap(20000) == 0
+
+
+def test_cover_rectangle_of_a_fused_crop(host):
+    """plan.h coverOfCrop: the rectangle a fused crop / rotate / mirror converts contains the crop, starts where the tile kernels can start
+    (x a multiple of 8, y even), reaches at most one run of pixels above the crop -- and for quarter turns of 4- and 8-byte pixels its first
+    row is the one that makes the 128-byte runs of the transposing stores whole cache lines if any candidate does, else the one that keeps
+    them furthest from an even 64 + 64 split (the measured ranking)."""
+    import random
+    rnd = random.Random(5)
+    for _ in range(4000):
+        W, H = rnd.choice([(7680, 4320), (4032, 3024), (1100, 150), (701, 61)])
+        cw, ch = rnd.randint(1, W), rnd.randint(1, H)
+        cx, cy = rnd.randint(0, W - cw), rnd.randint(0, H - ch)
+        turns, mirror, pb = rnd.choice([0, 1, 2, 3]), rnd.choice([-1, 0, 1]), rnd.choice([3, 4, 6, 8])
+        address = rnd.choice([0, 64, 128 * rnd.randint(1, 1000), 16 * rnd.randint(1, 10000)])
+        out = (C.c_uint32 * 4)()
+        host.hostCoverOfCrop(cx, cy, cw, ch, turns, mirror, address, pb, C.byref(out))
+        x, y, w, h = out
+        assert x % 8 == 0 and y % 2 == 0 and x <= cx and y <= cy and x + w == cx + cw and y + h == cy + ch and cx - x < 8
+        run = 128 // pb if pb in (4, 8) else 0
+        if not (turns & 1) or not run:
+            assert y == cy & ~1
+            continue
+        assert cy - y < run + 1
+        # the destination x of the crop's rows: x = sx * jj + kx with the map's sx, kx (plan.h makePixelMap)
+        dw = ch
+        sx, kx = {1: (1, 0), 3: (-1, ch - 1)}[turns]
+        if mirror == 1:
+            sx, kx = -sx, dw - 1 - kx
+
+        def offset(y0):
+            d = y0 - cy
+            start = kx + d if sx > 0 else kx - d - (run - 1)
+            return (address + start * pb) % 128
+
+        def score(y0):
+            off = offset(y0)
+            return 1000 if off == 0 else abs(off - 64)
+
+        candidates = [y0 for y0 in range(cy & ~1, -1, -2) if (cy & ~1) - y0 + 2 <= run or y0 == cy & ~1]
+        best = max(score(y0) for y0 in candidates)
+        assert score(y) == best or (best == 1000 and offset(y) == 0), (cx, cy, cw, ch, turns, mirror, pb, address, y, [(c, offset(c)) for c in candidates[:10]])

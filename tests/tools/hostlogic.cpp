@@ -4,11 +4,21 @@
 #include <string.h>
 
 #include "gainmap_plan.h"
+#include "plan.h"
 #include "scale_plan.h"
 
 using namespace avifhip;
 
 extern "C" {
+
+// the rectangle a fused crop / rotate / mirror converts (plan.h coverOfCrop): out = {x, y, width, height}
+void hostCoverOfCrop(uint32_t cx, uint32_t cy, uint32_t cw, uint32_t ch, int quarterTurns, int mirrorAxis, uint64_t pixelsAddress, uint32_t pixelBytes, uint32_t out[4])
+{
+    const avifCropRect r = { cx, cy, cw, ch };
+    const PixelMap map = makePixelMap(cx, cy, cw, ch, quarterTurns, mirrorAxis);
+    const avifCropRect c = coverOfCrop(r, map, (uintptr_t)pixelsAddress, pixelBytes);
+    out[0] = c.x, out[1] = c.y, out[2] = c.width, out[3] = c.height;
+}
 
 int hostScaleSchedule(int srcW, int srcH, int dstW, int dstH, int wide, int * colA, int * colB, int * rowA, int * rowB, int * rowF)
 {
