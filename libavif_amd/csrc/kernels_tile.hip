@@ -280,6 +280,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     L.table = nullptr;
     L.count = 1;
     L.stream = stream;
+    L.shiftStrips = 0;
     L.mapped = k.mapped, L.transposed = k.mapped && plan.rgb.map.transposed, L.streamLoads = false;
     decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)A.w4 * A.h2) || (plan.tuning & TUNE_SOLO_ALWAYS));
@@ -327,6 +328,7 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
     L.table = static_cast<const TileArgs *>(deviceTileTable);
     L.count = count;
     L.stream = stream;
+    L.shiftStrips = 0;
     L.mapped = k.mapped, L.transposed = k.mapped && representative.rgb.map.transposed;
     // (upper bound from the largest job: batches are made of equally sized tiles)
     L.streamLoads = (double)maxW * maxH * count * planeBytesPerPixel(representative, k) > kStreamPlaneBytes;

@@ -21,6 +21,9 @@ struct PkGeom
     // quarter turns (launches that store through a transposing PixelMap): tiles are numbered DOWN the columns of the tile grid and a chunk is
     // one tile column, so the workgroups an XCD runs one after the other write neighbouring pieces of the same destination rows
     uint32_t columnMajor, tilesY, magicTilesY;
+    // ... and their tile grid may start above the rectangle, by whole waves' worth of strips: the waves up there find no rows and only take
+    // part in the transposition; what it buys is WHERE along a destination row a tile's 128-byte run starts (launchSoloMapped)
+    uint32_t stripShift;
 };
 
 // (The index arithmetic below is constexpr -- callable from host and device code alike -- so that tests/tools/geometry_check.cpp can walk
@@ -57,7 +60,7 @@ __attribute__((always_inline)) constexpr PkPlace pkPlaceOf(uint32_t tile, uint32
     } else {
         trow = g.magicTilesX ? mulHi32(tile, g.magicTilesX) : tile, tcol = tile - trow * g.tilesX;
     }
-    return PkPlace { (tcol << g.wavesXLog2) + wx, (trow * wavesY + wy) * ns };
+    return PkPlace { (tcol << g.wavesXLog2) + wx, (trow * wavesY + wy) * ns - g.stripShift }; // (wraps above the rectangle: 2 * strip0 >= h2 there too)
 }
 
 // The cooperative kernels' order (tile_impl.h runBlock, tile_fx_impl.h): workgroups are dispatched round-robin over the 8 XCDs;
@@ -85,7 +88,9 @@ inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t 
     const uint32_t wavesX = 1u << wxl, wavesY = 4u / wavesX;
     g->wavesXLog2 = wxl;
     g->tilesX = (bands + wavesX - 1) / wavesX;
-    const uint32_t tilesY = (strips + ns * wavesY - 1) / (ns * wavesY);
+    const uint32_t shift = L.shiftStrips - L.shiftStrips % ns; // whole waves
+    g->stripShift = shift;
+    const uint32_t tilesY = (strips + shift + ns * wavesY - 1) / (ns * wavesY);
     g->nTiles = g->tilesX * tilesY;
     auto magic = [](uint32_t d) { return d > 1 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0u; };
     g->magicTilesX = magic(g->tilesX);

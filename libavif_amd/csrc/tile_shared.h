@@ -229,6 +229,7 @@ struct TileLaunch
     uint32_t pkStrips;      // strips (two luma rows) per wave: 2 or 4
     uint32_t wavesXLog2;    // waves of a workgroup side by side (1 << n), the rest stacked
     uint32_t chunkRows;     // tile rows per XCD chunk, 0 = plain raster order
+    uint32_t shiftStrips;   // the tile grid starts this many strips ABOVE the rectangle (a multiple of the strips per wave; 0 but for quarter turns: launchSoloMapped)
     bool mapped;            // stores go through the jobs' PixelMap
     bool transposed;        // ... which turns rows into columns (quarter turns)
     bool attenuate;         // TileKey::attenuate

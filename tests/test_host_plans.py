@@ -220,6 +220,7 @@ def geometry():
                         "-o", os.fspath(so), os.fspath(src)], check=True, capture_output=True)
     lib = C.CDLL(os.fspath(so))
     lib.geomCheckPk.restype, lib.geomCheckPk.argtypes = C.c_int, [C.c_uint32] * 6
+    lib.geomCheckPkShifted.restype, lib.geomCheckPkShifted.argtypes = C.c_int, [C.c_uint32] * 4
     lib.geomSweepPk.restype, lib.geomSweepPk.argtypes = C.c_uint64, [C.c_uint32, C.POINTER(C.c_uint32 * 7), C.POINTER(C.c_uint64)]
     lib.geomSweepRemap.restype, lib.geomSweepRemap.argtypes = C.c_uint64, [C.c_uint32]
     return lib
@@ -237,6 +238,15 @@ def test_every_wave_tile_of_a_launch_is_visited_exactly_once(geometry):
                 for wxl in (0, 1, 2):
                     for chunk_rows in (0, 1, 2, 5, 15):
                         assert geometry.geomCheckPk(w & ~3, h & ~1, count, strips, wxl, chunk_rows) == 0, (w, h, count, strips, wxl, chunk_rows)
+
+
+def test_a_tile_grid_that_starts_above_the_rectangle_still_visits_every_strip_once(geometry):
+    """Quarter turns of single images start their tile grid up to three waves' worth of strips above the rectangle (launchSoloMapped: where
+    the 128-byte runs of the transposing stores fall along a destination row); the waves up there own nothing, everything else exactly once."""
+    for w, h in [(7664, 4312), (7680, 4320), (256, 8), (300, 34), (4032, 3024), (1100, 150), (16384, 16382)]:
+        for strips in (2, 4):
+            for waves in (0, 1, 2, 3):
+                assert geometry.geomCheckPkShifted(w & ~3, h & ~1, strips, waves * strips) == 0, (w, h, strips, waves)
 
 
 def test_the_cooperative_kernels_block_order_is_a_permutation(geometry):

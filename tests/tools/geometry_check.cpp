@@ -17,11 +17,12 @@ namespace {
 
 // 0 = every wave-tile of a w4 x h2 job visited exactly once; otherwise a code saying what went wrong
 int checkPk(uint32_t w4, uint32_t h2, uint32_t count, uint32_t pkStrips, uint32_t wavesXLog2, uint32_t chunkRows, std::vector<uint8_t> & seenTile,
-            std::vector<uint8_t> & seenPlace, bool transposed = false)
+            std::vector<uint8_t> & seenPlace, bool transposed = false, uint32_t shiftStrips = 0)
 {
     TileLaunch L;
     memset(&L, 0, sizeof(L));
     L.count = count, L.pkStrips = pkStrips, L.wavesXLog2 = wavesXLog2, L.chunkRows = chunkRows;
+    L.shiftStrips = shiftStrips; // quarter turns of single images: the tile grid starts that many strips above the rectangle
     L.transposed = transposed; // quarter turns: tiles numbered down the columns, one tile column per XCD chunk
     uint32_t nsw = 0, blocks = 0;
     PkGeom g;
@@ -64,6 +65,13 @@ int checkPk(uint32_t w4, uint32_t h2, uint32_t count, uint32_t pkStrips, uint32_
 } // namespace
 
 extern "C" {
+
+// a turned launch whose tile grid starts `shiftStrips` strips above the rectangle (tile_impl.h launchSoloMapped): every strip still once
+int geomCheckPkShifted(uint32_t w4, uint32_t h2, uint32_t pkStrips, uint32_t shiftStrips)
+{
+    std::vector<uint8_t> a, b;
+    return checkPk(w4, h2, 1, pkStrips, 0, 1, a, b, true, shiftStrips);
+}
 
 int geomCheckPk(uint32_t w4, uint32_t h2, uint32_t count, uint32_t pkStrips, uint32_t wavesXLog2, uint32_t chunkRows)
 {
