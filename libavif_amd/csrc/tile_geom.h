@@ -74,6 +74,31 @@ __attribute__((always_inline)) constexpr uint32_t blockRemap(uint32_t b, uint32_
     return xcd * per + (xcd < rem ? xcd : rem) + slot;
 }
 
+// Quarter turns of a single image: how many strips above the rectangle the tile grid starts (a multiple of the strips per wave, at most
+// three waves' worth).  A tile's rows leave as one 128-byte run per source column; where along the destination row the runs start is set
+// by the row the tile grid starts on.  plan.h coverOfCrop picks the rectangle's first row with that in mind but cannot go above the canvas;
+// the grid can start above the RECTANGLE, by whole waves, whose lanes then find no rows.  Same ranking: whole cache lines if any start gives
+// them, else as far from an even split as possible.  Worth 12 % for 8-byte pixels and nothing measurable for 4-byte ones (the
+// packed kernels, tried: 38.2 -> 38.4 us), so only the fp32 tiles use it (tile_impl.h launchSoloMapped).
+inline uint32_t turnShiftStrips(const TileArgs & A, int pixelBytes, int stripsPerWave)
+{
+    if (pixelBytes != 4 && pixelBytes != 8)
+        return 0;
+    const PixelMap & m = A.map;
+    const int waveRows = 2 * stripsPerWave, runPx = 4 * waveRows, runBytes = runPx * pixelBytes; // the four stacked waves' rows: 64 or 128 bytes
+    int bestScore = -1;
+    uint32_t best = 0;
+    for (int w = 0; w < 4; ++w) {
+        const int64_t d = (int64_t)A.mapY0 - w * waveRows - (int64_t)m.cy; // first row of the tile grid, in crop rows
+        const int64_t startPx = m.sx > 0 ? (int64_t)m.kx + d : (int64_t)m.kx - d - (runPx - 1);
+        const int off = (int)(((int64_t)(uintptr_t)A.rgb + startPx * pixelBytes) & (runBytes - 1));
+        const int score = off == 0 ? 1000 : (off > runBytes / 2 ? off - runBytes / 2 : runBytes / 2 - off);
+        if (score > bestScore)
+            bestScore = score, best = (uint32_t)(w * stripsPerWave);
+    }
+    return best;
+}
+
 // Launch geometry: strips per wave, waves side by side, tile order (TuningBits; tests/tools/geometry_sweep.py)
 inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t * nsw, PkGeom * g, uint32_t * blocks)
 {

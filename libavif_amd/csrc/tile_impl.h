@@ -1429,24 +1429,8 @@ hipError_t launchSoloMapped(const TileLaunch & L)
     TileLaunch M = L;
     if (L.transposed) {
         M.pkStrips = kTurnNS, M.wavesXLog2 = 0;
-        if (L.args) {
-            // A tile's rows leave as one 128-byte run per source column; where along the destination row the runs start is set by the row
-            // the tile grid starts on.  plan.h coverOfCrop picks the rectangle's first row with that in mind but cannot go above the canvas;
-            // the grid can start above the RECTANGLE, by whole waves (2 * kTurnNS rows), whose lanes then find no rows.  Same ranking: whole
-            // cache lines if any start gives them, else as far from an even split as possible.
-            const TileArgs & A = *L.args;
-            const PixelMap & m = A.map;
-            constexpr int kPB = 4 * (int)sizeof(RT), kRunPx = 128 / kPB, kWaveRows = 2 * kTurnNS;
-            int bestScore = -1;
-            for (int w = 0; w < 4; ++w) {
-                const int64_t d = (int64_t)A.mapY0 - w * kWaveRows - (int64_t)m.cy; // first row of the tile grid, in crop rows
-                const int64_t startPx = m.sx > 0 ? (int64_t)m.kx + d : (int64_t)m.kx - d - (kRunPx - 1);
-                const int off = (int)(((int64_t)(uintptr_t)A.rgb + startPx * kPB) & 127);
-                const int score = off == 0 ? 1000 : (off > 64 ? off - 64 : 64 - off);
-                if (score > bestScore)
-                    bestScore = score, M.shiftStrips = (uint32_t)(w * kTurnNS);
-            }
-        }
+        if (L.args)
+            M.shiftStrips = turnShiftStrips(*L.args, 4 * (int)sizeof(RT), kTurnNS);
     }
     uint32_t nsw, blocks;
     PkGeom g;
