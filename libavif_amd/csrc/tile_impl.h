@@ -725,7 +725,13 @@ __device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, 
 // straight away; MAP_TURNED: quarter turns, into `held` (2 * NS rows of the lane's four pixels, 4 * PW words each), which the caller
 // transposes through LDS.  Separate instantiations: the rows of a whole tile held in registers cost the row-wise kernels their occupancy.
 enum MapMode : int { MAP_NONE = 0, MAP_ROWS = 1, MAP_TURNED = 2 };
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, int WAVES = 4, int MAP = MAP_NONE>
+// MULSEL (kernels with pending alpha arithmetic): 0 = the mode is read from the job (a wave-uniform branch around every row: all of them
+// compiled in), 1 = in-loop multiply, 3 = integer post-multiply compiled in alone -- what premultiplied destinations (Android's bitmaps,
+// cfg3) ask for.  With every mode in one kernel cfg3's took 76 KB of code and 116 registers (four waves per SIMD); its own: 28 KB, 94
+// registers.  The big kernel's speed depends on where the compiler happens to lay its blocks (84 us in one build, 100-102 in two others
+// that differed only in code it never executes: the eight unrolled row bodies a wave walks through are spread over more code than the
+// instruction cache holds); the small one ran at 78.8-82.6 us in every build measured.
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, int WAVES = 4, int MAP = MAP_NONE, int MULSEL = 0>
 __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & c, uint32_t tileY,
                                             const TileRaw<YT, SUB, BIL, APLANE || HASMUL, NS, WAVES> & T, f2 (*rows)[kRowPitch], WideRowExchange * xchg,
                                             unsigned * held = nullptr)
@@ -753,7 +759,8 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 #ifdef AVIFHIP_PROBE_MULMODE // instruction-count probes only (tests/tools/isa_count.py): one alpha mode compiled in
     const int inLoopMode = (AVIFHIP_PROBE_MULMODE) <= 2 ? (AVIFHIP_PROBE_MULMODE) : MUL_NONE, postMode = (AVIFHIP_PROBE_MULMODE) > 2 ? (AVIFHIP_PROBE_MULMODE) - 2 : MUL_NONE;
 #else
-    const int inLoopMode = A.inLoopMul, postMode = A.postMul;
+    const int inLoopMode = MULSEL == 0 ? A.inLoopMul : (MULSEL == 1 ? (int)MUL_MULTIPLY : (int)MUL_NONE);
+    const int postMode = MULSEL == 0 ? A.postMul : (MULSEL == 3 ? (int)MUL_MULTIPLY : (int)MUL_NONE);
 #endif
     // 3-channel pixels: bytes of the band's row segment that exist (storeRowContiguous)
     const uint32_t segBytes = ((A.w4 - c.bandX < (uint32_t)kBandW) ? A.w4 - c.bandX : (uint32_t)kBandW) * kPixBytes;
@@ -1270,7 +1277,7 @@ __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * 
 // ---- every wave for itself (the structure of tile_pk_impl.h): one wave = one tile of 256 x 2*NS pixels, every load issued up
 //      front, the chroma neighbourhood in a wave-private LDS block, NO workgroup barrier; tiles in per-XCD chunks (tile_geom.h).
 //      Replaces the cooperative runs above wherever it measured faster (launchOne) ----
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false, int MULSEL = 0>
 __device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2 * lds, WideRowExchange * xchg)
 {
     constexpr bool kNeedA = APLANE || HASMUL;
@@ -1299,18 +1306,18 @@ __device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, 1>(A, c, tileY, raw, rows, xchg ? xchg + wave : nullptr);
+    computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, 1, MAP_NONE, MULSEL>(A, c, tileY, raw, rows, xchg ? xchg + wave : nullptr);
 }
 
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, int MULSEL = 0>
 __global__ __launch_bounds__(256) void yuvToRgbTileSoloKernel(TileArgs A, PkGeom g)
 {
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, g, lds, xchg);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, false, MULSEL>(A, g, lds, xchg);
     } else {
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS>(A, g, lds, nullptr);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, false, MULSEL>(A, g, lds, nullptr);
     }
 }
 
@@ -1481,6 +1488,32 @@ hipError_t launchSolo(const TileLaunch & L)
         else
             hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, g);
     } else {
+        // single images with a pending alpha multiply: the kernel with that one mode compiled in (computeTile MULSEL)
+        int sel = 0;
+        if constexpr (MUL) {
+            if (L.args->tuning & TUNE_ALL_ALPHA_MODES)
+                sel = 0;
+            else if (L.args->inLoopMul == MUL_MULTIPLY && L.args->postMul == MUL_NONE)
+                sel = 1;
+            else if (L.args->inLoopMul == MUL_NONE && L.args->postMul == MUL_MULTIPLY)
+                sel = 3;
+        }
+        if constexpr (MUL) {
+            if (sel == 1) {
+                if (nsw == 4)
+                    hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, 1>), grid, block, 0, L.stream, *L.args, g);
+                else
+                    hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, 1>), grid, block, 0, L.stream, *L.args, g);
+                return hipGetLastError();
+            }
+            if (sel == 3) {
+                if (nsw == 4)
+                    hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, 3>), grid, block, 0, L.stream, *L.args, g);
+                else
+                    hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, 3>), grid, block, 0, L.stream, *L.args, g);
+                return hipGetLastError();
+            }
+        }
         if (nsw == 4)
             hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, *L.args, g);
         else
