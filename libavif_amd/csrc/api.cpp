@@ -100,6 +100,17 @@ struct ContextLease
     {
         if (!context)
             return;
+        // the thread's last use of the device scratch is marked now: the stream it ran on may be the thread's own, gone before the
+        // context's next holder asks (ScratchScope)
+        if (context->scratchPending && !context->scratchMarked && context->scratchUsed) {
+            if (hipEventRecord(context->scratchUsed, context->scratchStream) == hipSuccess) {
+                context->scratchMarked = true;
+            } else {
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+                context->scratchPending = false;
+            }
+        }
         ContextPool & pool = contextPool();
         std::lock_guard<std::mutex> lock(pool.mutex);
         pool.idle.push_back(context); // work still pending on its streams stays ordered: the next holder uses the same streams
@@ -247,22 +258,27 @@ avifResult ensureContext()
 ScratchScope::ScratchScope(hipStream_t s) : stream(s), result(AVIF_RESULT_OK)
 {
     if (tls.scratchPending && tls.scratchStream != s) {
-        const hipError_t e = hipStreamWaitEvent(s, tls.scratchUsed, 0);
+        // The previous user's stream is marked only now that somebody on another stream needs to wait for it: an event recorded here
+        // covers everything that stream was given before, and calls that stay on one stream (nearly all) pay for no event at all -- a
+        // record behind every launch kept the next kernel waiting for the signal (plane scaling: 24 us per call around an 18 us kernel).
+        hipError_t e = tls.scratchMarked ? hipSuccess : hipEventRecord(tls.scratchUsed, tls.scratchStream);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(s, tls.scratchUsed, 0);
+        if (e != hipSuccess) {
+            // (the caller may have destroyed that stream since: everything the device was given finishes first, then)
+            (void)hipGetLastError();
+            e = hipDeviceSynchronize();
+        }
         if (e != hipSuccess)
-            result = hipFailed(e, "hipStreamWaitEvent(scratch)");
+            result = hipFailed(e, "ordering the device scratch between streams");
     }
 }
 
 ScratchScope::~ScratchScope()
 {
-    if (tls.scratchUsed && hipEventRecord(tls.scratchUsed, stream) == hipSuccess) {
-        tls.scratchStream = stream;
-        tls.scratchPending = true;
-    } else {
-        (void)hipGetLastError();
-        (void)hipStreamSynchronize(stream); // could not mark the use: make sure nothing is pending instead
-        tls.scratchPending = false;
-    }
+    tls.scratchStream = stream;
+    tls.scratchPending = true;
+    tls.scratchMarked = false;
 }
 
 // Enqueues a copy of a small host table to device memory.  An asynchronous copy from pageable memory may still be reading
@@ -654,8 +670,14 @@ extern "C" void * avifhipStreamCreate(void)
 }
 extern "C" void avifhipStreamDestroy(void * hipStream)
 {
-    if (hipStream)
-        (void)hipStreamDestroy((hipStream_t)hipStream);
+    if (!hipStream)
+        return;
+    if (tls.scratchPending && tls.scratchStream == (hipStream_t)hipStream) {
+        // the stream that last used this thread's device scratch: a later call on another stream could no longer wait for it
+        (void)hipStreamSynchronize((hipStream_t)hipStream);
+        tls.scratchPending = false;
+    }
+    (void)hipStreamDestroy((hipStream_t)hipStream);
 }
 
 extern "C" avifResult avifhipSynchronize(void * hipStream)

@@ -144,6 +144,7 @@ struct Context
     hipEvent_t scratchUsed = nullptr;
     hipStream_t scratchStream = nullptr;
     bool scratchPending = false;
+    bool scratchMarked = false; // scratchUsed already covers the last use (recorded when the thread handed the context back)
     char lastError[512] = { 0 };
     const char * lastKernel = "";
     uint64_t launches = 0; // kernels enqueued by this thread
@@ -220,9 +221,9 @@ avifResult ensureContext();
 // The per-thread device scratch (descriptor tables, schedules, gain-map work buffers) is shared by every asynchronous entry point
 // that needs any, WHATEVER stream the caller passes: without ordering, a call on stream B could rewrite a table that a kernel
 // enqueued earlier on stream A is still reading.  An entry point that touches scratch opens a ScratchScope on its stream: the
-// constructor makes that stream wait for the scratch's previous user when that was a different stream, the destructor marks
-// everything enqueued on the stream so far as the new last user.  (Entry points that use no scratch -- single-image conversions --
-// pay nothing.)
+// constructor makes that stream wait for the scratch's previous user when that was a different stream (the event is recorded on the
+// previous user's stream at that moment), the destructor notes the stream as the new last user.  (Entry points that use no scratch --
+// single-image conversions -- pay nothing; calls that stay on one stream no event.)
 struct ScratchScope
 {
     hipStream_t stream;
