@@ -111,6 +111,15 @@ struct ContextLease
                 context->scratchPending = false;
             }
         }
+        for (int k = 0; k < Context::kTableRing; ++k) { // likewise the batch tables' slots (api_batch.cpp batchAsyncImpl)
+            if (!context->tableUnmarked[k] || !context->tableConsumed[k])
+                continue;
+            if (hipEventRecord(context->tableConsumed[k], context->tableLastStream[k]) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+            }
+            context->tableUnmarked[k] = false;
+        }
         ContextPool & pool = contextPool();
         std::lock_guard<std::mutex> lock(pool.mutex);
         pool.idle.push_back(context); // work still pending on its streams stays ordered: the next holder uses the same streams
@@ -676,6 +685,12 @@ extern "C" void avifhipStreamDestroy(void * hipStream)
         // the stream that last used this thread's device scratch: a later call on another stream could no longer wait for it
         (void)hipStreamSynchronize((hipStream_t)hipStream);
         tls.scratchPending = false;
+    }
+    for (int k = 0; k < Context::kTableRing; ++k) { // ... or off a resident batch table
+        if (tls.tableUnmarked[k] && tls.tableLastStream[k] == (hipStream_t)hipStream) {
+            (void)hipStreamSynchronize((hipStream_t)hipStream);
+            tls.tableUnmarked[k] = false;
+        }
     }
     (void)hipStreamDestroy((hipStream_t)hipStream);
 }

@@ -20,7 +20,7 @@ struct JobOverride
 // address comes back in *extraDevice, the ring slot in *slotOut -- the caller records tls.tableConsumed[slot] again after ITS kernels.
 static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects,
                                  const JobOverride * overrides, void * hipStream, const PixelMap * map = nullptr, const void * extra = nullptr, size_t extraBytes = 0,
-                                 const void ** extraDevice = nullptr, uint32_t * slotOut = nullptr)
+                                 const void ** extraDevice = nullptr, uint32_t * slotOut = nullptr, bool * residentOut = nullptr)
 {
     if (count == 0)
         return AVIF_RESULT_OK;
@@ -138,19 +138,37 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         *extraDevice = dev + extraOffset;
     // The table crosses the link on `upStream` while earlier batches compute on `stream`: the upload waits only for the kernels that read
     // this slot's device slice kRing batches ago (on whichever stream they ran), the batch's kernels wait for the upload.
-    if (!resident)
+    if (residentOut)
+        *residentOut = resident;
+    if (!resident) {
+        if (tls.tableUnmarked[slot]) { // its last readers ran off the resident copy and left no event (below): marked now
+            if (hipEventRecord(tls.tableConsumed[slot], tls.tableLastStream[slot]) != hipSuccess) {
+                (void)hipGetLastError();
+                HIP_TRY(hipDeviceSynchronize()); // (a stream the caller has destroyed since)
+            }
+            tls.tableUnmarked[slot] = false;
+        }
         HIP_TRY(hipStreamWaitEvent(tls.upStream, tls.tableConsumed[slot], 0));
+    }
+    // A batch that launches on the resident table records no event behind its kernels: the next kernel would wait for the event's signal
+    // (~5 us per call of a small grid), and the event is only needed once an upload wants the slot again -- it is recorded then, on the
+    // stream noted here, and covers everything that stream was given before.
     struct MarkConsumed
     {
         hipEvent_t ev;
         hipStream_t s;
-        bool armed;
+        bool armed, lazy;
+        uint32_t slot;
         ~MarkConsumed()
         {
-            if (armed)
+            if (!armed)
+                return;
+            if (lazy)
+                tls.tableUnmarked[slot] = true, tls.tableLastStream[slot] = s;
+            else
                 (void)hipEventRecord(ev, s);
         }
-    } markConsumed = { tls.tableConsumed[slot], stream, true };
+    } markConsumed = { tls.tableConsumed[slot], stream, true, resident, slot };
     auto upload = [&](void * to, const void * from, size_t n) -> hipError_t {
         if (resident)
             return hipSuccess;
@@ -299,17 +317,26 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
             ++jobs;
         }
     }
+    bool residentTable = false;
     avifResult r = batchAsyncImpl(jobs, viewPtrs.data(), rgbPtrs.data(), rects.data(), overrides.data(), hipStream, map, tiles.data(), tiles.size() * sizeof(GridTile),
-                                  &deviceTiles, &tableSlot);
+                                  &deviceTiles, &tableSlot, &residentTable);
     if (r != AVIF_RESULT_OK)
         return r;
     hipStream_t stream = pickStream(hipStream);
     struct SlotRead // the table's slot is free again after the last kernel that reads it: the seam kernel if there is one, the batch otherwise
-    {
+    {               // (a launch on the resident table: noted, not recorded -- batchAsyncImpl)
         hipEvent_t ev;
         hipStream_t s;
-        ~SlotRead() { (void)hipEventRecord(ev, s); }
-    } slotRead = { tls.tableConsumed[tableSlot], stream };
+        bool lazy;
+        uint32_t slot;
+        ~SlotRead()
+        {
+            if (lazy)
+                tls.tableUnmarked[slot] = true, tls.tableLastStream[slot] = s;
+            else
+                (void)hipEventRecord(ev, s);
+        }
+    } slotRead = { tls.tableConsumed[tableSlot], stream, residentTable, tableSlot };
     if (count == 1)
         return AVIF_RESULT_OK;
     // seams: only a filtering chroma upsampler looks across them

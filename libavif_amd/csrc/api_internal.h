@@ -129,6 +129,8 @@ struct Context
     uint32_t tableSlot = 0;
     hipEvent_t tableCopied[kTableRing] = {};   // the slot's upload has left the pinned memory (and the device slice holds it)
     hipEvent_t tableConsumed[kTableRing] = {}; // the kernels reading the slot's device slice are done
+    bool tableUnmarked[kTableRing] = {};        // the slot's last readers left no tableConsumed record (they ran off the resident copy) ...
+    hipStream_t tableLastStream[kTableRing] = {}; // ... on this stream: recorded when an upload wants the slot, or at the context's hand-back
     bool tableSlotIdle[kTableRing] = { true, true, true, true }; // no upload out of the slot's pinned memory since the thread last waited for tableCopied
     // the most recent upload, if small: a batch whose table is byte-identical launches on the copy the device still holds (batchAsyncImpl)
     static constexpr size_t kResidentTableMax = 256 * 1024;
