@@ -12,6 +12,13 @@ using namespace avifhip::api;
 
 namespace {
 
+// AVIFHIP_GAINMAP_KERNEL=general keeps calls off the fast apply kernel (tests run both kernels over the same cases)
+bool fastKernelDisabled()
+{
+    const char * e = getenv("AVIFHIP_GAINMAP_KERNEL");
+    return e && strcmp(e, "general") == 0;
+}
+
 void diagClear(avifDiagnostics * diag)
 {
     if (diag)
@@ -227,6 +234,23 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
             tables.resize(tables.size() + (S.guide.size() + 1) / 2, 0.0f); // the 16-bit guide entries ride in float slots
             memcpy(tables.data() + cache.guideOffset, S.guide.data(), S.guide.size() * sizeof(uint16_t));
             cache.maxCode = S.maxCode, cache.stepEntries = S.pieceEntries;
+            // the fast kernel's tables: the one-read locator (when the curve and depth have one) and the output alpha code of
+            // every base alpha code, (T)(0.5f + (a / max) * max') of avifGetRGBAPixel + avifSetRGBAPixel (src/reformat.c:1856-1937)
+            cache.locOffset = tables.size(), cache.locBuckets = (uint32_t)S.locator.size();
+            cache.locFirstBits = S.locFirstBits, cache.locShift = S.locShift;
+            tables.resize(tables.size() + S.locator.size(), 0.0f);
+            if (!S.locator.empty())
+                memcpy(tables.data() + cache.locOffset, S.locator.data(), S.locator.size() * sizeof(uint32_t));
+            cache.alphaOffset = tables.size();
+            if (!base->isFloat && !out->isFloat && base->depth <= 12) {
+                const uint32_t n = 1u << base->depth;
+                std::vector<uint16_t> alpha(n);
+                const float baseMaxF = (float)(n - 1), outMaxF = (float)((1u << key.outDepth) - 1);
+                for (uint32_t a = 0; a < n; ++a)
+                    alpha[a] = (uint16_t)((uint32_t)(int32_t)(0.5f + (((float)a / baseMaxF) * outMaxF)) & ((key.outDepth > 8) ? 0xffffu : 0xffu));
+                tables.resize(tables.size() + n / 2, 0.0f);
+                memcpy(tables.data() + cache.alphaOffset, alpha.data(), n * sizeof(uint16_t));
+            }
             // what the reference computes for a NaN input (the weight-0 path can meet one in a half-float base image)
             const float nanGamma = fminf(1.0f, fmaxf(0.0f, gainMapToGamma(outTC, NAN)));
             cache.nanCode = out->isFloat ? ((uint32_t)0) : (uint32_t)(0.5f + nanGamma * (float)((1u << key.outDepth) - 1));
@@ -256,24 +280,63 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
                      gainEntries = cache.stepsOffset - cache.gainLutOffset;
         if ((stepsEntries + baseEntries + gainEntries) * sizeof(float) + (kGainMapGuideBuckets + 2) * sizeof(uint16_t) <= 64 * 1024)
             A.ldsSteps = (uint32_t)stepsEntries, A.ldsBaseLut = (uint32_t)baseEntries, A.ldsGainLut = (uint32_t)gainEntries;
+        // the fast kernel: 4-channel integer pixels at naturally aligned addresses on both sides, a gain map, a locator, and
+        // tables that fit the LDS (kernels_gainmap.hip)
+        auto plain4 = [](const GainMapPixelLayout & L, const void * pixels, uint32_t pitch) {
+            return !L.isFloat && !L.is565 && L.hasAlpha && L.depth <= 12 && (L.pixelBytes == 4 || L.pixelBytes == 8) &&
+                   (((uintptr_t)pixels | pitch) & (L.pixelBytes - 1)) == 0;
+        };
+        A.locator = (const uint32_t *)(t + cache.locOffset), A.alphaLut = (const uint16_t *)(t + cache.alphaOffset);
+        A.locFirstBits = cache.locFirstBits, A.locShift = cache.locShift, A.locBuckets = cache.locBuckets;
+        A.fast = applyGain && cache.locBuckets && width >= 4 && plain4(A.baseL, A.base, A.basePitch) && plain4(A.outL, A.out, A.outPitch) && gainDepth <= 12 &&
+                 gainMapFastLdsBytes(A.baseL.pixelBytes, gainDepth, cache.locBuckets) <= kGainMapFastLdsBytes && !fastKernelDisabled();
+        if (A.fast) {
+            // selectors of the byte permutations between the pixels' layouts and R, G, B, A order (v_perm_b32: selector byte k names the
+            // source byte that lands in byte k of the result; 0-3 = second operand, 4-7 = first)
+            const uint32_t bo[4] = { A.baseL.offR, A.baseL.offG, A.baseL.offB, A.baseL.offA }, oo[4] = { A.outL.offR, A.outL.offG, A.outL.offB, A.outL.offA };
+            if (A.baseL.pixelBytes == 4) {
+                A.selBase[0] = bo[0] | (bo[1] << 8) | (bo[2] << 16) | (bo[3] << 24), A.selBase[1] = 0;
+            } else {
+                A.selBase[0] = bo[0] | ((bo[0] + 1) << 8) | (bo[1] << 16) | ((bo[1] + 1) << 24);
+                A.selBase[1] = bo[2] | ((bo[2] + 1) << 8) | (bo[3] << 16) | ((bo[3] + 1) << 24);
+            }
+            A.selOut[0] = A.selOut[1] = 0;
+            if (A.outL.pixelBytes == 4) {
+                const uint32_t from[4] = { 0, 1, 4, 5 }; // (c0 | c1 << 8) is the second operand, (c2 | alpha << 8) the first
+                for (int ch = 0; ch < 4; ++ch)
+                    A.selOut[0] |= from[ch] << (8 * oo[ch]);
+            } else {
+                for (int ch = 0; ch < 4; ++ch) // (c0 | c1 << 16) second operand, (c2 | alpha << 16) first: channel ch sits at bytes 2 ch, 2 ch + 1
+                    for (uint32_t b = 0; b < 2; ++b) {
+                        const uint32_t place = oo[ch] + b;
+                        A.selOut[place >> 2] |= (2 * (uint32_t)ch + b) << (8 * (place & 3));
+                    }
+            }
+        }
     }
 
-    const size_t partials = kGainMapMaxGroups;
-    const avifResult sr = reserve(tls.gainMap[3], 64 + partials * (sizeof(double) + sizeof(float)));
-    if (sr != AVIF_RESULT_OK)
-        return sr;
-    A.stats = (GainMapStats *)tls.gainMap[3].ptr;
-    A.blockSum = (double *)((uint8_t *)tls.gainMap[3].ptr + 64);
-    A.blockMax = (float *)(A.blockSum + partials);
-    HIP_TRY(hipMemsetAsync(A.stats, 0, sizeof(GainMapStats), stream));
-    const hipError_t e = launchGainMapApply(A, stream);
+    // statistics: every workgroup stores its partial into pinned host memory; added up here, in index order, once the stream has drained
+    if (!tls.gainMapPartials)
+        HIP_TRY(hipHostMalloc(&tls.gainMapPartials, (size_t)kGainMapMaxGroups * sizeof(GainMapPartial), hipHostMallocDefault));
+    A.partials = (GainMapPartial *)tls.gainMapPartials;
+    uint32_t partials = 0;
+    const hipError_t e = launchGainMapApply(A, stream, &partials);
     if (e != hipSuccess)
         return hipFailed(e, "gain map kernel launch");
-    tls.lastKernel = applyGain ? "gainmap_apply" : (A.convert ? "gainmap_convert" : "gainmap_requantise");
+    tls.lastKernel = applyGain ? (A.fast ? "gainmap_apply_fast" : "gainmap_apply") : (A.convert ? "gainmap_convert" : "gainmap_requantise");
     ++tls.launches;
-    GainMapStats stats;
-    HIP_TRY(hipMemcpyAsync(&stats, A.stats, sizeof(stats), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    GainMapStats stats = { 0, 0, 0.0 };
+    {
+        float rgbMax = 0.0f;
+        for (uint32_t k = 0; k < partials; ++k) {
+            const GainMapPartial & part = A.partials[k];
+            rgbMax = (part.max > rgbMax) ? part.max : rgbMax;
+            stats.sum += part.sum;
+            stats.nan |= (int32_t)part.nan;
+        }
+        memcpy(&stats.maxBits, &rgbMax, 4);
+    }
     if (applyGain && stats.nan) {
         diagPrintf(diag, "Degenerate gain map parameters produce NaN");
         return AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE;

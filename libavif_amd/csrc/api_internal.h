@@ -55,8 +55,9 @@ struct GainMapTableCache
         float gammaInv[3], minLog2[3], maxLog2[3], weight;
         uint64_t stream;
     } key;
-    size_t baseLutOffset = 0, gainLutOffset = 0, stepsOffset = 0, guideOffset = 0; // in floats
+    size_t baseLutOffset = 0, gainLutOffset = 0, stepsOffset = 0, guideOffset = 0, locOffset = 0, alphaOffset = 0; // in floats
     uint32_t maxCode = 0, nanCode = 0, stepEntries = 0;
+    uint32_t locBuckets = 0, locFirstBits = 0, locShift = 0; // GainMapSteps::locator (0 buckets: none for this curve / depth)
 };
 
 // Copies between pageable host memory and the device run at full PCIe rate on this platform, but "asynchronous" ones block the
@@ -121,6 +122,7 @@ struct Context
     Scratch gainMap[11]; // gain maps: [0] output pixels, [1] gain map as RGB, [2] tables, [3] statistics / partials, [4] scaled planes, [5] base pixels;
                          // computation: [6] tables, [7] ratios, [8] histograms, [9] alternate pixels, [10] gain-map planes
     GainMapTableCache gainMapCache; // what gainMap[2] holds
+    void * gainMapPartials = nullptr; // apply: the statistics as the workgroups leave them (pinned host memory, kGainMapMaxGroups partials)
     // batch descriptor tables travel through a ring of kTableRing slots (pinned host memory + the matching slice of `table`), uploaded on
     // `upStream`: the host prepares batch n + 1 and its table crosses the link while batch n computes (api_batch.cpp: batchAsyncImpl)
     static constexpr int kTableRing = 4;
@@ -172,6 +174,8 @@ struct Context
         for (Scratch & g : gainMap)
             if (g.ptr)
                 (void)hipFree(g.ptr);
+        if (gainMapPartials)
+            (void)hipHostFree(gainMapPartials);
         if (pinnedTable)
             (void)hipHostFree(pinnedTable);
         for (int k = 0; k < kTableRing; ++k) {

@@ -312,6 +312,62 @@ inline uint32_t keyOfFloat(float f)
     return (bits & 0x80000000u) ? ~bits : (bits ^ 0x80000000u);
 }
 
+inline uint32_t bitsOf(float f)
+{
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    return b;
+}
+
+// GainMapSteps::locator (gainmap_plan.h) from the finished step tables; leaves it empty when the curve does not qualify
+void buildLocator(GainMapSteps & S, bool isFloat)
+{
+    if (isFloat || S.maxCode > 4095 || S.maxCode < 1)
+        return;
+    const uint32_t n = S.pieceEntries;
+    const float * Tn = S.steps.data();
+    const float * T = S.steps.data() + n;
+    if (Tn[1] != INFINITY || !(T[1] > 0.0f) || T[1] == INFINITY || bitsOf(T[1]) < 2)
+        return; // a negative x reaches a code above 0, or +0 does
+    uint32_t K = 1;
+    while (K < S.maxCode && T[K + 1] != INFINITY)
+        ++K;
+    for (uint32_t k = 1; k < K; ++k)
+        if (!(T[k] < T[k + 1]))
+            return;
+    for (uint32_t shift = 19; shift >= 6; --shift) {
+        const uint32_t mask = (1u << shift) - 1, first = (bitsOf(T[1]) - 1) & ~mask;
+        bool distinct = true;
+        for (uint32_t k = 1; k < K && distinct; ++k)
+            distinct = ((bitsOf(T[k]) - first) >> shift) != ((bitsOf(T[k + 1]) - first) >> shift);
+        if (!distinct)
+            continue;
+        const uint32_t buckets = ((bitsOf(T[K]) - first) >> shift) + 2;
+        if (buckets > kGainMapLocatorMaxBuckets)
+            return; // finer buckets only grow the table
+        const uint32_t none = mask << (32 - shift);
+        std::vector<uint32_t> loc(buckets);
+        uint32_t k = 0; // the code at the start of the bucket
+        for (uint32_t b = 0; b < buckets; ++b) {
+            const uint32_t start = first + (b << shift);
+            while (k < K && bitsOf(T[k + 1]) <= start)
+                ++k;
+            uint32_t e = none | k;
+            if (k < K && ((bitsOf(T[k + 1]) - first) >> shift) == b)
+                e = ((bitsOf(T[k + 1]) - start - 1) << (32 - shift)) | k; // its offset is >= 1: a step AT the start is in k already
+            loc[b] = e;
+        }
+        S.locator = std::move(loc), S.locFirstBits = first, S.locShift = shift, S.locBuckets = buckets;
+        // the locator must say what the steps say at, and just below, every step and at the ends of the piece
+        bool ok = gainMapLocate(S, 0.0f) == 0 && gainMapLocate(S, -0.0f) == 0 && gainMapLocate(S, INFINITY) == K && gainMapLocate(S, -1.0f) == 0;
+        for (uint32_t c = 1; c <= K && ok; ++c)
+            ok = gainMapLocate(S, T[c]) == c && gainMapLocate(S, nextafterf(T[c], -INFINITY)) == c - 1;
+        if (!ok)
+            S.locator.clear();
+        return;
+    }
+}
+
 } // namespace
 
 std::vector<float> gainMapLinearLut(int tc, uint32_t depth, bool isFloat)
@@ -399,7 +455,18 @@ const GainMapSteps & gainMapOutputSteps(int tc, uint32_t depth, bool isFloat)
             S.guide[b] = (uint16_t)k;
         }
     }
+    buildLocator(S, isFloat);
     return cache.emplace(key, std::move(S)).first->second;
+}
+
+uint32_t gainMapLocate(const GainMapSteps & S, float x)
+{
+    uint32_t bits;
+    memcpy(&bits, &x, 4);
+    const int32_t b = (int32_t)bits, lo = (int32_t)S.locFirstBits, hi = lo + (int32_t)((S.locBuckets << S.locShift) - 1);
+    const uint32_t tc = (uint32_t)(((b < lo) ? lo : ((b > hi) ? hi : b)) - lo); // as signed integers: negative x sorts below every x >= 0
+    const uint32_t e = S.locator[tc >> S.locShift];
+    return (e & 0xfffu) + (((tc << (32 - S.locShift)) > e) ? 1u : 0u);
 }
 
 } // namespace avifhip

@@ -46,7 +46,19 @@ struct GainMapSteps
     // runs of 2^kGainMapGuideShift consecutive fp32 bit patterns from 2^kGainMapGuideMinExp up (64 per octave); the code of an x
     // in bucket b lies in [guide[b], guide[b + 1]].  kGainMapGuideBuckets + 1 entries.
     std::vector<uint16_t> guide;
+    // One-read locator over the x >= 0 piece (integer outputs up to 12 bits whose x < 0 piece is all code 0 -- every curve but
+    // BT.1361 / IEC 61966-2-4): buckets of 2^locShift consecutive fp32 bit patterns from locFirstBits up, narrow enough that
+    // no bucket holds two steps.  With t = clamp((int)bits(x), (int)locFirstBits, (int)locFirstBits + (locBuckets << locShift) - 1) - locFirstBits and
+    // e = locator[t >> locShift], the code of x is (e & 0xfff) + ((t << (32 - locShift)) > e): the low 12 bits of e are the code
+    // at the start of the bucket, the high locShift bits the offset of the bucket's step minus one (all ones: no step).
+    // Negative x (sign bit: a negative integer) and x below the first step clamp into bucket 0 ahead of its step: code 0; x past the last
+    // step, +inf and NaN clamp into the last bucket, which holds no step.  Empty when the curve / depth does not qualify.
+    std::vector<uint32_t> locator;
+    uint32_t locFirstBits = 0, locShift = 0, locBuckets = 0;
 };
+constexpr uint32_t kGainMapLocatorMaxBuckets = 12288; // 48 KB of LDS
+// the code the locator gives for x (what the fast kernel computes); S.locator must not be empty
+uint32_t gainMapLocate(const GainMapSteps & S, float x);
 constexpr int kGainMapGuideShift = 17, kGainMapGuideMinExp = -24, kGainMapGuideOctaves = 40;
 constexpr uint32_t kGainMapGuideBuckets = (uint32_t)kGainMapGuideOctaves << (23 - kGainMapGuideShift);
 constexpr uint32_t kGainMapGuideFirstBits = (uint32_t)(127 + kGainMapGuideMinExp) << 23;

@@ -161,6 +161,12 @@ struct GainMapStats
     int32_t nan;      // a tone-mapped value was NaN, :277-281
     double sum;       // sum over pixels of max(0, r, g, b): rgbSumLinear, :287
 };
+struct GainMapPartial // one workgroup's share of the statistics
+{
+    double sum;
+    float max;
+    uint32_t nan;
+};
 struct GainMapArgs
 {
     const uint8_t * base;
@@ -176,16 +182,27 @@ struct GainMapArgs
     uint32_t guideFirstBits, guideShift, guideBuckets;
     uint32_t maxCode, nanCode, stepEntries; // stepEntries: entries per piece of `steps`, a power of two
     uint32_t ldsSteps, ldsBaseLut, ldsGainLut; // entries of the tables when the kernel is to keep ALL of them (and the guide) in LDS, else all 0
+    // the fast kernel (4-channel integer pixels on both sides, a gain map, tables that fit the LDS): the output code through
+    // GainMapSteps::locator with one table read, alpha through a table of output alpha codes per base alpha code
+    const uint32_t * locator;
+    const uint16_t * alphaLut; // 1 << baseL.depth entries
+    uint32_t locFirstBits, locShift, locBuckets;
+    uint32_t selBase[2], selOut[2]; // v_perm_b32 selectors: base pixel -> R, G, B, A order; codes in that order -> output pixel
+    int32_t fast;
     int32_t convert;        // linearise, (convert primaries, apply the gain,) re-encode; 0: requantise the samples as they are
     int32_t inConv, outConv;
     double inM[9], outM[9]; // avifLinearRGBConvertColorSpace coefficients, row-major
     float baseOffset[3], altOffset[3];
-    GainMapStats * stats;
-    float * blockMax;   // one partial per workgroup (kGainMapMaxGroups entries each)
-    double * blockSum;
+    // statistics: one partial per workgroup, in pinned host memory (kGainMapMaxGroups entries); the caller adds them up in index order
+    GainMapPartial * partials;
 };
 constexpr uint32_t kGainMapMaxGroups = 4096; // persistent workgroups of the apply kernel
-hipError_t launchGainMapApply(const GainMapArgs & args, hipStream_t stream);
+// LDS the fast kernel may fill with tables (two workgroups per CU keep eight waves resident)
+constexpr size_t kGainMapFastLdsBytes = 64 * 1024;
+// what the fast kernel needs for 4- / 8-byte base pixels, a gain map of that depth and a locator of that many buckets
+size_t gainMapFastLdsBytes(uint32_t basePixelBytes, uint32_t gainDepth, uint32_t locBuckets);
+// *partials: how many entries of args.partials the launch fills (0: no statistics)
+hipError_t launchGainMapApply(const GainMapArgs & args, hipStream_t stream, uint32_t * partials);
 
 // Gain-map computation (avifRGBImageComputeGainMap, reference src/gainmap.c:535-843): three passes over the pixels.
 struct GainMapComputeArgs

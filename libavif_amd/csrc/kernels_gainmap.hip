@@ -7,6 +7,8 @@
 
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace avifhip {
 
 namespace {
@@ -144,6 +146,35 @@ __device__ __forceinline__ void codesOf(const float x[3], const StepSearch & S, 
         code[c] = (x[c] != x[c]) ? S.nanCode : lo[c];
 }
 
+// Statistics of a launch (rgbMaxLinear, rgbSumLinear, "a NaN appeared": src/gainmap.c:257-287) from every lane's own: wave reduction
+// -> workgroup reduction through LDS -> one partial per workgroup, stored straight into pinned host memory; the caller adds them up in
+// index order once the stream has drained.  (One atomic per wave on a single address cost 3 ms on a 4K image; a ticket counter --
+// one atomic per workgroup -- so that the last workgroup could do the sum, 78 us of a 110 us kernel: atomics on one address are
+// serialised across the eight L2s.)  WAVES: waves per workgroup (64 x WAVES threads).
+template <int WAVES>
+__device__ __forceinline__ void finishStatistics(const GainMapArgs & A, float toneMax, double sum, unsigned long long nanLanes, uint8_t * scratch)
+{
+    // `scratch`: 16 * WAVES bytes of LDS, 8-byte aligned, that no lane of the workgroup still reads as something else
+    double * const waveSums = reinterpret_cast<double *>(scratch);
+    float * const waveMaxima = reinterpret_cast<float *>(waveSums + WAVES);
+    uint32_t * const waveNan = reinterpret_cast<uint32_t *>(waveMaxima + WAVES);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        toneMax = fmaxf(toneMax, __shfl_xor(toneMax, m));
+        sum += __shfl_xor(sum, m);
+    }
+    if (threadIdx.x == 0)
+        waveMaxima[threadIdx.y] = toneMax, waveSums[threadIdx.y] = sum, waveNan[threadIdx.y] = nanLanes ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        GainMapPartial mine = { waveSums[0], waveMaxima[0], waveNan[0] };
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w)
+            mine.sum += waveSums[w], mine.max = fmaxf(mine.max, waveMaxima[w]), mine.nan |= waveNan[w];
+        A.partials[blockIdx.x] = mine;
+    }
+}
+
 // Persistent workgroups walking tiles of 64 x 4 pixels with a grid stride.  LDS_TABLES: the three tables (steps, base lookup,
 // gain lookup) are copied to LDS once per workgroup and addressed as LDS -- a pointer that may be either LDS or global memory
 // compiles to flat loads, which the searches cannot afford; the host picks this variant when everything fits (api_gainmap.cpp).
@@ -230,52 +261,164 @@ __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_
         writePixel(A.out + (size_t)j * A.outPitch + (size_t)i * A.outL.pixelBytes, A.outL, outVector, outCode, A.outL.hasAlpha ? quantise(alpha, A.outL) : 0);
     }
     if (A.gain) {
-        // statistics: wave reduction -> block reduction through LDS -> one partial per workgroup (no atomics: one atomic per
-        // wave on a single address cost 3 ms on a 4K image), summed by gainMapReduceKernel in a fixed order
-        __shared__ float waveMaxima[4];
-        __shared__ double waveSums[4];
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            toneMax = fmaxf(toneMax, __shfl_xor(toneMax, m));
-            sum += __shfl_xor(sum, m);
-        }
-        const unsigned long long nanLanes = __ballot(sawNan);
-        if (threadIdx.x == 0) {
-            waveMaxima[threadIdx.y] = toneMax, waveSums[threadIdx.y] = sum;
-            if (nanLanes)
-                atomicOr(&A.stats->nan, 1);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0 && threadIdx.y == 0) {
-            A.blockMax[blockIdx.x] = fmaxf(fmaxf(waveMaxima[0], waveMaxima[1]), fmaxf(waveMaxima[2], waveMaxima[3]));
-            A.blockSum[blockIdx.x] = ((waveSums[0] + waveSums[1]) + waveSums[2]) + waveSums[3];
-        }
+        __shared__ __attribute__((aligned(8))) uint8_t statistics[16 * 4];
+        finishStatistics<4>(A, toneMax, sum, __ballot(sawNan), statistics);
     }
 }
 
-__global__ __launch_bounds__(1024) void gainMapReduceKernel(GainMapStats * stats, const float * blockMax, const double * blockSum, uint32_t blocks)
+// ---- the fast kernel ---------------------------------------------------------------------------------------------------
+// 4-channel integer pixels on both sides (4 or 8 bytes each), a gain map, all tables in LDS at fixed places (host: api_gainmap.cpp
+// decides).  Four neighbouring pixels per lane: 16- / 32-byte accesses.  Per pixel: one byte permutation brings the base pixel into R, G, B, A
+// order whatever its layout (v_perm_b32 with a wave-uniform selector), three reads of the base table, three of the gain table, ONE read
+// of the locator per channel for the output code (gainmap_plan.h: GainMapSteps::locator -- no search), one of the alpha table, one
+// or two permutations into the output layout; in between the reference's fp32 / fp64 arithmetic in its order.  A NaN makes the whole call
+// fail (AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE, src/gainmap.c:277-281: the reference stops at that pixel), so its code does not matter.
+// Sample codes above the image's depth (garbage in a 16-bit container) read whatever lies at that place of the LDS.
+
+// LDS layout, in bytes.  With 4-byte pixels (8-bit samples) every table base is a compile-time constant of the instantiation (it rides in
+// the offset field of the ds_read); 16-bit base samples get room for 12 bits; gain-map tables of more than 8 bits follow the locator, at
+// a place and with a stride the launch knows (one more instruction per read).
+template <int BASE_BYTES, int GAIN_BYTES>
+struct FastLds
 {
-    __shared__ float maxima[1024];
-    __shared__ double sums[1024];
-    float m = 0.0f;
-    double s = 0.0;
-    for (uint32_t k = threadIdx.x; k < blocks; k += 1024) {
-        m = fmaxf(m, blockMax[k]);
-        s += blockSum[k];
-    }
-    maxima[threadIdx.x] = m, sums[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t half = 512; half > 0; half >>= 1) {
-        if (threadIdx.x < half) {
-            maxima[threadIdx.x] = fmaxf(maxima[threadIdx.x], maxima[threadIdx.x + half]);
-            sums[threadIdx.x] += sums[threadIdx.x + half];
-        }
+    static constexpr uint32_t kBaseEntries = (BASE_BYTES == 4) ? 256 : 4096;
+    static constexpr uint32_t kBaseLut = 0, kAlphaLut = kBaseLut + 4 * kBaseEntries, kGainLut = kAlphaLut + 2 * kBaseEntries,
+                              kLocator = kGainLut + ((GAIN_BYTES == 4) ? 3 * 4 * 256 : 0);
+};
+
+// kFastPixels neighbouring pixels of BYTES each (4-byte alignment is all the wide accesses need)
+constexpr int kFastPixels = 4; // per lane
+constexpr int kFastRows = 8;   // = waves per workgroup: 256 x 8 pixels per workgroup and step
+template <int BYTES>
+struct __attribute__((packed, aligned(4))) PixelRun
+{
+    uint32_t w[kFastPixels * BYTES / 4];
+};
+
+struct Locator
+{
+    int32_t first, lastRel; // the bit pattern the first bucket starts at; the last bucket's end relative to it
+    uint32_t shift;
+};
+template <uint32_t LOC_BASE>
+__device__ __forceinline__ uint32_t locate(float x, const Locator & L)
+{
+    // as signed integers the bit patterns of negative values sort below every x >= 0; the subtraction saturates instead of wrapping
+    const int32_t rel = __builtin_elementwise_sub_sat((int32_t)__float_as_uint(x), L.first);
+    uint32_t t;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(rel), "s"(L.lastRel));
+    const uint32_t e = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(LOC_BASE + ((t >> L.shift) << 2));
+    return (e & 0xfffu) + (((t << (32 - L.shift)) > e) ? 1u : 0u);
+}
+
+// CONV: bit 0 -- the base image's primaries differ from the gain-map math's (inM), bit 1 -- the output's do (outM)
+template <int BASE_BYTES, int OUT_BYTES, int GAIN_BYTES, int CONV>
+__global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMapArgs A, uint32_t tilesX, uint32_t tiles, uint32_t stepX, uint32_t stepY)
+{
+    using Lds = FastLds<BASE_BYTES, GAIN_BYTES>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    {
+        const uint32_t nBase = 1u << A.baseL.depth, nGain = 1u << A.gainDepth;
+        const uint32_t t = threadIdx.y * 64 + threadIdx.x;
+        for (uint32_t k = t; k < nBase; k += 64 * kFastRows)
+            reinterpret_cast<float *>(lds + Lds::kBaseLut)[k] = A.baseLut[k];
+        for (uint32_t k = t; k < nBase / 2; k += 64 * kFastRows) // two 16-bit entries per move
+            reinterpret_cast<uint32_t *>(lds + Lds::kAlphaLut)[k] = reinterpret_cast<const uint32_t *>(A.alphaLut)[k];
+        for (uint32_t k = t; k < 3 * nGain; k += 64 * kFastRows) // the three channels' tables one after the other
+            reinterpret_cast<float *>(lds + ((GAIN_BYTES == 4) ? Lds::kGainLut : Lds::kLocator + 4 * A.locBuckets))[k] = A.gainLut[k];
+        for (uint32_t k = t; k < A.locBuckets; k += 64 * kFastRows)
+            reinterpret_cast<uint32_t *>(lds + Lds::kLocator)[k] = A.locator[k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        stats->maxBits = __float_as_uint(maxima[0]);
-        stats->sum = sums[0];
+    const uint32_t gainR = (GAIN_BYTES == 4) ? Lds::kGainLut : Lds::kLocator + 4 * A.locBuckets;
+    const uint32_t gainG = gainR + ((GAIN_BYTES == 4) ? 1024 : (4u << A.gainDepth)), gainB = gainG + ((GAIN_BYTES == 4) ? 1024 : (4u << A.gainDepth));
+    const Locator L = { (int32_t)A.locFirstBits, (int32_t)((A.locBuckets << A.locShift) - 1), A.locShift };
+    const uint32_t selBaseX = A.selBase[0], selBaseY = A.selBase[1], selOutX = A.selOut[0], selOutY = A.selOut[1];
+    const float bo0 = A.baseOffset[0], bo1 = A.baseOffset[1], bo2 = A.baseOffset[2];
+    const float ao0 = A.altOffset[0], ao1 = A.altOffset[1], ao2 = A.altOffset[2];
+    // the dynamic LDS starts at address 0 (the kernel declares no other): tables are read at integer addresses, table base in the
+    // instruction's offset field
+    typedef __attribute__((address_space(3))) const float * LdsFloat;
+    typedef __attribute__((address_space(3))) const uint16_t * LdsU16;
+    auto lutF = [&](uint32_t byteOffset) -> float { return *(LdsFloat)(uintptr_t)byteOffset; };
+
+    float toneMax = 0.0f;
+    double sum = 0.0;
+    unsigned long long nanLanes = 0; // of this wave
+    // Workgroups walk tiles of 256 x 8 pixels (four neighbouring pixels per lane, a row per wave) with a grid stride; a lane whose run would cross the end of the row
+    // moves it left to end there: the pixels it shares with its neighbour are computed (and stored, same bytes) twice but counted once.
+    // The next tile's pixels are requested before the current ones are worked on: one tile's loads per wave do not cover the memory latency.
+    uint32_t tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
+    PixelRun<BASE_BYTES> bp, bpNext;
+    PixelRun<GAIN_BYTES> gp, gpNext;
+    uint32_t i = 0, i0 = 0, j = 0, iNext = 0, i0Next = 0, jNext = 0;
+    bool live = false, liveNext = false;
+    auto request = [&](uint32_t tile) {
+        liveNext = false;
+        if (tile >= tiles)
+            return;
+        iNext = tx * (64 * kFastPixels) + threadIdx.x * kFastPixels, jNext = ty * kFastRows + threadIdx.y;
+        tx += stepX, ty += stepY;
+        if (tx >= tilesX)
+            tx -= tilesX, ++ty;
+        liveNext = iNext < A.width && jNext < A.height;
+        if (liveNext) {
+            i0Next = min(iNext, A.width - kFastPixels);
+            bpNext = *reinterpret_cast<const PixelRun<BASE_BYTES> *>(A.base + (size_t)jNext * A.basePitch + (size_t)i0Next * BASE_BYTES);
+            gpNext = *reinterpret_cast<const PixelRun<GAIN_BYTES> *>(A.gain + (size_t)jNext * A.gainPitch + (size_t)i0Next * GAIN_BYTES);
+        }
+    };
+    request(blockIdx.x);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        bp = bpNext, gp = gpNext, i = iNext, i0 = i0Next, j = jNext, live = liveNext;
+        request(tile + gridDim.x);
+        if (!live)
+            continue;
+        PixelRun<OUT_BYTES> op;
+#pragma unroll
+        for (int p = 0; p < kFastPixels; ++p) {
+            // byte offsets into the tables: sample code x entry size
+            uint32_t r4, g4, b4, a2, gr4, gg4, gb4;
+            if constexpr (BASE_BYTES == 4) {
+                const uint32_t w = __builtin_amdgcn_perm(bp.w[p], bp.w[p], selBaseX); // R, G, B, A from byte 0 up
+                r4 = (w & 0xff) << 2, g4 = ((w >> 8) & 0xff) << 2, b4 = ((w >> 16) & 0xff) << 2, a2 = (w >> 24) << 1;
+            } else {
+                const uint32_t x = __builtin_amdgcn_perm(bp.w[2 * p + 1], bp.w[2 * p], selBaseX), y = __builtin_amdgcn_perm(bp.w[2 * p + 1], bp.w[2 * p], selBaseY);
+                r4 = (x & 0xffff) << 2, g4 = (x >> 16) << 2, b4 = (y & 0xffff) << 2, a2 = (y >> 16) << 1;
+            }
+            if constexpr (GAIN_BYTES == 4) { // the gain map is RGBA (avifRGBImageSetDefaults)
+                const uint32_t w = gp.w[p];
+                gr4 = (w & 0xff) << 2, gg4 = ((w >> 8) & 0xff) << 2, gb4 = ((w >> 16) & 0xff) << 2;
+            } else {
+                const uint32_t x = gp.w[2 * p], y = gp.w[2 * p + 1];
+                gr4 = (x & 0xffff) << 2, gg4 = (x >> 16) << 2, gb4 = (y & 0xffff) << 2;
+            }
+            float v[3] = { lutF(Lds::kBaseLut + r4), lutF(Lds::kBaseLut + g4), lutF(Lds::kBaseLut + b4) };
+            const uint32_t alphaCode = *(LdsU16)(uintptr_t)(Lds::kAlphaLut + a2);
+            if constexpr (CONV & 1)
+                convertPrimaries(v, A.inM);
+            // :236-270
+            v[0] = (v[0] + bo0) * lutF(gainR + gr4) - ao0;
+            v[1] = (v[1] + bo1) * lutF(gainG + gg4) - ao1;
+            v[2] = (v[2] + bo2) * lutF(gainB + gb4) - ao2;
+            const float pixelMax = fmaxf(fmaxf(fmaxf(0.0f, v[0]), v[1]), v[2]); // a NaN leaves the maximum as it is, like the reference's comparisons
+            toneMax = fmaxf(toneMax, pixelMax);
+            sum += (double)((i0 + p >= i) ? pixelMax : 0.0f);
+            if constexpr (CONV & 2)
+                convertPrimaries(v, A.outM);
+            nanLanes |= __builtin_amdgcn_fcmpf(v[0], v[1], 8) | __builtin_amdgcn_fcmpf(v[2], v[2], 8); // "unordered": one of the two is a NaN
+            const uint32_t c0 = locate<Lds::kLocator>(v[0], L), c1 = locate<Lds::kLocator>(v[1], L), c2 = locate<Lds::kLocator>(v[2], L);
+            if constexpr (OUT_BYTES == 4) {
+                op.w[p] = __builtin_amdgcn_perm(c2 | (alphaCode << 8), c0 | (c1 << 8), selOutX);
+            } else {
+                const uint32_t rg = c0 | (c1 << 16), ba = c2 | (alphaCode << 16);
+                op.w[2 * p] = __builtin_amdgcn_perm(ba, rg, selOutX), op.w[2 * p + 1] = __builtin_amdgcn_perm(ba, rg, selOutY);
+            }
+        }
+        *reinterpret_cast<PixelRun<OUT_BYTES> *>(A.out + (size_t)j * A.outPitch + (size_t)i0 * OUT_BYTES) = op;
     }
+    __syncthreads(); // the tables are done with: their place serves the reduction
+    finishStatistics<kFastRows>(A, toneMax, sum, nanLanes, lds);
 }
 
 // ---- gain-map computation -----------------------------------------------------------------------------------------
@@ -447,19 +590,62 @@ __global__ __launch_bounds__(256) void gainMapQuantiseKernel(const float * ratio
 
 } // namespace
 
-hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream)
+size_t gainMapFastLdsBytes(uint32_t basePixelBytes, uint32_t gainDepth, uint32_t locBuckets)
 {
+    const size_t fixed = (basePixelBytes == 4) ? FastLds<4, 8>::kLocator : FastLds<8, 8>::kLocator; // base and alpha tables
+    return fixed + ((size_t)12 << gainDepth) + (size_t)locBuckets * 4;
+}
+
+hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_t * partials)
+{
+    *partials = 0;
     if (!A.width || !A.height)
         return hipSuccess;
+    if (A.fast) {
+        // 256 x 8 pixels per workgroup and step; up to four workgroups (32 waves) per CU when the tables leave room; every workgroup the
+        // same number of steps when the tiles divide that way
+        const uint32_t tilesX = (A.width + 64 * kFastPixels - 1) / (64 * kFastPixels), tiles = tilesX * ((A.height + kFastRows - 1) / kFastRows);
+        const size_t lds = gainMapFastLdsBytes(A.baseL.pixelBytes, A.gainDepth, A.locBuckets);
+        const uint32_t perCu = (uint32_t)((160 * 1024) / (lds + 512));
+        const uint32_t resident = 256 * (perCu < 1 ? 1 : (perCu > 4 ? 4 : perCu));
+        const uint32_t steps = (tiles + resident - 1) / resident;
+        const uint32_t groups = (tiles + steps - 1) / steps;
+        const uint32_t stepX = groups % tilesX, stepY = groups / tilesX;
+        const int conv = (A.inConv ? 1 : 0) | (A.outConv ? 2 : 0);
+        auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(groups), dim3(64, kFastRows), lds, stream, A, tilesX, tiles, stepX, stepY); };
+        auto byConv = [&](auto b, auto o, auto g) {
+            constexpr int B = decltype(b)::value, O = decltype(o)::value, G = decltype(g)::value;
+            switch (conv) {
+                case 0: launch(gainMapApplyFastKernel<B, O, G, 0>); break;
+                case 1: launch(gainMapApplyFastKernel<B, O, G, 1>); break;
+                case 2: launch(gainMapApplyFastKernel<B, O, G, 2>); break;
+                default: launch(gainMapApplyFastKernel<B, O, G, 3>); break;
+            }
+        };
+        using I4 = std::integral_constant<int, 4>;
+        using I8 = std::integral_constant<int, 8>;
+        const int key = (A.baseL.pixelBytes == 8 ? 4 : 0) | (A.outL.pixelBytes == 8 ? 2 : 0) | (A.gainDepth > 8 ? 1 : 0);
+        switch (key) {
+            case 0: byConv(I4{}, I4{}, I4{}); break;
+            case 1: byConv(I4{}, I4{}, I8{}); break;
+            case 2: byConv(I4{}, I8{}, I4{}); break;
+            case 3: byConv(I4{}, I8{}, I8{}); break;
+            case 4: byConv(I8{}, I4{}, I4{}); break;
+            case 5: byConv(I8{}, I4{}, I8{}); break;
+            case 6: byConv(I8{}, I8{}, I4{}); break;
+            default: byConv(I8{}, I8{}, I8{}); break;
+        }
+        *partials = groups;
+        return hipGetLastError();
+    }
     const uint32_t tilesX = (A.width + 63) / 64, tiles = tilesX * ((A.height + 3) / 4);
     const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
+    *partials = A.gain ? groups : 0;
     const size_t lds = A.ldsSteps ? (size_t)(A.ldsSteps + A.ldsBaseLut + A.ldsGainLut) * sizeof(float) + ((size_t)A.guideBuckets + 2) * sizeof(uint16_t) : 0;
     if (lds)
         hipLaunchKernelGGL(gainMapApplyKernel<true>, dim3(groups), dim3(64, 4), lds, stream, A, tilesX, tiles);
     else
         hipLaunchKernelGGL(gainMapApplyKernel<false>, dim3(groups), dim3(64, 4), 0, stream, A, tilesX, tiles);
-    if (A.gain)
-        hipLaunchKernelGGL(gainMapReduceKernel, dim3(1), dim3(1024), 0, stream, A.stats, A.blockMax, A.blockSum, groups);
     return hipGetLastError();
 }
 

@@ -185,6 +185,54 @@ def test_gpu_equals_oracle_fp32_arithmetic(hip):
     _compare_gpu(hip, G.cases(120, seed=3), libyuv_build=False)
 
 
+def _fast_kernel_cases():
+    """What the fast apply kernel serves (4-channel integer pixels up to 12 bits on both sides, a gain map, a curve with a locator): every
+    channel order on both sides, every pixel-size combination, each of the four primaries-conversion variants, 8- / 10- / 12-bit gain maps (12 bits: with 8-bit images on both sides, whose tables leave the room), rows
+    that end inside a lane's run of four pixels, rows shorter than a tile, one-row images."""
+    four = [abi.AVIF_RGB_FORMAT_RGBA, abi.AVIF_RGB_FORMAT_ARGB, abi.AVIF_RGB_FORMAT_BGRA, abi.AVIF_RGB_FORMAT_ABGR]
+    out = []
+    k = 0
+    for bf in four:
+        for of in four:
+            bd, od = ((8, 8), (8, 10), (10, 8), (12, 12), (10, 10), (8, 12))[k % 6]
+            w, h = ((37, 21), (64, 9), (261, 5), (4, 3), (5, 1), (7, 2), (515, 17), (258, 8))[k % 8]
+            out.append(G.GainMapCase(w, h, base_format=bf, out_format=of, base_depth=bd, out_depth=od, out_tc=9 if od == 12 else (13, 16, 18, 1, 8)[k % 5],
+                                     base_primaries=(1, 1, 9, 12)[k % 4], out_primaries=(1, 9, 9, 1)[k % 4], use_base_color_space=bool(k % 3),
+                                     alt_primaries=9, gm_depth=(8, 8, 10, 12 if (bd, od) == (8, 8) else 10)[(k // 2) % 4], seed=900 + k))
+            k += 1
+    out.append(G.GainMapCase(1001, 67, base_depth=8, out_depth=10, out_tc=16, out_primaries=9, seed=77))  # many tiles per workgroup
+    out.append(G.GainMapCase(640, 360, base_depth=10, out_depth=10, base_tc=16, out_tc=13, base_primaries=9, out_primaries=1, headroom=1.0,
+                             base_headroom=(4, 1), alt_headroom=(0, 1), gm_min=((-4, 1),) * 3, gm_max=((0, 1),) * 3, gm_w=320, gm_h=180,
+                             gm_format=abi.AVIF_PIXEL_FORMAT_YUV420))
+    # NaN from degenerate metadata must still fail the call
+    out.append(G.GainMapCase(37, 21, gm_max=((2000, 1),) * 3, gm_min=((-2000, 1),) * 3, alt_headroom=(1, 1), headroom=1.0, out_primaries=9, base_offset=((0, 1),) * 3))
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_fast_kernel_and_general_kernel_on_the_same_cases(hip_auto_arithmetic, monkeypatch):
+    """The fast apply kernel (one table read per output code, kernels_gainmap.hip) must be the one that runs on its cases, and the general kernel
+    -- forced by AVIFHIP_GAINMAP_KERNEL=general -- must give the same bytes there: both against the oracle."""
+    from libavif_amd import native
+
+    o = oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    cases = _fast_kernel_cases()
+    want = [run(o.oracleRGBImageApplyGainMap, c, 1) for c in cases]
+    for forced, name in ((None, "gainmap_apply_fast"), ("general", "gainmap_apply")):
+        if forced:
+            monkeypatch.setenv("AVIFHIP_GAINMAP_KERNEL", forced)
+        bad = []
+        for c, (ra, pa, ca) in zip(cases, want):
+            rb, pb, cb = run(hip_auto_arithmetic.avifhipRGBImageApplyGainMap, c, C.byref(diag))
+            assert native.last_kernel() == name, (c.ident(), native.last_kernel())
+            if ra != rb or (ra == 0 and not (np.array_equal(pa, pb) and ca[0] == cb[0] and abs(ca[1] - cb[1]) <= 1)):
+                bad.append(f"{c.ident()} [{name}]: results {ra}/{rb} clli {ca}/{cb}" +
+                           ("" if ra or rb or np.array_equal(pa, pb) else f" {int((pa != pb).sum())} bytes differ"))
+        assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+    assert sum(r == 0 for r, _, _ in want) >= len(cases) - 1 and any(r == abi.AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE for r, _, _ in want)
+
+
 @pytest.mark.gpu
 def test_gpu_larger_images_and_16_bit_tables(hip_auto_arithmetic):
     cases = [G.GainMapCase(1001, 333, base_depth=8, out_depth=8, gm_w=500, gm_h=167, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, out_tc=16, out_primaries=9),

@@ -38,6 +38,8 @@ def host():
     lib.hostOutputSteps.restype = C.c_uint32
     lib.hostOutputSteps.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.hostChooseMathPrimaries.restype, lib.hostChooseMathPrimaries.argtypes = C.c_int, [C.c_int, C.c_int]
+    lib.hostLocatorCodes.restype = C.c_uint32
+    lib.hostLocatorCodes.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.hostCheckBucketSteps.restype = C.c_int
     lib.hostCheckBucketSteps.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(C.c_int)]
     lib.hostCheckCodeSteps.restype = C.c_int
@@ -138,6 +140,44 @@ def test_output_steps_reproduce_the_quantised_transfer_function(host, tc, depth,
         with np.errstate(invalid="ignore"):
             got = int(np.nonzero(piece[: max_code.value + 1] <= x)[0].max())
         assert got == want, (tc, depth, is_float, float(x), got, want)
+
+
+@pytest.mark.parametrize("tc", [1, 4, 5, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18])
+@pytest.mark.parametrize("depth", [8, 10, 12])
+def test_output_locator_reproduces_the_quantised_transfer_function(host, tc, depth):
+    """The fast apply kernel finds the output code with ONE table read (GainMapSteps::locator).  For random linear values, for every
+    step and for its predecessor, the locator must give quantise(clamp(linearToGamma(x))) as the oracle's transfer function computes
+    it; a curve whose x < 0 piece reaches above code 0 (BT.1361) must not have a locator."""
+    o = oracle_lib.oracle()
+    cap = 2 * 65536
+    steps = (C.c_float * cap)()
+    max_code = C.c_uint32()
+    entries = host.hostOutputSteps(tc, depth, 0, steps, cap, C.byref(max_code))
+    T = np.frombuffer(steps, dtype=np.float32, count=2 * entries).copy()
+    pos = T[entries: entries + max_code.value + 1]
+    finite = pos[1:][np.isfinite(pos[1:])]
+    rng = np.random.default_rng(tc * 1000 + depth)
+    xs = np.concatenate([rng.uniform(-0.3, 1.3, 4000), 10.0 ** rng.uniform(-10, 2, 4000), -(10.0 ** rng.uniform(-8, 0, 500)), finite,
+                         np.nextafter(finite, np.float32(-np.inf)), np.nextafter(finite, np.float32(np.inf)),
+                         [0.0, -0.0, 1.0, 1e30, -1e30, np.inf, -np.inf, 1e-45, 1e-38]]).astype(np.float32)
+    codes = (C.c_uint32 * len(xs))()
+    shift = C.c_uint32()
+    buckets = host.hostLocatorCodes(tc, depth, xs.ctypes.data_as(C.POINTER(C.c_float)), len(xs), codes, C.byref(shift))
+    if tc == 12:
+        assert buckets == 0, "BT.1361 reaches codes above 0 for negative x: it cannot use the locator"
+        return
+    if buckets == 0:
+        assert depth > 8, (tc, depth)  # only the finer tables may outgrow the LDS budget (the general kernel serves those)
+        return
+    assert buckets <= 12288 and 6 <= shift.value <= 19
+    max_f = np.float32((1 << depth) - 1)
+    got = np.frombuffer(codes, dtype=np.uint32)
+    for x, g in zip(xs[:9000], got[:9000]):  # against the transfer function itself
+        v = np.float32(min(np.float32(1.0), max(np.float32(0.0), np.float32(o.oracleTransferFunction(tc, 1, float(x))))))
+        assert int(g) == int(np.float32(np.float32(0.5) + v * max_f)), (tc, depth, float(x), int(g))
+    with np.errstate(invalid="ignore"):  # against the step search the general kernel does, on everything
+        want = np.array([0 if x < 0 else int(np.nonzero(pos <= x)[0].max()) for x in xs])
+    assert np.array_equal(got, want), (tc, depth, xs[got != want][:5], got[got != want][:5], want[got != want][:5])
 
 
 def test_gain_map_math_primaries_choice(host):

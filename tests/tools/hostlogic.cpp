@@ -65,6 +65,19 @@ uint32_t hostOutputSteps(int tc, uint32_t depth, int isFloat, float * steps, uin
     return S.pieceEntries;
 }
 
+// the one-read locator of the fast apply kernel: codes of `count` values of x; returns the bucket count (0: this curve / depth has
+// no locator and the general kernel serves it), *shift receives the bucket width in bits
+uint32_t hostLocatorCodes(int tc, uint32_t depth, const float * x, uint32_t count, uint32_t * codes, uint32_t * shift)
+{
+    const GainMapSteps & S = gainMapOutputSteps(tc, depth, false);
+    if (S.locator.empty())
+        return 0;
+    for (uint32_t k = 0; k < count; ++k)
+        codes[k] = gainMapLocate(S, x[k]);
+    *shift = S.locShift;
+    return S.locBuckets;
+}
+
 int hostChooseMathPrimaries(int basePrimaries, int altPrimaries)
 {
     int out = -1;
