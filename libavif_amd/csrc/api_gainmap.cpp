@@ -227,6 +227,16 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
                     tables.insert(tables.end(), g.begin(), g.end());
                 }
             }
+            // largest magnitudes of the tables (NaN / inf: infinity), for the bound that lets the fast kernel skip its NaN test
+            auto largest = [](const float * v, size_t n) {
+                float m = 0.0f;
+                for (size_t k = 0; k < n; ++k)
+                    m = (fabsf(v[k]) <= m) ? m : ((v[k] == v[k]) ? fabsf(v[k]) : INFINITY);
+                return m;
+            };
+            cache.baseMax = largest(tables.data(), cache.gainLutOffset);
+            for (int c = 0; c < 3; ++c)
+                cache.gainMax[c] = applyGain ? largest(tables.data() + cache.gainLutOffset + (size_t)c * ((size_t)1 << gainDepth), (size_t)1 << gainDepth) : 0.0f;
             cache.stepsOffset = tables.size();
             const GainMapSteps & S = gainMapOutputSteps(outTC, key.outDepth, out->isFloat != 0);
             tables.insert(tables.end(), S.steps.begin(), S.steps.end());
@@ -236,11 +246,14 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
             cache.maxCode = S.maxCode, cache.stepEntries = S.pieceEntries;
             // the fast kernel's tables: the one-read locator (when the curve and depth have one) and the output alpha code of
             // every base alpha code, (T)(0.5f + (a / max) * max') of avifGetRGBAPixel + avifSetRGBAPixel (src/reformat.c:1856-1937)
+            // (both 16-byte aligned and padded: the kernel moves them 16 bytes at a time)
+            tables.resize((tables.size() + 3) & ~(size_t)3, 0.0f);
             cache.locOffset = tables.size(), cache.locBuckets = (uint32_t)S.locator.size();
             cache.locFirstBits = S.locFirstBits, cache.locShift = S.locShift;
             tables.resize(tables.size() + S.locator.size(), 0.0f);
             if (!S.locator.empty())
                 memcpy(tables.data() + cache.locOffset, S.locator.data(), S.locator.size() * sizeof(uint32_t));
+            tables.resize((tables.size() + 3) & ~(size_t)3, 0.0f);
             cache.alphaOffset = tables.size();
             if (!base->isFloat && !out->isFloat && base->depth <= 12) {
                 const uint32_t n = 1u << base->depth;
@@ -251,6 +264,7 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
                 tables.resize(tables.size() + n / 2, 0.0f);
                 memcpy(tables.data() + cache.alphaOffset, alpha.data(), n * sizeof(uint16_t));
             }
+            tables.resize((tables.size() + 3) & ~(size_t)3, 0.0f);
             // what the reference computes for a NaN input (the weight-0 path can meet one in a half-float base image)
             const float nanGamma = fminf(1.0f, fmaxf(0.0f, gainMapToGamma(outTC, NAN)));
             cache.nanCode = out->isFloat ? ((uint32_t)0) : (uint32_t)(0.5f + nanGamma * (float)((1u << key.outDepth) - 1));
@@ -290,6 +304,27 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         A.locFirstBits = cache.locFirstBits, A.locShift = cache.locShift, A.locBuckets = cache.locBuckets;
         A.fast = applyGain && cache.locBuckets && width >= 4 && plain4(A.baseL, A.base, A.basePitch) && plain4(A.outL, A.out, A.outPitch) && gainDepth <= 12 &&
                  gainMapFastLdsBytes(A.baseL.pixelBytes, gainDepth, cache.locBuckets) <= kGainMapFastLdsBytes && !fastKernelDisabled();
+        if (A.fast) {
+            // no intermediate value can reach FLT_MAX (so none is infinite, so none is a NaN) when the tables are finite and the
+            // products of their largest entries with the coefficients stay far below it: only then may the fast kernel, which does
+            // not look for NaNs, serve the call
+            auto rowSum = [](const double M[9]) {
+                double m = 0.0;
+                for (int r = 0; r < 3; ++r)
+                    m = fmax(m, fabs(M[3 * r]) + fabs(M[3 * r + 1]) + fabs(M[3 * r + 2]));
+                return m;
+            };
+            double bound = cache.baseMax;
+            if (A.inConv)
+                bound *= rowSum(A.inM) * 1.001;
+            double tone = 0.0;
+            for (int c = 0; c < 3; ++c)
+                tone = fmax(tone, (bound + fabs((double)A.baseOffset[c])) * cache.gainMax[c] * 1.001 + fabs((double)A.altOffset[c]));
+            if (A.outConv)
+                tone *= rowSum(A.outM) * 1.001;
+            if (!(bound < 1e37 && tone < 1e37)) // (a NaN or an infinity on the way fails the comparisons too)
+                A.fast = 0;                     // the fast kernel has no NaN test: the general one serves this call
+        }
         if (A.fast) {
             // selectors of the byte permutations between the pixels' layouts and R, G, B, A order (v_perm_b32: selector byte k names the
             // source byte that lands in byte k of the result; 0-3 = second operand, 4-7 = first)

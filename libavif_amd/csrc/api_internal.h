@@ -58,6 +58,7 @@ struct GainMapTableCache
     size_t baseLutOffset = 0, gainLutOffset = 0, stepsOffset = 0, guideOffset = 0, locOffset = 0, alphaOffset = 0; // in floats
     uint32_t maxCode = 0, nanCode = 0, stepEntries = 0;
     uint32_t locBuckets = 0, locFirstBits = 0, locShift = 0; // GainMapSteps::locator (0 buckets: none for this curve / depth)
+    float baseMax = 0.0f, gainMax[3] = { 0.0f, 0.0f, 0.0f };    // largest magnitudes in the base / gain tables (infinity: a NaN or inf entry)
 };
 
 // Copies between pageable host memory and the device run at full PCIe rate on this platform, but "asynchronous" ones block the

@@ -335,7 +335,8 @@ void buildLocator(GainMapSteps & S, bool isFloat)
     for (uint32_t k = 1; k < K; ++k)
         if (!(T[k] < T[k + 1]))
             return;
-    for (uint32_t shift = 19; shift >= 6; --shift) {
+    // codes of more than 8 bits are packed by their low 16 bits: the threshold field has to stay clear of those
+    for (uint32_t shift = (S.maxCode > 255) ? 16 : 19; shift >= 6; --shift) {
         const uint32_t mask = (1u << shift) - 1, first = (bitsOf(T[1]) - 1) & ~mask;
         bool distinct = true;
         for (uint32_t k = 1; k < K && distinct; ++k)

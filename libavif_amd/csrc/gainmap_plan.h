@@ -50,7 +50,8 @@ struct GainMapSteps
     // BT.1361 / IEC 61966-2-4): buckets of 2^locShift consecutive fp32 bit patterns from locFirstBits up, narrow enough that
     // no bucket holds two steps.  With t = clamp((int)bits(x), (int)locFirstBits, (int)locFirstBits + (locBuckets << locShift) - 1) - locFirstBits and
     // e = locator[t >> locShift], the code of x is (e & 0xfff) + ((t << (32 - locShift)) > e): the low 12 bits of e are the code
-    // at the start of the bucket, the high locShift bits the offset of the bucket's step minus one (all ones: no step).
+    // at the start of the bucket, the high locShift bits the offset of the bucket's step minus one (all ones: no step); locShift <= 16
+    // for codes of more than 8 bits, so that bits 12-15 of e are clear (the kernel packs such codes by their low 16 bits).
     // Negative x (sign bit: a negative integer) and x below the first step clamp into bucket 0 ahead of its step: code 0; x past the last
     // step, +inf and NaN clamp into the last bucket, which holds no step.  Empty when the curve / depth does not qualify.
     std::vector<uint32_t> locator;

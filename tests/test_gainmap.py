@@ -225,7 +225,8 @@ def test_gpu_fast_kernel_and_general_kernel_on_the_same_cases(hip_auto_arithmeti
         bad = []
         for c, (ra, pa, ca) in zip(cases, want):
             rb, pb, cb = run(hip_auto_arithmetic.avifhipRGBImageApplyGainMap, c, C.byref(diag))
-            assert native.last_kernel() == name, (c.ident(), native.last_kernel())
+            # (the fast kernel has no NaN test: the library keeps calls whose tables could produce one on the general kernel)
+            assert native.last_kernel() == (name if ra == 0 else "gainmap_apply"), (c.ident(), native.last_kernel())
             if ra != rb or (ra == 0 and not (np.array_equal(pa, pb) and ca[0] == cb[0] and abs(ca[1] - cb[1]) <= 1)):
                 bad.append(f"{c.ident()} [{name}]: results {ra}/{rb} clli {ca}/{cb}" +
                            ("" if ra or rb or np.array_equal(pa, pb) else f" {int((pa != pb).sum())} bytes differ"))

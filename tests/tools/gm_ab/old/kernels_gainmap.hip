@@ -271,9 +271,8 @@ __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_
 // decides).  Four neighbouring pixels per lane: 16- / 32-byte accesses.  Per pixel: one byte permutation brings the base pixel into R, G, B, A
 // order whatever its layout (v_perm_b32 with a wave-uniform selector), three reads of the base table, three of the gain table, ONE read
 // of the locator per channel for the output code (gainmap_plan.h: GainMapSteps::locator -- no search), one of the alpha table, one
-// or two permutations into the output layout; in between the reference's fp32 / fp64 arithmetic in its order.  The kernel does not look
-// for NaNs (AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE, src/gainmap.c:277-281): the host sends a call here only when the tables and coefficients
-// bound every intermediate value below FLT_MAX -- no infinity, hence no NaN; the general kernel serves the rest.
+// or two permutations into the output layout; in between the reference's fp32 / fp64 arithmetic in its order.  A NaN makes the whole call
+// fail (AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE, src/gainmap.c:277-281: the reference stops at that pixel), so its code does not matter.
 // Sample codes above the image's depth (garbage in a 16-bit container) read whatever lies at that place of the LDS.
 
 // LDS layout, in bytes.  With 4-byte pixels (8-bit samples) every table base is a compile-time constant of the instantiation (it rides in
@@ -287,77 +286,29 @@ struct FastLds
                               kLocator = kGainLut + ((GAIN_BYTES == 4) ? 3 * 4 * 256 : 0);
 };
 
-// kFastPixels neighbouring pixels of BYTES each, moved 16 bytes at a time (4-byte alignment is all the wide accesses need).  Pixels are read
-// and written once: streaming accesses keep them from displacing one another in the L2.
+// kFastPixels neighbouring pixels of BYTES each (4-byte alignment is all the wide accesses need)
 constexpr int kFastPixels = 4; // per lane
-#ifndef AVIFHIP_GAINMAP_ROWS
-#define AVIFHIP_GAINMAP_ROWS 8
-#endif
-constexpr int kFastRows = AVIFHIP_GAINMAP_ROWS; // = waves per workgroup: 256 x 8 pixels per workgroup and step
-#ifndef AVIFHIP_GAINMAP_NT_LOADS
-#define AVIFHIP_GAINMAP_NT_LOADS 0
-#endif
-#ifndef AVIFHIP_GAINMAP_NT_STORES
-#define AVIFHIP_GAINMAP_NT_STORES 1
-#endif
-typedef uint32_t Quad __attribute__((ext_vector_type(4)));
-typedef Quad QuadA4 __attribute__((aligned(4)));
+constexpr int kFastRows = 8;   // = waves per workgroup: 256 x 8 pixels per workgroup and step
 template <int BYTES>
-struct PixelRun
+struct __attribute__((packed, aligned(4))) PixelRun
 {
     uint32_t w[kFastPixels * BYTES / 4];
-    __device__ __forceinline__ void load(const uint8_t * p)
-    {
-#pragma unroll
-        for (int k = 0; k < kFastPixels * BYTES / 16; ++k) {
-            const QuadA4 * q = reinterpret_cast<const QuadA4 *>(p) + k;
-            const Quad v = AVIFHIP_GAINMAP_NT_LOADS ? __builtin_nontemporal_load(q) : *q;
-            w[4 * k] = v.x, w[4 * k + 1] = v.y, w[4 * k + 2] = v.z, w[4 * k + 3] = v.w;
-        }
-    }
-    __device__ __forceinline__ void store(uint8_t * p) const
-    {
-#pragma unroll
-        for (int k = 0; k < kFastPixels * BYTES / 16; ++k) {
-            QuadA4 * q = reinterpret_cast<QuadA4 *>(p) + k;
-            const Quad v = { w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
-            if (AVIFHIP_GAINMAP_NT_STORES)
-                __builtin_nontemporal_store(v, q);
-            else
-                *q = v;
-        }
-    }
 };
 
 struct Locator
 {
-    int32_t first, last;  // the bit patterns the first bucket starts and the last bucket ends at (in every lane: v_med3_i32 takes one scalar)
-    uint32_t shift, base; // bucket width; LDS address of the table minus 4 x (first >> shift), modulo 2^32
+    int32_t first, lastRel; // the bit pattern the first bucket starts at; the last bucket's end relative to it
+    uint32_t shift;
 };
+template <uint32_t LOC_BASE>
 __device__ __forceinline__ uint32_t locate(float x, const Locator & L)
 {
-    // as signed integers the bit patterns of negative values sort below those of every x >= 0, NaNs of either sign beyond the ends
-    uint32_t b;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(b) : "v"(__float_as_uint(x)), "v"(L.first), "v"(L.last));
-    // `first` is a multiple of the bucket width: the offset inside the bucket is that of the pattern itself
-    const uint32_t e = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(((b >> L.shift) << 2) + L.base);
-    // the code in the low 12 bits, the entry's threshold field still above them: whoever packs the code takes its low byte (8-bit
-    // outputs) or its low 16 bits (deeper ones: the host keeps the bucket width at 2^16 or less there, so bits 12-15 are clear)
-    return e + (((b << (32 - L.shift)) > e) ? 1u : 0u);
-}
-
-// (code & 0xff) << 2 in one instruction: the compiler finds the sub-dword operand for bytes 1-3 but not for byte 0
-__device__ __forceinline__ uint32_t byte0Times4(uint32_t w, uint32_t two)
-{
-    uint32_t r;
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
-    return r;
-}
-__device__ __forceinline__ uint32_t word0Times4(uint32_t w, uint32_t two)
-{
-    uint32_t r;
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(two), "v"(w));
-    return r;
+    // as signed integers the bit patterns of negative values sort below every x >= 0; the subtraction saturates instead of wrapping
+    const int32_t rel = __builtin_elementwise_sub_sat((int32_t)__float_as_uint(x), L.first);
+    uint32_t t;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(t) : "v"(rel), "s"(L.lastRel));
+    const uint32_t e = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(LOC_BASE + ((t >> L.shift) << 2));
+    return (e & 0xfffu) + (((t << (32 - L.shift)) > e) ? 1u : 0u);
 }
 
 // CONV: bit 0 -- the base image's primaries differ from the gain-map math's (inM), bit 1 -- the output's do (outM)
@@ -366,17 +317,25 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
 {
     using Lds = FastLds<BASE_BYTES, GAIN_BYTES>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t gainR = (GAIN_BYTES == 4) ? Lds::kGainLut : Lds::kLocator + 16 * ((A.locBuckets + 3) / 4);
+    {
+        const uint32_t nBase = 1u << A.baseL.depth, nGain = 1u << A.gainDepth;
+        const uint32_t t = threadIdx.y * 64 + threadIdx.x;
+        for (uint32_t k = t; k < nBase; k += 64 * kFastRows)
+            reinterpret_cast<float *>(lds + Lds::kBaseLut)[k] = A.baseLut[k];
+        for (uint32_t k = t; k < nBase / 2; k += 64 * kFastRows) // two 16-bit entries per move
+            reinterpret_cast<uint32_t *>(lds + Lds::kAlphaLut)[k] = reinterpret_cast<const uint32_t *>(A.alphaLut)[k];
+        for (uint32_t k = t; k < 3 * nGain; k += 64 * kFastRows) // the three channels' tables one after the other
+            reinterpret_cast<float *>(lds + ((GAIN_BYTES == 4) ? Lds::kGainLut : Lds::kLocator + 4 * A.locBuckets))[k] = A.gainLut[k];
+        for (uint32_t k = t; k < A.locBuckets; k += 64 * kFastRows)
+            reinterpret_cast<uint32_t *>(lds + Lds::kLocator)[k] = A.locator[k];
+        __syncthreads();
+    }
+    const uint32_t gainR = (GAIN_BYTES == 4) ? Lds::kGainLut : Lds::kLocator + 4 * A.locBuckets;
     const uint32_t gainG = gainR + ((GAIN_BYTES == 4) ? 1024 : (4u << A.gainDepth)), gainB = gainG + ((GAIN_BYTES == 4) ? 1024 : (4u << A.gainDepth));
-    Locator L = { 0, 0, A.locShift, Lds::kLocator - 4 * (A.locFirstBits >> A.locShift) };
-    // (the two bounds in vector registers for the whole kernel: left to itself the compiler copies them over from scalar ones at every use)
-    asm volatile("v_mov_b32 %0, %1" : "=v"(L.first) : "s"(A.locFirstBits));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(L.last) : "s"(A.locFirstBits + ((A.locBuckets << A.locShift) - 1)));
+    const Locator L = { (int32_t)A.locFirstBits, (int32_t)((A.locBuckets << A.locShift) - 1), A.locShift };
     const uint32_t selBaseX = A.selBase[0], selBaseY = A.selBase[1], selOutX = A.selOut[0], selOutY = A.selOut[1];
     const float bo0 = A.baseOffset[0], bo1 = A.baseOffset[1], bo2 = A.baseOffset[2];
     const float ao0 = A.altOffset[0], ao1 = A.altOffset[1], ao2 = A.altOffset[2];
-    uint32_t two; // a shift count that has to sit in a register (SDWA takes no inline constants)
-    asm volatile("v_mov_b32 %0, 2" : "=v"(two));
     // the dynamic LDS starts at address 0 (the kernel declares no other): tables are read at integer addresses, table base in the
     // instruction's offset field
     typedef __attribute__((address_space(3))) const float * LdsFloat;
@@ -385,181 +344,81 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
 
     float toneMax = 0.0f;
     double sum = 0.0;
-    // Workgroups walk tiles of 256 x 8 pixels (four neighbouring pixels per lane, a row per wave) with a grid stride; a lane whose run would
-    // cross the end of the row moves it left to end there: the pixels it shares with its neighbour are computed (and stored, same bytes)
-    // twice but counted once.  The next tile's pixels are requested before the current ones are worked on (one tile's loads per wave do not
-    // cover the memory latency), into the other of two register sets: the loop body is written out for both, so nothing is copied.
-    struct Tile
-    {
-        PixelRun<BASE_BYTES> bp;
-        PixelRun<GAIN_BYTES> gp;
-        uint32_t i, i0, j;
-        bool live;
-    };
+    unsigned long long nanLanes = 0; // of this wave
+    // Workgroups walk tiles of 256 x 8 pixels (four neighbouring pixels per lane, a row per wave) with a grid stride; a lane whose run would cross the end of the row
+    // moves it left to end there: the pixels it shares with its neighbour are computed (and stored, same bytes) twice but counted once.
+    // The next tile's pixels are requested before the current ones are worked on: one tile's loads per wave do not cover the memory latency.
     uint32_t tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
-    auto request = [&](Tile & T, uint32_t tile) {
-        T.live = false;
+    PixelRun<BASE_BYTES> bp, bpNext;
+    PixelRun<GAIN_BYTES> gp, gpNext;
+    uint32_t i = 0, i0 = 0, j = 0, iNext = 0, i0Next = 0, jNext = 0;
+    bool live = false, liveNext = false;
+    auto request = [&](uint32_t tile) {
+        liveNext = false;
         if (tile >= tiles)
             return;
-        T.i = tx * (64 * kFastPixels) + threadIdx.x * kFastPixels, T.j = ty * kFastRows + threadIdx.y;
+        iNext = tx * (64 * kFastPixels) + threadIdx.x * kFastPixels, jNext = ty * kFastRows + threadIdx.y;
         tx += stepX, ty += stepY;
         if (tx >= tilesX)
             tx -= tilesX, ++ty;
-        T.live = T.i < A.width && T.j < A.height;
-        if (T.live) {
-            T.i0 = min(T.i, A.width - kFastPixels);
-            T.bp.load(A.base + (size_t)T.j * A.basePitch + (size_t)T.i0 * BASE_BYTES);
-            T.gp.load(A.gain + (size_t)T.j * A.gainPitch + (size_t)T.i0 * GAIN_BYTES);
+        liveNext = iNext < A.width && jNext < A.height;
+        if (liveNext) {
+            i0Next = min(iNext, A.width - kFastPixels);
+            bpNext = *reinterpret_cast<const PixelRun<BASE_BYTES> *>(A.base + (size_t)jNext * A.basePitch + (size_t)i0Next * BASE_BYTES);
+            gpNext = *reinterpret_cast<const PixelRun<GAIN_BYTES> *>(A.gain + (size_t)jNext * A.gainPitch + (size_t)i0Next * GAIN_BYTES);
         }
     };
-    // PLAIN: R, G, B, A order on both sides (the usual case): the three byte permutations per pixel fall away
-    auto work = [&](const Tile & T, auto plain) {
-        constexpr bool PLAIN = decltype(plain)::value;
-        if (!T.live)
-            return;
+    request(blockIdx.x);
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        bp = bpNext, gp = gpNext, i = iNext, i0 = i0Next, j = jNext, live = liveNext;
+        request(tile + gridDim.x);
+        if (!live)
+            continue;
         PixelRun<OUT_BYTES> op;
-        float pixelMax[kFastPixels];
 #pragma unroll
         for (int p = 0; p < kFastPixels; ++p) {
             // byte offsets into the tables: sample code x entry size
             uint32_t r4, g4, b4, a2, gr4, gg4, gb4;
             if constexpr (BASE_BYTES == 4) {
-                const uint32_t w = PLAIN ? T.bp.w[p] : __builtin_amdgcn_perm(T.bp.w[p], T.bp.w[p], selBaseX); // R, G, B, A from byte 0 up
-                r4 = byte0Times4(w, two), g4 = ((w >> 8) & 0xff) << 2, b4 = ((w >> 16) & 0xff) << 2, a2 = (w >> 24) << 1;
+                const uint32_t w = __builtin_amdgcn_perm(bp.w[p], bp.w[p], selBaseX); // R, G, B, A from byte 0 up
+                r4 = (w & 0xff) << 2, g4 = ((w >> 8) & 0xff) << 2, b4 = ((w >> 16) & 0xff) << 2, a2 = (w >> 24) << 1;
             } else {
-                const uint32_t x = PLAIN ? T.bp.w[2 * p] : __builtin_amdgcn_perm(T.bp.w[2 * p + 1], T.bp.w[2 * p], selBaseX);
-                const uint32_t y = PLAIN ? T.bp.w[2 * p + 1] : __builtin_amdgcn_perm(T.bp.w[2 * p + 1], T.bp.w[2 * p], selBaseY);
-                r4 = word0Times4(x, two), g4 = (x >> 16) << 2, b4 = word0Times4(y, two), a2 = (y >> 16) << 1;
+                const uint32_t x = __builtin_amdgcn_perm(bp.w[2 * p + 1], bp.w[2 * p], selBaseX), y = __builtin_amdgcn_perm(bp.w[2 * p + 1], bp.w[2 * p], selBaseY);
+                r4 = (x & 0xffff) << 2, g4 = (x >> 16) << 2, b4 = (y & 0xffff) << 2, a2 = (y >> 16) << 1;
             }
             if constexpr (GAIN_BYTES == 4) { // the gain map is RGBA (avifRGBImageSetDefaults)
-                const uint32_t w = T.gp.w[p];
-                gr4 = byte0Times4(w, two), gg4 = ((w >> 8) & 0xff) << 2, gb4 = ((w >> 16) & 0xff) << 2;
+                const uint32_t w = gp.w[p];
+                gr4 = (w & 0xff) << 2, gg4 = ((w >> 8) & 0xff) << 2, gb4 = ((w >> 16) & 0xff) << 2;
             } else {
-                const uint32_t x = T.gp.w[2 * p], y = T.gp.w[2 * p + 1];
-                gr4 = word0Times4(x, two), gg4 = (x >> 16) << 2, gb4 = word0Times4(y, two);
+                const uint32_t x = gp.w[2 * p], y = gp.w[2 * p + 1];
+                gr4 = (x & 0xffff) << 2, gg4 = (x >> 16) << 2, gb4 = (y & 0xffff) << 2;
             }
             float v[3] = { lutF(Lds::kBaseLut + r4), lutF(Lds::kBaseLut + g4), lutF(Lds::kBaseLut + b4) };
-            uint32_t alphaCode = *(LdsU16)(uintptr_t)(Lds::kAlphaLut + a2);
-#ifdef AVIFHIP_GAINMAP_PROBE // tests/tools/gmbench.hip: what the kernel costs without one of its parts (results are wrong then)
-            if (A.fast & 16)
-                v[0] = (float)r4, v[1] = (float)g4, v[2] = (float)b4, alphaCode = a2;
-#endif
+            const uint32_t alphaCode = *(LdsU16)(uintptr_t)(Lds::kAlphaLut + a2);
             if constexpr (CONV & 1)
                 convertPrimaries(v, A.inM);
             // :236-270
-#ifdef AVIFHIP_GAINMAP_PROBE
-            if (A.fast & 16) {
-                v[0] = (v[0] + bo0) * (float)gr4 - ao0, v[1] = (v[1] + bo1) * (float)gg4 - ao1, v[2] = (v[2] + bo2) * (float)gb4 - ao2;
-            } else
-#endif
-            {
-                v[0] = (v[0] + bo0) * lutF(gainR + gr4) - ao0;
-                v[1] = (v[1] + bo1) * lutF(gainG + gg4) - ao1;
-                v[2] = (v[2] + bo2) * lutF(gainB + gb4) - ao2;
-            }
-            pixelMax[p] = fmaxf(fmaxf(fmaxf(0.0f, v[0]), v[1]), v[2]); // a NaN leaves the maximum as it is, like the reference's comparisons
-            if constexpr (CONV & 2) {
-#ifdef AVIFHIP_GAINMAP_PROBE
-                if (!(A.fast & 8))
-#endif
-                    convertPrimaries(v, A.outM);
-            }
-            uint32_t c0, c1, c2;
-#ifdef AVIFHIP_GAINMAP_PROBE
-            if (A.fast & 4)
-                c0 = __float_as_uint(v[0]) >> 20, c1 = __float_as_uint(v[1]) >> 20, c2 = __float_as_uint(v[2]) >> 20;
-            else
-#endif
-                c0 = locate(v[0], L), c1 = locate(v[1], L), c2 = locate(v[2], L);
-            if constexpr (OUT_BYTES == 4) { // the codes' low bytes side by side, then into the output's order
-                const uint32_t rg = __builtin_amdgcn_perm(c1, c0, 0x0c0c0400u), ba = __builtin_amdgcn_perm(alphaCode, c2, 0x0c0c0400u);
-                op.w[p] = PLAIN ? (rg | (ba << 16)) : __builtin_amdgcn_perm(ba, rg, selOutX);
-            } else { // their low halves
-                const uint32_t rg = __builtin_amdgcn_perm(c1, c0, 0x05040100u), ba = __builtin_amdgcn_perm(alphaCode, c2, 0x05040100u);
-                op.w[2 * p] = PLAIN ? rg : __builtin_amdgcn_perm(ba, rg, selOutX), op.w[2 * p + 1] = PLAIN ? ba : __builtin_amdgcn_perm(ba, rg, selOutY);
+            v[0] = (v[0] + bo0) * lutF(gainR + gr4) - ao0;
+            v[1] = (v[1] + bo1) * lutF(gainG + gg4) - ao1;
+            v[2] = (v[2] + bo2) * lutF(gainB + gb4) - ao2;
+            const float pixelMax = fmaxf(fmaxf(fmaxf(0.0f, v[0]), v[1]), v[2]); // a NaN leaves the maximum as it is, like the reference's comparisons
+            toneMax = fmaxf(toneMax, pixelMax);
+            sum += (double)((i0 + p >= i) ? pixelMax : 0.0f);
+            if constexpr (CONV & 2)
+                convertPrimaries(v, A.outM);
+            nanLanes |= __builtin_amdgcn_fcmpf(v[0], v[1], 8) | __builtin_amdgcn_fcmpf(v[2], v[2], 8); // "unordered": one of the two is a NaN
+            const uint32_t c0 = locate<Lds::kLocator>(v[0], L), c1 = locate<Lds::kLocator>(v[1], L), c2 = locate<Lds::kLocator>(v[2], L);
+            if constexpr (OUT_BYTES == 4) {
+                op.w[p] = __builtin_amdgcn_perm(c2 | (alphaCode << 8), c0 | (c1 << 8), selOutX);
+            } else {
+                const uint32_t rg = c0 | (c1 << 16), ba = c2 | (alphaCode << 16);
+                op.w[2 * p] = __builtin_amdgcn_perm(ba, rg, selOutX), op.w[2 * p + 1] = __builtin_amdgcn_perm(ba, rg, selOutY);
             }
         }
-#ifdef AVIFHIP_GAINMAP_PROBE
-        if (A.fast & 128) { // 64 scalar instructions more per tile: do they take issue slots from the vector ALU?
-#pragma unroll
-            for (int k = 0; k < 64; ++k)
-                asm volatile("s_mov_b32 s90, 0" ::: "s90");
-        }
-        if (A.fast & 256) { // 64 vector instructions more per tile, for comparison
-#pragma unroll
-            for (int k = 0; k < 64; ++k)
-                asm volatile("v_mov_b32 %0, %0" : "+v"(op.w[0]));
-        }
-        if (!(A.fast & 32) || op.w[0] == 0xdeadbeefu)
-#endif
-            op.store(A.out + (size_t)T.j * A.outPitch + (size_t)T.i0 * OUT_BYTES);
-        toneMax = fmaxf(toneMax, fmaxf(fmaxf(pixelMax[0], pixelMax[1]), fmaxf(pixelMax[2], pixelMax[3])));
-        if (__builtin_expect(T.i0 == T.i, 1)) {
-            sum += ((double)pixelMax[0] + (double)pixelMax[1]) + ((double)pixelMax[2] + (double)pixelMax[3]);
-        } else { // the end of a row whose width is no multiple of four: the neighbouring lane counts the first pixels of this run
-#pragma unroll
-            for (int p = 0; p < kFastPixels; ++p)
-                if (T.i0 + p >= T.i)
-                    sum += (double)pixelMax[p];
-        }
-    };
-    Tile T0, T1;
-    request(T0, blockIdx.x); // the first pixels are on their way while the tables move into the LDS
-#ifdef AVIFHIP_GAINMAP_PROBE
-    if (!(A.fast & 64))
-#endif
-    {
-        // all four tables in one sweep of 16-byte moves, every lane's loads in flight before its first LDS write (a loop of load - write
-        // round trips took 4 of the kernel's 37 us on a 4K image); the host keeps the tables 16-byte aligned and padded
-        const uint32_t nBase = 1u << A.baseL.depth, nGain = 1u << A.gainDepth;
-        const uint32_t gainLds = (GAIN_BYTES == 4) ? Lds::kGainLut : Lds::kLocator + 16 * ((A.locBuckets + 3) / 4);
-        const uint32_t q0 = nBase / 4, q1 = q0 + nBase / 8, q2 = q1 + (3 * nGain) / 4, q3 = q2 + (A.locBuckets + 3) / 4; // in 16-byte units
-        const uint32_t t = threadIdx.y * 64 + threadIdx.x;
-        constexpr int kMoves = (int)(kGainMapFastLdsBytes / 16 / (64 * kFastRows));
-        Quad held[kMoves];
-#pragma unroll
-        for (int m = 0; m < kMoves; ++m) {
-            const uint32_t q = t + m * 64 * kFastRows;
-            if (q < q3) {
-                const Quad * src = (q < q0) ? reinterpret_cast<const Quad *>(A.baseLut) + q
-                                 : (q < q1) ? reinterpret_cast<const Quad *>(A.alphaLut) + (q - q0)
-                                 : (q < q2) ? reinterpret_cast<const Quad *>(A.gainLut) + (q - q1)
-                                            : reinterpret_cast<const Quad *>(A.locator) + (q - q2);
-                held[m] = *src;
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < kMoves; ++m) {
-            const uint32_t q = t + m * 64 * kFastRows;
-            if (q < q3) {
-                const uint32_t at = (q < q0) ? Lds::kBaseLut + 16 * q
-                                  : (q < q1) ? Lds::kAlphaLut + 16 * (q - q0)
-                                  : (q < q2) ? gainLds + 16 * (q - q1)
-                                             : Lds::kLocator + 16 * (q - q2);
-                *reinterpret_cast<Quad *>(lds + at) = held[m];
-            }
-        }
-        __syncthreads();
-    }
-    const bool plain = (BASE_BYTES == 4 ? selBaseX == 0x03020100u : (selBaseX == 0x03020100u && selBaseY == 0x07060504u)) &&
-                       (OUT_BYTES == 4 ? selOutX == 0x05040100u : (selOutX == 0x03020100u && selOutY == 0x07060504u));
-    if (plain) {
-        for (uint32_t tile = blockIdx.x; tile < tiles; tile += 2 * gridDim.x) {
-            request(T1, tile + gridDim.x);
-            work(T0, std::true_type{});
-            request(T0, tile + 2 * gridDim.x);
-            work(T1, std::true_type{});
-        }
-    } else {
-        for (uint32_t tile = blockIdx.x; tile < tiles; tile += 2 * gridDim.x) {
-            request(T1, tile + gridDim.x);
-            work(T0, std::false_type{});
-            request(T0, tile + 2 * gridDim.x);
-            work(T1, std::false_type{});
-        }
+        *reinterpret_cast<PixelRun<OUT_BYTES> *>(A.out + (size_t)j * A.outPitch + (size_t)i0 * OUT_BYTES) = op;
     }
     __syncthreads(); // the tables are done with: their place serves the reduction
-    finishStatistics<kFastRows>(A, toneMax, sum, 0, lds); // no NaN: the host sends a call here only when it can prove that (api_gainmap.cpp)
+    finishStatistics<kFastRows>(A, toneMax, sum, nanLanes, lds);
 }
 
 // ---- gain-map computation -----------------------------------------------------------------------------------------
@@ -734,7 +593,7 @@ __global__ __launch_bounds__(256) void gainMapQuantiseKernel(const float * ratio
 size_t gainMapFastLdsBytes(uint32_t basePixelBytes, uint32_t gainDepth, uint32_t locBuckets)
 {
     const size_t fixed = (basePixelBytes == 4) ? FastLds<4, 8>::kLocator : FastLds<8, 8>::kLocator; // base and alpha tables
-    return fixed + ((size_t)12 << gainDepth) + (size_t)((locBuckets + 3) / 4) * 16;
+    return fixed + ((size_t)12 << gainDepth) + (size_t)locBuckets * 4;
 }
 
 hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_t * partials)
@@ -743,41 +602,17 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_
     if (!A.width || !A.height)
         return hipSuccess;
     if (A.fast) {
-        // 256 x 8 pixels per workgroup and step.  As many workgroups as the CUs hold at once -- by the tables' LDS and by the registers of
-        // the instantiation (the variants with two primaries conversions need more than the 64 that leave room for eight waves per SIMD) --
-        // or fewer, so that every workgroup makes the same number of steps when the tiles divide that way.
+        // 256 x 8 pixels per workgroup and step; up to four workgroups (32 waves) per CU when the tables leave room; every workgroup the
+        // same number of steps when the tiles divide that way
         const uint32_t tilesX = (A.width + 64 * kFastPixels - 1) / (64 * kFastPixels), tiles = tilesX * ((A.height + kFastRows - 1) / kFastRows);
         const size_t lds = gainMapFastLdsBytes(A.baseL.pixelBytes, A.gainDepth, A.locBuckets);
-        const uint32_t byLds = (uint32_t)((160 * 1024) / (lds + 512));
+        const uint32_t perCu = (uint32_t)((160 * 1024) / (lds + 512));
+        const uint32_t resident = 256 * (perCu < 1 ? 1 : (perCu > 4 ? 4 : perCu));
+        const uint32_t steps = (tiles + resident - 1) / resident;
+        const uint32_t groups = (tiles + steps - 1) / steps;
+        const uint32_t stepX = groups % tilesX, stepY = groups / tilesX;
         const int conv = (A.inConv ? 1 : 0) | (A.outConv ? 2 : 0);
-        const int key = (A.baseL.pixelBytes == 8 ? 4 : 0) | (A.outL.pixelBytes == 8 ? 2 : 0) | (A.gainDepth > 8 ? 1 : 0);
-        static int wavesPerSimd[8][4]; // of each instantiation, from its register count (0: not asked yet)
-        uint32_t groups = 0;
-        auto launch = [&](auto kernel) {
-            int waves = wavesPerSimd[key][conv];
-            if (!waves) {
-                hipFuncAttributes attr;
-                waves = 4;
-                if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) == hipSuccess && attr.numRegs > 0)
-                    waves = 512 / ((attr.numRegs + 7) & ~7);
-                else
-                    (void)hipGetLastError();
-#ifdef AVIFHIP_GAINMAP_PROBE
-                printf("numRegs %d sharedSizeBytes %zu maxThreadsPerBlock %d\n", attr.numRegs, attr.sharedSizeBytes, attr.maxThreadsPerBlock);
-#endif
-                wavesPerSimd[key][conv] = waves = (waves > 8) ? 8 : ((waves < 2) ? 2 : waves);
-            }
-            const uint32_t byRegisters = (uint32_t)(4 * waves / kFastRows);
-            const uint32_t perCu = (byLds < byRegisters) ? byLds : byRegisters;
-            const uint32_t resident = 256 * (perCu < 1 ? 1 : perCu);
-            const uint32_t steps = (tiles + resident - 1) / resident;
-            groups = (tiles + steps - 1) / steps;
-#ifdef AVIFHIP_GAINMAP_PROBE
-            if (getenv("GM_GROUPS"))
-                groups = (uint32_t)atoi(getenv("GM_GROUPS"));
-#endif
-            hipLaunchKernelGGL(kernel, dim3(groups), dim3(64, kFastRows), lds, stream, A, tilesX, tiles, groups % tilesX, groups / tilesX);
-        };
+        auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(groups), dim3(64, kFastRows), lds, stream, A, tilesX, tiles, stepX, stepY); };
         auto byConv = [&](auto b, auto o, auto g) {
             constexpr int B = decltype(b)::value, O = decltype(o)::value, G = decltype(g)::value;
             switch (conv) {
@@ -789,6 +624,7 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_
         };
         using I4 = std::integral_constant<int, 4>;
         using I8 = std::integral_constant<int, 8>;
+        const int key = (A.baseL.pixelBytes == 8 ? 4 : 0) | (A.outL.pixelBytes == 8 ? 2 : 0) | (A.gainDepth > 8 ? 1 : 0);
         switch (key) {
             case 0: byConv(I4{}, I4{}, I4{}); break;
             case 1: byConv(I4{}, I4{}, I8{}); break;

@@ -16,8 +16,9 @@ __global__ __launch_bounds__(256) void k(float * out, float a, float b)
     for (int i = 0; i < 16; ++i) r[i] = a * (threadIdx.x + i);
     f2 * r2 = reinterpret_cast<f2 *>(r);
     unsigned u[8];
+    double dd[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = threadIdx.x * 77 + i;
+    for (int i = 0; i < 8; ++i) u[i] = threadIdx.x * 77 + i, dd[i] = 1.0 + 1e-9 * (threadIdx.x + i);
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
         for (int rep = 0; rep < 4; ++rep) {
@@ -66,6 +67,36 @@ __global__ __launch_bounds__(256) void k(float * out, float a, float b)
             } else if constexpr (OP == 15) { // v_lshl_or_b32
 #pragma unroll
                 for (int i = 0; i < 8; ++i) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            } else if constexpr (OP == 16) { // v_mul_f64 (the gain-map kernel's primaries matrices)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(dd[(i + 1) & 7]));
+            } else if constexpr (OP == 17) { // v_add_f64
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(dd[i]) : "v"(dd[(i + 1) & 7]));
+            } else if constexpr (OP == 18) { // v_fma_f64
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(dd[i]) : "v"(dd[(i + 1) & 7]));
+            } else if constexpr (OP == 19) { // v_cvt_f64_f32
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dd[i]) : "v"(r[i]));
+            } else if constexpr (OP == 20) { // v_cvt_f32_f64
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(r[i]) : "v"(dd[i]));
+            } else if constexpr (OP == 21) { // v_med3_i32
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
+            } else if constexpr (OP == 22) { // v_lshlrev_b32_sdwa (byte operand)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+            } else if constexpr (OP == 23) { // v_cmp_gt_u32 + v_addc_co_u32 (the pair the locator ends with)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 7]) : "vcc");
+            } else if constexpr (OP == 24) { // v_lshlrev_b32
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(u[i]));
+            } else if constexpr (OP == 25) { // v_max3_f32
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(r[(i + 1) & 7]), "v"(r[(i + 2) & 7]));
             }
         }
     }
@@ -73,7 +104,7 @@ __global__ __launch_bounds__(256) void k(float * out, float a, float b)
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += r[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += (float)u[i];
+    for (int i = 0; i < 8; ++i) s += (float)u[i] + (float)dd[i];
     if (s == 12345.678f) out[0] = s;
 }
 
@@ -103,5 +134,8 @@ int main()
     run<4>("v_mul_f32", d, cus, ghz); run<5>("v_add_f32", d, cus, ghz); run<6>("v_cvt_pk_u8_f32", d, cus, ghz); run<7>("v_cvt_f32_ubyte1", d, cus, ghz);
     run<8>("v_floor_f32", d, cus, ghz); run<9>("v_rcp_f32", d, cus, ghz); run<10>("v_mov_b32", d, cus, ghz); run<12>("v_med3_f32", d, cus, ghz);
     run<13>("v_cvt_u32_f32", d, cus, ghz); run<14>("v_perm_b32", d, cus, ghz); run<15>("v_lshl_or_b32", d, cus, ghz);
+    run<16>("v_mul_f64", d, cus, ghz); run<17>("v_add_f64", d, cus, ghz); run<18>("v_fma_f64", d, cus, ghz); run<19>("v_cvt_f64_f32", d, cus, ghz);
+    run<20>("v_cvt_f32_f64", d, cus, ghz); run<21>("v_med3_i32", d, cus, ghz); run<22>("v_lshlrev_b32_sdwa", d, cus, ghz);
+    run<23>("v_cmp_gt_u32+v_addc_co_u32", d, cus, ghz); run<24>("v_lshlrev_b32", d, cus, ghz); run<25>("v_max3_f32", d, cus, ghz);
     return 0;
 }
