@@ -11,9 +11,9 @@ libavif built without libyuv) is timed next to it and reported inside "roofline"
 
 Timed region: W untimed warm-up steps, then EXACTLY K steps between a barrier + device synchronisation on both sides
 (MAX over ranks); that region is repeated R times (default 9) and the MEDIAN is reported as ms_per_step / value -- a single
-region of a few dozen 30-microsecond launches is noise.  Steps cycle over 4 distinct frames (730 MB) and are issued
-round-robin on 2 HIP streams: frames are independent units of work (sequence frames / grid tiles), so consecutive steps
-overlap each other's head and tail; that is why ms_per_step can be below one kernel's own duration ("value_basis").
+region of a few dozen 30-microsecond launches is noise.  Steps cycle over 4 distinct frames (730 MB) on one HIP stream
+(--streams 2: round-robin on two; frames are independent units of work, so consecutive steps then overlap each other's head
+and tail and ms_per_step drops below one kernel's own duration -- reported as "two_streams").
 Before anything is timed the GPU is kept busy for --preheat-ms (default 300 ms): an idle MI355X sits at 95 MHz and
 needs ~40 ms of work to reach its running clocks (tests/tools/spread_probe.py: the first bursts run 55 -> 30 us per launch).
 
@@ -25,6 +25,13 @@ The line also carries, as first-class fields measured in the same run: "roofline
 nothing stays in the Infinity Cache), "fp32" (the built-in fp32 arithmetic, rgb.avoidLibYUV = 1, on the same frames) and "planes_4k"
 (3840x2160 planes, both arithmetics): the north star asks for 4K and 8K planes and the reference compiled from its own sources computes
 the fp32 arithmetic.
+
+"configs" carries the other BASELINE.json configurations measured in the same run and the same way (kernels alone, HIP events on the launch
+stream, the median of bursts; algorithmic bytes of SURVEY.md 8d): cfg1 (256x256 defaults), cfg3 (8K 10-bit 4:4:4 + alpha -> premultiplied
+RGBA16), cfg4 (4K RGBA8 -> 4:2:0 + alpha), cfg5x64 (64 separately stored 1080p 10-bit tiles, one batched launch) and cfg5grid (the same tiles
+into one canvas, seams included); "ceilings" the no-arithmetic byte-movement kernel on 4K and 1080p planes (what the chip sustains on jobs that
+short); "gainmap" avifRGBImageApplyGainMap on a 4K image.  The timed region itself runs on ONE stream, so that `value`,
+`ms_per_step` and `roofline.kernel_ms` describe the same thing; "two_streams" is the same region with consecutive frames on two streams.
 
   python bench.py --dry-run --gpus N   exercises the rank / aggregation code (process group, barriers, MAX over ranks, the single JSON
   line, cfg5's tile blocks) WITHOUT a GPU over gloo with a converter that only sleeps; the line says "data": "dry-run" and its numbers
@@ -55,7 +62,7 @@ sys.path.insert(0, str(ROOT))
 WIDTH, HEIGHT = 7680, 4320
 FRAMES_IN_FLIGHT = 4  # distinct frame buffers cycled by the timed loop (4 x 182 MB > Infinity Cache)
 DEEP_FRAMES = 12      # ... by the "deep_streaming" kernel timing (2.2 GB: inputs cannot stay in the Infinity Cache either)
-STREAMS = 2           # independent frames overlap head/tail on this many HIP streams
+STREAMS = 1           # the timed region's streams (2: consecutive frames overlap head and tail; measured as well, reported as "two_streams")
 ALGORITHMIC_BYTES_PER_PIXEL = 5.5  # 1.5 B read (Y + U/4 + V/4) + 4 B written (RGBA8), SURVEY.md 8d
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -297,18 +304,23 @@ def main():
     frames = make_frames(WIDTH, HEIGHT, DEEP_FRAMES)
     frames_4k = make_frames(WIDTH // 2, HEIGHT // 2, FRAMES_IN_FLIGHT)  # the north star's second plane size (3840x2160)
     n_streams = max(1, min(args.streams, FRAMES_IN_FLIGHT))
-    streams = [lib.avifhipStreamCreate() for _ in range(n_streams)]
+    streams = [lib.avifhipStreamCreate() for _ in range(max(n_streams, 2))]
     if any(not s for s in streams):
         raise SystemExit("bench.py: avifhipStreamCreate failed: " + lib.avifhipLastError().decode())
 
     convert = lib.avifhipImageYUVToRGBAsync
-    calls = [(frames[k][0].struct, frames[k][1].struct, streams[k % n_streams]) for k in range(FRAMES_IN_FLIGHT)]
 
-    def run(steps: int) -> None:
-        for k in range(steps):
-            a, b, s = calls[k % FRAMES_IN_FLIGHT]
-            if convert(a, b, s) != 0:
-                native.check(1, "avifhipImageYUVToRGBAsync")
+    def runner(count):
+        calls = [(frames[k][0].struct, frames[k][1].struct, streams[k % count]) for k in range(FRAMES_IN_FLIGHT)]
+
+        def run(steps: int) -> None:
+            for k in range(steps):
+                a, b, s = calls[k % FRAMES_IN_FLIGHT]
+                if convert(a, b, s) != 0:
+                    native.check(1, "avifhipImageYUVToRGBAsync")
+        return run
+
+    run = runner(n_streams)
 
     def device_sync() -> None:
         for s in streams:
@@ -324,6 +336,9 @@ def main():
     region_s = timed_regions(run, device_sync, args.steps, args.warmup, args.repeats, dist, torch)
     kernel_name = native.last_kernel()
     elapsed = median(region_s)
+    # the same region with consecutive frames on the other stream count (1 <-> 2): heads and tails of independent frames overlap on two
+    other_streams = 2 if n_streams == 1 else 1
+    other_s = timed_regions(runner(other_streams), device_sync, args.steps, args.warmup, max(3, args.repeats // 3), dist, torch)
 
     # ---- kernels alone: average launch duration from HIP events on the launch stream, single stream, back to back ----
     n4, imgs4, rgbs4 = _cycle_args(frames[:FRAMES_IN_FLIGHT])
@@ -334,10 +349,15 @@ def main():
         # 40 ms of the SAME kernel first: after a change of kernel the first ~10 ms of launches run up to 25 % slower (tests/tools/
         # sustain_probe.py, profiles/r03_sustain_probe.txt: the fp32 kernel 39.9, 34.8, 38.3 ... us per launch before it settles at 32-33),
         # then the median of 9 event-timed bursts of 40 launches (not the best one: the figure must agree with a profiler's average)
+        def checked(ms):
+            if ms < 0:
+                raise SystemExit("bench.py: a timing call failed: " + lib.avifhipLastError().decode())
+            return ms
+
         spent = 0.0
         while spent < 40.0:
-            spent += max(fn(*a, 0, 100, None), 1e-3) * 100
-        return median([fn(*a, 4, 40, None) for _ in range(9)])
+            spent += max(checked(fn(*a, 0, 100, None)), 1e-3) * 100
+        return median([checked(fn(*a, 4, 40, None)) for _ in range(9)])
 
     def set_arithmetic(use_integer: bool) -> None:
         for _, drgb in frames + frames_4k:
@@ -360,6 +380,8 @@ def main():
     ceil_ms_stream = burst(lib.avifhipTimeStreamCeiling, n4, imgs4, rgbs4)
     ceil_ms_deep = burst(lib.avifhipTimeStreamCeiling, nd, imgsd, rgbsd)
 
+    more = {} if (args.dry_run or rank != 0) else measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k)
+    set_arithmetic(integer)
     mp_per_step = WIDTH * HEIGHT / 1e6
     value = mp_per_step * args.steps * world / elapsed
     alg_bytes = ALGORITHMIC_BYTES_PER_PIXEL * WIDTH * HEIGHT
@@ -388,9 +410,18 @@ def main():
         "dtype": "i16" if integer else "f32",  # the arithmetic the path computes in: libyuv's fixed point in packed int16 lanes / libavif's fp32
         "data": "dry-run (no GPU, nothing converted: numbers are meaningless)" if args.dry_run else "synthetic",
         "value_basis": f"median of {len(region_s)} timed regions of {args.steps} steps each (min {1e3 * min(region_s) / args.steps:.5f}, max "
-                       f"{1e3 * max(region_s) / args.steps:.5f} ms/step); steps are issued round-robin on {n_streams} HIP streams, so "
-                       f"consecutive frames overlap head and tail and ms_per_step can be below roofline.kernel_ms (one kernel alone, single stream); "
-                       f"the input planes of the {FRAMES_IN_FLIGHT} cycled frames can stay in the Infinity Cache -- roofline.cold is the figure without that help",
+                       f"{1e3 * max(region_s) / args.steps:.5f} ms/step), host clock around back-to-back launches on {n_streams} HIP stream(s)"
+                       + (" -- one stream: ms_per_step is one kernel's duration plus what the launches leave between kernels, and roofline.kernel_ms "
+                          "(events on that stream) describes the same kernel" if n_streams == 1 else
+                          ", so consecutive frames overlap head and tail and ms_per_step can be below roofline.kernel_ms (one kernel alone, single stream)")
+                       + f"; the input planes of the {FRAMES_IN_FLIGHT} cycled frames can stay in the Infinity Cache -- roofline.cold is the figure without that help",
+        "two_streams" if n_streams == 1 else "one_stream": {
+            "what": f"the same timed region with consecutive frames issued round-robin on {other_streams} HIP stream(s)"
+                    + (": independent frames overlap each other's head and tail" if other_streams == 2 else ""),
+            "ms_per_step": round(1e3 * median(other_s) / args.steps, 5),
+            "value": round(mp_per_step * args.steps * world / median(other_s), 1),
+            "regions": len(other_s),
+        },
         "config": {
             "workload": "7680x4320 8-bit YUV420 BT.709 limited -> RGBA8, bilinear chroma upsampling, HBM-resident, "
                         f"{FRAMES_IN_FLIGHT} distinct frames cycled per rank on {n_streams} HIP streams",
@@ -437,6 +468,7 @@ def main():
             "fp32": block(timings["fp32"]["4k"], px4k),
         },
     }
+    out.update(more)
     # (names of round 2's line, kept for the profile tooling)
     out["roofline"]["deep_streaming"] = out["roofline"]["cold"]
     out["roofline"]["fp32_path" if integer else "integer_path"] = {k: out[other_fam][k] for k in ("kernel", "kernel_ms", "achieved", "frac")}
@@ -461,6 +493,145 @@ def main():
         lib.avifhipStreamDestroy(s)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
+    """The other BASELINE.json configurations, the byte-movement ceilings of the small plane sizes and the gain-map application, each measured
+    like roofline.kernel_ms: the kernel(s) alone, HIP events on the launch stream, 40 ms of the same launches first, then the median of 9 bursts.
+    Algorithmic bytes: SURVEY.md 8d (every input sample read once, every output byte written once)."""
+    BIL = abi.AVIF_CHROMA_UPSAMPLING_BILINEAR
+
+    def row(ms, alg_bytes, pixels, what, **extra):
+        gb = alg_bytes / (ms * 1e-3) / 1e9
+        return {"what": what, "kernel_ms": round(ms, 5), "algorithmic_bytes_per_launch": int(alg_bytes), "achieved": round(gb, 1),
+                "frac": round(gb / HBM_PEAK_GBPS, 4), "value": round(pixels / 1e6 / (ms * 1e-3), 1), "unit": "megapixels/s", **extra}
+
+    def y2r(w, h, depth, fmt, rng, mc, rgb_depth, alpha=False, premult=False, avoid=False, seed=0x12345678):
+        img = abi.make_yuv(w, h, depth, fmt, rng, mc, with_alpha=alpha)
+        synth.fill_yuv(img, seed)
+        rgb = abi.make_rgb(w, h, rgb_depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, alpha_premultiplied=premult, avoid_libyuv=avoid, allocate=False)
+        return device.DeviceYUV(img), device.DeviceRGB(rgb)
+
+    configs = {}
+    # cfg1: BASELINE.json configs[0], the reference's own CPU-runnable case -- 256x256 8-bit 4:2:0 BT.601 full range -> RGBA8, API defaults
+    pair = y2r(256, 256, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_FULL, 6, 8)
+    ms = burst(lib.avifhipTimeYUVToRGB, pair[0].struct, pair[1].struct)
+    configs["cfg1"] = row(ms, 5.5 * 256 * 256, 256 * 256, "256x256 8-bit 4:2:0 BT.601 full -> RGBA8, API defaults; one launch (0.36 MB: launch-bound)",
+                          kernel=native.last_kernel())
+    # cfg3: 8K 10-bit 4:4:4 BT.2020 full + alpha plane -> RGBA16 premultiplied (530 MB per frame: two frames cycled, nothing is cache-resident)
+    pairs = [y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, seed=0x12345678 + k) for k in range(2)]
+    imgs = (C.POINTER(abi.avifImage) * 2)(*[C.pointer(q[0].struct) for q in pairs])
+    rgbs = (C.POINTER(abi.avifRGBImage) * 2)(*[C.pointer(q[1].struct) for q in pairs])
+    ms = burst(lib.avifhipTimeYUVToRGBCycle, 2, imgs, rgbs)
+    configs["cfg3"] = row(ms, 16.0 * 7680 * 4320, 7680 * 4320, "7680x4320 10-bit 4:4:4 BT.2020 full + alpha -> RGBA16, alpha premultiplied in the same kernel; 2 frames cycled",
+                          kernel=native.last_kernel())
+    del pairs, imgs, rgbs
+    # cfg4: 4K RGBA8 -> 8-bit 4:2:0 BT.709 limited + alpha plane (6.5 B/pixel), the encode direction; same frame and 8 frames cycled (431 MB)
+    enc = []
+    for k in range(8):
+        rgb = abi.make_rgb(3840, 2160, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+        synth.fill_rgb(rgb, 0x12345678 + k % 2, opaque=True)
+        img = abi.make_yuv(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, with_alpha=True)
+        enc.append((device.DeviceYUV(img, upload=False), device.DeviceRGB(rgb, upload=True)))
+    imgs = (C.POINTER(abi.avifImage) * 8)(*[C.pointer(q[0].struct) for q in enc])
+    rgbs = (C.POINTER(abi.avifRGBImage) * 8)(*[C.pointer(q[1].struct) for q in enc])
+    ms_same = burst(lib.avifhipTimeRGBToYUV, enc[0][0].struct, enc[0][1].struct)
+    ms = burst(lib.avifhipTimeRGBToYUVCycle, 8, imgs, rgbs)
+    px4k = 3840 * 2160
+    configs["cfg4"] = row(ms, 6.5 * px4k, px4k, "3840x2160 RGBA8 -> 8-bit 4:2:0 BT.709 limited + alpha plane (avifImageRGBToYUV); 8 frames cycled",
+                          kernel=native.last_kernel(), same_frame=row(ms_same, 6.5 * px4k, px4k, "the same frame every launch (54 MB: cache-resident)"))
+    del enc, imgs, rgbs
+    # cfg5: 64 separately stored 1920x1080 10-bit 4:2:0 tiles -> RGBA (10 bits in 16-bit containers, API defaults), 11 B/pixel
+    tiles = []
+    for t in range(64):
+        img = abi.make_yuv(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+        synth.fill_yuv(img, 0x12345678 + t)
+        tiles.append(device.DeviceYUV(img))
+    timgs = (C.POINTER(abi.avifImage) * 64)(*[C.pointer(t.struct) for t in tiles])
+
+    def tile_outputs():
+        outs = [device.DeviceRGB(abi.make_rgb(1920, 1080, 10, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False)) for _ in range(64)]
+        return outs, (C.POINTER(abi.avifRGBImage) * 64)(*[C.pointer(o.struct) for o in outs])
+
+    outs_a, rgbs_a = tile_outputs()
+    px_tiles = 64 * 1920 * 1080
+    ms = burst(lib.avifhipTimeYUVToRGBBatch, 64, timgs, rgbs_a, None)
+    kernel = native.last_kernel()
+    # a decoder that rotates its output buffers sends a fresh descriptor table with every batch; one that reuses them launches on the table
+    # the device still holds (avifhipTableUploadCount): both regimes
+    outs_b, rgbs_b = tile_outputs()
+    uploads0 = lib.avifhipTableUploadCount()
+    t0 = time.perf_counter()
+    n_alt = 200
+    for k in range(n_alt):
+        native.check(lib.avifhipImageYUVToRGBBatchAsync(64, timgs, rgbs_b if k & 1 else rgbs_a, None, None), "avifhipImageYUVToRGBBatchAsync")
+    native.check(lib.avifhipSynchronize(None), "avifhipSynchronize")
+    ms_alt = (time.perf_counter() - t0) / n_alt * 1e3
+    configs["cfg5x64"] = row(ms, 11.0 * px_tiles, px_tiles, "64 separately stored 1920x1080 10-bit 4:2:0 tiles -> 64 RGBA (10 bits in 16-bit containers) images, ONE batched "
+                             "launch per step (avifhipImageYUVToRGBBatchAsync); the same buffers every step: the descriptor table stays on the device",
+                             kernel=kernel, rotating_outputs={"what": "two sets of output buffers alternated: every batch uploads its descriptor table; host clock "
+                                                              f"around {n_alt} back-to-back calls", "ms_per_batch": round(ms_alt, 5),
+                                                              "table_uploads_per_batch": round((lib.avifhipTableUploadCount() - uploads0) / n_alt, 2)})
+    del outs_a, outs_b, rgbs_a, rgbs_b
+    # ... and into ONE 15360x8640 canvas with the chroma filter reaching across the seams (avifhipGridYUVToRGBAsync), what avifdec's grid path does
+    canvas = device.DeviceRGB(abi.make_rgb(15360, 8640, 10, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False))
+    grid = native.avifhipGrid(8, 8, 15360, 8640)
+    ms = burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas.struct)
+    configs["cfg5grid"] = row(ms, 11.0 * px_tiles, px_tiles, "the same 64 tiles -> one 15360x8640 RGBA canvas, converted where they lie, seams as on the stitched canvas "
+                              "(avifhipGridYUVToRGBAsync: every kernel of the call)", kernel=native.last_kernel())
+    del canvas, tiles, timgs
+
+    # the chip's ceiling for short jobs: the no-arithmetic byte-movement kernel on 4K and 1080p 8-bit 4:2:0 -> RGBA8 frames (4 frames cycled)
+    nk, imgsk, rgbsk = _cycle_args(frames_4k)
+    ceil4k = burst(lib.avifhipTimeStreamCeiling, nk, imgsk, rgbsk)
+    small = [y2r(1920, 1080, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, seed=0x12345678 + k) for k in range(4)]
+    n1, imgs1, rgbs1 = _cycle_args(small)
+    ceil1080 = burst(lib.avifhipTimeStreamCeiling, n1, imgs1, rgbs1)
+    conv1080 = burst(lib.avifhipTimeYUVToRGBCycle, n1, imgs1, rgbs1)
+    px1080 = 1920 * 1080
+    ceilings = {
+        "what": "same bytes, same lane-to-byte mapping, no arithmetic (avifhipTimeStreamCeiling), 8-bit 4:2:0 -> RGBA8, 4 frames cycled: what the chip sustains on a job this short",
+        "planes_4k": row(ceil4k, 5.5 * px4k, px4k, "3840x2160 (45.6 MB per launch)"),
+        "planes_1080p": row(ceil1080, 5.5 * px1080, px1080, "1920x1080 (11.4 MB per launch)",
+                            conversion=row(conv1080, 5.5 * px1080, px1080, "the conversion kernel on the same frames (API defaults)", kernel=native.last_kernel())),
+    }
+    del small
+
+    # avifRGBImageApplyGainMap (SURVEY.md 8f rank 2): 3840x2160 RGBA8 sRGB / BT.709 base -> RGBA10 PQ / BT.2020, 8-bit 4:4:4 gain map of the same size
+    base = abi.make_rgb(3840, 2160, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+    synth.fill_rgb(base, 0x4242)
+    gimg = abi.make_yuv(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 6)
+    synth.fill_yuv(gimg, 0x99)
+    gm = abi.avifGainMap()
+    for i in range(3):
+        gm.gainMapMin[i].n, gm.gainMapMin[i].d = 0, 1
+        gm.gainMapMax[i].n, gm.gainMapMax[i].d = 3, 1
+        gm.gainMapGamma[i].n, gm.gainMapGamma[i].d = 1, 1
+        gm.baseOffset[i].n, gm.baseOffset[i].d = 1, 64
+        gm.alternateOffset[i].n, gm.alternateOffset[i].d = 1, 64
+    gm.baseHdrHeadroom.n, gm.baseHdrHeadroom.d, gm.alternateHdrHeadroom.n, gm.alternateHdrHeadroom.d = 0, 1, 3, 1
+    gm.useBaseColorSpace = 1
+    dbase, dgimg = device.DeviceRGB(base, upload=True), device.DeviceYUV(gimg)
+    gm.image = C.pointer(dgimg.struct)
+    dout = device.DeviceRGB(abi.make_rgb(3840, 2160, 10, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False, allocate=False))
+    clli, diag = abi.avifContentLightLevelInformationBox(), abi.avifDiagnostics()
+    ms_kernel = burst(lambda w, n, st: lib.avifhipTimeRGBImageApplyGainMap(dbase.struct, 1, 13, C.byref(gm), 3.0, 9, 16, dout.struct, w, max(n, 2), st))
+    kernel = native.last_kernel()
+    calls = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        for _ in range(20):
+            native.check(lib.avifhipRGBImageApplyGainMapAsync(dbase.struct, 1, 13, C.byref(gm), 3.0, 9, 16, dout.struct, C.byref(clli), C.byref(diag), None),
+                         "avifhipRGBImageApplyGainMapAsync")
+        calls.append((time.perf_counter() - t0) / 20 * 1e3)
+    gain_bytes = (4 + 3 + 8) * px4k  # base pixels + gain-map planes + tone-mapped pixels
+    gainmap = row(ms_kernel, (4 + 4 + 8) * px4k, px4k, "avifRGBImageApplyGainMap, 3840x2160 RGBA8 sRGB/BT.709 -> RGBA10 PQ/BT.2020, 8-bit 4:4:4 gain map: the apply kernel alone "
+                  "(base pixels 4 + gain map as RGBA 4 + tone-mapped pixels 8 B/pixel)", kernel=kernel,
+                  whole_call={"what": "the whole call (gain map YUV -> RGB, apply, statistics back on the host: it waits for its stream), host clock, median of 7 x 20 calls; "
+                                      "algorithmic bytes base 4 + gain-map planes 3 + output 8 B/pixel",
+                              "ms_per_call": round(median(calls), 5), "algorithmic_bytes_per_call": int(gain_bytes),
+                              "frac": round(gain_bytes / (median(calls) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "maxCLL": int(clli.maxCLL), "maxPALL": int(clli.maxPALL)})
+    return {"configs": configs, "ceilings": ceilings, "gainmap": gainmap}
 
 
 def timed_regions(run_steps, sync, steps, warmup, repeats, dist, torch):

@@ -187,6 +187,19 @@ AVIFHIP_API avifResult avifhipRGBImageApplyGainMapAsync(const avifRGBImage * bas
                                                         avifContentLightLevelInformationBox * clli,
                                                         avifDiagnostics * diag,
                                                         void * hipStream);
+/* Measurement helper (bench.py): the apply kernel of that ...Async call alone, milliseconds per launch over `iters` back-to-back launches
+ * (HIP events on the launch stream) after `warmup` untimed ones; the gain map's own conversion and the tables are prepared once.  < 0 on failure. */
+AVIFHIP_API double avifhipTimeRGBImageApplyGainMap(const avifRGBImage * baseImage,
+                                                   avifColorPrimaries baseColorPrimaries,
+                                                   avifTransferCharacteristics baseTransferCharacteristics,
+                                                   const avifGainMap * gainMap,
+                                                   float hdrHeadroom,
+                                                   avifColorPrimaries outputColorPrimaries,
+                                                   avifTransferCharacteristics outputTransferCharacteristics,
+                                                   avifRGBImage * toneMappedImage,
+                                                   int warmup,
+                                                   int iters,
+                                                   void * hipStream);
 /* Gain-map computation (the encode side): drop-in for avifRGBImageComputeGainMap (reference include/avif/avif.h:1688-1722,
  * src/gainmap.c:535-843): host images in; the metadata fractions of `gainMap` and the (malloc'ed) planes of gainMap->image -- whose
  * width, height, depth, yuvFormat (range, matrix) carry the request, as in the reference -- out.  Byte-identical planes and
@@ -345,6 +358,13 @@ AVIFHIP_API double avifhipTimeYUVToRGBCycle(uint32_t count, const avifImage * co
  * reads every plane sample once and writes every output byte once with NO arithmetic (kernels_bench.hip; the RGB buffers receive
  * meaningless bytes).  Negative for other formats. */
 AVIFHIP_API double avifhipTimeStreamCeiling(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
+/* The same event timing for the encode direction over `count` cycled frames, for a batch call (avifhipImageYUVToRGBBatchAsync: milliseconds
+ * per batch) and for a grid call (avifhipGridYUVToRGBAsync: milliseconds per canvas, every kernel the call launches included). */
+AVIFHIP_API double avifhipTimeRGBToYUVCycle(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
+AVIFHIP_API double avifhipTimeYUVToRGBBatch(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects,
+                                            int warmup, int iters, void * hipStream);
+AVIFHIP_API double avifhipTimeGridYUVToRGB(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
+                                           avifBool alphaIsLimitedRange, avifRGBImage * rgbCanvas, int warmup, int iters, void * hipStream);
 
 /* Synthetic planes for benchmarks/tests: xorshift32 stream
  * (x^=x<<13; x^=x>>17; x^=x<<5), one draw per sample, value = lo + draw % (hi-lo+1), written

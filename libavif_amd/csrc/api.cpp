@@ -870,6 +870,52 @@ extern "C" double avifhipTimeRGBToYUV(avifImage * image, const avifRGBImage * rg
     return ms < 0 ? -1.0 : (double)ms / iters;
 }
 
+// the remaining timing helpers share one shape: `warmup` untimed calls, then `iters` calls between two events on the launch stream
+template <typename Call>
+static double timeCalls(void * hipStream, int warmup, int iters, Call call)
+{
+    if (iters <= 0 || ensureContext() != AVIF_RESULT_OK)
+        return -1.0;
+    hipStream_t stream = pickStream(hipStream);
+    for (int k = 0; k < warmup; ++k)
+        if (call(k, stream) != AVIF_RESULT_OK)
+            return -1.0;
+    hipEvent_t t0, t1;
+    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess)
+        return -1.0;
+    (void)hipEventRecord(t0, stream);
+    bool ok = true;
+    for (int k = 0; k < iters && ok; ++k)
+        ok = call(k, stream) == AVIF_RESULT_OK;
+    (void)hipEventRecord(t1, stream);
+    float ms = -1.0f;
+    if (hipEventSynchronize(t1) != hipSuccess || hipEventElapsedTime(&ms, t0, t1) != hipSuccess)
+        ms = -1.0f;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return (!ok || ms < 0) ? -1.0 : (double)ms / iters;
+}
+
+extern "C" double avifhipTimeRGBToYUVCycle(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream)
+{
+    if (count == 0 || !images || !rgbs)
+        return -1.0;
+    return timeCalls(hipStream, warmup, iters, [&](int k, hipStream_t s) { return avifhipImageRGBToYUVAsync(images[k % count], rgbs[k % count], s); });
+}
+
+extern "C" double avifhipTimeYUVToRGBBatch(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects, int warmup,
+                                           int iters, void * hipStream)
+{
+    return timeCalls(hipStream, warmup, iters, [&](int, hipStream_t s) { return avifhipImageYUVToRGBBatchAsync(count, images, rgbs, rects, s); });
+}
+
+extern "C" double avifhipTimeGridYUVToRGB(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
+                                          avifBool alphaIsLimitedRange, avifRGBImage * rgbCanvas, int warmup, int iters, void * hipStream)
+{
+    return timeCalls(hipStream, warmup, iters,
+                     [&](int, hipStream_t s) { return avifhipGridYUVToRGBAsync(grid, colorTiles, alphaTiles, alphaIsLimitedRange, rgbCanvas, s); });
+}
+
 // Synthetic planes, BASELINE.md section 3 (xorshift32, one draw per sample, row-major)
 extern "C" uint32_t avifhipSynthFill(uint32_t state, uint8_t * plane, uint32_t rowBytes, uint32_t width, uint32_t height,
                                      uint32_t bytesPerSample, uint32_t lo, uint32_t hi)

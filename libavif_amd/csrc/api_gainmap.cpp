@@ -355,6 +355,23 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         HIP_TRY(hipHostMalloc(&tls.gainMapPartials, (size_t)kGainMapMaxGroups * sizeof(GainMapPartial), hipHostMallocDefault));
     A.partials = (GainMapPartial *)tls.gainMapPartials;
     uint32_t partials = 0;
+    if (tls.gainMapTimeIters > 0) { // avifhipTimeRGBImageApplyGainMap: the apply kernel alone, back to back, between two events
+        for (int k = 0; k < tls.gainMapTimeWarmup; ++k)
+            HIP_TRY(launchGainMapApply(A, stream, &partials));
+        hipEvent_t t0, t1;
+        HIP_TRY(hipEventCreate(&t0));
+        HIP_TRY(hipEventCreate(&t1));
+        (void)hipEventRecord(t0, stream);
+        for (int k = 0; k < tls.gainMapTimeIters - 1; ++k)
+            (void)launchGainMapApply(A, stream, &partials);
+        (void)hipEventRecord(t1, stream); // (the last of the iters launches is the call's own, below)
+        float ms = -1.0f;
+        if (hipEventSynchronize(t1) != hipSuccess || hipEventElapsedTime(&ms, t0, t1) != hipSuccess)
+            ms = -1.0f;
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+        tls.gainMapTimedMs = (ms < 0 || tls.gainMapTimeIters < 2) ? -1.0 : (double)ms / (tls.gainMapTimeIters - 1);
+    }
     const hipError_t e = launchGainMapApply(A, stream, &partials);
     if (e != hipSuccess)
         return hipFailed(e, "gain map kernel launch");
@@ -444,6 +461,21 @@ extern "C" avifResult avifhipRGBImageApplyGainMapAsync(const avifRGBImage * base
     }
     return applyGainMapOnDevice(baseImage, baseColorPrimaries, baseTransferCharacteristics, gainMap, gainMap->image, weight, outputColorPrimaries,
                                 outputTransferCharacteristics, toneMappedImage, clli, diag, stream);
+}
+
+// the apply kernel of that call alone: milliseconds per launch over back-to-back launches (HIP events on the launch stream)
+extern "C" double avifhipTimeRGBImageApplyGainMap(const avifRGBImage * baseImage, avifColorPrimaries baseColorPrimaries,
+                                                  avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap, float hdrHeadroom,
+                                                  avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
+                                                  avifRGBImage * toneMappedImage, int warmup, int iters, void * hipStream)
+{
+    if (iters < 2 || ensureContext() != AVIF_RESULT_OK)
+        return -1.0;
+    tls.gainMapTimeWarmup = warmup < 0 ? 0 : warmup, tls.gainMapTimeIters = iters, tls.gainMapTimedMs = -1.0;
+    const avifResult r = avifhipRGBImageApplyGainMapAsync(baseImage, baseColorPrimaries, baseTransferCharacteristics, gainMap, hdrHeadroom, outputColorPrimaries,
+                                                          outputTransferCharacteristics, toneMappedImage, nullptr, nullptr, hipStream);
+    tls.gainMapTimeIters = 0;
+    return (r == AVIF_RESULT_OK) ? tls.gainMapTimedMs : -1.0;
 }
 
 // host-resident images, like the reference: the tone-mapped image's pixels are (re)allocated with malloc (src/gainmap.c:112-114)

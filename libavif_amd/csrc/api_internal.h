@@ -123,6 +123,8 @@ struct Context
     Scratch gainMap[11]; // gain maps: [0] output pixels, [1] gain map as RGB, [2] tables, [3] statistics / partials, [4] scaled planes, [5] base pixels;
                          // computation: [6] tables, [7] ratios, [8] histograms, [9] alternate pixels, [10] gain-map planes
     GainMapTableCache gainMapCache; // what gainMap[2] holds
+    int gainMapTimeWarmup = 0, gainMapTimeIters = 0; // avifhipTimeRGBImageApplyGainMap in progress on this thread: repeat the apply kernel
+    double gainMapTimedMs = -1.0;                    // ... and what it measured
     void * gainMapPartials = nullptr; // apply: the statistics as the workgroups leave them (pinned host memory, kGainMapMaxGroups partials)
     // batch descriptor tables travel through a ring of kTableRing slots (pinned host memory + the matching slice of `table`), uploaded on
     // `upStream`: the host prepares batch n + 1 and its table crosses the link while batch n computes (api_batch.cpp: batchAsyncImpl)

@@ -25,9 +25,9 @@ EXPORTED_SYMBOLS = [
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
-    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipTableUploadCount", "avifhipCalcYUVCoefficients",
+    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipTimeRGBToYUVCycle", "avifhipTimeYUVToRGBBatch", "avifhipTimeGridYUVToRGB", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipTableUploadCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
-    "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap",
+    "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipTimeRGBImageApplyGainMap", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap",
 ]
 
 class avifSampleTransformToken(C.Structure):
@@ -88,6 +88,9 @@ def load() -> C.CDLL:
         "avifhipDeviceMemset": (i32, [vp, i32, C.c_size_t]),
         "avifhipTimeYUVToRGB": (C.c_double, [P_IMG, P_RGB, i32, i32, vp]),
         "avifhipTimeRGBToYUV": (C.c_double, [P_IMG, P_RGB, i32, i32, vp]),
+        "avifhipTimeRGBToYUVCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
+        "avifhipTimeYUVToRGBBatch": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), P_RECT, i32, i32, vp]),
+        "avifhipTimeGridYUVToRGB": (C.c_double, [C.POINTER(avifhipGrid), C.POINTER(P_IMG), C.POINTER(P_IMG), i32, P_RGB, i32, i32, vp]),
         "avifhipSynthFill": (u32, [u32, vp, u32, u32, u32, u32, u32, u32]),
         "avifhipStreamCreate": (vp, []),
         "avifhipStreamDestroy": (None, [vp]),
@@ -118,6 +121,8 @@ def load() -> C.CDLL:
                                               C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics)]),
         "avifhipRGBImageApplyGainMapAsync": (i32, [P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
                                                    C.POINTER(avifContentLightLevelInformationBox), C.POINTER(avifDiagnostics), vp]),
+        "avifhipTimeRGBImageApplyGainMap": (C.c_double, [P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
+                                                         i32, i32, vp]),
         "avifhipRGBImageComputeGainMap": (i32, [P_RGB, C.c_uint16, C.c_uint16, P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.POINTER(avifDiagnostics)]),
         "avifhipImageComputeGainMap": (i32, [P_IMG, P_IMG, C.POINTER(avifGainMap), C.POINTER(avifDiagnostics)]),
         "avifhipImageApplyGainMap": (i32, [P_IMG, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,
