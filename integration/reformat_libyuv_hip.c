@@ -26,6 +26,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* Below this many pixels a conversion costs less on the CPU than the PCIe round trip (env override for tests). */
 static uint32_t avifHipMinPixels(void)
@@ -51,12 +52,46 @@ static avifResult avifHipOrFallback(avifResult r)
     return (r == AVIF_RESULT_UNKNOWN_ERROR || r == AVIF_RESULT_OUT_OF_MEMORY) ? AVIF_RESULT_NOT_IMPLEMENTED : r;
 }
 
+/* Folding libavif's follow-up steps into the colour hook (below) leans on two properties of libavif's own code: which steps
+ * avifImageYUVToRGBImpl issues after its colour hook, and that it issues them right away on the same thread (src/reformat.c:1574-1590,
+ * :1649-1678; src/alpha.c:151-166).  They were checked for libavif 1.4.x; in a libavif of another major.minor this file still works as a
+ * backend, but the colour hook does only its own job (avifhipImageYUVToRGBColorOnly) and every follow-up call is a real pass.
+ * AVIFHIP_FOLD=0 / 1 in the environment overrides (read at every call: cheap, and tests switch it). */
+#if defined(AVIF_VERSION_MAJOR) && defined(AVIF_VERSION_MINOR) && AVIF_VERSION_MAJOR == 1 && AVIF_VERSION_MINOR == 4
+#define AVIFHIP_FOLD_VALIDATED 1
+#else
+#define AVIFHIP_FOLD_VALIDATED 0
+#endif
+static avifBool avifHipFoldEnabled(void)
+{
+    const char * e = getenv("AVIFHIP_FOLD");
+    if (e && *e)
+        return atoi(e) != 0;
+    /* (the headers this file was compiled against AND the library it runs in: a distribution may swap the shared object) */
+    return AVIFHIP_FOLD_VALIDATED && strncmp(avifVersion(), "1.4.", 4) == 0;
+}
+/* A note libavif has not consumed after this long is dropped: its follow-up call comes microseconds after the colour hook returns
+ * (AVIFHIP_FOLD_EXPIRY_MS overrides; tests) */
+static uint64_t avifHipFoldExpiryNs(void)
+{
+    const char * e = getenv("AVIFHIP_FOLD_EXPIRY_MS");
+    return (uint64_t)((e && *e) ? atoi(e) : 1000) * 1000000ull;
+}
+static uint64_t avifHipNowNs(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
 /* One-shot note from the colour hook to the hooks libavif calls right after it on the same thread for the same pixels
  * (src/reformat.c:1574-1590: avifRGBImagePremultiplyAlpha / UnpremultiplyAlpha, then avifRGBImageToF16): avifhipImageYUVToRGBHook has
  * already produced the FINAL pixels, so those calls are answered without moving the image across the bus again.  A step is skipped only
  * if it is the very next hook call of this thread, for the same buffer and geometry, and a sample of the pixels still reads as the colour
- * hook left it; every other hook call drops the note.  (Between the two calls there is only libavif's own code: no application code runs
- * inside avifImageYUVToRGB, and a later, separate avifRGBImagePremultiplyAlpha of the application finds no note.) */
+ * hook left it, and the note is fresh; every other hook call drops the note.  (Between the two calls there is only libavif's own code: no
+ * application code runs inside avifImageYUVToRGB, and a later, separate avifRGBImagePremultiplyAlpha of the application finds no note:
+ * libavif consumed it.  Should a libavif ever NOT issue the follow-up -- the version gate above is there so that this cannot happen
+ * silently -- the note dies with the thread's next hook call or of old age, whichever comes first.) */
 typedef struct avifHipFoldNote
 {
     const uint8_t * pixels;
@@ -64,6 +99,7 @@ typedef struct avifHipFoldNote
     avifRGBFormat format;
     uint32_t steps; /* AVIFHIP_FOLDED_* still to be answered */
     uint64_t sample;
+    uint64_t armedNs; /* when the colour hook left it */
 } avifHipFoldNote;
 static _Thread_local avifHipFoldNote avifHipNote;
 
@@ -92,7 +128,8 @@ static avifBool avifHipTakeFoldedStep(const avifRGBImage * rgb, uint32_t step)
 {
     avifHipFoldNote * n = &avifHipNote;
     const avifBool match = (n->steps & step) && n->pixels == rgb->pixels && n->width == rgb->width && n->height == rgb->height &&
-                           n->rowBytes == rgb->rowBytes && n->depth == rgb->depth && n->format == rgb->format && n->sample == avifHipSamplePixels(rgb);
+                           n->rowBytes == rgb->rowBytes && n->depth == rgb->depth && n->format == rgb->format &&
+                           avifHipNowNs() - n->armedNs <= avifHipFoldExpiryNs() && n->sample == avifHipSamplePixels(rgb);
     if (!match) {
         n->steps = 0;
         return AVIF_FALSE;
@@ -117,13 +154,15 @@ avifResult avifImageYUVToRGBLibYUV(const avifImage * image, avifRGBImage * rgb, 
     if (!avifHipWorthIt(image->width, image->height))
         return AVIF_RESULT_NOT_IMPLEMENTED;
     uint32_t folded = 0;
-    const avifResult r = avifHipOrFallback(avifhipImageYUVToRGBHook(image, rgb, reformatAlpha, &folded));
+    const avifResult r = avifHipOrFallback(avifHipFoldEnabled() ? avifhipImageYUVToRGBHook(image, rgb, reformatAlpha, &folded)
+                                                                : avifhipImageYUVToRGBColorOnly(image, rgb, reformatAlpha));
     if (r == AVIF_RESULT_OK && reformatAlpha)
         *alphaReformattedWithLibYUV = AVIF_TRUE; /* copied / rescaled from the alpha plane, or opaque fill */
     if (r == AVIF_RESULT_OK && folded) {
         avifHipNote.pixels = rgb->pixels, avifHipNote.width = rgb->width, avifHipNote.height = rgb->height, avifHipNote.rowBytes = rgb->rowBytes;
         avifHipNote.depth = rgb->depth, avifHipNote.format = rgb->format;
         avifHipNote.sample = avifHipSamplePixels(rgb);
+        avifHipNote.armedNs = avifHipNowNs();
         avifHipNote.steps = folded;
     }
     return r;

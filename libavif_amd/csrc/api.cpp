@@ -5,6 +5,8 @@
 // (RGB -> YUV, alpha), api_apps.cpp (Sample Transform, crop / rotate / mirror, row packing), api_gainmap.cpp, api_scale.cpp.
 #include "api_internal.h"
 
+#include <map>
+
 #include <algorithm>
 
 #include <unistd.h>
@@ -103,7 +105,8 @@ struct ContextLease
         // the thread's last use of the device scratch is marked now: the stream it ran on may be the thread's own, gone before the
         // context's next holder asks (ScratchScope)
         if (context->scratchPending && !context->scratchMarked && context->scratchUsed) {
-            if (hipEventRecord(context->scratchUsed, context->scratchStream) == hipSuccess) {
+            if (context->scratchGeneration && ownedStreamGeneration(context->scratchStream) == context->scratchGeneration &&
+                hipEventRecord(context->scratchUsed, context->scratchStream) == hipSuccess) {
                 context->scratchMarked = true;
             } else {
                 (void)hipGetLastError();
@@ -114,7 +117,8 @@ struct ContextLease
         for (int k = 0; k < Context::kTableRing; ++k) { // likewise the batch tables' slots (api_batch.cpp batchAsyncImpl)
             if (!context->tableUnmarked[k] || !context->tableConsumed[k])
                 continue;
-            if (hipEventRecord(context->tableConsumed[k], context->tableLastStream[k]) != hipSuccess) {
+            if (ownedStreamGeneration(context->tableLastStream[k]) != context->tableLastGeneration[k] ||
+                hipEventRecord(context->tableConsumed[k], context->tableLastStream[k]) != hipSuccess) {
                 (void)hipGetLastError();
                 (void)hipDeviceSynchronize();
             }
@@ -270,11 +274,15 @@ ScratchScope::ScratchScope(hipStream_t s) : stream(s), result(AVIF_RESULT_OK)
         // The previous user's stream is marked only now that somebody on another stream needs to wait for it: an event recorded here
         // covers everything that stream was given before, and calls that stay on one stream (nearly all) pay for no event at all -- a
         // record behind every launch kept the next kernel waiting for the signal (plane scaling: 24 us per call around an 18 us kernel).
-        hipError_t e = tls.scratchMarked ? hipSuccess : hipEventRecord(tls.scratchUsed, tls.scratchStream);
+        // (only a stream the library owns, still of the generation noted, is trusted with the deferred record)
+        hipError_t e = tls.scratchMarked ? hipSuccess
+                       : (tls.scratchGeneration && ownedStreamGeneration(tls.scratchStream) == tls.scratchGeneration)
+                           ? hipEventRecord(tls.scratchUsed, tls.scratchStream)
+                           : hipErrorInvalidHandle;
         if (e == hipSuccess)
             e = hipStreamWaitEvent(s, tls.scratchUsed, 0);
         if (e != hipSuccess) {
-            // (the caller may have destroyed that stream since: everything the device was given finishes first, then)
+            // (that stream is gone: everything the device was given finishes first, then)
             (void)hipGetLastError();
             e = hipDeviceSynchronize();
         }
@@ -286,8 +294,13 @@ ScratchScope::ScratchScope(hipStream_t s) : stream(s), result(AVIF_RESULT_OK)
 ScratchScope::~ScratchScope()
 {
     tls.scratchStream = stream;
+    tls.scratchGeneration = ownedStreamGeneration(stream);
     tls.scratchPending = true;
     tls.scratchMarked = false;
+    // a stream of the caller's own may be destroyed (and its address reused) before anybody asks: its use is marked while the handle is
+    // known to be good; the library's own streams wait until a call on another stream needs the mark (ScratchScope::ScratchScope)
+    if (!tls.scratchGeneration && tls.scratchUsed && hipEventRecord(tls.scratchUsed, stream) == hipSuccess)
+        tls.scratchMarked = true;
 }
 
 // Enqueues a copy of a small host table to device memory.  An asynchronous copy from pageable memory may still be reading
@@ -480,6 +493,32 @@ avifResult stagePixels(avifRGBImage * view, bool upload)
 hipStream_t pickStream(void * hipStream)
 {
     return hipStream ? (hipStream_t)hipStream : tls.stream;
+}
+
+namespace {
+struct OwnedStreams
+{
+    std::mutex mutex;
+    std::map<hipStream_t, uint64_t> generation;
+    uint64_t next = 2; // (1: a context's own stream)
+};
+OwnedStreams & ownedStreams()
+{
+    static OwnedStreams * set = new OwnedStreams; // never destroyed, like the context pool
+    return *set;
+}
+} // namespace
+
+uint64_t ownedStreamGeneration(hipStream_t stream)
+{
+    if (!stream)
+        return 0;
+    if (stream == tls.stream || stream == tls.upStream || stream == tls.downStream)
+        return 1; // lives as long as the context that remembers it
+    OwnedStreams & set = ownedStreams();
+    std::lock_guard<std::mutex> lock(set.mutex);
+    auto it = set.generation.find(stream);
+    return it == set.generation.end() ? 0 : it->second;
 }
 
 // malloc-backed avifImageAllocatePlanes, reference src/avif.c:431-490
@@ -675,6 +714,9 @@ extern "C" void * avifhipStreamCreate(void)
         hipFailed(e, "hipStreamCreateWithFlags");
         return nullptr;
     }
+    OwnedStreams & set = ownedStreams();
+    std::lock_guard<std::mutex> lock(set.mutex);
+    set.generation[s] = set.next++;
     return (void *)s;
 }
 extern "C" void avifhipStreamDestroy(void * hipStream)
@@ -691,6 +733,12 @@ extern "C" void avifhipStreamDestroy(void * hipStream)
             (void)hipStreamSynchronize((hipStream_t)hipStream);
             tls.tableUnmarked[k] = false;
         }
+    }
+    {
+        // (from here on another thread's deferred record on this handle finds no generation and waits for the device instead)
+        OwnedStreams & set = ownedStreams();
+        std::lock_guard<std::mutex> lock(set.mutex);
+        set.generation.erase((hipStream_t)hipStream);
     }
     (void)hipStreamDestroy((hipStream_t)hipStream);
 }

@@ -125,7 +125,10 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         }
     }
     // (same stream: that stream waited for the resident slot's upload when it ran the batch that brought it)
-    const bool resident = comparable && tls.residentSlot >= 0 && tls.residentBytes == bytes && tls.residentStream == stream && tls.residentAllTiled == allTiled &&
+    // (... which holds only for a stream the library owns: a caller's handle may be a new stream at a recycled address)
+    const uint64_t streamGeneration = ownedStreamGeneration(stream);
+    const bool resident = comparable && streamGeneration && tls.residentSlot >= 0 && tls.residentBytes == bytes && tls.residentStream == stream &&
+                          tls.residentGeneration == streamGeneration && tls.residentAllTiled == allTiled &&
                           memcmp((const uint8_t *)tls.pinnedTable + (size_t)tls.residentSlot * tls.pinnedTableCapacity, pinned, bytes) == 0;
     if (resident) {
         --tls.tableSlot; // the slot just filled was not used
@@ -142,9 +145,10 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         *residentOut = resident;
     if (!resident) {
         if (tls.tableUnmarked[slot]) { // its last readers ran off the resident copy and left no event (below): marked now
-            if (hipEventRecord(tls.tableConsumed[slot], tls.tableLastStream[slot]) != hipSuccess) {
+            if (ownedStreamGeneration(tls.tableLastStream[slot]) != tls.tableLastGeneration[slot] ||
+                hipEventRecord(tls.tableConsumed[slot], tls.tableLastStream[slot]) != hipSuccess) {
                 (void)hipGetLastError();
-                HIP_TRY(hipDeviceSynchronize()); // (a stream the caller has destroyed since)
+                HIP_TRY(hipDeviceSynchronize()); // (a stream destroyed since)
             }
             tls.tableUnmarked[slot] = false;
         }
@@ -159,16 +163,17 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         hipStream_t s;
         bool armed, lazy;
         uint32_t slot;
+        uint64_t generation;
         ~MarkConsumed()
         {
             if (!armed)
                 return;
             if (lazy)
-                tls.tableUnmarked[slot] = true, tls.tableLastStream[slot] = s;
+                tls.tableUnmarked[slot] = true, tls.tableLastStream[slot] = s, tls.tableLastGeneration[slot] = generation;
             else
                 (void)hipEventRecord(ev, s);
         }
-    } markConsumed = { tls.tableConsumed[slot], stream, true, resident, slot };
+    } markConsumed = { tls.tableConsumed[slot], stream, true, resident, slot, streamGeneration }; // (resident implies an owned stream)
     auto upload = [&](void * to, const void * from, size_t n) -> hipError_t {
         if (resident)
             return hipSuccess;
@@ -181,7 +186,8 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         if (ue == hipSuccess)
             ue = hipStreamWaitEvent(stream, tls.tableCopied[slot], 0);
         if (ue == hipSuccess && comparable)
-            tls.residentSlot = (int)slot, tls.residentBytes = bytes, tls.residentStream = stream, tls.residentAllTiled = allTiled;
+            tls.residentSlot = (int)slot, tls.residentBytes = bytes, tls.residentStream = stream, tls.residentGeneration = streamGeneration,
+            tls.residentAllTiled = allTiled;
         return ue;
     };
     hipError_t e = hipSuccess;
@@ -331,8 +337,8 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
         uint32_t slot;
         ~SlotRead()
         {
-            if (lazy)
-                tls.tableUnmarked[slot] = true, tls.tableLastStream[slot] = s;
+            if (lazy) // (a resident table implies a stream the library owns: batchAsyncImpl)
+                tls.tableUnmarked[slot] = true, tls.tableLastStream[slot] = s, tls.tableLastGeneration[slot] = ownedStreamGeneration(s);
             else
                 (void)hipEventRecord(ev, s);
         }

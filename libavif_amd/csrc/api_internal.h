@@ -136,12 +136,14 @@ struct Context
     hipEvent_t tableConsumed[kTableRing] = {}; // the kernels reading the slot's device slice are done
     bool tableUnmarked[kTableRing] = {};        // the slot's last readers left no tableConsumed record (they ran off the resident copy) ...
     hipStream_t tableLastStream[kTableRing] = {}; // ... on this stream: recorded when an upload wants the slot, or at the context's hand-back
+    uint64_t tableLastGeneration[kTableRing] = {}; // ... which was an owned stream of this generation (ownedStreamGeneration)
     bool tableSlotIdle[kTableRing] = { true, true, true, true }; // no upload out of the slot's pinned memory since the thread last waited for tableCopied
     // the most recent upload, if small: a batch whose table is byte-identical launches on the copy the device still holds (batchAsyncImpl)
     static constexpr size_t kResidentTableMax = 256 * 1024;
     int residentSlot = -1;
     size_t residentBytes = 0;
     hipStream_t residentStream = nullptr;
+    uint64_t residentGeneration = 0;
     bool residentAllTiled = false;
     void * pinnedUpload = nullptr; // staging for small host tables (grid tile tables, scale schedules): a ring of kTableRing slots, so that the
     size_t pinnedUploadCapacity = 0; // calling thread does not wait for the previous call's upload (which sits behind that call's kernels); bytes per slot
@@ -150,6 +152,7 @@ struct Context
     // last asynchronous user of the device scratch above (ScratchScope)
     hipEvent_t scratchUsed = nullptr;
     hipStream_t scratchStream = nullptr;
+    uint64_t scratchGeneration = 0; // of scratchStream when it was noted (0: a caller's own stream -- its use was marked right away)
     bool scratchPending = false;
     bool scratchMarked = false; // scratchUsed already covers the last use (recorded when the thread handed the context back)
     char lastError[512] = { 0 };
@@ -251,6 +254,11 @@ inline uint32_t alignUp(uint32_t v, uint32_t a)
     return (v + a - 1) / a * a;
 }
 hipStream_t pickStream(void * hipStream);
+// Streams the library made -- the context's own, and those of avifhipStreamCreate until avifhipStreamDestroy -- carry a generation number
+// (never reused); 0 for any other handle (a hipStream_t of the caller's, which may be destroyed, and its address reused, behind the
+// library's back).  Only owned streams may be remembered past a call: the deferred event records of the device scratch and of the batch
+// tables, and the "this stream has already waited for the resident table" shortcut, check the generation before they trust a handle.
+uint64_t ownedStreamGeneration(hipStream_t stream);
 
 struct PlaneGeometry
 {

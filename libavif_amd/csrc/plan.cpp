@@ -369,6 +369,9 @@ bool attenuateCovered(const avifRGBImage * rgb) // src/reformat_libyuv.c:1120-11
 
 } // namespace
 
+// NOTE for whoever adds an input here (or to prepareState): rebindYuvToRgbPlan below lists, by hand, every field of the two images a plan is
+// derived from -- a field missing there makes tiles 1 .. N-1 of a batch inherit tile 0's plan.  tests/test_host_plans.py
+// (test_rebound_plans_equal_plans_made_from_scratch) compares the two byte for byte over random jobs; extend its generator as well.
 avifResult makeYuvToRgbPlan(const avifImage * image, const avifRGBImage * rgb, const avifCropRect * rect, int arithMode, uint32_t tuning, YuvToRgbPlan * out,
                             bool colorOnly, bool reformatAlphaHook)
 {

@@ -91,3 +91,92 @@ def test_rect_entry_point_matches_oracle_rect(hip):
             drgb.download_into_host()
             wb = case.w * abi.rgb_pixel_size(case.rgb_format, case.rgb_depth)
             assert np.array_equal(got.pixels[:, :wb], want.pixels[:, :wb]), (case.ident(), rect, native.last_kernel(), H.describe_diff(want.pixels[:, :wb], got.pixels[:, :wb]))
+
+
+# ---- two PROCESSES with the product converter: the multi-process HIP path itself, on the one GPU a test box has ----
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _hip_rank(rank: int, world: int, port: int, out_dir: str) -> None:
+    """One rank of the farm as bench.py --gpus N runs it, except that every rank uses device 0 and the ranks meet over gloo (RCCL
+    wants one GPU per rank): own process, own HIP context and streams, HipRectConverter on this rank's block of tiles."""
+    import os
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    sys.path.insert(0, str(root / "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch
+    import torch.distributed as dist
+
+    import harness as Hh
+    from libavif_amd import farm as F, native as N
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = N.load()
+        assert lib.avifhipDeviceCount() >= 1
+        N.check(lib.avifhipSetDevice(0), "avifhipSetDevice")
+        lib.avifhipSetArithmetic(0)
+        conv = F.HipRectConverter()
+        for k, (case, (tw, th)) in enumerate(CASES[:3]):
+            canvas = Hh.make_y2r_inputs(case)  # the same decoded canvas on every rank
+            out = Hh.make_y2r_output(case)
+            rects = F.grid_rects(case.w, case.h, tw, th)
+            launches = lib.avifhipLaunchCount()
+            elapsed = F.timed_region(lambda: F.convert_shard(canvas, out, rects, rank, world, conv), lambda: N.check(lib.avifhipSynchronize(None)), dist)
+            assert lib.avifhipLaunchCount() > launches, "the HIP path did not run"
+            t = torch.tensor([conv.bytes_up, conv.bytes_down], dtype=torch.int64)
+            total = t.clone()
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)
+            np.save(os.path.join(out_dir, f"rgb_{k}_{rank}.npy"), out.pixels)
+            np.save(os.path.join(out_dir, f"meta_{k}_{rank}.npy"), np.array([conv.bytes_up, conv.bytes_down, int(total[0]), int(total[1]), int(elapsed * 1e9)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_share_one_gpu(hip, tmp_path):
+    """The first 8-GPU run must not be the multi-process HIP path's first run: two ranks (torch.distributed over gloo), both on device 0, each
+    converting its block of tiles through avifhipImageYUVToRGBRects; the union equals the oracle's whole-canvas conversion, nobody writes into
+    the other's tiles, each rank moves about half of the canvas over the host link and the timed region reduces to one MAX."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    world = 2
+    mp.spawn(_hip_rank, args=(world, _free_port(), os.fspath(tmp_path)), nprocs=world, join=True)
+    for k, (case, (tw, th)) in enumerate(CASES[:3]):
+        res, whole = H.run_y2r(H.oracle_backend() if case.avoid_libyuv else H.oracle_libyuv_backend(), case)
+        assert res == 0
+        rects = farm.grid_rects(case.w, case.h, tw, th)
+        px = abi.rgb_pixel_size(case.rgb_format, case.rgb_depth)
+        union = np.full_like(whole, H.FILL_BYTE)
+        metas = [np.load(tmp_path / f"meta_{k}_{r}.npy").tolist() for r in range(world)]
+        for r in range(world):
+            got = np.load(tmp_path / f"rgb_{k}_{r}.npy")
+            mine = farm.shard(len(rects), r, world)
+            for t, (x, y, w, h) in enumerate(rects):
+                tile = got[y:y + h, x * px:(x + w) * px]
+                if t in mine:
+                    union[y:y + h, x * px:(x + w) * px] = tile
+                else:
+                    assert (tile == H.FILL_BYTE).all(), f"rank {r} wrote into tile {t} of the other rank"
+        wb = case.w * px
+        assert np.array_equal(union[:, :wb], whole[:, :wb]), (case.ident(), H.describe_diff(whole[:, :wb], union[:, :wb]))
+        assert metas[0][2:4] == metas[1][2:4] and metas[0][4] == metas[1][4]  # the all-reduced totals and the MAX of the timed region
+        total_up, total_down = metas[0][2], metas[0][3]
+        assert total_down == case.w * case.h * px
+        canvas, out = H.make_y2r_inputs(case), H.make_y2r_output(case)
+        for r, (up, down, *_) in enumerate(metas):
+            # exactly what the library announces for this rank's block of tiles (the cropped last column / row make the blocks unequal), and
+            # never the whole canvas
+            assert (up, down) == farm.planned_transfers(canvas, out, [rects[t] for t in farm.shard(len(rects), r, world)]), (case.ident(), r, metas)
+            assert 0 < up < total_up and 0 < down < total_down, metas

@@ -151,6 +151,58 @@ def test_avifyuv_prints_the_same_on_the_builds(apps, mode):
             assert launches > 0
 
 
+# ---------------------------------------------------------------------------------------------------
+# seam A: the UNMODIFIED reference programs (linked against the shared, backend-less libavif_ref.so) with the interposer preloaded
+
+
+def _run_preloaded(exe: Path, args, timeout=300):
+    """LD_PRELOAD = the interposer + the launch-count shim; returns (stdout, launches)."""
+    preload = oracle_lib.ORACLE_DIR.parent / "libavif_amd" / "csrc" / "libavifhip_preload.so"
+    assert preload.exists(), "libavifhip_preload.so is missing"
+    env = dict(os.environ, AVIFHIP_MIN_PIXELS="0", LD_PRELOAD=f"{preload}:{REF_DIR / 'liblaunchcount.so'}")
+    env.pop("AVIFHIP_ARITHMETIC", None)  # the interposer pins what the interposed libavif computes itself (no libyuv there: fp32)
+    proc = subprocess.run([os.fspath(exe)] + [str(a) for a in args], capture_output=True, text=True, env=env, timeout=timeout)
+    assert proc.returncode == 0, f"{exe.name} {args} under the interposer: rc={proc.returncode}\n{proc.stdout[-2000:]}\n{proc.stderr[-2000:]}"
+    lines = [ln for ln in proc.stderr.splitlines() if ln.startswith("avifhip launches=")]
+    assert lines, proc.stderr[-2000:]
+    return proc.stdout, int(lines[-1].split("=")[1])
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_seam_a_y4m_to_png_under_the_interposer(apps, tmp_path, fixture):
+    """`LD_PRELOAD=libavifhip_preload.so refapp_ref y4m2png`: avifPNGWrite's avifImageYUVToRGB (apps/shared/avifpng.c:688) lands in the HIP
+    kernels, the files equal the ones the same program writes on its own."""
+    src = DATA / f"{fixture}.y4m"
+    _, planes = read_y4m(src)
+    for depth in (8, 16):
+        out_plain, _ = _run(apps / "refapp_ref", ["y4m2png", src, tmp_path / f"plain{depth}", depth])
+        out_hip, launches = _run_preloaded(apps / "refapp_ref", ["y4m2png", src, tmp_path / f"hip{depth}", depth])
+        assert out_plain.splitlines()[-1] == out_hip.splitlines()[-1] == f"frames={len(planes)}"
+        assert launches >= len(planes), (fixture, depth, launches)
+        for k in range(len(planes)):
+            assert (tmp_path / f"plain{depth}_{k}.png").read_bytes() == (tmp_path / f"hip{depth}_{k}.png").read_bytes(), (fixture, depth, k)
+
+
+@pytest.mark.parametrize("yuv", [("420", 8, 1, "limited"), ("444", 8, 6, "full"), ("422", 10, 9, "limited")])
+def test_seam_a_png_to_y4m_under_the_interposer(apps, tmp_path, yuv):
+    """... and avifReadImage's avifImageRGBToYUV (apps/shared/avifpng.c:552) likewise."""
+    fmt, depth, mc, rng = yuv
+    _run(apps / "refapp_ref", ["y4m2png", DATA / "kodim03_yuv420_8bpc.y4m", tmp_path / "src", 8])
+    png = tmp_path / "src_0.png"
+    out_plain, _ = _run(apps / "refapp_ref", ["png2y4m", png, tmp_path / "plain.y4m", fmt, depth, mc, rng])
+    out_hip, launches = _run_preloaded(apps / "refapp_ref", ["png2y4m", png, tmp_path / "hip.y4m", fmt, depth, mc, rng])
+    assert out_plain.splitlines()[-1] == out_hip.splitlines()[-1] and launches > 0
+    assert (tmp_path / "plain.y4m").read_bytes() == (tmp_path / "hip.y4m").read_bytes()
+
+
+@pytest.mark.parametrize("mode", ["rgb", "premultiply"])
+def test_seam_a_avifyuv_under_the_interposer(apps, mode):
+    out_plain, _ = _run(apps / "avifyuv_ref", ["-m", mode])
+    out_hip, launches = _run_preloaded(apps / "avifyuv_ref", ["-m", mode])
+    assert out_plain.splitlines() == out_hip.splitlines() and len(out_plain.splitlines()) >= 5
+    assert launches > 0
+
+
 def test_avifyuv_drift_bounded(apps):
     """-m drift walks the whole RGB cube of every depth (hours on a CPU): both builds run for a bounded time with line-buffered output and
     must agree on every line both of them finished -- at least the 36 combinations of 8-bit RGB (tests/avifyuv.c:118-152)."""

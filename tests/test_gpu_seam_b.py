@@ -275,3 +275,38 @@ def test_changed_pixels_between_hook_calls_fall_back_to_the_staged_path(libs, hi
             twin.pixels[...] = folded ^ 0x01
             assert o.premultiply(twin.struct) == 0
             assert np.array_equal(out.pixels, twin.pixels), H.describe_diff(twin.pixels, out.pixels)
+
+
+def test_fold_can_be_switched_off_and_notes_expire(libs, hip_auto_arithmetic, monkeypatch):
+    """The fold rests on libavif's own call sequence: it is compiled in only for the libavif it was validated against (1.4.x) and
+    AVIFHIP_FOLD=0 switches it off -- the colour hook then does only its own job and libavif's follow-up premultiply is a real pass with
+    the same bytes at the end.  A note that nobody consumed is dropped after AVIFHIP_FOLD_EXPIRY_MS."""
+    import time
+
+    be, _ = libs
+    lib, o = hip_auto_arithmetic, H.oracle_libyuv_backend()
+    c = _fold_case()
+    want_r, want = H.run_y2r(o, c)
+    before = lib.avifhipLaunchCount()
+    got_r, got = H.run_y2r(be, c)
+    folded_launches = lib.avifhipLaunchCount() - before
+    monkeypatch.setenv("AVIFHIP_FOLD", "0")
+    before = lib.avifhipLaunchCount()
+    off_r, off = H.run_y2r(be, c)
+    unfolded_launches = lib.avifhipLaunchCount() - before
+    monkeypatch.delenv("AVIFHIP_FOLD")
+    assert got_r == off_r == want_r == 0 and np.array_equal(got, want) and np.array_equal(off, want), c.ident()
+    assert unfolded_launches > folded_launches, (folded_launches, unfolded_launches)
+    # the hooks called directly: a colour hook whose follow-up never comes, then -- much later for a note -- a premultiply of the same buffer
+    raw = C.CDLL(os.fspath(BACKEND_SO), mode=os.RTLD_LOCAL)
+    y2r = raw.avifImageYUVToRGBLibYUV
+    y2r.restype, y2r.argtypes = C.c_int, [C.POINTER(abi.avifImage), C.POINTER(abi.avifRGBImage), C.c_int, C.POINTER(C.c_int)]
+    pre = raw.avifRGBImagePremultiplyAlphaLibYUV
+    pre.restype, pre.argtypes = C.c_int, [C.POINTER(abi.avifRGBImage)]
+    monkeypatch.setenv("AVIFHIP_FOLD_EXPIRY_MS", "5")
+    img, out, flag = H.make_y2r_inputs(c), H.make_y2r_output(c), C.c_int(0)
+    assert y2r(img.struct, out.struct, 1, C.byref(flag)) == 0
+    time.sleep(0.05)
+    before = lib.avifhipLaunchCount()
+    assert pre(out.struct) == 0
+    assert lib.avifhipLaunchCount() > before, "an expired note must not answer the call"

@@ -20,7 +20,7 @@ SO = ROOT / "tests" / "tools" / "libhostlogic.so"
 
 @pytest.fixture(scope="module")
 def host():
-    srcs = [ROOT / "tests" / "tools" / "hostlogic.cpp", CSRC / "scale_plan.cpp", CSRC / "gainmap_plan.cpp"]
+    srcs = [ROOT / "tests" / "tools" / "hostlogic.cpp", CSRC / "scale_plan.cpp", CSRC / "gainmap_plan.cpp", CSRC / "plan.cpp"]
     deps = srcs + [CSRC / "scale_plan.h", CSRC / "gainmap_plan.h", CSRC / "plan.h"]
     if not SO.exists() or any(d.stat().st_mtime > SO.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", f"-I{CSRC}", f"-I{ROOT / 'include'}", "-o", os.fspath(SO)] + [os.fspath(s) for s in srcs],
@@ -333,3 +333,15 @@ def test_cover_rectangle_of_a_fused_crop(host):
         candidates = [y0 for y0 in range(cy & ~1, -1, -2) if (cy & ~1) - y0 + 2 <= run or y0 == cy & ~1]
         best = max(score(y0) for y0 in candidates)
         assert score(y) == best or (best == 1000 and offset(y) == 0), (cx, cy, cw, ch, turns, mirror, pb, address, y, [(c, offset(c)) for c in candidates[:10]])
+
+
+def test_rebound_plans_equal_plans_made_from_scratch(host):
+    """Tiles 1 .. N-1 of a batch get their plan by rebinding tile 0's (plan.cpp: rebindYuvToRgbPlan), which lists by hand what plan derivation
+    reads.  Over random configurations, buffers, pitches and rectangles the rebound plan must equal the plan made from scratch BYTE FOR BYTE
+    (padding included: the resident batch table is compared with memcmp), and every difference in a field a plan depends on must be refused."""
+    host.hostCheckRebind.restype = C.c_int
+    host.hostCheckRebind.argtypes = [C.c_uint32, C.c_int] + [C.POINTER(C.c_int)] * 3
+    refused, mutated, rebound = C.c_int(), C.c_int(), C.c_int()
+    bad = host.hostCheckRebind(20260922, 20000, C.byref(refused), C.byref(mutated), C.byref(rebound))
+    assert bad == 0, bad
+    assert rebound.value > 5000 and mutated.value > 1000 and refused.value == mutated.value, (rebound.value, mutated.value, refused.value)

@@ -167,3 +167,120 @@ int hostCheckCodeSteps(float sign, float minRatio, float maxRatio, float minLog2
 }
 
 } // extern "C"
+
+
+// ---- rebindYuvToRgbPlan against makeYuvToRgbPlan (plan.cpp): the tiles 1 .. N-1 of a batch get their plans by rebinding tile 0's; whatever
+// plan derivation reads, the rebound plan must be the plan made from scratch, byte for byte (the batch tables are compared with memcmp) ----
+namespace {
+
+struct Job
+{
+    avifImage image;
+    avifRGBImage rgb;
+};
+
+uint32_t pick(std::mt19937 & rng, std::initializer_list<uint32_t> v)
+{
+    return *(v.begin() + rng() % v.size());
+}
+
+// a random configuration; `other` = the same configuration over different buffers, pitches (same alignment class) and, when asked, one changed field
+void drawJobs(std::mt19937 & rng, Job & a, Job & b, int mutate)
+{
+    memset(&a, 0, sizeof(a));
+    avifImage & im = a.image;
+    avifRGBImage & rgb = a.rgb;
+    im.width = 64 + 8 * (rng() % 64), im.height = 16 + 2 * (rng() % 64);
+    im.depth = pick(rng, { 8, 10, 12 });
+    im.yuvFormat = (avifPixelFormat)pick(rng, { AVIF_PIXEL_FORMAT_YUV444, AVIF_PIXEL_FORMAT_YUV422, AVIF_PIXEL_FORMAT_YUV420, AVIF_PIXEL_FORMAT_YUV400 });
+    im.yuvRange = (avifRange)pick(rng, { AVIF_RANGE_LIMITED, AVIF_RANGE_FULL });
+    im.matrixCoefficients = (avifMatrixCoefficients)pick(rng, { 1, 5, 6, 9, 2, 7 });
+    im.colorPrimaries = 1, im.transferCharacteristics = 13;
+    im.alphaPremultiplied = rng() % 4 == 0;
+    const bool alpha = rng() % 2;
+    const uint32_t bps = im.depth > 8 ? 2 : 1, cw = (im.yuvFormat == AVIF_PIXEL_FORMAT_YUV444) ? im.width : (im.width + 1) / 2;
+    const uint32_t pitchY = (im.width * bps + 255) & ~255u, pitchC = (cw * bps + 255) & ~255u;
+    uintptr_t at = 0x10000000;
+    for (int p = 0; p < 3; ++p) {
+        if (p && im.yuvFormat == AVIF_PIXEL_FORMAT_YUV400)
+            break;
+        im.yuvPlanes[p] = (uint8_t *)at, im.yuvRowBytes[p] = p ? pitchC : pitchY;
+        at += 0x1000000;
+    }
+    if (alpha)
+        im.alphaPlane = (uint8_t *)at, im.alphaRowBytes = pitchY;
+    rgb.width = im.width, rgb.height = im.height;
+    rgb.depth = pick(rng, { 8, 8, 10, 12, 16 });
+    rgb.format = (avifRGBFormat)pick(rng, { AVIF_RGB_FORMAT_RGB, AVIF_RGB_FORMAT_RGBA, AVIF_RGB_FORMAT_ARGB, AVIF_RGB_FORMAT_BGR, AVIF_RGB_FORMAT_BGRA, AVIF_RGB_FORMAT_ABGR });
+    rgb.chromaUpsampling = (avifChromaUpsampling)pick(rng, { 0, 1, 2, 3, 4 });
+    rgb.avoidLibYUV = rng() % 2, rgb.ignoreAlpha = rng() % 4 == 0, rgb.alphaPremultiplied = rng() % 3 == 0, rgb.isFloat = (rgb.depth == 16) && rng() % 2;
+    rgb.maxThreads = 1;
+    const uint32_t px = ((rgb.format == AVIF_RGB_FORMAT_RGB || rgb.format == AVIF_RGB_FORMAT_BGR) ? 3 : 4) * (rgb.depth > 8 ? 2 : 1);
+    rgb.rowBytes = (im.width * px + 255) & ~255u;
+    rgb.pixels = (uint8_t *)0x40000000;
+    b = a;
+    // the other tile: other addresses (same alignment), larger pitches
+    for (int p = 0; p < 3; ++p)
+        if (b.image.yuvPlanes[p])
+            b.image.yuvPlanes[p] += 0x4000 * (1 + rng() % 7), b.image.yuvRowBytes[p] += 256 * (rng() % 3);
+    if (b.image.alphaPlane)
+        b.image.alphaPlane += 0x8000, b.image.alphaRowBytes += 256;
+    b.rgb.pixels += 0x100000 * (1 + rng() % 5), b.rgb.rowBytes += 256 * (rng() % 2);
+    switch (mutate) { // a difference a plan depends on: rebinding must refuse
+        case 1: b.image.matrixCoefficients = (avifMatrixCoefficients)(im.matrixCoefficients == 1 ? 6 : 1); break;
+        case 2: b.image.yuvRange = (avifRange)(im.yuvRange == AVIF_RANGE_FULL ? AVIF_RANGE_LIMITED : AVIF_RANGE_FULL); break;
+        case 3: b.rgb.format = (avifRGBFormat)(rgb.format == AVIF_RGB_FORMAT_RGBA ? AVIF_RGB_FORMAT_BGRA : AVIF_RGB_FORMAT_RGBA); break;
+        case 4: b.rgb.alphaPremultiplied = !rgb.alphaPremultiplied; break;
+        case 5: b.image.depth = (im.depth == 8) ? 10 : 8; break;
+        case 6: b.rgb.avoidLibYUV = !rgb.avoidLibYUV; break;
+        case 7: b.image.height += 2, b.rgb.height += 2; break;
+        case 8: b.rgb.chromaUpsampling = (avifChromaUpsampling)(rgb.chromaUpsampling == 3 ? 4 : 3); break;
+        default: break;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+// `count` random jobs: returns how many rebound plans differ from the plan made from scratch (must be 0); *refused counts the mutated jobs
+// rebinding turned down (must equal *mutated: every one of those differences changes or may change the plan)
+int hostCheckRebind(uint32_t seed, int count, int * refused, int * mutated, int * rebound)
+{
+    std::mt19937 rng(seed);
+    int bad = 0;
+    *refused = *mutated = *rebound = 0;
+    for (int k = 0; k < count; ++k) {
+        const int mutate = (rng() % 4 == 0) ? 1 + (int)(rng() % 8) : 0;
+        Job a, b;
+        drawJobs(rng, a, b, mutate);
+        const int arith = (int)(rng() % 3);
+        const uint32_t tuning = 0;
+        avifCropRect rect = { 0, 0, b.image.width, b.image.height };
+        const bool useRect = rng() % 2;
+        if (useRect)
+            rect.x = 8 * (rng() % 4), rect.y = 2 * (rng() % 4), rect.width -= rect.x + 8 * (rng() % 3), rect.height -= rect.y + 2 * (rng() % 3);
+        YuvToRgbPlan proto, scratch, reboundPlan;
+        if (makeYuvToRgbPlan(&a.image, &a.rgb, nullptr, arith, tuning, &proto) != AVIF_RESULT_OK)
+            continue; // (an invalid combination: nothing to rebind)
+        avifResult rr = AVIF_RESULT_OK;
+        memset(&reboundPlan, 0xAB, sizeof(reboundPlan)); // padding bytes must come out of the rebind as the maker leaves them
+        const bool did = rebindYuvToRgbPlan(proto, &a.image, &a.rgb, &b.image, &b.rgb, useRect ? &rect : nullptr, &reboundPlan, &rr);
+        if (mutate) {
+            ++*mutated;
+            *refused += did ? 0 : 1;
+            continue;
+        }
+        if (!did) {
+            ++bad;
+            continue;
+        }
+        ++*rebound;
+        const avifResult mr = makeYuvToRgbPlan(&b.image, &b.rgb, useRect ? &rect : nullptr, arith, tuning, &scratch);
+        if (mr != rr || (mr == AVIF_RESULT_OK && memcmp(&scratch, &reboundPlan, sizeof(scratch)) != 0))
+            ++bad;
+    }
+    return bad;
+}
+
+} // extern "C"
