@@ -560,17 +560,20 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     # a decoder that rotates its output buffers sends a fresh descriptor table with every batch; one that reuses them launches on the table
     # the device still holds (avifhipTableUploadCount): both regimes
     outs_b, rgbs_b = tile_outputs()
-    uploads0 = lib.avifhipTableUploadCount()
-    t0 = time.perf_counter()
-    n_alt = 200
-    for k in range(n_alt):
-        native.check(lib.avifhipImageYUVToRGBBatchAsync(64, timgs, rgbs_b if k & 1 else rgbs_a, None, None), "avifhipImageYUVToRGBBatchAsync")
-    native.check(lib.avifhipSynchronize(None), "avifhipSynchronize")
-    ms_alt = (time.perf_counter() - t0) / n_alt * 1e3
+    n_alt, alt = 100, []
+    for rep in range(4):  # (the first pass is not timed: it is the new buffers' first touch)
+        uploads0 = lib.avifhipTableUploadCount()
+        t0 = time.perf_counter()
+        for k in range(n_alt):
+            native.check(lib.avifhipImageYUVToRGBBatchAsync(64, timgs, rgbs_b if k & 1 else rgbs_a, None, None), "avifhipImageYUVToRGBBatchAsync")
+        native.check(lib.avifhipSynchronize(None), "avifhipSynchronize")
+        if rep:
+            alt.append((time.perf_counter() - t0) / n_alt * 1e3)
+    ms_alt = median(alt)
     configs["cfg5x64"] = row(ms, 11.0 * px_tiles, px_tiles, "64 separately stored 1920x1080 10-bit 4:2:0 tiles -> 64 RGBA (10 bits in 16-bit containers) images, ONE batched "
                              "launch per step (avifhipImageYUVToRGBBatchAsync); the same buffers every step: the descriptor table stays on the device",
                              kernel=kernel, rotating_outputs={"what": "two sets of output buffers alternated: every batch uploads its descriptor table; host clock "
-                                                              f"around {n_alt} back-to-back calls", "ms_per_batch": round(ms_alt, 5),
+                                                              f"around {n_alt} back-to-back calls, median of {len(alt)} passes", "ms_per_batch": round(ms_alt, 5),
                                                               "table_uploads_per_batch": round((lib.avifhipTableUploadCount() - uploads0) / n_alt, 2)})
     del outs_a, outs_b, rgbs_a, rgbs_b
     # ... and into ONE 15360x8640 canvas with the chroma filter reaching across the seams (avifhipGridYUVToRGBAsync), what avifdec's grid path does

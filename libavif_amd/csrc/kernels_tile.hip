@@ -269,6 +269,19 @@ double planeBytesPerPixel(const YuvToRgbPlan & p, const TileKey & k)
 constexpr double kStreamPlaneBytes = 128.0 * 1048576.0;
 } // namespace
 
+// which single alpha mode a job with pending alpha arithmetic asks for (tile_impl.h computeTile MULSEL): 1 / 2 in-loop multiply / un-multiply,
+// 3 / 4 integer post-multiply / un-multiply; 0: none of the four (or AVIFHIP_TUNING asks for the kernel with every mode compiled in)
+static int alphaSelOf(const tile::TileArgs & a)
+{
+    if (a.tuning & TUNE_ALL_ALPHA_MODES)
+        return 0;
+    if (a.postMul == MUL_NONE)
+        return a.inLoopMul == MUL_MULTIPLY ? 1 : (a.inLoopMul == MUL_UNMULTIPLY ? 2 : 0);
+    if (a.inLoopMul == MUL_NONE)
+        return a.postMul == MUL_MULTIPLY ? 3 : (a.postMul == MUL_UNMULTIPLY ? 4 : 0);
+    return 0;
+}
+
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)
 {
     const TileKey k = keyFor(plan);
@@ -277,6 +290,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     const TileArgs A = distillArgs(plan);
     TileLaunch L;
     L.args = &A;
+    L.alphaSel = alphaSelOf(A);
     L.table = nullptr;
     L.count = 1;
     L.stream = stream;
@@ -325,6 +339,7 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
         *kernelName = kernelNameFor(k, representative.tuning);
     TileLaunch L;
     L.args = nullptr;
+    L.alphaSel = alphaSelOf(distillArgs(representative)); // (all jobs of a batch share their configuration)
     L.table = static_cast<const TileArgs *>(deviceTileTable);
     L.count = count;
     L.stream = stream;

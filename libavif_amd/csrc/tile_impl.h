@@ -726,8 +726,8 @@ __device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, 
 // transposes through LDS.  Separate instantiations: the rows of a whole tile held in registers cost the row-wise kernels their occupancy.
 enum MapMode : int { MAP_NONE = 0, MAP_ROWS = 1, MAP_TURNED = 2 };
 // MULSEL (kernels with pending alpha arithmetic): 0 = the mode is read from the job (a wave-uniform branch around every row: all of them
-// compiled in), 1 = in-loop multiply, 3 = integer post-multiply compiled in alone -- what premultiplied destinations (Android's bitmaps,
-// cfg3) ask for.  With every mode in one kernel cfg3's took 76 KB of code and 116 registers (four waves per SIMD); its own: 28 KB, 94
+// compiled in; only AVIFHIP_TUNING's TUNE_ALL_ALPHA_MODES asks for it now), 1 / 2 = in-loop multiply / un-multiply, 3 / 4 = integer post-
+// multiply / un-multiply compiled in alone (selOfAlphaModes) -- 1 and 3 are what premultiplied destinations (Android's bitmaps, cfg3) ask for.  With every mode in one kernel cfg3's took 76 KB of code and 116 registers (four waves per SIMD); its own: 28 KB, 94
 // registers.  The big kernel's speed depends on where the compiler happens to lay its blocks (84 us in one build, 100-102 in two others
 // that differed only in code it never executes: the eight unrolled row bodies a wave walks through are spread over more code than the
 // instruction cache holds); the small one ran at 78.8-82.6 us in every build measured.
@@ -759,8 +759,8 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 #ifdef AVIFHIP_PROBE_MULMODE // instruction-count probes only (tests/tools/isa_count.py): one alpha mode compiled in
     const int inLoopMode = (AVIFHIP_PROBE_MULMODE) <= 2 ? (AVIFHIP_PROBE_MULMODE) : MUL_NONE, postMode = (AVIFHIP_PROBE_MULMODE) > 2 ? (AVIFHIP_PROBE_MULMODE) - 2 : MUL_NONE;
 #else
-    const int inLoopMode = MULSEL == 0 ? A.inLoopMul : (MULSEL == 1 ? (int)MUL_MULTIPLY : (int)MUL_NONE);
-    const int postMode = MULSEL == 0 ? A.postMul : (MULSEL == 3 ? (int)MUL_MULTIPLY : (int)MUL_NONE);
+    const int inLoopMode = MULSEL == 0 ? A.inLoopMul : (MULSEL == 1 ? (int)MUL_MULTIPLY : (MULSEL == 2 ? (int)MUL_UNMULTIPLY : (int)MUL_NONE));
+    const int postMode = MULSEL == 0 ? A.postMul : (MULSEL == 3 ? (int)MUL_MULTIPLY : (MULSEL == 4 ? (int)MUL_UNMULTIPLY : (int)MUL_NONE));
 #endif
     // 3-channel pixels: bytes of the band's row segment that exist (storeRowContiguous)
     const uint32_t segBytes = ((A.w4 - c.bandX < (uint32_t)kBandW) ? A.w4 - c.bandX : (uint32_t)kBandW) * kPixBytes;
@@ -1321,16 +1321,16 @@ __global__ __launch_bounds__(256) void yuvToRgbTileSoloKernel(TileArgs A, PkGeom
     }
 }
 
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false>
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false, int MULSEL = 0>
 __global__ __launch_bounds__(256) void yuvToRgbTileSoloBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
     const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, g, lds, xchg);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(job, g, lds, xchg);
     } else {
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, g, lds, nullptr);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(job, g, lds, nullptr);
     }
 }
 
@@ -1467,6 +1467,30 @@ hipError_t launchSoloMapped(const TileLaunch & L)
     return hipGetLastError();
 }
 
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool MUL, int MULSEL>
+hipError_t launchSoloSel(const TileLaunch & L, uint32_t nsw, const PkGeom & g, dim3 grid, dim3 block)
+{
+    if (L.table && L.streamLoads && sizeof(YT) == 2) { // batches of 16-bit planes beyond the Infinity Cache: streaming loads
+        if constexpr (sizeof(YT) == 2) {
+            if (nsw == 4)
+                hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, true, MULSEL>), grid, block, 0, L.stream, L.table, g);
+            else
+                hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, true, MULSEL>), grid, block, 0, L.stream, L.table, g);
+        }
+    } else if (L.table) {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, false, MULSEL>), grid, block, 0, L.stream, L.table, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, false, MULSEL>), grid, block, 0, L.stream, L.table, g);
+    } else {
+        if (nsw == 4)
+            hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, MULSEL>), grid, block, 0, L.stream, *L.args, g);
+        else
+            hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, MULSEL>), grid, block, 0, L.stream, *L.args, g);
+    }
+    return hipGetLastError();
+}
+
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool MUL>
 hipError_t launchSolo(const TileLaunch & L)
 {
@@ -1475,51 +1499,17 @@ hipError_t launchSolo(const TileLaunch & L)
     pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(blocks, 1, L.count);
-    if (L.table && L.streamLoads && sizeof(YT) == 2) { // batches of 16-bit planes beyond the Infinity Cache: streaming loads
-        if constexpr (sizeof(YT) == 2) {
-            if (nsw == 4)
-                hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, true>), grid, block, 0, L.stream, L.table, g);
-            else
-                hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, true>), grid, block, 0, L.stream, L.table, g);
+    if constexpr (MUL) {
+        // jobs with pending alpha arithmetic: the kernel with that one mode compiled in (computeTile MULSEL; kernels_tile.hip alphaSelOf)
+        switch (L.alphaSel) {
+            case 1: return launchSoloSel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>(L, nsw, g, grid, block);
+            case 2: return launchSoloSel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>(L, nsw, g, grid, block);
+            case 3: return launchSoloSel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 3>(L, nsw, g, grid, block);
+            case 4: return launchSoloSel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4>(L, nsw, g, grid, block);
+            default: break;
         }
-    } else if (L.table) {
-        if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, L.table, g);
-        else
-            hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, g);
-    } else {
-        // single images with a pending alpha multiply: the kernel with that one mode compiled in (computeTile MULSEL)
-        int sel = 0;
-        if constexpr (MUL) {
-            if (L.args->tuning & TUNE_ALL_ALPHA_MODES)
-                sel = 0;
-            else if (L.args->inLoopMul == MUL_MULTIPLY && L.args->postMul == MUL_NONE)
-                sel = 1;
-            else if (L.args->inLoopMul == MUL_NONE && L.args->postMul == MUL_MULTIPLY)
-                sel = 3;
-        }
-        if constexpr (MUL) {
-            if (sel == 1) {
-                if (nsw == 4)
-                    hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, 1>), grid, block, 0, L.stream, *L.args, g);
-                else
-                    hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, 1>), grid, block, 0, L.stream, *L.args, g);
-                return hipGetLastError();
-            }
-            if (sel == 3) {
-                if (nsw == 4)
-                    hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, 3>), grid, block, 0, L.stream, *L.args, g);
-                else
-                    hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, 3>), grid, block, 0, L.stream, *L.args, g);
-                return hipGetLastError();
-            }
-        }
-        if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, *L.args, g);
-        else
-            hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, g);
     }
-    return hipGetLastError();
+    return launchSoloSel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 0>(L, nsw, g, grid, block);
 }
 
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool MUL>

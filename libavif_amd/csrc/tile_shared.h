@@ -237,6 +237,7 @@ struct TileLaunch
     bool solo;              // fp32 / 10-12-bit integer families: the wave-private kernels instead of the cooperative runs
     bool pkWide;            // 10-12-bit integer family without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)
     bool wideDownshift;     // ... entered through the reduction to 8 bits (TileKey)
+    int alphaSel;           // fp32 kernels with pending alpha arithmetic: the one mode the job(s) ask for (computeTile MULSEL), 0 = all compiled in
     hipStream_t stream;
 };
 

@@ -157,6 +157,19 @@ def run(name):
             w, h = (3840, 2160) if name == "cfg2_4k" else (7680, 4320)  # the north star asks for 4K planes beside the 8K headline
             pair = y2r(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR if name == "cfg2n" else BIL, avoid=avoid)
             px, bpp, ms = w * h, 5.5, time_y2r(pair)
+        elif name in ("cfg2_unpremul", "cfg3_unpremul"):
+            # images stored PREMULTIPLIED converted to straight-alpha pixels: the un-multiply inside the conversion (src/reformat.c:894-947);
+            # cfg2's planes + alpha -> RGBA8 (6.5 B/px), cfg3's -> RGBA16 (16 B/px)
+            if name == "cfg2_unpremul":
+                img = abi.make_yuv(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, with_alpha=True, alpha_premultiplied=True)
+                rgb = abi.make_rgb(7680, 4320, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=avoid, allocate=False)
+                px, bpp = 7680 * 4320, 6.5
+            else:
+                img = abi.make_yuv(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, with_alpha=True, alpha_premultiplied=True)
+                rgb = abi.make_rgb(7680, 4320, 16, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=avoid, allocate=False)
+                px, bpp = 7680 * 4320, 16.0
+            synth.fill_yuv(img, 0x12345678)
+            ms = time_y2r((device.DeviceYUV(img), device.DeviceRGB(rgb)), 20 if name == "cfg3_unpremul" else 100)
         elif name == "cfg3":
             pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, avoid=avoid)
             px, bpp, ms = 7680 * 4320, 16.0, time_y2r(pair, 20)
@@ -196,6 +209,22 @@ def run(name):
         elif name in ("cfg5", "cfg5_8"):
             pair = y2r(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 10 if name == "cfg5" else 8, avoid=avoid)
             px, bpp, ms = 1920 * 1080, (11.0 if name == "cfg5" else 7.0), time_y2r(pair)
+        elif name == "cfg5x64_rot":
+            # cfg5x64 with the OUTPUT buffers rotating between two sets: every batch carries a fresh descriptor table to the device (a decoder
+            # that does not reuse its tile buffers), against cfg5x64's resident table
+            if arith == "integer":
+                continue
+            pairs = [y2r(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 10, avoid=avoid, seed=0x12345678 + t) for t in range(64)]
+            outs_b = [device.DeviceRGB(abi.make_rgb(1920, 1080, 10, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=avoid, allocate=False)) for _ in range(64)]
+            imgs = (C.POINTER(abi.avifImage) * 64)(*[C.pointer(p[0].struct) for p in pairs])
+            rgbs = [(C.POINTER(abi.avifRGBImage) * 64)(*[C.pointer(p[1].struct) for p in pairs]), (C.POINTER(abi.avifRGBImage) * 64)(*[C.pointer(o.struct) for o in outs_b])]
+            k = [0]
+
+            def call():
+                k[0] += 1
+                native.check(lib.avifhipImageYUVToRGBBatchAsync(64, imgs, rgbs[k[0] & 1], None, None))
+            best = host_clock(call, burst=50)
+            px, bpp, ms = 64 * 1920 * 1080, 11.0, best
         elif name in ("cfg5x64", "cfg5x64_8"):
             rgb_depth = 10 if name == "cfg5x64" else 8
             pairs = [y2r(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, rgb_depth, avoid=avoid, seed=0x12345678 + t) for t in range(64)]
