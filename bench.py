@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=STREAMS)
+    ap.add_argument("--no-second-stream-count", action="store_true",
+                    help="skip the side measurement of the timed region on the other stream count (profiling runs: overlapping kernels of two streams "
+                         "would inflate the profiler's per-kernel average of the one kernel the line is about)")
     ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
                     help="cfg2 (default): 8K frames, one per step, frames sharded over the ranks (weak scaling); cfg5: ONE 15360x8640 canvas of 64 "
                          "10-bit tiles per step, its tiles sharded over the ranks (strong scaling, BASELINE.json configs[4])")
@@ -338,7 +341,7 @@ def main():
     elapsed = median(region_s)
     # the same region with consecutive frames on the other stream count (1 <-> 2): heads and tails of independent frames overlap on two
     other_streams = 2 if n_streams == 1 else 1
-    other_s = timed_regions(runner(other_streams), device_sync, args.steps, args.warmup, max(3, args.repeats // 3), dist, torch)
+    other_s = None if args.no_second_stream_count else timed_regions(runner(other_streams), device_sync, args.steps, args.warmup, max(3, args.repeats // 3), dist, torch)
 
     # ---- kernels alone: average launch duration from HIP events on the launch stream, single stream, back to back ----
     n4, imgs4, rgbs4 = _cycle_args(frames[:FRAMES_IN_FLIGHT])
@@ -415,7 +418,7 @@ def main():
                           "(events on that stream) describes the same kernel" if n_streams == 1 else
                           ", so consecutive frames overlap head and tail and ms_per_step can be below roofline.kernel_ms (one kernel alone, single stream)")
                        + f"; the input planes of the {FRAMES_IN_FLIGHT} cycled frames can stay in the Infinity Cache -- roofline.cold is the figure without that help",
-        "two_streams" if n_streams == 1 else "one_stream": {
+        "two_streams" if n_streams == 1 else "one_stream": None if other_s is None else {
             "what": f"the same timed region with consecutive frames issued round-robin on {other_streams} HIP stream(s)"
                     + (": independent frames overlap each other's head and tail" if other_streams == 2 else ""),
             "ms_per_step": round(1e3 * median(other_s) / args.steps, 5),

@@ -294,6 +294,12 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
                      gainEntries = cache.stepsOffset - cache.gainLutOffset;
         if ((stepsEntries + baseEntries + gainEntries) * sizeof(float) + (kGainMapGuideBuckets + 2) * sizeof(uint16_t) <= 64 * 1024)
             A.ldsSteps = (uint32_t)stepsEntries, A.ldsBaseLut = (uint32_t)baseEntries, A.ldsGainLut = (uint32_t)gainEntries;
+        // ... or, where the output curve has a locator, the base and gain tables and the locator: no search at all (the general kernel's
+        // own use of what the fast kernel below is built on; the weight-0 paths have no gain table)
+        if (cache.locBuckets && !A.baseL.isFloat && (baseEntries + gainEntries + cache.locBuckets) * sizeof(float) <= 64 * 1024 - 256 && !fastKernelDisabled()) {
+            A.ldsLocator = 1, A.ldsSteps = 0;
+            A.ldsBaseLut = (uint32_t)baseEntries, A.ldsGainLut = (uint32_t)gainEntries;
+        }
         // the fast kernel: 4-channel integer pixels at naturally aligned addresses on both sides, a gain map, a locator, and
         // tables that fit the LDS (kernels_gainmap.hip)
         auto plain4 = [](const GainMapPixelLayout & L, const void * pixels, uint32_t pitch) {

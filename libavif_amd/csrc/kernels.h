@@ -182,6 +182,7 @@ struct GainMapArgs
     uint32_t guideFirstBits, guideShift, guideBuckets;
     uint32_t maxCode, nanCode, stepEntries; // stepEntries: entries per piece of `steps`, a power of two
     uint32_t ldsSteps, ldsBaseLut, ldsGainLut; // entries of the tables when the kernel is to keep ALL of them (and the guide) in LDS, else all 0
+    uint32_t ldsLocator;    // the general kernel keeps the base and gain tables and the locator (below) in LDS instead, and searches nothing
     // the fast kernel (4-channel integer pixels on both sides, a gain map, tables that fit the LDS): the output code through
     // GainMapSteps::locator with one table read, alpha through a table of output alpha codes per base alpha code
     const uint32_t * locator;

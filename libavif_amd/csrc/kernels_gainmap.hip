@@ -175,17 +175,54 @@ __device__ __forceinline__ void finishStatistics(const GainMapArgs & A, float to
     }
 }
 
+// The one-read locator of the output code (gainmap_plan.h: GainMapSteps::locator), for tables in LDS at byte address L.base + ...
+struct Locator
+{
+    int32_t first, last;  // the bit patterns the first bucket starts and the last bucket ends at (in every lane: v_med3_i32 takes one scalar)
+    uint32_t shift, base; // bucket width; LDS address of the table minus 4 x (first >> shift), modulo 2^32
+};
+__device__ __forceinline__ uint32_t locate(float x, const Locator & L)
+{
+    // as signed integers the bit patterns of negative values sort below those of every x >= 0, NaNs of either sign beyond the ends
+    uint32_t b;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(b) : "v"(__float_as_uint(x)), "v"(L.first), "v"(L.last));
+    // `first` is a multiple of the bucket width: the offset inside the bucket is that of the pattern itself
+    const uint32_t e = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(((b >> L.shift) << 2) + L.base);
+    // the code in the low 12 bits, the entry's threshold field still above them: whoever packs the code takes its low byte (8-bit
+    // outputs) or its low 16 bits (deeper ones: the host keeps the bucket width at 2^16 or less there, so bits 12-15 are clear)
+    return e + (((b << (32 - L.shift)) > e) ? 1u : 0u);
+}
+
 // Persistent workgroups walking tiles of 64 x 4 pixels with a grid stride.  LDS_TABLES: the three tables (steps, base lookup,
 // gain lookup) are copied to LDS once per workgroup and addressed as LDS -- a pointer that may be either LDS or global memory
 // compiles to flat loads, which the searches cannot afford; the host picks this variant when everything fits (api_gainmap.cpp).
-template <bool LDS_TABLES>
+// TABLES: 0 -- tables in global memory; 1 -- steps, guide, base and gain tables in LDS; 2 -- base and gain tables and the LOCATOR in LDS
+// (integer outputs up to 12 bits whose curve has one: no search, as in the fast kernel below, which serves the 4-channel layouts)
+template <int TABLES>
 __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_t tilesX, uint32_t tiles)
 {
+    constexpr bool LDS_TABLES = TABLES == 1;
     extern __shared__ float ldsTables[];
     const float * steps = A.steps;
     const float * baseLut = A.baseLut;
     const float * gainLut = A.gainLut;
     const uint16_t * guide = A.guide;
+    Locator L = { 0, 0, A.locShift, 0 };
+    if constexpr (TABLES == 2) {
+        const uint32_t t = threadIdx.y * 64 + threadIdx.x;
+        for (uint32_t k = t; k < A.ldsBaseLut; k += 256)
+            ldsTables[k] = A.baseLut[k];
+        for (uint32_t k = t; k < A.ldsGainLut; k += 256)
+            ldsTables[A.ldsBaseLut + k] = A.gainLut[k];
+        for (uint32_t k = t; k < A.locBuckets; k += 256)
+            reinterpret_cast<uint32_t *>(ldsTables)[A.ldsBaseLut + A.ldsGainLut + k] = A.locator[k];
+        __syncthreads();
+        baseLut = ldsTables, gainLut = ldsTables + A.ldsBaseLut;
+        // (LDS addresses: the dynamic block follows the kernel's static LDS)
+        L.base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)(ldsTables + A.ldsBaseLut + A.ldsGainLut) - 4 * (A.locFirstBits >> A.locShift);
+        asm volatile("v_mov_b32 %0, %1" : "=v"(L.first) : "s"(A.locFirstBits));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(L.last) : "s"(A.locFirstBits + ((A.locBuckets << A.locShift) - 1)));
+    }
     if constexpr (LDS_TABLES) {
         const uint32_t t = threadIdx.y * 64 + threadIdx.x;
         for (uint32_t k = t; k < A.ldsSteps; k += 256)
@@ -256,7 +293,13 @@ __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_
                     convertPrimaries(v, A.outM);
                 sawNan = sawNan || (v[0] != v[0]) || (v[1] != v[1]) || (v[2] != v[2]);
             }
-            codesOf(v, search, outCode);
+            if constexpr (TABLES == 2) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) // (the low 12 bits: the entry's threshold field rides above them)
+                    outCode[c] = (v[c] != v[c]) ? A.nanCode : (locate(v[c], L) & 0xfffu);
+            } else {
+                codesOf(v, search, outCode);
+            }
         }
         writePixel(A.out + (size_t)j * A.outPitch + (size_t)i * A.outL.pixelBytes, A.outL, outVector, outCode, A.outL.hasAlpha ? quantise(alpha, A.outL) : 0);
     }
@@ -328,23 +371,6 @@ struct PixelRun
         }
     }
 };
-
-struct Locator
-{
-    int32_t first, last;  // the bit patterns the first bucket starts and the last bucket ends at (in every lane: v_med3_i32 takes one scalar)
-    uint32_t shift, base; // bucket width; LDS address of the table minus 4 x (first >> shift), modulo 2^32
-};
-__device__ __forceinline__ uint32_t locate(float x, const Locator & L)
-{
-    // as signed integers the bit patterns of negative values sort below those of every x >= 0, NaNs of either sign beyond the ends
-    uint32_t b;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(b) : "v"(__float_as_uint(x)), "v"(L.first), "v"(L.last));
-    // `first` is a multiple of the bucket width: the offset inside the bucket is that of the pattern itself
-    const uint32_t e = *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)(((b >> L.shift) << 2) + L.base);
-    // the code in the low 12 bits, the entry's threshold field still above them: whoever packs the code takes its low byte (8-bit
-    // outputs) or its low 16 bits (deeper ones: the host keeps the bucket width at 2^16 or less there, so bits 12-15 are clear)
-    return e + (((b << (32 - L.shift)) > e) ? 1u : 0u);
-}
 
 // (code & 0xff) << 2 in one instruction: the compiler finds the sub-dword operand for bytes 1-3 but not for byte 0
 __device__ __forceinline__ uint32_t byte0Times4(uint32_t w, uint32_t two)
@@ -806,10 +832,12 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_
     const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
     *partials = A.gain ? groups : 0;
     const size_t lds = A.ldsSteps ? (size_t)(A.ldsSteps + A.ldsBaseLut + A.ldsGainLut) * sizeof(float) + ((size_t)A.guideBuckets + 2) * sizeof(uint16_t) : 0;
-    if (lds)
-        hipLaunchKernelGGL(gainMapApplyKernel<true>, dim3(groups), dim3(64, 4), lds, stream, A, tilesX, tiles);
+    if (A.ldsLocator)
+        hipLaunchKernelGGL(gainMapApplyKernel<2>, dim3(groups), dim3(64, 4), (size_t)(A.ldsBaseLut + A.ldsGainLut + A.locBuckets) * sizeof(float), stream, A, tilesX, tiles);
+    else if (lds)
+        hipLaunchKernelGGL(gainMapApplyKernel<1>, dim3(groups), dim3(64, 4), lds, stream, A, tilesX, tiles);
     else
-        hipLaunchKernelGGL(gainMapApplyKernel<false>, dim3(groups), dim3(64, 4), 0, stream, A, tilesX, tiles);
+        hipLaunchKernelGGL(gainMapApplyKernel<0>, dim3(groups), dim3(64, 4), 0, stream, A, tilesX, tiles);
     return hipGetLastError();
 }
 

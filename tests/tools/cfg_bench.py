@@ -324,7 +324,7 @@ def run(name):
             grid = native.avifhipGrid(rows, cols, ow, oh)
             best = host_clock(lambda: native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None)))
             px, bpp, ms = ow * oh, (11.0 if rgb_depth == 10 else (7.0 if depth == 10 else 5.5)), best
-        elif name in ("gainmap4k", "gainmap4k_half", "gainmap4k_cpu"):
+        elif name in ("gainmap4k", "gainmap4k_half", "gainmap4k_cpu", "gainmap4k_rgb"):
             # avifRGBImageApplyGainMap: 3840x2160 RGBA8 sRGB BT.709 base -> RGBA10 PQ BT.2020 HDR rendition, 8-bit 4:4:4 gain map of the
             # same size (or 4:2:0 at half size, rescaled on the device first).  Algorithmic bytes: base 4 + gain-map planes + output 8.
             CLOCK = "host"
@@ -333,7 +333,9 @@ def run(name):
             import ctypes
             half = name == "gainmap4k_half"
             w, h = 3840, 2160
-            base = abi.make_rgb(w, h, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+            # (_rgb: 3-channel pixels on both sides -- the general kernel)
+            gm_fmt = abi.AVIF_RGB_FORMAT_RGB if name == "gainmap4k_rgb" else abi.AVIF_RGB_FORMAT_RGBA
+            base = abi.make_rgb(w, h, 8, gm_fmt, avoid_libyuv=False)
             synth.fill_rgb(base, 0x4242)
             gimg = abi.make_yuv(w // 2 if half else w, h // 2 if half else h, 8, abi.AVIF_PIXEL_FORMAT_YUV420 if half else abi.AVIF_PIXEL_FORMAT_YUV444,
                                 abi.AVIF_RANGE_FULL, 6)
@@ -349,7 +351,7 @@ def run(name):
             gm.useBaseColorSpace = 1
             clli, diag = abi.avifContentLightLevelInformationBox(), abi.avifDiagnostics()
             gain_bytes = (w * h * 3) if not half else (w * h * 3 // 8)
-            px, bpp = w * h, (4 * w * h + gain_bytes + 8 * w * h) / (w * h)
+            px, bpp = w * h, ((3 if name == "gainmap4k_rgb" else 4) * w * h + gain_bytes + (6 if name == "gainmap4k_rgb" else 8) * w * h) / (w * h)
             if name == "gainmap4k_cpu":
                 # the oracle (= the reference's arithmetic, one thread) on this host, for the ratio
                 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -364,7 +366,7 @@ def run(name):
             else:
                 dbase, dgimg = device.DeviceRGB(base, upload=True), device.DeviceYUV(gimg)
                 gm.image = C.pointer(dgimg.struct)
-                tone = abi.make_rgb(w, h, 10, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False, allocate=False)
+                tone = abi.make_rgb(w, h, 10, gm_fmt, avoid_libyuv=False, allocate=False)
                 dout = device.DeviceRGB(tone)
                 call = lambda: native.check(lib.avifhipRGBImageApplyGainMapAsync(dbase.struct, 1, 13, C.byref(gm), 3.0, 9, 16, dout.struct, C.byref(clli),
                                                                                  C.byref(diag), None))
