@@ -852,7 +852,26 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
             return hipFailed(e, "gain map quantisation kernel launch");
     }
     const uint32_t requestedWidth = gmImage->width, requestedHeight = gmImage->height;
-    freeHostPlanes(gmImage);
+    // The planes a previous call left in gainMap->image are released only after the stream has drained: free() of memory the runtime pinned
+    // for that call's downloads unmaps it from the GPU as well, and that stalls whatever kernel is running (the quantisation kernel above:
+    // 168 us in a process's first call, 15-25 ms in every later one, when the release sat here).
+    struct DeferredPlanes
+    {
+        uint8_t * yuv[3] = { nullptr, nullptr, nullptr };
+        uint8_t * alpha = nullptr;
+        ~DeferredPlanes()
+        {
+            for (uint8_t * p : yuv)
+                free(p);
+            free(alpha);
+        }
+    } stale;
+    if (gmImage->imageOwnsYUVPlanes)
+        for (int p = 0; p < 3; ++p)
+            stale.yuv[p] = gmImage->yuvPlanes[p], gmImage->yuvPlanes[p] = NULL;
+    if (gmImage->imageOwnsAlphaPlane)
+        stale.alpha = gmImage->alphaPlane, gmImage->alphaPlane = NULL;
+    freeHostPlanes(gmImage); // (what is left: pointers the image does not own)
     avifImage deviceGain;
     memcpy(&deviceGain, gmImage, sizeof(avifImage));
     if ((r = deviceGainMapPlanes(&deviceGain, width, height, tls.gainMap[10])) != AVIF_RESULT_OK)
