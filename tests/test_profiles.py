@@ -1,8 +1,8 @@
 """The committed measurement evidence is self-consistent: the bench line printed under rocprofv3 and the rocprofv3 kernel statistics of
 the same command agree on the dominant kernel's duration, the roofline fields follow from each other, the HBM traffic the PMC passes
 measured matches the algorithmic bytes the roofline is computed from, and the instruction counters back the "packed 16-bit"
-claim (profiles/r03_bench_*); and every configuration row of profiles/r03_cfgs_bench.jsonl agrees with the
-profiler's own average over the very launches it was timed on (profiles/r03_cfgs_kernel_stats.txt: one rocprofv3 run per configuration)."""
+claim (profiles/r04_bench_*); and every configuration row of profiles/r04_cfgs_bench.jsonl agrees with the
+profiler's own average over the very launches it was timed on (profiles/r04_cfgs_kernel_stats.txt: one rocprofv3 run per configuration)."""
 import json
 import re
 from pathlib import Path
@@ -16,13 +16,13 @@ def _line(name):
 
 
 def _dominant():
-    stats = (PROFILES / "r03_bench_kernel_stats.txt").read_text().splitlines()
+    stats = (PROFILES / "r04_bench_kernel_stats.txt").read_text().splitlines()
     assert "bench.py" in stats[0]
     return stats[2]
 
 
 def test_bench_line_and_rocprof_stats_agree():
-    line = _line("r03_bench_line_under_rocprof.json")
+    line = _line("r04_bench_line_under_rocprof.json")
     dominant = _dominant()
     assert "yuvToRgbPkKernel<2, true, 4, false" in dominant  # the packed 16-bit 4:2:0 bilinear RGBA8 kernel the bench line names
     assert line["config"]["kernel"] == "yuv2rgb_fixed_tile<u8,420,bilinear,rgba8,pk16>"
@@ -33,7 +33,7 @@ def test_bench_line_and_rocprof_stats_agree():
 
 
 def test_roofline_fields_follow_from_each_other():
-    for name in ("r03_bench_line.json", "r03_bench_line_under_rocprof.json", "r03_bench_line_default_run.json", "r03_bench_line_driver_flags.json"):
+    for name in ("r04_bench_line.json", "r04_bench_line_under_rocprof.json", "r04_bench_line_default_run.json", "r04_bench_line_driver_flags.json"):
         d = _line(name)
         r = d["roofline"]
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -57,6 +57,10 @@ def test_roofline_fields_follow_from_each_other():
         p4 = d["planes_4k"]
         assert abs(p4["integer"]["frac"] - ALG / 4 / (p4["integer"]["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-3 and p4["integer"]["frac"] >= 0.55 and p4["fp32"]["frac"] >= 0.45
         assert abs(d["value"] - 7680 * 4320 / 1e6 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+        # one stream: the timed region's step IS the kernel the roofline block describes, plus what launches leave between kernels
+        assert 0.97 * r["kernel_ms"] <= d["ms_per_step"] <= 1.08 * r["kernel_ms"], (d["ms_per_step"], r["kernel_ms"])
+        two = d.get("two_streams")
+        assert two is None or two["ms_per_step"] <= d["ms_per_step"] * 1.02
         assert d["metric"].startswith("megapixels/sec") and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
         assert d["dtype"] == "i16" and d["n_gpus"] == 1 and d["config"]["repeats"] >= 1
 
@@ -65,7 +69,7 @@ def test_pmc_traffic_and_instruction_counts():
     t = json.loads((PROFILES / "pmc_traffic.json").read_text())
     assert t["kernel_family"] == "yuv2rgb_fixed_tile<u8,420,bilinear,rgba8,pk16>" and "yuvToRgbPkKernel" in t["kernel"]
     assert abs(t["traffic_bytes_per_launch"] - ALG) / ALG < 0.03  # measured HBM bytes per launch vs algorithmic bytes: no wasted re-reads
-    pmc = (PROFILES / "r03_bench_pmc.txt").read_text()
+    pmc = (PROFILES / "r04_bench_pmc.txt").read_text()
     block = re.split(r"yuvToRgbPkKernel<2, true, 4, false, 4, false, 0>[^\n]*\n", pmc, maxsplit=1)[1].split("\nvoid ", 1)[0]  # 4:2:0, bilinear, 4 channels, opaque, 4 strips, rows, 8-bit planes
     valu = float(re.search(r"SQ_INSTS_VALU\s+dispatches=\s*\d+\s+avg_per_dispatch=\s*([0-9.]+)", block).group(1))
     per_pixel = valu * 64 / (7680 * 4320)
@@ -73,13 +77,13 @@ def test_pmc_traffic_and_instruction_counts():
 
 
 def test_default_run_carries_the_cpu_baseline():
-    for name in ("r03_bench_line_default_run.json", "r03_bench_line_driver_flags.json"):
+    for name in ("r04_bench_line_default_run.json", "r04_bench_line_driver_flags.json"):
         cb = _line(name)["cpu_baseline"]
         assert cb["kind"] == "reference" and cb["cores"] == 1 and cb["unit"] == "megapixels/s" and 50 < cb["value"] < 500
 
 
 def test_end_to_end_rows_present():
-    rows = [json.loads(l) for l in (PROFILES / "r03_e2e.jsonl").read_text().splitlines() if l.strip()]
+    rows = [json.loads(l) for l in (PROFILES / "r04_e2e.jsonl").read_text().splitlines() if l.strip()]
     by = {(r["config"], r["call"]): r for r in rows}
     cfg2 = by[("cfg2", "avifhipImageYUVToRGB (host buffers)")]
     assert cfg2["host_link_GBps"] >= 0.6 * 56.9  # both directions of the link busy: above 60% of the one-way PCIe rate measured on the box
@@ -95,8 +99,8 @@ def test_end_to_end_rows_present():
 
 
 def _cfg_blocks():
-    """{config: [(kernel, calls, avg_us)]} of profiles/r03_cfgs_kernel_stats.txt"""
-    text = (PROFILES / "r03_cfgs_kernel_stats.txt").read_text()
+    """{config: [(kernel, calls, avg_us)]} of profiles/r04_cfgs_kernel_stats.txt"""
+    text = (PROFILES / "r04_cfgs_kernel_stats.txt").read_text()
     out = {}
     for block in text.split("\n== ")[1:]:
         lines = block.splitlines()
@@ -109,33 +113,51 @@ def _cfg_blocks():
     return out
 
 
+# product-level kernel names (native.last_kernel()) -> what the device kernel of that family is called in the profiler's table
+_FAMILY = [("yuv2rgb_fixed_tile", ("yuvToRgbPk", "yuvToRgbTileFx", "yuvToRgbFixed")), ("yuv2rgb_tile", ("yuvToRgbTile",)), ("rgb2yuv_fixed_tile", ("rgbToYuvTileFx",)),
+           ("rgb2yuv_tile", ("rgbToYuvTile",)), ("gray2yuv_tile", ("grayToYuv",)), ("premultiply", ("alphaMul",)), ("unpremultiply", ("alphaMul",)),
+           ("attenuate", ("alphaMul", "attenuate")), ("unattenuate", ("alphaMul", "attenuate")), ("rgb_transform", ("rgbTransform", "transform")),
+           ("scale_", ("scalePlane",)), ("gainmap_apply", ("gainMapApply",)), ("gainmap_compute", ("gainMap",))]
+
+
+def _kernels_of_row(row, kernels):
+    """The profiler rows that belong to the bench row's kernel family (by NAME, not by whichever duration happens to be closest)."""
+    for prefix, needles in _FAMILY:
+        if row["kernel"].startswith(prefix):
+            named = [k for k in kernels if any(n.lower() in k[0].lower() for n in needles)]
+            return named or kernels
+    return kernels
+
+
 def test_every_configuration_row_agrees_with_the_profiler():
     """One box, one call, one run per configuration: the event-timed row (median of bursts after 60 ms of the same kernel) and rocprofv3's
-    average over all launches of that run are within 5 % for every single-kernel configuration; rows clocked on the host around API calls
-    (several kernels per call) are never faster than the kernels the profiler saw per call."""
-    rows = [json.loads(l) for l in (PROFILES / "r03_cfgs_bench.jsonl").read_text().splitlines() if l.startswith("{")]
+    average over all launches of that run are within 5 % for every single-kernel configuration -- compared with the profiler row of the SAME
+    kernel family; rows clocked on the host around API calls (several kernels per call) are never faster than the kernels the profiler saw per call."""
+    rows = [json.loads(l) for l in (PROFILES / "r04_cfgs_bench.jsonl").read_text().splitlines() if l.startswith("{")]
     blocks = _cfg_blocks()
-    assert len(rows) >= 70 and len(blocks) >= 45
+    assert len(rows) >= 75 and len(blocks) >= 48
     worst = 0.0
     for r in rows:
         kernels = blocks[r["config"]]
         assert kernels, r["config"]
+        own = _kernels_of_row(r, kernels)
         if r["clock"] == "events":
-            avg = min((a for _, _, a in kernels), key=lambda a: abs(a - r["us"]))
+            avg = min((a for _, _, a in own), key=lambda a: abs(a - r["us"]))
             rel = abs(avg - r["us"]) / avg
-            if avg < 12.0 and -0.7 <= r["us"] - avg < max(2.0, 0.8 * avg):
-                continue  # launches this short: the events also see the time between two kernels (1-2 us, more with the profiler
-                          # intercepting every launch of a run this short), the profiler does not -- and its average
-                          # carries the thousand-odd launches of the first slow milliseconds, which the median of the bursts does not
+            if avg < 12.0 and -0.7 <= r["us"] - avg <= 2.0:
+                continue  # launches this short: the events also see the time between two kernels (at most ~2 us, with the profiler intercepting
+                          # every launch), the profiler does not
+            if r["config"] == "gmcompute4k":
+                continue  # (a whole host-resident call: transfers included)
             worst = max(worst, rel)
-            assert rel < 0.05, (r["config"], r["arithmetic"], r["us"], kernels)
+            assert rel < 0.05, (r["config"], r["arithmetic"], r["us"], own)
         else:
             # wall clock per API call: never below the call's own kernel; one kernel per call -> the same 5 %
-            closest = min((a for _, _, a in kernels), key=lambda a: abs(a - r["us"]))
-            assert any(a <= 1.05 * r["us"] for _, _, a in kernels), (r["config"], r["us"], kernels)
+            closest = min((a for _, _, a in own), key=lambda a: abs(a - r["us"]))
+            assert any(a <= 1.05 * r["us"] for _, _, a in own), (r["config"], r["us"], own)
             one_kernel = r["config"].startswith(("tail", "xform", "premul", "unpremul", "cfg5x64")) and "two_pass" not in r["config"]
             if one_kernel:
-                assert abs(closest - r["us"]) / closest < 0.05, (r["config"], r["arithmetic"], r["us"], kernels)
+                assert abs(closest - r["us"]) / closest < 0.05, (r["config"], r["arithmetic"], r["us"], own)
     assert worst < 0.05
     by = {(r["config"], r["arithmetic"]): r for r in rows}
     # the round's targets, on the profiler's averages (VERDICT r02, items 1, 4, 5, 7)
@@ -152,11 +174,57 @@ def test_every_configuration_row_agrees_with_the_profiler():
     # the encode direction at 4K (a round-3 build had lost it: 14.9 us with the rare modes compiled into the same kernel)
     assert avg_of("cfg4", "rgbToYuvTileKernel<unsigned char, 4, unsigned char, 2, 1, true>") <= 9.6
     assert avg_of("cfg4rgb", "rgbToYuvTileKernel<unsigned char, 3, unsigned char, 2, 1, true>") <= 8.3
+    # round 4: the decode-side un-multiply has kernels of its own (cfg3's shape at 0.70 and more; cfg2's is bound by the un-multiply's own
+    # instructions), a batch that uploads a fresh descriptor table per call stays within 5 % of the resident one, and the gain-map application
+    assert by[("cfg3_unpremul", "float")]["frac_of_8TBps"] >= 0.70 and by[("cfg2_unpremul", "float")]["frac_of_8TBps"] >= 0.50
+    assert by[("cfg5x64_rot", "float")]["us"] <= 1.05 * by[("cfg5x64", "float")]["us"]
+    assert avg_of("gainmap4k", "gainMapApplyFastKernel<4, 8, 4, 2>") <= 31.5 and by[("gainmap4k", "float")]["us"] <= 75.0  # 93 us / 133 us per call in round 3
+    assert avg_of("gmcompute4k", "gainMapQuantiseKernel") <= 200.0  # (15-25 ms in every call but a process's first before the stale planes' release moved)
+
+
+def test_gain_map_application_evidence():
+    """the 4K RGBA8 -> RGBA10 PQ application at 30 us or less, with rocprof and counter evidence, and a block in the bench line."""
+    stats = (PROFILES / "r04_bench_kernel_stats.txt").read_text()
+    row = [l for l in stats.splitlines() if "gainMapApplyFastKernel<4, 8, 4, 2>" in l][0]
+    calls, avg_us = int(re.split(r"\s{2,}", row.strip())[-6]), float(re.split(r"\s{2,}", row.strip())[-4])
+    assert calls >= 1000 and avg_us <= 30.0, row  # back-to-back launches of the bench's gainmap block, the profiler's own average
+    for name in ("r04_bench_line_default_run.json", "r04_bench_line_driver_flags.json", "r04_bench_line_under_rocprof.json"):
+        g = _line(name)["gainmap"]
+        assert g["kernel"] == "gainmap_apply_fast" and g["kernel_ms"] <= 0.030 and g["frac"] >= 0.50
+        assert abs(g["kernel_ms"] * 1e3 - avg_us) / avg_us < 0.05
+        assert g["whole_call"]["ms_per_call"] <= 0.070 and g["whole_call"]["maxCLL"] > 0
+    pmc = (PROFILES / "r04_gainmap_pmc.txt").read_text()
+    block = pmc.split("gainMapApplyFastKernel<4, 8, 4, 2>", 1)[1]
+    valu = float(re.search(r"SQ_INSTS_VALU\s+dispatches=\s*\d+\s+avg_per_dispatch=\s*([0-9.]+)", block).group(1))
+    lds = float(re.search(r"SQ_INSTS_LDS\s+dispatches=\s*\d+\s+avg_per_dispatch=\s*([0-9.]+)", block).group(1))
+    px = 3840 * 2160
+    assert valu * 64 / px <= 75.0 and lds * 64 / px <= 12.0, (valu * 64 / px, lds * 64 / px)  # 317 and ~20 in round 3
+
+
+def test_bench_line_carries_every_baseline_configuration():
+    """cfg1 / cfg3 / cfg4 / cfg5 in the driver-run line, ceilings for the small plane sizes, each block's fields consistent."""
+    d = _line("r04_bench_line_default_run.json")
+    cfg = d["configs"]
+    assert set(cfg) >= {"cfg1", "cfg3", "cfg4", "cfg5x64", "cfg5grid"}
+    for k, v in cfg.items():
+        assert abs(v["achieved"] - v["algorithmic_bytes_per_launch"] / (v["kernel_ms"] * 1e-3) / 1e9) / v["achieved"] < 0.01, k
+        assert abs(v["frac"] - v["achieved"] / 8000.0) < 1e-3 and v["kernel"], k
+    assert cfg["cfg3"]["algorithmic_bytes_per_launch"] == 16 * 7680 * 4320 and cfg["cfg3"]["frac"] >= 0.60
+    assert cfg["cfg4"]["algorithmic_bytes_per_launch"] == 53913600 and cfg["cfg4"]["same_frame"]["frac"] >= 0.65
+    assert cfg["cfg5x64"]["frac"] >= 0.65 and cfg["cfg5grid"]["frac"] >= 0.60
+    rot = cfg["cfg5x64"]["rotating_outputs"]
+    assert rot["table_uploads_per_batch"] >= 0.95 and rot["ms_per_batch"] <= 1.08 * cfg["cfg5x64"]["kernel_ms"]
+    c = d["ceilings"]
+    assert c["planes_4k"]["kernel_ms"] <= d["planes_4k"]["integer"]["kernel_ms"] and c["planes_1080p"]["kernel_ms"] <= c["planes_1080p"]["conversion"]["kernel_ms"]
+    # the rows of cfg_bench.py for the same configurations (another run of the same box) agree within box noise
+    rows = {(r["config"], r["arithmetic"]): r for r in (json.loads(l) for l in (PROFILES / "r04_cfgs_bench.jsonl").read_text().splitlines() if l.startswith("{"))}
+    assert abs(cfg["cfg5x64"]["kernel_ms"] * 1e3 - rows[("cfg5x64", "float")]["us"]) / rows[("cfg5x64", "float")]["us"] < 0.05
+    assert abs(cfg["cfg4"]["same_frame"]["kernel_ms"] * 1e3 - rows[("cfg4", "float")]["us"]) / rows[("cfg4", "float")]["us"] < 0.10
 
 
 def test_fp32_instruction_counts():
     """the fp32 tiles' vector instructions per pixel (rocprofv3 --pmc SQ_INSTS_VALU, own pass)."""
-    text = (PROFILES / "r03_cfgs_pmc.txt").read_text()
+    text = (PROFILES / "r04_cfgs_pmc.txt").read_text()
     def valu_per_pixel(cfg, needle):
         block = text.split(f"\n== {cfg}\n", 1)[1].split("\n== ", 1)[0]
         kernel = [b for b in block.split("\n   void ") if needle in b][0]
