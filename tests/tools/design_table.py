@@ -6,7 +6,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[2]
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 DESC = {
     "cfg2": "cfg2: 8K 8-bit 4:2:0 BT.709 limited → RGBA8 bilinear (4 frames cycled)",
     "cfg2_4k": "cfg2 at 4K (3840 × 2160; the north star's second plane size)",
@@ -57,6 +57,12 @@ DESC = {
     "scale_box4": "plane scaling 8K → 4K (§4.8)",
     "scale_up2": "… 4K → 8K",
     "scale_down_1_5": "… 8K → 5120 × 2880",
+    "cfg2_unpremul": "cfg2 from PREMULTIPLIED planes + alpha → straight RGBA8 (un-multiply inside the conversion)",
+    "cfg3_unpremul": "cfg3's planes, stored premultiplied → straight RGBA16",
+    "cfg5x64_rot": "cfg5 canvas, the batch's OUTPUT buffers rotating between two sets (a fresh descriptor table per call)",
+    "gainmap4k": "gain-map application (§4.10): 4K RGBA8 sRGB/BT.709 → RGBA10 PQ/BT.2020, 8-bit 4:4:4 gain map; whole call (gain map YUV→RGB + apply + statistics)",
+    "gainmap4k_half": "… with a half-size 4:2:0 gain map (rescaled on the device first)",
+    "gmcompute4k": "gain-map computation from HOST images (4K RGBA8 + RGBA10 → 8-bit 4:4:4 gain map), transfers included",
 }
 
 
