@@ -20,8 +20,11 @@ struct JobOverride
 // address comes back in *extraDevice, the ring slot in *slotOut -- the caller records tls.tableConsumed[slot] again after ITS kernels.
 static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects,
                                  const JobOverride * overrides, void * hipStream, const PixelMap * map = nullptr, const void * extra = nullptr, size_t extraBytes = 0,
-                                 const void ** extraDevice = nullptr, uint32_t * slotOut = nullptr, bool * residentOut = nullptr)
+                                 const void ** extraDevice = nullptr, uint32_t * slotOut = nullptr, bool * residentOut = nullptr,
+                                 const TileNeighbours * neighbours = nullptr, bool * seamsDone = nullptr, int linkForced = -1)
 {
+    if (seamsDone)
+        *seamsDone = false;
     if (count == 0)
         return AVIF_RESULT_OK;
     if (!images || !rgbs)
@@ -124,6 +127,16 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
             restMaxW = w4 > restMaxW ? w4 : restMaxW;
         }
     }
+    // Tiles of one canvas whose every pixel goes through the tiled kernels: the jobs are linked to their neighbours and the seam-aware build
+    // of the family filters chroma across the seams in the same launch (tile_impl.h TILE_SEAMS).  With leftover columns / rows -- converted
+    // by the universal kernel from each job's own window -- the caller's seam pass still runs.
+    const bool linked = neighbours && allTiled && !restW && !restH && tileBatchLinksNeighbours(representative, count, maxW, maxH, linkForced);
+    if (linked) {
+        for (uint32_t k = 0; k < count; ++k)
+            linkTileBatchHalo(pinned, k, neighbours[k]);
+        if (seamsDone)
+            *seamsDone = true;
+    }
     // (same stream: that stream waited for the resident slot's upload when it ran the batch that brought it)
     // (... which holds only for a stream the library owns: a caller's handle may be a new stream at a recycled address)
     const uint64_t streamGeneration = ownedStreamGeneration(stream);
@@ -193,7 +206,7 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
     hipError_t e = hipSuccess;
     if (allTiled) {
         HIP_TRY(upload(dev, pinned, bytes));
-        e = launchYuvToRgbTileBatch(dev, representative, count, maxW, maxH, stream, &tls.lastKernel);
+        e = launchYuvToRgbTileBatch(dev, representative, count, maxW, maxH, stream, &tls.lastKernel, linked);
         if (e == hipSuccess && restW)
             e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)(dev + tileBytes), count, restW, restMaxH, stream);
         if (e == hipSuccess && restH)
@@ -258,6 +271,12 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
     std::vector<avifCropRect> rects(count);
     std::vector<JobOverride> overrides(count);
     std::vector<GridTile> tiles(count);
+    // one launch for tiles AND seams (kernels.h TileNeighbours) needs one chroma pitch per plane over the whole grid: a neighbour's sample is
+    // addressed with the job's own offset.  Whether it is used: tileBatchLinksNeighbours; AVIFHIP_GRID_SEAM_PASS=1 always keeps the second
+    // pass, =0 never does where the grid can be linked (A/B measurements, tests of the seam kernels)
+    const char * seamPassEnv = getenv("AVIFHIP_GRID_SEAM_PASS");
+    const int linkForced = seamPassEnv ? (atoi(seamPassEnv) != 0 ? 0 : 1) : -1;
+    bool linkable = subsampled && count > 1 && linkForced != 0;
     for (uint32_t t = 0; t < count; ++t) {
         const avifImage * tile = colorTiles[t];
         if (!tile || !tile->yuvPlanes[0])
@@ -267,6 +286,8 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
             tile->yuvRange != first->yuvRange || tile->colorPrimaries != first->colorPrimaries ||
             tile->transferCharacteristics != first->transferCharacteristics || tile->matrixCoefficients != first->matrixCoefficients)
             return AVIF_RESULT_INVALID_IMAGE_GRID;
+        if (tile->yuvRowBytes[1] != first->yuvRowBytes[1] || tile->yuvRowBytes[2] != first->yuvRowBytes[2] || !tile->yuvPlanes[1] || !tile->yuvPlanes[2])
+            linkable = false;
         const avifImage * atile = alphaTiles ? alphaTiles[t] : nullptr;
         if (alphaTiles && (!atile || !atile->alphaPlane || atile->width != tw || atile->height != th || atile->depth != first->depth))
             return AVIF_RESULT_INVALID_IMAGE_GRID;
@@ -310,6 +331,20 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
         o.window[2] = (int32_t)(Y0 >> sy), o.window[3] = (int32_t)((Y0 >> sy) + ((seenH + sy) >> sy) - 1);
         o.alphaLimited = atile && alphaIsLimitedRange;
     }
+    // every tile's neighbours in the grid, by the virtual plane pointers made above (a tile the crop drops from the batch still lends its samples)
+    std::vector<TileNeighbours> neighbours(linkable ? count : 0);
+    for (uint32_t t = 0; linkable && t < count; ++t) {
+        const int col = (int)(t % grid->columns), row = (int)(t / grid->columns);
+        TileNeighbours & n = neighbours[t];
+        n.above = row > 0, n.below = row + 1 < (int)grid->rows, n.left = col > 0, n.right = col + 1 < (int)grid->columns;
+        for (int d = 0; d < 9; ++d) {
+            const int dr = (d / 3 == 1) ? -1 : (d / 3 == 2 ? 1 : 0), dc = (d % 3 == 1) ? -1 : (d % 3 == 2 ? 1 : 0);
+            const int r2 = row + dr, c2 = col + dc;
+            const bool there = r2 >= 0 && r2 < (int)grid->rows && c2 >= 0 && c2 < (int)grid->columns;
+            const avifImage & nv = views[there ? (uint32_t)r2 * grid->columns + (uint32_t)c2 : t];
+            n.plane1[d] = nv.yuvPlanes[1], n.plane2[d] = nv.yuvPlanes[2];
+        }
+    }
     // the seam kernel's tile table rides in the batch's descriptor upload (its own copy on the compute stream cost 5 us plus two gaps)
     const void * deviceTiles = nullptr;
     uint32_t tableSlot = 0;
@@ -320,12 +355,14 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
             if (!rects[t].width || !rects[t].height)
                 continue;
             viewPtrs[jobs] = viewPtrs[t], rects[jobs] = rects[t], overrides[jobs] = overrides[t];
+            if (linkable)
+                neighbours[jobs] = neighbours[t];
             ++jobs;
         }
     }
-    bool residentTable = false;
+    bool residentTable = false, seamsDone = false;
     avifResult r = batchAsyncImpl(jobs, viewPtrs.data(), rgbPtrs.data(), rects.data(), overrides.data(), hipStream, map, tiles.data(), tiles.size() * sizeof(GridTile),
-                                  &deviceTiles, &tableSlot, &residentTable);
+                                  &deviceTiles, &tableSlot, &residentTable, linkable ? neighbours.data() : nullptr, &seamsDone, linkForced);
     if (r != AVIF_RESULT_OK)
         return r;
     hipStream_t stream = pickStream(hipStream);
@@ -343,8 +380,11 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
                 (void)hipEventRecord(ev, s);
         }
     } slotRead = { tls.tableConsumed[tableSlot], stream, residentTable, tableSlot };
-    if (count == 1)
-        return AVIF_RESULT_OK;
+    if (getenv("AVIFHIP_GRID_TRACE"))
+        fprintf(stderr, "avifhip grid %ux%u: %s, seams %s (%s)\n", grid->columns, grid->rows, linkable ? "linkable" : "not linkable",
+                seamsDone ? "in the tile kernels" : "in a second pass", tls.lastKernel ? tls.lastKernel : "?");
+    if (count == 1 || seamsDone)
+        return AVIF_RESULT_OK; // (one tile, or the tiled kernels read across the seams themselves)
     // seams: only a filtering chroma upsampler looks across them
     YuvToRgbPlan canvasPlan;
     r = makeYuvToRgbPlan(viewPtrs[0], rgbCanvas, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &canvasPlan);

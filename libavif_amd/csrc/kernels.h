@@ -48,7 +48,22 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
 size_t tileBatchTableBytes(uint32_t count);
 void fillTileBatchTable(const YuvToRgbPlan * plans, uint32_t count, void * hostTable);
 hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW,
-                                   uint32_t maxH, hipStream_t stream, const char ** kernelName);
+                                   uint32_t maxH, hipStream_t stream, const char ** kernelName, bool neighboursLinked = false);
+// Jobs that are the tiles of ONE canvas (grid images): a job whose neighbours are linked filters chroma across the seams inside the tiled
+// kernels (the seam-aware builds, tile_impl.h) -- no second pass.  Index 3 * v + h of the plane arrays: v 0 = the job's own tile, 1 = the
+// tile above, 2 = below; h 0 = own, 1 = left, 2 = right; every pointer addresses canvas sample (0,0) of the tile's U / V plane, virtually
+// (entries of absent neighbours are ignored).  All tiles must share the job's chroma pitches.
+struct TileNeighbours
+{
+    const uint8_t * plane1[9];
+    const uint8_t * plane2[9];
+    bool above, below, left, right;
+};
+// whether a batch of linkable jobs is to be linked: its kernel family filters chroma at all, and one launch measured faster than the tile
+// batch followed by the seam pass for this family and size (`forced`: -1 = by that measurement, 0 = never, 1 = whenever chroma is filtered)
+bool tileBatchLinksNeighbours(const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW, uint32_t maxH, int forced);
+// after fillTileBatchTable; launchYuvToRgbTileBatch is then told `neighboursLinked`
+void linkTileBatchHalo(void * hostTable, uint32_t job, const TileNeighbours & neighbours);
 hipError_t launchGrayChromaFill(const RgbToYuvPlan & plan, hipStream_t stream);
 bool tileRgbToYuvSupported(const RgbToYuvPlan & plan);
 hipError_t launchRgbToYuvTile(const RgbToYuvPlan & plan, hipStream_t stream, const char ** kernelName);

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 
@@ -24,6 +26,10 @@ AVIFHIP_DECLARE_TILE(u16_422n) AVIFHIP_DECLARE_TILE(u16_422b) AVIFHIP_DECLARE_TI
 AVIFHIP_DECLARE_TILE(u8_444n) AVIFHIP_DECLARE_TILE(u8_400n) AVIFHIP_DECLARE_TILE(u8_422n) AVIFHIP_DECLARE_TILE(u8_422b)
 AVIFHIP_DECLARE_TILE(u8_420n) AVIFHIP_DECLARE_TILE(u8_420b) AVIFHIP_DECLARE_TILE(u16_444n) AVIFHIP_DECLARE_TILE(u16_400n)
 AVIFHIP_DECLARE_TILE(u16_422n) AVIFHIP_DECLARE_TILE(u16_422b) AVIFHIP_DECLARE_TILE(u16_420n) AVIFHIP_DECLARE_TILE(u16_420b)
+#undef AVIFHIP_DECLARE_TILE
+// the seam-aware builds of the families that filter chroma (batch kernels only: tile_impl.h)
+#define AVIFHIP_DECLARE_TILE(name) hipError_t launchTileSeams_##name(const TileKey &, const TileLaunch &); hipError_t launchTileFxSeams_##name(const TileKey &, const TileLaunch &);
+AVIFHIP_DECLARE_TILE(u8_422b) AVIFHIP_DECLARE_TILE(u8_420b) AVIFHIP_DECLARE_TILE(u16_422b) AVIFHIP_DECLARE_TILE(u16_420b)
 #undef AVIFHIP_DECLARE_TILE
 } // namespace tile
 
@@ -76,6 +82,17 @@ const char * kernelNameFor(const TileKey & k, uint32_t tuning)
 
 hipError_t launchFamily(const TileKey & k, const TileLaunch & L)
 {
+    if (L.seams && L.table && k.bilinear) { // tiles of one canvas, neighbours linked: chroma is filtered across the seams in this launch
+        const bool s420 = k.sub == SUB_420;
+        if (k.fixedPoint) {
+            if (!k.wideYuv)
+                return s420 ? launchTileFxSeams_u8_420b(k, L) : launchTileFxSeams_u8_422b(k, L);
+            return s420 ? launchTileFxSeams_u16_420b(k, L) : launchTileFxSeams_u16_422b(k, L);
+        }
+        if (!k.wideYuv)
+            return s420 ? launchTileSeams_u8_420b(k, L) : launchTileSeams_u8_422b(k, L);
+        return s420 ? launchTileSeams_u16_420b(k, L) : launchTileSeams_u16_422b(k, L);
+    }
     if (k.fixedPoint) {
         if (!k.wideYuv) {
             switch (k.sub) {
@@ -293,6 +310,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     L.alphaSel = alphaSelOf(A);
     L.table = nullptr;
     L.count = 1;
+    L.seams = false;
     L.stream = stream;
     L.shiftStrips = 0;
     L.mapped = k.mapped, L.transposed = k.mapped && plan.rgb.map.transposed, L.streamLoads = false;
@@ -331,14 +349,46 @@ void fillTileBatchTable(const YuvToRgbPlan * plans, uint32_t count, void * hostT
         t[k] = distillArgs(plans[k]);
 }
 
+// Where one launch beats the tile batch plus the seam pass (A/B on one box, tests/tools/cfg_bench.py with AVIFHIP_GRID_SEAM_PASS = 1 / 0):
+// the packed 16-bit kernels have registers to spare for the seam-aware loads (42 -> 48, same occupancy) and win everywhere -- a 12-megapixel
+// photograph in 48 tiles 21.1 -> 12.9 us, cfg5's 64 tiles -> RGBA8 173.9 -> 165.9; the fp32 kernels pay for them with a step of occupancy
+// (the cooperative 10-bit kernel: 76 -> 86 registers), so they win where the second launch is a large part of the call (the photograph:
+// 21.4 -> 14.3 us) and lose where it is not (cfg5 -> RGBA(10): 263-269 -> 273 us; -> RGBA8 177.5 -> 183.9).
+bool tileBatchLinksNeighbours(const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW, uint32_t maxH, int forced)
+{
+    const TileKey k = keyFor(representative);
+    if (!k.bilinear)
+        return false; // (nothing is filtered: seams need nothing)
+    if (forced >= 0)
+        return forced != 0;
+    const bool packed = k.fixedPoint && (!k.hasMul || (k.attenuate && !k.mapped)) && (!k.wideYuv || (representative.tuning & TUNE_COOPERATIVE) == 0);
+    return packed || (uint64_t)maxW * maxH * count <= ((uint64_t)32 << 20);
+}
+
+void linkTileBatchHalo(void * hostTable, uint32_t job, const TileNeighbours & n)
+{
+    TileArgs & T = static_cast<TileArgs *>(hostTable)[job];
+    // distillArgs hands the planes to the kernels in the order of the pixel's colour channels (the "YVU trick"): follow it
+    const bool swapped = T.u == n.plane2[0] && T.u != n.plane1[0];
+    const bool present[9] = { true, n.left, n.right, n.above, n.above && n.left, n.above && n.right, n.below, n.below && n.left, n.below && n.right };
+    for (int d = 0; d < 9; ++d) {
+        const uint8_t * p1 = present[d] ? n.plane1[d] : n.plane1[0];
+        const uint8_t * p2 = present[d] ? n.plane2[d] : n.plane2[0];
+        T.halo.at[d].u = swapped ? p2 : p1;
+        T.halo.at[d].v = swapped ? p1 : p2;
+    }
+    T.haloSides = (n.above ? HALO_ABOVE : 0u) | (n.below ? HALO_BELOW : 0u) | (n.left ? HALO_LEFT : 0u) | (n.right ? HALO_RIGHT : 0u);
+}
+
 hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW,
-                                   uint32_t maxH, hipStream_t stream, const char ** kernelName)
+                                   uint32_t maxH, hipStream_t stream, const char ** kernelName, bool neighboursLinked)
 {
     const TileKey k = keyFor(representative);
     if (kernelName)
         *kernelName = kernelNameFor(k, representative.tuning);
     TileLaunch L;
     L.args = nullptr;
+    L.seams = neighboursLinked && k.bilinear;
     L.alphaSel = alphaSelOf(distillArgs(representative)); // (all jobs of a batch share their configuration)
     L.table = static_cast<const TileArgs *>(deviceTileTable);
     L.count = count;

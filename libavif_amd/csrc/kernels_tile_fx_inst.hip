@@ -1,6 +1,6 @@
 // kernels_tile_fx_inst.hip -- one instantiation unit of the tiled fixed-point YUV->RGB kernels (tile_fx_impl.h).  The
 // Makefile compiles this file once per (sample type, chroma layout, upsampling) with -DTILE_YT=... -DTILE_SUB=...
-// -DTILE_BIL=... and -DTILE_FN=<entry point name>.
+// -DTILE_BIL=... and -DTILE_FN=<entry point name>; the families that filter chroma a second time with -DTILE_SEAMS (tile_impl.h).
 #include "tile_fx_impl.h"
 
 #if !defined(TILE_YT) || !defined(TILE_SUB) || !defined(TILE_BIL) || !defined(TILE_FN)

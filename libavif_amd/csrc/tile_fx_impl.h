@@ -27,6 +27,7 @@
 
 namespace avifhip {
 namespace tile {
+inline namespace AVIFHIP_TILE_BUILD { // (tile_impl.h: the plain and the seam-aware build of a family)
 
 // LDS row of staged chroma: entry c+5 holds (u | v << 16) of chroma column cxb + c, c in [-4, 131]
 constexpr int kFxRowPitch = 140;
@@ -340,7 +341,7 @@ template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int
 __global__ __launch_bounds__(256) void yuvToRgbTileFxBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) unsigned rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch];
-    const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
+    const TileArgs job = jobOf(table); // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
     runBlockFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(job, tilesPerRun, rows);
 }
 
@@ -388,7 +389,7 @@ template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int
 __global__ __launch_bounds__(256) void yuvToRgbTileFxSoloBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     __shared__ __attribute__((aligned(16))) unsigned lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kFxRowPitch];
-    const TileArgs job = table[blockIdx.z];
+    const TileArgs job = jobOf(table);
     runSoloFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(job, g, lds);
 }
 
@@ -407,9 +408,9 @@ hipError_t launchSoloFx(const TileLaunch & L)
             hipLaunchKernelGGL((yuvToRgbTileFxSoloBatchKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, g);
     } else {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbTileFxSoloKernel<YT, SUB, BIL, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileFxSoloKernel<YT, SUB, BIL, NCH, APLANE, MUL, 4>), grid, block, 0, L.stream, *L.args, g);
         else
-            hipLaunchKernelGGL((yuvToRgbTileFxSoloKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileFxSoloKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, g);
     }
     return hipGetLastError();
 }
@@ -443,9 +444,9 @@ hipError_t launchOneFx(const TileLaunch & L)
     else if (L.table)
         hipLaunchKernelGGL((yuvToRgbTileFxBatchKernel<YT, SUB, BIL, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
     else if (L.stripsPerWave >= 2)
-        hipLaunchKernelGGL((yuvToRgbTileFxKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
+        AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileFxKernel<YT, SUB, BIL, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
     else
-        hipLaunchKernelGGL((yuvToRgbTileFxKernel<YT, SUB, BIL, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
+        AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileFxKernel<YT, SUB, BIL, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
     return hipGetLastError();
 }
 
@@ -463,5 +464,6 @@ hipError_t launchFxVariant(const TileKey & k, const TileLaunch & L)
     return k.alphaPlane ? launchOneFx<YT, SUB, BIL, 4, true, false>(L) : launchOneFx<YT, SUB, BIL, 4, false, false>(L);
 }
 
+} // namespace AVIFHIP_TILE_BUILD
 } // namespace tile
 } // namespace avifhip

@@ -39,8 +39,26 @@
 #include "tile_map_impl.h"
 #include "tile_shared.h"
 
+// The seam-aware build of a family (-DTILE_SEAMS: kernels_tile_inst.hip, kernels_tile_fx_inst.hip) compiles these headers a second time, with
+// the staging loads below reaching into the neighbouring tiles of a grid canvas (TileHalo).  Its kernels are batch kernels only and live in a
+// namespace of their own, so that both builds link into one library.
+#ifdef TILE_SEAMS
+#define AVIFHIP_TILE_BUILD seams
+#define AVIFHIP_SINGLE_LAUNCH(...) ((void)0) // (single images have no neighbours: not compiled)
+#else
+#define AVIFHIP_TILE_BUILD plain
+#define AVIFHIP_SINGLE_LAUNCH(...) hipLaunchKernelGGL(__VA_ARGS__)
+#endif
+
 namespace avifhip {
 namespace tile {
+inline namespace AVIFHIP_TILE_BUILD {
+
+#ifdef TILE_SEAMS
+constexpr bool kSeams = true;
+#else
+constexpr bool kSeams = false;
+#endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -570,6 +588,84 @@ __device__ __forceinline__ void ycgcoPixel(const TileArgs & A, float Y, f2 uvp, 
     X = A.cgFirst ? B : R, Z = A.cgFirst ? R : B; // cgFirst <=> blue is the first colour channel
 }
 
+// ---- where a staging lane finds a chroma sample.  HALO = false: coordinates clamp into the job's chroma window (the whole plane of the
+//      canvas unless the canvas is a grid of separately stored tiles) -- exactly the reference's border rule (src/reformat.c:768,784): the
+//      neighbour of an edge sample is the sample itself, which is also libyuv's ((3a + a + 2) >> 2 == a).  HALO = true (seam-aware builds,
+//      tiles whose neighbourhood crosses a seam): one sample beyond the window on every side with a neighbouring tile, read from that
+//      tile's plane (TileHalo) ----
+// the neighbours' planes of the wave's job, in LDS (seam-aware builds: jobOf puts them there)
+__device__ __forceinline__ TileHalo::Planes * haloOfWave()
+{
+    __shared__ __attribute__((aligned(16))) TileHalo::Planes held[4][9]; // (workgroups are 64 x 4: one copy per wave, no workgroup barrier needed)
+    return held[threadIdx.y];
+}
+
+// the private copy of a batch kernel's job (read through the table pointer, every field would be re-loaded after each store: the compiler
+// cannot rule out that the RGB stores alias the table -- ~20 scalar loads per tile inside the pipelined loop)
+__device__ __forceinline__ TileArgs jobOf(const TileArgs * __restrict__ table)
+{
+    // (the copy first: behind the fences below the table's fields would no longer qualify for scalar loads, and the job would live in
+    //  vector registers -- 140 instead of 76 in the cooperative 10-bit kernel)
+    const TileArgs job = table[blockIdx.z];
+    if constexpr (kSeams) {
+        TileHalo::Planes * mine = haloOfWave();
+        if (threadIdx.x < 9)
+            mine[threadIdx.x] = table[blockIdx.z].halo.at[threadIdx.x];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    return job;
+}
+
+// Wave-uniform: does the chroma neighbourhood of a tile -- rows cyFirst..cyLast, columns cxFirst..cxLast -- cross a seam of the canvas?
+// (Tiles away from the seams, most of a large canvas, take the plain loads: scalar base, 32-bit lane offset.)
+__device__ __forceinline__ bool haloNeeded(const TileArgs & A, int cyFirst, int cyLast, int cxFirst, int cxLast)
+{
+    if constexpr (!kSeams)
+        return false;
+    const uint32_t s = A.haloSides;
+    return ((s & HALO_ABOVE) && cyFirst < A.cyMin) || ((s & HALO_BELOW) && cyLast > A.cyMax) || ((s & HALO_LEFT) && cxFirst < A.cxMin) ||
+           ((s & HALO_RIGHT) && cxLast > A.cxMax);
+}
+
+struct HaloRow
+{
+    int cy;               // canvas chroma row to read
+    int index;            // 0: in the job's own tile, 3: in the tile above, 6: below (TileHalo)
+    const uint8_t *u, *v; // the planes holding the row's samples inside the window's columns
+};
+template <bool HALO>
+__device__ __forceinline__ HaloRow haloRow(const TileArgs & A, int cyRaw)
+{
+    HaloRow r;
+    if constexpr (!HALO) {
+        r.cy = clampI(cyRaw, A.cyMin, A.cyMax);
+        r.index = 0;
+        r.u = A.u, r.v = A.v;
+    } else {
+        r.cy = clampI(cyRaw, A.cyMin - ((A.haloSides & HALO_ABOVE) ? 1 : 0), A.cyMax + ((A.haloSides & HALO_BELOW) ? 1 : 0));
+        r.index = r.cy < A.cyMin ? 3 : (r.cy > A.cyMax ? 6 : 0);
+        const TileHalo::Planes p = haloOfWave()[r.index];
+        r.u = p.u, r.v = p.v;
+    }
+    return r;
+}
+// column `cxRaw` of that row: the column to read and the planes holding it
+template <bool HALO>
+__device__ __forceinline__ uint32_t haloColumn(const TileArgs & A, const HaloRow & r, int cxRaw, const uint8_t *& pu, const uint8_t *& pv)
+{
+    if constexpr (!HALO) {
+        pu = A.u, pv = A.v;
+        return (uint32_t)clampI(cxRaw, A.cxMin, A.cxMax);
+    } else {
+        const int cx = clampI(cxRaw, A.cxMin - ((A.haloSides & HALO_LEFT) ? 1 : 0), A.cxMax + ((A.haloSides & HALO_RIGHT) ? 1 : 0));
+        const TileHalo::Planes p = haloOfWave()[r.index + (cx < A.cxMin ? 1 : (cx > A.cxMax ? 2 : 0))];
+        pu = p.u, pv = p.v;
+        return (uint32_t)cx;
+    }
+}
+
 // Raw (undecoded) data of one strip (256 pixels x 2 rows) as loaded by one lane.
 template <typename YT, int SUB, bool BIL, bool NEEDA>
 struct StripRaw
@@ -602,18 +698,15 @@ struct BandCtx
     int cxb;        // canvas chroma column of the band's first sample
 };
 
-// issue every load of the tile whose first luma row (relative to the rectangle) is tileY
-template <typename YT, int SUB, bool BIL, bool NEEDA, int NS, int WAVES = 4, bool STREAM = false>
-__device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, uint32_t tileY, TileRaw<YT, SUB, BIL, NEEDA, NS, WAVES> & T)
+// this lane's share of a tile's chroma neighbourhood; LDS row 0 holds canvas chroma row `rowBase`
+template <typename YT, int SUB, bool NEEDA, int NS, int WAVES, bool HALO>
+__device__ __forceinline__ void loadNeighbourhood(const TileArgs & A, const BandCtx & c, int rowBase, TileRaw<YT, SUB, true, NEEDA, NS, WAVES> & T)
 {
     constexpr bool kWide = sizeof(YT) == 2;
     constexpr uint32_t BPS = sizeof(YT);
     typedef StageRows<SUB, NS, WAVES> SR;
     const int tx = threadIdx.x, wv = (WAVES == 1) ? 0 : (int)threadIdx.y;
-    // ---- bilinear: this lane's share of the tile's chroma neighbourhood (first: it heads the longest chain) ----
-    if constexpr (BIL) {
-        // canvas chroma row held by LDS row 0
-        const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)(tileY >> 1) - 1 : A.cy0 + (int)tileY;
+    {
         const int t = wv * kLanesX + tx;
 #pragma unroll
         for (int j = 0; j < SR::kRounds; ++j) {
@@ -624,21 +717,23 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
                 // of an edge sample is the sample itself
                 int row, grp;
                 SR::place(task, row, grp);
-                const int cy = clampI(rowBase + row, A.cyMin, A.cyMax);
+                const HaloRow hr = haloRow<HALO>(A, rowBase + row);
+                const int cy = hr.cy;
                 const int cxa = c.cxb - 4 + 4 * grp;
                 if (cxa >= A.cxMin && cxa + 3 <= A.cxMax) {
-                    T.su[j] = load4<YT>(A.u, (uint32_t)cy * A.uPitch + (uint32_t)cxa * BPS);
-                    T.sv[j] = load4<YT>(A.v, (uint32_t)cy * A.vPitch + (uint32_t)cxa * BPS);
+                    T.su[j] = load4<YT>(hr.u, (uint32_t)cy * A.uPitch + (uint32_t)cxa * BPS);
+                    T.sv[j] = load4<YT>(hr.v, (uint32_t)cy * A.vPitch + (uint32_t)cxa * BPS);
                 } else {
-                    // group cut by the left or right border of the canvas
+                    // group cut by the left or right border of the window
                     T.su[j].w[0] = T.sv[j].w[0] = 0;
                     if constexpr (kWide)
                         T.su[j].w[1] = T.sv[j].w[1] = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const uint32_t cx = (uint32_t)clampI(cxa + k, A.cxMin, A.cxMax);
-                        const unsigned u = load1<YT>(A.u, (uint32_t)cy * A.uPitch + cx * BPS);
-                        const unsigned v = load1<YT>(A.v, (uint32_t)cy * A.vPitch + cx * BPS);
+                        const uint8_t *pu, *pv;
+                        const uint32_t cx = haloColumn<HALO>(A, hr, cxa + k, pu, pv);
+                        const unsigned u = load1<YT>(pu, (uint32_t)cy * A.uPitch + cx * BPS);
+                        const unsigned v = load1<YT>(pv, (uint32_t)cy * A.vPitch + cx * BPS);
                         if constexpr (!kWide) {
                             T.su[j].w[0] |= u << (8 * k);
                             T.sv[j].w[0] |= v << (8 * k);
@@ -651,15 +746,33 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
             }
         }
     }
-    if constexpr (BIL && SR::kSplitHalo) {
+    if constexpr (SR::kSplitHalo) {
         T.hu = T.hv = 0;
         if (tx < 2 * SR::kRows) {
-            const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)(tileY >> 1) - 1 : A.cy0 + (int)tileY;
-            const int cy = clampI(rowBase + (tx >> 1), A.cyMin, A.cyMax);
-            const uint32_t cx = (uint32_t)clampI((tx & 1) ? c.cxb + 128 : c.cxb - 1, A.cxMin, A.cxMax);
-            T.hu = load1<YT>(A.u, (uint32_t)cy * A.uPitch + cx * BPS);
-            T.hv = load1<YT>(A.v, (uint32_t)cy * A.vPitch + cx * BPS);
+            const HaloRow hr = haloRow<HALO>(A, rowBase + (tx >> 1));
+            const uint8_t *pu, *pv;
+            const uint32_t cx = haloColumn<HALO>(A, hr, (tx & 1) ? c.cxb + 128 : c.cxb - 1, pu, pv);
+            T.hu = load1<YT>(pu, (uint32_t)hr.cy * A.uPitch + cx * BPS);
+            T.hv = load1<YT>(pv, (uint32_t)hr.cy * A.vPitch + cx * BPS);
         }
+    }
+}
+
+// issue every load of the tile whose first luma row (relative to the rectangle) is tileY
+template <typename YT, int SUB, bool BIL, bool NEEDA, int NS, int WAVES = 4, bool STREAM = false>
+__device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, uint32_t tileY, TileRaw<YT, SUB, BIL, NEEDA, NS, WAVES> & T)
+{
+    constexpr bool kWide = sizeof(YT) == 2;
+    constexpr uint32_t BPS = sizeof(YT);
+    const int wv = (WAVES == 1) ? 0 : (int)threadIdx.y;
+    // ---- bilinear: this lane's share of the tile's chroma neighbourhood (first: it heads the longest chain) ----
+    if constexpr (BIL) {
+        // canvas chroma row held by LDS row 0
+        const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)(tileY >> 1) - 1 : A.cy0 + (int)tileY;
+        if (haloNeeded(A, rowBase, rowBase + StageRows<SUB, NS, WAVES>::kRows - 1, c.cxb - 1, c.cxb + 128)) // (wave-uniform; never in the plain builds)
+            loadNeighbourhood<YT, SUB, NEEDA, NS, WAVES, true>(A, c, rowBase, T);
+        else
+            loadNeighbourhood<YT, SUB, NEEDA, NS, WAVES, false>(A, c, rowBase, T);
     }
     // ---- this wave's luma / alpha / co-sited chroma for all of its strips ----
 #pragma unroll
@@ -1265,7 +1378,7 @@ __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * 
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
     // a private copy of the job: read through the table pointer, every field would be re-loaded after each store (the compiler
     // cannot rule out that the RGB stores alias the table) -- ~20 scalar loads per tile inside the pipelined loop
-    const TileArgs job = table[blockIdx.z];
+    const TileArgs job = jobOf(table);
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
         runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, tilesPerRun, rows, xchg);
@@ -1325,7 +1438,7 @@ template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, boo
 __global__ __launch_bounds__(256) void yuvToRgbTileSoloBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
-    const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel
+    const TileArgs job = jobOf(table); // a private copy: see yuvToRgbTileBatchKernel
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
         runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(job, g, lds, xchg);
@@ -1423,7 +1536,7 @@ template <typename YT, int SUB, bool BIL, typename RT, bool APLANE, bool HASMUL,
 __global__ __launch_bounds__(256) void yuvToRgbTileSoloMappedBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsMapped[];
-    const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel
+    const TileArgs job = jobOf(table); // a private copy: see yuvToRgbTileBatchKernel
     runSoloMapped<YT, SUB, BIL, RT, APLANE, HASMUL, NS, TURNED>(job, g, ldsMapped);
 }
 
@@ -1449,7 +1562,7 @@ hipError_t launchSoloMapped(const TileLaunch & L)
         if (L.table)
             hipLaunchKernelGGL((yuvToRgbTileSoloMappedBatchKernel<YT, SUB, BIL, RT, APLANE, MUL, kTurnNS, true>), grid, block, lds, L.stream, L.table, g);
         else
-            hipLaunchKernelGGL((yuvToRgbTileSoloMappedKernel<YT, SUB, BIL, RT, APLANE, MUL, kTurnNS, true>), grid, block, lds, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloMappedKernel<YT, SUB, BIL, RT, APLANE, MUL, kTurnNS, true>), grid, block, lds, L.stream, *L.args, g);
         return hipGetLastError();
     }
     const uint32_t lds4 = SoloMapLds<YT, SUB, BIL, RT, 4>::kPlain, lds2 = SoloMapLds<YT, SUB, BIL, RT, 2>::kPlain;
@@ -1460,9 +1573,9 @@ hipError_t launchSoloMapped(const TileLaunch & L)
             hipLaunchKernelGGL((yuvToRgbTileSoloMappedBatchKernel<YT, SUB, BIL, RT, APLANE, MUL, 2, false>), grid, block, lds2, L.stream, L.table, g);
     } else {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbTileSoloMappedKernel<YT, SUB, BIL, RT, APLANE, MUL, 4, false>), grid, block, lds4, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloMappedKernel<YT, SUB, BIL, RT, APLANE, MUL, 4, false>), grid, block, lds4, L.stream, *L.args, g);
         else
-            hipLaunchKernelGGL((yuvToRgbTileSoloMappedKernel<YT, SUB, BIL, RT, APLANE, MUL, 2, false>), grid, block, lds2, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloMappedKernel<YT, SUB, BIL, RT, APLANE, MUL, 2, false>), grid, block, lds2, L.stream, *L.args, g);
     }
     return hipGetLastError();
 }
@@ -1484,9 +1597,9 @@ hipError_t launchSoloSel(const TileLaunch & L, uint32_t nsw, const PkGeom & g, d
             hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, false, MULSEL>), grid, block, 0, L.stream, L.table, g);
     } else {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, MULSEL>), grid, block, 0, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, MULSEL>), grid, block, 0, L.stream, *L.args, g);
         else
-            hipLaunchKernelGGL((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, MULSEL>), grid, block, 0, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, MULSEL>), grid, block, 0, L.stream, *L.args, g);
     }
     return hipGetLastError();
 }
@@ -1531,9 +1644,9 @@ hipError_t launchOne(const TileLaunch & L)
     else if (L.table)
         hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
     else if (L.stripsPerWave >= 2)
-        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
+        AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
     else
-        hipLaunchKernelGGL((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
+        AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
     return hipGetLastError();
 }
 
@@ -1573,5 +1686,6 @@ hipError_t launchSubVariant(const TileKey & k, const TileLaunch & L)
     return k.wideRgb ? launchAlphaVariant<YT, SUB, BIL, uint16_t>(k, L) : launchAlphaVariant<YT, SUB, BIL, uint8_t>(k, L);
 }
 
+} // namespace AVIFHIP_TILE_BUILD
 } // namespace tile
 } // namespace avifhip

@@ -44,6 +44,7 @@
 
 namespace avifhip {
 namespace tile {
+inline namespace AVIFHIP_TILE_BUILD { // (tile_impl.h: the plain and the seam-aware build of a family)
 
 constexpr int kPkPitch = 140;   // words per staged chroma row: entry c + 5 holds chroma column cxb + c, c in [-4, 131]
 constexpr int kPkGroups = 17;   // 8-column groups per staged row
@@ -156,7 +157,7 @@ __device__ __forceinline__ unsigned add3(unsigned a, unsigned b, unsigned c)
 }
 
 // ---- chroma neighbourhood: loads of one staging round (8 columns of both planes per lane) ----
-template <int SUB, int NSW, int WIDE>
+template <int SUB, int NSW, int WIDE, bool HALO>
 __device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int rowBase, int round, int slotMin, int slotMax, typename PkTypes<WIDE>::Col8 & uD,
                                             typename PkTypes<WIDE>::Col8 & vD)
 {
@@ -170,25 +171,26 @@ __device__ __forceinline__ void pkStageLoad(const TileArgs & A, int cxb, int row
     uD = Col8 {};
     vD = Col8 {};
     if (rr < kPkRowsPerRound && i < ST::kRows && i >= slotMin && i <= slotMax) {
-        // coordinates clamp to the job's chroma window (the whole plane unless the canvas is a grid of separately stored tiles):
-        // the neighbour of an edge sample is the sample itself, which IS libyuv's edge rule ((3a + a + 2) >> 2 == a)
-        const int cy = clampI(rowBase + i, A.cyMin, A.cyMax);
+        // coordinates clamp to the job's chroma window (haloRow, tile_impl.h: the whole plane unless the canvas is a grid of separately
+        // stored tiles; the seam-aware builds read one sample beyond it from the neighbouring tile)
+        const HaloRow hr = haloRow<HALO>(A, rowBase + i);
         const int cxa = cxb - 4 + 8 * j;
-        const uint32_t uRow = (uint32_t)cy * A.uPitch, vRow = (uint32_t)cy * A.vPitch;
+        const uint32_t uRow = (uint32_t)hr.cy * A.uPitch, vRow = (uint32_t)hr.cy * A.vPitch;
         if (cxa >= A.cxMin && cxa + 7 <= A.cxMax) {
-            uD = *reinterpret_cast<const Col8 *>(A.u + (uRow + (uint32_t)cxa * B));
-            vD = *reinterpret_cast<const Col8 *>(A.v + (vRow + (uint32_t)cxa * B));
+            uD = *reinterpret_cast<const Col8 *>(hr.u + (uRow + (uint32_t)cxa * B));
+            vD = *reinterpret_cast<const Col8 *>(hr.v + (vRow + (uint32_t)cxa * B));
         } else {
             // group cut by the left or right border of the window
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const uint32_t cx = (uint32_t)clampI(cxa + k, A.cxMin, A.cxMax);
+                const uint8_t *pu, *pv;
+                const uint32_t cx = haloColumn<HALO>(A, hr, cxa + k, pu, pv);
                 if constexpr (WIDE != WIDE_NONE) {
-                    const unsigned u = *reinterpret_cast<const uint16_t *>(A.u + (uRow + cx * 2u)), v = *reinterpret_cast<const uint16_t *>(A.v + (vRow + cx * 2u));
+                    const unsigned u = *reinterpret_cast<const uint16_t *>(pu + (uRow + cx * 2u)), v = *reinterpret_cast<const uint16_t *>(pv + (vRow + cx * 2u));
                     uD[k >> 1] |= u << (16 * (k & 1));
                     vD[k >> 1] |= v << (16 * (k & 1));
                 } else {
-                    const unsigned u = A.u[uRow + cx], v = A.v[vRow + cx];
+                    const unsigned u = pu[uRow + cx], v = pv[vRow + cx];
                     uD[k >> 2] |= u << (8 * (k & 3));
                     vD[k >> 2] |= v << (8 * (k & 3));
                 }
@@ -443,9 +445,15 @@ __device__ __forceinline__ void pkLoad(const TileArgs & A, const PkSpot & w, PkR
 #endif
             const int cxb = A.cx0 + (int)(bandX >> 1);
             const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)w.strip0 - 1 : A.cy0 + 2 * (int)w.strip0;
+            if (haloNeeded(A, rowBase, rowBase + ST::kRows - 1, cxb - 1, cxb + 128)) { // (wave-uniform; never in the plain builds)
 #pragma unroll
-            for (int t = 0; t < ST::kRounds; ++t)
-                pkStageLoad<SUB, NSW, WIDE>(A, cxb, rowBase, t, w.slotMin, w.slotMax, R.uD[t], R.vD[t]);
+                for (int t = 0; t < ST::kRounds; ++t)
+                    pkStageLoad<SUB, NSW, WIDE, true>(A, cxb, rowBase, t, w.slotMin, w.slotMax, R.uD[t], R.vD[t]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < ST::kRounds; ++t)
+                    pkStageLoad<SUB, NSW, WIDE, false>(A, cxb, rowBase, t, w.slotMin, w.slotMax, R.uD[t], R.vD[t]);
+            }
         }
     };
     // Which loads go first (tests/tools/pkbench.hip / pkbench_wide.hip with -DAVIFHIP_LUMA_FIRST / -DAVIFHIP_CHROMA_FIRST): 8-bit planes run
@@ -833,7 +841,7 @@ template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WID
 __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
-    const TileArgs job = table[blockIdx.z]; // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
+    const TileArgs job = jobOf(table); // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
     pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(job, g, lds);
 }
 
@@ -848,7 +856,7 @@ template <int SUB, bool BIL, int NSW, int WIDE>
 __global__ __launch_bounds__(256) void yuvToRgbPkAttenuateBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
-    const TileArgs job = table[blockIdx.z];
+    const TileArgs job = jobOf(table);
     pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, true>(job, g, lds);
 }
 
@@ -868,9 +876,9 @@ hipError_t launchPkAttenuate(const TileLaunch & L)
             hipLaunchKernelGGL((yuvToRgbPkAttenuateBatchKernel<SUB, BIL, 2, WIDE>), grid, block, lds2, L.stream, L.table, g);
     } else {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbPkAttenuateKernel<SUB, BIL, 4, WIDE>), grid, block, lds4, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkAttenuateKernel<SUB, BIL, 4, WIDE>), grid, block, lds4, L.stream, *L.args, g);
         else
-            hipLaunchKernelGGL((yuvToRgbPkAttenuateKernel<SUB, BIL, 2, WIDE>), grid, block, lds2, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkAttenuateKernel<SUB, BIL, 2, WIDE>), grid, block, lds2, L.stream, *L.args, g);
     }
     return hipGetLastError();
 }
@@ -899,9 +907,9 @@ hipError_t launchPkMapped(const TileLaunch & L)
             hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, lds2, L.stream, L.table, g);
     } else {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, lds4, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, lds4, L.stream, *L.args, g);
         else
-            hipLaunchKernelGGL((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, lds2, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, lds2, L.stream, *L.args, g);
     }
     return hipGetLastError();
 }
@@ -921,5 +929,6 @@ hipError_t launchPkWide(const TileLaunch & L)
     return L.wideDownshift ? launchPkMapped<SUB, BIL, NCH, APLANE, false, WIDE_DOWNSHIFT>(L) : launchPkMapped<SUB, BIL, NCH, APLANE, false, WIDE_NATIVE>(L);
 }
 
+} // namespace AVIFHIP_TILE_BUILD
 } // namespace tile
 } // namespace avifhip

@@ -13,6 +13,24 @@ namespace tile {
 
 enum Subsampling : int { SUB_444 = 0, SUB_422 = 1, SUB_420 = 2, SUB_400 = 3 };
 
+// Grid canvases in ONE launch (the seam-aware builds of the bilinear families: -DTILE_SEAMS, kernels_tile_inst.hip): where a job's chroma
+// filter reaches over the edge of its chroma window, the sample comes from the neighbouring tile instead of being clamped -- what
+// libavif gets by stitching the tiles into one canvas first (src/read.c:1823-1877) and filtering across the seams (src/reformat.c:766-816).
+// Index 3 * v + h, v: 0 = the job's own rows, 1 = the tile above, 2 = the tile below; h: 0 = own columns, 1 = left, 2 = right.  Every
+// pointer addresses CANVAS sample (0,0) of its tile's plane, virtually, like TileArgs::u / v (same pitch: the host checks), so one offset
+// serves all nine.  Filled by linkTileBatchHalo (kernels_tile.hip); entries of neighbours that do not exist hold the job's own planes and
+// are never read (TileArgs::haloSides stops the coordinates at the window there: the reference's border rule).  The kernels do not keep
+// these in registers: every wave copies the table's nine entries into LDS when it starts (jobOf, tile_impl.h), and the staging lanes of a
+// tile whose neighbourhood crosses a seam read their pair from there.
+struct TileHalo
+{
+    struct Planes
+    {
+        const uint8_t *u, *v;
+    } at[9];
+};
+enum HaloSides : uint32_t { HALO_ABOVE = 1, HALO_BELOW = 2, HALO_LEFT = 4, HALO_RIGHT = 8 };
+
 // Everything a tiled kernel reads, distilled from a YuvToRgbPlan: small enough to live in scalar registers for the
 // whole kernel (the full plan does not).  The kernel converts the w4 x h2 pixels at the rectangle origin, w4 a
 // multiple of 4 and h2 a multiple of 2; the at most 3 columns / 1 row left over go to the universal kernel.
@@ -85,6 +103,9 @@ struct TileArgs
         // v_perm_b32 selectors placing (x0 g0 x1 g1) [second operand] and (z0 z1 a0 a1) [first operand] into pixel 0 / pixel 1 of a pair
         uint32_t pkSel0, pkSel1;
     } fx;
+    // seam-aware builds (jobs that are tiles of one canvas): which sides have a neighbouring tile (HaloSides), and the neighbours' planes
+    uint32_t haloSides;
+    TileHalo halo;
 };
 
 
@@ -197,7 +218,7 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
         }
         A.fx.pkSel0 = sel0, A.fx.pkSel1 = sel1;
     }
-    return A;
+    return A; // (no neighbours: haloSides = 0)
 }
 
 struct TileKey
@@ -237,6 +258,7 @@ struct TileLaunch
     bool solo;              // fp32 / 10-12-bit integer families: the wave-private kernels instead of the cooperative runs
     bool pkWide;            // 10-12-bit integer family without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)
     bool wideDownshift;     // ... entered through the reduction to 8 bits (TileKey)
+    bool seams;             // batches: jobs are tiles of one canvas with their neighbours linked (TileHalo) -- the seam-aware builds
     int alphaSel;           // fp32 kernels with pending alpha arithmetic: the one mode the job(s) ask for (computeTile MULSEL), 0 = all compiled in
     hipStream_t stream;
 };

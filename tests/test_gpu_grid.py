@@ -41,7 +41,35 @@ def cases(avoid_libyuv):
     ]
 
 
-def run_grid(lib, g):
+def linked_cases(avoid_libyuv):
+    """Grids every pixel of which goes through the tiled kernels (tile and canvas sizes in whole 4 x 2 pixel groups): the jobs are linked to
+    their neighbours and ONE launch converts tiles and seams (the seam-aware builds, tile_impl.h TILE_SEAMS).  Every kernel flavour that
+    stages a chroma neighbourhood, tiles narrower / wider than a 256-pixel band, shorter / taller than a kernel tile, canvases that end
+    inside the last tile."""
+    base = dict(avoid_libyuv=avoid_libyuv)
+    Y = H.Y2RCase
+    return [
+        H.GridCase(3, 3, 512, 64, 1536, 192, Y(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, **base)),
+        H.GridCase(3, 3, 512, 64, 1100, 150, Y(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, **base)),
+        H.GridCase(2, 3, 320, 96, 960, 190, Y(0, 0, yuv_format=3, yuv_range=1, matrix=6, rgb_format=A.AVIF_RGB_FORMAT_BGRA, upsampling=4, **base)),
+        H.GridCase(4, 2, 64, 32, 128, 126, Y(0, 0, yuv_format=3, yuv_range=0, matrix=5, rgb_format=A.AVIF_RGB_FORMAT_RGB, upsampling=4, **base)),
+        H.GridCase(2, 2, 320, 40, 640, 80, Y(0, 0, yuv_format=2, yuv_range=1, matrix=6, upsampling=4, **base)),
+        H.GridCase(2, 3, 256, 32, 704, 60, Y(0, 0, yuv_format=2, yuv_range=0, matrix=1, rgb_format=A.AVIF_RGB_FORMAT_ARGB, upsampling=4, alpha=True, rgb_premultiplied=True, **base)),
+        # cfg5 in miniature, RGBA(10) and RGBA8, then 12-bit 4:2:2
+        H.GridCase(3, 3, 512, 64, 1536, 192, Y(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=10, upsampling=4, **base)),
+        H.GridCase(3, 3, 512, 64, 1100, 150, Y(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=8, upsampling=4, **base)),
+        H.GridCase(2, 2, 768, 48, 1280, 96, Y(0, 0, yuv_depth=12, yuv_format=2, yuv_range=1, matrix=9, rgb_depth=16, upsampling=4, alpha=True, **base)),
+        H.GridCase(3, 2, 64, 64, 128, 192, Y(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, upsampling=4, alpha=True, rgb_premultiplied=True, **base),
+                   alpha_limited=True),
+        H.GridCase(2, 2, 256, 64, 512, 128, Y(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=1, rgb_depth=8, upsampling=4, alpha=True, rgb_premultiplied=True, **base)),
+        H.GridCase(2, 2, 256, 64, 512, 128, Y(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, alpha=True, image_premultiplied=True, **base)),
+        H.GridCase(2, 2, 320, 64, 600, 100, Y(0, 0, yuv_depth=10, yuv_format=3, yuv_range=0, matrix=9, rgb_depth=16, rgb_format=A.AVIF_RGB_FORMAT_BGR, upsampling=4, **base)),
+        # a canvas large enough for the wave-private fp32 kernels (8-bit planes from 6 megapixels) and tall tiles
+        H.GridCase(2, 3, 1280, 1024, 3700, 1900, Y(0, 0, yuv_format=3, yuv_range=0, matrix=1, upsampling=4, **base)),
+    ]
+
+
+def run_grid(lib, g, launches=None):
     tiles = H.make_grid_tiles(g)
     want = H.grid_output(g)
     assert oracle_grid(g, tiles, want, libyuv_build=not g.conv.avoid_libyuv) == 0
@@ -53,11 +81,36 @@ def run_grid(lib, g):
     colour = (P * n)(*[C.pointer(d.struct) for d in dtiles])
     alpha = (P * n)(*[C.pointer(d.struct) for d in dtiles]) if g.conv.alpha else None
     grid = native.avifhipGrid(g.rows, g.columns, g.out_w, g.out_h)
+    before = lib.avifhipLaunchCount()
     native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), colour, alpha, int(g.alpha_limited), drgb.struct, None), "avifhipGridYUVToRGBAsync")
     native.check(lib.avifhipSynchronize(None), "sync")
     drgb.download_into_host()
     wb = g.out_w * abi.rgb_pixel_size(g.conv.rgb_format, g.conv.rgb_depth)
     assert np.array_equal(out.pixels[:, :wb], want.pixels[:, :wb]), (g.ident(), native.last_kernel(), H.describe_diff(want.pixels[:, :wb], out.pixels[:, :wb]))
+    if launches is not None:
+        assert lib.avifhipLaunchCount() - before == launches, (g.ident(), native.last_kernel())
+
+
+@pytest.mark.parametrize("g", linked_cases(True), ids=lambda g: g.ident())
+def test_linked_grid_is_one_launch_fp32_path(hip, g):
+    run_grid(hip, g, launches=1)
+
+
+@pytest.mark.parametrize("g", linked_cases(False), ids=lambda g: g.ident())
+def test_linked_grid_is_one_launch_default_arithmetic(hip_auto_arithmetic, g):
+    run_grid(hip_auto_arithmetic, g, launches=1)
+
+
+def test_linked_grids_with_the_seam_pass_forced(hip, monkeypatch):
+    """AVIFHIP_GRID_SEAM_PASS=1: the same grids through the tile batch + seam kernel of rounds 1-3 (two launches), same bytes."""
+    monkeypatch.setenv("AVIFHIP_GRID_SEAM_PASS", "1")
+    try:
+        for avoid in (True, False):
+            hip.avifhipSetArithmetic(1 if avoid else 0)
+            for g in linked_cases(avoid)[:8]:
+                run_grid(hip, g, launches=2)
+    finally:
+        hip.avifhipSetArithmetic(1)
 
 
 @pytest.mark.parametrize("g", cases(True), ids=lambda g: g.ident())
@@ -75,6 +128,7 @@ def test_both_seam_kernels(hip, pairs, monkeypatch):
     """Seams are redone by one lane per pixel (small grids) or one lane per pair of pixels either side of a seam sharing the chroma quad
     (large ones); AVIFHIP_SEAM_PAIRS forces either, so that the small test grids go through both, in both arithmetics."""
     monkeypatch.setenv("AVIFHIP_SEAM_PAIRS", pairs)
+    monkeypatch.setenv("AVIFHIP_GRID_SEAM_PASS", "1")  # (grids without leftovers would not reach the seam kernels otherwise)
     try:
         for avoid in (True, False):
             hip.avifhipSetArithmetic(1 if avoid else 0)
