@@ -218,6 +218,23 @@ __device__ __forceinline__ float unmulChannel(float c, const UnmulOperand & U)
     const float q0 = c * U.r;
     return fminf(__builtin_fmaf(__builtin_fmaf(-q0, U.d, c), U.r, q0), U.lim);
 }
+// ... with the divisor and its reciprocal of every 8-bit alpha code in LDS (unmulTable: built by the workgroup when the kernel starts, by
+// the instructions above, so the entries ARE unmulOperand's): the pixel reads its pair instead of forming it -- two compares, three selects,
+// v_rcp_f32 (a quarter-rate instruction) and its Newton step less per pixel -- and the three channels of a pixel pair go through the packed
+// multiply / fused multiply-add.  The upper clamp is min(q, 1) everywhere: where unmulOperand lifts it (a == 1) the quotient is c <= 1.
+struct UnmulEntry
+{
+    float d, r;
+};
+__device__ __forceinline__ void unmulPairFromTable(const UnmulEntry * table, unsigned a0, unsigned a1, f2 & x, f2 & g, f2 & z)
+{
+    const UnmulEntry e0 = table[a0], e1 = table[a1];
+    const f2 d = { e0.d, e1.d }, r = { e0.r, e1.r }, one = splat2(1.0f);
+    const f2 qx = x * r, qg = g * r, qz = z * r;
+    x = __builtin_elementwise_min(__builtin_elementwise_fma(__builtin_elementwise_fma(-qx, d, x), r, qx), one);
+    g = __builtin_elementwise_min(__builtin_elementwise_fma(__builtin_elementwise_fma(-qg, d, g), r, qg), one);
+    z = __builtin_elementwise_min(__builtin_elementwise_fma(__builtin_elementwise_fma(-qz, d, z), r, qz), one);
+}
 __device__ __forceinline__ void alphaOnPair(bool multiply, f2 a, f2 & x, f2 & g, f2 & z)
 {
     if (multiply) {
@@ -242,7 +259,7 @@ __device__ __forceinline__ int liftCode(float c, float maxf)
 // own (launchOne picks): with the YCgCo family and the alpha (un)multiply compiled into the same loop as wave-uniform branches, the
 // one-strip kernel that serves 4K frames took 120 vector registers (half the occupancy) and cfg4 went from 9.0 to 14.9 us.
 template <typename RT, int NCH, typename YT, int SUB, bool SWAP, bool PLAIN>
-__device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S)
+__device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S, const UnmulEntry * unmulTable)
 {
     constexpr uint32_t BPS = sizeof(YT);
     const int yuvMax = (int)A.yuvMax;
@@ -282,8 +299,12 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
                         ca[h] = channelOf<RT, NCH>(S.row[r], 2 * p + h, alphaFirst ? 0 : 3);
-                    const f2 a = div2((f2) { (float)ca[0], (float)ca[1] }, A.rcpRgbMax);
-                    alphaOnPair(A.mulMode == MUL_MULTIPLY, a, xs, Gs, zs);
+                    if (sizeof(RT) == 1 && A.mulMode == MUL_UNMULTIPLY) { // (8-bit channels: the alpha code addresses the workgroup's table)
+                        unmulPairFromTable(unmulTable, ca[0], ca[1], xs, Gs, zs);
+                    } else {
+                        const f2 a = div2((f2) { (float)ca[0], (float)ca[1] }, A.rcpRgbMax);
+                        alphaOnPair(A.mulMode == MUL_MULTIPLY, a, xs, Gs, zs);
+                    }
                 }
             }
             const f2 R = SWAP ? zs : xs, B = SWAP ? xs : zs;
@@ -390,14 +411,14 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
 }
 
 template <typename RT, int NCH, typename YT, int SUB, bool PLAIN>
-__device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S)
+__device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S, const UnmulEntry * unmulTable)
 {
     // which memory-order colour channel is red decides the operand ORDER of the luma sum (fp32 addition is not associative):
     // one wave-uniform branch instead of selects per pixel
     if (A.slotB < A.slotR)
-        computeStripT<RT, NCH, YT, SUB, true, PLAIN>(A, sy, X, laneValid, S);
+        computeStripT<RT, NCH, YT, SUB, true, PLAIN>(A, sy, X, laneValid, S, unmulTable);
     else
-        computeStripT<RT, NCH, YT, SUB, false, PLAIN>(A, sy, X, laneValid, S);
+        computeStripT<RT, NCH, YT, SUB, false, PLAIN>(A, sy, X, laneValid, S, unmulTable);
 }
 
 // ---- libyuv's fixed point (8-bit RGB -> 8-bit planes, BT.601, appendix D.5): same loads, stores and strip walk ----
@@ -549,17 +570,35 @@ __global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A)
     const bool laneValid = X < A.w4;
     const uint32_t Xc = laneValid ? X : 0;
     const uint32_t first = (chunk * kWaves + threadIdx.y) * (2 * NS);
-    if (first >= A.h2)
+    // pending un-multiply of 8-bit pixels: (divisor, reciprocal) of every alpha code, one entry per thread of the workgroup (before any
+    // wave leaves: the barrier is the workgroup's)
+    constexpr bool kTable = !PLAIN && NCH == 4 && sizeof(RT) == 1;
+    __shared__ UnmulEntry unmulTable[kTable ? 256 : 1];
+    const bool tabled = kTable && A.mulMode == MUL_UNMULTIPLY; // wave-uniform
+    if (first >= A.h2 && !tabled)
         return;
     StripRaw<RT, NCH> raw[NS];
+    if (first < A.h2) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-        loadStrip<RT, NCH>(A, first + 2 * s, Xc, raw[s]);
+        for (int s = 0; s < NS; ++s)
+            loadStrip<RT, NCH>(A, first + 2 * s, Xc, raw[s]);
+    }
+    if constexpr (kTable) {
+        if (tabled) {
+            const unsigned code = threadIdx.y * kLanes + threadIdx.x; // 0..255 (workgroups are kLanes x kWaves = 64 x 4)
+            const float a = divExact((float)code, A.rcpRgbMax);
+            const UnmulOperand U = unmulOperand(a);
+            unmulTable[code] = { U.d, U.r };
+            __syncthreads();
+            if (first >= A.h2)
+                return;
+        }
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         if (first + 2 * s >= A.h2) // wave-uniform
             break;
-        computeStrip<RT, NCH, YT, SUB, PLAIN>(A, first + 2 * s, X, laneValid, raw[s]);
+        computeStrip<RT, NCH, YT, SUB, PLAIN>(A, first + 2 * s, X, laneValid, raw[s], unmulTable);
     }
 }
 

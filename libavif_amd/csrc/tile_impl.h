@@ -295,6 +295,48 @@ __device__ __forceinline__ InLoopAlpha inLoopAlpha(const TileArgs & A, unsigned 
     }
     return L;
 }
+// 8-bit alpha planes: (divisor, reciprocal) of every alpha code in LDS, built by the workgroup when the kernel starts with inLoopAlpha's own
+// instructions (buildUnmulTable) -- a pixel reads its pair instead of forming it (a conversion, the normalisation, a compare, a select,
+// v_rcp_f32 -- a quarter-rate instruction -- and its Newton step less per pixel).  The reciprocal of alpha 0 is stored as 0: the quotient
+// then comes out as 0 (q0 = c * 0, fma(c, 0, 0)) without the select per channel.
+struct UnmulEntry
+{
+    float d, r;
+};
+__device__ __forceinline__ UnmulEntry * unmulTable()
+{
+    __shared__ UnmulEntry table[256];
+    return table;
+}
+// (every thread of the workgroup, before any wave leaves the kernel)
+__device__ __forceinline__ void buildUnmulTable(const TileArgs & A)
+{
+    const unsigned code = threadIdx.y * blockDim.x + threadIdx.x; // workgroups are 64 x 4
+    const InLoopAlpha L = inLoopAlpha<true, false>(A, code);
+    unmulTable()[code & 255u] = { L.Ac, L.zero ? 0.0f : L.r };
+    __syncthreads();
+}
+// quantiser arguments of a pixel's (first, third) colours and of green, un-multiplied by the alpha code `a`
+__device__ __forceinline__ void unmulFromTable(const TileArgs & A, unsigned a, float X, float G, float Z, f2 & tbr, float & tg)
+{
+    const UnmulEntry e = unmulTable()[a];
+    const f2 c = { X, Z }, d = splat(e.d), r = splat(e.r);
+    const f2 q0 = c * r;
+    const f2 er = __builtin_elementwise_fma(-q0, d, c);
+    const f2 q = { fmaSat01(er.x, e.r, q0.x), fmaSat01(er.y, e.r, q0.y) };
+    tbr = __builtin_elementwise_fma(q, splat(A.rgbMaxF), splat(0.5f));
+    const float g0 = G * e.r;
+    tg = quantizeArg(fmaSat01(__builtin_fmaf(-g0, e.d, G), e.r, g0), A.rgbMaxF);
+}
+// first thing in a kernel whose pixels may be un-multiplied from an 8-bit alpha plane (MULSEL: computeTile's; 0 = the job says)
+template <typename YT, bool HASMUL, int MULSEL>
+__device__ __forceinline__ void prepareAlphaTables(const TileArgs & A)
+{
+    if constexpr (HASMUL && sizeof(YT) == 1 && (MULSEL == 0 || MULSEL == 2)) {
+        if (MULSEL == 2 || A.inLoopMul == MUL_UNMULTIPLY) // wave-uniform (workgroup-uniform: one job per workgroup)
+            buildUnmulTable(A);
+    }
+}
 template <bool UNMUL>
 __device__ __forceinline__ float inLoopChannel(const TileArgs & A, float c, const InLoopAlpha & L)
 {
@@ -1209,7 +1251,11 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                             tbr[i] = (f2) { inLoopChannel<false>(A, X[i], L), inLoopChannel<false>(A, Z[i], L) };
                             tg[i] = inLoopChannel<false>(A, G[i], L);
                         }
-                    } else if (!kWide || A.yuvMax <= 4095u) {
+                    } else if constexpr (!kWide) { // 8-bit alpha planes: the workgroup's table (built by runBlock / runSolo / runSoloMapped)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            unmulFromTable(A, av[i], X[i], G[i], Z[i], tbr[i], tg[i]);
+                    } else if (A.yuvMax <= 4095u) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const InLoopAlpha L = inLoopAlpha<true, kWide>(A, av[i]);
@@ -1313,6 +1359,7 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRu
 {
     constexpr int kTileH = 8 * NS;
     constexpr bool kNeedA = APLANE || HASMUL;
+    prepareAlphaTables<YT, HASMUL, 0>(A);
     const uint32_t bands = (A.w4 + kBandW - 1) / kBandW;
     const uint32_t tilesY = (A.h2 + kTileH - 1) / kTileH;
     const uint32_t runsY = (tilesY + tilesPerRun - 1) / tilesPerRun;
@@ -1395,6 +1442,7 @@ __device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2
 {
     constexpr bool kNeedA = APLANE || HASMUL;
     typedef StageRows<SUB, NS, 1> SR;
+    prepareAlphaTables<YT, HASMUL, MULSEL>(A);
     const uint32_t tile = pkTileOf(blockIdx.x, g);
     if (tile >= g.nTiles)
         return;
@@ -1403,7 +1451,7 @@ __device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2
     const uint32_t bandX = place.band * (uint32_t)kBandW;
     const uint32_t tileY = place.strip0 * 2u;
     if (bandX >= A.w4 || tileY >= A.h2)
-        return; // no barrier anywhere: a wave without work simply leaves
+        return; // no barrier from here on: a wave without work simply leaves
     BandCtx c;
     c.bandX = bandX;
     c.X = bandX + 4 * threadIdx.x;
@@ -1470,6 +1518,7 @@ __device__ __forceinline__ void runSoloMapped(const TileArgs & A, const PkGeom &
     typedef StageRows<SUB, NS, 1> SR;
     typedef SoloMapLds<YT, SUB, BIL, RT, NS> LDS;
     static_assert(!TURNED || LDS::kTurns, "quarter turns: the workgroup's rows must be the transposition tile's");
+    prepareAlphaTables<YT, HASMUL, 0>(A);
     const uint32_t tile = pkTileOf(blockIdx.x, g);
     if (tile >= g.nTiles)
         return;
