@@ -57,7 +57,8 @@ TileKey keyFor(const YuvToRgbPlan & p)
     k.wideRgb = p.rgb.chanBytes == 2;
     k.nch = k.gray ? (p.rgb.hasAlpha ? 2 : 1) : (p.rgb.is565 ? 2 : (p.rgb.hasAlpha ? 4 : 3));
     k.hasMul = (p.inLoopMul != MUL_NONE) || (p.postMul != MUL_NONE);
-    k.alphaPlane = p.rgb.hasAlpha && !p.rgb.is565 && p.alphaSource == ALPHA_PLANE;
+    // (ALPHA_KEEP -- rgb->ignoreAlpha -- runs the same kernels: the "plane" is the destination's own alpha channel, TileArgs::alphaKeep)
+    k.alphaPlane = p.rgb.hasAlpha && !p.rgb.is565 && (p.alphaSource == ALPHA_PLANE || p.alphaSource == ALPHA_KEEP);
     k.mapped = p.rgb.map.on != 0;
     k.wideDownshift = k.fixedPoint && k.wideYuv && p.fxDownshift != 0;
     k.attenuate = k.fixedPoint && p.postMul == MUL_MULTIPLY && p.postMulFx && k.nch == 4 && k.alphaPlane && (p.tuning & TUNE_COOPERATIVE) == 0;
@@ -238,8 +239,12 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
             return false;
     }
     // (limited-range alpha planes, pre-1.0 files, src/read.c:6818-6828: converted sample by sample inside the tiled kernels)
-    if (o.hasAlpha && p.alphaSource == ALPHA_KEEP)
-        return false; // destination alpha bytes must stay untouched: per-channel stores only
+    if (o.hasAlpha && p.alphaSource == ALPHA_KEEP) {
+        // destination alpha samples must stay as they are: the fp32 tiles read them back per pixel (TileArgs::alphaKeep); not behind a pixel
+        // map, not with alpha arithmetic pending (the reference has none either: ignoreAlpha), not in the integer path (libyuv writes 255)
+        if (p.arith == ARITH_LIBYUV || o.map.on || p.inLoopMul != MUL_NONE || p.postMul != MUL_NONE || o.is565)
+            return false;
+    }
     if (p.w < 64 || p.h < 2)
         return false; // too small to fill even one row of lanes: the per-pixel kernel is the better fit
     // vector accesses: 4 samples per load, 4 pixels per store

@@ -1071,6 +1071,41 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
             }
             const uint32_t off = (sy + r) * A.rgbPitch + X * kPixBytes;
             const uint32_t bandOff = (sy + r) * A.rgbPitch + c.bandX * kPixBytes;
+            if constexpr (APLANE && !HASMUL && !MAPPED) {
+                if (A.alphaKeep) { // wave-uniform: rgb->ignoreAlpha -- the pixel keeps the alpha sample it has (read here, stored back with the colours)
+                    // the lane's four pixels as whole words (4 x kPixBytes = 8, 16 or 32 bytes), the alpha sample of each picked out
+                    constexpr int kWords = (int)kPixBytes; // 32-bit words of four pixels
+                    unsigned old[kWords];
+#pragma unroll
+                    for (int wd = 0; wd < kWords; ++wd)
+                        old[wd] = 0;
+                    if (laneValid) {
+                        if constexpr (kWords == 2) {
+                            const u2 t = *reinterpret_cast<const u2 *>(A.rgb + off);
+                            old[0] = t.x, old[1] = t.y;
+                        } else {
+#pragma unroll
+                            for (int q4 = 0; q4 < kWords / 4; ++q4) {
+                                const u4 t = *reinterpret_cast<const u4 *>(A.rgb + (off + 16u * (uint32_t)q4));
+                                old[4 * q4] = t.x, old[4 * q4 + 1] = t.y, old[4 * q4 + 2] = t.z, old[4 * q4 + 3] = t.w;
+                            }
+                        }
+                    }
+                    const uint32_t slotBits = A.slotA * 8u * (uint32_t)sizeof(RT); // bit position of the alpha sample inside its pixel
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // pixel i occupies kPixBytes * 8 bits from bit i * kPixBytes * 8 of `old`
+                        if constexpr (kPixBytes == 8) { // two words per pixel: the sample's word chosen by a wave-uniform select
+                            const unsigned wsel = (slotBits >= 32u) ? old[2 * i + 1] : old[2 * i];
+                            a[i] = (wsel >> (slotBits & 31u)) & 0xffffu;
+                        } else if constexpr (kPixBytes == 4) {
+                            a[i] = (old[i] >> slotBits) & (sizeof(RT) == 1 ? 0xffu : 0xffffu);
+                        } else { // 2-byte pixels (GRAYA8 / AGRAY8): two per word
+                            a[i] = (old[i >> 1] >> (16u * (uint32_t)(i & 1) + slotBits)) & 0xffu;
+                        }
+                    }
+                }
+            }
 
             // finished pixel words through the job's PixelMap: canvas pixel (mapX0 + X .. + 3, mapY0 + row)
             auto emitMapped = [&](const unsigned (&px)[4][PW]) {

@@ -57,6 +57,10 @@ struct TileArgs
     // (Z), and cB / cU (cR / cV) are the coefficients of that first (third) channel -- so no kernel selects channels per pixel
     uint32_t slotX, slotZ;
     int32_t alphaRescale;                // alpha plane depth differs from the rgb depth (src/alpha.c:84-103)
+    // rgb->ignoreAlpha on a format with an alpha channel, fp32 arithmetic: the destination's alpha samples stay as they are (src/reformat.c:
+    // 1449-1450 -- nothing writes them).  The kernels that take alpha from a plane serve it: a pixel's alpha is read from the destination
+    // pixel itself and stored back with the colours (`a` then addresses the luma plane: loaded, not looked at)
+    int32_t alphaKeep;
     float f16Mul;                        // half-float outputs (avifRGBImageToF16, src/reformat.c:1419-1443): the subnormal-trick multiplier, 0 = integer output
     int32_t inLoopMul, postMul;          // MulMode
     int32_t identityCopy;                // 8-bit full-range identity matrix: bytes are copied (src/reformat.c:1278-1309)
@@ -118,6 +122,7 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     memset(&A, 0, sizeof(A));
     A.y = s.plane[0] + (size_t)p.y0 * s.rowBytes[0] + (size_t)p.x0 * s.chanBytes;
     A.a = s.alpha ? s.alpha + (size_t)p.y0 * s.alphaRowBytes + (size_t)p.x0 * s.chanBytes : nullptr;
+    const bool keepsAlpha = o.hasAlpha && !o.is565 && p.alphaSource == ALPHA_KEEP;
     A.u = s.plane[1];
     A.v = s.plane[2];
     A.rgb = o.map.on ? o.pixels : o.pixels + (size_t)p.y0 * o.rowBytes + (size_t)p.x0 * o.pixBytes;
@@ -159,6 +164,10 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
         tf = A.cU, A.cU = A.cV, A.cV = tf;
     }
     A.alphaRescale = (s.depth != o.depth) ? 1 : 0;
+    if (keepsAlpha) {
+        A.alphaKeep = 1, A.alphaRescale = 0, A.alphaLim.on = 0;
+        A.a = A.y, A.aPitch = A.yPitch;
+    }
     A.f16Mul = o.isFloat ? o.f16Multiplier : 0.0f;
     A.inLoopMul = p.inLoopMul, A.postMul = p.postMul;
     A.identityCopy = p.identityCopy;

@@ -103,6 +103,37 @@ def test_gray_outputs_use_the_tiled_kernels(hip):
     _compare_y2r(H.hip_host_backend(), H.oracle_backend(), cases)
 
 
+def test_ignore_alpha_keeps_the_destination_alpha_in_the_tiled_kernels(hip, monkeypatch):
+    """rgb->ignoreAlpha on a format that has an alpha channel, fp32 arithmetic: nothing writes the destination's alpha samples
+    (src/reformat.c:1449-1450) -- whatever the buffer held stays, and the half-float pass still runs over it (:1419-1443).  The fp32 tiles
+    read a pixel's alpha back from the destination and store it with the colours (TileArgs::alphaKeep): every 4-channel order, 8- and
+    16-bit containers, gray + alpha, half floats, with and without an alpha plane in the image, every chroma layout."""
+    hip.avifhipSetTiledKernels(1)
+    cases = []
+    for (w, h) in TILED:
+        for fmt, yf, yd, rd, alpha, fl, up in ((1, 3, 8, 8, True, False, 4), (2, 3, 8, 8, False, False, 4), (4, 2, 8, 8, True, False, 3), (5, 1, 8, 8, False, False, 4),
+                                               (1, 3, 10, 10, True, False, 4), (2, 2, 12, 16, False, False, 4), (4, 1, 10, 16, True, False, 3), (5, 3, 8, 16, False, False, 4),
+                                               (1, 3, 10, 8, True, False, 4), (8, 3, 8, 8, True, False, 4), (9, 1, 10, 16, False, False, 4), (8, 4, 12, 12, True, False, 3),
+                                               (1, 3, 10, 16, True, True, 4), (2, 1, 8, 16, False, True, 4), (8, 3, 10, 16, True, True, 4)):
+            cases.append(H.Y2RCase(w, h, rgb_format=fmt, rgb_depth=rd, yuv_depth=yd, yuv_format=yf, alpha=alpha, ignore_alpha=True, is_float=fl,
+                                   image_premultiplied=alpha and (w + fmt) % 2 == 0, matrix=(1, 6, 9)[(w + fmt) % 3], yuv_range=(w + yd) % 2, upsampling=up))
+    # a destination whose every byte differs from its neighbours': a pixel must get back ITS alpha, not its neighbour's
+    plain_output = H.make_y2r_output
+
+    def patterned_output(c):
+        rgb = plain_output(c)
+        flat = rgb.pixels.reshape(-1)
+        flat[:] = (np.arange(flat.size, dtype=np.uint64) * 0x9E3779B1 >> 7).astype(np.uint8)
+        return rgb
+
+    monkeypatch.setattr(H, "make_y2r_output", patterned_output)
+    for c in cases:
+        H.run_y2r(H.HipDeviceBackend(), c)
+        assert native.last_kernel().startswith("yuv2rgb_tile"), (c.ident(), native.last_kernel())
+    _compare_y2r(H.HipDeviceBackend(), H.oracle_backend(), cases)
+    _compare_y2r(H.hip_host_backend(), H.oracle_backend(), cases)
+
+
 def test_rgb565_from_the_fp32_arithmetic_uses_the_tiled_kernels(hip):
     """RGB565 where libyuv has no entry (10- / 12-bit planes -- an HDR image into an Android RGB_565 bitmap --, filtered chroma, 4:4:4, gray,
     avoidLibYUV): the fp32 tiles quantise to 8 bits and pack b >> 3 | (g >> 2) << 5 | (r >> 3) << 11 (src/reformat.c:619-626), the identity

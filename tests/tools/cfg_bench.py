@@ -149,6 +149,16 @@ def run(name):
             # android_jni/.../libavif_jni.cc); 1.5 + 1 + 4 B/px
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, alpha=True, premult=(name == "cfg2_premul"), avoid=avoid)
             px, bpp, ms = 7680 * 4320, 6.5, time_y2r(pair)
+        elif name in ("cfg2_keep", "cfg2_keep16"):
+            # rgb->ignoreAlpha on RGBA (an application that wants RGBX): the destination's alpha samples stay as they are (src/reformat.c:1449-1450);
+            # the fp32 arithmetic only -- libyuv writes 255 whatever the flag says.  8K 8-bit 4:2:0 -> RGBA8 (1.5 + 4 B/px, the alpha byte read
+            # back inside the pixel's own cache line), or 10-bit -> RGBA(10) (3 + 8)
+            if arith == "integer":
+                continue
+            deep = name == "cfg2_keep16"
+            pair = y2r(7680, 4320, 10 if deep else 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 10 if deep else 8, avoid=avoid)
+            pair[1].struct.ignoreAlpha = 1
+            px, bpp, ms = 7680 * 4320, (11.0 if deep else 5.5), time_y2r(pair)
         elif name == "cfg2_rgb":
             # 3-byte pixels (what avifdec hands to its JPEG / opaque PNG writers): 8K 8-bit 4:2:0 -> RGB8, bilinear, 1.5 + 3 B/px
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB)
