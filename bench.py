@@ -585,7 +585,39 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     ms = burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas.struct)
     configs["cfg5grid"] = row(ms, 11.0 * px_tiles, px_tiles, "the same 64 tiles -> one 15360x8640 RGBA canvas, converted where they lie, seams as on the stitched canvas "
                               "(avifhipGridYUVToRGBAsync: every kernel of the call)", kernel=native.last_kernel())
-    del canvas, tiles, timgs
+    # ... -> RGBA8, where the default arithmetic runs the packed 16-bit kernels: their seam-aware build reads the chroma across the seams itself,
+    # ONE launch per canvas (7 B/pixel); AVIFHIP_GRID_SEAM_PASS=1 brings the tile batch + seam pass of rounds 1-3 back for comparison
+
+    def with_seam_pass(fn):
+        os.environ["AVIFHIP_GRID_SEAM_PASS"] = "1"
+        try:
+            return fn()
+        finally:
+            del os.environ["AVIFHIP_GRID_SEAM_PASS"]
+
+    canvas8 = device.DeviceRGB(abi.make_rgb(15360, 8640, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False))
+    ms8 = burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas8.struct)
+    kernel8 = native.last_kernel()
+    ms8_pass = with_seam_pass(lambda: burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas8.struct))
+    configs["cfg5grid"]["rgba8"] = row(ms8, 7.0 * px_tiles, px_tiles, "the same tiles -> one RGBA8 canvas: tiles and seams in ONE launch", kernel=kernel8,
+                                       with_seam_pass=row(ms8_pass, 7.0 * px_tiles, px_tiles, "tile batch, then the seam kernel (two launches)"))
+    del canvas, canvas8, tiles, timgs
+    # a phone photograph: 4032x3024 8-bit 4:2:0 stored as 8 x 6 tiles of 512x512 (the last row cropped) -> RGBA8, the same buffers call after call
+    ptiles = []
+    for t in range(48):
+        img = abi.make_yuv(512, 512, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_FULL, 6)
+        synth.fill_yuv(img, 0x2468 + t)
+        ptiles.append(device.DeviceYUV(img))
+    pimgs = (C.POINTER(abi.avifImage) * 48)(*[C.pointer(t.struct) for t in ptiles])
+    pcanvas = device.DeviceRGB(abi.make_rgb(4032, 3024, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False))
+    pgrid = native.avifhipGrid(6, 8, 4032, 3024)
+    px_photo = 4032 * 3024
+    msp = burst(lib.avifhipTimeGridYUVToRGB, C.byref(pgrid), pimgs, None, 0, pcanvas.struct)
+    kernelp = native.last_kernel()
+    msp_pass = with_seam_pass(lambda: burst(lib.avifhipTimeGridYUVToRGB, C.byref(pgrid), pimgs, None, 0, pcanvas.struct))
+    configs["photo_grid"] = row(msp, 5.5 * px_photo, px_photo, "4032x3024 8-bit 4:2:0 as 8 x 6 tiles of 512x512 -> one RGBA8 canvas (avifhipGridYUVToRGBAsync), ONE launch",
+                                kernel=kernelp, with_seam_pass=row(msp_pass, 5.5 * px_photo, px_photo, "tile batch, then the seam kernel (two launches)"))
+    del ptiles, pimgs, pcanvas
 
     # the chip's ceiling for short jobs: the no-arithmetic byte-movement kernel on 4K and 1080p 8-bit 4:2:0 -> RGBA8 frames (4 frames cycled)
     nk, imgsk, rgbsk = _cycle_args(frames_4k)

@@ -317,12 +317,20 @@ def run(name):
                     native.check(lib.avifhipImageYUVToRGBTransformedAsync(dimg.struct, ddst.struct, C.byref(crop), int(angle != 0), angle, int(angle != 0), 1, None))
             best = host_clock(call)
             px, bpp, ms = crop.width * crop.height, (11.0 if wide else 7.0 if deep else 5.5), best
-        elif name in ("cfg5grid", "cfg5grid_8", "photo_grid"):
+        elif name in ("cfg5grid", "cfg5grid_8", "photo_grid", "cfg5grid_link", "cfg5grid_8_pass", "photo_grid_pass"):
+            # (_pass: the tile batch + seam pass of rounds 1-3 forced, _link: one launch forced -- AVIFHIP_GRID_SEAM_PASS; without a suffix the
+            #  library chooses: one launch for the packed 16-bit kernels and for canvases up to 32 megapixels)
+            forced = "1" if name.endswith("_pass") else ("0" if name.endswith("_link") else None)
+            gname = name.rsplit("_pass", 1)[0].rsplit("_link", 1)[0]
+            if forced is None:
+                os.environ.pop("AVIFHIP_GRID_SEAM_PASS", None)
+            else:
+                os.environ["AVIFHIP_GRID_SEAM_PASS"] = forced
             # BASELINE configs[4]: 8 x 8 grid of decoded 1920x1080 10-bit 4:2:0 tiles -> one 15360x8640 RGBA canvas, tiles
             # converted where they lie (avifhipGridYUVToRGBAsync: no YUV canvas, seams redone across tiles)
             # photo_grid: what a phone camera writes -- 4032 x 3024 8-bit 4:2:0 as 8 x 6 tiles of 512 x 512 (the last row cropped) -> RGBA8
-            rgb_depth = 10 if name == "cfg5grid" else 8
-            cols, rows, tw, th, ow, oh, depth = (8, 6, 512, 512, 4032, 3024, 8) if name == "photo_grid" else (8, 8, 1920, 1080, 15360, 8640, 10)
+            rgb_depth = 10 if gname == "cfg5grid" else 8
+            cols, rows, tw, th, ow, oh, depth = (8, 6, 512, 512, 4032, 3024, 8) if gname == "photo_grid" else (8, 8, 1920, 1080, 15360, 8640, 10)
             tiles = []
             for t in range(cols * rows):
                 img = abi.make_yuv(tw, th, depth, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED if depth == 10 else abi.AVIF_RANGE_FULL, 1 if depth == 10 else 6)

@@ -49,9 +49,14 @@ DESC = {
     "tail180_rgba10": "… + half turn + mirror",
     "tail90_rgba10": "… + quarter turn + mirror",
     "tail90_rgba10_two_pass": "… in two passes",
-    "cfg5grid": "cfg5 through the grid entry point (tiles where the decoder left them + seam kernel) → RGBA(10)",
-    "cfg5grid_8": "… → RGBA8",
-    "photo_grid": "a phone photograph: 4032 × 3024 8-bit 4:2:0 as 8 × 6 tiles of 512 × 512 → RGBA8, grid entry point, same buffers call after call",
+    "cfg5grid": "cfg5 through the grid entry point (tiles where the decoder left them) → RGBA(10); the library's choice: tile batch + seam kernel for the fp32 kernels above 32 megapixels",
+    "cfg5grid_link": "… tiles and seams in ONE launch forced (`AVIFHIP_GRID_SEAM_PASS=0`: the seam-aware fp32 kernels)",
+    "cfg5grid_8": "… → RGBA8; the library's choice: ONE launch in the packed 16-bit kernels, tile batch + seam kernel in the fp32 ones",
+    "cfg5grid_8_pass": "… → RGBA8 with the seam pass forced (`AVIFHIP_GRID_SEAM_PASS=1`: two launches, rounds 1–3)",
+    "photo_grid": "a phone photograph: 4032 × 3024 8-bit 4:2:0 as 8 × 6 tiles of 512 × 512 → RGBA8, grid entry point, same buffers call after call: ONE launch",
+    "photo_grid_pass": "… with the seam pass forced (two launches, rounds 1–3)",
+    "cfg2_keep": "cfg2 with `rgb->ignoreAlpha` (the destination's alpha bytes stay: read back per pixel, 4 B/pixel more from HBM than the fraction counts)",
+    "cfg2_keep16": "… 8K 10-bit → RGBA(10) with `ignoreAlpha`",
     "xform90": "`avifhipRGBImageTransformAsync` alone: 8K RGBA8 crop + quarter turn",
     "xform180": "… crop + half turn",
     "scale_box4": "plane scaling 8K → 4K (§4.8)",

@@ -16,7 +16,7 @@ bash tests/tools/profile_round.sh "$TAG" > "gpurun_out/${TAG}_profile_round.log"
 python bench.py > "gpurun_out/${TAG}_bench_line_default_run.json" 2> "gpurun_out/${TAG}_bench_default.err"
 python bench.py --steps 20 --warmup 5 > "gpurun_out/${TAG}_bench_line_driver_flags.json" 2>> "gpurun_out/${TAG}_bench_default.err"
 python bench.py --workload cfg5 --no-cpu-baseline > "gpurun_out/${TAG}_bench_cfg5_line.json" 2>> "gpurun_out/${TAG}_bench_default.err"
-CFGS="cfg2 cfg2_4k cfg2n cfg2_rgb cfg2_565 cfg2_alpha cfg2_premul cfg2_unpremul cfg3 cfg3_unpremul cfg4 cfg4rgb cfg4_601 cfg4_8k cfg4_premul_8k cfg4_unpremul_8k cfg4_ycgco_8k ident8_enc gray_enc_8k graya_enc_8k cfg5 cfg5_8 cfg5x64 cfg5x64_8 f16_420 f16_444a ident8 ident8rgb gray8 graya16 premul8 unpremul8 unpremul16 tail0 tail180 tail90 tail90_two_pass tail0_10 tail90_10 tail0_rgba10 tail180_rgba10 tail90_rgba10 tail90_rgba10_two_pass cfg5grid cfg5grid_8 photo_grid cfg5x64_rot xform90 xform180 scale_box4 scale_up2 scale_down_1_5 gainmap4k gainmap4k_half gmcompute4k"
+CFGS="cfg2 cfg2_4k cfg2n cfg2_rgb cfg2_565 cfg2_alpha cfg2_premul cfg2_unpremul cfg3 cfg3_unpremul cfg4 cfg4rgb cfg4_601 cfg4_8k cfg4_premul_8k cfg4_unpremul_8k cfg4_ycgco_8k ident8_enc gray_enc_8k graya_enc_8k cfg5 cfg5_8 cfg5x64 cfg5x64_8 f16_420 f16_444a ident8 ident8rgb gray8 graya16 premul8 unpremul8 unpremul16 tail0 tail180 tail90 tail90_two_pass tail0_10 tail90_10 tail0_rgba10 tail180_rgba10 tail90_rgba10 tail90_rgba10_two_pass cfg5grid cfg5grid_link cfg5grid_8 cfg5grid_8_pass photo_grid photo_grid_pass cfg2_keep cfg2_keep16 cfg5x64_rot xform90 xform180 scale_box4 scale_up2 scale_down_1_5 gainmap4k gainmap4k_half gmcompute4k"
 bash tests/tools/profile_cfgs.sh "$TAG" $CFGS > "gpurun_out/${TAG}_profile_cfgs.log" 2>&1
 # the event-timed rows of those very runs, one file
 for c in $CFGS; do cat "gpurun_out/${TAG}_cfgs/$c.jsonl" 2>/dev/null | grep '^{' ; done > "gpurun_out/${TAG}_cfgs_bench.jsonl"
