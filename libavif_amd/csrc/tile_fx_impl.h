@@ -66,10 +66,8 @@ __device__ __forceinline__ void stageTileFx(const TileArgs & A, const TileRaw<YT
     const int t = ((WAVES == 1) ? 0 : (int)threadIdx.y * kLanesX) + (int)threadIdx.x;
 #pragma unroll
     for (int j = 0; j < SR::kRounds; ++j) {
-        const int task = t + SR::kThreads * j;
-        if (task < SR::kTasks) {
-            int row, grp;
-            SR::place(task, row, grp);
+        int row, grp;
+        if (SR::placeOf(t, j, row, grp)) {
             unsigned u[4], v[4];
             decode4<YT>(T.su[j], u);
             decode4<YT>(T.sv[j], v);
@@ -341,7 +339,7 @@ template <typename YT, int SUB, bool BIL, int NCH, bool APLANE, bool HASMUL, int
 __global__ __launch_bounds__(256) void yuvToRgbTileFxBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
 {
     __shared__ __attribute__((aligned(16))) unsigned rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kFxRowPitch];
-    const TileArgs job = jobOf(table); // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
+    const TileArgs job = jobOf<true>(table); // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
     runBlockFx<YT, SUB, BIL, NCH, APLANE, HASMUL, NS>(job, tilesPerRun, rows);
 }
 

@@ -89,12 +89,19 @@ struct StageRows
     static constexpr int kTasks = kRows * kGroups;
     static constexpr int kThreads = 64 * WAVES;
     static constexpr int kRounds = (kTasks + kThreads - 1) / kThreads;
+    // Seam-aware build, the four waves together: the 64 tasks of a wave and round lie in at most three consecutive rows, and which tile a
+    // ROW lies in -- the job's own, the one above or the one below -- is wave-uniform: loadNeighbourhood issues a wave's loads row by row,
+    // each with a scalar base
+    static constexpr bool kUniformRows = kSeams && WAVES == 4;
+    static constexpr int kRowsPerWaveRound = (64 + kGroups - 2) / kGroups + 1;
     static_assert(!kSplitHalo || 2 * kRows <= 64, "one lane per side sample");
-    // row and group (0 = the group left of the band) of a task
-    static __device__ __forceinline__ void place(int task, int & row, int & grp)
+    // row and group (0 = the group left of the band) thread `t` of the workgroup stages in round `j`; false: none
+    static __device__ __forceinline__ bool placeOf(int t, int j, int & row, int & grp)
     {
+        const int task = t + kThreads * j;
         row = task / kGroups;
         grp = task - row * kGroups + kFirstGroup;
+        return task < kTasks;
     }
 };
 
@@ -644,12 +651,15 @@ __device__ __forceinline__ TileHalo::Planes * haloOfWave()
 
 // the private copy of a batch kernel's job (read through the table pointer, every field would be re-loaded after each store: the compiler
 // cannot rule out that the RGB stores alias the table -- ~20 scalar loads per tile inside the pipelined loop)
+template <bool COOPERATIVE = false>
 __device__ __forceinline__ TileArgs jobOf(const TileArgs * __restrict__ table)
 {
     // (the copy first: behind the fences below the table's fields would no longer qualify for scalar loads, and the job would live in
     //  vector registers -- 140 instead of 76 in the cooperative 10-bit kernel)
-    const TileArgs job = table[blockIdx.z];
-    if constexpr (kSeams) {
+    TileArgs job = table[blockIdx.z];
+    if constexpr (kSeams && COOPERATIVE) {
+        job.haloRef = &table[blockIdx.z].halo; // the four waves together stage whole rows: scalar loads from the table where a row needs them
+    } else if constexpr (kSeams) {
         TileHalo::Planes * mine = haloOfWave();
         if (threadIdx.x < 9)
             mine[threadIdx.x] = table[blockIdx.z].halo.at[threadIdx.x];
@@ -748,17 +758,83 @@ __device__ __forceinline__ void loadNeighbourhood(const TileArgs & A, const Band
     constexpr uint32_t BPS = sizeof(YT);
     typedef StageRows<SUB, NS, WAVES> SR;
     const int tx = threadIdx.x, wv = (WAVES == 1) ? 0 : (int)threadIdx.y;
-    {
+    if constexpr (SR::kUniformRows) {
+        // Seam-aware build, the four waves together.  Which tile a ROW lies in is wave-uniform, so the row's planes come from the table by
+        // scalar loads (constant address space) and its loads keep the plain build's form, scalar base + 32-bit lane offset -- per-lane
+        // pointers cost this kernel ten vector registers and a step of occupancy (profiles/README.md).  A wave's 64 tasks of a round lie in
+        // at most kRowsPerWaveRound consecutive rows: one pass per row, the row's lanes active.  Groups cut by the window's left or right
+        // border (the tiles along the job's sides only) fetch their two pairs of planes from the table per lane.
+        typedef const __attribute__((address_space(4))) TileHalo * HaloTable;
+        typedef const __attribute__((address_space(1))) uint8_t * GlobalPlane;
+        typedef const __attribute__((address_space(1))) TileHalo * HaloTableG;
+        const HaloTable HT = (HaloTable)A.haloRef;
+        const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+        const int above = (A.haloSides & HALO_ABOVE) ? 1 : 0, below = (A.haloSides & HALO_BELOW) ? 1 : 0;
+        const int left = (A.haloSides & HALO_LEFT) ? 1 : 0, right = (A.haloSides & HALO_RIGHT) ? 1 : 0;
+        const int t = w * kLanesX + tx;
+#pragma unroll
+        for (int j = 0; j < SR::kRounds; ++j) {
+            int myRow, grp;
+            const bool mine = SR::placeOf(t, j, myRow, grp);
+            const int firstRow = (w * kLanesX + SR::kThreads * j) / SR::kGroups; // wave-uniform
+            const int cxa = c.cxb - 4 + 4 * grp;
+            const bool whole = cxa >= A.cxMin && cxa + 3 <= A.cxMax;
+            T.su[j].w[0] = T.sv[j].w[0] = 0;
+            if constexpr (kWide)
+                T.su[j].w[1] = T.sv[j].w[1] = 0;
+#pragma unroll
+            for (int seg = 0; seg < SR::kRowsPerWaveRound; ++seg) {
+                const int row = firstRow + seg; // wave-uniform
+                if (row >= SR::kRows)
+                    break;
+                const int cy = clampI(rowBase + row, A.cyMin - above, A.cyMax + below);
+                const int vi = cy < A.cyMin ? 3 : (cy > A.cyMax ? 6 : 0);
+                GlobalPlane ru = (GlobalPlane)A.u, rv = (GlobalPlane)A.v;
+                if (vi != 0)
+                    ru = (GlobalPlane)HT->at[vi].u, rv = (GlobalPlane)HT->at[vi].v;
+                // (the row's planes pinned in scalar registers, and a fence for the compiler: left alone it merges the passes into ONE load per
+                //  lane through a selected 64-bit pointer -- flat loads and 300 selects, the very registers this form is here to save)
+                asm volatile("" : "+s"(ru), "+s"(rv) : : "memory");
+                if (mine && whole && myRow == row) {
+                    T.su[j] = load4<YT>((const uint8_t *)ru, (uint32_t)cy * A.uPitch + (uint32_t)cxa * BPS);
+                    T.sv[j] = load4<YT>((const uint8_t *)rv, (uint32_t)cy * A.vPitch + (uint32_t)cxa * BPS);
+                }
+            }
+            if (mine && !whole) {
+                // group cut by the left or right border of the window: samples inside it from the row's tile, samples beyond it from that
+                // tile's left / right neighbour (or clamped, where the canvas ends)
+                const int cy = clampI(rowBase + myRow, A.cyMin - above, A.cyMax + below);
+                const int vi = cy < A.cyMin ? 3 : (cy > A.cyMax ? 6 : 0);
+                const HaloTableG G = (HaloTableG)A.haloRef;
+                const bool leftCut = cxa < A.cxMin;
+                const int si = vi + (leftCut ? left : 2 * right); // (no neighbour on that side: the row's own tile, coordinates clamped)
+                const uint8_t *rowU = G->at[vi].u, *rowV = G->at[vi].v, *sideU = G->at[si].u, *sideV = G->at[si].v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cx = clampI(cxa + k, A.cxMin - left, A.cxMax + right);
+                    const bool beyond = cx < A.cxMin || cx > A.cxMax;
+                    const GlobalPlane pu = (GlobalPlane)(beyond ? sideU : rowU), pv = (GlobalPlane)(beyond ? sideV : rowV);
+                    const unsigned u = load1<YT>((const uint8_t *)pu, (uint32_t)cy * A.uPitch + (uint32_t)cx * BPS);
+                    const unsigned v = load1<YT>((const uint8_t *)pv, (uint32_t)cy * A.vPitch + (uint32_t)cx * BPS);
+                    if constexpr (!kWide) {
+                        T.su[j].w[0] |= u << (8 * k);
+                        T.sv[j].w[0] |= v << (8 * k);
+                    } else {
+                        T.su[j].w[k >> 1] |= u << (16 * (k & 1));
+                        T.sv[j].w[k >> 1] |= v << (16 * (k & 1));
+                    }
+                }
+            }
+        }
+    } else {
         const int t = wv * kLanesX + tx;
 #pragma unroll
         for (int j = 0; j < SR::kRounds; ++j) {
-            const int task = t + SR::kThreads * j;
-            if (task < SR::kTasks) {
+            int row, grp;
+            if (SR::placeOf(t, j, row, grp)) {
                 // coordinates clamp to the job's chroma window (the whole plane of the canvas unless the canvas is a grid of
                 // separately stored tiles): exactly the reference's border rule (src/reformat.c:768,784) -- the neighbour
                 // of an edge sample is the sample itself
-                int row, grp;
-                SR::place(task, row, grp);
                 const HaloRow hr = haloRow<HALO>(A, rowBase + row);
                 const int cy = hr.cy;
                 const int cxa = c.cxb - 4 + 4 * grp;
@@ -811,7 +887,9 @@ __device__ __forceinline__ void loadTile(const TileArgs & A, const BandCtx & c, 
     if constexpr (BIL) {
         // canvas chroma row held by LDS row 0
         const int rowBase = (SUB == SUB_420) ? A.cy0 + (int)(tileY >> 1) - 1 : A.cy0 + (int)tileY;
-        if (haloNeeded(A, rowBase, rowBase + StageRows<SUB, NS, WAVES>::kRows - 1, c.cxb - 1, c.cxb + 128)) // (wave-uniform; never in the plain builds)
+        if constexpr (StageRows<SUB, NS, WAVES>::kUniformRows) // (seam-aware build, the four waves together: every tile the same way)
+            loadNeighbourhood<YT, SUB, NEEDA, NS, WAVES, true>(A, c, rowBase, T);
+        else if (haloNeeded(A, rowBase, rowBase + StageRows<SUB, NS, WAVES>::kRows - 1, c.cxb - 1, c.cxb + 128)) // (wave-uniform; never in the plain builds)
             loadNeighbourhood<YT, SUB, NEEDA, NS, WAVES, true>(A, c, rowBase, T);
         else
             loadNeighbourhood<YT, SUB, NEEDA, NS, WAVES, false>(A, c, rowBase, T);
@@ -855,10 +933,8 @@ __device__ __forceinline__ void stageTile(const TileArgs & A, const TileRaw<YT, 
     const int t = ((WAVES == 1) ? 0 : (int)threadIdx.y * kLanesX) + (int)threadIdx.x;
 #pragma unroll
     for (int j = 0; j < SR::kRounds; ++j) {
-        const int task = t + SR::kThreads * j;
-        if (task < SR::kTasks) {
-            int row, grp;
-            SR::place(task, row, grp);
+        int row, grp;
+        if (SR::placeOf(t, j, row, grp)) {
             float fu[4], fv[4];
             samples4<YT>(T.su[j], A.yuvMax, fu);
             samples4<YT>(T.sv[j], A.yuvMax, fv);
@@ -1460,7 +1536,7 @@ __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * 
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
     // a private copy of the job: read through the table pointer, every field would be re-loaded after each store (the compiler
     // cannot rule out that the RGB stores alias the table) -- ~20 scalar loads per tile inside the pipelined loop
-    const TileArgs job = jobOf(table);
+    const TileArgs job = jobOf<true>(table);
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
         runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, tilesPerRun, rows, xchg);

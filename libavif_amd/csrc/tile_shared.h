@@ -109,6 +109,7 @@ struct TileArgs
     } fx;
     // seam-aware builds (jobs that are tiles of one canvas): which sides have a neighbouring tile (HaloSides), and the neighbours' planes
     uint32_t haloSides;
+    const TileHalo * haloRef; // where the TABLE holds this job's `halo`: set by the kernel in its private copy of the job (jobOf, tile_impl.h)
     TileHalo halo;
 };
 
