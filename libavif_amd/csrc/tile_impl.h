@@ -761,9 +761,10 @@ __device__ __forceinline__ void loadNeighbourhood(const TileArgs & A, const Band
     if constexpr (SR::kUniformRows) {
         // Seam-aware build, the four waves together.  Which tile a ROW lies in is wave-uniform, so the row's planes come from the table by
         // scalar loads (constant address space) and its loads keep the plain build's form, scalar base + 32-bit lane offset -- per-lane
-        // pointers cost this kernel ten vector registers and a step of occupancy (profiles/README.md).  A wave's 64 tasks of a round lie in
-        // at most kRowsPerWaveRound consecutive rows: one pass per row, the row's lanes active.  Groups cut by the window's left or right
-        // border (the tiles along the job's sides only) fetch their two pairs of planes from the table per lane.
+        // pointers cost this kernel ten vector registers and a step of occupancy (profiles/README.md).  The rows of the job's own tile go in
+        // one pass, the row just above or below its window -- at most one each, and only in the tiles along the seam -- in a pass of its own
+        // with the neighbour's planes.  Groups cut by the window's left or right border (the tiles along the job's sides only) fetch their
+        // two pairs of planes from the table per lane.
         typedef const __attribute__((address_space(4))) TileHalo * HaloTable;
         typedef const __attribute__((address_space(1))) uint8_t * GlobalPlane;
         typedef const __attribute__((address_space(1))) TileHalo * HaloTableG;
@@ -782,16 +783,25 @@ __device__ __forceinline__ void loadNeighbourhood(const TileArgs & A, const Band
             T.su[j].w[0] = T.sv[j].w[0] = 0;
             if constexpr (kWide)
                 T.su[j].w[1] = T.sv[j].w[1] = 0;
+            // first the rows of the job's own tile -- every row of most tiles: ONE load per plane, exactly the plain build's (a first version
+            // went row by row for every tile: three masked loads per plane and wave, cfg5's canvas 8 % behind the plain kernel) ...
+            const int cyRaw = rowBase + myRow;
+            const bool foreign = (above && cyRaw < A.cyMin) || (below && cyRaw > A.cyMax);
+            if (mine && whole && !foreign) {
+                const int cy = clampI(cyRaw, A.cyMin, A.cyMax);
+                T.su[j] = load4<YT>(A.u, (uint32_t)cy * A.uPitch + (uint32_t)cxa * BPS);
+                T.sv[j] = load4<YT>(A.v, (uint32_t)cy * A.vPitch + (uint32_t)cxa * BPS);
+            }
+            // ... then the row just above / below the window, where this wave stages it (wave-uniform: the rows of a wave and round are
+            // lastRow - firstRow + 1 <= kRowsPerWaveRound consecutive ones)
+            const int lastRow = (w * kLanesX + SR::kThreads * j + kLanesX - 1) / SR::kGroups;
 #pragma unroll
-            for (int seg = 0; seg < SR::kRowsPerWaveRound; ++seg) {
-                const int row = firstRow + seg; // wave-uniform
-                if (row >= SR::kRows)
-                    break;
-                const int cy = clampI(rowBase + row, A.cyMin - above, A.cyMax + below);
-                const int vi = cy < A.cyMin ? 3 : (cy > A.cyMax ? 6 : 0);
-                GlobalPlane ru = (GlobalPlane)A.u, rv = (GlobalPlane)A.v;
-                if (vi != 0)
-                    ru = (GlobalPlane)HT->at[vi].u, rv = (GlobalPlane)HT->at[vi].v;
+            for (int side = 0; side < 2; ++side) {
+                const int cy = side ? A.cyMax + 1 : A.cyMin - 1; // the neighbour's row the filter reaches (rows beyond it belong to absent strips)
+                const int row = cy - rowBase;
+                if (!(side ? below : above) || row < firstRow || row > lastRow || row >= SR::kRows)
+                    continue;
+                GlobalPlane ru = (GlobalPlane)HT->at[side ? 6 : 3].u, rv = (GlobalPlane)HT->at[side ? 6 : 3].v;
                 // (the row's planes pinned in scalar registers, and a fence for the compiler: left alone it merges the passes into ONE load per
                 //  lane through a selected 64-bit pointer -- flat loads and 300 selects, the very registers this form is here to save)
                 asm volatile("" : "+s"(ru), "+s"(rv) : : "memory");
