@@ -372,17 +372,7 @@ bool tileBatchLinksNeighbours(const YuvToRgbPlan & representative, uint32_t coun
 
 void linkTileBatchHalo(void * hostTable, uint32_t job, const TileNeighbours & n)
 {
-    TileArgs & T = static_cast<TileArgs *>(hostTable)[job];
-    // distillArgs hands the planes to the kernels in the order of the pixel's colour channels (the "YVU trick"): follow it
-    const bool swapped = T.u == n.plane2[0] && T.u != n.plane1[0];
-    const bool present[9] = { true, n.left, n.right, n.above, n.above && n.left, n.above && n.right, n.below, n.below && n.left, n.below && n.right };
-    for (int d = 0; d < 9; ++d) {
-        const uint8_t * p1 = present[d] ? n.plane1[d] : n.plane1[0];
-        const uint8_t * p2 = present[d] ? n.plane2[d] : n.plane2[0];
-        T.halo.at[d].u = swapped ? p2 : p1;
-        T.halo.at[d].v = swapped ? p1 : p2;
-    }
-    T.haloSides = (n.above ? HALO_ABOVE : 0u) | (n.below ? HALO_BELOW : 0u) | (n.left ? HALO_LEFT : 0u) | (n.right ? HALO_RIGHT : 0u);
+    linkHalo(static_cast<TileArgs *>(hostTable)[job], n.plane1, n.plane2, n.above, n.below, n.left, n.right);
 }
 
 hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW,

@@ -231,6 +231,22 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     return A; // (no neighbours: haloSides = 0)
 }
 
+// Links a job of a batch to the eight tiles around its own (kernels.h TileNeighbours; index 3 * v + h as in TileHalo): `plane1` / `plane2` are
+// the nine tiles' U / V planes, each addressing canvas sample (0,0) virtually.  distillArgs hands the planes to the kernels in the order of
+// the pixel's colour channels (the "YVU trick"): the neighbours' follow the job's own.  Entries of absent neighbours hold the job's planes.
+inline void linkHalo(TileArgs & T, const uint8_t * const plane1[9], const uint8_t * const plane2[9], bool above, bool below, bool left, bool right)
+{
+    const bool swapped = T.u == plane2[0] && T.u != plane1[0];
+    const bool present[9] = { true, left, right, above, above && left, above && right, below, below && left, below && right };
+    for (int d = 0; d < 9; ++d) {
+        const uint8_t * p1 = present[d] ? plane1[d] : plane1[0];
+        const uint8_t * p2 = present[d] ? plane2[d] : plane2[0];
+        T.halo.at[d].u = swapped ? p2 : p1;
+        T.halo.at[d].v = swapped ? p1 : p2;
+    }
+    T.haloSides = (above ? HALO_ABOVE : 0u) | (below ? HALO_BELOW : 0u) | (left ? HALO_LEFT : 0u) | (right ? HALO_RIGHT : 0u);
+}
+
 struct TileKey
 {
     bool fixedPoint; // libyuv arithmetic (tile_fx_impl.h), 8-bit RGB outputs

@@ -289,6 +289,15 @@ def test_a_tile_grid_that_starts_above_the_rectangle_still_visits_every_strip_on
                 assert geometry.geomCheckPkShifted(w & ~3, h & ~1, strips, waves * strips) == 0, (w, h, strips, waves)
 
 
+def test_a_grid_job_is_linked_to_the_right_neighbours(geometry):
+    """tile_shared.h linkHalo (grids in one launch): whichever way round the job's planes were handed to the kernels, a neighbour's follow;
+    a neighbour that does not exist is the job's own tile (its entry is never read: the coordinates stop at the window on that side)."""
+    geometry.geomCheckHaloLink.restype, geometry.geomCheckHaloLink.argtypes = C.c_int, [C.c_int] * 5
+    for code in range(32):
+        bits = [(code >> k) & 1 for k in range(5)]
+        assert geometry.geomCheckHaloLink(*bits) == 0, bits
+
+
 def test_the_cooperative_kernels_block_order_is_a_permutation(geometry):
     assert geometry.geomSweepRemap(20000) == 0
 

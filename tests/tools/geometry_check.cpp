@@ -66,6 +66,33 @@ int checkPk(uint32_t w4, uint32_t h2, uint32_t count, uint32_t pkStrips, uint32_
 
 extern "C" {
 
+// tile_shared.h linkHalo: a job's neighbours in the order its own planes were handed to the kernels (`swapped`: the V plane feeds the
+// pixel's first colour channel), absent neighbours replaced by the job's own planes, the sides as bits.  0 = as specified.
+int geomCheckHaloLink(int swapped, int above, int below, int left, int right)
+{
+    static uint8_t arena[64];
+    const uint8_t *p1[9], *p2[9];
+    for (int d = 0; d < 9; ++d)
+        p1[d] = arena + 2 * d, p2[d] = arena + 2 * d + 1; // eighteen distinct addresses
+    TileArgs T;
+    memset(&T, 0, sizeof(T));
+    T.u = swapped ? p2[0] : p1[0], T.v = swapped ? p1[0] : p2[0];
+    linkHalo(T, p1, p2, above != 0, below != 0, left != 0, right != 0);
+    const uint32_t sides = (above ? HALO_ABOVE : 0u) | (below ? HALO_BELOW : 0u) | (left ? HALO_LEFT : 0u) | (right ? HALO_RIGHT : 0u);
+    if (T.haloSides != sides)
+        return 1;
+    for (int d = 0; d < 9; ++d) {
+        const int v = d / 3, h = d % 3;
+        const bool there = (v == 0 || (v == 1 ? above : below)) && (h == 0 || (h == 1 ? left : right));
+        const uint8_t * wantU = there ? (swapped ? p2[d] : p1[d]) : T.u;
+        const uint8_t * wantV = there ? (swapped ? p1[d] : p2[d]) : T.v;
+        if (T.halo.at[d].u != wantU || T.halo.at[d].v != wantV)
+            return 2 + d;
+    }
+    return 0;
+}
+
+
 // a turned launch whose tile grid starts `shiftStrips` strips above the rectangle (tile_impl.h launchSoloMapped): every strip still once
 int geomCheckPkShifted(uint32_t w4, uint32_t h2, uint32_t pkStrips, uint32_t shiftStrips)
 {
