@@ -121,6 +121,10 @@ AVIFHIP_API avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
  *   avifImageYUVToRGB(canvas, rgb)                      on the stitched canvas (src/reformat.c:1649)
  * without materialising the YUV canvas: tiles are converted where they lie, with the chroma filter reaching across tile
  * seams exactly as it would on the stitched canvas.  The result equals that three-step sequence byte for byte.
+ * One kernel launch where every pixel goes through the tiled kernels and the tiles share their chroma pitches (the tiles are linked
+ * to their neighbours and the kernels read the chroma sample beyond a seam from the neighbouring tile); otherwise, and for the
+ * fp32 kernels on canvases above 32 megapixels, the tiles first and the pixels along the seams again in a second launch.
+ * AVIFHIP_GRID_SEAM_PASS=1 / 0 in the environment forces either; same bytes.
  *   grid         rows, columns, outputWidth, outputHeight as in libavif's avifImageGrid (include/avif/internal.h)
  *   colorTiles   rows * columns images, row-major, all with the first tile's geometry and format (src/read.c:1832-1842);
  *                CICP, range and alphaPremultiplied are taken from colorTiles[0]
