@@ -85,6 +85,10 @@ def parse_args():
                          "10-bit tiles per step, its tiles sharded over the ranks (strong scaling, BASELINE.json configs[4])")
     ap.add_argument("--arithmetic", choices=("integer", "fp32"), default="integer",
                     help="integer: API defaults, libyuv's fixed point (default); fp32: rgb.avoidLibYUV = 1, libavif's built-in path")
+    ap.add_argument("--in-process", action="store_true",
+                    help="ONE process drives all --gpus N devices through the library's own device farm (avifhipSetDeviceSet: one worker thread, context and host "
+                         "link per GPU, no torch, no launcher): host-resident frames / canvas in, host-resident pixels out -- what an unmodified libavif over "
+                         "seam A / seam B gets from an N-GPU node (strong scaling of one image).  AVIFHIP_BENCH_DEVICES=0,0 names the set explicitly (one-GPU boxes)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: gloo process group and a converter that sleeps -- exercises the multi-rank plumbing only (numbers are meaningless)")
     return ap.parse_args()
@@ -141,12 +145,67 @@ def cpu_baseline(abi, synth, seconds: float):
                                          "sample": "best of 8 x the same frame, libavif 1.4.1 + libyuv 1922 (Pillow's binary), API defaults"}
     except Exception:
         pass
+    if kind == "reference":
+        out_extra.update(cpu_rows_threaded(abi, synth, lib))
     return {**out_extra, "value": round(mp * frames / t_total, 2), "unit": "megapixels/s", "cores": 1, "kind": kind,
             "sample": f"{frames} x 7680x4320 8-bit 4:2:0 BT.709 limited -> RGBA8 bilinear frames, libavif built-in float path "
                       f"(the reference compiled from its own sources has no libyuv: avoidLibYUV=1 arithmetic; maxThreads=1: the reference "
                       f"runs 4:2:0 bilinear single-threaded), {t_total:.1f} s of CPU; "
                       f"best frame {mp / best:.1f} MP/s",
             "best_value": round(mp / best, 2)}
+
+
+def cpu_rows_threaded(abi, synth, ref):
+    """BASELINE.md section 3's threaded rows, measured in this run on this box's host cores with the reference compiled from its sources:
+      threads8_cfg3      cfg3 (8K 10-bit 4:4:4 + alpha -> premultiplied RGBA16) with rgb.maxThreads = 8 -- legal for 4:4:4 (src/reformat.c:1680-1688), which
+                         the reference then splits into row bands on 8 threads itself (src/reformat.c:1695-1747); and the same with maxThreads = 1
+      all_cores_cfg5     cfg5's 64 tiles (1920x1080 10-bit 4:2:0 -> RGBA(10) bilinear), one single-threaded conversion per tile over a pool of host
+                         threads (ctypes releases the GIL): the CPU analogue of the tile farm"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    fn = ref.avifImageYUVToRGB
+    out = {}
+    try:
+        img = abi.make_yuv(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, with_alpha=True)
+        synth.fill_yuv(img, 0x12345678)
+        mp = 7680 * 4320 / 1e6
+        for threads, reps in ((8, 3), (1, 1)):
+            rgb = abi.make_rgb(7680, 4320, 16, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=True, alpha_premultiplied=True, max_threads=threads)
+            best = float("inf")
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                if fn(img.struct, rgb.struct) != 0:
+                    raise RuntimeError("conversion failed")
+                best = min(best, time.perf_counter() - t0)
+            out["threads8_cfg3" if threads == 8 else "threads1_cfg3"] = {
+                "value": round(mp / best, 1), "unit": "megapixels/s", "cores": threads, "ms": round(best * 1e3, 1),
+                "sample": f"best of {reps} x 7680x4320 10-bit 4:4:4 BT.2020 full + alpha -> RGBA16 premultiplied, reference from source, rgb.maxThreads = {threads}"}
+        del img, rgb
+        cores = os.cpu_count() or 1
+        tiles = []
+        for k in range(64):
+            timg = abi.make_yuv(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+            if k < 4:
+                synth.fill_yuv(timg, 0x12345678 + k)
+            else:
+                for p in range(3):
+                    timg.planes[p][...] = tiles[k % 4][0].planes[p]
+            trgb = abi.make_rgb(1920, 1080, 10, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, avoid_libyuv=True)
+            tiles.append((timg, trgb))
+        workers = min(64, cores)
+        best = float("inf")
+        with ThreadPoolExecutor(workers) as pool:
+            for _ in range(3):
+                t0 = time.perf_counter()
+                if any(r != 0 for r in pool.map(lambda t: fn(t[0].struct, t[1].struct), tiles)):
+                    raise RuntimeError("conversion failed")
+                best = min(best, time.perf_counter() - t0)
+        out["all_cores_cfg5"] = {"value": round(64 * 1920 * 1080 / 1e6 / best, 1), "unit": "megapixels/s", "cores": workers, "host_cores": cores, "ms": round(best * 1e3, 1),
+                                 "sample": "best of 3 x cfg5's 64 tiles (1920x1080 10-bit 4:2:0 -> RGBA(10) bilinear), reference from source, one single-threaded "
+                                           f"conversion per tile on {workers} host threads"}
+    except Exception as exc:  # the headline's baseline must not depend on these side rows
+        out["threaded_rows_error"] = repr(exc)
+    return out
 
 
 def spawn_ranks(n: int) -> int:
@@ -234,6 +293,9 @@ def median(xs):
 
 def main():
     args = parse_args()
+    if args.in_process:
+        print(json.dumps(run_in_process(args)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -442,6 +504,8 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            # the same kernel when nothing is cache-resident (12 frames cycled): what a decoder that streams frames sees -- `cold` below has the details
+            "frac_cold": round(gbps(kernel_ms_deep) / HBM_PEAK_GBPS, 4),
             "traffic": None,
             "traffic_source": None,
             "algorithmic_bytes_per_launch": int(alg_bytes),
@@ -509,6 +573,14 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
         return {"what": what, "kernel_ms": round(ms, 5), "algorithmic_bytes_per_launch": int(alg_bytes), "achieved": round(gb, 1),
                 "frac": round(gb / HBM_PEAK_GBPS, 4), "value": round(pixels / 1e6 / (ms * 1e-3), 1), "unit": "megapixels/s", **extra}
 
+    def ceiling(ceil_ms, conv_ms, alg_bytes):
+        """The byte-movement ceiling of a configuration's own shape (avifhipTimeStreamCeiling*: same planes, same pixels, same buffers cycled the same
+        way, no arithmetic; the fastest of the mover's tile shapes / orders), and where the conversion stands against it."""
+        gb = alg_bytes / (ceil_ms * 1e-3) / 1e9
+        return {"what": "same bytes, same buffers cycled the same way, no arithmetic (kernels_bench.hip streamMoveKernel: the fastest of its tile shapes / orders)",
+                "kernel_ms": round(ceil_ms, 5), "frac_of_peak": round(gb / HBM_PEAK_GBPS, 4), "conversion_vs_ceiling": round(ceil_ms / conv_ms, 4),
+                "pattern": native.last_kernel()}
+
     def y2r(w, h, depth, fmt, rng, mc, rgb_depth, alpha=False, premult=False, avoid=False, seed=0x12345678):
         img = abi.make_yuv(w, h, depth, fmt, rng, mc, with_alpha=alpha)
         synth.fill_yuv(img, seed)
@@ -528,6 +600,7 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     ms = burst(lib.avifhipTimeYUVToRGBCycle, 2, imgs, rgbs)
     configs["cfg3"] = row(ms, 16.0 * 7680 * 4320, 7680 * 4320, "7680x4320 10-bit 4:4:4 BT.2020 full + alpha -> RGBA16, alpha premultiplied in the same kernel; 2 frames cycled",
                           kernel=native.last_kernel())
+    configs["cfg3"]["ceiling"] = ceiling(burst(lib.avifhipTimeStreamCeiling, 2, imgs, rgbs), ms, 16.0 * 7680 * 4320)
     del pairs, imgs, rgbs
     # cfg4: 4K RGBA8 -> 8-bit 4:2:0 BT.709 limited + alpha plane (6.5 B/pixel), the encode direction; same frame and 8 frames cycled (431 MB)
     enc = []
@@ -543,6 +616,8 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     px4k = 3840 * 2160
     configs["cfg4"] = row(ms, 6.5 * px4k, px4k, "3840x2160 RGBA8 -> 8-bit 4:2:0 BT.709 limited + alpha plane (avifImageRGBToYUV); 8 frames cycled",
                           kernel=native.last_kernel(), same_frame=row(ms_same, 6.5 * px4k, px4k, "the same frame every launch (54 MB: cache-resident)"))
+    configs["cfg4"]["ceiling"] = ceiling(burst(lib.avifhipTimeStreamCeilingRGBToYUV, 8, imgs, rgbs), ms, 6.5 * px4k)
+    configs["cfg4"]["same_frame"]["ceiling"] = ceiling(burst(lib.avifhipTimeStreamCeilingRGBToYUV, 1, imgs, rgbs), ms_same, 6.5 * px4k)
     del enc, imgs, rgbs
     # cfg5: 64 separately stored 1920x1080 10-bit 4:2:0 tiles -> RGBA (10 bits in 16-bit containers, API defaults), 11 B/pixel
     tiles = []
@@ -560,6 +635,7 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     px_tiles = 64 * 1920 * 1080
     ms = burst(lib.avifhipTimeYUVToRGBBatch, 64, timgs, rgbs_a, None)
     kernel = native.last_kernel()
+    ceil_x64 = ceiling(burst(lib.avifhipTimeStreamCeilingBatch, 64, timgs, rgbs_a), ms, 11.0 * 64 * 1920 * 1080)
     # a decoder that rotates its output buffers sends a fresh descriptor table with every batch; one that reuses them launches on the table
     # the device still holds (avifhipTableUploadCount): both regimes
     outs_b, rgbs_b = tile_outputs()
@@ -575,7 +651,7 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     ms_alt = median(alt)
     configs["cfg5x64"] = row(ms, 11.0 * px_tiles, px_tiles, "64 separately stored 1920x1080 10-bit 4:2:0 tiles -> 64 RGBA (10 bits in 16-bit containers) images, ONE batched "
                              "launch per step (avifhipImageYUVToRGBBatchAsync); the same buffers every step: the descriptor table stays on the device",
-                             kernel=kernel, rotating_outputs={"what": "two sets of output buffers alternated: every batch uploads its descriptor table; host clock "
+                             kernel=kernel, ceiling=ceil_x64, rotating_outputs={"what": "two sets of output buffers alternated: every batch uploads its descriptor table; host clock "
                                                               f"around {n_alt} back-to-back calls, median of {len(alt)} passes", "ms_per_batch": round(ms_alt, 5),
                                                               "table_uploads_per_batch": round((lib.avifhipTableUploadCount() - uploads0) / n_alt, 2)})
     del outs_a, outs_b, rgbs_a, rgbs_b
@@ -585,6 +661,19 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     ms = burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas.struct)
     configs["cfg5grid"] = row(ms, 11.0 * px_tiles, px_tiles, "the same 64 tiles -> one 15360x8640 RGBA canvas, converted where they lie, seams as on the stitched canvas "
                               "(avifhipGridYUVToRGBAsync: every kernel of the call)", kernel=native.last_kernel())
+
+    def canvas_views(cv, depth, pixel_bytes):
+        """avifRGBImage views of the 64 tile rectangles of a canvas: the destinations of the byte-movement ceiling's 64 jobs"""
+        views = []
+        for t in range(64):
+            v = abi.make_rgb(1920, 1080, depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False)
+            v.struct.pixels = cv.buffer.ptr + (t // 8) * 1080 * cv.struct.rowBytes + (t % 8) * 1920 * pixel_bytes
+            v.struct.rowBytes = cv.struct.rowBytes
+            views.append(v)
+        return views, (C.POINTER(abi.avifRGBImage) * 64)(*[C.pointer(v.struct) for v in views])
+
+    views10, vrgbs10 = canvas_views(canvas, 10, 8)
+    configs["cfg5grid"]["ceiling"] = ceiling(burst(lib.avifhipTimeStreamCeilingBatch, 64, timgs, vrgbs10), ms, 11.0 * px_tiles)
     # ... -> RGBA8, where the default arithmetic runs the packed 16-bit kernels: their seam-aware build reads the chroma across the seams itself,
     # ONE launch per canvas (7 B/pixel); AVIFHIP_GRID_SEAM_PASS=1 brings the tile batch + seam pass of rounds 1-3 back for comparison
 
@@ -601,6 +690,9 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     ms8_pass = with_seam_pass(lambda: burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas8.struct))
     configs["cfg5grid"]["rgba8"] = row(ms8, 7.0 * px_tiles, px_tiles, "the same tiles -> one RGBA8 canvas: tiles and seams in ONE launch", kernel=kernel8,
                                        with_seam_pass=row(ms8_pass, 7.0 * px_tiles, px_tiles, "tile batch, then the seam kernel (two launches)"))
+    views8, vrgbs8 = canvas_views(canvas8, 8, 4)
+    configs["cfg5grid"]["rgba8"]["ceiling"] = ceiling(burst(lib.avifhipTimeStreamCeilingBatch, 64, timgs, vrgbs8), ms8, 7.0 * px_tiles)
+    del views10, vrgbs10, views8, vrgbs8
     del canvas, canvas8, tiles, timgs
     # a phone photograph: 4032x3024 8-bit 4:2:0 stored as 8 x 6 tiles of 512x512 (the last row cropped) -> RGBA8, the same buffers call after call
     ptiles = []
@@ -799,6 +891,68 @@ def run_cfg5(args, lib, rank, world, dist, torch):
             "rank0_link_GBps": round((up.value + down.value) / (host_elapsed / host_steps) / 1e9, 1),
         },
         "cpu_baseline": None,
+    }
+
+
+def run_in_process(args):
+    """`--in-process`: ONE process, the library's own device farm (include/avifhip.h avifhipSetDeviceSet; libavif_amd/csrc/api_farm.cpp) over --gpus N
+    devices.  A step = one host-resident image converted by ONE synchronous call (avifhipImageYUVToRGB -- what libavif's seam A / seam B hand
+    over), its rows shared out over the devices, every device on its own host link: STRONG scaling of one image, host to host.  This is NOT the
+    contract's HBM-resident `value` (that is the default run): the line says so in "metric" and "data"."""
+    from libavif_amd import abi, native, synth
+
+    lib = native.load()
+    have = lib.avifhipDeviceCount()
+    if have <= 0:
+        raise SystemExit("bench.py: no HIP device visible -- there is no CPU fallback for the product path")
+    named = os.environ.get("AVIFHIP_BENCH_DEVICES")
+    devices = [int(x) for x in named.split(",")] if named else list(range(args.gpus))
+    if not named and have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {have} HIP device(s) are visible -- refusing to report a {args.gpus}-GPU number "
+                         "(AVIFHIP_BENCH_DEVICES=0,0 names a set explicitly)")
+    native.check(lib.avifhipSetDeviceSet((C.c_int * len(devices))(*devices), len(devices)), "avifhipSetDeviceSet")
+    lib.avifhipSetArithmetic(0)
+    if args.workload == "cfg5":
+        w, h, depth, what = 15360, 8640, 10, "15360x8640 stitched canvas of the 8x8 grid of 1920x1080 10-bit YUV420 BT.709 limited tiles -> RGBA (10 bits in 16-bit containers, API defaults), bilinear"
+    else:
+        w, h, depth, what = WIDTH, HEIGHT, 8, "7680x4320 8-bit YUV420 BT.709 limited -> RGBA8, bilinear chroma upsampling, API defaults (integer path)"
+    img = abi.make_yuv(w, h, depth, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, abi.AVIF_MATRIX_COEFFICIENTS_BT709)
+    synth.fill_yuv(img, 0x12345678)
+    rgb = abi.make_rgb(w, h, depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, avoid_libyuv=False)
+    steps, warmup = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+
+    def run(k):
+        for _ in range(k):
+            native.check(lib.avifhipImageYUVToRGB(img.struct, rgb.struct), "avifhipImageYUVToRGB")
+
+    run(2)  # (the workers' contexts, device twins and download helpers are built by the first call)
+    regions = []
+    for _ in range(max(3, args.repeats // 3)):
+        run(warmup)
+        t0 = time.perf_counter()
+        run(steps)
+        regions.append(time.perf_counter() - t0)
+    elapsed = median(regions)
+    workers = []
+    for k in range(lib.avifhipLastFarmWorkers()):
+        dev, b, e, up, down = C.c_int(-1), C.c_uint32(0), C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        native.check(lib.avifhipLastFarmTransferBytes(k, C.byref(dev), C.byref(b), C.byref(e), C.byref(up), C.byref(down)), "avifhipLastFarmTransferBytes")
+        workers.append({"device": dev.value, "rows": [b.value, e.value], "bytes_up": up.value, "bytes_down": down.value})
+    up, down = C.c_uint64(0), C.c_uint64(0)
+    lib.avifhipLastTransferBytes(C.byref(up), C.byref(down))
+    mp = w * h / 1e6
+    ms = 1e3 * elapsed / steps
+    native.check(lib.avifhipSetDeviceSet(None, 0), "avifhipSetDeviceSet")
+    return {
+        "metric": "megapixels/sec YUV420->RGBA, HOST to HOST through one synchronous call, rows shared over the GPUs of one process",
+        "value": round(mp * steps / elapsed, 1), "unit": "megapixels/s", "n_gpus": len(devices), "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i16" if depth == 8 else "f32",
+        "data": "synthetic, host-resident in and out (pageable memory): staging over the host links is inside the timed region",
+        "value_basis": f"median of {len(regions)} regions of {steps} calls (min {1e3 * min(regions) / steps:.3f}, max {1e3 * max(regions) / steps:.3f} ms per call), host clock",
+        "config": {"workload": what, "kernel": native.last_kernel(), "devices": devices, "in_process": True,
+                   "parallelism": f"one process, {len(workers) or 1} worker thread(s), one per entry of the device set; no collective, halo rows uploaded per device"},
+        "host_link": {"bytes_up": up.value, "bytes_down": down.value, "GBps": round((up.value + down.value) / (ms * 1e-3) / 1e9, 1), "workers": workers},
+        "roofline": None, "cpu_baseline": None,
     }
 
 

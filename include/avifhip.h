@@ -81,7 +81,8 @@ AVIFHIP_API avifResult avifhipImageYUVToRGBRects(const avifImage * canvas, avifR
 /* The bytes that call moves over the host link for these rectangles (needs no device): *bytesUp, *bytesDown. */
 AVIFHIP_API avifResult avifhipPlanRectTransfers(const avifImage * canvas, const avifRGBImage * rgbCanvas, const avifCropRect * rects, uint32_t count, uint64_t * bytesUp,
                                                 uint64_t * bytesDown);
-/* ... and what the calling thread's last avifhipImageYUVToRGBRects actually moved. */
+/* ... and what the calling thread's last host-resident conversion (avifhipImageYUVToRGBRects, avifhipImageYUVToRGB, avifhipImageRGBToYUV, the
+ * in-place alpha / half-float passes) actually moved over the host link(s). */
 AVIFHIP_API void avifhipLastTransferBytes(uint64_t * bytesUp, uint64_t * bytesDown);
 
 /* ---- device-resident / asynchronous variants ------------------------------------------------- */
@@ -314,6 +315,34 @@ AVIFHIP_API void avifhipSetTuning(uint32_t bits);
 
 /* Selects the HIP device used by the calling thread's context (default: current device). */
 AVIFHIP_API avifResult avifhipSetDevice(int device);
+
+/* ---- every GPU of the node behind the same calls --------------------------------------------------------------------
+ * The device set: with two or more entries, the synchronous HOST-resident entry points -- avifhipImageYUVToRGB (and the hooks built on it:
+ * ...ColorOnly, ...Hook), avifhipImageRGBToYUV, avifhipRGBImagePremultiplyAlpha / UnpremultiplyAlpha, avifhipRGBImageToF16 and
+ * avifhipImageYUVToRGBRects -- cut an image of 4 megapixels or more into contiguous row shares (multiples of 32 rows, ~2 megapixels at
+ * least; rectangles: contiguous blocks of the row-major job list, i.e. whole tile rows of a grid) and convert each share on its own
+ * device: one persistent worker thread, pooled context, streams and staging per entry, every device moving its share over its own host
+ * link.  This is the reference's own row-band fan-out (src/reformat.c:1695-1747) across devices instead of host threads.  Nothing is
+ * exchanged between devices: the chroma filter's sample row above and below a share is uploaded with it.  Results are byte-identical to
+ * the single-device call (every share is the same rectangle of the whole-image conversion).  An unmodified libavif over seam A / seam B
+ * then uses every GPU of the node: AVIFHIP_DEVICES="all" or "0,1,2,3" in the environment selects the set without a code change
+ * (avifhipSetDeviceSet overrides it).  A device may be named more than once ("0,0": two workers on one GPU -- how a one-GPU box
+ * exercises the path).  count = 0 (the default): calls run on the calling thread's device as ever.  Device-resident (Async) entry
+ * points are not affected: their buffers live on one device. */
+AVIFHIP_API avifResult avifhipSetDeviceSet(const int * devices, uint32_t count);
+/* The smallest share that is worth a device of its own, in pixels (0 = the default, 2^21: below ~2 megapixels a second device costs more
+ * than its host link brings).  Tests lower it to send small images through the farm; shares stay multiples of 32 rows. */
+AVIFHIP_API void avifhipSetFarmMinSharePixels(uint64_t pixels);
+/* The current set: writes at most `capacity` entries, returns the set's size. */
+AVIFHIP_API uint32_t avifhipGetDeviceSet(int * devices, uint32_t capacity);
+/* Host-only (needs no GPU): the row shares a `workers`-entry set gives an image of this size -- bands[k] = { 0, first row, width, rows };
+ * *count = 1 means "not farmed".  bands may be NULL (count only); capacity >= workers always suffices. */
+AVIFHIP_API avifResult avifhipPlanFarmRows(uint32_t width, uint32_t height, uint32_t workers, avifCropRect * bands, uint32_t capacity, uint32_t * count);
+/* The calling thread's last host-resident call: how many workers took part (0: it ran on the thread's own device), and for worker k its
+ * device, its share (rows [begin, end) of the image; avifhipImageYUVToRGBRects: entries of the coalesced job list) and the bytes it moved
+ * over its host link.  avifhipLastTransferBytes reports the sum. */
+AVIFHIP_API uint32_t avifhipLastFarmWorkers(void);
+AVIFHIP_API avifResult avifhipLastFarmTransferBytes(uint32_t worker, int * device, uint32_t * begin, uint32_t * end, uint64_t * bytesUp, uint64_t * bytesDown);
 /* Number of visible HIP devices; 0 when no GPU / no driver. */
 AVIFHIP_API int avifhipDeviceCount(void);
 /* Extra HIP streams (returned as void*, usable as the `hipStream` argument of the Async entry points) so that
@@ -358,10 +387,20 @@ AVIFHIP_API double avifhipTimeRGBToYUV(avifImage * image, const avifRGBImage * r
 /* Same for launches that cycle over `count` distinct device-resident frames (launch k converts frame k % count), so
  * that a working set larger than the Infinity Cache makes every launch stream from and to HBM. */
 AVIFHIP_API double avifhipTimeYUVToRGBCycle(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
-/* The chip's own ceiling for the byte movement of an 8-bit 4:2:0 -> 4-byte-pixel conversion: the same timing for a kernel that
- * reads every plane sample once and writes every output byte once with NO arithmetic (kernels_bench.hip; the RGB buffers receive
- * meaningless bytes).  Negative for other formats. */
+/* The chip's own ceiling for the byte movement of a conversion: the same timing for a kernel that reads every plane sample the
+ * conversion reads once and writes every output byte once with NO arithmetic (kernels_bench.hip; the destination buffers receive
+ * meaningless bytes), in the tiled kernels' own access shapes (4 samples per lane and plane row, 16 bytes of pixels per lane at
+ * consecutive addresses, streaming stores).  Any plane layout (8-bit or 16-bit containers, 4:4:4 / 4:2:2 / 4:2:0 / 4:0:0, with or without
+ * an alpha plane the conversion reads) into 4- or 8-byte pixels; all jobs of a call share one layout.  The fastest of the tile shapes /
+ * orders the kernel knows (1024 x 2 and 1024 x 4 pixels in raster order, 256 x 16 and 256 x 32 in per-XCD bands) is reported;
+ * avifhipLastKernel() then names it.  Negative for anything else (avifhipLastError() says why).
+ *   avifhipTimeStreamCeiling          launch k moves job k % count (frames cycled, like avifhipTimeYUVToRGBCycle)
+ *   avifhipTimeStreamCeilingRGBToYUV  the encode direction: pixels read, planes written (avifhipTimeRGBToYUVCycle)
+ *   avifhipTimeStreamCeilingBatch     all `count` jobs in ONE launch (avifhipTimeYUVToRGBBatch; a grid: rgbs[k] = tile k's rectangle
+ *                                     of the canvas) */
 AVIFHIP_API double avifhipTimeStreamCeiling(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
+AVIFHIP_API double avifhipTimeStreamCeilingRGBToYUV(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
+AVIFHIP_API double avifhipTimeStreamCeilingBatch(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
 /* The same event timing for the encode direction over `count` cycled frames, for a batch call (avifhipImageYUVToRGBBatchAsync: milliseconds
  * per batch) and for a grid call (avifhipGridYUVToRGBAsync: milliseconds per canvas, every kernel the call launches included). */
 AVIFHIP_API double avifhipTimeRGBToYUVCycle(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);

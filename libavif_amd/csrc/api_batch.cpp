@@ -274,8 +274,9 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
     // one launch for tiles AND seams (kernels.h TileNeighbours) needs one chroma pitch per plane over the whole grid: a neighbour's sample is
     // addressed with the job's own offset.  Whether it is used: tileBatchLinksNeighbours; AVIFHIP_GRID_SEAM_PASS=1 always keeps the second
     // pass, =0 never does where the grid can be linked (A/B measurements, tests of the seam kernels)
+    // (exactly "1" or "0": anything else -- "yes", an empty string -- is ignored rather than read as 0)
     const char * seamPassEnv = getenv("AVIFHIP_GRID_SEAM_PASS");
-    const int linkForced = seamPassEnv ? (atoi(seamPassEnv) != 0 ? 0 : 1) : -1;
+    const int linkForced = (seamPassEnv && (seamPassEnv[0] == '0' || seamPassEnv[0] == '1') && !seamPassEnv[1]) ? (seamPassEnv[0] == '1' ? 0 : 1) : -1;
     bool linkable = subsampled && count > 1 && linkForced != 0;
     for (uint32_t t = 0; t < count; ++t) {
         const avifImage * tile = colorTiles[t];
@@ -380,7 +381,8 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
                 (void)hipEventRecord(ev, s);
         }
     } slotRead = { tls.tableConsumed[tableSlot], stream, residentTable, tableSlot };
-    if (getenv("AVIFHIP_GRID_TRACE"))
+    static const bool traceGrids = getenv("AVIFHIP_GRID_TRACE") != nullptr; // (read once: a debugging aid, not a switch to flip while running)
+    if (traceGrids)
         fprintf(stderr, "avifhip grid %ux%u: %s, seams %s (%s)\n", grid->columns, grid->rows, linkable ? "linkable" : "not linkable",
                 seamsDone ? "in the tile kernels" : "in a second pass", tls.lastKernel ? tls.lastKernel : "?");
     if (count == 1 || seamsDone)

@@ -35,20 +35,14 @@ extern "C" avifResult avifhipImageYUVToRGBAsync(const avifImage * image, avifRGB
 // -- PCIe is full duplex (tests/tools/pcie_probe.hip: 56 GB/s each way alone, 53 + 20 GB/s together).  Bands start on multiples
 // of 32 rows (whole tiles of the tiled kernels), at least ~2 megapixels each, at most Context::kMaxBands.
 
-static avifResult yuvToRgbSync(const avifImage * image, avifRGBImage * rgb, bool colorOnly, bool reformatAlpha)
+// Rows [rowBegin, rowEnd) of the conversion on the calling thread's device (the whole image: 0, image->height; a farm worker: its share --
+// rowBegin a multiple of 32, so that shares are whole tiles and start on even rows).  Everything has been validated by the caller.
+static avifResult yuvToRgbRows(const avifImage * image, avifRGBImage * rgb, bool colorOnly, bool reformatAlpha, uint32_t rowBegin, uint32_t rowEnd)
 {
-    if (!image || !rgb)
-        return AVIF_RESULT_INVALID_ARGUMENT;
-    // Validate exactly like the reference before touching the device (error-code matrix,
-    // tests/gtest/avif_fuzztest_yuvrgb.cc:36-46).
     YuvToRgbPlan probe;
     const avifResult pr = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &probe, colorOnly, reformatAlpha);
     if (pr != AVIF_RESULT_OK)
         return pr;
-    if (!rgb->pixels) {
-        setError("avifhipImageYUVToRGB: rgb->pixels is NULL");
-        return AVIF_RESULT_INVALID_ARGUMENT;
-    }
     const avifResult cr = ensureContext();
     if (cr != AVIF_RESULT_OK)
         return cr;
@@ -77,15 +71,18 @@ static avifResult yuvToRgbSync(const avifImage * image, avifRGBImage * rgb, bool
     const PlaneGeometry g = planeGeometry(image);
     const bool subY = image->yuvFormat == AVIF_PIXEL_FORMAT_YUV420;
     const uint32_t pixelRowBytes = rgb->width * rgbPixelBytes(rgb);
-    const uint32_t bandRows = bandRowsFor(image->width, image->height);
-    const bool banded = pixelsOnHost && bandRows < image->height;
+    const uint32_t bandRows = bandRowsFor(image->width, rowEnd - rowBegin);
+    const bool banded = pixelsOnHost && bandRows < rowEnd - rowBegin;
     if (banded && !tls.downloader)
         tls.downloader = new CopyWorker(tls.device, tls.downStream);
     DrainOnExit drainOnExit = { banded ? tls.downloader : nullptr };
-    uint32_t chromaUploaded = 0; // chroma rows [0, chromaUploaded) are on the device (or on their way, on upStream)
+    // chroma rows [.., chromaUploaded) that this call needs are on the device (or on their way, on upStream): a share that starts inside the
+    // image begins one chroma row above its first (the 4:2:0 filter's upper neighbour)
+    uint32_t chromaUploaded = subY ? ((rowBegin >> 1) ? (rowBegin >> 1) - 1 : 0) : rowBegin;
+    tls.bytesUp = tls.bytesDown = 0;
     int band = 0;
-    for (uint32_t y0 = 0; y0 < image->height; y0 += bandRows, ++band) {
-        const uint32_t y1 = (y0 + bandRows < image->height) ? y0 + bandRows : image->height;
+    for (uint32_t y0 = rowBegin; y0 < rowEnd; y0 += bandRows, ++band) {
+        const uint32_t y1 = (y0 + bandRows < rowEnd) ? y0 + bandRows : rowEnd;
         const int e = band % Context::kMaxBands;
         // ---- up: luma / alpha rows [y0, y1); chroma rows up to the one below the band's last (the 4:2:0 filter's lower
         //      neighbour; the upper one arrived with the previous band): every row crosses the bus exactly once ----
@@ -106,6 +103,7 @@ static avifResult yuvToRgbSync(const avifImage * image, avifRGBImage * rgb, bool
             if (r1 > r0) {
                 HIP_TRY(hipMemcpy2DAsync(dev + (size_t)r0 * devRowBytes, devRowBytes, host + (size_t)r0 * hostRowBytes, hostRowBytes, g.widthBytes[p], r1 - r0,
                                          hipMemcpyHostToDevice, tls.upStream));
+                tls.bytesUp += (uint64_t)g.widthBytes[p] * (r1 - r0);
                 uploaded = true;
             }
             if (p == 2 || (p == 1 && !planeOnHost[2]))
@@ -114,6 +112,7 @@ static avifResult yuvToRgbSync(const avifImage * image, avifRGBImage * rgb, bool
         if (pixelsOnHost && keepsBytes) {
             HIP_TRY(hipMemcpy2DAsync(rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes,
                                      y1 - y0, hipMemcpyHostToDevice, tls.upStream));
+            tls.bytesUp += (uint64_t)pixelRowBytes * (y1 - y0);
             uploaded = true;
         }
         if (uploaded) {
@@ -138,6 +137,7 @@ static avifResult yuvToRgbSync(const avifImage * image, avifRGBImage * rgb, bool
             HIP_TRY(hipEventRecord(tls.bandDone[e], tls.stream));
             const CopyWorker::Job job = { tls.bandDone[e], rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes,
                                           pixelRowBytes, y1 - y0 };
+            tls.bytesDown += (uint64_t)pixelRowBytes * (y1 - y0);
             if (banded) {
                 tls.downloader->post(job);
             } else {
@@ -157,6 +157,53 @@ static avifResult yuvToRgbSync(const avifImage * image, avifRGBImage * rgb, bool
         }
     }
     return AVIF_RESULT_OK;
+}
+
+static bool planesAndPixelsOnHost(const avifImage * image, const avifRGBImage * rgb)
+{
+    for (int p = 0; p < 4; ++p) {
+        const uint8_t * plane = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
+        if (plane && isDevicePointer(plane))
+            return false;
+    }
+    return !isDevicePointer(rgb->pixels);
+}
+
+static avifResult yuvToRgbSync(const avifImage * image, avifRGBImage * rgb, bool colorOnly, bool reformatAlpha)
+{
+    if (!image || !rgb)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    // Validate exactly like the reference before touching the device (error-code matrix,
+    // tests/gtest/avif_fuzztest_yuvrgb.cc:36-46).
+    YuvToRgbPlan probe;
+    const avifResult pr = makeYuvToRgbPlan(image, rgb, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &probe, colorOnly, reformatAlpha);
+    if (pr != AVIF_RESULT_OK)
+        return pr;
+    if (!rgb->pixels) {
+        setError("avifhipImageYUVToRGB: rgb->pixels is NULL");
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    }
+    // A device set of two or more workers (avifhipSetDeviceSet / AVIFHIP_DEVICES) takes host-resident images of 4 megapixels and more in row
+    // shares, one per device (api_farm.cpp).  Shares start on multiples of 32 rows: every share is the same rectangle of the whole-image
+    // conversion, byte for byte (chroma edge rules against the image; the halo row either side is uploaded with the share).
+    const uint32_t workers = farmWorkers();
+    if (workers >= 2) {
+        const std::vector<FarmShare> shares = planFarmRows(image->width, image->height, workers);
+        if (shares.size() >= 2 && planesAndPixelsOnHost(image, rgb)) {
+            struct Call
+            {
+                const avifImage * image;
+                avifRGBImage * rgb;
+                bool colorOnly, reformatAlpha;
+            } call = { image, rgb, colorOnly, reformatAlpha };
+            return farmRun(shares, [](void * arg, uint32_t, FarmShare share) -> avifResult {
+                const Call & c = *static_cast<const Call *>(arg);
+                return yuvToRgbRows(c.image, c.rgb, c.colorOnly, c.reformatAlpha, share.begin, share.end);
+            }, &call);
+        }
+    }
+    tls.farmReports.clear();
+    return yuvToRgbRows(image, rgb, colorOnly, reformatAlpha, 0, image->height);
 }
 
 // ---- rectangles of a host-resident canvas (the tile farm's per-rank primitive) ----
@@ -217,6 +264,20 @@ static std::vector<avifCropRect> coalesceRects(const avifCropRect * rects, uint3
     return jobs;
 }
 
+// ... and a tall job is cut into pieces of ~2 megapixels (bandRowsFor: multiples of 32 rows), so that the upload of one piece, the kernel of
+// the previous and the download of the one before overlap inside a job too (a farm worker often has ONE job: its tile row)
+static std::vector<avifCropRect> pipelinePieces(const avifCropRect * jobs, uint32_t count)
+{
+    std::vector<avifCropRect> pieces;
+    for (uint32_t k = 0; k < count; ++k) {
+        const avifCropRect & rc = jobs[k];
+        const uint32_t rows = bandRowsFor(rc.width, rc.height);
+        for (uint32_t y = 0; y < rc.height; y += rows)
+            pieces.push_back({ rc.x, rc.y + y, rc.width, (rc.height - y > rows) ? rows : rc.height - y });
+    }
+    return pieces;
+}
+
 extern "C" avifResult avifhipPlanRectTransfers(const avifImage * canvas, const avifRGBImage * rgbCanvas, const avifCropRect * rects, uint32_t count, uint64_t * bytesUp,
                                                uint64_t * bytesDown)
 {
@@ -230,7 +291,8 @@ extern "C" avifResult avifhipPlanRectTransfers(const avifImage * canvas, const a
         if (pr != AVIF_RESULT_OK)
             return pr;
     }
-    for (const avifCropRect & rc : coalesceRects(rects, count)) {
+    const std::vector<avifCropRect> coalesced = coalesceRects(rects, count);
+    for (const avifCropRect & rc : pipelinePieces(coalesced.data(), (uint32_t)coalesced.size())) {
         YuvToRgbPlan plan;
         const avifResult pr = makeYuvToRgbPlan(canvas, rgbCanvas, &rc, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan);
         if (pr != AVIF_RESULT_OK)
@@ -249,6 +311,8 @@ extern "C" avifResult avifhipPlanRectTransfers(const avifImage * canvas, const a
         *bytesDown = down;
     return AVIF_RESULT_OK;
 }
+
+static avifResult rectJobsOnThisDevice(const avifImage * canvas, avifRGBImage * rgbCanvas, const avifCropRect * jobs, uint32_t count);
 
 extern "C" avifResult avifhipImageYUVToRGBRects(const avifImage * canvas, avifRGBImage * rgbCanvas, const avifCropRect * rects, uint32_t count)
 {
@@ -278,6 +342,32 @@ extern "C" avifResult avifhipImageYUVToRGBRects(const avifImage * canvas, avifRG
         setError("avifhipImageYUVToRGBRects: host-resident canvases only (device-resident ones: avifhipImageYUVToRGBBatchAsync)");
         return AVIF_RESULT_INVALID_ARGUMENT;
     }
+    // a device set of two or more workers: contiguous blocks of the (coalesced, row-major) job list, one per device -- whole tile rows when the
+    // rectangles are the tiles of a grid (libavif_amd/farm.py: shard)
+    const std::vector<avifCropRect> jobs = coalesceRects(rects, count);
+    const uint32_t workers = farmWorkers();
+    if (workers >= 2 && jobs.size() >= 2) {
+        const std::vector<FarmShare> shares = planFarmJobs((uint32_t)jobs.size(), workers);
+        struct Call
+        {
+            const avifImage * canvas;
+            avifRGBImage * rgbCanvas;
+            const std::vector<avifCropRect> * jobs;
+        } call = { canvas, rgbCanvas, &jobs };
+        return farmRun(shares, [](void * arg, uint32_t, FarmShare share) -> avifResult {
+            const Call & c = *static_cast<const Call *>(arg);
+            return rectJobsOnThisDevice(c.canvas, c.rgbCanvas, c.jobs->data() + share.begin, share.end - share.begin);
+        }, &call);
+    }
+    tls.farmReports.clear();
+    return rectJobsOnThisDevice(canvas, rgbCanvas, jobs.data(), (uint32_t)jobs.size());
+}
+
+// the coalesced jobs `jobs[0 .. count)` of avifhipImageYUVToRGBRects on the calling thread's device
+static avifResult rectJobsOnThisDevice(const avifImage * canvas, avifRGBImage * rgbCanvas, const avifCropRect * coalesced, uint32_t coalescedCount)
+{
+    const std::vector<avifCropRect> jobs = pipelinePieces(coalesced, coalescedCount);
+    const uint32_t count = (uint32_t)jobs.size();
     const avifResult cr = ensureContext();
     if (cr != AVIF_RESULT_OK)
         return cr;
@@ -296,8 +386,6 @@ extern "C" avifResult avifhipImageYUVToRGBRects(const avifImage * canvas, avifRG
     DrainOnExit drainOnExit = { tls.downloader };
     const uint32_t bps = (canvas->depth > 8) ? 2 : 1, px = rgbPixelBytes(rgbCanvas);
     tls.bytesUp = tls.bytesDown = 0;
-    const std::vector<avifCropRect> jobs = coalesceRects(rects, count);
-    count = (uint32_t)jobs.size();
     for (uint32_t k = 0; k < count; ++k) {
         const avifCropRect & rc = jobs[k];
         const int e = (int)(k % Context::kMaxBands);

@@ -33,23 +33,15 @@ extern "C" avifResult avifhipImageRGBToYUVAsync(avifImage * image, const avifRGB
     return enqueueRgbToYuv(plan, pickStream(hipStream));
 }
 
-extern "C" avifResult avifhipImageRGBToYUV(avifImage * image, const avifRGBImage * rgb)
+// Rows [rowBegin, rowEnd) of the conversion on the calling thread's device (the whole image, or a farm worker's share: rowBegin even, so
+// that no 2 x 2 block is cut).  Arguments validated and destination planes allocated by the caller.
+static avifResult rgbToYuvRows(avifImage * image, const avifRGBImage * rgb, uint32_t rowBegin, uint32_t rowEnd)
 {
-    if (!image || !rgb)
-        return AVIF_RESULT_INVALID_ARGUMENT;
     RgbToYuvPlan plan;
     avifResult r = makeRgbToYuvPlan(image, rgb, effectiveArithmetic(), &plan);
     if (r != AVIF_RESULT_OK)
         return r;
-    const bool hasAlpha = plan.rgb.hasAlpha && !rgb->ignoreAlpha;
     const bool pixelsOnHost = !isDevicePointer(rgb->pixels);
-    if (pixelsOnHost || !image->yuvPlanes[0]) {
-        r = allocateHostPlanes(image, hasAlpha); // src/reformat.c:236-240
-        if (r != AVIF_RESULT_OK)
-            return r;
-    }
-    if (sharpYuvRequested(image, rgb))
-        return AVIF_RESULT_NOT_IMPLEMENTED;
     r = ensureContext();
     if (r != AVIF_RESULT_OK)
         return r;
@@ -73,19 +65,21 @@ extern "C" avifResult avifhipImageRGBToYUV(avifImage * image, const avifRGBImage
     // Row bands, like yuvToRgbSync: a band of RGB rows is an independent sub-image of this direction (2 x 2 blocks never cross an
     // even row), so band b is converted as an image of its own rows while band b+1 uploads and band b-1 downloads.
     // Gray sources keep the single pass (their chroma planes are filled pitch-wide).
-    const uint32_t bandRows = gray ? image->height : bandRowsFor(image->width, image->height);
-    const bool banded = bandRows < image->height;
+    const uint32_t bandRows = gray ? image->height : bandRowsFor(image->width, rowEnd - rowBegin);
+    const bool banded = bandRows < rowEnd - rowBegin;
     if (banded && !tls.downloader)
         tls.downloader = new CopyWorker(tls.device, tls.downStream);
     DrainOnExit drainOnExit = { banded ? tls.downloader : nullptr };
+    tls.bytesUp = tls.bytesDown = 0;
     int band = 0;
-    for (uint32_t y0 = 0; y0 < image->height; y0 += bandRows, ++band) {
-        const uint32_t y1 = (y0 + bandRows < image->height) ? y0 + bandRows : image->height;
+    for (uint32_t y0 = rowBegin; y0 < rowEnd; y0 += bandRows, ++band) {
+        const uint32_t y1 = (y0 + bandRows < rowEnd) ? y0 + bandRows : rowEnd;
         const int e = band % Context::kMaxBands;
         const uint32_t c0 = subY ? (y0 >> 1) : y0, c1 = subY ? ((y1 + 1) >> 1) : y1; // chroma rows of the band
         if (pixelsOnHost) {
             HIP_TRY(hipMemcpy2DAsync(rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes,
                                      y1 - y0, hipMemcpyHostToDevice, tls.upStream));
+            tls.bytesUp += (uint64_t)pixelRowBytes * (y1 - y0);
             HIP_TRY(hipEventRecord(tls.bandUp[e], tls.upStream));
             HIP_TRY(hipStreamWaitEvent(tls.stream, tls.bandUp[e], 0));
         }
@@ -124,9 +118,13 @@ extern "C" avifResult avifhipImageRGBToYUV(avifImage * image, const avifRGBImage
             const uint32_t r0 = chroma ? c0 : y0, r1 = chroma ? c1 : y1;
             if (gray && chroma) {
                 HIP_TRY(hipMemcpyAsync(host, dev, (size_t)hostRowBytes * g.rows[p], hipMemcpyDeviceToHost, tls.downStream));
+                tls.bytesDown += (uint64_t)hostRowBytes * g.rows[p];
+                continue;
             } else if (chroma && image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400) {
                 continue; // colour source into 4:0:0: chroma untouched
-            } else if (banded) {
+            }
+            tls.bytesDown += (uint64_t)g.widthBytes[p] * (r1 - r0);
+            if (banded) {
                 tls.downloader->post({ tls.bandDone[e], host + (size_t)r0 * hostRowBytes, hostRowBytes, dev + (size_t)r0 * devRowBytes, devRowBytes, g.widthBytes[p], r1 - r0 });
             } else {
                 HIP_TRY(hipMemcpy2DAsync(host + (size_t)r0 * hostRowBytes, hostRowBytes, dev + (size_t)r0 * devRowBytes, devRowBytes, g.widthBytes[p], r1 - r0, hipMemcpyDeviceToHost,
@@ -143,6 +141,49 @@ extern "C" avifResult avifhipImageRGBToYUV(avifImage * image, const avifRGBImage
         HIP_TRY(hipStreamSynchronize(tls.downStream));
     }
     return AVIF_RESULT_OK;
+}
+
+extern "C" avifResult avifhipImageRGBToYUV(avifImage * image, const avifRGBImage * rgb)
+{
+    if (!image || !rgb)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    RgbToYuvPlan plan;
+    avifResult r = makeRgbToYuvPlan(image, rgb, effectiveArithmetic(), &plan);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    const bool hasAlpha = plan.rgb.hasAlpha && !rgb->ignoreAlpha;
+    const bool pixelsOnHost = !isDevicePointer(rgb->pixels);
+    if (pixelsOnHost || !image->yuvPlanes[0]) {
+        r = allocateHostPlanes(image, hasAlpha); // src/reformat.c:236-240
+        if (r != AVIF_RESULT_OK)
+            return r;
+    }
+    if (sharpYuvRequested(image, rgb))
+        return AVIF_RESULT_NOT_IMPLEMENTED;
+    // a device set of two or more workers takes host-resident images of 4 megapixels and more in row shares (api_farm.cpp); gray sources
+    // keep their single pass (their chroma planes are filled pitch-wide by one launch)
+    const uint32_t workers = farmWorkers();
+    if (workers >= 2 && pixelsOnHost && !rgbFormatIsGray((int)rgb->format)) {
+        bool planesOnHost = true;
+        for (int p = 0; p < 4; ++p) {
+            const uint8_t * plane = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
+            planesOnHost = planesOnHost && !(plane && isDevicePointer(plane));
+        }
+        const std::vector<FarmShare> shares = planFarmRows(image->width, image->height, workers);
+        if (planesOnHost && shares.size() >= 2) {
+            struct Call
+            {
+                avifImage * image;
+                const avifRGBImage * rgb;
+            } call = { image, rgb };
+            return farmRun(shares, [](void * arg, uint32_t, FarmShare share) -> avifResult {
+                const Call & c = *static_cast<const Call *>(arg);
+                return rgbToYuvRows(c.image, c.rgb, share.begin, share.end);
+            }, &call);
+        }
+    }
+    tls.farmReports.clear();
+    return rgbToYuvRows(image, rgb, 0, image->height);
 }
 
 // =================================================================================================
@@ -167,20 +208,25 @@ static avifResult alphaMulAsync(avifRGBImage * rgb, bool unmultiply, void * hipS
 // so that both directions of the link and the kernel overlap (the same three streams and helper thread as yuvToRgbSync).
 // `launch(view, y0, rows, stream)` enqueues the pass on rows [y0, y0 + rows) of the device copy.
 template <class Launch>
-static avifResult inPlaceBanded(avifRGBImage * rgb, uint32_t pixelRowBytes, Launch launch)
+static avifResult inPlaceBandedRows(avifRGBImage * rgb, uint32_t pixelRowBytes, Launch & launch, uint32_t rowBegin, uint32_t rowEnd)
 {
-    avifRGBImage view = *rgb;
-    avifResult r = stagePixels(&view, /*upload=*/false);
+    avifResult r = ensureContext();
     if (r != AVIF_RESULT_OK)
         return r;
-    const uint32_t bandRows = bandRowsFor(rgb->width, rgb->height);
-    const bool banded = bandRows < rgb->height;
+    avifRGBImage view = *rgb;
+    r = stagePixels(&view, /*upload=*/false);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    const uint32_t bandRows = bandRowsFor(rgb->width, rowEnd - rowBegin);
+    const bool banded = bandRows < rowEnd - rowBegin;
     if (banded && !tls.downloader)
         tls.downloader = new CopyWorker(tls.device, tls.downStream);
     DrainOnExit drainOnExit = { banded ? tls.downloader : nullptr };
+    tls.bytesUp = tls.bytesDown = 0;
     int band = 0;
-    for (uint32_t y0 = 0; y0 < rgb->height; y0 += bandRows, ++band) {
-        const uint32_t rows = (y0 + bandRows < rgb->height) ? bandRows : rgb->height - y0;
+    for (uint32_t y0 = rowBegin; y0 < rowEnd; y0 += bandRows, ++band) {
+        const uint32_t rows = (y0 + bandRows < rowEnd) ? bandRows : rowEnd - y0;
+        tls.bytesUp += (uint64_t)pixelRowBytes * rows, tls.bytesDown += (uint64_t)pixelRowBytes * rows;
         const int e = band % Context::kMaxBands;
         HIP_TRY(hipMemcpy2DAsync(view.pixels + (size_t)y0 * view.rowBytes, view.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes, rows,
                                  hipMemcpyHostToDevice, tls.upStream));
@@ -211,6 +257,30 @@ static avifResult inPlaceBanded(avifRGBImage * rgb, uint32_t pixelRowBytes, Laun
         HIP_TRY(hipStreamSynchronize(tls.downStream));
     }
     return AVIF_RESULT_OK;
+}
+
+// ... over the whole image: on the calling thread's device, or in row shares over the device set (api_farm.cpp; every row is independent)
+template <class Launch>
+static avifResult inPlaceBanded(avifRGBImage * rgb, uint32_t pixelRowBytes, Launch launch)
+{
+    const uint32_t workers = farmWorkers();
+    if (workers >= 2) {
+        const std::vector<FarmShare> shares = planFarmRows(rgb->width, rgb->height, workers);
+        if (shares.size() >= 2) {
+            struct Call
+            {
+                avifRGBImage * rgb;
+                uint32_t pixelRowBytes;
+                Launch * launch;
+            } call = { rgb, pixelRowBytes, &launch };
+            return farmRun(shares, [](void * arg, uint32_t, FarmShare share) -> avifResult {
+                const Call & c = *static_cast<const Call *>(arg);
+                return inPlaceBandedRows(c.rgb, c.pixelRowBytes, *c.launch, share.begin, share.end);
+            }, &call);
+        }
+    }
+    tls.farmReports.clear();
+    return inPlaceBandedRows(rgb, pixelRowBytes, launch, 0, rgb->height);
 }
 
 static avifResult alphaMulSync(avifRGBImage * rgb, bool unmultiply)
@@ -266,6 +336,7 @@ extern "C" avifResult avifhipRGBImageToF16(avifRGBImage * rgb)
         const hipError_t e = launchToF16Generic(view.pixels + (size_t)y0 * view.rowBytes, view.rowBytes, view.width * channels, rows, multiplier, stream);
         if (e != hipSuccess)
             return hipFailed(e, "half-float kernel launch");
+        tls.lastKernel = "to_f16_generic"; // (a farm worker's own context: the caller's is filled in from it)
         ++tls.launches;
         return AVIF_RESULT_OK;
     });

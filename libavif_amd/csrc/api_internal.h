@@ -159,7 +159,16 @@ struct Context
     const char * lastKernel = "";
     uint64_t launches = 0; // kernels enqueued by this thread
     uint64_t tableUploads = 0; // batch tables sent to the device by this thread
-    uint64_t bytesUp = 0, bytesDown = 0; // host link traffic of the last avifhipImageYUVToRGBRects call
+    uint64_t bytesUp = 0, bytesDown = 0; // host link traffic of the thread's last host-resident conversion (avifhipLastTransferBytes)
+    char lastKernelText[128] = { 0 };    // a farmed call's kernel name, copied from the worker that ran it (lastKernel may point here)
+    // the last farmed call of this thread: one entry per worker that took part (avifhipLastFarmWorkers / avifhipLastFarmTransferBytes)
+    struct FarmReport
+    {
+        int device;
+        uint32_t rowBegin, rowEnd; // the worker's share (rows of the image; rectangles: indices of the coalesced job list)
+        uint64_t bytesUp, bytesDown;
+    };
+    std::vector<FarmReport> farmReports;
 
     ~Context()
     {
@@ -301,6 +310,27 @@ void finishRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, RgbTo
 bool sharpYuvRequested(const avifImage * image, const avifRGBImage * rgb);
 // row bands of a host-resident call (api_decode.cpp: yuvToRgbSync): rows per band -- multiples of 32 rows, at least ~2 megapixels each
 uint32_t bandRowsFor(uint32_t width, uint32_t height);
+
+// ---- the in-process device farm (api_farm.cpp; SURVEY.md 8e: one host thread + streams + staging per GPU) ----
+// A host-resident call whose image is large enough is cut into contiguous row shares, one per worker of the device set
+// (avifhipSetDeviceSet / AVIFHIP_DEVICES); every worker is a persistent thread with a pooled context of its own on its device, uploads only
+// what its share needs (its rows plus the chroma filter's halo row either side -- uploaded, not exchanged), converts with the ordinary banded
+// path and downloads its rows over its own host link.  No device talks to another.
+struct FarmShare
+{
+    uint32_t begin, end; // rows [begin, end) of the image, or entries of a job list
+};
+// contiguous shares of `height` rows for at most `workers` workers: multiples of 32 rows (whole tiles of the tiled kernels, even rows for
+// subsampled chroma), at least ~2 megapixels each (below that a second device costs more than it brings); one share = not farmed
+std::vector<FarmShare> planFarmRows(uint32_t width, uint32_t height, uint32_t workers);
+// contiguous blocks of a list of `count` jobs (libavif_amd/farm.py: shard -- the first count % workers blocks are one longer)
+std::vector<FarmShare> planFarmJobs(uint32_t count, uint32_t workers);
+// number of workers of the current device set (0 or 1: calls run on the calling thread's own device as ever)
+uint32_t farmWorkers();
+// Runs job(k, shares[k]) on worker k for every share and waits for all of them.  The result is the first failure in share order (its error text
+// becomes the calling thread's), AVIF_RESULT_OK otherwise; the calling thread's launch count, transfer bytes, kernel name and farm report are
+// updated from the workers'.
+avifResult farmRun(const std::vector<FarmShare> & shares, avifResult (*job)(void * arg, uint32_t worker, FarmShare share), void * arg);
 // leaves no download running into the caller's memory when a banded call returns early
 struct DrainOnExit
 {

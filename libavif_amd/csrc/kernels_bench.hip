@@ -7,6 +7,8 @@
 
 #include "api_internal.h"
 
+#include <vector>
+
 namespace avifhip {
 namespace {
 
@@ -79,6 +81,236 @@ bool launchCeiling(const avifImage * image, const avifRGBImage * rgb, int patter
     return hipGetLastError() == hipSuccess;
 }
 
+
+// ---- the general mover (round 5): any plane layout of the tiled kernels, both directions, single jobs and batches --------------------------
+// What a conversion of the job's shape has to move and nothing else: every sample of every plane the conversion reads (or writes) once, every
+// pixel byte written (or read) once, lane = 4 pixels of every row of its wave, plane accesses of 4 samples per lane, pixel accesses of 16 bytes
+// per lane at consecutive addresses (a wave instruction covers 1 KiB of a row), streaming stores -- the tiled kernels' own access shapes
+// (tile_impl.h store4WideRgba, r2y_tile_impl.h loadStrip).  The bytes written are a mix of the bytes read, so that nothing can be elided.
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+// four consecutive samples of a plane row: one 4-byte (8-bit samples) or 8-byte (16-bit containers) access, like tile_impl.h load4
+template <int YB>
+__device__ __forceinline__ void moveLoad4(const uint8_t * p, unsigned (&w)[YB])
+{
+    if constexpr (YB == 1) {
+        w[0] = *reinterpret_cast<const unsigned *>(p);
+    } else {
+        const u2 t = *reinterpret_cast<const u2 *>(p);
+        w[0] = t.x, w[1] = t.y;
+    }
+}
+template <int YB>
+__device__ __forceinline__ void moveStore4(uint8_t * p, const unsigned (&w)[YB], unsigned salt)
+{
+    if constexpr (YB == 1)
+        __builtin_nontemporal_store(w[0] ^ salt, reinterpret_cast<unsigned *>(p));
+    else
+        __builtin_nontemporal_store((u2) { w[0] ^ salt, w[1] + salt }, reinterpret_cast<u2 *>(p));
+}
+struct MoveJob
+{
+    const uint8_t * plane[4]; // Y, U, V, A; nullptr = absent (A: not read by the conversion)
+    uint8_t * pixels;
+    uint32_t planePitch[4], pixelPitch;
+    uint32_t w4, h2;
+};
+
+template <int YB, int PB, int WAVES_X, int RPW, bool BANDED, bool TO_RGB>
+__global__ __launch_bounds__(256) void streamMoveKernel(const MoveJob * __restrict__ jobs, uint32_t subX, uint32_t subY, uint32_t tilesX, uint32_t tilesPerJob)
+{
+    constexpr int WAVES_Y = 4 / WAVES_X;
+    constexpr int VEC = PB / 4; // 16-byte pieces of a lane's 4 pixels
+    const MoveJob J = jobs[blockIdx.y];
+    const uint32_t tile = BANDED ? bandedTile(blockIdx.x, gridDim.x) : blockIdx.x;
+    if (tile >= tilesPerJob)
+        return;
+    const uint32_t trow = tile / tilesX, tcol = tile - trow * tilesX;
+    const uint32_t wave = threadIdx.y, wx = wave % WAVES_X, wy = wave / WAVES_X;
+    const uint32_t band = tcol * WAVES_X + wx;
+    const uint32_t X = band * 256u + 4u * threadIdx.x;
+    const uint32_t Y0 = (trow * WAVES_Y + wy) * RPW;
+    if (band * 256u >= J.w4 || Y0 >= J.h2)
+        return;
+    const bool laneValid = X < J.w4;
+    const uint32_t Xc = laneValid ? X : 0u;
+    const bool hasC = J.plane[1] != nullptr, hasA = J.plane[3] != nullptr;
+    // lane l of pixel-store instruction h covers bytes [1024 * h + 16 * l, + 16) of the wave's row segment (4 * PB * 64 bytes)
+    const uint32_t segBytes = (J.w4 - band * 256u < 256u ? J.w4 - band * 256u : 256u) * PB;
+    if constexpr (TO_RGB) {
+        unsigned ly[RPW][YB], lc[RPW][2][YB], la[RPW][YB];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const uint32_t Y = Y0 + r < J.h2 ? Y0 + r : J.h2 - 1;
+            moveLoad4<YB>(J.plane[0] + (size_t)Y * J.planePitch[0] + (size_t)Xc * YB, ly[r]);
+#pragma unroll
+            for (int k = 0; k < YB; ++k)
+                la[r][k] = lc[r][0][k] = lc[r][1][k] = 0;
+            if (hasA)
+                moveLoad4<YB>(J.plane[3] + (size_t)Y * J.planePitch[3] + (size_t)Xc * YB, la[r]);
+            if (hasC && (!subY || !(r & 1))) { // (RPW is even and Y0 a multiple of it: r even <=> Y even)
+                const uint32_t cy = Y >> subY;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const uint8_t * row = J.plane[1 + c] + (size_t)cy * J.planePitch[1 + c] + (size_t)(Xc >> subX) * YB;
+                    if (subX) {
+                        if constexpr (YB == 1)
+                            lc[r][c][0] = *reinterpret_cast<const uint16_t *>(row);
+                        else
+                            lc[r][c][0] = *reinterpret_cast<const unsigned *>(row);
+                    } else {
+                        moveLoad4<YB>(row, lc[r][c]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            if (Y0 + r >= J.h2)
+                break;
+            const int rc = subY ? (r & ~1) : r;
+            unsigned mix = 0;
+#pragma unroll
+            for (int k = 0; k < YB; ++k)
+                mix ^= ly[r][k] ^ la[r][k] ^ lc[rc][0][k] ^ (lc[rc][1][k] << 8);
+            uint8_t * rowPx = J.pixels + (size_t)(Y0 + r) * J.pixelPitch + (size_t)band * 256u * PB;
+#pragma unroll
+            for (int h = 0; h < VEC; ++h) {
+                const uint32_t byte = 1024u * h + 16u * threadIdx.x;
+                if (byte < segBytes) {
+                    const u4 o = { mix, mix + (unsigned)h, mix ^ 0x5a5a5a5au, mix + threadIdx.x };
+                    __builtin_nontemporal_store(o, reinterpret_cast<u4 *>(rowPx + byte));
+                }
+            }
+        }
+    } else {
+        u4 px[RPW][VEC];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const uint32_t Y = Y0 + r < J.h2 ? Y0 + r : J.h2 - 1;
+            const uint8_t * rowPx = J.pixels + (size_t)Y * J.pixelPitch + (size_t)band * 256u * PB;
+#pragma unroll
+            for (int h = 0; h < VEC; ++h) {
+                const uint32_t byte = 1024u * h + 16u * threadIdx.x;
+                px[r][h] = *reinterpret_cast<const u4 *>(rowPx + (byte < segBytes ? byte : 0u));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            if (Y0 + r >= J.h2 || !laneValid)
+                break;
+            unsigned mix[YB];
+#pragma unroll
+            for (int k = 0; k < YB; ++k) {
+                mix[k] = 0;
+#pragma unroll
+                for (int h = 0; h < VEC; ++h)
+                    mix[k] ^= px[r][h][k] ^ px[r][h][2 + k % 2];
+            }
+            const uint32_t Y = Y0 + r;
+            moveStore4<YB>(const_cast<uint8_t *>(J.plane[0]) + (size_t)Y * J.planePitch[0] + (size_t)X * YB, mix, 0u);
+            if (hasA)
+                moveStore4<YB>(const_cast<uint8_t *>(J.plane[3]) + (size_t)Y * J.planePitch[3] + (size_t)X * YB, mix, 0xffu);
+            if (hasC && (!subY || !(r & 1))) {
+                const unsigned both = subY ? (mix[0] ^ px[r | 1][0][1]) : mix[0]; // 4:2:0: a chroma row is made of two pixel rows
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    uint8_t * row = const_cast<uint8_t *>(J.plane[1 + c]) + (size_t)(Y >> subY) * J.planePitch[1 + c] + (size_t)(X >> subX) * YB;
+                    if (subX) {
+                        if constexpr (YB == 1)
+                            __builtin_nontemporal_store((uint16_t)(both >> (8 * c)), reinterpret_cast<uint16_t *>(row));
+                        else
+                            __builtin_nontemporal_store(both + (unsigned)c, reinterpret_cast<unsigned *>(row));
+                    } else {
+                        moveStore4<YB>(row, mix, 1u + (unsigned)c);
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct MoveShape
+{
+    int yb, pb;
+    uint32_t subX, subY;
+    uint32_t maxW4, maxH2;
+};
+
+// Fills `job` from an image / pixel pair; false when the pair is outside what the mover covers (the tiled kernels' own alignment rules).
+// `alphaRead`: the conversion touches the alpha plane (TO_RGB: the plan reads it; encode: it writes one when the pixels carry alpha).
+bool moveJobOf(const avifImage * image, const avifRGBImage * rgb, bool toRgb, MoveJob * job, MoveShape * shape)
+{
+    if (!image || !rgb || !image->yuvPlanes[0] || !rgb->pixels || rgb->format == AVIF_RGB_FORMAT_RGB_565)
+        return false;
+    const int yb = image->depth > 8 ? 2 : 1, nch = rgbFormatChannelCount((int)rgb->format), pb = nch * (rgb->depth > 8 ? 2 : 1);
+    if (pb != 4 && pb != 8)
+        return false;
+    const bool has444 = image->yuvFormat == AVIF_PIXEL_FORMAT_YUV444, has400 = image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400;
+    const uint32_t subX = (has444 || has400) ? 0u : 1u, subY = image->yuvFormat == AVIF_PIXEL_FORMAT_YUV420 ? 1u : 0u;
+    memset(job, 0, sizeof(*job));
+    job->plane[0] = image->yuvPlanes[0], job->planePitch[0] = image->yuvRowBytes[0];
+    if (!has400) {
+        if (!image->yuvPlanes[1] || !image->yuvPlanes[2])
+            return false;
+        for (int c = 1; c <= 2; ++c)
+            job->plane[c] = image->yuvPlanes[c], job->planePitch[c] = image->yuvRowBytes[c];
+    }
+    const bool pixelsCarryAlpha = nch == 4 && !rgb->ignoreAlpha;
+    if (image->alphaPlane && image->alphaRowBytes && pixelsCarryAlpha)
+        job->plane[3] = image->alphaPlane, job->planePitch[3] = image->alphaRowBytes;
+    job->pixels = rgb->pixels, job->pixelPitch = rgb->rowBytes;
+    job->w4 = image->width & ~3u, job->h2 = image->height & ~1u;
+    if (!job->w4 || !job->h2 || ((uintptr_t)rgb->pixels & 15u) || (rgb->rowBytes & 15u))
+        return false;
+    for (int p = 0; p < 4; ++p) {
+        if (!job->plane[p])
+            continue;
+        const uint32_t need = (p == 1 || p == 2) ? ((4u >> subX) * (uint32_t)yb) : 4u * (uint32_t)yb;
+        if (((uintptr_t)job->plane[p] % need) || (job->planePitch[p] % need))
+            return false;
+    }
+    if (shape->yb && (shape->yb != yb || shape->pb != pb || shape->subX != subX || shape->subY != subY))
+        return false; // all jobs of a call share one shape
+    shape->yb = yb, shape->pb = pb, shape->subX = subX, shape->subY = subY;
+    shape->maxW4 = job->w4 > shape->maxW4 ? job->w4 : shape->maxW4, shape->maxH2 = job->h2 > shape->maxH2 ? job->h2 : shape->maxH2;
+    return true;
+}
+
+constexpr int kMovePatterns = 4;
+const char * const kMovePatternName[kMovePatterns] = { "1024x2 raster", "256x16 per-XCD bands", "1024x4 raster", "256x32 per-XCD bands" };
+
+template <int YB, int PB, bool TO_RGB>
+void launchMove(int pattern, const MoveJob * deviceJobs, uint32_t jobs, const MoveShape & s, hipStream_t stream)
+{
+    auto go = [&](auto kernel, uint32_t wavesX, uint32_t rpw) {
+        const uint32_t wavesY = 4u / wavesX;
+        const uint32_t tilesX = (s.maxW4 + 256u * wavesX - 1) / (256u * wavesX), tilesY = (s.maxH2 + rpw * wavesY - 1) / (rpw * wavesY);
+        hipLaunchKernelGGL(kernel, dim3(tilesX * tilesY, jobs), dim3(64, 4), 0, stream, deviceJobs, s.subX, s.subY, tilesX, tilesX * tilesY);
+    };
+    switch (pattern) {
+        case 0: go(streamMoveKernel<YB, PB, 4, 2, false, TO_RGB>, 4, 2); break;
+        case 1: go(streamMoveKernel<YB, PB, 1, 4, true, TO_RGB>, 1, 4); break;
+        case 2: go(streamMoveKernel<YB, PB, 4, 4, false, TO_RGB>, 4, 4); break;
+        default: go(streamMoveKernel<YB, PB, 1, 8, true, TO_RGB>, 1, 8); break;
+    }
+}
+
+bool launchMoveShape(int pattern, bool toRgb, const MoveJob * deviceJobs, uint32_t jobs, const MoveShape & s, hipStream_t stream)
+{
+    if (toRgb) {
+        if (s.yb == 1)
+            s.pb == 4 ? launchMove<1, 4, true>(pattern, deviceJobs, jobs, s, stream) : launchMove<1, 8, true>(pattern, deviceJobs, jobs, s, stream);
+        else
+            s.pb == 4 ? launchMove<2, 4, true>(pattern, deviceJobs, jobs, s, stream) : launchMove<2, 8, true>(pattern, deviceJobs, jobs, s, stream);
+    } else {
+        if (s.yb == 1)
+            s.pb == 4 ? launchMove<1, 4, false>(pattern, deviceJobs, jobs, s, stream) : launchMove<1, 8, false>(pattern, deviceJobs, jobs, s, stream);
+        else
+            s.pb == 4 ? launchMove<2, 4, false>(pattern, deviceJobs, jobs, s, stream) : launchMove<2, 8, false>(pattern, deviceJobs, jobs, s, stream);
+    }
+    return hipGetLastError() == hipSuccess;
+}
+
 } // namespace
 } // namespace avifhip
 
@@ -109,14 +341,97 @@ static double timeCeilingPattern(uint32_t count, const avifImage * const * image
     return ms < 0 ? -1.0 : (double)ms / iters;
 }
 
+// the general mover over `groups` launches' worth of jobs, `perLaunch` jobs each (launch k moves group k % groups): the fastest of its patterns
+static double timeMover(const std::vector<MoveJob> & jobs, uint32_t groups, uint32_t perLaunch, const MoveShape & shape, bool toRgb, int warmup, int iters, hipStream_t stream)
+{
+    MoveJob * deviceJobs = nullptr;
+    if (hipMalloc(&deviceJobs, jobs.size() * sizeof(MoveJob)) != hipSuccess || hipMemcpy(deviceJobs, jobs.data(), jobs.size() * sizeof(MoveJob), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        if (deviceJobs)
+            (void)hipFree(deviceJobs);
+        return -1.0;
+    }
+    double best = -1.0;
+    int bestPattern = -1;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool ok = hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess;
+    for (int pattern = 0; ok && pattern < kMovePatterns; ++pattern) {
+        for (int k = 0; ok && k < warmup; ++k)
+            ok = launchMoveShape(pattern, toRgb, deviceJobs + (size_t)(k % groups) * perLaunch, perLaunch, shape, stream);
+        ok = ok && hipEventRecord(t0, stream) == hipSuccess;
+        for (int k = 0; ok && k < iters; ++k)
+            ok = launchMoveShape(pattern, toRgb, deviceJobs + (size_t)(k % groups) * perLaunch, perLaunch, shape, stream);
+        float ms = -1.0f;
+        ok = ok && hipEventRecord(t1, stream) == hipSuccess && hipEventSynchronize(t1) == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess;
+        if (ok && (best < 0 || ms / iters < best))
+            best = (double)ms / iters, bestPattern = pattern;
+    }
+    if (t0)
+        (void)hipEventDestroy(t0);
+    if (t1)
+        (void)hipEventDestroy(t1);
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(deviceJobs);
+    if (!ok) {
+        (void)hipGetLastError();
+        return -1.0;
+    }
+    static thread_local char name[96];
+    snprintf(name, sizeof(name), "stream_ceiling<%s,%s,%s>", toRgb ? "planes->pixels" : "pixels->planes", perLaunch > 1 ? "batch" : "single", kMovePatternName[bestPattern]);
+    tls.lastKernel = name;
+    return best;
+}
+
+static double timeCeilingGeneral(uint32_t count, const avifImage * const * images, const avifRGBImage * const * rgbs, bool toRgb, bool batch, int warmup, int iters, void * hipStream)
+{
+    if (iters <= 0 || count == 0 || !images || !rgbs || ensureContext() != AVIF_RESULT_OK)
+        return -1.0;
+    std::vector<MoveJob> jobs(count);
+    MoveShape shape;
+    memset(&shape, 0, sizeof(shape));
+    for (uint32_t k = 0; k < count; ++k) {
+        if (!moveJobOf(images[k], rgbs[k], toRgb, &jobs[k], &shape)) {
+            setError("avifhipTimeStreamCeiling*: job %u is outside the mover's shapes (4- or 8-byte pixels, planes and pixels aligned like the tiled kernels ask, one shape per call)", k);
+            return -1.0;
+        }
+        if (toRgb && jobs[k].plane[3]) {
+            // the conversion reads the alpha plane only when the plan says so (alpha into the pixels, or pending alpha arithmetic)
+            YuvToRgbPlan plan;
+            if (makeYuvToRgbPlan(images[k], rgbs[k], nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan) != AVIF_RESULT_OK)
+                return -1.0;
+            if (!(plan.alphaSource == ALPHA_PLANE || plan.inLoopMul != MUL_NONE || plan.postMul != MUL_NONE))
+                jobs[k].plane[3] = nullptr;
+        }
+    }
+    return batch ? timeMover(jobs, 1, count, shape, toRgb, warmup, iters, pickStream(hipStream)) : timeMover(jobs, count, 1, shape, toRgb, warmup, iters, pickStream(hipStream));
+}
+
 extern "C" double avifhipTimeStreamCeiling(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream)
 {
     if (iters <= 0 || count == 0 || !images || !rgbs || ensureContext() != AVIF_RESULT_OK)
         return -1.0;
     hipStream_t stream = pickStream(hipStream);
+    // 8-bit 4:2:0 planes into 4-byte pixels without an alpha plane: the headline's shape keeps rounds 2-4's kernel (comparable figures)
+    bool headlineShape = true;
+    for (uint32_t k = 0; k < count && headlineShape; ++k)
+        headlineShape = images[k] && rgbs[k] && images[k]->depth == 8 && images[k]->yuvFormat == AVIF_PIXEL_FORMAT_YUV420 && rgbs[k]->depth == 8 &&
+                        rgbFormatChannelCount((int)rgbs[k]->format) == 4 && !(images[k]->alphaPlane && !rgbs[k]->ignoreAlpha);
+    if (!headlineShape)
+        return timeCeilingGeneral(count, images, rgbs, true, false, warmup, iters, hipStream);
     const double a = timeCeilingPattern(count, images, rgbs, warmup, iters, 0, stream);
     const double b = timeCeilingPattern(count, images, rgbs, warmup, iters, 1, stream);
     if (a < 0 || b < 0)
         return -1.0;
+    tls.lastKernel = a < b ? "stream_ceiling<planes->pixels,single,1024x2 raster>" : "stream_ceiling<planes->pixels,single,256x16 per-XCD bands>";
     return a < b ? a : b;
+}
+
+extern "C" double avifhipTimeStreamCeilingRGBToYUV(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream)
+{
+    return timeCeilingGeneral(count, images, rgbs, false, false, warmup, iters, hipStream);
+}
+
+extern "C" double avifhipTimeStreamCeilingBatch(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream)
+{
+    return timeCeilingGeneral(count, images, rgbs, true, true, warmup, iters, hipStream);
 }

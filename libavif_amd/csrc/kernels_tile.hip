@@ -319,6 +319,9 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     L.stream = stream;
     L.shiftStrips = 0;
     L.mapped = k.mapped, L.transposed = k.mapped && plan.rgb.map.transposed, L.streamLoads = false;
+    // single images: plain loads (profiles/r02_stream_single_ab.txt: a frame converted again and again finds part of itself in the Infinity
+    // Cache) unless TUNE_STREAM_LOADS asks the unfiltered 16-bit families for streaming ones (A/B measurements: tests/tools/stream_sweep.py)
+    L.streamLoads = (plan.tuning & TUNE_STREAM_LOADS) != 0;
     decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)A.w4 * A.h2) || (plan.tuning & TUNE_SOLO_ALWAYS));
     L.pkWide = (plan.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift, L.attenuate = k.attenuate;
@@ -392,8 +395,9 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
     L.mapped = k.mapped, L.transposed = k.mapped && representative.rgb.map.transposed;
     // (upper bound from the largest job: batches are made of equally sized tiles)
     L.streamLoads = (double)maxW * maxH * count * planeBytesPerPixel(representative, k) > kStreamPlaneBytes;
-    if (const char * e = getenv("AVIFHIP_STREAM_LOADS")) // diagnostics / A-B measurements only
-        L.streamLoads = atoi(e) != 0;
+    if (const char * e = getenv("AVIFHIP_STREAM_LOADS")) // diagnostics / A-B measurements only; exactly "1" or "0"
+        if ((e[0] == '0' || e[0] == '1') && !e[1])
+            L.streamLoads = e[0] == '1';
     decompose(representative.tuning, maxW & ~3u, maxH & ~1u, count, true, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)(maxW & ~3u) * (maxH & ~1u) * count) || (representative.tuning & TUNE_SOLO_ALWAYS));
     L.pkWide = (representative.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift, L.attenuate = k.attenuate;

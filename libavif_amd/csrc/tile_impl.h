@@ -1591,15 +1591,17 @@ __device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2
     computeTile<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, 1, MAP_NONE, MULSEL>(A, c, tileY, raw, rows, xchg ? xchg + wave : nullptr);
 }
 
-template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, int MULSEL = 0>
+// (STREAM: single images of 16-bit planes too large for the Infinity Cache -- 8K 4:4:4 + alpha is 265 MB of planes -- may take streaming
+//  loads: kernels_tile.hip launchYuvToRgbTile)
+template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, int MULSEL = 0, bool STREAM = false>
 __global__ __launch_bounds__(256) void yuvToRgbTileSoloKernel(TileArgs A, PkGeom g)
 {
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, false, MULSEL>(A, g, lds, xchg);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(A, g, lds, xchg);
     } else {
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, false, MULSEL>(A, g, lds, nullptr);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(A, g, lds, nullptr);
     }
 }
 
@@ -1765,6 +1767,13 @@ hipError_t launchSoloSel(const TileLaunch & L, uint32_t nsw, const PkGeom & g, d
             hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, false, MULSEL>), grid, block, 0, L.stream, L.table, g);
         else
             hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, false, MULSEL>), grid, block, 0, L.stream, L.table, g);
+    } else if (L.streamLoads && sizeof(YT) == 2 && !BIL) {
+        if constexpr (sizeof(YT) == 2 && !BIL) {
+            if (nsw == 4)
+                AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, MULSEL, true>), grid, block, 0, L.stream, *L.args, g);
+            else
+                AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, MULSEL, true>), grid, block, 0, L.stream, *L.args, g);
+        }
     } else {
         if (nsw == 4)
             AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, MULSEL>), grid, block, 0, L.stream, *L.args, g);

@@ -25,8 +25,9 @@ EXPORTED_SYMBOLS = [
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
-    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipTimeRGBToYUVCycle", "avifhipTimeYUVToRGBBatch", "avifhipTimeGridYUVToRGB", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipTableUploadCount", "avifhipCalcYUVCoefficients",
+    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipTimeStreamCeilingRGBToYUV", "avifhipTimeStreamCeilingBatch", "avifhipTimeRGBToYUVCycle", "avifhipTimeYUVToRGBBatch", "avifhipTimeGridYUVToRGB", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipTableUploadCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
+    "avifhipSetDeviceSet", "avifhipSetFarmMinSharePixels", "avifhipGetDeviceSet", "avifhipPlanFarmRows", "avifhipLastFarmWorkers", "avifhipLastFarmTransferBytes",
     "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipTimeRGBImageApplyGainMap", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap",
 ]
 
@@ -110,6 +111,14 @@ def load() -> C.CDLL:
         "avifhipPlanRectTransfers": (i32, [P_IMG, P_RGB, P_RECT, u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "avifhipLastTransferBytes": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "avifhipTimeStreamCeiling": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
+        "avifhipTimeStreamCeilingRGBToYUV": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
+        "avifhipTimeStreamCeilingBatch": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
+        "avifhipSetDeviceSet": (i32, [C.POINTER(C.c_int), u32]),
+        "avifhipGetDeviceSet": (u32, [C.POINTER(C.c_int), u32]),
+        "avifhipSetFarmMinSharePixels": (None, [C.c_uint64]),
+        "avifhipPlanFarmRows": (i32, [u32, u32, u32, P_RECT, u32, C.POINTER(u32)]),
+        "avifhipLastFarmWorkers": (u32, []),
+        "avifhipLastFarmTransferBytes": (i32, [u32, C.POINTER(C.c_int), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "avifhipExplainYUVToRGB": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
         "avifhipExplainRGBToYUV": (i32, [P_IMG, P_RGB, C.c_char_p, C.c_size_t]),
         "avifhipRGBImageTransformAsync": (i32, [P_RGB, P_RGB, P_RECT, i32, C.c_uint8, i32, C.c_uint8, vp]),

@@ -1,0 +1,150 @@
+"""The BASELINE configurations that stream (working set beyond the 256 MB Infinity Cache) under the result-preserving tuning knobs, with the
+byte-movement ceiling of each shape beside them -- ONE process, one box, so that the rows compare (boxes differ by +-6 %).
+    python tests/tools/stream_sweep.py [cfg3 cfg4 cfg5x64 cfg5grid cfg2cold cfg2cold_fp32 ...]
+Each row: configuration, knob, microseconds per launch (median of 7 event-timed bursts of 30 after 30 ms of the same launches), fraction of
+8 TB/s on the algorithmic bytes.  Knobs: plan.h TuningBits through avifhipSetTuning (bit 0 per-XCD bands, bits 8-11 strips
+per wave, bits 16-17 1 + log2(waves side by side), bits 20-23 tile rows per XCD chunk), AVIFHIP_STREAM_LOADS, AVIFHIP_R2Y_SPW."""
+import ctypes as C
+import json
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from libavif_amd import abi, device, native, synth  # noqa: E402
+
+if os.environ.get("AVIFHIP_BENCH_LIB"):
+    native.LIB_PATH = Path(os.environ["AVIFHIP_BENCH_LIB"]).resolve()
+lib = native.load()
+BIL = abi.AVIF_CHROMA_UPSAMPLING_BILINEAR
+PEAK = 8000.0
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def burst(fn, *a, iters=30):
+    spent = 0.0
+    while spent < 30.0:
+        ms = fn(*a, 0, 50, None)
+        if ms < 0:
+            raise SystemExit("timing call failed: " + lib.avifhipLastError().decode())
+        spent += max(ms, 1e-3) * 50
+    return median([fn(*a, 2, iters, None) for _ in range(7)])
+
+
+def emit(cfg, knob, ms, alg_bytes, **extra):
+    gb = alg_bytes / (ms * 1e-3) / 1e9
+    print(json.dumps({"config": cfg, "knob": knob, "us": round(ms * 1e3, 2), "frac": round(gb / PEAK, 4), "kernel": native.last_kernel(), **extra}), flush=True)
+
+
+def arr(pairs):
+    n = len(pairs)
+    return n, (C.POINTER(abi.avifImage) * n)(*[C.pointer(q[0].struct) for q in pairs]), (C.POINTER(abi.avifRGBImage) * n)(*[C.pointer(q[1].struct) for q in pairs])
+
+
+def y2r(w, h, depth, fmt, rng, mc, rgb_depth, alpha=False, premult=False, avoid=False, seed=1):
+    img = abi.make_yuv(w, h, depth, fmt, rng, mc, with_alpha=alpha)
+    synth.fill_yuv(img, 0x12345678 + seed)
+    rgb = abi.make_rgb(w, h, rgb_depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, alpha_premultiplied=premult, avoid_libyuv=avoid, allocate=False)
+    return device.DeviceYUV(img), device.DeviceRGB(rgb)
+
+
+TUNINGS = [("default", 0x1), ("raster", 0x0), ("bands,2 strips", 0x201), ("bands,4 strips", 0x401), ("raster,2 strips", 0x200), ("raster,4 strips", 0x400),
+           ("raster,4 waves wide,2 strips", 0x30200), ("raster,4 waves wide,4 strips", 0x30400), ("raster,2 waves wide,2 strips", 0x20200),
+           ("bands,4 waves wide,2 strips", 0x30201), ("bands,2 rows/chunk", 0x200001), ("bands,4 rows/chunk", 0x400001),
+           ("default + streaming loads (single 16-bit unfiltered)", 0x41), ("raster + streaming loads", 0x40), ("raster,4 waves wide,2 strips + streaming loads", 0x30240),
+           ("plain stores off: nt bit", 0x3)]
+
+
+def sweep_y2r(cfg, pairs, alg_bytes, tunings=TUNINGS, stream_env=True):
+    n, imgs, rgbs = arr(pairs)
+    ms = burst(lib.avifhipTimeStreamCeiling, n, imgs, rgbs)
+    emit(cfg, "ceiling", ms, alg_bytes)
+    for name, bits in tunings:
+        lib.avifhipSetTuning(bits)
+        emit(cfg, name, burst(lib.avifhipTimeYUVToRGBCycle, n, imgs, rgbs), alg_bytes, tuning=hex(bits))
+    lib.avifhipSetTuning(1)
+    if stream_env:
+        for v in ("1", "0"):
+            os.environ["AVIFHIP_STREAM_LOADS"] = v
+            emit(cfg, "AVIFHIP_STREAM_LOADS=" + v, burst(lib.avifhipTimeYUVToRGBCycle, n, imgs, rgbs), alg_bytes)
+        del os.environ["AVIFHIP_STREAM_LOADS"]
+
+
+def run(name):
+    lib.avifhipSetArithmetic(0)
+    lib.avifhipSetTuning(1)
+    if name == "cfg3":
+        pairs = [y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, seed=k) for k in range(2)]
+        sweep_y2r("cfg3 (2 frames cycled)", pairs, 16.0 * 7680 * 4320)
+    elif name in ("cfg2cold", "cfg2cold_fp32"):
+        pairs = [y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=name.endswith("fp32"), seed=k) for k in range(12)]
+        sweep_y2r(name + " (12 frames cycled)", pairs, 5.5 * 7680 * 4320)
+    elif name == "cfg2_4k":
+        pairs = [y2r(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, seed=k) for k in range(4)]
+        sweep_y2r("cfg2_4k (4 frames cycled)", pairs, 5.5 * 3840 * 2160)
+    elif name == "cfg4":
+        enc = []
+        for k in range(8):
+            rgb = abi.make_rgb(3840, 2160, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+            synth.fill_rgb(rgb, 0x12345678 + k % 2, opaque=True)
+            img = abi.make_yuv(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, with_alpha=True)
+            enc.append((device.DeviceYUV(img, upload=False), device.DeviceRGB(rgb, upload=True)))
+        n, imgs, rgbs = arr(enc)
+        alg = 6.5 * 3840 * 2160
+        emit("cfg4 (8 frames cycled)", "ceiling", burst(lib.avifhipTimeStreamCeilingRGBToYUV, n, imgs, rgbs), alg)
+        emit("cfg4 (8 frames cycled)", "default", burst(lib.avifhipTimeRGBToYUVCycle, n, imgs, rgbs), alg)
+        for spw in ("1", "2", "4"):
+            os.environ["AVIFHIP_R2Y_SPW"] = spw
+            emit("cfg4 (8 frames cycled)", "AVIFHIP_R2Y_SPW=" + spw, burst(lib.avifhipTimeRGBToYUVCycle, n, imgs, rgbs), alg)
+        del os.environ["AVIFHIP_R2Y_SPW"]
+        emit("cfg4 (same frame)", "ceiling", burst(lib.avifhipTimeStreamCeilingRGBToYUV, 1, imgs, rgbs), alg)
+        emit("cfg4 (same frame)", "default", burst(lib.avifhipTimeRGBToYUV, enc[0][0].struct, enc[0][1].struct), alg)
+    elif name in ("cfg5x64", "cfg5grid", "cfg5grid8"):
+        depth = 8 if name.endswith("8") else 10
+        tiles = []
+        for t in range(64):
+            img = abi.make_yuv(1920, 1080, 10, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+            synth.fill_yuv(img, 0x12345678 + t)
+            tiles.append(device.DeviceYUV(img))
+        timgs = (C.POINTER(abi.avifImage) * 64)(*[C.pointer(t.struct) for t in tiles])
+        px = 64 * 1920 * 1080
+        alg = (3.0 + (8.0 if depth == 10 else 4.0)) * px
+        if name == "cfg5x64":
+            outs = [device.DeviceRGB(abi.make_rgb(1920, 1080, depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False)) for _ in range(64)]
+            rgbs = (C.POINTER(abi.avifRGBImage) * 64)(*[C.pointer(o.struct) for o in outs])
+            emit(name, "ceiling", burst(lib.avifhipTimeStreamCeilingBatch, 64, timgs, rgbs), alg)
+            for tname, bits in TUNINGS:
+                lib.avifhipSetTuning(bits)
+                emit(name, tname, burst(lib.avifhipTimeYUVToRGBBatch, 64, timgs, rgbs, None), alg, tuning=hex(bits))
+            lib.avifhipSetTuning(1)
+        else:
+            canvas = device.DeviceRGB(abi.make_rgb(15360, 8640, depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False))
+            pb = 8 if depth == 10 else 4
+            views = []
+            for t in range(64):
+                v = abi.make_rgb(1920, 1080, depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False)
+                v.struct.pixels = canvas.buffer.ptr + (t // 8) * 1080 * canvas.struct.rowBytes + (t % 8) * 1920 * pb
+                v.struct.rowBytes = canvas.struct.rowBytes
+                views.append(v)
+            rgbs = (C.POINTER(abi.avifRGBImage) * 64)(*[C.pointer(v.struct) for v in views])
+            emit(name, "ceiling", burst(lib.avifhipTimeStreamCeilingBatch, 64, timgs, rgbs), alg)
+            grid = native.avifhipGrid(8, 8, 15360, 8640)
+            for tname, bits in TUNINGS[:6]:
+                lib.avifhipSetTuning(bits)
+                emit(name, tname, burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas.struct), alg, tuning=hex(bits))
+            lib.avifhipSetTuning(1)
+            for v in ("1", "0"):
+                os.environ["AVIFHIP_GRID_SEAM_PASS"] = v
+                emit(name, "AVIFHIP_GRID_SEAM_PASS=" + v, burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas.struct), alg)
+            del os.environ["AVIFHIP_GRID_SEAM_PASS"]
+    else:
+        raise SystemExit("unknown configuration " + name)
+
+
+if __name__ == "__main__":
+    for n in sys.argv[1:] or ["cfg3", "cfg4", "cfg5x64", "cfg5grid"]:
+        run(n)
