@@ -392,7 +392,8 @@ AVIFHIP_API double avifhipTimeYUVToRGBCycle(uint32_t count, const avifImage * co
  * meaningless bytes), in the tiled kernels' own access shapes (4 samples per lane and plane row, 16 bytes of pixels per lane at
  * consecutive addresses, streaming stores).  Any plane layout (8-bit or 16-bit containers, 4:4:4 / 4:2:2 / 4:2:0 / 4:0:0, with or without
  * an alpha plane the conversion reads) into 4- or 8-byte pixels; all jobs of a call share one layout.  The fastest of the tile shapes /
- * orders the kernel knows (1024 x 2 and 1024 x 4 pixels in raster order, 256 x 16 and 256 x 32 in per-XCD bands) is reported;
+ * orders / load policies the kernel knows (1024 x 2, 1024 x 4, 512 x 4 and 256 x 8 pixels in raster order, 256 x 16 and 256 x 32 in per-XCD bands;
+ * plain and streaming loads) is reported;
  * avifhipLastKernel() then names it.  Negative for anything else (avifhipLastError() says why).
  *   avifhipTimeStreamCeiling          launch k moves job k % count (frames cycled, like avifhipTimeYUVToRGBCycle)
  *   avifhipTimeStreamCeilingRGBToYUV  the encode direction: pixels read, planes written (avifhipTimeRGBToYUVCycle)

@@ -345,6 +345,58 @@ avifResult reserve(Scratch & s, size_t bytes)
     return AVIF_RESULT_OK;
 }
 
+bool hostRowsWantOneBlock(const void * host, size_t hostPitch, size_t widthBytes, size_t rows)
+{
+    if ((((uintptr_t)host | hostPitch | widthBytes) & 3u) == 0)
+        return false; // the 2-D copy runs at link speed
+    return rows >= 8 && hostPitch >= widthBytes && hostPitch <= 2 * widthBytes + 256;
+}
+
+avifResult uploadRows(Scratch & raw, uint8_t * dev, size_t devPitch, const uint8_t * host, size_t hostPitch, size_t widthBytes, size_t rows, hipStream_t stream)
+{
+    if (!rows || !widthBytes)
+        return AVIF_RESULT_OK;
+    if ((devPitch & 3u) || ((uintptr_t)dev & 3u) || !hostRowsWantOneBlock(host, hostPitch, widthBytes, rows) || (hostPitch >> 32) || (devPitch >> 32) || (widthBytes >> 32) || (rows >> 32)) {
+        HIP_TRY(hipMemcpy2DAsync(dev, devPitch, host, hostPitch, widthBytes, rows, hipMemcpyHostToDevice, stream));
+        return AVIF_RESULT_OK;
+    }
+    const size_t bytes = (rows - 1) * hostPitch + widthBytes;
+    if (bytes > raw.capacity) {
+        // (grows with the first band of a call at most: the kernel that read the previous band's block runs on this very stream)
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (raw.ptr)
+            HIP_TRY(hipFree(raw.ptr));
+        raw.ptr = nullptr, raw.capacity = 0;
+        const size_t rounded = ((bytes + bytes / 8) + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        HIP_TRY(hipMalloc(&raw.ptr, rounded));
+        raw.capacity = rounded;
+    }
+    HIP_TRY(hipMemcpyAsync(raw.ptr, host, bytes, hipMemcpyHostToDevice, stream));
+    const PackArgs a = { (const uint8_t *)raw.ptr, dev, (uint32_t)hostPitch, (uint32_t)devPitch, (uint32_t)widthBytes, (uint32_t)rows, 0 };
+    const hipError_t e = launchUnpackRows(a, stream);
+    if (e != hipSuccess)
+        return hipFailed(e, "re-pitch of uploaded rows");
+    return AVIF_RESULT_OK;
+}
+
+bool packRowsForDownload(Scratch & raw, size_t rawOffset, const uint8_t * dev, size_t devPitch, uint8_t * host, size_t hostPitch, size_t widthBytes, size_t rows,
+                         hipStream_t stream, hipEvent_t after, CopyWorker::Job * job, avifResult * result)
+{
+    *result = AVIF_RESULT_OK;
+    if (hostPitch != widthBytes || !hostRowsWantOneBlock(host, hostPitch, widthBytes, rows) || !raw.ptr || rawOffset + widthBytes * rows > raw.capacity ||
+        (devPitch >> 32) || (widthBytes >> 32) || (rows >> 32))
+        return false;
+    uint8_t * block = (uint8_t *)raw.ptr + rawOffset;
+    const PackArgs a = { dev, block, (uint32_t)devPitch, (uint32_t)widthBytes, (uint32_t)widthBytes, (uint32_t)rows, 0 };
+    const hipError_t e = launchPackRows(a, stream);
+    if (e != hipSuccess) {
+        *result = hipFailed(e, "packing of rows for download");
+        return true;
+    }
+    *job = { after, host, widthBytes * rows, block, widthBytes * rows, widthBytes * rows, 1 }; // one "row": the whole block
+    return true;
+}
+
 bool isDevicePointer(const void * p)
 {
     if (!p)
@@ -402,7 +454,7 @@ avifResult enqueueRgbToYuv(const RgbToYuvPlan & plan, hipStream_t stream)
 {
     hipError_t e;
     if (gTiledKernels.load(std::memory_order_relaxed) && tileRgbToYuvSupported(plan)) {
-        e = launchRgbToYuvTile(plan, stream, &tls.lastKernel);
+        e = launchRgbToYuvTile(plan, stream, &tls.lastKernel, gTuning.load(std::memory_order_relaxed));
     } else {
         tls.lastKernel = (plan.arith == ARITH_LIBYUV) ? "rgb2yuv_fixed_generic" : "rgb2yuv_generic";
         e = launchRgbToYuvGeneric(plan, stream);

@@ -76,6 +76,11 @@ static avifResult yuvToRgbRows(const avifImage * image, avifRGBImage * rgb, bool
     if (banded && !tls.downloader)
         tls.downloader = new CopyWorker(tls.device, tls.downStream);
     DrainOnExit drainOnExit = { banded ? tls.downloader : nullptr };
+    if (pixelsOnHost && rgb->rowBytes == pixelRowBytes && hostRowsWantOneBlock(rgb->pixels, rgb->rowBytes, pixelRowBytes, rowEnd - rowBegin)) {
+        r = reserve(tls.rawDown[4], (size_t)pixelRowBytes * (rowEnd - rowBegin)); // (api_internal.h: packRowsForDownload)
+        if (r != AVIF_RESULT_OK)
+            return r;
+    }
     // chroma rows [.., chromaUploaded) that this call needs are on the device (or on their way, on upStream): a share that starts inside the
     // image begins one chroma row above its first (the 4:2:0 filter's upper neighbour)
     uint32_t chromaUploaded = subY ? ((rowBegin >> 1) ? (rowBegin >> 1) - 1 : 0) : rowBegin;
@@ -101,8 +106,9 @@ static avifResult yuvToRgbRows(const avifImage * image, avifRGBImage * rgb, bool
                 r1 = (r1 > g.rows[p] || y1 == image->height) ? g.rows[p] : r1;
             }
             if (r1 > r0) {
-                HIP_TRY(hipMemcpy2DAsync(dev + (size_t)r0 * devRowBytes, devRowBytes, host + (size_t)r0 * hostRowBytes, hostRowBytes, g.widthBytes[p], r1 - r0,
-                                         hipMemcpyHostToDevice, tls.upStream));
+                r = uploadRows(tls.rawUp[p], dev + (size_t)r0 * devRowBytes, devRowBytes, host + (size_t)r0 * hostRowBytes, hostRowBytes, g.widthBytes[p], r1 - r0, tls.upStream);
+                if (r != AVIF_RESULT_OK)
+                    return r;
                 tls.bytesUp += (uint64_t)g.widthBytes[p] * (r1 - r0);
                 uploaded = true;
             }
@@ -110,8 +116,10 @@ static avifResult yuvToRgbRows(const avifImage * image, avifRGBImage * rgb, bool
                 chromaUploaded = r1 > chromaUploaded ? r1 : chromaUploaded;
         }
         if (pixelsOnHost && keepsBytes) {
-            HIP_TRY(hipMemcpy2DAsync(rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes,
-                                     y1 - y0, hipMemcpyHostToDevice, tls.upStream));
+            r = uploadRows(tls.rawUp[4], rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes,
+                           y1 - y0, tls.upStream);
+            if (r != AVIF_RESULT_OK)
+                return r;
             tls.bytesUp += (uint64_t)pixelRowBytes * (y1 - y0);
             uploaded = true;
         }
@@ -134,9 +142,13 @@ static avifResult yuvToRgbRows(const avifImage * image, avifRGBImage * rgb, bool
         }
         // ---- down: by the helper thread (a pageable download blocks its caller), or right here when there is one band only ----
         if (pixelsOnHost) {
+            CopyWorker::Job job = { tls.bandDone[e], rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes,
+                                    pixelRowBytes, y1 - y0 };
+            // (tight rows of an unfriendly width -- RGB of odd width: packed on the device, one block back)
+            if (packRowsForDownload(tls.rawDown[4], (size_t)(y0 - rowBegin) * pixelRowBytes, rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes,
+                                    rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes, y1 - y0, tls.stream, tls.bandDone[e], &job, &r) && r != AVIF_RESULT_OK)
+                return r;
             HIP_TRY(hipEventRecord(tls.bandDone[e], tls.stream));
-            const CopyWorker::Job job = { tls.bandDone[e], rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes,
-                                          pixelRowBytes, y1 - y0 };
             tls.bytesDown += (uint64_t)pixelRowBytes * (y1 - y0);
             if (banded) {
                 tls.downloader->post(job);
@@ -401,8 +413,10 @@ static avifResult rectJobsOnThisDevice(const avifImage * canvas, avifRGBImage * 
             const uint32_t hostPitch = (p < 3) ? canvas->yuvRowBytes[p] : canvas->alphaRowBytes;
             uint8_t * dev = (p < 3) ? view.yuvPlanes[p] : view.alphaPlane;
             const uint32_t devPitch = (p < 3) ? view.yuvRowBytes[p] : view.alphaRowBytes;
-            HIP_TRY(hipMemcpy2DAsync(dev + (size_t)W.y0[p] * devPitch + (size_t)W.x0[p] * bps, devPitch, host + (size_t)W.y0[p] * hostPitch + (size_t)W.x0[p] * bps, hostPitch,
-                                     (size_t)W.w[p] * bps, W.h[p], hipMemcpyHostToDevice, tls.upStream));
+            r = uploadRows(tls.rawUp[p], dev + (size_t)W.y0[p] * devPitch + (size_t)W.x0[p] * bps, devPitch, host + (size_t)W.y0[p] * hostPitch + (size_t)W.x0[p] * bps, hostPitch,
+                           (size_t)W.w[p] * bps, W.h[p], tls.upStream);
+            if (r != AVIF_RESULT_OK)
+                return r;
             tls.bytesUp += (uint64_t)W.w[p] * W.h[p] * bps;
         }
         uint8_t * hostPx = rgbCanvas->pixels + (size_t)rc.y * rgbCanvas->rowBytes + (size_t)rc.x * px;

@@ -71,14 +71,27 @@ static avifResult rgbToYuvRows(avifImage * image, const avifRGBImage * rgb, uint
         tls.downloader = new CopyWorker(tls.device, tls.downStream);
     DrainOnExit drainOnExit = { banded ? tls.downloader : nullptr };
     tls.bytesUp = tls.bytesDown = 0;
+    for (int p = 0; p < 4 && !gray; ++p) {
+        uint8_t * host = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
+        const uint32_t hostRowBytes = (p < 3) ? image->yuvRowBytes[p] : image->alphaRowBytes;
+        const bool chroma = p == 1 || p == 2;
+        const uint32_t rows = chroma && subY ? ((rowEnd + 1) >> 1) - (rowBegin >> 1) : rowEnd - rowBegin;
+        if (host && hostRowBytes == g.widthBytes[p] && !isDevicePointer(host) && hostRowsWantOneBlock(host, hostRowBytes, g.widthBytes[p], rows)) {
+            r = reserve(tls.rawDown[p], (size_t)g.widthBytes[p] * rows);
+            if (r != AVIF_RESULT_OK)
+                return r;
+        }
+    }
     int band = 0;
     for (uint32_t y0 = rowBegin; y0 < rowEnd; y0 += bandRows, ++band) {
         const uint32_t y1 = (y0 + bandRows < rowEnd) ? y0 + bandRows : rowEnd;
         const int e = band % Context::kMaxBands;
         const uint32_t c0 = subY ? (y0 >> 1) : y0, c1 = subY ? ((y1 + 1) >> 1) : y1; // chroma rows of the band
         if (pixelsOnHost) {
-            HIP_TRY(hipMemcpy2DAsync(rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes,
-                                     y1 - y0, hipMemcpyHostToDevice, tls.upStream));
+            r = uploadRows(tls.rawUp[4], rgbView.pixels + (size_t)y0 * rgbView.rowBytes, rgbView.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes,
+                           y1 - y0, tls.upStream);
+            if (r != AVIF_RESULT_OK)
+                return r;
             tls.bytesUp += (uint64_t)pixelRowBytes * (y1 - y0);
             HIP_TRY(hipEventRecord(tls.bandUp[e], tls.upStream));
             HIP_TRY(hipStreamWaitEvent(tls.stream, tls.bandUp[e], 0));
@@ -104,6 +117,23 @@ static avifResult rgbToYuvRows(avifImage * image, const avifRGBImage * rgb, uint
             (void)hipStreamSynchronize(tls.downStream);
             return r;
         }
+        // the downloads of the band's plane rows: 2-D copies, or -- tight rows of an unfriendly width (every image of odd width whose planes
+        // avifImageAllocatePlanes made) -- packed on the device behind the conversion and fetched as one block (api_internal.h)
+        CopyWorker::Job planeJob[4];
+        for (int p = 0; p < 4; ++p) {
+            uint8_t * host = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
+            const uint32_t hostRowBytes = (p < 3) ? image->yuvRowBytes[p] : image->alphaRowBytes;
+            const uint8_t * dev = (p < 3) ? imageView.yuvPlanes[p] : imageView.alphaPlane;
+            const uint32_t devRowBytes = (p < 3) ? imageView.yuvRowBytes[p] : imageView.alphaRowBytes;
+            const bool chroma = p == 1 || p == 2;
+            if (!host || !hostRowBytes || host == dev || (chroma && (gray || image->yuvFormat == AVIF_PIXEL_FORMAT_YUV400)))
+                continue;
+            const uint32_t r0 = chroma ? c0 : y0, r1 = chroma ? c1 : y1, first = chroma ? (subY ? rowBegin >> 1 : rowBegin) : rowBegin;
+            planeJob[p] = { tls.bandDone[e], host + (size_t)r0 * hostRowBytes, hostRowBytes, dev + (size_t)r0 * devRowBytes, devRowBytes, g.widthBytes[p], r1 - r0 };
+            if (packRowsForDownload(tls.rawDown[p], (size_t)(r0 - first) * g.widthBytes[p], dev + (size_t)r0 * devRowBytes, devRowBytes, host + (size_t)r0 * hostRowBytes, hostRowBytes,
+                                    g.widthBytes[p], r1 - r0, tls.stream, tls.bandDone[e], &planeJob[p], &r) && r != AVIF_RESULT_OK)
+                return r;
+        }
         HIP_TRY(hipEventRecord(tls.bandDone[e], tls.stream));
         if (!banded)
             HIP_TRY(hipStreamWaitEvent(tls.downStream, tls.bandDone[e], 0));
@@ -111,7 +141,6 @@ static avifResult rgbToYuvRows(avifImage * image, const avifRGBImage * rgb, uint
             uint8_t * host = (p < 3) ? image->yuvPlanes[p] : image->alphaPlane;
             const uint32_t hostRowBytes = (p < 3) ? image->yuvRowBytes[p] : image->alphaRowBytes;
             const uint8_t * dev = (p < 3) ? imageView.yuvPlanes[p] : imageView.alphaPlane;
-            const uint32_t devRowBytes = (p < 3) ? imageView.yuvRowBytes[p] : imageView.alphaRowBytes;
             if (!host || !hostRowBytes || host == dev)
                 continue; // absent, or already device-resident
             const bool chroma = p == 1 || p == 2;
@@ -124,11 +153,11 @@ static avifResult rgbToYuvRows(avifImage * image, const avifRGBImage * rgb, uint
                 continue; // colour source into 4:0:0: chroma untouched
             }
             tls.bytesDown += (uint64_t)g.widthBytes[p] * (r1 - r0);
+            const CopyWorker::Job & job = planeJob[p];
             if (banded) {
-                tls.downloader->post({ tls.bandDone[e], host + (size_t)r0 * hostRowBytes, hostRowBytes, dev + (size_t)r0 * devRowBytes, devRowBytes, g.widthBytes[p], r1 - r0 });
+                tls.downloader->post(job);
             } else {
-                HIP_TRY(hipMemcpy2DAsync(host + (size_t)r0 * hostRowBytes, hostRowBytes, dev + (size_t)r0 * devRowBytes, devRowBytes, g.widthBytes[p], r1 - r0, hipMemcpyDeviceToHost,
-                                         tls.downStream));
+                HIP_TRY(hipMemcpy2DAsync(job.dst, job.dstPitch, job.src, job.srcPitch, job.widthBytes, job.rows, hipMemcpyDeviceToHost, tls.downStream));
             }
         }
     }
@@ -228,8 +257,9 @@ static avifResult inPlaceBandedRows(avifRGBImage * rgb, uint32_t pixelRowBytes, 
         const uint32_t rows = (y0 + bandRows < rowEnd) ? bandRows : rowEnd - y0;
         tls.bytesUp += (uint64_t)pixelRowBytes * rows, tls.bytesDown += (uint64_t)pixelRowBytes * rows;
         const int e = band % Context::kMaxBands;
-        HIP_TRY(hipMemcpy2DAsync(view.pixels + (size_t)y0 * view.rowBytes, view.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes, rows,
-                                 hipMemcpyHostToDevice, tls.upStream));
+        r = uploadRows(tls.rawUp[4], view.pixels + (size_t)y0 * view.rowBytes, view.rowBytes, rgb->pixels + (size_t)y0 * rgb->rowBytes, rgb->rowBytes, pixelRowBytes, rows, tls.upStream);
+        if (r != AVIF_RESULT_OK)
+            return r;
         HIP_TRY(hipEventRecord(tls.bandUp[e], tls.upStream));
         HIP_TRY(hipStreamWaitEvent(tls.stream, tls.bandUp[e], 0));
         r = launch(view, y0, rows, tls.stream);

@@ -115,6 +115,9 @@ struct Context
     CopyWorker * downloader = nullptr; // issues the downloads of banded host-resident calls (created on first use)
     Scratch planes[4]; // Y, U, V, A staging
     Scratch pixels;    // interleaved RGB staging
+    // rows whose host pitch, width or address is not a multiple of 4 cross the link as ONE block per band and are re-pitched on the device
+    // (uploadRows / packRowsForDownload): [0..3] planes, [4] pixels
+    Scratch rawUp[5], rawDown[5];
     Scratch table;     // batch descriptor table (device)
     Scratch scaleTable; // schedules of a plane scale (device)
     ScaleTableCache scaleCache; // ... and which geometry they belong to
@@ -178,6 +181,12 @@ struct Context
                 (void)hipFree(s.ptr);
         if (pixels.ptr)
             (void)hipFree(pixels.ptr);
+        for (Scratch & s : rawUp)
+            if (s.ptr)
+                (void)hipFree(s.ptr);
+        for (Scratch & s : rawDown)
+            if (s.ptr)
+                (void)hipFree(s.ptr);
         if (table.ptr)
             (void)hipFree(table.ptr);
         if (scaleTable.ptr)
@@ -257,6 +266,20 @@ struct ScratchScope
 // Enqueues a copy of a small host table to device memory through a pinned per-thread staging buffer (api.cpp: uploadTableAsync)
 avifResult uploadTableAsync(void * deviceDst, const void * hostSrc, size_t bytes, hipStream_t stream);
 avifResult reserve(Scratch & s, size_t bytes);
+// hipMemcpy2DAsync between pageable host memory and the device degenerates into one copy per row -- ~9 us each -- when the host pitch, the row
+// width or the host address is not a multiple of 4 (tests/c/farm_check, 12 megapixels host to host: 1.1 ms at 4096 pixels per row, 56 ms at
+// 4098, 29 ms at 4100 whose chroma rows are 2050 bytes): every libavif image of odd width, whose planes avifImageAllocatePlanes packs tight.
+// Such rows cross the link as ONE block per band instead (host rows are contiguous in memory, pitch by pitch) and change their pitch on the
+// device.  true: this block of rows wants that treatment (an unfriendly alignment, enough rows to matter, and a pitch that does not drag
+// more than twice the rows' own bytes along -- a narrow view into a wide canvas keeps the 2-D copy).
+bool hostRowsWantOneBlock(const void * host, size_t hostPitch, size_t widthBytes, size_t rows);
+// host rows -> device rows at `devPitch` (a multiple of 4), enqueued on `stream`: a 2-D copy, or one block into `raw` and a re-pitch kernel
+avifResult uploadRows(Scratch & raw, uint8_t * dev, size_t devPitch, const uint8_t * host, size_t hostPitch, size_t widthBytes, size_t rows, hipStream_t stream);
+// The way back for TIGHT host rows (pitch == width: nothing between the rows that a block copy could overwrite): enqueues, on `stream`, the
+// packing of `rows` device rows into `raw` at byte offset `rawOffset` and fills `job` with the one-block download of them; false (nothing
+// enqueued): use the 2-D copy.  `raw` must have been reserved for the whole call before its first band (reserve()).
+bool packRowsForDownload(Scratch & raw, size_t rawOffset, const uint8_t * dev, size_t devPitch, uint8_t * host, size_t hostPitch, size_t widthBytes, size_t rows,
+                         hipStream_t stream, hipEvent_t after, CopyWorker::Job * job, avifResult * result);
 bool isDevicePointer(const void * p);
 inline uint32_t alignUp(uint32_t v, uint32_t a)
 {

@@ -66,7 +66,7 @@ bool tileBatchLinksNeighbours(const YuvToRgbPlan & representative, uint32_t coun
 void linkTileBatchHalo(void * hostTable, uint32_t job, const TileNeighbours & neighbours);
 hipError_t launchGrayChromaFill(const RgbToYuvPlan & plan, hipStream_t stream);
 bool tileRgbToYuvSupported(const RgbToYuvPlan & plan);
-hipError_t launchRgbToYuvTile(const RgbToYuvPlan & plan, hipStream_t stream, const char ** kernelName);
+hipError_t launchRgbToYuvTile(const RgbToYuvPlan & plan, hipStream_t stream, const char ** kernelName, uint32_t tuning = TUNE_DEFAULT);
 
 // crop + rotate + mirror of an interleaved pixel buffer in one pass (kernels_transform.hip)
 struct TransformArgs
@@ -92,6 +92,8 @@ struct PackArgs
     int32_t swap16; // swap the bytes of every 16-bit sample (little-endian -> big-endian)
 };
 hipError_t launchPackRows(const PackArgs & args, hipStream_t stream);
+// rows at any source pitch / alignment -> rows at a 4-byte aligned destination pitch (dstPitch, dst: multiples of 4)
+hipError_t launchUnpackRows(const PackArgs & args, hipStream_t stream);
 
 // plane scaling (kernels_scale.hip): schedule tables live in device memory, modes as in scale_plan.h
 enum { SCALE_POINT_MODE = 0, SCALE_DOWN_MODE = 1, SCALE_UP_MODE = 2, SCALE_BOX_MODE = 3, SCALE_UP2_MODE = 4 };

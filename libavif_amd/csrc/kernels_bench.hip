@@ -89,13 +89,13 @@ bool launchCeiling(const avifImage * image, const avifRGBImage * rgb, int patter
 // (tile_impl.h store4WideRgba, r2y_tile_impl.h loadStrip).  The bytes written are a mix of the bytes read, so that nothing can be elided.
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 // four consecutive samples of a plane row: one 4-byte (8-bit samples) or 8-byte (16-bit containers) access, like tile_impl.h load4
-template <int YB>
+template <int YB, bool NT = false>
 __device__ __forceinline__ void moveLoad4(const uint8_t * p, unsigned (&w)[YB])
 {
     if constexpr (YB == 1) {
-        w[0] = *reinterpret_cast<const unsigned *>(p);
+        w[0] = NT ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p)) : *reinterpret_cast<const unsigned *>(p);
     } else {
-        const u2 t = *reinterpret_cast<const u2 *>(p);
+        const u2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const u2 *>(p)) : *reinterpret_cast<const u2 *>(p);
         w[0] = t.x, w[1] = t.y;
     }
 }
@@ -115,7 +115,7 @@ struct MoveJob
     uint32_t w4, h2;
 };
 
-template <int YB, int PB, int WAVES_X, int RPW, bool BANDED, bool TO_RGB>
+template <int YB, int PB, int WAVES_X, int RPW, bool BANDED, bool TO_RGB, bool NT = false>
 __global__ __launch_bounds__(256) void streamMoveKernel(const MoveJob * __restrict__ jobs, uint32_t subX, uint32_t subY, uint32_t tilesX, uint32_t tilesPerJob)
 {
     constexpr int WAVES_Y = 4 / WAVES_X;
@@ -141,12 +141,12 @@ __global__ __launch_bounds__(256) void streamMoveKernel(const MoveJob * __restri
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const uint32_t Y = Y0 + r < J.h2 ? Y0 + r : J.h2 - 1;
-            moveLoad4<YB>(J.plane[0] + (size_t)Y * J.planePitch[0] + (size_t)Xc * YB, ly[r]);
+            moveLoad4<YB, NT>(J.plane[0] + (size_t)Y * J.planePitch[0] + (size_t)Xc * YB, ly[r]);
 #pragma unroll
             for (int k = 0; k < YB; ++k)
                 la[r][k] = lc[r][0][k] = lc[r][1][k] = 0;
             if (hasA)
-                moveLoad4<YB>(J.plane[3] + (size_t)Y * J.planePitch[3] + (size_t)Xc * YB, la[r]);
+                moveLoad4<YB, NT>(J.plane[3] + (size_t)Y * J.planePitch[3] + (size_t)Xc * YB, la[r]);
             if (hasC && (!subY || !(r & 1))) { // (RPW is even and Y0 a multiple of it: r even <=> Y even)
                 const uint32_t cy = Y >> subY;
 #pragma unroll
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void streamMoveKernel(const MoveJob * __restri
                         else
                             lc[r][c][0] = *reinterpret_cast<const unsigned *>(row);
                     } else {
-                        moveLoad4<YB>(row, lc[r][c]);
+                        moveLoad4<YB, NT>(row, lc[r][c]);
                     }
                 }
             }
@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void streamMoveKernel(const MoveJob * __restri
 #pragma unroll
             for (int h = 0; h < VEC; ++h) {
                 const uint32_t byte = 1024u * h + 16u * threadIdx.x;
-                px[r][h] = *reinterpret_cast<const u4 *>(rowPx + (byte < segBytes ? byte : 0u));
+                const u4 * src = reinterpret_cast<const u4 *>(rowPx + (byte < segBytes ? byte : 0u));
+                px[r][h] = NT ? __builtin_nontemporal_load(src) : *src;
             }
         }
 #pragma unroll
@@ -276,8 +277,11 @@ bool moveJobOf(const avifImage * image, const avifRGBImage * rgb, bool toRgb, Mo
     return true;
 }
 
-constexpr int kMovePatterns = 4;
-const char * const kMovePatternName[kMovePatterns] = { "1024x2 raster", "256x16 per-XCD bands", "1024x4 raster", "256x32 per-XCD bands" };
+// tile shapes / orders / load policies the mover knows: the ceiling of a shape is the fastest of them
+constexpr int kMovePatterns = 10;
+const char * const kMovePatternName[kMovePatterns] = { "1024x2 raster", "256x16 per-XCD bands", "1024x4 raster", "256x32 per-XCD bands", "512x4 raster",
+                                                       "1024x2 raster, streaming loads", "256x16 per-XCD bands, streaming loads", "1024x4 raster, streaming loads",
+                                                       "512x4 raster, streaming loads", "256x8 raster" };
 
 template <int YB, int PB, bool TO_RGB>
 void launchMove(int pattern, const MoveJob * deviceJobs, uint32_t jobs, const MoveShape & s, hipStream_t stream)
@@ -291,7 +295,13 @@ void launchMove(int pattern, const MoveJob * deviceJobs, uint32_t jobs, const Mo
         case 0: go(streamMoveKernel<YB, PB, 4, 2, false, TO_RGB>, 4, 2); break;
         case 1: go(streamMoveKernel<YB, PB, 1, 4, true, TO_RGB>, 1, 4); break;
         case 2: go(streamMoveKernel<YB, PB, 4, 4, false, TO_RGB>, 4, 4); break;
-        default: go(streamMoveKernel<YB, PB, 1, 8, true, TO_RGB>, 1, 8); break;
+        case 3: go(streamMoveKernel<YB, PB, 1, 8, true, TO_RGB>, 1, 8); break;
+        case 4: go(streamMoveKernel<YB, PB, 2, 2, false, TO_RGB>, 2, 2); break;
+        case 5: go(streamMoveKernel<YB, PB, 4, 2, false, TO_RGB, true>, 4, 2); break;
+        case 6: go(streamMoveKernel<YB, PB, 1, 4, true, TO_RGB, true>, 1, 4); break;
+        case 7: go(streamMoveKernel<YB, PB, 4, 4, false, TO_RGB, true>, 4, 4); break;
+        case 8: go(streamMoveKernel<YB, PB, 2, 2, false, TO_RGB, true>, 2, 2); break;
+        default: go(streamMoveKernel<YB, PB, 1, 2, false, TO_RGB>, 1, 2); break;
     }
 }
 

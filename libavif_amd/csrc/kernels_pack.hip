@@ -62,7 +62,38 @@ __global__ __launch_bounds__(256) void packRowsKernel(PackArgs A)
     }
 }
 
+// The other direction (api.cpp uploadRows): rows that arrived from the host as ONE block -- source pitch, width and base of any alignment --
+// into rows at a 4-byte aligned destination pitch.  Lane = one destination dword, its source bytes read one by one.
+__global__ __launch_bounds__(256) void unpackRowsKernel(PackArgs A)
+{
+    const uint32_t dwordsPerRow = (A.widthBytes + 3u) >> 2;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint64_t)dwordsPerRow * A.rows)
+        return;
+    const uint32_t r = (uint32_t)(i / dwordsPerRow), c = (uint32_t)(i - (uint64_t)r * dwordsPerRow) * 4u;
+    const uint8_t * s = A.src + (size_t)r * A.srcPitch + c;
+    uint8_t * d = A.dst + (size_t)r * A.dstPitch + c;
+    const uint32_t n = A.widthBytes - c < 4u ? A.widthBytes - c : 4u;
+    if (n == 4u) {
+        *reinterpret_cast<unsigned *>(d) = (unsigned)s[0] | ((unsigned)s[1] << 8) | ((unsigned)s[2] << 16) | ((unsigned)s[3] << 24);
+    } else {
+        for (uint32_t k = 0; k < n; ++k)
+            d[k] = s[k];
+    }
+}
+
 } // namespace
+
+hipError_t launchUnpackRows(const PackArgs & A, hipStream_t stream)
+{
+    if (!A.rows || !A.widthBytes)
+        return hipSuccess;
+    if ((A.dstPitch & 3u) || ((uintptr_t)A.dst & 3u))
+        return hipErrorInvalidValue;
+    const uint64_t dwords = (uint64_t)((A.widthBytes + 3u) >> 2) * A.rows;
+    hipLaunchKernelGGL(unpackRowsKernel, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0, stream, A);
+    return hipGetLastError();
+}
 
 hipError_t launchPackRows(const PackArgs & A, hipStream_t stream)
 {

@@ -159,7 +159,7 @@ hipError_t launchGrayToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const
 }
 } // namespace
 
-hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const char ** kernelName)
+hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const char ** kernelName, uint32_t tuning)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
@@ -203,6 +203,7 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
     if (!plain && !k.fixedPoint && spw < 2)
         spw = 2; // the kernels of the rare modes exist with two strips per wave or more (r2y_tile_impl.h launchOnePlainOrNot)
     A.stripsPerWave = spw;
+    A.xcdBands = (tuning & TUNE_R2Y_RASTER) ? 0u : 1u;
     const uint32_t chunks = (strips + 4 * spw - 1) / (4 * spw);
     if (k.fixedPoint) { // appendix D.5, coefficients in memory order of the colour channels
         const bool full = p.fxFullRange != 0;

@@ -61,7 +61,7 @@ TileKey keyFor(const YuvToRgbPlan & p)
     k.alphaPlane = p.rgb.hasAlpha && !p.rgb.is565 && (p.alphaSource == ALPHA_PLANE || p.alphaSource == ALPHA_KEEP);
     k.mapped = p.rgb.map.on != 0;
     k.wideDownshift = k.fixedPoint && k.wideYuv && p.fxDownshift != 0;
-    k.attenuate = k.fixedPoint && p.postMul == MUL_MULTIPLY && p.postMulFx && k.nch == 4 && k.alphaPlane && (p.tuning & TUNE_COOPERATIVE) == 0;
+    k.attenuate = (k.fixedPoint && p.postMul != MUL_NONE && p.postMulFx && k.nch == 4 && k.alphaPlane && (p.tuning & TUNE_COOPERATIVE) == 0) ? (p.postMul == MUL_MULTIPLY ? 1 : 2) : 0;
     return k;
 }
 
@@ -278,7 +278,7 @@ int tileYuvToRgbVariant(const YuvToRgbPlan & plan)
     const TileKey k = keyFor(plan);
     return (k.wideYuv ? 1 : 0) | (k.sub << 1) | ((k.bilinear ? 1 : 0) << 3) | ((k.wideRgb ? 1 : 0) << 4) | ((k.nch == 4 ? 1 : 0) << 5) | ((k.nch == 2 ? 1 : 0) << 10) |
            ((k.hasMul ? 1 : 0) << 6) | ((k.alphaPlane ? 1 : 0) << 7) | ((k.fixedPoint ? 1 : 0) << 8) | ((k.mapped ? 1 : 0) << 9) |
-           ((k.wideDownshift ? 1 : 0) << 11) | ((k.gray ? 1 : 0) << 12) | ((k.attenuate ? 1 : 0) << 13);
+           ((k.wideDownshift ? 1 : 0) << 11) | ((k.gray ? 1 : 0) << 12) | ((k.attenuate & 3) << 13);
 }
 
 namespace {
@@ -325,6 +325,19 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     decompose(plan.tuning, A.w4, A.h2, 1, false, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)A.w4 * A.h2) || (plan.tuning & TUNE_SOLO_ALWAYS));
     L.pkWide = (plan.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift, L.attenuate = k.attenuate;
+    // A frame whose planes and pixels together exceed the 256 MB Infinity Cache (8K 10-bit 4:4:4 + alpha -> RGBA16: 530 MB) streams from and to
+    // HBM whatever the tile order, and its next frame finds nothing of it in the cache either.  The per-XCD bands of tall tiles that pay when
+    // planes are cache-resident then only scatter the DRAM accesses: the unfiltered fp32 families (no chroma halo to share, so the tile shape is
+    // free) take short wide tiles -- the four waves of a workgroup side by side, 1024 x 4 pixels -- in raster order, with streaming plane loads.
+    // tests/tools/stream_sweep.py cfg3, two frames cycled, one box: 103.5 us -> 92.5 (0.64 -> 0.72; its byte-movement ceiling: 94.9 / 92 us
+    // without / with streaming loads).  Explicit geometry bits in AVIFHIP_TUNING / avifhipSetTuning switch the rule off (A/B measurements).
+    const bool geometryForced = (plan.tuning & (0xfu << TUNE_STRIPS_SHIFT | 3u << TUNE_WAVESX_SHIFT | 0xfu << TUNE_CHUNK_SHIFT | TUNE_STREAM_LOADS)) != 0 ||
+                                (plan.tuning & TUNE_XCD_BANDS) == 0;
+    if (!k.fixedPoint && !k.bilinear && L.solo && !k.mapped && !geometryForced &&
+        (double)A.w4 * A.h2 * (planeBytesPerPixel(plan, k) + (double)plan.rgb.pixBytes) > 256.0 * 1048576.0) {
+        L.chunkRows = 0, L.wavesXLog2 = 2, L.pkStrips = 2;
+        L.streamLoads = true;
+    }
     hipError_t e = launchFamily(k, L);
     if (e != hipSuccess)
         return e;

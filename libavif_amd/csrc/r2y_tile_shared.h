@@ -35,6 +35,7 @@ struct R2YArgs
     uint32_t slotR, slotB, slotA;
     int32_t alphaMode;
     uint32_t stripsPerWave;
+    uint32_t xcdBands; // workgroups of one XCD (blockIdx % 8) take a contiguous run of tiles (r2yBlockOf)
     uint32_t identity; // identity matrix: the planes are G, B, R, each quantised on luma's scale (rangeUV / biasUV hold luma's)
     // the other matrices without coefficients (src/reformat.c:368-381): MODE_YCGCO (three adds on the normalised channels) and
     // MODE_YCGCO_RE / _RO (integer lifting on the channel codes, then "/ range" in the verified reciprocal form); MODE_COEFF otherwise

@@ -419,13 +419,20 @@ hipError_t launchOneFx(const TileLaunch & L)
     // 8-bit planes without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)
     if constexpr (sizeof(YT) == 1 && !MUL)
         return launchPk<SUB, BIL, NCH, APLANE>(L);
-    // premultiplied outputs (ARGBAttenuate after the conversion): the packed kernels with the pass fused in; unattenuate stays here
+    // libyuv's ARGBAttenuate / ARGBUnattenuate after the conversion (premultiplied outputs / premultiplied images into straight pixels): the packed
+    // kernels with the pass fused in
     if constexpr (MUL) {
-        if (L.attenuate && !L.mapped) {
+        if (L.attenuate == 1 && !L.mapped) {
             if constexpr (sizeof(YT) == 1)
-                return launchPkAttenuate<SUB, BIL, WIDE_NONE>(L);
+                return launchPkAttenuate<SUB, BIL, WIDE_NONE, 1>(L);
             else if (L.pkWide)
-                return L.wideDownshift ? launchPkAttenuate<SUB, BIL, WIDE_DOWNSHIFT>(L) : launchPkAttenuate<SUB, BIL, WIDE_NATIVE>(L);
+                return L.wideDownshift ? launchPkAttenuate<SUB, BIL, WIDE_DOWNSHIFT, 1>(L) : launchPkAttenuate<SUB, BIL, WIDE_NATIVE, 1>(L);
+        }
+        if (L.attenuate == 2 && !L.mapped) { // (round 5: the un-attenuate pass too)
+            if constexpr (sizeof(YT) == 1)
+                return launchPkAttenuate<SUB, BIL, WIDE_NONE, 2>(L);
+            else if (L.pkWide)
+                return L.wideDownshift ? launchPkAttenuate<SUB, BIL, WIDE_DOWNSHIFT, 2>(L) : launchPkAttenuate<SUB, BIL, WIDE_NATIVE, 2>(L);
         }
     }
     // 10- / 12-bit planes without a post-pass: the same kernels behind a front end for 16-bit containers

@@ -303,9 +303,15 @@ __device__ __forceinline__ unsigned pkAlpha(const TileArgs & A, typename PkTypes
 // `xchg` / `segBytes`: 3-byte pixels only -- the wave's exchange buffer and the bytes of its row segment that exist (storeRowContiguous)
 // ATT: libyuv's ARGBAttenuate on the three colour bytes, (c * a + 255) >> 8 (appendix D.4; what libavif runs after the conversion when the
 // pixels are to be premultiplied, src/reformat.c:1574-1585 -> src/alpha.c:163) -- on pixel pairs, before the bytes are packed.
-template <int SUB, int NCH, bool APLANE, bool MAPPED, bool ATT = false>
+// ATT == 2: libyuv's ARGBUnattenuate (appendix D.4; src/reformat_libyuv.c:1138-1161 -- what libavif runs after the conversion when a premultiplied
+// image is wanted as straight-alpha pixels): t = ((c * 0x101) * ia) >> 16 with ia the fixed-point reciprocal of the pixel's alpha from the
+// workgroup's LDS table `recip` (pkBuildReciprocals: 0, 0xffff, 0x10000 / a, 0x100 for a = 0, 1, 2..254, 255), then libyuv's signed saturating
+// pack: t >= 0x8000 becomes 0 (the a == 1, c >= 128 artefact), everything else min(t, 255).  Two 16 x 16-bit products per channel and pixel pair
+// (v_mul_u32_u24: both factors are below 2^16), their upper halves gathered into one register and clamped by v_sat_pk_u8_i16, whose signed
+// reading of the halves IS the artefact.
+template <int SUB, int NCH, bool APLANE, bool MAPPED, int ATT = 0>
 __device__ __forceinline__ void pkRow(const TileArgs & A, const unsigned Y[2], unsigned araw, const unsigned Up[2], const unsigned Vp[2], uint32_t off, bool laneValid,
-                                      unsigned out[4], WideRowExchange * xchg, uint32_t segBytes)
+                                      unsigned out[4], WideRowExchange * xchg, uint32_t segBytes, const unsigned * recip = nullptr)
 {
     const TileArgs::Fx & F = A.fx;
     unsigned px[4] = { 0, 0, 0, 0 };
@@ -327,7 +333,15 @@ __device__ __forceinline__ void pkRow(const TileArgs & A, const unsigned Y[2], u
             G = satPkU8(pkAshr6(G));
             Z = satPkU8(pkAshr6(Z));
         }
-        if constexpr (ATT) {
+        if constexpr (ATT == 2) {
+            const unsigned i0 = recip[(araw >> (16 * p)) & 0xffu], i1 = recip[(araw >> (16 * p + 8)) & 0xffu];
+            auto unatt = [&](unsigned c) { // c = (c0 c1 . .)
+                const unsigned p0 = __umul24(__builtin_amdgcn_perm(0u, c, 0x0c0c0000u), i0); // c0 * 0x101 = (c0 c0 . .)
+                const unsigned p1 = __umul24(__builtin_amdgcn_perm(0u, c, 0x0c0c0101u), i1);
+                return satPkU8(__builtin_amdgcn_perm(p1, p0, 0x07060302u)); // (t0 | t1 << 16) -> (clamp(t0) clamp(t1) . .)
+            };
+            X = unatt(X), G = unatt(G), Z = unatt(Z);
+        } else if constexpr (ATT == 1) {
             // colour bytes (c0 c1 . .) and alpha bytes spread to 16-bit pairs, (c * a + 255) >> 8 per half (65280 at most), bytes gathered again
             const unsigned Ap = __builtin_amdgcn_perm(0u, araw, p ? 0x0c030c02u : 0x0c010c00u);
             auto att = [&](unsigned c) {
@@ -641,9 +655,9 @@ __device__ __forceinline__ void pkTransposeStore(const TileArgs & A, const unsig
 }
 
 // ---- filter, matrix, stores of a wave tile ----
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool ATT = false>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, int ATT = 0>
 __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, const PkRaw<SUB, BIL, APLANE, NSW, WIDE> & R, const unsigned * ring, WideRowExchange * xchg,
-                                          unsigned * xposeTile, uint32_t wy)
+                                          unsigned * xposeTile, uint32_t wy, const unsigned * recip = nullptr)
 {
     constexpr bool kStaged = PkRaw<SUB, BIL, APLANE, NSW, WIDE>::kStaged;
     // 16-bit containers, wave-uniform shift pairs: filtered fields (weight sum 16 or 4) / plain samples down to a byte
@@ -744,7 +758,7 @@ __device__ __forceinline__ void pkCompute(const TileArgs & A, const PkSpot & w, 
                 pkLuma<WIDE>(A, R.y[2 * s + r], Y);
                 if constexpr (APLANE)
                     araw = pkAlpha<WIDE>(A, R.a[2 * s + r]);
-                pkRow<SUB, NCH, APLANE, MAPPED, ATT>(A, Y, araw, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid, px, xchg, segBytes);
+                pkRow<SUB, NCH, APLANE, MAPPED, ATT>(A, Y, araw, Up[r], Vp[r], (sy + r) * A.rgbPitch + X * (uint32_t)NCH, laneValid, px, xchg, segBytes, recip);
                 if constexpr (MAPPED) {
                     if (A.map.transposed) { // wave-uniform
 #pragma unroll
@@ -792,7 +806,7 @@ struct PkLds
     static constexpr int kWords = kPlain > kXposeWords ? kPlain : kXposeWords;
 };
 
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM, bool ATT = false>
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM, int ATT = 0>
 __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g, unsigned * lds)
 {
     typedef PkRaw<SUB, BIL, APLANE, NSW, WIDE> RawT;
@@ -800,6 +814,15 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     const uint32_t tile = pkTileOf(blockIdx.x, g);
     if (tile >= g.nTiles)
         return;
+    // un-attenuate: the reciprocal of every alpha code, one entry per thread of the workgroup (64 x 4), behind the chroma blocks; built before any
+    // wave leaves -- the barrier is the workgroup's
+    unsigned * recip = nullptr;
+    if constexpr (ATT == 2) {
+        recip = lds + PkLds<SUB, BIL, NCH, NSW, MAPPED>::kPlain;
+        const unsigned code = threadIdx.y * (unsigned)kLanesX + threadIdx.x;
+        recip[code] = fxUnattenuateReciprocal(code);
+        __syncthreads();
+    }
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
     const PkPlace place = pkPlaceOf(tile, wave, g, (uint32_t)NSW);
     const uint32_t wy = wave >> g.wavesXLog2, wavesY = 4u >> g.wavesXLog2; // the wave's row among the workgroup's stacked waves
@@ -826,7 +849,7 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     pkStage<SUB, BIL, APLANE, NSW, WIDE>(A, w, shared, raw, ring);
     if (!rowsValid && !xpose)
         return;
-    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, ATT>(A, w, raw, ring, xchg, xpose ? lds : nullptr, wy);
+    pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, ATT>(A, w, raw, ring, xchg, xpose ? lds : nullptr, wy, recip);
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
@@ -845,22 +868,23 @@ __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __
     pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(job, g, lds);
 }
 
-// ... with the attenuate pass of premultiplied outputs fused in (alpha from the plane, 4-byte pixels, rows)
-template <int SUB, bool BIL, int NSW, int WIDE>
+// ... with libyuv's attenuate (ATT = 1: premultiplied outputs) or un-attenuate (ATT = 2: premultiplied images into straight-alpha pixels) pass
+// fused in (alpha from the plane, 4-byte pixels, rows)
+template <int SUB, bool BIL, int NSW, int WIDE, int ATT>
 __global__ __launch_bounds__(256) void yuvToRgbPkAttenuateKernel(TileArgs A, PkGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
-    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, true>(A, g, lds);
+    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, ATT>(A, g, lds);
 }
-template <int SUB, bool BIL, int NSW, int WIDE>
+template <int SUB, bool BIL, int NSW, int WIDE, int ATT>
 __global__ __launch_bounds__(256) void yuvToRgbPkAttenuateBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     const TileArgs job = jobOf(table);
-    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, true>(job, g, lds);
+    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, ATT>(job, g, lds);
 }
 
-template <int SUB, bool BIL, int WIDE>
+template <int SUB, bool BIL, int WIDE, int ATT>
 hipError_t launchPkAttenuate(const TileLaunch & L)
 {
     uint32_t nsw, blocks;
@@ -868,17 +892,18 @@ hipError_t launchPkAttenuate(const TileLaunch & L)
     pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock);
     const dim3 grid(blocks, 1, L.count);
-    const uint32_t lds4 = 4u * (uint32_t)PkLds<SUB, BIL, 4, 4, false>::kPlain, lds2 = 4u * (uint32_t)PkLds<SUB, BIL, 4, 2, false>::kPlain;
+    constexpr uint32_t kTable = (ATT == 2) ? 256u : 0u; // words: the reciprocal of every alpha code (pkRunBlock)
+    const uint32_t lds4 = 4u * ((uint32_t)PkLds<SUB, BIL, 4, 4, false>::kPlain + kTable), lds2 = 4u * ((uint32_t)PkLds<SUB, BIL, 4, 2, false>::kPlain + kTable);
     if (L.table) {
         if (nsw == 4)
-            hipLaunchKernelGGL((yuvToRgbPkAttenuateBatchKernel<SUB, BIL, 4, WIDE>), grid, block, lds4, L.stream, L.table, g);
+            hipLaunchKernelGGL((yuvToRgbPkAttenuateBatchKernel<SUB, BIL, 4, WIDE, ATT>), grid, block, lds4, L.stream, L.table, g);
         else
-            hipLaunchKernelGGL((yuvToRgbPkAttenuateBatchKernel<SUB, BIL, 2, WIDE>), grid, block, lds2, L.stream, L.table, g);
+            hipLaunchKernelGGL((yuvToRgbPkAttenuateBatchKernel<SUB, BIL, 2, WIDE, ATT>), grid, block, lds2, L.stream, L.table, g);
     } else {
         if (nsw == 4)
-            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkAttenuateKernel<SUB, BIL, 4, WIDE>), grid, block, lds4, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkAttenuateKernel<SUB, BIL, 4, WIDE, ATT>), grid, block, lds4, L.stream, *L.args, g);
         else
-            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkAttenuateKernel<SUB, BIL, 2, WIDE>), grid, block, lds2, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkAttenuateKernel<SUB, BIL, 2, WIDE, ATT>), grid, block, lds2, L.stream, *L.args, g);
     }
     return hipGetLastError();
 }

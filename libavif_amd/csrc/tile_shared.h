@@ -259,7 +259,7 @@ struct TileKey
     bool hasMul;
     bool mapped;     // stores go through a PixelMap (fused crop / rotate / mirror)
     bool wideDownshift; // integer path on 16-bit containers: samples are reduced to 8 bits first (no high-bit-depth libyuv entry)
-    bool attenuate;     // integer path with libyuv's ARGBAttenuate after the conversion (premultiplied outputs): fused into the packed kernels
+    int attenuate;      // integer path with libyuv's ARGBAttenuate (1) / ARGBUnattenuate (2) after the conversion: fused into the packed kernels
     bool gray;          // GRAY / GRAYA / AGRAY outputs: nch = 1 or 2, luma only
 };
 
@@ -279,7 +279,7 @@ struct TileLaunch
     uint32_t shiftStrips;   // the tile grid starts this many strips ABOVE the rectangle (a multiple of the strips per wave; 0 but for quarter turns: launchSoloMapped)
     bool mapped;            // stores go through the jobs' PixelMap
     bool transposed;        // ... which turns rows into columns (quarter turns)
-    bool attenuate;         // TileKey::attenuate
+    int attenuate;          // TileKey::attenuate
     bool streamLoads;       // batches: the jobs' planes exceed what the Infinity Cache can hold -- luma / alpha rows as streaming loads
     bool solo;              // fp32 / 10-12-bit integer families: the wave-private kernels instead of the cooperative runs
     bool pkWide;            // 10-12-bit integer family without a post-pass: the packed 16-bit kernels (tile_pk_impl.h)

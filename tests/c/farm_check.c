@@ -1,6 +1,6 @@
 /* farm_check.c -- a C consumer of libavifhip.so (no Python anywhere): the in-process device farm behind the C ABI, checked against the oracle.
  *
- *   AVIFHIP_DEVICES=0,0 ./farm_check [width height depth [cfg2|cfg5|cfg4]]
+ *   AVIFHIP_DEVICES=0,0 ./farm_check [width height depth [cfg2|cfg5|cfg4 [plane row padding in bytes]]]
  *
  * Builds a synthetic host-resident image, converts it with the product's synchronous entry point under the device set the environment (or
  * -d <list>) names, converts the same image with the oracle (liboracle.so: the CPU restatement of libavif's reformat path -- test
@@ -76,6 +76,7 @@ int main(int argc, char ** argv)
         width = (uint32_t)atoi(argv[1]), height = (uint32_t)atoi(argv[2]), depth = (uint32_t)atoi(argv[3]);
     if (argc >= 5)
         workload = argv[4];
+    const uint32_t pad = argc >= 6 ? (uint32_t)atoi(argv[5]) : 64u; /* rows padded by this much: the padding must come back untouched */
     if (!width || !height || (depth != 8 && depth != 10 && depth != 12))
         return fail("usage: farm_check [width height depth [cfg2|cfg5|cfg4]]");
     if (avifhipDeviceCount() <= 0)
@@ -98,14 +99,14 @@ int main(int argc, char ** argv)
     const int encode = !strcmp(workload, "cfg4");
     const int wide = !strcmp(workload, "cfg5");
     for (int p = 0; p < 3; ++p) {
-        image.yuvRowBytes[p] = (p ? cw : width) * bps + 64; /* padded rows: the padding must come back untouched */
+        image.yuvRowBytes[p] = (p ? cw : width) * bps + pad;
         image.yuvPlanes[p] = (uint8_t *)malloc((size_t)image.yuvRowBytes[p] * (p ? ch : height));
         if (!image.yuvPlanes[p])
             return fail("out of memory");
         memset(image.yuvPlanes[p], 0x5a, (size_t)image.yuvRowBytes[p] * (p ? ch : height));
     }
     if (encode) {
-        image.alphaRowBytes = width * bps + 64;
+        image.alphaRowBytes = width * bps + pad;
         image.alphaPlane = (uint8_t *)malloc((size_t)image.alphaRowBytes * height);
         memset(image.alphaPlane, 0x5a, (size_t)image.alphaRowBytes * height);
     }

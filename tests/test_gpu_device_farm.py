@@ -101,7 +101,7 @@ def test_alpha_passes_in_place_through_three_workers(farm3):
             for fn_name in ("premultiply", "unpremultiply"):
                 imgs = []
                 for b in (oracle, be):
-                    rgb = abi.make_rgb(333, 150, depth, fmt, avoid_libyuv=True, row_pad=5, fill=0x5A)
+                    rgb = abi.make_rgb(333, 150, depth, fmt, avoid_libyuv=True, row_pad=6, fill=0x5A)
                     synth.fill_rgb(rgb, 0x77 + depth)
                     if depth == 10:
                         rgb.pixels.view(np.uint16)[...] &= 1023

@@ -98,6 +98,54 @@ def test_premultiplied_outputs_fuse_the_attenuate_pass(hip_auto_arithmetic):
     assert fused > 0.6 * 2 * len(cases), kernels
 
 
+def test_premultiplied_images_fuse_the_unattenuate_pass(hip_auto_arithmetic):
+    """Images stored PREMULTIPLIED into straight-alpha RGBA / BGRA: libyuv's conversion followed by ARGBUnattenuate (src/reformat.c:1574-1585 ->
+    src/alpha.c:350 -> src/reformat_libyuv.c:1138-1161), in one pass of the packed kernels (round 5; round 1's cooperative 32-bit kernel before)."""
+    import itertools
+    cases = []
+    for (w, h), depth, yf, up, fmt in itertools.product(TILED, (8, 10, 12), (1, 2, 3, 4), (3, 4), (1, 4)):
+        cases.append(H.Y2RCase(w, h, yuv_depth=depth, yuv_format=yf, upsampling=up, rgb_format=fmt, rgb_depth=8, alpha=True, image_premultiplied=True, avoid_libyuv=False,
+                               matrix=(1, 6, 9)[(w + depth + yf) % 3], yuv_range=(w + yf + fmt) % 2, row_pad=64 if (h + fmt) % 2 else 0,
+                               seed=(w * 19 + depth * 13 + yf * 5 + up * 3 + fmt) | 1))
+    kernels = {}
+    bad = []
+    o = H.oracle_libyuv_backend()
+    for be in (H.HipDeviceBackend(), H.hip_host_backend()):
+        for c in cases:
+            ro, po = H.run_y2r(o, c)
+            rh, ph = H.run_y2r(be, c)
+            k = native.last_kernel()
+            kernels[k] = kernels.get(k, 0) + 1
+            if ro != rh or not np.array_equal(po, ph):
+                bad.append(f"{c.ident()} [{k}]: results {ro}/{rh}" + ("" if ro != rh else " " + H.describe_diff(po, ph)))
+    assert not bad, f"{len(bad)} of {2 * len(cases)} cases differ:\n" + "\n".join(bad[:25])
+    fused = sum(v for k, v in kernels.items() if "alphamul,pk16" in k)
+    assert fused > 0.6 * 2 * len(cases), kernels
+
+
+def test_unattenuate_in_the_packed_kernel_every_colour_alpha_pair(hip_auto_arithmetic):
+    """All 65,536 (colour byte, alpha byte) pairs through the conversion + ARGBUnattenuate of the packed kernel, the a == 1, c >= 128 -> 0
+    artefact of libyuv's signed saturating pack included: a gray 4:4:4 image whose luma runs over every code in x and whose alpha runs over
+    every code in y (full range, identity-like: R = G = B = Y for chroma 128), 8-bit planes -> RGBA8, image premultiplied."""
+    w, h = 256, 256
+    img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 6, with_alpha=True, alpha_premultiplied=True)
+    img.planes[0][:h, :w] = np.arange(256, dtype=np.uint8)[None, :]
+    img.planes[1][:h, :w] = 128
+    img.planes[2][:h, :w] = 128
+    img.alpha[:h, :w] = np.arange(256, dtype=np.uint8)[:, None]
+    outs = []
+    for be_name in ("oracle", "hip"):
+        rgb = abi.make_rgb(w, h, 8, abi.AVIF_RGB_FORMAT_RGBA, upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, avoid_libyuv=False, fill=0x5A)
+        be = H.oracle_libyuv_backend() if be_name == "oracle" else H.hip_host_backend()
+        assert be.yuv_to_rgb(img.struct, rgb.struct) == 0
+        outs.append(rgb.pixels.copy())
+    assert "alphamul,pk16" in native.last_kernel(), native.last_kernel()
+    px = outs[0].reshape(h, -1)[:, : 4 * w].reshape(h, w, 4)
+    assert (px[1, 128:, 0] == 0).all() and px[1, 127, 0] == 255  # the artefact is in the oracle's picture: a == 1, c >= 128 -> 0
+    assert len(np.unique(px[:, :, 0])) == 256
+    assert np.array_equal(outs[0], outs[1]), H.describe_diff(outs[0], outs[1])
+
+
 def test_wide_planes_cooperative_kernels_still_exact(hip_auto_arithmetic):
     """The round-1 kernels of the 10/12-bit integer family stay selectable for A/B runs (plan.h TUNE_COOPERATIVE): same bytes."""
     hip_auto_arithmetic.avifhipSetTuning(5)

@@ -52,7 +52,7 @@ def y2r(w, h, depth, fmt, rng, mc, rgb_depth, alpha=False, premult=False, avoid=
     return device.DeviceYUV(img), device.DeviceRGB(rgb)
 
 
-TUNINGS = [("default", 0x1), ("raster", 0x0), ("bands,2 strips", 0x201), ("bands,4 strips", 0x401), ("raster,2 strips", 0x200), ("raster,4 strips", 0x400),
+TUNINGS = [("default", 0x1), ("raster", 0x0), ("bands,2 strips", 0x201), ("bands,4 strips (rounds 2-4 for big frames)", 0x401), ("raster,2 strips", 0x200), ("raster,4 strips", 0x400),
            ("raster,4 waves wide,2 strips", 0x30200), ("raster,4 waves wide,4 strips", 0x30400), ("raster,2 waves wide,2 strips", 0x20200),
            ("bands,4 waves wide,2 strips", 0x30201), ("bands,2 rows/chunk", 0x200001), ("bands,4 rows/chunk", 0x400001),
            ("default + streaming loads (single 16-bit unfiltered)", 0x41), ("raster + streaming loads", 0x40), ("raster,4 waves wide,2 strips + streaming loads", 0x30240),
@@ -83,6 +83,21 @@ def run(name):
     elif name in ("cfg2cold", "cfg2cold_fp32"):
         pairs = [y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=name.endswith("fp32"), seed=k) for k in range(12)]
         sweep_y2r(name + " (12 frames cycled)", pairs, 5.5 * 7680 * 4320)
+    elif name in ("cfg2warm", "cfg2warm_fp32"):
+        pairs = [y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=name.endswith("fp32"), seed=k) for k in range(4)]
+        sweep_y2r(name + " (4 frames cycled)", pairs, 5.5 * 7680 * 4320, stream_env=False)
+    elif name == "cfg3same":
+        pairs = [y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, seed=0)]
+        sweep_y2r("cfg3 (same frame)", pairs, 16.0 * 7680 * 4320, tunings=[("default", 0x1), ("bands,4 strips (rounds 2-4)", 0x401), ("raster,4 waves wide,2 strips + streaming loads", 0x30240)], stream_env=False)
+    elif name == "f16_444a":
+        pairs = []
+        for k in range(2):
+            img = abi.make_yuv(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_LIMITED, 9, with_alpha=True)
+            synth.fill_yuv(img, 0x4242 + k)
+            rgb = abi.make_rgb(7680, 4320, 16, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=True, allocate=False)
+            rgb.struct.isFloat = 1
+            pairs.append((device.DeviceYUV(img), device.DeviceRGB(rgb)))
+        sweep_y2r("f16_444a (2 frames cycled)", pairs, 16.0 * 7680 * 4320, tunings=[("default", 0x1), ("bands,4 strips (rounds 2-4)", 0x401), ("raster,4 waves wide,2 strips + streaming loads", 0x30240)], stream_env=False)
     elif name == "cfg2_4k":
         pairs = [y2r(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, seed=k) for k in range(4)]
         sweep_y2r("cfg2_4k (4 frames cycled)", pairs, 5.5 * 3840 * 2160)
@@ -97,6 +112,10 @@ def run(name):
         alg = 6.5 * 3840 * 2160
         emit("cfg4 (8 frames cycled)", "ceiling", burst(lib.avifhipTimeStreamCeilingRGBToYUV, n, imgs, rgbs), alg)
         emit("cfg4 (8 frames cycled)", "default", burst(lib.avifhipTimeRGBToYUVCycle, n, imgs, rgbs), alg)
+        lib.avifhipSetTuning(0x81)
+        emit("cfg4 (8 frames cycled)", "raster order (TUNE_R2Y_RASTER)", burst(lib.avifhipTimeRGBToYUVCycle, n, imgs, rgbs), alg)
+        emit("cfg4 (same frame)", "raster order (TUNE_R2Y_RASTER)", burst(lib.avifhipTimeRGBToYUV, enc[0][0].struct, enc[0][1].struct), alg)
+        lib.avifhipSetTuning(1)
         for spw in ("1", "2", "4"):
             os.environ["AVIFHIP_R2Y_SPW"] = spw
             emit("cfg4 (8 frames cycled)", "AVIFHIP_R2Y_SPW=" + spw, burst(lib.avifhipTimeRGBToYUVCycle, n, imgs, rgbs), alg)
