@@ -170,7 +170,10 @@ AVIFHIP_API avifResult avifhipRGBImageTransformAsync(avifRGBImage * dst,
  * follows the library's arithmetic setting (default: what a libavif built with libyuv computes).
  * avifhipRGBImageApplyGainMap: host images; toneMappedImage->pixels is (re)allocated with malloc like the reference does.
  * ...Async: base pixels, gain-map planes and (pre-allocated) tone-mapped pixels are device-resident; the call enqueues on
- * `hipStream` and WAITS for it, because the result code (NaN check) and the CLLI values depend on the pixels. */
+ * `hipStream` and WAITS for it when its answer depends on the pixels: the CLLI values (clli != NULL), or the result code where the
+ * curves' tables cannot rule a NaN out.  With clli == NULL and tables that prove no NaN can arise (4-channel integer pixels up to
+ * 12 bits: the fast kernel's precondition) it returns with its work enqueued, like every other Async entry point.  The tone-mapped
+ * pixels may lie on top of the base pixels (same layout): such a call keeps to the general kernel, one lane per pixel. */
 AVIFHIP_API avifResult avifhipRGBImageApplyGainMap(const avifRGBImage * baseImage,
                                                    avifColorPrimaries baseColorPrimaries,
                                                    avifTransferCharacteristics baseTransferCharacteristics,
@@ -401,6 +404,9 @@ AVIFHIP_API double avifhipTimeYUVToRGBCycle(uint32_t count, const avifImage * co
  *                                     of the canvas) */
 AVIFHIP_API double avifhipTimeStreamCeiling(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
 AVIFHIP_API double avifhipTimeStreamCeilingRGBToYUV(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
+/* ... of a plane scaling job (avifhipImageScaleAsync): every sample of `src`'s planes read once, every sample of `dst`'s planes written once, 16 bytes
+ * per lane, nothing computed.  Planes and pitches must be multiples of 16 bytes. */
+AVIFHIP_API double avifhipTimeStreamCeilingScale(const avifImage * src, avifImage * dst, int warmup, int iters, void * hipStream);
 AVIFHIP_API double avifhipTimeStreamCeilingBatch(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
 /* The same event timing for the encode direction over `count` cycled frames, for a batch call (avifhipImageYUVToRGBBatchAsync: milliseconds
  * per batch) and for a grid call (avifhipGridYUVToRGBAsync: milliseconds per canvas, every kernel the call launches included). */

@@ -270,7 +270,10 @@ avifResult ensureContext()
 
 ScratchScope::ScratchScope(hipStream_t s) : stream(s), result(AVIF_RESULT_OK)
 {
-    if (tls.scratchPending && tls.scratchStream != s) {
+    // (a caller's own stream -- generation 0 -- was marked when it was noted, and is waited for even when the handle LOOKS like the one asking now:
+    //  a stream destroyed behind the library's back may have handed its address to a new one, which is ordered behind nothing; when it is the
+    //  same stream after all, waiting for its own event costs next to nothing)
+    if (tls.scratchPending && (tls.scratchStream != s || (tls.scratchGeneration == 0 && tls.scratchMarked))) {
         // The previous user's stream is marked only now that somebody on another stream needs to wait for it: an event recorded here
         // covers everything that stream was given before, and calls that stay on one stream (nearly all) pay for no event at all -- a
         // record behind every launch kept the next kernel waiting for the signal (plane scaling: 24 us per call around an 18 us kernel).

@@ -21,7 +21,7 @@ struct JobOverride
 static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects,
                                  const JobOverride * overrides, void * hipStream, const PixelMap * map = nullptr, const void * extra = nullptr, size_t extraBytes = 0,
                                  const void ** extraDevice = nullptr, uint32_t * slotOut = nullptr, bool * residentOut = nullptr,
-                                 const TileNeighbours * neighbours = nullptr, bool * seamsDone = nullptr, int linkForced = -1)
+                                 const TileNeighbours * neighbours = nullptr, bool * seamsDone = nullptr, int linkForced = -1, uint32_t canvasColumns = 0)
 {
     if (seamsDone)
         *seamsDone = false;
@@ -206,7 +206,7 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
     hipError_t e = hipSuccess;
     if (allTiled) {
         HIP_TRY(upload(dev, pinned, bytes));
-        e = launchYuvToRgbTileBatch(dev, representative, count, maxW, maxH, stream, &tls.lastKernel, linked);
+        e = launchYuvToRgbTileBatch(dev, representative, count, maxW, maxH, stream, &tls.lastKernel, linked, canvasColumns);
         if (e == hipSuccess && restW)
             e = launchYuvToRgbGenericBatch((const YuvToRgbPlan *)(dev + tileBytes), count, restW, restMaxH, stream);
         if (e == hipSuccess && restH)
@@ -363,7 +363,9 @@ static avifResult gridYuvToRgbImpl(const avifhipGrid * grid, const avifImage * c
     }
     bool residentTable = false, seamsDone = false;
     avifResult r = batchAsyncImpl(jobs, viewPtrs.data(), rgbPtrs.data(), rects.data(), overrides.data(), hipStream, map, tiles.data(), tiles.size() * sizeof(GridTile),
-                                  &deviceTiles, &tableSlot, &residentTable, linkable ? neighbours.data() : nullptr, &seamsDone, linkForced);
+                                  &deviceTiles, &tableSlot, &residentTable, linkable ? neighbours.data() : nullptr, &seamsDone, linkForced,
+                                  // (every tile a job, row-major, into one canvas: the kernels may walk along the canvas rows)
+                                  (!only && !map && jobs == count) ? grid->columns : 0u);
     if (r != AVIF_RESULT_OK)
         return r;
     hipStream_t stream = pickStream(hipStream);

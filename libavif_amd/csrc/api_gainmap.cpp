@@ -116,7 +116,7 @@ bool gainMapLayout(const avifRGBImage * rgb, GainMapPixelLayout * L) // avifGetR
 // values depend on the pixels.
 avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries basePrimaries, avifTransferCharacteristics baseTC, const avifGainMap * gainMap,
                                 const avifImage * gainImage, float weight, avifColorPrimaries outPrimaries, avifTransferCharacteristics outTC,
-                                avifRGBImage * out, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag, hipStream_t stream)
+                                avifRGBImage * out, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag, hipStream_t stream, bool mayReturnEarly = false)
 {
     const uint32_t width = base->width, height = base->height;
     GainMapArgs A;
@@ -311,6 +311,15 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         A.fast = applyGain && cache.locBuckets && width >= 4 && plain4(A.baseL, A.base, A.basePitch) && plain4(A.outL, A.out, A.outPitch) && gainDepth <= 12 &&
                  gainMapFastLdsBytes(A.baseL.pixelBytes, gainDepth, cache.locBuckets) <= kGainMapFastLdsBytes && !fastKernelDisabled();
         if (A.fast) {
+            // in place (the device entry point with the tone-mapped pixels on top of the base pixels, same layout): the fast kernel's lanes take runs
+            // of 4 pixels and the last run of a row is shifted left to stay inside it -- over pixels a neighbouring lane, possibly of another
+            // workgroup, has already replaced.  The general kernel, one lane per pixel, reads every pixel exactly once before it writes it.
+            const uint8_t * b0 = A.base, * b1 = b0 + (size_t)A.basePitch * height;
+            const uint8_t * o0 = A.out, * o1 = o0 + (size_t)A.outPitch * height;
+            if (b0 < o1 && o0 < b1)
+                A.fast = 0;
+        }
+        if (A.fast) {
             // no intermediate value can reach FLT_MAX (so none is infinite, so none is a NaN) when the tables are finite and the
             // products of their largest entries with the coefficients stay far below it: only then may the fast kernel, which does
             // not look for NaNs, serve the call
@@ -364,18 +373,24 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
     if (tls.gainMapTimeIters > 0) { // avifhipTimeRGBImageApplyGainMap: the apply kernel alone, back to back, between two events
         for (int k = 0; k < tls.gainMapTimeWarmup; ++k)
             HIP_TRY(launchGainMapApply(A, stream, &partials));
-        hipEvent_t t0, t1;
+        hipEvent_t t0 = nullptr, t1 = nullptr;
         HIP_TRY(hipEventCreate(&t0));
-        HIP_TRY(hipEventCreate(&t1));
+        if (hipEventCreate(&t1) != hipSuccess) {
+            (void)hipEventDestroy(t0);
+            return hipFailed(hipGetLastError(), "hipEventCreate");
+        }
         (void)hipEventRecord(t0, stream);
-        for (int k = 0; k < tls.gainMapTimeIters - 1; ++k)
-            (void)launchGainMapApply(A, stream, &partials);
+        hipError_t timed = hipSuccess;
+        for (int k = 0; k < tls.gainMapTimeIters - 1 && timed == hipSuccess; ++k)
+            timed = launchGainMapApply(A, stream, &partials);
         (void)hipEventRecord(t1, stream); // (the last of the iters launches is the call's own, below)
         float ms = -1.0f;
         if (hipEventSynchronize(t1) != hipSuccess || hipEventElapsedTime(&ms, t0, t1) != hipSuccess)
             ms = -1.0f;
         (void)hipEventDestroy(t0);
         (void)hipEventDestroy(t1);
+        if (timed != hipSuccess)
+            return hipFailed(timed, "gain map kernel launch (timed loop)");
         tls.gainMapTimedMs = (ms < 0 || tls.gainMapTimeIters < 2) ? -1.0 : (double)ms / (tls.gainMapTimeIters - 1);
     }
     const hipError_t e = launchGainMapApply(A, stream, &partials);
@@ -383,6 +398,11 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         return hipFailed(e, "gain map kernel launch");
     tls.lastKernel = applyGain ? (A.fast ? "gainmap_apply_fast" : "gainmap_apply") : (A.convert ? "gainmap_convert" : "gainmap_requantise");
     ++tls.launches;
+    // Nothing of the answer depends on the pixels when the caller wants no light levels and the fast kernel serves the call: its precondition
+    // (above) is that no NaN can arise, and the result code is then AVIF_RESULT_OK whatever the pixels hold.  The asynchronous entry point
+    // returns with its work enqueued, like every other Async call.
+    if (mayReturnEarly && applyGain && A.fast && !clli && tls.gainMapTimeIters <= 0)
+        return AVIF_RESULT_OK;
     HIP_TRY(hipStreamSynchronize(stream));
     GainMapStats stats = { 0, 0, 0.0 };
     {
@@ -466,7 +486,7 @@ extern "C" avifResult avifhipRGBImageApplyGainMapAsync(const avifRGBImage * base
         return AVIF_RESULT_OK;
     }
     return applyGainMapOnDevice(baseImage, baseColorPrimaries, baseTransferCharacteristics, gainMap, gainMap->image, weight, outputColorPrimaries,
-                                outputTransferCharacteristics, toneMappedImage, clli, diag, stream);
+                                outputTransferCharacteristics, toneMappedImage, clli, diag, stream, /*mayReturnEarly=*/true);
 }
 
 // the apply kernel of that call alone: milliseconds per launch over back-to-back launches (HIP events on the launch stream)

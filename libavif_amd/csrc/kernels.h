@@ -48,7 +48,7 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
 size_t tileBatchTableBytes(uint32_t count);
 void fillTileBatchTable(const YuvToRgbPlan * plans, uint32_t count, void * hostTable);
 hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW,
-                                   uint32_t maxH, hipStream_t stream, const char ** kernelName, bool neighboursLinked = false);
+                                   uint32_t maxH, hipStream_t stream, const char ** kernelName, bool neighboursLinked = false, uint32_t canvasColumns = 0);
 // Jobs that are the tiles of ONE canvas (grid images): a job whose neighbours are linked filters chroma across the seams inside the tiled
 // kernels (the seam-aware builds, tile_impl.h) -- no second pass.  Index 3 * v + h of the plane arrays: v 0 = the job's own tile, 1 = the
 // tile above, 2 = below; h 0 = own, 1 = left, 2 = right; every pointer addresses canvas sample (0,0) of the tile's U / V plane, virtually

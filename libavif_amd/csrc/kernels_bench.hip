@@ -115,13 +115,20 @@ struct MoveJob
     uint32_t w4, h2;
 };
 
+// `columns` != 0 (batches whose jobs are the tiles of ONE canvas, `columns` per canvas row): workgroups are numbered along the rows of the CANVAS
+// -- grid x = (tile column of the grid, tile of the job's row), y = tile row inside the job, z = tile row of the grid -- so that the pixels of a
+// canvas row leave in one sweep across all the jobs that share it, instead of job by job.
 template <int YB, int PB, int WAVES_X, int RPW, bool BANDED, bool TO_RGB, bool NT = false>
-__global__ __launch_bounds__(256) void streamMoveKernel(const MoveJob * __restrict__ jobs, uint32_t subX, uint32_t subY, uint32_t tilesX, uint32_t tilesPerJob)
+__global__ __launch_bounds__(256) void streamMoveKernel(const MoveJob * __restrict__ jobs, uint32_t subX, uint32_t subY, uint32_t tilesX, uint32_t tilesPerJob, uint32_t columns)
 {
     constexpr int WAVES_Y = 4 / WAVES_X;
     constexpr int VEC = PB / 4; // 16-byte pieces of a lane's 4 pixels
-    const MoveJob J = jobs[blockIdx.y];
-    const uint32_t tile = BANDED ? bandedTile(blockIdx.x, gridDim.x) : blockIdx.x;
+    uint32_t job = blockIdx.y, tile = BANDED ? bandedTile(blockIdx.x, gridDim.x) : blockIdx.x;
+    if (columns) {
+        const uint32_t c = blockIdx.x / tilesX;
+        job = blockIdx.z * columns + c, tile = blockIdx.y * tilesX + (blockIdx.x - c * tilesX);
+    }
+    const MoveJob J = jobs[job];
     if (tile >= tilesPerJob)
         return;
     const uint32_t trow = tile / tilesX, tcol = tile - trow * tilesX;
@@ -235,6 +242,7 @@ struct MoveShape
     int yb, pb;
     uint32_t subX, subY;
     uint32_t maxW4, maxH2;
+    uint32_t columns; // jobs per canvas row when the jobs of a batch are the tiles of one canvas (row-major), else 0
 };
 
 // Fills `job` from an image / pixel pair; false when the pair is outside what the mover covers (the tiled kernels' own alignment rules).
@@ -278,47 +286,61 @@ bool moveJobOf(const avifImage * image, const avifRGBImage * rgb, bool toRgb, Mo
 }
 
 // tile shapes / orders / load policies the mover knows: the ceiling of a shape is the fastest of them
-constexpr int kMovePatterns = 10;
+constexpr int kMovePatterns = 13;
 const char * const kMovePatternName[kMovePatterns] = { "1024x2 raster", "256x16 per-XCD bands", "1024x4 raster", "256x32 per-XCD bands", "512x4 raster",
                                                        "1024x2 raster, streaming loads", "256x16 per-XCD bands, streaming loads", "1024x4 raster, streaming loads",
-                                                       "512x4 raster, streaming loads", "256x8 raster" };
+                                                       "512x4 raster, streaming loads", "256x8 raster", "1024x4 along the canvas rows", "256x16 along the canvas rows",
+                                                       "1024x4 along the canvas rows, streaming loads" };
 
 template <int YB, int PB, bool TO_RGB>
-void launchMove(int pattern, const MoveJob * deviceJobs, uint32_t jobs, const MoveShape & s, hipStream_t stream)
+bool launchMove(int pattern, const MoveJob * deviceJobs, uint32_t jobs, const MoveShape & s, hipStream_t stream)
 {
-    auto go = [&](auto kernel, uint32_t wavesX, uint32_t rpw) {
+    auto go = [&](auto kernel, uint32_t wavesX, uint32_t rpw, bool alongCanvas = false) {
         const uint32_t wavesY = 4u / wavesX;
         const uint32_t tilesX = (s.maxW4 + 256u * wavesX - 1) / (256u * wavesX), tilesY = (s.maxH2 + rpw * wavesY - 1) / (rpw * wavesY);
-        hipLaunchKernelGGL(kernel, dim3(tilesX * tilesY, jobs), dim3(64, 4), 0, stream, deviceJobs, s.subX, s.subY, tilesX, tilesX * tilesY);
+        if (alongCanvas) {
+            if (!s.columns || jobs % s.columns)
+                return false; // (separate buffers: there is no canvas)
+            hipLaunchKernelGGL(kernel, dim3(tilesX * s.columns, tilesY, jobs / s.columns), dim3(64, 4), 0, stream, deviceJobs, s.subX, s.subY, tilesX, tilesX * tilesY, s.columns);
+        } else {
+            hipLaunchKernelGGL(kernel, dim3(tilesX * tilesY, jobs), dim3(64, 4), 0, stream, deviceJobs, s.subX, s.subY, tilesX, tilesX * tilesY, 0u);
+        }
+        return true;
     };
     switch (pattern) {
-        case 0: go(streamMoveKernel<YB, PB, 4, 2, false, TO_RGB>, 4, 2); break;
-        case 1: go(streamMoveKernel<YB, PB, 1, 4, true, TO_RGB>, 1, 4); break;
-        case 2: go(streamMoveKernel<YB, PB, 4, 4, false, TO_RGB>, 4, 4); break;
-        case 3: go(streamMoveKernel<YB, PB, 1, 8, true, TO_RGB>, 1, 8); break;
-        case 4: go(streamMoveKernel<YB, PB, 2, 2, false, TO_RGB>, 2, 2); break;
-        case 5: go(streamMoveKernel<YB, PB, 4, 2, false, TO_RGB, true>, 4, 2); break;
-        case 6: go(streamMoveKernel<YB, PB, 1, 4, true, TO_RGB, true>, 1, 4); break;
-        case 7: go(streamMoveKernel<YB, PB, 4, 4, false, TO_RGB, true>, 4, 4); break;
-        case 8: go(streamMoveKernel<YB, PB, 2, 2, false, TO_RGB, true>, 2, 2); break;
-        default: go(streamMoveKernel<YB, PB, 1, 2, false, TO_RGB>, 1, 2); break;
+        case 0: return go(streamMoveKernel<YB, PB, 4, 2, false, TO_RGB>, 4, 2);
+        case 1: return go(streamMoveKernel<YB, PB, 1, 4, true, TO_RGB>, 1, 4);
+        case 2: return go(streamMoveKernel<YB, PB, 4, 4, false, TO_RGB>, 4, 4);
+        case 3: return go(streamMoveKernel<YB, PB, 1, 8, true, TO_RGB>, 1, 8);
+        case 4: return go(streamMoveKernel<YB, PB, 2, 2, false, TO_RGB>, 2, 2);
+        case 5: return go(streamMoveKernel<YB, PB, 4, 2, false, TO_RGB, true>, 4, 2);
+        case 6: return go(streamMoveKernel<YB, PB, 1, 4, true, TO_RGB, true>, 1, 4);
+        case 7: return go(streamMoveKernel<YB, PB, 4, 4, false, TO_RGB, true>, 4, 4);
+        case 8: return go(streamMoveKernel<YB, PB, 2, 2, false, TO_RGB, true>, 2, 2);
+        case 9: return go(streamMoveKernel<YB, PB, 1, 2, false, TO_RGB>, 1, 2);
+        case 10: return go(streamMoveKernel<YB, PB, 4, 4, false, TO_RGB>, 4, 4, true);
+        case 11: return go(streamMoveKernel<YB, PB, 1, 4, false, TO_RGB>, 1, 4, true);
+        default: return go(streamMoveKernel<YB, PB, 4, 4, false, TO_RGB, true>, 4, 4, true);
     }
 }
 
-bool launchMoveShape(int pattern, bool toRgb, const MoveJob * deviceJobs, uint32_t jobs, const MoveShape & s, hipStream_t stream)
+// false: the pattern does not apply to this batch (nothing launched), or the launch failed (`failed` says which)
+bool launchMoveShape(int pattern, bool toRgb, const MoveJob * deviceJobs, uint32_t jobs, const MoveShape & s, hipStream_t stream, bool * failed)
 {
+    bool launched;
     if (toRgb) {
         if (s.yb == 1)
-            s.pb == 4 ? launchMove<1, 4, true>(pattern, deviceJobs, jobs, s, stream) : launchMove<1, 8, true>(pattern, deviceJobs, jobs, s, stream);
+            launched = s.pb == 4 ? launchMove<1, 4, true>(pattern, deviceJobs, jobs, s, stream) : launchMove<1, 8, true>(pattern, deviceJobs, jobs, s, stream);
         else
-            s.pb == 4 ? launchMove<2, 4, true>(pattern, deviceJobs, jobs, s, stream) : launchMove<2, 8, true>(pattern, deviceJobs, jobs, s, stream);
+            launched = s.pb == 4 ? launchMove<2, 4, true>(pattern, deviceJobs, jobs, s, stream) : launchMove<2, 8, true>(pattern, deviceJobs, jobs, s, stream);
     } else {
         if (s.yb == 1)
-            s.pb == 4 ? launchMove<1, 4, false>(pattern, deviceJobs, jobs, s, stream) : launchMove<1, 8, false>(pattern, deviceJobs, jobs, s, stream);
+            launched = s.pb == 4 ? launchMove<1, 4, false>(pattern, deviceJobs, jobs, s, stream) : launchMove<1, 8, false>(pattern, deviceJobs, jobs, s, stream);
         else
-            s.pb == 4 ? launchMove<2, 4, false>(pattern, deviceJobs, jobs, s, stream) : launchMove<2, 8, false>(pattern, deviceJobs, jobs, s, stream);
+            launched = s.pb == 4 ? launchMove<2, 4, false>(pattern, deviceJobs, jobs, s, stream) : launchMove<2, 8, false>(pattern, deviceJobs, jobs, s, stream);
     }
-    return hipGetLastError() == hipSuccess;
+    *failed = launched && hipGetLastError() != hipSuccess;
+    return launched && !*failed;
 }
 
 } // namespace
@@ -330,6 +352,31 @@ using namespace avifhip::api;
 // Average milliseconds per launch of the byte-movement-only kernel, cycling over `count` device-resident frames like
 // avifhipTimeYUVToRGBCycle (the RGB buffers are overwritten with meaningless bytes); the faster of the two access patterns
 // above.  Negative when the frames are not 8-bit 4:2:0 planes with 4-byte pixels.
+// `warmup` untimed launches, then `iters` between two events on the launch stream: milliseconds per launch (< 0 on failure)
+template <typename Launch>
+static double timeCalls(void * hipStream, int warmup, int iters, Launch launch)
+{
+    hipStream_t stream = pickStream(hipStream);
+    for (int k = 0; k < warmup; ++k)
+        if (!launch(stream))
+            return -1.0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (hipEventCreate(&t0) != hipSuccess)
+        return -1.0;
+    if (hipEventCreate(&t1) != hipSuccess) {
+        (void)hipEventDestroy(t0);
+        return -1.0;
+    }
+    bool ok = hipEventRecord(t0, stream) == hipSuccess;
+    for (int k = 0; k < iters && ok; ++k)
+        ok = launch(stream);
+    float ms = -1.0f;
+    ok = ok && hipEventRecord(t1, stream) == hipSuccess && hipEventSynchronize(t1) == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess;
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return ok ? (double)ms / iters : -1.0;
+}
+
 static double timeCeilingPattern(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, int pattern, hipStream_t stream)
 {
     for (int k = 0; k < warmup; ++k)
@@ -366,11 +413,16 @@ static double timeMover(const std::vector<MoveJob> & jobs, uint32_t groups, uint
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool ok = hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess;
     for (int pattern = 0; ok && pattern < kMovePatterns; ++pattern) {
+        bool failed = false;
+        if (!launchMoveShape(pattern, toRgb, deviceJobs, perLaunch, shape, stream, &failed)) {
+            ok = !failed;
+            continue; // (the pattern does not apply to this batch)
+        }
         for (int k = 0; ok && k < warmup; ++k)
-            ok = launchMoveShape(pattern, toRgb, deviceJobs + (size_t)(k % groups) * perLaunch, perLaunch, shape, stream);
+            ok = launchMoveShape(pattern, toRgb, deviceJobs + (size_t)(k % groups) * perLaunch, perLaunch, shape, stream, &failed);
         ok = ok && hipEventRecord(t0, stream) == hipSuccess;
         for (int k = 0; ok && k < iters; ++k)
-            ok = launchMoveShape(pattern, toRgb, deviceJobs + (size_t)(k % groups) * perLaunch, perLaunch, shape, stream);
+            ok = launchMoveShape(pattern, toRgb, deviceJobs + (size_t)(k % groups) * perLaunch, perLaunch, shape, stream, &failed);
         float ms = -1.0f;
         ok = ok && hipEventRecord(t1, stream) == hipSuccess && hipEventSynchronize(t1) == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess;
         if (ok && (best < 0 || ms / iters < best))
@@ -413,6 +465,13 @@ static double timeCeilingGeneral(uint32_t count, const avifImage * const * image
                 jobs[k].plane[3] = nullptr;
         }
     }
+    if (batch && count > 1) {
+        // the tiles of one canvas, row-major: the leading jobs whose pixels start inside the first job's first pixel row share a canvas row
+        uint32_t columns = 1;
+        while (columns < count && jobs[columns].pixelPitch == jobs[0].pixelPitch && jobs[columns].pixels > jobs[0].pixels && jobs[columns].pixels < jobs[0].pixels + jobs[0].pixelPitch)
+            ++columns;
+        shape.columns = (columns > 1 && count % columns == 0) ? columns : 0;
+    }
     return batch ? timeMover(jobs, 1, count, shape, toRgb, warmup, iters, pickStream(hipStream)) : timeMover(jobs, count, 1, shape, toRgb, warmup, iters, pickStream(hipStream));
 }
 
@@ -434,6 +493,98 @@ extern "C" double avifhipTimeStreamCeiling(uint32_t count, const avifImage * con
         return -1.0;
     tls.lastKernel = a < b ? "stream_ceiling<planes->pixels,single,1024x2 raster>" : "stream_ceiling<planes->pixels,single,256x16 per-XCD bands>";
     return a < b ? a : b;
+}
+
+// ---- plane scaling: every sample of the source planes read once, every sample of the destination planes written once ----
+namespace {
+struct PlanePair
+{
+    const uint8_t * src;
+    uint8_t * dst;
+    uint32_t srcPitch, dstPitch, srcWidthBytes, dstWidthBytes, srcRows, dstRows;
+};
+struct ScaleMove
+{
+    PlanePair plane[4];
+    uint32_t planes;
+};
+// one workgroup = 256 lanes x 16 bytes of ROWS consecutive rows of one plane, source rows first and destination rows after them (grid y = plane)
+template <int ROWS>
+__global__ __launch_bounds__(256) void scaleMoveKernel(ScaleMove M, uint32_t chunksPerRow)
+{
+    const PlanePair P = M.plane[blockIdx.y];
+    const uint32_t group = blockIdx.x / chunksPerRow, chunk = blockIdx.x - group * chunksPerRow;
+    const uint32_t byte = (chunk * 256u + threadIdx.x) * 16u;
+    u4 v[ROWS];
+    unsigned seen = 0;
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const uint32_t row = group * ROWS + k;
+        v[k] = (u4) { byte, row, chunk, 0x5a5a5a5au };
+        if (row < P.srcRows && byte + 16u <= P.srcWidthBytes)
+            v[k] = *reinterpret_cast<const u4 *>(P.src + (size_t)row * P.srcPitch + byte);
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const uint32_t row = group * ROWS + k;
+        if (row < P.srcRows) {
+            seen ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+        } else if (row - P.srcRows < P.dstRows && byte + 16u <= P.dstWidthBytes) {
+            __builtin_nontemporal_store(v[k], reinterpret_cast<u4 *>(P.dst + (size_t)(row - P.srcRows) * P.dstPitch + byte));
+        }
+    }
+    if (seen == 0x9e3779b9u && byte + 16u <= P.dstWidthBytes) // (never, in effect: the loads must not be optimised away)
+        __builtin_nontemporal_store(v[0], reinterpret_cast<u4 *>(P.dst + byte));
+}
+} // namespace
+
+extern "C" double avifhipTimeStreamCeilingScale(const avifImage * src, avifImage * dst, int warmup, int iters, void * hipStream)
+{
+    if (iters <= 0 || !src || !dst || src->depth != dst->depth || src->yuvFormat != dst->yuvFormat || ensureContext() != AVIF_RESULT_OK)
+        return -1.0;
+    ScaleMove M;
+    memset(&M, 0, sizeof(M));
+    const PlaneGeometry gs = planeGeometry(src), gd = planeGeometry(dst);
+    uint32_t maxRows = 0, maxWidth = 0;
+    for (int p = 0; p < 4; ++p) {
+        const uint8_t * sp = (p < 3) ? src->yuvPlanes[p] : src->alphaPlane;
+        uint8_t * dp = (p < 3) ? dst->yuvPlanes[p] : dst->alphaPlane;
+        const uint32_t sPitch = (p < 3) ? src->yuvRowBytes[p] : src->alphaRowBytes, dPitch = (p < 3) ? dst->yuvRowBytes[p] : dst->alphaRowBytes;
+        if (!sp || !dp || ((p == 1 || p == 2) && src->yuvFormat == AVIF_PIXEL_FORMAT_YUV400))
+            continue;
+        if ((((uintptr_t)sp | (uintptr_t)dp | sPitch | dPitch) & 15u) != 0) {
+            setError("avifhipTimeStreamCeilingScale: planes and pitches must be multiples of 16 bytes");
+            return -1.0;
+        }
+        PlanePair & P = M.plane[M.planes++];
+        P.src = sp, P.dst = dp, P.srcPitch = sPitch, P.dstPitch = dPitch;
+        P.srcWidthBytes = gs.widthBytes[p] & ~15u, P.dstWidthBytes = gd.widthBytes[p] & ~15u, P.srcRows = gs.rows[p], P.dstRows = gd.rows[p];
+        maxRows = P.srcRows + P.dstRows > maxRows ? P.srcRows + P.dstRows : maxRows;
+        maxWidth = P.srcWidthBytes > maxWidth ? P.srcWidthBytes : maxWidth;
+        maxWidth = P.dstWidthBytes > maxWidth ? P.dstWidthBytes : maxWidth;
+    }
+    if (!M.planes || !maxWidth)
+        return -1.0;
+    const uint32_t chunksPerRow = (maxWidth + 4095u) / 4096u;
+    double ms = -1.0;
+    for (int rowsPerGroup : { 1, 4, 8 }) { // the fastest of three depths of requests in flight per lane
+        const double t = timeCalls(hipStream, warmup, iters, [&](hipStream_t s) {
+            const dim3 grid(chunksPerRow * ((maxRows + rowsPerGroup - 1) / rowsPerGroup), M.planes);
+            if (rowsPerGroup == 1)
+                hipLaunchKernelGGL(scaleMoveKernel<1>, grid, dim3(256), 0, s, M, chunksPerRow);
+            else if (rowsPerGroup == 4)
+                hipLaunchKernelGGL(scaleMoveKernel<4>, grid, dim3(256), 0, s, M, chunksPerRow);
+            else
+                hipLaunchKernelGGL(scaleMoveKernel<8>, grid, dim3(256), 0, s, M, chunksPerRow);
+            return hipGetLastError() == hipSuccess;
+        });
+        if (t < 0)
+            return -1.0;
+        ms = (ms < 0 || t < ms) ? t : ms;
+    }
+    if (ms >= 0)
+        tls.lastKernel = "stream_ceiling<scale: source planes read, destination planes written>";
+    return ms;
 }
 
 extern "C" double avifhipTimeStreamCeilingRGBToYUV(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream)

@@ -5,6 +5,8 @@
 // search among the function's fp32 steps (in LDS up to 12-bit outputs).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "kernels.h"
 
 #include <type_traits>
@@ -777,10 +779,10 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_
         const uint32_t byLds = (uint32_t)((160 * 1024) / (lds + 512));
         const int conv = (A.inConv ? 1 : 0) | (A.outConv ? 2 : 0);
         const int key = (A.baseL.pixelBytes == 8 ? 4 : 0) | (A.outL.pixelBytes == 8 ? 2 : 0) | (A.gainDepth > 8 ? 1 : 0);
-        static int wavesPerSimd[8][4]; // of each instantiation, from its register count (0: not asked yet)
+        static std::atomic<int> wavesPerSimd[8][4]; // of each instantiation, from its register count (0: not asked yet; any thread may ask: same answer)
         uint32_t groups = 0;
         auto launch = [&](auto kernel) {
-            int waves = wavesPerSimd[key][conv];
+            int waves = wavesPerSimd[key][conv].load(std::memory_order_relaxed);
             if (!waves) {
                 hipFuncAttributes attr;
                 waves = 4;
@@ -791,7 +793,8 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_
 #ifdef AVIFHIP_GAINMAP_PROBE
                 printf("numRegs %d sharedSizeBytes %zu maxThreadsPerBlock %d\n", attr.numRegs, attr.sharedSizeBytes, attr.maxThreadsPerBlock);
 #endif
-                wavesPerSimd[key][conv] = waves = (waves > 8) ? 8 : ((waves < 2) ? 2 : waves);
+                waves = (waves > 8) ? 8 : ((waves < 2) ? 2 : waves);
+                wavesPerSimd[key][conv].store(waves, std::memory_order_relaxed);
             }
             const uint32_t byRegisters = (uint32_t)(4 * waves / kFastRows);
             const uint32_t perCu = (byLds < byRegisters) ? byLds : byRegisters;

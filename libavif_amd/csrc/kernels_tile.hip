@@ -150,7 +150,9 @@ void decompose(uint32_t tuning, uint32_t w4, uint32_t h2, uint32_t jobs, bool ba
     }
     L->stripsPerWave = ns;
     L->tilesPerRun = run;
-    L->blocksPerJob = bands * ((tilesY + run - 1) / run);
+    L->bandsPerJob = bands, L->runsPerJob = (tilesY + run - 1) / run;
+    L->blocksPerJob = L->bandsPerJob * L->runsPerJob;
+    L->canvasColumns = 0;
     // packed 16-bit integer kernels (tile_pk_impl.h) derive their own grid from these
     L->maxW4 = w4, L->maxH2 = h2;
     L->pkStrips = (tuning >> TUNE_STRIPS_SHIFT) & 0xfu;
@@ -331,6 +333,12 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     // free) take short wide tiles -- the four waves of a workgroup side by side, 1024 x 4 pixels -- in raster order, with streaming plane loads.
     // tests/tools/stream_sweep.py cfg3, two frames cycled, one box: 103.5 us -> 92.5 (0.64 -> 0.72; its byte-movement ceiling: 94.9 / 92 us
     // without / with streaming loads).  Explicit geometry bits in AVIFHIP_TUNING / avifhipSetTuning switch the rule off (A/B measurements).
+    // 8-bit 4:2:0 planes filtered by the packed integer kernels (the headline's kernel), four waves stacked and one chroma neighbourhood per
+    // workgroup: two strips per wave (256 x 16 tiles) at every size.  Four (256 x 32) were the rule from 2048 workgroups up until round 4; since
+    // the workgroup shares its neighbourhood the taller tile buys nothing when the planes are cache-resident (8K, 4 frames cycled: 28.14 / 28.24
+    // us, interleaved A/B) and costs 2.8 % when they stream (12 frames cycled: 34.98 -> 34.01 us; profiles/r05_stream_sweep_ab.jsonl)
+    if (k.fixedPoint && !k.wideYuv && k.bilinear && k.sub == SUB_420 && L.pkStrips == 0)
+        L.pkStrips = 2;
     const bool geometryForced = (plan.tuning & (0xfu << TUNE_STRIPS_SHIFT | 3u << TUNE_WAVESX_SHIFT | 0xfu << TUNE_CHUNK_SHIFT | TUNE_STREAM_LOADS)) != 0 ||
                                 (plan.tuning & TUNE_XCD_BANDS) == 0;
     if (!k.fixedPoint && !k.bilinear && L.solo && !k.mapped && !geometryForced &&
@@ -392,7 +400,7 @@ void linkTileBatchHalo(void * hostTable, uint32_t job, const TileNeighbours & n)
 }
 
 hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW,
-                                   uint32_t maxH, hipStream_t stream, const char ** kernelName, bool neighboursLinked)
+                                   uint32_t maxH, hipStream_t stream, const char ** kernelName, bool neighboursLinked, uint32_t canvasColumns)
 {
     const TileKey k = keyFor(representative);
     if (kernelName)
@@ -414,12 +422,35 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
     decompose(representative.tuning, maxW & ~3u, maxH & ~1u, count, true, &L);
     L.solo = L.solo && (soloPays(k, (uint64_t)(maxW & ~3u) * (maxH & ~1u) * count) || (representative.tuning & TUNE_SOLO_ALWAYS));
     L.pkWide = (representative.tuning & TUNE_COOPERATIVE) == 0, L.wideDownshift = k.wideDownshift, L.attenuate = k.attenuate;
+    const double bytesPerPixel = (double)representative.yuv.chanBytes * (k.sub == SUB_444 ? 3.0 : k.sub == SUB_422 ? 2.0 : k.sub == SUB_420 ? 1.5 : 1.0) +
+                                 (double)representative.rgb.pixBytes + (k.alphaPlane || k.hasMul ? (double)representative.yuv.chanBytes : 0.0);
+    const bool streams = (double)maxW * maxH * count * bytesPerPixel > 192.0 * 1048576.0; // beyond what the 256 MB Infinity Cache holds next to anything else
+    const bool packed = k.fixedPoint && (!k.hasMul || (k.attenuate && !k.mapped)) && (!k.wideYuv || L.pkWide);
+    // The tiles of one canvas (grids) that stream: workgroups along the rows of the CANVAS (tile_geom.h PkGeom::canvasColumns), so that a canvas
+    // row's pixels leave in one sweep across the tiles that share it -- in the wave-private kernels, whose tiles need nothing from one another:
+    // the packed ones with tall tiles (4 strips per wave), the fp32 ones in place of the cooperative runs.  Interleaved A/B on one box,
+    // cfg5's 64 tiles of 1080p 10-bit into one canvas (profiles/r05_grid_ab.jsonl): -> RGBA8 168.6 us job by job (round 4) / 164.2 job by
+    // job with 4 strips / 160.2 along the canvas with 4 strips / 184.1 along the canvas with 2; -> RGBA(10) 266.0 cooperative job by job
+    // (round 4) / 281.7 cooperative along the canvas / 267.9 wave-private job by job / 256.4 wave-private along the canvas.  A grid that fits
+    // the cache (the 12-megapixel photograph in 48 tiles) keeps the job-by-job order: 12.8 us against 14.1.  TUNE_JOB_MAJOR: round 4's order.
+    L.canvasColumns = 0;
+    if (canvasColumns > 1 && (streams || (representative.tuning & TUNE_CANVAS_ORDER)) && !k.mapped && (representative.tuning & TUNE_JOB_MAJOR) == 0) {
+        if (packed) {
+            L.canvasColumns = canvasColumns;
+            if (L.pkStrips == 0)
+                L.pkStrips = 4;
+        } else if (!k.fixedPoint && (representative.tuning & TUNE_COOPERATIVE) == 0) {
+            L.canvasColumns = canvasColumns;
+            L.solo = true;
+        }
+    }
+    // Linked grids in the packed kernels (tiles and seams in one launch): tall tiles at every size -- the photograph 12.8 -> 11.2 us
+    if (L.seams && packed && L.pkStrips == 0)
+        L.pkStrips = 4;
     // A batch whose bytes exceed the Infinity Cache (256 MB) streams from and to HBM whatever the tile order; the per-XCD chunks, which pay
     // when planes are cache-resident, then only scatter the DRAM accesses: plain raster order (tests/tools/pkbench_wide.hip, 64 tiles of
     // 1080p 10-bit -> RGBA8: 188 -> 175 us)
-    const double bytesPerPixel = (double)representative.yuv.chanBytes * (k.sub == SUB_444 ? 3.0 : k.sub == SUB_422 ? 2.0 : k.sub == SUB_420 ? 1.5 : 1.0) +
-                                 (double)representative.rgb.pixBytes + (k.alphaPlane || k.hasMul ? (double)representative.yuv.chanBytes : 0.0);
-    if ((double)maxW * maxH * count * bytesPerPixel > 192.0 * 1048576.0 && ((representative.tuning >> TUNE_CHUNK_SHIFT) & 0xfu) == 0) {
+    if (streams && ((representative.tuning >> TUNE_CHUNK_SHIFT) & 0xfu) == 0) {
         if (k.fixedPoint && k.wideYuv && !k.hasMul && L.pkWide && L.pkStrips == 0 && L.chunkRows)
             L.pkStrips = 2; // 16-bit containers: twice the registers per strip -- shorter tiles in per-XCD rows (pkbench_wide: 174 -> 169 us)
         else

@@ -188,6 +188,8 @@ enum TuningBits : uint32_t {
     TUNE_ALL_ALPHA_MODES = 1u << 5, // fp32 tiles with a pending alpha multiply: the kernel that carries every alpha mode, not the one compiled for the job's (A/B measurements)
     TUNE_STREAM_LOADS = 1u << 6,  // single images of 16-bit planes, unfiltered chroma: streaming (non-temporal) plane loads (A/B measurements)
     TUNE_R2Y_RASTER = 1u << 7,    // RGB -> YUV tiles in plain raster order instead of per-XCD bands (A/B measurements)
+    TUNE_CANVAS_ORDER = 1u << 25, // grids: workgroups along the rows of the canvas whatever the canvas's size (tests: small grids through the order large ones take)
+    TUNE_JOB_MAJOR = 1u << 24,    // grids: workgroups job by job (rounds 1-4) instead of along the rows of the canvas (A/B measurements)
     TUNE_PRIVATE_HALO = 1u << 4,  // packed kernels, 4:2:0 bilinear: every wave stages its own chroma halo rows (no workgroup barrier; A/B measurements)
     TUNE_DEFAULT = TUNE_XCD_BANDS,
     TUNE_STRIPS_SHIFT = 8,        // bits 8..11: forced strips per wave (tile height / 8) of the tiled kernels, 0 = automatic

@@ -652,17 +652,17 @@ __device__ __forceinline__ TileHalo::Planes * haloOfWave()
 // the private copy of a batch kernel's job (read through the table pointer, every field would be re-loaded after each store: the compiler
 // cannot rule out that the RGB stores alias the table -- ~20 scalar loads per tile inside the pipelined loop)
 template <bool COOPERATIVE = false>
-__device__ __forceinline__ TileArgs jobOf(const TileArgs * __restrict__ table)
+__device__ __forceinline__ TileArgs jobOf(const TileArgs * __restrict__ table, uint32_t jobIndex = blockIdx.z)
 {
     // (the copy first: behind the fences below the table's fields would no longer qualify for scalar loads, and the job would live in
     //  vector registers -- 140 instead of 76 in the cooperative 10-bit kernel)
-    TileArgs job = table[blockIdx.z];
+    TileArgs job = table[jobIndex];
     if constexpr (kSeams && COOPERATIVE) {
-        job.haloRef = &table[blockIdx.z].halo; // the four waves together stage whole rows: scalar loads from the table where a row needs them
+        job.haloRef = &table[jobIndex].halo; // the four waves together stage whole rows: scalar loads from the table where a row needs them
     } else if constexpr (kSeams) {
         TileHalo::Planes * mine = haloOfWave();
         if (threadIdx.x < 9)
-            mine[threadIdx.x] = table[blockIdx.z].halo.at[threadIdx.x];
+            mine[threadIdx.x] = table[jobIndex].halo.at[threadIdx.x];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1476,7 +1476,7 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
 // per tile; vertically consecutive tiles also re-read their shared chroma halo rows from the nearest cache.
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false>
 __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRun, f2 (*rows)[BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch],
-                                         WideRowExchange * xchg)
+                                         WideRowExchange * xchg, uint32_t canvasColumns = 0)
 {
     constexpr int kTileH = 8 * NS;
     constexpr bool kNeedA = APLANE || HASMUL;
@@ -1485,11 +1485,19 @@ __device__ __forceinline__ void runBlock(const TileArgs & A, uint32_t tilesPerRu
     const uint32_t tilesY = (A.h2 + kTileH - 1) / kTileH;
     const uint32_t runsY = (tilesY + tilesPerRun - 1) / tilesPerRun;
     const uint32_t nRuns = bands * runsY;
-    const uint32_t run = blockRemap(blockIdx.x, gridDim.x, (A.tuning & TUNE_XCD_BANDS) != 0 && (gridDim.z == 1 || (gridDim.x & 7) == 0));
-    if (run >= nRuns)
-        return;
-    const uint32_t rrow = run / bands;
-    const uint32_t bandX = (run - rrow * bands) * kBandW;
+    uint32_t rrow, band;
+    if (canvasColumns) { // tiles of one canvas, workgroups along the canvas rows (tile_geom.h PkGeom::canvasColumns): x = (canvas column, band), y = run row
+        const uint32_t bandsPerJob = gridDim.x / canvasColumns;
+        band = blockIdx.x % bandsPerJob, rrow = blockIdx.y;
+        if (band >= bands || rrow >= runsY)
+            return;
+    } else {
+        const uint32_t run = blockRemap(blockIdx.x, gridDim.x, (A.tuning & TUNE_XCD_BANDS) != 0 && (gridDim.z == 1 || (gridDim.x & 7) == 0));
+        if (run >= nRuns)
+            return;
+        rrow = run / bands, band = run - rrow * bands;
+    }
+    const uint32_t bandX = band * kBandW;
     const uint32_t firstTile = rrow * tilesPerRun;
     const uint32_t nTiles = (tilesY - firstTile < tilesPerRun) ? (tilesY - firstTile) : tilesPerRun;
 
@@ -1541,17 +1549,18 @@ __global__ __launch_bounds__(256) void yuvToRgbTileKernel(TileArgs A, uint32_t t
 
 // one launch for a table of jobs (grid z = job); the descriptor is read with scalar loads
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false>
-__global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun)
+__global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * __restrict__ table, uint32_t tilesPerRun, uint32_t canvasColumns)
 {
     __shared__ __attribute__((aligned(16))) f2 rows[BIL ? 2 : 1][BIL ? StageRows<SUB, NS>::kRows : 1][kRowPitch];
     // a private copy of the job: read through the table pointer, every field would be re-loaded after each store (the compiler
     // cannot rule out that the RGB stores alias the table) -- ~20 scalar loads per tile inside the pipelined loop
-    const TileArgs job = jobOf<true>(table);
+    const uint32_t jobIndex = canvasColumns ? blockIdx.z * canvasColumns + blockIdx.x / (gridDim.x / canvasColumns) : blockIdx.z;
+    const TileArgs job = jobOf<true>(table, jobIndex);
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, tilesPerRun, rows, xchg);
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, tilesPerRun, rows, xchg, canvasColumns);
     } else {
-        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, tilesPerRun, rows, nullptr);
+        runBlock<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM>(job, tilesPerRun, rows, nullptr, canvasColumns);
     }
 }
 
@@ -1559,12 +1568,11 @@ __global__ __launch_bounds__(256) void yuvToRgbTileBatchKernel(const TileArgs * 
 //      front, the chroma neighbourhood in a wave-private LDS block, NO workgroup barrier; tiles in per-XCD chunks (tile_geom.h).
 //      Replaces the cooperative runs above wherever it measured faster (launchOne) ----
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, bool STREAM = false, int MULSEL = 0>
-__device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2 * lds, WideRowExchange * xchg)
+__device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2 * lds, WideRowExchange * xchg, uint32_t tile)
 {
     constexpr bool kNeedA = APLANE || HASMUL;
     typedef StageRows<SUB, NS, 1> SR;
     prepareAlphaTables<YT, HASMUL, MULSEL>(A);
-    const uint32_t tile = pkTileOf(blockIdx.x, g);
     if (tile >= g.nTiles)
         return;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
@@ -1599,9 +1607,9 @@ __global__ __launch_bounds__(256) void yuvToRgbTileSoloKernel(TileArgs A, PkGeom
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(A, g, lds, xchg);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(A, g, lds, xchg, pkTileOf(blockIdx.x, g));
     } else {
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(A, g, lds, nullptr);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(A, g, lds, nullptr, pkTileOf(blockIdx.x, g));
     }
 }
 
@@ -1609,12 +1617,13 @@ template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, boo
 __global__ __launch_bounds__(256) void yuvToRgbTileSoloBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
-    const TileArgs job = jobOf(table); // a private copy: see yuvToRgbTileBatchKernel
+    const BatchWhere where = pkBatchWhere(g);
+    const TileArgs job = jobOf(table, where.job); // a private copy: see yuvToRgbTileBatchKernel
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(job, g, lds, xchg);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(job, g, lds, xchg, where.tile);
     } else {
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(job, g, lds, nullptr);
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(job, g, lds, nullptr, where.tile);
     }
 }
 
@@ -1790,7 +1799,7 @@ hipError_t launchSolo(const TileLaunch & L)
     PkGeom g;
     pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock);
-    const dim3 grid(blocks, 1, L.count);
+    const dim3 grid = pkBatchGrid(g, blocks, L.count);
     if constexpr (MUL) {
         // jobs with pending alpha arithmetic: the kernel with that one mode compiled in (computeTile MULSEL; kernels_tile.hip alphaSelOf)
         switch (L.alphaSel) {
@@ -1810,18 +1819,20 @@ hipError_t launchOne(const TileLaunch & L)
     if (L.solo)
         return launchSolo<YT, SUB, BIL, RT, NCH, APLANE, MUL>(L);
     const dim3 block(kLanesX, kWavesPerBlock);
-    const dim3 grid(L.blocksPerJob, 1, L.count);
+    // (tiles of one canvas: workgroups along the canvas rows -- tile_geom.h PkGeom::canvasColumns)
+    const uint32_t columns = (L.table && L.canvasColumns > 1 && !L.mapped && L.count % L.canvasColumns == 0) ? L.canvasColumns : 0u;
+    const dim3 grid = columns ? dim3(L.bandsPerJob * columns, L.runsPerJob, L.count / columns) : dim3(L.blocksPerJob, 1, L.count);
     if (L.table && L.streamLoads && sizeof(YT) == 2) {
         if constexpr (sizeof(YT) == 2) {
             if (L.stripsPerWave >= 2)
-                hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, true>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
+                hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, true>), grid, block, 0, L.stream, L.table, L.tilesPerRun, columns);
             else
-                hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1, true>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
+                hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1, true>), grid, block, 0, L.stream, L.table, L.tilesPerRun, columns);
         }
     } else if (L.table && L.stripsPerWave >= 2)
-        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
+        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, L.table, L.tilesPerRun, columns);
     else if (L.table)
-        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table, L.tilesPerRun);
+        hipLaunchKernelGGL((yuvToRgbTileBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 1>), grid, block, 0, L.stream, L.table, L.tilesPerRun, columns);
     else if (L.stripsPerWave >= 2)
         AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2>), grid, block, 0, L.stream, *L.args, L.tilesPerRun);
     else

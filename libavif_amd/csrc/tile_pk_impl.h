@@ -807,11 +807,10 @@ struct PkLds
 };
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM, int ATT = 0>
-__device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g, unsigned * lds)
+__device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g, unsigned * lds, uint32_t tile)
 {
     typedef PkRaw<SUB, BIL, APLANE, NSW, WIDE> RawT;
     constexpr int kRingWords = PkLds<SUB, BIL, NCH, NSW, MAPPED>::kRingWords;
-    const uint32_t tile = pkTileOf(blockIdx.x, g);
     if (tile >= g.nTiles)
         return;
     // un-attenuate: the reciprocal of every alpha code, one entry per thread of the workgroup (64 x 4), behind the chroma blocks; built before any
@@ -840,7 +839,11 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     if (!bandValid || (!rowsValid && !shared && !xpose))
         return; // tiles at the right / bottom edge: a wave without work simply leaves (sharing: its rows are still its neighbour's halo)
     w.slotMin = (shared && wy > 0) ? 1 : 0;
-    w.slotMax = (shared && wy + 1 < wavesY) ? NSW : NSW + 1;
+    // (every staged row of the wave's own neighbourhood -- NSW + 2 for 4:2:0, 2 * NSW for 4:2:2 -- unless the wave below stages the last one.
+    //  Until round 5 this read NSW + 1 for both layouts: right for 4:2:0, two rows short for 4:2:2 with four strips per wave -- the geometry
+    //  that images of ~8 megapixels and more select -- whose rows 6 and 7 of every wave were filtered from unstaged LDS.  No test converted a
+    //  4:2:2 image that large; tests/test_gpu_parity_libyuv.py::test_packed_kernels_at_every_tile_height does now.)
+    w.slotMax = (shared && wy + 1 < wavesY) ? NSW : PkStage<SUB, NSW>::kRows - 1;
     unsigned * ring = shared ? lds + wy * (uint32_t)(NSW * kPkPitch) : lds + wave * (uint32_t)kRingWords;
     // 3-byte pixels, stored as rows: one exchange buffer per wave behind the chroma blocks
     WideRowExchange * xchg = (NCH == 3 && !MAPPED) ? reinterpret_cast<WideRowExchange *>(lds + kWavesPerBlock * PkLds<SUB, BIL, NCH, NSW, MAPPED>::kRingWords) + wave : nullptr;
@@ -857,15 +860,16 @@ __global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g)
 {
     constexpr bool STREAM = false; // single images: their planes are assumed cache-resident (just decoded / uploaded / produced)
     extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
-    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(A, g, lds);
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(A, g, lds, pkTileOf(blockIdx.x, g));
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM = false>
 __global__ __launch_bounds__(256) void yuvToRgbPkBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
-    const TileArgs job = jobOf(table); // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
-    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(job, g, lds);
+    const BatchWhere where = pkBatchWhere(g);
+    const TileArgs job = jobOf(table, where.job); // a private copy: see yuvToRgbTileBatchKernel (tile_impl.h)
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(job, g, lds, where.tile);
 }
 
 // ... with libyuv's attenuate (ATT = 1: premultiplied outputs) or un-attenuate (ATT = 2: premultiplied images into straight-alpha pixels) pass
@@ -874,14 +878,15 @@ template <int SUB, bool BIL, int NSW, int WIDE, int ATT>
 __global__ __launch_bounds__(256) void yuvToRgbPkAttenuateKernel(TileArgs A, PkGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
-    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, ATT>(A, g, lds);
+    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, ATT>(A, g, lds, pkTileOf(blockIdx.x, g));
 }
 template <int SUB, bool BIL, int NSW, int WIDE, int ATT>
 __global__ __launch_bounds__(256) void yuvToRgbPkAttenuateBatchKernel(const TileArgs * __restrict__ table, PkGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
-    const TileArgs job = jobOf(table);
-    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, ATT>(job, g, lds);
+    const BatchWhere where = pkBatchWhere(g);
+    const TileArgs job = jobOf(table, where.job);
+    pkRunBlock<SUB, BIL, 4, true, NSW, false, WIDE, false, ATT>(job, g, lds, where.tile);
 }
 
 template <int SUB, bool BIL, int WIDE, int ATT>
@@ -891,7 +896,7 @@ hipError_t launchPkAttenuate(const TileLaunch & L)
     PkGeom g;
     pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock);
-    const dim3 grid(blocks, 1, L.count);
+    const dim3 grid = pkBatchGrid(g, blocks, L.count);
     constexpr uint32_t kTable = (ATT == 2) ? 256u : 0u; // words: the reciprocal of every alpha code (pkRunBlock)
     const uint32_t lds4 = 4u * ((uint32_t)PkLds<SUB, BIL, 4, 4, false>::kPlain + kTable), lds2 = 4u * ((uint32_t)PkLds<SUB, BIL, 4, 2, false>::kPlain + kTable);
     if (L.table) {
@@ -915,7 +920,7 @@ hipError_t launchPkMapped(const TileLaunch & L)
     PkGeom g;
     pkGeometry(L, L.maxW4, L.maxH2, &nsw, &g, &blocks);
     const dim3 block(kLanesX, kWavesPerBlock);
-    const dim3 grid(blocks, 1, L.count);
+    const dim3 grid = pkBatchGrid(g, blocks, L.count);
     // LDS: the waves' chroma blocks (+ exchange buffers); quarter turns overlay them with the workgroup's transposition tile
     const bool xpose = MAPPED && L.transposed;
     const uint32_t lds4 = 4u * (uint32_t)(xpose ? PkLds<SUB, BIL, NCH, 4, MAPPED>::kWords : PkLds<SUB, BIL, NCH, 4, MAPPED>::kPlain);

@@ -56,6 +56,7 @@ struct TileArgs
     // feeding the FIRST colour channel of a pixel (X: R for RGB orders, B for BGR orders), `v` the one feeding the third
     // (Z), and cB / cU (cR / cV) are the coefficients of that first (third) channel -- so no kernel selects channels per pixel
     uint32_t slotX, slotZ;
+    uint32_t planesSwapped; // ... `u` addresses the image's V plane (host side: linkHalo hands the neighbours' planes over in the same order)
     int32_t alphaRescale;                // alpha plane depth differs from the rgb depth (src/alpha.c:84-103)
     // rgb->ignoreAlpha on a format with an alpha channel, fp32 arithmetic: the destination's alpha samples stay as they are (src/reformat.c:
     // 1449-1450 -- nothing writes them).  The kernels that take alpha from a plane serve it: a pixel's alpha is read from the destination
@@ -158,6 +159,7 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     if (redFirstColour && p.arith != ARITH_LIBYUV) { // the fixed-point block below does its own swap
         const uint8_t * t = A.u;
         A.u = A.v, A.v = t;
+        A.planesSwapped = 1;
         const uint32_t tp = A.uPitch;
         A.uPitch = A.vPitch, A.vPitch = tp;
         float tf = A.cB;
@@ -190,6 +192,7 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
         if (redFirst) { // X = R is fed by the V plane
             const uint8_t * t = A.u;
             A.u = A.v, A.v = t;
+            A.planesSwapped = 1;
             const uint32_t tp = A.uPitch;
             A.uPitch = A.vPitch, A.vPitch = tp;
             A.fx.kX4 = 4 * kR, A.fx.cX4 = 4 * m.vr, A.fx.kZ4 = 4 * kB, A.fx.cZ4 = 4 * m.ub, A.fx.gLo4 = 4 * m.vg, A.fx.gHi4 = 4 * m.ug;
@@ -236,7 +239,7 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
 // the pixel's colour channels (the "YVU trick"): the neighbours' follow the job's own.  Entries of absent neighbours hold the job's planes.
 inline void linkHalo(TileArgs & T, const uint8_t * const plane1[9], const uint8_t * const plane2[9], bool above, bool below, bool left, bool right)
 {
-    const bool swapped = T.u == plane2[0] && T.u != plane1[0];
+    const bool swapped = T.planesSwapped != 0; // (distillArgs' own decision: comparing pointers would misread a tile whose U and V planes are one buffer)
     const bool present[9] = { true, left, right, above, above && left, above && right, below, below && left, below && right };
     for (int d = 0; d < 9; ++d) {
         const uint8_t * p1 = present[d] ? plane1[d] : plane1[0];
@@ -268,7 +271,9 @@ struct TileLaunch
     const TileArgs * args;  // single job (kernarg) ...
     const TileArgs * table; // ... or device table of `count` jobs
     uint32_t count;
-    uint32_t blocksPerJob;  // workgroups covering the largest job: one per run of tiles
+    uint32_t blocksPerJob;  // workgroups covering the largest job: one per run of tiles (= bandsPerJob * runsPerJob)
+    uint32_t bandsPerJob, runsPerJob;
+    uint32_t canvasColumns; // batches: the jobs are the tiles of one canvas, row-major, this many per canvas row (tile_geom.h PkGeom::canvasColumns); 0 = no
     uint32_t stripsPerWave; // NS: 1 or 2 vertically consecutive 256x2 strips per wave (tile = 256 x 8*NS pixels)
     uint32_t tilesPerRun;   // vertically consecutive tiles one workgroup walks through (software-pipelined)
     // packed 16-bit kernels (tile_pk_impl.h): size of the largest job, and the tuning knobs (0 = automatic)

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
-    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipTimeStreamCeilingRGBToYUV", "avifhipTimeStreamCeilingBatch", "avifhipTimeRGBToYUVCycle", "avifhipTimeYUVToRGBBatch", "avifhipTimeGridYUVToRGB", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipTableUploadCount", "avifhipCalcYUVCoefficients",
+    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipTimeStreamCeilingRGBToYUV", "avifhipTimeStreamCeilingBatch", "avifhipTimeStreamCeilingScale", "avifhipTimeRGBToYUVCycle", "avifhipTimeYUVToRGBBatch", "avifhipTimeGridYUVToRGB", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipTableUploadCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
     "avifhipSetDeviceSet", "avifhipSetFarmMinSharePixels", "avifhipGetDeviceSet", "avifhipPlanFarmRows", "avifhipLastFarmWorkers", "avifhipLastFarmTransferBytes",
     "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipTimeRGBImageApplyGainMap", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap",
@@ -113,6 +113,7 @@ def load() -> C.CDLL:
         "avifhipTimeStreamCeiling": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
         "avifhipTimeStreamCeilingRGBToYUV": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
         "avifhipTimeStreamCeilingBatch": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
+        "avifhipTimeStreamCeilingScale": (C.c_double, [P_IMG, P_IMG, i32, i32, vp]),
         "avifhipSetDeviceSet": (i32, [C.POINTER(C.c_int), u32]),
         "avifhipGetDeviceSet": (u32, [C.POINTER(C.c_int), u32]),
         "avifhipSetFarmMinSharePixels": (None, [C.c_uint64]),

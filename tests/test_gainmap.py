@@ -273,6 +273,45 @@ def test_gpu_device_resident(hip_auto_arithmetic):
 
 
 @pytest.mark.gpu
+def test_gpu_device_resident_without_light_levels_and_in_place(hip_auto_arithmetic):
+    """avifhipRGBImageApplyGainMapAsync with clli = NULL returns with its work enqueued (round 5: nothing of the answer depends on the pixels
+    when the fast kernel's precondition rules NaNs out) -- the pixels after a synchronisation are the oracle's; and with the tone-mapped pixels
+    ON TOP of the base pixels (same layout) the call keeps off the fast kernel, whose lanes re-read their neighbours' pixels at row ends."""
+    from libavif_amd import device, native
+
+    o = oracle_lib.oracle()
+    for c in [G.GainMapCase(258, 40, base_depth=8, out_depth=8, out_tc=13, seed=11), G.GainMapCase(515, 33, base_depth=10, out_depth=10, out_tc=16, out_primaries=9, seed=12),
+              G.GainMapCase(1001, 67, base_depth=8, out_depth=10, out_tc=16, out_primaries=9, seed=77)]:
+        ra, pa, ca = run(o.oracleRGBImageApplyGainMap, c, 1)
+        assert ra == 0
+        base = G.make_base(c)
+        gm, keep = G.make_gain_map(c)
+        dbase = device.DeviceRGB(base, upload=True)
+        dgm_img = device.DeviceYUV(keep)
+        gm.image = C.pointer(dgm_img.struct)
+        out = abi.make_rgb(c.w, c.h, c.out_depth, c.out_format, is_float=c.out_float, avoid_libyuv=False)
+        dout = device.DeviceRGB(out, upload=True)
+        diag = abi.avifDiagnostics()
+        wb = c.w * abi.rgb_pixel_size(c.out_format, c.out_depth)
+        rb = hip_auto_arithmetic.avifhipRGBImageApplyGainMapAsync(dbase.struct, c.base_primaries, c.base_tc, C.byref(gm), c.headroom, c.out_primaries,
+                                                                 c.out_tc, dout.struct, None, C.byref(diag), None)
+        assert rb == 0 and native.last_kernel() == "gainmap_apply_fast", (c.ident(), rb, native.last_kernel())
+        native.check(hip_auto_arithmetic.avifhipSynchronize(None))
+        dout.download_into_host()
+        assert np.array_equal(out.pixels[:, :wb], pa[:, :wb]), c.ident()
+        if c.base_depth == c.out_depth and c.base_format == c.out_format:
+            # in place: the output struct points at the base pixels
+            inplace = abi.avifRGBImage()
+            C.memmove(C.byref(inplace), C.byref(dbase.struct), C.sizeof(abi.avifRGBImage))
+            rb = hip_auto_arithmetic.avifhipRGBImageApplyGainMapAsync(dbase.struct, c.base_primaries, c.base_tc, C.byref(gm), c.headroom, c.out_primaries,
+                                                                     c.out_tc, inplace, None, C.byref(diag), None)
+            assert rb == 0 and native.last_kernel() == "gainmap_apply", (c.ident(), rb, native.last_kernel())
+            native.check(hip_auto_arithmetic.avifhipSynchronize(None))
+            dbase.download_into_host()
+            assert np.array_equal(base.pixels[:, :wb], pa[:, :wb]), c.ident() + " in place"
+
+
+@pytest.mark.gpu
 def test_gpu_argument_errors(hip):
     diag = abi.avifDiagnostics()
     fn = hip.avifhipRGBImageApplyGainMap

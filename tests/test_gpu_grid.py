@@ -113,6 +113,22 @@ def test_linked_grids_with_the_seam_pass_forced(hip, monkeypatch):
         hip.avifhipSetArithmetic(1)
 
 
+def test_grids_along_the_canvas_rows(hip):
+    """Round 5: a grid that streams (cfg5's 64 tiles: more than the Infinity Cache holds) is walked along the rows of the CANVAS by the
+    wave-private kernels (tile_geom.h PkGeom::canvasColumns) instead of job by job.  TUNE_CANVAS_ORDER (plan.h) sends small grids the same
+    way: every grid case of this file, linked or not, both arithmetics, tall and short tiles -- the oracle's bytes."""
+    try:
+        for avoid in (True, False):
+            hip.avifhipSetArithmetic(1 if avoid else 0)
+            for strips in (0, 2, 4):
+                hip.avifhipSetTuning(0x2000001 | (strips << 8))
+                for g in (linked_cases(avoid) + cases(avoid))[:: (1 if strips == 0 else 3)]:
+                    run_grid(hip, g)
+    finally:
+        hip.avifhipSetTuning(1)
+        hip.avifhipSetArithmetic(1)
+
+
 @pytest.mark.parametrize("g", cases(True), ids=lambda g: g.ident())
 def test_grid_fp32_path(hip, g):
     run_grid(hip, g)

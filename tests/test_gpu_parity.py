@@ -50,6 +50,71 @@ def test_yuv_to_rgb_tiled_sweep_host(hip):
     assert "yuv2rgb_generic" in kernels  # YCgCo matrices, wider identity copies, untouched alpha bytes still go through the universal kernel
 
 
+def test_fp32_tiles_at_every_launch_geometry(hip):
+    """The fp32 tiles' launch geometry follows the image size too (wave-private kernels with 2 or 4 strips per wave, waves stacked or side by
+    side, per-XCD chunks or raster order; the cooperative runs with 1 or 2 strips and runs of 1-3 tiles): every geometry forced on images the
+    oracle converts in milliseconds (the twin of test_gpu_parity_libyuv.py::test_packed_kernels_at_every_tile_height, which found a geometry
+    that only 8-megapixel 4:2:2 images select computing wrong rows)."""
+    import itertools
+    cases = []
+    for (w, h), depth, yf, up in itertools.product([(777, 70), (512, 64), (1027, 35)], (8, 10, 12), (1, 2, 3, 4), (3, 4)):
+        rd = (8, depth, 16)[(w + yf + up) % 3]
+        cases.append(H.Y2RCase(w, h, yuv_depth=depth, yuv_format=yf, upsampling=up, rgb_format=(abi.AVIF_RGB_FORMAT_RGBA, abi.AVIF_RGB_FORMAT_BGR)[(w + depth) % 2], rgb_depth=rd,
+                               alpha=(w + depth) % 3 == 0, rgb_premultiplied=(w + depth + yf) % 6 == 0, matrix=(1, 6, 9)[(w + depth + yf) % 3], yuv_range=(w + yf) % 2,
+                               seed=(w * 29 + depth * 7 + yf * 5 + up * 3) | 1))
+    cases = [c for c in cases if H.valid_y2r(c)]
+    o = H.oracle_backend()
+    want = [H.run_y2r(o, c) for c in cases]
+    be = H.HipDeviceBackend()
+    bad = []
+    try:
+        hip.avifhipSetTiledKernels(1)
+        tunings = [b | (st << 8) | (wx << 16) | 0x8 for st, wx, b in itertools.product((2, 4), (1, 2, 3), (0, 1))]   # wave-private kernels for every family
+        tunings += [0x4 | b | (st << 8) | (run << 12) for st, run, b in itertools.product((1, 2), (1, 3), (0, 1))]     # cooperative runs
+        for t in tunings:
+            hip.avifhipSetTuning(t)
+            for c, (ro, po) in zip(cases, want):
+                rh, ph = H.run_y2r(be, c)
+                if ro != rh or not np.array_equal(po, ph):
+                    bad.append(f"tuning {t:#x}: {c.ident()} [{native.last_kernel()}]: results {ro}/{rh}" + ("" if ro != rh else " " + H.describe_diff(po, ph)))
+    finally:
+        hip.avifhipSetTuning(1)
+    assert not bad, f"{len(bad)} differ:\n" + "\n".join(bad[:25])
+
+
+def test_universal_kernels_serve_only_the_enumerated_rest(hip):
+    """What still reaches the one-lane-per-pixel kernels once a conversion fills the tiled kernels' 4 x 2 pixel groups (DESIGN.md 7;
+    tests/tools/list_generic.py prints the census: 18 of 1089 conversions of this sweep in the fp32 arithmetic, 28 in the default one): RGB565
+    outside what its two tiled routes cover (alpha arithmetic pending, matrices off the verified divisor list, padded rows of 2-byte
+    pixels), and -- in the integer arithmetic only -- destinations whose alpha libyuv cannot serve: `ignoreAlpha` on a format with alpha
+    (libyuv writes 255, the reference then leaves the channel alone) and a pending alpha (un)multiply on ARGB / ABGR (libyuv attenuates
+    RGBA / BGRA only, so the reference runs its fp32 post-pass over libyuv's bytes).  Anything else through a universal kernel fails here."""
+    from dataclasses import replace
+    try:
+        for arith, avoid in ((1, True), (0, False)):
+            hip.avifhipSetArithmetic(arith)
+            hip.avifhipSetTiledKernels(1)
+            be = H.HipDeviceBackend()
+            generic, total = [], 0
+            for c in H.y2r_sweep(TILED, n_random=600, seed=5):
+                c = replace(c, avoid_libyuv=avoid)
+                res, _ = H.run_y2r(be, c)
+                if res != 0:
+                    continue
+                total += 1
+                if "generic" in native.last_kernel():
+                    generic.append(c)
+            assert total > 900 and len(generic) <= 0.04 * total, (len(generic), total)
+            for c in generic:
+                is565 = c.rgb_format == abi.AVIF_RGB_FORMAT_RGB_565
+                alpha_first = c.rgb_format in (abi.AVIF_RGB_FORMAT_ARGB, abi.AVIF_RGB_FORMAT_ABGR)
+                pending = c.alpha and c.image_premultiplied != c.rgb_premultiplied
+                integer_only = arith == 0 and ((c.ignore_alpha and abi.rgb_format_has_alpha(c.rgb_format)) or (pending and alpha_first))
+                assert is565 or integer_only, (arith, c.ident())
+    finally:
+        hip.avifhipSetArithmetic(1)
+
+
 def test_half_float_and_identity_copy_use_the_tiled_kernels(hip):
     """Half-float RGB(A) outputs (avifRGBImageToF16 fused, src/reformat.c:1419-1443) and the 8-bit identity byte shuffle
     (src/reformat.c:1278-1309) are served by the bandwidth-tuned kernels, byte-exact."""

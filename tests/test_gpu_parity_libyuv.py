@@ -73,6 +73,34 @@ def test_wide_planes_run_in_the_packed_kernels(hip_auto_arithmetic):
     assert not [k for k in kernels if k.startswith("yuv2rgb_fixed_tile<u16") and "alphamul" not in k and "pk16" not in k], kernels
 
 
+def test_packed_kernels_at_every_tile_height(hip_auto_arithmetic):
+    """The packed kernels' launch geometry is chosen by image size (tile_geom.h pkGeometry: 2 or 4 strips per wave, waves stacked or side by
+    side, per-XCD chunks or raster order), so the parity sweeps' small images only ever see one of the geometries.  Every geometry is forced
+    here (plan.h TuningBits) on images small enough for the oracle: all chroma layouts, nearest and bilinear, 8- / 10- / 12-bit planes, with
+    and without alpha, RGBA and RGB.  Round 5 found the 4:2:2 bilinear kernel with four strips per wave -- what 8-megapixel images select --
+    staging two chroma rows too few (rows 6 and 7 of every wave wrong): this test fails on that build."""
+    import itertools
+    cases = []
+    for (w, h), depth, yf, up, fmt in itertools.product([(777, 70), (512, 64), (1027, 35)], (8, 10, 12), (1, 2, 3, 4), (3, 4), (abi.AVIF_RGB_FORMAT_RGBA, abi.AVIF_RGB_FORMAT_RGB)):
+        cases.append(H.Y2RCase(w, h, yuv_depth=depth, yuv_format=yf, upsampling=up, rgb_format=fmt, rgb_depth=8, alpha=(w + depth) % 3 == 0, avoid_libyuv=False,
+                               matrix=(1, 6, 9)[(w + depth + yf) % 3], yuv_range=(w + yf + fmt) % 2, seed=(w * 23 + depth * 7 + yf * 5 + up * 3 + fmt) | 1))
+    o = H.oracle_libyuv_backend()
+    want = [H.run_y2r(o, c) for c in cases]
+    be = H.HipDeviceBackend()
+    bad = []
+    try:
+        for strips, waves_x, bands in itertools.product((2, 4), (1, 2, 3), (0, 1)):
+            hip_auto_arithmetic.avifhipSetTuning(bands | (strips << 8) | (waves_x << 16))
+            for c, (ro, po) in zip(cases, want):
+                rh, ph = H.run_y2r(be, c)
+                if ro != rh or not np.array_equal(po, ph):
+                    bad.append(f"strips {strips} waves-x code {waves_x} bands {bands}: {c.ident()} [{native.last_kernel()}]: results {ro}/{rh}" +
+                               ("" if ro != rh else " " + H.describe_diff(po, ph)))
+    finally:
+        hip_auto_arithmetic.avifhipSetTuning(1)
+    assert not bad, f"{len(bad)} differ:\n" + "\n".join(bad[:25])
+
+
 def test_premultiplied_outputs_fuse_the_attenuate_pass(hip_auto_arithmetic):
     """Images with an alpha plane into premultiplied RGBA / BGRA (Android's bitmaps): libyuv's conversion followed by ARGBAttenuate
     (src/reformat.c:1574-1585 -> src/alpha.c:163), in one pass of the packed kernels -- 8-, 10- and 12-bit planes, every chroma layout."""

@@ -296,6 +296,21 @@ def test_a_grid_job_is_linked_to_the_right_neighbours(geometry):
     for code in range(32):
         bits = [(code >> k) & 1 for k in range(5)]
         assert geometry.geomCheckHaloLink(*bits) == 0, bits
+    # (a tile whose U and V planes are one buffer -- the order is distillArgs' record, not a pointer comparison)
+    geometry.geomCheckHaloLinkSharedPlanes.restype, geometry.geomCheckHaloLinkSharedPlanes.argtypes = C.c_int, [C.c_int]
+    assert geometry.geomCheckHaloLinkSharedPlanes(0) == 0 and geometry.geomCheckHaloLinkSharedPlanes(1) == 0
+
+
+def test_grid_batches_along_the_canvas_rows_visit_every_tile_once(geometry):
+    """tile_geom.h pkBatchWhereOf / pkBatchGrid (round 5): the tiles of one canvas walked along the canvas rows -- grid x = (tile column of the
+    canvas, tile of the job's row), y = tile row inside the job, z = tile row of the canvas -- visit every tile of every job exactly once, for
+    any tile size, grid shape, strips per wave and wave arrangement; one column (or separate buffers) keeps the job-by-job order."""
+    geometry.geomCheckCanvasOrder.restype, geometry.geomCheckCanvasOrder.argtypes = C.c_int, [C.c_uint32] * 6
+    for (w, h) in ((1920, 1080), (512, 512), (256, 34), (1028, 66), (64, 2), (4100, 700)):
+        for (cols, rows) in ((8, 8), (8, 6), (2, 3), (1, 4), (5, 1), (3, 3)):
+            for strips in (0, 2, 4):
+                for waves_x in (0, 1, 2):
+                    assert geometry.geomCheckCanvasOrder(w & ~3, h & ~1, cols, rows, strips, waves_x) == 0, (w, h, cols, rows, strips, waves_x)
 
 
 def test_the_cooperative_kernels_block_order_is_a_permutation(geometry):

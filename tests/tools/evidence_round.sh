@@ -9,7 +9,7 @@
 #   <tag>_e2e.jsonl          host-to-host rows (C ABI and seam B)
 # Everything lands in gpurun_out/; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 mkdir -p gpurun_out
 bash tests/tools/profile_round.sh "$TAG" > "gpurun_out/${TAG}_profile_round.log" 2>&1
@@ -20,7 +20,7 @@ CFGS="cfg2 cfg2_4k cfg2n cfg2_rgb cfg2_565 cfg2_alpha cfg2_premul cfg2_unpremul 
 bash tests/tools/profile_cfgs.sh "$TAG" $CFGS > "gpurun_out/${TAG}_profile_cfgs.log" 2>&1
 # the event-timed rows of those very runs, one file
 for c in $CFGS; do cat "gpurun_out/${TAG}_cfgs/$c.jsonl" 2>/dev/null | grep '^{' ; done > "gpurun_out/${TAG}_cfgs_bench.jsonl"
-bash tests/tools/pmc_cfgs.sh "$TAG" cfg2 cfg2_premul cfg3 cfg4_8k > "gpurun_out/${TAG}_pmc_cfgs.log" 2>&1
+bash tests/tools/pmc_cfgs.sh "$TAG" cfg2 cfg2_premul cfg2_unpremul cfg3 cfg4 cfg4_8k > "gpurun_out/${TAG}_pmc_cfgs.log" 2>&1
 # the gain-map application on its own: kernel durations of the 4K case (same runs as the rows above), its instruction counters, the kernel with one
 # of its parts taken out (tests/tools/gmbench.hip), and the issue rates its instruction mix is priced with
 python - "$TAG" > "gpurun_out/${TAG}_gainmap_kernel_stats.txt" <<'PY'
@@ -40,5 +40,20 @@ cp "gpurun_out/${TAG}_gainmap/digest_pmc.txt" "gpurun_out/${TAG}_gainmap_pmc.txt
   tests/tools/gmbench.bin 4 8 16 32 64 124; echo "== the kernel as the library builds it (no probes), 4K and 4 x 4K rows"; tests/tools/gmbench_np.bin; GM_H=8640 tests/tools/gmbench_np.bin; } > "gpurun_out/${TAG}_gainmap_probes.txt" 2>&1
 tests/tools/valu_rate.bin > "gpurun_out/${TAG}_valu_rate.txt" 2>&1
 python tests/tools/e2e_bench.py > "gpurun_out/${TAG}_e2e.jsonl" 2> "gpurun_out/${TAG}_e2e.err"
+# round 5: the configurations that stream under the tuning knobs with the byte-movement ceiling of each shape (one process: the rows compare), the
+# interleaved A/Bs behind the round's launch rules, HBM traffic and wait counters of cfg3 / cfg4, and the in-process device farm (a C consumer
+# checking itself against the oracle; the host-to-host bench lines of one process driving two workers)
+S=tests/tools/stream_sweep.py
+timeout 600 python $S cfg3 cfg3same f16_444a cfg4 cfg5x64 cfg5grid cfg5grid8 cfg2cold cfg2cold_fp32 cfg2warm cfg2warm_fp32 batch1080 > "gpurun_out/${TAG}_stream_sweep.jsonl" 2> "gpurun_out/${TAG}_stream_sweep.err"
+{ timeout 200 python $S ab cfg2cold 0x1 0x401; timeout 200 python $S ab cfg2warm 0x1 0x401;
+  timeout 300 python $S ab cfg5grid8 0x1 0x1000001 0x1000401 0x201; timeout 300 python $S ab cfg5grid 0x1 0x1000001 0x1000009 0x2000001;
+  timeout 200 python $S ab photo_grid 0x1 0x1000201 0x2000001; } > "gpurun_out/${TAG}_stream_sweep_ab.jsonl" 2>> "gpurun_out/${TAG}_stream_sweep.err"
+bash tests/tools/traffic_cfgs.sh "$TAG" cfg3 cfg4 > "gpurun_out/${TAG}_traffic.log" 2>&1
+rm -rf "gpurun_out/${TAG}_traffic"
+{ for w in "7680 4320 8 cfg2" "15360 8640 10 cfg5" "3840 2160 8 cfg4" "4099 3001 8 cfg2 0" "4099 3001 8 cfg4 0"; do
+    AVIFHIP_DEVICES=0,0 timeout 300 tests/c/farm_check $w; echo "exit $?"; timeout 300 tests/c/farm_check $w; echo "exit $?"; done; } > "gpurun_out/${TAG}_farm_check.txt" 2>&1
+AVIFHIP_BENCH_DEVICES=0,0 timeout 300 python bench.py --in-process --gpus 2 > "gpurun_out/${TAG}_bench_inprocess_cfg2_line.json" 2>> "gpurun_out/${TAG}_bench_default.err"
+AVIFHIP_BENCH_DEVICES=0,0 timeout 300 python bench.py --in-process --gpus 2 --workload cfg5 > "gpurun_out/${TAG}_bench_inprocess_cfg5_line.json" 2>> "gpurun_out/${TAG}_bench_default.err"
+timeout 300 python tests/tools/list_generic.py > "gpurun_out/${TAG}_generic_rest.txt" 2>&1
 rm -rf "gpurun_out/${TAG}_cfgs" "gpurun_out/${TAG}_pmc_cfgs" "gpurun_out/$TAG" "gpurun_out/${TAG}_gainmap"
 ls -la gpurun_out | tail -20

@@ -77,6 +77,7 @@ int geomCheckHaloLink(int swapped, int above, int below, int left, int right)
     TileArgs T;
     memset(&T, 0, sizeof(T));
     T.u = swapped ? p2[0] : p1[0], T.v = swapped ? p1[0] : p2[0];
+    T.planesSwapped = swapped ? 1u : 0u; // (distillArgs' own record: linkHalo no longer compares pointers -- a tile whose U and V planes are one buffer)
     linkHalo(T, p1, p2, above != 0, below != 0, left != 0, right != 0);
     const uint32_t sides = (above ? HALO_ABOVE : 0u) | (below ? HALO_BELOW : 0u) | (left ? HALO_LEFT : 0u) | (right ? HALO_RIGHT : 0u);
     if (T.haloSides != sides)
@@ -92,6 +93,57 @@ int geomCheckHaloLink(int swapped, int above, int below, int left, int right)
     return 0;
 }
 
+
+// ... and with the job's own U and V planes being ONE buffer (a gray image stored as 4:2:0 with shared chroma): the neighbours, whose planes
+// are distinct, must still follow the recorded order
+int geomCheckHaloLinkSharedPlanes(int swapped)
+{
+    static uint8_t arena[64];
+    const uint8_t *p1[9], *p2[9];
+    for (int d = 0; d < 9; ++d)
+        p1[d] = arena + 2 * d, p2[d] = arena + 2 * d + 1;
+    p2[0] = p1[0];
+    TileArgs T;
+    memset(&T, 0, sizeof(T));
+    T.u = T.v = p1[0];
+    T.planesSwapped = swapped ? 1u : 0u;
+    linkHalo(T, p1, p2, true, true, true, true);
+    for (int d = 1; d < 9; ++d)
+        if (T.halo.at[d].u != (swapped ? p2[d] : p1[d]) || T.halo.at[d].v != (swapped ? p1[d] : p2[d]))
+            return 2 + d;
+    return 0;
+}
+
+// batches along the rows of a canvas (tile_geom.h PkGeom::canvasColumns): every (job, tile) of every job exactly once over the launch's grid
+int geomCheckCanvasOrder(uint32_t w4, uint32_t h2, uint32_t columns, uint32_t rows, uint32_t pkStrips, uint32_t wavesXLog2)
+{
+    TileLaunch L;
+    memset(&L, 0, sizeof(L));
+    static const TileArgs table[1] = {};
+    L.table = table, L.count = columns * rows, L.canvasColumns = columns;
+    L.pkStrips = pkStrips, L.wavesXLog2 = wavesXLog2, L.chunkRows = 1;
+    uint32_t nsw = 0, blocks = 0;
+    PkGeom g;
+    pkGeometry(L, w4, h2, &nsw, &g, &blocks);
+    if (columns > 1 && g.canvasColumns != columns)
+        return 1;
+    const dim3 grid = pkBatchGrid(g, blocks, L.count);
+    std::vector<uint32_t> seen((size_t)L.count * g.nTiles, 0);
+    for (uint32_t bz = 0; bz < grid.z; ++bz)
+        for (uint32_t by = 0; by < grid.y; ++by)
+            for (uint32_t bx = 0; bx < grid.x; ++bx) {
+                const BatchWhere w = pkBatchWhereOf(bx, by, bz, g);
+                if (w.job >= L.count)
+                    return 2;
+                if (w.tile >= g.nTiles)
+                    continue; // (padding of the chunked order: leaves at once)
+                ++seen[(size_t)w.job * g.nTiles + w.tile];
+            }
+    for (uint32_t v : seen)
+        if (v != 1)
+            return 3;
+    return 0;
+}
 
 // a turned launch whose tile grid starts `shiftStrips` strips above the rectangle (tile_impl.h launchSoloMapped): every strip still once
 int geomCheckPkShifted(uint32_t w4, uint32_t h2, uint32_t pkStrips, uint32_t shiftStrips)

@@ -98,6 +98,19 @@ def run(name):
             rgb.struct.isFloat = 1
             pairs.append((device.DeviceYUV(img), device.DeviceRGB(rgb)))
         sweep_y2r("f16_444a (2 frames cycled)", pairs, 16.0 * 7680 * 4320, tunings=[("default", 0x1), ("bands,4 strips (rounds 2-4)", 0x401), ("raster,4 waves wide,2 strips + streaming loads", 0x30240)], stream_env=False)
+    elif name == "batch1080":
+        # sequences of small frames: N 1080p frames (8-bit 4:2:0 -> RGBA8, API defaults) per launch through avifhipImageYUVToRGBBatchAsync, against
+        # one launch per frame -- where the batch starts to pay (a 1080p frame alone is launch plus one load -> stage -> compute -> store chain)
+        pairs = [y2r(1920, 1080, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, seed=k) for k in range(16)]
+        n, imgs, rgbs = arr(pairs)
+        alg = 5.5 * 1920 * 1080
+        emit("1080p, one frame per launch (16 frames cycled)", "avifhipImageYUVToRGBAsync", burst(lib.avifhipTimeYUVToRGBCycle, n, imgs, rgbs), alg)
+        emit("1080p, one frame per launch (16 frames cycled)", "ceiling", burst(lib.avifhipTimeStreamCeiling, n, imgs, rgbs), alg)
+        for k in (2, 4, 8, 16):
+            ms = burst(lib.avifhipTimeYUVToRGBBatch, k, imgs, rgbs, None)
+            emit(f"1080p, {k} frames per launch", "avifhipImageYUVToRGBBatchAsync, per frame", ms / k, alg, us_per_launch=round(ms * 1e3, 2))
+            ms = burst(lib.avifhipTimeStreamCeilingBatch, k, imgs, rgbs)
+            emit(f"1080p, {k} frames per launch", "ceiling, per frame", ms / k, alg, us_per_launch=round(ms * 1e3, 2))
     elif name == "cfg2_4k":
         pairs = [y2r(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, seed=k) for k in range(4)]
         sweep_y2r("cfg2_4k (4 frames cycled)", pairs, 5.5 * 3840 * 2160)
@@ -152,7 +165,7 @@ def run(name):
             rgbs = (C.POINTER(abi.avifRGBImage) * 64)(*[C.pointer(v.struct) for v in views])
             emit(name, "ceiling", burst(lib.avifhipTimeStreamCeilingBatch, 64, timgs, rgbs), alg)
             grid = native.avifhipGrid(8, 8, 15360, 8640)
-            for tname, bits in TUNINGS[:6]:
+            for tname, bits in TUNINGS[:6] + [("job by job (TUNE_JOB_MAJOR: rounds 1-4)", 0x1000001), ("default again", 0x1), ("job by job again", 0x1000001)]:
                 lib.avifhipSetTuning(bits)
                 emit(name, tname, burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas.struct), alg, tuning=hex(bits))
             lib.avifhipSetTuning(1)
@@ -164,6 +177,85 @@ def run(name):
         raise SystemExit("unknown configuration " + name)
 
 
+def ab(name, tunings, rounds=5):
+    """Interleaved A/B of tuning words on one configuration: `rounds` passes over the list, every entry preheated and timed each pass; the
+    median per entry -- run-order effects (clock state after an ALU-heavy kernel: +-4 %) average out instead of favouring the last entry."""
+    lib.avifhipSetArithmetic(0)
+    if name in ("cfg5grid", "cfg5grid8", "photo_grid"):
+        return ab_grid(name, tunings, rounds)
+    fp32 = name.endswith("_fp32")
+    base = name[:-5] if fp32 else name
+    frames = {"cfg2cold": 12, "cfg2warm": 4, "cfg2_4k": 4, "cfg2_1080p": 4, "cfg2_4k_cold": 24}[base]
+    w, h = {"cfg2cold": (7680, 4320), "cfg2warm": (7680, 4320), "cfg2_4k": (3840, 2160), "cfg2_4k_cold": (3840, 2160), "cfg2_1080p": (1920, 1080)}[base]
+    pairs = [y2r(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=fp32, seed=k) for k in range(frames)]
+    n, imgs, rgbs = arr(pairs)
+    got = {t: [] for t in tunings}
+    for _ in range(rounds):
+        for t in tunings:
+            lib.avifhipSetTuning(t)
+            got[t].append(burst(lib.avifhipTimeYUVToRGBCycle, n, imgs, rgbs))
+    lib.avifhipSetTuning(1)
+    for t in tunings:
+        emit(f"{name} ({frames} frames cycled), interleaved x{rounds}", hex(t), median(got[t]), 5.5 * w * h, all_us=[round(x * 1e3, 2) for x in got[t]])
+
+
+def ab_grid(name, tunings, rounds):
+    """... for the grid entry point: cfg5's 64 tiles of 1080p 10-bit into one RGBA(10) / RGBA8 canvas, or the 12-megapixel photograph of 48 tiles"""
+    if name == "photo_grid":
+        tw, th, cols, rows_, cw, ch, ydepth, depth = 512, 512, 8, 6, 4032, 3024, 8, 8
+    else:
+        tw, th, cols, rows_, cw, ch, ydepth, depth = 1920, 1080, 8, 8, 15360, 8640, 10, (8 if name.endswith("8") else 10)
+    tiles = []
+    for t in range(cols * rows_):
+        img = abi.make_yuv(tw, th, ydepth, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1)
+        synth.fill_yuv(img, 0x12345678 + t)
+        tiles.append(device.DeviceYUV(img))
+    timgs = (C.POINTER(abi.avifImage) * len(tiles))(*[C.pointer(t.struct) for t in tiles])
+    canvas = device.DeviceRGB(abi.make_rgb(cw, ch, depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False))
+    grid = native.avifhipGrid(rows_, cols, cw, ch)
+    alg = ((3.0 if ydepth > 8 else 1.5) + (8.0 if depth > 8 else 4.0)) * cw * ch
+    got, kernels = {t: [] for t in tunings}, {}
+    for _ in range(rounds):
+        for t in tunings:
+            lib.avifhipSetTuning(t)
+            got[t].append(burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas.struct))
+            kernels[t] = native.last_kernel()
+    lib.avifhipSetTuning(1)
+    for t in tunings:
+        print(json.dumps({"config": f"{name}, interleaved x{rounds}", "knob": hex(t), "us": round(median(got[t]) * 1e3, 2), "frac": round(alg / (median(got[t]) * 1e-3) / 1e9 / PEAK, 4),
+                          "kernel": kernels[t], "all_us": [round(x * 1e3, 2) for x in got[t]]}), flush=True)
+
+
+def run_only(name, launches=400):
+    """`run <cfg3|cfg4>`: nothing but `launches` launches of the configuration's default kernel over its cycled frames -- what the counter passes
+    of tests/tools/traffic_cfgs.sh profile (FETCH_SIZE / WRITE_SIZE per dispatch against the algorithmic bytes)."""
+    lib.avifhipSetArithmetic(0)
+    lib.avifhipSetTuning(1)
+    if name == "cfg3":
+        pairs = [y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, seed=k) for k in range(2)]
+        n, imgs, rgbs = arr(pairs)
+        ms = lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 20, launches // 4, None)
+        emit("cfg3 (2 frames cycled)", "run", ms, 16.0 * 7680 * 4320, algorithmic_read_bytes=8 * 7680 * 4320, algorithmic_write_bytes=8 * 7680 * 4320)
+    elif name == "cfg4":
+        enc = []
+        for k in range(8):
+            rgb = abi.make_rgb(3840, 2160, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
+            synth.fill_rgb(rgb, 0x12345678 + k % 2, opaque=True)
+            img = abi.make_yuv(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, with_alpha=True)
+            enc.append((device.DeviceYUV(img, upload=False), device.DeviceRGB(rgb, upload=True)))
+        n, imgs, rgbs = arr(enc)
+        ms = lib.avifhipTimeRGBToYUVCycle(n, imgs, rgbs, 20, launches, None)
+        emit("cfg4 (8 frames cycled)", "run", ms, 6.5 * 3840 * 2160, algorithmic_read_bytes=4 * 3840 * 2160, algorithmic_write_bytes=int(2.5 * 3840 * 2160))
+    else:
+        raise SystemExit("run: cfg3 or cfg4")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "run":
+        run_only(sys.argv[2])
+        sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[1] == "ab":
+        ab(sys.argv[2], [int(x, 0) for x in sys.argv[3:]])
+        sys.exit(0)
     for n in sys.argv[1:] or ["cfg3", "cfg4", "cfg5x64", "cfg5grid"]:
         run(n)
