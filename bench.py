@@ -85,6 +85,10 @@ def parse_args():
                          "10-bit tiles per step, its tiles sharded over the ranks (strong scaling, BASELINE.json configs[4])")
     ap.add_argument("--arithmetic", choices=("integer", "fp32"), default="integer",
                     help="integer: API defaults, libyuv's fixed point (default); fp32: rgb.avoidLibYUV = 1, libavif's built-in path")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the 8K frames of the headline (timed regions, kernel timings of both arithmetics warm / cold / same frame, the live ceiling): no 4K planes, no "
+                         "other configurations, no gain map -- profiling runs: since round 5 one kernel instantiation serves 8K, 4K and 1080p frames, and a profiler's "
+                         "per-kernel average over the whole bench would mix their durations and byte counts")
     ap.add_argument("--in-process", action="store_true",
                     help="ONE process drives all --gpus N devices through the library's own device farm (avifhipSetDeviceSet: one worker thread, context and host "
                          "link per GPU, no torch, no launcher): host-resident frames / canvas in, host-resident pixels out -- what an unmodified libavif over "
@@ -367,7 +371,7 @@ def main():
         return out
 
     frames = make_frames(WIDTH, HEIGHT, DEEP_FRAMES)
-    frames_4k = make_frames(WIDTH // 2, HEIGHT // 2, FRAMES_IN_FLIGHT)  # the north star's second plane size (3840x2160)
+    frames_4k = [] if args.headline_only else make_frames(WIDTH // 2, HEIGHT // 2, FRAMES_IN_FLIGHT)  # the north star's second plane size (3840x2160)
     n_streams = max(1, min(args.streams, FRAMES_IN_FLIGHT))
     streams = [lib.avifhipStreamCreate() for _ in range(max(n_streams, 2))]
     if any(not s for s in streams):
@@ -408,7 +412,7 @@ def main():
     # ---- kernels alone: average launch duration from HIP events on the launch stream, single stream, back to back ----
     n4, imgs4, rgbs4 = _cycle_args(frames[:FRAMES_IN_FLIGHT])
     nd, imgsd, rgbsd = _cycle_args(frames)
-    nk, imgsk, rgbsk = _cycle_args(frames_4k)
+    nk, imgsk, rgbsk = _cycle_args(frames_4k) if frames_4k else (0, None, None)
 
     def burst(fn, *a):
         # 40 ms of the SAME kernel first: after a change of kernel the first ~10 ms of launches run up to 25 % slower (tests/tools/
@@ -435,7 +439,7 @@ def main():
         t["kernel"] = native.last_kernel()
         t["cold"] = burst(lib.avifhipTimeYUVToRGBCycle, nd, imgsd, rgbsd)
         t["same"] = burst(lib.avifhipTimeYUVToRGB, frames[0][0].struct, frames[0][1].struct)
-        t["4k"] = burst(lib.avifhipTimeYUVToRGBCycle, nk, imgsk, rgbsk)
+        t["4k"] = burst(lib.avifhipTimeYUVToRGBCycle, nk, imgsk, rgbsk) if nk else None
         timings[fam] = t
     set_arithmetic(integer)
     main_fam, other_fam = ("integer", "fp32") if integer else ("fp32", "integer")
@@ -445,7 +449,7 @@ def main():
     ceil_ms_stream = burst(lib.avifhipTimeStreamCeiling, n4, imgs4, rgbs4)
     ceil_ms_deep = burst(lib.avifhipTimeStreamCeiling, nd, imgsd, rgbsd)
 
-    more = {} if (args.dry_run or rank != 0) else measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k)
+    more = {} if (args.dry_run or rank != 0 or args.headline_only) else measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k)
     set_arithmetic(integer)
     mp_per_step = WIDTH * HEIGHT / 1e6
     value = mp_per_step * args.steps * world / elapsed
@@ -529,7 +533,7 @@ def main():
                       what="rgb.avoidLibYUV = 1: libavif's built-in fp32 arithmetic (what the reference compiled from its own sources computes), same 8K frames"),
         "integer": block(timings["integer"]["warm"], kernel=timings["integer"]["kernel"], cold=block(timings["integer"]["cold"]),
                          what="API defaults: libyuv's fixed point (what a stock libavif computes), same 8K frames"),
-        "planes_4k": {
+        "planes_4k": None if args.headline_only else {
             "what": f"3840x2160 planes, same configuration, {FRAMES_IN_FLIGHT} frames cycled, kernel alone ({int(ALGORITHMIC_BYTES_PER_PIXEL * px4k)} B per launch)",
             "integer": block(timings["integer"]["4k"], px4k),
             "fp32": block(timings["fp32"]["4k"], px4k),

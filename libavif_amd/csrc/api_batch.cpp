@@ -130,7 +130,7 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
     // Tiles of one canvas whose every pixel goes through the tiled kernels: the jobs are linked to their neighbours and the seam-aware build
     // of the family filters chroma across the seams in the same launch (tile_impl.h TILE_SEAMS).  With leftover columns / rows -- converted
     // by the universal kernel from each job's own window -- the caller's seam pass still runs.
-    const bool linked = neighbours && allTiled && !restW && !restH && tileBatchLinksNeighbours(representative, count, maxW, maxH, linkForced);
+    const bool linked = neighbours && allTiled && !restW && !restH && tileBatchLinksNeighbours(representative, count, maxW, maxH, linkForced, canvasColumns);
     if (linked) {
         for (uint32_t k = 0; k < count; ++k)
             linkTileBatchHalo(pinned, k, neighbours[k]);

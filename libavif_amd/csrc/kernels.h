@@ -61,7 +61,7 @@ struct TileNeighbours
 };
 // whether a batch of linkable jobs is to be linked: its kernel family filters chroma at all, and one launch measured faster than the tile
 // batch followed by the seam pass for this family and size (`forced`: -1 = by that measurement, 0 = never, 1 = whenever chroma is filtered)
-bool tileBatchLinksNeighbours(const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW, uint32_t maxH, int forced);
+bool tileBatchLinksNeighbours(const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW, uint32_t maxH, int forced, uint32_t canvasColumns = 0);
 // after fillTileBatchTable; launchYuvToRgbTileBatch is then told `neighboursLinked`
 void linkTileBatchHalo(void * hostTable, uint32_t job, const TileNeighbours & neighbours);
 hipError_t launchGrayChromaFill(const RgbToYuvPlan & plan, hipStream_t stream);

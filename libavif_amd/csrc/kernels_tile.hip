@@ -337,7 +337,8 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
     // workgroup: two strips per wave (256 x 16 tiles) at every size.  Four (256 x 32) were the rule from 2048 workgroups up until round 4; since
     // the workgroup shares its neighbourhood the taller tile buys nothing when the planes are cache-resident (8K, 4 frames cycled: 28.14 / 28.24
     // us, interleaved A/B) and costs 2.8 % when they stream (12 frames cycled: 34.98 -> 34.01 us; profiles/r05_stream_sweep_ab.jsonl)
-    if (k.fixedPoint && !k.wideYuv && k.bilinear && k.sub == SUB_420 && L.pkStrips == 0)
+    // (not behind a pixel map: quarter turns transpose 32-row tiles through LDS -- 16-row ones cost them 38 -> 63 us at 8K)
+    if (k.fixedPoint && !k.wideYuv && k.bilinear && k.sub == SUB_420 && L.pkStrips == 0 && !k.mapped)
         L.pkStrips = 2;
     const bool geometryForced = (plan.tuning & (0xfu << TUNE_STRIPS_SHIFT | 3u << TUNE_WAVESX_SHIFT | 0xfu << TUNE_CHUNK_SHIFT | TUNE_STREAM_LOADS)) != 0 ||
                                 (plan.tuning & TUNE_XCD_BANDS) == 0;
@@ -383,7 +384,7 @@ void fillTileBatchTable(const YuvToRgbPlan * plans, uint32_t count, void * hostT
 // photograph in 48 tiles 21.1 -> 12.9 us, cfg5's 64 tiles -> RGBA8 173.9 -> 165.9; the fp32 kernels pay for them with a step of occupancy
 // (the cooperative 10-bit kernel: 76 -> 86 registers), so they win where the second launch is a large part of the call (the photograph:
 // 21.4 -> 14.3 us) and lose where it is not (cfg5 -> RGBA(10): 263-269 -> 273 us; -> RGBA8 177.5 -> 183.9).
-bool tileBatchLinksNeighbours(const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW, uint32_t maxH, int forced)
+bool tileBatchLinksNeighbours(const YuvToRgbPlan & representative, uint32_t count, uint32_t maxW, uint32_t maxH, int forced, uint32_t canvasColumns)
 {
     const TileKey k = keyFor(representative);
     if (!k.bilinear)
@@ -391,7 +392,15 @@ bool tileBatchLinksNeighbours(const YuvToRgbPlan & representative, uint32_t coun
     if (forced >= 0)
         return forced != 0;
     const bool packed = k.fixedPoint && (!k.hasMul || (k.attenuate && !k.mapped)) && (!k.wideYuv || (representative.tuning & TUNE_COOPERATIVE) == 0);
-    return packed || (uint64_t)maxW * maxH * count <= ((uint64_t)32 << 20);
+    if (packed || (uint64_t)maxW * maxH * count <= ((uint64_t)32 << 20))
+        return true;
+    // Round 5: large fp32 grids that walk along the canvas rows in the wave-private kernels (launchYuvToRgbTileBatch) read across the seams
+    // themselves too -- in that order one launch beats the tile batch + seam pass (cfg5's canvas, interleaved on one box: 251.0 against 259.3
+    // us), where the cooperative runs job by job had lost to it (283.2 against 279.6: round 4's rule, which TUNE_JOB_MAJOR / TUNE_COOPERATIVE keep)
+    const double bytesPerPixel = (double)representative.yuv.chanBytes * (k.sub == SUB_444 ? 3.0 : k.sub == SUB_422 ? 2.0 : k.sub == SUB_420 ? 1.5 : 1.0) +
+                                 (double)representative.rgb.pixBytes + (k.alphaPlane || k.hasMul ? (double)representative.yuv.chanBytes : 0.0);
+    const bool streams = (double)maxW * maxH * count * bytesPerPixel > 192.0 * 1048576.0;
+    return canvasColumns > 1 && streams && !k.fixedPoint && !k.mapped && (representative.tuning & (TUNE_COOPERATIVE | TUNE_JOB_MAJOR)) == 0;
 }
 
 void linkTileBatchHalo(void * hostTable, uint32_t job, const TileNeighbours & n)

@@ -125,8 +125,12 @@ def util_ref():
 
 
 def pillow():
+    """The libyuv-enabled libavif binary the integer-path oracle is pinned against: Pillow's bundled libavif 1.4.1 + libyuv 1922 -- or, when
+    AVIFHIP_LIBYUV_BINARY names one, a libavif built with another libyuv (tests/tools/repin_libyuv.sh builds the reference with the pinned
+    1949 where a libyuv checkout exists: the re-pin is then `AVIFHIP_LIBYUV_BINARY=... pytest tests/test_libyuv_oracle.py`)."""
     if "pillow" not in _cache:
-        hits = sorted(glob.glob("/usr/local/lib/python3*/dist-packages/pillow.libs/libavif-*.so*"))
+        override = os.environ.get("AVIFHIP_LIBYUV_BINARY")
+        hits = [override] if override else sorted(glob.glob("/usr/local/lib/python3*/dist-packages/pillow.libs/libavif-*.so*"))
         lib = None
         if hits:
             try:

@@ -78,6 +78,16 @@ def test_cfg2_nearest_and_padded_rows(hip_auto_arithmetic):
     _y2r(be, H.oracle_libyuv_backend(), replace(CFG2, avoid_libyuv=False, row_pad=64, seed=99))
 
 
+def test_8k_frames_of_the_other_chroma_layouts_default_arithmetic(hip_auto_arithmetic):
+    """The headline's frame size in 4:2:2 and 4:4:4, 8- and 10-bit planes, bilinear: the launch geometry a frame of this size selects is not the
+    one the parity sweeps' small images see (round 5: 4:2:2 with four strips per wave staged two chroma rows too few -- wrong rows in every
+    4:2:2 image of ~8 megapixels and more since round 2, found only when another rule forced that geometry on a small grid)."""
+    be = H.HipDeviceBackend()
+    for depth, yf, fmt in ((8, 2, abi.AVIF_RGB_FORMAT_RGBA), (10, 2, abi.AVIF_RGB_FORMAT_BGRA), (8, 1, abi.AVIF_RGB_FORMAT_RGB), (12, 3, abi.AVIF_RGB_FORMAT_RGBA)):
+        k = _y2r(be, H.oracle_libyuv_backend(), replace(CFG2, yuv_depth=depth, yuv_format=yf, rgb_format=fmt, avoid_libyuv=False, seed=depth * 31 + yf))
+        assert "tile<" in k, k
+
+
 def test_cfg3(hip):
     for name, be in _backends():
         _y2r(be, H.oracle_backend(), CFG3)

@@ -172,7 +172,8 @@ def run(name):
             deep = name == "cfg2_keep16"
             pair = y2r(7680, 4320, 10 if deep else 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 10 if deep else 8, avoid=avoid)
             pair[1].struct.ignoreAlpha = 1
-            px, bpp, ms = 7680 * 4320, (11.0 if deep else 5.5), time_y2r(pair)
+            # (bytes: the planes + the destination pixels READ for their alpha + the pixels written: 1.5 + 4 + 4, or 3 + 8 + 8)
+            px, bpp, ms = 7680 * 4320, (19.0 if deep else 9.5), time_y2r(pair)
         elif name == "cfg2_rgb":
             # 3-byte pixels (what avifdec hands to its JPEG / opaque PNG writers): 8K 8-bit 4:2:0 -> RGB8, bilinear, 1.5 + 3 B/px
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB)

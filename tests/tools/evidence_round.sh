@@ -46,7 +46,7 @@ python tests/tools/e2e_bench.py > "gpurun_out/${TAG}_e2e.jsonl" 2> "gpurun_out/$
 S=tests/tools/stream_sweep.py
 timeout 600 python $S cfg3 cfg3same f16_444a cfg4 cfg5x64 cfg5grid cfg5grid8 cfg2cold cfg2cold_fp32 cfg2warm cfg2warm_fp32 batch1080 > "gpurun_out/${TAG}_stream_sweep.jsonl" 2> "gpurun_out/${TAG}_stream_sweep.err"
 { timeout 200 python $S ab cfg2cold 0x1 0x401; timeout 200 python $S ab cfg2warm 0x1 0x401;
-  timeout 300 python $S ab cfg5grid8 0x1 0x1000001 0x1000401 0x201; timeout 300 python $S ab cfg5grid 0x1 0x1000001 0x1000009 0x2000001;
+  timeout 300 python $S ab cfg5grid8 0x1 0x1000001 0x1000201 0x201; timeout 300 python $S ab cfg5grid 0x1 0x1000001 0x1000009 0x2000001;
   timeout 200 python $S ab photo_grid 0x1 0x1000201 0x2000001; } > "gpurun_out/${TAG}_stream_sweep_ab.jsonl" 2>> "gpurun_out/${TAG}_stream_sweep.err"
 bash tests/tools/traffic_cfgs.sh "$TAG" cfg3 cfg4 > "gpurun_out/${TAG}_traffic.log" 2>&1
 rm -rf "gpurun_out/${TAG}_traffic"

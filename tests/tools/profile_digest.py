@@ -46,7 +46,7 @@ def main():
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     stats = kernel_stats(os.path.join(src, "stats"))
     total = sum(sum(v) for v in stats.values()) or 1
-    lines = ["rocprofv3 --kernel-trace --stats -- python bench.py --steps 1000 --warmup 100 --repeats 3 --streams 1 --no-cpu-baseline",
+    lines = ["rocprofv3 --kernel-trace --stats -- python bench.py --steps 1000 --warmup 100 --repeats 3 --streams 1 --no-second-stream-count --no-cpu-baseline --headline-only",
              f"{'kernel':110s} {'calls':>6s} {'total_us':>12s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}"]
     dominant = None
     for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1])):

@@ -12,8 +12,8 @@ R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 1000 --warmup 100 --repeats 3 --streams 1 --no-second-stream-count --no-cpu-baseline"
-SHORT="python $R/bench.py --steps 300 --warmup 100 --repeats 1 --preheat-ms 50 --streams 1 --no-second-stream-count --no-cpu-baseline"   # counter passes: smaller databases
+BENCH="python $R/bench.py --steps 1000 --warmup 100 --repeats 3 --streams 1 --no-second-stream-count --no-cpu-baseline --headline-only"
+SHORT="python $R/bench.py --steps 300 --warmup 100 --repeats 1 --preheat-ms 50 --streams 1 --no-second-stream-count --no-cpu-baseline --headline-only"   # counter passes: smaller databases
 $BENCH > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/stats.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- $SHORT > /dev/null 2> "$OUT/pmc_fetch.log"

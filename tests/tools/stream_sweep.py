@@ -214,15 +214,21 @@ def ab_grid(name, tunings, rounds):
     canvas = device.DeviceRGB(abi.make_rgb(cw, ch, depth, abi.AVIF_RGB_FORMAT_RGBA, upsampling=BIL, avoid_libyuv=False, allocate=False))
     grid = native.avifhipGrid(rows_, cols, cw, ch)
     alg = ((3.0 if ydepth > 8 else 1.5) + (8.0 if depth > 8 else 4.0)) * cw * ch
+    # (tuning words at or above 2^32 carry AVIFHIP_GRID_SEAM_PASS in bits 32-33: 1 = "0" (link: tiles and seams in one launch), 2 = "1" (seam pass))
     got, kernels = {t: [] for t in tunings}, {}
     for _ in range(rounds):
         for t in tunings:
-            lib.avifhipSetTuning(t)
+            lib.avifhipSetTuning(t & 0xffffffff)
+            seam = {1: "0", 2: "1"}.get(t >> 32)
+            if seam is not None:
+                os.environ["AVIFHIP_GRID_SEAM_PASS"] = seam
             got[t].append(burst(lib.avifhipTimeGridYUVToRGB, C.byref(grid), timgs, None, 0, canvas.struct))
             kernels[t] = native.last_kernel()
+            os.environ.pop("AVIFHIP_GRID_SEAM_PASS", None)
     lib.avifhipSetTuning(1)
     for t in tunings:
-        print(json.dumps({"config": f"{name}, interleaved x{rounds}", "knob": hex(t), "us": round(median(got[t]) * 1e3, 2), "frac": round(alg / (median(got[t]) * 1e-3) / 1e9 / PEAK, 4),
+        knob = hex(t & 0xffffffff) + {0: "", 1: " one launch (AVIFHIP_GRID_SEAM_PASS=0)", 2: " seam pass (AVIFHIP_GRID_SEAM_PASS=1)"}[t >> 32]
+        print(json.dumps({"config": f"{name}, interleaved x{rounds}", "knob": knob, "us": round(median(got[t]) * 1e3, 2), "frac": round(alg / (median(got[t]) * 1e-3) / 1e9 / PEAK, 4),
                           "kernel": kernels[t], "all_us": [round(x * 1e3, 2) for x in got[t]]}), flush=True)
 
 
