@@ -278,12 +278,18 @@ static std::vector<avifCropRect> coalesceRects(const avifCropRect * rects, uint3
 
 // ... and a tall job is cut into pieces of ~2 megapixels (bandRowsFor: multiples of 32 rows), so that the upload of one piece, the kernel of
 // the previous and the download of the one before overlap inside a job too (a farm worker often has ONE job: its tile row)
+// -- but only as far as the call (or the farm worker's share of it) lacks jobs to overlap: with four jobs or more the pipeline is full as it
+// is, and more, smaller copies only cost (cfg5's canvas on one device, 8 full-width jobs: 20.8 ms; cut into 56 pieces: 27.1 ms)
 static std::vector<avifCropRect> pipelinePieces(const avifCropRect * jobs, uint32_t count)
 {
     std::vector<avifCropRect> pieces;
+    const uint32_t wanted = count ? (4u + count - 1) / count : 1u; // pieces per job that bring the call to about four
     for (uint32_t k = 0; k < count; ++k) {
         const avifCropRect & rc = jobs[k];
-        const uint32_t rows = bandRowsFor(rc.width, rc.height);
+        const uint32_t finest = bandRowsFor(rc.width, rc.height); // no piece below ~2 megapixels
+        uint32_t rows = (rc.height + wanted - 1) / wanted;
+        rows = (rows + 31u) & ~31u;
+        rows = rows < finest ? finest : rows;
         for (uint32_t y = 0; y < rc.height; y += rows)
             pieces.push_back({ rc.x, rc.y + y, rc.width, (rc.height - y > rows) ? rows : rc.height - y });
     }
@@ -303,8 +309,19 @@ extern "C" avifResult avifhipPlanRectTransfers(const avifImage * canvas, const a
         if (pr != AVIF_RESULT_OK)
             return pr;
     }
+    // (the pieces are cut per farm worker when a device set is active: the same shares avifhipImageYUVToRGBRects will hand out)
     const std::vector<avifCropRect> coalesced = coalesceRects(rects, count);
-    for (const avifCropRect & rc : pipelinePieces(coalesced.data(), (uint32_t)coalesced.size())) {
+    std::vector<avifCropRect> pieces;
+    const uint32_t workers = farmWorkers();
+    if (workers >= 2 && coalesced.size() >= 2) {
+        for (const FarmShare & share : planFarmJobs((uint32_t)coalesced.size(), workers)) {
+            const std::vector<avifCropRect> part = pipelinePieces(coalesced.data() + share.begin, share.end - share.begin);
+            pieces.insert(pieces.end(), part.begin(), part.end());
+        }
+    } else {
+        pieces = pipelinePieces(coalesced.data(), (uint32_t)coalesced.size());
+    }
+    for (const avifCropRect & rc : pieces) {
         YuvToRgbPlan plan;
         const avifResult pr = makeYuvToRgbPlan(canvas, rgbCanvas, &rc, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan);
         if (pr != AVIF_RESULT_OK)

@@ -271,6 +271,30 @@ def test_rgb_to_yuv_tiled_sweep_device(hip):
     assert kernels.get("rgb2yuv_tile", 0) > 100, kernels
 
 
+def test_rgb_to_yuv_tiles_at_every_strip_count(hip, monkeypatch):
+    """The encode tiles take 1, 2 or 4 strips per wave by image size (kernels_r2y_tile.hip: 2 from 8K frames up) and per-XCD bands or raster
+    order: each forced on the sweep's small images (AVIFHIP_R2Y_SPW, plan.h TUNE_R2Y_RASTER), both arithmetics' kernels -- the encode-side
+    twin of test_fp32_tiles_at_every_launch_geometry."""
+    from dataclasses import replace
+    hip.avifhipSetTiledKernels(1)
+    cases = H.r2y_sweep([(777, 70), (512, 64), (1027, 35)], n_random=120, seed=83)
+    try:
+        for spw in ("1", "2", "4"):
+            monkeypatch.setenv("AVIFHIP_R2Y_SPW", spw)
+            for tuning in (0x1, 0x81):
+                hip.avifhipSetTuning(tuning)
+                kernels = _compare_r2y(H.HipDeviceBackend(), H.oracle_backend(), cases, padding=False)
+                assert kernels.get("rgb2yuv_tile", 0) > 40, (spw, tuning, kernels)
+        hip.avifhipSetArithmetic(0)  # libyuv's fixed-point encode kernel (BT.601) under the same knobs
+        fx = [replace(c, avoid_libyuv=False) for c in H.libyuv_r2y_cases([(777, 70), (512, 64)], n_random=80, seed=89)]
+        for spw in ("1", "2", "4"):
+            monkeypatch.setenv("AVIFHIP_R2Y_SPW", spw)
+            _compare_r2y(H.HipDeviceBackend(), H.oracle_libyuv_backend(), fx, padding=False)
+    finally:
+        hip.avifhipSetTuning(1)
+        hip.avifhipSetArithmetic(1)
+
+
 def test_rgb_to_yuv_generic_kernels_on_tiled_sizes(hip):
     hip.avifhipSetTiledKernels(0)
     try:

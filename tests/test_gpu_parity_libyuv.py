@@ -89,12 +89,16 @@ def test_packed_kernels_at_every_tile_height(hip_auto_arithmetic):
     be = H.HipDeviceBackend()
     bad = []
     try:
-        for strips, waves_x, bands in itertools.product((2, 4), (1, 2, 3), (0, 1)):
-            hip_auto_arithmetic.avifhipSetTuning(bands | (strips << 8) | (waves_x << 16))
+        tunings = [(f"strips {st} waves-x code {wx} bands {b}", b | (st << 8) | (wx << 16)) for st, wx, b in itertools.product((2, 4), (1, 2, 3), (0, 1))]
+        # ... and round 1's cooperative 32-bit kernels of the 10- / 12-bit family (plan.h TUNE_COOPERATIVE), 1 or 2 strips, runs of 1 or 3 tiles
+        tunings += [(f"cooperative, strips {st} run {run} bands {b}", 0x4 | b | (st << 8) | (run << 12)) for st, run, b in itertools.product((1, 2), (1, 3), (0, 1))]
+        for label, tuning in tunings:
+            strips, waves_x, bands = label, "", ""
+            hip_auto_arithmetic.avifhipSetTuning(tuning)
             for c, (ro, po) in zip(cases, want):
                 rh, ph = H.run_y2r(be, c)
                 if ro != rh or not np.array_equal(po, ph):
-                    bad.append(f"strips {strips} waves-x code {waves_x} bands {bands}: {c.ident()} [{native.last_kernel()}]: results {ro}/{rh}" +
+                    bad.append(f"{label}: {c.ident()} [{native.last_kernel()}]: results {ro}/{rh}" +
                                ("" if ro != rh else " " + H.describe_diff(po, ph)))
     finally:
         hip_auto_arithmetic.avifhipSetTuning(1)
