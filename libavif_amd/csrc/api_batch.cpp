@@ -105,6 +105,21 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         if (v < 0 || v != variant)
             allTiled = false;
     }
+    // A plain batch whose jobs are the tiles of ONE canvas in row-major order (avifhipImageYUVToRGBBatchAsync with one RGB canvas and its tile
+    // rectangles: what a rank of the tile farm converts) may walk along the canvas rows like a grid call does (launchYuvToRgbTileBatch):
+    // `canvasColumns` = the number of leading jobs that share the first job's canvas rows, if the rest repeats that pattern.
+    if (!canvasColumns && !map && rects && count > 1) {
+        uint32_t cols = 1;
+        while (cols < count && rgbs[cols]->pixels == rgbs[0]->pixels && rgbs[cols]->rowBytes == rgbs[0]->rowBytes && rects[cols].y == rects[0].y &&
+               rects[cols].x == rects[cols - 1].x + rects[cols - 1].width)
+            ++cols;
+        bool regular = cols > 1 && count % cols == 0;
+        for (uint32_t k = cols; regular && k < count; ++k)
+            regular = rgbs[k]->pixels == rgbs[0]->pixels && rgbs[k]->rowBytes == rgbs[0]->rowBytes && rects[k].x == rects[k % cols].x &&
+                      rects[k].y == rects[k - cols].y + rects[k - cols].height && (k % cols == 0 || rects[k].y == rects[k - 1].y);
+        if (regular)
+            canvasColumns = cols;
+    }
     const avifResult rr = reserve(tls.table, tls.pinnedTableCapacity * kRing); // (growing it waits for the device: nothing reads the old one then)
     if (rr != AVIF_RESULT_OK)
         return rr;

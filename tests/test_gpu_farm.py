@@ -2,6 +2,7 @@
 (avifhipImageYUVToRGBBatchAsync) must reproduce the whole-canvas conversion of the oracle byte for byte, seams included;
 and the single-rectangle entry point (avifhipImageYUVToRGBRectAsync) must agree with the oracle's rectangle function."""
 import ctypes as C
+import dataclasses
 
 import numpy as np
 import pytest
@@ -40,6 +41,36 @@ def test_grid_farm_equals_whole_canvas(hip, world):
                 union.pixels[y:y + h, x * px:(x + w) * px] = out.pixels[y:y + h, x * px:(x + w) * px]
         wb = case.w * px
         assert np.array_equal(union.pixels[:, :wb], whole[:, :wb]), (case.ident(), native.last_kernel(), H.describe_diff(whole[:, :wb], union.pixels[:, :wb]))
+
+
+def test_batches_of_canvas_tiles_along_the_canvas_rows(hip):
+    """A batch whose jobs are the row-major tiles of one canvas (avifhipImageYUVToRGBBatchAsync: one device-resident canvas, its tile
+    rectangles) walks along the canvas rows when it streams (round 5; api_batch.cpp infers the columns from the rectangles).
+    TUNE_CANVAS_ORDER sends these small canvases the same way, in the packed and in the wave-private fp32 kernels, tall and short tiles."""
+    try:
+        for arith, oracle in ((1, H.oracle_backend()), (0, H.oracle_libyuv_backend())):
+            hip.avifhipSetArithmetic(arith)
+            for tuning in (0x2000001, 0x2000401, 0x2000009):
+                hip.avifhipSetTuning(tuning)
+                for case, (tw, th) in CASES:
+                    case = dataclasses.replace(case, avoid_libyuv=(arith == 1))
+                    res, whole = H.run_y2r(oracle, case)
+                    assert res == 0
+                    canvas, out = H.make_y2r_inputs(case), H.make_y2r_output(case)
+                    dimg, drgb = device.DeviceYUV(canvas), device.DeviceRGB(out, upload=True)
+                    rects = farm.grid_rects(case.w, case.h, tw, th)
+                    n = len(rects)
+                    imgs = (C.POINTER(abi.avifImage) * n)(*[C.pointer(dimg.struct)] * n)
+                    rgbs = (C.POINTER(abi.avifRGBImage) * n)(*[C.pointer(drgb.struct)] * n)
+                    crops = (abi.avifCropRect * n)(*[abi.avifCropRect(*r) for r in rects])
+                    native.check(hip.avifhipImageYUVToRGBBatchAsync(n, imgs, rgbs, crops, None), "avifhipImageYUVToRGBBatchAsync")
+                    native.check(hip.avifhipSynchronize(None), "sync")
+                    drgb.download_into_host()
+                    wb = case.w * abi.rgb_pixel_size(case.rgb_format, case.rgb_depth)
+                    assert np.array_equal(out.pixels[:, :wb], whole[:, :wb]), (arith, hex(tuning), case.ident(), native.last_kernel(), H.describe_diff(whole[:, :wb], out.pixels[:, :wb]))
+    finally:
+        hip.avifhipSetTuning(1)
+        hip.avifhipSetArithmetic(1)
 
 
 def test_farm_moves_only_its_share_over_the_host_link(hip):
