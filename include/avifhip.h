@@ -334,7 +334,8 @@ AVIFHIP_API avifResult avifhipSetDevice(int device);
  * points are not affected: their buffers live on one device. */
 AVIFHIP_API avifResult avifhipSetDeviceSet(const int * devices, uint32_t count);
 /* The smallest share that is worth a device of its own, in pixels (0 = the default, 2^21: below ~2 megapixels a second device costs more
- * than its host link brings).  Tests lower it to send small images through the farm; shares stay multiples of 32 rows. */
+ * than its host link brings).  Tests lower it to send small images through the farm; shares stay multiples of 32 rows.
+ * AVIFHIP_FARM_MIN_PIXELS=<n> in the environment (read with AVIFHIP_DEVICES) is the same knob for a process that cannot call this. */
 AVIFHIP_API void avifhipSetFarmMinSharePixels(uint64_t pixels);
 /* The current set: writes at most `capacity` entries, returns the set's size. */
 AVIFHIP_API uint32_t avifhipGetDeviceSet(int * devices, uint32_t capacity);

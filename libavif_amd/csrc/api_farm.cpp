@@ -169,11 +169,14 @@ std::vector<int> deviceSetFromEnvironment()
     }
 }
 
+void setMinShareFromEnvironment();
+
 // (state.mutex held)
 void decide(FarmState & state)
 {
     if (!state.decided) {
         state.deviceSet = deviceSetFromEnvironment();
+        setMinShareFromEnvironment();
         state.decided = true;
     }
 }
@@ -193,6 +196,25 @@ void retire(FarmState & state)
 
 // smallest share worth a device of its own, in pixels (avifhipSetFarmMinSharePixels; default 2^21)
 static std::atomic<uint64_t> gFarmMinShare { (uint64_t)1 << 21 };
+
+namespace {
+// AVIFHIP_FARM_MIN_PIXELS=<n> beside AVIFHIP_DEVICES: the same knob for processes that cannot call the API (tests drive the reference's own
+// programs over seam A / seam B with small fixtures through the farm)
+void setMinShareFromEnvironment()
+{
+    const char * e = getenv("AVIFHIP_FARM_MIN_PIXELS");
+    if (!e || !*e)
+        return;
+    uint64_t v = 0;
+    for (const char * p = e; *p; ++p) {
+        if (*p < '0' || *p > '9' || v > ((uint64_t)1 << 40))
+            return;
+        v = v * 10 + (uint64_t)(*p - '0');
+    }
+    if (v)
+        gFarmMinShare.store(v, std::memory_order_relaxed);
+}
+} // namespace
 
 std::vector<FarmShare> planFarmRows(uint32_t width, uint32_t height, uint32_t workers)
 {
@@ -266,6 +288,15 @@ avifResult farmRun(const std::vector<FarmShare> & shares, avifResult (*job)(void
     {
         std::unique_lock<std::mutex> lock(batch.mutex);
         batch.done.wait(lock, [&batch] { return batch.pending == 0; });
+    }
+    // AVIFHIP_FARM_TRACE: one line on stderr per farmed call (which devices took which shares) -- how a test of an unmodified application sees
+    // that the device set from its environment was used
+    static const bool trace = getenv("AVIFHIP_FARM_TRACE") != nullptr;
+    if (trace) {
+        fprintf(stderr, "avifhip farm: %u shares", n);
+        for (uint32_t k = 0; k < n; ++k)
+            fprintf(stderr, " [%u,%u)@%d", shares[k].begin, shares[k].end, batch.outcomes[k].device);
+        fprintf(stderr, "\n");
     }
     Context & c = tls;
     c.farmReports.clear();

@@ -121,6 +121,46 @@ def test_y4m_to_png_over_the_backend(apps, tmp_path, fixture, png_depth):
             assert a == b, f"{fixture} frame {k}, {arithmetic} arithmetic: the PNG differs from the one {other} writes"
 
 
+@pytest.mark.parametrize("seam", ["B", "A"])
+def test_device_set_from_the_environment_under_the_reference_apps(apps, tmp_path, seam):
+    """Round 5: AVIFHIP_DEVICES in the environment of an UNMODIFIED application makes the library share every host-resident conversion out over
+    the device set (libavif_amd/csrc/api_farm.cpp).  The reference's own y4m -> PNG and PNG -> y4m programs over seam B (the hip-backed
+    build) and seam A (a stock build under the LD_PRELOAD interposer), three workers on device 0, shares from 64 x 32 pixels up so that the
+    768 x 512 fixtures are farmed: the files are byte-identical to the ones written without the variable, and the trace shows the shares."""
+    src = DATA / "kodim03_yuv420_8bpc.y4m"
+    exe = apps / ("refapp_hip" if seam == "B" else "refapp_ref")
+    extra = {"AVIFHIP_DEVICES": "0,0,0", "AVIFHIP_FARM_MIN_PIXELS": "2048", "AVIFHIP_FARM_TRACE": "1"}
+
+    def run(tag, farmed, args):
+        env = dict(os.environ, AVIFHIP_MIN_PIXELS="0")
+        if seam == "A":
+            preload = oracle_lib.ORACLE_DIR.parent / "libavif_amd" / "csrc" / "libavifhip_preload.so"
+            assert preload.exists(), "libavifhip_preload.so is missing"
+            env["LD_PRELOAD"] = os.fspath(preload)
+            env.pop("AVIFHIP_ARITHMETIC", None)
+        else:
+            env["AVIFHIP_ARITHMETIC"] = "auto"
+        for name in extra:
+            env.pop(name, None)
+        if farmed:
+            env.update(extra)
+        proc = subprocess.run([os.fspath(exe)] + [str(a) for a in args], capture_output=True, text=True, env=env, timeout=300)
+        assert proc.returncode == 0, (tag, proc.stdout[-1000:], proc.stderr[-1000:])
+        return proc.stderr
+
+    for depth in (8, 16):
+        plain = run("plain", False, ["y4m2png", src, tmp_path / f"plain{depth}", depth])
+        farmed = run("farmed", True, ["y4m2png", src, tmp_path / f"farmed{depth}", depth])
+        assert "avifhip farm:" not in plain and "avifhip farm: 3 shares" in farmed, farmed[-500:]
+        assert (tmp_path / f"plain{depth}_0.png").read_bytes() == (tmp_path / f"farmed{depth}_0.png").read_bytes()
+    # ... and the encode direction: PNG -> avifReadImage (avifImageRGBToYUV) -> y4m
+    png = tmp_path / "plain8_0.png"
+    a = run("plain", False, ["png2y4m", png, tmp_path / "back_plain.y4m", "420", 8, 1, "limited"])
+    b = run("farmed", True, ["png2y4m", png, tmp_path / "back_farmed.y4m", "420", 8, 1, "limited"])
+    assert "avifhip farm:" not in a and "avifhip farm: 3 shares" in b, b[-500:]
+    assert (tmp_path / "back_plain.y4m").read_bytes() == (tmp_path / "back_farmed.y4m").read_bytes()
+
+
 @pytest.mark.parametrize("yuv", [("420", 8, 1, "limited"), ("444", 8, 6, "full"), ("422", 10, 9, "limited"), ("420", 8, 6, "limited")])
 @pytest.mark.parametrize("fixture", ["kodim03_yuv420_8bpc", "cosmos1650_yuv444_10bpc_p3pq"])
 def test_png_to_y4m_over_the_backend(apps, tmp_path, fixture, yuv):
