@@ -769,13 +769,13 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
         native.check(lib.avifhipSynchronize(None), "avifhipSynchronize")
         calls_async.append((time.perf_counter() - t0) / 20 * 1e3)
     gain_bytes = (4 + 3 + 8) * px4k  # base pixels + gain-map planes + tone-mapped pixels
-    gainmap = row(ms_kernel, (4 + 4 + 8) * px4k, px4k, "avifRGBImageApplyGainMap, 3840x2160 RGBA8 sRGB/BT.709 -> RGBA10 PQ/BT.2020, 8-bit 4:4:4 gain map: the apply kernel alone "
-                  "(base pixels 4 + gain map as RGBA 4 + tone-mapped pixels 8 B/pixel)", kernel=kernel,
-                  whole_call={"what": "the whole call (gain map YUV -> RGB, apply, statistics back on the host: it waits for its stream), host clock, median of 7 x 20 calls; "
+    gainmap = row(ms_kernel, gain_bytes, px4k, "avifRGBImageApplyGainMap, 3840x2160 RGBA8 sRGB/BT.709 -> RGBA10 PQ/BT.2020, 8-bit 4:4:4 gain map: the apply kernel alone, which "
+                  "converts the gain map's planes itself since round 5 (base pixels 4 + gain-map planes 3 + tone-mapped pixels 8 B/pixel)", kernel=kernel,
+                  whole_call={"what": "the whole call (apply with the gain map's YUV -> RGB inside, statistics back on the host: it waits for its stream), host clock, median of 7 x 20 calls; "
                                       "algorithmic bytes base 4 + gain-map planes 3 + output 8 B/pixel",
                               "ms_per_call": round(median(calls), 5), "algorithmic_bytes_per_call": int(gain_bytes),
                               "frac": round(gain_bytes / (median(calls) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "maxCLL": int(clli.maxCLL), "maxPALL": int(clli.maxPALL)},
-                  whole_call_without_light_levels={"what": "the same call with clli = NULL: no statistics to wait for, the call returns with its kernels enqueued (gain map YUV -> RGB + apply); "
+                  whole_call_without_light_levels={"what": "the same call with clli = NULL: no statistics to wait for, the call returns with its kernel enqueued; "
                                                            "host clock around 20 back-to-back calls and one synchronisation, median of 7",
                                                    "ms_per_call": round(median(calls_async), 5),
                                                    "frac": round(gain_bytes / (median(calls_async) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})

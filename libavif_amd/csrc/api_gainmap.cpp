@@ -19,6 +19,47 @@ bool fastKernelDisabled()
     return e && strcmp(e, "general") == 0;
 }
 
+// AVIFHIP_GAINMAP_PLANES=0: the gain map is converted by a launch of its own into an RGBA copy (rounds 2-4) even where the fast apply kernel
+// could read its planes (tests and A/B measurements run both)
+bool gainPlanesDisabled()
+{
+    const char * e = getenv("AVIFHIP_GAINMAP_PLANES");
+    return e && strcmp(e, "0") == 0;
+}
+
+// The fast apply kernel converts the gain map's pixels itself when the map's own avifImageYUVToRGB (src/gainmap.c:185-212) is a function of
+// one pixel's samples that it carries (kernels.h: GainMapPlaneConversion): 8-bit 4:4:4 or 4:0:0, no pending alpha arithmetic, libyuv's 8-bit
+// entries or the fp32 loops with the matrix-coefficient / identity / YCgCo transforms and divisors on the verified list.
+bool gainPlaneConversionOf(const YuvToRgbPlan & p, GainMapPlaneConversion * K)
+{
+    const YuvSide & s = p.yuv;
+    memset(K, 0, sizeof(*K));
+    if (s.depth != 8 || s.chanBytes != 1 || (s.format != AVIF_PIXEL_FORMAT_YUV444 && s.format != AVIF_PIXEL_FORMAT_YUV400))
+        return false;
+    if (p.inLoopMul != MUL_NONE || p.postMul != MUL_NONE || p.rgb.isFloat || p.rgb.is565 || p.rgb.isGray || p.rgb.depth != 8 || p.rgb.map.on)
+        return false;
+    if (s.format == AVIF_PIXEL_FORMAT_YUV444 && (!s.hasColor || !s.plane[1] || !s.plane[2] || s.rowBytes[1] != s.rowBytes[2]))
+        return false;
+    K->hasColor = s.hasColor ? 1 : 0;
+    if (p.identityCopy) {
+        K->identityCopy = 1;
+        return s.hasColor != 0;
+    }
+    if (p.arith == ARITH_LIBYUV) {
+        if (p.fxNative != 8 || p.fxDownshift != 0 || (p.fxMono != 0) != (s.hasColor == 0))
+            return false;
+        K->fixedPoint = 1, K->fx = p.fx;
+        return true;
+    }
+    if (!s.exactDiv || (s.hasColor && s.mode != MODE_COEFF && s.mode != MODE_IDENTITY && s.mode != MODE_YCGCO))
+        return false;
+    K->mode = s.mode;
+    K->biasY = s.biasY, K->rangeY = s.rangeY, K->biasUV = s.biasUV, K->rangeUV = s.rangeUV;
+    K->twoOneMinusKr = s.twoOneMinusKr, K->twoOneMinusKb = s.twoOneMinusKb, K->krOneMinusKr = s.krOneMinusKr, K->kbOneMinusKb = s.kbOneMinusKb;
+    K->rcpKgTimes2 = s.rcpKgTimes2;
+    return true;
+}
+
 void diagClear(avifDiagnostics * diag)
 {
     if (diag)
@@ -151,8 +192,9 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
 
     // ---- the gain map as RGB at the base image's size, :185-212 ----
     uint32_t gainDepth = 8;
+    avifImage gm;
+    memset(&gm, 0, sizeof(gm));
     if (applyGain) {
-        avifImage gm;
         memcpy(&gm, gainImage, sizeof(avifImage));
         if (gm.width != width || gm.height != height) {
             avifImage scaled;
@@ -184,20 +226,7 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
                 return sr;
             memcpy(&gm, &scaled, sizeof(avifImage));
         }
-        avifRGBImage rgbGain; // avifRGBImageSetDefaults, src/avif.c:700-717
-        memset(&rgbGain, 0, sizeof(rgbGain));
-        rgbGain.width = width, rgbGain.height = height, rgbGain.depth = gm.depth, rgbGain.format = AVIF_RGB_FORMAT_RGBA;
-        rgbGain.chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, rgbGain.chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
-        rgbGain.maxThreads = 1;
-        rgbGain.rowBytes = alignUp(width * 4 * ((gm.depth > 8) ? 2 : 1), 256);
-        const avifResult rr = reserve(tls.gainMap[1], (size_t)rgbGain.rowBytes * height);
-        if (rr != AVIF_RESULT_OK)
-            return rr;
-        rgbGain.pixels = (uint8_t *)tls.gainMap[1].ptr;
-        const avifResult cr = avifhipImageYUVToRGBAsync(&gm, &rgbGain, stream);
-        if (cr != AVIF_RESULT_OK)
-            return cr;
-        A.gain = rgbGain.pixels, A.gainPitch = rgbGain.rowBytes, A.gainDepth = gainDepth = gm.depth;
+        A.gainDepth = gainDepth = gm.depth; // (where the samples come from is decided below, once the kernel is known)
         for (int c = 0; c < 3; ++c)
             A.baseOffset[c] = fractionToFloat(gainMap->baseOffset[c]), A.altOffset[c] = fractionToFloat(gainMap->alternateOffset[c]);
     }
@@ -365,6 +394,41 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         }
     }
 
+    // ---- the gain map's samples: its planes, converted by the fast kernel pixel by pixel, or an RGBA copy made by the conversion kernels ----
+    bool gainFromPlanes = false;
+    if (applyGain) {
+        avifRGBImage rgbGain; // avifRGBImageSetDefaults, src/avif.c:700-717
+        memset(&rgbGain, 0, sizeof(rgbGain));
+        rgbGain.width = width, rgbGain.height = height, rgbGain.depth = gm.depth, rgbGain.format = AVIF_RGB_FORMAT_RGBA;
+        rgbGain.chromaUpsampling = AVIF_CHROMA_UPSAMPLING_AUTOMATIC, rgbGain.chromaDownsampling = AVIF_CHROMA_DOWNSAMPLING_AUTOMATIC;
+        rgbGain.maxThreads = 1;
+        rgbGain.rowBytes = alignUp(width * 4 * ((gm.depth > 8) ? 2 : 1), 256);
+        if (A.fast && gm.depth == 8 && (gm.yuvFormat == AVIF_PIXEL_FORMAT_YUV444 || gm.yuvFormat == AVIF_PIXEL_FORMAT_YUV400) && gm.yuvPlanes[0] &&
+            gainMapFastLdsBytes(A.baseL.pixelBytes, gainDepth, A.locBuckets, true) <= kGainMapFastLdsBytes && !gainPlanesDisabled()) {
+            YuvToRgbPlan plan;
+            rgbGain.pixels = gm.yuvPlanes[0]; // (a plan wants a destination; nothing is converted into it)
+            if (makeYuvToRgbPlan(&gm, &rgbGain, nullptr, effectiveArithmetic(), gTuning.load(std::memory_order_relaxed), &plan) == AVIF_RESULT_OK &&
+                gainPlaneConversionOf(plan, &A.gainConv)) {
+                gainFromPlanes = true;
+                A.gainPlanes = 1;
+                A.gain = gm.yuvPlanes[0], A.gainPitch = gm.yuvRowBytes[0];
+                A.gainU = A.gainConv.hasColor ? gm.yuvPlanes[1] : nullptr, A.gainV = A.gainConv.hasColor ? gm.yuvPlanes[2] : nullptr;
+                A.gainPitchUV = A.gainConv.hasColor ? gm.yuvRowBytes[1] : 0;
+            }
+            rgbGain.pixels = nullptr;
+        }
+        if (!gainFromPlanes) {
+            const avifResult rr = reserve(tls.gainMap[1], (size_t)rgbGain.rowBytes * height);
+            if (rr != AVIF_RESULT_OK)
+                return rr;
+            rgbGain.pixels = (uint8_t *)tls.gainMap[1].ptr;
+            const avifResult cr = avifhipImageYUVToRGBAsync(&gm, &rgbGain, stream);
+            if (cr != AVIF_RESULT_OK)
+                return cr;
+            A.gain = rgbGain.pixels, A.gainPitch = rgbGain.rowBytes;
+        }
+    }
+
     // statistics: every workgroup stores its partial into pinned host memory; added up here, in index order, once the stream has drained
     if (!tls.gainMapPartials)
         HIP_TRY(hipHostMalloc(&tls.gainMapPartials, (size_t)kGainMapMaxGroups * sizeof(GainMapPartial), hipHostMallocDefault));
@@ -396,7 +460,7 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
     const hipError_t e = launchGainMapApply(A, stream, &partials);
     if (e != hipSuccess)
         return hipFailed(e, "gain map kernel launch");
-    tls.lastKernel = applyGain ? (A.fast ? "gainmap_apply_fast" : "gainmap_apply") : (A.convert ? "gainmap_convert" : "gainmap_requantise");
+    tls.lastKernel = applyGain ? (A.fast ? (gainFromPlanes ? "gainmap_apply_fast<planes>" : "gainmap_apply_fast") : "gainmap_apply") : (A.convert ? "gainmap_convert" : "gainmap_requantise");
     ++tls.launches;
     // Nothing of the answer depends on the pixels when the caller wants no light levels and the fast kernel serves the call: its precondition
     // (above) is that no NaN can arise, and the result code is then AVIF_RESULT_OK whatever the pixels hold.  The asynchronous entry point

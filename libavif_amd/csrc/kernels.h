@@ -184,12 +184,33 @@ struct GainMapPartial // one workgroup's share of the statistics
     float max;
     uint32_t nan;
 };
+// The gain map's own avifImageYUVToRGB (src/gainmap.c:185-212: into avifRGBImageSetDefaults' RGBA of the map's depth) for one pixel of an 8-bit
+// 4:4:4 / 4:0:0 map, as the fast apply kernel computes it itself instead of reading a converted copy: what of a YuvToRgbPlan that takes.
+struct GainMapPlaneConversion
+{
+    int32_t fixedPoint;   // libyuv's arithmetic (pixel_fixed.h: fxMatrix) / the reference's fp32 (pixel_math.h: yuvToRgbCore)
+    int32_t hasColor;     // 4:4:4 with chroma planes (else: monochrome)
+    int32_t identityCopy; // src/reformat.c:1278-1309: G, B, R are the samples
+    int32_t mode;         // fp32: MODE_COEFF / MODE_IDENTITY / MODE_YCGCO
+    FixedPointMatrix fx;
+    float biasY, rangeY, biasUV, rangeUV;
+    float twoOneMinusKr, twoOneMinusKb, krOneMinusKr, kbOneMinusKb;
+    RcpHL rcpKgTimes2;    // (the plan's divisors are on the verified list: YuvSide::exactDiv)
+};
+
 struct GainMapArgs
 {
     const uint8_t * base;
     uint8_t * out;
     const uint8_t * gain; // the gain map as RGBA of gainDepth bits (avifRGBImageSetDefaults layout), or null: weight 0
     uint32_t basePitch, outPitch, gainPitch, gainDepth;
+    // gainPlanes: `gain` is the luma plane of an 8-bit gain map instead (gainPitch its pitch), gainU / gainV its 4:4:4 chroma planes (null:
+    // 4:0:0) -- the fast kernel converts every pixel itself (no conversion launch, no 4-byte-per-pixel intermediate)
+    int32_t gainPlanes;
+    uint32_t gainPitchUV;
+    const uint8_t * gainU;
+    const uint8_t * gainV;
+    GainMapPlaneConversion gainConv;
     GainMapPixelLayout baseL, outL;
     uint32_t width, height;
     const float * baseLut;  // linear light of every base sample code
@@ -218,7 +239,8 @@ constexpr uint32_t kGainMapMaxGroups = 4096; // persistent workgroups of the app
 // LDS the fast kernel may fill with tables (two workgroups per CU keep eight waves resident)
 constexpr size_t kGainMapFastLdsBytes = 64 * 1024;
 // what the fast kernel needs for 4- / 8-byte base pixels, a gain map of that depth and a locator of that many buckets
-size_t gainMapFastLdsBytes(uint32_t basePixelBytes, uint32_t gainDepth, uint32_t locBuckets);
+// (planes: the kernel converts the gain map's planes itself -- two more tables of 256 floats)
+size_t gainMapFastLdsBytes(uint32_t basePixelBytes, uint32_t gainDepth, uint32_t locBuckets, bool planes = false);
 // *partials: how many entries of args.partials the launch fills (0: no statistics)
 hipError_t launchGainMapApply(const GainMapArgs & args, hipStream_t stream, uint32_t * partials);
 

@@ -8,6 +8,7 @@
 #include <atomic>
 
 #include "kernels.h"
+#include "pixel_math.h"
 
 #include <type_traits>
 
@@ -328,8 +329,12 @@ template <int BASE_BYTES, int GAIN_BYTES>
 struct FastLds
 {
     static constexpr uint32_t kBaseEntries = (BASE_BYTES == 4) ? 256 : 4096;
+    // GAIN_BYTES < 4: the gain map arrives as 8-bit planes and the kernel converts them itself -- 0 in the reference's fp32 arithmetic
+    // (normalised luma and chroma of every sample code behind the gain tables), 1 in libyuv's fixed point (the same layout, those two unused)
+    static constexpr bool kPlanes = GAIN_BYTES < 4;
     static constexpr uint32_t kBaseLut = 0, kAlphaLut = kBaseLut + 4 * kBaseEntries, kGainLut = kAlphaLut + 2 * kBaseEntries,
-                              kLocator = kGainLut + ((GAIN_BYTES == 4) ? 3 * 4 * 256 : 0);
+                              kNormY = kGainLut + 3 * 4 * 256, kNormUV = kNormY + 4 * 256,
+                              kLocator = kGainLut + ((GAIN_BYTES == 4) ? 3 * 4 * 256 : kPlanes ? 5 * 4 * 256 : 0);
 };
 
 // kFastPixels neighbouring pixels of BYTES each, moved 16 bytes at a time (4-byte alignment is all the wide accesses need).  Pixels are read
@@ -374,6 +379,19 @@ struct PixelRun
     }
 };
 
+// four neighbouring samples of each plane of an 8-bit gain map (the kernel converts them itself)
+struct PlaneRun
+{
+    uint32_t y, u, v;
+    // (a run that ends a row whose width is no multiple of four starts at any byte)
+    static __device__ __forceinline__ uint32_t four(const uint8_t * p)
+    {
+        if (__builtin_expect(((uintptr_t)p & 3) == 0, 1))
+            return *reinterpret_cast<const uint32_t *>(p);
+        return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    }
+};
+
 // (code & 0xff) << 2 in one instruction: the compiler finds the sub-dword operand for bytes 1-3 but not for byte 0
 __device__ __forceinline__ uint32_t byte0Times4(uint32_t w, uint32_t two)
 {
@@ -394,8 +412,8 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
 {
     using Lds = FastLds<BASE_BYTES, GAIN_BYTES>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t gainR = (GAIN_BYTES == 4) ? Lds::kGainLut : Lds::kLocator + 16 * ((A.locBuckets + 3) / 4);
-    const uint32_t gainG = gainR + ((GAIN_BYTES == 4) ? 1024 : (4u << A.gainDepth)), gainB = gainG + ((GAIN_BYTES == 4) ? 1024 : (4u << A.gainDepth));
+    const uint32_t gainR = (GAIN_BYTES != 8) ? Lds::kGainLut : Lds::kLocator + 16 * ((A.locBuckets + 3) / 4);
+    const uint32_t gainG = gainR + ((GAIN_BYTES != 8) ? 1024 : (4u << A.gainDepth)), gainB = gainG + ((GAIN_BYTES != 8) ? 1024 : (4u << A.gainDepth));
     Locator L = { 0, 0, A.locShift, Lds::kLocator - 4 * (A.locFirstBits >> A.locShift) };
     // (the two bounds in vector registers for the whole kernel: left to itself the compiler copies them over from scalar ones at every use)
     asm volatile("v_mov_b32 %0, %1" : "=v"(L.first) : "s"(A.locFirstBits));
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
     struct Tile
     {
         PixelRun<BASE_BYTES> bp;
-        PixelRun<GAIN_BYTES> gp;
+        std::conditional_t<Lds::kPlanes, PlaneRun, PixelRun<Lds::kPlanes ? 4 : GAIN_BYTES>> gp;
         uint32_t i, i0, j;
         bool live;
     };
@@ -437,8 +455,57 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
         if (T.live) {
             T.i0 = min(T.i, A.width - kFastPixels);
             T.bp.load(A.base + (size_t)T.j * A.basePitch + (size_t)T.i0 * BASE_BYTES);
-            T.gp.load(A.gain + (size_t)T.j * A.gainPitch + (size_t)T.i0 * GAIN_BYTES);
+            if constexpr (!Lds::kPlanes) {
+                T.gp.load(A.gain + (size_t)T.j * A.gainPitch + (size_t)T.i0 * GAIN_BYTES);
+            } else {
+                T.gp.y = PlaneRun::four(A.gain + (size_t)T.j * A.gainPitch + T.i0);
+                if (A.gainU) {
+                    const size_t at = (size_t)T.j * A.gainPitchUV + T.i0;
+                    T.gp.u = PlaneRun::four(A.gainU + at), T.gp.v = PlaneRun::four(A.gainV + at);
+                }
+            }
         }
+    };
+    // the gain map's own conversion at one pixel (planes): the R, G, B codes avifImageYUVToRGB gives the samples, side by side in one word
+    // like a pixel of the converted copy (pixel_generic.h / pixel_fixed.h: the universal kernels' per-pixel routines, restated on tables)
+    const GainMapPlaneConversion & K = A.gainConv;
+    auto convertGainFixed = [&](uint32_t y, uint32_t u, uint32_t v) -> uint32_t {
+        uint32_t r, g, b;
+        if (K.identityCopy) { // src/reformat.c:1278-1309
+            g = y, b = u, r = v;
+        } else {
+            const int y1 = (int)(((y * 0x0101u) * (uint32_t)K.fx.yg) >> 16) + K.fx.yb;
+            if (!K.hasColor) { // I400ToARGBMatrix: chroma 128
+                r = g = b = (uint32_t)clampInt(y1 >> 6, 0, 255);
+            } else {
+                const int ub = (int)u - 128, vb = (int)v - 128;
+                b = (uint32_t)clampInt((y1 + K.fx.ub * ub) >> 6, 0, 255);
+                g = (uint32_t)clampInt((y1 - (K.fx.ug * ub + K.fx.vg * vb)) >> 6, 0, 255);
+                r = (uint32_t)clampInt((y1 + K.fx.vr * vb) >> 6, 0, 255);
+            }
+        }
+        return r | (g << 8) | (b << 16);
+    };
+    // fp32: the operands of the quantiser's truncation, 0.5f + (c * 255.0f) of the UNCLAMPED channels (src/reformat.c:952-961 runs on channels
+    // clamped to [0, 1]; packGainCodes explains why the clamp can wait)
+    auto convertGainFloat = [&](uint32_t y, uint32_t u, uint32_t v, float t[3]) {
+        const float Y = lutF(Lds::kNormY + (y << 2));
+        float R = Y, G = Y, B = Y;
+        if (K.hasColor) {
+            const float Cb = lutF(Lds::kNormUV + (u << 2)), Cr = lutF(Lds::kNormUV + (v << 2));
+            if (K.mode == MODE_COEFF) { // src/reformat.c:874-884
+                R = Y + K.twoOneMinusKr * Cr;
+                B = Y + K.twoOneMinusKb * Cb;
+                const float sum = (K.krOneMinusKr * Cr) + (K.kbOneMinusKb * Cb);
+                G = Y - __builtin_fmaf(sum, K.rcpKgTimes2.hi, sum * K.rcpKgTimes2.lo); // (2 * sum) / kg, exactdiv.h
+            } else if (K.mode == MODE_IDENTITY) {
+                G = Y, B = Cb, R = Cr;
+            } else { // MODE_YCGCO, :851-857
+                const float h = Y - Cb;
+                G = Y + Cb, B = h - Cr, R = h + Cr;
+            }
+        }
+        t[0] = 0.5f + (R * 255.0f), t[1] = 0.5f + (G * 255.0f), t[2] = 0.5f + (B * 255.0f);
     };
     // PLAIN: R, G, B, A order on both sides (the usual case): the three byte permutations per pixel fall away
     auto work = [&](const Tile & T, auto plain) {
@@ -447,6 +514,41 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
             return;
         PixelRun<OUT_BYTES> op;
         float pixelMax[kFastPixels];
+        uint32_t gainWord[kFastPixels]; // (planes) the four pixels of the gain map, converted before anything else of the tile is touched
+        if constexpr (GAIN_BYTES == 1) {
+#pragma unroll
+            for (int p = 0; p < kFastPixels; ++p)
+                gainWord[p] = convertGainFixed((T.gp.y >> (8 * p)) & 0xff, (T.gp.u >> (8 * p)) & 0xff, (T.gp.v >> (8 * p)) & 0xff);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (GAIN_BYTES == 0) {
+            float t[kFastPixels][3];
+#pragma unroll
+            for (int p = 0; p < kFastPixels; ++p)
+                convertGainFloat((T.gp.y >> (8 * p)) & 0xff, (T.gp.u >> (8 * p)) & 0xff, (T.gp.v >> (8 * p)) & 0xff, t[p]);
+            // (uint8_t)(0.5f + AVIF_CLAMP(c, 0, 1) * 255.0f) of twelve channels.  v_cvt_pk_u8_f32 converts with the current rounding mode and
+            // saturates to [0, 255]; under round-toward-zero that is the truncation of every operand in [0, 256), 0 for the negative ones and
+            // 255 from 256 up.  The operand of an unclamped channel c is 0.5f + c * 255.0f: the same number where 0 <= c <= 1; below 0.5
+            // (code 0, or negative: saturated to 0) where c < 0, as for the clamped 0; at least 255.5 (code 255, or saturated) where c > 1, as
+            // for the clamped 1.  The rounding mode is changed only inside the block.
+            static_assert(kFastPixels == 4, "the block below converts four pixels");
+            asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                         "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\t"
+                         "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\t"
+                         "v_cvt_pk_u8_f32 %2, %10, 0, 0\n\t"
+                         "v_cvt_pk_u8_f32 %3, %13, 0, 0\n\t"
+                         "v_cvt_pk_u8_f32 %0, %5, 1, %0\n\t"
+                         "v_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+                         "v_cvt_pk_u8_f32 %2, %11, 1, %2\n\t"
+                         "v_cvt_pk_u8_f32 %3, %14, 1, %3\n\t"
+                         "v_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
+                         "v_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+                         "v_cvt_pk_u8_f32 %2, %12, 2, %2\n\t"
+                         "v_cvt_pk_u8_f32 %3, %15, 2, %3\n\t"
+                         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                         : "=&v"(gainWord[0]), "=&v"(gainWord[1]), "=&v"(gainWord[2]), "=&v"(gainWord[3])
+                         : "v"(t[0][0]), "v"(t[0][1]), "v"(t[0][2]), "v"(t[1][0]), "v"(t[1][1]), "v"(t[1][2]), "v"(t[2][0]), "v"(t[2][1]), "v"(t[2][2]),
+                           "v"(t[3][0]), "v"(t[3][1]), "v"(t[3][2]));
+        }
 #pragma unroll
         for (int p = 0; p < kFastPixels; ++p) {
             // byte offsets into the tables: sample code x entry size
@@ -459,8 +561,12 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
                 const uint32_t y = PLAIN ? T.bp.w[2 * p + 1] : __builtin_amdgcn_perm(T.bp.w[2 * p + 1], T.bp.w[2 * p], selBaseY);
                 r4 = word0Times4(x, two), g4 = (x >> 16) << 2, b4 = word0Times4(y, two), a2 = (y >> 16) << 1;
             }
-            if constexpr (GAIN_BYTES == 4) { // the gain map is RGBA (avifRGBImageSetDefaults)
-                const uint32_t w = T.gp.w[p];
+            if constexpr (GAIN_BYTES != 8) { // the gain map is RGBA8 (avifRGBImageSetDefaults), or its planes converted above
+                uint32_t w;
+                if constexpr (Lds::kPlanes)
+                    w = gainWord[p];
+                else
+                    w = T.gp.w[p];
                 gr4 = byte0Times4(w, two), gg4 = ((w >> 8) & 0xff) << 2, gb4 = ((w >> 16) & 0xff) << 2;
             } else {
                 const uint32_t x = T.gp.w[2 * p], y = T.gp.w[2 * p + 1];
@@ -540,7 +646,7 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
         // all four tables in one sweep of 16-byte moves, every lane's loads in flight before its first LDS write (a loop of load - write
         // round trips took 4 of the kernel's 37 us on a 4K image); the host keeps the tables 16-byte aligned and padded
         const uint32_t nBase = 1u << A.baseL.depth, nGain = 1u << A.gainDepth;
-        const uint32_t gainLds = (GAIN_BYTES == 4) ? Lds::kGainLut : Lds::kLocator + 16 * ((A.locBuckets + 3) / 4);
+        const uint32_t gainLds = (GAIN_BYTES != 8) ? Lds::kGainLut : Lds::kLocator + 16 * ((A.locBuckets + 3) / 4);
         const uint32_t q0 = nBase / 4, q1 = q0 + nBase / 8, q2 = q1 + (3 * nGain) / 4, q3 = q2 + (A.locBuckets + 3) / 4; // in 16-byte units
         const uint32_t t = threadIdx.y * 64 + threadIdx.x;
         constexpr int kMoves = (int)(kGainMapFastLdsBytes / 16 / (64 * kFastRows));
@@ -565,6 +671,17 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
                                   : (q < q2) ? gainLds + 16 * (q - q1)
                                              : Lds::kLocator + 16 * (q - q2);
                 *reinterpret_cast<Quad *>(lds + at) = held[m];
+            }
+        }
+        if constexpr (GAIN_BYTES == 0) {
+            // unormFloatTableY / unormFloatTableUV of the gain map's conversion (src/reformat.c:575-603), with the reference's own division;
+            // identity mode reuses the luma table for chroma (:587-589)
+            {
+                for (uint32_t k = t; k < 512; k += 64 * kFastRows) {
+                    const bool chroma = k >= 256 && K.mode != MODE_IDENTITY;
+                    const float code = (float)(k & 255);
+                    *reinterpret_cast<float *>(lds + Lds::kNormY + 4 * k) = chroma ? (code - K.biasUV) / K.rangeUV : (code - K.biasY) / K.rangeY;
+                }
             }
         }
         __syncthreads();
@@ -759,10 +876,10 @@ __global__ __launch_bounds__(256) void gainMapQuantiseKernel(const float * ratio
 
 } // namespace
 
-size_t gainMapFastLdsBytes(uint32_t basePixelBytes, uint32_t gainDepth, uint32_t locBuckets)
+size_t gainMapFastLdsBytes(uint32_t basePixelBytes, uint32_t gainDepth, uint32_t locBuckets, bool planes)
 {
     const size_t fixed = (basePixelBytes == 4) ? FastLds<4, 8>::kLocator : FastLds<8, 8>::kLocator; // base and alpha tables
-    return fixed + ((size_t)12 << gainDepth) + (size_t)((locBuckets + 3) / 4) * 16;
+    return fixed + ((size_t)12 << gainDepth) + (planes ? 2 * 4 * 256 : 0) + (size_t)((locBuckets + 3) / 4) * 16;
 }
 
 hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_t * partials)
@@ -775,11 +892,13 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_
         // the instantiation (the variants with two primaries conversions need more than the 64 that leave room for eight waves per SIMD) --
         // or fewer, so that every workgroup makes the same number of steps when the tiles divide that way.
         const uint32_t tilesX = (A.width + 64 * kFastPixels - 1) / (64 * kFastPixels), tiles = tilesX * ((A.height + kFastRows - 1) / kFastRows);
-        const size_t lds = gainMapFastLdsBytes(A.baseL.pixelBytes, A.gainDepth, A.locBuckets);
+        const size_t lds = gainMapFastLdsBytes(A.baseL.pixelBytes, A.gainDepth, A.locBuckets, A.gainPlanes != 0);
         const uint32_t byLds = (uint32_t)((160 * 1024) / (lds + 512));
         const int conv = (A.inConv ? 1 : 0) | (A.outConv ? 2 : 0);
-        const int key = (A.baseL.pixelBytes == 8 ? 4 : 0) | (A.outL.pixelBytes == 8 ? 2 : 0) | (A.gainDepth > 8 ? 1 : 0);
-        static std::atomic<int> wavesPerSimd[8][4]; // of each instantiation, from its register count (0: not asked yet; any thread may ask: same answer)
+        // (gain map: RGBA8, RGBA16, or its own 8-bit planes)
+        const bool planesFixed = A.gainConv.fixedPoint || A.gainConv.identityCopy;
+        const int key = 4 * ((A.baseL.pixelBytes == 8 ? 2 : 0) | (A.outL.pixelBytes == 8 ? 1 : 0)) + (A.gainPlanes ? (planesFixed ? 3 : 2) : (A.gainDepth > 8 ? 1 : 0));
+        static std::atomic<int> wavesPerSimd[16][4]; // of each instantiation, from its register count (0: not asked yet; any thread may ask: same answer)
         uint32_t groups = 0;
         auto launch = [&](auto kernel) {
             int waves = wavesPerSimd[key][conv].load(std::memory_order_relaxed);
@@ -816,17 +935,23 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_
                 default: launch(gainMapApplyFastKernel<B, O, G, 3>); break;
             }
         };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
         using I4 = std::integral_constant<int, 4>;
         using I8 = std::integral_constant<int, 8>;
-        switch (key) {
-            case 0: byConv(I4{}, I4{}, I4{}); break;
-            case 1: byConv(I4{}, I4{}, I8{}); break;
-            case 2: byConv(I4{}, I8{}, I4{}); break;
-            case 3: byConv(I4{}, I8{}, I8{}); break;
-            case 4: byConv(I8{}, I4{}, I4{}); break;
-            case 5: byConv(I8{}, I4{}, I8{}); break;
-            case 6: byConv(I8{}, I8{}, I4{}); break;
-            default: byConv(I8{}, I8{}, I8{}); break;
+        auto byGain = [&](auto b, auto o) {
+            switch (key % 4) {
+                case 0: byConv(b, o, I4{}); break;
+                case 1: byConv(b, o, I8{}); break;
+                case 2: byConv(b, o, I0{}); break;
+                default: byConv(b, o, I1{}); break;
+            }
+        };
+        switch (key / 4) {
+            case 0: byGain(I4{}, I4{}); break;
+            case 1: byGain(I4{}, I8{}); break;
+            case 2: byGain(I8{}, I4{}); break;
+            default: byGain(I8{}, I8{}); break;
         }
         *partials = groups;
         return hipGetLastError();

@@ -226,12 +226,72 @@ def test_gpu_fast_kernel_and_general_kernel_on_the_same_cases(hip_auto_arithmeti
         for c, (ra, pa, ca) in zip(cases, want):
             rb, pb, cb = run(hip_auto_arithmetic.avifhipRGBImageApplyGainMap, c, C.byref(diag))
             # (the fast kernel has no NaN test: the library keeps calls whose tables could produce one on the general kernel)
-            assert native.last_kernel() == (name if ra == 0 else "gainmap_apply"), (c.ident(), native.last_kernel())
+            # (8-bit 4:4:4 / 4:0:0 gain maps: the fast kernel converts the map's planes itself, `gainmap_apply_fast<planes>`)
+            assert native.last_kernel().split("<")[0] == (name if ra == 0 else "gainmap_apply"), (c.ident(), native.last_kernel())
             if ra != rb or (ra == 0 and not (np.array_equal(pa, pb) and ca[0] == cb[0] and abs(ca[1] - cb[1]) <= 1)):
                 bad.append(f"{c.ident()} [{name}]: results {ra}/{rb} clli {ca}/{cb}" +
                            ("" if ra or rb or np.array_equal(pa, pb) else f" {int((pa != pb).sum())} bytes differ"))
         assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
     assert sum(r == 0 for r, _, _ in want) >= len(cases) - 1 and any(r == abi.AVIF_RESULT_INVALID_TONE_MAPPED_IMAGE for r, _, _ in want)
+
+
+def _plane_cases():
+    """8-bit 4:4:4 and 4:0:0 gain maps at the base image's size -- what the fast apply kernel converts itself (round 5): every matrix the conversion
+    has a transform for (BT.709 / BT.601 / BT.2020 coefficients, identity, YCgCo), both ranges, every pixel-size combination and primaries
+    variant of the kernel, rows that end inside a lane's run of four pixels (the last run starts at an odd byte of the planes)."""
+    out = []
+    k = 0
+    for fmt in (abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_PIXEL_FORMAT_YUV400):
+        for matrix in (1, 6, 9, 0, 8, 2):
+            for rng in (abi.AVIF_RANGE_FULL, abi.AVIF_RANGE_LIMITED):
+                if (matrix == 0 and fmt == abi.AVIF_PIXEL_FORMAT_YUV400) or (matrix == 8 and rng == abi.AVIF_RANGE_LIMITED):
+                    continue  # (limited-range YCgCo: the conversion refuses it, below)
+                bd, od = ((8, 8), (8, 10), (10, 8), (12, 12))[k % 4]
+                w, h = ((37, 21), (261, 5), (64, 9), (5, 3), (515, 17), (258, 8), (7, 2))[k % 7]
+                out.append(G.GainMapCase(w, h, base_depth=bd, out_depth=od, out_tc=9 if od == 12 else (13, 16, 18, 1, 8)[k % 5], base_primaries=(1, 1, 9, 12)[k % 4],
+                                         out_primaries=(1, 9, 9, 1)[k % 4], use_base_color_space=bool(k % 3), alt_primaries=9, gm_format=fmt, gm_matrix=matrix,
+                                         gm_range=rng, base_format=(abi.AVIF_RGB_FORMAT_RGBA, abi.AVIF_RGB_FORMAT_BGRA, abi.AVIF_RGB_FORMAT_ARGB)[k % 3], seed=1300 + k))
+                k += 1
+    out.append(G.GainMapCase(1001, 67, base_depth=8, out_depth=10, out_tc=16, out_primaries=9, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400, seed=78))
+    out.append(G.GainMapCase(1920, 1080, base_depth=8, out_depth=10, out_tc=16, out_primaries=9, gm_matrix=1, seed=79))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arithmetic", ["float", "auto"])
+def test_gpu_fast_kernel_converts_the_gain_maps_planes_itself(hip, monkeypatch, arithmetic):
+    """Round 5: the gain map's own avifImageYUVToRGB inside the apply kernel.  On 8-bit 4:4:4 / 4:0:0 maps the fast kernel must
+    read the planes (`gainmap_apply_fast<planes>`), and give the oracle's bytes in both arithmetics -- the reference's fp32 loops and what a
+    libavif built with libyuv computes (the matrices libyuv has no constants for fall to the fp32 loops there too); with
+    AVIFHIP_GAINMAP_PLANES=0 the same calls take a conversion launch and the RGBA copy (rounds 2-4), same bytes."""
+    from libavif_amd import native
+
+    hip.avifhipSetArithmetic(1 if arithmetic == "float" else 0)
+    try:
+        o = oracle_lib.oracle()
+        diag = abi.avifDiagnostics()
+        cases = _plane_cases()
+        want = [run(o.oracleRGBImageApplyGainMap, c, int(arithmetic == "auto")) for c in cases]
+        assert all(r == 0 for r, _, _ in want)
+        for planes in (True, False):
+            if not planes:
+                monkeypatch.setenv("AVIFHIP_GAINMAP_PLANES", "0")
+            bad = []
+            for c, (ra, pa, ca) in zip(cases, want):
+                rb, pb, cb = run(hip.avifhipRGBImageApplyGainMap, c, C.byref(diag))
+                name = native.last_kernel()
+                # (the full-range identity map is a copy of the samples; YCgCo and "unspecified" are transforms like the others)
+                assert name == ("gainmap_apply_fast<planes>" if planes else "gainmap_apply_fast"), (c.ident(), name, arithmetic)
+                if ra != rb or not (np.array_equal(pa, pb) and ca[0] == cb[0] and abs(ca[1] - cb[1]) <= 1):
+                    bad.append(f"{c.ident()} m{c.gm_matrix} r{c.gm_range} [{name}]: results {ra}/{rb} clli {ca}/{cb}" +
+                               ("" if rb or pb is None or np.array_equal(pa, pb) else f" {int((pa != pb).sum())} bytes differ"))
+            assert not bad, f"{arithmetic}, planes={planes}: {len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+            # a map whose conversion the reference refuses (limited-range YCgCo, src/reformat.c:128-134) fails the call the same way
+            refused = G.GainMapCase(37, 21, gm_matrix=8, gm_range=abi.AVIF_RANGE_LIMITED)
+            ra = run(o.oracleRGBImageApplyGainMap, refused, int(arithmetic == "auto"))[0]
+            assert ra != 0 and run(hip.avifhipRGBImageApplyGainMap, refused, C.byref(diag))[0] == ra
+    finally:
+        hip.avifhipSetArithmetic(1)
 
 
 @pytest.mark.gpu
@@ -295,7 +355,7 @@ def test_gpu_device_resident_without_light_levels_and_in_place(hip_auto_arithmet
         wb = c.w * abi.rgb_pixel_size(c.out_format, c.out_depth)
         rb = hip_auto_arithmetic.avifhipRGBImageApplyGainMapAsync(dbase.struct, c.base_primaries, c.base_tc, C.byref(gm), c.headroom, c.out_primaries,
                                                                  c.out_tc, dout.struct, None, C.byref(diag), None)
-        assert rb == 0 and native.last_kernel() == "gainmap_apply_fast", (c.ident(), rb, native.last_kernel())
+        assert rb == 0 and native.last_kernel() == "gainmap_apply_fast<planes>", (c.ident(), rb, native.last_kernel())
         native.check(hip_auto_arithmetic.avifhipSynchronize(None))
         dout.download_into_host()
         assert np.array_equal(out.pixels[:, :wb], pa[:, :wb]), c.ident()
