@@ -3,6 +3,10 @@
 // gainmap_plan.cpp, kernels from kernels_gainmap.hip.
 #include "api_internal.h"
 
+#include <malloc.h>
+
+#include <chrono>
+
 using namespace avifhip;
 using namespace avifhip::api;
 
@@ -18,6 +22,29 @@ bool fastKernelDisabled()
     const char * e = getenv("AVIFHIP_GAINMAP_KERNEL");
     return e && strcmp(e, "general") == 0;
 }
+
+// AVIFHIP_GAINMAP_TRACE: the phases of the host-resident gain-map calls on stderr, milliseconds since the call began (where a call's time goes:
+// tests/tools/gm_call_bench.py)
+struct PhaseTrace
+{
+    bool on;
+    std::chrono::steady_clock::time_point start;
+    explicit PhaseTrace(const char * what) : on(getenv("AVIFHIP_GAINMAP_TRACE") != nullptr), start(std::chrono::steady_clock::now())
+    {
+        if (on)
+            fprintf(stderr, "avifhip %s:", what);
+    }
+    void mark(const char * phase)
+    {
+        if (on)
+            fprintf(stderr, " %s %.3f", phase, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count());
+    }
+    ~PhaseTrace()
+    {
+        if (on)
+            fprintf(stderr, "\n");
+    }
+};
 
 // AVIFHIP_GAINMAP_PLANES=0: the gain map is converted by a launch of its own into an RGBA copy (rounds 2-4) even where the fast apply kernel
 // could read its planes (tests and A/B measurements run both)
@@ -568,33 +595,57 @@ extern "C" double avifhipTimeRGBImageApplyGainMap(const avifRGBImage * baseImage
     return (r == AVIF_RESULT_OK) ? tls.gainMapTimedMs : -1.0;
 }
 
-// host-resident images, like the reference: the tone-mapped image's pixels are (re)allocated with malloc (src/gainmap.c:112-114)
-extern "C" avifResult avifhipRGBImageApplyGainMap(const avifRGBImage * baseImage, avifColorPrimaries baseColorPrimaries,
-                                                  avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap, float hdrHeadroom,
-                                                  avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
-                                                  avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag)
+// host-resident images, like the reference: the tone-mapped image's pixels are (re)allocated with malloc (src/gainmap.c:112-114).
+// baseOnDevice: the base pixels are a device buffer of this call's own (avifhipImageApplyGainMap below: the YUV base image converted straight
+// into HBM, rows padded to 256 bytes) standing for the tightly packed host image the reference allocates there.
+static avifResult applyGainMapToHostImage(const avifRGBImage * baseImage, bool baseOnDevice, avifColorPrimaries baseColorPrimaries,
+                                          avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap, float hdrHeadroom,
+                                          avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
+                                          avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag)
 {
     const avifResult ar = gainMapCheckArguments(baseImage, gainMap, hdrHeadroom, toneMappedImage, diag);
     if (ar != AVIF_RESULT_OK)
         return ar;
     const uint32_t width = baseImage->width, height = baseImage->height;
     toneMappedImage->width = width, toneMappedImage->height = height;
-    // avifRGBImageAllocatePixels, src/avif.c:719-737
-    free(toneMappedImage->pixels);
-    toneMappedImage->pixels = NULL, toneMappedImage->rowBytes = 0;
+    // avifRGBImageAllocatePixels, src/avif.c:719-737 (frees what the image holds, allocates width x height pixels).  A buffer that already has
+    // that size stays (round 5): the caller cannot tell, and a buffer the runtime pinned for the last call's download costs 3.8 ms to release
+    // and another 2.6 ms of page faults under this call's download when it is 66 MB (a 4K RGBA10 image: 8.7 -> 2.5 ms per call for callers
+    // that tone-map a sequence into one avifRGBImage).
     const uint32_t outPixelBytes = rgbPixelBytes(toneMappedImage);
-    if (!width || !height || width > UINT32_MAX / outPixelBytes)
+    if (!width || !height || width > UINT32_MAX / outPixelBytes) {
+        free(toneMappedImage->pixels);
+        toneMappedImage->pixels = NULL, toneMappedImage->rowBytes = 0;
         return AVIF_RESULT_INVALID_ARGUMENT;
+    }
     const uint32_t outRowBytes = width * outPixelBytes;
-    toneMappedImage->pixels = (uint8_t *)malloc((size_t)outRowBytes * height);
-    if (!toneMappedImage->pixels)
-        return AVIF_RESULT_OUT_OF_MEMORY;
+    const size_t outBytes = (size_t)outRowBytes * height;
+    const size_t have = toneMappedImage->pixels ? malloc_usable_size(toneMappedImage->pixels) : 0;
+    if (have < outBytes || have > outBytes + outBytes / 8 + 4096) {
+        free(toneMappedImage->pixels);
+        toneMappedImage->pixels = NULL, toneMappedImage->rowBytes = 0;
+        toneMappedImage->pixels = (uint8_t *)malloc(outBytes);
+        if (!toneMappedImage->pixels)
+            return AVIF_RESULT_OUT_OF_MEMORY;
+    }
     toneMappedImage->rowBytes = outRowBytes;
 
+    PhaseTrace trace("apply gain map");
+    trace.mark("pixels allocated");
     const float weight = gainMapWeight(hdrHeadroom, gainMap);
-    if (gainMapIsPlainCopy(baseImage, baseColorPrimaries, baseTransferCharacteristics, weight, outputColorPrimaries, outputTransferCharacteristics,
+    const uint32_t baseWidthBytes = width * rgbPixelBytes(baseImage);
+    avifRGBImage asTheReferenceSeesIt; // (the row pitch decides whether the call is a plain copy, :120-128)
+    memcpy(&asTheReferenceSeesIt, baseImage, sizeof(avifRGBImage));
+    if (baseOnDevice)
+        asTheReferenceSeesIt.rowBytes = baseWidthBytes;
+    if (gainMapIsPlainCopy(&asTheReferenceSeesIt, baseColorPrimaries, baseTransferCharacteristics, weight, outputColorPrimaries, outputTransferCharacteristics,
                            toneMappedImage)) {
-        memcpy(toneMappedImage->pixels, baseImage->pixels, (size_t)baseImage->rowBytes * baseImage->height); // "Copy the base image", :124-127
+        if (baseOnDevice) {
+            HIP_TRY(hipMemcpy2DAsync(toneMappedImage->pixels, outRowBytes, baseImage->pixels, baseImage->rowBytes, baseWidthBytes, height, hipMemcpyDeviceToHost, tls.stream));
+            HIP_TRY(hipStreamSynchronize(tls.stream));
+        } else {
+            memcpy(toneMappedImage->pixels, baseImage->pixels, (size_t)baseImage->rowBytes * baseImage->height); // "Copy the base image", :124-127
+        }
         return AVIF_RESULT_OK;
     }
     if (!baseImage->pixels || (weight != 0.0f && !gainMap->image))
@@ -606,13 +657,15 @@ extern "C" avifResult avifhipRGBImageApplyGainMap(const avifRGBImage * baseImage
     avifRGBImage baseView, outView;
     memcpy(&baseView, baseImage, sizeof(avifRGBImage));
     memcpy(&outView, toneMappedImage, sizeof(avifRGBImage));
-    const uint32_t baseWidthBytes = width * rgbPixelBytes(baseImage);
-    baseView.rowBytes = alignUp(baseWidthBytes, 256);
-    avifResult r = reserve(tls.gainMap[5], (size_t)baseView.rowBytes * height);
-    if (r != AVIF_RESULT_OK)
-        return r;
-    baseView.pixels = (uint8_t *)tls.gainMap[5].ptr;
-    HIP_TRY(hipMemcpy2DAsync(baseView.pixels, baseView.rowBytes, baseImage->pixels, baseImage->rowBytes, baseWidthBytes, height, hipMemcpyHostToDevice, tls.stream));
+    avifResult r = AVIF_RESULT_OK;
+    if (!baseOnDevice) {
+        baseView.rowBytes = alignUp(baseWidthBytes, 256);
+        r = reserve(tls.gainMap[5], (size_t)baseView.rowBytes * height);
+        if (r != AVIF_RESULT_OK)
+            return r;
+        baseView.pixels = (uint8_t *)tls.gainMap[5].ptr;
+        HIP_TRY(hipMemcpy2DAsync(baseView.pixels, baseView.rowBytes, baseImage->pixels, baseImage->rowBytes, baseWidthBytes, height, hipMemcpyHostToDevice, tls.stream));
+    }
     outView.rowBytes = alignUp(outRowBytes, 256);
     r = reserve(tls.gainMap[0], (size_t)outView.rowBytes * height);
     if (r != AVIF_RESULT_OK)
@@ -626,16 +679,30 @@ extern "C" avifResult avifhipRGBImageApplyGainMap(const avifRGBImage * baseImage
         if (r != AVIF_RESULT_OK)
             return r;
     }
+    trace.mark("uploads");
     r = applyGainMapOnDevice(&baseView, baseColorPrimaries, baseTransferCharacteristics, gainMap, &gainView, weight, outputColorPrimaries,
                              outputTransferCharacteristics, &outView, clli, diag, tls.stream);
     if (r != AVIF_RESULT_OK)
         return r;
+    trace.mark("applied");
     HIP_TRY(hipMemcpy2DAsync(toneMappedImage->pixels, outRowBytes, outView.pixels, outView.rowBytes, outRowBytes, height, hipMemcpyDeviceToHost, tls.stream));
     HIP_TRY(hipStreamSynchronize(tls.stream));
+    trace.mark("downloaded");
     return AVIF_RESULT_OK;
 }
 
-// avifImageApplyGainMap, src/gainmap.c:317-355: the base image arrives as YUV
+extern "C" avifResult avifhipRGBImageApplyGainMap(const avifRGBImage * baseImage, avifColorPrimaries baseColorPrimaries,
+                                                  avifTransferCharacteristics baseTransferCharacteristics, const avifGainMap * gainMap, float hdrHeadroom,
+                                                  avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
+                                                  avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag)
+{
+    return applyGainMapToHostImage(baseImage, false, baseColorPrimaries, baseTransferCharacteristics, gainMap, hdrHeadroom, outputColorPrimaries,
+                                   outputTransferCharacteristics, toneMappedImage, clli, diag);
+}
+
+// avifImageApplyGainMap, src/gainmap.c:317-355: the base image arrives as YUV.  The reference converts it into an RGB image of the API's defaults
+// on the heap and hands that to avifRGBImageApplyGainMap; here that image lives in HBM only (round 5: it used to travel to the host and back --
+// 8 bytes per pixel over the link for nothing): planes up, conversion, application, tone-mapped pixels down.
 extern "C" avifResult avifhipImageApplyGainMap(const avifImage * baseImage, const avifGainMap * gainMap, float hdrHeadroom,
                                                avifColorPrimaries outputColorPrimaries, avifTransferCharacteristics outputTransferCharacteristics,
                                                avifRGBImage * toneMappedImage, avifContentLightLevelInformationBox * clli, avifDiagnostics * diag)
@@ -655,16 +722,19 @@ extern "C" avifResult avifhipImageApplyGainMap(const avifImage * baseImage, cons
     const uint32_t pixelBytes = rgbPixelBytes(&baseRgb);
     if (!baseRgb.width || !baseRgb.height || baseRgb.width > UINT32_MAX / pixelBytes)
         return AVIF_RESULT_INVALID_ARGUMENT;
-    baseRgb.rowBytes = baseRgb.width * pixelBytes;
-    baseRgb.pixels = (uint8_t *)malloc((size_t)baseRgb.rowBytes * baseRgb.height);
-    if (!baseRgb.pixels)
-        return AVIF_RESULT_OUT_OF_MEMORY;
-    avifResult r = avifhipImageYUVToRGB(baseImage, &baseRgb);
-    if (r == AVIF_RESULT_OK)
-        r = avifhipRGBImageApplyGainMap(&baseRgb, baseImage->colorPrimaries, baseImage->transferCharacteristics, gainMap, hdrHeadroom, outputColorPrimaries,
-                                        outputTransferCharacteristics, toneMappedImage, clli, diag);
-    free(baseRgb.pixels);
-    return r;
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    baseRgb.rowBytes = alignUp(baseRgb.width * pixelBytes, 256);
+    avifResult r = reserve(tls.gainMap[5], (size_t)baseRgb.rowBytes * baseRgb.height);
+    if (r != AVIF_RESULT_OK)
+        return r;
+    baseRgb.pixels = (uint8_t *)tls.gainMap[5].ptr;
+    r = avifhipImageYUVToRGB(baseImage, &baseRgb); // host planes (or device ones) into the device buffer
+    if (r != AVIF_RESULT_OK)
+        return r;
+    return applyGainMapToHostImage(&baseRgb, true, baseImage->colorPrimaries, baseImage->transferCharacteristics, gainMap, hdrHeadroom, outputColorPrimaries,
+                                   outputTransferCharacteristics, toneMappedImage, clli, diag);
 }
 
 // ---- gain-map computation (the encode side), reference src/gainmap.c:535-843 ----
@@ -751,6 +821,7 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
     if (r != AVIF_RESULT_OK)
         return r;
     hipStream_t stream = tls.stream;
+    PhaseTrace trace("compute gain map");
     tls.gainMapCache.valid = false; // (the apply path's tables are not touched, but keep the two paths independent of call order)
 
     // avifGainMapSetEncodingDefaults, :18-30
@@ -786,6 +857,7 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
     A.base = (const uint8_t *)tls.gainMap[5].ptr, A.alt = (const uint8_t *)tls.gainMap[9].ptr;
     HIP_TRY(hipMemcpy2DAsync(tls.gainMap[5].ptr, A.basePitch, baseRgbImage->pixels, baseRgbImage->rowBytes, baseWidthBytes, height, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpy2DAsync(tls.gainMap[9].ptr, A.altPitch, altRgbImage->pixels, altRgbImage->rowBytes, altWidthBytes, height, hipMemcpyHostToDevice, stream));
+    trace.mark("uploads");
     std::vector<float> tables = gainMapLinearLut(baseTransferCharacteristics, baseRgbImage->depth, baseRgbImage->isFloat != 0);
     const size_t altLutOffset = tables.size();
     {
@@ -816,6 +888,7 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
         HIP_TRY(hipMemcpyAsync(partials.data(), A.partials, partials.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         float channelMin[3] = { 0.0f, 0.0f, 0.0f };
+        trace.mark("minima");
         for (uint32_t g = 0; g < groups; ++g)
             for (int c = 0; c < 3; ++c)
                 channelMin[c] = (channelMin[c] < partials[(size_t)g * 8 + c]) ? channelMin[c] : partials[(size_t)g * 8 + c];
@@ -842,6 +915,7 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
             return hipFailed(e, "gain map ratio kernel launch");
         HIP_TRY(hipMemcpyAsync(partials.data(), A.partials, partials.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        trace.mark("ratios");
     }
     float baseMax = 1.0f, altMax = 1.0f, minRatio[3] = { INFINITY, INFINITY, INFINITY }, maxRatio[3] = { 0.0f, 0.0f, 0.0f };
     for (uint32_t g = 0; g < groups; ++g) {
@@ -893,6 +967,7 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
         std::vector<uint32_t> hostHistograms(histogramTotal);
         HIP_TRY(hipMemcpyAsync(hostHistograms.data(), tls.gainMap[8].ptr, histogramTotal * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        trace.mark("histograms");
         for (int c = 0; c < channels; ++c)
             if (ranges[c].numBuckets > 0)
                 gainMapRangeWithoutOutliers(ranges[c], hostHistograms.data() + histogramOffset[c], &minLog2[c], &maxLog2[c]);
@@ -950,11 +1025,29 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
             free(alpha);
         }
     } stale;
+    // ... and a plane that already has the size and pitch the allocation below would give it stays where it is (the reference frees and
+    // allocates, src/gainmap.c:792-793: the same bytes at an address the caller cannot tell apart).  A caller that computes gain maps for a
+    // sequence of frames into one avifGainMap spares every call the release of 25 MB the runtime had pinned and the faults of 6 000 fresh pages
+    // under the downloads (3.5 of 9.3 ms for a 4K 4:4:4 map, and 15-25 ms stalls of the NEXT call's kernels while the unpinning ran).
+    {
+        const PlaneGeometry want = planeGeometry(gmImage);
+        auto fits = [&](const uint8_t * plane, uint32_t rowBytes, int p) {
+            return plane && want.rows[p] && rowBytes == want.widthBytes[p] && malloc_usable_size((void *)plane) >= (size_t)rowBytes * want.rows[p];
+        };
+        if (gmImage->imageOwnsYUVPlanes)
+            for (int p = 0; p < 3; ++p)
+                if (!fits(gmImage->yuvPlanes[p], gmImage->yuvRowBytes[p], p))
+                    stale.yuv[p] = gmImage->yuvPlanes[p], gmImage->yuvPlanes[p] = NULL;
+        if (gmImage->imageOwnsAlphaPlane && !fits(gmImage->alphaPlane, gmImage->alphaRowBytes, 3))
+            stale.alpha = gmImage->alphaPlane, gmImage->alphaPlane = NULL;
+    }
+    DeferredPlanes kept; // (out of the image while the device works -- an early return releases them -- and back in before the downloads)
+    uint32_t keptRowBytes[4] = { gmImage->yuvRowBytes[0], gmImage->yuvRowBytes[1], gmImage->yuvRowBytes[2], gmImage->alphaRowBytes };
     if (gmImage->imageOwnsYUVPlanes)
         for (int p = 0; p < 3; ++p)
-            stale.yuv[p] = gmImage->yuvPlanes[p], gmImage->yuvPlanes[p] = NULL;
+            kept.yuv[p] = gmImage->yuvPlanes[p], gmImage->yuvPlanes[p] = NULL;
     if (gmImage->imageOwnsAlphaPlane)
-        stale.alpha = gmImage->alphaPlane, gmImage->alphaPlane = NULL;
+        kept.alpha = gmImage->alphaPlane, gmImage->alphaPlane = NULL;
     freeHostPlanes(gmImage); // (what is left: pointers the image does not own)
     avifImage deviceGain;
     memcpy(&deviceGain, gmImage, sizeof(avifImage));
@@ -971,10 +1064,17 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
             return r;
     }
     gmImage->width = deviceFinal.width, gmImage->height = deviceFinal.height;
+    trace.mark("enqueued");
+    for (int p = 0; p < 3; ++p)
+        if (kept.yuv[p])
+            gmImage->yuvPlanes[p] = kept.yuv[p], gmImage->yuvRowBytes[p] = keptRowBytes[p], kept.yuv[p] = nullptr;
+    if (kept.alpha)
+        gmImage->alphaPlane = kept.alpha, gmImage->alphaRowBytes = keptRowBytes[3], kept.alpha = nullptr;
     if ((r = allocateHostPlanes(gmImage, true)) != AVIF_RESULT_OK) {
         freeHostPlanes(gmImage);
         return r;
     }
+    trace.mark("planes allocated");
     const PlaneGeometry g = planeGeometry(gmImage);
     for (int p = 0; p < 4; ++p) {
         uint8_t * host = (p < 3) ? gmImage->yuvPlanes[p] : gmImage->alphaPlane;
@@ -985,6 +1085,7 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
                                  g.widthBytes[p], g.rows[p], hipMemcpyDeviceToHost, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    trace.mark("downloaded");
     tls.lastKernel = "gainmap_compute";
     return AVIF_RESULT_OK;
 }

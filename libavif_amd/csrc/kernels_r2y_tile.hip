@@ -195,7 +195,11 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
     const uint32_t bands = (A.w4 + 255) / 256;
     const uint32_t strips = A.h2 / 2;
     const uint64_t waveStrips = (uint64_t)bands * strips;
-    uint32_t spw = waveStrips >= 4 * 8192 ? 2 : 1;
+    // Two strips from the size on at which one strip per wave no longer fits the chip at once (8 192 waves: 1 024 SIMDs x 8): a 4K frame's
+    // 16 200 strips are 8 100 waves, all resident from the first cycle to the last instead of 2.26 rounds of short ones -- 8.67 -> 7.70 us
+    // for a frame the caches hold, no difference (10.63 / 10.65 us) for frames that stream; 1080p frames want one strip (4.34 / 5.00 us),
+    // four strips lose everywhere (interleaved A/B, tests/tools/spw_ab.py)
+    uint32_t spw = waveStrips > 8192 ? 2 : 1;
     if (const char * e = getenv("AVIFHIP_R2Y_SPW")) // diagnostics / A-B measurements only
         spw = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : spw;
     spw = spw >= 4 ? 4 : (spw >= 2 ? 2 : 1);

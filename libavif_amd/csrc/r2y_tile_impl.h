@@ -258,7 +258,9 @@ __device__ __forceinline__ int liftCode(float c, float maxf)
 // PLAIN: matrix coefficients or the identity matrix and no pending alpha arithmetic -- what nearly every encode is.  It is a kernel of its
 // own (launchOne picks): with the YCgCo family and the alpha (un)multiply compiled into the same loop as wave-uniform branches, the
 // one-strip kernel that serves 4K frames took 120 vector registers (half the occupancy) and cfg4 went from 9.0 to 14.9 us.
-template <typename RT, int NCH, typename YT, int SUB, bool SWAP, bool PLAIN>
+// IDENT (PLAIN kernels only): the identity matrix, known when the code is generated -- left as a run-time test the compiler computes BOTH
+// transforms and picks per value (three v_cndmask_b32 per pixel of the 25 instructions the matrix-coefficient path took).
+template <typename RT, int NCH, typename YT, int SUB, bool SWAP, bool PLAIN, bool IDENT>
 __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S, const UnmulEntry * unmulTable)
 {
     constexpr uint32_t BPS = sizeof(YT);
@@ -325,7 +327,7 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
                 }
                 U[r][p] = (f2) { uv2[0], uv2[1] }, V[r][p] = (f2) { vv[0], vv[1] };
                 tY[r][p] = unormOperand((f2) { yv[0], yv[1] }, A.rangeY, A.biasY);
-            } else if (A.identity) { // wave-uniform: GBR planes (lossless RGB), src/reformat.c:362-366 -- Y = G, U = B, V = R, all three on luma's scale
+            } else if (PLAIN ? IDENT : (A.identity != 0)) { // wave-uniform: GBR planes (lossless RGB), src/reformat.c:362-366 -- Y = G, U = B, V = R, all three on luma's scale
                 U[r][p] = B, V[r][p] = R;
                 tY[r][p] = unormOperand(G2, A.rangeY, A.biasY);
             } else {
@@ -415,10 +417,20 @@ __device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uin
 {
     // which memory-order colour channel is red decides the operand ORDER of the luma sum (fp32 addition is not associative):
     // one wave-uniform branch instead of selects per pixel
+    // (the identity matrix takes 4:4:4 or 4:0:0 planes, src/reformat.c:141-144: only those kernels carry its code, behind a branch of its own)
+    if constexpr (PLAIN && (SUB == SUB_444 || SUB == SUB_400)) {
+        if (A.identity) {
+            if (A.slotB < A.slotR)
+                computeStripT<RT, NCH, YT, SUB, true, PLAIN, true>(A, sy, X, laneValid, S, unmulTable);
+            else
+                computeStripT<RT, NCH, YT, SUB, false, PLAIN, true>(A, sy, X, laneValid, S, unmulTable);
+            return;
+        }
+    }
     if (A.slotB < A.slotR)
-        computeStripT<RT, NCH, YT, SUB, true, PLAIN>(A, sy, X, laneValid, S, unmulTable);
+        computeStripT<RT, NCH, YT, SUB, true, PLAIN, false>(A, sy, X, laneValid, S, unmulTable);
     else
-        computeStripT<RT, NCH, YT, SUB, false, PLAIN>(A, sy, X, laneValid, S, unmulTable);
+        computeStripT<RT, NCH, YT, SUB, false, PLAIN, false>(A, sy, X, laneValid, S, unmulTable);
 }
 
 // ---- libyuv's fixed point (8-bit RGB -> 8-bit planes, BT.601, appendix D.5): same loads, stores and strip walk ----

@@ -66,6 +66,30 @@ def main():
                 out[mode] = {"kernel_name": names[mode], **{k: round(median(v) * 1e3, 2) for k, v in rows[mode].items()}}
             out["unit"] = "us, medians: the apply kernel alone / the whole call with light levels / per call of 50 back to back without"
             print(json.dumps(out), flush=True)
+    # host-resident images, the reference's signatures: the RGB base image, and the YUV one (avifImageApplyGainMap: its RGB form lives in HBM only)
+    lib.avifhipSetArithmetic(0)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    gimg = abi.make_yuv(W, H, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 6)
+    synth.fill_yuv(gimg, 0x99)
+    gm.image = C.pointer(gimg.struct)
+    ybase = abi.make_yuv(W, H, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_FULL, 1)
+    synth.fill_yuv(ybase, 0x77)
+    ybase.struct.colorPrimaries, ybase.struct.transferCharacteristics = 1, 13
+    out = abi.make_rgb(W, H, 10, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False, allocate=False)
+    clli, diag = abi.avifContentLightLevelInformationBox(), abi.avifDiagnostics()
+    t_rgb, t_yuv = [], []
+    for _ in range(passes + 1):
+        t0 = time.perf_counter()
+        native.check(lib.avifhipRGBImageApplyGainMap(base.struct, 1, 13, C.byref(gm), 3.0, 9, 16, out.struct, C.byref(clli), C.byref(diag)), "host rgb")
+        t_rgb.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        native.check(lib.avifhipImageApplyGainMap(ybase.struct, C.byref(gm), 3.0, 9, 16, out.struct, C.byref(clli), C.byref(diag)), "host yuv")
+        t_yuv.append((time.perf_counter() - t0) * 1e3)
+    libc.free(C.cast(out.struct.pixels, C.c_void_p))
+    out.struct.pixels = None
+    print(json.dumps({"host_resident_ms": {"avifhipRGBImageApplyGainMap (RGBA8 base, 4:4:4 map, RGBA10 out: 4 + 3 up, 8 down B/pixel)": round(median(t_rgb[1:]), 3),
+                                           "avifhipImageApplyGainMap (8-bit 4:2:0 base: 1.5 + 3 up, 8 down B/pixel)": round(median(t_yuv[1:]), 3)}}), flush=True)
     lib.avifhipSetArithmetic(1)
 
 

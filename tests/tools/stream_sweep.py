@@ -13,6 +13,12 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from libavif_amd import abi, device, native, synth  # noqa: E402
 
+# (tests/tools/lib_ab.py: the same measurement over another build of the library, interleaved on one box)
+if os.environ.get("AVIFHIP_TOOLS_LIBRARY"):
+    from pathlib import Path as _Path
+
+    native.LIB_PATH = _Path(os.environ["AVIFHIP_TOOLS_LIBRARY"])
+
 if os.environ.get("AVIFHIP_BENCH_LIB"):
     native.LIB_PATH = Path(os.environ["AVIFHIP_BENCH_LIB"]).resolve()
 lib = native.load()
