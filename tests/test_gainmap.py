@@ -295,6 +295,50 @@ def test_gpu_fast_kernel_converts_the_gain_maps_planes_itself(hip, monkeypatch, 
 
 
 @pytest.mark.gpu
+def test_gpu_buffers_of_a_previous_call_are_kept_when_they_fit(hip_auto_arithmetic):
+    """Round 5: avifRGBImageApplyGainMap frees and allocates the tone-mapped pixels, avifRGBImageComputeGainMap the gain map's planes
+    (src/gainmap.c:114, :792-793).  A buffer of the right size that a previous call left in the struct stays where it is (releasing memory the
+    runtime had pinned costs milliseconds): same bytes as the oracle's, same address; another size gets a new buffer."""
+    o = oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    out = G.make_output(G.GainMapCase(258, 40, out_depth=10))
+    seen = []
+    for c in (G.GainMapCase(258, 40, out_depth=10, out_tc=16, seed=5), G.GainMapCase(258, 40, out_depth=10, out_tc=13, out_primaries=9, seed=6),
+              G.GainMapCase(515, 33, out_depth=10, out_tc=16, seed=7), G.GainMapCase(64, 9, out_depth=10, out_tc=16, seed=8)):
+        ra, pa, ca = run(o.oracleRGBImageApplyGainMap, c, 1)
+        base = G.make_base(c)
+        gm, keep = G.make_gain_map(c)
+        clli = abi.avifContentLightLevelInformationBox(0xFFFF, 0xFFFF)
+        out.struct.width, out.struct.height = 1, 1  # (the callee sets them, like the reference)
+        rb = hip_auto_arithmetic.avifhipRGBImageApplyGainMap(base.struct, c.base_primaries, c.base_tc, C.byref(gm), c.headroom, c.out_primaries, c.out_tc, out.struct,
+                                                            C.byref(clli), C.byref(diag))
+        assert ra == rb == 0 and (out.struct.width, out.struct.height) == (c.w, c.h)
+        assert np.array_equal(G.output_bytes(out), pa), c.ident()
+        seen.append(C.cast(out.struct.pixels, C.c_void_p).value)
+    assert seen[0] == seen[1] and seen[2] != seen[1], seen  # kept for the same size; the larger image cannot fit
+    libc.free(C.cast(out.struct.pixels, C.c_void_p))
+    out.struct.pixels = None
+
+    import test_scale as TS
+
+    cases = [G.ComputeCase(261, 37, alt_primaries=9, seed=21), G.ComputeCase(261, 37, alt_primaries=1, seed=22), G.ComputeCase(64, 33, seed=23)]
+    gm, img = G.make_compute_gain_map(cases[0])
+    addresses = []
+    for c in cases:
+        ra, sa = run_compute(o.oracleRGBImageComputeGainMap, c, 1)
+        base, alt = G.make_compute_inputs(c)
+        want_gm, want_img = G.make_compute_gain_map(c)
+        img.struct.width, img.struct.height, img.struct.depth, img.struct.yuvFormat = want_img.struct.width, want_img.struct.height, want_img.struct.depth, want_img.struct.yuvFormat
+        rb = hip_auto_arithmetic.avifhipRGBImageComputeGainMap(base.struct, c.base_primaries, c.base_tc, alt.struct, c.alt_primaries, c.alt_tc, C.byref(gm), C.byref(diag))
+        assert ra == rb == 0, (c.ident(), ra, rb)
+        assert states_equal(sa, gain_map_state(gm, img.struct)), c.ident()
+        addresses.append(C.cast(img.struct.yuvPlanes[0], C.c_void_p).value)
+        TS.free_owned(want_img.struct)
+    assert addresses[0] == addresses[1], addresses
+    TS.free_owned(img.struct)
+
+
+@pytest.mark.gpu
 def test_gpu_larger_images_and_16_bit_tables(hip_auto_arithmetic):
     cases = [G.GainMapCase(1001, 333, base_depth=8, out_depth=8, gm_w=500, gm_h=167, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, out_tc=16, out_primaries=9),
              G.GainMapCase(640, 360, base_depth=10, out_depth=10, base_tc=16, out_tc=13, base_primaries=9, out_primaries=1, headroom=1.0,
