@@ -427,6 +427,8 @@ static double timeMover(const std::vector<MoveJob> & jobs, uint32_t groups, uint
         ok = ok && hipEventRecord(t1, stream) == hipSuccess && hipEventSynchronize(t1) == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess;
         if (ok && (best < 0 || ms / iters < best))
             best = (double)ms / iters, bestPattern = pattern;
+        if (ok && getenv("AVIFHIP_CEILING_TRACE")) // every pattern's time, not just the fastest one's (which access shape costs what)
+            fprintf(stderr, "avifhip ceiling: %-48s %8.3f us\n", kMovePatternName[pattern], 1e3 * ms / iters);
     }
     if (t0)
         (void)hipEventDestroy(t0);
