@@ -55,5 +55,10 @@ rm -rf "gpurun_out/${TAG}_traffic"
 AVIFHIP_BENCH_DEVICES=0,0 timeout 300 python bench.py --in-process --gpus 2 > "gpurun_out/${TAG}_bench_inprocess_cfg2_line.json" 2>> "gpurun_out/${TAG}_bench_default.err"
 AVIFHIP_BENCH_DEVICES=0,0 timeout 300 python bench.py --in-process --gpus 2 --workload cfg5 > "gpurun_out/${TAG}_bench_inprocess_cfg5_line.json" 2>> "gpurun_out/${TAG}_bench_default.err"
 timeout 300 python tests/tools/list_generic.py > "gpurun_out/${TAG}_generic_rest.txt" 2>&1
+# the gain map's conversion inside the apply kernel against the conversion launch + RGBA copy (interleaved in one process), the host-resident calls
+# with their phases, and the encode kernels' strips-per-wave rule with every pattern of the byte-movement ceiling
+timeout 300 python tests/tools/gm_call_bench.py 5 > "gpurun_out/${TAG}_gainmap_call_ab.jsonl" 2> "gpurun_out/${TAG}_gainmap_call_ab.err"
+AVIFHIP_GAINMAP_TRACE=1 timeout 300 python tests/tools/gm_trace.py > "gpurun_out/${TAG}_gainmap_host_trace.txt" 2>&1
+AVIFHIP_CEILING_TRACE=1 timeout 300 python tests/tools/spw_ab.py > "gpurun_out/${TAG}_encode_strips_ab.txt" 2>&1
 rm -rf "gpurun_out/${TAG}_cfgs" "gpurun_out/${TAG}_pmc_cfgs" "gpurun_out/$TAG" "gpurun_out/${TAG}_gainmap"
 ls -la gpurun_out | tail -20
