@@ -474,14 +474,16 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
         if (K.identityCopy) { // src/reformat.c:1278-1309
             g = y, b = u, r = v;
         } else {
-            const int y1 = (int)(((y * 0x0101u) * (uint32_t)K.fx.yg) >> 16) + K.fx.yb;
+            // (every factor fits 24 bits -- 16-bit y * 0x0101, coefficients below 2^15, chroma within +-128 --: the full-rate 24-bit multiplies
+            //  give the products exactly; left as 32-bit ones they are quarter-rate v_mul_lo_u32 / v_mad_u64_u32)
+            const int y1 = (int)(__umul24(y * 0x0101u, (uint32_t)K.fx.yg) >> 16) + K.fx.yb;
             if (!K.hasColor) { // I400ToARGBMatrix: chroma 128
                 r = g = b = (uint32_t)clampInt(y1 >> 6, 0, 255);
             } else {
                 const int ub = (int)u - 128, vb = (int)v - 128;
-                b = (uint32_t)clampInt((y1 + K.fx.ub * ub) >> 6, 0, 255);
-                g = (uint32_t)clampInt((y1 - (K.fx.ug * ub + K.fx.vg * vb)) >> 6, 0, 255);
-                r = (uint32_t)clampInt((y1 + K.fx.vr * vb) >> 6, 0, 255);
+                b = (uint32_t)clampInt((y1 + __mul24(K.fx.ub, ub)) >> 6, 0, 255);
+                g = (uint32_t)clampInt((y1 - (__mul24(K.fx.ug, ub) + __mul24(K.fx.vg, vb))) >> 6, 0, 255);
+                r = (uint32_t)clampInt((y1 + __mul24(K.fx.vr, vb)) >> 6, 0, 255);
             }
         }
         return r | (g << 8) | (b << 16);
