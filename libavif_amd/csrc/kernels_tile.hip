@@ -202,8 +202,13 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
         if (p.postMulFx)
             return false;
         if (p.identityCopy) {
-            // lossless RGB in 8-bit 4:4:4 planes: a byte shuffle inside the 4:4:4 kernel (no arithmetic, no divisors to verify)
-            if (p.inLoopMul != MUL_NONE || p.postMul != MUL_NONE || s.chanBytes != 1 || o.chanBytes != 1 || s.format != AVIF_PIXEL_FORMAT_YUV444)
+            // lossless RGB in 8-bit 4:4:4 planes: a byte shuffle inside the 4:4:4 kernel (no arithmetic, no divisors to verify) ...
+            if (p.inLoopMul != MUL_NONE || s.chanBytes != 1 || o.chanBytes != 1 || s.format != AVIF_PIXEL_FORMAT_YUV444)
+                return false;
+            // ... unless an integer alpha (un)multiply follows the copy (src/reformat.c:1574-1585: premultiplied lossless images): then the
+            // kernels with alpha arithmetic run the identity transform as arithmetic -- (uint8_t)(0.5f + (c / 255.0f) * 255.0f) is c for every
+            // code, the error of the quotient is below 2e-5 -- and the post-pass on the codes (tile_shared.h: identityMatrix)
+            if (p.postMul != MUL_NONE && !s.exactDiv)
                 return false;
         } else {
             // matrix coefficients, the identity matrix at any depth / range (GBR planes: 4:4:4; without chroma every matrix is the same), or the

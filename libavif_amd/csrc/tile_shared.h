@@ -173,8 +173,11 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
     }
     A.f16Mul = o.isFloat ? o.f16Multiplier : 0.0f;
     A.inLoopMul = p.inLoopMul, A.postMul = p.postMul;
-    A.identityCopy = p.identityCopy;
-    A.identityMatrix = (p.arith != ARITH_LIBYUV && s.mode == MODE_IDENTITY && !p.identityCopy) ? 1 : 0;
+    // (the 8-bit copy with an integer alpha (un)multiply behind it: the identity transform as arithmetic, which reproduces every code, then the
+    //  post-pass of the kernels that carry alpha arithmetic -- the byte shuffle lives in the kernels without)
+    const bool copyThenMul = p.identityCopy && p.postMul != MUL_NONE;
+    A.identityCopy = (p.identityCopy && !copyThenMul) ? 1 : 0;
+    A.identityMatrix = (p.arith != ARITH_LIBYUV && s.mode == MODE_IDENTITY && (!p.identityCopy || copyThenMul)) ? 1 : 0;
     if (A.identityMatrix)
         A.biasUV = s.biasY, A.rcpRangeUV = s.rcpRangeY; // src/reformat.c:587-589: identity reads chroma through luma's table
     A.ycgco = (p.arith == ARITH_LIBYUV) ? 0 : (s.mode == MODE_YCGCO ? 1 : ((s.mode == MODE_YCGCO_RE || s.mode == MODE_YCGCO_RO) ? 2 : 0));

@@ -11,8 +11,15 @@ if str(ROOT / "tests") not in sys.path:
     sys.path.insert(0, str(ROOT / "tests"))
 
 
+def pytest_addoption(parser):
+    parser.addoption("--seed-rotation", action="store", default=None, metavar="N",
+                     help="move the random part of every parity sweep to another seed stream (tests/harness.py: sweep_rng); 0 = the committed set")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if config.getoption("--seed-rotation") is not None:
+        os.environ["AVIFHIP_TEST_SEED_ROTATION"] = str(int(config.getoption("--seed-rotation")))
 
 
 def _gpu_run(config) -> bool:

@@ -96,7 +96,7 @@ def output_bytes(out: abi.HostRGB) -> np.ndarray:
 
 
 def cases(n_random: int, seed: int, sizes=((37, 21), (64, 33), (5, 3), (1, 1))) -> list:
-    rnd = random.Random(seed)
+    rnd = H.sweep_rng(seed)
     out = []
     w0, h0 = sizes[0]
     for tc in TCS:  # every transfer function, both directions
@@ -217,7 +217,7 @@ def make_compute_gain_map(c: ComputeCase):
 
 
 def compute_cases(n_random: int, seed: int, sizes=((37, 21), (64, 33), (5, 3), (120, 40))) -> list:
-    rnd = random.Random(seed)
+    rnd = H.sweep_rng(seed)
     w0, h0 = sizes[0]
     out = [ComputeCase(w0, h0), ComputeCase(w0, h0, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400), ComputeCase(w0, h0, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, gm_depth=10),
            ComputeCase(64, 48, gm_w=32, gm_h=24), ComputeCase(64, 48, gm_w=16, gm_h=12, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400, gm_depth=12),

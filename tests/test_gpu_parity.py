@@ -87,8 +87,11 @@ def test_universal_kernels_serve_only_the_enumerated_rest(hip):
     tests/tools/list_generic.py prints the census: 18 of 1089 conversions of this sweep in the fp32 arithmetic, 28 in the default one): RGB565
     outside what its two tiled routes cover (alpha arithmetic pending, matrices off the verified divisor list, padded rows of 2-byte
     pixels), and -- in the integer arithmetic only -- destinations whose alpha libyuv cannot serve: `ignoreAlpha` on a format with alpha
-    (libyuv writes 255, the reference then leaves the channel alone) and a pending alpha (un)multiply on ARGB / ABGR (libyuv attenuates
-    RGBA / BGRA only, so the reference runs its fp32 post-pass over libyuv's bytes).  Anything else through a universal kernel fails here."""
+    (libyuv writes 255, the reference then leaves the channel alone) and a pending alpha (un)multiply that mixes the two arithmetics: on
+    ARGB / ABGR libyuv attenuates nothing (RGBA / BGRA only), so the reference runs its fp32 post-pass over libyuv's bytes; on RGBA / BGRA
+    converted by the fp32 loops (sources libyuv has no entry for: 10- / 12-bit 4:0:0, matrices it lacks) the reference runs libyuv's
+    ARGBAttenuate / ARGBUnattenuate over fp32's bytes (`postMulFx`; found by `--seed-rotation 1`: the committed seeds never drew one at a tiled
+    size).  Anything else through a universal kernel fails here."""
     from dataclasses import replace
     try:
         for arith, avoid in ((1, True), (0, False)):
@@ -104,12 +107,12 @@ def test_universal_kernels_serve_only_the_enumerated_rest(hip):
                 total += 1
                 if "generic" in native.last_kernel():
                     generic.append(c)
-            assert total > 900 and len(generic) <= 0.04 * total, (len(generic), total)
+            assert total > 900 and len(generic) <= 0.05 * total, (len(generic), total)  # (18-28 with the committed seeds; up to 44 of 1093 over four rotations)
             for c in generic:
                 is565 = c.rgb_format == abi.AVIF_RGB_FORMAT_RGB_565
                 alpha_first = c.rgb_format in (abi.AVIF_RGB_FORMAT_ARGB, abi.AVIF_RGB_FORMAT_ABGR)
                 pending = c.alpha and c.image_premultiplied != c.rgb_premultiplied
-                integer_only = arith == 0 and ((c.ignore_alpha and abi.rgb_format_has_alpha(c.rgb_format)) or (pending and alpha_first))
+                integer_only = arith == 0 and ((c.ignore_alpha and abi.rgb_format_has_alpha(c.rgb_format)) or pending)
                 assert is565 or integer_only, (arith, c.ident())
     finally:
         hip.avifhipSetArithmetic(1)
@@ -128,6 +131,11 @@ def test_half_float_and_identity_copy_use_the_tiled_kernels(hip):
                                rgb_premultiplied=True))
         for fmt, alpha in ((1, False), (1, True), (0, False), (4, True), (5, False), (3, False)):
             cases.append(H.Y2RCase(w, h, rgb_format=fmt, rgb_depth=8, yuv_depth=8, yuv_format=1, matrix=0, yuv_range=1, alpha=alpha, row_pad=64))
+        # ... and with the integer alpha (un)multiply that follows the copy for premultiplied lossless images (src/reformat.c:1574-1585; the
+        # identity transform as arithmetic reproduces every code: round 5, found by --seed-rotation 1)
+        for fmt, image_pm, rgb_pm in ((1, True, False), (1, False, True), (4, True, False), (2, False, True)):
+            cases.append(H.Y2RCase(w, h, rgb_format=fmt, rgb_depth=8, yuv_depth=8, yuv_format=1, matrix=0, yuv_range=1, alpha=True, image_premultiplied=image_pm,
+                                   rgb_premultiplied=rgb_pm, row_pad=64))
     for c in cases:
         H.run_y2r(H.HipDeviceBackend(), c)
         assert native.last_kernel().startswith("yuv2rgb_tile"), (c.ident(), native.last_kernel())
