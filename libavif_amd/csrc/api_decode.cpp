@@ -75,6 +75,7 @@ static avifResult yuvToRgbRows(const avifImage * image, avifRGBImage * rgb, bool
     const bool banded = pixelsOnHost && bandRows < rowEnd - rowBegin;
     if (banded && !tls.downloader)
         tls.downloader = new CopyWorker(tls.device, tls.downStream);
+    QuiesceOnExit quiesceOnExit; // (destroyed after drainOnExit: the helper thread's downloads first, then the streams)
     DrainOnExit drainOnExit = { banded ? tls.downloader : nullptr };
     if (pixelsOnHost && rgb->rowBytes == pixelRowBytes && hostRowsWantOneBlock(rgb->pixels, rgb->rowBytes, pixelRowBytes, rowEnd - rowBegin)) {
         r = reserve(tls.rawDown[4], (size_t)pixelRowBytes * (rowEnd - rowBegin)); // (api_internal.h: packRowsForDownload)
@@ -412,6 +413,7 @@ static avifResult rectJobsOnThisDevice(const avifImage * canvas, avifRGBImage * 
         return r;
     if (!tls.downloader)
         tls.downloader = new CopyWorker(tls.device, tls.downStream);
+    QuiesceOnExit quiesceOnExit; // (destroyed after drainOnExit: the helper thread's downloads first, then the streams)
     DrainOnExit drainOnExit = { tls.downloader };
     const uint32_t bps = (canvas->depth > 8) ? 2 : 1, px = rgbPixelBytes(rgbCanvas);
     tls.bytesUp = tls.bytesDown = 0;

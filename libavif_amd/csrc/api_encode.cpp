@@ -69,6 +69,7 @@ static avifResult rgbToYuvRows(avifImage * image, const avifRGBImage * rgb, uint
     const bool banded = bandRows < rowEnd - rowBegin;
     if (banded && !tls.downloader)
         tls.downloader = new CopyWorker(tls.device, tls.downStream);
+    QuiesceOnExit quiesceOnExit; // (destroyed after drainOnExit: the helper thread's downloads first, then the streams)
     DrainOnExit drainOnExit = { banded ? tls.downloader : nullptr };
     tls.bytesUp = tls.bytesDown = 0;
     for (int p = 0; p < 4 && !gray; ++p) {
@@ -250,6 +251,7 @@ static avifResult inPlaceBandedRows(avifRGBImage * rgb, uint32_t pixelRowBytes, 
     const bool banded = bandRows < rowEnd - rowBegin;
     if (banded && !tls.downloader)
         tls.downloader = new CopyWorker(tls.device, tls.downStream);
+    QuiesceOnExit quiesceOnExit; // (destroyed after drainOnExit: the helper thread's downloads first, then the streams)
     DrainOnExit drainOnExit = { banded ? tls.downloader : nullptr };
     tls.bytesUp = tls.bytesDown = 0;
     int band = 0;

@@ -653,6 +653,7 @@ static avifResult applyGainMapToHostImage(const avifRGBImage * baseImage, bool b
     const avifResult cr = ensureContext();
     if (cr != AVIF_RESULT_OK)
         return cr;
+    QuiesceOnExit quiesceOnExit; // (an unsupported colour space, a NaN ... is found after the uploads were enqueued)
     // device copies: base pixels, gain map planes, tone-mapped pixels
     avifRGBImage baseView, outView;
     memcpy(&baseView, baseImage, sizeof(avifRGBImage));
@@ -821,6 +822,7 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
     if (r != AVIF_RESULT_OK)
         return r;
     hipStream_t stream = tls.stream;
+    QuiesceOnExit quiesceOnExit;
     PhaseTrace trace("compute gain map");
     tls.gainMapCache.valid = false; // (the apply path's tables are not touched, but keep the two paths independent of call order)
 

@@ -354,6 +354,26 @@ uint32_t farmWorkers();
 // becomes the calling thread's), AVIF_RESULT_OK otherwise; the calling thread's launch count, transfer bytes, kernel name and farm report are
 // updated from the workers'.
 avifResult farmRun(const std::vector<FarmShare> & shares, avifResult (*job)(void * arg, uint32_t worker, FarmShare share), void * arg);
+// Host-resident entry points: however a call ends -- an error half way included -- nothing it enqueued may still be reading (uploads) or writing
+// (downloads) the caller's memory when it returns.  An "asynchronous" copy from pageable memory blocks its caller on this platform
+// UNLESS the runtime still has that memory pinned from an earlier copy: then it returns at once, and a call that gave up after its uploads were
+// enqueued (an unsupported colour space found later, say) handed the caller back memory the GPU was still reading -- a "Memory access fault by
+// GPU" once the caller freed it.  Declared
+// before the first upload of every host-resident entry point; the streams of a call that ended normally are idle already.
+struct QuiesceOnExit
+{
+    ~QuiesceOnExit()
+    {
+        Context & c = tls;
+        if (c.upStream)
+            (void)hipStreamSynchronize(c.upStream);
+        if (c.stream)
+            (void)hipStreamSynchronize(c.stream);
+        if (c.downStream)
+            (void)hipStreamSynchronize(c.downStream);
+    }
+};
+
 // leaves no download running into the caller's memory when a banded call returns early
 struct DrainOnExit
 {

@@ -295,6 +295,7 @@ extern "C" avifResult avifhipImageScale(avifImage * image, uint32_t dstWidth, ui
     if (r != AVIF_RESULT_OK)
         return r;
     uint8_t * base = (uint8_t *)tls.pixels.ptr;
+    QuiesceOnExit quiesceOnExit; // (the scaler may still refuse the job after the planes' uploads were enqueued)
     for (int p = 0; p < 4; ++p) {
         uint8_t ** sv = (p < 3) ? &srcView.yuvPlanes[p] : &srcView.alphaPlane;
         uint8_t ** dv = (p < 3) ? &dstView.yuvPlanes[p] : &dstView.alphaPlane;

@@ -298,7 +298,7 @@ def test_gpu_fast_kernel_converts_the_gain_maps_planes_itself(hip, monkeypatch, 
 def test_gpu_buffers_of_a_previous_call_are_kept_when_they_fit(hip_auto_arithmetic):
     """Round 5: avifRGBImageApplyGainMap frees and allocates the tone-mapped pixels, avifRGBImageComputeGainMap the gain map's planes
     (src/gainmap.c:114, :792-793).  A buffer of the right size that a previous call left in the struct stays where it is (releasing memory the
-    runtime had pinned costs milliseconds): same bytes as the oracle's, same address; another size gets a new buffer."""
+    runtime had pinned costs milliseconds): same bytes as the oracle's, same address; another size gets a buffer of its own."""
     o = oracle_lib.oracle()
     diag = abi.avifDiagnostics()
     out = G.make_output(G.GainMapCase(258, 40, out_depth=10))
@@ -315,7 +315,7 @@ def test_gpu_buffers_of_a_previous_call_are_kept_when_they_fit(hip_auto_arithmet
         assert ra == rb == 0 and (out.struct.width, out.struct.height) == (c.w, c.h)
         assert np.array_equal(G.output_bytes(out), pa), c.ident()
         seen.append(C.cast(out.struct.pixels, C.c_void_p).value)
-    assert seen[0] == seen[1] and seen[2] != seen[1], seen  # kept for the same size; the larger image cannot fit
+    assert seen[0] == seen[1], seen  # kept for the same size (the larger and the smaller image get buffers of their own: wherever malloc puts them)
     libc.free(C.cast(out.struct.pixels, C.c_void_p))
     out.struct.pixels = None
 
