@@ -417,6 +417,13 @@ AVIFHIP_API double avifhipTimeStreamCeilingBatch(uint32_t count, const avifImage
 AVIFHIP_API double avifhipTimeRGBToYUVCycle(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
 AVIFHIP_API double avifhipTimeYUVToRGBBatch(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects,
                                             int warmup, int iters, void * hipStream);
+/* ... and for a sequence walked `perLaunch` frames at a time: launch k converts frames (k * perLaunch + j) % count, j < perLaunch, in ONE
+ * launch (avifhipImageYUVToRGBBatchAsync, whole images).  Milliseconds per launch. */
+AVIFHIP_API double avifhipTimeYUVToRGBBatchCycle(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, uint32_t perLaunch, int warmup,
+                                                 int iters, void * hipStream);
+/* (its byte-movement ceiling: `count` must be a multiple of `perLaunch`) */
+AVIFHIP_API double avifhipTimeStreamCeilingBatchCycle(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, uint32_t perLaunch, int warmup,
+                                                      int iters, void * hipStream);
 AVIFHIP_API double avifhipTimeGridYUVToRGB(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
                                            avifBool alphaIsLimitedRange, avifRGBImage * rgbCanvas, int warmup, int iters, void * hipStream);
 

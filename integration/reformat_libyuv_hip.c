@@ -26,7 +26,6 @@
 
 #include <stdlib.h>
 #include <string.h>
-#include <time.h>
 
 /* Below this many pixels a conversion costs less on the CPU than the PCIe round trip (env override for tests). */
 static uint32_t avifHipMinPixels(void)
@@ -70,28 +69,17 @@ static avifBool avifHipFoldEnabled(void)
     /* (the headers this file was compiled against AND the library it runs in: a distribution may swap the shared object) */
     return AVIFHIP_FOLD_VALIDATED && strncmp(avifVersion(), "1.4.", 4) == 0;
 }
-/* A note libavif has not consumed after this long is dropped: its follow-up call comes microseconds after the colour hook returns
- * (AVIFHIP_FOLD_EXPIRY_MS overrides; tests) */
-static uint64_t avifHipFoldExpiryNs(void)
-{
-    const char * e = getenv("AVIFHIP_FOLD_EXPIRY_MS");
-    return (uint64_t)((e && *e) ? atoi(e) : 1000) * 1000000ull;
-}
-static uint64_t avifHipNowNs(void)
-{
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
-}
-
 /* One-shot note from the colour hook to the hooks libavif calls right after it on the same thread for the same pixels
  * (src/reformat.c:1574-1590: avifRGBImagePremultiplyAlpha / UnpremultiplyAlpha, then avifRGBImageToF16): avifhipImageYUVToRGBHook has
  * already produced the FINAL pixels, so those calls are answered without moving the image across the bus again.  A step is skipped only
  * if it is the very next hook call of this thread, for the same buffer and geometry, and a sample of the pixels still reads as the colour
- * hook left it, and the note is fresh; every other hook call drops the note.  (Between the two calls there is only libavif's own code: no
- * application code runs inside avifImageYUVToRGB, and a later, separate avifRGBImagePremultiplyAlpha of the application finds no note:
- * libavif consumed it.  Should a libavif ever NOT issue the follow-up -- the version gate above is there so that this cannot happen
- * silently -- the note dies with the thread's next hook call or of old age, whichever comes first.) */
+ * hook left it; every other hook call drops the note.  (Between the two calls there is only libavif's own code: no application code runs
+ * inside avifImageYUVToRGB, and a later, separate avifRGBImagePremultiplyAlpha of the application finds no note: libavif consumed it.
+ * Should a libavif ever NOT issue the follow-up -- the version gate above is there so that this cannot happen silently -- the note dies with
+ * the thread's next hook call.)
+ * No clock takes part (until round 6 a note also expired after a second): the follow-up of a stalled thread -- SIGSTOP, a paused VM, swap --
+ * arrives late but is still the follow-up, and answering it with a real pass would multiply pixels that are final already.  How long ago the
+ * colour hook ran says nothing about whose call this is; the thread, the buffer, the geometry and the pixels do. */
 typedef struct avifHipFoldNote
 {
     const uint8_t * pixels;
@@ -99,7 +87,6 @@ typedef struct avifHipFoldNote
     avifRGBFormat format;
     uint32_t steps; /* AVIFHIP_FOLDED_* still to be answered */
     uint64_t sample;
-    uint64_t armedNs; /* when the colour hook left it */
 } avifHipFoldNote;
 static _Thread_local avifHipFoldNote avifHipNote;
 
@@ -129,7 +116,7 @@ static avifBool avifHipTakeFoldedStep(const avifRGBImage * rgb, uint32_t step)
     avifHipFoldNote * n = &avifHipNote;
     const avifBool match = (n->steps & step) && n->pixels == rgb->pixels && n->width == rgb->width && n->height == rgb->height &&
                            n->rowBytes == rgb->rowBytes && n->depth == rgb->depth && n->format == rgb->format &&
-                           avifHipNowNs() - n->armedNs <= avifHipFoldExpiryNs() && n->sample == avifHipSamplePixels(rgb);
+                           n->sample == avifHipSamplePixels(rgb);
     if (!match) {
         n->steps = 0;
         return AVIF_FALSE;
@@ -162,7 +149,6 @@ avifResult avifImageYUVToRGBLibYUV(const avifImage * image, avifRGBImage * rgb, 
         avifHipNote.pixels = rgb->pixels, avifHipNote.width = rgb->width, avifHipNote.height = rgb->height, avifHipNote.rowBytes = rgb->rowBytes;
         avifHipNote.depth = rgb->depth, avifHipNote.format = rgb->format;
         avifHipNote.sample = avifHipSamplePixels(rgb);
-        avifHipNote.armedNs = avifHipNowNs();
         avifHipNote.steps = folded;
     }
     return r;

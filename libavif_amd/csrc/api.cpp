@@ -1012,6 +1012,24 @@ extern "C" double avifhipTimeYUVToRGBBatch(uint32_t count, const avifImage * con
     return timeCalls(hipStream, warmup, iters, [&](int, hipStream_t s) { return avifhipImageYUVToRGBBatchAsync(count, images, rgbs, rects, s); });
 }
 
+// launch k converts frames (k * perLaunch + j) % count, j < perLaunch, in ONE launch: a sequence walked `perLaunch` frames at a time, over a
+// working set (count frames) the caches cannot hold.  Milliseconds per LAUNCH.
+extern "C" double avifhipTimeYUVToRGBBatchCycle(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, uint32_t perLaunch, int warmup,
+                                                int iters, void * hipStream)
+{
+    if (count == 0 || perLaunch == 0 || perLaunch > count || !images || !rgbs)
+        return -1.0;
+    std::vector<const avifImage *> im(perLaunch);
+    std::vector<avifRGBImage *> px(perLaunch);
+    return timeCalls(hipStream, warmup, iters, [&](int k, hipStream_t s) {
+        for (uint32_t j = 0; j < perLaunch; ++j) {
+            const uint32_t f = (uint32_t)(((uint64_t)k * perLaunch + j) % count);
+            im[j] = images[f], px[j] = rgbs[f];
+        }
+        return avifhipImageYUVToRGBBatchAsync(perLaunch, im.data(), px.data(), nullptr, s);
+    });
+}
+
 extern "C" double avifhipTimeGridYUVToRGB(const avifhipGrid * grid, const avifImage * const * colorTiles, const avifImage * const * alphaTiles,
                                           avifBool alphaIsLimitedRange, avifRGBImage * rgbCanvas, int warmup, int iters, void * hipStream)
 {

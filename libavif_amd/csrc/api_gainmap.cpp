@@ -456,10 +456,23 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         }
     }
 
-    // statistics: every workgroup stores its partial into pinned host memory; added up here, in index order, once the stream has drained
+    // statistics: every workgroup stores its partial into device scratch; a copy behind the kernel brings them into pinned host memory, where they
+    // are added up, in index order, once the stream has drained.  (Until round 6 the kernel stored them straight into the pinned buffer;
+    // AVIFHIP_GM_PARTIALS=host keeps that route for experiments.)
+    static const bool partialsOnHost = [] {
+        const char * e = getenv("AVIFHIP_GM_PARTIALS");
+        return e && !strcmp(e, "host");
+    }();
     if (!tls.gainMapPartials)
         HIP_TRY(hipHostMalloc(&tls.gainMapPartials, (size_t)kGainMapMaxGroups * sizeof(GainMapPartial), hipHostMallocDefault));
-    A.partials = (GainMapPartial *)tls.gainMapPartials;
+    if (partialsOnHost) {
+        A.partials = (GainMapPartial *)tls.gainMapPartials;
+    } else {
+        const avifResult pr = reserve(tls.gainMap[3], (size_t)kGainMapMaxGroups * 8 * sizeof(float)); // (the computation's partials share the buffer)
+        if (pr != AVIF_RESULT_OK)
+            return pr;
+        A.partials = (GainMapPartial *)tls.gainMap[3].ptr;
+    }
     uint32_t partials = 0;
     if (tls.gainMapTimeIters > 0) { // avifhipTimeRGBImageApplyGainMap: the apply kernel alone, back to back, between two events
         for (int k = 0; k < tls.gainMapTimeWarmup; ++k)
@@ -494,12 +507,15 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
     // returns with its work enqueued, like every other Async call.
     if (mayReturnEarly && applyGain && A.fast && !clli && tls.gainMapTimeIters <= 0)
         return AVIF_RESULT_OK;
+    const GainMapPartial * hostPartials = (const GainMapPartial *)tls.gainMapPartials;
+    if (!partialsOnHost && partials)
+        HIP_TRY(hipMemcpyAsync(tls.gainMapPartials, A.partials, (size_t)partials * sizeof(GainMapPartial), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     GainMapStats stats = { 0, 0, 0.0 };
     {
         float rgbMax = 0.0f;
         for (uint32_t k = 0; k < partials; ++k) {
-            const GainMapPartial & part = A.partials[k];
+            const GainMapPartial & part = hostPartials[k];
             rgbMax = (part.max > rgbMax) ? part.max : rgbMax;
             stats.sum += part.sum;
             stats.nan |= (int32_t)part.nan;
@@ -653,6 +669,11 @@ static avifResult applyGainMapToHostImage(const avifRGBImage * baseImage, bool b
     const avifResult cr = ensureContext();
     if (cr != AVIF_RESULT_OK)
         return cr;
+    // the work buffers and tables below are the thread's, not a stream's: an asynchronous application this thread enqueued on ANOTHER stream
+    // (which since round 5 may return with its kernel pending) must have finished reading them before this call rewrites them
+    ScratchScope scratch(tls.stream);
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
     QuiesceOnExit quiesceOnExit; // (an unsupported colour space, a NaN ... is found after the uploads were enqueued)
     // device copies: base pixels, gain map planes, tone-mapped pixels
     avifRGBImage baseView, outView;
@@ -726,6 +747,9 @@ extern "C" avifResult avifhipImageApplyGainMap(const avifImage * baseImage, cons
     const avifResult cr = ensureContext();
     if (cr != AVIF_RESULT_OK)
         return cr;
+    ScratchScope scratch(tls.stream); // (the base pixels go into the thread's gain-map scratch: see applyGainMapToHostImage)
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
     baseRgb.rowBytes = alignUp(baseRgb.width * pixelBytes, 256);
     avifResult r = reserve(tls.gainMap[5], (size_t)baseRgb.rowBytes * baseRgb.height);
     if (r != AVIF_RESULT_OK)
@@ -822,6 +846,9 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
     if (r != AVIF_RESULT_OK)
         return r;
     hipStream_t stream = tls.stream;
+    ScratchScope scratch(stream); // (shares work buffers with the application's asynchronous entry point: see applyGainMapToHostImage)
+    if (scratch.result != AVIF_RESULT_OK)
+        return scratch.result;
     QuiesceOnExit quiesceOnExit;
     PhaseTrace trace("compute gain map");
     tls.gainMapCache.valid = false; // (the apply path's tables are not touched, but keep the two paths independent of call order)

@@ -446,8 +446,11 @@ static double timeMover(const std::vector<MoveJob> & jobs, uint32_t groups, uint
     return best;
 }
 
-static double timeCeilingGeneral(uint32_t count, const avifImage * const * images, const avifRGBImage * const * rgbs, bool toRgb, bool batch, int warmup, int iters, void * hipStream)
+static double timeCeilingGeneral(uint32_t count, const avifImage * const * images, const avifRGBImage * const * rgbs, bool toRgb, bool batch, int warmup, int iters, void * hipStream,
+                                 uint32_t perLaunch = 0)
 {
+    if (perLaunch && (perLaunch > count || count % perLaunch))
+        return -1.0;
     if (iters <= 0 || count == 0 || !images || !rgbs || ensureContext() != AVIF_RESULT_OK)
         return -1.0;
     std::vector<MoveJob> jobs(count);
@@ -474,6 +477,8 @@ static double timeCeilingGeneral(uint32_t count, const avifImage * const * image
             ++columns;
         shape.columns = (columns > 1 && count % columns == 0) ? columns : 0;
     }
+    if (perLaunch) // a sequence walked perLaunch frames at a time (avifhipTimeYUVToRGBBatchCycle)
+        return timeMover(jobs, count / perLaunch, perLaunch, shape, toRgb, warmup, iters, pickStream(hipStream));
     return batch ? timeMover(jobs, 1, count, shape, toRgb, warmup, iters, pickStream(hipStream)) : timeMover(jobs, count, 1, shape, toRgb, warmup, iters, pickStream(hipStream));
 }
 
@@ -597,4 +602,10 @@ extern "C" double avifhipTimeStreamCeilingRGBToYUV(uint32_t count, avifImage * c
 extern "C" double avifhipTimeStreamCeilingBatch(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream)
 {
     return timeCeilingGeneral(count, images, rgbs, true, true, warmup, iters, hipStream);
+}
+
+extern "C" double avifhipTimeStreamCeilingBatchCycle(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, uint32_t perLaunch, int warmup,
+                                                     int iters, void * hipStream)
+{
+    return timeCeilingGeneral(count, images, rgbs, true, false, warmup, iters, hipStream, perLaunch ? perLaunch : 1);
 }

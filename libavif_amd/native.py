@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
     "avifhipCopyToDevice", "avifhipCopyToHost", "avifhipDeviceMemset", "avifhipTimeYUVToRGB", "avifhipTimeRGBToYUV",
-    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipTimeStreamCeilingRGBToYUV", "avifhipTimeStreamCeilingBatch", "avifhipTimeStreamCeilingScale", "avifhipTimeRGBToYUVCycle", "avifhipTimeYUVToRGBBatch", "avifhipTimeGridYUVToRGB", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipTableUploadCount", "avifhipCalcYUVCoefficients",
+    "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipTimeStreamCeilingRGBToYUV", "avifhipTimeStreamCeilingBatch", "avifhipTimeStreamCeilingScale", "avifhipTimeRGBToYUVCycle", "avifhipTimeYUVToRGBBatch", "avifhipTimeYUVToRGBBatchCycle", "avifhipTimeStreamCeilingBatchCycle", "avifhipTimeGridYUVToRGB", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipTableUploadCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
     "avifhipSetDeviceSet", "avifhipSetFarmMinSharePixels", "avifhipGetDeviceSet", "avifhipPlanFarmRows", "avifhipLastFarmWorkers", "avifhipLastFarmTransferBytes",
     "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipTimeRGBImageApplyGainMap", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap",
@@ -91,6 +91,8 @@ def load() -> C.CDLL:
         "avifhipTimeRGBToYUV": (C.c_double, [P_IMG, P_RGB, i32, i32, vp]),
         "avifhipTimeRGBToYUVCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
         "avifhipTimeYUVToRGBBatch": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), P_RECT, i32, i32, vp]),
+        "avifhipTimeYUVToRGBBatchCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), u32, i32, i32, vp]),
+        "avifhipTimeStreamCeilingBatchCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), u32, i32, i32, vp]),
         "avifhipTimeGridYUVToRGB": (C.c_double, [C.POINTER(avifhipGrid), C.POINTER(P_IMG), C.POINTER(P_IMG), i32, P_RGB, i32, i32, vp]),
         "avifhipSynthFill": (u32, [u32, vp, u32, u32, u32, u32, u32, u32]),
         "avifhipStreamCreate": (vp, []),

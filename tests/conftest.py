@@ -14,12 +14,32 @@ if str(ROOT / "tests") not in sys.path:
 def pytest_addoption(parser):
     parser.addoption("--seed-rotation", action="store", default=None, metavar="N",
                      help="move the random part of every parity sweep to another seed stream (tests/harness.py: sweep_rng); 0 = the committed set")
+    parser.addoption("--order-seed", action="store", default=None, metavar="N",
+                     help="run the test FILES in a shuffled order (seeded; tests keep their order inside a file): the library keeps pooled contexts, "
+                          "worker threads and cached pinned buffers between calls, and the reference's functions are stateless -- no result may "
+                          "depend on what ran before (VERDICT round 5: the open fault was found by running two files in the other order)")
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     if config.getoption("--seed-rotation") is not None:
         os.environ["AVIFHIP_TEST_SEED_ROTATION"] = str(int(config.getoption("--seed-rotation")))
+
+
+def pytest_collection_modifyitems(config, items):
+    seed = config.getoption("--order-seed")
+    if seed is None:
+        return
+    import random
+
+    files = []
+    for item in items:
+        if item.fspath not in files:
+            files.append(item.fspath)
+    random.Random(int(seed)).shuffle(files)
+    rank = {f: k for k, f in enumerate(files)}
+    items.sort(key=lambda item: rank[item.fspath])  # (stable: the order inside a file stays)
+    print(f"\n--order-seed {seed}: " + " ".join(Path(str(f)).name for f in files))
 
 
 def _gpu_run(config) -> bool:

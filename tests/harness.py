@@ -232,9 +232,14 @@ class HipDeviceBackend(Backend):
 # runners
 
 
+_KEPT = []  # AVIFHIP_TEST_KEEP=1 (tests/tools/fault_hunt.sh): no buffer a conversion has seen is ever freed
+
+
 def run_y2r(backend: Backend, c: Y2RCase):
     img = make_y2r_inputs(c)
     rgb = make_y2r_output(c)
+    if os.environ.get("AVIFHIP_TEST_KEEP"):
+        _KEPT.append((img, rgb))
     if isinstance(backend, HipDeviceBackend):
         backend.bind_host(img.struct, img)
         backend.bind_host(rgb.struct, rgb)

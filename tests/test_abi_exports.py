@@ -47,6 +47,27 @@ def test_host_only_entry_points():
     assert abs(kr.value - 0.2126) < 1e-7 and abs(kb.value - 0.0722) < 1e-7 and abs(kg.value - 0.7152) < 1e-6
 
 
+def test_limited_full_exports_over_the_whole_code_range():
+    """avifhip{LimitedToFull,FullToLimited}{Y,UV} (host-only exports; src/reformat.c:1750-1840) against the reference compiled here and the
+    oracle, for every depth the reference's switch knows (8 / 10 / 12), one it does not (9: the value comes back unchanged), and every code of
+    the depth plus a margin either side (the reference clamps: out-of-range inputs included)."""
+    import oracle_lib
+
+    lib, o, r = native.load(), oracle_lib.oracle(), oracle_lib.ref()
+    pairs = [("avifhipLimitedToFullY", "oracleLimitedToFullY", "avifLimitedToFullY"), ("avifhipLimitedToFullUV", "oracleLimitedToFullUV", "avifLimitedToFullUV"),
+             ("avifhipFullToLimitedY", "oracleFullToLimitedY", "avifFullToLimitedY"), ("avifhipFullToLimitedUV", "oracleFullToLimitedUV", "avifFullToLimitedUV")]
+    checked = 0
+    for depth in (8, 10, 12, 9, 16):
+        for v in range(-70, (1 << min(depth, 12)) + 70):
+            for mine, orc, ref in pairs:
+                got, want = getattr(lib, mine)(depth, v), getattr(o, orc)(depth, v)
+                assert got == want, (mine, depth, v, got, want)
+                if r is not None:
+                    assert got == getattr(r, ref)(depth, v), (mine, depth, v)
+                checked += 1
+    assert checked > 4 * (256 + 1024 + 4096)
+
+
 def test_no_silent_cpu_fallback_without_gpu():
     lib = native.load()
     if lib.avifhipDeviceCount() > 0:

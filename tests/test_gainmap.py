@@ -416,6 +416,55 @@ def test_gpu_device_resident_without_light_levels_and_in_place(hip_auto_arithmet
 
 
 @pytest.mark.gpu
+def test_gpu_async_application_then_a_host_call_with_other_parameters(hip_auto_arithmetic):
+    """avifhipRGBImageApplyGainMapAsync on a stream of the caller's may return with its kernel pending; that kernel reads the
+    THREAD's scratch (the gain map scaled and converted to RGBA, the lookup tables).  A host-resident application or computation on the same
+    thread right behind it -- other sizes, other curves: it rewrites all of that on the library's own stream -- must wait for the pending
+    kernel.  The asynchronous call's pixels, read after its stream has drained, are the oracle's."""
+    from libavif_amd import device, native
+
+    lib, o = hip_auto_arithmetic, oracle_lib.oracle()
+    stream = lib.avifhipStreamCreate()
+    assert stream
+    diag = abi.avifDiagnostics()
+    # a scaled 4:2:0 gain map (scaled planes and an RGBA copy of them in scratch), large enough that its kernels are still running when
+    # the call returns
+    first = G.GainMapCase(2560, 1440, base_depth=8, out_depth=10, out_tc=16, out_primaries=9, gm_w=1280, gm_h=720, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, seed=31)
+    others = [G.GainMapCase(640, 360, base_depth=10, out_depth=8, out_tc=13, out_primaries=1, gm_w=320, gm_h=180, gm_format=abi.AVIF_PIXEL_FORMAT_YUV444,
+                            gm_gamma=((2, 1), (2, 1), (2, 1)), headroom=1.5, seed=32),
+              G.GainMapCase(1920, 1080, base_depth=8, out_depth=8, out_tc=1, gm_w=480, gm_h=270, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400, headroom=2.0, seed=33)]
+    ra, pa, _ = run(o.oracleRGBImageApplyGainMap, first, 1)
+    assert ra == 0
+    base = G.make_base(first)
+    gm, keep = G.make_gain_map(first)
+    dbase, dgm_img = device.DeviceRGB(base, upload=True), device.DeviceYUV(keep)
+    gm.image = C.pointer(dgm_img.struct)
+    wb = first.w * abi.rgb_pixel_size(first.out_format, first.out_depth)
+    try:
+        for rep in range(6):
+            other = others[rep % len(others)]
+            out = abi.make_rgb(first.w, first.h, first.out_depth, first.out_format, is_float=first.out_float, avoid_libyuv=False)
+            dout = device.DeviceRGB(out, upload=True)
+            rb = lib.avifhipRGBImageApplyGainMapAsync(dbase.struct, first.base_primaries, first.base_tc, C.byref(gm), first.headroom, first.out_primaries,
+                                                      first.out_tc, dout.struct, None, C.byref(diag), stream)
+            assert rb == 0, (rb, diag.error)
+            if rep % 2 == 0:
+                rc, pc, _ = run(lib.avifhipRGBImageApplyGainMap, other, C.byref(diag))
+                rw, pw, _ = run(o.oracleRGBImageApplyGainMap, other, 1)
+                assert rc == rw == 0 and np.array_equal(pc, pw), other.ident()
+            else:
+                cc = G.compute_cases(0, seed=11)[rep]
+                rc, sc = run_compute(lib.avifhipRGBImageComputeGainMap, cc, C.byref(diag))
+                rw, sw = run_compute(o.oracleRGBImageComputeGainMap, cc, 1)
+                assert rc == rw and states_equal(sc, sw), cc.ident()
+            native.check(lib.avifhipSynchronize(stream))
+            dout.download_into_host()
+            assert np.array_equal(out.pixels[:, :wb], pa[:, :wb]), f"repetition {rep}: the pending application read scratch a later call rewrote"
+    finally:
+        lib.avifhipStreamDestroy(stream)
+
+
+@pytest.mark.gpu
 def test_gpu_argument_errors(hip):
     diag = abi.avifDiagnostics()
     fn = hip.avifhipRGBImageApplyGainMap

@@ -4,6 +4,7 @@ real kernels and real transfers.  Every farmed call must produce the bytes of th
 padding included; every worker must move about 1/N of the image plus the chroma halo row of its seams."""
 import ctypes as C
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -33,6 +34,15 @@ def farm2(hip):
     assert hip.avifhipSetDeviceSet((C.c_int * 2)(0, 0), 2) == 0
     yield hip
     assert hip.avifhipSetDeviceSet(None, 0) == 0
+
+
+def _flush(hip):
+    """AVIFHIP_TEST_FLUSH=1 (tests/tools/fault_hunt.sh): small farmed calls right after a large one, while the large one's buffers are still alive."""
+    if os.environ.get("AVIFHIP_TEST_FLUSH"):
+        hip.avifhipSetFarmMinSharePixels(64 * 32)
+        for k in range(4):
+            H.run_y2r(H.hip_host_backend(), H.Y2RCase(300, 128 + 32 * k, yuv_depth=8, yuv_format=3, yuv_range=0, matrix=1, upsampling=4))
+        hip.avifhipSetFarmMinSharePixels(0)
 
 
 def reports(lib):
@@ -142,6 +152,7 @@ def test_headline_frame_and_grid_canvas_on_two_workers(farm2):
         total_up, total_down = C.c_uint64(0), C.c_uint64(0)
         farm2.avifhipLastTransferBytes(C.byref(total_up), C.byref(total_down))
         assert (total_up.value, total_down.value) == (sum(ups), sum(downs))
+        _flush(farm2)
 
 
 def test_encode_direction_4k_on_two_workers(farm2):

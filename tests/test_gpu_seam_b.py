@@ -277,10 +277,12 @@ def test_changed_pixels_between_hook_calls_fall_back_to_the_staged_path(libs, hi
             assert np.array_equal(out.pixels, twin.pixels), H.describe_diff(twin.pixels, out.pixels)
 
 
-def test_fold_can_be_switched_off_and_notes_expire(libs, hip_auto_arithmetic, monkeypatch):
+def test_fold_can_be_switched_off_and_a_late_follow_up_is_still_the_follow_up(libs, hip_auto_arithmetic, monkeypatch):
     """The fold rests on libavif's own call sequence: it is compiled in only for the libavif it was validated against (1.4.x) and
     AVIFHIP_FOLD=0 switches it off -- the colour hook then does only its own job and libavif's follow-up premultiply is a real pass with
-    the same bytes at the end.  A note that nobody consumed is dropped after AVIFHIP_FOLD_EXPIRY_MS."""
+    the same bytes at the end.  No clock takes part: a follow-up that arrives two seconds after the colour hook (a stopped process, a
+    paused VM) is answered from the note like a prompt one -- a real premultiply would run over pixels that are final already
+    (src/reformat.c:1574-1590: libavif issues the follow-up unconditionally, on the same thread)."""
     import time
 
     be, _ = libs
@@ -297,16 +299,21 @@ def test_fold_can_be_switched_off_and_notes_expire(libs, hip_auto_arithmetic, mo
     monkeypatch.delenv("AVIFHIP_FOLD")
     assert got_r == off_r == want_r == 0 and np.array_equal(got, want) and np.array_equal(off, want), c.ident()
     assert unfolded_launches > folded_launches, (folded_launches, unfolded_launches)
-    # the hooks called directly: a colour hook whose follow-up never comes, then -- much later for a note -- a premultiply of the same buffer
+    # the hooks called directly: the colour hook, a stall of two seconds, then libavif's follow-up premultiply of the same buffer
     raw = C.CDLL(os.fspath(BACKEND_SO), mode=os.RTLD_LOCAL)
     y2r = raw.avifImageYUVToRGBLibYUV
     y2r.restype, y2r.argtypes = C.c_int, [C.POINTER(abi.avifImage), C.POINTER(abi.avifRGBImage), C.c_int, C.POINTER(C.c_int)]
     pre = raw.avifRGBImagePremultiplyAlphaLibYUV
     pre.restype, pre.argtypes = C.c_int, [C.POINTER(abi.avifRGBImage)]
-    monkeypatch.setenv("AVIFHIP_FOLD_EXPIRY_MS", "5")
+    monkeypatch.setenv("AVIFHIP_FOLD_EXPIRY_MS", "5")  # (the knob of rounds 4-5: must be dead)
     img, out, flag = H.make_y2r_inputs(c), H.make_y2r_output(c), C.c_int(0)
     assert y2r(img.struct, out.struct, 1, C.byref(flag)) == 0
-    time.sleep(0.05)
+    time.sleep(2.0)
     before = lib.avifhipLaunchCount()
     assert pre(out.struct) == 0
-    assert lib.avifhipLaunchCount() > before, "an expired note must not answer the call"
+    assert lib.avifhipLaunchCount() == before, "the late follow-up ran a second pass over final pixels"
+    assert np.array_equal(out.pixels, want), "a stalled follow-up: " + H.describe_diff(want, out.pixels)
+    # ... and the note is gone: the application's own premultiply of that buffer afterwards is a real pass
+    before = lib.avifhipLaunchCount()
+    assert pre(out.struct) == 0
+    assert lib.avifhipLaunchCount() > before
