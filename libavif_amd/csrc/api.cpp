@@ -345,6 +345,17 @@ avifResult reserve(Scratch & s, size_t bytes)
     const size_t rounded = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
     HIP_TRY(hipMalloc(&s.ptr, rounded));
     s.capacity = rounded;
+    // AVIFHIP_POISON_SCRATCH=1 (the GPU test tier sets it, tests/conftest.py): new scratch starts as 0xA5 bytes instead of whatever the
+    // allocator hands out -- zeros in a young process, another context's pixels later.  A kernel that reads scratch nobody wrote (a table
+    // past its padding, a staging row past the upload) then misbehaves in EVERY process, not in two of three after the right history.
+    static const bool poison = [] {
+        const char * e = getenv("AVIFHIP_POISON_SCRATCH");
+        return e && *e && strcmp(e, "0") != 0;
+    }();
+    if (poison) {
+        HIP_TRY(hipMemsetAsync(s.ptr, 0xA5, rounded, tls.stream));
+        HIP_TRY(hipStreamSynchronize(tls.stream));
+    }
     return AVIF_RESULT_OK;
 }
 

@@ -297,6 +297,19 @@ static std::vector<avifCropRect> pipelinePieces(const avifCropRect * jobs, uint3
     return pieces;
 }
 
+// number of farm workers a list of rectangle jobs is worth: the device set's, capped like a whole image's row shares (planFarmRows) at one worker
+// per gFarmMinShare pixels of the jobs together -- two small rectangles are not worth a second device, whose worker stages device twins of the
+// whole canvas
+static uint32_t rectFarmWorkers(const std::vector<avifCropRect> & jobs)
+{
+    uint64_t pixels = 0;
+    for (const avifCropRect & rc : jobs)
+        pixels += (uint64_t)rc.width * rc.height;
+    const uint32_t workers = farmWorkers(); // (first: reads the environment's share size with its device set)
+    const uint64_t byPixels = pixels / farmMinSharePixels();
+    return (uint64_t)workers > byPixels ? (uint32_t)byPixels : workers;
+}
+
 extern "C" avifResult avifhipPlanRectTransfers(const avifImage * canvas, const avifRGBImage * rgbCanvas, const avifCropRect * rects, uint32_t count, uint64_t * bytesUp,
                                                uint64_t * bytesDown)
 {
@@ -313,7 +326,7 @@ extern "C" avifResult avifhipPlanRectTransfers(const avifImage * canvas, const a
     // (the pieces are cut per farm worker when a device set is active: the same shares avifhipImageYUVToRGBRects will hand out)
     const std::vector<avifCropRect> coalesced = coalesceRects(rects, count);
     std::vector<avifCropRect> pieces;
-    const uint32_t workers = farmWorkers();
+    const uint32_t workers = rectFarmWorkers(coalesced);
     if (workers >= 2 && coalesced.size() >= 2) {
         for (const FarmShare & share : planFarmJobs((uint32_t)coalesced.size(), workers)) {
             const std::vector<avifCropRect> part = pipelinePieces(coalesced.data() + share.begin, share.end - share.begin);
@@ -375,7 +388,7 @@ extern "C" avifResult avifhipImageYUVToRGBRects(const avifImage * canvas, avifRG
     // a device set of two or more workers: contiguous blocks of the (coalesced, row-major) job list, one per device -- whole tile rows when the
     // rectangles are the tiles of a grid (libavif_amd/farm.py: shard)
     const std::vector<avifCropRect> jobs = coalesceRects(rects, count);
-    const uint32_t workers = farmWorkers();
+    const uint32_t workers = rectFarmWorkers(jobs);
     if (workers >= 2 && jobs.size() >= 2) {
         const std::vector<FarmShare> shares = planFarmJobs((uint32_t)jobs.size(), workers);
         struct Call

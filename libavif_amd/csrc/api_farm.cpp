@@ -151,8 +151,8 @@ std::vector<int> deviceSetFromEnvironment()
     const char * e = getenv("AVIFHIP_DEVICES");
     if (!e || !*e)
         return set;
+    const int n = avifhipDeviceCount();
     if (!strcmp(e, "all")) {
-        const int n = avifhipDeviceCount();
         for (int d = 0; d < n; ++d)
             set.push_back(d);
         return set;
@@ -165,6 +165,12 @@ std::vector<int> deviceSetFromEnvironment()
             v = v * 10 + (*p++ - '0');
         if (v >= 4096)
             return std::vector<int>();
+        if (v >= n) {
+            // like avifhipSetDeviceSet, which refuses such a set: a worker on a device that does not exist would fail every farmed call
+            //  -- the set is ignored, calls run on the calling thread's device, and the user is told once
+            fprintf(stderr, "avifhip: AVIFHIP_DEVICES=%s names device %ld, but %d HIP device(s) are visible: the device set is ignored\n", e, v, n);
+            return std::vector<int>();
+        }
         set.push_back((int)v);
         if (!*p)
             return set;
@@ -255,6 +261,12 @@ std::vector<FarmShare> planFarmJobs(uint32_t count, uint32_t workers)
     return shares;
 }
 
+uint64_t farmMinSharePixels()
+{
+    const uint64_t v = gFarmMinShare.load(std::memory_order_relaxed);
+    return v ? v : 1;
+}
+
 uint32_t farmWorkers()
 {
     FarmState & state = farmState();
@@ -266,6 +278,7 @@ uint32_t farmWorkers()
 avifResult farmRun(const std::vector<FarmShare> & shares, avifResult (*job)(void * arg, uint32_t worker, FarmShare share), void * arg)
 {
     Batch batch;
+    bool runHere = false;
     const uint32_t n = (uint32_t)shares.size();
     batch.pending = n;
     batch.outcomes.resize(n);
@@ -275,19 +288,27 @@ avifResult farmRun(const std::vector<FarmShare> & shares, avifResult (*job)(void
         decide(state);
         if (state.farm && (state.farm->pid != (int)getpid() || state.farm->devices != state.deviceSet))
             retire(state);
-        if (n > state.deviceSet.size()) {
-            setError("farmRun: %u shares for a device set of %zu", n, state.deviceSet.size());
-            return AVIF_RESULT_UNKNOWN_ERROR;
-        }
-        if (!state.farm) {
+        if (n > state.deviceSet.size())
+            runHere = true; // the set shrank between the caller's plan and now (avifhipSetDeviceSet from another thread): see below
+        if (!runHere && !state.farm) {
             state.farm = new Farm;
             state.farm->devices = state.deviceSet;
             state.farm->pid = (int)getpid();
             for (int d : state.deviceSet)
                 state.farm->workers.emplace_back(new Worker(d));
         }
-        for (uint32_t k = 0; k < n; ++k)
+        for (uint32_t k = 0; !runHere && k < n; ++k)
             state.farm->workers[k]->post({ job, arg, k, shares[k], &batch });
+    }
+    if (runHere) {
+        // the shares are still a valid cut of the work: the calling thread takes them one after the other on its own device
+        tls.farmReports.clear();
+        for (uint32_t k = 0; k < n; ++k) {
+            const avifResult r = job(arg, k, shares[k]);
+            if (r != AVIF_RESULT_OK)
+                return r;
+        }
+        return AVIF_RESULT_OK;
     }
     {
         std::unique_lock<std::mutex> lock(batch.mutex);

@@ -3,7 +3,9 @@
 // gainmap_plan.cpp, kernels from kernels_gainmap.hip.
 #include "api_internal.h"
 
+#if defined(__GLIBC__)
 #include <malloc.h>
+#endif
 
 #include <chrono>
 
@@ -611,6 +613,24 @@ extern "C" double avifhipTimeRGBImageApplyGainMap(const avifRGBImage * baseImage
     return (r == AVIF_RESULT_OK) ? tls.gainMapTimedMs : -1.0;
 }
 
+// How many bytes a block the CALLER's image owns can take, for the "a buffer of the right size stays" shortcuts below: known only where the C
+// library can be asked (glibc, whose allocator libavif's avifAlloc and this library's malloc share in an ordinary build); 0 -- "unknown: release
+// and allocate, as the reference always does" -- anywhere else, and under AVIFHIP_KEEP_BUFFERS=0 for processes whose avifAlloc is not malloc
+// (malloc_usable_size on a pointer of another allocator is undefined).
+static size_t ownedBlockCapacity(const void * block)
+{
+#if defined(__GLIBC__)
+    static const bool keep = [] {
+        const char * e = getenv("AVIFHIP_KEEP_BUFFERS");
+        return !(e && !strcmp(e, "0"));
+    }();
+    return (block && keep) ? malloc_usable_size(const_cast<void *>(block)) : 0;
+#else
+    (void)block;
+    return 0;
+#endif
+}
+
 // host-resident images, like the reference: the tone-mapped image's pixels are (re)allocated with malloc (src/gainmap.c:112-114).
 // baseOnDevice: the base pixels are a device buffer of this call's own (avifhipImageApplyGainMap below: the YUV base image converted straight
 // into HBM, rows padded to 256 bytes) standing for the tightly packed host image the reference allocates there.
@@ -636,7 +656,7 @@ static avifResult applyGainMapToHostImage(const avifRGBImage * baseImage, bool b
     }
     const uint32_t outRowBytes = width * outPixelBytes;
     const size_t outBytes = (size_t)outRowBytes * height;
-    const size_t have = toneMappedImage->pixels ? malloc_usable_size(toneMappedImage->pixels) : 0;
+    const size_t have = ownedBlockCapacity(toneMappedImage->pixels);
     if (have < outBytes || have > outBytes + outBytes / 8 + 4096) {
         free(toneMappedImage->pixels);
         toneMappedImage->pixels = NULL, toneMappedImage->rowBytes = 0;
@@ -1061,7 +1081,7 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
     {
         const PlaneGeometry want = planeGeometry(gmImage);
         auto fits = [&](const uint8_t * plane, uint32_t rowBytes, int p) {
-            return plane && want.rows[p] && rowBytes == want.widthBytes[p] && malloc_usable_size((void *)plane) >= (size_t)rowBytes * want.rows[p];
+            return plane && want.rows[p] && rowBytes == want.widthBytes[p] && ownedBlockCapacity(plane) >= (size_t)rowBytes * want.rows[p];
         };
         if (gmImage->imageOwnsYUVPlanes)
             for (int p = 0; p < 3; ++p)

@@ -350,6 +350,8 @@ std::vector<FarmShare> planFarmRows(uint32_t width, uint32_t height, uint32_t wo
 std::vector<FarmShare> planFarmJobs(uint32_t count, uint32_t workers);
 // number of workers of the current device set (0 or 1: calls run on the calling thread's own device as ever)
 uint32_t farmWorkers();
+// smallest share worth a device of its own, in pixels (avifhipSetFarmMinSharePixels / AVIFHIP_FARM_MIN_PIXELS; never 0)
+uint64_t farmMinSharePixels();
 // Runs job(k, shares[k]) on worker k for every share and waits for all of them.  The result is the first failure in share order (its error text
 // becomes the calling thread's), AVIF_RESULT_OK otherwise; the calling thread's launch count, transfer bytes, kernel name and farm report are
 // updated from the workers'.

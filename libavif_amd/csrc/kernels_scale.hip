@@ -368,8 +368,14 @@ __device__ __forceinline__ void scalePlaneWindow(const ScaleArgs & A, int rowsPe
         return;
     const int jEnd = min(jBase + rowsPerWave, A.dstH);
 
-    // the lane's four destination columns (the column tables are padded with copies of their last entry, api_scale.cpp)
-    const int4 ca4 = *reinterpret_cast<const int4 *>(A.colA + i0), cb4 = *reinterpret_cast<const int4 *>(A.colB + i0);
+    // the lane's four destination columns.  The column tables are padded with copies of their last entry up to the next multiple of 16 + 16
+    // (api_scale.cpp) -- NOT up to the end of the block's 256 columns: lanes past the plane's last column take the entries of the last group of
+    // four that has one.  (Until round 6 they read colA[i0 ..] unclamped: beyond the padding for every plane narrower than its block, i.e. into
+    // the tables behind or past the upload into whatever the scratch allocation held before.  The entries decide the lane's load address: zeros
+    // -- fresh device memory -- are harmless, pixels of a buffer another context has just freed are a "Memory access fault by GPU" a gigabyte
+    // below the plane.  That was the open fault of round 5: gain maps scaled after the device farm had recycled its buffers.)
+    const int iTable = min(i0, (A.dstW - 1) & ~3);
+    const int4 ca4 = *reinterpret_cast<const int4 *>(A.colA + iTable), cb4 = *reinterpret_cast<const int4 *>(A.colB + iTable);
     const int ca[4] = { ca4.x, ca4.y, ca4.z, ca4.w }, cb[4] = { cb4.x, cb4.y, cb4.z, cb4.w };
     int c1[4];
     int cmin = 0x7fffffff;

@@ -24,6 +24,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     if config.getoption("--seed-rotation") is not None:
         os.environ["AVIFHIP_TEST_SEED_ROTATION"] = str(int(config.getoption("--seed-rotation")))
+    # The GPU tier runs with poisoned device scratch (libavif_amd/csrc/api.cpp: reserve): whatever a kernel reads from scratch that nobody
+    # wrote is 0xA5 bytes in every process -- not zeros in a young process and another context's pixels after the right history.  (Round 5's
+    # open fault was such a read: the window scaling kernel past its column tables; it showed only after the device farm had recycled
+    # its buffers, in two processes of three.)  AVIFHIP_POISON_SCRATCH=0 in the environment switches it off.
+    os.environ.setdefault("AVIFHIP_POISON_SCRATCH", "1")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -203,3 +203,38 @@ def test_single_device_calls_report_no_farm(hip):
     up, down = C.c_uint64(0), C.c_uint64(0)
     hip.avifhipLastTransferBytes(C.byref(up), C.byref(down))
     assert down.value == 512 * 128 * 4 and up.value >= 512 * 128 * 3 // 2
+
+
+def test_gain_maps_between_farmed_calls(hip):
+    """Round 5's open fault, as a test: host-resident gain-map applications (scaled gain maps: the window scaling kernel) after the device farm
+    has been used in the same process, then the farm again.  The reference's functions are stateless (src/gainmap.c:73, src/reformat.c:1709-1735):
+    what ran before -- worker threads come and gone, their contexts pooled, their device buffers freed and recycled -- must not matter."""
+    import gainmap_cases as G
+    import oracle_lib
+    import test_gainmap as TG
+
+    o = oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    big = H.Y2RCase(2560, 2560, yuv_depth=8, yuv_format=abi.AVIF_PIXEL_FORMAT_YUV420, yuv_range=abi.AVIF_RANGE_LIMITED, matrix=1,
+                    upsampling=abi.AVIF_CHROMA_UPSAMPLING_BILINEAR, avoid_libyuv=True)
+    want_r, want = H.run_y2r(H.oracle_backend(), big)
+    maps = [G.GainMapCase(66, 64, gm_w=23, gm_h=24, gm_format=abi.AVIF_PIXEL_FORMAT_YUV422, seed=3),
+            G.GainMapCase(300, 200, gm_w=77, gm_h=51, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420, out_depth=10, out_tc=16, seed=4),
+            G.GainMapCase(640, 360, gm_w=320, gm_h=180, gm_format=abi.AVIF_PIXEL_FORMAT_YUV444, seed=5),
+            G.GainMapCase(129, 65, gm_w=64, gm_h=33, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400, gm_depth=10, seed=6)]
+    for round_ in range(3):
+        assert hip.avifhipSetDeviceSet((C.c_int * 3)(0, 0, 0), 3) == 0
+        try:
+            got_r, got = H.run_y2r(H.hip_host_backend(), big)
+            assert hip.avifhipLastFarmWorkers() >= 2
+        finally:
+            assert hip.avifhipSetDeviceSet(None, 0) == 0  # the workers end: their contexts go back to the pool
+        assert got_r == want_r == 0 and np.array_equal(got, want), H.describe_diff(want, got)
+        hip.avifhipSetArithmetic(0)
+        try:
+            for c in maps:
+                ra, pa, ca = TG.run(o.oracleRGBImageApplyGainMap, c, 1)
+                rb, pb, cb = TG.run(hip.avifhipRGBImageApplyGainMap, c, C.byref(diag))
+                assert ra == rb == 0 and np.array_equal(pa, pb) and ca[0] == cb[0] and abs(ca[1] - cb[1]) <= 1, (round_, c.ident(), native.last_kernel())
+        finally:
+            hip.avifhipSetArithmetic(1)

@@ -23,7 +23,7 @@ typedef int hipError_t;
 typedef void * hipStream_t;
 typedef struct { uint32_t x, y, z; } dim3;
 
-enum { RING = 1 << 15, LIVE = 4096 };
+enum { RING = 1 << 13, LIVE = 4096, HISTORY = 1 << 14 };
 struct Event
 {
     double t;
@@ -59,8 +59,28 @@ static void note(const char * op, const void * a, const void * b, size_t n, size
     e->t = now(), e->tid = (int)syscall(SYS_gettid), e->op = op, e->a = a, e->b = b, e->n = n, e->m = m, e->stream = stream, e->result = result;
 }
 
+/* every allocation and release of the process, in order (allocations are few): was the faulting address EVER device memory, and who freed it when */
+struct Past
+{
+    double t;
+    const void * ptr;
+    size_t bytes;
+    int tid, kind; /* 0 device, 1 pinned; +2: release */
+};
+static struct Past history[HISTORY];
+static volatile uint64_t historyNext;
+static void remember(const void * p, size_t bytes, int kind)
+{
+    const uint64_t k = __atomic_fetch_add(&historyNext, 1, __ATOMIC_RELAXED);
+    if (k < HISTORY) {
+        struct Past * h = &history[k];
+        h->t = now(), h->ptr = p, h->bytes = bytes, h->tid = (int)syscall(SYS_gettid), h->kind = kind;
+    }
+}
+
 static void liveAdd(const void * p, size_t bytes, int pinned)
 {
+    remember(p, bytes, pinned);
     pthread_mutex_lock(&liveMutex);
     for (int k = 0; k < LIVE; ++k)
         if (!live[k].ptr) {
@@ -71,6 +91,7 @@ static void liveAdd(const void * p, size_t bytes, int pinned)
 }
 static void liveRemove(const void * p)
 {
+    remember(p, 0, 2);
     pthread_mutex_lock(&liveMutex);
     for (int k = 0; k < LIVE; ++k)
         if (live[k].ptr == p) {
@@ -258,6 +279,10 @@ static void dump(int sig)
         if (live[k].ptr)
             out(fd, "%s %p .. %p (%zu bytes) by thread %d\n", live[k].pinned ? "pinned" : "device", live[k].ptr, (const char *)live[k].ptr + live[k].bytes,
                 live[k].bytes, live[k].tid);
+    out(fd, "== every allocation / release, oldest first ==\n");
+    for (uint64_t k = 0; k < historyNext && k < HISTORY; ++k)
+        out(fd, "%.6f t%d %s %p .. %p (%zu bytes)\n", history[k].t, history[k].tid, history[k].kind == 0 ? "device" : history[k].kind == 1 ? "pinned" : "release",
+            history[k].ptr, (const char *)history[k].ptr + history[k].bytes, history[k].bytes);
     const uint64_t end = ringNext, begin = end > RING ? end - RING : 0;
     out(fd, "== last %llu runtime calls (oldest first) ==\n", (unsigned long long)(end - begin));
     for (uint64_t k = begin; k < end; ++k) {
