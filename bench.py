@@ -62,6 +62,8 @@ sys.path.insert(0, str(ROOT))
 WIDTH, HEIGHT = 7680, 4320
 FRAMES_IN_FLIGHT = 4  # distinct frame buffers cycled by the timed loop (4 x 182 MB > Infinity Cache)
 DEEP_FRAMES = 12      # ... by the "deep_streaming" kernel timing (2.2 GB: inputs cannot stay in the Infinity Cache either)
+SEQUENCE_FRAMES = 4   # frames per launch of the sequence rows (avifhipImageYUVToRGBBatchAsync over large frames: one launch of the single-image kernels)
+DEEP_FRAMES_4K = 24   # 4K frames cycled by the cold rows of planes_4k (1.1 GB)
 STREAMS = 1           # the timed region's streams (2: consecutive frames overlap head and tail; measured as well, reported as "two_streams")
 ALGORITHMIC_BYTES_PER_PIXEL = 5.5  # 1.5 B read (Y + U/4 + V/4) + 4 B written (RGBA8), SURVEY.md 8d
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -371,7 +373,9 @@ def main():
         return out
 
     frames = make_frames(WIDTH, HEIGHT, DEEP_FRAMES)
-    frames_4k = [] if args.headline_only else make_frames(WIDTH // 2, HEIGHT // 2, FRAMES_IN_FLIGHT)  # the north star's second plane size (3840x2160)
+    # the north star's second plane size (3840x2160): the first FRAMES_IN_FLIGHT are the cycled ones, all of them the cold rows'
+    frames_4k_all = [] if args.headline_only else make_frames(WIDTH // 2, HEIGHT // 2, DEEP_FRAMES_4K)
+    frames_4k = frames_4k_all[:FRAMES_IN_FLIGHT]
     n_streams = max(1, min(args.streams, FRAMES_IN_FLIGHT))
     streams = [lib.avifhipStreamCreate() for _ in range(max(n_streams, 2))]
     if any(not s for s in streams):
@@ -413,6 +417,7 @@ def main():
     n4, imgs4, rgbs4 = _cycle_args(frames[:FRAMES_IN_FLIGHT])
     nd, imgsd, rgbsd = _cycle_args(frames)
     nk, imgsk, rgbsk = _cycle_args(frames_4k) if frames_4k else (0, None, None)
+    nkd, imgskd, rgbskd = _cycle_args(frames_4k_all) if frames_4k_all else (0, None, None)
 
     def burst(fn, *a):
         # 40 ms of the SAME kernel first: after a change of kernel the first ~10 ms of launches run up to 25 % slower (tests/tools/
@@ -429,7 +434,7 @@ def main():
         return median([checked(fn(*a, 4, 40, None)) for _ in range(9)])
 
     def set_arithmetic(use_integer: bool) -> None:
-        for _, drgb in frames + frames_4k:
+        for _, drgb in frames + frames_4k_all:
             drgb.struct.avoidLibYUV = 0 if use_integer else 1
 
     timings = {}
@@ -440,6 +445,13 @@ def main():
         t["cold"] = burst(lib.avifhipTimeYUVToRGBCycle, nd, imgsd, rgbsd)
         t["same"] = burst(lib.avifhipTimeYUVToRGB, frames[0][0].struct, frames[0][1].struct)
         t["4k"] = burst(lib.avifhipTimeYUVToRGBCycle, nk, imgsk, rgbsk) if nk else None
+        # sequences: SEQUENCE_FRAMES frames per launch (milliseconds per LAUNCH), inputs cache-resident and not
+        t["seq_warm"] = burst(lib.avifhipTimeYUVToRGBBatchCycle, n4, imgs4, rgbs4, SEQUENCE_FRAMES)
+        t["seq_kernel"] = native.last_kernel()
+        t["seq_cold"] = burst(lib.avifhipTimeYUVToRGBBatchCycle, nd, imgsd, rgbsd, SEQUENCE_FRAMES)
+        t["4k_cold"] = burst(lib.avifhipTimeYUVToRGBCycle, nkd, imgskd, rgbskd) if nkd else None
+        t["4k_seq_warm"] = burst(lib.avifhipTimeYUVToRGBBatchCycle, nk, imgsk, rgbsk, SEQUENCE_FRAMES) if nk else None
+        t["4k_seq_cold"] = burst(lib.avifhipTimeYUVToRGBBatchCycle, nkd, imgskd, rgbskd, SEQUENCE_FRAMES) if nkd else None
         timings[fam] = t
     set_arithmetic(integer)
     main_fam, other_fam = ("integer", "fp32") if integer else ("fp32", "integer")
@@ -448,6 +460,8 @@ def main():
     # the chip's ceiling for this byte movement: same bytes, same lane mapping, no arithmetic (overwrites the RGB buffers)
     ceil_ms_stream = burst(lib.avifhipTimeStreamCeiling, n4, imgs4, rgbs4)
     ceil_ms_deep = burst(lib.avifhipTimeStreamCeiling, nd, imgsd, rgbsd)
+    ceil_ms_seq_cold = burst(lib.avifhipTimeStreamCeilingBatchCycle, nd, imgsd, rgbsd, SEQUENCE_FRAMES)
+    ceil_seq_pattern = native.last_kernel()
 
     more = {} if (args.dry_run or rank != 0 or args.headline_only) else measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k)
     set_arithmetic(integer)
@@ -465,6 +479,26 @@ def main():
 
     achieved = gbps(kernel_ms_stream)
     px4k = (WIDTH // 2) * (HEIGHT // 2)
+
+    def seq_block(ms_per_launch, pixels_per_frame, frames_cycled, what, **extra):
+        """a sequence row: one launch converts SEQUENCE_FRAMES frames -- algorithmic bytes per launch = 5.5 B x the launch's pixels"""
+        if ms_per_launch is None:
+            return None
+        px = pixels_per_frame * SEQUENCE_FRAMES
+        return {"what": what, "frames_per_launch": SEQUENCE_FRAMES, "frames_cycled": frames_cycled, "kernel_ms": round(ms_per_launch, 5),
+                "us_per_frame": round(1e3 * ms_per_launch / SEQUENCE_FRAMES, 3), "algorithmic_bytes_per_launch": int(ALGORITHMIC_BYTES_PER_PIXEL * px),
+                "achieved": round(gbps(ms_per_launch, px), 1), "frac": round(gbps(ms_per_launch, px) / HBM_PEAK_GBPS, 4),
+                "value": round(px / 1e6 / (ms_per_launch * 1e-3), 1), **extra}
+
+    def sequences(fam):
+        t = timings[fam]
+        return {
+            "what": f"avifhipImageYUVToRGBBatchAsync over {SEQUENCE_FRAMES} frames: ONE launch of the single-image kernel, grid z = frame, the frames' addresses in the "
+                    "kernel arguments (no descriptor table, no upload, no event between launches)",
+            "kernel": t["seq_kernel"],
+            "inputs_cache_resident": seq_block(t["seq_warm"], WIDTH * HEIGHT, FRAMES_IN_FLIGHT, f"{FRAMES_IN_FLIGHT} frames cycled (L3-resident planes: not an HBM figure)"),
+            "cold": seq_block(t["seq_cold"], WIDTH * HEIGHT, DEEP_FRAMES, f"{DEEP_FRAMES} frames cycled (2.2 GB): every byte comes from and goes to HBM"),
+        }
     out = {
         "metric": "megapixels/sec YUV420->RGBA (8K)",
         "value": round(value, 1),
@@ -527,16 +561,25 @@ def main():
             "cold": block(kernel_ms_deep, what=f"{DEEP_FRAMES} frames cycled (2.2 GB): neither planes nor pixels can stay in the 256 MB Infinity Cache",
                           frames_cycled=DEEP_FRAMES, ceiling_kernel_ms=round(ceil_ms_deep, 5),
                           ceiling_frac_of_peak=round(gbps(ceil_ms_deep) / HBM_PEAK_GBPS, 4), conversion_vs_ceiling=round(ceil_ms_deep / kernel_ms_deep, 4)),
+            # the HBM regime with the launch's ramp and tail shared by SEQUENCE_FRAMES frames: the figure a decoder of image sequences sees
+            "cold_batched": dict(sequences(main_fam)["cold"], kernel=timings[main_fam]["seq_kernel"], traffic=None, traffic_source=None,
+                                 ceiling={"what": "same bytes, same frames per launch, no arithmetic (avifhipTimeStreamCeilingBatchCycle: the fastest of the mover's patterns)",
+                                          "kernel_ms": round(ceil_ms_seq_cold, 5), "pattern": ceil_seq_pattern,
+                                          "frac_of_peak": round(gbps(ceil_ms_seq_cold, WIDTH * HEIGHT * SEQUENCE_FRAMES) / HBM_PEAK_GBPS, 4),
+                                          "conversion_vs_ceiling": round(ceil_ms_seq_cold / timings[main_fam]["seq_cold"], 4)}),
         },
         # the other arithmetic and the other plane size, measured in this run with the same method as roofline.kernel_ms
-        "fp32": block(timings["fp32"]["warm"], kernel=timings["fp32"]["kernel"], cold=block(timings["fp32"]["cold"]),
+        "fp32": block(timings["fp32"]["warm"], kernel=timings["fp32"]["kernel"], cold=block(timings["fp32"]["cold"]), sequence=sequences("fp32"),
                       what="rgb.avoidLibYUV = 1: libavif's built-in fp32 arithmetic (what the reference compiled from its own sources computes), same 8K frames"),
-        "integer": block(timings["integer"]["warm"], kernel=timings["integer"]["kernel"], cold=block(timings["integer"]["cold"]),
+        "integer": block(timings["integer"]["warm"], kernel=timings["integer"]["kernel"], cold=block(timings["integer"]["cold"]), sequence=sequences("integer"),
                          what="API defaults: libyuv's fixed point (what a stock libavif computes), same 8K frames"),
         "planes_4k": None if args.headline_only else {
-            "what": f"3840x2160 planes, same configuration, {FRAMES_IN_FLIGHT} frames cycled, kernel alone ({int(ALGORITHMIC_BYTES_PER_PIXEL * px4k)} B per launch)",
-            "integer": block(timings["integer"]["4k"], px4k),
-            "fp32": block(timings["fp32"]["4k"], px4k),
+            "what": f"3840x2160 planes, same configuration, kernel alone ({int(ALGORITHMIC_BYTES_PER_PIXEL * px4k)} B per frame): {FRAMES_IN_FLIGHT} frames cycled "
+                    f"(183 MB: L3-resident, not an HBM figure), `cold` {DEEP_FRAMES_4K} frames cycled (1.1 GB), `sequence` {SEQUENCE_FRAMES} frames per launch",
+            **{fam: block(timings[fam]["4k"], px4k, cold=block(timings[fam]["4k_cold"], px4k),
+                          sequence={"inputs_cache_resident": seq_block(timings[fam]["4k_seq_warm"], px4k, FRAMES_IN_FLIGHT, f"{FRAMES_IN_FLIGHT} frames cycled (L3-resident)"),
+                                    "cold": seq_block(timings[fam]["4k_seq_cold"], px4k, DEEP_FRAMES_4K, f"{DEEP_FRAMES_4K} frames cycled (1.1 GB)")})
+               for fam in ("integer", "fp32")},
         },
     }
     out.update(more)

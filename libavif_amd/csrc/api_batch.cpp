@@ -239,12 +239,63 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
     return AVIF_RESULT_OK;
 }
 
+// A batch of large frames that differ in their buffers only -- an image sequence -- runs through the single-image kernels, up to 8 frames per
+// launch, the frames' addresses in the kernel arguments (kernels.h launchYuvToRgbTileSequence): nothing is uploaded and no event sits between
+// consecutive launches, which costs a table batch of two 8K frames more than the second frame's ramp and tail save it.  *taken = false:
+// not a sequence (or a kernel family without sequence kernels) and nothing was launched.  AVIFHIP_SEQUENCE=0 keeps the table batches.
+static avifResult sequenceAsync(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects, void * hipStream, bool * taken)
+{
+    *taken = false;
+    static const bool off = [] {
+        const char * e = getenv("AVIFHIP_SEQUENCE");
+        return e && e[0] == '0' && !e[1];
+    }();
+    if (off || count == 0 || !images || !rgbs || !gTiledKernels.load(std::memory_order_relaxed))
+        return AVIF_RESULT_OK;
+    for (uint32_t k = 0; k < count; ++k)
+        if (!images[k] || !rgbs[k] || (uint64_t)images[k]->width * images[k]->height < ((uint64_t)2 << 20))
+            return AVIF_RESULT_OK; // (cheap rejection of grids of small tiles before anything is planned)
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    const int arithmetic = effectiveArithmetic();
+    const uint32_t tuning = gTuning.load(std::memory_order_relaxed);
+    std::vector<YuvToRgbPlan> plans(count);
+    for (uint32_t k = 0; k < count; ++k) {
+        avifResult pr = AVIF_RESULT_OK;
+        if (k == 0 || !rebindYuvToRgbPlan(plans[0], images[0], rgbs[0], images[k], rgbs[k], rects ? &rects[k] : nullptr, &plans[k], &pr))
+            pr = makeYuvToRgbPlan(images[k], rgbs[k], rects ? &rects[k] : nullptr, arithmetic, tuning, &plans[k]);
+        if (pr != AVIF_RESULT_OK)
+            return AVIF_RESULT_OK; // (the table path reports it, with its own message)
+        if (!tileSequenceCompatible(plans[0], plans[k]))
+            return AVIF_RESULT_OK;
+    }
+    hipStream_t stream = pickStream(hipStream);
+    for (uint32_t first = 0; first < count; first += kTileSequenceMax) {
+        const uint32_t n = count - first < kTileSequenceMax ? count - first : kTileSequenceMax;
+        const hipError_t e = launchYuvToRgbTileSequence(plans.data() + first, n, stream, &tls.lastKernel);
+        if (e == hipErrorNotSupported && first == 0) {
+            (void)hipGetLastError();
+            return AVIF_RESULT_OK;
+        }
+        if (e != hipSuccess)
+            return hipFailed(e, "YUV->RGB sequence kernel launch");
+        ++tls.launches;
+    }
+    *taken = true;
+    return AVIF_RESULT_OK;
+}
+
 extern "C" avifResult avifhipImageYUVToRGBBatchAsync(uint32_t count,
                                                      const avifImage * const * images,
                                                      avifRGBImage * const * rgbs,
                                                      const avifCropRect * rects,
                                                      void * hipStream)
 {
+    bool taken = false;
+    const avifResult sr = sequenceAsync(count, images, rgbs, rects, hipStream, &taken);
+    if (sr != AVIF_RESULT_OK || taken)
+        return sr;
     return batchAsyncImpl(count, images, rgbs, rects, nullptr, hipStream);
 }
 

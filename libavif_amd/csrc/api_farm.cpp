@@ -98,10 +98,6 @@ private:
                 c.bytesUp = c.bytesDown = 0;
                 c.lastError[0] = 0;
                 o.result = task.job(task.arg, task.index, task.share);
-                // (round 6 experiments on the open fault: what the worker does with its device before it parks)
-                static const char * fix = getenv("AVIFHIP_FARM_FIX");
-                if (fix && !strcmp(fix, "devsync"))
-                    (void)hipDeviceSynchronize();
                 o.launches = c.launches - launches0;
                 o.bytesUp = c.bytesUp, o.bytesDown = c.bytesDown;
                 snprintf(o.error, sizeof(o.error), "%s", c.lastError);

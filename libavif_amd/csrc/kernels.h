@@ -42,6 +42,13 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & plan);
 // id of the tiled-kernel instantiation serving `plan`, or -1 when only the generic kernel can
 int tileYuvToRgbVariant(const YuvToRgbPlan & plan);
 hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName);
+// Sequences (tile_shared.h SeqFrames): `count` <= 8 jobs that differ in their buffers only, each a frame large enough for the single image's
+// launch geometry, in ONE launch of the single-image kernels with the frames' addresses in the kernel arguments -- no device table, nothing
+// uploaded, no event between launches.  tileSequenceCompatible: `other` may share a launch with `first`; the launcher answers
+// hipErrorNotSupported (and launches nothing) for kernel families without sequence kernels.
+constexpr uint32_t kTileSequenceMax = 8;
+bool tileSequenceCompatible(const YuvToRgbPlan & first, const YuvToRgbPlan & other);
+hipError_t launchYuvToRgbTileSequence(const YuvToRgbPlan * plans, uint32_t count, hipStream_t stream, const char ** kernelName);
 // batch launches read a device table of distilled descriptors: tileBatchTableBytes(count) bytes, written on the host
 // by fillTileBatchTable.  They convert the whole-group part (w & ~3, h & ~1) of every job; the caller hands the
 // leftover columns/rows to launchYuvToRgbGenericBatch.

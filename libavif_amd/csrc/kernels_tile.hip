@@ -311,16 +311,14 @@ static int alphaSelOf(const tile::TileArgs & a)
     return 0;
 }
 
-hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)
+// the launch of one image's whole-group part (a sequence: of its first frame's, tile_shared.h SeqFrames)
+static void singleLaunchOf(const YuvToRgbPlan & plan, const TileKey & k, const TileArgs & A, hipStream_t stream, TileLaunch * out)
 {
-    const TileKey k = keyFor(plan);
-    if (kernelName)
-        *kernelName = kernelNameFor(k, plan.tuning);
-    const TileArgs A = distillArgs(plan);
-    TileLaunch L;
+    TileLaunch & L = *out;
     L.args = &A;
     L.alphaSel = alphaSelOf(A);
     L.table = nullptr;
+    L.seq = nullptr, L.seqCount = 0;
     L.count = 1;
     L.seams = false;
     L.stream = stream;
@@ -352,11 +350,12 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
         L.chunkRows = 0, L.wavesXLog2 = 2, L.pkStrips = 2;
         L.streamLoads = true;
     }
-    hipError_t e = launchFamily(k, L);
-    if (e != hipSuccess)
-        return e;
-    // leftovers: columns [w4, w) of every row, then row h2 of the columns before w4 (both rectangles start on even
-    // coordinates, as the chroma rules of the universal kernel require)
+}
+
+// leftovers of one image: columns [w4, w) of every row, then row h2 of the columns before w4
+static hipError_t launchLeftovers(const YuvToRgbPlan & plan, const TileArgs & A, hipStream_t stream)
+{
+    hipError_t e = hipSuccess;
     if (A.w4 != plan.w) {
         YuvToRgbPlan rest = plan;
         rest.x0 = plan.x0 + A.w4, rest.w = plan.w - A.w4;
@@ -370,6 +369,62 @@ hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, con
         e = launchYuvToRgbGeneric(rest, stream);
     }
     return e;
+}
+
+// A sequence's frames must be large enough that the single image's launch geometry is the right one for each of them (smaller jobs are what
+// the table batches are tuned for: grids of tiles)
+static constexpr uint64_t kSequenceMinPixels = (uint64_t)2 << 20;
+
+static_assert(kTileSequenceMax == kSeqMaxFrames, "kernels.h and tile_shared.h disagree on the frames of a sequence launch");
+bool tileSequenceCompatible(const YuvToRgbPlan & first, const YuvToRgbPlan & other)
+{
+    if (tileYuvToRgbVariant(first) < 0 || tileYuvToRgbVariant(first) != tileYuvToRgbVariant(other) || first.rgb.map.on || other.rgb.map.on)
+        return false;
+    if (first.w != other.w || first.h != other.h || (uint64_t)first.w * first.h < kSequenceMinPixels)
+        return false;
+    return seqCompatible(distillArgs(first), distillArgs(other));
+}
+
+hipError_t launchYuvToRgbTileSequence(const YuvToRgbPlan * plans, uint32_t count, hipStream_t stream, const char ** kernelName)
+{
+    if (count == 0 || count > kSeqMaxFrames)
+        return hipErrorInvalidValue;
+    const YuvToRgbPlan & plan = plans[0];
+    const TileKey k = keyFor(plan);
+    const TileArgs A = distillArgs(plan);
+    TileLaunch L;
+    singleLaunchOf(plan, k, A, stream, &L);
+    // the families with sequence kernels: the packed 16-bit integer kernels and the wave-private fp32 kernels, rows stored in place
+    const bool packed = k.fixedPoint && !k.hasMul && (!k.wideYuv || L.pkWide);
+    const bool soloFp32 = !k.fixedPoint && L.solo;
+    if (k.mapped || !(packed || soloFp32))
+        return hipErrorNotSupported;
+    SeqFrames S = seqOfOne(A);
+    for (uint32_t f = 1; f < count; ++f)
+        seqSetFrame(S, f, distillArgs(plans[f]));
+    L.seq = &S, L.seqCount = count;
+    hipError_t e = launchFamily(k, L);
+    if (e != hipSuccess)
+        return e; // (hipErrorNotSupported: nothing was launched)
+    if (kernelName)
+        *kernelName = kernelNameFor(k, plan.tuning);
+    for (uint32_t f = 0; f < count && e == hipSuccess; ++f)
+        e = launchLeftovers(plans[f], A, stream);
+    return e;
+}
+
+hipError_t launchYuvToRgbTile(const YuvToRgbPlan & plan, hipStream_t stream, const char ** kernelName)
+{
+    const TileKey k = keyFor(plan);
+    if (kernelName)
+        *kernelName = kernelNameFor(k, plan.tuning);
+    const TileArgs A = distillArgs(plan);
+    TileLaunch L;
+    singleLaunchOf(plan, k, A, stream, &L);
+    hipError_t e = launchFamily(k, L);
+    if (e != hipSuccess)
+        return e;
+    return launchLeftovers(plan, A, stream);
 }
 
 size_t tileBatchTableBytes(uint32_t count)
@@ -421,6 +476,7 @@ hipError_t launchYuvToRgbTileBatch(const void * deviceTileTable, const YuvToRgbP
         *kernelName = kernelNameFor(k, representative.tuning);
     TileLaunch L;
     L.args = nullptr;
+    L.seq = nullptr, L.seqCount = 0;
     L.seams = neighboursLinked && k.bilinear;
     L.alphaSel = alphaSelOf(distillArgs(representative)); // (all jobs of a batch share their configuration)
     L.table = static_cast<const TileArgs *>(deviceTileTable);

@@ -440,6 +440,8 @@ hipError_t launchOneFx(const TileLaunch & L)
         if (L.pkWide)
             return launchPkWide<SUB, BIL, NCH, APLANE>(L);
     }
+    if (L.seq)
+        return hipErrorNotSupported; // (sequences: the packed kernels above)
     if (L.solo)
         return launchSoloFx<YT, SUB, BIL, NCH, APLANE, MUL>(L);
     const dim3 block(kLanesX, kWavesPerBlock);

@@ -73,6 +73,16 @@ inline dim3 pkBatchGrid(const PkGeom & g, uint32_t blocks, uint32_t count)
     return g.canvasColumns ? dim3(g.tilesX * g.canvasColumns, g.tilesY, count / g.canvasColumns) : dim3(blocks, 1, count);
 }
 
+// The job of a workgroup of a sequence launch (tile_shared.h SeqFrames): the launch's arguments with the addresses of frame blockIdx.z.
+// (Kernel arguments live in constant memory: the copy costs five scalar loads whose offset depends on the workgroup.)
+__device__ __forceinline__ TileArgs seqJob(const TileArgs & A, const SeqFrames & S)
+{
+    TileArgs job = A;
+    const SeqFrames::Frame f = S.f[blockIdx.z];
+    job.y = f.y, job.a = f.a, job.u = f.u, job.v = f.v, job.rgb = f.rgb;
+    return job;
+}
+
 // Where wave `wave` (0..3) of the workgroup that took `tile` works: its band of 256 pixels and its first strip of 2 rows (it owns
 // `ns` consecutive strips)
 struct PkPlace
@@ -129,11 +139,11 @@ inline uint32_t turnShiftStrips(const TileArgs & A, int pixelBytes, int stripsPe
 }
 
 // Launch geometry: strips per wave, waves side by side, tile order (TuningBits; tests/tools/geometry_sweep.py)
-inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t * nsw, PkGeom * g, uint32_t * blocks)
+inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t * nsw, PkGeom * g, uint32_t * blocks, bool oneStripKernels = false)
 {
     const uint32_t bands = (w4 + 256u - 1) / 256u, strips = h2 / 2;
     uint32_t ns = L.pkStrips; // 0 = automatic
-    if (ns != 2 && ns != 4)
+    if (ns != 2 && ns != 4 && !(ns == 1 && oneStripKernels))
         ns = ((uint64_t)bands * ((strips + 15) / 16) * L.count >= 2048) ? 4 : 2; // 4 strips per wave only if that still makes 2048 workgroups
                                                                                  // (8 per CU): a 4K frame runs 12 % faster with 2 (9.4 -> 8.2 us)
     uint32_t wxl = L.wavesXLog2 <= 2 ? L.wavesXLog2 : 2;

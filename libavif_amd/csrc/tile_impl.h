@@ -1602,14 +1602,15 @@ __device__ __forceinline__ void runSolo(const TileArgs & A, const PkGeom & g, f2
 // (STREAM: single images of 16-bit planes too large for the Infinity Cache -- 8K 4:4:4 + alpha is 265 MB of planes -- may take streaming
 //  loads: kernels_tile.hip launchYuvToRgbTile)
 template <typename YT, int SUB, bool BIL, typename RT, int NCH, bool APLANE, bool HASMUL, int NS, int MULSEL = 0, bool STREAM = false>
-__global__ __launch_bounds__(256) void yuvToRgbTileSoloKernel(TileArgs A, PkGeom g)
+__global__ __launch_bounds__(256) void yuvToRgbTileSoloKernel(TileArgs A, PkGeom g, SeqFrames S)
 {
     __shared__ __attribute__((aligned(16))) f2 lds[kWavesPerBlock * (BIL ? StageRows<SUB, NS, 1>::kRows : 1) * kRowPitch];
+    const TileArgs job = seqJob(A, S); // (grid z = frame of a sequence, tile_shared.h SeqFrames: a single image is a sequence of one)
     if constexpr ((sizeof(RT) == 2 && NCH == 4) || NCH == 3) {
         __shared__ WideRowExchange xchg[kWavesPerBlock];
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(A, g, lds, xchg, pkTileOf(blockIdx.x, g));
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(job, g, lds, xchg, pkTileOf(blockIdx.x, g));
     } else {
-        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(A, g, lds, nullptr, pkTileOf(blockIdx.x, g));
+        runSolo<YT, SUB, BIL, RT, NCH, APLANE, HASMUL, NS, STREAM, MULSEL>(job, g, lds, nullptr, pkTileOf(blockIdx.x, g));
     }
 }
 
@@ -1727,6 +1728,8 @@ hipError_t launchSoloMapped(const TileLaunch & L)
     // quarter turns: the workgroup's rows must be the transposition tile's (tile_map_impl.h MapTile: 32 rows of 4-byte pixels, 16 of
     // 8-byte pixels), the four waves stacked, tiles numbered down the columns (tile_geom.h); rows: the automatic choice
     constexpr int kTurnNS = (sizeof(RT) == 1) ? 4 : 2;
+    if (L.seq)
+        return hipErrorNotSupported; // (a pixel map is per job)
     TileLaunch M = L;
     if (L.transposed) {
         M.pkStrips = kTurnNS, M.wavesXLog2 = 0;
@@ -1776,18 +1779,23 @@ hipError_t launchSoloSel(const TileLaunch & L, uint32_t nsw, const PkGeom & g, d
             hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, false, MULSEL>), grid, block, 0, L.stream, L.table, g);
         else
             hipLaunchKernelGGL((yuvToRgbTileSoloBatchKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, false, MULSEL>), grid, block, 0, L.stream, L.table, g);
-    } else if (L.streamLoads && sizeof(YT) == 2 && !BIL) {
-        if constexpr (sizeof(YT) == 2 && !BIL) {
-            if (nsw == 4)
-                AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, MULSEL, true>), grid, block, 0, L.stream, *L.args, g);
-            else
-                AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, MULSEL, true>), grid, block, 0, L.stream, *L.args, g);
-        }
     } else {
-        if (nsw == 4)
-            AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, MULSEL>), grid, block, 0, L.stream, *L.args, g);
-        else
-            AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, MULSEL>), grid, block, 0, L.stream, *L.args, g);
+        const SeqFrames S = L.seq ? *L.seq : seqOfOne(*L.args);
+        const dim3 frames(grid.x, 1, L.seq ? L.seqCount : 1u);
+        (void)S, (void)frames; // (seam-aware builds compile no single launches)
+        if (L.streamLoads && sizeof(YT) == 2 && !BIL) {
+            if constexpr (sizeof(YT) == 2 && !BIL) {
+                if (nsw == 4)
+                    AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, MULSEL, true>), frames, block, 0, L.stream, *L.args, g, S);
+                else
+                    AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, MULSEL, true>), frames, block, 0, L.stream, *L.args, g, S);
+            }
+        } else {
+            if (nsw == 4)
+                AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 4, MULSEL>), frames, block, 0, L.stream, *L.args, g, S);
+            else
+                AVIFHIP_SINGLE_LAUNCH((yuvToRgbTileSoloKernel<YT, SUB, BIL, RT, NCH, APLANE, MUL, 2, MULSEL>), frames, block, 0, L.stream, *L.args, g, S);
+        }
     }
     return hipGetLastError();
 }
@@ -1818,6 +1826,8 @@ hipError_t launchOne(const TileLaunch & L)
 {
     if (L.solo)
         return launchSolo<YT, SUB, BIL, RT, NCH, APLANE, MUL>(L);
+    if (L.seq)
+        return hipErrorNotSupported; // (the cooperative runs know single jobs and tables)
     const dim3 block(kLanesX, kWavesPerBlock);
     // (tiles of one canvas: workgroups along the canvas rows -- tile_geom.h PkGeom::canvasColumns)
     const uint32_t columns = (L.table && L.canvasColumns > 1 && !L.mapped && L.count % L.canvasColumns == 0) ? L.canvasColumns : 0u;

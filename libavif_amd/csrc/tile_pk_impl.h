@@ -855,12 +855,14 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     pkCompute<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, ATT>(A, w, raw, ring, xchg, xpose ? lds : nullptr, wy, recip);
 }
 
-template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE>
-__global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g)
+// (grid z = frame of a sequence, tile_shared.h SeqFrames: a single image is a sequence of one)
+// (STREAM = false for single images: their planes are assumed cache-resident -- just decoded / uploaded / produced; sequence launches whose
+//  bytes exceed the Infinity Cache take streaming luma / alpha loads, launchPkMapped)
+template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM = false>
+__global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g, SeqFrames S)
 {
-    constexpr bool STREAM = false; // single images: their planes are assumed cache-resident (just decoded / uploaded / produced)
     extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
-    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(A, g, lds, pkTileOf(blockIdx.x, g));
+    pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(seqJob(A, S), g, lds, pkTileOf(blockIdx.x, g));
 }
 
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM = false>
@@ -899,6 +901,8 @@ hipError_t launchPkAttenuate(const TileLaunch & L)
     const dim3 grid = pkBatchGrid(g, blocks, L.count);
     constexpr uint32_t kTable = (ATT == 2) ? 256u : 0u; // words: the reciprocal of every alpha code (pkRunBlock)
     const uint32_t lds4 = 4u * ((uint32_t)PkLds<SUB, BIL, 4, 4, false>::kPlain + kTable), lds2 = 4u * ((uint32_t)PkLds<SUB, BIL, 4, 2, false>::kPlain + kTable);
+    if (L.seq)
+        return hipErrorNotSupported;
     if (L.table) {
         if (nsw == 4)
             hipLaunchKernelGGL((yuvToRgbPkAttenuateBatchKernel<SUB, BIL, 4, WIDE, ATT>), grid, block, lds4, L.stream, L.table, g);
@@ -936,10 +940,15 @@ hipError_t launchPkMapped(const TileLaunch & L)
         else
             hipLaunchKernelGGL((yuvToRgbPkBatchKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, lds2, L.stream, L.table, g);
     } else {
+        if (L.seq && MAPPED)
+            return hipErrorNotSupported; // (a pixel map is per job)
+        const SeqFrames S = L.seq ? *L.seq : seqOfOne(*L.args);
+        const dim3 frames(grid.x, 1, L.seq ? L.seqCount : 1u);
+        (void)S, (void)frames; // (seam-aware builds compile no single launches)
         if (nsw == 4)
-            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), grid, block, lds4, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 4, MAPPED, WIDE>), frames, block, lds4, L.stream, *L.args, g, S);
         else
-            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), grid, block, lds2, L.stream, *L.args, g);
+            AVIFHIP_SINGLE_LAUNCH((yuvToRgbPkKernel<SUB, BIL, NCH, APLANE, 2, MAPPED, WIDE>), frames, block, lds2, L.stream, *L.args, g, S);
     }
     return hipGetLastError();
 }

@@ -115,6 +115,21 @@ struct TileArgs
 };
 
 
+// Sequences (round 6): up to kSeqMaxFrames jobs that differ in their buffers only -- the frames of an image sequence, each large enough to
+// fill the chip on its own -- converted by ONE launch of the single-image kernels: grid z = frame, the frame's five addresses taken from the
+// kernel arguments (no device table, so no upload and no event between launches: avifhipImageYUVToRGBBatchAsync, api_batch.cpp).  A single
+// image is a sequence of one.
+constexpr uint32_t kSeqMaxFrames = 8;
+struct SeqFrames
+{
+    struct Frame
+    {
+        const uint8_t *y, *a, *u, *v;
+        uint8_t * rgb;
+    } f[kSeqMaxFrames];
+};
+inline void seqSetFrame(SeqFrames & S, uint32_t k, const struct TileArgs & A);
+
 // The tiled kernel's arguments for the w4 x h2 whole-group part of a plan's rectangle.
 inline TileArgs distillArgs(const YuvToRgbPlan & p)
 {
@@ -253,6 +268,27 @@ inline void linkHalo(TileArgs & T, const uint8_t * const plane1[9], const uint8_
     T.haloSides = (above ? HALO_ABOVE : 0u) | (below ? HALO_BELOW : 0u) | (left ? HALO_LEFT : 0u) | (right ? HALO_RIGHT : 0u);
 }
 
+inline void seqSetFrame(SeqFrames & S, uint32_t k, const TileArgs & A)
+{
+    S.f[k].y = A.y, S.f[k].a = A.a, S.f[k].u = A.u, S.f[k].v = A.v, S.f[k].rgb = A.rgb;
+}
+inline SeqFrames seqOfOne(const TileArgs & A)
+{
+    SeqFrames S;
+    for (uint32_t k = 0; k < kSeqMaxFrames; ++k)
+        seqSetFrame(S, k, A);
+    return S;
+}
+// two jobs that may share a sequence launch: everything but the five addresses agrees (the halo entries of an unlinked job are never read)
+inline bool seqCompatible(const TileArgs & a, const TileArgs & b)
+{
+    TileArgs x = a, y = b;
+    x.y = y.y = nullptr, x.a = y.a = nullptr, x.u = y.u = nullptr, x.v = y.v = nullptr, x.rgb = y.rgb = nullptr;
+    x.haloRef = y.haloRef = nullptr;
+    memset(&x.halo, 0, sizeof(x.halo)), memset(&y.halo, 0, sizeof(y.halo));
+    return a.haloSides == 0 && b.haloSides == 0 && (a.a == nullptr) == (b.a == nullptr) && memcmp(&x, &y, sizeof(TileArgs)) == 0;
+}
+
 struct TileKey
 {
     bool fixedPoint; // libyuv arithmetic (tile_fx_impl.h), 8-bit RGB outputs
@@ -273,6 +309,10 @@ struct TileLaunch
 {
     const TileArgs * args;  // single job (kernarg) ...
     const TileArgs * table; // ... or device table of `count` jobs
+    // ... or a sequence: `args` with the addresses of `seqCount` frames (count stays 1: a frame's geometry is the single image's).  Families
+    // without sequence kernels answer hipErrorNotSupported (kernels_tile.hip launchYuvToRgbTileSequence asks only those that have them)
+    const SeqFrames * seq;
+    uint32_t seqCount;
     uint32_t count;
     uint32_t blocksPerJob;  // workgroups covering the largest job: one per run of tiles (= bandsPerJob * runsPerJob)
     uint32_t bandsPerJob, runsPerJob;
