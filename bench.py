@@ -664,6 +664,12 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     configs["cfg4"] = row(ms, 6.5 * px4k, px4k, "3840x2160 RGBA8 -> 8-bit 4:2:0 BT.709 limited + alpha plane (avifImageRGBToYUV); 8 frames cycled",
                           kernel=native.last_kernel(), same_frame=row(ms_same, 6.5 * px4k, px4k, "the same frame every launch (54 MB: cache-resident)"))
     configs["cfg4"]["ceiling"] = ceiling(burst(lib.avifhipTimeStreamCeilingRGBToYUV, 8, imgs, rgbs), ms, 6.5 * px4k)
+    # ... and as an image sequence on its way into an encoder: avifhipImageRGBToYUVBatchAsync, SEQUENCE_FRAMES frames per launch of the same kernel
+    ms_seq = burst(lib.avifhipTimeRGBToYUVBatchCycle, 8, imgs, rgbs, SEQUENCE_FRAMES)
+    configs["cfg4"]["sequence"] = row(ms_seq, 6.5 * px4k * SEQUENCE_FRAMES, px4k * SEQUENCE_FRAMES,
+                                      f"avifhipImageRGBToYUVBatchAsync: {SEQUENCE_FRAMES} frames per launch (grid z = frame, addresses in the kernel arguments), 8 frames cycled",
+                                      kernel=native.last_kernel(), frames_per_launch=SEQUENCE_FRAMES, us_per_frame=round(1e3 * ms_seq / SEQUENCE_FRAMES, 3))
+    configs["cfg4"]["sequence"]["ceiling"] = ceiling(burst(lib.avifhipTimeStreamCeilingRGBToYUVBatchCycle, 8, imgs, rgbs, SEQUENCE_FRAMES), ms_seq, 6.5 * px4k * SEQUENCE_FRAMES)
     configs["cfg4"]["same_frame"]["ceiling"] = ceiling(burst(lib.avifhipTimeStreamCeilingRGBToYUV, 1, imgs, rgbs), ms_same, 6.5 * px4k)
     del enc, imgs, rgbs
     # cfg5: 64 separately stored 1920x1080 10-bit 4:2:0 tiles -> RGBA (10 bits in 16-bit containers, API defaults), 11 B/pixel

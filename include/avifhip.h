@@ -96,6 +96,12 @@ AVIFHIP_API avifResult avifhipImageRGBToYUVAsync(avifImage * image, const avifRG
 AVIFHIP_API avifResult avifhipRGBImagePremultiplyAlphaAsync(avifRGBImage * rgb, void * hipStream);
 AVIFHIP_API avifResult avifhipRGBImageUnpremultiplyAlphaAsync(avifRGBImage * rgb, void * hipStream);
 
+/* `count` device-resident RGB -> YUV conversions enqueued on `hipStream` (the frames of an image sequence on their way into an encoder;
+ * src/reformat.c:161-519 per frame, same rules and results as `count` calls of avifhipImageRGBToYUVAsync, destination planes allocated
+ * by the caller).  Frames of 2 megapixels or more that differ in their buffers only share launches of the single-image kernel, up to 8
+ * frames per launch, so that a launch's ramp and tail are paid once per 8 frames; any other mix is converted frame by frame. */
+AVIFHIP_API avifResult avifhipImageRGBToYUVBatchAsync(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, void * hipStream);
+
 /* Grid tiles / sequence frames.  Converts the sub-rectangle `rect` of a stitched
  * canvas; chroma edge rules (src/reformat.c:768,784) are evaluated against the canvas, so the
  * output equals the same rectangle of a whole-canvas avifImageYUVToRGB.  Plane pointers of
@@ -415,6 +421,10 @@ AVIFHIP_API double avifhipTimeStreamCeilingBatch(uint32_t count, const avifImage
 /* The same event timing for the encode direction over `count` cycled frames, for a batch call (avifhipImageYUVToRGBBatchAsync: milliseconds
  * per batch) and for a grid call (avifhipGridYUVToRGBAsync: milliseconds per canvas, every kernel the call launches included). */
 AVIFHIP_API double avifhipTimeRGBToYUVCycle(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, int warmup, int iters, void * hipStream);
+AVIFHIP_API double avifhipTimeRGBToYUVBatchCycle(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, uint32_t perLaunch, int warmup, int iters,
+                                                 void * hipStream);
+AVIFHIP_API double avifhipTimeStreamCeilingRGBToYUVBatchCycle(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, uint32_t perLaunch, int warmup,
+                                                              int iters, void * hipStream);
 AVIFHIP_API double avifhipTimeYUVToRGBBatch(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects,
                                             int warmup, int iters, void * hipStream);
 /* ... and for a sequence walked `perLaunch` frames at a time: launch k converts frames (k * perLaunch + j) % count, j < perLaunch, in ONE

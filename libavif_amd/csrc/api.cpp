@@ -1017,6 +1017,23 @@ extern "C" double avifhipTimeRGBToYUVCycle(uint32_t count, avifImage * const * i
     return timeCalls(hipStream, warmup, iters, [&](int k, hipStream_t s) { return avifhipImageRGBToYUVAsync(images[k % count], rgbs[k % count], s); });
 }
 
+// ... walked `perLaunch` frames at a time through avifhipImageRGBToYUVBatchAsync: milliseconds per LAUNCH
+extern "C" double avifhipTimeRGBToYUVBatchCycle(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, uint32_t perLaunch, int warmup, int iters,
+                                                void * hipStream)
+{
+    if (count == 0 || perLaunch == 0 || perLaunch > count || !images || !rgbs)
+        return -1.0;
+    std::vector<avifImage *> im(perLaunch);
+    std::vector<const avifRGBImage *> px(perLaunch);
+    return timeCalls(hipStream, warmup, iters, [&](int k, hipStream_t s) {
+        for (uint32_t j = 0; j < perLaunch; ++j) {
+            const uint32_t f = (uint32_t)(((uint64_t)k * perLaunch + j) % count);
+            im[j] = images[f], px[j] = rgbs[f];
+        }
+        return avifhipImageRGBToYUVBatchAsync(perLaunch, im.data(), px.data(), s);
+    });
+}
+
 extern "C" double avifhipTimeYUVToRGBBatch(uint32_t count, const avifImage * const * images, avifRGBImage * const * rgbs, const avifCropRect * rects, int warmup,
                                            int iters, void * hipStream)
 {

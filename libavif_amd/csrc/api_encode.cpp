@@ -33,6 +33,59 @@ extern "C" avifResult avifhipImageRGBToYUVAsync(avifImage * image, const avifRGB
     return enqueueRgbToYuv(plan, pickStream(hipStream));
 }
 
+// `count` device-resident frames in as few launches as their configurations allow (include/avifhip.h): frames that differ in their buffers
+// only -- an image sequence on its way into an encoder -- share launches of the single-image kernel, up to 8 per launch (kernels.h
+// launchRgbToYuvTileSequence); anything else is converted frame by frame, exactly like `count` calls of avifhipImageRGBToYUVAsync.
+extern "C" avifResult avifhipImageRGBToYUVBatchAsync(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, void * hipStream)
+{
+    if (count == 0)
+        return AVIF_RESULT_OK;
+    if (!images || !rgbs)
+        return AVIF_RESULT_INVALID_ARGUMENT;
+    std::vector<RgbToYuvPlan> plans(count);
+    const uint32_t tuning = gTuning.load(std::memory_order_relaxed);
+    bool sequence = gTiledKernels.load(std::memory_order_relaxed) != 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        avifImage * image = images[k];
+        const avifRGBImage * rgb = rgbs[k];
+        if (!image || !rgb)
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        const avifResult pr = makeRgbToYuvPlan(image, rgb, effectiveArithmetic(), &plans[k]);
+        if (pr != AVIF_RESULT_OK)
+            return pr;
+        if (sharpYuvRequested(image, rgb))
+            return AVIF_RESULT_NOT_IMPLEMENTED; // (like avifhipImageRGBToYUVAsync)
+        const bool needAlpha = plans[k].rgb.hasAlpha && !rgb->ignoreAlpha;
+        if (!image->yuvPlanes[0] || (image->yuvFormat != AVIF_PIXEL_FORMAT_YUV400 && (!image->yuvPlanes[1] || !image->yuvPlanes[2])) ||
+            (needAlpha && !image->alphaPlane)) {
+            setError("avifhipImageRGBToYUVBatchAsync: destination planes must be allocated by the caller (frame %u)", k);
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        }
+        finishRgbToYuvPlan(image, rgb, &plans[k]);
+        sequence = sequence && tileRgbToYuvSequenceCompatible(plans[0], plans[k], tuning);
+    }
+    const avifResult cr = ensureContext();
+    if (cr != AVIF_RESULT_OK)
+        return cr;
+    hipStream_t stream = pickStream(hipStream);
+    if (!sequence) {
+        for (uint32_t k = 0; k < count; ++k) {
+            const avifResult r = enqueueRgbToYuv(plans[k], stream);
+            if (r != AVIF_RESULT_OK)
+                return r;
+        }
+        return AVIF_RESULT_OK;
+    }
+    for (uint32_t first = 0; first < count; first += kRgbToYuvSequenceMax) {
+        const uint32_t n = count - first < kRgbToYuvSequenceMax ? count - first : kRgbToYuvSequenceMax;
+        const hipError_t e = launchRgbToYuvTileSequence(plans.data() + first, n, stream, &tls.lastKernel, tuning);
+        if (e != hipSuccess)
+            return hipFailed(e, "RGB->YUV sequence kernel launch");
+        ++tls.launches;
+    }
+    return AVIF_RESULT_OK;
+}
+
 // Rows [rowBegin, rowEnd) of the conversion on the calling thread's device (the whole image, or a farm worker's share: rowBegin even, so
 // that no 2 x 2 block is cut).  Arguments validated and destination planes allocated by the caller.
 static avifResult rgbToYuvRows(avifImage * image, const avifRGBImage * rgb, uint32_t rowBegin, uint32_t rowEnd)

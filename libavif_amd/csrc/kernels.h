@@ -74,6 +74,11 @@ void linkTileBatchHalo(void * hostTable, uint32_t job, const TileNeighbours & ne
 hipError_t launchGrayChromaFill(const RgbToYuvPlan & plan, hipStream_t stream);
 bool tileRgbToYuvSupported(const RgbToYuvPlan & plan);
 hipError_t launchRgbToYuvTile(const RgbToYuvPlan & plan, hipStream_t stream, const char ** kernelName, uint32_t tuning = TUNE_DEFAULT);
+// Sequences of the encode direction (r2y_tile_shared.h R2YSeqFrames), like launchYuvToRgbTileSequence: `count` <= 8 colour frames of 2
+// megapixels or more that differ in their buffers only, ONE launch of the single-image kernel
+constexpr uint32_t kRgbToYuvSequenceMax = 8;
+bool tileRgbToYuvSequenceCompatible(const RgbToYuvPlan & first, const RgbToYuvPlan & other, uint32_t tuning = TUNE_DEFAULT);
+hipError_t launchRgbToYuvTileSequence(const RgbToYuvPlan * plans, uint32_t count, hipStream_t stream, const char ** kernelName, uint32_t tuning = TUNE_DEFAULT);
 
 // crop + rotate + mirror of an interleaved pixel buffer in one pass (kernels_transform.hip)
 struct TransformArgs

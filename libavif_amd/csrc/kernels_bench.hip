@@ -609,3 +609,9 @@ extern "C" double avifhipTimeStreamCeilingBatchCycle(uint32_t count, const avifI
 {
     return timeCeilingGeneral(count, images, rgbs, true, false, warmup, iters, hipStream, perLaunch ? perLaunch : 1);
 }
+
+extern "C" double avifhipTimeStreamCeilingRGBToYUVBatchCycle(uint32_t count, avifImage * const * images, const avifRGBImage * const * rgbs, uint32_t perLaunch, int warmup,
+                                                             int iters, void * hipStream)
+{
+    return timeCeilingGeneral(count, images, rgbs, false, false, warmup, iters, hipStream, perLaunch ? perLaunch : 1);
+}

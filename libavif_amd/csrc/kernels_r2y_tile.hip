@@ -159,16 +159,13 @@ hipError_t launchGrayToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const
 }
 } // namespace
 
-hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const char ** kernelName, uint32_t tuning)
+namespace {
+// the tiled kernel's arguments for the whole-group part of a colour plan, and the workgroups of its launch
+uint32_t colourArgsOf(const RgbToYuvPlan & p, const R2YKey & k, uint32_t tuning, R2YArgs * out)
 {
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
-    if (o.isGray)
-        return launchGrayToYuvTile(p, stream, kernelName);
-    const R2YKey k = keyFor(p);
-    if (kernelName)
-        *kernelName = kernelNameFor(k);
-    R2YArgs A;
+    R2YArgs & A = *out;
     memset(&A, 0, sizeof(A));
     A.rgb = o.pixels;
     A.y = s.plane[0], A.u = s.plane[1], A.v = s.plane[2], A.a = s.alpha;
@@ -219,11 +216,13 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
         A.fx.u0 = redFirst ? ur : ub, A.fx.u1 = ug, A.fx.u2 = redFirst ? ub : ur;
         A.fx.v0 = redFirst ? vr : vb, A.fx.v1 = vg, A.fx.v2 = redFirst ? vb : vr;
     }
-    hipError_t e = k.fixedPoint ? launchR2YTileFx(k, A, bands * chunks, stream)
-                                : (k.wideRgb ? launchR2YTileRgb16(k, A, bands * chunks, stream) : launchR2YTileRgb8(k, A, bands * chunks, stream));
-    if (e != hipSuccess)
-        return e;
-    // leftovers: columns [w4, width) of every row, then row h2 of the columns before w4 (even origins: whole 2x2 blocks)
+    return bands * chunks;
+}
+
+// leftovers: columns [w4, width) of every row, then row h2 of the columns before w4 (even origins: whole 2x2 blocks)
+hipError_t colourLeftovers(const RgbToYuvPlan & p, const R2YArgs & A, hipStream_t stream)
+{
+    hipError_t e = hipSuccess;
     if (A.w4 != p.width) {
         RgbToYuvPlan rest = p;
         rest.rx0 = A.w4, rest.rw = p.width - A.w4;
@@ -236,6 +235,64 @@ hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const 
         rest.ry0 = A.h2, rest.rh = p.height - A.h2, rest.rw = A.w4;
         e = launchRgbToYuvGeneric(rest, stream);
     }
+    return e;
+}
+
+hipError_t launchColour(const R2YKey & k, const R2YArgs & A, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & S, uint32_t frames)
+{
+    return k.fixedPoint ? launchR2YTileFx(k, A, blocks, stream, S, frames)
+                        : (k.wideRgb ? launchR2YTileRgb16(k, A, blocks, stream, S, frames) : launchR2YTileRgb8(k, A, blocks, stream, S, frames));
+}
+} // namespace
+
+hipError_t launchRgbToYuvTile(const RgbToYuvPlan & p, hipStream_t stream, const char ** kernelName, uint32_t tuning)
+{
+    if (p.rgb.isGray)
+        return launchGrayToYuvTile(p, stream, kernelName);
+    const R2YKey k = keyFor(p);
+    if (kernelName)
+        *kernelName = kernelNameFor(k);
+    R2YArgs A;
+    const uint32_t blocks = colourArgsOf(p, k, tuning, &A);
+    const hipError_t e = launchColour(k, A, blocks, stream, r2ySeqOfOne(A), 1);
+    if (e != hipSuccess)
+        return e;
+    return colourLeftovers(p, A, stream);
+}
+
+// Sequences: frames that differ in their buffers only, each large enough for the single image's launch geometry to be the right one
+static_assert(kRgbToYuvSequenceMax == kR2YSeqMaxFrames, "kernels.h and r2y_tile_shared.h disagree on the frames of a sequence launch");
+bool tileRgbToYuvSequenceCompatible(const RgbToYuvPlan & first, const RgbToYuvPlan & other, uint32_t tuning)
+{
+    if (first.rgb.isGray || other.rgb.isGray || !tileRgbToYuvSupported(first) || !tileRgbToYuvSupported(other))
+        return false;
+    if (first.width != other.width || first.height != other.height || (uint64_t)first.width * first.height < ((uint64_t)2 << 20))
+        return false;
+    const R2YKey ka = keyFor(first), kb = keyFor(other);
+    if (ka.fixedPoint != kb.fixedPoint || ka.wideRgb != kb.wideRgb || ka.wideYuv != kb.wideYuv || ka.nch != kb.nch || ka.sub != kb.sub || ka.hasMul != kb.hasMul)
+        return false;
+    R2YArgs a, b;
+    return colourArgsOf(first, ka, tuning, &a) == colourArgsOf(other, kb, tuning, &b) && r2ySeqCompatible(a, b);
+}
+
+hipError_t launchRgbToYuvTileSequence(const RgbToYuvPlan * plans, uint32_t count, hipStream_t stream, const char ** kernelName, uint32_t tuning)
+{
+    if (count == 0 || count > kR2YSeqMaxFrames)
+        return hipErrorInvalidValue;
+    const R2YKey k = keyFor(plans[0]);
+    if (kernelName)
+        *kernelName = kernelNameFor(k);
+    R2YArgs A;
+    const uint32_t blocks = colourArgsOf(plans[0], k, tuning, &A);
+    R2YSeqFrames S = r2ySeqOfOne(A);
+    for (uint32_t f = 1; f < count; ++f) {
+        R2YArgs B;
+        (void)colourArgsOf(plans[f], k, tuning, &B);
+        r2ySeqSetFrame(S, f, B);
+    }
+    hipError_t e = launchColour(k, A, blocks, stream, S, count);
+    for (uint32_t f = 0; f < count && e == hipSuccess; ++f)
+        e = colourLeftovers(plans[f], A, stream);
     return e;
 }
 

@@ -8,9 +8,9 @@
 
 namespace avifhip {
 namespace r2y {
-hipError_t R2Y_FN(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream)
+hipError_t R2Y_FN(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & frames, uint32_t frameCount)
 {
-    return launchFamily<R2Y_RT>(key, args, blocks, stream);
+    return launchFamily<R2Y_RT>(key, args, blocks, stream, frames, frameCount);
 }
 #ifdef R2Y_GRAY_FN
 hipError_t R2Y_GRAY_FN(int grayChannels, bool wideYuv, const GrayArgs & args, hipStream_t stream)
@@ -19,9 +19,9 @@ hipError_t R2Y_GRAY_FN(int grayChannels, bool wideYuv, const GrayArgs & args, hi
 }
 #endif
 #ifdef R2Y_WITH_FX
-hipError_t launchR2YTileFx(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream)
+hipError_t launchR2YTileFx(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & frames, uint32_t frameCount)
 {
-    return key.nch == 4 ? launchFxSub<4>(key.sub, args, blocks, stream) : launchFxSub<3>(key.sub, args, blocks, stream);
+    return key.nch == 4 ? launchFxSub<4>(key.sub, args, blocks, stream, frames, frameCount) : launchFxSub<3>(key.sub, args, blocks, stream, frames, frameCount);
 }
 #endif
 } // namespace r2y

@@ -535,9 +535,19 @@ __device__ __forceinline__ uint32_t r2yBlockOf(uint32_t b, uint32_t n, bool xcdB
     return xcd * per + (xcd < rem ? xcd : rem) + slot;
 }
 
-template <int NCH, int SUB, int NS>
-__global__ __launch_bounds__(256) void rgbToYuvTileFxKernel(R2YArgs A)
+// the job of a workgroup of a sequence launch (r2y_tile_shared.h R2YSeqFrames): the launch's arguments with the addresses of frame blockIdx.z
+__device__ __forceinline__ R2YArgs r2ySeqJob(const R2YArgs & A, const R2YSeqFrames & S)
 {
+    R2YArgs job = A;
+    const R2YSeqFrames::Frame f = S.f[blockIdx.z];
+    job.rgb = f.rgb, job.y = f.y, job.u = f.u, job.v = f.v, job.a = f.a;
+    return job;
+}
+
+template <int NCH, int SUB, int NS>
+__global__ __launch_bounds__(256) void rgbToYuvTileFxKernel(R2YArgs A0, R2YSeqFrames S)
+{
+    const R2YArgs A = r2ySeqJob(A0, S);
     const uint32_t bands = (A.w4 + 255) / 256;
     const uint32_t block = r2yBlockOf(blockIdx.x, gridDim.x, A.xcdBands != 0);
     const uint32_t band = block % bands, chunk = block / bands;
@@ -560,25 +570,25 @@ __global__ __launch_bounds__(256) void rgbToYuvTileFxKernel(R2YArgs A)
 }
 
 template <int NCH, int SUB>
-void launchFxOne(const R2YArgs & A, uint32_t blocks, hipStream_t stream)
+void launchFxOne(const R2YArgs & A, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & S, uint32_t frames)
 {
-    const dim3 block(kLanes, kWaves);
+    const dim3 block(kLanes, kWaves), grid(blocks, 1, frames);
     if (A.stripsPerWave >= 4)
-        hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB, 4>), dim3(blocks), block, 0, stream, A);
+        hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB, 4>), grid, block, 0, stream, A, S);
     else if (A.stripsPerWave >= 2)
-        hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB, 2>), dim3(blocks), block, 0, stream, A);
+        hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB, 2>), grid, block, 0, stream, A, S);
     else
-        hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB, 1>), dim3(blocks), block, 0, stream, A);
+        hipLaunchKernelGGL((rgbToYuvTileFxKernel<NCH, SUB, 1>), grid, block, 0, stream, A, S);
 }
 
 template <int NCH>
-hipError_t launchFxSub(int sub, const R2YArgs & A, uint32_t blocks, hipStream_t stream)
+hipError_t launchFxSub(int sub, const R2YArgs & A, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & S, uint32_t frames)
 {
     switch (sub) {
-        case SUB_444: launchFxOne<NCH, SUB_444>(A, blocks, stream); break;
-        case SUB_422: launchFxOne<NCH, SUB_422>(A, blocks, stream); break;
-        case SUB_420: launchFxOne<NCH, SUB_420>(A, blocks, stream); break;
-        default: launchFxOne<NCH, SUB_400>(A, blocks, stream); break;
+        case SUB_444: launchFxOne<NCH, SUB_444>(A, blocks, stream, S, frames); break;
+        case SUB_422: launchFxOne<NCH, SUB_422>(A, blocks, stream, S, frames); break;
+        case SUB_420: launchFxOne<NCH, SUB_420>(A, blocks, stream, S, frames); break;
+        default: launchFxOne<NCH, SUB_400>(A, blocks, stream, S, frames); break;
     }
     return hipGetLastError();
 }
@@ -587,8 +597,9 @@ hipError_t launchFxSub(int sub, const R2YArgs & A, uint32_t blocks, hipStream_t 
 // four waves of a workgroup are stacked and independent.  (Round 1 walked a wave down its strips with the next strip's loads in
 // flight; like in the decode direction, many short-lived waves keep the memory pipes fuller: 4K RGBA8 -> 4:2:0 10.9 -> 9.9 us.)
 template <typename RT, int NCH, typename YT, int SUB, int NS, bool PLAIN>
-__global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A)
+__global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A0, R2YSeqFrames S)
 {
+    const R2YArgs A = r2ySeqJob(A0, S);
     const uint32_t bands = (A.w4 + 255) / 256;
     const uint32_t block = r2yBlockOf(blockIdx.x, gridDim.x, A.xcdBands != 0);
     const uint32_t band = block % bands, chunk = block / bands;
@@ -629,43 +640,44 @@ __global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A)
 }
 
 template <typename RT, int NCH, typename YT, int SUB, bool PLAIN>
-hipError_t launchOnePlainOrNot(const R2YArgs & A, uint32_t blocks, hipStream_t stream)
+hipError_t launchOnePlainOrNot(const R2YArgs & A, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & S, uint32_t frames)
 {
+    const dim3 grid(blocks, 1, frames), block(kLanes, kWaves);
     if (A.stripsPerWave >= 4)
-        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 4, PLAIN>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
+        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 4, PLAIN>), grid, block, 0, stream, A, S);
     else if (A.stripsPerWave >= 2)
-        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 2, PLAIN>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
+        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 2, PLAIN>), grid, block, 0, stream, A, S);
     else if constexpr (PLAIN)
-        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 1, PLAIN>), dim3(blocks), dim3(kLanes, kWaves), 0, stream, A);
+        hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 1, PLAIN>), grid, block, 0, stream, A, S);
     else
         return hipErrorInvalidValue; // (the rare modes run two strips per wave or more: kernels_r2y_tile.hip)
     return hipGetLastError();
 }
 
 template <typename RT, int NCH, typename YT, int SUB>
-hipError_t launchOne(const R2YArgs & A, uint32_t blocks, hipStream_t stream)
+hipError_t launchOne(const R2YArgs & A, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & S, uint32_t frames)
 {
     const bool plain = A.mulMode == MUL_NONE && A.matrixMode != MODE_YCGCO && A.matrixMode != MODE_YCGCO_RE && A.matrixMode != MODE_YCGCO_RO;
-    return plain ? launchOnePlainOrNot<RT, NCH, YT, SUB, true>(A, blocks, stream) : launchOnePlainOrNot<RT, NCH, YT, SUB, false>(A, blocks, stream);
+    return plain ? launchOnePlainOrNot<RT, NCH, YT, SUB, true>(A, blocks, stream, S, frames) : launchOnePlainOrNot<RT, NCH, YT, SUB, false>(A, blocks, stream, S, frames);
 }
 
 template <typename RT, int NCH, typename YT>
-hipError_t launchSub(int sub, const R2YArgs & A, uint32_t blocks, hipStream_t stream)
+hipError_t launchSub(int sub, const R2YArgs & A, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & S, uint32_t frames)
 {
     switch (sub) {
-        case SUB_444: return launchOne<RT, NCH, YT, SUB_444>(A, blocks, stream);
-        case SUB_422: return launchOne<RT, NCH, YT, SUB_422>(A, blocks, stream);
-        case SUB_420: return launchOne<RT, NCH, YT, SUB_420>(A, blocks, stream);
-        default: return launchOne<RT, NCH, YT, SUB_400>(A, blocks, stream);
+        case SUB_444: return launchOne<RT, NCH, YT, SUB_444>(A, blocks, stream, S, frames);
+        case SUB_422: return launchOne<RT, NCH, YT, SUB_422>(A, blocks, stream, S, frames);
+        case SUB_420: return launchOne<RT, NCH, YT, SUB_420>(A, blocks, stream, S, frames);
+        default: return launchOne<RT, NCH, YT, SUB_400>(A, blocks, stream, S, frames);
     }
 }
 
 template <typename RT>
-hipError_t launchFamily(const R2YKey & k, const R2YArgs & A, uint32_t blocks, hipStream_t stream)
+hipError_t launchFamily(const R2YKey & k, const R2YArgs & A, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & S, uint32_t frames)
 {
     if (k.nch == 4)
-        return k.wideYuv ? launchSub<RT, 4, uint16_t>(k.sub, A, blocks, stream) : launchSub<RT, 4, uint8_t>(k.sub, A, blocks, stream);
-    return k.wideYuv ? launchSub<RT, 3, uint16_t>(k.sub, A, blocks, stream) : launchSub<RT, 3, uint8_t>(k.sub, A, blocks, stream);
+        return k.wideYuv ? launchSub<RT, 4, uint16_t>(k.sub, A, blocks, stream, S, frames) : launchSub<RT, 4, uint8_t>(k.sub, A, blocks, stream, S, frames);
+    return k.wideYuv ? launchSub<RT, 3, uint16_t>(k.sub, A, blocks, stream, S, frames) : launchSub<RT, 3, uint8_t>(k.sub, A, blocks, stream, S, frames);
 }
 
 // ---- gray sources (GRAY / GRAYA / AGRAY -> the luma plane, src/reformat.c:471-519; the chroma planes, if any, are set to the half value by

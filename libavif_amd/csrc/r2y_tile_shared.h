@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <string.h>
+
 #include "plan.h"
 
 namespace avifhip {
@@ -56,6 +58,37 @@ struct R2YArgs
     } fx;
 };
 
+// Sequences (round 6, like tile_shared.h SeqFrames in the other direction): up to kR2YSeqMaxFrames frames that differ in their buffers only,
+// encoded by ONE launch of the single-image kernels -- grid z = frame, the frame's five addresses taken from the kernel arguments.
+// A single image is a sequence of one.
+constexpr uint32_t kR2YSeqMaxFrames = 8;
+struct R2YSeqFrames
+{
+    struct Frame
+    {
+        const uint8_t * rgb;
+        uint8_t *y, *u, *v, *a;
+    } f[kR2YSeqMaxFrames];
+};
+inline void r2ySeqSetFrame(R2YSeqFrames & S, uint32_t k, const R2YArgs & A)
+{
+    S.f[k].rgb = A.rgb, S.f[k].y = A.y, S.f[k].u = A.u, S.f[k].v = A.v, S.f[k].a = A.a;
+}
+inline R2YSeqFrames r2ySeqOfOne(const R2YArgs & A)
+{
+    R2YSeqFrames S;
+    for (uint32_t k = 0; k < kR2YSeqMaxFrames; ++k)
+        r2ySeqSetFrame(S, k, A);
+    return S;
+}
+// everything but the five addresses agrees (both filled by the same code from a zeroed struct: padding included)
+inline bool r2ySeqCompatible(const R2YArgs & a, const R2YArgs & b)
+{
+    R2YArgs x = a, y = b;
+    x.rgb = y.rgb = nullptr, x.y = y.y = nullptr, x.u = y.u = nullptr, x.v = y.v = nullptr, x.a = y.a = nullptr;
+    return (a.u == nullptr) == (b.u == nullptr) && (a.v == nullptr) == (b.v == nullptr) && (a.a == nullptr) == (b.a == nullptr) && memcmp(&x, &y, sizeof(R2YArgs)) == 0;
+}
+
 struct R2YKey
 {
     bool fixedPoint; // libyuv arithmetic: 8-bit RGB -> 8-bit planes
@@ -82,9 +115,10 @@ struct GrayArgs
 hipError_t launchR2YGray8(int grayChannels, bool wideYuv, const GrayArgs & args, hipStream_t stream);
 hipError_t launchR2YGray16(int grayChannels, bool wideYuv, const GrayArgs & args, hipStream_t stream);
 
-hipError_t launchR2YTileRgb8(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);
-hipError_t launchR2YTileRgb16(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);
-hipError_t launchR2YTileFx(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream);
+// (`frames`: the launch's frames -- r2ySeqOfOne(args) for a single image -- and how many of them: grid z)
+hipError_t launchR2YTileRgb8(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & frames, uint32_t frameCount);
+hipError_t launchR2YTileRgb16(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & frames, uint32_t frameCount);
+hipError_t launchR2YTileFx(const R2YKey & key, const R2YArgs & args, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & frames, uint32_t frameCount);
 
 } // namespace r2y
 } // namespace avifhip

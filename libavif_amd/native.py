@@ -20,7 +20,8 @@ LIB_PATH = CSRC / "libavifhip.so"
 EXPORTED_SYMBOLS = [
     "avifhipImageYUVToRGB", "avifhipImageRGBToYUV", "avifhipRGBImagePremultiplyAlpha", "avifhipRGBImageUnpremultiplyAlpha",
     "avifhipImageYUVToRGBAsync", "avifhipImageRGBToYUVAsync", "avifhipRGBImagePremultiplyAlphaAsync",
-    "avifhipRGBImageUnpremultiplyAlphaAsync", "avifhipImageYUVToRGBRectAsync", "avifhipImageYUVToRGBBatchAsync",
+    "avifhipRGBImageUnpremultiplyAlphaAsync", "avifhipImageYUVToRGBRectAsync", "avifhipImageYUVToRGBBatchAsync", "avifhipImageRGBToYUVBatchAsync",
+    "avifhipTimeRGBToYUVBatchCycle", "avifhipTimeStreamCeilingRGBToYUVBatchCycle",
     "avifhipLimitedToFullY", "avifhipLimitedToFullUV", "avifhipFullToLimitedY", "avifhipFullToLimitedUV",
     "avifhipSetArithmetic", "avifhipGetArithmetic", "avifhipSetTiledKernels", "avifhipSetDevice", "avifhipDeviceCount",
     "avifhipSynchronize", "avifhipLastError", "avifhipLastKernel", "avifhipVersion", "avifhipDeviceAlloc", "avifhipDeviceFree",
@@ -90,6 +91,9 @@ def load() -> C.CDLL:
         "avifhipTimeYUVToRGB": (C.c_double, [P_IMG, P_RGB, i32, i32, vp]),
         "avifhipTimeRGBToYUV": (C.c_double, [P_IMG, P_RGB, i32, i32, vp]),
         "avifhipTimeRGBToYUVCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), i32, i32, vp]),
+        "avifhipImageRGBToYUVBatchAsync": (i32, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), vp]),
+        "avifhipTimeRGBToYUVBatchCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), u32, i32, i32, vp]),
+        "avifhipTimeStreamCeilingRGBToYUVBatchCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), u32, i32, i32, vp]),
         "avifhipTimeYUVToRGBBatch": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), P_RECT, i32, i32, vp]),
         "avifhipTimeYUVToRGBBatchCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), u32, i32, i32, vp]),
         "avifhipTimeStreamCeilingBatchCycle": (C.c_double, [u32, C.POINTER(P_IMG), C.POINTER(P_RGB), u32, i32, i32, vp]),

@@ -112,3 +112,71 @@ def test_batches_that_are_not_sequences_keep_the_table_path(hip):
         _check(c, outs, H.oracle_libyuv_backend(), ("attenuate", kernel))
     finally:
         hip.avifhipSetArithmetic(1)
+
+
+# ---- the encode direction: avifhipImageRGBToYUVBatchAsync (src/reformat.c:161-519 per frame) ----
+
+ENCODE_SEQUENCES = [
+    # cfg4's layout: RGBA8 -> 8-bit 4:2:0 BT.709 limited + alpha plane, both arithmetics (BT.601 is the one libyuv serves)
+    H.R2YCase(2051, 1031, yuv_format=3, yuv_range=0, matrix=1),
+    H.R2YCase(2052, 1030, yuv_format=3, yuv_range=0, matrix=6),
+    H.R2YCase(2048, 1026, rgb_format=abi.AVIF_RGB_FORMAT_BGR, yuv_format=2, yuv_range=1, matrix=6),
+    H.R2YCase(2050, 1028, rgb_depth=16, yuv_depth=12, yuv_format=1, yuv_range=1, matrix=9, rgb_premultiplied=False),
+    H.R2YCase(2304, 914, rgb_depth=8, yuv_depth=10, yuv_format=1, yuv_range=1, matrix=16),   # YCgCo-Re: one of the rare modes
+    H.R2YCase(2056, 1024, yuv_format=1, yuv_range=1, matrix=0),                               # identity (lossless)
+]
+
+
+def _run_encode_batch(hip, cases, stream=None):
+    hosts = [(H.make_r2y_output(c), H.make_r2y_inputs(c)) for c in cases]
+    devs = [(device.DeviceYUV(i, upload=True), device.DeviceRGB(o, upload=True)) for i, o in hosts]
+    n = len(cases)
+    imgs = (C.POINTER(abi.avifImage) * n)(*[C.pointer(d[0].struct) for d in devs])
+    rgbs = (C.POINTER(abi.avifRGBImage) * n)(*[C.pointer(d[1].struct) for d in devs])
+    launches0 = hip.avifhipLaunchCount()
+    native.check(hip.avifhipImageRGBToYUVBatchAsync(n, imgs, rgbs, stream), "avifhipImageRGBToYUVBatchAsync")
+    native.check(hip.avifhipSynchronize(stream), "sync")
+    kernel = native.last_kernel()
+    for d in devs:
+        d[0].download_into_host()
+    return [i for i, _ in hosts], hip.avifhipLaunchCount() - launches0, kernel
+
+
+@pytest.mark.parametrize("frames", [1, 2, 3, 9])
+@pytest.mark.parametrize("arith", [1, 0], ids=["fp32", "integer"])
+def test_encode_sequences_equal_frame_by_frame_conversions(hip, arith, frames):
+    oracle = H.oracle_backend() if arith == 1 else H.oracle_libyuv_backend()
+    hip.avifhipSetArithmetic(arith)
+    try:
+        for base in ENCODE_SEQUENCES if frames <= 3 else ENCODE_SEQUENCES[:2]:
+            cases = [dataclasses.replace(base, avoid_libyuv=(arith == 1), seed=0x4321 + 613 * k) for k in range(frames)]
+            outs, launches, kernel = _run_encode_batch(hip, cases)
+            for k, (c, got) in enumerate(zip(cases, outs)):
+                res, want = H.run_r2y(oracle, c)
+                assert res == 0
+                assert H.planes_equal(want, got, padding=False) is None, (arith, frames, k, c.ident(), kernel, H.planes_equal(want, got, padding=False))
+            # one launch per 8 frames wherever the tiled kernels serve the layout (all but what the universal kernel keeps)
+            assert launches == ((frames + 7) // 8 if "tile" in kernel else frames), (kernel, launches)
+            if base is ENCODE_SEQUENCES[0] or base is ENCODE_SEQUENCES[1]:
+                assert "tile" in kernel, kernel
+    finally:
+        hip.avifhipSetArithmetic(1)
+
+
+def test_encode_batches_that_are_not_sequences_run_frame_by_frame(hip):
+    hip.avifhipSetArithmetic(1)
+    mixed = [dataclasses.replace(ENCODE_SEQUENCES[0], seed=3), dataclasses.replace(ENCODE_SEQUENCES[0], w=1030, h=514, seed=4),
+             dataclasses.replace(ENCODE_SEQUENCES[2], seed=5)]
+    outs, launches, kernel = _run_encode_batch(hip, mixed)
+    assert launches == 3
+    for c, got in zip(mixed, outs):
+        res, want = H.run_r2y(H.oracle_backend(), c)
+        assert res == 0 and H.planes_equal(want, got, padding=False) is None, (c.ident(), kernel)
+    # a missing destination plane is the caller's error, like in the single-frame entry point
+    img, rgb = H.make_r2y_output(ENCODE_SEQUENCES[0]), H.make_r2y_inputs(ENCODE_SEQUENCES[0])
+    dimg, drgb = device.DeviceYUV(img, upload=False), device.DeviceRGB(rgb, upload=True)
+    dimg.struct.yuvPlanes[1] = None
+    imgs = (C.POINTER(abi.avifImage) * 1)(C.pointer(dimg.struct))
+    rgbs = (C.POINTER(abi.avifRGBImage) * 1)(C.pointer(drgb.struct))
+    assert hip.avifhipImageRGBToYUVBatchAsync(1, imgs, rgbs, None) == abi.AVIF_RESULT_INVALID_ARGUMENT
+    assert hip.avifhipImageRGBToYUVBatchAsync(0, None, None, None) == abi.AVIF_RESULT_OK
