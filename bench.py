@@ -597,6 +597,18 @@ def main():
         except Exception:
             pass
 
+    seq_file = ROOT / "profiles" / "pmc_traffic_sequence.json"
+    if seq_file.exists() and not args.dry_run:
+        try:
+            sj = json.loads(seq_file.read_text()).get("cfg2seq" if integer else "cfg2seq_fp32", {})
+            cb = out["roofline"]["cold_batched"]
+            if sj.get("kernel_family", "") == cb["kernel"] and sj.get("frames_per_launch") == SEQUENCE_FRAMES and sj.get("traffic_bytes_per_launch"):
+                cb["traffic"] = sj["traffic_bytes_per_launch"]
+                cb["traffic_source"] = ("profiles/pmc_traffic_sequence.json (tests/tools/seq_evidence.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                        "`stream_sweep.py run cfg2seq`, the same launches and nothing else; not measured in this run)")
+        except Exception:
+            pass
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(abi, synth, args.cpu_seconds)

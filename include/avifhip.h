@@ -230,6 +230,31 @@ AVIFHIP_API avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRg
                                                      avifTransferCharacteristics altTransferCharacteristics,
                                                      avifGainMap * gainMap,
                                                      avifDiagnostics * diag);
+/* ... with everything in device memory: the two renditions' pixels, and the planes of gainMap->image, which the caller allocates at the
+ * requested size (width, height, depth, yuvFormat as in the host call; yuvRowBytes as allocated).  The metadata fractions are final when
+ * the call returns -- they are functions of every pixel (channel minima, extreme ratios, the outlier histogram: src/gainmap.c:618-749), so the
+ * call waits for its first passes on `hipStream` (NULL = the calling thread's library stream) -- the planes once that stream has drained.
+ * Same bytes and metadata as avifhipRGBImageComputeGainMap on the downloaded copies.  avifhipTimeRGBImageComputeGainMap: `iters` such calls
+ * back to back after `warmup` untimed ones, wall clock around them with the stream drained on both sides: milliseconds per call. */
+AVIFHIP_API avifResult avifhipRGBImageComputeGainMapAsync(const avifRGBImage * baseRgbImage,
+                                                          avifColorPrimaries baseColorPrimaries,
+                                                          avifTransferCharacteristics baseTransferCharacteristics,
+                                                          const avifRGBImage * altRgbImage,
+                                                          avifColorPrimaries altColorPrimaries,
+                                                          avifTransferCharacteristics altTransferCharacteristics,
+                                                          avifGainMap * gainMap,
+                                                          avifDiagnostics * diag,
+                                                          void * hipStream);
+AVIFHIP_API double avifhipTimeRGBImageComputeGainMap(const avifRGBImage * baseRgbImage,
+                                                     avifColorPrimaries baseColorPrimaries,
+                                                     avifTransferCharacteristics baseTransferCharacteristics,
+                                                     const avifRGBImage * altRgbImage,
+                                                     avifColorPrimaries altColorPrimaries,
+                                                     avifTransferCharacteristics altTransferCharacteristics,
+                                                     avifGainMap * gainMap,
+                                                     int warmup,
+                                                     int iters,
+                                                     void * hipStream);
 /* avifImageComputeGainMap (reference src/gainmap.c:843-912): both renditions as YUV images */
 AVIFHIP_API avifResult avifhipImageComputeGainMap(const avifImage * baseImage, const avifImage * altImage, avifGainMap * gainMap, avifDiagnostics * diag);
 AVIFHIP_API avifResult avifhipImageApplyGainMap(const avifImage * baseImage,

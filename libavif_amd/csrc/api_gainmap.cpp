@@ -827,11 +827,12 @@ void freeHostPlanes(avifImage * image) // avifImageFreePlanes(AVIF_PLANES_ALL), 
 
 } // namespace
 
-// Host images in, gain-map metadata and (malloc'ed) gain-map planes out, like the reference.
-extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgbImage, avifColorPrimaries baseColorPrimaries,
-                                                    avifTransferCharacteristics baseTransferCharacteristics, const avifRGBImage * altRgbImage,
-                                                    avifColorPrimaries altColorPrimaries, avifTransferCharacteristics altTransferCharacteristics,
-                                                    avifGainMap * gainMap, avifDiagnostics * diag)
+// Host images in, gain-map metadata and (malloc'ed) gain-map planes out, like the reference; or (deviceResident) everything in device memory:
+// the two renditions' pixels, and the planes of gainMap->image, which the caller allocated at the requested size.
+static avifResult computeGainMapImpl(const avifRGBImage * baseRgbImage, avifColorPrimaries baseColorPrimaries,
+                                     avifTransferCharacteristics baseTransferCharacteristics, const avifRGBImage * altRgbImage,
+                                     avifColorPrimaries altColorPrimaries, avifTransferCharacteristics altTransferCharacteristics,
+                                     avifGainMap * gainMap, avifDiagnostics * diag, bool deviceResident, void * hipStream)
 {
     diagClear(diag);
     if (baseRgbImage == NULL || altRgbImage == NULL || gainMap == NULL || gainMap->image == NULL)
@@ -865,12 +866,22 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
     avifResult r = ensureContext();
     if (r != AVIF_RESULT_OK)
         return r;
-    hipStream_t stream = tls.stream;
+    hipStream_t stream = deviceResident ? pickStream(hipStream) : tls.stream;
     ScratchScope scratch(stream); // (shares work buffers with the application's asynchronous entry point: see applyGainMapToHostImage)
     if (scratch.result != AVIF_RESULT_OK)
         return scratch.result;
     QuiesceOnExit quiesceOnExit;
     PhaseTrace trace("compute gain map");
+    if (deviceResident) {
+        const PlaneGeometry want = planeGeometry(gmImage);
+        for (int p = 0; p < 3; ++p) {
+            const bool needed = p == 0 || gmImage->yuvFormat != AVIF_PIXEL_FORMAT_YUV400;
+            if (needed && (!gmImage->yuvPlanes[p] || gmImage->yuvRowBytes[p] < want.widthBytes[p])) {
+                setError("avifhipRGBImageComputeGainMapAsync: gainMap->image's planes must be allocated by the caller, in device memory, at the requested size");
+                return AVIF_RESULT_INVALID_ARGUMENT;
+            }
+        }
+    }
     tls.gainMapCache.valid = false; // (the apply path's tables are not touched, but keep the two paths independent of call order)
 
     // avifGainMapSetEncodingDefaults, :18-30
@@ -900,13 +911,19 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
     // ---- device copies of the two images, lookup tables ----
     A.width = width, A.height = height;
     const uint32_t baseWidthBytes = width * rgbPixelBytes(baseRgbImage), altWidthBytes = width * rgbPixelBytes(altRgbImage);
-    A.basePitch = alignUp(baseWidthBytes, 256), A.altPitch = alignUp(altWidthBytes, 256);
-    if ((r = reserve(tls.gainMap[5], (size_t)A.basePitch * height)) != AVIF_RESULT_OK || (r = reserve(tls.gainMap[9], (size_t)A.altPitch * height)) != AVIF_RESULT_OK)
-        return r;
-    A.base = (const uint8_t *)tls.gainMap[5].ptr, A.alt = (const uint8_t *)tls.gainMap[9].ptr;
-    HIP_TRY(hipMemcpy2DAsync(tls.gainMap[5].ptr, A.basePitch, baseRgbImage->pixels, baseRgbImage->rowBytes, baseWidthBytes, height, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpy2DAsync(tls.gainMap[9].ptr, A.altPitch, altRgbImage->pixels, altRgbImage->rowBytes, altWidthBytes, height, hipMemcpyHostToDevice, stream));
-    trace.mark("uploads");
+    if (deviceResident) {
+        if (baseRgbImage->rowBytes < baseWidthBytes || altRgbImage->rowBytes < altWidthBytes)
+            return AVIF_RESULT_INVALID_ARGUMENT;
+        A.base = baseRgbImage->pixels, A.basePitch = baseRgbImage->rowBytes, A.alt = altRgbImage->pixels, A.altPitch = altRgbImage->rowBytes;
+    } else {
+        A.basePitch = alignUp(baseWidthBytes, 256), A.altPitch = alignUp(altWidthBytes, 256);
+        if ((r = reserve(tls.gainMap[5], (size_t)A.basePitch * height)) != AVIF_RESULT_OK || (r = reserve(tls.gainMap[9], (size_t)A.altPitch * height)) != AVIF_RESULT_OK)
+            return r;
+        A.base = (const uint8_t *)tls.gainMap[5].ptr, A.alt = (const uint8_t *)tls.gainMap[9].ptr;
+        HIP_TRY(hipMemcpy2DAsync(tls.gainMap[5].ptr, A.basePitch, baseRgbImage->pixels, baseRgbImage->rowBytes, baseWidthBytes, height, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpy2DAsync(tls.gainMap[9].ptr, A.altPitch, altRgbImage->pixels, altRgbImage->rowBytes, altWidthBytes, height, hipMemcpyHostToDevice, stream));
+        trace.mark("uploads");
+    }
     std::vector<float> tables = gainMapLinearLut(baseTransferCharacteristics, baseRgbImage->depth, baseRgbImage->isFloat != 0);
     const size_t altLutOffset = tables.size();
     {
@@ -921,12 +938,12 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
         return r;
     float * deviceTables = (float *)tls.gainMap[6].ptr;
     A.baseLut = deviceTables, A.altLut = deviceTables + altLutOffset;
+    A.baseLutEntries = (uint32_t)altLutOffset, A.altLutEntries = (uint32_t)(tables.size() - altLutOffset);
     if ((r = reserve(tls.gainMap[7], (size_t)channels * numPixels * sizeof(float))) != AVIF_RESULT_OK ||
         (r = reserve(tls.gainMap[3], (size_t)kGainMapMaxGroups * 8 * sizeof(float))) != AVIF_RESULT_OK)
         return r;
     A.ratios = (float *)tls.gainMap[7].ptr, A.partials = (float *)tls.gainMap[3].ptr;
-    const uint32_t tiles = ((width + 63) / 64) * ((height + 3) / 4);
-    const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
+    const uint32_t groups = gainMapComputeGroups(width, height);
     std::vector<float> partials((size_t)groups * 8);
 
     // ---- pass 0: offsets that keep the converted side's channels positive, :618-660 ----
@@ -996,6 +1013,14 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
             const std::vector<float> steps = gainMapBucketSteps(ranges[c], &entries);
             stepTables[c].steps = deviceTables + stepsOffset + hostSteps.size();
             stepTables[c].entries = entries, stepTables[c].flipped = sign < 0 ? 1 : 0, stepTables[c].flip = (uint32_t)ranges[c].numBuckets - 1;
+            // the buckets are equally wide in log2 of the ratio: a line through the first and the last finite step gives the kernel its first
+            // guess of a sample's bucket (it corrects the guess against the steps themselves: kernels_gainmap.hip stepIndexGuessed)
+            const uint32_t lastStep = (uint32_t)ranges[c].numBuckets - 1;
+            if (lastStep >= 2 && steps[1] > 0.0f && steps[lastStep] > steps[1] && std::isfinite(steps[lastStep])) {
+                const double l1 = std::log2((double)steps[1]), l2 = std::log2((double)steps[lastStep]);
+                const double a = (double)(lastStep - 1) / (l2 - l1);
+                stepTables[c].guessA = (float)a, stepTables[c].guessB = (float)(1.0 - a * l1 + 0.5);
+            }
             hostSteps.insert(hostSteps.end(), steps.begin(), steps.end());
             histogramOffset[c] = histogramTotal, histogramTotal += (size_t)ranges[c].numBuckets;
             anyHistogram = true;
@@ -1041,6 +1066,15 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
         const std::vector<float> steps = gainMapCodeSteps(ranges[c], minLog2[c], maxLog2[c], fractionToFloat(gainMap->gainMapGamma[c]), depth);
         stepTables[c].steps = deviceTables + stepsOffset + hostSteps.size();
         stepTables[c].entries = (uint32_t)steps.size(), stepTables[c].flipped = sign < 0 ? 1 : 0, stepTables[c].flip = (1u << depth) - 1;
+        // gamma 1 (the encoding default): the codes are equally spaced in log2 of the ratio between the range's ends -- the kernel starts from
+        // the line through the first and the last step and corrects against the steps (any other gamma: bisection)
+        const uint32_t lastCode = (1u << depth) - 1;
+        if (fractionToFloat(gainMap->gainMapGamma[c]) == 1.0f && lastCode >= 2 && steps.size() > lastCode && steps[1] > 0.0f && steps[lastCode] > steps[1] &&
+            std::isfinite(steps[lastCode])) {
+            const double l1 = std::log2((double)steps[1]), l2 = std::log2((double)steps[lastCode]);
+            const double a = (double)(lastCode - 1) / (l2 - l1);
+            stepTables[c].guessA = (float)a, stepTables[c].guessB = (float)(1.0 - a * l1 + 0.5);
+        }
         hostSteps.insert(hostSteps.end(), steps.begin(), steps.end());
     }
     if (!hostSteps.empty() && (r = uploadTableAsync(deviceTables + stepsOffset, hostSteps.data(), hostSteps.size() * sizeof(float), stream)) != AVIF_RESULT_OK)
@@ -1060,6 +1094,25 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
             return hipFailed(e, "gain map quantisation kernel launch");
     }
     const uint32_t requestedWidth = gmImage->width, requestedHeight = gmImage->height;
+    if (deviceResident) {
+        // the codes become planes where the caller put them: RGBA -> YUV at the images' size (into the caller's planes when that is the
+        // requested size, else into scratch and through the plane scaler); nothing is downloaded, the planes are final when `stream` has drained
+        avifImage deviceGain;
+        memcpy(&deviceGain, gmImage, sizeof(avifImage));
+        const bool scaled = requestedWidth != width || requestedHeight != height;
+        if (scaled && (r = deviceGainMapPlanes(&deviceGain, width, height, tls.gainMap[10])) != AVIF_RESULT_OK)
+            return r;
+        if (scaled && !gmImage->alphaPlane)
+            deviceGain.alphaPlane = nullptr, deviceGain.alphaRowBytes = 0; // (the scratch image mirrors the caller's planes)
+        avifRGBImage codes = rgbGain; // (the gain map has no alpha plane: the opaque alpha of its RGBA codes goes nowhere, src/gainmap.c:792-800)
+        codes.ignoreAlpha = deviceGain.alphaPlane ? AVIF_FALSE : AVIF_TRUE;
+        if ((r = avifhipImageRGBToYUVAsync(&deviceGain, &codes, stream)) != AVIF_RESULT_OK)
+            return r;
+        if (scaled && (r = avifhipImageScaleAsync(&deviceGain, gmImage, stream)) != AVIF_RESULT_OK)
+            return r;
+        tls.lastKernel = "gainmap_compute";
+        return AVIF_RESULT_OK;
+    }
     // The planes a previous call left in gainMap->image are released only after the stream has drained: free() of memory the runtime pinned
     // for that call's downloads unmaps it from the GPU as well, and that stalls whatever kernel is running (the quantisation kernel above:
     // 168 us in a process's first call, 15-25 ms in every later one, when the release sat here).
@@ -1139,6 +1192,50 @@ extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgb
     return AVIF_RESULT_OK;
 }
 
+
+extern "C" avifResult avifhipRGBImageComputeGainMap(const avifRGBImage * baseRgbImage, avifColorPrimaries baseColorPrimaries,
+                                                    avifTransferCharacteristics baseTransferCharacteristics, const avifRGBImage * altRgbImage,
+                                                    avifColorPrimaries altColorPrimaries, avifTransferCharacteristics altTransferCharacteristics,
+                                                    avifGainMap * gainMap, avifDiagnostics * diag)
+{
+    return computeGainMapImpl(baseRgbImage, baseColorPrimaries, baseTransferCharacteristics, altRgbImage, altColorPrimaries, altTransferCharacteristics, gainMap, diag,
+                              false, nullptr);
+}
+
+// ... with both renditions and gainMap->image's planes in device memory (include/avifhip.h)
+extern "C" avifResult avifhipRGBImageComputeGainMapAsync(const avifRGBImage * baseRgbImage, avifColorPrimaries baseColorPrimaries,
+                                                         avifTransferCharacteristics baseTransferCharacteristics, const avifRGBImage * altRgbImage,
+                                                         avifColorPrimaries altColorPrimaries, avifTransferCharacteristics altTransferCharacteristics,
+                                                         avifGainMap * gainMap, avifDiagnostics * diag, void * hipStream)
+{
+    return computeGainMapImpl(baseRgbImage, baseColorPrimaries, baseTransferCharacteristics, altRgbImage, altColorPrimaries, altTransferCharacteristics, gainMap, diag,
+                              true, hipStream);
+}
+
+// the kernels of avifhipRGBImageComputeGainMapAsync between two events on the stream (a tool for bench.py / rocprof rows): milliseconds per call
+extern "C" double avifhipTimeRGBImageComputeGainMap(const avifRGBImage * baseRgbImage, avifColorPrimaries baseColorPrimaries,
+                                                    avifTransferCharacteristics baseTransferCharacteristics, const avifRGBImage * altRgbImage,
+                                                    avifColorPrimaries altColorPrimaries, avifTransferCharacteristics altTransferCharacteristics,
+                                                    avifGainMap * gainMap, int warmup, int iters, void * hipStream)
+{
+    if (iters <= 0 || ensureContext() != AVIF_RESULT_OK)
+        return -1.0;
+    hipStream_t stream = pickStream(hipStream);
+    for (int k = 0; k < warmup; ++k)
+        if (avifhipRGBImageComputeGainMapAsync(baseRgbImage, baseColorPrimaries, baseTransferCharacteristics, altRgbImage, altColorPrimaries, altTransferCharacteristics,
+                                               gainMap, nullptr, stream) != AVIF_RESULT_OK)
+            return -1.0;
+    if (hipStreamSynchronize(stream) != hipSuccess)
+        return -1.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < iters; ++k)
+        if (avifhipRGBImageComputeGainMapAsync(baseRgbImage, baseColorPrimaries, baseTransferCharacteristics, altRgbImage, altColorPrimaries, altTransferCharacteristics,
+                                               gainMap, nullptr, stream) != AVIF_RESULT_OK)
+            return -1.0;
+    if (hipStreamSynchronize(stream) != hipSuccess)
+        return -1.0;
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+}
 
 // avifImageComputeGainMap, src/gainmap.c:843-912: both renditions arrive as YUV
 extern "C" avifResult avifhipImageComputeGainMap(const avifImage * baseImage, const avifImage * altImage, avifGainMap * gainMap, avifDiagnostics * diag)

@@ -266,6 +266,7 @@ struct GainMapComputeArgs
     uint32_t width, height;
     const float * baseLut; // linear light per sample code (gainmap_plan.h)
     const float * altLut;
+    uint32_t baseLutEntries, altLutEntries; // tables of at most 4096 entries each are staged in LDS by the kernels (0: unknown, read from memory)
     int32_t convertAlt, convertBase; // at most one: which side goes through M into the other's primaries (:676-684)
     double M[9];
     int32_t singleChannel;
@@ -285,7 +286,11 @@ struct GainMapStepTable
     uint32_t entries;
     uint32_t flip;       // index = flip - m when `flipped` (negative sign), else m
     int32_t flipped;
+    // bucket tables (pass 2): index ~ guessA * log2(x) + guessB, corrected against the steps by the kernel (any values are safe; 0 / 0: bisection)
+    float guessA, guessB;
 };
+// workgroups of passes 0 and 1 for an image: the host reads that many partials
+uint32_t gainMapComputeGroups(uint32_t width, uint32_t height);
 // pass 2: histogram[c][bucket] += 1 for every sample; channels with tables[c].entries == 0 are skipped
 hipError_t launchGainMapHistogram(const float * ratios, size_t numPixels, int channels, const GainMapStepTable tables[3], uint32_t * const histograms[3],
                                   hipStream_t stream);

@@ -710,29 +710,91 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
 }
 
 // ---- gain-map computation -----------------------------------------------------------------------------------------
+// Round 6: a lane owns FOUR consecutive pixels of a row (one 16-byte load per image for 4-byte pixels, 16-byte stores of the ratio planes),
+// a workgroup a run of 1024 pixels of a row per step; the linear-light tables sit in LDS up to 12-bit samples; the bucket of a ratio is
+// found from a guess (the buckets are equally wide in log2: a line through two of the table's steps, v_log_f32) corrected against the
+// exact steps; histogram counts are aggregated inside the wave before they meet the LDS atomics.  The arithmetic per pixel is what it was
+// (the reference's, in its order): 762 us -> see profiles/r06_gainmap_compute.txt for the 4K pair of profiles/r05_gainmap_kernel_stats.txt.
 
-// linear light of the two images at one pixel, in the primaries the gain-map math runs in
-__device__ __forceinline__ void computeLinearPair(const GainMapComputeArgs & A, uint32_t i, uint32_t j, float b[3], float a[3])
+constexpr uint32_t kComputeRun = 1024;        // pixels of a row a workgroup takes per step (256 lanes x 4)
+constexpr uint32_t kComputeLdsLutMax = 4096;  // entries per linear-light table that go to LDS (12-bit samples)
+
+// which run of which row workgroup-step `unit` is
+struct ComputeRuns
 {
-    uint32_t code[3];
-    float alpha;
-    // 4-channel pixels at naturally aligned addresses: one 4- or 8-byte load per pixel (uniform conditions)
-    const bool baseVector = A.baseL.hasAlpha && (((uintptr_t)A.base | A.basePitch) & (A.baseL.pixelBytes - 1)) == 0;
-    const bool altVector = A.altL.hasAlpha && (((uintptr_t)A.alt | A.altPitch) & (A.altL.pixelBytes - 1)) == 0;
-    readPixel(A.base + (size_t)j * A.basePitch + (size_t)i * A.baseL.pixelBytes, A.baseL, baseVector, code, alpha);
-    b[0] = A.baseLut[code[0]], b[1] = A.baseLut[code[1]], b[2] = A.baseLut[code[2]];
-    readPixel(A.alt + (size_t)j * A.altPitch + (size_t)i * A.altL.pixelBytes, A.altL, altVector, code, alpha);
-    a[0] = A.altLut[code[0]], a[1] = A.altLut[code[1]], a[2] = A.altLut[code[2]];
-    if (A.convertAlt)
-        convertPrimaries(a, A.M);
-    if (A.convertBase)
-        convertPrimaries(b, A.M);
+    uint32_t runsX, units;
+};
+__host__ __device__ __forceinline__ ComputeRuns computeRuns(uint32_t width, uint32_t height)
+{
+    const uint32_t runsX = (width + kComputeRun - 1) / kComputeRun;
+    return { runsX, runsX * height };
+}
+
+// the sample codes of up to four consecutive pixels starting at pixel i of the row at `row`
+__device__ __forceinline__ void readCodes4(const uint8_t * row, uint32_t i, uint32_t n, const GainMapPixelLayout & L, bool vector, bool vector16, uint32_t code[4][3])
+{
+    if (vector16 && n == 4) { // 4-byte pixels, rows aligned to 16 bytes, i a multiple of 4
+        const uint4 w = *reinterpret_cast<const uint4 *>(row + (size_t)i * 4);
+        const uint32_t word[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            code[k][0] = (word[k] >> (8 * L.offR)) & 0xff, code[k][1] = (word[k] >> (8 * L.offG)) & 0xff, code[k][2] = (word[k] >> (8 * L.offB)) & 0xff;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        code[k][0] = code[k][1] = code[k][2] = 0;
+        if ((uint32_t)k < n) {
+            float alpha;
+            readPixel(row + (size_t)(i + k) * L.pixelBytes, L, vector, code[k], alpha);
+        }
+    }
+}
+
+struct ComputeLayout
+{
+    bool baseVector, altVector, baseVector16, altVector16;
+};
+__device__ __forceinline__ ComputeLayout computeLayout(const GainMapComputeArgs & A)
+{
+    ComputeLayout c;
+    c.baseVector = A.baseL.hasAlpha && (((uintptr_t)A.base | A.basePitch) & (A.baseL.pixelBytes - 1)) == 0;
+    c.altVector = A.altL.hasAlpha && (((uintptr_t)A.alt | A.altPitch) & (A.altL.pixelBytes - 1)) == 0;
+    c.baseVector16 = c.baseVector && A.baseL.pixelBytes == 4 && (((uintptr_t)A.base | A.basePitch) & 15) == 0;
+    c.altVector16 = c.altVector && A.altL.pixelBytes == 4 && (((uintptr_t)A.alt | A.altPitch) & 15) == 0;
+    return c;
+}
+
+// the workgroup's copies of the two linear-light tables (LDSLUT: both have at most kComputeLdsLutMax entries)
+template <bool LDSLUT>
+struct ComputeLuts
+{
+    const float * base;
+    const float * alt;
+};
+template <bool LDSLUT>
+__device__ __forceinline__ ComputeLuts<LDSLUT> stageLuts(const GainMapComputeArgs & A, float * lds)
+{
+    ComputeLuts<LDSLUT> T;
+    if constexpr (LDSLUT) {
+        const uint32_t nb = A.baseLutEntries, na = A.altLutEntries;
+        for (uint32_t k = threadIdx.x; k < nb; k += 256)
+            lds[k] = A.baseLut[k];
+        for (uint32_t k = threadIdx.x; k < na; k += 256)
+            lds[nb + k] = A.altLut[k];
+        __syncthreads();
+        T.base = lds, T.alt = lds + nb;
+    } else {
+        T.base = A.baseLut, T.alt = A.altLut;
+    }
+    return T;
 }
 
 template <int N>
 __device__ __forceinline__ void blockReduceStore(float v[N], const bool isMax[N], float * out)
 {
     __shared__ float scratch[4][N];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
@@ -741,12 +803,12 @@ __device__ __forceinline__ void blockReduceStore(float v[N], const bool isMax[N]
             v[k] = isMax[k] ? fmaxf(v[k], o) : fminf(v[k], o);
         }
     }
-    if (threadIdx.x == 0)
+    if (lane == 0)
 #pragma unroll
         for (int k = 0; k < N; ++k)
-            scratch[threadIdx.y][k] = v[k];
+            scratch[wave][k] = v[k];
     __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
+    if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             float r = scratch[0][k];
@@ -757,50 +819,102 @@ __device__ __forceinline__ void blockReduceStore(float v[N], const bool isMax[N]
     }
 }
 
-__global__ __launch_bounds__(256) void gainMapChannelMinKernel(GainMapComputeArgs A, uint32_t tilesX, uint32_t tiles)
+// pass 0: minima of the converted side's channels (the other image is not read)
+template <bool LDSLUT>
+__global__ __launch_bounds__(256) void gainMapChannelMinKernel(GainMapComputeArgs A)
 {
+    extern __shared__ __attribute__((aligned(16))) float ldsLut[];
+    const ComputeLuts<LDSLUT> T = stageLuts<LDSLUT>(A, ldsLut);
+    const ComputeLayout lay = computeLayout(A);
+    const ComputeRuns R = computeRuns(A.width, A.height);
+    const bool alt = A.convertAlt != 0;
+    const uint8_t * image = alt ? A.alt : A.base;
+    const uint32_t pitch = alt ? A.altPitch : A.basePitch;
+    const GainMapPixelLayout & L = alt ? A.altL : A.baseL;
+    const float * lut = alt ? T.alt : T.base;
     float mn[3] = { 0.0f, 0.0f, 0.0f };
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint32_t i = (tile % tilesX) * 64 + threadIdx.x, j = (tile / tilesX) * 4 + threadIdx.y;
-        if (i >= A.width || j >= A.height)
+    for (uint32_t unit = blockIdx.x; unit < R.units; unit += gridDim.x) {
+        const uint32_t j = unit / R.runsX, i = (unit - j * R.runsX) * kComputeRun + 4 * threadIdx.x;
+        if (i >= A.width)
             continue;
-        float b[3], a[3];
-        computeLinearPair(A, i, j, b, a);
-        const float * v = A.convertAlt ? a : b;
+        const uint32_t n = A.width - i < 4 ? A.width - i : 4;
+        uint32_t code[4][3];
+        readCodes4(image + (size_t)j * pitch, i, n, L, alt ? lay.altVector : lay.baseVector, alt ? lay.altVector16 : lay.baseVector16, code);
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            mn[c] = (mn[c] < v[c]) ? mn[c] : v[c]; // AVIF_MIN: a NaN candidate replaces the minimum, like the reference's macro
+        for (int k = 0; k < 4; ++k) {
+            if ((uint32_t)k >= n)
+                break;
+            float v[3] = { lut[code[k][0]], lut[code[k][1]], lut[code[k][2]] };
+            convertPrimaries(v, A.M);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                mn[c] = (mn[c] < v[c]) ? mn[c] : v[c]; // AVIF_MIN: a NaN candidate replaces the minimum, like the reference's macro
+        }
     }
     const bool isMax[3] = { false, false, false };
     blockReduceStore<3>(mn, isMax, A.partials + (size_t)blockIdx.x * 8);
 }
 
-__global__ __launch_bounds__(256) void gainMapRatioKernel(GainMapComputeArgs A, uint32_t tilesX, uint32_t tiles)
+// pass 1: ratios + per-workgroup [baseMax, altMax, minRatio x 3, maxRatio x 3]
+template <bool LDSLUT, int CHANNELS>
+__global__ __launch_bounds__(256) void gainMapRatioKernel(GainMapComputeArgs A)
 {
+    extern __shared__ __attribute__((aligned(16))) float ldsLut[];
+    const ComputeLuts<LDSLUT> T = stageLuts<LDSLUT>(A, ldsLut);
+    const ComputeLayout lay = computeLayout(A);
+    const ComputeRuns R = computeRuns(A.width, A.height);
     const size_t numPixels = (size_t)A.width * A.height;
-    const int channels = A.singleChannel ? 1 : 3;
-    // [baseMax, altMax, minRatio x 3, maxRatio x 3]
+    constexpr int channels = CHANNELS; // 1: A.singleChannel (a compile-time count keeps the per-channel arrays in registers)
+    const bool vectorStores = (A.width & 3u) == 0; // (every plane of the ratio buffer then starts on 16 bytes, and so does every lane's run)
     float acc[8] = { 1.0f, 1.0f, __builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f, 0.0f, 0.0f };
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint32_t i = (tile % tilesX) * 64 + threadIdx.x, j = (tile / tilesX) * 4 + threadIdx.y;
-        if (i >= A.width || j >= A.height)
+    for (uint32_t unit = blockIdx.x; unit < R.units; unit += gridDim.x) {
+        const uint32_t j = unit / R.runsX, i = (unit - j * R.runsX) * kComputeRun + 4 * threadIdx.x;
+        if (i >= A.width)
             continue;
-        float b[3], a[3];
-        computeLinearPair(A, i, j, b, a);
-        for (int c = 0; c < channels; ++c) {
-            float base = b[c], alt = a[c];
-            if (A.singleChannel) { // :699-703, products and sums in the reference's order
-                base = A.yCoeffs[0] * b[0] + A.yCoeffs[1] * b[1] + A.yCoeffs[2] * b[2];
-                alt = A.yCoeffs[0] * a[0] + A.yCoeffs[1] * a[1] + A.yCoeffs[2] * a[2];
+        const uint32_t n = A.width - i < 4 ? A.width - i : 4;
+        uint32_t bc[4][3], ac[4][3];
+        readCodes4(A.base + (size_t)j * A.basePitch, i, n, A.baseL, lay.baseVector, lay.baseVector16, bc);
+        readCodes4(A.alt + (size_t)j * A.altPitch, i, n, A.altL, lay.altVector, lay.altVector16, ac);
+        float ratio[CHANNELS][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float b[3] = { T.base[bc[k][0]], T.base[bc[k][1]], T.base[bc[k][2]] };
+            float a[3] = { T.alt[ac[k][0]], T.alt[ac[k][1]], T.alt[ac[k][2]] };
+            if (A.convertAlt)
+                convertPrimaries(a, A.M);
+            if (A.convertBase)
+                convertPrimaries(b, A.M);
+            const bool live = (uint32_t)k < n;
+#pragma unroll
+            for (int c = 0; c < channels; ++c) {
+                float base = b[c], alt = a[c];
+                if constexpr (CHANNELS == 1) { // :699-703, products and sums in the reference's order
+                    base = A.yCoeffs[0] * b[0] + A.yCoeffs[1] * b[1] + A.yCoeffs[2] * b[2];
+                    alt = A.yCoeffs[0] * a[0] + A.yCoeffs[1] * a[1] + A.yCoeffs[2] * a[2];
+                }
+                const float q = (alt + A.altOffset[c]) / (base + A.baseOffset[c]);
+                const float r = (q > 1e-10f) ? q : 1e-10f; // AVIF_MAX(ratio, kEpsilon): NaN -> epsilon
+                ratio[c][k] = r;
+                if (live) {
+                    if (base > acc[0])
+                        acc[0] = base;
+                    if (alt > acc[1])
+                        acc[1] = alt;
+                    acc[2 + c] = fminf(acc[2 + c], r), acc[5 + c] = fmaxf(acc[5 + c], r);
+                }
             }
-            if (base > acc[0])
-                acc[0] = base;
-            if (alt > acc[1])
-                acc[1] = alt;
-            const float ratio = (alt + A.altOffset[c]) / (base + A.baseOffset[c]);
-            const float r = (ratio > 1e-10f) ? ratio : 1e-10f; // AVIF_MAX(ratio, kEpsilon): NaN -> epsilon
-            A.ratios[(size_t)c * numPixels + (size_t)j * A.width + i] = r;
-            acc[2 + c] = fminf(acc[2 + c], r), acc[5 + c] = fmaxf(acc[5 + c], r);
+        }
+#pragma unroll
+        for (int c = 0; c < channels; ++c) {
+            float * dst = A.ratios + (size_t)c * numPixels + (size_t)j * A.width + i;
+            if (vectorStores) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(ratio[c][0], ratio[c][1], ratio[c][2], ratio[c][3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((uint32_t)k < n)
+                        dst[k] = ratio[c][k];
+            }
         }
     }
     const bool isMax[8] = { true, true, false, false, false, true, true, true };
@@ -815,6 +929,19 @@ __device__ __forceinline__ uint32_t stepIndex(const float * steps, uint32_t entr
         pos += (steps[pos + s] <= x) ? s : 0;
     return pos;
 }
+// ... from a guess: the steps of a bucket table are equally spaced in log2(x), so a line through two of them (GainMapStepTable::guessA / B,
+// gainmap_plan.cpp) lands within a bucket of the answer; the exact steps then decide.  Correct for any guess (a bad one only walks longer);
+// `last`: the last finite step's index.
+__device__ __forceinline__ uint32_t stepIndexGuessed(const float * steps, uint32_t last, float a, float b, float x)
+{
+    const float g = a * __log2f(x) + b;
+    uint32_t m = (g >= 0.0f) ? (g < (float)last ? (uint32_t)g : last) : 0u; // (NaN: 0)
+    while (m < last && steps[m + 1] <= x)
+        ++m;
+    while (m > 0 && !(steps[m] <= x))
+        --m;
+    return m;
+}
 
 struct GainMapStepTables
 {
@@ -823,56 +950,188 @@ struct GainMapStepTables
 
 // Histograms are privatised: each (persistent) workgroup counts one channel at a time in LDS (<= 10000 buckets = 40 KB) and adds
 // its non-zero counts to the global histogram at the end -- one global atomic per sample took 5.9 ms on a 4K image (the
-// distribution is peaked: most samples fall into a few buckets).
+// distribution is peaked: most samples fall into a few buckets).  For the same reason the lanes of a wave first agree on what they hold:
+// up to four rounds of "the first lane's bucket, counted over the wave, added once" before the rest go to the LDS atomics one by one.
 constexpr uint32_t kHistogramLdsBuckets = 10240;
+// Few, large workgroups: what a workgroup adds to the global histogram at the end is one atomic per non-zero counter -- 2048 workgroups of 256
+// lanes spent more time flushing a spread-out histogram (4 300 buckets x 3 channels x 2048) than counting (round 6: 140 us of 4K's 8.3 MP)
+constexpr uint32_t kHistogramThreads = 1024, kHistogramGroups = 512;
 
-__global__ __launch_bounds__(256) void gainMapHistogramKernel(const float * ratios, size_t numPixels, int channels, GainMapStepTables T, uint32_t * h0,
-                                                              uint32_t * h1, uint32_t * h2)
+__device__ __forceinline__ void histogramAdd(uint32_t * local, uint32_t bucket, bool valid)
 {
-    __shared__ uint32_t local[kHistogramLdsBuckets];
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);
+#pragma unroll 1
+    for (int round = 0; round < 4 && todo; ++round) {
+        const int leader = __ffsll((long long)todo) - 1; // (wave-uniform: from the ballot)
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bucket, leader);
+        const unsigned long long same = __ballot(valid && bucket == b) & todo;
+        if ((int)lane == leader)
+            atomicAdd(&local[b], (uint32_t)__popcll(same));
+        todo &= ~same;
+        if (__popcll(same) < 12)
+            break; // a spread-out wave: the rounds cost more than the conflicts of the plain atomics they save
+    }
+    if ((todo >> lane) & 1ull)
+        atomicAdd(&local[bucket], 1u);
+}
+
+__global__ __launch_bounds__(1024) void gainMapHistogramKernel(const float * ratios, size_t numPixels, int channels, GainMapStepTables T, uint32_t * h0,
+                                                              uint32_t * h1, uint32_t * h2, uint32_t capacity)
+{
+    // `capacity` counters, then as many steps (the channel's: the corrections of a guess read two or three of them per sample).  Sized at launch
+    // by the widest channel -- a few hundred buckets for a real HDR / SDR pair, 10 000 at most -- so that several workgroups share a CU
+    extern __shared__ __attribute__((aligned(16))) uint32_t histogramLds[];
+    uint32_t * local = histogramLds;
+    float * ldsSteps = reinterpret_cast<float *>(histogramLds + capacity);
     uint32_t * const hist[3] = { h0, h1, h2 };
+    const size_t quads = numPixels >> 2; // (ratio planes start on 16 bytes when numPixels is a multiple of 4; the tail below otherwise)
     for (int c = 0; c < channels; ++c) {
         if (!T.t[c].entries)
             continue;
         const uint32_t buckets = T.t[c].flip + 1;
-        for (uint32_t k = threadIdx.x; k < buckets; k += 256)
+        const uint32_t last = T.t[c].flip, flip = T.t[c].flip;
+        const bool flipped = T.t[c].flipped != 0;
+        const float ga = T.t[c].guessA, gb = T.t[c].guessB;
+        const bool guessed = ga != 0.0f; // (workgroup-uniform)
+        for (uint32_t k = threadIdx.x; k < buckets; k += kHistogramThreads) {
             local[k] = 0;
-        __syncthreads();
-        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < numPixels; k += (size_t)gridDim.x * 256) {
-            const uint32_t m = stepIndex(T.t[c].steps, T.t[c].entries, ratios[(size_t)c * numPixels + k]);
-            atomicAdd(&local[T.t[c].flipped ? T.t[c].flip - m : m], 1u);
+            if (guessed)
+                ldsSteps[k] = T.t[c].steps[k];
         }
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < buckets; k += 256)
+        const float * plane = ratios + (size_t)c * numPixels;
+        const bool aligned = (((uintptr_t)plane) & 15) == 0;
+        const float * steps = T.t[c].steps;
+        auto bucketOf = [&](float x) -> uint32_t {
+            const uint32_t m = guessed ? stepIndexGuessed(ldsSteps, last, ga, gb, x) : stepIndex(steps, T.t[c].entries, x);
+            return flipped ? flip - m : m;
+        };
+        // (uniform trip count over the workgroup's waves: the ballots of histogramAdd need every lane of a wave in the loop)
+        const size_t stride = (size_t)gridDim.x * kHistogramThreads;
+        if (aligned) {
+            // two 16-byte loads in flight per lane; eight chains of table reads side by side
+            for (size_t k0 = (size_t)blockIdx.x * kHistogramThreads; k0 < quads; k0 += 2 * stride) {
+                const size_t ka = k0 + threadIdx.x, kb = ka + stride;
+                const bool va = ka < quads, vb = kb < quads;
+                float4 p = make_float4(1.0f, 1.0f, 1.0f, 1.0f), q = p;
+                if (va)
+                    p = reinterpret_cast<const float4 *>(plane)[ka];
+                if (vb)
+                    q = reinterpret_cast<const float4 *>(plane)[kb];
+                const uint32_t b0 = bucketOf(p.x), b1 = bucketOf(p.y), b2 = bucketOf(p.z), b3 = bucketOf(p.w);
+                const uint32_t b4 = bucketOf(q.x), b5 = bucketOf(q.y), b6 = bucketOf(q.z), b7 = bucketOf(q.w);
+                histogramAdd(local, b0, va);
+                histogramAdd(local, b1, va);
+                histogramAdd(local, b2, va);
+                histogramAdd(local, b3, va);
+                histogramAdd(local, b4, vb);
+                histogramAdd(local, b5, vb);
+                histogramAdd(local, b6, vb);
+                histogramAdd(local, b7, vb);
+            }
+            for (size_t k = quads * 4 + (size_t)blockIdx.x * kHistogramThreads + threadIdx.x; k < numPixels; k += stride)
+                atomicAdd(&local[bucketOf(plane[k])], 1u);
+        } else {
+            for (size_t k = (size_t)blockIdx.x * kHistogramThreads + threadIdx.x; k < numPixels; k += stride)
+                atomicAdd(&local[bucketOf(plane[k])], 1u);
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < buckets; k += kHistogramThreads)
             if (local[k])
                 atomicAdd(&hist[c][k], local[k]);
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void gainMapQuantiseKernel(const float * ratios, uint32_t width, uint32_t height, int channels, GainMapStepTables T,
+// pass 3: codes.  The code steps of the three channels sit in LDS up to 12-bit maps (LDSSTEPS); a lane owns four consecutive pixels of a row.
+template <bool LDSSTEPS, int CHANNELS>
+__global__ __launch_bounds__(256) void gainMapQuantiseKernel(const float * ratios, uint32_t width, uint32_t height, GainMapStepTables T,
                                                              uint8_t * rgba, uint32_t rgbaPitch, uint32_t depth)
 {
+    constexpr int channels = CHANNELS;
+    extern __shared__ __attribute__((aligned(16))) float ldsSteps[];
+    const float * steps[3] = { T.t[0].steps, T.t[1].steps, T.t[2].steps };
+    if constexpr (LDSSTEPS) {
+        uint32_t at = 0;
+        for (int c = 0; c < channels; ++c) {
+            for (uint32_t k = threadIdx.x; k < T.t[c].entries; k += 256)
+                ldsSteps[at + k] = T.t[c].steps[k];
+            steps[c] = ldsSteps + at;
+            at += T.t[c].entries;
+        }
+        __syncthreads();
+    }
     const size_t numPixels = (size_t)width * height;
     const uint32_t maxCode = (1u << depth) - 1;
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < numPixels; k += (size_t)gridDim.x * 256) {
-        const uint32_t j = (uint32_t)(k / width), i = (uint32_t)(k - (size_t)j * width);
-        uint32_t code[3];
+    const ComputeRuns R = computeRuns(width, height);
+    const bool vectorLoads = (width & 3u) == 0 && (((uintptr_t)ratios) & 15) == 0;
+    const bool vectorStores = (((uintptr_t)rgba | rgbaPitch) & 15) == 0;
+    for (uint32_t unit = blockIdx.x; unit < R.units; unit += gridDim.x) {
+        const uint32_t j = unit / R.runsX, i = (unit - j * R.runsX) * kComputeRun + 4 * threadIdx.x;
+        if (i >= width)
+            continue;
+        const uint32_t n = width - i < 4 ? width - i : 4;
+        uint32_t code[3][4];
+#pragma unroll
         for (int c = 0; c < channels; ++c) {
-            if (!T.t[c].entries) {
-                code[c] = 0;
-                continue;
+            const float * src = ratios + (size_t)c * numPixels + (size_t)j * width + i;
+            float v[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+            if (vectorLoads) {
+                const float4 q = *reinterpret_cast<const float4 *>(src);
+                v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((uint32_t)k < n)
+                        v[k] = src[k];
             }
-            const uint32_t m = stepIndex(T.t[c].steps, T.t[c].entries, ratios[(size_t)c * numPixels + k]);
-            code[c] = T.t[c].flipped ? T.t[c].flip - m : m;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!T.t[c].entries) {
+                    code[c][k] = 0;
+                } else {
+                    // (gamma 1: the codes are equally spaced in log2 of the ratio between the range's ends -- a guess, corrected against the steps)
+                    const uint32_t m = (T.t[c].guessA != 0.0f) ? stepIndexGuessed(steps[c], T.t[c].flip, T.t[c].guessA, T.t[c].guessB, v[k])
+                                                               : stepIndex(steps[c], T.t[c].entries, v[k]);
+                    code[c][k] = T.t[c].flipped ? T.t[c].flip - m : m;
+                }
+            }
         }
-        if (channels == 1)
-            code[1] = code[2] = code[0];
+        if constexpr (CHANNELS == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                code[1][k] = code[2][k] = code[0][k];
+        }
         uint8_t * p = rgba + (size_t)j * rgbaPitch;
-        if (depth > 8)
-            reinterpret_cast<uint2 *>(p)[i] = { code[0] | (code[1] << 16), code[2] | (maxCode << 16) };
-        else
-            reinterpret_cast<uint32_t *>(p)[i] = code[0] | (code[1] << 8) | (code[2] << 16) | (maxCode << 24);
+        if (depth > 8) {
+            uint2 px[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                px[k] = { code[0][k] | (code[1][k] << 16), code[2][k] | (maxCode << 16) };
+            if (vectorStores && n == 4) {
+                reinterpret_cast<uint4 *>(p)[i / 2] = make_uint4(px[0].x, px[0].y, px[1].x, px[1].y);
+                reinterpret_cast<uint4 *>(p)[i / 2 + 1] = make_uint4(px[2].x, px[2].y, px[3].x, px[3].y);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((uint32_t)k < n)
+                        reinterpret_cast<uint2 *>(p)[i + k] = px[k];
+            }
+        } else {
+            uint32_t px[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                px[k] = code[0][k] | (code[1][k] << 8) | (code[2][k] << 16) | (maxCode << 24);
+            if (vectorStores && n == 4) {
+                reinterpret_cast<uint4 *>(p)[i / 4] = make_uint4(px[0], px[1], px[2], px[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((uint32_t)k < n)
+                        reinterpret_cast<uint32_t *>(p)[i + k] = px[k];
+            }
+        }
     }
 }
 
@@ -971,19 +1230,43 @@ hipError_t launchGainMapApply(const GainMapArgs & A, hipStream_t stream, uint32_
     return hipGetLastError();
 }
 
+uint32_t gainMapComputeGroups(uint32_t width, uint32_t height)
+{
+    // (one or two runs per workgroup: 2048 workgroups with four runs each measured 5 % slower -- the passes wait on memory, not on the table staging)
+    const uint32_t units = computeRuns(width, height).units, most = kGainMapMaxGroups;
+    return units < most ? (units ? units : 1u) : most;
+}
+
+static bool computeLutsFitLds(const GainMapComputeArgs & A)
+{
+    return A.baseLutEntries && A.altLutEntries && A.baseLutEntries <= kComputeLdsLutMax && A.altLutEntries <= kComputeLdsLutMax;
+}
+
 hipError_t launchGainMapChannelMin(const GainMapComputeArgs & A, hipStream_t stream)
 {
-    const uint32_t tilesX = (A.width + 63) / 64, tiles = tilesX * ((A.height + 3) / 4);
-    const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
-    hipLaunchKernelGGL(gainMapChannelMinKernel, dim3(groups), dim3(64, 4), 0, stream, A, tilesX, tiles);
+    const uint32_t groups = gainMapComputeGroups(A.width, A.height);
+    if (computeLutsFitLds(A))
+        hipLaunchKernelGGL(gainMapChannelMinKernel<true>, dim3(groups), dim3(256), (A.baseLutEntries + A.altLutEntries) * sizeof(float), stream, A);
+    else
+        hipLaunchKernelGGL(gainMapChannelMinKernel<false>, dim3(groups), dim3(256), 0, stream, A);
     return hipGetLastError();
 }
 
 hipError_t launchGainMapRatios(const GainMapComputeArgs & A, hipStream_t stream)
 {
-    const uint32_t tilesX = (A.width + 63) / 64, tiles = tilesX * ((A.height + 3) / 4);
-    const uint32_t groups = tiles < kGainMapMaxGroups ? tiles : kGainMapMaxGroups;
-    hipLaunchKernelGGL(gainMapRatioKernel, dim3(groups), dim3(64, 4), 0, stream, A, tilesX, tiles);
+    const uint32_t groups = gainMapComputeGroups(A.width, A.height);
+    const uint32_t lds = (A.baseLutEntries + A.altLutEntries) * (uint32_t)sizeof(float);
+    if (computeLutsFitLds(A)) {
+        if (A.singleChannel)
+            hipLaunchKernelGGL((gainMapRatioKernel<true, 1>), dim3(groups), dim3(256), lds, stream, A);
+        else
+            hipLaunchKernelGGL((gainMapRatioKernel<true, 3>), dim3(groups), dim3(256), lds, stream, A);
+    } else {
+        if (A.singleChannel)
+            hipLaunchKernelGGL((gainMapRatioKernel<false, 1>), dim3(groups), dim3(256), 0, stream, A);
+        else
+            hipLaunchKernelGGL((gainMapRatioKernel<false, 3>), dim3(groups), dim3(256), 0, stream, A);
+    }
     return hipGetLastError();
 }
 
@@ -993,9 +1276,17 @@ hipError_t launchGainMapHistogram(const float * ratios, size_t numPixels, int ch
     GainMapStepTables T;
     for (int c = 0; c < 3; ++c)
         T.t[c] = tables[c];
-    const size_t want = (numPixels + 255) / 256;
-    const uint32_t groups = (uint32_t)(want < 1024 ? (want ? want : 1) : 1024); // few workgroups: each flushes a whole histogram
-    hipLaunchKernelGGL(gainMapHistogramKernel, dim3(groups), dim3(256), 0, stream, ratios, numPixels, channels, T, histograms[0], histograms[1], histograms[2]);
+    const size_t want = (numPixels + 4 * kHistogramThreads - 1) / (4 * kHistogramThreads);
+    const uint32_t groups = (uint32_t)(want < kHistogramGroups ? (want ? want : 1) : kHistogramGroups);
+    uint32_t capacity = 64;
+    for (int c = 0; c < channels; ++c)
+        if (T.t[c].entries && T.t[c].flip + 1 > capacity)
+            capacity = T.t[c].flip + 1;
+    capacity = (capacity + 63u) & ~63u;
+    if (capacity > kHistogramLdsBuckets)
+        return hipErrorInvalidValue; // (the reference caps its histogram at 10 000 buckets, src/gainmap.c:393)
+    hipLaunchKernelGGL(gainMapHistogramKernel, dim3(groups), dim3(kHistogramThreads), 2 * capacity * sizeof(uint32_t), stream, ratios, numPixels, channels, T, histograms[0],
+                       histograms[1], histograms[2], capacity);
     return hipGetLastError();
 }
 
@@ -1005,9 +1296,23 @@ hipError_t launchGainMapQuantise(const float * ratios, uint32_t width, uint32_t 
     GainMapStepTables T;
     for (int c = 0; c < 3; ++c)
         T.t[c] = tables[c];
-    const size_t want = ((size_t)width * height + 255) / 256;
-    const uint32_t groups = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
-    hipLaunchKernelGGL(gainMapQuantiseKernel, dim3(groups), dim3(256), 0, stream, ratios, width, height, channels, T, rgba, rgbaPitch, depth);
+    const uint32_t units = computeRuns(width, height).units;
+    const uint32_t groups = units < 8192 ? (units ? units : 1u) : 8192u; // (2048: 45 -> 52 us for a 4K map)
+    size_t entries = 0;
+    for (int c = 0; c < channels; ++c)
+        entries += T.t[c].entries;
+    const size_t lds = (entries ? entries : 1) * sizeof(float);
+    if (entries <= 3 * 4096) {
+        if (channels == 1)
+            hipLaunchKernelGGL((gainMapQuantiseKernel<true, 1>), dim3(groups), dim3(256), lds, stream, ratios, width, height, T, rgba, rgbaPitch, depth);
+        else
+            hipLaunchKernelGGL((gainMapQuantiseKernel<true, 3>), dim3(groups), dim3(256), lds, stream, ratios, width, height, T, rgba, rgbaPitch, depth);
+    } else {
+        if (channels == 1)
+            hipLaunchKernelGGL((gainMapQuantiseKernel<false, 1>), dim3(groups), dim3(256), 0, stream, ratios, width, height, T, rgba, rgbaPitch, depth);
+        else
+            hipLaunchKernelGGL((gainMapQuantiseKernel<false, 3>), dim3(groups), dim3(256), 0, stream, ratios, width, height, T, rgba, rgbaPitch, depth);
+    }
     return hipGetLastError();
 }
 

@@ -561,3 +561,50 @@ def test_gpu_compute_from_yuv_images(hip_auto_arithmetic):
     assert (gm_b.altColorPrimaries, gm_b.altTransferCharacteristics, gm_b.altMatrixCoefficients, gm_b.altDepth, gm_b.altPlaneCount) == (9, 16, 9, 10, 3)
     TS.free_owned(img_a.struct)
     TS.free_owned(img_b.struct)
+
+
+@pytest.mark.gpu
+def test_gpu_compute_device_resident(hip_auto_arithmetic):
+    """avifhipRGBImageComputeGainMapAsync (round 6): both renditions and the gain map's planes in device memory, the caller's stream.  Metadata
+    and planes equal the oracle's (src/gainmap.c:535-843) -- the same cases as the host entry point, larger images with odd widths included
+    (the kernels' four-pixel lanes, their row ends, the histogram's vector tail)."""
+    import test_scale as TS
+    from libavif_amd import device
+
+    lib = hip_auto_arithmetic
+    o = oracle_lib.oracle()
+    diag = abi.avifDiagnostics()
+    stream = lib.avifhipStreamCreate()
+    assert stream
+    bad = []
+    cases = G.compute_cases(40, seed=21) + [G.ComputeCase(1001, 333, gm_w=500, gm_h=167, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420),
+                                            G.ComputeCase(1027, 301, alt_primaries=9), G.ComputeCase(2050, 130, gm_format=abi.AVIF_PIXEL_FORMAT_YUV400, gm_depth=10),
+                                            G.ComputeCase(1920, 1080, alt_primaries=9, seed=5), G.ComputeCase(1030, 517, base_format=abi.AVIF_RGB_FORMAT_RGB, alt_format=abi.AVIF_RGB_FORMAT_BGRA)]
+    try:
+        for c in cases:
+            ra, sa = run_compute(o.oracleRGBImageComputeGainMap, c, 1)
+            base, alt = G.make_compute_inputs(c)
+            dbase, dalt = device.DeviceRGB(base, upload=True), device.DeviceRGB(alt, upload=True)
+            gw, gh = c.gm_w or c.w, c.gm_h or c.h
+            # (with an alpha plane: avifImageRGBToYUV gives the reference's gain-map image one -- opaque -- because the codes are RGBA, src/gainmap.c:792-800)
+            host_gm = abi.make_yuv(gw, gh, c.gm_depth, c.gm_format, c.gm_range, c.gm_matrix, with_alpha=True)
+            dgm = device.DeviceYUV(host_gm, upload=False)
+            gm = abi.avifGainMap()
+            gm.image = C.pointer(dgm.struct)
+            rb = lib.avifhipRGBImageComputeGainMapAsync(dbase.struct, c.base_primaries, c.base_tc, dalt.struct, c.alt_primaries, c.alt_tc, C.byref(gm), C.byref(diag), stream)
+            sb = None
+            if rb == 0:
+                assert lib.avifhipSynchronize(stream) == 0
+                dgm.download_into_host()
+                sb = gain_map_state(gm, host_gm.struct)
+            if ra != rb or not states_equal(sa, sb):
+                bad.append(f"{c.ident()}: results {ra}/{rb}" + ("" if sa is None or sb is None else f" meta equal {sa[0] == sb[0]} size {sa[1]}/{sb[1]}"))
+    finally:
+        lib.avifhipStreamDestroy(stream)
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ:\n" + "\n".join(bad[:20])
+    # planes the caller did not allocate are the caller's error
+    c = cases[0]
+    base, alt = G.make_compute_inputs(c)
+    dbase, dalt = device.DeviceRGB(base, upload=True), device.DeviceRGB(alt, upload=True)
+    gm, img = G.make_compute_gain_map(c)
+    assert lib.avifhipRGBImageComputeGainMapAsync(dbase.struct, c.base_primaries, c.base_tc, dalt.struct, c.alt_primaries, c.alt_tc, C.byref(gm), C.byref(diag), None) == abi.AVIF_RESULT_INVALID_ARGUMENT

@@ -421,7 +421,7 @@ def run(name):
                         call()  # waits for its stream: result code and CLLI depend on the pixels
                     best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
                 ms = best
-        elif name in ("gmcompute4k", "gmcompute4k_cpu"):
+        elif name in ("gmcompute4k", "gmcompute4k_cpu", "gmcompute4k_dev"):
             # avifRGBImageComputeGainMap: 3840x2160 RGBA8 sRGB base + RGBA10 PQ BT.2020 alternate -> 8-bit 4:4:4 gain map + metadata.
             # The entry point takes HOST images (the encode side is host-driven): the time includes the PCIe transfers both ways.
             if arith == "integer":
@@ -433,7 +433,18 @@ def run(name):
             gm, img = G.make_compute_gain_map(c)
             diag = abi.avifDiagnostics()
             px, bpp = c.w * c.h, 4 + 8 + 3
-            if name == "gmcompute4k_cpu":
+            if name == "gmcompute4k_dev":
+                # round 6: everything in device memory (avifhipRGBImageComputeGainMapAsync): what the passes cost without the host link.  Wall clock
+                # around back-to-back calls (each waits for its own first passes: the metadata is a function of every pixel)
+                dbase, dalt = device.DeviceRGB(base, upload=True), device.DeviceRGB(alt, upload=True)
+                host_gm = abi.make_yuv(c.w, c.h, c.gm_depth, c.gm_format, c.gm_range, c.gm_matrix)
+                dgm = device.DeviceYUV(host_gm, upload=False)
+                gm.image = C.pointer(dgm.struct)
+                t = lib.avifhipTimeRGBImageComputeGainMap
+                assert t(dbase.struct, 1, 13, dalt.struct, 9, 16, C.byref(gm), 3, 10, None) > 0, lib.avifhipLastError()
+                ms = sorted(t(dbase.struct, 1, 13, dalt.struct, 9, 16, C.byref(gm), 1, 10, None) for _ in range(5))[2]
+                extra["clock_note"] = "wall clock around 10 back-to-back device-resident calls, median of 5"
+            elif name == "gmcompute4k_cpu":
                 import oracle_lib
                 t0 = time.perf_counter()
                 assert oracle_lib.oracle().oracleRGBImageComputeGainMap(base.struct, 1, 13, alt.struct, 9, 16, C.byref(gm), 1) == 0

@@ -24,6 +24,7 @@ if os.environ.get("AVIFHIP_BENCH_LIB"):
 lib = native.load()
 BIL = abi.AVIF_CHROMA_UPSAMPLING_BILINEAR
 PEAK = 8000.0
+SEQ = 4  # frames per launch of the sequence rows (bench.py SEQUENCE_FRAMES)
 
 
 def median(xs):
@@ -248,7 +249,7 @@ def run_only(name, launches=400):
         n, imgs, rgbs = arr(pairs)
         ms = lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 20, launches // 4, None)
         emit("cfg3 (2 frames cycled)", "run", ms, 16.0 * 7680 * 4320, algorithmic_read_bytes=8 * 7680 * 4320, algorithmic_write_bytes=8 * 7680 * 4320)
-    elif name == "cfg4":
+    elif name in ("cfg4", "cfg4seq"):
         enc = []
         for k in range(8):
             rgb = abi.make_rgb(3840, 2160, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=False)
@@ -256,10 +257,34 @@ def run_only(name, launches=400):
             img = abi.make_yuv(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, with_alpha=True)
             enc.append((device.DeviceYUV(img, upload=False), device.DeviceRGB(rgb, upload=True)))
         n, imgs, rgbs = arr(enc)
-        ms = lib.avifhipTimeRGBToYUVCycle(n, imgs, rgbs, 20, launches, None)
-        emit("cfg4 (8 frames cycled)", "run", ms, 6.5 * 3840 * 2160, algorithmic_read_bytes=4 * 3840 * 2160, algorithmic_write_bytes=int(2.5 * 3840 * 2160))
+        if name == "cfg4seq":  # the encode direction as a sequence: SEQ frames per launch (avifhipImageRGBToYUVBatchAsync)
+            lib.avifhipTimeStreamCeilingRGBToYUV(n, imgs, rgbs, 0, 6000, None)  # ~60 ms of another kernel first (clocks)
+            launches = 1200
+            ms = lib.avifhipTimeRGBToYUVBatchCycle(n, imgs, rgbs, SEQ, 20, launches // SEQ, None)
+            emit(f"cfg4 (8 frames cycled), {SEQ} frames per launch", "run", ms, 6.5 * 3840 * 2160 * SEQ, frames_per_launch=SEQ, us_per_frame=round(ms * 1e3 / SEQ, 3),
+                 algorithmic_read_bytes=4 * 3840 * 2160 * SEQ, algorithmic_write_bytes=int(2.5 * 3840 * 2160) * SEQ)
+        else:
+            ms = lib.avifhipTimeRGBToYUVCycle(n, imgs, rgbs, 20, launches, None)
+            emit("cfg4 (8 frames cycled)", "run", ms, 6.5 * 3840 * 2160, algorithmic_read_bytes=4 * 3840 * 2160, algorithmic_write_bytes=int(2.5 * 3840 * 2160))
+    elif name in ("cfg2seq", "cfg2seq_fp32", "cfg2cold", "cfg2cold_fp32", "4kseq", "4kseq_fp32", "4kcold", "4kcold_fp32"):
+        # the headline's frames where nothing is cache-resident (12 8K frames = 2.2 GB, 24 4K frames = 1.1 GB), one frame per launch (...cold) or
+        # SEQ frames per launch (...seq: avifhipImageYUVToRGBBatchAsync over large frames)
+        fp32 = name.endswith("_fp32")
+        base = name[:-5] if fp32 else name
+        w, h, frames = (3840, 2160, 24) if base.startswith("4k") else (7680, 4320, 12)
+        pairs = [y2r(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=fp32, seed=k % 4) for k in range(frames)]
+        n, imgs, rgbs = arr(pairs)
+        per = SEQ if base.endswith("seq") else 1
+        lib.avifhipTimeStreamCeiling(n, imgs, rgbs, 0, 60000 // (33 if w > 4000 else 9), None)  # ~60 ms of ANOTHER kernel: the clocks are up before the profiled one starts
+        launches = 1200
+        if per > 1:
+            ms = lib.avifhipTimeYUVToRGBBatchCycle(n, imgs, rgbs, per, 20, launches // per, None)
+        else:
+            ms = lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 20, launches, None)
+        emit(f"{w}x{h} 8-bit 4:2:0 -> RGBA8 ({'fp32' if fp32 else 'integer'}), {frames} frames cycled, {per} per launch", "run", ms, 5.5 * w * h * per, frames_per_launch=per,
+             us_per_frame=round(ms * 1e3 / per, 3), algorithmic_read_bytes=int(1.5 * w * h) * per, algorithmic_write_bytes=4 * w * h * per)
     else:
-        raise SystemExit("run: cfg3 or cfg4")
+        raise SystemExit("run: cfg3, cfg4, cfg4seq, cfg2seq[_fp32], cfg2cold[_fp32], 4kseq[_fp32] or 4kcold[_fp32]")
 
 
 if __name__ == "__main__":
