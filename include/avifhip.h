@@ -172,7 +172,9 @@ AVIFHIP_API avifResult avifhipRGBImageTransformAsync(avifRGBImage * dst,
  * transcendental of the reference is tabulated on the host with the host's libm (per sample code on the input side; as the
  * fp32 steps of the quantised output transfer function on the output side), the GPU does the IEEE arithmetic in between.
  * The only tolerance: clli->maxPALL, which the reference accumulates in fp32 pixel by pixel (order-dependent rounding) and
- * this library in fp64 partial sums -- it may differ by rounding of the last nit.  The gain map's own YUV -> RGB conversion
+ * this library in fp64 partial sums -- it may differ by rounding of the last nit -- unless avifhipSetExactLightLevels(1) (or
+ * AVIFHIP_EXACT_LIGHT_LEVELS=1) asks for the reference's own sum: the kernels then also leave every pixel's maximum, and the host adds them
+ * up in one fp32 accumulator in raster order like src/gainmap.c:293 does (8 ms of host time and a 33 MB download for a 4K image: opt-in).  The gain map's own YUV -> RGB conversion
  * follows the library's arithmetic setting (default: what a libavif built with libyuv computes).
  * avifhipRGBImageApplyGainMap: host images; toneMappedImage->pixels is (re)allocated with malloc like the reference does -- except that a
  * buffer the struct already holds is kept when malloc_usable_size() says it has the size the reference would allocate (same bytes, same
@@ -217,6 +219,11 @@ AVIFHIP_API double avifhipTimeRGBImageApplyGainMap(const avifRGBImage * baseImag
                                                    int warmup,
                                                    int iters,
                                                    void * hipStream);
+AVIFHIP_API void avifhipSetExactLightLevels(int on);
+/* avifhipRGBImageApplyGainMapAsync with clli != NULL (round 6): where the fast kernel serves the call (4-channel integer pixels, tables that
+ * fit the LDS, no NaN possible: the usual case) the call returns with its work enqueued like every other Async entry point, and *clli is
+ * filled by a host function the stream runs behind the kernel -- read it after the stream has been synchronised (avifhipSynchronize), and
+ * keep it alive until then.  Every other case (and exact light levels) waits for the stream before it returns, as before. */
 /* Gain-map computation (the encode side): drop-in for avifRGBImageComputeGainMap (reference include/avif/avif.h:1688-1722,
  * src/gainmap.c:535-843): host images in; the metadata fractions of `gainMap` and the (malloc'ed) planes of gainMap->image -- whose
  * width, height, depth, yuvFormat (range, matrix) carry the request, as in the reference -- out.  Byte-identical planes and

@@ -17,6 +17,47 @@ using namespace avifhip::api;
 // =================================================================================================
 
 namespace {
+// ---- light levels ----
+std::atomic<int> gExactLightLevels { -1 }; // -1: AVIFHIP_EXACT_LIGHT_LEVELS decides (read once)
+bool exactLightLevels()
+{
+    int v = gExactLightLevels.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char * e = getenv("AVIFHIP_EXACT_LIGHT_LEVELS");
+        v = (e && e[0] == '1' && !e[1]) ? 1 : 0;
+        gExactLightLevels.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+uint16_t lightLevelNits(float v) // src/gainmap.c:303,305
+{
+    const float r = floorf(v * 203.0f + 0.5f);
+    return (uint16_t)((r < 0.0f) ? 0.0f : ((65535.0f < r) ? 65535.0f : r));
+}
+// what the stream runs behind the copy of an asynchronous call's partials (hipLaunchHostFunc: no runtime calls in here)
+struct LightLevelJob
+{
+    const GainMapPartial * partials;
+    uint32_t count;
+    size_t pixels;
+    avifContentLightLevelInformationBox * clli;
+};
+void lightLevelsFromPartials(void * user)
+{
+    LightLevelJob * job = static_cast<LightLevelJob *>(user);
+    float rgbMax = 0.0f;
+    double sum = 0.0;
+    for (uint32_t k = 0; k < job->count; ++k) {
+        rgbMax = (job->partials[k].max > rgbMax) ? job->partials[k].max : rgbMax;
+        sum += job->partials[k].sum;
+    }
+    job->clli->maxCLL = lightLevelNits(rgbMax);
+    job->clli->maxPALL = lightLevelNits((float)sum / (float)job->pixels);
+    delete job;
+}
+} // namespace
+
+namespace {
 
 // AVIFHIP_GAINMAP_KERNEL=general keeps calls off the fast apply kernel (tests run both kernels over the same cases)
 bool fastKernelDisabled()
@@ -475,6 +516,14 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
             return pr;
         A.partials = (GainMapPartial *)tls.gainMap[3].ptr;
     }
+    // exact light levels (opt-in): the kernel also leaves every pixel's max(0, r, g, b); the host adds them up like the reference does
+    const bool exactLevels = applyGain && clli && exactLightLevels() && tls.gainMapTimeIters <= 0;
+    if (exactLevels) {
+        const avifResult xr = reserve(tls.gainMap[11], (size_t)width * height * sizeof(float));
+        if (xr != AVIF_RESULT_OK)
+            return xr;
+        A.pixelMax = (float *)tls.gainMap[11].ptr;
+    }
     uint32_t partials = 0;
     if (tls.gainMapTimeIters > 0) { // avifhipTimeRGBImageApplyGainMap: the apply kernel alone, back to back, between two events
         for (int k = 0; k < tls.gainMapTimeWarmup; ++k)
@@ -509,7 +558,34 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
     // returns with its work enqueued, like every other Async call.
     if (mayReturnEarly && applyGain && A.fast && !clli && tls.gainMapTimeIters <= 0)
         return AVIF_RESULT_OK;
+    // ... and with light levels asked for, the asynchronous entry point still returns with its work enqueued: the partials travel into a pinned
+    // slot behind the kernel and a host function the stream runs behind that copy fills *clli (valid once the stream has reached that point;
+    // the fast kernel's precondition rules the NaN result out, so the result code is known now)
+    if (mayReturnEarly && applyGain && A.fast && clli && !exactLevels && !partialsOnHost && partials && tls.gainMapTimeIters <= 0) {
+        const uint32_t slot = tls.lightSlot++ % (uint32_t)Context::kLightSlots;
+        if (!tls.lightPinned[slot])
+            HIP_TRY(hipHostMalloc(&tls.lightPinned[slot], (size_t)kGainMapMaxGroups * sizeof(GainMapPartial), hipHostMallocDefault));
+        if (!tls.lightRead[slot])
+            HIP_TRY(hipEventCreateWithFlags(&tls.lightRead[slot], hipEventDisableTiming));
+        if (tls.lightBusy[slot])
+            HIP_TRY(hipEventSynchronize(tls.lightRead[slot])); // (the call of kLightSlots calls ago has been read)
+        HIP_TRY(hipMemcpyAsync(tls.lightPinned[slot], A.partials, (size_t)partials * sizeof(GainMapPartial), hipMemcpyDeviceToHost, stream));
+        LightLevelJob * job = new LightLevelJob { (const GainMapPartial *)tls.lightPinned[slot], partials, (size_t)width * height, clli };
+        const hipError_t he = hipLaunchHostFunc(stream, lightLevelsFromPartials, job);
+        if (he != hipSuccess) {
+            delete job;
+            return hipFailed(he, "hipLaunchHostFunc (light levels)");
+        }
+        HIP_TRY(hipEventRecord(tls.lightRead[slot], stream));
+        tls.lightBusy[slot] = true;
+        return AVIF_RESULT_OK;
+    }
     const GainMapPartial * hostPartials = (const GainMapPartial *)tls.gainMapPartials;
+    std::vector<float> pixelMaxima;
+    if (exactLevels) {
+        pixelMaxima.resize((size_t)width * height);
+        HIP_TRY(hipMemcpyAsync(pixelMaxima.data(), A.pixelMax, pixelMaxima.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    }
     if (!partialsOnHost && partials)
         HIP_TRY(hipMemcpyAsync(tls.gainMapPartials, A.partials, (size_t)partials * sizeof(GainMapPartial), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -531,13 +607,17 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
     if (applyGain && clli) { // src/gainmap.c:292-302 (the reference sums in fp32 pixel by pixel; here fp64 partial sums)
         float rgbMaxLinear;
         memcpy(&rgbMaxLinear, &stats.maxBits, 4);
-        const float kSdrWhiteNits = 203.0f;
-        auto toNits = [&](float v) -> uint16_t {
-            const float r = floorf(v * kSdrWhiteNits + 0.5f);
-            return (uint16_t)((r < 0.0f) ? 0.0f : ((65535.0f < r) ? 65535.0f : r));
-        };
-        clli->maxCLL = toNits(rgbMaxLinear);
-        clli->maxPALL = toNits((float)stats.sum / (float)((size_t)width * height));
+        clli->maxCLL = lightLevelNits(rgbMaxLinear);
+        if (exactLevels) {
+            // src/gainmap.c:223,293,304: ONE fp32 accumulator over the pixels in raster order -- at 8 megapixels the sum is past 2^23 and every
+            // addition rounds, so only the same additions in the same order give the same average (8 ms of host time for a 4K image)
+            float rgbSumLinear = 0.0f;
+            for (const float m : pixelMaxima)
+                rgbSumLinear += m;
+            clli->maxPALL = lightLevelNits(rgbSumLinear / (float)((size_t)width * height));
+        } else {
+            clli->maxPALL = lightLevelNits((float)stats.sum / (float)((size_t)width * height));
+        }
     }
     return AVIF_RESULT_OK;
 }
@@ -1284,4 +1364,10 @@ extern "C" avifResult avifhipImageComputeGainMap(const avifImage * baseImage, co
     free(rgb[0].pixels);
     free(rgb[1].pixels);
     return r;
+}
+
+// Light levels exactly like the reference accumulates them (include/avifhip.h)
+extern "C" void avifhipSetExactLightLevels(int on)
+{
+    gExactLightLevels.store(on ? 1 : 0, std::memory_order_relaxed);
 }

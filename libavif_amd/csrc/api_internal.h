@@ -123,12 +123,19 @@ struct Context
     ScaleTableCache scaleCache; // ... and which geometry they belong to
     Scratch satoTable;  // input plane tables of a sample transform (device)
     Scratch xformCanvas; // canvas-sized RGB of the two-pass route of avifhip*TransformedAsync (device)
-    Scratch gainMap[11]; // gain maps: [0] output pixels, [1] gain map as RGB, [2] tables, [3] statistics / partials, [4] scaled planes, [5] base pixels;
+    Scratch gainMap[12]; // gain maps: [0] output pixels, [1] gain map as RGB, [2] tables, [3] statistics / partials, [4] scaled planes, [5] base pixels;
                          // computation: [6] tables, [7] ratios, [8] histograms, [9] alternate pixels, [10] gain-map planes
     GainMapTableCache gainMapCache; // what gainMap[2] holds
     int gainMapTimeWarmup = 0, gainMapTimeIters = 0; // avifhipTimeRGBImageApplyGainMap in progress on this thread: repeat the apply kernel
     double gainMapTimedMs = -1.0;                    // ... and what it measured
     void * gainMapPartials = nullptr; // apply: the statistics as the workgroups leave them (pinned host memory, kGainMapMaxGroups partials)
+    // ... of asynchronous calls that asked for light levels (avifhipRGBImageApplyGainMapAsync with clli): a ring of pinned slots, each read by a
+    // host function the stream runs behind the copy that fills it; the event says when a slot may be written again
+    static constexpr int kLightSlots = 4;
+    void * lightPinned[kLightSlots] = {};
+    hipEvent_t lightRead[kLightSlots] = {};
+    bool lightBusy[kLightSlots] = {};
+    uint32_t lightSlot = 0;
     // batch descriptor tables travel through a ring of kTableRing slots (pinned host memory + the matching slice of `table`), uploaded on
     // `upStream`: the host prepares batch n + 1 and its table crosses the link while batch n computes (api_batch.cpp: batchAsyncImpl)
     static constexpr int kTableRing = 4;
@@ -200,6 +207,14 @@ struct Context
                 (void)hipFree(g.ptr);
         if (gainMapPartials)
             (void)hipHostFree(gainMapPartials);
+        for (int k = 0; k < kLightSlots; ++k) {
+            if (lightRead[k]) {
+                (void)hipEventSynchronize(lightRead[k]);
+                (void)hipEventDestroy(lightRead[k]);
+            }
+            if (lightPinned[k])
+                (void)hipHostFree(lightPinned[k]);
+        }
         if (pinnedTable)
             (void)hipHostFree(pinnedTable);
         for (int k = 0; k < kTableRing; ++k) {

@@ -246,6 +246,9 @@ struct GainMapArgs
     float baseOffset[3], altOffset[3];
     // statistics: one partial per workgroup, in pinned host memory (kGainMapMaxGroups entries); the caller adds them up in index order
     GainMapPartial * partials;
+    // exact light levels (opt-in, api_gainmap.cpp): every pixel's max(0, r, g, b) of the tone-mapped linear values, `width` floats per row --
+    // the host adds them up in the reference's order (src/gainmap.c:293: one fp32 accumulator, raster order); null otherwise
+    float * pixelMax;
 };
 constexpr uint32_t kGainMapMaxGroups = 4096; // persistent workgroups of the apply kernel
 // LDS the fast kernel may fill with tables (two workgroups per CU keep eight waves resident)

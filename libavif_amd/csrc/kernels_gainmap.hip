@@ -292,6 +292,8 @@ __global__ __launch_bounds__(256) void gainMapApplyKernel(GainMapArgs A, uint32_
                     v[c] = tone;
                 }
                 sum += (double)pixelMax;
+                if (A.pixelMax)
+                    A.pixelMax[(size_t)j * A.width + i] = pixelMax;
                 if (A.outConv)
                     convertPrimaries(v, A.outM);
                 sawNan = sawNan || (v[0] != v[0]) || (v[1] != v[1]) || (v[2] != v[2]);
@@ -629,6 +631,12 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
         if (!(A.fast & 32) || op.w[0] == 0xdeadbeefu)
 #endif
             op.store(A.out + (size_t)T.j * A.outPitch + (size_t)T.i0 * OUT_BYTES);
+        if (A.pixelMax) { // (wave-uniform; a run moved left at the end of a row stores the pixels it shares with its neighbour again: same values)
+            float * pm = A.pixelMax + (size_t)T.j * A.width + T.i0;
+#pragma unroll
+            for (int p = 0; p < kFastPixels; ++p)
+                pm[p] = pixelMax[p];
+        }
         toneMax = fmaxf(toneMax, fmaxf(fmaxf(pixelMax[0], pixelMax[1]), fmaxf(pixelMax[2], pixelMax[3])));
         if (__builtin_expect(T.i0 == T.i, 1)) {
             sum += ((double)pixelMax[0] + (double)pixelMax[1]) + ((double)pixelMax[2] + (double)pixelMax[3]);

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "avifhipSynthFill", "avifhipStreamCreate", "avifhipStreamDestroy", "avifhipSetTuning", "avifhipTimeYUVToRGBCycle", "avifhipTimeStreamCeiling", "avifhipTimeStreamCeilingRGBToYUV", "avifhipTimeStreamCeilingBatch", "avifhipTimeStreamCeilingScale", "avifhipTimeRGBToYUVCycle", "avifhipTimeYUVToRGBBatch", "avifhipTimeYUVToRGBBatchCycle", "avifhipTimeStreamCeilingBatchCycle", "avifhipTimeGridYUVToRGB", "avifhipImageYUVToRGBTransformedAsync", "avifhipGridYUVToRGBTransformedAsync", "avifhipY4MFrameBytes", "avifhipImagePackY4MFrameAsync", "avifhipRGBImagePackPNGRowsAsync", "avifhipImageYUVToRGBRects", "avifhipPlanRectTransfers", "avifhipLastTransferBytes", "avifhipImageYUVToRGBColorOnly", "avifhipImageYUVToRGBHook", "avifhipRGBImageToF16", "avifhipLaunchCount", "avifhipTableUploadCount", "avifhipCalcYUVCoefficients",
     "avifhipExplainYUVToRGB", "avifhipExplainRGBToYUV", "avifhipGridYUVToRGBAsync", "avifhipRGBImageTransformAsync", "avifhipImageScale", "avifhipImageScaleAsync", "avifhipImageApplyOperationsAsync",
     "avifhipSetDeviceSet", "avifhipSetFarmMinSharePixels", "avifhipGetDeviceSet", "avifhipPlanFarmRows", "avifhipLastFarmWorkers", "avifhipLastFarmTransferBytes",
-    "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipTimeRGBImageApplyGainMap", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap", "avifhipRGBImageComputeGainMapAsync", "avifhipTimeRGBImageComputeGainMap",
+    "avifhipRGBImageApplyGainMap", "avifhipRGBImageApplyGainMapAsync", "avifhipTimeRGBImageApplyGainMap", "avifhipImageApplyGainMap", "avifhipRGBImageComputeGainMap", "avifhipImageComputeGainMap", "avifhipRGBImageComputeGainMapAsync", "avifhipTimeRGBImageComputeGainMap", "avifhipSetExactLightLevels",
 ]
 
 class avifSampleTransformToken(C.Structure):
@@ -141,6 +141,7 @@ def load() -> C.CDLL:
                                                          i32, i32, vp]),
         "avifhipRGBImageComputeGainMap": (i32, [P_RGB, C.c_uint16, C.c_uint16, P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.POINTER(avifDiagnostics)]),
         "avifhipRGBImageComputeGainMapAsync": (i32, [P_RGB, C.c_uint16, C.c_uint16, P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), C.POINTER(avifDiagnostics), vp]),
+        "avifhipSetExactLightLevels": (None, [i32]),
         "avifhipTimeRGBImageComputeGainMap": (C.c_double, [P_RGB, C.c_uint16, C.c_uint16, P_RGB, C.c_uint16, C.c_uint16, C.POINTER(avifGainMap), i32, i32, vp]),
         "avifhipImageComputeGainMap": (i32, [P_IMG, P_IMG, C.POINTER(avifGainMap), C.POINTER(avifDiagnostics)]),
         "avifhipImageApplyGainMap": (i32, [P_IMG, C.POINTER(avifGainMap), C.c_float, C.c_uint16, C.c_uint16, P_RGB,

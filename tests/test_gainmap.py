@@ -370,6 +370,8 @@ def test_gpu_device_resident(hip_auto_arithmetic):
                                                                  c.out_tc, dout.struct, C.byref(clli), C.byref(diag), None)
         assert ra == rb, (c.ident(), ra, rb, diag.error)
         if ra == 0:
+            # (round 6: the light levels of an asynchronous call arrive with the stream -- a host function behind the kernel fills them)
+            assert hip_auto_arithmetic.avifhipSynchronize(None) == 0
             dout.download_into_host()
             wb = c.w * abi.rgb_pixel_size(c.out_format, c.out_depth)
             assert np.array_equal(out.pixels[:, :wb], pa[:, :wb]), (c.ident(), native.last_kernel())
@@ -608,3 +610,36 @@ def test_gpu_compute_device_resident(hip_auto_arithmetic):
     dbase, dalt = device.DeviceRGB(base, upload=True), device.DeviceRGB(alt, upload=True)
     gm, img = G.make_compute_gain_map(c)
     assert lib.avifhipRGBImageComputeGainMapAsync(dbase.struct, c.base_primaries, c.base_tc, dalt.struct, c.alt_primaries, c.alt_tc, C.byref(gm), C.byref(diag), None) == abi.AVIF_RESULT_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_gpu_exact_light_levels(hip_auto_arithmetic):
+    """avifhipSetExactLightLevels(1): maxPALL is the reference's own -- one fp32 accumulator over the pixels in raster order (src/gainmap.c:223,
+    293, 304) -- not the fp64 partial sums' rounding of it: no tolerance left, on the host entry point and on the device-resident one, small
+    images and an 8-megapixel one (where the fp32 sum is past 2^23 and every addition rounds)."""
+    from libavif_amd import device
+
+    lib = hip_auto_arithmetic
+    o = oracle_lib.oracle()
+    lib.avifhipSetExactLightLevels(1)
+    try:
+        cases = G.cases(0, seed=31)[:40:2] + [G.GainMapCase(3840, 2160, seed=7), G.GainMapCase(1001, 333, gm_w=500, gm_h=167, gm_format=abi.AVIF_PIXEL_FORMAT_YUV420)]
+        for c in cases:
+            ra, pa, ca = run(o.oracleRGBImageApplyGainMap, c, 1)
+            diag = abi.avifDiagnostics()
+            rb, pb, cb = run(lib.avifhipRGBImageApplyGainMap, c, C.byref(diag))
+            assert ra == rb and ca == cb, (c.ident(), ra, rb, ca, cb)
+            if ra != 0:
+                continue
+            assert np.array_equal(pa, pb), c.ident()
+            base = G.make_base(c)
+            gm, keep = G.make_gain_map(c)
+            dbase, dgm_img = device.DeviceRGB(base, upload=True), device.DeviceYUV(keep)
+            gm.image = C.pointer(dgm_img.struct)
+            dout = device.DeviceRGB(abi.make_rgb(c.w, c.h, c.out_depth, c.out_format, is_float=c.out_float, avoid_libyuv=False), upload=True)
+            clli = abi.avifContentLightLevelInformationBox(0xFFFF, 0xFFFF)
+            assert lib.avifhipRGBImageApplyGainMapAsync(dbase.struct, c.base_primaries, c.base_tc, C.byref(gm), c.headroom, c.out_primaries, c.out_tc, dout.struct,
+                                                        C.byref(clli), C.byref(diag), None) == 0
+            assert (clli.maxCLL, clli.maxPALL) == ca, (c.ident(), ca, (clli.maxCLL, clli.maxPALL))
+    finally:
+        lib.avifhipSetExactLightLevels(0)
