@@ -597,6 +597,37 @@ def main():
         except Exception:
             pass
 
+    # ---- N > 1: the other two multi-GPU shapes in the same line (one driver command captures all three; N = 1 prints today's line) ----
+    #   strong_scaling_cfg5      ONE 15360x8640 canvas of 64 tiles per step, its tiles sharded over the ranks (what `--workload cfg5` prints)
+    #   in_process_host_to_host  ONE process (rank 0) driving all N devices through the library's device farm, host image in, host pixels out
+    #                            (what `--in-process` prints: an unmodified libavif over seam A / seam B with AVIFHIP_DEVICES=all); the other ranks wait
+    if (world > 1 or os.environ.get("AVIFHIP_BENCH_ALL_BLOCKS") == "1") and not args.headline_only:
+        import copy
+
+        side = copy.copy(args)
+        side.steps, side.warmup, side.repeats, side.preheat_ms = min(args.steps, 50), min(args.warmup, 10), min(args.repeats, 3), min(args.preheat_ms, 100.0)
+        try:
+            cfg5 = run_cfg5(side, lib, rank, world, dist, torch)
+            out["strong_scaling_cfg5"] = {k: cfg5[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "roofline", "host_to_host")}
+        except Exception as exc:  # (the headline must not depend on a side block; a failing rank would hang the others in a collective: re-raise there)
+            if dist is not None:
+                raise
+            out["strong_scaling_cfg5"] = {"error": repr(exc)}
+        if dist is not None:
+            dist.barrier()
+        if rank == 0 and not args.dry_run:
+            try:
+                side.gpus = world
+                block = run_in_process(side)
+                out["in_process_host_to_host"] = {k: block[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "data", "config", "host_link")}
+                native.check(lib.avifhipSetDevice(local_rank if world > 1 else 0), "avifhipSetDevice")
+            except (Exception, SystemExit) as exc:
+                out["in_process_host_to_host"] = {"error": repr(exc)}
+        else:
+            out["in_process_host_to_host"] = None
+        if dist is not None:
+            dist.barrier()
+
     seq_file = ROOT / "profiles" / "pmc_traffic_sequence.json"
     if seq_file.exists() and not args.dry_run:
         try:
@@ -818,6 +849,7 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
         for _ in range(20):
             native.check(lib.avifhipRGBImageApplyGainMapAsync(dbase.struct, 1, 13, C.byref(gm), 3.0, 9, 16, dout.struct, C.byref(clli), C.byref(diag), None),
                          "avifhipRGBImageApplyGainMapAsync")
+        native.check(lib.avifhipSynchronize(None), "avifhipSynchronize")  # (round 6: the light levels arrive with the stream -- a host function behind each kernel)
         calls.append((time.perf_counter() - t0) / 20 * 1e3)
     # ... and without light levels (clli = NULL): nothing of the answer depends on the pixels then (the fast kernel's precondition rules NaNs out), so
     # the asynchronous entry point returns with its work enqueued -- calls follow each other at the device's pace, one synchronisation at the end
@@ -832,14 +864,42 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     gain_bytes = (4 + 3 + 8) * px4k  # base pixels + gain-map planes + tone-mapped pixels
     gainmap = row(ms_kernel, gain_bytes, px4k, "avifRGBImageApplyGainMap, 3840x2160 RGBA8 sRGB/BT.709 -> RGBA10 PQ/BT.2020, 8-bit 4:4:4 gain map: the apply kernel alone, which "
                   "converts the gain map's planes itself since round 5 (base pixels 4 + gain-map planes 3 + tone-mapped pixels 8 B/pixel)", kernel=kernel,
-                  whole_call={"what": "the whole call (apply with the gain map's YUV -> RGB inside, statistics back on the host: it waits for its stream), host clock, median of 7 x 20 calls; "
-                                      "algorithmic bytes base 4 + gain-map planes 3 + output 8 B/pixel",
+                  whole_call={"what": "the whole call WITH light levels (apply with the gain map's YUV -> RGB inside; since round 6 the statistics come back through a copy and a host "
+                                      "function the stream runs behind the kernel, the call returns with its work enqueued), host clock around 20 back-to-back calls and one "
+                                      "synchronisation, median of 7; algorithmic bytes base 4 + gain-map planes 3 + output 8 B/pixel",
                               "ms_per_call": round(median(calls), 5), "algorithmic_bytes_per_call": int(gain_bytes),
                               "frac": round(gain_bytes / (median(calls) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "maxCLL": int(clli.maxCLL), "maxPALL": int(clli.maxPALL)},
                   whole_call_without_light_levels={"what": "the same call with clli = NULL: no statistics to wait for, the call returns with its kernel enqueued; "
                                                            "host clock around 20 back-to-back calls and one synchronisation, median of 7",
                                                    "ms_per_call": round(median(calls_async), 5),
                                                    "frac": round(gain_bytes / (median(calls_async) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+    # avifRGBImageComputeGainMap (the encode side), device-resident (round 6: avifhipRGBImageComputeGainMapAsync): 3840x2160 RGBA8 sRGB / BT.709 base + RGBA10 PQ /
+    # BT.2020 alternate -> 8-bit 4:4:4 gain map + metadata.  The call waits for its own first passes (the metadata is a function of every pixel): host clock
+    # around back-to-back calls, median of 5 bursts of 10
+    try:
+        sys.path.insert(0, os.fspath(ROOT / "tests"))
+        import gainmap_cases as G
+
+        cc = G.ComputeCase(3840, 2160, alt_primaries=9, seed=3)
+        cbase, calt = G.make_compute_inputs(cc)
+        dcb, dca = device.DeviceRGB(cbase, upload=True), device.DeviceRGB(calt, upload=True)
+        dgm = device.DeviceYUV(abi.make_yuv(cc.w, cc.h, cc.gm_depth, cc.gm_format, cc.gm_range, cc.gm_matrix), upload=False)
+        cgm = abi.avifGainMap()
+        cgm.image = C.pointer(dgm.struct)
+        t = lib.avifhipTimeRGBImageComputeGainMap
+        if t(dcb.struct, 1, 13, dca.struct, 9, 16, C.byref(cgm), 3, 10, None) <= 0:
+            raise RuntimeError(lib.avifhipLastError().decode())
+        ms_compute = median([t(dcb.struct, 1, 13, dca.struct, 9, 16, C.byref(cgm), 1, 10, None) for _ in range(5)])
+        compute_bytes = (4 + 8 + 3) * px4k
+        gainmap["compute"] = {
+            "what": "avifhipRGBImageComputeGainMapAsync, 3840x2160 RGBA8 sRGB/BT.709 + RGBA10 PQ/BT.2020 -> 8-bit 4:4:4 gain map + metadata, everything device-resident: "
+                    "channel minima, ratios, outlier histogram, codes, RGBA -> YUV (five kernels, three waits for the host: offsets, histogram ranges, code steps), host clock "
+                    "around 10 back-to-back calls, median of 5; the kernels' own durations: profiles/r06_gainmap_compute.txt",
+            "ms_per_call": round(ms_compute, 5), "algorithmic_bytes_per_call": int(compute_bytes),
+            "achieved": round(compute_bytes / (ms_compute * 1e-3) / 1e9, 1), "frac": round(compute_bytes / (ms_compute * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "value": round(px4k / 1e6 / (ms_compute * 1e-3), 1), "unit": "megapixels/s"}
+    except Exception as exc:  # (the headline must not depend on this side row)
+        gainmap["compute"] = {"error": repr(exc)}
     return {"configs": configs, "ceilings": ceilings, "gainmap": gainmap}
 
 

@@ -50,6 +50,15 @@ def test_frames_workload_line(ranks, self_spawn):
         assert key in d
     assert {"frac", "achieved", "peak", "bound", "traffic", "cold", "kernel_ms_inputs_cache_resident"} <= set(d["roofline"])
     assert {"kernel_ms", "frac", "value"} <= set(d["fp32"]) and {"integer", "fp32"} <= set(d["planes_4k"])
+    # round 6: sequence rows beside the single-frame ones, and with more than one rank the other two multi-GPU shapes in the same line
+    assert {"frames_per_launch", "frames_cycled", "us_per_frame", "frac", "ceiling", "traffic"} <= set(d["roofline"]["cold_batched"])
+    assert {"inputs_cache_resident", "cold", "kernel"} <= set(d["integer"]["sequence"]) and "sequence" in d["planes_4k"]["integer"]
+    if ranks > 1:
+        strong = d["strong_scaling_cfg5"]
+        assert strong["n_gpus"] == ranks and strong["scaling"] == "strong" and sum(strong["config"]["tiles_per_rank"]) == 64
+        assert "in_process_host_to_host" in d  # (None in a dry run: it needs the devices)
+    else:
+        assert "strong_scaling_cfg5" not in d and "in_process_host_to_host" not in d
 
 
 @pytest.mark.parametrize("ranks", [2, 3, 8])
