@@ -849,7 +849,7 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
         for _ in range(20):
             native.check(lib.avifhipRGBImageApplyGainMapAsync(dbase.struct, 1, 13, C.byref(gm), 3.0, 9, 16, dout.struct, C.byref(clli), C.byref(diag), None),
                          "avifhipRGBImageApplyGainMapAsync")
-        native.check(lib.avifhipSynchronize(None), "avifhipSynchronize")  # (round 6: the light levels arrive with the stream -- a host function behind each kernel)
+        native.check(lib.avifhipSynchronize(None), "avifhipSynchronize")  # (round 6: the statistics travel behind each kernel; this call turns them into clli)
         calls.append((time.perf_counter() - t0) / 20 * 1e3)
     # ... and without light levels (clli = NULL): nothing of the answer depends on the pixels then (the fast kernel's precondition rules NaNs out), so
     # the asynchronous entry point returns with its work enqueued -- calls follow each other at the device's pace, one synchronisation at the end
@@ -864,8 +864,8 @@ def measured_elsewhere(lib, abi, device, native, synth, burst, frames_4k):
     gain_bytes = (4 + 3 + 8) * px4k  # base pixels + gain-map planes + tone-mapped pixels
     gainmap = row(ms_kernel, gain_bytes, px4k, "avifRGBImageApplyGainMap, 3840x2160 RGBA8 sRGB/BT.709 -> RGBA10 PQ/BT.2020, 8-bit 4:4:4 gain map: the apply kernel alone, which "
                   "converts the gain map's planes itself since round 5 (base pixels 4 + gain-map planes 3 + tone-mapped pixels 8 B/pixel)", kernel=kernel,
-                  whole_call={"what": "the whole call WITH light levels (apply with the gain map's YUV -> RGB inside; since round 6 the statistics come back through a copy and a host "
-                                      "function the stream runs behind the kernel, the call returns with its work enqueued), host clock around 20 back-to-back calls and one "
+                  whole_call={"what": "the whole call WITH light levels (apply with the gain map's YUV -> RGB inside; since round 6 the statistics travel into pinned memory behind the kernel and "
+                                      "avifhipSynchronize turns them into clli: the call returns with its work enqueued), host clock around 20 back-to-back calls and one "
                                       "synchronisation, median of 7; algorithmic bytes base 4 + gain-map planes 3 + output 8 B/pixel",
                               "ms_per_call": round(median(calls), 5), "algorithmic_bytes_per_call": int(gain_bytes),
                               "frac": round(gain_bytes / (median(calls) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "maxCLL": int(clli.maxCLL), "maxPALL": int(clli.maxPALL)},

@@ -222,8 +222,10 @@ AVIFHIP_API double avifhipTimeRGBImageApplyGainMap(const avifRGBImage * baseImag
 AVIFHIP_API void avifhipSetExactLightLevels(int on);
 /* avifhipRGBImageApplyGainMapAsync with clli != NULL (round 6): where the fast kernel serves the call (4-channel integer pixels, tables that
  * fit the LDS, no NaN possible: the usual case) the call returns with its work enqueued like every other Async entry point, and *clli is
- * filled by a host function the stream runs behind the kernel -- read it after the stream has been synchronised (avifhipSynchronize), and
- * keep it alive until then.  Every other case (and exact light levels) waits for the stream before it returns, as before. */
+ * filled by the calling thread's next avifhipSynchronize(hipStream) (the statistics travel into pinned memory behind the kernel;
+ * synchronising the stream through the HIP runtime directly does not fill it) -- keep it alive until then; at most 8 such calls per
+ * thread stay unsettled (the ninth settles the oldest, waiting for it).  Every other case (and exact light levels) waits for the stream
+ * before it returns, as before. */
 /* Gain-map computation (the encode side): drop-in for avifRGBImageComputeGainMap (reference include/avif/avif.h:1688-1722,
  * src/gainmap.c:535-843): host images in; the metadata fractions of `gainMap` and the (malloc'ed) planes of gainMap->image -- whose
  * width, height, depth, yuvFormat (range, matrix) carry the request, as in the reference -- out.  Byte-identical planes and

@@ -814,8 +814,9 @@ extern "C" avifResult avifhipSynchronize(void * hipStream)
     const avifResult cr = ensureContext();
     if (cr != AVIF_RESULT_OK)
         return cr;
-    HIP_TRY(hipStreamSynchronize(pickStream(hipStream)));
-    return AVIF_RESULT_OK;
+    hipStream_t stream = pickStream(hipStream);
+    HIP_TRY(hipStreamSynchronize(stream));
+    return settleLightLevels(stream, false, true); // (asynchronous gain-map applications that asked for light levels: their clli are filled here)
 }
 
 extern "C" avifResult avifhipExplainYUVToRGB(const avifImage * image, const avifRGBImage * rgb, char * text, size_t size)

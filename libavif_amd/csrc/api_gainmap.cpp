@@ -34,27 +34,6 @@ uint16_t lightLevelNits(float v) // src/gainmap.c:303,305
     const float r = floorf(v * 203.0f + 0.5f);
     return (uint16_t)((r < 0.0f) ? 0.0f : ((65535.0f < r) ? 65535.0f : r));
 }
-// what the stream runs behind the copy of an asynchronous call's partials (hipLaunchHostFunc: no runtime calls in here)
-struct LightLevelJob
-{
-    const GainMapPartial * partials;
-    uint32_t count;
-    size_t pixels;
-    avifContentLightLevelInformationBox * clli;
-};
-void lightLevelsFromPartials(void * user)
-{
-    LightLevelJob * job = static_cast<LightLevelJob *>(user);
-    float rgbMax = 0.0f;
-    double sum = 0.0;
-    for (uint32_t k = 0; k < job->count; ++k) {
-        rgbMax = (job->partials[k].max > rgbMax) ? job->partials[k].max : rgbMax;
-        sum += job->partials[k].sum;
-    }
-    job->clli->maxCLL = lightLevelNits(rgbMax);
-    job->clli->maxPALL = lightLevelNits((float)sum / (float)job->pixels);
-    delete job;
-}
 } // namespace
 
 namespace {
@@ -559,25 +538,23 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
     if (mayReturnEarly && applyGain && A.fast && !clli && tls.gainMapTimeIters <= 0)
         return AVIF_RESULT_OK;
     // ... and with light levels asked for, the asynchronous entry point still returns with its work enqueued: the partials travel into a pinned
-    // slot behind the kernel and a host function the stream runs behind that copy fills *clli (valid once the stream has reached that point;
-    // the fast kernel's precondition rules the NaN result out, so the result code is known now)
+    // slot behind the kernel, and the thread's next avifhipSynchronize on that stream turns them into *clli (settleLightLevels; the fast
+    // kernel's precondition rules the NaN result out, so the result code is known now)
     if (mayReturnEarly && applyGain && A.fast && clli && !exactLevels && !partialsOnHost && partials && tls.gainMapTimeIters <= 0) {
         const uint32_t slot = tls.lightSlot++ % (uint32_t)Context::kLightSlots;
         if (!tls.lightPinned[slot])
             HIP_TRY(hipHostMalloc(&tls.lightPinned[slot], (size_t)kGainMapMaxGroups * sizeof(GainMapPartial), hipHostMallocDefault));
-        if (!tls.lightRead[slot])
-            HIP_TRY(hipEventCreateWithFlags(&tls.lightRead[slot], hipEventDisableTiming));
-        if (tls.lightBusy[slot])
-            HIP_TRY(hipEventSynchronize(tls.lightRead[slot])); // (the call of kLightSlots calls ago has been read)
-        HIP_TRY(hipMemcpyAsync(tls.lightPinned[slot], A.partials, (size_t)partials * sizeof(GainMapPartial), hipMemcpyDeviceToHost, stream));
-        LightLevelJob * job = new LightLevelJob { (const GainMapPartial *)tls.lightPinned[slot], partials, (size_t)width * height, clli };
-        const hipError_t he = hipLaunchHostFunc(stream, lightLevelsFromPartials, job);
-        if (he != hipSuccess) {
-            delete job;
-            return hipFailed(he, "hipLaunchHostFunc (light levels)");
+        if (!tls.lightCopied[slot])
+            HIP_TRY(hipEventCreateWithFlags(&tls.lightCopied[slot], hipEventDisableTiming));
+        if (tls.lightPending[slot].pending) { // the call of kLightSlots calls ago has not been settled: its clli is filled now (waits for its copy)
+            const avifResult sr = settleLightLevels(nullptr, true, true);
+            if (sr != AVIF_RESULT_OK)
+                return sr;
         }
-        HIP_TRY(hipEventRecord(tls.lightRead[slot], stream));
-        tls.lightBusy[slot] = true;
+        HIP_TRY(hipMemcpyAsync(tls.lightPinned[slot], A.partials, (size_t)partials * sizeof(GainMapPartial), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(tls.lightCopied[slot], stream));
+        Context::PendingLight & P = tls.lightPending[slot];
+        P.pending = true, P.count = partials, P.pixels = (size_t)width * height, P.clli = clli, P.stream = stream;
         return AVIF_RESULT_OK;
     }
     const GainMapPartial * hostPartials = (const GainMapPartial *)tls.gainMapPartials;
@@ -1370,4 +1347,31 @@ extern "C" avifResult avifhipImageComputeGainMap(const avifImage * baseImage, co
 extern "C" void avifhipSetExactLightLevels(int on)
 {
     gExactLightLevels.store(on ? 1 : 0, std::memory_order_relaxed);
+}
+
+avifResult avifhip::api::settleLightLevels(hipStream_t stream, bool everyStream, bool wait)
+{
+    for (int k = 0; k < Context::kLightSlots; ++k) {
+        Context::PendingLight & P = tls.lightPending[k];
+        if (!P.pending || (!everyStream && P.stream != stream))
+            continue;
+        if (wait) {
+            HIP_TRY(hipEventSynchronize(tls.lightCopied[k]));
+        } else if (hipEventQuery(tls.lightCopied[k]) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
+        const GainMapPartial * partials = (const GainMapPartial *)tls.lightPinned[k];
+        float rgbMax = 0.0f;
+        double sum = 0.0;
+        for (uint32_t g = 0; g < P.count; ++g) { // (index order, like the synchronous path)
+            rgbMax = (partials[g].max > rgbMax) ? partials[g].max : rgbMax;
+            sum += partials[g].sum;
+        }
+        avifContentLightLevelInformationBox * clli = static_cast<avifContentLightLevelInformationBox *>(P.clli);
+        clli->maxCLL = lightLevelNits(rgbMax);
+        clli->maxPALL = lightLevelNits((float)sum / (float)P.pixels);
+        P.pending = false;
+    }
+    return AVIF_RESULT_OK;
 }

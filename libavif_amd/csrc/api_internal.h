@@ -129,12 +129,21 @@ struct Context
     int gainMapTimeWarmup = 0, gainMapTimeIters = 0; // avifhipTimeRGBImageApplyGainMap in progress on this thread: repeat the apply kernel
     double gainMapTimedMs = -1.0;                    // ... and what it measured
     void * gainMapPartials = nullptr; // apply: the statistics as the workgroups leave them (pinned host memory, kGainMapMaxGroups partials)
-    // ... of asynchronous calls that asked for light levels (avifhipRGBImageApplyGainMapAsync with clli): a ring of pinned slots, each read by a
-    // host function the stream runs behind the copy that fills it; the event says when a slot may be written again
-    static constexpr int kLightSlots = 4;
+    // ... of asynchronous calls that asked for light levels (avifhipRGBImageApplyGainMapAsync with clli): a ring of pinned slots, each filled by a
+    // copy behind the kernel (the event says when) and turned into the caller's clli by the thread's next avifhipSynchronize on that stream
+    // (api.cpp settleLightLevels; a host function on the stream cost 30 us per call)
+    static constexpr int kLightSlots = 8;
+    struct PendingLight
+    {
+        bool pending = false;
+        uint32_t count = 0;   // partials in the slot
+        size_t pixels = 0;
+        void * clli = nullptr; // avifContentLightLevelInformationBox * of the caller
+        hipStream_t stream = nullptr;
+    };
     void * lightPinned[kLightSlots] = {};
-    hipEvent_t lightRead[kLightSlots] = {};
-    bool lightBusy[kLightSlots] = {};
+    hipEvent_t lightCopied[kLightSlots] = {};
+    PendingLight lightPending[kLightSlots];
     uint32_t lightSlot = 0;
     // batch descriptor tables travel through a ring of kTableRing slots (pinned host memory + the matching slice of `table`), uploaded on
     // `upStream`: the host prepares batch n + 1 and its table crosses the link while batch n computes (api_batch.cpp: batchAsyncImpl)
@@ -207,10 +216,10 @@ struct Context
                 (void)hipFree(g.ptr);
         if (gainMapPartials)
             (void)hipHostFree(gainMapPartials);
-        for (int k = 0; k < kLightSlots; ++k) {
-            if (lightRead[k]) {
-                (void)hipEventSynchronize(lightRead[k]);
-                (void)hipEventDestroy(lightRead[k]);
+        for (int k = 0; k < kLightSlots; ++k) { // (pending light levels of a thread that ends without synchronising are dropped: its clli may be gone)
+            if (lightCopied[k]) {
+                (void)hipEventSynchronize(lightCopied[k]);
+                (void)hipEventDestroy(lightCopied[k]);
             }
             if (lightPinned[k])
                 (void)hipHostFree(lightPinned[k]);
@@ -342,6 +351,9 @@ extern std::atomic<uint32_t> gTuning;
 int effectiveArithmetic();
 // launches of the planned conversions on `stream` (tiled kernels where the plan allows, the universal kernel otherwise)
 avifResult enqueueYuvToRgb(const YuvToRgbPlan & plan, hipStream_t stream);
+// fills the clli of the calling thread's asynchronous gain-map applications whose copies have arrived (`stream`: only that stream's; nullptr:
+// every stream's), waiting for them when `wait` (api_gainmap.cpp)
+avifResult settleLightLevels(hipStream_t stream, bool everyStream, bool wait);
 avifResult enqueueRgbToYuv(const RgbToYuvPlan & plan, hipStream_t stream);
 avifResult enqueueAlphaMul(const AlphaMulPlan & plan, hipStream_t stream);
 void finishRgbToYuvPlan(const avifImage * image, const avifRGBImage * rgb, RgbToYuvPlan * plan);

@@ -7,6 +7,11 @@
 
 #include "tile_shared.h"
 
+// waves of a workgroup of the wave-private kernels (measurement builds may change it: tests/tools/seqbench.hip)
+#ifndef AVIFHIP_PK_WAVES
+#define AVIFHIP_PK_WAVES 4
+#endif
+
 namespace avifhip {
 namespace tile {
 
@@ -92,7 +97,7 @@ struct PkPlace
 __attribute__((always_inline)) constexpr PkPlace pkPlaceOf(uint32_t tile, uint32_t wave, const PkGeom & g, uint32_t ns)
 {
     const uint32_t wx = wave & ((1u << g.wavesXLog2) - 1u), wy = wave >> g.wavesXLog2;
-    const uint32_t wavesY = 4u >> g.wavesXLog2;
+    const uint32_t wavesY = (uint32_t)AVIFHIP_PK_WAVES >> g.wavesXLog2;
     uint32_t trow = 0, tcol = 0;
     if (g.columnMajor) {
         tcol = g.magicTilesY ? mulHi32(tile, g.magicTilesY) : tile, trow = tile - tcol * g.tilesY;
@@ -149,7 +154,7 @@ inline void pkGeometry(const TileLaunch & L, uint32_t w4, uint32_t h2, uint32_t 
     uint32_t wxl = L.wavesXLog2 <= 2 ? L.wavesXLog2 : 2;
     while (wxl > 0 && (1u << wxl) > bands)
         --wxl;
-    const uint32_t wavesX = 1u << wxl, wavesY = 4u / wavesX;
+    const uint32_t wavesX = 1u << wxl, wavesY = (uint32_t)AVIFHIP_PK_WAVES / wavesX;
     g->wavesXLog2 = wxl;
     g->tilesX = (bands + wavesX - 1) / wavesX;
     const uint32_t shift = L.shiftStrips - L.shiftStrips % ns; // whole waves

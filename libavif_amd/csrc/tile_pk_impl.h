@@ -802,7 +802,7 @@ struct PkLds
     static constexpr int kRingWordsRaw = (BIL && (SUB == SUB_420 || SUB == SUB_422)) ? PkStage<SUB, NSW>::kRows * kPkPitch : 1;
     static constexpr int kRingWords = (NCH == 3 && !MAPPED) ? ((kRingWordsRaw + 3) & ~3) : kRingWordsRaw;
     static constexpr int kXposeWords = MAPPED ? 8 * NSW * 256 : 0; // quarter turns: the workgroup's tile, overlaying the chroma blocks
-    static constexpr int kPlain = kWavesPerBlock * kRingWords + ((NCH == 3 && !MAPPED) ? kWavesPerBlock * (int)(sizeof(WideRowExchange) / 4) : 0);
+    static constexpr int kPlain = AVIFHIP_PK_WAVES * kRingWords + ((NCH == 3 && !MAPPED) ? AVIFHIP_PK_WAVES * (int)(sizeof(WideRowExchange) / 4) : 0);
     static constexpr int kWords = kPlain > kXposeWords ? kPlain : kXposeWords;
 };
 
@@ -824,7 +824,7 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     }
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.y);
     const PkPlace place = pkPlaceOf(tile, wave, g, (uint32_t)NSW);
-    const uint32_t wy = wave >> g.wavesXLog2, wavesY = 4u >> g.wavesXLog2; // the wave's row among the workgroup's stacked waves
+    const uint32_t wy = wave >> g.wavesXLog2, wavesY = (uint32_t)AVIFHIP_PK_WAVES >> g.wavesXLog2; // the wave's row among the workgroup's stacked waves
     PkSpot w;
     w.band = place.band;
     w.strip0 = place.strip0;
@@ -846,7 +846,7 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
     w.slotMax = (shared && wy + 1 < wavesY) ? NSW : PkStage<SUB, NSW>::kRows - 1;
     unsigned * ring = shared ? lds + wy * (uint32_t)(NSW * kPkPitch) : lds + wave * (uint32_t)kRingWords;
     // 3-byte pixels, stored as rows: one exchange buffer per wave behind the chroma blocks
-    WideRowExchange * xchg = (NCH == 3 && !MAPPED) ? reinterpret_cast<WideRowExchange *>(lds + kWavesPerBlock * PkLds<SUB, BIL, NCH, NSW, MAPPED>::kRingWords) + wave : nullptr;
+    WideRowExchange * xchg = (NCH == 3 && !MAPPED) ? reinterpret_cast<WideRowExchange *>(lds + AVIFHIP_PK_WAVES * PkLds<SUB, BIL, NCH, NSW, MAPPED>::kRingWords) + wave : nullptr;
     RawT raw;
     pkLoad<SUB, BIL, APLANE, NSW, WIDE, STREAM>(A, w, raw);
     pkStage<SUB, BIL, APLANE, NSW, WIDE>(A, w, shared, raw, ring);
@@ -859,7 +859,7 @@ __device__ __forceinline__ void pkRunBlock(const TileArgs & A, const PkGeom & g,
 // (STREAM = false for single images: their planes are assumed cache-resident -- just decoded / uploaded / produced; sequence launches whose
 //  bytes exceed the Infinity Cache take streaming luma / alpha loads, launchPkMapped)
 template <int SUB, bool BIL, int NCH, bool APLANE, int NSW, bool MAPPED, int WIDE, bool STREAM = false>
-__global__ __launch_bounds__(256) void yuvToRgbPkKernel(TileArgs A, PkGeom g, SeqFrames S)
+__global__ __launch_bounds__(64 * AVIFHIP_PK_WAVES) void yuvToRgbPkKernel(TileArgs A, PkGeom g, SeqFrames S)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned lds[]; // PkLds<...>::kPlain words, or kWords for quarter turns (launchPkMapped)
     pkRunBlock<SUB, BIL, NCH, APLANE, NSW, MAPPED, WIDE, STREAM>(seqJob(A, S), g, lds, pkTileOf(blockIdx.x, g));

@@ -370,7 +370,7 @@ def test_gpu_device_resident(hip_auto_arithmetic):
                                                                  c.out_tc, dout.struct, C.byref(clli), C.byref(diag), None)
         assert ra == rb, (c.ident(), ra, rb, diag.error)
         if ra == 0:
-            # (round 6: the light levels of an asynchronous call arrive with the stream -- a host function behind the kernel fills them)
+            # (round 6: the light levels of an asynchronous call are filled by the next avifhipSynchronize on its stream)
             assert hip_auto_arithmetic.avifhipSynchronize(None) == 0
             dout.download_into_host()
             wb = c.w * abi.rgb_pixel_size(c.out_format, c.out_depth)

@@ -366,7 +366,7 @@ def run(name):
             grid = native.avifhipGrid(rows, cols, ow, oh)
             best = host_clock(lambda: native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None)))
             px, bpp, ms = ow * oh, (11.0 if rgb_depth == 10 else (7.0 if depth == 10 else 5.5)), best
-        elif name in ("gainmap4k", "gainmap4k_half", "gainmap4k_cpu", "gainmap4k_rgb"):
+        elif name in ("gainmap4k", "gainmap4k_half", "gainmap4k_cpu", "gainmap4k_rgb", "gainmap4k_photo"):
             # avifRGBImageApplyGainMap: 3840x2160 RGBA8 sRGB BT.709 base -> RGBA10 PQ BT.2020 HDR rendition, 8-bit 4:4:4 gain map of the
             # same size (or 4:2:0 at half size, rescaled on the device first).  Algorithmic bytes: base 4 + gain-map planes + output 8.
             CLOCK = "host"
@@ -382,6 +382,18 @@ def run(name):
             gimg = abi.make_yuv(w // 2 if half else w, h // 2 if half else h, 8, abi.AVIF_PIXEL_FORMAT_YUV420 if half else abi.AVIF_PIXEL_FORMAT_YUV444,
                                 abi.AVIF_RANGE_FULL, 6)
             synth.fill_yuv(gimg, 0x99)
+            if name == "gainmap4k_photo":
+                # what a photograph looks like to the table gathers: neighbouring pixels hold neighbouring codes (a smooth ramp across the frame with two
+                # codes of noise) -- the lanes of a wave read a handful of table entries, not 64 random ones (round 6: the LDS bank-conflict counters)
+                rng = np.random.default_rng(7)
+                yy, xx = np.mgrid[0:h, 0:w]
+                ramp = ((xx * 200 // w + yy * 55 // h) % 256).astype(np.int32)
+                ch = base.channels()
+                for k in range(3):
+                    ch[:, :, k] = np.clip(ramp + 10 * k + rng.integers(-2, 3, size=ramp.shape), 0, 255).astype(np.uint8)
+                ch[:, :, 3] = 255
+                for pl in range(3):
+                    gimg.planes[pl][:h, :w] = np.clip(128 + ramp // 4 + rng.integers(-1, 2, size=ramp.shape), 0, 255).astype(np.uint8)
             gm = abi.avifGainMap()
             for i in range(3):
                 gm.gainMapMin[i].n, gm.gainMapMin[i].d = 0, 1

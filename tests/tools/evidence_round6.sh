@@ -1,0 +1,45 @@
+#!/bin/bash
+# evidence_round6.sh [tag] -- round 6's committed figures from ONE box (run via gpurun; everything lands in gpurun_out/, copy what is to be judged into profiles/):
+#   <tag>_bench_*                bench.py --headline-only under rocprofv3 --kernel-trace --stats, the HBM-traffic passes, the SQ counter passes (profile_round.sh)
+#   <tag>_bench_line_*.json      bench.py as the driver runs it (default flags; --steps 20 --warmup 5), and with every multi-GPU block on a one-GPU box
+#   <tag>_sequence.txt / .json   sequence launches and their one-frame-per-launch twins in the HBM regime: HIP events, rocprofv3 averages, FETCH / WRITE traffic (seq_evidence.sh)
+#   <tag>_cfgs_*                 cfg_bench.py configurations, each run once under rocprofv3 (event-timed row and profiler average from the same launches)
+#   <tag>_gainmap_compute.txt    the gain-map computation's kernels (device-resident call), <tag>_gainmap_pmc.txt the apply kernel's counters
+#   <tag>_tsan.txt               the concurrency stress under ThreadSanitizer / AddressSanitizer (sanitizer_run.sh)
+#   <tag>_fault_regression.txt   farm -> gain maps -> farm, the two files of round 5's fault in the order that died, 20 fresh processes
+set -u
+TAG=${1:-r06}
+R=$PWD
+mkdir -p gpurun_out
+bash tests/tools/profile_round.sh "$TAG" > "gpurun_out/${TAG}_profile_round.log" 2>&1
+python bench.py > "gpurun_out/${TAG}_bench_line_default_run.json" 2> "gpurun_out/${TAG}_bench_default.err"
+python bench.py --steps 20 --warmup 5 > "gpurun_out/${TAG}_bench_line_driver_flags.json" 2>> "gpurun_out/${TAG}_bench_default.err"
+AVIFHIP_BENCH_ALL_BLOCKS=1 AVIFHIP_BENCH_DEVICES=0,0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "gpurun_out/${TAG}_bench_line_all_blocks_one_gpu.json" 2>> "gpurun_out/${TAG}_bench_default.err"
+bash tests/tools/seq_evidence.sh "$TAG" > "gpurun_out/${TAG}_seq_evidence.log" 2>&1
+CFGS="cfg2 cfg2_4k cfg2n cfg2_alpha cfg2_premul cfg3 cfg4 cfg4rgb cfg4_8k cfg5 cfg5x64 cfg5x64_8 cfg5grid cfg5grid_8 photo_grid f16_444a ident8 gray8 tail90 scale_box4 scale_down_1_5 gainmap4k gainmap4k_photo gainmap4k_half gmcompute4k gmcompute4k_dev"
+bash tests/tools/profile_cfgs.sh "$TAG" $CFGS > "gpurun_out/${TAG}_profile_cfgs.log" 2>&1
+for c in $CFGS; do cat "gpurun_out/${TAG}_cfgs/$c.jsonl" 2>/dev/null | grep '^{' ; done > "gpurun_out/${TAG}_cfgs_bench.jsonl"
+python - "$TAG" > "gpurun_out/${TAG}_gainmap_compute.txt" <<'PY'
+import sys
+tag = sys.argv[1]
+keep, out = False, []
+for line in open(f"gpurun_out/{tag}_cfgs_kernel_stats.txt"):
+    if line.startswith("== "):
+        keep = line.split()[1] in ("gmcompute4k", "gmcompute4k_dev", "gainmap4k", "gainmap4k_half")
+    if keep or line.startswith("rocprofv3"):
+        out.append(line)
+sys.stdout.write("".join(out))
+PY
+bash tests/tools/pmc_cfg.sh "${TAG}_gainmap" gainmap4k > "gpurun_out/${TAG}_gainmap_pmc.log" 2>&1
+cp "gpurun_out/${TAG}_gainmap/digest_pmc.txt" "gpurun_out/${TAG}_gainmap_pmc.txt" 2>/dev/null
+# ... and on a photograph-like pair (neighbouring pixels hold neighbouring codes): what the table gathers' bank conflicts are on real images
+bash tests/tools/pmc_cfg.sh "${TAG}_gainmap_photo" gainmap4k_photo > "gpurun_out/${TAG}_gainmap_photo_pmc.log" 2>&1
+cp "gpurun_out/${TAG}_gainmap_photo/digest_pmc.txt" "gpurun_out/${TAG}_gainmap_photo_pmc.txt" 2>/dev/null
+bash tests/tools/sanitizer_run.sh "$TAG" 10 > /dev/null 2>&1
+{ echo "== pytest tests/test_gpu_device_farm.py tests/test_gainmap.py -m gpu (the order that died in round 5), 20 fresh processes, scratch poisoned =="
+  for k in $(seq 1 20); do
+    timeout 300 python -m pytest tests/test_gpu_device_farm.py tests/test_gainmap.py -m gpu -q -p no:cacheprovider 2>&1 | tail -1 | sed "s/^/run $k: /"
+  done; } > "gpurun_out/${TAG}_fault_regression.txt" 2>&1
+python tests/tools/e2e_bench.py > "gpurun_out/${TAG}_e2e.jsonl" 2> "gpurun_out/${TAG}_e2e.err"
+rm -rf "gpurun_out/${TAG}_cfgs" "gpurun_out/$TAG" "gpurun_out/${TAG}_gainmap" "gpurun_out/${TAG}_gainmap_photo"
+ls -la gpurun_out | tail -30

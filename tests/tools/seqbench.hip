@@ -67,7 +67,7 @@ int main(int argc, char ** argv)
     uint32_t nsw, blocks; PkGeom g;
     pkGeometry(L, W, H, &nsw, &g, &blocks, true);
     if (nsw != SQB_NSW) { printf("geometry chose %u strips\n", nsw); return 1; }
-    const dim3 block(kLanesX, kWavesPerBlock), grid(blocks, 1, F);
+    const dim3 block(kLanesX, AVIFHIP_PK_WAVES), grid(blocks, 1, F);
     const uint32_t ldsBytes = 4u * (uint32_t)PkLds<SUB_420, true, 4, SQB_NSW, false>::kPlain;
     SeqFrames S[NB];
     for (int k = 0; k < NB; ++k)
