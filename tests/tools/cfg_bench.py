@@ -109,6 +109,18 @@ def time_y2r_two_frames(pair, iters=20):
     return settled(lambda: lib.avifhipTimeYUVToRGBCycle(2, imgs, rgbs, 4, iters, None))
 
 
+def time_y2r_cycle(pairs, per=1, iters=40):
+    """`len(pairs)` frames cycled, `per` frames per launch (1: avifhipImageYUVToRGBAsync; more: a sequence launch): ms per FRAME -- bench.py's own regimes"""
+    n = len(pairs)
+    imgs = (C.POINTER(abi.avifImage) * n)(*[C.pointer(q[0].struct) for q in pairs])
+    rgbs = (C.POINTER(abi.avifRGBImage) * n)(*[C.pointer(q[1].struct) for q in pairs])
+    if per == 1:
+        preheat(lambda k: lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 0, k, None))
+        return settled(lambda: lib.avifhipTimeYUVToRGBCycle(n, imgs, rgbs, 4, iters, None))
+    preheat(lambda k: lib.avifhipTimeYUVToRGBBatchCycle(n, imgs, rgbs, per, 0, max(1, k // per), None) / per)
+    return settled(lambda: lib.avifhipTimeYUVToRGBBatchCycle(n, imgs, rgbs, per, 2, iters, None)) / per
+
+
 def run(name):
     global CLOCK
     out = []
@@ -178,8 +190,18 @@ def run(name):
             # 3-byte pixels (what avifdec hands to its JPEG / opaque PNG writers): 8K 8-bit 4:2:0 -> RGB8, bilinear, 1.5 + 3 B/px
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB)
             px, bpp, ms = 7680 * 4320, 4.5, time_y2r(pair)
-        elif name in ("cfg2", "cfg2n", "cfg2_4k"):
-            w, h = (3840, 2160) if name == "cfg2_4k" else (7680, 4320)  # the north star asks for 4K planes beside the 8K headline
+        elif name in ("cfg2_4k", "cfg2_4k_seq", "cfg2_4k_cold", "cfg2_4k_seq_cold", "cfg2_seq", "cfg2_seq_cold", "cfg2_cold"):
+            # bench.py's regimes (round 6: the table's 4K row relaunched ONE frame -- 45.6 MB, pixels included, all of it cache-resident: 8.2 us --
+            # where bench.py cycles four -- 9.0 us; same kernel, different regime, now the same measurement): frames cycled x frames per launch
+            w, h = (3840, 2160) if "4k" in name else (7680, 4320)
+            frames = (24 if "4k" in name else 12) if name.endswith("cold") else 4
+            per = 4 if "_seq" in name else 1
+            pairs = [y2r(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, avoid=avoid, seed=0x12345678 + k % 4) for k in range(frames)]
+            px, bpp, ms = w * h, 5.5, time_y2r_cycle(pairs, per)
+            extra["frames_cycled"], extra["frames_per_launch"] = frames, per
+            extra["regime"] = "HBM (nothing cache-resident)" if name.endswith("cold") else "planes L3-resident"
+        elif name in ("cfg2", "cfg2n"):
+            w, h = 7680, 4320
             pair = y2r(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR if name == "cfg2n" else BIL, avoid=avoid)
             px, bpp, ms = w * h, 5.5, time_y2r(pair)
         elif name in ("cfg2_unpremul", "cfg3_unpremul"):
@@ -221,6 +243,25 @@ def run(name):
             px, bpp = w * h, (8.0 if name in ("ident8_enc", "cfg4_ycgco_8k") else (6.5 if fmt == abi.AVIF_RGB_FORMAT_RGBA else 4.5))
             preheat(lambda n: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 0, n, None))
             ms = settled(lambda: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 4, 100, None))
+        elif name in ("cfg4_cycled", "cfg4_seq"):
+            # cfg4 as bench.py measures it: 8 frames cycled (431 MB: it streams), one frame per launch or four (avifhipImageRGBToYUVBatchAsync, round 6)
+            enc = []
+            for k in range(8):
+                rgb = abi.make_rgb(3840, 2160, 8, abi.AVIF_RGB_FORMAT_RGBA, avoid_libyuv=avoid)
+                synth.fill_rgb(rgb, 0x12345678 + k % 2, opaque=True)
+                img = abi.make_yuv(3840, 2160, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, with_alpha=True)
+                enc.append((device.DeviceYUV(img, upload=False), device.DeviceRGB(rgb, upload=True)))
+            imgs = (C.POINTER(abi.avifImage) * 8)(*[C.pointer(q[0].struct) for q in enc])
+            rgbs = (C.POINTER(abi.avifRGBImage) * 8)(*[C.pointer(q[1].struct) for q in enc])
+            per = 4 if name == "cfg4_seq" else 1
+            if per == 1:
+                preheat(lambda n: lib.avifhipTimeRGBToYUVCycle(8, imgs, rgbs, 0, n, None))
+                ms = settled(lambda: lib.avifhipTimeRGBToYUVCycle(8, imgs, rgbs, 4, 100, None))
+            else:
+                preheat(lambda n: lib.avifhipTimeRGBToYUVBatchCycle(8, imgs, rgbs, per, 0, max(1, n // per), None) / per)
+                ms = settled(lambda: lib.avifhipTimeRGBToYUVBatchCycle(8, imgs, rgbs, per, 2, 40, None)) / per
+            px, bpp = 3840 * 2160, 6.5
+            extra["frames_cycled"], extra["frames_per_launch"], extra["regime"] = 8, per, "HBM (431 MB cycled)"
         elif name in ("gray_enc_8k", "graya_enc_8k"):
             # gray sources of the encode direction (a grayscale PNG through avifenc): 8K GRAY8 -> 4:0:0 luma (1 + 1 B/px); GRAYA8 -> luma + alpha (2 + 2 B/px)
             if arith == "integer":

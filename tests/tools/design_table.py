@@ -9,7 +9,17 @@ ROOT = Path(__file__).resolve().parents[2]
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 DESC = {
     "cfg2": "cfg2: 8K 8-bit 4:2:0 BT.709 limited → RGBA8 bilinear (4 frames cycled)",
-    "cfg2_4k": "cfg2 at 4K (3840 × 2160; the north star's second plane size)",
+    "cfg2_4k": "cfg2 at 4K (3840 × 2160; the north star's second plane size), 4 frames cycled (L3-resident planes)",
+    "cfg2_cold": "cfg2, 12 frames cycled (HBM regime), one frame per launch",
+    "cfg2_seq": "cfg2 as a sequence: 4 frames per launch, 4 cycled (L3-resident planes)",
+    "cfg2_seq_cold": "cfg2 as a sequence: 4 frames per launch, 12 cycled (HBM regime)",
+    "cfg2_4k_seq": "4K as a sequence: 4 frames per launch, 4 cycled (L3-resident planes)",
+    "cfg2_4k_cold": "4K, 24 frames cycled (HBM regime), one frame per launch",
+    "cfg2_4k_seq_cold": "4K as a sequence: 4 frames per launch, 24 cycled (HBM regime)",
+    "cfg4_cycled": "cfg4, 8 frames cycled (HBM regime), one frame per launch",
+    "cfg4_seq": "cfg4 as a sequence: 4 frames per launch (avifhipImageRGBToYUVBatchAsync), 8 cycled (HBM regime)",
+    "gainmap4k_photo": "gain-map application on a photograph-like pair (neighbouring pixels hold neighbouring codes)",
+    "gmcompute4k_dev": "gain-map computation, device-resident (avifhipRGBImageComputeGainMapAsync), per call",
     "cfg2n": "cfg2 with nearest upsampling",
     "cfg2_rgb": "cfg2 → RGB8 (3-byte pixels)",
     "cfg2_565": "cfg2 → RGB565, nearest (Android bitmaps)",
@@ -91,9 +101,10 @@ print("| config | arithmetic | kernel | µs: HIP events or wall clock per call (
 print("|---|---|---|---|---|")
 for r in rows:
     ks = B[r["config"]]
-    closest = min((a for _, _, a in ks), key=lambda a: abs(a - r["us"]))
+    per = r.get("frames_per_launch", 1)  # sequence rows: `us` is per FRAME, the profiler's average per launch of `per` frames
+    closest = min((a for _, _, a in ks), key=lambda a: abs(a - r["us"] * per)) / per
     if r["clock"] == "events" or len(ks) == 1 or abs(closest - r["us"]) / closest < 0.06:
-        prof = f"{closest:.1f}"
+        prof = f"{closest:.1f}" + (f" = {closest * per:.1f} per launch of {per}" if per > 1 else "")
     else:
         most = max(c for _, c, _ in ks)
         prof = " + ".join(f"{a:.1f}" for _, c, a in ks if 2 * c >= most)
