@@ -191,15 +191,18 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
     const YuvSide & s = p.yuv;
     const RgbSide & o = p.rgb;
     if (p.arith == ARITH_LIBYUV) {
-        // fixed-point kernels (tile_fx_impl.h): the only post-pass they carry is libyuv's own attenuate / unattenuate
-        if (p.postMul != MUL_NONE && !p.postMulFx)
+        // fixed-point kernels (tile_fx_impl.h): the post-pass is libyuv's own attenuate / unattenuate, or -- ARGB / ABGR, which libyuv does not
+        // attenuate -- the reference's fp32 form over libyuv's bytes (4-channel 8-bit pixels, rows: the fp32 form lives in the 32-bit kernels)
+        if (p.postMul != MUL_NONE && !p.postMulFx && (!o.hasAlpha || o.chanBytes != 1 || o.map.on || o.is565))
             return false;
         if ((s.hasColor != 0) != (s.format != AVIF_PIXEL_FORMAT_YUV400))
             return false;
         if (p.fxAlpha == FXA_FLOAT && s.depth != o.depth && !s.exactDiv)
             return false;
     } else {
-        if (p.postMulFx)
+        // libyuv's attenuate over the fp32 loops' bytes (8-bit RGBA / BGRA whose conversion libyuv has no entry for): the post-pass of the fp32
+        // tiles in libyuv's arithmetic (rows, no pixel map)
+        if (p.postMulFx && (o.chanBytes != 1 || !o.hasAlpha || o.map.on || o.is565 || p.postMul == MUL_NONE))
             return false;
         if (p.identityCopy) {
             // lossless RGB in 8-bit 4:4:4 planes: a byte shuffle inside the 4:4:4 kernel (no arithmetic, no divisors to verify) ...

@@ -247,7 +247,12 @@ __device__ __forceinline__ void computeTileFx(const TileArgs & A, const BandCtx 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         unsigned x = X4[i] >> 8, g = G4[i] >> 8, z = Z4[i] >> 8;
-                        if (A.postMul == MUL_MULTIPLY) { // ARGBAttenuate / ARGBUnattenuate (tileYuvToRgbSupported admits no other post-pass)
+                        if (!A.postMulFx) {
+                            // (wave-uniform) ARGB / ABGR: libyuv attenuates RGBA / BGRA only, so the reference runs its own fp32 post-pass over
+                            // libyuv's bytes (src/alpha.c:171-246, 358-430)
+                            x = alphaMulInt(x & 0xffu, a[i], 255u, 255.0f, A.postMul), g = alphaMulInt(g & 0xffu, a[i], 255u, 255.0f, A.postMul);
+                            z = alphaMulInt(z & 0xffu, a[i], 255u, 255.0f, A.postMul);
+                        } else if (A.postMul == MUL_MULTIPLY) { // ARGBAttenuate / ARGBUnattenuate
                             x = fxAttenuate(x, a[i]), g = fxAttenuate(g, a[i]), z = fxAttenuate(z, a[i]);
                         } else if (A.postMul == MUL_UNMULTIPLY) {
                             const unsigned ia = fxUnattenuateReciprocal(a[i]); // once per pixel, no integer division

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include "exactdiv.h"
+#include "pixel_fixed.h"
 #include "pixel_math.h"
 #include "tile_geom.h"
 #include "tile_map_impl.h"
@@ -1441,7 +1442,13 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                     q[i].g = quantizeSat(g[i], A.rgbMaxF, A.rgbMax);
                     q[i].b = quantizeSat(br[i].y, A.rgbMaxF, A.rgbMax);
                 }
-                if (postMode == MUL_MULTIPLY) {
+                if (sizeof(RT) == 1 && A.postMulFx) {
+                    // (wave-uniform) a libyuv build runs libyuv's ARGBAttenuate / ARGBUnattenuate over 8-bit RGBA / BGRA pixels whoever converted them
+                    // (src/alpha.c:163,350): here over the fp32 loops' bytes -- sources libyuv has no entry for
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        q[i].r = fxAlphaMul(q[i].r, a[i], postMode), q[i].g = fxAlphaMul(q[i].g, a[i], postMode), q[i].b = fxAlphaMul(q[i].b, a[i], postMode);
+                } else if (postMode == MUL_MULTIPLY) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const PostAlpha P = postAlpha<false>(A, a[i]);

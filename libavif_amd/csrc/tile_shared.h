@@ -64,6 +64,9 @@ struct TileArgs
     int32_t alphaKeep;
     float f16Mul;                        // half-float outputs (avifRGBImageToF16, src/reformat.c:1419-1443): the subnormal-trick multiplier, 0 = integer output
     int32_t inLoopMul, postMul;          // MulMode
+    // which arithmetic the integer post-pass runs in (plan.h postMulFx): libyuv's ARGBAttenuate / ARGBUnattenuate, or the reference's own
+    // fp32 form (src/alpha.c).  The two mix in a libyuv build: libyuv attenuates RGBA / BGRA only, whatever converted the pixels
+    int32_t postMulFx;
     int32_t identityCopy;                // 8-bit full-range identity matrix: bytes are copied (src/reformat.c:1278-1309)
     int32_t identityMatrix;              // identity matrix otherwise: the planes are G, B, R on luma's scale (biasUV / rcpRangeUV hold luma's)
     // YCgCo (1: three adds on the normalised samples, src/reformat.c:853-858) and YCgCo-Re / -Ro (2: integer lifting from the luma code and
@@ -187,7 +190,7 @@ inline TileArgs distillArgs(const YuvToRgbPlan & p)
         A.a = A.y, A.aPitch = A.yPitch;
     }
     A.f16Mul = o.isFloat ? o.f16Multiplier : 0.0f;
-    A.inLoopMul = p.inLoopMul, A.postMul = p.postMul;
+    A.inLoopMul = p.inLoopMul, A.postMul = p.postMul, A.postMulFx = p.postMulFx;
     // (the 8-bit copy with an integer alpha (un)multiply behind it: the identity transform as arithmetic, which reproduces every code, then the
     //  post-pass of the kernels that carry alpha arithmetic -- the byte shuffle lives in the kernels without)
     const bool copyThenMul = p.identityCopy && p.postMul != MUL_NONE;

@@ -85,13 +85,13 @@ def test_fp32_tiles_at_every_launch_geometry(hip):
 def test_universal_kernels_serve_only_the_enumerated_rest(hip):
     """What still reaches the one-lane-per-pixel kernels once a conversion fills the tiled kernels' 4 x 2 pixel groups (DESIGN.md 7;
     tests/tools/list_generic.py prints the census: 18 of 1089 conversions of this sweep in the fp32 arithmetic, 28 in the default one): RGB565
-    outside what its two tiled routes cover (alpha arithmetic pending, matrices off the verified divisor list, padded rows of 2-byte
-    pixels), and -- in the integer arithmetic only -- destinations whose alpha libyuv cannot serve: `ignoreAlpha` on a format with alpha
-    (libyuv writes 255, the reference then leaves the channel alone) and a pending alpha (un)multiply that mixes the two arithmetics: on
-    ARGB / ABGR libyuv attenuates nothing (RGBA / BGRA only), so the reference runs its fp32 post-pass over libyuv's bytes; on RGBA / BGRA
-    converted by the fp32 loops (sources libyuv has no entry for: 10- / 12-bit 4:0:0, matrices it lacks) the reference runs libyuv's
-    ARGBAttenuate / ARGBUnattenuate over fp32's bytes (`postMulFx`; found by `--seed-rotation 1`: the committed seeds never drew one at a tiled
-    size).  Anything else through a universal kernel fails here."""
+    outside what its two tiled routes cover (alpha arithmetic pending, matrices off the verified divisor list, rows of 2-byte pixels whose
+    pitch is no multiple of 8 bytes).  Until round 6 the integer arithmetic added the pending alpha (un)multiplies that mix the two
+    arithmetics: on ARGB / ABGR libyuv attenuates nothing (RGBA / BGRA only), so the reference runs its fp32 post-pass over libyuv's bytes;
+    on RGBA / BGRA converted by the fp32 loops (sources libyuv has no entry for: 10- / 12-bit 4:0:0, matrices it lacks) the reference runs
+    libyuv's ARGBAttenuate / ARGBUnattenuate over fp32's bytes (`postMulFx`; found by `--seed-rotation 1`).  Both post-passes now run in the
+    tiled kernels of the arithmetic that converted the pixels (tile_fx_impl.h / tile_impl.h).  Anything but RGB565 through a universal kernel
+    fails here."""
     from dataclasses import replace
     try:
         for arith, avoid in ((1, True), (0, False)):
@@ -109,11 +109,7 @@ def test_universal_kernels_serve_only_the_enumerated_rest(hip):
                     generic.append(c)
             assert total > 900 and len(generic) <= 0.05 * total, (len(generic), total)  # (18-28 with the committed seeds; up to 44 of 1093 over four rotations)
             for c in generic:
-                is565 = c.rgb_format == abi.AVIF_RGB_FORMAT_RGB_565
-                alpha_first = c.rgb_format in (abi.AVIF_RGB_FORMAT_ARGB, abi.AVIF_RGB_FORMAT_ABGR)
-                pending = c.alpha and c.image_premultiplied != c.rgb_premultiplied
-                integer_only = arith == 0 and ((c.ignore_alpha and abi.rgb_format_has_alpha(c.rgb_format)) or pending)
-                assert is565 or integer_only, (arith, c.ident())
+                assert c.rgb_format == abi.AVIF_RGB_FORMAT_RGB_565, (arith, c.ident())
     finally:
         hip.avifhipSetArithmetic(1)
 

@@ -407,7 +407,7 @@ def run(name):
             grid = native.avifhipGrid(rows, cols, ow, oh)
             best = host_clock(lambda: native.check(lib.avifhipGridYUVToRGBAsync(C.byref(grid), imgs, None, 0, drgb.struct, None)))
             px, bpp, ms = ow * oh, (11.0 if rgb_depth == 10 else (7.0 if depth == 10 else 5.5)), best
-        elif name in ("gainmap4k", "gainmap4k_half", "gainmap4k_cpu", "gainmap4k_rgb", "gainmap4k_photo"):
+        elif name in ("gainmap4k", "gainmap4k_half", "gainmap4k_cpu", "gainmap4k_rgb", "gainmap4k_photo", "gainmap4k_same"):
             # avifRGBImageApplyGainMap: 3840x2160 RGBA8 sRGB BT.709 base -> RGBA10 PQ BT.2020 HDR rendition, 8-bit 4:4:4 gain map of the
             # same size (or 4:2:0 at half size, rescaled on the device first).  Algorithmic bytes: base 4 + gain-map planes + output 8.
             CLOCK = "host"
@@ -463,7 +463,9 @@ def run(name):
                 gm.image = C.pointer(dgimg.struct)
                 tone = abi.make_rgb(w, h, 10, gm_fmt, avoid_libyuv=False, allocate=False)
                 dout = device.DeviceRGB(tone)
-                call = lambda: native.check(lib.avifhipRGBImageApplyGainMapAsync(dbase.struct, 1, 13, C.byref(gm), 3.0, 9, 16, dout.struct, C.byref(clli),
+                # (_same: the output keeps the base image's primaries -- no fp64 matrix per pixel, src/gainmap.c:263-266: what the kernel costs without it)
+                out_primaries = 1 if name == "gainmap4k_same" else 9
+                call = lambda: native.check(lib.avifhipRGBImageApplyGainMapAsync(dbase.struct, 1, 13, C.byref(gm), 3.0, out_primaries, 16, dout.struct, C.byref(clli),
                                                                                  C.byref(diag), None))
                 for _ in range(3):
                     call()

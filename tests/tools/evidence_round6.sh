@@ -16,7 +16,7 @@ python bench.py > "gpurun_out/${TAG}_bench_line_default_run.json" 2> "gpurun_out
 python bench.py --steps 20 --warmup 5 > "gpurun_out/${TAG}_bench_line_driver_flags.json" 2>> "gpurun_out/${TAG}_bench_default.err"
 AVIFHIP_BENCH_ALL_BLOCKS=1 AVIFHIP_BENCH_DEVICES=0,0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "gpurun_out/${TAG}_bench_line_all_blocks_one_gpu.json" 2>> "gpurun_out/${TAG}_bench_default.err"
 bash tests/tools/seq_evidence.sh "$TAG" > "gpurun_out/${TAG}_seq_evidence.log" 2>&1
-CFGS="cfg2 cfg2_cold cfg2_seq cfg2_seq_cold cfg2_4k cfg2_4k_seq cfg2_4k_cold cfg2_4k_seq_cold cfg2n cfg2_alpha cfg2_premul cfg3 cfg4 cfg4_cycled cfg4_seq cfg4rgb cfg4_8k cfg5 cfg5x64 cfg5x64_8 cfg5grid cfg5grid_8 photo_grid f16_444a ident8 gray8 tail90 scale_box4 scale_down_1_5 gainmap4k gainmap4k_photo gainmap4k_half gmcompute4k gmcompute4k_dev"
+CFGS="cfg2 cfg2_cold cfg2_seq cfg2_seq_cold cfg2_4k cfg2_4k_seq cfg2_4k_cold cfg2_4k_seq_cold cfg2n cfg2_alpha cfg2_premul cfg3 cfg4 cfg4_cycled cfg4_seq cfg4rgb cfg4_8k cfg5 cfg5x64 cfg5x64_8 cfg5grid cfg5grid_8 photo_grid f16_444a ident8 gray8 tail90 scale_box4 scale_down_1_5 gainmap4k gainmap4k_photo gainmap4k_same gainmap4k_half gmcompute4k gmcompute4k_dev"
 bash tests/tools/profile_cfgs.sh "$TAG" $CFGS > "gpurun_out/${TAG}_profile_cfgs.log" 2>&1
 for c in $CFGS; do cat "gpurun_out/${TAG}_cfgs/$c.jsonl" 2>/dev/null | grep '^{' ; done > "gpurun_out/${TAG}_cfgs_bench.jsonl"
 python - "$TAG" > "gpurun_out/${TAG}_gainmap_compute.txt" <<'PY'

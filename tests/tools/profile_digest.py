@@ -19,25 +19,41 @@ def dbs(path):
     return sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))
 
 
-def kernel_stats(path):
+def _geometry_name(kname, grid_z, workgroup_z):
+    """Round 6: one kernel instantiation serves single images (grid z = 1) and sequence launches (grid z = frames): a profiler's per-kernel
+    average would mix 30 us and 120 us launches and their bytes.  Launches with more than one layer of workgroups carry it in their name."""
+    layers = (grid_z // workgroup_z) if workgroup_z else 1
+    return kname if layers <= 1 else f"{kname} [grid z = {layers}]"
+
+
+def kernel_stats(path, by_geometry=True):
     rows = defaultdict(list)
     for f in dbs(path):
         db = sqlite3.connect(f)
         names = {r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")}
         if "kernels" in names:
-            for kname, dur in db.execute("select name, duration from kernels"):
-                rows[kname].append(dur)
+            cols = {r[1] for r in db.execute("pragma table_info(kernels)")}
+            if by_geometry and {"grid_z", "workgroup_z"} <= cols:
+                for kname, dur, gz, wz in db.execute("select name, duration, grid_z, workgroup_z from kernels"):
+                    rows[_geometry_name(kname, gz, wz)].append(dur)
+            else:
+                for kname, dur in db.execute("select name, duration from kernels"):
+                    rows[kname].append(dur)
     return rows
 
 
-def counters(path):
+def counters(path, by_geometry=True):
     acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
     for f in dbs(path):
         db = sqlite3.connect(f)
         names = {r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")}
         if "counters_collection" in names:
+            layers = {}
+            if by_geometry and "kernels" in names and {"grid_z", "workgroup_z", "dispatch_id"} <= {r[1] for r in db.execute("pragma table_info(kernels)")}:
+                layers = {d: (gz, wz) for d, gz, wz in db.execute("select dispatch_id, grid_z, workgroup_z from kernels")}
             for kname, cname, value, disp in db.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
-                acc[kname][cname][disp] += value
+                gz, wz = layers.get(disp, (1, 1))
+                acc[_geometry_name(kname, gz, wz)][cname][disp] += value
     return acc
 
 

@@ -61,9 +61,12 @@ for c in sys.argv[3:]:
         ar, aw = row.get("algorithmic_read_bytes", 0), row.get("algorithmic_write_bytes", 0)
         for name in sorted(avg):
             print(f"      {name:14s} dispatches={len(cs[name]):6d} avg_per_dispatch={avg[name]:18.1f}")
-        if ar and aw:
+        if not avg.get("FETCH_SIZE") or not avg.get("WRITE_SIZE"):
+            print("      (one of the two counter passes collected nothing for this kernel: no traffic figure)")
+        elif ar and aw:
             print(f"      read {rd / 1e6:.1f} MB = {rd / ar:.3f} x algorithmic; write {wr / 1e6:.1f} MB = {wr / aw:.3f} x; total {(rd + wr) / 1e6:.1f} MB per launch = {(rd + wr) / (ar + aw):.3f} x algorithmic")
-        entry.update(FETCH_SIZE_avg=avg.get("FETCH_SIZE"), WRITE_SIZE_avg=avg.get("WRITE_SIZE"), traffic_bytes_per_launch=int(rd + wr),
+        entry.update(FETCH_SIZE_avg=avg.get("FETCH_SIZE"), WRITE_SIZE_avg=avg.get("WRITE_SIZE"),
+                     traffic_bytes_per_launch=int(rd + wr) if avg.get("FETCH_SIZE") and avg.get("WRITE_SIZE") else None,
                      traffic_note="FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (MI355X_MICROARCH.md), separate rocprofv3 --pmc passes")
     result[c] = entry
 open(jpath, "w").write(json.dumps(result, indent=1) + "\n")
