@@ -230,10 +230,14 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
     if (o.is565) {
         // RGB565 (Android's bitmap format, android_jni/.../libavif_jni.cc:206-223): libyuv's I420ToRGB565Matrix / I422ToRGB565Matrix --
         // 8-bit 4:2:0 / 4:2:2 planes, nearest upsampling -- in the packed 16-bit kernels
-        const bool packed = p.arith == ARITH_LIBYUV && s.chanBytes == 1 && !p.bilinear && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE &&
+        // (10- / 12-bit planes reach those two entries through Convert16To8Plane, src/reformat_libyuv.c:906-930: the packed kernels' front end
+        //  for 16-bit containers, which unfiltered chroma always selects -- soloPays)
+        const bool packed = p.arith == ARITH_LIBYUV && !p.bilinear && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE &&
+                            (s.chanBytes == 1 || (p.fxDownshift != 0 && (p.tuning & TUNE_COOPERATIVE) == 0)) &&
                             (s.format == AVIF_PIXEL_FORMAT_YUV420 || s.format == AVIF_PIXEL_FORMAT_YUV422) && s.hasColor;
         // ... and from the fp32 arithmetic (10- / 12-bit sources, filtered chroma, avoidLibYUV) in the fp32 tiles, alpha arithmetic aside
-        const bool fp32 = p.arith != ARITH_LIBYUV && p.inLoopMul == MUL_NONE && p.postMul == MUL_NONE;
+        // (an alpha plane that the format drops is multiplied in inside the loop, src/reformat.c:1503-1511: the kernels with alpha arithmetic)
+        const bool fp32 = p.arith != ARITH_LIBYUV && p.postMul == MUL_NONE;
         if (!(packed || fp32) || o.map.on)
             return false;
     }
@@ -271,7 +275,7 @@ bool tileYuvToRgbSupported(const YuvToRgbPlan & p)
     if (p.postMul != MUL_NONE && p.alphaSource != ALPHA_PLANE)
         return false;
     const int nch = o.is565 ? 2 : (o.hasAlpha ? 4 : 3);
-    const uint32_t storeAlign = o.map.on ? 1u : (o.isGray ? 4u * (uint32_t)o.pixBytes : ((nch == 4) ? 16u : (nch == 2 ? 8u : (o.chanBytes == 1 ? 4u : 8u))));
+    const uint32_t storeAlign = o.map.on ? 1u : (o.isGray ? 4u * (uint32_t)o.pixBytes : ((nch == 4) ? 16u : (nch == 2 ? 2u : (o.chanBytes == 1 ? 4u : 8u))));
     if (!aligned(o.pixels, o.rowBytes, storeAlign))
         return false;
     // 32-bit lane offsets from the plane bases

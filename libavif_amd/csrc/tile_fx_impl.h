@@ -469,6 +469,10 @@ hipError_t launchFxVariant(const TileKey & k, const TileLaunch & L)
         if (k.nch == 2) // RGB565: the packed 16-bit kernels only (tileYuvToRgbSupported admits nothing else)
             return launchPk<SUB, BIL, 2, false>(L);
     }
+    if constexpr (sizeof(YT) == 2 && !BIL && (SUB == SUB_420 || SUB == SUB_422)) {
+        if (k.nch == 2) // ... from 10- / 12-bit planes: Convert16To8Plane in the kernel's front end, then the same arithmetic
+            return L.wideDownshift ? launchPkMapped<SUB, BIL, 2, false, false, WIDE_DOWNSHIFT>(L) : hipErrorInvalidValue;
+    }
     if (k.nch == 3)
         return launchOneFx<YT, SUB, BIL, 3, false, false>(L);
     if (k.hasMul)

@@ -64,6 +64,7 @@ constexpr bool kSeams = false;
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2a2 __attribute__((ext_vector_type(2), aligned(2))); // four RGB565 pixels: rows of 16-bit pixels are 2-byte aligned, no more
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBandW = 256; // pixels per strip row: 64 lanes x 4 pixels
@@ -984,7 +985,8 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
     constexpr bool kWide = sizeof(YT) == 2;
     constexpr bool kNeedA = APLANE || HASMUL;
     constexpr bool IS565 = NCH == 5; // RGB565: one 16-bit word per pixel (template code 5; 8-bit RT)
-    static_assert(!IS565 || (sizeof(RT) == 1 && !HASMUL && !APLANE && !MAPPED), "RGB565: 8-bit channels, no alpha");
+    // (HASMUL: an image with an alpha plane converted to RGB565 is premultiplied in the loop -- src/reformat.c:1503-1511 -- there is no post-pass)
+    static_assert(!IS565 || (sizeof(RT) == 1 && !APLANE && !MAPPED), "RGB565: 8-bit channels, no alpha channel");
     constexpr uint32_t kPixBytes = IS565 ? 2u : NCH * sizeof(RT);
     const int tx = threadIdx.x, wv = (WAVES == 1) ? 0 : (int)threadIdx.y; // WAVES == 1: `xchg` is this wave's own exchange buffer
     const bool nt = (A.tuning & TUNE_NONTEMPORAL) != 0;
@@ -1211,6 +1213,18 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                     }
                 }
             };
+            // RGB565 (Android's bitmap format; here from the fp32 arithmetic: 10- / 12-bit sources, filtered chroma, avoidLibYUV): the format has no
+            // channel offsets, so the 'first' colour is blue and the 'third' red (tile_shared.h distillArgs); four pixels = 8 bytes per lane, at
+            // the 2-byte alignment a row of 16-bit pixels has (odd widths, padded pitches: the hardware splits what straddles).
+            // b >> 3 | (g >> 2) << 5 | (r >> 3) << 11 of the 8-bit channels, src/reformat.c:619-626
+            auto emit565 = [&](const unsigned (&b8)[4], const unsigned (&g8)[4], const unsigned (&r8)[4]) {
+                unsigned h[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    h[i] = pack565(r8[i], g8[i], b8[i]);
+                if (laneValid)
+                    storeVec(A.rgb, off, (u2a2) { h[0] | (h[1] << 16), h[2] | (h[3] << 16) }, nt);
+            };
             // finished integers (q[i].r / q[i].b: first / third colour channel) to their pixels
             auto emitQ = [&](PixelOut (&q)[4]) {
                 if constexpr (sizeof(RT) == 2) {
@@ -1242,22 +1256,12 @@ __device__ __forceinline__ void computeTile(const TileArgs & A, const BandCtx & 
                     if (laneValid)
                         storeGray4<RT, NCH>(A.rgb, off, q, a, alphaFirst, nt);
                 } else if constexpr (IS565) {
-                    // (RGB565 leaves through emitT / emit565)
+                    const unsigned b8[4] = { q[0].r, q[1].r, q[2].r, q[3].r }, g8[4] = { q[0].g, q[1].g, q[2].g, q[3].g }, r8[4] = { q[0].b, q[1].b, q[2].b, q[3].b };
+                    emit565(b8, g8, r8);
                 } else {
                     if (laneValid)
                         store4<RT, NCH>(A.rgb, off, q, a, false, alphaFirst, nt);
                 }
-            };
-            // RGB565 (Android's bitmap format; here from the fp32 arithmetic: 10- / 12-bit sources, filtered chroma, avoidLibYUV): the format has no
-            // channel offsets, so the 'first' colour is blue and the 'third' red (tile_shared.h distillArgs); four pixels = 8 bytes per lane.
-            // b >> 3 | (g >> 2) << 5 | (r >> 3) << 11 of the 8-bit channels, src/reformat.c:619-626
-            auto emit565 = [&](const unsigned (&b8)[4], const unsigned (&g8)[4], const unsigned (&r8)[4]) {
-                unsigned h[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    h[i] = pack565(r8[i], g8[i], b8[i]);
-                if (laneValid)
-                    storeVec(A.rgb, off, (u2) { h[0] | (h[1] << 16), h[2] | (h[3] << 16) }, nt);
             };
             // the quantiser's arguments t = c * max + 0.5f (quantizeArg) of the row's (first, third) colours and of green to their pixels:
             // 8-bit colour outputs truncate, saturate and pack in one instruction per channel (packRgba8Row), the others through v_cvt_u32_f32
@@ -1860,9 +1864,9 @@ hipError_t launchOne(const TileLaunch & L)
 template <typename YT, int SUB, bool BIL, typename RT>
 hipError_t launchAlphaVariant(const TileKey & k, const TileLaunch & L)
 {
-    if (!k.gray && k.nch == 2) { // RGB565 (tileYuvToRgbSupported: 8-bit channels, no pending alpha arithmetic, no map)
+    if (!k.gray && k.nch == 2) { // RGB565 (tileYuvToRgbSupported: 8-bit channels, no map; alpha arithmetic in the loop only: wave-private kernels)
         if constexpr (sizeof(RT) == 1)
-            return launchOne<YT, SUB, BIL, RT, 5, false, false>(L);
+            return k.hasMul ? launchSolo<YT, SUB, BIL, RT, 5, false, true>(L) : launchOne<YT, SUB, BIL, RT, 5, false, false>(L);
         else
             return hipErrorInvalidValue;
     }

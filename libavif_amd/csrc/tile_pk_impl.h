@@ -382,7 +382,7 @@ __device__ __forceinline__ void pkRow(const TileArgs & A, const unsigned Y[2], u
     if (!laneValid)
         return;
     if constexpr (NCH == 2) {
-        storeVec(A.rgb, off, (u2) { px[0], px[1] }, true); // four 16-bit pixels
+        storeVec(A.rgb, off, (u2a2) { px[0], px[1] }, true); // four 16-bit pixels (2-byte aligned rows)
     } else if constexpr (NCH == 4) {
         storeVec(A.rgb, off, (u4) { px[0], px[1], px[2], px[3] }, true);
     }

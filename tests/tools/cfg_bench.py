@@ -132,6 +132,15 @@ def run(name):
             # Android's bitmap format (android_jni/.../libavif_jni.cc:206-223): 8K 8-bit 4:2:0 -> RGB565, nearest (libyuv has no filtering 565 entry)
             pair = y2r(7680, 4320, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR, avoid=avoid, rgb_format=abi.AVIF_RGB_FORMAT_RGB_565)
             px, bpp, ms = 7680 * 4320, 3.5, time_y2r(pair)
+        elif name in ("cfg2_565_odd", "cfg2_565_alpha", "cfg2_565_10"):
+            # round 6: what had gone through the one-lane-per-pixel kernels -- RGB565 rows that are 2-byte aligned only (an odd width: every other
+            # row's 8-byte stores straddle), an alpha plane multiplied in inside the loop (the format drops it, src/reformat.c:1503-1511: 1.5 + 1 + 2
+            # B/px, the fp32 loops in both arithmetics), and 10-bit planes (integer: Convert16To8Plane + I420ToRGB565Matrix; 3 + 2 B/px)
+            w = 7679 if name == "cfg2_565_odd" else 7680
+            depth = 10 if name == "cfg2_565_10" else 8
+            pair = y2r(w, 4320, depth, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, 1, 8, up=NEAR, alpha=(name == "cfg2_565_alpha"), avoid=avoid,
+                       rgb_format=abi.AVIF_RGB_FORMAT_RGB_565)
+            px, bpp, ms = w * 4320, {"cfg2_565_odd": 3.5, "cfg2_565_alpha": 4.5, "cfg2_565_10": 5.0}[name], time_y2r(pair)
         elif name in ("f16_420", "f16_444a"):
             # half-float outputs (what an HDR compositor takes): 8K 10-bit -> RGBA F16; 4:2:0 bilinear without alpha (1.5*2 + 8 B/px), 4:4:4 with alpha (4*2 + 8)
             if arith == "integer":
