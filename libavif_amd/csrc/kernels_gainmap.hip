@@ -346,6 +346,9 @@ constexpr int kFastPixels = 4; // per lane
 #define AVIFHIP_GAINMAP_ROWS 8
 #endif
 constexpr int kFastRows = AVIFHIP_GAINMAP_ROWS; // = waves per workgroup: 256 x 8 pixels per workgroup and step
+#ifndef AVIFHIP_GAINMAP_DEPTH
+#define AVIFHIP_GAINMAP_DEPTH 2 // tiles in flight per wave, the one being worked on included (3, round 6: 89 registers instead of 80, no faster -- 24.2 / 24.3 us on one box)
+#endif
 #ifndef AVIFHIP_GAINMAP_NT_LOADS
 #define AVIFHIP_GAINMAP_NT_LOADS 0
 #endif
@@ -649,6 +652,10 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
     };
     Tile T0, T1;
     request(T0, blockIdx.x); // the first pixels are on their way while the tables move into the LDS
+#if AVIFHIP_GAINMAP_DEPTH == 3
+    Tile T2;
+    request(T1, blockIdx.x + gridDim.x);
+#endif
 #ifdef AVIFHIP_GAINMAP_PROBE
     if (!(A.fast & 64))
 #endif
@@ -698,6 +705,28 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
     }
     const bool plain = (BASE_BYTES == 4 ? selBaseX == 0x03020100u : (selBaseX == 0x03020100u && selBaseY == 0x07060504u)) &&
                        (OUT_BYTES == 4 ? selOutX == 0x05040100u : (selOutX == 0x03020100u && selOutY == 0x07060504u));
+#if AVIFHIP_GAINMAP_DEPTH == 3
+    // (round 6, tried) two tiles requested ahead of the one being worked on
+    if (plain) {
+        for (uint32_t tile = blockIdx.x; tile < tiles; tile += 3 * gridDim.x) {
+            request(T2, tile + 2 * gridDim.x);
+            work(T0, std::true_type{});
+            request(T0, tile + 3 * gridDim.x);
+            work(T1, std::true_type{});
+            request(T1, tile + 4 * gridDim.x);
+            work(T2, std::true_type{});
+        }
+    } else {
+        for (uint32_t tile = blockIdx.x; tile < tiles; tile += 3 * gridDim.x) {
+            request(T2, tile + 2 * gridDim.x);
+            work(T0, std::false_type{});
+            request(T0, tile + 3 * gridDim.x);
+            work(T1, std::false_type{});
+            request(T1, tile + 4 * gridDim.x);
+            work(T2, std::false_type{});
+        }
+    }
+#else
     if (plain) {
         for (uint32_t tile = blockIdx.x; tile < tiles; tile += 2 * gridDim.x) {
             request(T1, tile + gridDim.x);
@@ -713,6 +742,7 @@ __global__ __launch_bounds__(64 * kFastRows) void gainMapApplyFastKernel(GainMap
             work(T1, std::false_type{});
         }
     }
+#endif
     __syncthreads(); // the tables are done with: their place serves the reduction
     finishStatistics<kFastRows>(A, toneMax, sum, 0, lds); // no NaN: the host sends a call here only when it can prove that (api_gainmap.cpp)
 }

@@ -197,6 +197,10 @@ uint32_t colourArgsOf(const RgbToYuvPlan & p, const R2YKey & k, uint32_t tuning,
     // for a frame the caches hold, no difference (10.63 / 10.65 us) for frames that stream; 1080p frames want one strip (4.34 / 5.00 us),
     // four strips lose everywhere (interleaved A/B, tests/tools/spw_ab.py)
     uint32_t spw = waveStrips > 8192 ? 2 : 1;
+    // (the identity matrix -- lossless GBR planes -- has next to no arithmetic between a wave's loads and its four planes' stores: two strips
+    //  per wave ran an 8K RGBA8 frame in 44-53 us, box to box, one strip in 37.5 = 0.885; round 6, AVIFHIP_R2Y_SPW sweep)
+    if (p.arith == ARITH_FLOAT && s.mode == MODE_IDENTITY && p.mul == MUL_NONE)
+        spw = 1;
     if (const char * e = getenv("AVIFHIP_R2Y_SPW")) // diagnostics / A-B measurements only
         spw = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : spw;
     spw = spw >= 4 ? 4 : (spw >= 2 ? 2 : 1);

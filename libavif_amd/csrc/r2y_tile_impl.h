@@ -412,25 +412,19 @@ __device__ __forceinline__ void computeStripT(const R2YArgs & A, uint32_t sy, ui
     }
 }
 
-template <typename RT, int NCH, typename YT, int SUB, bool PLAIN>
+template <typename RT, int NCH, typename YT, int SUB, bool PLAIN, bool IDENT>
 __device__ __forceinline__ void computeStrip(const R2YArgs & A, uint32_t sy, uint32_t X, bool laneValid, const StripRaw<RT, NCH> & S, const UnmulEntry * unmulTable)
 {
     // which memory-order colour channel is red decides the operand ORDER of the luma sum (fp32 addition is not associative):
-    // one wave-uniform branch instead of selects per pixel
-    // (the identity matrix takes 4:4:4 or 4:0:0 planes, src/reformat.c:141-144: only those kernels carry its code, behind a branch of its own)
-    if constexpr (PLAIN && (SUB == SUB_444 || SUB == SUB_400)) {
-        if (A.identity) {
-            if (A.slotB < A.slotR)
-                computeStripT<RT, NCH, YT, SUB, true, PLAIN, true>(A, sy, X, laneValid, S, unmulTable);
-            else
-                computeStripT<RT, NCH, YT, SUB, false, PLAIN, true>(A, sy, X, laneValid, S, unmulTable);
-            return;
-        }
-    }
+    // one wave-uniform branch instead of selects per pixel.
+    // (IDENT -- the identity matrix in the PLAIN kernels, 4:4:4 or 4:0:0 planes only, src/reformat.c:141-144 -- is a kernel of its own since
+    //  round 6: as a branch inside the PLAIN kernels (round 5) it cost them their registers -- 72 against 60, 110 with one strip per wave --
+    //  and the lossless encode ran at 44-53 us per 8K frame where the all-modes kernel took 38.4)
+    static_assert(!IDENT || (PLAIN && (SUB == SUB_444 || SUB == SUB_400)), "the identity matrix takes 4:4:4 or 4:0:0 planes");
     if (A.slotB < A.slotR)
-        computeStripT<RT, NCH, YT, SUB, true, PLAIN, false>(A, sy, X, laneValid, S, unmulTable);
+        computeStripT<RT, NCH, YT, SUB, true, PLAIN, IDENT>(A, sy, X, laneValid, S, unmulTable);
     else
-        computeStripT<RT, NCH, YT, SUB, false, PLAIN, false>(A, sy, X, laneValid, S, unmulTable);
+        computeStripT<RT, NCH, YT, SUB, false, PLAIN, IDENT>(A, sy, X, laneValid, S, unmulTable);
 }
 
 // ---- libyuv's fixed point (8-bit RGB -> 8-bit planes, BT.601, appendix D.5): same loads, stores and strip walk ----
@@ -596,7 +590,7 @@ hipError_t launchFxSub(int sub, const R2YArgs & A, uint32_t blocks, hipStream_t 
 // One wave, one tile of 256 x 2*NS pixels (NS vertically consecutive strips), every load issued before the first result is needed; the
 // four waves of a workgroup are stacked and independent.  (Round 1 walked a wave down its strips with the next strip's loads in
 // flight; like in the decode direction, many short-lived waves keep the memory pipes fuller: 4K RGBA8 -> 4:2:0 10.9 -> 9.9 us.)
-template <typename RT, int NCH, typename YT, int SUB, int NS, bool PLAIN>
+template <typename RT, int NCH, typename YT, int SUB, int NS, bool PLAIN, bool IDENT = false>
 __global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A0, R2YSeqFrames S)
 {
     const R2YArgs A = r2ySeqJob(A0, S);
@@ -635,7 +629,7 @@ __global__ __launch_bounds__(256) void rgbToYuvTileKernel(R2YArgs A0, R2YSeqFram
     for (int s = 0; s < NS; ++s) {
         if (first + 2 * s >= A.h2) // wave-uniform
             break;
-        computeStrip<RT, NCH, YT, SUB, PLAIN>(A, first + 2 * s, X, laneValid, raw[s], unmulTable);
+        computeStrip<RT, NCH, YT, SUB, PLAIN, IDENT>(A, first + 2 * s, X, laneValid, raw[s], unmulTable);
     }
 }
 
@@ -643,6 +637,17 @@ template <typename RT, int NCH, typename YT, int SUB, bool PLAIN>
 hipError_t launchOnePlainOrNot(const R2YArgs & A, uint32_t blocks, hipStream_t stream, const R2YSeqFrames & S, uint32_t frames)
 {
     const dim3 grid(blocks, 1, frames), block(kLanes, kWaves);
+    if constexpr (PLAIN && (SUB == SUB_444 || SUB == SUB_400)) {
+        if (A.identity) { // lossless RGB in GBR planes (avifenc -l): its own kernels
+            if (A.stripsPerWave >= 4)
+                hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 4, true, true>), grid, block, 0, stream, A, S);
+            else if (A.stripsPerWave >= 2)
+                hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 2, true, true>), grid, block, 0, stream, A, S);
+            else
+                hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 1, true, true>), grid, block, 0, stream, A, S);
+            return hipGetLastError();
+        }
+    }
     if (A.stripsPerWave >= 4)
         hipLaunchKernelGGL((rgbToYuvTileKernel<RT, NCH, YT, SUB, 4, PLAIN>), grid, block, 0, stream, A, S);
     else if (A.stripsPerWave >= 2)

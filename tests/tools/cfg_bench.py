@@ -230,7 +230,7 @@ def run(name):
         elif name == "cfg3":
             pair = y2r(7680, 4320, 10, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 9, 16, alpha=True, premult=True, avoid=avoid)
             px, bpp, ms = 7680 * 4320, 16.0, time_y2r_two_frames(pair)
-        elif name in ("cfg4", "cfg4rgb", "cfg4_601", "cfg4_8k", "cfg4rgb_8k", "ident8_enc", "cfg4_premul_8k", "cfg4_unpremul_8k", "cfg4_ycgco_8k"):
+        elif name in ("cfg4", "cfg4rgb", "cfg4_601", "cfg4_8k", "cfg4rgb_8k", "ident8_enc", "cfg4_premul_8k", "cfg4_unpremul_8k", "cfg4_ycgco_8k", "cfg4_444_8k"):
             fmt = abi.AVIF_RGB_FORMAT_RGB if name.startswith("cfg4rgb") else abi.AVIF_RGB_FORMAT_RGBA
             mc = 6 if name == "cfg4_601" else 1
             w, h = (7680, 4320) if name.endswith("_8k") or name == "ident8_enc" else (3840, 2160)  # the encode direction on the headline's frame size
@@ -242,6 +242,8 @@ def run(name):
             synth.fill_rgb(rgb, 0x12345678, opaque=(mul == 0))
             if name == "ident8_enc":  # lossless encode (avifenc -l): 8K RGBA8 -> GBR planes 8-bit 4:4:4 full range + alpha, 4 + 3 + 1 B/px
                 img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_FULL, 0, with_alpha=True)
+            elif name == "cfg4_444_8k":  # BT.709 limited 8-bit 4:4:4 + alpha (avifenc -y 444), 4 + 3 + 1 B/px
+                img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV444, abi.AVIF_RANGE_LIMITED, 1, with_alpha=True)
             elif name == "cfg4_ycgco_8k":  # YCgCo 8-bit 4:4:4 full range + alpha, 4 + 3 + 1 B/px
                 if arith == "integer":
                     continue
@@ -249,7 +251,7 @@ def run(name):
             else:
                 img = abi.make_yuv(w, h, 8, abi.AVIF_PIXEL_FORMAT_YUV420, abi.AVIF_RANGE_LIMITED, mc, with_alpha=(fmt == abi.AVIF_RGB_FORMAT_RGBA), alpha_premultiplied=(mul == 1))
             dimg, drgb = device.DeviceYUV(img), device.DeviceRGB(rgb, upload=True)
-            px, bpp = w * h, (8.0 if name in ("ident8_enc", "cfg4_ycgco_8k") else (6.5 if fmt == abi.AVIF_RGB_FORMAT_RGBA else 4.5))
+            px, bpp = w * h, (8.0 if name in ("ident8_enc", "cfg4_ycgco_8k", "cfg4_444_8k") else (6.5 if fmt == abi.AVIF_RGB_FORMAT_RGBA else 4.5))
             preheat(lambda n: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 0, n, None))
             ms = settled(lambda: lib.avifhipTimeRGBToYUV(dimg.struct, drgb.struct, 4, 100, None))
         elif name in ("cfg4_cycled", "cfg4_seq"):
