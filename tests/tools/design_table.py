@@ -20,6 +20,12 @@ DESC = {
     "cfg4_seq": "cfg4 as a sequence: 4 frames per launch (avifhipImageRGBToYUVBatchAsync), 8 cycled (HBM regime)",
     "gainmap4k_photo": "gain-map application on a photograph-like pair (neighbouring pixels hold neighbouring codes)",
     "gmcompute4k_dev": "gain-map computation, device-resident (avifhipRGBImageComputeGainMapAsync), per call",
+    "gainmap4k_same": "gain-map application, output in the base image's primaries (no fp64 matrix per pixel)",
+    "cfg2_565_odd": "… RGB565 on rows aligned to 2 bytes only (width 7679; round 5: universal kernel)",
+    "cfg2_565_alpha": "… RGB565 from planes with an alpha plane, multiplied in inside the loop (round 5: universal kernel)",
+    "cfg2_565_10": "… RGB565 from 10-bit planes (integer: Convert16To8Plane in the packed kernels' front end; round 5: universal kernel)",
+    "cfg4_444_8k": "8K RGBA8 → BT.709 4:4:4 + A (avifenc -y 444)",
+    "cfg4rgb_8k": "cfg4 from RGB8 at 8K",
     "cfg2n": "cfg2 with nearest upsampling",
     "cfg2_rgb": "cfg2 → RGB8 (3-byte pixels)",
     "cfg2_565": "cfg2 → RGB565, nearest (Android bitmaps)",
