@@ -894,30 +894,24 @@ __global__ __launch_bounds__(256) void gainMapChannelMinKernel(GainMapComputeArg
 }
 
 // pass 1: ratios + per-workgroup [baseMax, altMax, minRatio x 3, maxRatio x 3]
-template <bool LDSLUT, int CHANNELS>
+template <bool LDSLUT, int CHANNELS, int FAST> // FAST: 0 -- any layout; 4 / 8 -- whole 16-byte runs, the alternate image's pixels of 4 / 8 bytes
 __global__ __launch_bounds__(256) void gainMapRatioKernel(GainMapComputeArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float ldsLut[];
-    const ComputeLuts<LDSLUT> T = stageLuts<LDSLUT>(A, ldsLut);
+    ComputeLuts<LDSLUT> tables = { nullptr, nullptr }; // (staged below, behind the first step's loads where they can be issued early)
     const ComputeLayout lay = computeLayout(A);
     const ComputeRuns R = computeRuns(A.width, A.height);
     const size_t numPixels = (size_t)A.width * A.height;
     constexpr int channels = CHANNELS; // 1: A.singleChannel (a compile-time count keeps the per-channel arrays in registers)
     const bool vectorStores = (A.width & 3u) == 0; // (every plane of the ratio buffer then starts on 16 bytes, and so does every lane's run)
     float acc[8] = { 1.0f, 1.0f, __builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f, 0.0f, 0.0f };
-    for (uint32_t unit = blockIdx.x; unit < R.units; unit += gridDim.x) {
-        const uint32_t j = unit / R.runsX, i = (unit - j * R.runsX) * kComputeRun + 4 * threadIdx.x;
-        if (i >= A.width)
-            continue;
-        const uint32_t n = A.width - i < 4 ? A.width - i : 4;
-        uint32_t bc[4][3], ac[4][3];
-        readCodes4(A.base + (size_t)j * A.basePitch, i, n, A.baseL, lay.baseVector, lay.baseVector16, bc);
-        readCodes4(A.alt + (size_t)j * A.altPitch, i, n, A.altL, lay.altVector, lay.altVector16, ac);
+    // what a lane does with the codes of its (up to) four pixels at (i .. i + n - 1, j)
+    auto process = [&](uint32_t j, uint32_t i, uint32_t n, const uint32_t (&bc)[4][3], const uint32_t (&ac)[4][3]) {
         float ratio[CHANNELS][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float b[3] = { T.base[bc[k][0]], T.base[bc[k][1]], T.base[bc[k][2]] };
-            float a[3] = { T.alt[ac[k][0]], T.alt[ac[k][1]], T.alt[ac[k][2]] };
+            float b[3] = { tables.base[bc[k][0]], tables.base[bc[k][1]], tables.base[bc[k][2]] };
+            float a[3] = { tables.alt[ac[k][0]], tables.alt[ac[k][1]], tables.alt[ac[k][2]] };
             if (A.convertAlt)
                 convertPrimaries(a, A.M);
             if (A.convertBase)
@@ -953,6 +947,81 @@ __global__ __launch_bounds__(256) void gainMapRatioKernel(GainMapComputeArgs A)
                     if ((uint32_t)k < n)
                         dst[k] = ratio[c][k];
             }
+        }
+    };
+    // Whole 16-byte runs on both sides (4- or 8-byte pixels, rows on 16 bytes, a width of whole quads -- what every RGBA image of libavif's
+    // own allocation is): the next step's pixels are requested before this step's are worked on, the first step's before the tables are staged
+    // (round 6: a workgroup's two steps had been load - wait - compute - store, twice, behind the staging of its tables).  Wave-uniform.
+    // FAST: a kernel of its own (launchGainMapRatios decides: gainMapRatioFast), without the general path's five pixel layouts
+    if constexpr (FAST != 0) {
+        constexpr bool alt8 = FAST == 8;
+        struct Raw
+        {
+            uint4 b, a0, a1;
+            uint32_t j, i;
+            bool live;
+        };
+        auto issue = [&](Raw & Q, uint32_t unit) {
+            Q.live = unit < R.units;
+            if (!Q.live)
+                return;
+            Q.j = unit / R.runsX, Q.i = (unit - Q.j * R.runsX) * kComputeRun + 4 * threadIdx.x;
+            Q.live = Q.i < A.width;
+            if (!Q.live)
+                return;
+            Q.b = *reinterpret_cast<const uint4 *>(A.base + (size_t)Q.j * A.basePitch + (size_t)Q.i * 4);
+            if constexpr (alt8) {
+                const uint4 * q = reinterpret_cast<const uint4 *>(A.alt + (size_t)Q.j * A.altPitch + (size_t)Q.i * 8);
+                Q.a0 = q[0], Q.a1 = q[1];
+            } else {
+                Q.a0 = *reinterpret_cast<const uint4 *>(A.alt + (size_t)Q.j * A.altPitch + (size_t)Q.i * 4);
+            }
+        };
+        auto work = [&](const Raw & Q) {
+            if (!Q.live)
+                return;
+            uint32_t bc[4][3], ac[4][3];
+            const uint32_t bw[4] = { Q.b.x, Q.b.y, Q.b.z, Q.b.w };
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                bc[k][0] = (bw[k] >> (8 * A.baseL.offR)) & 0xff, bc[k][1] = (bw[k] >> (8 * A.baseL.offG)) & 0xff, bc[k][2] = (bw[k] >> (8 * A.baseL.offB)) & 0xff;
+            if constexpr (alt8) { // (readPixel's 8-byte form)
+                const uint32_t lo[4] = { Q.a0.x, Q.a0.z, Q.a1.x, Q.a1.z }, hi[4] = { Q.a0.y, Q.a0.w, Q.a1.y, Q.a1.w };
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    auto pick = [&](uint32_t off) -> uint32_t { return (((off & 4) ? hi[k] : lo[k]) >> (8 * (off & 3))) & 0xffff; };
+                    ac[k][0] = pick(A.altL.offR), ac[k][1] = pick(A.altL.offG), ac[k][2] = pick(A.altL.offB);
+                }
+            } else {
+                const uint32_t aw[4] = { Q.a0.x, Q.a0.y, Q.a0.z, Q.a0.w };
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    ac[k][0] = (aw[k] >> (8 * A.altL.offR)) & 0xff, ac[k][1] = (aw[k] >> (8 * A.altL.offG)) & 0xff, ac[k][2] = (aw[k] >> (8 * A.altL.offB)) & 0xff;
+            }
+            process(Q.j, Q.i, 4, bc, ac);
+        };
+        Raw Q0, Q1;
+        issue(Q0, blockIdx.x);
+        const ComputeLuts<LDSLUT> T = stageLuts<LDSLUT>(A, ldsLut);
+        tables = T;
+        for (uint32_t unit = blockIdx.x; unit < R.units; unit += 2 * gridDim.x) {
+            issue(Q1, unit + gridDim.x);
+            work(Q0);
+            issue(Q0, unit + 2 * gridDim.x);
+            work(Q1);
+        }
+    } else {
+        const ComputeLuts<LDSLUT> T = stageLuts<LDSLUT>(A, ldsLut);
+        tables = T;
+        for (uint32_t unit = blockIdx.x; unit < R.units; unit += gridDim.x) {
+            const uint32_t j = unit / R.runsX, i = (unit - j * R.runsX) * kComputeRun + 4 * threadIdx.x;
+            if (i >= A.width)
+                continue;
+            const uint32_t n = A.width - i < 4 ? A.width - i : 4;
+            uint32_t bc[4][3], ac[4][3];
+            readCodes4(A.base + (size_t)j * A.basePitch, i, n, A.baseL, lay.baseVector, lay.baseVector16, bc);
+            readCodes4(A.alt + (size_t)j * A.altPitch, i, n, A.altL, lay.altVector, lay.altVector16, ac);
+            process(j, i, n, bc, ac);
         }
     }
     const bool isMax[8] = { true, true, false, false, false, true, true, true };
@@ -1290,20 +1359,41 @@ hipError_t launchGainMapChannelMin(const GainMapComputeArgs & A, hipStream_t str
     return hipGetLastError();
 }
 
+// whole 16-byte runs on both sides (gainMapRatioKernel's FAST form): 4-channel pixels of 4 or 8 bytes, bases and pitches on 16 bytes, whole quads
+static bool gainMapRatioFast(const GainMapComputeArgs & A)
+{
+    const bool base16 = A.baseL.hasAlpha && A.baseL.pixelBytes == 4 && (((uintptr_t)A.base | A.basePitch) & 15) == 0;
+    const bool alt16 = A.altL.hasAlpha && (A.altL.pixelBytes == 4 || A.altL.pixelBytes == 8) && (((uintptr_t)A.alt | A.altPitch) & 15) == 0;
+    return (A.width & 3u) == 0 && base16 && alt16;
+}
+
 hipError_t launchGainMapRatios(const GainMapComputeArgs & A, hipStream_t stream)
 {
     const uint32_t groups = gainMapComputeGroups(A.width, A.height);
     const uint32_t lds = (A.baseLutEntries + A.altLutEntries) * (uint32_t)sizeof(float);
+    const bool fast = gainMapRatioFast(A);
+    auto launch = [&](auto ldsLut, auto channels) {
+        constexpr bool L = decltype(ldsLut)::value;
+        constexpr int C = decltype(channels)::value;
+        if (fast && A.altL.pixelBytes == 8)
+            hipLaunchKernelGGL((gainMapRatioKernel<L, C, 8>), dim3(groups), dim3(256), L ? lds : 0, stream, A);
+        else if (fast)
+            hipLaunchKernelGGL((gainMapRatioKernel<L, C, 4>), dim3(groups), dim3(256), L ? lds : 0, stream, A);
+        else
+            hipLaunchKernelGGL((gainMapRatioKernel<L, C, 0>), dim3(groups), dim3(256), L ? lds : 0, stream, A);
+    };
+    using One = std::integral_constant<int, 1>;
+    using Three = std::integral_constant<int, 3>;
     if (computeLutsFitLds(A)) {
         if (A.singleChannel)
-            hipLaunchKernelGGL((gainMapRatioKernel<true, 1>), dim3(groups), dim3(256), lds, stream, A);
+            launch(std::true_type{}, One{});
         else
-            hipLaunchKernelGGL((gainMapRatioKernel<true, 3>), dim3(groups), dim3(256), lds, stream, A);
+            launch(std::true_type{}, Three{});
     } else {
         if (A.singleChannel)
-            hipLaunchKernelGGL((gainMapRatioKernel<false, 1>), dim3(groups), dim3(256), 0, stream, A);
+            launch(std::false_type{}, One{});
         else
-            hipLaunchKernelGGL((gainMapRatioKernel<false, 3>), dim3(groups), dim3(256), 0, stream, A);
+            launch(std::false_type{}, Three{});
     }
     return hipGetLastError();
 }

@@ -29,8 +29,13 @@ __global__ void checksumKernel(const uint32_t * p, size_t n, unsigned long long 
 
 int main(int argc, char ** argv)
 {
-    const uint32_t W = 7680, H = 4320;
-    const int NB = 12;
+#ifndef SQB_W
+#define SQB_W 7680
+#define SQB_H 4320
+#define SQB_NB 12
+#endif
+    const uint32_t W = SQB_W, H = SQB_H; // (-DSQB_W=3840 -DSQB_H=2160 -DSQB_NB=24: 4K frames, round 6)
+    const int NB = SQB_NB;
     const char * name = argc > 1 ? argv[1] : "seqbench";
     const uint32_t wavesXLog2 = argc > 2 ? (uint32_t)atoi(argv[2]) : 0, chunkRows = argc > 3 ? (uint32_t)atoi(argv[3]) : 1;
     const uint32_t F = argc > 4 ? (uint32_t)atoi(argv[4]) : 4;
@@ -90,6 +95,6 @@ int main(int argc, char ** argv)
     unsigned long long * d; CK(hipMalloc(&d, 8)); CK(hipMemset(d, 0, 8));
     checksumKernel<<<1024, 256>>>((const uint32_t *)o[0], (size_t)W * H, d);
     unsigned long long h = 0; CK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
-    printf("%-52s grid %5u x %u  %d frames cycled: %6.2f us per frame (%.3f)   checksum %016llx\n", name, blocks, F, NB, t[3], 22.8096 / t[3], h);
+    printf("%-52s grid %5u x %u  %d frames cycled: %6.2f us per frame (%.3f)   checksum %016llx\n", name, blocks, F, NB, t[3], (double)W * H * 5.5 / 8e6 / t[3], h);
     return 0;
 }
