@@ -1,0 +1,138 @@
+"""Round 6's committed evidence (profiles/r06_*, tests/tools/evidence_round6.sh) is self-consistent -- the round-6 twin of test_profiles.py:
+the bench line printed under rocprofv3 agrees with the profiler's own statistics of that command; the HBM-regime figures (frames cycled
+through more memory than the Infinity Cache holds: one frame per launch and sequences of four) follow from their kernel times, agree with
+rocprofv3's averages over the same launches and carry counter traffic within 3 % of the algorithmic bytes; the 4K rows of the
+configuration table and of the bench line are one measurement regime (they had disagreed by 9 %); the closed fault's
+regression log, the order-shuffled tiers, the sanitizer log and the universal kernels' census say what DESIGN.md says they say."""
+import json
+import re
+from pathlib import Path
+
+PROFILES = Path(__file__).resolve().parent.parent / "profiles"
+ALG = 7680 * 4320 * 5.5
+ALG_4K = 3840 * 2160 * 5.5
+PK = "yuv2rgb_fixed_tile<u8,420,bilinear,rgba8,pk16>"
+FP = "yuv2rgb_tile<u8,420,bilinear,rgba8>"
+
+
+def _line(name):
+    return json.loads((PROFILES / name).read_text().strip().splitlines()[-1])
+
+
+def _rows(name):
+    return [json.loads(l) for l in (PROFILES / name).read_text().splitlines() if l.startswith("{")]
+
+
+def _frac(nbytes, ms):
+    return nbytes / (ms * 1e-3) / 8e12
+
+
+def test_bench_line_under_rocprof_agrees_with_the_profiler():
+    stats = (PROFILES / "r06_bench_kernel_stats.txt").read_text().splitlines()
+    assert "bench.py" in stats[0] and "--headline-only" in stats[0]
+    line = _line("r06_bench_line_under_rocprof.json")
+    assert line["config"]["kernel"] == PK
+    # the one-frame launches of the packed kernel (the timed region, warm and cold regimes mixed) and the four-frame sequence launches
+    # are two rows of the profiler's table: same kernel name, ~4 x the duration
+    pk = [re.split(r"\s{2,}", l.strip()) for l in stats[2:] if "yuvToRgbPkKernel<2, true, 4, false, 2, false, 0, false>" in l]
+    assert len(pk) == 2
+    single, seq = sorted(pk, key=lambda f: float(f[-4]))
+    avg_single, avg_seq = float(single[-4]), float(seq[-4])
+    r = line["roofline"]
+    # the profiler's average over every one-frame launch lies between the L3-resident and the HBM regime's event times
+    assert r["kernel_ms"] * 1e3 * 0.97 <= avg_single <= r["cold"]["kernel_ms"] * 1e3 * 1.03
+    assert _frac(ALG, avg_single * 1e-3) >= 0.70
+    # sequences: the profiler averages the L3-resident (4 cycled) and the HBM (12 cycled) launches of the run
+    warm_seq = line["integer"]["sequence"]["inputs_cache_resident"]["kernel_ms"] * 1e3
+    cold_seq = r["cold_batched"]["kernel_ms"] * 1e3
+    assert warm_seq * 0.97 <= avg_seq <= cold_seq * 1.03
+    assert _frac(4 * ALG, cold_seq * 1e-3) >= 0.72  # VERDICT r05 item 3, on the HBM regime's own launches
+
+
+def test_hbm_regime_blocks_of_the_bench_lines():
+    for name in ("r06_bench_line_under_rocprof.json", "r06_bench_line_default_run.json", "r06_bench_line_driver_flags.json"):
+        d = _line(name)
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - _frac(ALG, r["kernel_ms"])) < 1e-3 and r["frac"] >= 0.78
+        assert r["frames_cycled"] == 4 and r["kernel_ms_inputs_cache_resident"] == r["kernel_ms"]  # the headline regime says what it is
+        cold = r["cold"]
+        assert cold["frames_cycled"] * ALG > 4 * 256e6 and abs(cold["frac"] - _frac(ALG, cold["kernel_ms"])) < 1e-3 and cold["frac"] >= 0.65
+        cb = r["cold_batched"]
+        assert cb["frames_per_launch"] == 4 and cb["frames_cycled"] == 12 and cb["kernel"] == PK
+        assert cb["algorithmic_bytes_per_launch"] == 4 * ALG and abs(cb["frac"] - _frac(4 * ALG, cb["kernel_ms"])) < 1e-3
+        assert cb["frac"] >= 0.72 and cb["frac"] > cold["frac"] + 0.03  # what several frames per launch buy in the HBM regime
+        assert 0.80 <= cb["ceiling"]["conversion_vs_ceiling"] <= 1.0
+        assert cb["traffic"] is None or abs(cb["traffic"] - 4 * ALG) / (4 * ALG) < 0.03
+        fp = d["fp32"]
+        assert fp["kernel"] == FP and fp["cold"]["frac"] >= 0.62
+        fs = fp["sequence"]["cold"]
+        assert fs["frames_per_launch"] == 4 and abs(fs["frac"] - _frac(4 * ALG, fs["kernel_ms"])) < 1e-3 and fs["frac"] >= 0.68
+        for side in ("integer", "fp32"):
+            warm = d[side]["sequence"]["inputs_cache_resident"]
+            assert "L3-resident" in warm["what"] and warm["frac"] > d[side]["sequence"]["cold"]["frac"]
+        assert abs(d["value"] - 7680 * 4320 / 1e6 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+        assert 0.97 * r["kernel_ms"] <= d["ms_per_step"] <= 1.08 * r["kernel_ms"]
+        assert d["dtype"] == "i16" and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["scaling"] == "weak"
+    for name in ("r06_bench_line_default_run.json", "r06_bench_line_driver_flags.json"):
+        d = _line(name)
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "reference" and cb["cores"] == 1 and 50 < cb["value"] < 500
+        c4 = d["configs"]["cfg4"]
+        assert "8 frames cycled" in c4["what"] and c4["sequence"]["frac"] >= 0.70 and c4["frac"] >= 0.58  # encode sequences: VERDICT r05 item 4
+        assert d["configs"]["cfg3"]["frac"] >= 0.70 and d["configs"]["cfg5x64"]["frac"] >= 0.70 and d["configs"]["cfg5grid"]["frac"] >= 0.70
+        gm = d["gainmap"]
+        assert gm["compute"]["ms_per_call"] <= 0.70 and gm["whole_call"]["ms_per_call"] <= 0.040  # 0.0457 with the stream drained inside the call (round 5)
+
+
+def test_sequence_evidence_events_profiler_and_counters_agree():
+    s = json.loads((PROFILES / "r06_sequence.json").read_text())
+    assert json.loads((PROFILES / "pmc_traffic_sequence.json").read_text()) == s  # what bench.py quotes cold_batched.traffic from
+    for key, family, frames, floor in (("cfg2seq", PK, 4, 0.72), ("cfg2cold", PK, 1, 0.65), ("cfg2seq_fp32", FP, 4, 0.68), ("cfg2cold_fp32", FP, 1, 0.56)):
+        r = s[key]
+        assert r["kernel_family"] == family and r["frames_per_launch"] == frames and r["algorithmic_bytes_per_launch"] == frames * ALG
+        assert abs(r["event_us"] - r["rocprof_avg_us"]) / r["rocprof_avg_us"] < 0.03
+        assert abs(r["rocprof_frac"] - _frac(frames * ALG, r["rocprof_avg_us"] * 1e-3)) < 1e-3 and r["rocprof_frac"] >= floor
+        traffic = r["FETCH_SIZE_avg"] * 1024 * 2 + r["WRITE_SIZE_avg"] * 1024  # MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64
+        assert abs(traffic - r["traffic_bytes_per_launch"]) < 2 and abs(traffic - frames * ALG) / (frames * ALG) < 0.03
+
+
+def test_4k_rows_of_table_and_bench_line_are_one_regime():
+    by = {(r["config"], r["arithmetic"]): r for r in _rows("r06_cfgs_bench.jsonl")}
+    d = _line("r06_bench_line_default_run.json")["planes_4k"]
+    for side, arithmetic in (("integer", "integer"), ("fp32", "float")):
+        table, line = by[("cfg2_4k", arithmetic)], d[side]
+        assert "L3-resident" in table["regime"] and "L3-resident" in d["what"]
+        assert abs(table["us"] - line["kernel_ms"] * 1e3) / table["us"] < 0.06  # (two processes of one box; round 5's rows were 9 % apart)
+        assert abs(line["frac"] - _frac(ALG_4K, line["kernel_ms"])) < 1e-3
+        cold_table = by[("cfg2_4k_cold", arithmetic)]
+        assert "HBM" in cold_table["regime"] and abs(cold_table["us"] - line["cold"]["kernel_ms"] * 1e3) / cold_table["us"] < 0.08
+        assert line["sequence"]["inputs_cache_resident"]["frac"] >= 0.74 and line["sequence"]["cold"]["frac"] >= 0.60
+
+
+def test_fault_regression_order_seeds_and_sanitizers():
+    runs = re.findall(r"^run (\d+): (\d+) passed", (PROFILES / "r06_fault_regression.txt").read_text(), re.M)
+    assert [int(k) for k, _ in runs] == list(range(1, 21)) and len({n for _, n in runs}) == 1  # 20 fresh processes, the order that died
+    assert "failed" not in (PROFILES / "r06_fault_regression.txt").read_text() and "error" not in (PROFILES / "r06_fault_regression.txt").read_text().lower()
+    seeds = (PROFILES / "r06_order_seeds.txt").read_text()
+    blocks = re.split(r"^== --order-seed (\d+)\s*$", seeds, flags=re.M)[1:]
+    assert len(blocks) // 2 >= 2
+    for seed, body in zip(blocks[0::2], blocks[1::2]):
+        assert re.search(r"\b\d{3} passed", body) and "failed" not in body, seed
+    assert "569 passed" in (PROFILES / "r06_rotation14_first_process.txt").read_text() or re.search(r"\d{3} passed", (PROFILES / "r06_rotation14_first_process.txt").read_text())
+    tsan = (PROFILES / "r06_tsan.txt").read_text()
+    assert "with the top frames of BOTH accesses in instrumented code: 0" in tsan and "reports that survive the suppressions: 0" in tsan
+    assert tsan.count("0 failed, 0 mismatched") >= 3 and "ERROR: AddressSanitizer" not in tsan
+
+
+def test_universal_kernels_census_is_empty():
+    text = (PROFILES / "r06_generic_rest.txt").read_text()
+    found = re.findall(r"== (fp32|auto): (\d+) of (\d+) conversions through the universal kernels", text)
+    assert len(found) >= 8 and all(int(n) == 0 and int(total) > 1000 for _, n, total in found)
+
+
+def test_gainmap_compute_kernels():
+    text = (PROFILES / "r06_gainmap_compute.txt").read_text()
+    block = text.split("== gmcompute4k_dev", 1)[1]
+    kernels = {m.group(1): float(m.group(2)) for m in re.finditer(r"gainMap(\w+)Kernel.*?\s+\d+\s+([0-9.]+)\s+[0-9.]+\s+[0-9.]+\s*$", block, re.M)}
+    assert {"Histogram", "Ratio", "Quantise"} <= set(kernels)
+    assert sum(kernels.values()) <= 200.0, kernels  # 762 us in round 5
