@@ -597,12 +597,40 @@ def main():
         except Exception:
             pass
 
+    seq_file = ROOT / "profiles" / "pmc_traffic_sequence.json"
+    if seq_file.exists() and not args.dry_run:
+        try:
+            sj = json.loads(seq_file.read_text()).get("cfg2seq" if integer else "cfg2seq_fp32", {})
+            cb = out["roofline"]["cold_batched"]
+            if sj.get("kernel_family", "") == cb["kernel"] and sj.get("frames_per_launch") == SEQUENCE_FRAMES and sj.get("traffic_bytes_per_launch"):
+                cb["traffic"] = sj["traffic_bytes_per_launch"]
+                cb["traffic_source"] = ("profiles/pmc_traffic_sequence.json (tests/tools/seq_evidence.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                        "`stream_sweep.py run cfg2seq`, the same launches and nothing else; not measured in this run)")
+        except Exception:
+            pass
+
     # ---- N > 1: the other two multi-GPU shapes in the same line (one driver command captures all three; N = 1 prints today's line) ----
     #   strong_scaling_cfg5      ONE 15360x8640 canvas of 64 tiles per step, its tiles sharded over the ranks (what `--workload cfg5` prints)
     #   in_process_host_to_host  ONE process (rank 0) driving all N devices through the library's device farm, host image in, host pixels out
     #                            (what `--in-process` prints: an unmodified libavif over seam A / seam B with AVIFHIP_DEVICES=all); the other ranks wait
-    if (world > 1 or os.environ.get("AVIFHIP_BENCH_ALL_BLOCKS") == "1") and not args.headline_only:
+    if (world > 1 or os.environ.get("AVIFHIP_BENCH_ALL_BLOCKS") == "1") and not args.headline_only and os.environ.get("AVIFHIP_BENCH_SIDE_BLOCKS", "1") != "0":
         import copy
+        import threading
+
+        # The headline above is measured; the side blocks below have never met more than one physical GPU (no node was to be had).
+        # A rank that hangs in one of them must not cost the line: past AVIFHIP_BENCH_SIDE_TIMEOUT seconds rank 0 prints the line without
+        # them and every rank leaves.  (AVIFHIP_BENCH_SIDE_BLOCKS=0 skips them.)
+        side_done = threading.Event()
+        side_timeout = float(os.environ.get("AVIFHIP_BENCH_SIDE_TIMEOUT", "240"))
+        fallback_line = json.dumps(dict(out, strong_scaling_cfg5={"error": f"side blocks did not finish within {side_timeout:.0f} s"}, in_process_host_to_host=None, cpu_baseline=None))
+
+        def side_watchdog():
+            if not side_done.wait(side_timeout):
+                if rank == 0:
+                    print(fallback_line, flush=True)
+                os._exit(0)
+
+        threading.Thread(target=side_watchdog, daemon=True).start()
 
         side = copy.copy(args)
         side.steps, side.warmup, side.repeats, side.preheat_ms = min(args.steps, 50), min(args.warmup, 10), min(args.repeats, 3), min(args.preheat_ms, 100.0)
@@ -627,18 +655,7 @@ def main():
             out["in_process_host_to_host"] = None
         if dist is not None:
             dist.barrier()
-
-    seq_file = ROOT / "profiles" / "pmc_traffic_sequence.json"
-    if seq_file.exists() and not args.dry_run:
-        try:
-            sj = json.loads(seq_file.read_text()).get("cfg2seq" if integer else "cfg2seq_fp32", {})
-            cb = out["roofline"]["cold_batched"]
-            if sj.get("kernel_family", "") == cb["kernel"] and sj.get("frames_per_launch") == SEQUENCE_FRAMES and sj.get("traffic_bytes_per_launch"):
-                cb["traffic"] = sj["traffic_bytes_per_launch"]
-                cb["traffic_source"] = ("profiles/pmc_traffic_sequence.json (tests/tools/seq_evidence.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
-                                        "`stream_sweep.py run cfg2seq`, the same launches and nothing else; not measured in this run)")
-        except Exception:
-            pass
+        side_done.set()
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:

@@ -13,8 +13,8 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _bench(args, launcher_ranks=None, timeout=600):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+def _bench(args, launcher_ranks=None, timeout=600, extra_env=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(extra_env or {}))
     if launcher_ranks:  # the driver's way: torch.distributed.run starts the ranks
         import socket
 
@@ -74,3 +74,14 @@ def test_launcher_world_overrides_the_flag():
     """`--gpus 2` under a launcher that started 3 ranks: the line reports the ranks that ran."""
     d = _bench(["--dry-run", "--gpus", "2", "--steps", "10", "--warmup", "1", "--repeats", "1"], 3)
     assert d["n_gpus"] == 3
+
+
+@pytest.mark.parametrize("self_spawn", [True, False])
+def test_side_blocks_cannot_cost_the_headline(self_spawn):
+    """A rank that hangs in the N > 1 side blocks (cfg5 strong scaling, the in-process farm: never yet run on more than one physical GPU):
+    past the timeout rank 0 prints the line it already has, every rank leaves with status 0, stdout still carries exactly one line."""
+    d = _bench(["--dry-run", "--gpus", "2", "--steps", "10", "--warmup", "1", "--repeats", "1"], None if self_spawn else 2, extra_env={"AVIFHIP_BENCH_SIDE_TIMEOUT": "0.001"})
+    assert CONTRACT_KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
+    assert "did not finish" in d["strong_scaling_cfg5"]["error"] and d["in_process_host_to_host"] is None
+    d = _bench(["--dry-run", "--gpus", "2", "--steps", "10", "--warmup", "1", "--repeats", "1"], None if self_spawn else 2, extra_env={"AVIFHIP_BENCH_SIDE_BLOCKS": "0"})
+    assert d["n_gpus"] == 2 and "strong_scaling_cfg5" not in d
