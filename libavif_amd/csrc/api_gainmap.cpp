@@ -70,6 +70,12 @@ struct PhaseTrace
 
 // AVIFHIP_GAINMAP_PLANES=0: the gain map is converted by a launch of its own into an RGBA copy (rounds 2-4) even where the fast apply kernel
 // could read its planes (tests and A/B measurements run both)
+
+// tls.gainMapPartials, pinned: the apply kernel's statistics (kGainMapMaxGroups partials of 16 bytes) and what the computation fetches between
+// its passes -- kGainMapMaxGroups x 8 floats of partials, at most 3 x 10 000 histogram counters (round 6: those downloads went into pageable
+// vectors, through the runtime's staging copy)
+static constexpr size_t kGainMapPinnedBytes = (size_t)kGainMapMaxGroups * 8 * sizeof(float);
+static_assert(kGainMapPinnedBytes >= (size_t)kGainMapMaxGroups * sizeof(GainMapPartial) && kGainMapPinnedBytes >= (size_t)3 * 10240 * sizeof(uint32_t), "pinned buffer size");
 bool gainPlanesDisabled()
 {
     const char * e = getenv("AVIFHIP_GAINMAP_PLANES");
@@ -486,7 +492,7 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         return e && !strcmp(e, "host");
     }();
     if (!tls.gainMapPartials)
-        HIP_TRY(hipHostMalloc(&tls.gainMapPartials, (size_t)kGainMapMaxGroups * sizeof(GainMapPartial), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&tls.gainMapPartials, kGainMapPinnedBytes, hipHostMallocDefault));
     if (partialsOnHost) {
         A.partials = (GainMapPartial *)tls.gainMapPartials;
     } else {
@@ -1001,14 +1007,19 @@ static avifResult computeGainMapImpl(const avifRGBImage * baseRgbImage, avifColo
         return r;
     A.ratios = (float *)tls.gainMap[7].ptr, A.partials = (float *)tls.gainMap[3].ptr;
     const uint32_t groups = gainMapComputeGroups(width, height);
-    std::vector<float> partials((size_t)groups * 8);
+    if (!tls.gainMapPartials)
+        HIP_TRY(hipHostMalloc(&tls.gainMapPartials, kGainMapPinnedBytes, hipHostMallocDefault));
+    float * const partials = (float *)tls.gainMapPartials; // (groups x 8, fetched after passes 0 and 1; the histograms after pass 2)
+    const size_t partialsBytes = (size_t)groups * 8 * sizeof(float);
+    if (partialsBytes > kGainMapPinnedBytes)
+        return AVIF_RESULT_UNKNOWN_ERROR;
 
     // ---- pass 0: offsets that keep the converted side's channels positive, :618-660 ----
     if (colorSpacesDiffer) {
         hipError_t e = launchGainMapChannelMin(A, stream);
         if (e != hipSuccess)
             return hipFailed(e, "gain map channel-minimum kernel launch");
-        HIP_TRY(hipMemcpyAsync(partials.data(), A.partials, partials.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(partials, A.partials, partialsBytes, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         float channelMin[3] = { 0.0f, 0.0f, 0.0f };
         trace.mark("minima");
@@ -1036,7 +1047,7 @@ static avifResult computeGainMapImpl(const avifRGBImage * baseRgbImage, avifColo
         hipError_t e = launchGainMapRatios(A, stream);
         if (e != hipSuccess)
             return hipFailed(e, "gain map ratio kernel launch");
-        HIP_TRY(hipMemcpyAsync(partials.data(), A.partials, partials.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(partials, A.partials, partialsBytes, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         trace.mark("ratios");
     }
@@ -1095,13 +1106,15 @@ static avifResult computeGainMapImpl(const avifRGBImage * baseRgbImage, avifColo
         const hipError_t e = launchGainMapHistogram(A.ratios, numPixels, channels, stepTables, histograms, stream);
         if (e != hipSuccess)
             return hipFailed(e, "gain map histogram kernel launch");
-        std::vector<uint32_t> hostHistograms(histogramTotal);
-        HIP_TRY(hipMemcpyAsync(hostHistograms.data(), tls.gainMap[8].ptr, histogramTotal * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        if (histogramTotal * sizeof(uint32_t) > kGainMapPinnedBytes)
+            return AVIF_RESULT_UNKNOWN_ERROR; // (the reference caps a histogram at 10 000 buckets, src/gainmap.c:393)
+        const uint32_t * const hostHistograms = (const uint32_t *)tls.gainMapPartials;
+        HIP_TRY(hipMemcpyAsync(tls.gainMapPartials, tls.gainMap[8].ptr, histogramTotal * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         trace.mark("histograms");
         for (int c = 0; c < channels; ++c)
             if (ranges[c].numBuckets > 0)
-                gainMapRangeWithoutOutliers(ranges[c], hostHistograms.data() + histogramOffset[c], &minLog2[c], &maxLog2[c]);
+                gainMapRangeWithoutOutliers(ranges[c], hostHistograms + histogramOffset[c], &minLog2[c], &maxLog2[c]);
     }
     for (int c = 0; c < 3; ++c) { // metadata, :751-760
         const int k = singleChannel ? 0 : c;
