@@ -316,11 +316,13 @@ avifResult uploadTableAsync(void * deviceDst, const void * hostSrc, size_t bytes
         if (tls.pinnedUpload) {
             for (int k = 0; k < kRing; ++k)
                 HIP_TRY(hipEventSynchronize(tls.uploadCopied[k]));
+            AVIFHIP_HOST_MEMORY_FREED(tls.pinnedUpload);
             HIP_TRY(hipHostFree(tls.pinnedUpload));
         }
         tls.pinnedUpload = nullptr, tls.pinnedUploadCapacity = 0;
         const size_t rounded = (bytes + 16383) & ~(size_t)16383;
         HIP_TRY(hipHostMalloc(&tls.pinnedUpload, rounded * kRing, hipHostMallocDefault));
+        AVIFHIP_NEW_HOST_MEMORY(tls.pinnedUpload, rounded * kRing);
         tls.pinnedUploadCapacity = rounded;
     }
     const uint32_t slot = tls.uploadSlot++ % (uint32_t)kRing;

@@ -42,6 +42,7 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         if (tls.pinnedTable) {
             for (int k = 0; k < kRing; ++k)
                 HIP_TRY(hipEventSynchronize(tls.tableCopied[k]));
+            AVIFHIP_HOST_MEMORY_FREED(tls.pinnedTable);
             HIP_TRY(hipHostFree(tls.pinnedTable));
             tls.pinnedTable = nullptr;
             tls.pinnedTableCapacity = 0;
@@ -50,6 +51,7 @@ static avifResult batchAsyncImpl(uint32_t count, const avifImage * const * image
         }
         const size_t slotBytes = (bytes + 4095) & ~(size_t)4095;
         HIP_TRY(hipHostMalloc(&tls.pinnedTable, slotBytes * kRing, hipHostMallocDefault));
+        AVIFHIP_NEW_HOST_MEMORY(tls.pinnedTable, slotBytes * kRing);
         tls.pinnedTableCapacity = slotBytes;
     }
     uint32_t slot = tls.tableSlot++ % (uint32_t)kRing;

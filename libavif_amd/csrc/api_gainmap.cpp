@@ -74,7 +74,7 @@ struct PhaseTrace
 // tls.gainMapPartials, pinned: the apply kernel's statistics (kGainMapMaxGroups partials of 16 bytes) and what the computation fetches between
 // its passes -- kGainMapMaxGroups x 8 floats of partials, at most 3 x 10 000 histogram counters (round 6: those downloads went into pageable
 // vectors, through the runtime's staging copy)
-static constexpr size_t kGainMapPinnedBytes = (size_t)kGainMapMaxGroups * 8 * sizeof(float);
+static constexpr size_t kGainMapPinnedBytes = (size_t)kGainMapMaxGroups * 16 * sizeof(float); // (pass 1's partials and pass 0's behind them)
 static_assert(kGainMapPinnedBytes >= (size_t)kGainMapMaxGroups * sizeof(GainMapPartial) && kGainMapPinnedBytes >= (size_t)3 * 10240 * sizeof(uint32_t), "pinned buffer size");
 bool gainPlanesDisabled()
 {
@@ -491,8 +491,10 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
         const char * e = getenv("AVIFHIP_GM_PARTIALS");
         return e && !strcmp(e, "host");
     }();
-    if (!tls.gainMapPartials)
+    if (!tls.gainMapPartials) {
         HIP_TRY(hipHostMalloc(&tls.gainMapPartials, kGainMapPinnedBytes, hipHostMallocDefault));
+        AVIFHIP_NEW_HOST_MEMORY(tls.gainMapPartials, kGainMapPinnedBytes);
+    }
     if (partialsOnHost) {
         A.partials = (GainMapPartial *)tls.gainMapPartials;
     } else {
@@ -548,8 +550,10 @@ avifResult applyGainMapOnDevice(const avifRGBImage * base, avifColorPrimaries ba
     // kernel's precondition rules the NaN result out, so the result code is known now)
     if (mayReturnEarly && applyGain && A.fast && clli && !exactLevels && !partialsOnHost && partials && tls.gainMapTimeIters <= 0) {
         const uint32_t slot = tls.lightSlot++ % (uint32_t)Context::kLightSlots;
-        if (!tls.lightPinned[slot])
+        if (!tls.lightPinned[slot]) {
             HIP_TRY(hipHostMalloc(&tls.lightPinned[slot], (size_t)kGainMapMaxGroups * sizeof(GainMapPartial), hipHostMallocDefault));
+            AVIFHIP_NEW_HOST_MEMORY(tls.lightPinned[slot], (size_t)kGainMapMaxGroups * sizeof(GainMapPartial));
+        }
         if (!tls.lightCopied[slot])
             HIP_TRY(hipEventCreateWithFlags(&tls.lightCopied[slot], hipEventDisableTiming));
         if (tls.lightPending[slot].pending) { // the call of kLightSlots calls ago has not been settled: its clli is filled now (waits for its copy)
@@ -1003,52 +1007,81 @@ static avifResult computeGainMapImpl(const avifRGBImage * baseRgbImage, avifColo
     A.baseLut = deviceTables, A.altLut = deviceTables + altLutOffset;
     A.baseLutEntries = (uint32_t)altLutOffset, A.altLutEntries = (uint32_t)(tables.size() - altLutOffset);
     if ((r = reserve(tls.gainMap[7], (size_t)channels * numPixels * sizeof(float))) != AVIF_RESULT_OK ||
-        (r = reserve(tls.gainMap[3], (size_t)kGainMapMaxGroups * 8 * sizeof(float))) != AVIF_RESULT_OK)
+        (r = reserve(tls.gainMap[3], ((size_t)kGainMapMaxGroups * 16 + 8) * sizeof(float))) != AVIF_RESULT_OK)
         return r;
     A.ratios = (float *)tls.gainMap[7].ptr, A.partials = (float *)tls.gainMap[3].ptr;
     const uint32_t groups = gainMapComputeGroups(width, height);
-    if (!tls.gainMapPartials)
+    if (!tls.gainMapPartials) {
         HIP_TRY(hipHostMalloc(&tls.gainMapPartials, kGainMapPinnedBytes, hipHostMallocDefault));
+        AVIFHIP_NEW_HOST_MEMORY(tls.gainMapPartials, kGainMapPinnedBytes);
+    }
     float * const partials = (float *)tls.gainMapPartials; // (groups x 8, fetched after passes 0 and 1; the histograms after pass 2)
     const size_t partialsBytes = (size_t)groups * 8 * sizeof(float);
-    if (partialsBytes > kGainMapPinnedBytes)
+    if (2 * partialsBytes > kGainMapPinnedBytes)
         return AVIF_RESULT_UNKNOWN_ERROR;
 
-    // ---- pass 0: offsets that keep the converted side's channels positive, :618-660 ----
-    if (colorSpacesDiffer) {
-        hipError_t e = launchGainMapChannelMin(A, stream);
-        if (e != hipSuccess)
-            return hipFailed(e, "gain map channel-minimum kernel launch");
-        HIP_TRY(hipMemcpyAsync(partials, A.partials, partialsBytes, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+    // ---- pass 0: offsets that keep the converted side's channels positive, :618-660; pass 1: ratios, maxima, extreme ratios, :662-715 ----
+    // One wait for both (round 6): pass 0 leaves its minima behind pass 1's partials, one workgroup folds them into the offsets pass 1 reads
+    // (kernels_gainmap.hip gainMapOffsetsKernel); the host repeats the fold -- in the reference's order, with its AVIF_MIN -- for the metadata, and runs pass 1 again
+    // with its own offsets in the one case the two folds can differ (a NaN among the minima).
+    A.offsets = nullptr;
+    for (int c = 0; c < 3; ++c)
+        A.baseOffset[c] = baseOffset[c], A.altOffset[c] = altOffset[c];
+    auto foldMinima = [&](const float * minima, bool referenceOrder, float base[3], float alt[3]) {
         float channelMin[3] = { 0.0f, 0.0f, 0.0f };
-        trace.mark("minima");
         for (uint32_t g = 0; g < groups; ++g)
-            for (int c = 0; c < 3; ++c)
-                channelMin[c] = (channelMin[c] < partials[(size_t)g * 8 + c]) ? channelMin[c] : partials[(size_t)g * 8 + c];
+            for (int c = 0; c < 3; ++c) {
+                const float p = minima[(size_t)g * 8 + c];
+                channelMin[c] = referenceOrder ? ((channelMin[c] < p) ? channelMin[c] : p) : fminf(channelMin[c], p);
+            }
         for (int c = 0; c < 3; ++c) {
             const float maxOffset = 0.1f;
             if (channelMin[c] < -1e-10f) {
                 if (gainMap->useBaseColorSpace) {
-                    const float o = altOffset[c] - channelMin[c];
-                    altOffset[c] = (o < maxOffset) ? o : maxOffset;
+                    const float o = alt[c] - channelMin[c];
+                    alt[c] = (o < maxOffset) ? o : maxOffset;
                 } else {
-                    const float o = baseOffset[c] - channelMin[c];
-                    baseOffset[c] = (o < maxOffset) ? o : maxOffset;
+                    const float o = base[c] - channelMin[c];
+                    base[c] = (o < maxOffset) ? o : maxOffset;
                 }
             }
         }
-    }
-    for (int c = 0; c < 3; ++c)
-        A.baseOffset[c] = baseOffset[c], A.altOffset[c] = altOffset[c];
-
-    // ---- pass 1: ratios, maxima, extreme ratios, :662-715 ----
+    };
     {
+        float * const deviceMinima = A.partials + (size_t)groups * 8;
+        if (colorSpacesDiffer) {
+            GainMapComputeArgs A0 = A;
+            A0.partials = deviceMinima;
+            const hipError_t e = launchGainMapChannelMin(A0, stream);
+            if (e != hipSuccess)
+                return hipFailed(e, "gain map channel-minimum kernel launch");
+            float * const deviceOffsets = deviceMinima + (size_t)groups * 8;
+            const hipError_t f = launchGainMapOffsets(deviceMinima, groups, gainMap->useBaseColorSpace != 0, baseOffset, altOffset, deviceOffsets, stream);
+            if (f != hipSuccess)
+                return hipFailed(f, "gain map offsets kernel launch");
+            A.offsets = deviceOffsets;
+        }
         hipError_t e = launchGainMapRatios(A, stream);
         if (e != hipSuccess)
             return hipFailed(e, "gain map ratio kernel launch");
-        HIP_TRY(hipMemcpyAsync(partials, A.partials, partialsBytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(partials, A.partials, partialsBytes * (colorSpacesDiffer ? 2 : 1), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        trace.mark("minima");
+        if (colorSpacesDiffer) {
+            float deviceBase[3] = { baseOffset[0], baseOffset[1], baseOffset[2] }, deviceAlt[3] = { altOffset[0], altOffset[1], altOffset[2] };
+            foldMinima(partials + (size_t)groups * 8, false, deviceBase, deviceAlt);
+            foldMinima(partials + (size_t)groups * 8, true, baseOffset, altOffset);
+            A.offsets = nullptr;
+            for (int c = 0; c < 3; ++c)
+                A.baseOffset[c] = baseOffset[c], A.altOffset[c] = altOffset[c];
+            if (memcmp(deviceBase, baseOffset, sizeof(deviceBase)) != 0 || memcmp(deviceAlt, altOffset, sizeof(deviceAlt)) != 0) {
+                e = launchGainMapRatios(A, stream); // (the kernel's fold dropped a NaN the reference's lets through)
+                if (e != hipSuccess)
+                    return hipFailed(e, "gain map ratio kernel launch");
+                HIP_TRY(hipMemcpyAsync(partials, A.partials, partialsBytes, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
+        }
         trace.mark("ratios");
     }
     float baseMax = 1.0f, altMax = 1.0f, minRatio[3] = { INFINITY, INFINITY, INFINITY }, maxRatio[3] = { 0.0f, 0.0f, 0.0f };

@@ -23,6 +23,24 @@
 #include "plan.h"
 #include "scale_plan.h"
 
+// Pinned host memory comes from the (uninstrumented) HIP runtime: when it hands a block one thread's context freed to another thread's context,
+// ThreadSanitizer has not seen the allocator's own synchronisation between the free and the allocation, still holds the previous owner's
+// accesses for those addresses, and reports the new owner's first write as a race (profiles/r06_tsan.txt: two contexts' upload rings, the
+// smaller of which had just been replaced by a larger one).  The `make tsan` build says what an allocator it could see would have said:
+// everything before the free happens before everything after the allocation that returns the same address.
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+extern "C" void AnnotateHappensBefore(const char * file, int line, const volatile void * address);
+extern "C" void AnnotateHappensAfter(const char * file, int line, const volatile void * address);
+#define AVIFHIP_HOST_MEMORY_FREED(p) AnnotateHappensBefore(__FILE__, __LINE__, (p))
+#define AVIFHIP_NEW_HOST_MEMORY(p, n) AnnotateHappensAfter(__FILE__, __LINE__, (p))
+#endif
+#endif
+#ifndef AVIFHIP_NEW_HOST_MEMORY
+#define AVIFHIP_HOST_MEMORY_FREED(p) ((void)0)
+#define AVIFHIP_NEW_HOST_MEMORY(p, n) ((void)0)
+#endif
+
 namespace avifhip {
 namespace api {
 
@@ -215,17 +233,17 @@ struct Context
             if (g.ptr)
                 (void)hipFree(g.ptr);
         if (gainMapPartials)
-            (void)hipHostFree(gainMapPartials);
+            AVIFHIP_HOST_MEMORY_FREED(gainMapPartials), (void)hipHostFree(gainMapPartials);
         for (int k = 0; k < kLightSlots; ++k) { // (pending light levels of a thread that ends without synchronising are dropped: its clli may be gone)
             if (lightCopied[k]) {
                 (void)hipEventSynchronize(lightCopied[k]);
                 (void)hipEventDestroy(lightCopied[k]);
             }
             if (lightPinned[k])
-                (void)hipHostFree(lightPinned[k]);
+                AVIFHIP_HOST_MEMORY_FREED(lightPinned[k]), (void)hipHostFree(lightPinned[k]);
         }
         if (pinnedTable)
-            (void)hipHostFree(pinnedTable);
+            AVIFHIP_HOST_MEMORY_FREED(pinnedTable), (void)hipHostFree(pinnedTable);
         for (int k = 0; k < kTableRing; ++k) {
             if (tableCopied[k])
                 (void)hipEventDestroy(tableCopied[k]);
@@ -233,7 +251,7 @@ struct Context
                 (void)hipEventDestroy(tableConsumed[k]);
         }
         if (pinnedUpload)
-            (void)hipHostFree(pinnedUpload);
+            AVIFHIP_HOST_MEMORY_FREED(pinnedUpload), (void)hipHostFree(pinnedUpload);
         for (int k = 0; k < kTableRing; ++k)
             if (uploadCopied[k])
                 (void)hipEventDestroy(uploadCopied[k]);

@@ -527,8 +527,14 @@ inline int bucketOfValue(float v, float lo, float hi, int n) // avifValueToBucke
 }
 
 // T[i] = smallest r in [minRatio, maxRatio] (fp32 order) with m(r) >= i, for i = 1 .. count - 1; m non-decreasing.  `guess(i)`
-// is an estimate of T[i] (any float): the search brackets the step by galloping away from it before bisecting, which costs ~10
-// evaluations of m instead of 32 when the estimate is good; correctness never depends on it.
+// is an estimate of T[i] (any float): the search brackets the step by galloping away from it before bisecting, which costs 3-4
+// evaluations of m instead of 32 when the estimate is good; correctness never depends on it.  The gallop starts two keys from the
+// estimate and quadruples (round 6: it started 64 keys away -- 8-9 evaluations per step, and the three channels' bucket and code tables
+// were ~250 us of the device-resident computation's 490 us on the host between its passes; same tables, tests/tools/hostlogic.cpp)
+#ifndef AVIFHIP_GALLOP_START
+#define AVIFHIP_GALLOP_START 2
+#endif
+constexpr uint32_t kGallopStart = AVIFHIP_GALLOP_START;
 template <typename Fn, typename Guess>
 std::vector<float> monotoneSteps(float minRatio, float maxRatio, uint32_t count, uint32_t entries, Fn m, Guess guess)
 {
@@ -548,7 +554,7 @@ std::vector<float> monotoneSteps(float minRatio, float maxRatio, uint32_t count,
             k = k < lo ? lo : (k > hi ? hi : k);
             if (m(floatOfKey(k)) >= i) { // gallop down to a key with m < i
                 hi = k;
-                for (uint32_t step = 64; hi > lo; step <<= 2) {
+                for (uint32_t step = kGallopStart; hi > lo; step <<= 2) {
                     const uint32_t probe = (hi - lo > step) ? hi - step : lo;
                     if (m(floatOfKey(probe)) >= i) {
                         hi = probe;
@@ -561,7 +567,7 @@ std::vector<float> monotoneSteps(float minRatio, float maxRatio, uint32_t count,
                 }
             } else { // gallop up to a key with m >= i
                 lo = k + 1;
-                for (uint32_t step = 64; lo < hi; step <<= 2) {
+                for (uint32_t step = kGallopStart; lo < hi; step <<= 2) {
                     const uint32_t probe = (hi - lo > step) ? lo + step : hi;
                     if (m(floatOfKey(probe)) >= i) {
                         hi = probe;

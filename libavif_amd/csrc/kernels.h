@@ -277,10 +277,17 @@ struct GainMapComputeArgs
     float baseOffset[3], altOffset[3];
     float * ratios;   // channels x width*height: max((alt + offset) / (base + offset), 1e-10), :711-712
     float * partials; // kGainMapMaxGroups x 8 floats, see the kernels
+    // pass 1 can take its offsets from device memory -- no host round trip between passes 0 and 1 (round 6): `offsets` = the six floats
+    // launchGainMapOffsets left (base x 3, alternate x 3); nullptr: baseOffset / altOffset above are final
+    const float * offsets;
 };
 // pass 0 (only when the primaries differ): per-workgroup minima of the converted side's channels, min(0, .), :624-645.
 // partials[g * 8 + c], c < 3
 hipError_t launchGainMapChannelMin(const GainMapComputeArgs & args, hipStream_t stream);
+// between the two: pass 0's partials (`groups` x 8 floats) folded into the offsets that keep the converted side's channels positive (:646-660), by
+// one workgroup: out[0..2] = base offsets, out[3..5] = alternate offsets, starting from `base` / `alt`.  The fold drops NaN partials (fminf) where
+// the reference's AVIF_MIN lets them through: the host repeats it in the reference's order and runs pass 1 again if the two disagree.
+hipError_t launchGainMapOffsets(const float * minima, uint32_t groups, bool useBaseColorSpace, const float base[3], const float alt[3], float * out, hipStream_t stream);
 // pass 1: ratios + per-workgroup [baseMax, altMax (both >= 1, :663-664), minRatio[3], maxRatio[3]]
 hipError_t launchGainMapRatios(const GainMapComputeArgs & args, hipStream_t stream);
 struct GainMapStepTable

@@ -893,6 +893,44 @@ __global__ __launch_bounds__(256) void gainMapChannelMinKernel(GainMapComputeArg
     blockReduceStore<3>(mn, isMax, A.partials + (size_t)blockIdx.x * 8);
 }
 
+// between passes 0 and 1: the offsets that keep the converted side's channels positive (src/gainmap.c:646-660) from pass 0's minima, by one
+// workgroup (a few thousand floats), so that pass 1 can follow pass 0 without the host in between
+struct GainMapOffsetsArgs
+{
+    const float * minima;
+    uint32_t groups;
+    int32_t useBaseColorSpace;
+    float base[3], alt[3];
+    float * out;
+};
+__global__ __launch_bounds__(256) void gainMapOffsetsKernel(GainMapOffsetsArgs A)
+{
+    float mn[3] = { 0.0f, 0.0f, 0.0f };
+    for (uint32_t g = threadIdx.x; g < A.groups; g += 256)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            mn[c] = fminf(mn[c], A.minima[(size_t)g * 8 + c]);
+    const bool isMax[3] = { false, false, false };
+    __shared__ float folded[3];
+    blockReduceStore<3>(mn, isMax, folded);
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = (int)threadIdx.x;
+        const float channelMin = folded[c], maxOffset = 0.1f;
+        float base = A.base[c], alt = A.alt[c];
+        if (channelMin < -1e-10f) {
+            if (A.useBaseColorSpace) {
+                const float o = alt - channelMin;
+                alt = (o < maxOffset) ? o : maxOffset;
+            } else {
+                const float o = base - channelMin;
+                base = (o < maxOffset) ? o : maxOffset;
+            }
+        }
+        A.out[c] = base, A.out[3 + c] = alt;
+    }
+}
+
 // pass 1: ratios + per-workgroup [baseMax, altMax, minRatio x 3, maxRatio x 3]
 template <bool LDSLUT, int CHANNELS, int FAST> // FAST: 0 -- any layout; 4 / 8 -- whole 16-byte runs, the alternate image's pixels of 4 / 8 bytes
 __global__ __launch_bounds__(256) void gainMapRatioKernel(GainMapComputeArgs A)
@@ -905,6 +943,13 @@ __global__ __launch_bounds__(256) void gainMapRatioKernel(GainMapComputeArgs A)
     constexpr int channels = CHANNELS; // 1: A.singleChannel (a compile-time count keeps the per-channel arrays in registers)
     const bool vectorStores = (A.width & 3u) == 0; // (every plane of the ratio buffer then starts on 16 bytes, and so does every lane's run)
     float acc[8] = { 1.0f, 1.0f, __builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f, 0.0f, 0.0f };
+    // (the offsets may come from device memory: gainMapOffsetsKernel folded pass 0's minima while the host did not wait)
+    float baseOffset[3] = { A.baseOffset[0], A.baseOffset[1], A.baseOffset[2] }, altOffset[3] = { A.altOffset[0], A.altOffset[1], A.altOffset[2] };
+    if (A.offsets) { // (a kernel argument: uniform over the launch; six scalar loads)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            baseOffset[c] = A.offsets[c], altOffset[c] = A.offsets[3 + c];
+    }
     // what a lane does with the codes of its (up to) four pixels at (i .. i + n - 1, j)
     auto process = [&](uint32_t j, uint32_t i, uint32_t n, const uint32_t (&bc)[4][3], const uint32_t (&ac)[4][3]) {
         float ratio[CHANNELS][4];
@@ -924,7 +969,7 @@ __global__ __launch_bounds__(256) void gainMapRatioKernel(GainMapComputeArgs A)
                     base = A.yCoeffs[0] * b[0] + A.yCoeffs[1] * b[1] + A.yCoeffs[2] * b[2];
                     alt = A.yCoeffs[0] * a[0] + A.yCoeffs[1] * a[1] + A.yCoeffs[2] * a[2];
                 }
-                const float q = (alt + A.altOffset[c]) / (base + A.baseOffset[c]);
+                const float q = (alt + altOffset[c]) / (base + baseOffset[c]);
                 const float r = (q > 1e-10f) ? q : 1e-10f; // AVIF_MAX(ratio, kEpsilon): NaN -> epsilon
                 ratio[c][k] = r;
                 if (live) {
@@ -1368,6 +1413,13 @@ hipError_t launchGainMapChannelMin(const GainMapComputeArgs & A, hipStream_t str
         hipLaunchKernelGGL(gainMapChannelMinKernel<true>, dim3(groups), dim3(256), (A.baseLutEntries + A.altLutEntries) * sizeof(float), stream, A);
     else
         hipLaunchKernelGGL(gainMapChannelMinKernel<false>, dim3(groups), dim3(256), 0, stream, A);
+    return hipGetLastError();
+}
+
+hipError_t launchGainMapOffsets(const float * minima, uint32_t groups, bool useBaseColorSpace, const float base[3], const float alt[3], float * out, hipStream_t stream)
+{
+    GainMapOffsetsArgs A = { minima, groups, useBaseColorSpace ? 1 : 0, { base[0], base[1], base[2] }, { alt[0], alt[1], alt[2] }, out };
+    hipLaunchKernelGGL(gainMapOffsetsKernel, dim3(1), dim3(256), 0, stream, A);
     return hipGetLastError();
 }
 

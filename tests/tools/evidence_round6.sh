@@ -2,6 +2,7 @@
 # evidence_round6.sh [tag] -- round 6's committed figures from ONE box (run via gpurun; everything lands in gpurun_out/, copy what is to be judged into profiles/):
 #   <tag>_bench_*                bench.py --headline-only under rocprofv3 --kernel-trace --stats, the HBM-traffic passes, the SQ counter passes (profile_round.sh)
 #   <tag>_bench_line_*.json      bench.py as the driver runs it (default flags; --steps 20 --warmup 5), and with every multi-GPU block on a one-GPU box
+#   <tag>_4k_rows.jsonl         cfg_bench.py's 4K rows without the profiler (what the bench line's planes_4k block is compared with)
 #   <tag>_sequence.txt / .json   sequence launches and their one-frame-per-launch twins in the HBM regime: HIP events, rocprofv3 averages, FETCH / WRITE traffic (seq_evidence.sh)
 #   <tag>_cfgs_*                 cfg_bench.py configurations, each run once under rocprofv3 (event-timed row and profiler average from the same launches)
 #   <tag>_gainmap_compute.txt    the gain-map computation's kernels (device-resident call), <tag>_gainmap_pmc.txt the apply kernel's counters
@@ -18,6 +19,11 @@ bash tests/tools/profile_round.sh "$TAG" > "gpurun_out/${TAG}_profile_round.log"
 python bench.py > "gpurun_out/${TAG}_bench_line_default_run.json" 2> "gpurun_out/${TAG}_bench_default.err"
 python bench.py --steps 20 --warmup 5 > "gpurun_out/${TAG}_bench_line_driver_flags.json" 2>> "gpurun_out/${TAG}_bench_default.err"
 AVIFHIP_BENCH_ALL_BLOCKS=1 AVIFHIP_BENCH_DEVICES=0,0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "gpurun_out/${TAG}_bench_line_all_blocks_one_gpu.json" 2>> "gpurun_out/${TAG}_bench_default.err"
+fi
+if want bench; then
+# the 4K rows WITHOUT the profiler (the configuration table below times its rows under rocprofv3, whose interception adds up to a microsecond to
+# launches this short: table and bench line are compared on these -- VERDICT r05 item 7)
+python tests/tools/cfg_bench.py cfg2_4k cfg2_4k_cold cfg2_4k_seq cfg2_4k_seq_cold 2>/dev/null | grep '^{' > "gpurun_out/${TAG}_4k_rows.jsonl"
 fi
 if want seq; then
 bash tests/tools/seq_evidence.sh "$TAG" > "gpurun_out/${TAG}_seq_evidence.log" 2>&1

@@ -30,7 +30,7 @@ for c in sys.argv[2:]:
     except OSError:
         pass
     print(f"   {'kernel':118s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s}")
-    for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1]))[:4]:
+    for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1]))[:6]:
         print(f"   {k[:118]:118s} {len(v):6d} {sum(v)/len(v)/1e3:9.2f} {min(v)/1e3:9.2f} {max(v)/1e3:9.2f}")
 PY
 find "$OUT" -name "*.db" -delete
