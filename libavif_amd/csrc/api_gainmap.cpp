@@ -994,8 +994,19 @@ static avifResult computeGainMapImpl(const avifRGBImage * baseRgbImage, avifColo
     std::vector<float> tables = gainMapLinearLut(baseTransferCharacteristics, baseRgbImage->depth, baseRgbImage->isFloat != 0);
     const size_t altLutOffset = tables.size();
     {
-        const std::vector<float> alt = gainMapLinearLut(altTransferCharacteristics, altRgbImage->depth, altRgbImage->isFloat != 0);
+        const std::vector<float> & alt = gainMapLinearLut(altTransferCharacteristics, altRgbImage->depth, altRgbImage->isFloat != 0);
         tables.insert(tables.end(), alt.begin(), alt.end());
+    }
+    // Pass 0 looks for negative channels on the converted side (:618-660).  Where every coefficient of the conversion and every entry of that
+    // side's linear-light table is >= 0, every product and every sum is, the minimum the pass would find is the 0 it starts from, and the
+    // offsets stay as they are: the pass is not run (BT.709 or P3 into BT.2020 -- the math space is the wider gamut -- is such a conversion).
+    bool minimaAreZero = colorSpacesDiffer;
+    if (colorSpacesDiffer) {
+        for (int k = 0; k < 9; ++k)
+            minimaAreZero = minimaAreZero && A.M[k] >= 0.0;
+        const size_t first = A.convertAlt ? altLutOffset : 0, last = A.convertAlt ? tables.size() : altLutOffset;
+        for (size_t k = first; k < last && minimaAreZero; ++k)
+            minimaAreZero = tables[k] >= 0.0f; // (a NaN entry fails the comparison too)
     }
     // room for the step tables that follow (3 channels x at most 65536 entries)
     const size_t stepsOffset = (tables.size() + 3) & ~(size_t)3, stepsCapacity = (size_t)3 * 65536;
@@ -1049,7 +1060,8 @@ static avifResult computeGainMapImpl(const avifRGBImage * baseRgbImage, avifColo
     };
     {
         float * const deviceMinima = A.partials + (size_t)groups * 8;
-        if (colorSpacesDiffer) {
+        const bool runPass0 = colorSpacesDiffer && !minimaAreZero;
+        if (runPass0) {
             GainMapComputeArgs A0 = A;
             A0.partials = deviceMinima;
             const hipError_t e = launchGainMapChannelMin(A0, stream);
@@ -1064,10 +1076,10 @@ static avifResult computeGainMapImpl(const avifRGBImage * baseRgbImage, avifColo
         hipError_t e = launchGainMapRatios(A, stream);
         if (e != hipSuccess)
             return hipFailed(e, "gain map ratio kernel launch");
-        HIP_TRY(hipMemcpyAsync(partials, A.partials, partialsBytes * (colorSpacesDiffer ? 2 : 1), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(partials, A.partials, partialsBytes * (runPass0 ? 2 : 1), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         trace.mark("minima");
-        if (colorSpacesDiffer) {
+        if (runPass0) {
             float deviceBase[3] = { baseOffset[0], baseOffset[1], baseOffset[2] }, deviceAlt[3] = { altOffset[0], altOffset[1], altOffset[2] };
             foldMinima(partials + (size_t)groups * 8, false, deviceBase, deviceAlt);
             foldMinima(partials + (size_t)groups * 8, true, baseOffset, altOffset);

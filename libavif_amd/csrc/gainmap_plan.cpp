@@ -371,14 +371,23 @@ void buildLocator(GainMapSteps & S, bool isFloat)
 
 } // namespace
 
-std::vector<float> gainMapLinearLut(int tc, uint32_t depth, bool isFloat)
+// (a function of its three arguments only: built once per process and kept -- two powf per entry, ~80 us of every computation call for an
+//  8-bit / 10-bit pair until round 6)
+const std::vector<float> & gainMapLinearLut(int tc, uint32_t depth, bool isFloat)
 {
+    static std::mutex mutex;
+    static std::map<uint32_t, std::vector<float>> cache;
+    const uint32_t key = ((uint32_t)tc << 16) | (depth << 1) | (isFloat ? 1u : 0u);
+    std::lock_guard<std::mutex> lock(mutex);
+    auto it = cache.find(key);
+    if (it != cache.end())
+        return it->second;
     const uint32_t n = isFloat ? 65536u : (1u << depth);
     std::vector<float> lut(n);
     const float maxF = (float)((1u << depth) - 1);
     for (uint32_t v = 0; v < n; ++v)
         lut[v] = gainMapToLinear(tc, isFloat ? f16ToFloat(v) : (float)v / maxF); // avifGetRGBAPixel, src/reformat.c:1857-1888
-    return lut;
+    return cache.emplace(key, std::move(lut)).first->second; // (map nodes stay where they are: the reference outlives the lock)
 }
 
 std::vector<float> gainMapGainLut(uint32_t depth, float gammaInv, float minLog2, float maxLog2, float weight)

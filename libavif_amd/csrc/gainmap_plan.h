@@ -28,7 +28,7 @@ float gainMapToGamma(int transferCharacteristics, float linear);
 bool gainMapPrimariesMatrix(int srcPrimaries, int dstPrimaries, double coeffs[9]);
 
 // linear light of every sample code of an image: codes 0 .. 2^depth - 1 (v / max), or the 65536 half-float codes
-std::vector<float> gainMapLinearLut(int transferCharacteristics, uint32_t depth, bool isFloat);
+const std::vector<float> & gainMapLinearLut(int transferCharacteristics, uint32_t depth, bool isFloat); // (cached per process)
 
 // exp2f(lerp(minLog2, maxLog2, powf(v / max, gammaInv)) * weight) for every sample code of the gain map, src/gainmap.c:253-254
 std::vector<float> gainMapGainLut(uint32_t depth, float gammaInv, float minLog2, float maxLog2, float weight);
