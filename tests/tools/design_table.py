@@ -127,3 +127,12 @@ if DAGGER:
     print("† launches shorter than the ~10 µs at which a stream under rocprofv3 (every launch intercepted) issues kernels: the events of these profiled runs "
           "measure the launch rate, the fraction is taken from the kernel's own average duration in the same run (unprofiled, back to back: "
           "`tests/tools/cfg_bench.py` on its own, e.g. cfg4 7.7 µs, cfg4 from RGB8 6.6 µs on round 5's box).")
+
+# the 4K rows without the profiler, from the same call (what the bench line's planes_4k block is compared with: tests/test_profiles_r06.py)
+plain = ROOT / "profiles" / f"{TAG}_4k_rows.jsonl"
+if plain.exists():
+    got = [json.loads(l) for l in plain.read_text().splitlines() if l.startswith("{")]
+    print()
+    print("4K rows WITHOUT the profiler (same box, same call as the bench line; under rocprofv3 a launch this short is slowed by the interception): "
+          + "; ".join(f"{DESC.get(r['config'], r['config']).split(',')[0].split(':')[0]} [{r['config']}] {r['arithmetic'].replace('float', 'fp32')} "
+                      f"{r['us']:.2f} µs = {r['frac_of_8TBps']:.2f}" for r in got) + ".")
