@@ -7,6 +7,7 @@
 
 #include <atomic>
 
+#include "gainmap_steps.h"
 #include "kernels.h"
 #include "pixel_math.h"
 
@@ -1087,24 +1088,8 @@ __device__ __forceinline__ uint32_t stepIndex(const float * steps, uint32_t entr
 __device__ __forceinline__ uint32_t stepIndexGuessed(const float * steps, uint32_t last, float a, float b, float x)
 {
     const float g = a * __log2f(x) + b;
-    uint32_t m = (g >= 0.0f) ? (g < (float)last ? (uint32_t)g : last) : 0u; // (NaN: 0)
-    // The answer is the largest k in [0, last] with steps[k] <= x (0 if there is none; the steps are monotone).  Four steps around the guess,
-    // read side by side -- no loop whose trip count differs from lane to lane, so the eight samples a lane holds keep their table reads in
-    // flight together (round 6: the two correction walks, each iteration an LDS round trip inside divergent control flow, were most of the
-    // histogram and quantiser kernels' time) -- decide every guess that lies within one step below / two above the answer; the walks serve the
-    // rest (a bad guess, a NaN, an infinity).
-    const uint32_t i0 = m - (m != 0u ? 1u : 0u), i2 = min(m + 1u, last), i3 = min(m + 2u, last);
-    const float s0 = steps[i0], s1 = steps[m], s2 = steps[i2], s3 = steps[i3];
-    const bool c0 = m == 0u || s0 <= x, c1 = s1 <= x, c2 = m + 1u <= last && s2 <= x, c3 = m + 2u <= last && s3 <= x;
-    if (__builtin_expect((c3 && m + 2u < last) || (!c0 && m >= 2u), 0)) {
-        while (m < last && steps[m + 1] <= x)
-            ++m;
-        while (m > 0 && !(steps[m] <= x))
-            --m;
-        return m;
-    }
-    const int k = (int)m - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0) + (c3 ? 1 : 0);
-    return (uint32_t)(k < 0 ? 0 : k);
+    const uint32_t m = (g >= 0.0f) ? (g < (float)last ? (uint32_t)g : last) : 0u; // (NaN: 0)
+    return stepIndexFromGuess(steps, last, m, x); // gainmap_steps.h: four steps around the guess decide, the walks serve the rest
 }
 
 struct GainMapStepTables

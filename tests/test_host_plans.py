@@ -21,7 +21,7 @@ SO = ROOT / "tests" / "tools" / "libhostlogic.so"
 @pytest.fixture(scope="module")
 def host():
     srcs = [ROOT / "tests" / "tools" / "hostlogic.cpp", CSRC / "scale_plan.cpp", CSRC / "gainmap_plan.cpp", CSRC / "plan.cpp"]
-    deps = srcs + [CSRC / "scale_plan.h", CSRC / "gainmap_plan.h", CSRC / "plan.h"]
+    deps = srcs + [CSRC / "scale_plan.h", CSRC / "gainmap_plan.h", CSRC / "gainmap_steps.h", CSRC / "plan.h"]
     if not SO.exists() or any(d.stat().st_mtime > SO.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", f"-I{CSRC}", f"-I{ROOT / 'include'}", "-o", os.fspath(SO)] + [os.fspath(s) for s in srcs],
                        check=True, capture_output=True)
@@ -42,6 +42,7 @@ def host():
     lib.hostLocatorCodes.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.hostCheckBucketSteps.restype = C.c_int
     lib.hostCheckBucketSteps.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(C.c_int)]
+    lib.hostCheckStepSearch.restype, lib.hostCheckStepSearch.argtypes = C.c_int, [C.c_int, C.c_uint32]
     lib.hostCheckCodeSteps.restype = C.c_int
     lib.hostCheckCodeSteps.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int, C.c_uint32]
     return lib
@@ -369,3 +370,10 @@ def test_rebound_plans_equal_plans_made_from_scratch(host):
     bad = host.hostCheckRebind(20260922, 20000, C.byref(refused), C.byref(mutated), C.byref(rebound))
     assert bad == 0, bad
     assert rebound.value > 5000 and mutated.value > 1000 and refused.value == mutated.value, (rebound.value, mutated.value, refused.value)
+
+
+def test_kernels_step_search_equals_the_walks(host):
+    """gainmap_steps.h stepIndexFromGuess -- what the histogram and quantiser kernels of the gain-map computation run per sample -- decides a
+    guess from four steps around it; the walks it replaced give the same index on 4 million (table, guess, sample) triples, NaN / infinite
+    samples and wild guesses included.  (The device code is this very function: kernels_gainmap.hip includes the header.)"""
+    assert host.hostCheckStepSearch(20000, 1) == 0 and host.hostCheckStepSearch(2000, 77) == 0

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "gainmap_plan.h"
+#include "gainmap_steps.h"
 #include "plan.h"
 #include "scale_plan.h"
 
@@ -162,6 +163,35 @@ int hostCheckCodeSteps(float sign, float minRatio, float maxRatio, float minLog2
         v = fminf(1.0f, fmaxf(0.0f, v));
         const uint32_t want = (uint32_t)(0.5f + v * (float)maxCode);
         bad += got != want;
+    }
+    return bad;
+}
+
+// The kernels' step search from a guessed index (gainmap_steps.h stepIndexFromGuess: four steps around the guess decide, the walks serve the
+// rest) against the plain walks, on random monotone tables (equal steps, NaN padding behind `last`) with guesses near and far, NaN and
+// infinite samples: mismatches over `trials` tables x 200 samples.
+int hostCheckStepSearch(int trials, uint32_t seed)
+{
+    std::mt19937 rng(seed);
+    auto draw = [&](uint32_t n) { return (uint32_t)(rng() % n); };
+    int bad = 0;
+    for (int t = 0; t < trials; ++t) {
+        const uint32_t last = draw(40);
+        std::vector<float> st(last + 4);
+        st[0] = -INFINITY;
+        float v = (float)draw(100) / 10.0f - 3.0f;
+        for (uint32_t k = 1; k <= last; ++k) {
+            v += draw(4) == 0 ? 0.0f : (float)draw(100) / 50.0f;
+            st[k] = v;
+        }
+        for (uint32_t k = last + 1; k < last + 4; ++k)
+            st[k] = NAN;
+        for (int q = 0; q < 200; ++q) {
+            const uint32_t kind = draw(20);
+            const float x = kind == 0 ? NAN : kind == 1 ? INFINITY : kind == 2 ? -INFINITY : (kind < 8 && last > 0) ? st[1 + draw(last)] : (float)draw(10000) / 100.0f - 10.0f;
+            const uint32_t m = draw(4) == 0 ? draw(last + 1) : (uint32_t)std::min<int64_t>(last, std::max<int64_t>(0, (int64_t)avifhip::stepIndexWalk(st.data(), last, 0, x) + (int)draw(7) - 3));
+            bad += avifhip::stepIndexFromGuess(st.data(), last, m, x) != avifhip::stepIndexWalk(st.data(), last, m, x);
+        }
     }
     return bad;
 }
